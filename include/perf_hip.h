@@ -1,0 +1,228 @@
+/* perf_hip.h -- C ABI of libperf_hip.so: the MI355X (gfx950) panoramic-NeRF hot path.
+ *
+ * This is the drop-in boundary for PeRF's modules/fields + modules/scene hot path.
+ * Every entry point replaces an operator PeRF reaches through a third-party CUDA
+ * extension (tinycudann / nerfacc / torch_efficient_distloss) or through a chain of
+ * torch ops; the replaced call site is cited per function (paths relative to the
+ * reference tree).  INTEGRATION.md shows the ctypes binding and the Python shim
+ * packages (`tinycudann`, `nerfacc`, `torch_efficient_distloss`) that sit on top.
+ *
+ * Contract
+ *  - plain C: raw device pointers, element counts, POD descriptors, a hipStream_t
+ *    passed as void*.  No torch types, no C++ exceptions cross the boundary.
+ *  - every function returns 0 on success or a negative PERF_E_* code; the message is
+ *    available from perf_last_error() (thread local).
+ *  - the library never allocates or frees device memory: outputs and workspaces are
+ *    caller-owned (PyTorch caching allocator).  Variable-size outputs use the
+ *    count -> scan -> (caller allocates) -> write protocol.
+ *  - all work is enqueued on the given stream; no implicit device synchronisation;
+ *    fixed-shape call sequences are hipGraph-capturable.
+ *  - "16-bit" buffers hold bf16 (PERF_DTYPE_BF16) or IEEE fp16 (PERF_DTYPE_FP16).
+ */
+#ifndef PERF_HIP_H
+#define PERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PERF_ABI_VERSION 1
+
+#define PERF_OK 0
+#define PERF_E_INVALID (-1)   /* bad argument */
+#define PERF_E_LAUNCH (-2)    /* HIP launch / runtime error */
+#define PERF_E_UNSUPPORTED (-3)
+
+#define PERF_DTYPE_BF16 0
+#define PERF_DTYPE_FP16 1
+
+#define PERF_ACT_NONE 0
+#define PERF_ACT_SIGMOID 1
+#define PERF_ACT_EXP 2        /* y -> exp(y - exp_shift); backward clamps the exponent at 15 (trunc_exp) */
+
+#define PERF_INTERP_LINEAR 0
+#define PERF_INTERP_SMOOTHSTEP 1
+
+#define PERF_MAX_LEVELS 16
+
+/* Geometry of a multiresolution hash grid (tcnn "HashGrid", 3 input dims, 2 features/level).
+ * Entry e of level l lives at table[(offset[l] + e) * 2 + f].  Levels with hashed[l]==0 are
+ * dense (index x + y*res + z*res^2), the others use the prime-XOR hash; both modulo size[l]. */
+typedef struct perf_grid_desc {
+    int32_t n_levels;              /* <= PERF_MAX_LEVELS */
+    int32_t interpolation;         /* PERF_INTERP_* */
+    float scale[PERF_MAX_LEVELS];
+    uint32_t res[PERF_MAX_LEVELS];
+    uint32_t size[PERF_MAX_LEVELS];
+    uint32_t offset[PERF_MAX_LEVELS];
+    uint32_t hashed[PERF_MAX_LEVELS];
+} perf_grid_desc;
+
+/* Bias-free 64-wide MLP (tcnn "FullyFusedMLP"): n_levels*2 inputs (zero padded to a multiple
+ * of 16), n_hidden_layers in {1,2} ReLU layers of 64, output padded to 16 rows.  Weights are
+ * row-major [out,in] 16-bit matrices, concatenated: [64 x n_in_pad][64 x 64]*(h-1)[16 x 64]. */
+typedef struct perf_mlp_desc {
+    int32_t n_levels;              /* inputs = 2*n_levels */
+    int32_t n_hidden_layers;       /* 1 or 2 */
+    int32_t n_out;                 /* 1..16 */
+    int32_t out_act;               /* PERF_ACT_* */
+    float exp_shift;               /* PERF_ACT_EXP only */
+} perf_mlp_desc;
+
+int perf_version(void);
+const char* perf_last_error(void);
+
+/* ---- parameters ------------------------------------------------------------------------ */
+
+/* fp32 master -> 16-bit working copy.  Replaces the per-call half cast inside tcnn's torch
+ * binding (reached from modules/fields/ngp_nerf.py:142,158). */
+int perf_cast_params(const float* src, void* dst16, int64_t n, int dtype, void* stream);
+
+/* One Adam step (torch.optim.Adam semantics, modules/scene/nerf.py:171,180,253,293) fused with
+ * the refresh of the 16-bit working copy and the zeroing of the gradient.
+ * p,m,v,g fp32 [n]; step >= 1; w16 may be NULL; zero_grad != 0 clears g. */
+int perf_adam_step(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype,
+                   int32_t step, float lr, float beta1, float beta2, float eps, int zero_grad,
+                   void* stream);
+
+/* ---- sample positions ------------------------------------------------------------------ */
+
+/* x = o[ray] + d[ray]*(t0+t1)/2 (modules/scene/nerf_renderer.py:125-127), then
+ * x01 = (x-aabb_min)/(aabb_max-aabb_min) and sel = all(0<x01<1) (modules/fields/ngp_nerf.py:137-140).
+ * aabb: 6 host floats.  x01 [n,3], sel [n] (uint8).  ray_indices int64 [n]. */
+int perf_points_from_rays(const float* rays_o, const float* rays_d, const int64_t* ray_indices,
+                          const float* t_starts, const float* t_ends, const float* aabb,
+                          float* x01, uint8_t* sel, int64_t n, void* stream);
+
+/* Same normalisation for explicit points x [n,3] (NGPNeRF.query_density/query_rgb called on points). */
+int perf_points_normalize(const float* x, const float* aabb, float* x01, uint8_t* sel, int64_t n,
+                          void* stream);
+
+/* ---- multiresolution hash grid ----------------------------------------------------------- */
+
+/* tcnn kernel_grid: x01 [n,3] -> features, LEVEL-MAJOR: feat[(l*n + i)*2 + f], 16-bit.
+ * Replaces the encoding half of tcnn.NetworkWithInputEncoding.forward (ngp_nerf.py:142,158,258). */
+int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* table16,
+                      void* feat16, int64_t n, int dtype, void* stream);
+
+/* Same with fp32 table and fp32 output feat[(l*n+i)*2+f] (tcnn.Encoding as used by
+ * modules/geo_predictors/pano_joint_predictor.py:30-41 keeps full precision available). */
+int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const float* table,
+                          float* feat, int64_t n, void* stream);
+
+/* tcnn kernel_grid_backward: scatter dfeat (fp32, level-major like feat) into grad_table
+ * (fp32 [total*2], ACCUMULATED with atomics; caller zeroes). */
+int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
+                      float* grad_table, int64_t n, void* stream);
+
+/* tcnn kernel_grid_backward_input: dL/dx01 [n,3] from dfeat and the table (fp32 table). */
+int perf_hashgrid_bwd_input(const perf_grid_desc* grid, const float* x01, const float* dfeat,
+                            const float* table, float* dx, int64_t n, void* stream);
+
+/* ---- 64-wide MLP on MFMA ----------------------------------------------------------------- */
+
+/* tcnn kernel_mlp_fused: feat16 (level-major) -> out [n, n_out] fp32 after out_act, multiplied
+ * by sel[i] when sel != NULL (ngp_nerf.py:146-149,161). */
+int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
+                 float* out, int64_t n, int dtype, void* stream);
+
+/* Bytes of caller-owned workspace perf_mlp_bwd needs for n samples. */
+int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n);
+
+/* tcnn kernel_mlp_fused_backward + weight-gradient GEMMs.  The forward is recomputed in
+ * registers (nothing but feat16 is kept from the forward pass).  dout [n, n_out] is the
+ * gradient w.r.t. the ACTIVATED output (before the sel multiply is undone: the kernel applies
+ * sel and the activation derivative itself).  Outputs: dfeat fp32 level-major (may be NULL),
+ * dw fp32 [n_net_params] (overwritten; deterministic two-stage reduction). */
+int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
+                 const float* dout, float* dfeat, float* dw, void* workspace, int64_t workspace_bytes,
+                 int64_t n, int dtype, void* stream);
+
+/* ---- rays ---------------------------------------------------------------------------------- */
+
+/* gen_pano_rays (utils/camera_utils.py:229-234) for rows [row0,row0+nrows) of an H x W panorama.
+ * pose: 16 host floats, row major 4x4.  rays_o, rays_d [nrows*W,3]. */
+int perf_pano_raygen(const float* pose, int32_t height, int32_t width, int32_t row0, int32_t nrows,
+                     float* rays_o, float* rays_d, void* stream);
+
+/* ---- occupancy-grid marching (nerfacc traverse_grids; nerf_renderer.py:145-155) ------------ */
+
+/* bool bytes [n_cells] -> bit field (uint32 words, bit i of word w = cell 32*w+i). */
+int perf_occ_pack_bits(const uint8_t* binaries, uint32_t* bits, int64_t n_cells, void* stream);
+
+/* number of uint64 mask words per ray for max_steps lattice intervals */
+int64_t perf_occ_mask_words(int32_t max_steps);
+
+/* Pass 1: per ray, test lattice intervals k=0..max_steps-1 (t_k = fl(t0 + fl(k*step)), midpoint
+ * inside [max(tmin,t0), min(tmax,far)] and in an occupied cell); writes the keep bit masks
+ * (masks [n_rays * mask_words]) and counts [n_rays].  t0 [n_rays] is the lattice origin
+ * (near plane plus the stratified jitter); aabb: 6 host floats. */
+int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
+                         const uint32_t* occ_bits, int32_t res, const float* aabb, float far_plane,
+                         float step, int32_t max_steps, uint64_t* masks, int32_t* counts, void* stream);
+
+/* Exclusive prefix sum of int32 (counts -> offsets); total [1] (int64, device) receives the sum.
+ * workspace >= perf_scan_workspace_bytes(n). */
+int64_t perf_scan_workspace_bytes(int64_t n);
+int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t* total, int64_t n,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Pass 2: expand masks into packed samples sorted by ray then t.  packed_info [n_rays,2] =
+ * (start,count) int32.  capacity = allocated length of the sample arrays. */
+int perf_occ_march_write(const float* t0, int64_t n_rays, float step, int32_t max_steps,
+                         const uint64_t* masks, const int32_t* counts, const int32_t* offsets,
+                         int64_t capacity, int64_t* ray_indices, float* t_starts, float* t_ends,
+                         int32_t* packed_info, void* stream);
+
+/* ---- compositing (nerfacc render_weight_from_density / accumulate_along_rays /
+ *      render_visibility_from_density; nerf_renderer.py:170-183) ---------------------------- */
+
+/* Per-ray exclusive sum of sigma*delta in the canonical 64-chunk Kogge-Stone order, thresholded:
+ * new_counts[r] = number of leading samples with exclusive_sum <= thr (thr = -ln(early_stop_eps)).
+ * Also writes exsum [S] when not NULL. */
+int perf_visibility_count(const float* sigmas, const float* t_starts, const float* t_ends,
+                          const int32_t* packed_info, int64_t n_rays, float thr, int32_t* new_counts,
+                          float* exsum, void* stream);
+
+/* Copy the first new_counts[r] samples of every ray to new_offsets[r] (the boolean-mask
+ * compaction of nerfacc's sampling).  sigmas_in/out may be NULL. */
+int perf_compact_prefix(const int32_t* packed_info, const int32_t* new_counts, const int32_t* new_offsets,
+                        int64_t n_rays, const float* ts_in, const float* te_in, const float* sig_in,
+                        int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out,
+                        int32_t* packed_out, void* stream);
+
+/* weights/trans/alphas [S] and per-ray opacity [R], distance [R], colour [R,3] (rgbs may be NULL).
+ * One wave per ray: no atomics. */
+int perf_composite_fwd(const float* sigmas, const float* rgbs, const float* t_starts,
+                       const float* t_ends, const int32_t* packed_info, int64_t n_rays,
+                       float* weights, float* trans, float* alphas, float* opacity, float* distance,
+                       float* color, void* stream);
+
+/* Backward of the above w.r.t. sigmas (and rgbs when d_rgbs != NULL):
+ * inputs g_weights [S] (may be NULL), g_opacity [R], g_distance [R], g_color [R,3] (may be NULL;
+ * colour uses detached weights as nerf_renderer.py:183). */
+int perf_composite_bwd(const float* sigmas, const float* rgbs, const float* t_starts,
+                       const float* t_ends, const int32_t* packed_info, int64_t n_rays,
+                       const float* weights, const float* trans,
+                       const float* g_weights, const float* g_opacity, const float* g_distance,
+                       const float* g_color, float* d_sigmas, float* d_rgbs, void* stream);
+
+/* flatten_eff_distloss forward (per-ray partial losses [R], caller sums and divides by n_rays)
+ * and analytic gradient w.r.t. w (modules/scene/nerf.py:226-230). */
+int perf_distloss_fwd(const float* w, const float* t_starts, const float* t_ends,
+                      const int32_t* packed_info, int64_t n_rays, float* loss_per_ray, void* stream);
+int perf_distloss_bwd(const float* w, const float* t_starts, const float* t_ends,
+                      const int32_t* packed_info, int64_t n_rays, float scale, float* g_w,
+                      void* stream);
+
+/* ---- occupancy pre-grid (modules/dataset/sup_info.py:304-330) ------------------------------ */
+int perf_occ_splat(const float* rays_o, const float* rays_d, const float* dist, int64_t n,
+                   int32_t res, uint8_t* occ, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PERF_HIP_H */

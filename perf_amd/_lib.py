@@ -1,0 +1,98 @@
+"""ctypes binding of libperf_hip.so (the C ABI declared in include/perf_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails, this
+module raises.  Build the library with `python -m perf_amd.build` (or __graft_entry__.build()).
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libperf_hip.so')
+
+MAX_LEVELS = 16
+DTYPE_BF16, DTYPE_FP16 = 0, 1
+ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
+INTERP_LINEAR, INTERP_SMOOTHSTEP = 0, 1
+
+
+class GridDesc(Structure):
+    _fields_ = [('n_levels', c_int32), ('interpolation', c_int32),
+                ('scale', c_float * MAX_LEVELS), ('res', c_uint32 * MAX_LEVELS), ('size', c_uint32 * MAX_LEVELS),
+                ('offset', c_uint32 * MAX_LEVELS), ('hashed', c_uint32 * MAX_LEVELS)]
+
+
+class MlpDesc(Structure):
+    _fields_ = [('n_levels', c_int32), ('n_hidden_layers', c_int32), ('n_out', c_int32), ('out_act', c_int32),
+                ('exp_shift', c_float)]
+
+
+class PerfError(RuntimeError):
+    pass
+
+
+P = c_void_p
+_SIGS = {
+    'perf_version': (c_int, []),
+    'perf_last_error': (c_char_p, []),
+    'perf_cast_params': (c_int, [P, P, c_int64, c_int, P]),
+    'perf_adam_step': (c_int, [P, P, P, P, P, c_int64, c_int, c_int32, c_float, c_float, c_float, c_float, c_int, P]),
+    'perf_points_from_rays': (c_int, [P, P, P, P, P, POINTER(c_float), P, P, c_int64, P]),
+    'perf_points_normalize': (c_int, [P, POINTER(c_float), P, P, c_int64, P]),
+    'perf_hashgrid_fwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P]),
+    'perf_hashgrid_fwd_f32': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
+    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
+    'perf_hashgrid_bwd_input': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),
+    'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, c_int, P]),
+    'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
+    'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, P, P, P, P, c_int64, c_int64, c_int, P]),
+    'perf_pano_raygen': (c_int, [POINTER(c_float), c_int32, c_int32, c_int32, c_int32, P, P, P]),
+    'perf_occ_pack_bits': (c_int, [P, P, c_int64, P]),
+    'perf_occ_mask_words': (c_int64, [c_int32]),
+    'perf_occ_march_count': (c_int, [P, P, P, c_int64, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, P, P, P]),
+    'perf_scan_workspace_bytes': (c_int64, [c_int64]),
+    'perf_exclusive_scan_i32': (c_int, [P, P, P, c_int64, P, c_int64, P]),
+    'perf_occ_march_write': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P]),
+    'perf_visibility_count': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
+    'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P]),
+    'perf_composite_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
+    'perf_composite_bwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P, P]),
+    'perf_distloss_fwd': (c_int, [P, P, P, P, c_int64, P, P]),
+    'perf_distloss_bwd': (c_int, [P, P, P, P, c_int64, c_float, P, P]),
+    'perf_occ_splat': (c_int, [P, P, P, c_int64, c_int32, P, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises PerfError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PerfError(f'{LIB_PATH} not found: build it with `python -m perf_amd.build` '
+                        '(there is no CPU fallback for the HIP path)')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().perf_last_error()
+        raise PerfError(f'{what} failed (code {rc}): {msg.decode() if msg else ""}')
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)

@@ -1,0 +1,55 @@
+"""Build libperf_hip.so (gfx950) in-tree with hipcc.  `python -m perf_amd.build [--force]`."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libperf_hip.so')
+SOURCES = ['misc.hip', 'hashgrid.hip', 'mlp.hip', 'march.hip', 'composite.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'common.hpp'),
+                                                          os.path.join(HERE, '..', 'include', 'perf_hip.h')]
+    if not force and _newer(LIB, deps):
+        return LIB
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+
+    def cc(src):
+        obj = os.path.join(objdir, src.replace('.hip', '.o'))
+        if not force and _newer(obj, [os.path.join(CSRC, src), os.path.join(CSRC, 'common.hpp'),
+                                      os.path.join(HERE, '..', 'include', 'perf_hip.h')]):
+            return obj
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {src}:\n{r.stdout}\n{r.stderr}')
+        if verbose and r.stderr:
+            print(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(cc, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,305 @@
+// Packed-ray compositing for gfx950: per-ray exclusive scans, visibility compaction, weights and
+// segmented accumulation (nerfacc render_weight_from_density / accumulate_along_rays /
+// render_visibility_from_density), the distortion loss (A.5) and their backward passes.
+//
+// One 64-lane wavefront owns one ray: samples of a ray are contiguous in the packed arrays
+// (packed_info[r] = (start, count)), so every access is a coalesced 256-byte row, prefix sums are
+// wave scans (Kogge-Stone over 64 lanes + a scalar carry between chunks) and the per-ray reductions
+// need no atomics (the reference's index_add_ does).  The scan uses a fixed association order with
+// unfused adds so that thresholds on it (early termination) are bit-exact against
+// oracle/perf_oracle.py:packed_exclusive_sum_canonical.
+#include "common.hpp"
+
+namespace perf {
+
+__device__ __forceinline__ float wave_incl_scan_f(float x, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        float y = __shfl_up(x, off);
+        if (lane >= off) x = add_rn(x, y);
+    }
+    return x;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+// exclusive prefix within the ray: returns ex for this lane's sample, updates carry
+__device__ __forceinline__ float chunk_excl(float v, int lane, float& carry) {
+    const float inc = wave_incl_scan_f(v, lane);
+    float prev = __shfl_up(inc, 1);
+    if (lane == 0) prev = 0.f;
+    const float ex = add_rn(carry, prev);
+    carry = add_rn(carry, __shfl(inc, 63));
+    return ex;
+}
+
+__global__ __launch_bounds__(256) void visibility_count_kernel(const float* __restrict__ sig, const float* __restrict__ ts,
+                                                               const float* __restrict__ te, const int32_t* __restrict__ packed,
+                                                               int64_t n_rays, float thr, int32_t* __restrict__ new_counts,
+                                                               float* __restrict__ exsum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int64_t start = packed[2 * r];
+    const int cnt = packed[2 * r + 1];
+    float carry = 0.f;
+    int kept = 0;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < cnt;
+        float sd = 0.f;
+        if (valid) sd = mul_rn(sig[start + i], sub_rn(te[start + i], ts[start + i]));
+        const float ex = chunk_excl(sd, lane, carry);
+        if (valid && exsum) exsum[start + i] = ex;
+        kept += __popcll(__ballot(valid && (ex <= thr)));
+    }
+    if (lane == 0) new_counts[r] = kept;
+}
+
+__global__ __launch_bounds__(256) void compact_prefix_kernel(const int32_t* __restrict__ packed, const int32_t* __restrict__ new_counts,
+                                                             const int32_t* __restrict__ new_offsets, int64_t n_rays,
+                                                             const float* __restrict__ ts_in, const float* __restrict__ te_in,
+                                                             const float* __restrict__ sig_in, int64_t* __restrict__ ri_out,
+                                                             float* __restrict__ ts_out, float* __restrict__ te_out,
+                                                             float* __restrict__ sig_out, int32_t* __restrict__ packed_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int64_t src = packed[2 * r];
+    const int cnt = new_counts[r];
+    const int64_t dst = new_offsets[r];
+    if (lane == 0) { packed_out[2 * r] = (int32_t)dst; packed_out[2 * r + 1] = cnt; }
+    for (int i = lane; i < cnt; i += 64) {
+        ts_out[dst + i] = ts_in[src + i];
+        te_out[dst + i] = te_in[src + i];
+        ri_out[dst + i] = r;
+        if (sig_out) sig_out[dst + i] = sig_in[src + i];
+    }
+}
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ sig, const float* __restrict__ rgb,
+                                                            const float* __restrict__ ts, const float* __restrict__ te,
+                                                            const int32_t* __restrict__ packed, int64_t n_rays,
+                                                            float* __restrict__ weights, float* __restrict__ trans,
+                                                            float* __restrict__ alphas, float* __restrict__ opacity,
+                                                            float* __restrict__ distance, float* __restrict__ color) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int64_t start = packed[2 * r];
+    const int cnt = packed[2 * r + 1];
+    float carry = 0.f;
+    float a_op = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < cnt;
+        float sd = 0.f, t0 = 0.f, t1 = 0.f;
+        if (valid) { t0 = ts[start + i]; t1 = te[start + i]; sd = mul_rn(sig[start + i], sub_rn(t1, t0)); }
+        const float ex = chunk_excl(sd, lane, carry);
+        if (valid) {
+            const float T = expf(-ex);
+            const float al = 1.0f - expf(-sd);
+            const float w = T * al;
+            if (weights) weights[start + i] = w;
+            if (trans) trans[start + i] = T;
+            if (alphas) alphas[start + i] = al;
+            a_op += w;
+            a_d += w * ((t0 + t1) * 0.5f);
+            if (rgb) {
+                a_r += w * rgb[3 * (start + i)];
+                a_g += w * rgb[3 * (start + i) + 1];
+                a_b += w * rgb[3 * (start + i) + 2];
+            }
+        }
+    }
+    a_op = wave_sum(a_op); a_d = wave_sum(a_d);
+    if (rgb) { a_r = wave_sum(a_r); a_g = wave_sum(a_g); a_b = wave_sum(a_b); }
+    if (lane == 0) {
+        if (opacity) opacity[r] = a_op;
+        if (distance) distance[r] = a_d;
+        if (rgb && color) { color[3 * r] = a_r; color[3 * r + 1] = a_g; color[3 * r + 2] = a_b; }
+    }
+}
+
+// d sigma_i = delta_i * ( G_i * T_i * (1 - alpha_i) - sum_{j>i} G_j w_j ),  G = g_w + g_op + g_dist * t_mid
+// d rgb_i   = w_i * g_color[r]     (colour is accumulated with detached weights)
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ sig, const float* __restrict__ ts,
+                                                            const float* __restrict__ te, const int32_t* __restrict__ packed,
+                                                            int64_t n_rays, const float* __restrict__ weights,
+                                                            const float* __restrict__ trans, const float* __restrict__ g_w,
+                                                            const float* __restrict__ g_op, const float* __restrict__ g_dist,
+                                                            const float* __restrict__ g_col, float* __restrict__ d_sig,
+                                                            float* __restrict__ d_rgb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int64_t start = packed[2 * r];
+    const int cnt = packed[2 * r + 1];
+    if (cnt == 0) return;
+    const float gop = g_op ? g_op[r] : 0.f, gd = g_dist ? g_dist[r] : 0.f;
+    float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
+    if (g_col && d_rgb) { gc0 = g_col[3 * r]; gc1 = g_col[3 * r + 1]; gc2 = g_col[3 * r + 2]; }
+    float carry = 0.f;   // sum of G_j w_j over all later chunks
+    const int n_chunks = (cnt + 63) / 64;
+    for (int q = n_chunks - 1; q >= 0; --q) {
+        const int i = q * 64 + lane;
+        const bool valid = i < cnt;
+        float w = 0.f, T = 0.f, t0 = 0.f, t1 = 0.f, s = 0.f, G = 0.f;
+        if (valid) {
+            w = weights[start + i]; T = trans[start + i]; t0 = ts[start + i]; t1 = te[start + i]; s = sig[start + i];
+            G = gop + gd * ((t0 + t1) * 0.5f) + (g_w ? g_w[start + i] : 0.f);
+        }
+        const float qv = G * w;
+        // inclusive suffix sum within the chunk
+        float suf = qv;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            float y = __shfl_down(suf, off);
+            if (lane + off < 64) suf += y;
+        }
+        const float later = carry + (suf - qv);
+        if (valid) {
+            const float delta = t1 - t0;
+            if (d_sig) d_sig[start + i] = delta * (G * T * expf(-s * delta) - later);
+            if (d_rgb) { d_rgb[3 * (start + i)] = w * gc0; d_rgb[3 * (start + i) + 1] = w * gc1; d_rgb[3 * (start + i) + 2] = w * gc2; }
+        }
+        carry += __shfl(suf, 0);
+    }
+}
+
+// distortion loss, per ray:  sum_i ( d_i w_i^2 / 3 + 2 w_i (m_i W_i - WM_i) ),  W, WM exclusive prefixes
+__global__ __launch_bounds__(256) void distloss_fwd_kernel(const float* __restrict__ w, const float* __restrict__ ts,
+                                                           const float* __restrict__ te, const int32_t* __restrict__ packed,
+                                                           int64_t n_rays, float* __restrict__ loss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int64_t start = packed[2 * r];
+    const int cnt = packed[2 * r + 1];
+    float cW = 0.f, cWM = 0.f, acc = 0.f;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < cnt;
+        float wi = 0.f, m = 0.f, d = 0.f;
+        if (valid) { wi = w[start + i]; const float a = ts[start + i], b = te[start + i]; m = (a + b) * 0.5f; d = b - a; }
+        const float W = chunk_excl(wi, lane, cW);
+        const float WM = chunk_excl(wi * m, lane, cWM);
+        if (valid) acc += d * wi * wi * (1.0f / 3.0f) + 2.0f * wi * (m * W - WM);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) loss[r] = acc;
+}
+
+// d loss / d w_i = scale * ( 2/3 d_i w_i + 2 ( m_i (W_i - Wsuf_i) - (WM_i - WMsuf_i) ) )
+__global__ __launch_bounds__(256) void distloss_bwd_kernel(const float* __restrict__ w, const float* __restrict__ ts,
+                                                           const float* __restrict__ te, const int32_t* __restrict__ packed,
+                                                           int64_t n_rays, float scale, float* __restrict__ g_w) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int64_t start = packed[2 * r];
+    const int cnt = packed[2 * r + 1];
+    float totW = 0.f, totWM = 0.f;
+    for (int i = lane; i < cnt; i += 64) {
+        const float wi = w[start + i];
+        totW += wi; totWM += wi * ((ts[start + i] + te[start + i]) * 0.5f);
+    }
+    totW = wave_sum(totW); totWM = wave_sum(totWM);
+    float cW = 0.f, cWM = 0.f;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < cnt;
+        float wi = 0.f, m = 0.f, d = 0.f;
+        if (valid) { wi = w[start + i]; const float a = ts[start + i], b = te[start + i]; m = (a + b) * 0.5f; d = b - a; }
+        const float W = chunk_excl(wi, lane, cW);
+        const float WM = chunk_excl(wi * m, lane, cWM);
+        if (valid) {
+            const float Wsuf = totW - W - wi, WMsuf = totWM - WM - wi * m;
+            g_w[start + i] = scale * ((2.0f / 3.0f) * d * wi + 2.0f * (m * (W - Wsuf) - (WM - WMsuf)));
+        }
+    }
+}
+
+static inline dim3 ray_grid(int64_t n_rays) { return dim3((unsigned)div_up(n_rays, 4)); }
+
+}  // namespace perf
+
+using namespace perf;
+
+extern "C" int perf_visibility_count(const float* sigmas, const float* t_starts, const float* t_ends,
+                                     const int32_t* packed_info, int64_t n_rays, float thr, int32_t* new_counts,
+                                     float* exsum, void* stream) {
+    PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_info && new_counts, "NULL pointer");
+    hipLaunchKernelGGL(visibility_count_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
+                       packed_info, n_rays, thr, new_counts, exsum);
+    PERF_LAUNCH_CHECK("perf_visibility_count");
+    return PERF_OK;
+}
+
+extern "C" int perf_compact_prefix(const int32_t* packed_info, const int32_t* new_counts, const int32_t* new_offsets,
+                                   int64_t n_rays, const float* ts_in, const float* te_in, const float* sig_in,
+                                   int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out,
+                                   int32_t* packed_out, void* stream) {
+    PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_info && new_counts && new_offsets && packed_out, "NULL pointer");
+    PERF_REQUIRE((sig_in == nullptr) == (sig_out == nullptr), "sig_in/sig_out must both be given or both be NULL");
+    hipLaunchKernelGGL(compact_prefix_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), packed_info, new_counts,
+                       new_offsets, n_rays, ts_in, te_in, sig_in, ray_indices_out, ts_out, te_out, sig_out, packed_out);
+    PERF_LAUNCH_CHECK("perf_compact_prefix");
+    return PERF_OK;
+}
+
+extern "C" int perf_composite_fwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+                                  const int32_t* packed_info, int64_t n_rays, float* weights, float* trans, float* alphas,
+                                  float* opacity, float* distance, float* color, void* stream) {
+    PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_info, "NULL pointer");
+    hipLaunchKernelGGL(composite_fwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
+                       t_ends, packed_info, n_rays, weights, trans, alphas, opacity, distance, color);
+    PERF_LAUNCH_CHECK("perf_composite_fwd");
+    return PERF_OK;
+}
+
+extern "C" int perf_composite_bwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+                                  const int32_t* packed_info, int64_t n_rays, const float* weights, const float* trans,
+                                  const float* g_weights, const float* g_opacity, const float* g_distance,
+                                  const float* g_color, float* d_sigmas, float* d_rgbs, void* stream) {
+    (void)rgbs;
+    PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_info && weights && trans, "NULL pointer");
+    hipLaunchKernelGGL(composite_bwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
+                       packed_info, n_rays, weights, trans, g_weights, g_opacity, g_distance, g_color, d_sigmas, d_rgbs);
+    PERF_LAUNCH_CHECK("perf_composite_bwd");
+    return PERF_OK;
+}
+
+extern "C" int perf_distloss_fwd(const float* w, const float* t_starts, const float* t_ends, const int32_t* packed_info,
+                                 int64_t n_rays, float* loss_per_ray, void* stream) {
+    PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_info && loss_per_ray, "NULL pointer");
+    hipLaunchKernelGGL(distloss_fwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), w, t_starts, t_ends,
+                       packed_info, n_rays, loss_per_ray);
+    PERF_LAUNCH_CHECK("perf_distloss_fwd");
+    return PERF_OK;
+}
+
+extern "C" int perf_distloss_bwd(const float* w, const float* t_starts, const float* t_ends, const int32_t* packed_info,
+                                 int64_t n_rays, float scale, float* g_w, void* stream) {
+    PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_info && g_w, "NULL pointer");
+    hipLaunchKernelGGL(distloss_bwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), w, t_starts, t_ends,
+                       packed_info, n_rays, scale, g_w);
+    PERF_LAUNCH_CHECK("perf_distloss_bwd");
+    return PERF_OK;
+}

@@ -1,0 +1,243 @@
+// Occupancy-grid ray marching (nerfacc traverse_grids semantics as restated in SURVEY.md A.3 and
+// oracle/perf_oracle.py:occ_march) for gfx950.
+//
+// One 64-lane wavefront owns one ray.  Lane k of chunk q tests lattice interval 64*q+k: the 64
+// midpoints of a chunk are consecutive points on the ray, so their occupancy words are neighbours
+// in the bit field (256^3 bits = 2 MiB: L2 resident).  A wave ballot turns the 64 tests into one
+// uint64 keep-mask; pass 1 stores the masks and the per-ray popcount, an exclusive scan over rays
+// gives the packed offsets, pass 2 expands the masks with a per-lane prefix popcount -- the
+// "count -> scan -> write" protocol with bit-exact, t-sorted output and no atomics.
+// All lattice/cell arithmetic is unfused fp32 (mul_rn/add_rn) so it matches numpy bit for bit.
+#include "common.hpp"
+
+namespace perf {
+
+struct MarchParams {
+    float lo[3], inv_ext[3];
+    float hi[3];
+    float far_plane, step;
+    int32_t res, max_steps, mask_words;
+};
+
+__device__ __forceinline__ float lattice(float t0, int k, float step) { return add_rn(t0, mul_rn((float)k, step)); }
+
+__global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const float* __restrict__ ro,
+                                                          const float* __restrict__ rd, const float* __restrict__ t0s,
+                                                          int64_t n_rays, const uint32_t* __restrict__ bits,
+                                                          uint64_t* __restrict__ masks, int32_t* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const float o[3] = {ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]};
+    const float d[3] = {rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]};
+    const float t0 = t0s[r];
+    // slab test (fminf/fmaxf drop NaNs like np.fmin/np.fmax)
+    float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inv = __fdiv_rn(1.0f, d[a]);
+        const float t1 = mul_rn(sub_rn(mp.lo[a], o[a]), inv), t2 = mul_rn(sub_rn(mp.hi[a], o[a]), inv);
+        const float l = fminf(t1, t2), h = fmaxf(t1, t2);
+        tmin = (a == 0) ? l : fmaxf(tmin, l);
+        tmax = (a == 0) ? h : fminf(tmax, h);
+    }
+    const float lo = fmaxf(tmin, t0), hi = fminf(tmax, mp.far_plane);
+    int32_t count = 0;
+    const int res = mp.res;
+    const float rf = (float)res;
+    for (int q = 0; q < mp.mask_words; ++q) {
+        const int k0 = q * 64;
+        bool keep = false;
+        // chunk entirely past the far bound / before the near bound: nothing to test
+        const bool chunk_live = !(lattice(t0, k0, mp.step) > hi) && !(lattice(t0, k0 + 64, mp.step) < lo);
+        if (chunk_live) {
+            const int k = k0 + lane;
+            if (k < mp.max_steps) {
+                const float ta = lattice(t0, k, mp.step), tb = lattice(t0, k + 1, mp.step);
+                const float mid = mul_rn(add_rn(ta, tb), 0.5f);
+                if (mid >= lo && mid <= hi) {
+                    int cell[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const float p = add_rn(o[a], mul_rn(d[a], mid));
+                        const float u = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
+                        const float f = fminf(fmaxf(floorf(u), 0.0f), rf - 1.0f);
+                        cell[a] = (int)f;
+                    }
+                    const uint32_t ci = (uint32_t)((cell[0] * res + cell[1]) * res + cell[2]);
+                    keep = (bits[ci >> 5] >> (ci & 31)) & 1u;
+                }
+            }
+        }
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) masks[r * mp.mask_words + q] = m;
+        count += __popcll(m);
+    }
+    if (lane == 0) counts[r] = count;
+}
+
+__global__ __launch_bounds__(256) void march_write_kernel(const float* __restrict__ t0s, int64_t n_rays, float step,
+                                                          int32_t mask_words, const uint64_t* __restrict__ masks,
+                                                          const int32_t* __restrict__ counts,
+                                                          const int32_t* __restrict__ offsets, int64_t capacity,
+                                                          int64_t* __restrict__ ray_indices, float* __restrict__ ts,
+                                                          float* __restrict__ te, int32_t* __restrict__ packed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int32_t cnt = counts[r], off = offsets[r];
+    if (lane == 0) { packed[2 * r] = off; packed[2 * r + 1] = cnt; }
+    if (cnt == 0) return;
+    const float t0 = t0s[r];
+    int64_t run = off;
+    const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int q = 0; q < mask_words; ++q) {
+        const uint64_t m = masks[r * mask_words + q];
+        if (m == 0) continue;
+        if ((m >> lane) & 1ull) {
+            const int64_t pos = run + __popcll(m & below);
+            if (pos < capacity) {
+                const int k = q * 64 + lane;
+                ts[pos] = lattice(t0, k, step);
+                te[pos] = lattice(t0, k + 1, step);
+                ray_indices[pos] = r;
+            }
+        }
+        run += __popcll(m);
+    }
+}
+
+// ---------------- exclusive scan of int32 (counts -> offsets) -----------------------------------
+constexpr int kScanBlock = 1024;   // elements per block (256 threads x 4)
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int y = __shfl_up(v, off);
+        if (lane >= off) v += y;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); returns exclusive value, total in *total
+__device__ __forceinline__ int block_excl_scan(int v, int* lds4, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int inc = wave_incl_scan(v, lane);
+    if (lane == 63) lds4[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w2 = 0; w2 < wave; ++w2) base += lds4[w2];
+    *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t* __restrict__ in, int64_t n, int64_t* __restrict__ sums) {
+    __shared__ int lds4[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanBlock + threadIdx.x * 4;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < n) s += in[base + k];
+    int total;
+    block_excl_scan(s, lds4, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scan_sums_kernel(int64_t* __restrict__ sums, int64_t n_blocks, int64_t* __restrict__ total_out) {
+    // single block; sequential over chunks of 256 block sums (n_blocks is small)
+    __shared__ int64_t carry_s;
+    __shared__ int64_t buf[256];
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < n_blocks; c0 += 256) {
+        const int64_t i = c0 + threadIdx.x;
+        buf[threadIdx.x] = (i < n_blocks) ? sums[i] : 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t run = carry_s;
+            for (int k = 0; k < 256; ++k) { int64_t v = buf[k]; buf[k] = run; run += v; }
+            carry_s = run;
+        }
+        __syncthreads();
+        if (i < n_blocks) sums[i] = buf[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
+                                                         const int64_t* __restrict__ sums) {
+    __shared__ int lds4[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanBlock + threadIdx.x * 4;
+    int v[4];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    int total;
+    int ex = block_excl_scan(s, lds4, &total) + (int)sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+}
+
+}  // namespace perf
+
+using namespace perf;
+
+extern "C" int64_t perf_occ_mask_words(int32_t max_steps) { return max_steps > 0 ? (max_steps + 63) / 64 : 0; }
+
+extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
+                                    const uint32_t* occ_bits, int32_t res, const float* aabb, float far_plane, float step,
+                                    int32_t max_steps, uint64_t* masks, int32_t* counts, void* stream) {
+    PERF_REQUIRE(n_rays >= 0 && res > 0 && res <= 1024 && max_steps > 0 && step > 0.f, "perf_occ_march_count: bad arguments");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(rays_o && rays_d && t0 && occ_bits && aabb && masks && counts, "NULL pointer");
+    MarchParams mp;
+    for (int a = 0; a < 3; ++a) {
+        mp.lo[a] = aabb[a]; mp.hi[a] = aabb[3 + a];
+        mp.inv_ext[a] = 1.0f / (aabb[3 + a] - aabb[a]);
+    }
+    mp.far_plane = far_plane; mp.step = step; mp.res = res; mp.max_steps = max_steps;
+    mp.mask_words = (int32_t)perf_occ_mask_words(max_steps);
+    hipLaunchKernelGGL(march_count_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
+                       rays_d, t0, n_rays, occ_bits, masks, counts);
+    PERF_LAUNCH_CHECK("perf_occ_march_count");
+    return PERF_OK;
+}
+
+extern "C" int64_t perf_scan_workspace_bytes(int64_t n) { return (div_up(n > 0 ? n : 1, kScanBlock) + 1) * (int64_t)sizeof(int64_t); }
+
+extern "C" int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t* total, int64_t n, void* workspace,
+                                       int64_t workspace_bytes, void* stream) {
+    PERF_REQUIRE(n >= 0 && total, "perf_exclusive_scan_i32: bad arguments");
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(total, 0, sizeof(int64_t), as_stream(stream));
+        if (e != hipSuccess) { set_error("memset failed"); return PERF_E_LAUNCH; }
+        return PERF_OK;
+    }
+    PERF_REQUIRE(in && out && workspace, "NULL pointer");
+    PERF_REQUIRE(workspace_bytes >= perf_scan_workspace_bytes(n), "scan workspace too small");
+    const int64_t nb = div_up(n, kScanBlock);
+    int64_t* sums = (int64_t*)workspace;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), in, n, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, as_stream(stream), sums, nb, total);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), in, out, n, sums);
+    PERF_LAUNCH_CHECK("perf_exclusive_scan_i32");
+    return PERF_OK;
+}
+
+extern "C" int perf_occ_march_write(const float* t0, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
+                                    const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
+                                    float* t_starts, float* t_ends, int32_t* packed_info, void* stream) {
+    PERF_REQUIRE(n_rays >= 0 && max_steps > 0 && capacity >= 0, "perf_occ_march_write: bad arguments");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(t0 && masks && counts && offsets && packed_info, "NULL pointer");
+    PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends), "NULL sample arrays");
+    hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), t0, n_rays,
+                       step, (int32_t)perf_occ_mask_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
+                       t_ends, packed_info);
+    PERF_LAUNCH_CHECK("perf_occ_march_write");
+    return PERF_OK;
+}

@@ -1,0 +1,262 @@
+// Streaming helpers: parameter cast, fused Adam, sample positions, panorama ray generation,
+// occupancy bit packing and the occupancy pre-grid splat.  All are one-pass HBM-bound kernels with
+// fully coalesced accesses.
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.hpp"
+
+namespace perf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+template <typename T16>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 v = *reinterpret_cast<const float4*>(src + i);
+        uint2 o = make_uint2(T16::pack(v.x, v.y), T16::pack(v.z, v.w));
+        *reinterpret_cast<uint2*>(dst + i) = o;
+    } else {
+        for (; i < n; ++i) dst[i] = T16::one(src[i]);
+    }
+}
+
+// torch.optim.Adam (foreach form): m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+template <typename T16, bool W16>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ g, uint16_t* __restrict__ w16, int64_t n,
+                                                   float one_minus_b1, float b2, float one_minus_b2, float step_size,
+                                                   float inv_bc2_sqrt, float eps, int zero_grad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    float mi = m[i], vi = v[i], pi = p[i];
+    mi = mi + one_minus_b1 * (gi - mi);
+    vi = vi * b2 + one_minus_b2 * gi * gi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);
+    m[i] = mi; v[i] = vi; p[i] = pi;
+    if (W16) w16[i] = T16::one(pi);
+    if (zero_grad) g[i] = 0.f;
+}
+
+struct Aabb { float lo[3], hi[3]; };
+
+__device__ __forceinline__ void normalize_store(float px, float py, float pz, const Aabb& bb, float* x01, uint8_t* sel,
+                                                int64_t i) {
+    // (x - aabb_min) / (aabb_max - aabb_min), IEEE division like torch
+    float ux = __fdiv_rn(sub_rn(px, bb.lo[0]), sub_rn(bb.hi[0], bb.lo[0]));
+    float uy = __fdiv_rn(sub_rn(py, bb.lo[1]), sub_rn(bb.hi[1], bb.lo[1]));
+    float uz = __fdiv_rn(sub_rn(pz, bb.lo[2]), sub_rn(bb.hi[2], bb.lo[2]));
+    x01[3 * i] = ux; x01[3 * i + 1] = uy; x01[3 * i + 2] = uz;
+    if (sel) sel[i] = (ux > 0.f && ux < 1.f && uy > 0.f && uy < 1.f && uz > 0.f && uz < 1.f) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void points_from_rays_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                                               const int64_t* __restrict__ ri, const float* __restrict__ ts,
+                                                               const float* __restrict__ te, Aabb bb, float* __restrict__ x01,
+                                                               uint8_t* __restrict__ sel, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = ri[i];
+    const float tsum = add_rn(ts[i], te[i]);
+    // t_origins + t_dirs * (t0+t1) / 2.0   (nerf_renderer.py:127): multiply, divide, add -- unfused
+    float px = add_rn(o[3 * r], __fdiv_rn(mul_rn(d[3 * r], tsum), 2.0f));
+    float py = add_rn(o[3 * r + 1], __fdiv_rn(mul_rn(d[3 * r + 1], tsum), 2.0f));
+    float pz = add_rn(o[3 * r + 2], __fdiv_rn(mul_rn(d[3 * r + 2], tsum), 2.0f));
+    normalize_store(px, py, pz, bb, x01, sel, i);
+}
+
+__global__ __launch_bounds__(256) void points_normalize_kernel(const float* __restrict__ x, Aabb bb, float* __restrict__ x01,
+                                                               uint8_t* __restrict__ sel, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    normalize_store(x[3 * i], x[3 * i + 1], x[3 * i + 2], bb, x01, sel, i);
+}
+
+struct RayGen {
+    float pose[16];
+    float i_start, i_end, i_step, j_start, j_end, j_step;
+    int32_t height, width, row0, nrows;
+};
+
+// torch.linspace(start, end, n)[idx] in fp32: symmetric evaluation around the midpoint
+__device__ __forceinline__ float linspace_at(float start, float end, float step, int n, int idx) {
+    return (idx < n / 2) ? start + step * (float)idx : end - step * (float)(n - 1 - idx);
+}
+
+__global__ __launch_bounds__(256) void pano_raygen_kernel(RayGen rg, float* __restrict__ ro, float* __restrict__ rd) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)rg.nrows * rg.width;
+    if (t >= total) return;
+    const int i = rg.row0 + (int)(t / rg.width), j = (int)(t % rg.width);
+    const float y = linspace_at(rg.i_start, rg.i_end, rg.i_step, rg.height, i);
+    const float x = linspace_at(rg.j_start, rg.j_end, rg.j_step, rg.width, j);
+    const float kPi = 3.14159274101257324f;
+    const float beta = -(y - 0.5f) * kPi;
+    const float alpha = (-(x - 0.5f) * 2.0f) * kPi;
+    const float cb = cosf(beta), sb = sinf(beta), ca = cosf(alpha), sa = sinf(alpha);
+    const float dx = ca * cb, dy = sa * cb, dz = sb;
+    const float* P = rg.pose;
+    rd[3 * t] = P[0] * dx + P[1] * dy + P[2] * dz;
+    rd[3 * t + 1] = P[4] * dx + P[5] * dy + P[6] * dz;
+    rd[3 * t + 2] = P[8] * dx + P[9] * dy + P[10] * dz;
+    ro[3 * t] = P[3]; ro[3 * t + 1] = P[7]; ro[3 * t + 2] = P[11];
+}
+
+__global__ __launch_bounds__(256) void occ_pack_kernel(const uint8_t* __restrict__ b, uint32_t* __restrict__ bits, int64_t n_cells) {
+    const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi * 32 >= n_cells) return;
+    uint32_t word = 0;
+    for (int k = 0; k < 32; ++k) {
+        const int64_t c = wi * 32 + k;
+        if (c < n_cells && b[c]) word |= 1u << k;
+    }
+    bits[wi] = word;
+}
+
+// SupInfoPool.gen_occ_grid: 27 shifted copies of p = o + d*dist, index of
+// int64((clip(p+shift, +-.999)*.5+.5)*res), x-major.
+__global__ __launch_bounds__(256) void occ_splat_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                                        const float* __restrict__ dist, int64_t n, int32_t res, float shift,
+                                                        uint8_t* __restrict__ occ) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = dist[i];
+    float p[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p[a] = add_rn(o[3 * i + a], mul_rn(d[3 * i + a], t));
+    const float sh[3] = {-shift, 0.f, shift};
+    const float rf = (float)res;
+    int64_t c[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v = add_rn(sh[k], p[a]);
+            v = fminf(fmaxf(v, -0.999f), 0.999f);
+            v = mul_rn(add_rn(mul_rn(v, 0.5f), 0.5f), rf);
+            c[a][k] = (int64_t)v;
+        }
+    const int64_t r = res;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kz = 0; kz < 3; ++kz) occ[c[0][kx] * r * r + c[1][ky] * r + c[2][kz]] = 1;
+}
+
+}  // namespace perf
+
+using namespace perf;
+
+extern "C" int perf_version(void) { return PERF_ABI_VERSION; }
+extern "C" const char* perf_last_error(void) { return g_err; }
+
+extern "C" int perf_cast_params(const float* src, void* dst16, int64_t n, int dtype, void* stream) {
+    PERF_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(src && dst16, "NULL pointer");
+    PERF_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst16) & 7) == 0,
+                 "perf_cast_params: src must be 16-byte and dst 8-byte aligned");
+    dim3 g((unsigned)div_up(div_up(n, 4), 256)), b(256);
+    if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL(cast_kernel<BF16>, g, b, 0, as_stream(stream), src, (uint16_t*)dst16, n);
+    else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL(cast_kernel<FP16>, g, b, 0, as_stream(stream), src, (uint16_t*)dst16, n);
+    else { set_error("perf_cast_params: bad dtype %d", dtype); return PERF_E_INVALID; }
+    PERF_LAUNCH_CHECK("perf_cast_params");
+    return PERF_OK;
+}
+
+extern "C" int perf_adam_step(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype, int32_t step,
+                              float lr, float beta1, float beta2, float eps, int zero_grad, void* stream) {
+    PERF_REQUIRE(n >= 0 && step >= 1, "perf_adam_step: n < 0 or step < 1");
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(p && m && v && g, "NULL pointer");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    dim3 gr((unsigned)div_up(n, 256)), b(256);
+    const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+    if (!w16) hipLaunchKernelGGL((adam_kernel<BF16, false>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad);
+    else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam_kernel<BF16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad);
+    else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam_kernel<FP16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad);
+    else { set_error("perf_adam_step: bad dtype %d", dtype); return PERF_E_INVALID; }
+    PERF_LAUNCH_CHECK("perf_adam_step");
+    return PERF_OK;
+}
+
+static Aabb make_aabb(const float* a) {
+    Aabb bb;
+    for (int i = 0; i < 3; ++i) { bb.lo[i] = a[i]; bb.hi[i] = a[3 + i]; }
+    return bb;
+}
+
+extern "C" int perf_points_from_rays(const float* rays_o, const float* rays_d, const int64_t* ray_indices,
+                                     const float* t_starts, const float* t_ends, const float* aabb, float* x01,
+                                     uint8_t* sel, int64_t n, void* stream) {
+    PERF_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(rays_o && rays_d && ray_indices && t_starts && t_ends && aabb && x01, "NULL pointer");
+    hipLaunchKernelGGL(points_from_rays_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, as_stream(stream), rays_o,
+                       rays_d, ray_indices, t_starts, t_ends, make_aabb(aabb), x01, sel, n);
+    PERF_LAUNCH_CHECK("perf_points_from_rays");
+    return PERF_OK;
+}
+
+extern "C" int perf_points_normalize(const float* x, const float* aabb, float* x01, uint8_t* sel, int64_t n, void* stream) {
+    PERF_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(x && aabb && x01, "NULL pointer");
+    hipLaunchKernelGGL(points_normalize_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, as_stream(stream), x,
+                       make_aabb(aabb), x01, sel, n);
+    PERF_LAUNCH_CHECK("perf_points_normalize");
+    return PERF_OK;
+}
+
+extern "C" int perf_pano_raygen(const float* pose, int32_t height, int32_t width, int32_t row0, int32_t nrows,
+                                float* rays_o, float* rays_d, void* stream) {
+    PERF_REQUIRE(pose && rays_o && rays_d, "NULL pointer");
+    PERF_REQUIRE(height >= 2 && width >= 2 && row0 >= 0 && nrows >= 0 && row0 + nrows <= height, "bad panorama shape");
+    if (nrows == 0) return PERF_OK;
+    RayGen rg;
+    for (int i = 0; i < 16; ++i) rg.pose[i] = pose[i];
+    rg.i_start = (float)(.5 / height); rg.i_end = (float)(1. - .5 / height);
+    rg.j_start = (float)(.5 / width); rg.j_end = (float)(1. - .5 / width);
+    rg.i_step = (rg.i_end - rg.i_start) / (float)(height - 1);
+    rg.j_step = (rg.j_end - rg.j_start) / (float)(width - 1);
+    rg.height = height; rg.width = width; rg.row0 = row0; rg.nrows = nrows;
+    const int64_t total = (int64_t)nrows * width;
+    hipLaunchKernelGGL(pano_raygen_kernel, dim3((unsigned)div_up(total, 256)), dim3(256), 0, as_stream(stream), rg, rays_o, rays_d);
+    PERF_LAUNCH_CHECK("perf_pano_raygen");
+    return PERF_OK;
+}
+
+extern "C" int perf_occ_pack_bits(const uint8_t* binaries, uint32_t* bits, int64_t n_cells, void* stream) {
+    PERF_REQUIRE(binaries && bits && n_cells > 0, "bad arguments");
+    hipLaunchKernelGGL(occ_pack_kernel, dim3((unsigned)div_up(div_up(n_cells, 32), 256)), dim3(256), 0, as_stream(stream),
+                       binaries, bits, n_cells);
+    PERF_LAUNCH_CHECK("perf_occ_pack_bits");
+    return PERF_OK;
+}
+
+extern "C" int perf_occ_splat(const float* rays_o, const float* rays_d, const float* dist, int64_t n, int32_t res,
+                              uint8_t* occ, void* stream) {
+    PERF_REQUIRE(n >= 0 && res > 0, "bad arguments");
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(rays_o && rays_d && dist && occ, "NULL pointer");
+    const float shift = (float)(1.0 / res);
+    hipLaunchKernelGGL(occ_splat_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, as_stream(stream), rays_o, rays_d,
+                       dist, n, res, shift, occ);
+    PERF_LAUNCH_CHECK("perf_occ_splat");
+    return PERF_OK;
+}

@@ -1,0 +1,540 @@
+// 64-wide bias-free MLP on gfx950 MFMA (tcnn "FullyFusedMLP" semantics).
+//
+// One wave owns a tile of 32 samples and chains v_mfma_f32_32x32x16_{bf16,f16}:
+//     H^T[64 x 32] = W[64 x K] * X^T[K x 32]        (neurons = M rows, samples = N columns)
+// so the accumulator of one layer (lane = sample column, registers = neuron rows) IS the B
+// operand of the next layer after ReLU + 16-bit packing -- no cross-lane traffic, no LDS.  The
+// price is a fixed permutation of the K slots, which is folded into the weight (A) fragments once
+// per block when they are staged into LDS:
+//   D layout (32x32 tile):  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+//   operand slot (h=lane>>5, j=0..7) of k-step s=2*m1+t  <->  neuron 32*m1 + 16*t + 8*(j>>2) + 4*h + (j&3)
+//   input   slot (h, j) of k-step s                       <->  level 8*s + 2*(j>>1) + h, feature j&1
+// Input features arrive LEVEL-MAJOR (feat[l][sample] = packed pair), so each B-fragment dword is
+// one coalesced 128-byte read per half-wave.
+//
+// Backward recomputes the forward in registers (only feat is kept from the forward pass), chains
+// dH = W^T dY the same way with transposed weight fragments, and forms the weight gradients
+// dW = dH * H^T (contraction over the 32 samples) through a wave-private LDS transpose.
+#include "common.hpp"
+
+namespace perf {
+
+struct MlpParams {
+    int32_t n_levels;
+    int32_t n_out;
+    int32_t out_act;
+    float exp_shift;
+};
+
+constexpr int kTile = 32;      // samples per wave tile
+constexpr int kPitch = 40;     // 16-bit elements per LDS transpose row (32 samples + pad, 16-B aligned)
+
+__device__ __forceinline__ int slot_neuron(int s, int h, int j) {
+    return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+}
+__device__ __forceinline__ int d_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int NH, int KS>
+struct Layout {
+    static constexpr int n_in_pad = 16 * KS;
+    static constexpr int w1_off = 0;
+    static constexpr int w2_off = 64 * n_in_pad;
+    static constexpr int wo_off = w2_off + (NH == 2 ? 64 * 64 : 0);
+    static constexpr int n_params = wo_off + 16 * 64;
+    // forward fragments: A1[m][s] (2*KS), A2[m][s] (8 if NH==2), Ao[s] (4)
+    static constexpr int f_a1 = 0;
+    static constexpr int f_a2 = 2 * KS;
+    static constexpr int f_ao = f_a2 + (NH == 2 ? 8 : 0);
+    static constexpr int n_fwd = f_ao + 4;
+    // backward (transposed) fragments: AoT[m] (2), A2T[m][s] (8 if NH==2), A1T[s] (4)
+    static constexpr int f_aot = n_fwd;
+    static constexpr int f_a2t = f_aot + 2;
+    static constexpr int f_a1t = f_a2t + (NH == 2 ? 8 : 0);
+    static constexpr int n_all = f_a1t + 4;
+};
+
+__device__ __forceinline__ u32x4 pack8(const uint16_t v[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (uint32_t)v[2 * i] | ((uint32_t)v[2 * i + 1] << 16);
+    return r;
+}
+
+// Stage permuted weight fragments into LDS: frag f occupies lds[f*64 + lane] (16 B per lane).
+template <int NH, int KS, bool BWD>
+__device__ __forceinline__ void stage_fragments(const uint16_t* __restrict__ w, u32x4* lds) {
+    using L = Layout<NH, KS>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int nf = BWD ? L::n_all : L::n_fwd;
+    for (int f = wave; f < nf; f += nw) {
+        uint16_t v[8];
+        if (f < L::f_a2) {                       // A1[m][s]: row = neuron 32m+c, slot -> input feature
+            const int m = (f - L::f_a1) / KS, s = (f - L::f_a1) % KS;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = 2 * (8 * s + 2 * (j >> 1) + h) + (j & 1);
+                v[j] = w[L::w1_off + (32 * m + c) * L::n_in_pad + col];
+            }
+        } else if (f < L::f_ao) {                // A2[m][s]
+            const int m = (f - L::f_a2) >> 2, s = (f - L::f_a2) & 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w[L::w2_off + (32 * m + c) * 64 + slot_neuron(s, h, j)];
+        } else if (f < L::n_fwd) {               // Ao[s]: rows 0..15 = output layer, 16..31 zero
+            const int s = f - L::f_ao;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (c < 16) ? w[L::wo_off + c * 64 + slot_neuron(s, h, j)] : (uint16_t)0;
+        } else if (f < L::f_a2t) {               // AoT[m]: row = neuron 32m+c, slot (h,j) -> output row d_row(j,h)
+            const int m = f - L::f_aot;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w[L::wo_off + d_row(j, h) * 64 + 32 * m + c];
+        } else if (f < L::f_a1t) {               // A2T[m][s]: row = input neuron 32m+c, slot -> output neuron
+            const int m = (f - L::f_a2t) >> 2, s = (f - L::f_a2t) & 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w[L::w2_off + slot_neuron(s, h, j) * 64 + 32 * m + c];
+        } else {                                 // A1T[s]: row = input feature c, slot -> neuron
+            const int s = f - L::f_a1t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = (c < L::n_in_pad) ? w[L::w1_off + slot_neuron(s, h, j) * L::n_in_pad + c] : (uint16_t)0;
+        }
+        lds[f * 64 + lane] = pack8(v);
+    }
+}
+
+template <typename T16>
+__device__ __forceinline__ void relu_pack(const f32x16& acc, u32x4& lo, u32x4& hi, uint32_t& mask_bits, int shift) {
+    // regs 0..7 -> k-step t=0, regs 8..15 -> t=1.  mask bit (shift+r) = acc[r] > 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float a = acc[2 * i], b = acc[2 * i + 1], c = acc[8 + 2 * i], d = acc[8 + 2 * i + 1];
+        lo[i] = T16::pack(fmaxf(a, 0.f), fmaxf(b, 0.f));
+        hi[i] = T16::pack(fmaxf(c, 0.f), fmaxf(d, 0.f));
+        mask_bits |= (a > 0.f ? 1u : 0u) << (shift + 2 * i);
+        mask_bits |= (b > 0.f ? 1u : 0u) << (shift + 2 * i + 1);
+        mask_bits |= (c > 0.f ? 1u : 0u) << (shift + 8 + 2 * i);
+        mask_bits |= (d > 0.f ? 1u : 0u) << (shift + 8 + 2 * i + 1);
+    }
+}
+
+__device__ __forceinline__ float act_fwd(float y, int act, float shift) {
+    if (act == PERF_ACT_SIGMOID) return 1.0f / (1.0f + expf(-y));
+    if (act == PERF_ACT_EXP) return expf(y - shift);
+    return y;
+}
+__device__ __forceinline__ float act_bwd(float y, float g, int act, float shift) {
+    if (act == PERF_ACT_SIGMOID) { float s = 1.0f / (1.0f + expf(-y)); return g * s * (1.0f - s); }
+    if (act == PERF_ACT_EXP) return g * expf(fminf(y - shift, 15.0f));
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <typename T16, int NH, int KS>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
+                                                      const uint32_t* __restrict__ feat,
+                                                      const uint8_t* __restrict__ sel, float* __restrict__ out,
+                                                      int64_t n) {
+    using L = Layout<NH, KS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* frag = reinterpret_cast<u32x4*>(smem);
+    stage_fragments<NH, KS, false>(w, frag);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (n + kTile - 1) / kTile;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t si = tile * kTile + c;
+        const bool valid = si < n;
+        u32x4 b1[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int level = 8 * s + 2 * i + h;
+                b1[s][i] = (valid && level < mp.n_levels) ? feat[(int64_t)level * n + si] : 0u;
+            }
+        f32x16 acc[2];
+        uint32_t mask_unused = 0;
+        u32x4 hb[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            acc[m] = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc[m] = T16::mfma(frag[(L::f_a1 + m * KS + s) * 64 + lane], b1[s], acc[m]);
+            relu_pack<T16>(acc[m], hb[2 * m], hb[2 * m + 1], mask_unused, 0);
+        }
+        if constexpr (NH == 2) {
+            u32x4 hb2[4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m] = f32x16{0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[m] = T16::mfma(frag[(L::f_a2 + m * 4 + s) * 64 + lane], hb[s], acc[m]);
+                relu_pack<T16>(acc[m], hb2[2 * m], hb2[2 * m + 1], mask_unused, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
+        }
+        f32x16 o = f32x16{0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o = T16::mfma(frag[(L::f_ao + s) * 64 + lane], hb[s], o);
+        if (valid) {
+            const float sv = sel ? (float)sel[si] : 1.0f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int row = d_row(r, h);
+                if (row < mp.n_out) out[si * mp.n_out + row] = act_fwd(o[r], mp.out_act, mp.exp_shift) * sv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+// scatter a packed B-fragment set (4 k-steps x 4 dwords: the 32 channels this lane owns of a
+// 64-channel tensor) into the [channel][sample] LDS transpose tile
+__device__ __forceinline__ void lds_put_hidden(uint16_t* tile, const u32x4 fr[4], int c, int h) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = slot_neuron(s, h, 2 * i);
+            tile[ch * kPitch + c] = (uint16_t)(fr[s][i] & 0xffffu);
+            tile[(ch + 1) * kPitch + c] = (uint16_t)(fr[s][i] >> 16);
+        }
+}
+
+__device__ __forceinline__ u32x4 lds_get_frag(const uint16_t* tile, int row, int s, int h) {
+    return *reinterpret_cast<const u32x4*>(tile + row * kPitch + 16 * s + 8 * h);
+}
+
+template <typename T16>
+__device__ __forceinline__ void pack_masked(const f32x16& acc, uint32_t mask_bits, int shift, u32x4& lo, u32x4& hi) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float a = ((mask_bits >> (shift + 2 * i)) & 1u) ? acc[2 * i] : 0.f;
+        float b = ((mask_bits >> (shift + 2 * i + 1)) & 1u) ? acc[2 * i + 1] : 0.f;
+        float c = ((mask_bits >> (shift + 8 + 2 * i)) & 1u) ? acc[8 + 2 * i] : 0.f;
+        float d = ((mask_bits >> (shift + 8 + 2 * i + 1)) & 1u) ? acc[8 + 2 * i + 1] : 0.f;
+        lo[i] = T16::pack(a, b);
+        hi[i] = T16::pack(c, d);
+    }
+}
+
+template <typename T16, int NH, int KS>
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
+                                                      const uint32_t* __restrict__ feat,
+                                                      const uint8_t* __restrict__ sel,
+                                                      const float* __restrict__ dout, float2* __restrict__ dfeat,
+                                                      float* __restrict__ partials, int64_t n) {
+    using L = Layout<NH, KS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* frag = reinterpret_cast<u32x4*>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t* tA = reinterpret_cast<uint16_t*>(smem + L::n_all * 1024) + wave * (2 * 64 * kPitch);
+    uint16_t* tB = tA + 64 * kPitch;
+    stage_fragments<NH, KS, true>(w, frag);
+    __syncthreads();
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (n + kTile - 1) / kTile;
+
+    f32x16 gW1[2], gWo[2], gW2[NH == 2 ? 4 : 1];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { gW1[m] = f32x16{0}; gWo[m] = f32x16{0}; }
+#pragma unroll
+    for (int m = 0; m < (NH == 2 ? 4 : 1); ++m) gW2[m] = f32x16{0};
+
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t si = tile * kTile + c;
+        const bool valid = si < n;
+        // ---- recompute forward
+        u32x4 b1[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int level = 8 * s + 2 * i + h;
+                b1[s][i] = (valid && level < mp.n_levels) ? feat[(int64_t)level * n + si] : 0u;
+            }
+        f32x16 acc[2];
+        u32x4 hb1[4], hb2[4];
+        uint32_t mask1 = 0, mask2 = 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            acc[m] = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc[m] = T16::mfma(frag[(L::f_a1 + m * KS + s) * 64 + lane], b1[s], acc[m]);
+            relu_pack<T16>(acc[m], hb1[2 * m], hb1[2 * m + 1], mask1, 16 * m);
+        }
+        if constexpr (NH == 2) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m] = f32x16{0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[m] = T16::mfma(frag[(L::f_a2 + m * 4 + s) * 64 + lane], hb1[s], acc[m]);
+                relu_pack<T16>(acc[m], hb2[2 * m], hb2[2 * m + 1], mask2, 16 * m);
+            }
+        }
+        const u32x4* hlast = (NH == 2) ? hb2 : hb1;
+        const uint32_t mask_last = (NH == 2) ? mask2 : mask1;
+        f32x16 o = f32x16{0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o = T16::mfma(frag[(L::f_ao + s) * 64 + lane], hlast[s], o);
+        // ---- output gradient (activation derivative and selector applied here)
+        float dy[8];
+        const float sv = (valid && sel) ? (float)sel[si] : (valid ? 1.0f : 0.0f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = d_row(r, h);
+            float g = 0.f;
+            if (valid && row < mp.n_out) g = act_bwd(o[r], dout[si * mp.n_out + row] * sv, mp.out_act, mp.exp_shift);
+            dy[r] = g;
+        }
+        u32x4 dyb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dyb[i] = T16::pack(dy[2 * i], dy[2 * i + 1]);
+        // ---- dH_last = Wo^T dY, masked
+        u32x4 dhl[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f32x16 d = T16::mfma(frag[(L::f_aot + m) * 64 + lane], dyb, f32x16{0});
+            pack_masked<T16>(d, mask_last, 16 * m, dhl[2 * m], dhl[2 * m + 1]);
+        }
+        // ---- weight gradient of the output layer: dWo[16 x 64] += dY * Hlast^T
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // dY rows d_row(2i,h), d_row(2i+1,h) -> tile A rows 0..15
+            tA[d_row(2 * i, h) * kPitch + c] = (uint16_t)(dyb[i] & 0xffffu);
+            tA[d_row(2 * i + 1, h) * kPitch + c] = (uint16_t)(dyb[i] >> 16);
+        }
+        lds_put_hidden(tB, hlast, c, h);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 a = (c < 16) ? lds_get_frag(tA, c, s, h) : u32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) gWo[nn] = T16::mfma(a, lds_get_frag(tB, 32 * nn + c, s, h), gWo[nn]);
+        }
+        u32x4 dh1[4];
+        if constexpr (NH == 2) {
+            // ---- dH1 = W2^T dH2, masked by layer-1 activations
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x16 d = f32x16{0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) d = T16::mfma(frag[(L::f_a2t + m * 4 + s) * 64 + lane], dhl[s], d);
+                pack_masked<T16>(d, mask1, 16 * m, dh1[2 * m], dh1[2 * m + 1]);
+            }
+            // ---- dW2[64 x 64] += dH2 * H1^T
+            __builtin_amdgcn_wave_barrier();
+            lds_put_hidden(tA, dhl, c, h);
+            lds_put_hidden(tB, hb1, c, h);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    u32x4 a = lds_get_frag(tA, 32 * m + c, s, h);
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn)
+                        gW2[2 * m + nn] = T16::mfma(a, lds_get_frag(tB, 32 * nn + c, s, h), gW2[2 * m + nn]);
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dh1[s] = dhl[s];
+        }
+        // ---- dX = W1^T dH1 (rows = input features in natural order 2*level+feat)
+        if (dfeat != nullptr) {
+            f32x16 dx = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dx = T16::mfma(frag[(L::f_a1t + s) * 64 + lane], dh1[s], dx);
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {      // register pair (2q,2q+1) -> level d_row(2q,h)/2
+                    const int level = d_row(2 * q, h) >> 1;
+                    if (level < mp.n_levels) dfeat[(int64_t)level * n + si] = make_float2(dx[2 * q], dx[2 * q + 1]);
+                }
+            }
+        }
+        // ---- dW1[64 x n_in_pad] += dH1 * X^T
+        __builtin_amdgcn_wave_barrier();
+        lds_put_hidden(tA, dh1, c, h);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = 2 * (8 * s + 2 * i + h);
+                tB[ch * kPitch + c] = (uint16_t)(b1[s][i] & 0xffffu);
+                tB[(ch + 1) * kPitch + c] = (uint16_t)(b1[s][i] >> 16);
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 b = (c < L::n_in_pad) ? lds_get_frag(tB, c, s, h) : u32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) gW1[m] = T16::mfma(lds_get_frag(tA, 32 * m + c, s, h), b, gW1[m]);
+        }
+    }
+    // ---- per-wave partial weight gradients -> global (reduced by mlp_reduce_kernel)
+    float* p = partials + ((int64_t)blockIdx.x * 4 + wave) * L::n_params;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * m + d_row(r, h);
+            if (c < L::n_in_pad) p[L::w1_off + row * L::n_in_pad + c] = gW1[m][r];
+        }
+    if constexpr (NH == 2) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    p[L::w2_off + (32 * m + d_row(r, h)) * 64 + 32 * nn + c] = gW2[2 * m + nn][r];
+    }
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = d_row(r, h);
+            if (row < 16) p[L::wo_off + row * 64 + 32 * nn + c] = gWo[nn][r];
+        }
+}
+
+__global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
+                                                         int n_params, int n_partials) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_params) return;
+    float s = 0.f;
+    for (int k = 0; k < n_partials; ++k) s += partials[(int64_t)k * n_params + i];
+    dw[i] = s;
+}
+
+static inline int mlp_blocks(int64_t n, int per_cu) {
+    int64_t tiles = div_up(n, kTile);
+    int64_t want = div_up(tiles, 4);
+    int64_t cap = (int64_t)kNumCU * per_cu;
+    return (int)(want < cap ? (want > 0 ? want : 1) : cap);
+}
+
+static int check_mlp(const perf_mlp_desc* m, int* nh, int* ks) {
+    PERF_REQUIRE(m != nullptr, "mlp desc is NULL");
+    PERF_REQUIRE(m->n_levels >= 1 && m->n_levels <= 16, "mlp n_levels %d out of range", m->n_levels);
+    PERF_REQUIRE(m->n_hidden_layers == 1 || m->n_hidden_layers == 2, "n_hidden_layers must be 1 or 2");
+    PERF_REQUIRE(m->n_out >= 1 && m->n_out <= 16, "n_out out of range");
+    PERF_REQUIRE(m->out_act >= 0 && m->out_act <= 2, "bad out_act");
+    *nh = m->n_hidden_layers;
+    *ks = m->n_levels > 8 ? 2 : 1;
+    return PERF_OK;
+}
+
+template <int NH, int KS>
+static int n_params_of() { return Layout<NH, KS>::n_params; }
+
+static int n_params_rt(int nh, int ks) {
+    if (nh == 1) return ks == 1 ? n_params_of<1, 1>() : n_params_of<1, 2>();
+    return ks == 1 ? n_params_of<2, 1>() : n_params_of<2, 2>();
+}
+
+constexpr int kBwdBlocksPerCU = 1;
+
+}  // namespace perf
+
+using namespace perf;
+
+template <typename T16, int NH, int KS>
+static void launch_fwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t* w, const uint32_t* feat, const uint8_t* sel,
+                       float* out, int64_t n) {
+    constexpr int lds_bytes = Layout<NH, KS>::n_fwd * 1024;
+    mlp_fwd_kernel<T16, NH, KS><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, out, n);
+}
+
+template <typename T16, int NH, int KS>
+static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t* w, const uint32_t* feat, const uint8_t* sel,
+                       const float* dout, float2* dfeat, float* partials, int64_t n) {
+    constexpr int lds_bytes = Layout<NH, KS>::n_all * 1024 + 4 * 2 * 64 * kPitch * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<T16, NH, KS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    mlp_bwd_kernel<T16, NH, KS><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, n);
+}
+
+template <typename T16, typename... Args>
+static void dispatch_fwd(int nh, int ks, Args... a) {
+    if (nh == 1 && ks == 1) launch_fwd<T16, 1, 1>(a...);
+    else if (nh == 1) launch_fwd<T16, 1, 2>(a...);
+    else if (ks == 1) launch_fwd<T16, 2, 1>(a...);
+    else launch_fwd<T16, 2, 2>(a...);
+}
+
+template <typename T16, typename... Args>
+static void dispatch_bwd(int nh, int ks, Args... a) {
+    if (nh == 1 && ks == 1) launch_bwd<T16, 1, 1>(a...);
+    else if (nh == 1) launch_bwd<T16, 1, 2>(a...);
+    else if (ks == 1) launch_bwd<T16, 2, 1>(a...);
+    else launch_bwd<T16, 2, 2>(a...);
+}
+
+extern "C" int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
+                            float* out, int64_t n, int dtype, void* stream) {
+    int nh, ks;
+    int rc = check_mlp(mlp, &nh, &ks);
+    if (rc) return rc;
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(w16 && feat16 && out, "NULL pointer");
+    PERF_REQUIRE(dtype == PERF_DTYPE_BF16 || dtype == PERF_DTYPE_FP16, "bad dtype %d", dtype);
+    MlpParams mp{mlp->n_levels, mlp->n_out, mlp->out_act, mlp->exp_shift};
+    const int blocks = mlp_blocks(n, 8);
+    if (dtype == PERF_DTYPE_BF16)
+        dispatch_fwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, out, n);
+    else
+        dispatch_fwd<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, out, n);
+    PERF_LAUNCH_CHECK("perf_mlp_fwd");
+    return PERF_OK;
+}
+
+extern "C" int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n) {
+    int nh, ks;
+    if (check_mlp(mlp, &nh, &ks)) return -1;
+    const int blocks = mlp_blocks(n > 0 ? n : 1, kBwdBlocksPerCU);
+    return (int64_t)blocks * 4 * n_params_rt(nh, ks) * (int64_t)sizeof(float);
+}
+
+extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
+                            const float* dout, float* dfeat, float* dw, void* workspace, int64_t workspace_bytes,
+                            int64_t n, int dtype, void* stream) {
+    int nh, ks;
+    int rc = check_mlp(mlp, &nh, &ks);
+    if (rc) return rc;
+    PERF_REQUIRE(w16 && dw && workspace, "NULL pointer");
+    PERF_REQUIRE(dtype == PERF_DTYPE_BF16 || dtype == PERF_DTYPE_FP16, "bad dtype %d", dtype);
+    const int np = n_params_rt(nh, ks);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(dw, 0, np * sizeof(float), as_stream(stream));
+        if (e != hipSuccess) { set_error("perf_mlp_bwd: memset failed"); return PERF_E_LAUNCH; }
+        return PERF_OK;
+    }
+    PERF_REQUIRE(feat16 && dout, "NULL pointer");
+    const int64_t need = perf_mlp_bwd_workspace_bytes(mlp, n);
+    PERF_REQUIRE(workspace_bytes >= need, "perf_mlp_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    MlpParams mp{mlp->n_levels, mlp->n_out, mlp->out_act, mlp->exp_shift};
+    const int blocks = mlp_blocks(n, kBwdBlocksPerCU);
+    if (dtype == PERF_DTYPE_BF16)
+        dispatch_bwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,
+                           (float2*)dfeat, (float*)workspace, n);
+    else
+        dispatch_bwd<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,
+                           (float2*)dfeat, (float*)workspace, n);
+    PERF_LAUNCH_CHECK("perf_mlp_bwd");
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)div_up(np, 256)), dim3(256), 0, as_stream(stream),
+                       (const float*)workspace, dw, np, blocks * 4);
+    PERF_LAUNCH_CHECK("perf_mlp_bwd(reduce)");
+    return PERF_OK;
+}

@@ -1,0 +1,132 @@
+"""Host-side geometry of the multiresolution hash grid and the 64-wide MLP (product code).
+
+Mirrors the configuration dictionaries PeRF hands to tinycudann
+(modules/fields/ngp_nerf.py:96-134,230-245; modules/geo_predictors/pano_joint_predictor.py:30-41):
+per level  scale = N_min * b^l - 1 (fp32),  res = ceil(scale) + 1,
+size = min(align8(res^3), 2^T), offsets = running sum.
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+
+_F = np.float32
+
+
+@dataclass
+class GridConfig:
+    n_levels: int = 16
+    n_features_per_level: int = 2
+    log2_hashmap_size: int = 18
+    base_resolution: int = 16
+    per_level_scale: float = 1.4472692012786865
+    interpolation: str = 'Linear'
+    scale: np.ndarray = field(init=False, repr=False)
+    res: np.ndarray = field(init=False, repr=False)
+    size: np.ndarray = field(init=False, repr=False)
+    offset: np.ndarray = field(init=False, repr=False)
+    hashed: np.ndarray = field(init=False, repr=False)
+    total: int = field(init=False)
+
+    def __post_init__(self):
+        if self.n_features_per_level != 2:
+            raise ValueError('only n_features_per_level == 2 is supported by the gfx950 kernels')
+        if not (1 <= self.n_levels <= _lib.MAX_LEVELS):
+            raise ValueError(f'n_levels must be in [1, {_lib.MAX_LEVELS}]')
+        if self.interpolation not in ('Linear', 'Smoothstep'):
+            raise ValueError(f'unsupported interpolation {self.interpolation!r}')
+        L = self.n_levels
+        log2_b = _F(np.log2(_F(self.per_level_scale)))
+        self.scale = np.zeros(L, _F)
+        self.res = np.zeros(L, np.uint32)
+        self.size = np.zeros(L, np.uint32)
+        self.offset = np.zeros(L, np.uint32)
+        self.hashed = np.zeros(L, np.uint32)
+        total = 0
+        for l in range(L):
+            growth = _F(np.exp2(np.float64(_F(l) * log2_b)))
+            s = _F(_F(growth * _F(self.base_resolution)) - _F(1.0))
+            r = int(math.ceil(float(s))) + 1
+            cells = r ** 3
+            n = min(cells, 0xFFFFFFFF // 2)
+            n = -(-n // 8) * 8
+            n = min(n, 1 << self.log2_hashmap_size)
+            self.scale[l], self.res[l], self.size[l], self.offset[l] = s, r, n, total
+            self.hashed[l] = 1 if cells > n else 0
+            total += n
+        self.total = total
+
+    @classmethod
+    def from_tcnn(cls, cfg: dict) -> 'GridConfig':
+        otype = cfg.get('otype', 'HashGrid')
+        if otype not in ('HashGrid', 'Grid'):
+            raise ValueError(f'unsupported encoding otype {otype!r}')
+        return cls(n_levels=int(cfg.get('n_levels', 16)),
+                   n_features_per_level=int(cfg.get('n_features_per_level', 2)),
+                   log2_hashmap_size=int(cfg.get('log2_hashmap_size', 19)),
+                   base_resolution=int(cfg.get('base_resolution', 16)),
+                   per_level_scale=float(cfg.get('per_level_scale', 2.0)),
+                   interpolation=str(cfg.get('interpolation', 'Linear')))
+
+    @property
+    def n_params(self) -> int:
+        return self.total * 2
+
+    @property
+    def n_output_dims(self) -> int:
+        return self.n_levels * 2
+
+    def desc(self) -> '_lib.GridDesc':
+        d = _lib.GridDesc()
+        d.n_levels = self.n_levels
+        d.interpolation = _lib.INTERP_SMOOTHSTEP if self.interpolation == 'Smoothstep' else _lib.INTERP_LINEAR
+        for l in range(self.n_levels):
+            d.scale[l] = float(self.scale[l]); d.res[l] = int(self.res[l]); d.size[l] = int(self.size[l])
+            d.offset[l] = int(self.offset[l]); d.hashed[l] = int(self.hashed[l])
+        return d
+
+
+_ACTS = {'None': _lib.ACT_NONE, 'Sigmoid': _lib.ACT_SIGMOID, 'Exponential': _lib.ACT_EXP}
+
+
+@dataclass
+class MlpConfig:
+    n_levels: int                 # inputs = 2 * n_levels
+    n_hidden_layers: int = 1
+    n_output_dims: int = 1
+    output_activation: str = 'None'
+    exp_shift: float = 0.0
+    n_neurons: int = 64
+
+    def __post_init__(self):
+        if self.n_neurons != 64:
+            raise ValueError('only n_neurons == 64 is supported by the gfx950 MFMA kernels')
+        if self.n_hidden_layers not in (1, 2):
+            raise ValueError('n_hidden_layers must be 1 or 2')
+        if not (1 <= self.n_output_dims <= 16):
+            raise ValueError('n_output_dims must be in [1, 16]')
+        if self.output_activation not in _ACTS:
+            raise ValueError(f'unsupported output activation {self.output_activation!r}')
+
+    @property
+    def n_in_pad(self) -> int:
+        return 32 if self.n_levels > 8 else 16
+
+    @property
+    def shapes(self):
+        return [(64, self.n_in_pad)] + [(64, 64)] * (self.n_hidden_layers - 1) + [(16, 64)]
+
+    @property
+    def n_params(self) -> int:
+        return sum(o * i for o, i in self.shapes)
+
+    def desc(self) -> '_lib.MlpDesc':
+        d = _lib.MlpDesc()
+        d.n_levels = self.n_levels
+        d.n_hidden_layers = self.n_hidden_layers
+        d.n_out = self.n_output_dims
+        d.out_act = _ACTS[self.output_activation]
+        d.exp_shift = self.exp_shift
+        return d

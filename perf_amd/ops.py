@@ -1,0 +1,285 @@
+"""Tensor-level wrappers over the C ABI (include/perf_hip.h).
+
+Every function takes contiguous CUDA tensors, allocates outputs/workspaces with torch's caching
+allocator, and enqueues on torch's current stream.  Nothing here has a CPU fallback: a CPU tensor
+or a missing libperf_hip.so raises.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import DTYPE_BF16, DTYPE_FP16
+from .grid import GridConfig, MlpConfig
+
+_T16 = {DTYPE_BF16: torch.bfloat16, DTYPE_FP16: torch.float16}
+_CODE = {torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_FP16, 'bf16': DTYPE_BF16, 'fp16': DTYPE_FP16,
+         DTYPE_BF16: DTYPE_BF16, DTYPE_FP16: DTYPE_FP16}
+
+
+def dtype_code(d) -> int:
+    return _CODE[d]
+
+
+def torch_dtype(d):
+    return _T16[dtype_code(d)]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.PerfError('perf_amd ops need CUDA (HIP) tensors; there is no CPU path')
+    if not t.is_contiguous():
+        raise _lib.PerfError('perf_amd ops need contiguous tensors')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise _lib.PerfError(f'{name} must be float32, got {t.dtype}')
+    return t
+
+
+def _aabb6(aabb):
+    vals = [float(v) for v in (aabb.detach().cpu().tolist() if torch.is_tensor(aabb) else aabb)]
+    if len(vals) != 6:
+        raise _lib.PerfError('aabb must hold 6 values')
+    return (ctypes.c_float * 6)(*vals)
+
+
+# ---- parameters ----------------------------------------------------------------------------------
+def cast_params(src: torch.Tensor, dtype, out: torch.Tensor = None) -> torch.Tensor:
+    _f32(src, 'params')
+    code = dtype_code(dtype)
+    if out is None:
+        out = torch.empty(src.numel(), dtype=_T16[code], device=src.device)
+    _lib.call('perf_cast_params', _p(src), _p(out), src.numel(), code, _stream())
+    return out
+
+
+def adam_step(p, m, v, g, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, w16=None, zero_grad=True):
+    code = dtype_code(w16.dtype) if w16 is not None else 0
+    _lib.call('perf_adam_step', _p(_f32(p, 'p')), _p(_f32(m, 'm')), _p(_f32(v, 'v')), _p(_f32(g, 'g')), _p(w16),
+              p.numel(), code, int(step), float(lr), float(beta1), float(beta2), float(eps), int(bool(zero_grad)),
+              _stream())
+
+
+# ---- positions -----------------------------------------------------------------------------------
+def points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, aabb):
+    n = ray_indices.numel()
+    if ray_indices.dtype != torch.int64:
+        raise _lib.PerfError('ray_indices must be int64')
+    x01 = torch.empty(n, 3, dtype=torch.float32, device=rays_o.device)
+    sel = torch.empty(n, dtype=torch.uint8, device=rays_o.device)
+    _lib.call('perf_points_from_rays', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(ray_indices),
+              _p(_f32(t_starts, 't_starts')), _p(_f32(t_ends, 't_ends')), _aabb6(aabb), _p(x01), _p(sel), n, _stream())
+    return x01, sel
+
+
+def points_normalize(x, aabb):
+    x = _f32(x, 'x').reshape(-1, 3)
+    n = x.shape[0]
+    x01 = torch.empty(n, 3, dtype=torch.float32, device=x.device)
+    sel = torch.empty(n, dtype=torch.uint8, device=x.device)
+    _lib.call('perf_points_normalize', _p(x), _aabb6(aabb), _p(x01), _p(sel), n, _stream())
+    return x01, sel
+
+
+# ---- hash grid -----------------------------------------------------------------------------------
+def hashgrid_fwd(grid: GridConfig, x01, table16):
+    """x01 [n,3] f32, table16 [total*2] 16-bit -> feat [L, n, 2] 16-bit (level major)."""
+    n = x01.shape[0]
+    feat = torch.empty(grid.n_levels, n, 2, dtype=table16.dtype, device=x01.device)
+    d = grid.desc()
+    _lib.call('perf_hashgrid_fwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(table16), _p(feat), n,
+              dtype_code(table16.dtype), _stream())
+    return feat
+
+
+def hashgrid_fwd_f32(grid: GridConfig, x01, table):
+    n = x01.shape[0]
+    feat = torch.empty(grid.n_levels, n, 2, dtype=torch.float32, device=x01.device)
+    d = grid.desc()
+    _lib.call('perf_hashgrid_fwd_f32', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(table, 'table')), _p(feat), n, _stream())
+    return feat
+
+
+def hashgrid_bwd(grid: GridConfig, x01, dfeat, grad_table=None):
+    """dfeat [L, n, 2] f32 -> grad_table [total*2] f32 (accumulated into grad_table when given)."""
+    n = x01.shape[0]
+    if grad_table is None:
+        grad_table = torch.zeros(grid.n_params, dtype=torch.float32, device=x01.device)
+    d = grid.desc()
+    _lib.call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(grad_table, 'grad')),
+              n, _stream())
+    return grad_table
+
+
+def hashgrid_bwd_input(grid: GridConfig, x01, dfeat, table):
+    n = x01.shape[0]
+    dx = torch.empty(n, 3, dtype=torch.float32, device=x01.device)
+    d = grid.desc()
+    _lib.call('perf_hashgrid_bwd_input', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')),
+              _p(_f32(table, 'table')), _p(dx), n, _stream())
+    return dx
+
+
+# ---- MLP -----------------------------------------------------------------------------------------
+def mlp_fwd(mlp: MlpConfig, w16, feat16, sel=None):
+    n = feat16.shape[1]
+    out = torch.empty(n, mlp.n_output_dims, dtype=torch.float32, device=feat16.device)
+    d = mlp.desc()
+    _lib.call('perf_mlp_fwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(out), n, dtype_code(w16.dtype), _stream())
+    return out
+
+
+def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True):
+    """Returns (dfeat [L,n,2] f32 or None, dw [n_net_params] f32)."""
+    n = feat16.shape[1]
+    d = mlp.desc()
+    lib = _lib.load()
+    ws_bytes = lib.perf_mlp_bwd_workspace_bytes(ctypes.byref(d), n)
+    ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=feat16.device)
+    dfeat = torch.empty(mlp.n_levels, n, 2, dtype=torch.float32, device=feat16.device) if need_dfeat else None
+    dw = torch.empty(mlp.n_params, dtype=torch.float32, device=feat16.device)
+    _lib.call('perf_mlp_bwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(_f32(dout, 'dout')), _p(dfeat), _p(dw),
+              _p(ws), ws.numel() * 4, n, dtype_code(w16.dtype), _stream())
+    return dfeat, dw
+
+
+# ---- rays ----------------------------------------------------------------------------------------
+def pano_raygen(pose, height, width, row0=0, nrows=None, device='cuda'):
+    nrows = height - row0 if nrows is None else nrows
+    pose_h = (ctypes.c_float * 16)(*[float(v) for v in torch.as_tensor(pose).detach().cpu().reshape(-1).tolist()])
+    o = torch.empty(nrows, width, 3, dtype=torch.float32, device=device)
+    d = torch.empty(nrows, width, 3, dtype=torch.float32, device=device)
+    _lib.call('perf_pano_raygen', pose_h, height, width, row0, nrows, _p(o), _p(d), _stream())
+    return o, d
+
+
+# ---- occupancy marching ----------------------------------------------------------------------------
+def occ_pack_bits(binaries: torch.Tensor) -> torch.Tensor:
+    b = binaries.reshape(-1)
+    if b.dtype == torch.bool:
+        b = b.view(torch.uint8)
+    n = b.numel()
+    bits = torch.empty((n + 31) // 32, dtype=torch.int32, device=b.device)
+    _lib.call('perf_occ_pack_bits', _p(b), _p(bits), n, _stream())
+    return bits
+
+
+def exclusive_scan_i32(counts: torch.Tensor):
+    n = counts.numel()
+    lib = _lib.load()
+    out = torch.empty_like(counts)
+    total = torch.empty(1, dtype=torch.int64, device=counts.device)
+    ws = torch.empty(lib.perf_scan_workspace_bytes(n) // 8 + 1, dtype=torch.int64, device=counts.device)
+    _lib.call('perf_exclusive_scan_i32', _p(counts), _p(out), _p(total), n, _p(ws), ws.numel() * 8, _stream())
+    return out, total
+
+
+def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, capacity=None):
+    """Returns (ray_indices i64 [S], t_starts, t_ends f32 [S], packed_info i32 [R,2]).
+    capacity=None reads the total back (one host sync, like the reference's boolean indexing);
+    an int capacity keeps the call sync-free and returns arrays of that length plus `total` on device."""
+    R = rays_o.shape[0]
+    dev = rays_o.device
+    lib = _lib.load()
+    mw = lib.perf_occ_mask_words(max_steps)
+    masks = torch.empty(max(R * mw, 1), dtype=torch.int64, device=dev)
+    counts = torch.empty(R, dtype=torch.int32, device=dev)
+    a6 = _aabb6(aabb)
+    _lib.call('perf_occ_march_count', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(t0, 't0')), R,
+              _p(occ_bits), int(res), a6, float(far_plane), float(step), int(max_steps), _p(masks), _p(counts), _stream())
+    offsets, total = exclusive_scan_i32(counts)
+    S = int(total.item()) if capacity is None else int(capacity)
+    ri = torch.empty(S, dtype=torch.int64, device=dev)
+    ts = torch.empty(S, dtype=torch.float32, device=dev)
+    te = torch.empty(S, dtype=torch.float32, device=dev)
+    packed = torch.empty(R, 2, dtype=torch.int32, device=dev)
+    _lib.call('perf_occ_march_write', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
+              _p(ri), _p(ts), _p(te), _p(packed), _stream())
+    if capacity is None:
+        return ri, ts, te, packed
+    return ri, ts, te, packed, total
+
+
+# ---- compositing -----------------------------------------------------------------------------------
+def visibility_count(sigmas, t_starts, t_ends, packed, early_stop_eps=1e-4, want_exsum=False):
+    R = packed.shape[0]
+    thr = float(-math.log(early_stop_eps)) if early_stop_eps > 0 else float('inf')
+    new_counts = torch.empty(R, dtype=torch.int32, device=packed.device)
+    ex = torch.empty_like(sigmas) if want_exsum else None
+    _lib.call('perf_visibility_count', _p(_f32(sigmas, 'sigmas')), _p(t_starts), _p(t_ends), _p(packed), R, thr,
+              _p(new_counts), _p(ex), _stream())
+    return (new_counts, ex) if want_exsum else new_counts
+
+
+def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=None):
+    R = packed.shape[0]
+    dev = packed.device
+    new_offsets, total = exclusive_scan_i32(new_counts)
+    S = int(total.item()) if capacity is None else int(capacity)
+    ri = torch.empty(S, dtype=torch.int64, device=dev)
+    ts = torch.empty(S, dtype=torch.float32, device=dev)
+    te = torch.empty(S, dtype=torch.float32, device=dev)
+    sg = torch.empty(S, dtype=torch.float32, device=dev) if sigmas is not None else None
+    packed_out = torch.empty(R, 2, dtype=torch.int32, device=dev)
+    _lib.call('perf_compact_prefix', _p(packed), _p(new_counts), _p(new_offsets), R, _p(t_starts), _p(t_ends), _p(sigmas),
+              _p(ri), _p(ts), _p(te), _p(sg), _p(packed_out), _stream())
+    return ri, ts, te, sg, packed_out
+
+
+def composite_fwd(sigmas, rgbs, t_starts, t_ends, packed, want_samples=True):
+    R = packed.shape[0]
+    S = sigmas.numel()
+    dev = sigmas.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    w = f(S) if want_samples else None
+    T = f(S) if want_samples else None
+    al = f(S) if want_samples else None
+    op, dist = f(R, 1), f(R, 1)
+    col = f(R, 3) if rgbs is not None else None
+    _lib.call('perf_composite_fwd', _p(_f32(sigmas, 'sigmas')), _p(rgbs), _p(t_starts), _p(t_ends), _p(packed), R, _p(w),
+              _p(T), _p(al), _p(op), _p(dist), _p(col), _stream())
+    return w, T, al, op, dist, col
+
+
+def composite_bwd(sigmas, t_starts, t_ends, packed, weights, trans, g_weights=None, g_opacity=None, g_distance=None,
+                  g_color=None, want_dsigma=True, want_drgb=False):
+    R = packed.shape[0]
+    S = sigmas.numel()
+    dev = sigmas.device
+    ds = torch.empty(S, dtype=torch.float32, device=dev) if want_dsigma else None
+    dr = torch.empty(S, 3, dtype=torch.float32, device=dev) if want_drgb else None
+    _lib.call('perf_composite_bwd', _p(sigmas), None, _p(t_starts), _p(t_ends), _p(packed), R, _p(weights), _p(trans),
+              _p(g_weights), _p(g_opacity), _p(g_distance), _p(g_color), _p(ds), _p(dr), _stream())
+    return ds, dr
+
+
+def distloss_fwd(w, t_starts, t_ends, packed):
+    R = packed.shape[0]
+    loss = torch.empty(R, dtype=torch.float32, device=w.device)
+    _lib.call('perf_distloss_fwd', _p(_f32(w, 'w')), _p(t_starts), _p(t_ends), _p(packed), R, _p(loss), _stream())
+    return loss
+
+
+def distloss_bwd(w, t_starts, t_ends, packed, scale):
+    R = packed.shape[0]
+    g = torch.empty_like(w)
+    _lib.call('perf_distloss_bwd', _p(_f32(w, 'w')), _p(t_starts), _p(t_ends), _p(packed), R, float(scale), _p(g), _stream())
+    return g
+
+
+def occ_splat(rays_o, rays_d, dist, res):
+    n = rays_o.shape[0]
+    occ = torch.zeros(res ** 3, dtype=torch.uint8, device=rays_o.device)
+    _lib.call('perf_occ_splat', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(dist.reshape(-1), 'dist')), n,
+              int(res), _p(occ), _stream())
+    return occ

@@ -1,0 +1,110 @@
+"""CPU tests (no GPU): the oracle against the golden vectors made from the reference, and the
+C-ABI library's loadability / exported symbols."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import torch
+
+from oracle import perf_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, 'tests', 'golden')
+
+
+def test_rays_match_reference():
+    g = np.load(f'{G}/rays.npz')
+    for name in ('eye', 'rt'):
+        pose = torch.from_numpy(g[f'pose_{name}'])
+        o, d = O.pano_rays(pose, 32, 64)
+        assert np.abs(d.numpy() - g[f'pano_{name}_32x64_d']).max() < 1e-6
+        assert np.array_equal(o.numpy(), g[f'pano_{name}_32x64_o'])
+        for (h, w) in ((256, 512), (1024, 2048)):
+            _, d = O.pano_rays(pose, h, w)
+            ij = g[f'pano_{name}_{h}x{w}_ij']
+            assert np.abs(d.numpy()[ij[:, 0], ij[:, 1]] - g[f'pano_{name}_{h}x{w}_d']).max() < 1e-6
+        o, d = O.pers_rays(pose, np.deg2rad(75.), 64)
+        assert np.abs(d.numpy() - g[f'pers_{name}_d']).max() < 1e-6
+        assert np.abs(o.numpy() - g[f'pers_{name}_o']).max() == 0
+
+
+def test_trunc_exp_and_contract():
+    g = np.load(f'{G}/field_bits.npz')
+    x = torch.from_numpy(g['te_x']).requires_grad_(True)
+    y = O.trunc_exp(x)
+    y.sum().backward()
+    assert np.allclose(y.detach().numpy(), g['te_y'], rtol=1e-6) and np.allclose(x.grad.numpy(), g['te_g'], rtol=1e-6)
+    c = O.contract_to_unisphere(torch.from_numpy(g['ct_x']), torch.tensor([-1., -1, -1, 1, 1, 1]))
+    assert np.abs(c.numpy() - g['ct_y']).max() < 1e-6
+
+
+def test_occ_grid_and_batch_sampler():
+    g = np.load(f'{G}/sup.npz')
+    for (h, w, res) in ((16, 32, 64), (64, 128, 256)):
+        o, d = O.pano_rays(torch.eye(4), h, w)
+        dist, _ = O.synthetic_room(d)
+        occ = O.gen_occ_grid(o.reshape(-1, 3), d.reshape(-1, 3), dist.reshape(-1, 1), res)
+        assert np.array_equal(torch.where(occ > 0)[0].numpy(), g[f'occ_{h}x{w}_r{res}_idx'])
+    torch.manual_seed(0)
+    idx = O.rand_ray_indices(16 * 32, 8192)
+    assert np.array_equal(idx.numpy(), g['rand_idx_seed0_n512_b8192'])
+
+
+def test_lr_schedule():
+    g = np.load(f'{G}/lr.npz')
+    for row, conf in zip(g['lr'], g['conf']):
+        got = [O.lr_schedule(float(p), *conf) for p in g['progress']]
+        assert np.allclose(got, row, rtol=1e-12, atol=0)
+
+
+def test_renderer_glue_matches_reference():
+    """oracle.occ_render == the reference's NeRFOCCRenderer.render run over the same operators."""
+    g = np.load(f'{G}/render_glue.npz')
+    res = int(g['res'])
+    occ = np.unpackbits(g['binaries'])[:res ** 3].reshape(res, res, res).astype(bool)
+    gs, as_ = O.geo_spec(), O.app_spec()
+    geo = O.init_field_params(gs, int(g['geo_seed'])); app = O.init_field_params(as_, int(g['app_seed']))
+    geo[gs.n_net:] *= float(g['grid_gain']); app[as_.n_net:] *= float(g['grid_gain'])
+    o = torch.from_numpy(g['o']); d = torch.from_numpy(g['d'])
+    R = o.shape[0]
+    step = float(g['step'])
+    for mode in ('train', 'eval'):
+        t0 = (np.zeros(R, np.float32) + g[f'{mode}_jitter'] * np.float32(step)).astype(np.float32) if mode == 'train' else None
+        out = O.occ_render(o, d, geo, app, occ, [-1, -1, -1, 1, 1, 1], training=(mode == 'train'), t0=t0,
+                           bg_color=torch.from_numpy(g[f'{mode}_bg']), dist_noise=torch.from_numpy(g[f'{mode}_noise']),
+                           near=0.0, far=1.5, step=step)
+        assert np.array_equal(out['ray_indices'].numpy(), g[f'{mode}_ray_indices'])
+        assert np.array_equal(out['t_starts'].numpy(), g[f'{mode}_t_starts'])
+        for k in ('rgb', 'distance', 'weights', 'opacities', 'trans'):
+            assert np.abs(out[k].detach().numpy() - g[f'{mode}_{k}']).max() < 1e-6, k
+
+
+def test_canonical_scan_is_a_prefix_sum():
+    rng = np.random.RandomState(0)
+    counts = rng.randint(0, 200, 50); counts[0] = 0
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    packed = np.stack([starts, counts], -1).astype(np.int32)
+    v = rng.rand(counts.sum()).astype(np.float32)
+    ex = O.packed_exclusive_sum_canonical(v, packed)
+    ref = O.packed_exclusive_sum(torch.from_numpy(v), packed).numpy()
+    assert np.abs(ex - ref).max() < 1e-4
+
+
+def test_library_exports_every_declared_symbol():
+    from perf_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'perf_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(perf_[a-z0-9_]+)\s*\(', header)))
+    assert declared == _lib.exported_symbols()
+    lib = _lib.load()                      # raises if the .so is missing: no CPU fallback
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.perf_version() == 1
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    from perf_amd import ops, _lib
+    from perf_amd.grid import GridConfig
+    with pytest.raises(_lib.PerfError):
+        ops.hashgrid_fwd(GridConfig(), torch.rand(4, 3), torch.zeros(8, dtype=torch.bfloat16))

@@ -1,0 +1,360 @@
+"""GPU parity tests: every C-ABI kernel against the CPU oracle on the same seeded inputs.
+
+Integer / index bookkeeping is compared bit-exactly; floating point within the tolerance
+written next to each assertion.  All calls go through libperf_hip.so (perf_amd.ops)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import perf_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    from perf_amd import ops as _ops
+    return _ops
+
+
+def _grid_cfg(**kw):
+    from perf_amd.grid import GridConfig
+    return GridConfig(**kw)
+
+
+def _lv_of(cfg):
+    return O.grid_levels(cfg.n_levels, 2, cfg.log2_hashmap_size, cfg.base_resolution, cfg.per_level_scale)
+
+
+DT = {'bf16': (torch.bfloat16, 2.0 ** -8), 'fp16': (torch.float16, 2.0 ** -11)}
+
+
+def test_level_table_matches_oracle():
+    cfg = _grid_cfg()
+    lv = O.grid_levels()
+    assert cfg.total == lv.total == 3320608
+    assert np.array_equal(cfg.scale, lv.scale) and np.array_equal(cfg.res, lv.res)
+    assert np.array_equal(cfg.size, lv.size) and np.array_equal(cfg.offset, lv.offset)
+
+
+def test_pano_raygen(ops, golden_dir):
+    g = np.load(f'{golden_dir}/rays.npz')
+    for name in ('eye', 'rt'):
+        pose = torch.from_numpy(g[f'pose_{name}'])
+        o, d = ops.pano_raygen(pose, 32, 64)
+        # fp32 tolerance: GPU sinf/cosf vs the reference's CPU libm, unit vectors -> 2e-6 absolute
+        assert np.abs(d.cpu().numpy() - g[f'pano_{name}_32x64_d']).max() < 2e-6
+        assert np.array_equal(o.cpu().numpy(), g[f'pano_{name}_32x64_o'])
+        for (h, w) in ((256, 512), (1024, 2048)):
+            o, d = ops.pano_raygen(pose, h, w)
+            ij = g[f'pano_{name}_{h}x{w}_ij']
+            got = d.cpu().numpy()[ij[:, 0], ij[:, 1]]
+            assert np.abs(got - g[f'pano_{name}_{h}x{w}_d']).max() < 2e-6
+        # row-sharded generation is identical to the full one (multi-GPU eval partitioning)
+        o2, d2 = ops.pano_raygen(pose, 256, 512, row0=64, nrows=32)
+        o1, d1 = ops.pano_raygen(pose, 256, 512)
+        assert torch.equal(d1[64:96], d2) and torch.equal(o1[64:96], o2)
+    # full-size size-independent property: unit norm and direction -> pixel round trip
+    o, d = ops.pano_raygen(torch.eye(4), 1024, 2048)
+    assert (d.norm(dim=-1) - 1).abs().max() < 1e-6
+
+
+def test_points_from_rays_bit_exact(ops):
+    g = torch.Generator().manual_seed(0)
+    R, S = 257, 5000
+    o = torch.rand(R, 3, generator=g) * 0.4 - 0.2
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    ri = torch.sort(torch.randint(0, R, (S,), generator=g)).values
+    ts = torch.rand(S, generator=g) * 1.5
+    te = ts + 5e-4
+    aabb = torch.tensor([-1., -1, -1, 1, 1, 1])
+    x01, sel = ops.points_from_rays(o.cuda(), d.cuda(), ri.cuda(), ts.cuda(), te.cuda(), aabb)
+    pos = o[ri] + d[ri] * (ts + te)[:, None] / 2.0
+    ref = (pos - aabb[:3]) / (aabb[3:] - aabb[:3])
+    assert torch.equal(x01.cpu(), ref)
+    assert torch.equal(sel.cpu().bool(), ((ref > 0) & (ref < 1)).all(-1))
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('interp', ['Linear', 'Smoothstep'])
+def test_hashgrid_fwd(ops, dt, interp):
+    tdt, ulp = DT[dt]
+    cfg = _grid_cfg(interpolation=interp)
+    lv = _lv_of(cfg)
+    g = torch.Generator().manual_seed(1)
+    table = (torch.rand(cfg.total, 2, generator=g) * 2 - 1)
+    n = 3001                                   # ragged: not a multiple of the block or tile size
+    x = torch.rand(n, 3, generator=g)
+    x[:7] = torch.tensor([[0., 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1e-7, 1 - 1e-7, 0.25], [0.999999, 0, 1],
+                          [1.0, 0.0, 0.3], [0.3, 1.0, 0.0]])
+    t16 = table.to(tdt)
+    feat = ops.hashgrid_fwd(cfg, x.cuda(), t16.reshape(-1).cuda())
+    got = feat.float().cpu().permute(1, 0, 2).reshape(n, -1)
+    ref = O.hashgrid_encode(x, table, lv, interpolation=interp, quant=dt)
+    # the kernel rounds the fp32 interpolation to 16 bits: 1 ulp of the storage type (+ fp32 noise)
+    err = (got - ref).abs()
+    assert (err <= ulp * ref.abs() * 1.01 + 1e-6).all(), err.max()
+    # empty input is legal
+    assert ops.hashgrid_fwd(cfg, x[:0].cuda(), t16.reshape(-1).cuda()).shape == (cfg.n_levels, 0, 2)
+
+
+def test_hashgrid_fwd_f32_and_small_grid(ops):
+    cfg = _grid_cfg(n_levels=5, log2_hashmap_size=17, base_resolution=16,
+                    per_level_scale=float(np.exp((np.log(128) - np.log(16)) / 4)))
+    lv = _lv_of(cfg)
+    g = torch.Generator().manual_seed(2)
+    table = torch.rand(cfg.total, 2, generator=g) * 2 - 1
+    x = torch.rand(1000, 3, generator=g)
+    feat = ops.hashgrid_fwd_f32(cfg, x.cuda(), table.reshape(-1).cuda())
+    got = feat.cpu().permute(1, 0, 2).reshape(1000, -1)
+    ref = O.hashgrid_encode(x, table, lv)
+    assert (got - ref).abs().max() < 2e-6       # fp32 accumulation-order noise only
+
+
+def test_hashgrid_bwd_indices_and_weights(ops):
+    """The scatter touches exactly the oracle's corner indices (bit-exact bookkeeping) with the
+    oracle's trilinear weights (fp32 atomics: summation-order tolerance)."""
+    cfg = _grid_cfg()
+    lv = _lv_of(cfg)
+    g = torch.Generator().manual_seed(3)
+    n = 777
+    x = torch.rand(n, 3, generator=g)
+    dfeat = torch.randn(cfg.n_levels, n, 2, generator=g)
+    grad = ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda()).cpu().numpy().reshape(-1, 2)
+    ref = np.zeros((cfg.total, 2), np.float64)
+    xn = x.numpy()
+    for l in range(cfg.n_levels):
+        idx, f = O.grid_corner_indices(xn, lv, l)
+        for c in range(8):
+            w = np.ones(n, np.float32)
+            for a in range(3):
+                w = w * (f[:, a] if (c >> a) & 1 else (np.float32(1) - f[:, a]))
+            np.add.at(ref, idx[:, c].astype(np.int64) + int(lv.offset[l]), w[:, None].astype(np.float64) * dfeat[l].numpy())
+    assert np.array_equal(grad != 0, ref != 0)            # same set of touched entries
+    assert np.abs(grad - ref).max() < 1e-5
+
+
+def test_hashgrid_bwd_input(ops):
+    for interp in ('Linear', 'Smoothstep'):
+        cfg = _grid_cfg(n_levels=8, log2_hashmap_size=15, interpolation=interp)
+        lv = _lv_of(cfg)
+        g = torch.Generator().manual_seed(4)
+        table = torch.rand(cfg.total, 2, generator=g) * 2 - 1
+        x = (torch.rand(500, 3, generator=g) * 0.98 + 0.01).requires_grad_(True)
+        dfeat = torch.randn(cfg.n_levels, 500, 2, generator=g)
+        ref_feat = O.hashgrid_encode(x, table, lv, interpolation=interp)
+        (ref_feat * dfeat.permute(1, 0, 2).reshape(500, -1)).sum().backward()
+        dx = ops.hashgrid_bwd_input(cfg, x.detach().cuda(), dfeat.cuda(), table.reshape(-1).cuda()).cpu()
+        scale = x.grad.abs().max()
+        assert (dx - x.grad).abs().max() < 1e-4 * scale
+
+
+def _mlp_case(ops, dt, nh, n_out, act, n, n_levels=16, seed=0):
+    from perf_amd.grid import MlpConfig
+    tdt, ulp = DT[dt]
+    cfgm = MlpConfig(n_levels=n_levels, n_hidden_layers=nh, n_output_dims=n_out, output_activation=act,
+                     exp_shift=1.0 if act == 'Exponential' else 0.0)
+    g = torch.Generator().manual_seed(seed)
+    w = torch.cat([(torch.rand(o * i, generator=g) * 2 - 1) * math.sqrt(6.0 / (i + o)) * 1.5 for o, i in cfgm.shapes])
+    feat = (torch.rand(n_levels, n, 2, generator=g) * 2 - 1)
+    sel = (torch.rand(n, generator=g) > 0.2).to(torch.uint8)
+    return cfgm, w, feat, sel, tdt, ulp
+
+
+def _mlp_oracle(cfgm, w, feat, sel, dt):
+    n = feat.shape[1]
+    x = feat.permute(1, 0, 2).reshape(n, -1)
+    if cfgm.n_in_pad > x.shape[1]:
+        x = torch.cat([x, torch.zeros(n, cfgm.n_in_pad - x.shape[1])], 1)
+    y = O.mlp_forward(x, w, cfgm.n_in_pad, cfgm.n_hidden_layers, cfgm.n_output_dims, 'None', quant=dt)
+    if cfgm.output_activation == 'Sigmoid':
+        y = torch.sigmoid(y)
+    elif cfgm.output_activation == 'Exponential':
+        y = O.trunc_exp(y - cfgm.exp_shift)
+    return y * sel[:, None].float()
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('nh,n_out,act', [(1, 1, 'None'), (1, 1, 'Exponential'), (2, 3, 'Sigmoid'), (2, 16, 'None')])
+def test_mlp_fwd(ops, dt, nh, n_out, act):
+    cfgm, w, feat, sel, tdt, ulp = _mlp_case(ops, dt, nh, n_out, act, n=1000 + 13)
+    w16 = w.to(tdt)
+    f16 = feat.to(tdt)
+    out = ops.mlp_fwd(cfgm, w16.cuda(), f16.cuda(), sel.cuda()).cpu()
+    ref = _mlp_oracle(cfgm, w16.float(), f16.float(), sel, dt)
+    # operands are identical 16-bit values on both sides; differences come from fp32 accumulation order
+    # and from hidden activations that round differently at 16-bit ties: a few 16-bit ulps of the largest activation
+    tol = 8 * ulp * max(1.0, float(ref.abs().max()))
+    assert (out - ref).abs().max() < tol, (out - ref).abs().max()
+
+
+def test_mlp_fwd_small_input(ops):
+    cfgm, w, feat, sel, tdt, ulp = _mlp_case(ops, 'fp16', 1, 1, 'Exponential', n=300, n_levels=5, seed=5)
+    out = ops.mlp_fwd(cfgm, w.to(tdt).cuda(), feat.to(tdt).cuda(), None).cpu()
+    ref = _mlp_oracle(cfgm, w.to(tdt).float(), feat.to(tdt).float(), torch.ones(300, dtype=torch.uint8), 'fp16')
+    assert (out - ref).abs().max() < 8 * ulp * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('nh,n_out,act', [(1, 1, 'Exponential'), (2, 3, 'Sigmoid'), (1, 1, 'None')])
+def test_mlp_bwd(ops, dt, nh, n_out, act):
+    cfgm, w, feat, sel, tdt, ulp = _mlp_case(ops, dt, nh, n_out, act, n=2000 + 7, seed=7)
+    w16 = w.to(tdt); f16 = feat.to(tdt)
+    g = torch.Generator().manual_seed(8)
+    dout = torch.randn(feat.shape[1], n_out, generator=g)
+    dfeat, dw = ops.mlp_bwd(cfgm, w16.cuda(), f16.cuda(), dout.cuda(), sel.cuda())
+    wr = w16.float().requires_grad_(True)
+    fr = f16.float().requires_grad_(True)
+    y = _mlp_oracle(cfgm, wr, fr, sel, dt)
+    (y * dout).sum().backward()
+    # the kernel rounds dY and every dH to 16 bits before the MFMA chain (tcnn does the same in fp16):
+    # a few 16-bit ulps relative to the largest gradient of the tensor
+    def close(a, b, k):
+        return (a - b).abs().max() <= k * ulp * float(b.abs().max()) + 1e-6
+    assert close(dfeat.cpu(), fr.grad, 16), ((dfeat.cpu() - fr.grad).abs().max(), fr.grad.abs().max())
+    assert close(dw.cpu(), wr.grad, 16), ((dw.cpu() - wr.grad).abs().max(), wr.grad.abs().max())
+
+
+def test_cast_and_adam(ops):
+    g = torch.Generator().manual_seed(9)
+    n = 100003
+    p = torch.randn(n, generator=g)
+    assert torch.equal(ops.cast_params(p.cuda(), 'bf16').cpu(), p.to(torch.bfloat16))
+    assert torch.equal(ops.cast_params(p.cuda(), 'fp16').cpu(), p.to(torch.float16))
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-2)
+    pd = p.cuda().clone(); m = torch.zeros_like(pd); v = torch.zeros_like(pd)
+    w16 = torch.empty(n, dtype=torch.bfloat16, device='cuda')
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * 128
+        ref.grad = gr.clone()
+        opt.step()
+        gd = gr.cuda()
+        ops.adam_step(pd, m, v, gd, step, 1e-2, w16=w16)
+        assert float(gd.abs().max()) == 0.0                       # gradient cleared in the same pass
+    assert (pd.cpu() - ref.detach()).abs().max() < 2e-6            # fp32, 1-2 ulp of |p|~1
+    assert torch.equal(w16.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+def _room(R_h=24, R_w=48, res=64, seed=0):
+    o, d = O.pano_rays(torch.eye(4), R_h, R_w)
+    o = o.reshape(-1, 3).contiguous(); d = d.reshape(-1, 3).contiguous()
+    dist, rgb = O.synthetic_room(d)
+    occ = O.gen_occ_grid(o, d, dist, res)
+    return o, d, dist, rgb, occ
+
+
+def test_occ_splat_and_pack(ops, golden_dir):
+    o, d, dist, rgb, occ = _room(16, 32, 64)
+    got = ops.occ_splat(o.cuda(), d.cuda(), dist.cuda(), 64)
+    assert torch.equal(got.cpu(), occ)
+    gold = np.load(f'{golden_dir}/sup.npz')['occ_16x32_r64_idx']
+    assert np.array_equal(torch.where(got.cpu() > 0)[0].numpy(), gold)
+    bits = ops.occ_pack_bits(got).cpu().numpy().view(np.uint32)
+    ref_bits = np.packbits(occ.numpy().astype(bool), bitorder='little').view(np.uint32)
+    assert np.array_equal(bits, ref_bits)
+
+
+@pytest.mark.parametrize('stratified', [False, True])
+def test_occ_march_bit_exact(ops, stratified):
+    o, d, dist, rgb, occ = _room(24, 48, 64)
+    # move the camera off-centre and add rays that miss / graze the box
+    o = o + torch.tensor([0.2, -0.1, 0.05])
+    o[:5] = torch.tensor([3.0, 0.0, 0.0]); d[5] = torch.tensor([1.0, 0.0, 0.0]); d[6] = torch.tensor([0.0, 0.0, -1.0])
+    R = o.shape[0]
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    step, far, near = 2e-3, 1.5, 0.0
+    max_steps = int(math.ceil((far - near) / step)) + 1
+    g = torch.Generator().manual_seed(5)
+    t0 = torch.full((R,), near) + (torch.rand(R, generator=g) * step if stratified else 0.0)
+    binaries = occ.reshape(64, 64, 64).bool()
+    ri, ts, te, packed = O.occ_march(o.numpy(), d.numpy(), binaries.numpy(), aabb, near, far, step, t0.numpy(), max_steps)
+    bits = ops.occ_pack_bits(occ.cuda())
+    gri, gts, gte, gpacked = ops.occ_march(o.cuda(), d.cuda(), t0.cuda(), bits, 64, aabb, far, step, max_steps)
+    assert ri.size > 1000
+    assert np.array_equal(gri.cpu().numpy(), ri)
+    assert np.array_equal(gts.cpu().numpy(), ts) and np.array_equal(gte.cpu().numpy(), te)   # bit-exact floats
+    assert np.array_equal(gpacked.cpu().numpy(), packed)
+
+
+def test_scan_and_empty(ops):
+    g = torch.Generator().manual_seed(6)
+    for n in (1, 5, 1024, 1025, 100000):
+        c = torch.randint(0, 300, (n,), generator=g, dtype=torch.int32)
+        out, total = ops.exclusive_scan_i32(c.cuda())
+        ref = torch.cumsum(c.long(), 0) - c.long()
+        assert torch.equal(out.cpu().long(), ref) and int(total.item()) == int(c.sum())
+    # a batch with no occupied cell returns zero samples (nerf_renderer.py:156-162 guard)
+    occ = torch.zeros(32 ** 3, dtype=torch.uint8)
+    o = torch.zeros(10, 3); d = torch.nn.functional.normalize(torch.randn(10, 3, generator=g), dim=-1)
+    bits = ops.occ_pack_bits(occ.cuda())
+    ri, ts, te, packed = ops.occ_march(o.cuda(), d.cuda(), torch.zeros(10).cuda(), bits, 32, [-1, -1, -1, 1, 1, 1], 1.5, 1e-2, 151)
+    assert ri.numel() == 0 and int(packed[:, 1].sum()) == 0
+
+
+def _packed_case(seed=0, R=300, maxc=200):
+    g = torch.Generator().manual_seed(seed)
+    counts = torch.randint(0, maxc, (R,), generator=g)
+    counts[3] = 0; counts[10] = 64; counts[11] = 65; counts[12] = 1
+    starts = torch.cumsum(counts, 0) - counts
+    packed = torch.stack([starts, counts], -1).to(torch.int32)
+    S = int(counts.sum())
+    ri = torch.repeat_interleave(torch.arange(R), counts)
+    ts = torch.rand(S, generator=g) * 1.5
+    te = ts + 5e-3 * (1 + torch.rand(S, generator=g))
+    sig = torch.exp(torch.randn(S, generator=g) * 2 + 2)
+    rgb = torch.rand(S, 3, generator=g)
+    return packed, ri, ts, te, sig, rgb
+
+
+def test_visibility_and_compaction_bit_exact(ops):
+    packed, ri, ts, te, sig, rgb = _packed_case(1)
+    keep, ex = O.visibility_keep_mask(sig.numpy(), ts.numpy(), te.numpy(), packed.numpy(), 1e-4)
+    nc, gex = ops.visibility_count(sig.cuda(), ts.cuda(), te.cuda(), packed.cuda(), 1e-4, want_exsum=True)
+    assert np.array_equal(gex.cpu().numpy(), ex)            # canonical scan order: bit-exact fp32
+    ref_counts = np.bincount(ri.numpy()[keep], minlength=packed.shape[0])
+    assert np.array_equal(nc.cpu().numpy(), ref_counts)
+    assert 0 < keep.sum() < keep.size
+    gri, gts, gte, gsig, gpacked = ops.compact_prefix(packed.cuda(), nc, ts.cuda(), te.cuda(), sig.cuda())
+    assert np.array_equal(gri.cpu().numpy(), ri.numpy()[keep])
+    assert np.array_equal(gts.cpu().numpy(), ts.numpy()[keep]) and np.array_equal(gsig.cpu().numpy(), sig.numpy()[keep])
+    assert np.array_equal(gpacked.cpu().numpy(), O.packed_info_from_ray_indices(ri.numpy()[keep], packed.shape[0]))
+
+
+def test_composite_fwd_bwd(ops):
+    packed, ri, ts, te, sig, rgb = _packed_case(2)
+    sig = sig * 0.05
+    R = packed.shape[0]
+    sr = sig.clone().requires_grad_(True); cr = rgb.clone().requires_grad_(True)
+    w, T, al = O.render_weight_from_density(ts, te, sr, packed.numpy())
+    op = O.accumulate_along_rays(w, None, ri, R)
+    dist = O.accumulate_along_rays(w, ((ts + te) / 2)[:, None], ri, R)
+    col = O.accumulate_along_rays(w.detach(), cr, ri, R)
+    gw, gT, gal, gop, gdist, gcol = ops.composite_fwd(sig.cuda(), rgb.cuda(), ts.cuda(), te.cuda(), packed.cuda())
+    # fp32, sums of <=200 terms in a different association order: 1e-5 absolute on O(1) quantities
+    for a, b in ((gw, w), (gT, T), (gal, al), (gop, op), (gdist, dist), (gcol, col)):
+        assert (a.cpu() - b.detach()).abs().max() < 1e-5
+    g = torch.Generator().manual_seed(3)
+    g_w = torch.randn(sig.numel(), generator=g); g_op = torch.randn(R, 1, generator=g)
+    g_d = torch.randn(R, 1, generator=g); g_c = torch.randn(R, 3, generator=g)
+    ((w * g_w).sum() + (op * g_op).sum() + (dist * g_d).sum() + (col * g_c).sum()).backward()
+    ds, dr = ops.composite_bwd(sig.cuda(), ts.cuda(), te.cuda(), packed.cuda(), gw, gT, g_w.cuda(), g_op.cuda(), g_d.cuda(),
+                               g_c.cuda(), want_drgb=True)
+    assert (ds.cpu() - sr.grad).abs().max() < 2e-5 * max(1.0, float(sr.grad.abs().max()))
+    assert (dr.cpu() - cr.grad).abs().max() < 1e-5
+
+
+def test_distloss(ops):
+    packed, ri, ts, te, sig, rgb = _packed_case(4)
+    R = packed.shape[0]
+    w = (torch.rand(sig.numel(), generator=torch.Generator().manual_seed(1)) * 0.02).requires_grad_(True)
+    loss = O.flatten_eff_distloss(w, (ts + te) * .5, te - ts, ri)
+    loss.backward()
+    n_rays = int(ri.max()) + 1
+    per_ray = ops.distloss_fwd(w.detach().cuda(), ts.cuda(), te.cuda(), packed.cuda())
+    assert abs(float(per_ray.sum()) / n_rays - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    gw = ops.distloss_bwd(w.detach().cuda(), ts.cuda(), te.cuda(), packed.cuda(), 1.0 / n_rays)
+    assert (gw.cpu() - w.grad).abs().max() < 1e-5 * max(1.0, float(w.grad.abs().max()))
