@@ -113,10 +113,13 @@ int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* 
 int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const float* table,
                           float* feat, int64_t n, void* stream);
 
-/* tcnn kernel_grid_backward: scatter dfeat (fp32, level-major like feat) into grad_table
- * (fp32 [total*2], ACCUMULATED with atomics; caller zeroes). */
+/* tcnn kernel_grid_backward: reduce dfeat (fp32, level-major like feat) into grad_table
+ * (fp32 [total*2]).  Every entry of grad_table is written exactly once: overwritten when
+ * accumulate == 0 (no zero-fill needed), added to when accumulate != 0.  No global atomics. */
+int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid);
 int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
-                      float* grad_table, int64_t n, void* stream);
+                      float* grad_table, int64_t n, int accumulate, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 
 /* tcnn kernel_grid_backward_input: dL/dx01 [n,3] from dfeat and the table (fp32 table). */
 int perf_hashgrid_bwd_input(const perf_grid_desc* grid, const float* x01, const float* dfeat,

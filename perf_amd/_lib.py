@@ -41,7 +41,8 @@ _SIGS = {
     'perf_points_normalize': (c_int, [P, POINTER(c_float), P, P, c_int64, P]),
     'perf_hashgrid_fwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P]),
     'perf_hashgrid_fwd_f32': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
-    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
+    'perf_hashgrid_bwd_workspace_bytes': (c_int64, [POINTER(GridDesc)]),
+    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P, c_int64, P]),
     'perf_hashgrid_bwd_input': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),
     'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, c_int, P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),

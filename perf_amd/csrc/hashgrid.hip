@@ -154,32 +154,142 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_f32_kernel(GridParams gp, co
     }
 }
 
-// Parameter gradient: scatter w_c * dfeat into the fp32 gradient table with hardware fp32
-// atomics (global_atomic_add_f32).  Samples whose incoming gradient is exactly zero (masked by
-// the selector, or pruned) issue no atomics.
-__global__ __launch_bounds__(256) void hashgrid_bwd_kernel(GridParams gp, const float* __restrict__ x01,
-                                                           const float2* __restrict__ dfeat,
-                                                           float* __restrict__ grad, int64_t n) {
-    const int group = blockIdx.x & 7;
-    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+// Parameter gradient.  gfx950 global fp32 atomics retire at a flat ~2e10/s whatever their scope or
+// address distribution (tools/exp/atomics.hip), i.e. ~13 ms for the 2.7e8 corner updates of a
+// 1 M-sample batch -- so the scatter is turned inside out: the fp32 gradient table (26.6 MB for
+// L16/T18) is cut into 128 KiB tiles of 16384 entries and each tile is OWNED by one workgroup that
+// keeps it in LDS (203 tiles <= 256 CUs: the whole table is resident in the chip's aggregate LDS).
+// Every owner streams all samples of its level (coalesced x01 + dfeat reads that the sibling owners
+// share through L2), recomputes the 8 corner indices and applies only those that fall in its tile
+// with LDS atomics; at the end the tile is written back with plain coalesced stores.  No global
+// atomics, no zero-fill pass, every table entry written exactly once.
+constexpr int kTileEntries = 16384;
+constexpr int kBwdThreads = 1024;
+constexpr int kMaxReplicas = 16;
+
+// Load balance: a hashed level has 16 tiles, each receiving 1/16 of the level's 8 corner updates per
+// sample; a coarse dense level has only 1..8 tiles receiving the same total.  Coarse tiles are therefore
+// REPLICATED (R_l = 16 / n_tiles_l copies, each streaming 1/R_l of the samples) so that every workgroup
+// applies ~N/2 corner updates; replicas are summed by a small second kernel.  L16/T18: 255 workgroups.
+struct TileParams {
+    int32_t tiles_of[PERF_MAX_LEVELS];     // tiles per level
+    int32_t replicas_of[PERF_MAX_LEVELS];  // replicas per tile
+    int64_t ws_off[PERF_MAX_LEVELS];       // float2 offset of the level's replica slabs in the workspace
+    int32_t accumulate;
+};
+
+static void plan_tiles(const GridParams& gp, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
+    int nb = 0;
+    int64_t ws = 0;
+    for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
+        tp->tiles_of[l] = 0; tp->replicas_of[l] = 1; tp->ws_off[l] = 0;
+        if (l >= gp.n_levels) continue;
+        const int nt = (int)((gp.size[l] + kTileEntries - 1) / kTileEntries);
+        int r = kMaxReplicas / nt;
+        if (r < 1) r = 1;
+        tp->tiles_of[l] = nt; tp->replicas_of[l] = r;
+        if (r > 1) { tp->ws_off[l] = ws; ws += (int64_t)nt * r * kTileEntries; }
+        nb += nt * r;
+    }
+    *n_blocks = nb; *ws_entries = ws;
+}
+
+__global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp, TileParams tp,
+                                                                   const float* __restrict__ x01,
+                                                                   const float2* __restrict__ dfeat,
+                                                                   float2* __restrict__ grad, float2* __restrict__ ws,
+                                                                   int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats
+    int b = blockIdx.x, l = 0;
+    while (b >= tp.tiles_of[l] * tp.replicas_of[l]) { b -= tp.tiles_of[l] * tp.replicas_of[l]; ++l; }
+    const int R = tp.replicas_of[l];
+    const int t = b / R, rep = b % R;
+    const float scale = gp.scale[l];
+    const uint32_t res = gp.res[l], size = gp.size[l];
+    const bool hashed = gp.hashed[l] != 0;
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int l = level_of(group, pass, gp.n_levels);
-        if (l < 0) continue;
-        const float2 g = dfeat[(int64_t)l * n + i];
+    const uint32_t tile_lo = (uint32_t)t * kTileEntries;
+    const uint32_t tile_n = (size - tile_lo < (uint32_t)kTileEntries) ? size - tile_lo : (uint32_t)kTileEntries;
+    for (int i = threadIdx.x; i < 2 * kTileEntries / 4; i += kBwdThreads)
+        reinterpret_cast<float4*>(lds_tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const float2* g_l = dfeat + (int64_t)l * n;
+    const uint32_t r2 = res * res;
+    for (int64_t base = (int64_t)rep * kBwdThreads; base < n; base += (int64_t)R * kBwdThreads) {
+        const int64_t i = base + threadIdx.x;
+        if (i >= n) continue;
+        const float2 g = g_l[i];
         if (g.x == 0.f && g.y == 0.f) continue;
-        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
-        float w[8];
-        corner_weights(c.f, smooth, w);
-        float* t = grad + 2 * (int64_t)gp.offset[l];
+        const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+        const float px = add_rn(mul_rn(x, scale), 0.5f), py = add_rn(mul_rn(y, scale), 0.5f), pz = add_rn(mul_rn(z, scale), 0.5f);
+        const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+        float fx = px - flx, fy = py - fly, fz = pz - flz;
+        const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+        // per-axis contributions of the two corner choices (index part)
+        uint32_t ax[2], ay[2], az[2];
+        ax[0] = gx; ax[1] = gx + 1u;
+        if (hashed) {
+            ay[0] = gy * kPrimeY; ay[1] = ay[0] + kPrimeY;
+            az[0] = gz * kPrimeZ; az[1] = az[0] + kPrimeZ;
+        } else {
+            ay[0] = gy * res; ay[1] = ay[0] + res;
+            az[0] = gz * r2; az[1] = az[0] + r2;
+        }
+        uint32_t match = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            unsafeAtomicAdd(t + 2 * (int64_t)c.idx[k], w[k] * g.x);
-            unsafeAtomicAdd(t + 2 * (int64_t)c.idx[k] + 1, w[k] * g.y);
+            uint32_t idx;
+            if (hashed) idx = (ax[k & 1] ^ ay[(k >> 1) & 1] ^ az[k >> 2]) & (size - 1u);
+            else { idx = ax[k & 1] + ay[(k >> 1) & 1] + az[k >> 2]; if (idx >= size) idx = idx % size; }
+            match |= ((idx / (uint32_t)kTileEntries) == (uint32_t)t ? 1u : 0u) << k;
         }
+        if (match == 0) continue;
+        if (smooth) {
+            fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz);
+        }
+        while (match) {
+            const int k = __ffs(match) - 1;
+            match &= match - 1u;
+            const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
+            const uint32_t cx = bx ? ax[1] : ax[0], cy = by ? ay[1] : ay[0], cz = bz ? az[1] : az[0];
+            uint32_t idx;
+            if (hashed) idx = (cx ^ cy ^ cz) & (size - 1u);
+            else { idx = cx + cy + cz; if (idx >= size) idx = idx % size; }
+            const float w = ((bx ? fx : 1.0f - fx) * (by ? fy : 1.0f - fy)) * (bz ? fz : 1.0f - fz);
+            const uint32_t a = idx - tile_lo;
+            unsafeAtomicAdd(&lds_tile[2 * a], w * g.x);
+            unsafeAtomicAdd(&lds_tile[2 * a + 1], w * g.y);
+        }
+    }
+    __syncthreads();
+    const float2* src = reinterpret_cast<const float2*>(lds_tile);
+    if (R > 1) {
+        float2* out = ws + tp.ws_off[l] + ((int64_t)t * R + rep) * kTileEntries;
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kTileEntries; i += kBwdThreads) out[i] = src[i];
+    } else {
+        float2* out = grad + gp.offset[l] + tile_lo;
+        if (tp.accumulate) {
+            for (uint32_t i = threadIdx.x; i < tile_n; i += kBwdThreads) { float2 o = out[i]; o.x += src[i].x; o.y += src[i].y; out[i] = o; }
+        } else {
+            for (uint32_t i = threadIdx.x; i < tile_n; i += kBwdThreads) out[i] = src[i];
+        }
+    }
+}
+
+// sum the replica slabs of the replicated (coarse) levels into the gradient table
+__global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp, TileParams tp, const float2* __restrict__ ws,
+                                                                  float2* __restrict__ grad) {
+    const int l = blockIdx.y;
+    const int R = tp.replicas_of[l];
+    if (l >= gp.n_levels || R <= 1) return;
+    const uint32_t size = gp.size[l];
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < size; e += gridDim.x * 256) {
+        const float2* p = ws + tp.ws_off[l] + (int64_t)(e / kTileEntries) * R * kTileEntries + (e % kTileEntries);
+        float sx = 0.f, sy = 0.f;
+        for (int r = 0; r < R; ++r) { const float2 v = p[(int64_t)r * kTileEntries]; sx += v.x; sy += v.y; }
+        float2* o = grad + gp.offset[l] + e;
+        if (tp.accumulate) { float2 c = *o; sx += c.x; sy += c.y; }
+        *o = make_float2(sx, sy);
     }
 }
 
@@ -255,16 +365,43 @@ extern "C" int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x0
     return PERF_OK;
 }
 
+extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid) {
+    GridParams gp;
+    if (fill_params(grid, &gp)) return -1;
+    TileParams tp; int nb; int64_t ws;
+    plan_tiles(gp, &tp, &nb, &ws);
+    return ws * (int64_t)sizeof(float2) + 16;
+}
+
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
-                                 float* grad_table, int64_t n, void* stream) {
+                                 float* grad_table, int64_t n, int accumulate, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
     GridParams gp;
     int rc = fill_params(grid, &gp);
     if (rc) return rc;
-    if (n == 0) return PERF_OK;
-    PERF_REQUIRE(x01 && dfeat && grad_table, "NULL pointer");
-    hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3(grouped_grid(n)), dim3(256), 0, as_stream(stream), gp, x01,
-                       (const float2*)dfeat, grad_table, n);
+    PERF_REQUIRE(grad_table, "NULL pointer");
+    PERF_REQUIRE(n == 0 || (x01 && dfeat), "NULL pointer");
+    TileParams tp;
+    int n_blocks = 0;
+    int64_t ws_entries = 0;
+    plan_tiles(gp, &tp, &n_blocks, &ws_entries);
+    PERF_REQUIRE(ws_entries == 0 || (workspace && workspace_bytes >= ws_entries * (int64_t)sizeof(float2)),
+                 "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(ws_entries * sizeof(float2)));
+    tp.accumulate = accumulate;
+    const int lds_bytes = 2 * kTileEntries * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hashgrid_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    hashgrid_bwd_kernel<<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
+        gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, n);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
+    if (ws_entries > 0) {
+        hashgrid_bwd_reduce_kernel<<<dim3(64, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(gp, tp, (const float2*)workspace,
+                                                                                              (float2*)grad_table);
+        PERF_LAUNCH_CHECK("perf_hashgrid_bwd(reduce)");
+    }
     return PERF_OK;
 }
 

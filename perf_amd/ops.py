@@ -111,13 +111,16 @@ def hashgrid_fwd_f32(grid: GridConfig, x01, table):
 
 
 def hashgrid_bwd(grid: GridConfig, x01, dfeat, grad_table=None):
-    """dfeat [L, n, 2] f32 -> grad_table [total*2] f32 (accumulated into grad_table when given)."""
+    """dfeat [L, n, 2] f32 -> grad_table [total*2] f32 (added into grad_table when given, else fresh)."""
     n = x01.shape[0]
+    accumulate = grad_table is not None
     if grad_table is None:
-        grad_table = torch.zeros(grid.n_params, dtype=torch.float32, device=x01.device)
+        grad_table = torch.empty(grid.n_params, dtype=torch.float32, device=x01.device)
     d = grid.desc()
+    ws_bytes = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=x01.device)
     _lib.call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(grad_table, 'grad')),
-              n, _stream())
+              n, int(accumulate), _p(ws), ws.numel() * 4, _stream())
     return grad_table
 
 

@@ -358,3 +358,20 @@ def test_distloss(ops):
     assert abs(float(per_ray.sum()) / n_rays - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
     gw = ops.distloss_bwd(w.detach().cuda(), ts.cuda(), te.cuda(), packed.cuda(), 1.0 / n_rays)
     assert (gw.cpu() - w.grad).abs().max() < 1e-5 * max(1.0, float(w.grad.abs().max()))
+
+
+def test_hashgrid_bwd_accumulates(ops):
+    cfg = _grid_cfg()
+    g = torch.Generator().manual_seed(11)
+    n = 5000
+    x = torch.rand(n, 3, generator=g).cuda()
+    dfeat = torch.randn(cfg.n_levels, n, 2, generator=g).cuda()
+    g1 = ops.hashgrid_bwd(cfg, x, dfeat)
+    acc = g1.clone()
+    ops.hashgrid_bwd(cfg, x, dfeat, acc)
+    assert (acc - 2 * g1).abs().max() < 1e-4 * float(g1.abs().max())
+    # masked samples (zero incoming gradient) contribute nothing; n == 0 writes an all-zero table
+    z = ops.hashgrid_bwd(cfg, x, torch.zeros_like(dfeat))
+    assert float(z.abs().max()) == 0.0
+    z0 = ops.hashgrid_bwd(cfg, x[:0], dfeat[:, :0])
+    assert z0.numel() == cfg.n_params and float(z0.abs().max()) == 0.0
