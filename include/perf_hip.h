@@ -204,14 +204,22 @@ int perf_composite_fwd(const float* sigmas, const float* rgbs, const float* t_st
                        float* weights, float* trans, float* alphas, float* opacity, float* distance,
                        float* color, void* stream);
 
-/* Backward of the above w.r.t. sigmas (and rgbs when d_rgbs != NULL):
- * inputs g_weights [S] (may be NULL), g_opacity [R], g_distance [R], g_color [R,3] (may be NULL;
- * colour uses detached weights as nerf_renderer.py:183). */
-int perf_composite_bwd(const float* sigmas, const float* rgbs, const float* t_starts,
-                       const float* t_ends, const int32_t* packed_info, int64_t n_rays,
-                       const float* weights, const float* trans,
-                       const float* g_weights, const float* g_opacity, const float* g_distance,
-                       const float* g_color, float* d_sigmas, float* d_rgbs, void* stream);
+/* Backward of the above w.r.t. sigmas (and rgbs when d_rgbs != NULL).  Incoming gradients, all optional
+ * (NULL = zero): per sample g_weights, g_trans, g_alphas [S]; per ray g_opacity [R], g_distance [R],
+ * g_color [R,3] (colour uses detached weights as nerf_renderer.py:183, so it only feeds d_rgbs). */
+int perf_composite_bwd(const float* sigmas, const float* t_starts, const float* t_ends,
+                       const int32_t* packed_info, int64_t n_rays, const float* weights, const float* trans,
+                       const float* g_weights, const float* g_trans, const float* g_alphas,
+                       const float* g_opacity, const float* g_distance, const float* g_color,
+                       float* d_sigmas, float* d_rgbs, void* stream);
+
+/* nerfacc.accumulate_along_rays forward (nerf_renderer.py:173-183): out[r,c] = sum_i w_i * values[i,c]
+ * (values == NULL: n_channels must be 1 and out[r] = sum_i w_i).  One wave per ray, no atomics. */
+int perf_accumulate_fwd(const float* weights, const float* values, const int32_t* packed_info, int64_t n_rays,
+                        int32_t n_channels, float* out, void* stream);
+
+/* nerfacc.pack_info: (start,count) per ray from SORTED int64 ray_indices [n]. */
+int perf_pack_info(const int64_t* ray_indices, int64_t n, int64_t n_rays, int32_t* packed_info, void* stream);
 
 /* flatten_eff_distloss forward (per-ray partial losses [R], caller sums and divides by n_rays)
  * and analytic gradient w.r.t. w (modules/scene/nerf.py:226-230). */

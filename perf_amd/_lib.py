@@ -57,7 +57,9 @@ _SIGS = {
     'perf_visibility_count': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
     'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P]),
     'perf_composite_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
-    'perf_composite_bwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P, P]),
+    'perf_composite_bwd': (c_int, [P, P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P]),
+    'perf_accumulate_fwd': (c_int, [P, P, P, c_int64, c_int32, P, P]),
+    'perf_pack_info': (c_int, [P, c_int64, c_int64, P, P]),
     'perf_distloss_fwd': (c_int, [P, P, P, P, c_int64, P, P]),
     'perf_distloss_bwd': (c_int, [P, P, P, P, c_int64, c_float, P, P]),
     'perf_occ_splat': (c_int, [P, P, P, c_int64, c_int32, P, P]),

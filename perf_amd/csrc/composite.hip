@@ -125,12 +125,14 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     }
 }
 
-// d sigma_i = delta_i * ( G_i * T_i * (1 - alpha_i) - sum_{j>i} G_j w_j ),  G = g_w + g_op + g_dist * t_mid
+// d sigma_i = delta_i * ( (G_i T_i + gA_i) (1 - alpha_i) - sum_{j>i} (G_j w_j + gT_j T_j) ),
+//   G = g_w + g_op + g_dist * t_mid,  gT = g_trans, gA = g_alphas (both optional)
 // d rgb_i   = w_i * g_color[r]     (colour is accumulated with detached weights)
 __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ sig, const float* __restrict__ ts,
                                                             const float* __restrict__ te, const int32_t* __restrict__ packed,
                                                             int64_t n_rays, const float* __restrict__ weights,
                                                             const float* __restrict__ trans, const float* __restrict__ g_w,
+                                                            const float* __restrict__ g_T, const float* __restrict__ g_al,
                                                             const float* __restrict__ g_op, const float* __restrict__ g_dist,
                                                             const float* __restrict__ g_col, float* __restrict__ d_sig,
                                                             float* __restrict__ d_rgb) {
@@ -148,12 +150,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     for (int q = n_chunks - 1; q >= 0; --q) {
         const int i = q * 64 + lane;
         const bool valid = i < cnt;
-        float w = 0.f, T = 0.f, t0 = 0.f, t1 = 0.f, s = 0.f, G = 0.f;
+        float w = 0.f, T = 0.f, t0 = 0.f, t1 = 0.f, s = 0.f, G = 0.f, gT = 0.f, gA = 0.f;
         if (valid) {
             w = weights[start + i]; T = trans[start + i]; t0 = ts[start + i]; t1 = te[start + i]; s = sig[start + i];
             G = gop + gd * ((t0 + t1) * 0.5f) + (g_w ? g_w[start + i] : 0.f);
+            if (g_T) gT = g_T[start + i];
+            if (g_al) gA = g_al[start + i];
         }
-        const float qv = G * w;
+        const float qv = G * w + gT * T;
         // inclusive suffix sum within the chunk
         float suf = qv;
 #pragma unroll
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
         const float later = carry + (suf - qv);
         if (valid) {
             const float delta = t1 - t0;
-            if (d_sig) d_sig[start + i] = delta * (G * T * expf(-s * delta) - later);
+            if (d_sig) d_sig[start + i] = delta * ((G * T + gA) * expf(-s * delta) - later);
             if (d_rgb) { d_rgb[3 * (start + i)] = w * gc0; d_rgb[3 * (start + i) + 1] = w * gc1; d_rgb[3 * (start + i) + 2] = w * gc2; }
         }
         carry += __shfl(suf, 0);
@@ -224,6 +228,36 @@ __global__ __launch_bounds__(256) void distloss_bwd_kernel(const float* __restri
     }
 }
 
+// accumulate_along_rays: out[r, c] = sum_i w_i * v[i, c]  (v == NULL: C = 1, out[r] = sum_i w_i)
+__global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict__ w, const float* __restrict__ v,
+                                                         const int32_t* __restrict__ packed, int64_t n_rays, int C,
+                                                         float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int64_t start = packed[2 * r];
+    const int cnt = packed[2 * r + 1];
+    for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
+        for (int i = lane; i < cnt; i += 64) acc += w[start + i] * (v ? v[(start + i) * C + c] : 1.0f);
+        acc = wave_sum(acc);
+        if (lane == 0) out[r * C + c] = acc;
+    }
+}
+
+// packed_info from sorted ray_indices: start[r] = lower_bound(ray_indices, r)
+__global__ __launch_bounds__(256) void pack_info_kernel(const int64_t* __restrict__ ri, int64_t n, int64_t n_rays,
+                                                        int32_t* __restrict__ packed) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rays) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ri[mid] < r) lo = mid + 1; else hi = mid; }
+    const int64_t first = lo;
+    hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ri[mid] <= r) lo = mid + 1; else hi = mid; }
+    packed[2 * r] = (int32_t)first; packed[2 * r + 1] = (int32_t)(lo - first);
+}
+
 static inline dim3 ray_grid(int64_t n_rays) { return dim3((unsigned)div_up(n_rays, 4)); }
 
 }  // namespace perf
@@ -268,16 +302,16 @@ extern "C" int perf_composite_fwd(const float* sigmas, const float* rgbs, const 
     return PERF_OK;
 }
 
-extern "C" int perf_composite_bwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+extern "C" int perf_composite_bwd(const float* sigmas, const float* t_starts, const float* t_ends,
                                   const int32_t* packed_info, int64_t n_rays, const float* weights, const float* trans,
-                                  const float* g_weights, const float* g_opacity, const float* g_distance,
+                                  const float* g_weights, const float* g_trans, const float* g_alphas,
+                                  const float* g_opacity, const float* g_distance,
                                   const float* g_color, float* d_sigmas, float* d_rgbs, void* stream) {
-    (void)rgbs;
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && weights && trans, "NULL pointer");
     hipLaunchKernelGGL(composite_bwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
-                       packed_info, n_rays, weights, trans, g_weights, g_opacity, g_distance, g_color, d_sigmas, d_rgbs);
+                       packed_info, n_rays, weights, trans, g_weights, g_trans, g_alphas, g_opacity, g_distance, g_color, d_sigmas, d_rgbs);
     PERF_LAUNCH_CHECK("perf_composite_bwd");
     return PERF_OK;
 }
@@ -301,5 +335,26 @@ extern "C" int perf_distloss_bwd(const float* w, const float* t_starts, const fl
     hipLaunchKernelGGL(distloss_bwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), w, t_starts, t_ends,
                        packed_info, n_rays, scale, g_w);
     PERF_LAUNCH_CHECK("perf_distloss_bwd");
+    return PERF_OK;
+}
+
+extern "C" int perf_accumulate_fwd(const float* weights, const float* values, const int32_t* packed_info, int64_t n_rays,
+                                   int32_t n_channels, float* out, void* stream) {
+    PERF_REQUIRE(n_rays >= 0 && n_channels >= 1, "bad arguments");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_info && out, "NULL pointer");
+    hipLaunchKernelGGL(accumulate_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), weights, values, packed_info,
+                       n_rays, (int)n_channels, out);
+    PERF_LAUNCH_CHECK("perf_accumulate_fwd");
+    return PERF_OK;
+}
+
+extern "C" int perf_pack_info(const int64_t* ray_indices, int64_t n, int64_t n_rays, int32_t* packed_info, void* stream) {
+    PERF_REQUIRE(n >= 0 && n_rays >= 0, "bad arguments");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_info && (n == 0 || ray_indices), "NULL pointer");
+    hipLaunchKernelGGL(pack_info_kernel, dim3((unsigned)div_up(n_rays, 256)), dim3(256), 0, as_stream(stream), ray_indices, n,
+                       n_rays, packed_info);
+    PERF_LAUNCH_CHECK("perf_pack_info");
     return PERF_OK;
 }

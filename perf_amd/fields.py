@@ -1,0 +1,149 @@
+"""Host-side mirror of PeRF's modules/fields/ngp_nerf.py on the gfx950 kernels: same class names, method
+names, argument meaning and state_dict keys (`aabb`, `geo_mlp.params`, `app_mlp.params`).
+
+The arithmetic of the two tcnn networks is in perf_amd.tcnn; what this file adds is the reference's glue
+(ngp_nerf.py:136-176): aabb normalisation, the 0<x<1 selector, trunc_exp on the density logit -- fused here
+into the position and MLP-epilogue kernels (PERF_ACT_EXP + selector), so a density query is three launches.
+"""
+from typing import List, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import tcnn
+from .tcnn import _FieldFn
+
+PER_LEVEL_SCALE = 1.4472692012786865
+
+
+def _grid_cfg(n_levels=16, log2_hashmap_size=18, base_resolution=16, per_level_scale=PER_LEVEL_SCALE):
+    return {"otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": 2,
+            "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution,
+            "per_level_scale": per_level_scale}
+
+
+class _TruncExp(torch.autograd.Function):
+    """exp forward, gradient exp(min(x, 15)) (ngp_nerf.py:24-40)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(torch.clamp(x, max=15))
+
+
+trunc_exp = _TruncExp.apply
+
+
+def contract_to_unisphere(x, aabb, eps: float = 1e-6, derivative: bool = False):
+    """ngp_nerf.py:43-65."""
+    aabb_min, aabb_max = torch.split(aabb, 3, dim=-1)
+    x = (x - aabb_min) / (aabb_max - aabb_min)
+    x = x * 2 - 1
+    mag = x.norm(dim=-1, keepdim=True)
+    mask = mag.squeeze(-1) > 1
+    if derivative:
+        dev = (2 * mag - 1) / mag ** 2 + 2 * x ** 2 * (1 / mag ** 3 - (2 * mag - 1) / mag ** 4)
+        dev[~mask] = 1.0
+        return torch.clamp(dev, min=eps)
+    x = x.clone()
+    x[mask] = (2 - 1 / mag[mask]) * (x[mask] / mag[mask])
+    return x / 4 + 0.5
+
+
+class _DensityNet(tcnn.NetworkWithInputEncoding):
+    """geo network whose kernel epilogue applies trunc_exp(y - shift) * selector."""
+
+    def __init__(self, grid_cfg, exp_shift=0.0, seed=tcnn.DEFAULT_SEED, dtype=None):
+        super().__init__(3, 1, grid_cfg, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                                          "n_neurons": 64, "n_hidden_layers": 1}, seed=seed, dtype=dtype)
+        self.mlp.output_activation = 'Exponential'
+        self.mlp.exp_shift = exp_shift
+
+
+class NGPNeRF(nn.Module):
+    """Instant-NGP radiance field (ngp_nerf.py:68-198)."""
+
+    def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = False,
+                 unbounded: bool = False, n_levels: int = 16, dtype=None):
+        super().__init__()
+        if not isinstance(aabb, torch.Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        self.register_buffer("aabb", aabb.float().cuda())
+        self.num_dim = num_dim
+        self.use_viewdirs = use_viewdirs
+        self.unbounded = unbounded
+        self.n_levels = n_levels
+        self.dtype_name = dtype
+        self.geo_mlp = _DensityNet(_grid_cfg(n_levels), dtype=dtype)
+        self.app_mlp = tcnn.NetworkWithInputEncoding(
+            3, 3, _grid_cfg(n_levels),
+            {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "Sigmoid", "n_neurons": 64,
+             "n_hidden_layers": 2}, dtype=dtype)
+
+    # -- point queries (ngp_nerf.py:136-162) ---------------------------------------------------------
+    def query_density(self, x):
+        shape = list(x.shape[:-1])
+        x01, sel = ops.points_normalize(x.reshape(-1, 3).contiguous().float(), self.aabb)
+        return _FieldFn.apply(x01, self.geo_mlp.params, sel, self.geo_mlp).view(shape + [1])
+
+    def query_rgb(self, x):
+        shape = list(x.shape[:-1])
+        x01, sel = ops.points_normalize(x.reshape(-1, 3).contiguous().float(), self.aabb)
+        return _FieldFn.apply(x01, self.app_mlp.params, sel, self.app_mlp).view(shape + [3])
+
+    # -- ray-sample queries: positions o + d (t0+t1)/2 are formed in-kernel (nerf_renderer.py:125-127) --
+    def sample_points(self, rays_o, rays_d, ray_indices, t_starts, t_ends):
+        return ops.points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, self.aabb)
+
+    def density_at(self, x01, sel):
+        return _FieldFn.apply(x01, self.geo_mlp.params, sel, self.geo_mlp)[:, 0]
+
+    def rgb_at(self, x01, sel):
+        return _FieldFn.apply(x01, self.app_mlp.params, sel, self.app_mlp)
+
+    def forward(self, positions, directions=None, contract=None):
+        if self.use_viewdirs and (directions is not None):
+            assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
+        density = self.query_density(positions)
+        rgb = self.query_rgb(positions)
+        return rgb, density
+
+    def reset_geo(self):
+        """Fresh geometry network, identical initialisation every episode (ngp_nerf.py:178-197)."""
+        self.geo_mlp = _DensityNet(_grid_cfg(16), dtype=self.dtype_name)
+
+
+class NGPDensityField(nn.Module):
+    """Proposal density field (ngp_nerf.py:200-265): sigma = trunc_exp(net(x) - 1) * selector."""
+
+    def __init__(self, aabb, num_dim: int = 3, unbounded: bool = False, base_resolution: int = 16,
+                 max_resolution: int = 128, n_levels: int = 5, log2_hashmap_size: int = 17, dtype=None):
+        super().__init__()
+        if not isinstance(aabb, torch.Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        self.register_buffer("aabb", aabb.float().cuda())
+        self.num_dim = num_dim
+        self.unbounded = unbounded
+        self.base_resolution = base_resolution
+        self.max_resolution = max_resolution
+        self.n_levels = n_levels
+        self.log2_hashmap_size = log2_hashmap_size
+        per_level_scale = np.exp((np.log(max_resolution) - np.log(base_resolution)) / (n_levels - 1)).tolist()
+        self.mlp_base = _DensityNet(_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale),
+                                    exp_shift=1.0, dtype=dtype)
+
+    def forward(self, positions: torch.Tensor):
+        shape = list(positions.shape[:-1])
+        if self.unbounded:
+            x01 = contract_to_unisphere(positions, self.aabb).reshape(-1, 3).contiguous().float()
+            sel = ((x01 > 0.0) & (x01 < 1.0)).all(dim=-1).to(torch.uint8)
+        else:
+            x01, sel = ops.points_normalize(positions.reshape(-1, 3).contiguous().float(), self.aabb)
+        return _FieldFn.apply(x01, self.mlp_base.params, sel, self.mlp_base).view(shape + [1])

@@ -1,0 +1,224 @@
+"""The part of nerfacc's surface PeRF uses, on the gfx950 kernels.
+
+PeRF imports (modules/scene/nerf_renderer.py:5-7, modules/scene/nerf.py:24-25):
+    from nerfacc import accumulate_along_rays, render_weight_from_density, render_transmittance_from_alpha
+    from nerfacc.estimators.occ_grid import OccGridEstimator
+    from nerfacc.estimators.prop_net import PropNetEstimator
+Semantics follow nerfacc==0.5.3 as restated in SURVEY.md Appendix A.3/A.4 (parity unpinned: the package is
+not in the reference tree); integer bookkeeping is bit-exact against oracle/perf_oracle.py.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _packed_of(ray_indices, n_rays):
+    """packed_info for sorted ray_indices; sampling() attaches it to the tensor it returns so the usual
+    sampling -> render_weight_from_density -> accumulate_along_rays chain never recomputes it."""
+    cached = getattr(ray_indices, '_perf_packed', None)
+    if cached is not None and cached.shape[0] == n_rays:
+        return cached
+    packed = ops.pack_info(ray_indices.contiguous(), int(n_rays))
+    try:
+        ray_indices._perf_packed = packed
+    except Exception:
+        pass
+    return packed
+
+
+class _WeightsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sigmas, t_starts, t_ends, packed):
+        ctx.set_materialize_grads(False)
+        w, T, al, _, _, _ = ops.composite_fwd(sigmas, None, t_starts, t_ends, packed)
+        ctx.save_for_backward(sigmas, t_starts, t_ends, packed, w, T)
+        return w, T, al
+
+    @staticmethod
+    def backward(ctx, g_w, g_T, g_al):
+        sigmas, ts, te, packed, w, T = ctx.saved_tensors
+        f = lambda g: None if g is None else g.contiguous().float()
+        ds, _ = ops.composite_bwd(sigmas, ts, te, packed, w, T, g_weights=f(g_w), g_trans=f(g_T), g_alphas=f(g_al))
+        return ds, None, None, None
+
+
+def render_weight_from_density(t_starts, t_ends, sigmas, packed_info=None, ray_indices=None, n_rays=None,
+                               prefix_trans=None):
+    """-> (weights, trans, alphas), each [S].  Call site: nerf_renderer.py:170-171."""
+    if prefix_trans is not None:
+        raise NotImplementedError('prefix_trans is not used by PeRF')
+    if t_starts.dim() != 1:
+        raise NotImplementedError('only the packed (flattened) layout PeRF uses is supported')
+    if packed_info is None:
+        if ray_indices is None:
+            raise ValueError('ray_indices or packed_info is required')
+        if n_rays is None:
+            n_rays = int(ray_indices.max().item()) + 1 if ray_indices.numel() else 0
+        packed_info = _packed_of(ray_indices, n_rays)
+    elif packed_info.dtype != torch.int32:
+        packed_info = packed_info.to(torch.int32).contiguous()
+    return _WeightsFn.apply(sigmas.contiguous().float(), t_starts.contiguous(), t_ends.contiguous(), packed_info)
+
+
+class _AccumulateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, values, ray_indices, packed):
+        out = ops.accumulate_fwd(weights, values, packed)
+        ctx.save_for_backward(weights, values if values is not None else torch.empty(0, device=weights.device), ray_indices)
+        ctx.has_values = values is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        weights, values, ray_indices = ctx.saved_tensors
+        g = g_out[ray_indices]                                   # [S, C] gather: elementwise from here on
+        gw = gv = None
+        if ctx.needs_input_grad[0]:
+            gw = (g * values).sum(-1) if ctx.has_values else g[:, 0]
+        if ctx.has_values and ctx.needs_input_grad[1]:
+            gv = g * weights[:, None]
+        return gw, gv, None, None
+
+
+def accumulate_along_rays(weights, values=None, ray_indices=None, n_rays=None):
+    """-> [n_rays, C] (C = 1 when values is None).  Call sites: nerf_renderer.py:173,175,183."""
+    if ray_indices is None:
+        raise NotImplementedError('only the packed layout (ray_indices given) is supported')
+    if n_rays is None:
+        n_rays = int(ray_indices.max().item()) + 1 if ray_indices.numel() else 0
+    packed = _packed_of(ray_indices, n_rays)
+    v = None if values is None else values.contiguous().float()
+    return _AccumulateFn.apply(weights.contiguous().float(), v, ray_indices, packed)
+
+
+def render_transmittance_from_alpha(*args, **kwargs):
+    raise NotImplementedError('imported but never called by PeRF (nerf_renderer.py:5)')
+
+
+class OccGridEstimator(nn.Module):
+    """nerfacc.estimators.occ_grid.OccGridEstimator for levels == 1 (PeRF: nerf.py:68,144)."""
+
+    def __init__(self, roi_aabb, resolution=128, levels=1, **kwargs):
+        super().__init__()
+        if levels != 1:
+            raise NotImplementedError('PeRF uses a single-level occupancy grid')
+        if isinstance(resolution, int):
+            resolution = [resolution] * 3
+        if not (resolution[0] == resolution[1] == resolution[2]):
+            raise NotImplementedError('cubic grids only')
+        if not torch.is_tensor(roi_aabb):
+            roi_aabb = torch.tensor(roi_aabb, dtype=torch.float32)
+        res = int(resolution[0])
+        self.levels = 1
+        self.cells_per_lvl = res ** 3
+        self.register_buffer('resolution', torch.tensor(resolution, dtype=torch.int32))
+        self.register_buffer('aabbs', roi_aabb.detach().float().reshape(1, 6).clone())
+        self.register_buffer('occs', torch.zeros(self.cells_per_lvl, dtype=torch.float32))
+        self.register_buffer('binaries', torch.zeros(1, res, res, res, dtype=torch.bool))
+        self._bits = None
+        self._bits_version = None
+
+    # -- occupancy bit field used by the marching kernel -------------------------------------------
+    def occ_bits(self):
+        key = (self.binaries.data_ptr(), self.binaries._version)
+        if self._bits is None or self._bits_version != key:
+            self._bits = ops.occ_pack_bits(self.binaries)
+            self._bits_version = key
+        return self._bits
+
+    def set_binaries(self, occ_flat):
+        """Install a precomputed occupancy (x-major flat uint8/bool [res^3])."""
+        res = int(self.resolution[0])
+        self.binaries = occ_flat.reshape(1, res, res, res).bool().to(self.binaries.device)
+        self.occs = self.binaries.reshape(-1).float()
+        self._bits = None
+
+    @torch.no_grad()
+    def sampling(self, rays_o, rays_d, sigma_fn=None, alpha_fn=None, near_plane=0.0, far_plane=1e10, t_min=None,
+                 t_max=None, render_step_size=1e-3, early_stop_eps=1e-4, alpha_thre=0.0, stratified=False,
+                 cone_angle=0.0):
+        ri, ts, te, _, _ = self.sampling_ex(rays_o, rays_d, sigma_fn, near_plane, far_plane, render_step_size,
+                                            early_stop_eps, alpha_thre, stratified, cone_angle, alpha_fn, t_min, t_max)
+        return ri, ts, te
+
+    @torch.no_grad()
+    def sampling_ex(self, rays_o, rays_d, sigma_fn=None, near_plane=0.0, far_plane=1e10, render_step_size=1e-3,
+                    early_stop_eps=1e-4, alpha_thre=0.0, stratified=False, cone_angle=0.0, alpha_fn=None,
+                    t_min=None, t_max=None, jitter=None):
+        """sampling() that also returns (packed_info, sigmas of the kept samples or None)."""
+        if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
+            raise NotImplementedError('PeRF samples with cone_angle=0 and a sigma_fn (nerf_renderer.py:145-155)')
+        if alpha_thre != 0.0:
+            raise NotImplementedError('alpha_thre > 0 is not used by PeRF')
+        R = rays_o.shape[0]
+        dev = rays_o.device
+        rays_o = rays_o.contiguous().float(); rays_d = rays_d.contiguous().float()
+        t0 = torch.full((R,), float(near_plane), dtype=torch.float32, device=dev)
+        if stratified:
+            u = torch.rand(R, device=dev) if jitter is None else jitter
+            t0 = t0 + u * render_step_size
+        aabb = self.aabbs[0]
+        diag = float(torch.linalg.norm(aabb[3:] - aabb[:3]))
+        span = min(float(far_plane) - float(near_plane), diag)
+        max_steps = int(math.ceil(span / render_step_size)) + 1
+        res = int(self.resolution[0])
+        ri, ts, te, packed = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane),
+                                           float(render_step_size), max_steps)
+        sig = None
+        if sigma_fn is not None and early_stop_eps > 0 and ri.numel() > 0:
+            ri._perf_packed = packed
+            sig = sigma_fn(ts, te, ri)
+            if sig.dim() > 1:
+                sig = sig.squeeze(-1)
+            sig = sig.float().contiguous()
+            new_counts = ops.visibility_count(sig, ts, te, packed, early_stop_eps)
+            ri, ts, te, sig, packed = ops.compact_prefix(packed, new_counts, ts, te, sig)
+        ri._perf_packed = packed
+        return ri, ts, te, packed, sig
+
+    @torch.no_grad()
+    def update_every_n_steps(self, step, occ_eval_fn, occ_thre=1e-2, ema_decay=0.95, warmup_steps=256, n=16):
+        """Follows nerfacc: while step < warmup_steps every cell is evaluated at (coord + U[0,1))/res mapped to
+        the aabb; occs = max(occs*ema_decay, occ); binaries = occs > min(mean(occs), occ_thre).
+        (PeRF: nerf.py:160-168 -- 256 warm-up calls with an occupancy look-up closure.)"""
+        if not self.training:
+            raise RuntimeError('update_every_n_steps() should only be called in training mode')
+        if step % n != 0:
+            return
+        res = int(self.resolution[0])
+        dev = self.occs.device
+        if step < warmup_steps:
+            idx = torch.arange(self.cells_per_lvl, device=dev)
+        else:
+            k = self.cells_per_lvl // 4
+            uni = torch.randint(self.cells_per_lvl, (k,), device=dev)
+            occ_idx = torch.nonzero(self.binaries.reshape(-1))[:, 0]
+            if occ_idx.numel() > k:
+                occ_idx = occ_idx[torch.randint(occ_idx.numel(), (k,), device=dev)]
+            idx = torch.cat([uni, occ_idx])
+        cz = idx % res; cy = (idx // res) % res; cx = idx // (res * res)
+        coords = torch.stack([cx, cy, cz], -1).float()
+        x = (coords + torch.rand_like(coords)) / res
+        aabb = self.aabbs[0]
+        x = aabb[:3] + x * (aabb[3:] - aabb[:3])
+        occ = occ_eval_fn(x).reshape(-1).float()
+        self.occs[idx] = torch.maximum(self.occs[idx] * ema_decay, occ)
+        thre = torch.clamp(self.occs.mean(), max=occ_thre)
+        self.binaries = (self.occs > thre).reshape(self.binaries.shape)
+        self._bits = None
+
+
+class PropNetEstimator(nn.Module):
+    """Imported by PeRF (nerf.py:24) but only reachable through estimator_type == 'prop', a path that is dead
+    in the reference (NameError at nerf_renderer.py:73).  Constructible so that imports resolve."""
+
+    def __init__(self, optimizer=None, scheduler=None):
+        super().__init__()
+        self.optimizer = optimizer
+        self.scheduler = scheduler
+
+    def sampling(self, *args, **kwargs):
+        raise NotImplementedError('proposal-network sampling: see perf_amd.resample for the hierarchical resampler')

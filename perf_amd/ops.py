@@ -110,18 +110,23 @@ def hashgrid_fwd_f32(grid: GridConfig, x01, table):
     return feat
 
 
-def hashgrid_bwd(grid: GridConfig, x01, dfeat, grad_table=None):
-    """dfeat [L, n, 2] f32 -> grad_table [total*2] f32 (added into grad_table when given, else fresh)."""
+def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False):
+    """dfeat [L, n, 2] f32 -> gradient table [total*2] f32.  `out` (a contiguous fp32 view, e.g. the grid
+    part of a flat gradient) is overwritten, or added to when accumulate=True."""
     n = x01.shape[0]
-    accumulate = grad_table is not None
-    if grad_table is None:
-        grad_table = torch.empty(grid.n_params, dtype=torch.float32, device=x01.device)
+    if out is None:
+        out = torch.empty(grid.n_params, dtype=torch.float32, device=x01.device)
+        accumulate = False
     d = grid.desc()
     ws_bytes = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=x01.device)
-    _lib.call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(grad_table, 'grad')),
-              n, int(accumulate), _p(ws), ws.numel() * 4, _stream())
-    return grad_table
+    _lib.call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),
+              n, int(bool(accumulate)), _p(ws), ws.numel() * 4, _stream())
+    return out
+
+
+def hashgrid_bwd_into(grid, x01, dfeat, out):
+    return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False)
 
 
 def hashgrid_bwd_input(grid: GridConfig, x01, dfeat, table):
@@ -255,15 +260,29 @@ def composite_fwd(sigmas, rgbs, t_starts, t_ends, packed, want_samples=True):
 
 
 def composite_bwd(sigmas, t_starts, t_ends, packed, weights, trans, g_weights=None, g_opacity=None, g_distance=None,
-                  g_color=None, want_dsigma=True, want_drgb=False):
+                  g_color=None, g_trans=None, g_alphas=None, want_dsigma=True, want_drgb=False):
     R = packed.shape[0]
     S = sigmas.numel()
     dev = sigmas.device
     ds = torch.empty(S, dtype=torch.float32, device=dev) if want_dsigma else None
     dr = torch.empty(S, 3, dtype=torch.float32, device=dev) if want_drgb else None
-    _lib.call('perf_composite_bwd', _p(sigmas), None, _p(t_starts), _p(t_ends), _p(packed), R, _p(weights), _p(trans),
-              _p(g_weights), _p(g_opacity), _p(g_distance), _p(g_color), _p(ds), _p(dr), _stream())
+    _lib.call('perf_composite_bwd', _p(sigmas), _p(t_starts), _p(t_ends), _p(packed), R, _p(weights), _p(trans),
+              _p(g_weights), _p(g_trans), _p(g_alphas), _p(g_opacity), _p(g_distance), _p(g_color), _p(ds), _p(dr), _stream())
     return ds, dr
+
+
+def accumulate_fwd(weights, values, packed):
+    R = packed.shape[0]
+    C = 1 if values is None else values.shape[-1]
+    out = torch.empty(R, C, dtype=torch.float32, device=weights.device)
+    _lib.call('perf_accumulate_fwd', _p(_f32(weights, 'weights')), _p(values), _p(packed), R, C, _p(out), _stream())
+    return out
+
+
+def pack_info(ray_indices, n_rays):
+    packed = torch.empty(n_rays, 2, dtype=torch.int32, device=ray_indices.device)
+    _lib.call('perf_pack_info', _p(ray_indices), ray_indices.numel(), n_rays, _p(packed), _stream())
+    return packed
 
 
 def distloss_fwd(w, t_starts, t_ends, packed):

@@ -1,0 +1,108 @@
+"""Host-side mirror of PeRF's NeRFOCCRenderer (modules/scene/nerf_renderer.py:105-209) on the gfx950 kernels.
+
+Same class name, constructor and render() signature, same result dictionary.  Differences are fusions that do
+not change results: sample positions and the selector are produced in-kernel; weights, opacity, distance and
+colour come out of ONE compositing kernel (one wave per ray, no index_add_ atomics); in no-grad density paths
+the sigmas evaluated for the visibility test inside sampling are reused instead of being recomputed
+(the reference evaluates sigma_fn twice, :145-148 and :166-168 -- identical values).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .fields import NGPNeRF
+from .nerfacc_impl import OccGridEstimator
+
+
+class _VolumeRenderFn(torch.autograd.Function):
+    """(sigmas, rgbs) -> (weights, trans, opacity, distance, colour); colour uses detached weights
+    (nerf_renderer.py:183), so d colour / d sigma = 0 and d colour / d rgb_i = w_i."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, t_starts, t_ends, packed):
+        ctx.set_materialize_grads(False)
+        w, T, _, op, dist, col = ops.composite_fwd(sigmas, rgbs, t_starts, t_ends, packed)
+        ctx.save_for_backward(sigmas, t_starts, t_ends, packed, w, T)
+        return w, T, op, dist, col
+
+    @staticmethod
+    def backward(ctx, g_w, g_T, g_op, g_dist, g_col):
+        sigmas, ts, te, packed, w, T = ctx.saved_tensors
+        f = lambda g: None if g is None else g.contiguous().float()
+        want_ds, want_dr = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ds, dr = ops.composite_bwd(sigmas, ts, te, packed, w, T, g_weights=f(g_w), g_trans=f(g_T), g_opacity=f(g_op),
+                                   g_distance=f(g_dist), g_color=f(g_col) if want_dr else None,
+                                   want_dsigma=want_ds, want_drgb=want_dr)
+        return ds, dr, None, None, None
+
+
+volume_render = _VolumeRenderFn.apply
+
+
+class NeRFOCCRenderer(nn.Module):
+    def __init__(self, max_radius, bg_color):
+        super().__init__()
+        self.max_radius = max_radius
+        self.bg_color = bg_color
+        assert self.bg_color in ['rand_noise', 'black', 'white']
+        # sampling constants hard-coded by the reference (nerf_renderer.py:149-154)
+        self.near_plane = 0.
+        self.far_plane = 1.5
+        self.render_step_size = 5e-4
+        self.early_stop_eps = 1e-4
+
+    def render(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, near, far,
+               geo_inference=False, app_inference=False, rand=None):
+        """`rand` (optional dict with 'jitter' [R], 'bg' [R,3], 'noise' [R,1]) injects the random draws of
+        :152,:185,:193 for tests; by default they are drawn with torch.rand on the device in that order."""
+        assert near.shape[-1] == 1 and len(near.shape) == 2
+        n_rays = rays_o.shape[0]
+        dev = rays_o.device
+        rays_o = rays_o.contiguous().float(); rays_d = rays_d.contiguous().float()
+        rand = rand or {}
+        grad_geo = torch.is_grad_enabled() and not geo_inference
+        grad_app = torch.is_grad_enabled() and not app_inference
+
+        def sigma_fn(t_starts, t_ends, ray_indices):
+            x01, sel = nerf.sample_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
+            return nerf.density_at(x01, sel)
+
+        ray_indices, t_starts, t_ends, packed, sig0 = estimator.sampling_ex(
+            rays_o, rays_d, sigma_fn=sigma_fn, near_plane=self.near_plane, far_plane=self.far_plane,
+            render_step_size=self.render_step_size, early_stop_eps=self.early_stop_eps, stratified=nerf.training,
+            cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'))
+        if ray_indices.numel() <= 0:
+            return {'is_valid': False, 'rgb': torch.zeros(n_rays, 3, device=dev), 'distance': torch.zeros(n_rays, 1, device=dev),
+                    'opacities': torch.zeros(n_rays, 1, device=dev)}
+
+        x01, sel = nerf.sample_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
+        if grad_geo:
+            sigmas = nerf.density_at(x01, sel)
+        elif sig0 is not None:
+            sigmas = sig0                                    # same values the reference recomputes under no_grad
+        else:
+            with torch.no_grad():
+                sigmas = nerf.density_at(x01, sel)
+        with torch.set_grad_enabled(grad_app):
+            rgbs = nerf.rgb_at(x01, sel)
+
+        weights, trans, opacities, distances, colors = volume_render(sigmas, rgbs, t_starts, t_ends, packed)
+
+        if self.bg_color == 'rand_noise':
+            bg_color = rand['bg'] if 'bg' in rand else torch.rand(n_rays, 3, device=dev)
+        elif self.bg_color == 'white':
+            bg_color = torch.ones(n_rays, 3, device=dev)
+        else:
+            bg_color = torch.zeros(n_rays, 3, device=dev)
+
+        if nerf.training:
+            noise = rand['noise'] if 'noise' in rand else torch.rand_like(distances)
+            distances = torch.relu(distances + (noise * 2. - 1.) * (1. - opacities))
+            colors = colors + bg_color * (1. - opacities).detach()
+        else:
+            distances = distances + 5. * (1. - opacities).detach()
+            colors = colors + .5 * (1. - opacities).detach()
+
+        return {'is_valid': True, 'rgb': colors, 'distance': distances, 'weights': weights, 'opacities': opacities,
+                'trans': trans, 't_starts': t_starts, 't_ends': t_ends, 'ray_indices': ray_indices,
+                'packed_info': packed}

@@ -1,0 +1,352 @@
+"""Host-side mirror of PeRF's training/rendering scene (modules/scene/nerf.py:28-396) and of the two
+supervision-pool functions on the hot path (modules/dataset/sup_info.py:236-259, 304-330).
+
+Same names and semantics as the reference so that parity tests read like its code:
+NeRFScene.render / render_once / fit / train_one_episode / train_one_step_geo / train_one_step_app / update_lr /
+state_dict / load_state_dict / set_train / set_eval, SupInfoPool.rand_ray_color_data / gen_occ_grid.
+
+Reference quirks that are reproduced on purpose:
+  * the GradScaler(2**7) is only used for .scale(): Adam sees gradients multiplied by 128 (nerf.py:139,252-253);
+  * geo `progress` is iter_i / app_res_iters (nerf.py:178), distortion ratio min(2*progress, 1) (:235);
+  * the occupancy grid is static during an episode; the 256 warm-up calls of :160-168 leave binaries == pre_grid
+    (up to a handful of cells from fp32 jitter), so by default binaries := pre_grid; warmup='reference' replays
+    the 256 calls instead.
+Data parallelism (not in the reference): every rank draws the SAME global index stream and takes
+its slice; the local loss is pre-scaled so the summed gradient equals the 1-GPU gradient; one RCCL all-reduce of
+the active network's flat gradient per step.
+"""
+import math
+from dataclasses import dataclass
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .distloss import flatten_eff_distloss
+from .fields import NGPNeRF
+from .nerfacc_impl import OccGridEstimator
+from .renderer import NeRFOCCRenderer
+
+
+@dataclass
+class Rays:
+    """utils/camera_utils.py:9-21"""
+    o: torch.Tensor
+    d: torch.Tensor
+
+    def __len__(self):
+        return len(self.o)
+
+    def __getitem__(self, idx):
+        return Rays(self.o[idx], self.d[idx])
+
+    def collapse(self):
+        return self.o, self.d
+
+
+def gen_pano_rays(pose, height=512, width=1024, device='cuda'):
+    """utils/camera_utils.py:229-234, generated in one kernel."""
+    o, d = ops.pano_raygen(pose, height, width, device=device)
+    return Rays(o, d)
+
+
+def default_train_conf():
+    """configs/nerf.yaml:24-74"""
+    opt = lambda i, p, a, l: SimpleNamespace(init_lr=i, peak_lr=p, peak_at=a, lr_alpha=l)
+    return SimpleNamespace(
+        raw_phase_iter_geo=3000, raw_phase_iter_app=1500,
+        geo_optimizer=opt(0.0, 1e-2, 0.2, 1e-2), app_optimizer=opt(0.0, 1e-2, 0.2, 1e-2),
+        color_loss_weight=1., depth_loss_weight=1., density_loss_weight=0., distortion_loss_weight=0.1,
+        pixel_loss_batch_size=8192)
+
+
+class SupInfoPool:
+    """Supervision rays of all registered panoramas (sup_info.py:141-259, 304-330): flat device tensors."""
+
+    def __init__(self):
+        self.all_sup_rays = None
+        self.all_sup_colors = None
+        self.all_sup_distances = None
+        self.all_sup_normals = None
+        self.n_panos = 0
+
+    def register_rays(self, rays_o, rays_d, colors, distances, normals=None):
+        o = rays_o.reshape(-1, 3).contiguous().float(); d = rays_d.reshape(-1, 3).contiguous().float()
+        c = colors.reshape(-1, 3).contiguous().float(); t = distances.reshape(-1, 1).contiguous().float()
+        n = torch.zeros_like(c) if normals is None else normals.reshape(-1, 3).contiguous().float()
+        if self.all_sup_rays is None:
+            self.all_sup_rays, self.all_sup_colors, self.all_sup_distances, self.all_sup_normals = Rays(o, d), c, t, n
+        else:
+            self.all_sup_rays = Rays(torch.cat([self.all_sup_rays.o, o]), torch.cat([self.all_sup_rays.d, d]))
+            self.all_sup_colors = torch.cat([self.all_sup_colors, c])
+            self.all_sup_distances = torch.cat([self.all_sup_distances, t])
+            self.all_sup_normals = torch.cat([self.all_sup_normals, n])
+        self.n_panos += 1
+
+    def register_sup_info(self, pose, mask, rgb, distance, normal=None):
+        """Panorama [H,W,*] maps -> supervision rays of the valid pixels (mask & distance > 1e-5)."""
+        h, w, _ = rgb.shape
+        rays = gen_pano_rays(pose, h, w, device=rgb.device)
+        distance = distance.reshape(h, w, 1)
+        valid = (mask.reshape(h, w) > .5) & (distance[..., 0] > 1e-5)
+        idx = torch.where(valid)
+        self.register_rays(rays.o[idx], rays.d[idx], rgb[idx], distance[idx], None if normal is None else normal[idx])
+
+    def __len__(self):
+        return 0 if self.all_sup_colors is None else len(self.all_sup_colors)
+
+    def rand_ray_color_data(self, batch_size, rand_mode='by_all_pixels', generator=None, rank=0, world_size=1):
+        """sup_info.py:236-259.  With world_size > 1 every rank draws the same `batch_size` indices and keeps
+        the contiguous slice [rank*b/W, (rank+1)*b/W) -- the union is the 1-GPU batch."""
+        assert rand_mode == 'by_all_pixels'
+        n = len(self)
+        indices = torch.randint(0, n, (batch_size,), device=self.all_sup_colors.device, generator=generator)
+        if world_size > 1:
+            per = batch_size // world_size
+            indices = indices[rank * per:(rank + 1) * per]
+        return (self.all_sup_rays[indices], self.all_sup_colors[indices], self.all_sup_distances[indices],
+                self.all_sup_normals[indices])
+
+    def gen_occ_grid(self, res):
+        """sup_info.py:304-330 as one splat kernel.  Returns (occ uint8 [res^3], points of occupied cells)."""
+        rays_o, rays_d = self.all_sup_rays.collapse()
+        occ = ops.occ_splat(rays_o, rays_d, self.all_sup_distances, res)
+        valid_idx = torch.where(occ > 0)[0]
+        pts = torch.stack([valid_idx // (res * res), (valid_idx // res) % res, valid_idx % res], -1)
+        return occ, (pts / float(res) - .5) * 2.
+
+
+class FusedAdam:
+    """torch.optim.Adam(params, lr) for ONE flat fp32 parameter, as a single kernel that also refreshes the
+    network's 16-bit working copy and clears the gradient (perf_adam_step)."""
+
+    def __init__(self, net, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.net = net
+        self.param_groups = [{'lr': lr, 'betas': betas, 'eps': eps}]
+        p = net.params
+        self.exp_avg = torch.zeros_like(p.data)
+        self.exp_avg_sq = torch.zeros_like(p.data)
+        self.step_count = 0
+        self.w16 = torch.empty(p.numel(), dtype=ops.torch_dtype(net.dtype_name), device=p.device)
+
+    def zero_grad(self):
+        pass                                       # the step kernel clears the gradient it consumed
+
+    def step(self):
+        p = self.net.params
+        if p.grad is None:
+            return
+        self.step_count += 1
+        g = self.param_groups[0]
+        ops.adam_step(p.data, self.exp_avg, self.exp_avg_sq, p.grad, self.step_count, g['lr'], g['betas'][0],
+                      g['betas'][1], g['eps'], w16=self.w16, zero_grad=False)
+        p.grad = None                              # the next backward installs a fresh gradient (no accumulate pass)
+        self.net.set_working_copy(self.w16)        # the kernel wrote the refreshed 16-bit copy
+
+
+class NeRFScene:
+    def __init__(self, base_exp_dir=None, train_conf=None, estimator_type='occ', renderer_conf=None, dtype=None,
+                 fused_adam=True, writer=None):
+        if estimator_type != 'occ':
+            raise NotImplementedError("estimator_type 'prop' is dead code in the reference (nerf_renderer.py:73)")
+        self.aabb = torch.tensor([-1.0, -1.0, -1.0, 1.0, 1.0, 1.0])
+        self.base_exp_dir = base_exp_dir
+        self.writer = writer
+        self.train_conf = train_conf or default_train_conf()
+        self.nerf = NGPNeRF(aabb=self.aabb, dtype=dtype)
+        self.estimator = OccGridEstimator(roi_aabb=self.aabb, resolution=256, levels=1).cuda()
+        self.renderer = NeRFOCCRenderer(**(renderer_conf or {'max_radius': 2, 'bg_color': 'rand_noise'}))
+        self.fused_adam = fused_adam
+        self.global_iter_step_geo = 0
+        self.global_iter_step_app = 0
+        self.loss_scale = 2.0 ** 7
+        self.last_losses = {}
+
+    # ---- distributed helpers ---------------------------------------------------------------------
+    @staticmethod
+    def _dist():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist, dist.get_rank(), dist.get_world_size()
+        return None, 0, 1
+
+    # ---- rendering (nerf.py:74-123) --------------------------------------------------------------
+    @torch.no_grad()
+    def render(self, rays: Rays, query_keys=('rgb',), batch_size=32768):
+        last_train = self.nerf.training
+        self.set_eval()
+        rays_o, rays_d = rays.collapse()
+        pre_shape = list(rays_o.shape[:-1])
+        rays_o = rays_o.reshape(-1, 3); rays_d = rays_d.reshape(-1, 3)
+        ret = {k: [] for k in query_keys}
+        for ro, rd in zip(rays_o.split(batch_size), rays_d.split(batch_size)):
+            cur = self.render_once(Rays(ro, rd), query_keys)
+            for k in query_keys:
+                ret[k].append(cur[k])
+        for k in query_keys:
+            ret[k] = torch.cat(ret[k], dim=0).reshape(pre_shape + [-1])
+        if last_train:
+            self.set_train()
+        return ret
+
+    def render_once(self, rays: Rays, query_keys=('rgb',), geo_inference=False, app_inference=False, rand=None):
+        rays_o, rays_d = rays.collapse()
+        assert len(rays_o.shape) == 2
+        n = len(rays_o)
+        near = 1e-2 * torch.ones([n, 1], device=rays_o.device)       # to_bounded_rays (nerf.py:313-319); unused by occ
+        far = torch.ones([n, 1], device=rays_o.device)
+        res = self.renderer.render(self.nerf, self.estimator, rays_o, rays_d, near, far,
+                                   geo_inference=geo_inference, app_inference=app_inference, rand=rand)
+        if (res is None) or (not res['is_valid']):
+            return res
+        return {k: res[k] for k in list(query_keys) + ['is_valid']}
+
+    # ---- training (nerf.py:125-311) ----------------------------------------------------------------
+    def fit(self, sup_pool: SupInfoPool, **kw):
+        self.train_one_episode(sup_pool, self.train_conf.raw_phase_iter_geo, self.train_conf.raw_phase_iter_app, **kw)
+
+    def prepare_occupancy(self, sup_pool, warmup='direct'):
+        self.estimator = OccGridEstimator(roi_aabb=self.aabb, resolution=256, levels=1).cuda()
+        self.estimator.train()
+        pre_grid, _ = sup_pool.gen_occ_grid(res=256)
+        if warmup == 'direct':
+            self.estimator.set_binaries(pre_grid)
+        else:
+            occ_res = 256
+
+            def occ_eval_fn(x):
+                x = (x.clip(-0.999, 0.999) * .5 + .5) * occ_res
+                x = x.to(torch.int64)
+                return pre_grid[x[..., 0] * occ_res * occ_res + x[..., 1] * occ_res + x[..., 2]].float()
+
+            for i in range(256):
+                self.estimator.update_every_n_steps(step=i, occ_eval_fn=occ_eval_fn, occ_thre=1e-2, ema_decay=0.1,
+                                                    warmup_steps=256, n=1)
+        return pre_grid
+
+    def make_optimizer(self, net, lr):
+        return FusedAdam(net, lr) if self.fused_adam else torch.optim.Adam(net.parameters(), lr=lr)
+
+    def train_one_episode(self, sup_pool, geo_res_iters, app_res_iters, warmup='direct', callback=None):
+        self.set_train()
+        self.prepare_occupancy(sup_pool, warmup)
+        self.nerf.reset_geo()
+        geo_optimizer = self.make_optimizer(self.nerf.geo_mlp, self.train_conf.geo_optimizer.init_lr)
+        for iter_i in range(geo_res_iters):
+            self.update_lr(geo_optimizer, self.train_conf.geo_optimizer, iter_i / geo_res_iters)
+            self.train_one_step_geo(geo_optimizer, sup_pool, progress=iter_i / app_res_iters)
+            if callback:
+                callback('geo', iter_i)
+        app_optimizer = self.make_optimizer(self.nerf.app_mlp, self.train_conf.app_optimizer.init_lr)
+        for iter_i in range(app_res_iters):
+            self.update_lr(app_optimizer, self.train_conf.app_optimizer, iter_i / app_res_iters)
+            self.train_one_step_app(app_optimizer, sup_pool, progress=iter_i / app_res_iters)
+            if callback:
+                callback('app', iter_i)
+
+    def _batch(self, sup_pool, generator=None):
+        dist, rank, world = self._dist()
+        bs = self.train_conf.pixel_loss_batch_size
+        rays, col, dep, nrm = sup_pool.rand_ray_color_data(bs, generator=generator, rank=rank, world_size=world)
+        return rays, col, dep, bs, (dist, rank, world)
+
+    def _finish_step(self, loss, net, optimizer, dist_info):
+        dist, rank, world = dist_info
+        (loss * self.loss_scale).backward()                   # grad_scaler.scale(loss).backward(), never unscaled
+        if dist is not None:
+            g = net.params.grad
+            if g is None:
+                g = net.params.grad = torch.zeros_like(net.params)
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)           # one RCCL all-reduce of the flat gradient
+        optimizer.step()
+
+    def train_one_step_geo(self, optimizer, sup_pool, progress, rand=None, generator=None):
+        tc = self.train_conf
+        optimizer.zero_grad()
+        rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
+        res = self.render_once(rays, ['rgb', 'distance', 'weights', 't_starts', 't_ends', 'trans', 'ray_indices', 'packed_info'],
+                               app_inference=True, rand=rand)
+        if (res is None) or (not res['is_valid']):
+            if dist_info[0] is not None:                      # keep the collective matched across ranks
+                self._finish_step(self.nerf.geo_mlp.params.sum() * 0.0, self.nerf.geo_mlp, optimizer, dist_info)
+            self.global_iter_step_geo += 1
+            return
+        n_local = len(rays)
+        loss = 0.
+        if tc.depth_loss_weight > 1e-7:
+            # mean over the GLOBAL batch: local sum / global count
+            depth_loss = F.smooth_l1_loss(res['distance'], gt_depths, beta=1e-2, reduction='sum') / bs
+            loss = loss + depth_loss * tc.depth_loss_weight
+            self.last_losses['depth_loss'] = depth_loss.detach()
+        if tc.distortion_loss_weight > 1e-7:
+            mid = (res['t_ends'] + res['t_starts']) * .5
+            sec = res['t_ends'] - res['t_starts']
+            dist_loss = flatten_eff_distloss(res['weights'], mid, sec, res['ray_indices'], packed_info=res['packed_info'])
+            if dist_info[2] > 1:                               # local /n_local -> global /bs
+                dist_loss = dist_loss * ((res['ray_indices'][-1:].float() + 1.0) / bs).squeeze()
+            ratio = float(np.min([progress * 2., 1]))
+            loss = loss + dist_loss * tc.distortion_loss_weight * ratio
+            self.last_losses['dist_loss'] = dist_loss.detach()
+        if tc.density_loss_weight > 1e-7:
+            rand_pts = (torch.rand(8192, 3, device=gt_depths.device) * 2. - 1.) * 0.99
+            density_loss = self.nerf.query_density(rand_pts).mean()
+            loss = loss + density_loss * tc.density_loss_weight
+        self._finish_step(loss, self.nerf.geo_mlp, optimizer, dist_info)
+        self.global_iter_step_geo += 1
+
+    def train_one_step_app(self, optimizer, sup_pool, progress, rand=None, generator=None):
+        tc = self.train_conf
+        optimizer.zero_grad()
+        rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
+        res = self.render_once(rays, ['rgb', 'distance', 'weights', 't_starts', 't_ends', 'trans', 'ray_indices'],
+                               geo_inference=True, rand=rand)
+        if (res is None) or (not res['is_valid']):
+            if dist_info[0] is not None:
+                self._finish_step(self.nerf.app_mlp.params.sum() * 0.0, self.nerf.app_mlp, optimizer, dist_info)
+            self.global_iter_step_app += 1
+            return
+        loss = 0.
+        if tc.color_loss_weight > 1e-7:
+            color_loss = F.smooth_l1_loss(res['rgb'], gt_colors, beta=5e-2, reduction='sum') / (bs * 3)
+            loss = loss + color_loss * tc.color_loss_weight
+            self.last_losses['color_loss'] = color_loss.detach()
+        self._finish_step(loss, self.nerf.app_mlp, optimizer, dist_info)
+        self.global_iter_step_app += 1
+
+    @staticmethod
+    def lr_at(optim_conf, progress):
+        """nerf.py:300-311"""
+        if progress < optim_conf.peak_at:
+            lp = progress / optim_conf.peak_at
+            return optim_conf.peak_lr * lp + optim_conf.init_lr * (1. - lp)
+        lp = (progress - optim_conf.peak_at) / (1. - optim_conf.peak_at)
+        return optim_conf.peak_lr * ((np.cos(lp * np.pi) + 1.) * .5 * (1. - optim_conf.lr_alpha) + optim_conf.lr_alpha)
+
+    def update_lr(self, optimizer, optim_conf, progress):
+        lr = self.lr_at(optim_conf, progress)
+        for p in optimizer.param_groups:
+            p['lr'] = lr
+
+    # ---- state (nerf.py:368-395) --------------------------------------------------------------------
+    def state_dict(self):
+        return {'render': self.renderer.state_dict(), 'nerf': self.nerf.state_dict(),
+                'estimator': self.estimator.state_dict()}
+
+    def load_state_dict(self, state_dict):
+        self.renderer.load_state_dict(state_dict['render'])
+        self.nerf.load_state_dict(state_dict['nerf'])
+        self.estimator.load_state_dict(state_dict['estimator'])
+        self.estimator._bits = None
+
+    def set_train(self):
+        self.nerf.train(); self.estimator.train(); self.renderer.train()
+
+    def set_eval(self):
+        self.nerf.eval(); self.estimator.eval(); self.renderer.eval()
+
+
+def psnr(pred, gt):
+    """-10 log10(mean((pred-gt)^2))  (the reference never computes it)."""
+    return float(-10.0 * torch.log10(torch.mean((pred.float() - gt.float()) ** 2)))

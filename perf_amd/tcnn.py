@@ -1,0 +1,161 @@
+"""tiny-cuda-nn's torch module surface, re-implemented on the gfx950 kernels.
+
+PeRF constructs `tcnn.NetworkWithInputEncoding(n_input_dims, n_output_dims, encoding_config,
+network_config)` (modules/fields/ngp_nerf.py:96-134,179-197,230-245) and
+`tcnn.Encoding(n_input_dims, encoding_config)` (modules/geo_predictors/pano_joint_predictor.py:30-41,
+pano_geo_refiner.py:19).  The contract kept here:
+  * one nn.Parameter named `params`: flat fp32, [network weights | grid table] (tcnn layout: row-major
+    [out,in] matrices, first-layer input width and output rows padded to 16) -- this is the tensor that
+    lands in ckpt.pth through NGPNeRF.state_dict() and is handed to torch.optim.Adam;
+  * forward(x [N, 3] float32 on the GPU, values in [0,1]) -> [N, n_output_dims] in the 16-bit compute
+    dtype (tcnn returns half), differentiable w.r.t. params (and x for Encoding);
+  * the fp32 -> 16-bit weight cast happens inside forward, cached on the parameter's version counter.
+There is no CPU path: a CPU tensor raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .grid import GridConfig, MlpConfig
+
+DEFAULT_DTYPE = 'bf16'     # BASELINE.json config 2 names bf16; 'fp16' reproduces tcnn's own precision
+DEFAULT_SEED = 1337        # tcnn's torch binding seeds its init with 1337
+
+
+def _init_params(mlp: MlpConfig, grid: GridConfig, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    parts = []
+    if mlp is not None:
+        for (o, i) in mlp.shapes:
+            s = math.sqrt(6.0 / (i + o))                 # Xavier uniform
+            parts.append((torch.rand(o * i, generator=g) * 2 - 1) * s)
+    parts.append((torch.rand(grid.n_params, generator=g) * 2 - 1) * 1e-4)
+    return torch.cat(parts)
+
+
+class _FieldFn(torch.autograd.Function):
+    """encode + MLP with the whole backward in two kernels (MLP backward recomputes the forward)."""
+
+    @staticmethod
+    def forward(ctx, x01, params, sel, module):
+        w16 = module.working_copy(params)
+        n_net = module.mlp.n_params
+        feat = ops.hashgrid_fwd(module.grid, x01, w16[n_net:])
+        out = ops.mlp_fwd(module.mlp, w16[:n_net], feat, sel)
+        ctx.module = module
+        ctx.save_for_backward(x01, w16, feat, sel if sel is not None else torch.empty(0, device=x01.device))
+        ctx.has_sel = sel is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x01, w16, feat, sel = ctx.saved_tensors
+        module = ctx.module
+        sel = sel if ctx.has_sel else None
+        n_net = module.mlp.n_params
+        dout = dout.contiguous().float()
+        dfeat, dw = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout, sel)
+        grad = torch.empty(n_net + module.grid.n_params, dtype=torch.float32, device=x01.device)
+        grad[:n_net] = dw
+        ops.hashgrid_bwd_into(module.grid, x01, dfeat, grad[n_net:])
+        return None, grad, None, None
+
+
+class NetworkWithInputEncoding(nn.Module):
+    def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=DEFAULT_SEED, dtype=None):
+        super().__init__()
+        if n_input_dims != 3:
+            raise ValueError('the gfx950 hash grid is built for 3 input dims')
+        otype = network_config.get('otype', 'FullyFusedMLP')
+        if otype not in ('FullyFusedMLP', 'CutlassMLP'):
+            raise ValueError(f'unsupported network otype {otype!r}')
+        if network_config.get('activation', 'ReLU') != 'ReLU':
+            raise ValueError('only ReLU hidden activation is supported')
+        self.n_input_dims = n_input_dims
+        self.n_output_dims = n_output_dims
+        self.encoding_config = dict(encoding_config)
+        self.network_config = dict(network_config)
+        self.seed = seed
+        self.dtype_name = dtype or DEFAULT_DTYPE
+        self.grid = GridConfig.from_tcnn(encoding_config)
+        self.mlp = MlpConfig(n_levels=self.grid.n_levels,
+                             n_hidden_layers=int(network_config.get('n_hidden_layers', 1)),
+                             n_output_dims=n_output_dims,
+                             output_activation=network_config.get('output_activation', 'None'),
+                             n_neurons=int(network_config.get('n_neurons', 64)))
+        self.params = nn.Parameter(_init_params(self.mlp, self.grid, seed).to(_default_device()))
+        self._w16 = None
+        self._w16_key = None
+
+    # -- 16-bit working copy, refreshed when the fp32 master changes -------------------------------
+    def working_copy(self, params=None):
+        p = self.params if params is None else params
+        key = (p.data_ptr(), p._version, self.dtype_name)
+        if self._w16 is None or self._w16_key != key:
+            self._w16 = ops.cast_params(p.detach(), self.dtype_name, self._w16 if (self._w16 is not None and self._w16.dtype == ops.torch_dtype(self.dtype_name) and self._w16.numel() == p.numel()) else None)
+            self._w16_key = key
+        return self._w16
+
+    def set_working_copy(self, w16):
+        """Adopt a working copy written by the fused Adam kernel (perf_adam_step)."""
+        self._w16 = w16
+        self._w16_key = (self.params.data_ptr(), self.params._version, self.dtype_name)
+
+    def forward(self, x, selector=None, out_fp32=False):
+        x = x.reshape(-1, self.n_input_dims).contiguous().float()
+        out = _FieldFn.apply(x, self.params, selector, self)
+        return out if out_fp32 else out.to(ops.torch_dtype(self.dtype_name))
+
+    def extra_repr(self):
+        return f'n_params={self.params.numel()}, grid={self.grid.n_levels}x2 T={self.grid.log2_hashmap_size}, ' \
+               f'mlp={self.mlp.n_hidden_layers}x64->{self.n_output_dims}, dtype={self.dtype_name}'
+
+
+class _EncodingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x01, params, module):
+        feat = ops.hashgrid_fwd_f32(module.grid, x01, params.detach())
+        ctx.module = module
+        ctx.save_for_backward(x01, params)
+        return feat.permute(1, 0, 2).reshape(x01.shape[0], -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x01, params = ctx.saved_tensors
+        module = ctx.module
+        n = x01.shape[0]
+        dfeat = dout.float().reshape(n, module.grid.n_levels, 2).permute(1, 0, 2).contiguous()
+        gx = gp = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.hashgrid_bwd_input(module.grid, x01, dfeat, params.detach())
+        if ctx.needs_input_grad[1]:
+            gp = ops.hashgrid_bwd(module.grid, x01, dfeat)
+        return gx, gp, None
+
+
+class Encoding(nn.Module):
+    """tcnn.Encoding (HashGrid, Linear or Smoothstep interpolation), fp32 table, first-order autograd
+    w.r.t. the table and the input."""
+
+    def __init__(self, n_input_dims, encoding_config, seed=DEFAULT_SEED, dtype=None):
+        super().__init__()
+        if n_input_dims != 3:
+            raise ValueError('the gfx950 hash grid is built for 3 input dims')
+        self.n_input_dims = n_input_dims
+        self.encoding_config = dict(encoding_config)
+        self.grid = GridConfig.from_tcnn(encoding_config)
+        self.n_output_dims = self.grid.n_output_dims
+        self.out_dtype = ops.torch_dtype(dtype or 'fp16')      # tcnn hands back half
+        self.params = nn.Parameter(_init_params(None, self.grid, seed).to(_default_device()))
+
+    def forward(self, x):
+        x = x.reshape(-1, self.n_input_dims).contiguous().float()
+        return _EncodingFn.apply(x, self.params, self).to(self.out_dtype)
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('perf_amd.tcnn needs a HIP device (there is no CPU fallback)')
+    return torch.device('cuda', torch.cuda.current_device())

@@ -340,9 +340,11 @@ def test_composite_fwd_bwd(ops):
     g = torch.Generator().manual_seed(3)
     g_w = torch.randn(sig.numel(), generator=g); g_op = torch.randn(R, 1, generator=g)
     g_d = torch.randn(R, 1, generator=g); g_c = torch.randn(R, 3, generator=g)
-    ((w * g_w).sum() + (op * g_op).sum() + (dist * g_d).sum() + (col * g_c).sum()).backward()
+    ((w * g_w).sum() + (op * g_op).sum() + (dist * g_d).sum() + (col * g_c).sum()).backward(retain_graph=True)
+    g_T = torch.randn(sig.numel(), generator=g); g_a = torch.randn(sig.numel(), generator=g)
+    ((T * g_T).sum() + (al * g_a).sum()).backward()
     ds, dr = ops.composite_bwd(sig.cuda(), ts.cuda(), te.cuda(), packed.cuda(), gw, gT, g_w.cuda(), g_op.cuda(), g_d.cuda(),
-                               g_c.cuda(), want_drgb=True)
+                               g_c.cuda(), g_trans=g_T.cuda(), g_alphas=g_a.cuda(), want_drgb=True)
     assert (ds.cpu() - sr.grad).abs().max() < 2e-5 * max(1.0, float(sr.grad.abs().max()))
     assert (dr.cpu() - cr.grad).abs().max() < 1e-5
 
@@ -368,10 +370,22 @@ def test_hashgrid_bwd_accumulates(ops):
     dfeat = torch.randn(cfg.n_levels, n, 2, generator=g).cuda()
     g1 = ops.hashgrid_bwd(cfg, x, dfeat)
     acc = g1.clone()
-    ops.hashgrid_bwd(cfg, x, dfeat, acc)
+    ops.hashgrid_bwd(cfg, x, dfeat, out=acc, accumulate=True)
     assert (acc - 2 * g1).abs().max() < 1e-4 * float(g1.abs().max())
     # masked samples (zero incoming gradient) contribute nothing; n == 0 writes an all-zero table
     z = ops.hashgrid_bwd(cfg, x, torch.zeros_like(dfeat))
     assert float(z.abs().max()) == 0.0
     z0 = ops.hashgrid_bwd(cfg, x[:0], dfeat[:, :0])
     assert z0.numel() == cfg.n_params and float(z0.abs().max()) == 0.0
+
+
+def test_accumulate_and_pack_info(ops):
+    packed, ri, ts, te, sig, rgb = _packed_case(6)
+    R = packed.shape[0]
+    w = torch.rand(sig.numel(), generator=torch.Generator().manual_seed(2))
+    assert torch.equal(ops.pack_info(ri.cuda(), R).cpu(), packed)
+    assert torch.equal(ops.pack_info(ri[:0].cuda(), R).cpu()[:, 1], torch.zeros(R, dtype=torch.int32))
+    for vals in (None, rgb):
+        ref = O.accumulate_along_rays(w, vals, ri, R)
+        got = ops.accumulate_fwd(w.cuda(), None if vals is None else vals.cuda(), packed.cuda())
+        assert (got.cpu() - ref).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))

@@ -1,0 +1,223 @@
+"""GPU parity of the host-side mirror (fields / renderer / training steps) against the CPU oracle, and the
+drop-in shim packages.  Fields are compared with the oracle's 16-bit emulation (quant=...), which rounds the
+same operands the kernels round."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import perf_oracle as O  # noqa: E402
+
+AABB = [-1., -1, -1, 1, 1, 1]
+
+
+def _params(gain=1e4):
+    gs, as_ = O.geo_spec(), O.app_spec()
+    geo = O.init_field_params(gs, 1337); app = O.init_field_params(as_, 4242)
+    geo[gs.n_net:] *= gain; app[as_.n_net:] *= gain
+    return geo, app
+
+
+def _nerf(dtype, geo, app):
+    from perf_amd.fields import NGPNeRF
+    nerf = NGPNeRF(aabb=AABB, dtype=dtype)
+    with torch.no_grad():
+        nerf.geo_mlp.params.copy_(geo.cuda()); nerf.app_mlp.params.copy_(app.cuda())
+    return nerf
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_field_queries(dtype):
+    geo, app = _params()
+    nerf = _nerf(dtype, geo, app)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2000, 3, generator=g) * 2.2 - 1.1            # some points outside the aabb (selector = 0)
+    aabb = torch.tensor(AABB)
+    sig = nerf.query_density(x.cuda()).cpu()
+    rgb = nerf.query_rgb(x.cuda()).cpu()
+    rs = O.query_density(x, geo, O.geo_spec(), aabb, quant=dtype)
+    rr = O.query_rgb(x, app, O.app_spec(), aabb, quant=dtype)
+    ulp = 2.0 ** -8 if dtype == 'bf16' else 2.0 ** -11
+    # sigma = exp(logit): relative error = absolute logit error (a few 16-bit ulps of |logit| <~ 8)
+    assert ((sig - rs).abs() <= 0.25 * (64 * ulp) * rs.abs() + 1e-6).all()
+    assert (rgb - rr).abs().max() < 32 * ulp
+    assert float(sig[(x.abs() > 1).any(-1)].abs().max()) == 0.0
+    # state_dict keys are what PeRF checkpoints hold (nerf.py:374-380)
+    assert set(nerf.state_dict().keys()) == {'aabb', 'geo_mlp.params', 'app_mlp.params'}
+    assert nerf.geo_mlp.params.numel() == 6644288 and nerf.app_mlp.params.numel() == 6648384
+
+
+def _glue_setup(golden_dir):
+    g = np.load(f'{golden_dir}/render_glue.npz')
+    res = int(g['res'])
+    occ = np.unpackbits(g['binaries'])[:res ** 3].reshape(res, res, res).astype(bool)
+    return g, res, occ
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_renderer_matches_oracle(golden_dir, mode):
+    """NeRFOCCRenderer mirror on HIP == oracle.occ_render (itself pinned on the reference's renderer glue)."""
+    from perf_amd.nerfacc_impl import OccGridEstimator
+    from perf_amd.renderer import NeRFOCCRenderer
+    dtype = 'fp16'
+    g, res, occ = _glue_setup(golden_dir)
+    geo, app = _params(float(g['grid_gain']))
+    nerf = _nerf(dtype, geo, app)
+    nerf.train(mode == 'train')
+    est = OccGridEstimator(AABB, resolution=res).cuda()
+    est.set_binaries(torch.from_numpy(occ.reshape(-1)).cuda())
+    rend = NeRFOCCRenderer(max_radius=2, bg_color='rand_noise')
+    rend.render_step_size = float(g['step'])
+    o = torch.from_numpy(g['o']); d = torch.from_numpy(g['d'])
+    R = o.shape[0]
+    rand = {'jitter': torch.from_numpy(g[f'{mode}_jitter']).cuda(), 'bg': torch.from_numpy(g[f'{mode}_bg']).cuda(),
+            'noise': torch.from_numpy(g[f'{mode}_noise']).cuda()}
+    out = rend.render(nerf, est, o.cuda(), d.cuda(), torch.zeros(R, 1).cuda(), torch.ones(R, 1).cuda(),
+                      geo_inference=False, app_inference=True, rand=rand)
+    t0 = (np.zeros(R, np.float32) + g[f'{mode}_jitter'] * np.float32(float(g['step']))).astype(np.float32) if mode == 'train' else None
+    ref = O.occ_render(o, d, geo, app, occ, AABB, training=(mode == 'train'), t0=t0, bg_color=torch.from_numpy(g[f'{mode}_bg']),
+                       dist_noise=torch.from_numpy(g[f'{mode}_noise']), step=float(g['step']), quant=dtype)
+    # ray bookkeeping: identical unless a sample sits within rounding of the early-stop threshold
+    gri, rri = out['ray_indices'].cpu().numpy(), ref['ray_indices'].numpy()
+    assert abs(len(gri) - len(rri)) <= 2
+    if len(gri) == len(rri):
+        assert np.array_equal(gri, rri)
+        assert np.array_equal(out['t_starts'].cpu().numpy(), ref['t_starts'].numpy())
+        assert (out['weights'].cpu() - ref['weights'].detach()).abs().max() < 5e-3
+    for k in ('rgb', 'distance', 'opacities'):
+        assert (out[k].detach().cpu() - ref[k].detach()).abs().max() < 5e-3, k      # fp16 fields: ~1e-3 on O(1) outputs
+
+
+def test_geo_step_gradient_matches_oracle(golden_dir):
+    """One geometry training step: d loss / d geo params from the HIP path vs autograd through the oracle."""
+    from perf_amd.nerfacc_impl import OccGridEstimator
+    from perf_amd.renderer import NeRFOCCRenderer
+    from perf_amd.distloss import flatten_eff_distloss
+    dtype = 'fp16'
+    g, res, occ = _glue_setup(golden_dir)
+    geo, app = _params(float(g['grid_gain']))
+    nerf = _nerf(dtype, geo, app)
+    nerf.train()
+    est = OccGridEstimator(AABB, resolution=res).cuda()
+    est.set_binaries(torch.from_numpy(occ.reshape(-1)).cuda())
+    rend = NeRFOCCRenderer(max_radius=2, bg_color='rand_noise')
+    rend.render_step_size = float(g['step'])
+    o = torch.from_numpy(g['o']); d = torch.from_numpy(g['d'])
+    R = o.shape[0]
+    gt_dist, _ = O.synthetic_room(d)
+    rand = {k2: torch.from_numpy(g[f'train_{k}']).cuda() for k2, k in (('jitter', 'jitter'), ('bg', 'bg'), ('noise', 'noise'))}
+    out = rend.render(nerf, est, o.cuda(), d.cuda(), torch.zeros(R, 1).cuda(), torch.ones(R, 1).cuda(), app_inference=True, rand=rand)
+    dl = torch.nn.functional.smooth_l1_loss(out['distance'], gt_dist.cuda(), beta=1e-2, reduction='mean')
+    distl = flatten_eff_distloss(out['weights'], (out['t_ends'] + out['t_starts']) * .5, out['t_ends'] - out['t_starts'],
+                                 out['ray_indices'], packed_info=out['packed_info'])
+    ((dl + distl * 0.1 * 0.5) * 128.0).backward()
+    grad = nerf.geo_mlp.params.grad.cpu()
+    assert nerf.app_mlp.params.grad is None
+    geo_r = geo.clone().requires_grad_(True)
+    t0 = (np.zeros(R, np.float32) + g['train_jitter'] * np.float32(float(g['step']))).astype(np.float32)
+    ref = O.occ_render(o, d, geo_r, app, occ, AABB, training=True, t0=t0, bg_color=torch.from_numpy(g['train_bg']),
+                       dist_noise=torch.from_numpy(g['train_noise']), step=float(g['step']), quant=dtype)
+    loss, rdl, rdistl = O.geo_step_loss(ref, gt_dist, progress=0.25)
+    loss.backward()
+    assert abs(float(dl) - float(rdl)) < 2e-3 * max(1.0, abs(float(rdl)))
+    assert abs(float(distl) - float(rdistl)) < 2e-2 * max(1e-3, abs(float(rdistl)))
+    rg = geo_r.grad
+    n_net = O.geo_spec().n_net
+    # 16-bit gradient operands: compare in relative L2 over the network and over the touched grid entries
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-12))
+    assert rel(grad[:n_net], rg[:n_net]) < 3e-2, rel(grad[:n_net], rg[:n_net])
+    assert rel(grad[n_net:], rg[n_net:]) < 3e-2, rel(grad[n_net:], rg[n_net:])
+
+
+def test_shims_resolve_and_run():
+    import perf_amd
+    perf_amd.install_shims()
+    import tinycudann as tcnn
+    from nerfacc import accumulate_along_rays, render_weight_from_density
+    from nerfacc.estimators.occ_grid import OccGridEstimator
+    from torch_efficient_distloss import flatten_eff_distloss
+    net = tcnn.NetworkWithInputEncoding(
+        n_input_dims=3, n_output_dims=1,
+        encoding_config={"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 18,
+                         "base_resolution": 16, "per_level_scale": 1.4472692012786865},
+        network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+                        "n_hidden_layers": 1})
+    assert [n for n, _ in net.named_parameters()] == ['params'] and net.params.dtype == torch.float32
+    x = torch.rand(1000, 3, device='cuda')
+    y = net(x)
+    assert y.shape == (1000, 1) and y.dtype in (torch.bfloat16, torch.float16)
+    y.float().sum().backward()
+    assert net.params.grad is not None and net.params.grad.shape == net.params.shape
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)      # PeRF hands .parameters() to Adam (nerf.py:171)
+    opt.step()
+    y2 = net(x)
+    assert not torch.equal(y, y2)                          # the cached 16-bit copy was refreshed after the update
+    enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19,
+                            "base_resolution": 16, "per_level_scale": 1.38, "interpolation": "Smoothstep"})
+    xe = torch.rand(500, 3, device='cuda', requires_grad=True)
+    f = enc(xe)
+    assert f.shape == (500, 32)
+    f.float().sum().backward()
+    assert xe.grad is not None and enc.params.grad is not None
+    est = OccGridEstimator(roi_aabb=torch.tensor(AABB), resolution=32, levels=1).cuda()
+    assert set(est.state_dict().keys()) == {'resolution', 'aabbs', 'occs', 'binaries'}
+    est.eval()
+    with pytest.raises(RuntimeError):
+        est.update_every_n_steps(step=0, occ_eval_fn=lambda x: x[:, 0])
+    est.train()
+    est.update_every_n_steps(step=0, occ_eval_fn=lambda x: (x.norm(dim=-1) < 0.8).float(), occ_thre=1e-2, ema_decay=0.1,
+                             warmup_steps=256, n=1)
+    o = torch.zeros(64, 3, device='cuda'); d = torch.nn.functional.normalize(torch.randn(64, 3, device='cuda'), dim=-1)
+    ri, ts, te = est.sampling(o, d, sigma_fn=lambda a, b, c: torch.ones_like(a) * 3.0, near_plane=0., far_plane=1.5,
+                              render_step_size=5e-3, stratified=True, cone_angle=0., alpha_thre=0.)
+    assert ri.dtype == torch.int64 and ri.numel() > 0 and bool((ri[1:] >= ri[:-1]).all())
+    sig = torch.full_like(ts, 2.0, requires_grad=True)
+    w, T, a = render_weight_from_density(ts, te, sig, ray_indices=ri, n_rays=64)
+    op = accumulate_along_rays(w, values=None, ray_indices=ri, n_rays=64)
+    col = accumulate_along_rays(w.detach(), values=torch.rand(ri.numel(), 3, device='cuda'), ray_indices=ri, n_rays=64)
+    assert op.shape == (64, 1) and col.shape == (64, 3)
+    loss = op.sum() + flatten_eff_distloss(w, (ts + te) * .5, te - ts, ri)
+    loss.backward()
+    assert sig.grad is not None and torch.isfinite(sig.grad).all()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_short_training_improves_psnr(dtype):
+    """Equal-iteration training on the synthetic room: loss goes down and eval PSNR goes up."""
+    from perf_amd import synthetic
+    from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays, psnr
+    torch.manual_seed(0)
+    scene = NeRFScene(dtype=dtype)
+    rays = gen_pano_rays(torch.eye(4), 128, 256)
+    dist, rgb = synthetic.room(rays.d)
+    pool = SupInfoPool()
+    pool.register_rays(rays.o, rays.d, rgb, dist)
+    p0 = None
+    tc = scene.train_conf
+    tc.pixel_loss_batch_size = 2048
+    scene.set_train()
+    scene.prepare_occupancy(pool)
+    scene.nerf.reset_geo()
+    opt_g = scene.make_optimizer(scene.nerf.geo_mlp, 0.0)
+    n_geo, n_app = 150, 100
+    for i in range(n_geo):
+        scene.update_lr(opt_g, tc.geo_optimizer, i / n_geo)
+        scene.train_one_step_geo(opt_g, pool, progress=i / n_app)
+        if i == 5:
+            d0 = float(scene.last_losses['depth_loss'])
+    d1 = float(scene.last_losses['depth_loss'])
+    assert d1 < 0.5 * d0, (d0, d1)
+    out0 = scene.render(rays, ['rgb', 'distance'])
+    p0 = psnr(out0['rgb'], rgb)
+    opt_a = scene.make_optimizer(scene.nerf.app_mlp, 0.0)
+    for i in range(n_app):
+        scene.update_lr(opt_a, tc.app_optimizer, i / n_app)
+        scene.train_one_step_app(opt_a, pool, progress=i / n_app)
+    out1 = scene.render(rays, ['rgb', 'distance'])
+    p1 = psnr(out1['rgb'], rgb)
+    derr = float((out1['distance'] - dist).abs().mean())
+    assert p1 > p0 + 3.0 and p1 > 15.0, (p0, p1)
+    assert derr < 0.05, derr
+    print(f'[{dtype}] PSNR {p0:.2f} -> {p1:.2f} dB, mean |distance err| {derr:.4f}')
