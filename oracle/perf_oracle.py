@@ -154,28 +154,31 @@ def grid_corner_indices(x: np.ndarray, lv: GridLevels, level: int):
 def hashgrid_encode(x: torch.Tensor, table: torch.Tensor, lv: GridLevels,
                     interpolation: str = 'Linear', quant=None) -> torch.Tensor:
     """x [N,3] in grid coordinates, table [total, F] fp32 -> features [N, L*F] fp32.
-    Differentiable w.r.t. table and x (autograd supplies first and second order)."""
+    Differentiable w.r.t. table and x (autograd supplies first and second order).  All levels share one
+    gather (one index_put in backward)."""
     N = x.shape[0]
     tq = _quant(table, quant)
-    outs = []
     xn = x.detach().cpu().numpy().astype(F32)
+    idx_all, w_all = [], []
     for l in range(lv.n_levels):
         idx_np, _ = grid_corner_indices(xn, lv, l)
-        idx = torch.from_numpy(idx_np.astype(np.int64)) + int(lv.offset[l])
+        idx_all.append(torch.from_numpy(idx_np.astype(np.int64)) + int(lv.offset[l]))
         s = float(lv.scale[l])
         pos = x * s + 0.5
         f = pos - torch.floor(pos).detach()
         if interpolation == 'Smoothstep':
             f = f * f * (3.0 - 2.0 * f)
-        acc = torch.zeros(N, lv.n_feat, dtype=torch.float32)
+        ws = []
         for c in range(8):
             wx = f[:, 0] if (c & 1) else 1.0 - f[:, 0]
             wy = f[:, 1] if (c & 2) else 1.0 - f[:, 1]
             wz = f[:, 2] if (c & 4) else 1.0 - f[:, 2]
-            w = (wx * wy) * wz
-            acc = acc + w[:, None] * tq[idx[:, c]]
-        outs.append(acc)
-    return torch.cat(outs, -1)
+            ws.append((wx * wy) * wz)
+        w_all.append(torch.stack(ws, -1))
+    idx = torch.stack(idx_all, 1)                       # [N, L, 8]
+    w = torch.stack(w_all, 1)                           # [N, L, 8]
+    vals = tq[idx.reshape(-1)].view(N, lv.n_levels, 8, lv.n_feat)
+    return (w[..., None] * vals).sum(2).reshape(N, lv.n_levels * lv.n_feat)
 
 
 def mlp_shapes(n_in: int, n_hidden_layers: int, width: int = 64, n_out_padded: int = 16):
@@ -494,7 +497,7 @@ def flatten_eff_distloss(w, m, interval, ray_id):
 # --------------------------------------------------------------------------------------
 def occ_render(o, d, geo_params, app_params, binaries, aabb, training, t0=None,
                bg_color=None, dist_noise=None, near=0.0, far=1.5, step=5e-4,
-               early_stop_eps=1e-4, quant=None, geo_grad=True, app_grad=False):
+               early_stop_eps=1e-4, quant=None, geo_grad=True, app_grad=False, max_steps=None):
     """NeRFOCCRenderer.render restated on the oracle's operators.  o,d torch [R,3].
     bg_color [R,3] and dist_noise [R,1] are the torch.rand draws of :185,:193 (caller
     supplies them so both sides see the same numbers)."""
@@ -502,7 +505,7 @@ def occ_render(o, d, geo_params, app_params, binaries, aabb, training, t0=None,
     aabb_t = torch.as_tensor(aabb, dtype=torch.float32)
     R = o.shape[0]
     ri, ts, te, packed = occ_march(o.detach().numpy(), d.detach().numpy(), binaries, np.asarray(aabb, F32),
-                                   near, far, step, t0)
+                                   near, far, step, t0, max_steps)
     def positions(ri_t, ts_t, te_t):
         return o[ri_t] + d[ri_t] * ((ts_t + te_t)[:, None] / 2.0)
     ri_t = torch.from_numpy(ri); ts_t = torch.from_numpy(ts); te_t = torch.from_numpy(te)

@@ -188,10 +188,22 @@ static void plan_tiles(const GridParams& gp, TileParams* tp, int* n_blocks, int6
         int r = kMaxReplicas / nt;
         if (r < 1) r = 1;
         tp->tiles_of[l] = nt; tp->replicas_of[l] = r;
-        if (r > 1) { tp->ws_off[l] = ws; ws += (int64_t)nt * r * kTileEntries; }
+        if (r > 1) { tp->ws_off[l] = ws; ws += (int64_t)r * gp.size[l]; }
         nb += nt * r;
     }
     *n_blocks = nb; *ws_entries = ws;
+}
+
+// Tile ownership.  Hashed levels: tile = idx / 16384 (the hash already spreads cells uniformly).  Dense levels:
+// ownership is INTERLEAVED in chunks of 32 entries (chunk c = idx/32 belongs to tile c % n_tiles, local slot
+// (c / n_tiles)*32 + idx%32) -- contiguous slabs would be spatial slabs, and samples concentrate near the
+// camera / the surfaces, which overloads a few owners.
+constexpr uint32_t kChunk = 32;
+
+__device__ __forceinline__ bool dense_owner(uint32_t idx, uint32_t n_tiles, uint32_t t, uint32_t* local) {
+    const uint32_t c = idx / kChunk;
+    *local = (c / n_tiles) * kChunk + (idx % kChunk);
+    return (c % n_tiles) == t;
 }
 
 __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp, TileParams tp,
@@ -203,80 +215,96 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     int b = blockIdx.x, l = 0;
     while (b >= tp.tiles_of[l] * tp.replicas_of[l]) { b -= tp.tiles_of[l] * tp.replicas_of[l]; ++l; }
     const int R = tp.replicas_of[l];
-    const int t = b / R, rep = b % R;
+    const uint32_t n_tiles = (uint32_t)tp.tiles_of[l];
+    const uint32_t t = (uint32_t)(b / R);
+    const int rep = b % R;
     const float scale = gp.scale[l];
     const uint32_t res = gp.res[l], size = gp.size[l];
     const bool hashed = gp.hashed[l] != 0;
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
-    const uint32_t tile_lo = (uint32_t)t * kTileEntries;
-    const uint32_t tile_n = (size - tile_lo < (uint32_t)kTileEntries) ? size - tile_lo : (uint32_t)kTileEntries;
     for (int i = threadIdx.x; i < 2 * kTileEntries / 4; i += kBwdThreads)
         reinterpret_cast<float4*>(lds_tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     const float2* g_l = dfeat + (int64_t)l * n;
     const uint32_t r2 = res * res;
-    for (int64_t base = (int64_t)rep * kBwdThreads; base < n; base += (int64_t)R * kBwdThreads) {
-        const int64_t i = base + threadIdx.x;
-        if (i >= n) continue;
-        const float2 g = g_l[i];
-        if (g.x == 0.f && g.y == 0.f) continue;
-        const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+    const int64_t stride = (int64_t)R * kBwdThreads;
+    // software pipeline: the next sample's gradient and position are in flight while this one is applied
+    int64_t i = (int64_t)rep * kBwdThreads + threadIdx.x;
+    float2 g_nx = make_float2(0.f, 0.f);
+    float x_nx = 0.f, y_nx = 0.f, z_nx = 0.f;
+    if (i < n) { g_nx = g_l[i]; x_nx = x01[3 * i]; y_nx = x01[3 * i + 1]; z_nx = x01[3 * i + 2]; }
+    for (int64_t base = (int64_t)rep * kBwdThreads; base < n; base += stride) {
+        const float2 g = g_nx;
+        const float x = x_nx, y = y_nx, z = z_nx;
+        const bool live = (i < n) && !(g.x == 0.f && g.y == 0.f);
+        i += stride;
+        g_nx = make_float2(0.f, 0.f);
+        if (i < n) { g_nx = g_l[i]; x_nx = x01[3 * i]; y_nx = x01[3 * i + 1]; z_nx = x01[3 * i + 2]; }
+        if (!live) continue;
         const float px = add_rn(mul_rn(x, scale), 0.5f), py = add_rn(mul_rn(y, scale), 0.5f), pz = add_rn(mul_rn(z, scale), 0.5f);
         const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
         float fx = px - flx, fy = py - fly, fz = pz - flz;
         const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
-        // per-axis contributions of the two corner choices (index part)
-        uint32_t ax[2], ay[2], az[2];
-        ax[0] = gx; ax[1] = gx + 1u;
-        if (hashed) {
-            ay[0] = gy * kPrimeY; ay[1] = ay[0] + kPrimeY;
-            az[0] = gz * kPrimeZ; az[1] = az[0] + kPrimeZ;
-        } else {
-            ay[0] = gy * res; ay[1] = ay[0] + res;
-            az[0] = gz * r2; az[1] = az[0] + r2;
-        }
-        uint32_t match = 0;
+        uint32_t ay[2], az[2];
+        if (hashed) { ay[0] = gy * kPrimeY; ay[1] = ay[0] + kPrimeY; az[0] = gz * kPrimeZ; az[1] = az[0] + kPrimeZ; }
+        else { ay[0] = gy * res; ay[1] = ay[0] + res; az[0] = gz * r2; az[1] = az[0] + r2; }
+        const uint32_t m = size - 1u;
+        uint32_t match = 0;     // bit k: corner k (bit0 = x, bit1 = y, bit2 = z) is owned by this tile
+        if (hashed && gx < (uint32_t)(kTileEntries - 1)) {
+            // the tile of a hashed corner depends on (y,z) only while gx+1 < 2^14: test x-pairs
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uint32_t idx;
-            if (hashed) idx = (ax[k & 1] ^ ay[(k >> 1) & 1] ^ az[k >> 2]) & (size - 1u);
-            else { idx = ax[k & 1] + ay[(k >> 1) & 1] + az[k >> 2]; if (idx >= size) idx = idx % size; }
-            match |= ((idx / (uint32_t)kTileEntries) == (uint32_t)t ? 1u : 0u) << k;
+            for (int c = 0; c < 4; ++c)
+                match |= (((((ay[c & 1] ^ az[c >> 1]) & m) / (uint32_t)kTileEntries) == t) ? 3u : 0u) << (2 * c);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t idx, local;
+                bool own;
+                if (hashed) { idx = ((gx + (uint32_t)(k & 1)) ^ ay[(k >> 1) & 1] ^ az[k >> 2]) & m; own = (idx / (uint32_t)kTileEntries) == t; }
+                else {
+                    idx = (gx + (uint32_t)(k & 1)) + ay[(k >> 1) & 1] + az[k >> 2];
+                    if (idx >= size) idx = idx % size;
+                    own = dense_owner(idx, n_tiles, t, &local);
+                }
+                match |= (own ? 1u : 0u) << k;
+            }
         }
         if (match == 0) continue;
-        if (smooth) {
-            fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz);
-        }
+        if (smooth) { fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz); }
         while (match) {
             const int k = __ffs(match) - 1;
             match &= match - 1u;
             const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
-            const uint32_t cx = bx ? ax[1] : ax[0], cy = by ? ay[1] : ay[0], cz = bz ? az[1] : az[0];
-            uint32_t idx;
-            if (hashed) idx = (cx ^ cy ^ cz) & (size - 1u);
-            else { idx = cx + cy + cz; if (idx >= size) idx = idx % size; }
+            const uint32_t cy = by ? ay[1] : ay[0], cz = bz ? az[1] : az[0];
+            uint32_t a;
+            if (hashed) a = (((gx + (uint32_t)bx) ^ cy ^ cz) & m) - t * (uint32_t)kTileEntries;
+            else {
+                uint32_t idx = (gx + (uint32_t)bx) + cy + cz;
+                if (idx >= size) idx = idx % size;
+                dense_owner(idx, n_tiles, t, &a);
+            }
             const float w = ((bx ? fx : 1.0f - fx) * (by ? fy : 1.0f - fy)) * (bz ? fz : 1.0f - fz);
-            const uint32_t a = idx - tile_lo;
             unsafeAtomicAdd(&lds_tile[2 * a], w * g.x);
             unsafeAtomicAdd(&lds_tile[2 * a + 1], w * g.y);
         }
     }
     __syncthreads();
+    // ---- write back: local slot j of tile t is entry e(j)
     const float2* src = reinterpret_cast<const float2*>(lds_tile);
-    if (R > 1) {
-        float2* out = ws + tp.ws_off[l] + ((int64_t)t * R + rep) * kTileEntries;
-        for (uint32_t i = threadIdx.x; i < (uint32_t)kTileEntries; i += kBwdThreads) out[i] = src[i];
-    } else {
-        float2* out = grad + gp.offset[l] + tile_lo;
-        if (tp.accumulate) {
-            for (uint32_t i = threadIdx.x; i < tile_n; i += kBwdThreads) { float2 o = out[i]; o.x += src[i].x; o.y += src[i].y; out[i] = o; }
-        } else {
-            for (uint32_t i = threadIdx.x; i < tile_n; i += kBwdThreads) out[i] = src[i];
-        }
+    float2* out = (R > 1) ? ws + tp.ws_off[l] + (int64_t)rep * size : grad + gp.offset[l];
+    const bool acc = (R == 1) && tp.accumulate;
+    for (uint32_t j = threadIdx.x; j < (uint32_t)kTileEntries; j += kBwdThreads) {
+        uint32_t e;
+        if (hashed) e = t * (uint32_t)kTileEntries + j;
+        else e = ((j / kChunk) * n_tiles + t) * kChunk + (j % kChunk);
+        if (e >= size) continue;
+        float2 v = src[j];
+        if (acc) { const float2 o = out[e]; v.x += o.x; v.y += o.y; }
+        out[e] = v;
     }
 }
 
-// sum the replica slabs of the replicated (coarse) levels into the gradient table
+// sum the replica slabs (ws[level][replica][entry]) of the replicated (coarse) levels into the gradient table
 __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp, TileParams tp, const float2* __restrict__ ws,
                                                                   float2* __restrict__ grad) {
     const int l = blockIdx.y;
@@ -284,9 +312,9 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp,
     if (l >= gp.n_levels || R <= 1) return;
     const uint32_t size = gp.size[l];
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < size; e += gridDim.x * 256) {
-        const float2* p = ws + tp.ws_off[l] + (int64_t)(e / kTileEntries) * R * kTileEntries + (e % kTileEntries);
+        const float2* p = ws + tp.ws_off[l] + e;
         float sx = 0.f, sy = 0.f;
-        for (int r = 0; r < R; ++r) { const float2 v = p[(int64_t)r * kTileEntries]; sx += v.x; sy += v.y; }
+        for (int r = 0; r < R; ++r) { const float2 v = p[(int64_t)r * size]; sx += v.x; sy += v.y; }
         float2* o = grad + gp.offset[l] + e;
         if (tp.accumulate) { float2 c = *o; sx += c.x; sy += c.y; }
         *o = make_float2(sx, sy);

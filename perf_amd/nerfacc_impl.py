@@ -147,8 +147,9 @@ class OccGridEstimator(nn.Module):
     @torch.no_grad()
     def sampling_ex(self, rays_o, rays_d, sigma_fn=None, near_plane=0.0, far_plane=1e10, render_step_size=1e-3,
                     early_stop_eps=1e-4, alpha_thre=0.0, stratified=False, cone_angle=0.0, alpha_fn=None,
-                    t_min=None, t_max=None, jitter=None):
-        """sampling() that also returns (packed_info, sigmas of the kept samples or None)."""
+                    t_min=None, t_max=None, jitter=None, max_steps=None):
+        """sampling() that also returns (packed_info, sigmas of the kept samples or None).
+        max_steps caps the number of lattice intervals per ray (fixed-count benchmark mode)."""
         if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
             raise NotImplementedError('PeRF samples with cone_angle=0 and a sigma_fn (nerf_renderer.py:145-155)')
         if alpha_thre != 0.0:
@@ -163,7 +164,8 @@ class OccGridEstimator(nn.Module):
         aabb = self.aabbs[0]
         diag = float(torch.linalg.norm(aabb[3:] - aabb[:3]))
         span = min(float(far_plane) - float(near_plane), diag)
-        max_steps = int(math.ceil(span / render_step_size)) + 1
+        if max_steps is None:
+            max_steps = int(math.ceil(span / render_step_size)) + 1
         res = int(self.resolution[0])
         ri, ts, te, packed = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane),
                                            float(render_step_size), max_steps)

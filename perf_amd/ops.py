@@ -18,6 +18,34 @@ _CODE = {torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_FP16, 'bf16': DTYPE_BF
          DTYPE_BF16: DTYPE_BF16, DTYPE_FP16: DTYPE_FP16}
 
 
+# ---- optional per-kernel timing with HIP events on the launch stream (used by bench.py) ------------------
+_PROF = None
+
+
+def start_kernel_timing():
+    """Record a HIP event pair around every C-ABI launch until stop_kernel_timing()."""
+    global _PROF
+    _PROF = {}
+
+
+def stop_kernel_timing():
+    """-> {entry point: (n_launches, mean milliseconds)}; synchronises the device."""
+    global _PROF
+    prof, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in (prof or {}).items() if v}
+
+
+def _call(name, *args):
+    if _PROF is None:
+        return _lib.call(name, *args)
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    _lib.call(name, *args)
+    b.record()
+    _PROF.setdefault(name, []).append((a, b))
+
+
 def dtype_code(d) -> int:
     return _CODE[d]
 
@@ -59,13 +87,13 @@ def cast_params(src: torch.Tensor, dtype, out: torch.Tensor = None) -> torch.Ten
     code = dtype_code(dtype)
     if out is None:
         out = torch.empty(src.numel(), dtype=_T16[code], device=src.device)
-    _lib.call('perf_cast_params', _p(src), _p(out), src.numel(), code, _stream())
+    _call('perf_cast_params', _p(src), _p(out), src.numel(), code, _stream())
     return out
 
 
 def adam_step(p, m, v, g, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, w16=None, zero_grad=True):
     code = dtype_code(w16.dtype) if w16 is not None else 0
-    _lib.call('perf_adam_step', _p(_f32(p, 'p')), _p(_f32(m, 'm')), _p(_f32(v, 'v')), _p(_f32(g, 'g')), _p(w16),
+    _call('perf_adam_step', _p(_f32(p, 'p')), _p(_f32(m, 'm')), _p(_f32(v, 'v')), _p(_f32(g, 'g')), _p(w16),
               p.numel(), code, int(step), float(lr), float(beta1), float(beta2), float(eps), int(bool(zero_grad)),
               _stream())
 
@@ -77,7 +105,7 @@ def points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, aabb):
         raise _lib.PerfError('ray_indices must be int64')
     x01 = torch.empty(n, 3, dtype=torch.float32, device=rays_o.device)
     sel = torch.empty(n, dtype=torch.uint8, device=rays_o.device)
-    _lib.call('perf_points_from_rays', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(ray_indices),
+    _call('perf_points_from_rays', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(ray_indices),
               _p(_f32(t_starts, 't_starts')), _p(_f32(t_ends, 't_ends')), _aabb6(aabb), _p(x01), _p(sel), n, _stream())
     return x01, sel
 
@@ -87,7 +115,7 @@ def points_normalize(x, aabb):
     n = x.shape[0]
     x01 = torch.empty(n, 3, dtype=torch.float32, device=x.device)
     sel = torch.empty(n, dtype=torch.uint8, device=x.device)
-    _lib.call('perf_points_normalize', _p(x), _aabb6(aabb), _p(x01), _p(sel), n, _stream())
+    _call('perf_points_normalize', _p(x), _aabb6(aabb), _p(x01), _p(sel), n, _stream())
     return x01, sel
 
 
@@ -97,7 +125,7 @@ def hashgrid_fwd(grid: GridConfig, x01, table16):
     n = x01.shape[0]
     feat = torch.empty(grid.n_levels, n, 2, dtype=table16.dtype, device=x01.device)
     d = grid.desc()
-    _lib.call('perf_hashgrid_fwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(table16), _p(feat), n,
+    _call('perf_hashgrid_fwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(table16), _p(feat), n,
               dtype_code(table16.dtype), _stream())
     return feat
 
@@ -106,7 +134,7 @@ def hashgrid_fwd_f32(grid: GridConfig, x01, table):
     n = x01.shape[0]
     feat = torch.empty(grid.n_levels, n, 2, dtype=torch.float32, device=x01.device)
     d = grid.desc()
-    _lib.call('perf_hashgrid_fwd_f32', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(table, 'table')), _p(feat), n, _stream())
+    _call('perf_hashgrid_fwd_f32', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(table, 'table')), _p(feat), n, _stream())
     return feat
 
 
@@ -120,7 +148,7 @@ def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False):
     d = grid.desc()
     ws_bytes = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=x01.device)
-    _lib.call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),
+    _call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),
               n, int(bool(accumulate)), _p(ws), ws.numel() * 4, _stream())
     return out
 
@@ -133,7 +161,7 @@ def hashgrid_bwd_input(grid: GridConfig, x01, dfeat, table):
     n = x01.shape[0]
     dx = torch.empty(n, 3, dtype=torch.float32, device=x01.device)
     d = grid.desc()
-    _lib.call('perf_hashgrid_bwd_input', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')),
+    _call('perf_hashgrid_bwd_input', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')),
               _p(_f32(table, 'table')), _p(dx), n, _stream())
     return dx
 
@@ -143,7 +171,7 @@ def mlp_fwd(mlp: MlpConfig, w16, feat16, sel=None):
     n = feat16.shape[1]
     out = torch.empty(n, mlp.n_output_dims, dtype=torch.float32, device=feat16.device)
     d = mlp.desc()
-    _lib.call('perf_mlp_fwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(out), n, dtype_code(w16.dtype), _stream())
+    _call('perf_mlp_fwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(out), n, dtype_code(w16.dtype), _stream())
     return out
 
 
@@ -156,7 +184,7 @@ def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True):
     ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=feat16.device)
     dfeat = torch.empty(mlp.n_levels, n, 2, dtype=torch.float32, device=feat16.device) if need_dfeat else None
     dw = torch.empty(mlp.n_params, dtype=torch.float32, device=feat16.device)
-    _lib.call('perf_mlp_bwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(_f32(dout, 'dout')), _p(dfeat), _p(dw),
+    _call('perf_mlp_bwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(_f32(dout, 'dout')), _p(dfeat), _p(dw),
               _p(ws), ws.numel() * 4, n, dtype_code(w16.dtype), _stream())
     return dfeat, dw
 
@@ -167,7 +195,7 @@ def pano_raygen(pose, height, width, row0=0, nrows=None, device='cuda'):
     pose_h = (ctypes.c_float * 16)(*[float(v) for v in torch.as_tensor(pose).detach().cpu().reshape(-1).tolist()])
     o = torch.empty(nrows, width, 3, dtype=torch.float32, device=device)
     d = torch.empty(nrows, width, 3, dtype=torch.float32, device=device)
-    _lib.call('perf_pano_raygen', pose_h, height, width, row0, nrows, _p(o), _p(d), _stream())
+    _call('perf_pano_raygen', pose_h, height, width, row0, nrows, _p(o), _p(d), _stream())
     return o, d
 
 
@@ -178,7 +206,7 @@ def occ_pack_bits(binaries: torch.Tensor) -> torch.Tensor:
         b = b.view(torch.uint8)
     n = b.numel()
     bits = torch.empty((n + 31) // 32, dtype=torch.int32, device=b.device)
-    _lib.call('perf_occ_pack_bits', _p(b), _p(bits), n, _stream())
+    _call('perf_occ_pack_bits', _p(b), _p(bits), n, _stream())
     return bits
 
 
@@ -188,7 +216,7 @@ def exclusive_scan_i32(counts: torch.Tensor):
     out = torch.empty_like(counts)
     total = torch.empty(1, dtype=torch.int64, device=counts.device)
     ws = torch.empty(lib.perf_scan_workspace_bytes(n) // 8 + 1, dtype=torch.int64, device=counts.device)
-    _lib.call('perf_exclusive_scan_i32', _p(counts), _p(out), _p(total), n, _p(ws), ws.numel() * 8, _stream())
+    _call('perf_exclusive_scan_i32', _p(counts), _p(out), _p(total), n, _p(ws), ws.numel() * 8, _stream())
     return out, total
 
 
@@ -203,7 +231,7 @@ def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_step
     masks = torch.empty(max(R * mw, 1), dtype=torch.int64, device=dev)
     counts = torch.empty(R, dtype=torch.int32, device=dev)
     a6 = _aabb6(aabb)
-    _lib.call('perf_occ_march_count', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(t0, 't0')), R,
+    _call('perf_occ_march_count', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(t0, 't0')), R,
               _p(occ_bits), int(res), a6, float(far_plane), float(step), int(max_steps), _p(masks), _p(counts), _stream())
     offsets, total = exclusive_scan_i32(counts)
     S = int(total.item()) if capacity is None else int(capacity)
@@ -211,7 +239,7 @@ def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_step
     ts = torch.empty(S, dtype=torch.float32, device=dev)
     te = torch.empty(S, dtype=torch.float32, device=dev)
     packed = torch.empty(R, 2, dtype=torch.int32, device=dev)
-    _lib.call('perf_occ_march_write', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
+    _call('perf_occ_march_write', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
               _p(ri), _p(ts), _p(te), _p(packed), _stream())
     if capacity is None:
         return ri, ts, te, packed
@@ -224,7 +252,7 @@ def visibility_count(sigmas, t_starts, t_ends, packed, early_stop_eps=1e-4, want
     thr = float(-math.log(early_stop_eps)) if early_stop_eps > 0 else float('inf')
     new_counts = torch.empty(R, dtype=torch.int32, device=packed.device)
     ex = torch.empty_like(sigmas) if want_exsum else None
-    _lib.call('perf_visibility_count', _p(_f32(sigmas, 'sigmas')), _p(t_starts), _p(t_ends), _p(packed), R, thr,
+    _call('perf_visibility_count', _p(_f32(sigmas, 'sigmas')), _p(t_starts), _p(t_ends), _p(packed), R, thr,
               _p(new_counts), _p(ex), _stream())
     return (new_counts, ex) if want_exsum else new_counts
 
@@ -239,7 +267,7 @@ def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=N
     te = torch.empty(S, dtype=torch.float32, device=dev)
     sg = torch.empty(S, dtype=torch.float32, device=dev) if sigmas is not None else None
     packed_out = torch.empty(R, 2, dtype=torch.int32, device=dev)
-    _lib.call('perf_compact_prefix', _p(packed), _p(new_counts), _p(new_offsets), R, _p(t_starts), _p(t_ends), _p(sigmas),
+    _call('perf_compact_prefix', _p(packed), _p(new_counts), _p(new_offsets), R, _p(t_starts), _p(t_ends), _p(sigmas),
               _p(ri), _p(ts), _p(te), _p(sg), _p(packed_out), _stream())
     return ri, ts, te, sg, packed_out
 
@@ -254,7 +282,7 @@ def composite_fwd(sigmas, rgbs, t_starts, t_ends, packed, want_samples=True):
     al = f(S) if want_samples else None
     op, dist = f(R, 1), f(R, 1)
     col = f(R, 3) if rgbs is not None else None
-    _lib.call('perf_composite_fwd', _p(_f32(sigmas, 'sigmas')), _p(rgbs), _p(t_starts), _p(t_ends), _p(packed), R, _p(w),
+    _call('perf_composite_fwd', _p(_f32(sigmas, 'sigmas')), _p(rgbs), _p(t_starts), _p(t_ends), _p(packed), R, _p(w),
               _p(T), _p(al), _p(op), _p(dist), _p(col), _stream())
     return w, T, al, op, dist, col
 
@@ -266,7 +294,7 @@ def composite_bwd(sigmas, t_starts, t_ends, packed, weights, trans, g_weights=No
     dev = sigmas.device
     ds = torch.empty(S, dtype=torch.float32, device=dev) if want_dsigma else None
     dr = torch.empty(S, 3, dtype=torch.float32, device=dev) if want_drgb else None
-    _lib.call('perf_composite_bwd', _p(sigmas), _p(t_starts), _p(t_ends), _p(packed), R, _p(weights), _p(trans),
+    _call('perf_composite_bwd', _p(sigmas), _p(t_starts), _p(t_ends), _p(packed), R, _p(weights), _p(trans),
               _p(g_weights), _p(g_trans), _p(g_alphas), _p(g_opacity), _p(g_distance), _p(g_color), _p(ds), _p(dr), _stream())
     return ds, dr
 
@@ -275,33 +303,33 @@ def accumulate_fwd(weights, values, packed):
     R = packed.shape[0]
     C = 1 if values is None else values.shape[-1]
     out = torch.empty(R, C, dtype=torch.float32, device=weights.device)
-    _lib.call('perf_accumulate_fwd', _p(_f32(weights, 'weights')), _p(values), _p(packed), R, C, _p(out), _stream())
+    _call('perf_accumulate_fwd', _p(_f32(weights, 'weights')), _p(values), _p(packed), R, C, _p(out), _stream())
     return out
 
 
 def pack_info(ray_indices, n_rays):
     packed = torch.empty(n_rays, 2, dtype=torch.int32, device=ray_indices.device)
-    _lib.call('perf_pack_info', _p(ray_indices), ray_indices.numel(), n_rays, _p(packed), _stream())
+    _call('perf_pack_info', _p(ray_indices), ray_indices.numel(), n_rays, _p(packed), _stream())
     return packed
 
 
 def distloss_fwd(w, t_starts, t_ends, packed):
     R = packed.shape[0]
     loss = torch.empty(R, dtype=torch.float32, device=w.device)
-    _lib.call('perf_distloss_fwd', _p(_f32(w, 'w')), _p(t_starts), _p(t_ends), _p(packed), R, _p(loss), _stream())
+    _call('perf_distloss_fwd', _p(_f32(w, 'w')), _p(t_starts), _p(t_ends), _p(packed), R, _p(loss), _stream())
     return loss
 
 
 def distloss_bwd(w, t_starts, t_ends, packed, scale):
     R = packed.shape[0]
     g = torch.empty_like(w)
-    _lib.call('perf_distloss_bwd', _p(_f32(w, 'w')), _p(t_starts), _p(t_ends), _p(packed), R, float(scale), _p(g), _stream())
+    _call('perf_distloss_bwd', _p(_f32(w, 'w')), _p(t_starts), _p(t_ends), _p(packed), R, float(scale), _p(g), _stream())
     return g
 
 
 def occ_splat(rays_o, rays_d, dist, res):
     n = rays_o.shape[0]
     occ = torch.zeros(res ** 3, dtype=torch.uint8, device=rays_o.device)
-    _lib.call('perf_occ_splat', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(dist.reshape(-1), 'dist')), n,
+    _call('perf_occ_splat', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(dist.reshape(-1), 'dist')), n,
               int(res), _p(occ), _stream())
     return occ
