@@ -378,8 +378,42 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpParams mp, const uint16
             for (int m = 0; m < 2; ++m) gW1[m] = T16::mfma(lds_get_frag(tA, 32 * m + c, s, h), b, gW1[m]);
         }
     }
-    // ---- per-wave partial weight gradients -> global (reduced by mlp_reduce_kernel)
-    float* p = partials + ((int64_t)blockIdx.x * 4 + wave) * L::n_params;
+    // ---- block reduction of the four waves' accumulators through LDS (lane-linear slots, conflict free),
+    //      then ONE partial per block -> global (summed by mlp_reduce_kernel)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int kAcc = 2 + 2 + (NH == 2 ? 4 : 0);          // f32x16 accumulators per lane
+    for (int src = 1; src < 4; ++src) {
+        if (wave == src) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { red[((m) * 16 + r) * 64 + lane] = gW1[m][r]; red[((2 + m) * 16 + r) * 64 + lane] = gWo[m][r]; }
+            if constexpr (NH == 2) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((4 + m) * 16 + r) * 64 + lane] = gW2[m][r];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { gW1[m][r] += red[((m) * 16 + r) * 64 + lane]; gWo[m][r] += red[((2 + m) * 16 + r) * 64 + lane]; }
+            if constexpr (NH == 2) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gW2[m][r] += red[((4 + m) * 16 + r) * 64 + lane];
+            }
+        }
+        __syncthreads();
+    }
+    static_assert(kAcc * 16 * 64 * 4 <= Layout<NH, KS>::n_all * 1024 + 4 * 2 * 64 * kPitch * 2, "reduction scratch exceeds LDS");
+    if (wave != 0) return;
+    float* p = partials + (int64_t)blockIdx.x * L::n_params;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -405,13 +439,18 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpParams mp, const uint16
         }
 }
 
+// dw[i] = sum_k partials[k][i]: 64 parameters x 4 partial-segments per block, combined through LDS
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
                                                          int n_params, int n_partials) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_params) return;
+    __shared__ float acc[4][64];
+    const int pi = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int seg = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < n_partials; ++k) s += partials[(int64_t)k * n_params + i];
-    dw[i] = s;
+    if (pi < n_params)
+        for (int k = seg; k < n_partials; k += 4) s += partials[(int64_t)k * n_params + pi];
+    acc[seg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (seg == 0 && pi < n_params) dw[pi] = acc[0][threadIdx.x] + acc[1][threadIdx.x] + acc[2][threadIdx.x] + acc[3][threadIdx.x];
 }
 
 static inline int mlp_blocks(int64_t n, int per_cu) {
@@ -504,7 +543,7 @@ extern "C" int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_
     int nh, ks;
     if (check_mlp(mlp, &nh, &ks)) return -1;
     const int blocks = mlp_blocks(n > 0 ? n : 1, kBwdBlocksPerCU);
-    return (int64_t)blocks * 4 * n_params_rt(nh, ks) * (int64_t)sizeof(float);
+    return (int64_t)blocks * n_params_rt(nh, ks) * (int64_t)sizeof(float);
 }
 
 extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
@@ -533,8 +572,8 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
         dispatch_bwd<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,
                            (float2*)dfeat, (float*)workspace, n);
     PERF_LAUNCH_CHECK("perf_mlp_bwd");
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)div_up(np, 256)), dim3(256), 0, as_stream(stream),
-                       (const float*)workspace, dw, np, blocks * 4);
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)div_up(np, 64)), dim3(256), 0, as_stream(stream),
+                       (const float*)workspace, dw, np, blocks);
     PERF_LAUNCH_CHECK("perf_mlp_bwd(reduce)");
     return PERF_OK;
 }
