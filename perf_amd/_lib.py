@@ -73,6 +73,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: it carries its own libamdhip64, and the HIP runtime that owns the device
+    # context has to be the one this library's kernels register with (one runtime per process).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise PerfError(f'{LIB_PATH} not found: build it with `python -m perf_amd.build` '
                         '(there is no CPU fallback for the HIP path)')
