@@ -50,6 +50,7 @@ def parse():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='run the timed steps eagerly instead of replaying a hipGraph')
     ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample')
     return ap.parse_args()
 
@@ -122,23 +123,42 @@ def main():
     r.far_plane = 10.0
     r.early_stop_eps = 0.0
     r.max_steps = args.spp
+    r.sample_capacity = args.rays_per_gpu * args.spp if args.mode != 'render' else None
     scene.nerf.reset_geo()
     gen = torch.Generator(device=dev); gen.manual_seed(1234)          # same index stream on every rank
 
+    use_graph = (world == 1) and (not args.no_graph) and args.mode != 'render'
+    graphed = None
     if args.mode == 'train_geo':
         opt = scene.make_optimizer(scene.nerf.geo_mlp, 0.0)
         conf = tc.geo_optimizer
 
-        def step(i):
+        def eager_step(i):
             scene.update_lr(opt, conf, min(i / 3000.0, 0.999))
-            scene.train_one_step_geo(opt, pool, progress=0.25, generator=gen)
+            scene.train_one_step_geo(opt, pool, progress=0.25, generator=None if world == 1 else gen)
+        if use_graph:
+            graphed = scene.make_graphed_step('geo', opt, pool)
+
+        def step(i):
+            if graphed is not None:
+                graphed(scene.lr_at(conf, min(i / 3000.0, 0.999)), 0.25)
+            else:
+                eager_step(i)
     elif args.mode == 'train_app':
         opt = scene.make_optimizer(scene.nerf.app_mlp, 0.0)
         conf = tc.app_optimizer
 
-        def step(i):
+        def eager_step(i):
             scene.update_lr(opt, conf, min(i / 1500.0, 0.999))
-            scene.train_one_step_app(opt, pool, progress=0.25, generator=gen)
+            scene.train_one_step_app(opt, pool, progress=0.25, generator=None if world == 1 else gen)
+        if use_graph:
+            graphed = scene.make_graphed_step('app', opt, pool)
+
+        def step(i):
+            if graphed is not None:
+                graphed(scene.lr_at(conf, min(i / 1500.0, 0.999)), 0.25)
+            else:
+                eager_step(i)
     else:
         scene.set_eval()
         n_batches = (args.height * args.width) // 32768
@@ -149,6 +169,7 @@ def main():
             b = i % n_batches
             with torch.no_grad():
                 scene.render_once(Rays(flat_o[b * 32768:(b + 1) * 32768], flat_d[b * 32768:(b + 1) * 32768]), ['rgb', 'distance'])
+        eager_step = step
 
     rays_per_step = args.rays_per_gpu if args.mode != 'render' else 32768
     for i in range(args.warmup):
@@ -156,7 +177,9 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ops.start_kernel_timing()
+    instrument_inline = graphed is None           # HIP events cannot be recorded inside a graph replay
+    if instrument_inline:
+        ops.start_kernel_timing()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -166,7 +189,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern = ops.stop_kernel_timing()
+    if instrument_inline:
+        kern = ops.stop_kernel_timing()
+    else:
+        # same K steps again, launched eagerly with a HIP event pair around every kernel (same kernels, same shapes)
+        ops.start_kernel_timing()
+        for i in range(args.steps):
+            eager_step(args.warmup + args.steps + i)
+        kern = ops.stop_kernel_timing()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,7 +237,10 @@ def main():
                                    f'hash grid L16/F2/T18 + 64-wide MLPs, mode={args.mode}',
                        'rays_per_gpu_per_step': rays_per_step, 'ray_samples_per_gpu_per_step': samples_per_step,
                        'parallelism': f'dp{world} (rays sharded, one RCCL all-reduce of the flat gradient per step)' if world > 1 else 'single GPU',
-                       'per_gpu_value': value / world},
+                       'per_gpu_value': value / world,
+                       'launch': 'hipGraph replay of the whole step' if graphed is not None else 'eager',
+                       'kernel_timing': 'HIP events around every launch, ' + ('over the timed region' if instrument_inline
+                                        else 'eager re-run of the same steps right after the graph-replayed timed region')},
             'roofline': roof, 'cpu_baseline': cpu, 'kernels': table,
         }
         print(json.dumps(line))

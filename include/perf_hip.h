@@ -88,6 +88,12 @@ int perf_adam_step(float* p, float* m, float* v, float* g, void* w16, int64_t n,
                    int32_t step, float lr, float beta1, float beta2, float eps, int zero_grad,
                    void* stream);
 
+/* Same with the step count (int32, >= 1) and the learning rate read from DEVICE memory, so that a captured
+ * hipGraph of the training step can be replayed while the schedule advances. */
+int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype,
+                       const int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float eps,
+                       int zero_grad, void* stream);
+
 /* ---- sample positions ------------------------------------------------------------------ */
 
 /* x = o[ray] + d[ray]*(t0+t1)/2 (modules/scene/nerf_renderer.py:125-127), then
@@ -115,11 +121,15 @@ int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const fl
 
 /* tcnn kernel_grid_backward: reduce dfeat (fp32, level-major like feat) into grad_table
  * (fp32 [total*2]).  Every entry of grad_table is written exactly once: overwritten when
- * accumulate == 0 (no zero-fill needed), added to when accumulate != 0.  No global atomics. */
+ * accumulate == 0 (no zero-fill needed), added to when accumulate != 0.  No global atomics.
+ * level_absmax == NULL: fp32 LDS accumulation.  level_absmax != NULL (device, PERF_MAX_LEVELS floats, the
+ * per-level max |dfeat| as produced by perf_mlp_bwd): packed fixed-point accumulation with full-rate integer
+ * LDS atomics, unit = 2^ceil(log2 absmax) * 2^-19; *overflow_flag (device int32, may be NULL) is OR-ed with 1
+ * when any field comes within 2x of the int32 range (then repeat the call with level_absmax == NULL). */
 int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid);
 int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
-                      float* grad_table, int64_t n, int accumulate, void* workspace,
-                      int64_t workspace_bytes, void* stream);
+                      float* grad_table, int64_t n, int accumulate, const float* level_absmax,
+                      int32_t* overflow_flag, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* tcnn kernel_grid_backward_input: dL/dx01 [n,3] from dfeat and the table (fp32 table). */
 int perf_hashgrid_bwd_input(const perf_grid_desc* grid, const float* x01, const float* dfeat,
@@ -139,10 +149,12 @@ int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n);
  * registers (nothing but feat16 is kept from the forward pass).  dout [n, n_out] is the
  * gradient w.r.t. the ACTIVATED output (before the sel multiply is undone: the kernel applies
  * sel and the activation derivative itself).  Outputs: dfeat fp32 level-major (may be NULL),
- * dw fp32 [n_net_params] (overwritten; deterministic two-stage reduction). */
+ * dw fp32 [n_net_params] (overwritten; deterministic two-stage reduction), level_absmax (may be NULL):
+ * PERF_MAX_LEVELS floats, an upper bound of max |dfeat| of every level (the max over the group of 8 levels a
+ * half-wave owns; zeroed by the call). */
 int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
-                 const float* dout, float* dfeat, float* dw, void* workspace, int64_t workspace_bytes,
-                 int64_t n, int dtype, void* stream);
+                 const float* dout, float* dfeat, float* dw, float* level_absmax, void* workspace,
+                 int64_t workspace_bytes, int64_t n, int dtype, void* stream);
 
 /* ---- rays ---------------------------------------------------------------------------------- */
 

@@ -37,16 +37,17 @@ _SIGS = {
     'perf_last_error': (c_char_p, []),
     'perf_cast_params': (c_int, [P, P, c_int64, c_int, P]),
     'perf_adam_step': (c_int, [P, P, P, P, P, c_int64, c_int, c_int32, c_float, c_float, c_float, c_float, c_int, P]),
+    'perf_adam_step_dev': (c_int, [P, P, P, P, P, c_int64, c_int, P, P, c_float, c_float, c_float, c_int, P]),
     'perf_points_from_rays': (c_int, [P, P, P, P, P, POINTER(c_float), P, P, c_int64, P]),
     'perf_points_normalize': (c_int, [P, POINTER(c_float), P, P, c_int64, P]),
     'perf_hashgrid_fwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P]),
     'perf_hashgrid_fwd_f32': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
     'perf_hashgrid_bwd_workspace_bytes': (c_int64, [POINTER(GridDesc)]),
-    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P, c_int64, P]),
+    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P, P, P, c_int64, P]),
     'perf_hashgrid_bwd_input': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),
     'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, c_int, P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
-    'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, P, P, P, P, c_int64, c_int64, c_int, P]),
+    'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, P, P, P, P, P, c_int64, c_int64, c_int, P]),
     'perf_pano_raygen': (c_int, [POINTER(c_float), c_int32, c_int32, c_int32, c_int32, P, P, P]),
     'perf_occ_pack_bits': (c_int, [P, P, c_int64, P]),
     'perf_occ_mask_words': (c_int64, [c_int32]),

@@ -176,6 +176,7 @@ struct TileParams {
     int32_t replicas_of[PERF_MAX_LEVELS];  // replicas per tile
     int64_t ws_off[PERF_MAX_LEVELS];       // float2 offset of the level's replica slabs in the workspace
     int32_t accumulate;
+    int32_t fixed_headroom_log2;           // fixed-point mode: log2 of the assumed max sum / max contribution
 };
 
 static void plan_tiles(const GridParams& gp, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
@@ -206,12 +207,21 @@ __device__ __forceinline__ bool dense_owner(uint32_t idx, uint32_t n_tiles, uint
     return (c % n_tiles) == t;
 }
 
+// FIXED = true: the two features of an entry are accumulated as two signed 32-bit fixed-point fields packed in one
+// 64-bit LDS word (sum of h*2^32 + l is exact integer arithmetic; fields are recovered at write-back) with ONE
+// full-rate integer ds_add_u64 per corner -- gfx950 serialises ds_add_f32 at ~3 cycles per active lane
+// (tools/exp/lds_atomics.hip).  The unit is a power of two derived on the device from the level's max |dfeat|:
+// unit = 2^ceil(log2(absmax)) * 2^(headroom - 31).  A tile whose largest field comes within 2x of the int32 range
+// raises *overflow_flag (the caller then falls back to the fp32 mode).
+template <bool FIXED>
 __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp, TileParams tp,
                                                                    const float* __restrict__ x01,
                                                                    const float2* __restrict__ dfeat,
                                                                    float2* __restrict__ grad, float2* __restrict__ ws,
-                                                                   int64_t n) {
+                                                                   const float* __restrict__ level_absmax,
+                                                                   int32_t* __restrict__ overflow_flag, int64_t n) {
     extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats
+    unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
     int b = blockIdx.x, l = 0;
     while (b >= tp.tiles_of[l] * tp.replicas_of[l]) { b -= tp.tiles_of[l] * tp.replicas_of[l]; ++l; }
     const int R = tp.replicas_of[l];
@@ -225,6 +235,15 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     for (int i = threadIdx.x; i < 2 * kTileEntries / 4; i += kBwdThreads)
         reinterpret_cast<float4*>(lds_tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    float to_fixed = 1.0f, from_fixed = 1.0f;
+    if (FIXED) {
+        const float am = level_absmax[l];
+        int e = 0;
+        if (am > 0.f) (void)frexpf(am, &e);                         // am < 2^e
+        const int sh = 31 - tp.fixed_headroom_log2 - e;               // units per 1.0 = 2^sh
+        to_fixed = ldexpf(1.0f, sh);
+        from_fixed = ldexpf(1.0f, -sh);
+    }
     const float2* g_l = dfeat + (int64_t)l * n;
     const uint32_t r2 = res * res;
     const int64_t stride = (int64_t)R * kBwdThreads;
@@ -284,11 +303,18 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                 dense_owner(idx, n_tiles, t, &a);
             }
             const float w = ((bx ? fx : 1.0f - fx) * (by ? fy : 1.0f - fy)) * (bz ? fz : 1.0f - fz);
-            unsafeAtomicAdd(&lds_tile[2 * a], w * g.x);
-            unsafeAtomicAdd(&lds_tile[2 * a + 1], w * g.y);
+            if (FIXED) {
+                const long long lo = (long long)__float2int_rn(w * g.x * to_fixed);
+                const long long hi = (long long)__float2int_rn(w * g.y * to_fixed);
+                atomicAdd(&lds64[a], (unsigned long long)((hi << 32) + lo));
+            } else {
+                unsafeAtomicAdd(&lds_tile[2 * a], w * g.x);
+                unsafeAtomicAdd(&lds_tile[2 * a + 1], w * g.y);
+            }
         }
     }
     __syncthreads();
+    int32_t field_max = 0;
     // ---- write back: local slot j of tile t is entry e(j)
     const float2* src = reinterpret_cast<const float2*>(lds_tile);
     float2* out = (R > 1) ? ws + tp.ws_off[l] + (int64_t)rep * size : grad + gp.offset[l];
@@ -298,10 +324,21 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         if (hashed) e = t * (uint32_t)kTileEntries + j;
         else e = ((j / kChunk) * n_tiles + t) * kChunk + (j % kChunk);
         if (e >= size) continue;
-        float2 v = src[j];
+        float2 v;
+        if (FIXED) {
+            const long long tot = (long long)lds64[j];
+            const int32_t lo = (int32_t)(tot & 0xffffffffll);
+            const int32_t hi = (int32_t)((tot - (long long)lo) >> 32);
+            v = make_float2((float)lo * from_fixed, (float)hi * from_fixed);
+            const int32_t alo = lo < 0 ? -(lo + 1) : lo, ahi = hi < 0 ? -(hi + 1) : hi;
+            field_max = max(field_max, max(alo, ahi));
+        } else {
+            v = src[j];
+        }
         if (acc) { const float2 o = out[e]; v.x += o.x; v.y += o.y; }
         out[e] = v;
     }
+    if (FIXED && overflow_flag && field_max >= (1 << 30)) atomicOr(overflow_flag, 1);
 }
 
 // sum the replica slabs (ws[level][replica][entry]) of the replicated (coarse) levels into the gradient table
@@ -402,8 +439,8 @@ extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid)
 }
 
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
-                                 float* grad_table, int64_t n, int accumulate, void* workspace,
-                                 int64_t workspace_bytes, void* stream) {
+                                 float* grad_table, int64_t n, int accumulate, const float* level_absmax,
+                                 int32_t* overflow_flag, void* workspace, int64_t workspace_bytes, void* stream) {
     GridParams gp;
     int rc = fill_params(grid, &gp);
     if (rc) return rc;
@@ -416,14 +453,20 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     PERF_REQUIRE(ws_entries == 0 || (workspace && workspace_bytes >= ws_entries * (int64_t)sizeof(float2)),
                  "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(ws_entries * sizeof(float2)));
     tp.accumulate = accumulate;
+    tp.fixed_headroom_log2 = 12;
     const int lds_bytes = 2 * kTileEntries * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hashgrid_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hashgrid_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hashgrid_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    hashgrid_bwd_kernel<<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
-        gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, n);
+    if (level_absmax)
+        hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
+            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, n);
+    else
+        hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
+            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, n);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (ws_entries > 0) {
         hashgrid_bwd_reduce_kernel<<<dim3(64, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(gp, tp, (const float2*)workspace,

@@ -34,7 +34,20 @@ template <typename T16, bool W16>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ g, uint16_t* __restrict__ w16, int64_t n,
                                                    float one_minus_b1, float b2, float one_minus_b2, float step_size,
-                                                   float inv_bc2_sqrt, float eps, int zero_grad) {
+                                                   float inv_bc2_sqrt, float eps, int zero_grad,
+                                                   const int32_t* __restrict__ step_dev, const float* __restrict__ lr_dev) {
+    __shared__ float sc[2];
+    if (step_dev) {       // step count and learning rate live on the device (hipGraph replay): derive the scalars here
+        if (threadIdx.x == 0) {
+            const float t = (float)step_dev[0];
+            const float bc1 = 1.0f - powf(1.0f - one_minus_b1, t), bc2 = 1.0f - powf(b2, t);
+            sc[0] = lr_dev[0] / bc1;
+            sc[1] = 1.0f / sqrtf(bc2);
+        }
+        __syncthreads();
+        step_size = sc[0];
+        inv_bc2_sqrt = sc[1];
+    }
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i];
@@ -176,9 +189,27 @@ extern "C" int perf_cast_params(const float* src, void* dst16, int64_t n, int dt
     return PERF_OK;
 }
 
+static int adam_launch(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype, int32_t step,
+                       float lr, float beta1, float beta2, float eps, int zero_grad, const int32_t* step_dev,
+                       const float* lr_dev, void* stream);
+
 extern "C" int perf_adam_step(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype, int32_t step,
                               float lr, float beta1, float beta2, float eps, int zero_grad, void* stream) {
-    PERF_REQUIRE(n >= 0 && step >= 1, "perf_adam_step: n < 0 or step < 1");
+    PERF_REQUIRE(step >= 1, "perf_adam_step: step < 1");
+    return adam_launch(p, m, v, g, w16, n, dtype, step, lr, beta1, beta2, eps, zero_grad, nullptr, nullptr, stream);
+}
+
+extern "C" int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype,
+                                  const int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float eps,
+                                  int zero_grad, void* stream) {
+    PERF_REQUIRE(step_dev && lr_dev, "perf_adam_step_dev: NULL scalar pointers");
+    return adam_launch(p, m, v, g, w16, n, dtype, 1, 0.f, beta1, beta2, eps, zero_grad, step_dev, lr_dev, stream);
+}
+
+static int adam_launch(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype, int32_t step,
+                       float lr, float beta1, float beta2, float eps, int zero_grad, const int32_t* step_dev,
+                       const float* lr_dev, void* stream) {
+    PERF_REQUIRE(n >= 0, "perf_adam_step: n < 0");
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(p && m && v && g, "NULL pointer");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -187,9 +218,9 @@ extern "C" int perf_adam_step(float* p, float* m, float* v, float* g, void* w16,
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     dim3 gr((unsigned)div_up(n, 256)), b(256);
     const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
-    if (!w16) hipLaunchKernelGGL((adam_kernel<BF16, false>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad);
-    else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam_kernel<BF16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad);
-    else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam_kernel<FP16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad);
+    if (!w16) hipLaunchKernelGGL((adam_kernel<BF16, false>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev);
+    else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam_kernel<BF16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev);
+    else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam_kernel<FP16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev);
     else { set_error("perf_adam_step: bad dtype %d", dtype); return PERF_E_INVALID; }
     PERF_LAUNCH_CHECK("perf_adam_step");
     return PERF_OK;

@@ -229,8 +229,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpParams mp, const uint16
                                                       const uint32_t* __restrict__ feat,
                                                       const uint8_t* __restrict__ sel,
                                                       const float* __restrict__ dout, float2* __restrict__ dfeat,
-                                                      float* __restrict__ partials, int64_t n) {
+                                                      float* __restrict__ partials, float* __restrict__ level_absmax,
+                                                      int64_t n) {
     using L = Layout<NH, KS>;
+    float amax = 0.f;      // running max |dfeat| over the 8 levels this half-wave owns (one register, not eight)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* frag = reinterpret_cast<u32x4*>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -355,7 +357,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpParams mp, const uint16
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {      // register pair (2q,2q+1) -> level d_row(2q,h)/2
                     const int level = d_row(2 * q, h) >> 1;
-                    if (level < mp.n_levels) dfeat[(int64_t)level * n + si] = make_float2(dx[2 * q], dx[2 * q + 1]);
+                    if (level < mp.n_levels) {
+                        dfeat[(int64_t)level * n + si] = make_float2(dx[2 * q], dx[2 * q + 1]);
+                        amax = fmaxf(amax, fmaxf(fabsf(dx[2 * q]), fabsf(dx[2 * q + 1])));
+                    }
                 }
             }
         }
@@ -377,6 +382,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpParams mp, const uint16
 #pragma unroll
             for (int m = 0; m < 2; ++m) gW1[m] = T16::mfma(lds_get_frag(tA, 32 * m + c, s, h), b, gW1[m]);
         }
+    }
+    // ---- per-level max |dfeat| (feeds the fixed-point scale of the grid backward): lanes of one half-wave hold the
+    //      same 8 levels, non-negative floats order like their bit patterns
+    if (level_absmax != nullptr) {      // per-(wave, half) max -> workspace slot; mlp_reduce_kernel folds them (no atomics)
+        float v = amax;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+        if (c == 0) level_absmax[((int64_t)blockIdx.x * 4 + wave) * 2 + h] = v;
     }
     // ---- block reduction of the four waves' accumulators through LDS (lane-linear slots, conflict free),
     //      then ONE partial per block -> global (summed by mlp_reduce_kernel)
@@ -441,8 +454,25 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpParams mp, const uint16
 
 // dw[i] = sum_k partials[k][i]: 64 parameters x 4 partial-segments per block, combined through LDS
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
-                                                         int n_params, int n_partials) {
+                                                         int n_params, int n_partials, const float* __restrict__ amax_slots,
+                                                         float* __restrict__ level_absmax, int n_levels) {
     __shared__ float acc[4][64];
+    if (blockIdx.x == gridDim.x - 1) {
+        // extra block: level_absmax[l] = max over all (wave, half) slots of the half that owns level l
+        if (level_absmax == nullptr) return;
+        float m0 = 0.f, m1 = 0.f;
+        for (int k = threadIdx.x; k < n_partials * 4; k += 256) { m0 = fmaxf(m0, amax_slots[2 * k]); m1 = fmaxf(m1, amax_slots[2 * k + 1]); }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, off)); m1 = fmaxf(m1, __shfl_xor(m1, off)); }
+        if ((threadIdx.x & 63) == 0) { acc[0][threadIdx.x >> 6] = m0; acc[1][threadIdx.x >> 6] = m1; }
+        __syncthreads();
+        if (threadIdx.x < PERF_MAX_LEVELS) {
+            const int h = (threadIdx.x >> 1) & 1;          // levels {0,1,4,5,..} live in half 0, {2,3,6,7,..} in half 1
+            const float v = fmaxf(fmaxf(acc[h][0], acc[h][1]), fmaxf(acc[h][2], acc[h][3]));
+            level_absmax[threadIdx.x] = (int)threadIdx.x < n_levels ? v : 0.f;
+        }
+        return;
+    }
     const int pi = blockIdx.x * 64 + (threadIdx.x & 63);
     const int seg = threadIdx.x >> 6;
     float s = 0.f;
@@ -494,7 +524,7 @@ static void launch_fwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t*
 
 template <typename T16, int NH, int KS>
 static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t* w, const uint32_t* feat, const uint8_t* sel,
-                       const float* dout, float2* dfeat, float* partials, int64_t n) {
+                       const float* dout, float2* dfeat, float* partials, float* level_absmax, int64_t n) {
     constexpr int lds_bytes = Layout<NH, KS>::n_all * 1024 + 4 * 2 * 64 * kPitch * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -502,7 +532,7 @@ static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t*
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    mlp_bwd_kernel<T16, NH, KS><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, n);
+    mlp_bwd_kernel<T16, NH, KS><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, level_absmax, n);
 }
 
 template <typename T16, typename... Args>
@@ -543,12 +573,12 @@ extern "C" int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_
     int nh, ks;
     if (check_mlp(mlp, &nh, &ks)) return -1;
     const int blocks = mlp_blocks(n > 0 ? n : 1, kBwdBlocksPerCU);
-    return (int64_t)blocks * n_params_rt(nh, ks) * (int64_t)sizeof(float);
+    return ((int64_t)blocks * n_params_rt(nh, ks) + (int64_t)blocks * 8) * (int64_t)sizeof(float);
 }
 
 extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
-                            const float* dout, float* dfeat, float* dw, void* workspace, int64_t workspace_bytes,
-                            int64_t n, int dtype, void* stream) {
+                            const float* dout, float* dfeat, float* dw, float* level_absmax, void* workspace,
+                            int64_t workspace_bytes, int64_t n, int dtype, void* stream) {
     int nh, ks;
     int rc = check_mlp(mlp, &nh, &ks);
     if (rc) return rc;
@@ -556,6 +586,7 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
     PERF_REQUIRE(dtype == PERF_DTYPE_BF16 || dtype == PERF_DTYPE_FP16, "bad dtype %d", dtype);
     const int np = n_params_rt(nh, ks);
     if (n == 0) {
+        if (level_absmax) (void)hipMemsetAsync(level_absmax, 0, PERF_MAX_LEVELS * sizeof(float), as_stream(stream));
         hipError_t e = hipMemsetAsync(dw, 0, np * sizeof(float), as_stream(stream));
         if (e != hipSuccess) { set_error("perf_mlp_bwd: memset failed"); return PERF_E_LAUNCH; }
         return PERF_OK;
@@ -565,15 +596,16 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
     PERF_REQUIRE(workspace_bytes >= need, "perf_mlp_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     MlpParams mp{mlp->n_levels, mlp->n_out, mlp->out_act, mlp->exp_shift};
     const int blocks = mlp_blocks(n, kBwdBlocksPerCU);
+    float* amax_slots = level_absmax ? (float*)workspace + (int64_t)blocks * np : nullptr;
     if (dtype == PERF_DTYPE_BF16)
         dispatch_bwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,
-                           (float2*)dfeat, (float*)workspace, n);
+                           (float2*)dfeat, (float*)workspace, amax_slots, n);
     else
         dispatch_bwd<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,
-                           (float2*)dfeat, (float*)workspace, n);
+                           (float2*)dfeat, (float*)workspace, amax_slots, n);
     PERF_LAUNCH_CHECK("perf_mlp_bwd");
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)div_up(np, 64)), dim3(256), 0, as_stream(stream),
-                       (const float*)workspace, dw, np, blocks);
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)div_up(np, 64) + 1), dim3(256), 0, as_stream(stream),
+                       (const float*)workspace, dw, np, blocks, (const float*)amax_slots, level_absmax, (int)mlp->n_levels);
     PERF_LAUNCH_CHECK("perf_mlp_bwd(reduce)");
     return PERF_OK;
 }

@@ -76,6 +76,7 @@ class NGPNeRF(nn.Module):
         if not isinstance(aabb, torch.Tensor):
             aabb = torch.tensor(aabb, dtype=torch.float32)
         self.register_buffer("aabb", aabb.float().cuda())
+        self._aabb_host = [float(v) for v in aabb.reshape(-1).tolist()]
         self.num_dim = num_dim
         self.use_viewdirs = use_viewdirs
         self.unbounded = unbounded
@@ -90,17 +91,17 @@ class NGPNeRF(nn.Module):
     # -- point queries (ngp_nerf.py:136-162) ---------------------------------------------------------
     def query_density(self, x):
         shape = list(x.shape[:-1])
-        x01, sel = ops.points_normalize(x.reshape(-1, 3).contiguous().float(), self.aabb)
+        x01, sel = ops.points_normalize(x.reshape(-1, 3).contiguous().float(), self._aabb_host)
         return _FieldFn.apply(x01, self.geo_mlp.params, sel, self.geo_mlp).view(shape + [1])
 
     def query_rgb(self, x):
         shape = list(x.shape[:-1])
-        x01, sel = ops.points_normalize(x.reshape(-1, 3).contiguous().float(), self.aabb)
+        x01, sel = ops.points_normalize(x.reshape(-1, 3).contiguous().float(), self._aabb_host)
         return _FieldFn.apply(x01, self.app_mlp.params, sel, self.app_mlp).view(shape + [3])
 
     # -- ray-sample queries: positions o + d (t0+t1)/2 are formed in-kernel (nerf_renderer.py:125-127) --
     def sample_points(self, rays_o, rays_d, ray_indices, t_starts, t_ends):
-        return ops.points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, self.aabb)
+        return ops.points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, self._aabb_host)
 
     def density_at(self, x01, sel):
         return _FieldFn.apply(x01, self.geo_mlp.params, sel, self.geo_mlp)[:, 0]
@@ -129,6 +130,7 @@ class NGPDensityField(nn.Module):
         if not isinstance(aabb, torch.Tensor):
             aabb = torch.tensor(aabb, dtype=torch.float32)
         self.register_buffer("aabb", aabb.float().cuda())
+        self._aabb_host = [float(v) for v in aabb.reshape(-1).tolist()]
         self.num_dim = num_dim
         self.unbounded = unbounded
         self.base_resolution = base_resolution
@@ -145,5 +147,5 @@ class NGPDensityField(nn.Module):
             x01 = contract_to_unisphere(positions, self.aabb).reshape(-1, 3).contiguous().float()
             sel = ((x01 > 0.0) & (x01 < 1.0)).all(dim=-1).to(torch.uint8)
         else:
-            x01, sel = ops.points_normalize(positions.reshape(-1, 3).contiguous().float(), self.aabb)
+            x01, sel = ops.points_normalize(positions.reshape(-1, 3).contiguous().float(), self._aabb_host)
         return _FieldFn.apply(x01, self.mlp_base.params, sel, self.mlp_base).view(shape + [1])

@@ -118,6 +118,10 @@ class OccGridEstimator(nn.Module):
         self.register_buffer('aabbs', roi_aabb.detach().float().reshape(1, 6).clone())
         self.register_buffer('occs', torch.zeros(self.cells_per_lvl, dtype=torch.float32))
         self.register_buffer('binaries', torch.zeros(1, res, res, res, dtype=torch.bool))
+        # host copies of the constants the launchers need (no device read-back on the hot path)
+        self._res = res
+        self._aabb_host = [float(v) for v in roi_aabb.detach().cpu().reshape(-1).tolist()]
+        self._diag = math.sqrt(sum((self._aabb_host[3 + i] - self._aabb_host[i]) ** 2 for i in range(3)))
         self._bits = None
         self._bits_version = None
 
@@ -131,7 +135,7 @@ class OccGridEstimator(nn.Module):
 
     def set_binaries(self, occ_flat):
         """Install a precomputed occupancy (x-major flat uint8/bool [res^3])."""
-        res = int(self.resolution[0])
+        res = self._res
         self.binaries = occ_flat.reshape(1, res, res, res).bool().to(self.binaries.device)
         self.occs = self.binaries.reshape(-1).float()
         self._bits = None
@@ -147,7 +151,7 @@ class OccGridEstimator(nn.Module):
     @torch.no_grad()
     def sampling_ex(self, rays_o, rays_d, sigma_fn=None, near_plane=0.0, far_plane=1e10, render_step_size=1e-3,
                     early_stop_eps=1e-4, alpha_thre=0.0, stratified=False, cone_angle=0.0, alpha_fn=None,
-                    t_min=None, t_max=None, jitter=None, max_steps=None):
+                    t_min=None, t_max=None, jitter=None, max_steps=None, capacity=None):
         """sampling() that also returns (packed_info, sigmas of the kept samples or None).
         max_steps caps the number of lattice intervals per ray (fixed-count benchmark mode)."""
         if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
@@ -161,12 +165,17 @@ class OccGridEstimator(nn.Module):
         if stratified:
             u = torch.rand(R, device=dev) if jitter is None else jitter
             t0 = t0 + u * render_step_size
-        aabb = self.aabbs[0]
-        diag = float(torch.linalg.norm(aabb[3:] - aabb[:3]))
-        span = min(float(far_plane) - float(near_plane), diag)
+        aabb = self._aabb_host
+        span = min(float(far_plane) - float(near_plane), self._diag)
         if max_steps is None:
             max_steps = int(math.ceil(span / render_step_size)) + 1
-        res = int(self.resolution[0])
+        res = self._res
+        if capacity is not None:
+            # sync-free fixed-shape mode (hipGraph capture): the caller guarantees exactly `capacity` samples
+            ri, ts, te, packed, total = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane),
+                                                      float(render_step_size), max_steps, capacity=capacity)
+            ri._perf_packed = packed
+            return ri, ts, te, packed, None
         ri, ts, te, packed = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane),
                                            float(render_step_size), max_steps)
         sig = None
@@ -190,7 +199,7 @@ class OccGridEstimator(nn.Module):
             raise RuntimeError('update_every_n_steps() should only be called in training mode')
         if step % n != 0:
             return
-        res = int(self.resolution[0])
+        res = self._res
         dev = self.occs.device
         if step < warmup_steps:
             idx = torch.arange(self.cells_per_lvl, device=dev)

@@ -98,6 +98,12 @@ def adam_step(p, m, v, g, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, w16=None, 
               _stream())
 
 
+def adam_step_dev(p, m, v, g, step_dev, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8, w16=None, zero_grad=False):
+    code = dtype_code(w16.dtype) if w16 is not None else 0
+    _call('perf_adam_step_dev', _p(_f32(p, 'p')), _p(_f32(m, 'm')), _p(_f32(v, 'v')), _p(_f32(g, 'g')), _p(w16),
+          p.numel(), code, _p(step_dev), _p(lr_dev), float(beta1), float(beta2), float(eps), int(bool(zero_grad)), _stream())
+
+
 # ---- positions -----------------------------------------------------------------------------------
 def points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, aabb):
     n = ray_indices.numel()
@@ -138,9 +144,21 @@ def hashgrid_fwd_f32(grid: GridConfig, x01, table):
     return feat
 
 
-def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False):
+_OVERFLOW_FLAG = {}
+
+
+def overflow_flag(device):
+    """Device int32 that the fixed-point grid backward ORs with 1 when a field nears the int32 range."""
+    key = str(device)
+    if key not in _OVERFLOW_FLAG:
+        _OVERFLOW_FLAG[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _OVERFLOW_FLAG[key]
+
+
+def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False, level_absmax=None):
     """dfeat [L, n, 2] f32 -> gradient table [total*2] f32.  `out` (a contiguous fp32 view, e.g. the grid
-    part of a flat gradient) is overwritten, or added to when accumulate=True."""
+    part of a flat gradient) is overwritten, or added to when accumulate=True.  level_absmax (device, 16 floats
+    from mlp_bwd) selects the packed fixed-point accumulation."""
     n = x01.shape[0]
     if out is None:
         out = torch.empty(grid.n_params, dtype=torch.float32, device=x01.device)
@@ -148,13 +166,14 @@ def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False):
     d = grid.desc()
     ws_bytes = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=x01.device)
+    flag = overflow_flag(x01.device) if level_absmax is not None else None
     _call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),
-              n, int(bool(accumulate)), _p(ws), ws.numel() * 4, _stream())
+              n, int(bool(accumulate)), _p(level_absmax), _p(flag), _p(ws), ws.numel() * 4, _stream())
     return out
 
 
-def hashgrid_bwd_into(grid, x01, dfeat, out):
-    return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False)
+def hashgrid_bwd_into(grid, x01, dfeat, out, level_absmax=None):
+    return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False, level_absmax=level_absmax)
 
 
 def hashgrid_bwd_input(grid: GridConfig, x01, dfeat, table):
@@ -175,8 +194,8 @@ def mlp_fwd(mlp: MlpConfig, w16, feat16, sel=None):
     return out
 
 
-def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True):
-    """Returns (dfeat [L,n,2] f32 or None, dw [n_net_params] f32)."""
+def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True, want_absmax=False):
+    """Returns (dfeat [L,n,2] f32 or None, dw [n_net_params] f32[, level_absmax [16] f32])."""
     n = feat16.shape[1]
     d = mlp.desc()
     lib = _lib.load()
@@ -184,9 +203,10 @@ def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True):
     ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=feat16.device)
     dfeat = torch.empty(mlp.n_levels, n, 2, dtype=torch.float32, device=feat16.device) if need_dfeat else None
     dw = torch.empty(mlp.n_params, dtype=torch.float32, device=feat16.device)
-    _call('perf_mlp_bwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(_f32(dout, 'dout')), _p(dfeat), _p(dw),
+    amax = torch.empty(_lib.MAX_LEVELS, dtype=torch.float32, device=feat16.device) if want_absmax else None
+    _call('perf_mlp_bwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(_f32(dout, 'dout')), _p(dfeat), _p(dw), _p(amax),
               _p(ws), ws.numel() * 4, n, dtype_code(w16.dtype), _stream())
-    return dfeat, dw
+    return (dfeat, dw, amax) if want_absmax else (dfeat, dw)
 
 
 # ---- rays ----------------------------------------------------------------------------------------

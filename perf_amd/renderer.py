@@ -51,6 +51,7 @@ class NeRFOCCRenderer(nn.Module):
         self.render_step_size = 5e-4
         self.early_stop_eps = 1e-4
         self.max_steps = None          # None: ceil((far-near)/step)+1 like the reference; an int fixes the count
+        self.sample_capacity = None    # int: sync-free fixed-shape sampling (exactly that many samples per batch)
 
     def render(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, near, far,
                geo_inference=False, app_inference=False, rand=None):
@@ -71,7 +72,7 @@ class NeRFOCCRenderer(nn.Module):
         ray_indices, t_starts, t_ends, packed, sig0 = estimator.sampling_ex(
             rays_o, rays_d, sigma_fn=sigma_fn, near_plane=self.near_plane, far_plane=self.far_plane,
             render_step_size=self.render_step_size, early_stop_eps=self.early_stop_eps, stratified=nerf.training,
-            cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'), max_steps=self.max_steps)
+            cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'), max_steps=self.max_steps, capacity=self.sample_capacity)
         if ray_indices.numel() <= 0:
             return {'is_valid': False, 'rgb': torch.zeros(n_rays, 3, device=dev), 'distance': torch.zeros(n_rays, 1, device=dev),
                     'opacities': torch.zeros(n_rays, 1, device=dev)}

@@ -28,6 +28,9 @@ from .distloss import flatten_eff_distloss
 from .fields import NGPNeRF
 from .nerfacc_impl import OccGridEstimator
 from .renderer import NeRFOCCRenderer
+from . import tcnn as _tcnn
+
+OVERFLOW_CHECK_EVERY = 64      # training steps between reads of the fixed-point overflow flag (one host sync each)
 
 
 @dataclass
@@ -120,7 +123,8 @@ class SupInfoPool:
 
 class FusedAdam:
     """torch.optim.Adam(params, lr) for ONE flat fp32 parameter, as a single kernel that also refreshes the
-    network's 16-bit working copy and clears the gradient (perf_adam_step)."""
+    network's 16-bit working copy (perf_adam_step_dev).  Step count and learning rate live in device scalars so
+    that a captured hipGraph of the whole training step can be replayed while the schedule advances."""
 
     def __init__(self, net, lr, betas=(0.9, 0.999), eps=1e-8):
         self.net = net
@@ -128,20 +132,28 @@ class FusedAdam:
         p = net.params
         self.exp_avg = torch.zeros_like(p.data)
         self.exp_avg_sq = torch.zeros_like(p.data)
-        self.step_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=p.device)
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=p.device)
+        self.capturing = False
         self.w16 = torch.empty(p.numel(), dtype=ops.torch_dtype(net.dtype_name), device=p.device)
 
+    @property
+    def step_count(self):
+        return int(self.step_dev.item())
+
     def zero_grad(self):
-        pass                                       # the step kernel clears the gradient it consumed
+        pass                                       # the step consumes the gradient and drops it
 
     def step(self):
         p = self.net.params
         if p.grad is None:
             return
-        self.step_count += 1
         g = self.param_groups[0]
-        ops.adam_step(p.data, self.exp_avg, self.exp_avg_sq, p.grad, self.step_count, g['lr'], g['betas'][0],
-                      g['betas'][1], g['eps'], w16=self.w16, zero_grad=False)
+        if not self.capturing:
+            self.lr_dev.fill_(g['lr'])             # under capture the replay wrapper refreshes lr_dev instead
+        self.step_dev += 1
+        ops.adam_step_dev(p.data, self.exp_avg, self.exp_avg_sq, p.grad, self.step_dev, self.lr_dev, g['betas'][0],
+                          g['betas'][1], g['eps'], w16=self.w16, zero_grad=False)
         p.grad = None                              # the next backward installs a fresh gradient (no accumulate pass)
         self.net.set_working_copy(self.w16)        # the kernel wrote the refreshed 16-bit copy
 
@@ -163,6 +175,8 @@ class NeRFScene:
         self.global_iter_step_app = 0
         self.loss_scale = 2.0 ** 7
         self.last_losses = {}
+        self._capturing = False
+        self._ratio_dev = torch.zeros((), dtype=torch.float32, device='cuda')   # distortion-loss ramp min(2*progress, 1)
 
     # ---- distributed helpers ---------------------------------------------------------------------
     @staticmethod
@@ -261,6 +275,10 @@ class NeRFScene:
                 g = net.params.grad = torch.zeros_like(net.params)
             dist.all_reduce(g, op=dist.ReduceOp.SUM)           # one RCCL all-reduce of the flat gradient
         optimizer.step()
+        self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
+        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY and _tcnn.GRID_GRAD_ACCUM == 'fixed':
+            self._steps_since_check = 0
+            _tcnn.check_fixed_point_overflow(net.params.device)
 
     def train_one_step_geo(self, optimizer, sup_pool, progress, rand=None, generator=None):
         tc = self.train_conf
@@ -286,8 +304,9 @@ class NeRFScene:
             dist_loss = flatten_eff_distloss(res['weights'], mid, sec, res['ray_indices'], packed_info=res['packed_info'])
             if dist_info[2] > 1:                               # local /n_local -> global /bs
                 dist_loss = dist_loss * ((res['ray_indices'][-1:].float() + 1.0) / bs).squeeze()
-            ratio = float(np.min([progress * 2., 1]))
-            loss = loss + dist_loss * tc.distortion_loss_weight * ratio
+            if not self._capturing:
+                self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
+            loss = loss + dist_loss * (tc.distortion_loss_weight * self._ratio_dev)
             self.last_losses['dist_loss'] = dist_loss.detach()
         if tc.density_loss_weight > 1e-7:
             rand_pts = (torch.rand(8192, 3, device=gt_depths.device) * 2. - 1.) * 0.99
@@ -314,6 +333,47 @@ class NeRFScene:
             self.last_losses['color_loss'] = color_loss.detach()
         self._finish_step(loss, self.nerf.app_mlp, optimizer, dist_info)
         self.global_iter_step_app += 1
+
+    # ---- hipGraph capture of a whole training step (launch-bound inner loop) ---------------------------
+    def make_graphed_step(self, kind, optimizer, sup_pool, warmup=3):
+        """Capture train_one_step_{geo,app} (batch draw, sampling, both fields, compositing, losses, backward, Adam)
+        into one hipGraph.  Needs fixed shapes: renderer.sample_capacity must be set (exact sample count per batch,
+        e.g. rays*spp in fixed-count mode), a FusedAdam optimizer and a single process.  Returns
+        replay(lr, progress)."""
+        assert isinstance(optimizer, FusedAdam), 'graph capture needs the fused Adam (device-side step/lr)'
+        assert self.renderer.sample_capacity is not None, 'graph capture needs a fixed sample capacity'
+        assert self._dist()[0] is None, 'graphed steps are single-process (the all-reduce stays eager)'
+        step_fn = self.train_one_step_geo if kind == 'geo' else self.train_one_step_app
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step_fn(optimizer, sup_pool, progress=0.0)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self._capturing = optimizer.capturing = True
+        try:
+            with torch.cuda.graph(graph):
+                step_fn(optimizer, sup_pool, progress=0.0)
+        finally:
+            self._capturing = optimizer.capturing = False
+
+        state = {'graph': graph, 'n': 0}
+
+        def replay(lr, progress):
+            optimizer.lr_dev.fill_(lr)
+            if kind == 'geo':
+                self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
+            state['graph'].replay()
+            state['n'] += 1
+            if state['n'] % OVERFLOW_CHECK_EVERY == 0 and _tcnn.GRID_GRAD_ACCUM == 'fixed':
+                if _tcnn.check_fixed_point_overflow(optimizer.net.params.device):
+                    # the accumulation mode is baked into the graph: capture again in fp32 mode
+                    state['graph'] = self.make_graphed_step(kind, optimizer, sup_pool, warmup=1).graph
+
+        replay.graph = graph
+        return replay
 
     @staticmethod
     def lr_at(optim_conf, progress):

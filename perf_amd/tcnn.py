@@ -22,6 +22,24 @@ from .grid import GridConfig, MlpConfig
 
 DEFAULT_DTYPE = 'bf16'     # BASELINE.json config 2 names bf16; 'fp16' reproduces tcnn's own precision
 DEFAULT_SEED = 1337        # tcnn's torch binding seeds its init with 1337
+# accumulation of the grid gradient: 'fp32' (LDS float atomics) or 'fixed' (packed 2x int32 fixed point, integer LDS
+# atomics, per-level power-of-two unit from max|dfeat| with 2^12 headroom; see hashgrid.hip)
+import os as _os
+GRID_GRAD_ACCUM = _os.environ.get('PERF_GRID_GRAD_ACCUM', 'fixed')
+
+
+def check_fixed_point_overflow(device=None):
+    """Read (one host sync) and clear the overflow-suspect flag of the fixed-point grid backward.  On overflow the
+    accumulation mode is switched to 'fp32' for the rest of the process and True is returned."""
+    global GRID_GRAD_ACCUM
+    flag = ops.overflow_flag(device or _default_device())
+    hit = bool(int(flag.item()))
+    if hit:
+        flag.zero_()
+        GRID_GRAD_ACCUM = 'fp32'
+        import warnings
+        warnings.warn('perf_amd: fixed-point grid-gradient accumulation came within 2x of its range; falling back to fp32 LDS accumulation')
+    return hit
 
 
 def _init_params(mlp: MlpConfig, grid: GridConfig, seed: int) -> torch.Tensor:
@@ -56,10 +74,12 @@ class _FieldFn(torch.autograd.Function):
         sel = sel if ctx.has_sel else None
         n_net = module.mlp.n_params
         dout = dout.contiguous().float()
-        dfeat, dw = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout, sel)
+        fixed = GRID_GRAD_ACCUM == 'fixed'          # module-level switch, see check_fixed_point_overflow()
+        res = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout, sel, want_absmax=fixed)
+        dfeat, dw = res[0], res[1]
         grad = torch.empty(n_net + module.grid.n_params, dtype=torch.float32, device=x01.device)
         grad[:n_net] = dw
-        ops.hashgrid_bwd_into(module.grid, x01, dfeat, grad[n_net:])
+        ops.hashgrid_bwd_into(module.grid, x01, dfeat, grad[n_net:], level_absmax=res[2] if fixed else None)
         return None, grad, None, None
 
 

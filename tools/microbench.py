@@ -44,6 +44,9 @@ def main():
                 tb = timeit(lambda: ops.hashgrid_bwd(cfg, x, dfeat, grad))
                 res[f'{dt}/n{n}/{name}/hashgrid_fwd_Msps'] = n / tf / 1e6
                 res[f'{dt}/n{n}/{name}/hashgrid_bwd_Msps'] = n / tb / 1e6
+                amax = torch.zeros(16, device=dev); amax[:] = dfeat.abs().amax(dim=(1, 2))
+                tbf = timeit(lambda: ops.hashgrid_bwd(cfg, x, dfeat, grad, level_absmax=amax))
+                res[f'{dt}/n{n}/{name}/hashgrid_bwd_fixed_Msps'] = n / tbf / 1e6
             tg = timeit(lambda: ops.mlp_fwd(geo, wg, feat))
             ta = timeit(lambda: ops.mlp_fwd(app, wa, feat))
             dg = torch.randn(n, 1, device=dev); da = torch.randn(n, 3, device=dev)
