@@ -8,6 +8,7 @@
 // Infinity-Cache round trips.  Placement is a speed assumption only: results do not depend
 // on it.  Features leave the kernel LEVEL-MAJOR (feat[l][sample] as one packed 2x16-bit
 // dword), so every store and the MLP kernel's loads are fully coalesced.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace perf {
@@ -169,25 +170,31 @@ constexpr int kMaxReplicas = 16;
 
 // Load balance: a hashed level has 16 tiles, each receiving 1/16 of the level's 8 corner updates per
 // sample; a coarse dense level has only 1..8 tiles receiving the same total.  Coarse tiles are therefore
-// REPLICATED (R_l = 16 / n_tiles_l copies, each streaming 1/R_l of the samples) so that every workgroup
-// applies ~N/2 corner updates; replicas are summed by a small second kernel.  L16/T18: 255 workgroups.
+// REPLICATED (R_l copies, each streaming 1/R_l of the samples) so that every workgroup takes about as long as
+// a hashed-tile owner; replicas are summed by a small second kernel.  L16/T18: 8+8+15+32+192 = 255 workgroups.
 struct TileParams {
     int32_t tiles_of[PERF_MAX_LEVELS];     // tiles per level
     int32_t replicas_of[PERF_MAX_LEVELS];  // replicas per tile
     int64_t ws_off[PERF_MAX_LEVELS];       // float2 offset of the level's replica slabs in the workspace
     int32_t accumulate;
     int32_t fixed_headroom_log2;           // fixed-point mode: log2 of the assumed max sum / max contribution
+    int64_t dbg_off;                       // >0: float2 offset in the workspace where per-block cycle counts go (dev tool)
 };
 
-static void plan_tiles(const GridParams& gp, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
+static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
     int nb = 0;
     int64_t ws = 0;
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->tiles_of[l] = 0; tp->replicas_of[l] = 1; tp->ws_off[l] = 0;
         if (l >= gp.n_levels) continue;
         const int nt = (int)((gp.size[l] + kTileEntries - 1) / kTileEntries);
-        int r = kMaxReplicas / nt;
+        // replication factors from measured per-workgroup times (tools/exp/bwd_block_times.py, 1 M samples):
+        // hashed tile 0.68 ms; dense tile streaming ALL samples: 1 tile 2.7-4.1 ms, 3 tiles 2.9 ms, 8 tiles 2.2 ms
+        // (fp32 mode is bound by ds_add_f32 lane-serialisation instead: equal corner-update counts, r = 16 / nt)
+        int r = 1;
+        if (!gp.hashed[l]) r = fixed ? ((nt == 1) ? 8 : (nt <= 4 ? 5 : (nt <= 8 ? 4 : (nt < 16 ? 2 : 1)))) : kMaxReplicas / nt;
         if (r < 1) r = 1;
+        if (r > kMaxReplicas) r = kMaxReplicas;
         tp->tiles_of[l] = nt; tp->replicas_of[l] = r;
         if (r > 1) { tp->ws_off[l] = ws; ws += (int64_t)r * gp.size[l]; }
         nb += nt * r;
@@ -201,10 +208,147 @@ static void plan_tiles(const GridParams& gp, TileParams* tp, int* n_blocks, int6
 // camera / the surfaces, which overloads a few owners.
 constexpr uint32_t kChunk = 32;
 
-__device__ __forceinline__ bool dense_owner(uint32_t idx, uint32_t n_tiles, uint32_t t, uint32_t* local) {
-    const uint32_t c = idx / kChunk;
-    *local = (c / n_tiles) * kChunk + (idx % kChunk);
-    return (c % n_tiles) == t;
+struct BwdCtx {
+    float scale, to_fixed;
+    uint32_t res, r2, size, mask, n_tiles, t;
+    float inv_tiles;
+    bool smooth;
+};
+
+// c / n_tiles and c % n_tiles for c < 2^22 through an fp32 reciprocal with a one-step correction
+__device__ __forceinline__ void divmod_small(uint32_t c, uint32_t n, float inv, uint32_t* q, uint32_t* r) {
+    uint32_t qq = (uint32_t)((float)c * inv);
+    int32_t rr = (int32_t)(c - qq * n);
+    if (rr < 0) { --qq; rr += (int32_t)n; }
+    if (rr >= (int32_t)n) { ++qq; rr -= (int32_t)n; }
+    *q = qq; *r = (uint32_t)rr;
+}
+
+// one sample's contribution to the tile this workgroup owns
+template <bool FIXED, bool HASHED>
+__device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, const float2 g, const float x, const float y,
+                                          const float z) {
+    unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
+    const float px = add_rn(mul_rn(x, cx.scale), 0.5f), py = add_rn(mul_rn(y, cx.scale), 0.5f), pz = add_rn(mul_rn(z, cx.scale), 0.5f);
+    const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+    float fx = px - flx, fy = py - fly, fz = pz - flz;
+    const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+    uint32_t ay[2], az[2];
+    uint32_t match = 0;     // bit k: corner k (bit0 = x, bit1 = y, bit2 = z) is owned by this tile
+    if (HASHED) {
+        ay[0] = gy * kPrimeY; ay[1] = ay[0] + kPrimeY; az[0] = gz * kPrimeZ; az[1] = az[0] + kPrimeZ;
+        if (gx < (uint32_t)(kTileEntries - 1)) {
+            // The tile of a hashed corner depends on (y,z) only while gx+1 < 2^14, so the two x-corners of a (y,z)
+            // combination are tested and applied together: 4 tests and at most 4 (usually 0-1) pair updates.
+            uint32_t cm = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                cm |= (((((ay[c & 1] ^ az[c >> 1]) & cx.mask) / (uint32_t)kTileEntries) == cx.t) ? 1u : 0u) << c;
+            if (cm == 0) return;
+            if (cx.smooth) { fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz); }
+            const uint32_t tlo = cx.t * (uint32_t)kTileEntries;
+            while (cm) {
+                const int c = __ffs(cm) - 1;
+                cm &= cm - 1u;
+                const int by = c & 1, bz = c >> 1;
+                const uint32_t h = (by ? ay[1] : ay[0]) ^ (bz ? az[1] : az[0]);
+                const float wyz = (by ? fy : 1.0f - fy) * (bz ? fz : 1.0f - fz);
+                const uint32_t a0 = ((gx ^ h) & cx.mask) - tlo, a1 = (((gx + 1u) ^ h) & cx.mask) - tlo;
+                const float w0 = (1.0f - fx) * wyz, w1 = fx * wyz;
+                if (FIXED) {
+                    const float sx = g.x * cx.to_fixed, sy = g.y * cx.to_fixed;
+                    const long long v0 = ((long long)__float2int_rn(w0 * sy) << 32) + (long long)__float2int_rn(w0 * sx);
+                    const long long v1 = ((long long)__float2int_rn(w1 * sy) << 32) + (long long)__float2int_rn(w1 * sx);
+                    atomicAdd(&lds64[a0], (unsigned long long)v0);
+                    atomicAdd(&lds64[a1], (unsigned long long)v1);
+                } else {
+                    unsafeAtomicAdd(&lds_tile[2 * a0], w0 * g.x); unsafeAtomicAdd(&lds_tile[2 * a0 + 1], w0 * g.y);
+                    unsafeAtomicAdd(&lds_tile[2 * a1], w1 * g.x); unsafeAtomicAdd(&lds_tile[2 * a1 + 1], w1 * g.y);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t idx = ((gx + (uint32_t)(k & 1)) ^ ay[(k >> 1) & 1] ^ az[k >> 2]) & cx.mask;
+            match |= ((idx / (uint32_t)kTileEntries) == cx.t ? 1u : 0u) << k;
+        }
+    } else {
+        ay[0] = gy * cx.res; ay[1] = ay[0] + cx.res; az[0] = gz * cx.r2; az[1] = az[0] + cx.r2;
+        if (cx.n_tiles == 1) match = 0xffu;
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t idx = (gx + (uint32_t)(k & 1)) + ay[(k >> 1) & 1] + az[k >> 2];
+                if (idx >= cx.size) idx = idx % cx.size;
+                uint32_t q, r;
+                divmod_small(idx / kChunk, cx.n_tiles, cx.inv_tiles, &q, &r);
+                match |= (r == cx.t ? 1u : 0u) << k;
+            }
+        }
+    }
+    if (match == 0) return;
+    if (cx.smooth) { fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz); }
+    while (match) {
+        const int k = __ffs(match) - 1;
+        match &= match - 1u;
+        const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
+        const uint32_t cy = by ? ay[1] : ay[0], cz = bz ? az[1] : az[0];
+        uint32_t a;
+        if (HASHED) a = (((gx + (uint32_t)bx) ^ cy ^ cz) & cx.mask) - cx.t * (uint32_t)kTileEntries;
+        else {
+            uint32_t idx = (gx + (uint32_t)bx) + cy + cz;
+            if (idx >= cx.size) idx = idx % cx.size;
+            uint32_t q, r;
+            divmod_small(idx / kChunk, cx.n_tiles, cx.inv_tiles, &q, &r);
+            a = q * kChunk + (idx % kChunk);
+        }
+        const float w = ((bx ? fx : 1.0f - fx) * (by ? fy : 1.0f - fy)) * (bz ? fz : 1.0f - fz);
+        if (FIXED) {
+            const long long lo = (long long)__float2int_rn(w * g.x * cx.to_fixed);
+            const long long hi = (long long)__float2int_rn(w * g.y * cx.to_fixed);
+            atomicAdd(&lds64[a], (unsigned long long)((hi << 32) + lo));
+        } else {
+            unsafeAtomicAdd(&lds_tile[2 * a], w * g.x);
+            unsafeAtomicAdd(&lds_tile[2 * a + 1], w * g.y);
+        }
+    }
+}
+
+// Streaming loop: a thread owns 4 consecutive samples per iteration -- 3 x 16 B of positions + 2 x 16 B of
+// gradients, all 16-byte loads -- and the next group is in flight while the current one is applied.
+template <bool FIXED, bool HASHED>
+__device__ __forceinline__ void bwd_stream(const BwdCtx& cx, float* lds_tile, const float* __restrict__ x01,
+                                           const float2* __restrict__ g_l, int64_t n, int rep, int R) {
+    constexpr int kGroup = 4;
+    const int64_t n_full = n / kGroup;
+    const float4* x4 = reinterpret_cast<const float4*>(x01);
+    const float4* g4 = reinterpret_cast<const float4*>(g_l);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x01) | reinterpret_cast<uintptr_t>(g_l)) & 15) == 0;
+    if (aligned) {
+        int64_t grp = (int64_t)rep * kBwdThreads + threadIdx.x;
+        const int64_t gstride = (int64_t)R * kBwdThreads;
+        float4 xa = {}, xb = {}, xc = {}, ga = {}, gb = {};
+        if (grp < n_full) { xa = x4[3 * grp]; xb = x4[3 * grp + 1]; xc = x4[3 * grp + 2]; ga = g4[2 * grp]; gb = g4[2 * grp + 1]; }
+        while (grp < n_full) {
+            const float4 cxa = xa, cxb = xb, cxc = xc, cga = ga, cgb = gb;
+            grp += gstride;
+            if (grp < n_full) { xa = x4[3 * grp]; xb = x4[3 * grp + 1]; xc = x4[3 * grp + 2]; ga = g4[2 * grp]; gb = g4[2 * grp + 1]; }
+            if (!(cga.x == 0.f && cga.y == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, make_float2(cga.x, cga.y), cxa.x, cxa.y, cxa.z);
+            if (!(cga.z == 0.f && cga.w == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, make_float2(cga.z, cga.w), cxa.w, cxb.x, cxb.y);
+            if (!(cgb.x == 0.f && cgb.y == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, make_float2(cgb.x, cgb.y), cxb.z, cxb.w, cxc.x);
+            if (!(cgb.z == 0.f && cgb.w == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, make_float2(cgb.z, cgb.w), cxc.y, cxc.z, cxc.w);
+        }
+        if (rep == 0) {     // ragged tail (n % 4 samples)
+            const int64_t i = n_full * kGroup + threadIdx.x;
+            if (i < n) { const float2 g = g_l[i]; if (!(g.x == 0.f && g.y == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, g, x01[3 * i], x01[3 * i + 1], x01[3 * i + 2]); }
+        }
+    } else {
+        for (int64_t i = (int64_t)rep * kBwdThreads + threadIdx.x; i < n; i += (int64_t)R * kBwdThreads) {
+            const float2 g = g_l[i];
+            if (!(g.x == 0.f && g.y == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, g, x01[3 * i], x01[3 * i + 1], x01[3 * i + 2]);
+        }
+    }
 }
 
 // FIXED = true: the two features of an entry are accumulated as two signed 32-bit fixed-point fields packed in one
@@ -222,97 +366,35 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    int32_t* __restrict__ overflow_flag, int64_t n) {
     extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats
     unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
+    const long long t_start = (tp.dbg_off > 0) ? (long long)wall_clock64() : 0;
     int b = blockIdx.x, l = 0;
     while (b >= tp.tiles_of[l] * tp.replicas_of[l]) { b -= tp.tiles_of[l] * tp.replicas_of[l]; ++l; }
     const int R = tp.replicas_of[l];
     const uint32_t n_tiles = (uint32_t)tp.tiles_of[l];
     const uint32_t t = (uint32_t)(b / R);
     const int rep = b % R;
-    const float scale = gp.scale[l];
-    const uint32_t res = gp.res[l], size = gp.size[l];
+    const uint32_t size = gp.size[l];
     const bool hashed = gp.hashed[l] != 0;
-    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     for (int i = threadIdx.x; i < 2 * kTileEntries / 4; i += kBwdThreads)
         reinterpret_cast<float4*>(lds_tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    float to_fixed = 1.0f, from_fixed = 1.0f;
+    float from_fixed = 1.0f;
+    BwdCtx cx;
+    cx.scale = gp.scale[l]; cx.res = gp.res[l]; cx.r2 = cx.res * cx.res; cx.size = size; cx.mask = size - 1u;
+    cx.n_tiles = n_tiles; cx.t = t; cx.inv_tiles = 1.0f / (float)n_tiles;
+    cx.smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+    cx.to_fixed = 1.0f;
     if (FIXED) {
         const float am = level_absmax[l];
         int e = 0;
         if (am > 0.f) (void)frexpf(am, &e);                         // am < 2^e
         const int sh = 31 - tp.fixed_headroom_log2 - e;               // units per 1.0 = 2^sh
-        to_fixed = ldexpf(1.0f, sh);
+        cx.to_fixed = ldexpf(1.0f, sh);
         from_fixed = ldexpf(1.0f, -sh);
     }
     const float2* g_l = dfeat + (int64_t)l * n;
-    const uint32_t r2 = res * res;
-    const int64_t stride = (int64_t)R * kBwdThreads;
-    // software pipeline: the next sample's gradient and position are in flight while this one is applied
-    int64_t i = (int64_t)rep * kBwdThreads + threadIdx.x;
-    float2 g_nx = make_float2(0.f, 0.f);
-    float x_nx = 0.f, y_nx = 0.f, z_nx = 0.f;
-    if (i < n) { g_nx = g_l[i]; x_nx = x01[3 * i]; y_nx = x01[3 * i + 1]; z_nx = x01[3 * i + 2]; }
-    for (int64_t base = (int64_t)rep * kBwdThreads; base < n; base += stride) {
-        const float2 g = g_nx;
-        const float x = x_nx, y = y_nx, z = z_nx;
-        const bool live = (i < n) && !(g.x == 0.f && g.y == 0.f);
-        i += stride;
-        g_nx = make_float2(0.f, 0.f);
-        if (i < n) { g_nx = g_l[i]; x_nx = x01[3 * i]; y_nx = x01[3 * i + 1]; z_nx = x01[3 * i + 2]; }
-        if (!live) continue;
-        const float px = add_rn(mul_rn(x, scale), 0.5f), py = add_rn(mul_rn(y, scale), 0.5f), pz = add_rn(mul_rn(z, scale), 0.5f);
-        const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-        float fx = px - flx, fy = py - fly, fz = pz - flz;
-        const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
-        uint32_t ay[2], az[2];
-        if (hashed) { ay[0] = gy * kPrimeY; ay[1] = ay[0] + kPrimeY; az[0] = gz * kPrimeZ; az[1] = az[0] + kPrimeZ; }
-        else { ay[0] = gy * res; ay[1] = ay[0] + res; az[0] = gz * r2; az[1] = az[0] + r2; }
-        const uint32_t m = size - 1u;
-        uint32_t match = 0;     // bit k: corner k (bit0 = x, bit1 = y, bit2 = z) is owned by this tile
-        if (hashed && gx < (uint32_t)(kTileEntries - 1)) {
-            // the tile of a hashed corner depends on (y,z) only while gx+1 < 2^14: test x-pairs
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                match |= (((((ay[c & 1] ^ az[c >> 1]) & m) / (uint32_t)kTileEntries) == t) ? 3u : 0u) << (2 * c);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                uint32_t idx, local;
-                bool own;
-                if (hashed) { idx = ((gx + (uint32_t)(k & 1)) ^ ay[(k >> 1) & 1] ^ az[k >> 2]) & m; own = (idx / (uint32_t)kTileEntries) == t; }
-                else {
-                    idx = (gx + (uint32_t)(k & 1)) + ay[(k >> 1) & 1] + az[k >> 2];
-                    if (idx >= size) idx = idx % size;
-                    own = dense_owner(idx, n_tiles, t, &local);
-                }
-                match |= (own ? 1u : 0u) << k;
-            }
-        }
-        if (match == 0) continue;
-        if (smooth) { fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz); }
-        while (match) {
-            const int k = __ffs(match) - 1;
-            match &= match - 1u;
-            const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
-            const uint32_t cy = by ? ay[1] : ay[0], cz = bz ? az[1] : az[0];
-            uint32_t a;
-            if (hashed) a = (((gx + (uint32_t)bx) ^ cy ^ cz) & m) - t * (uint32_t)kTileEntries;
-            else {
-                uint32_t idx = (gx + (uint32_t)bx) + cy + cz;
-                if (idx >= size) idx = idx % size;
-                dense_owner(idx, n_tiles, t, &a);
-            }
-            const float w = ((bx ? fx : 1.0f - fx) * (by ? fy : 1.0f - fy)) * (bz ? fz : 1.0f - fz);
-            if (FIXED) {
-                const long long lo = (long long)__float2int_rn(w * g.x * to_fixed);
-                const long long hi = (long long)__float2int_rn(w * g.y * to_fixed);
-                atomicAdd(&lds64[a], (unsigned long long)((hi << 32) + lo));
-            } else {
-                unsafeAtomicAdd(&lds_tile[2 * a], w * g.x);
-                unsafeAtomicAdd(&lds_tile[2 * a + 1], w * g.y);
-            }
-        }
-    }
+    if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n, rep, R);
+    else bwd_stream<FIXED, false>(cx, lds_tile, x01, g_l, n, rep, R);
     __syncthreads();
     int32_t field_max = 0;
     // ---- write back: local slot j of tile t is entry e(j)
@@ -339,6 +421,8 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         out[e] = v;
     }
     if (FIXED && overflow_flag && field_max >= (1 << 30)) atomicOr(overflow_flag, 1);
+    if (tp.dbg_off > 0 && threadIdx.x == 0)
+        reinterpret_cast<long long*>(ws + tp.dbg_off)[blockIdx.x] = (long long)wall_clock64() - t_start;
 }
 
 // sum the replica slabs (ws[level][replica][entry]) of the replicated (coarse) levels into the gradient table
@@ -434,8 +518,10 @@ extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid)
     GridParams gp;
     if (fill_params(grid, &gp)) return -1;
     TileParams tp; int nb; int64_t ws;
-    plan_tiles(gp, &tp, &nb, &ws);
-    return ws * (int64_t)sizeof(float2) + 16;
+    int64_t ws2;
+    plan_tiles(gp, false, &tp, &nb, &ws);
+    plan_tiles(gp, true, &tp, &nb, &ws2);
+    return (ws > ws2 ? ws : ws2) * (int64_t)sizeof(float2) + 16;
 }
 
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
@@ -449,11 +535,13 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     TileParams tp;
     int n_blocks = 0;
     int64_t ws_entries = 0;
-    plan_tiles(gp, &tp, &n_blocks, &ws_entries);
+    plan_tiles(gp, level_absmax != nullptr, &tp, &n_blocks, &ws_entries);
     PERF_REQUIRE(ws_entries == 0 || (workspace && workspace_bytes >= ws_entries * (int64_t)sizeof(float2)),
                  "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(ws_entries * sizeof(float2)));
     tp.accumulate = accumulate;
     tp.fixed_headroom_log2 = 12;
+    tp.dbg_off = 0;
+    if (getenv("PERF_BWD_DEBUG") && workspace_bytes >= (ws_entries + 4096) * (int64_t)sizeof(float2)) tp.dbg_off = ws_entries + 1;
     const int lds_bytes = 2 * kTileEntries * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
