@@ -225,6 +225,15 @@ def main():
             achieved = samples_per_step * flop / (ms_l * 1e-3) / 1e12
             roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(achieved / MFMA_PEAK_TFLOPS, 5), 'traffic': None, 'ms_per_launch': round(ms_l, 4)}
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same workload (profiles/)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels']
+            if roof['kernel'] in pmc and args.mode == 'train_geo' and args.rays_per_gpu == 8192 and args.spp == 128:
+                roof['traffic'] = pmc[roof['kernel']]['hbm_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 fetch correction)'
+                roof['algorithmic_bytes_per_launch'] = samples_per_step * per_sample if kind == 'hbm' else None
+        except Exception:
+            pass
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.spp, args.cpu_rays)

@@ -114,6 +114,12 @@ int perf_points_normalize(const float* x, const float* aabb, float* x01, uint8_t
 int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* table16,
                       void* feat16, int64_t n, int dtype, void* stream);
 
+/* Two tables of identical geometry (PeRF's density and colour grids) at the same points in one pass:
+ * corner indices/weights are shared.  Same layouts as perf_hashgrid_fwd. */
+int perf_hashgrid_fwd2(const perf_grid_desc* grid, const float* x01, const void* table16_a,
+                       const void* table16_b, void* feat16_a, void* feat16_b, int64_t n, int dtype,
+                       void* stream);
+
 /* Same with fp32 table and fp32 output feat[(l*n+i)*2+f] (tcnn.Encoding as used by
  * modules/geo_predictors/pano_joint_predictor.py:30-41 keeps full precision available). */
 int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const float* table,

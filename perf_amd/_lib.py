@@ -41,6 +41,7 @@ _SIGS = {
     'perf_points_from_rays': (c_int, [P, P, P, P, P, POINTER(c_float), P, P, c_int64, P]),
     'perf_points_normalize': (c_int, [P, POINTER(c_float), P, P, c_int64, P]),
     'perf_hashgrid_fwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P]),
+    'perf_hashgrid_fwd2': (c_int, [POINTER(GridDesc), P, P, P, P, P, c_int64, c_int, P]),
     'perf_hashgrid_fwd_f32': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
     'perf_hashgrid_bwd_workspace_bytes': (c_int64, [POINTER(GridDesc)]),
     'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P, P, P, c_int64, P]),

@@ -128,6 +128,42 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const 
     }
 }
 
+// Two tables with the SAME grid geometry (PeRF's density and colour fields, ngp_nerf.py:96-134) evaluated at the
+// same points: corner indices and weights are computed once, 16 gathers are in flight per (sample, level).
+template <typename T16>
+__global__ __launch_bounds__(256) void hashgrid_fwd2_kernel(GridParams gp, const float* __restrict__ x01,
+                                                            const uint32_t* __restrict__ table_a,
+                                                            const uint32_t* __restrict__ table_b,
+                                                            uint32_t* __restrict__ feat_a, uint32_t* __restrict__ feat_b,
+                                                            int64_t n) {
+    const int group = blockIdx.x & 7;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int l = level_of(group, pass, gp.n_levels);
+        if (l < 0) continue;
+        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+        const uint32_t* ta = table_a + gp.offset[l];
+        const uint32_t* tb = table_b + gp.offset[l];
+        uint32_t va[8], vb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { va[k] = ta[c.idx[k]]; vb[k] = tb[c.idx[k]]; }
+        float w[8];
+        corner_weights(c.f, smooth, w);
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a0 = fmaf(w[k], T16::lo(va[k]), a0); a1 = fmaf(w[k], T16::hi(va[k]), a1);
+            b0 = fmaf(w[k], T16::lo(vb[k]), b0); b1 = fmaf(w[k], T16::hi(vb[k]), b1);
+        }
+        feat_a[(int64_t)l * n + i] = T16::pack(a0, a1);
+        feat_b[(int64_t)l * n + i] = T16::pack(b0, b1);
+    }
+}
+
 __global__ __launch_bounds__(256) void hashgrid_fwd_f32_kernel(GridParams gp, const float* __restrict__ x01,
                                                                const float2* __restrict__ table,
                                                                float2* __restrict__ feat, int64_t n) {
@@ -498,6 +534,26 @@ extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, c
         hipLaunchKernelGGL(hashgrid_fwd_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n);
     else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
     PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
+    return PERF_OK;
+}
+
+extern "C" int perf_hashgrid_fwd2(const perf_grid_desc* grid, const float* x01, const void* table16_a,
+                                  const void* table16_b, void* feat16_a, void* feat16_b, int64_t n, int dtype,
+                                  void* stream) {
+    GridParams gp;
+    int rc = fill_params(grid, &gp);
+    if (rc) return rc;
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(x01 && table16_a && table16_b && feat16_a && feat16_b, "NULL pointer");
+    dim3 g(grouped_grid(n)), b(256);
+    if (dtype == PERF_DTYPE_BF16)
+        hipLaunchKernelGGL(hashgrid_fwd2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16_a,
+                           (const uint32_t*)table16_b, (uint32_t*)feat16_a, (uint32_t*)feat16_b, n);
+    else if (dtype == PERF_DTYPE_FP16)
+        hipLaunchKernelGGL(hashgrid_fwd2_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16_a,
+                           (const uint32_t*)table16_b, (uint32_t*)feat16_a, (uint32_t*)feat16_b, n);
+    else { set_error("perf_hashgrid_fwd2: bad dtype %d", dtype); return PERF_E_INVALID; }
+    PERF_LAUNCH_CHECK("perf_hashgrid_fwd2");
     return PERF_OK;
 }
 

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import ops
 from . import tcnn
-from .tcnn import _FieldFn
+from .tcnn import _DualFieldFn, _FieldFn
 
 PER_LEVEL_SCALE = 1.4472692012786865
 
@@ -108,6 +108,14 @@ class NGPNeRF(nn.Module):
 
     def rgb_at(self, x01, sel):
         return _FieldFn.apply(x01, self.app_mlp.params, sel, self.app_mlp)
+
+    def density_rgb_at(self, x01, sel, geo_grad=True, app_grad=False):
+        """sigma [n] and rgb [n,3] at the same points with ONE shared encode pass (both grids have the same geometry).
+        geo_grad / app_grad = False detach the respective parameters (nerf_renderer.py:166-179 no_grad branches)."""
+        pg = self.geo_mlp.params if geo_grad else self.geo_mlp.params.detach()
+        pa = self.app_mlp.params if app_grad else self.app_mlp.params.detach()
+        sig, rgb = _DualFieldFn.apply(x01, pg, pa, sel, self.geo_mlp, self.app_mlp)
+        return sig[:, 0], rgb
 
     def forward(self, positions, directions=None, contract=None):
         if self.use_viewdirs and (directions is not None):

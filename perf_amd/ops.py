@@ -136,6 +136,17 @@ def hashgrid_fwd(grid: GridConfig, x01, table16):
     return feat
 
 
+def hashgrid_fwd2(grid: GridConfig, x01, table16_a, table16_b):
+    """Both tables (same geometry) at the same points -> (feat_a, feat_b), each [L, n, 2] 16-bit."""
+    n = x01.shape[0]
+    fa = torch.empty(grid.n_levels, n, 2, dtype=table16_a.dtype, device=x01.device)
+    fb = torch.empty(grid.n_levels, n, 2, dtype=table16_a.dtype, device=x01.device)
+    d = grid.desc()
+    _call('perf_hashgrid_fwd2', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(table16_a), _p(table16_b), _p(fa), _p(fb), n,
+          dtype_code(table16_a.dtype), _stream())
+    return fa, fb
+
+
 def hashgrid_fwd_f32(grid: GridConfig, x01, table):
     n = x01.shape[0]
     feat = torch.empty(grid.n_levels, n, 2, dtype=torch.float32, device=x01.device)

@@ -78,6 +78,8 @@ class NeRFOCCRenderer(nn.Module):
                     'opacities': torch.zeros(n_rays, 1, device=dev)}
 
         x01, sel = nerf.sample_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
+        # (A shared-index pass over both grids -- perf_hashgrid_fwd2 -- measured 2x SLOWER than two passes: the
+        #  per-XCD working set doubles to 4 MiB = the whole L2.  The fields are therefore queried one after the other.)
         if grad_geo:
             sigmas = nerf.density_at(x01, sel)
         elif sig0 is not None:

@@ -72,15 +72,46 @@ class _FieldFn(torch.autograd.Function):
         x01, w16, feat, sel = ctx.saved_tensors
         module = ctx.module
         sel = sel if ctx.has_sel else None
-        n_net = module.mlp.n_params
-        dout = dout.contiguous().float()
-        fixed = GRID_GRAD_ACCUM == 'fixed'          # module-level switch, see check_fixed_point_overflow()
-        res = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout, sel, want_absmax=fixed)
-        dfeat, dw = res[0], res[1]
-        grad = torch.empty(n_net + module.grid.n_params, dtype=torch.float32, device=x01.device)
-        grad[:n_net] = dw
-        ops.hashgrid_bwd_into(module.grid, x01, dfeat, grad[n_net:], level_absmax=res[2] if fixed else None)
-        return None, grad, None, None
+        return None, _field_backward(module, x01, w16, feat, sel, dout), None, None
+
+
+def _field_backward(module, x01, w16, feat, sel, dout):
+    n_net = module.mlp.n_params
+    fixed = GRID_GRAD_ACCUM == 'fixed'          # module-level switch, see check_fixed_point_overflow()
+    res = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout.contiguous().float(), sel, want_absmax=fixed)
+    grad = torch.empty(n_net + module.grid.n_params, dtype=torch.float32, device=x01.device)
+    grad[:n_net] = res[1]
+    ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=res[2] if fixed else None)
+    return grad
+
+
+class _DualFieldFn(torch.autograd.Function):
+    """Two fields with the same grid geometry (PeRF's geo and app networks) at the same points: one encode pass
+    shares the corner indices, then each network's MLP.  Returns (out_a, out_b)."""
+
+    @staticmethod
+    def forward(ctx, x01, params_a, params_b, sel, mod_a, mod_b):
+        ctx.set_materialize_grads(False)
+        wa, wb = mod_a.working_copy(params_a), mod_b.working_copy(params_b)
+        na, nb = mod_a.mlp.n_params, mod_b.mlp.n_params
+        fa, fb = ops.hashgrid_fwd2(mod_a.grid, x01, wa[na:], wb[nb:])
+        out_a = ops.mlp_fwd(mod_a.mlp, wa[:na], fa, sel)
+        out_b = ops.mlp_fwd(mod_b.mlp, wb[:nb], fb, sel)
+        ctx.mods = (mod_a, mod_b)
+        ctx.has_sel = sel is not None
+        ctx.save_for_backward(x01, wa, wb, fa, fb, sel if sel is not None else torch.empty(0, device=x01.device))
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, da, db):
+        x01, wa, wb, fa, fb, sel = ctx.saved_tensors
+        sel = sel if ctx.has_sel else None
+        ga = gb = None
+        if ctx.needs_input_grad[1] and da is not None:
+            ga = _field_backward(ctx.mods[0], x01, wa, fa, sel, da)
+        if ctx.needs_input_grad[2] and db is not None:
+            gb = _field_backward(ctx.mods[1], x01, wb, fb, sel, db)
+        return None, ga, gb, None, None, None
 
 
 class NetworkWithInputEncoding(nn.Module):

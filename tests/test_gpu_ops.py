@@ -418,3 +418,13 @@ def test_hashgrid_bwd_fixed_point_mode(ops):
     dfe, dw, am = ops.mlp_bwd(mlp, w, feat, torch.randn(n, 1, generator=g).cuda(), want_absmax=True)
     true = dfe.abs().amax(dim=(1, 2))
     assert bool((am >= true).all()) and float(am.max()) == float(true.max())      # a bound per level, tight overall
+
+
+def test_hashgrid_fwd2_equals_two_single_passes(ops):
+    cfg = _grid_cfg()
+    g = torch.Generator().manual_seed(31)
+    ta = (torch.rand(cfg.n_params, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    tb = (torch.rand(cfg.n_params, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    x = torch.rand(4099, 3, generator=g).cuda()
+    fa, fb = ops.hashgrid_fwd2(cfg, x, ta, tb)
+    assert torch.equal(fa, ops.hashgrid_fwd(cfg, x, ta)) and torch.equal(fb, ops.hashgrid_fwd(cfg, x, tb))
