@@ -247,6 +247,14 @@ int perf_distloss_bwd(const float* w, const float* t_starts, const float* t_ends
                       const int32_t* packed_info, int64_t n_rays, float scale, float* g_w,
                       void* stream);
 
+/* ---- hierarchical resampling (nerfacc importance_sampling via PropNetEstimator.sampling,
+ *      modules/scene/nerf_renderer.py:60-70; dead in the reference, semantics restated in oracle/) ------------- */
+
+/* Per ray: n_in intervals with edges s_in [R, n_in+1] and CDF cdf [R, n_in+1] (non-decreasing, 0..1) ->
+ * n_out+1 sorted edges s_out [R, n_out+1] at u_j = (j + tau_r)/(n_out+1); tau [R] (stratified) or NULL (0.5). */
+int perf_pdf_resample(const float* s_in, const float* cdf, const float* tau, int64_t n_rays, int32_t n_in,
+                      int32_t n_out, float* s_out, void* stream);
+
 /* ---- occupancy pre-grid (modules/dataset/sup_info.py:304-330) ------------------------------ */
 int perf_occ_splat(const float* rays_o, const float* rays_d, const float* dist, int64_t n,
                    int32_t res, uint8_t* occ, void* stream);

@@ -492,6 +492,50 @@ def flatten_eff_distloss(w, m, interval, ray_id):
     return (uni + bi) / n_rays
 
 
+def pdf_resample(s_in: np.ndarray, cdf: np.ndarray, n_out: int, tau=None) -> np.ndarray:
+    """Inverse-CDF resampling of intervals (nerfacc importance_sampling as used by PropNetEstimator.sampling,
+    nerf_renderer.py:60-70; A.6).  The path is dead in the reference and the package is absent: this is the repo's own
+    definition.  edges u_j = fl(fl(j + tau_r) / (n_out+1)), j = 0..n_out (tau_r = 0.5 unless stratified);
+    k = last interval with cdf_k <= u_j; t_j = s_k + (u_j-cdf_k)/(cdf_{k+1}-cdf_k) * (s_{k+1}-s_k), unfused fp32."""
+    s_in = np.asarray(s_in, F32); cdf = np.asarray(cdf, F32)
+    R, n1 = s_in.shape
+    n_in = n1 - 1
+    tau = np.full(R, 0.5, F32) if tau is None else np.asarray(tau, F32)
+    j = np.arange(n_out + 1, dtype=F32)[None, :]
+    u = ((j + tau[:, None]).astype(F32) / F32(n_out + 1)).astype(F32)
+    out = np.zeros((R, n_out + 1), F32)
+    for r in range(R):
+        k = np.clip(np.searchsorted(cdf[r], u[r], side='right') - 1, 0, n_in - 1)
+        c0, c1, s0, s1 = cdf[r][k], cdf[r][k + 1], s_in[r][k], s_in[r][k + 1]
+        den = (c1 - c0).astype(F32)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            frac = ((u[r] - c0).astype(F32) / den).astype(F32)
+            v = (s0 + (frac * (s1 - s0).astype(F32)).astype(F32)).astype(F32)
+        v = np.where(den > 0, v, s0)
+        out[r] = np.minimum(np.maximum(v, s0), s1)
+    return out
+
+
+def prop_sampling(sigma_fns, prop_samples, num_samples, n_rays, near, far, taus=None):
+    """PropNetEstimator.sampling restated (A.6): start from CDF [0,1]; per proposal level resample n edges, map
+    s -> t uniformly on [near, far], query sigma at the intervals, cdf = 1 - [T, 0]; final level draws num_samples.
+    sigma_fns take (t_starts, t_ends) numpy [R, n] and return sigma [R, n]."""
+    s = np.concatenate([np.zeros((n_rays, 1), F32), np.ones((n_rays, 1), F32)], 1)
+    cdf = s.copy()
+    levels = list(zip(sigma_fns, prop_samples)) + [(None, num_samples)]
+    for li, (fn, n_out) in enumerate(levels):
+        s = pdf_resample(s, cdf, n_out, None if taus is None else taus[li])
+        t = (F32(near) + (s * F32(far - near)).astype(F32)).astype(F32)
+        ts, te = t[:, :-1], t[:, 1:]
+        if fn is None:
+            return ts, te
+        sd = (fn(ts, te).astype(F32) * (te - ts).astype(F32)).astype(F32)
+        ex = np.cumsum(sd, -1, dtype=F32) - sd
+        trans = np.exp(-ex).astype(F32)
+        cdf = (F32(1.0) - np.concatenate([trans, np.zeros((n_rays, 1), F32)], 1)).astype(F32)
+        cdf = np.maximum.accumulate(np.clip(cdf, 0, 1), axis=1).astype(F32)
+
+
 # --------------------------------------------------------------------------------------
 # a6  the renderer  (modules/scene/nerf_renderer.py:112-209)
 # --------------------------------------------------------------------------------------

@@ -358,3 +358,42 @@ extern "C" int perf_pack_info(const int64_t* ray_indices, int64_t n, int64_t n_r
     PERF_LAUNCH_CHECK("perf_pack_info");
     return PERF_OK;
 }
+
+// ---- hierarchical (inverse-CDF) resampling: nerfacc importance_sampling / PropNetEstimator.sampling, SURVEY.md A.6.
+// Dead in the reference (nerf_renderer.py:60-73 raises NameError before use), so the semantics are this repo's own
+// restatement (oracle/perf_oracle.py:pdf_resample):  edges u_j = (j + tau_r) / (n_out + 1), j = 0..n_out, tau_r = 0.5
+// or the per-ray stratified draw; t_j = s_k + (u_j - cdf_k) / (cdf_{k+1} - cdf_k) * (s_{k+1} - s_k) for the interval
+// k with cdf_k <= u_j < cdf_{k+1}.  One thread per output edge, binary search in the ray's (L1-resident) CDF row.
+namespace perf {
+__global__ __launch_bounds__(256) void pdf_resample_kernel(const float* __restrict__ s_in, const float* __restrict__ cdf,
+                                                           const float* __restrict__ tau, int64_t n_rays, int n_in,
+                                                           int n_out, float* __restrict__ s_out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = n_rays * (int64_t)(n_out + 1);
+    if (t >= total) return;
+    const int64_t r = t / (n_out + 1);
+    const int j = (int)(t % (n_out + 1));
+    const float* c = cdf + r * (int64_t)(n_in + 1);
+    const float* s = s_in + r * (int64_t)(n_in + 1);
+    const float u = __fdiv_rn(add_rn((float)j, tau ? tau[r] : 0.5f), (float)(n_out + 1));
+    int lo = 0, hi = n_in;                 // largest k in [0, n_in-1] with c[k] <= u
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c[mid] <= u) lo = mid; else hi = mid; }
+    const float c0 = c[lo], c1 = c[lo + 1], s0 = s[lo], s1 = s[lo + 1];
+    const float den = sub_rn(c1, c0);
+    float v = s0;
+    if (den > 0.f) v = add_rn(s0, mul_rn(__fdiv_rn(sub_rn(u, c0), den), sub_rn(s1, s0)));
+    s_out[t] = fminf(fmaxf(v, s0), s1);
+}
+}  // namespace perf
+
+extern "C" int perf_pdf_resample(const float* s_in, const float* cdf, const float* tau, int64_t n_rays, int32_t n_in,
+                                 int32_t n_out, float* s_out, void* stream) {
+    PERF_REQUIRE(n_rays >= 0 && n_in >= 1 && n_out >= 1, "perf_pdf_resample: bad arguments");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(s_in && cdf && s_out, "NULL pointer");
+    const int64_t total = n_rays * (int64_t)(n_out + 1);
+    hipLaunchKernelGGL(perf::pdf_resample_kernel, dim3((unsigned)perf::div_up(total, 256)), dim3(256), 0, perf::as_stream(stream),
+                       s_in, cdf, tau, n_rays, (int)n_in, (int)n_out, s_out);
+    PERF_LAUNCH_CHECK("perf_pdf_resample");
+    return PERF_OK;
+}

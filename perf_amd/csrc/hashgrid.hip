@@ -101,10 +101,15 @@ __device__ __forceinline__ int level_of(int group, int pass, int L) {
 template <typename T16>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const float* __restrict__ x01,
                                                            const uint32_t* __restrict__ table,
-                                                           uint32_t* __restrict__ feat, int64_t n) {
-    const int group = blockIdx.x & 7;
-    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
-    if (i >= n) return;
+                                                           uint32_t* __restrict__ feat, int64_t n, int xcd_affinity) {
+    // xcd_affinity == 0 (experiment only): consecutive blocks of one XCD walk through all level groups, so every L2
+    // sees the whole table -- used to measure what the level-group <-> XCD pinning is worth.
+    const int nchunks = (int)(gridDim.x >> 3);
+    const int group = xcd_affinity ? (int)(blockIdx.x & 7) : (int)((blockIdx.x >> 3) & 7);
+    const int64_t chunk = xcd_affinity ? (int64_t)(blockIdx.x >> 3)
+                                       : (int64_t)(blockIdx.x & 7) * ((nchunks + 7) >> 3) + (int64_t)(blockIdx.x >> 6);
+    const int64_t i = chunk * 256 + threadIdx.x;
+    if (i >= n || (!xcd_affinity && chunk >= nchunks)) return;
     const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
 #pragma unroll
@@ -527,11 +532,12 @@ extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, c
     PERF_REQUIRE(n >= 0 && n < (int64_t(1) << 31) * 16, "n out of range");
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(x01 && table16 && feat16, "NULL pointer");
-    dim3 g(grouped_grid(n)), b(256);
+    static const int xcd_affinity = getenv("PERF_FWD_NO_XCD_AFFINITY") ? 0 : 1;
+    dim3 g(xcd_affinity ? grouped_grid(n) : (unsigned)(div_up(div_up(n, 256), 8) * 64)), b(256);
     if (dtype == PERF_DTYPE_BF16)
-        hipLaunchKernelGGL(hashgrid_fwd_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n);
+        hipLaunchKernelGGL(hashgrid_fwd_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, xcd_affinity);
     else if (dtype == PERF_DTYPE_FP16)
-        hipLaunchKernelGGL(hashgrid_fwd_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n);
+        hipLaunchKernelGGL(hashgrid_fwd_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, xcd_affinity);
     else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
     PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
     return PERF_OK;

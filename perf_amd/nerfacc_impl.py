@@ -223,13 +223,47 @@ class OccGridEstimator(nn.Module):
 
 
 class PropNetEstimator(nn.Module):
-    """Imported by PeRF (nerf.py:24) but only reachable through estimator_type == 'prop', a path that is dead
-    in the reference (NameError at nerf_renderer.py:73).  Constructible so that imports resolve."""
+    """nerfacc.estimators.prop_net.PropNetEstimator.sampling (forward): proposal-network guided hierarchical
+    resampling.  Reachable in PeRF only through estimator_type == 'prop', which is dead in the
+    reference (NameError at nerf_renderer.py:73; the proposal networks are never trained), so this follows the
+    repo's own restatement (oracle/perf_oracle.py:prop_sampling) and supports inference only."""
 
     def __init__(self, optimizer=None, scheduler=None):
         super().__init__()
         self.optimizer = optimizer
         self.scheduler = scheduler
+        self.prop_cache = []
 
-    def sampling(self, *args, **kwargs):
-        raise NotImplementedError('proposal-network sampling: see perf_amd.resample for the hierarchical resampler')
+    @torch.no_grad()
+    def sampling(self, prop_sigma_fns, prop_samples, num_samples, n_rays, near_plane, far_plane,
+                 sampling_type='uniform', stratified=False, requires_grad=False, taus=None):
+        """-> (t_starts, t_ends) [n_rays, num_samples].  taus: optional list of per-ray stratified draws (tests)."""
+        if requires_grad:
+            raise NotImplementedError('proposal-network training is not on any live PeRF path')
+        if sampling_type != 'uniform':
+            raise NotImplementedError("PeRF samples with sampling_type='uniform' (nerf_renderer.py:67)")
+        dev = next(iter(self.buffers()), torch.empty(0, device='cuda')).device if False else torch.device('cuda', torch.cuda.current_device())
+        s = torch.cat([torch.zeros(n_rays, 1, device=dev), torch.ones(n_rays, 1, device=dev)], -1)
+        cdf = s.clone()
+        levels = list(zip(prop_sigma_fns, prop_samples)) + [(None, num_samples)]
+        for li, (fn, n_out) in enumerate(levels):
+            tau = None
+            if stratified:
+                tau = taus[li] if taus is not None else torch.rand(n_rays, device=dev)
+            s = ops.pdf_resample(s, cdf, n_out, tau)
+            t_vals = near_plane + s * (far_plane - near_plane)
+            t_starts, t_ends = t_vals[:, :-1].contiguous(), t_vals[:, 1:].contiguous()
+            if fn is None:
+                return t_starts, t_ends
+            sigmas = fn(t_starts, t_ends)
+            sd = sigmas * (t_ends - t_starts)
+            trans = torch.exp(-(torch.cumsum(sd, -1) - sd))                      # exclusive: T_i = exp(-sum_{j<i} sd_j)
+            cdf = 1.0 - torch.cat([trans, torch.zeros_like(trans[:, :1])], -1)
+            cdf = torch.cummax(cdf.clamp(0, 1), -1).values.contiguous()          # sigma = inf tails make NaN-free, monotone CDFs
+
+
+def render_weight_from_alpha(alphas):
+    """Dense [R, n] alpha compositing: T_i = prod_{j<i} (1 - alpha_j), w = T * alpha (the function
+    nerf_renderer.py:73 calls without importing it)."""
+    T = torch.cumprod(torch.cat([torch.ones_like(alphas[:, :1]), 1.0 - alphas[:, :-1]], -1), -1)
+    return T * alphas, T

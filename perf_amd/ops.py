@@ -364,3 +364,12 @@ def occ_splat(rays_o, rays_d, dist, res):
     _call('perf_occ_splat', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(dist.reshape(-1), 'dist')), n,
               int(res), _p(occ), _stream())
     return occ
+
+
+def pdf_resample(s_in, cdf, n_out, tau=None):
+    """s_in, cdf [R, n_in+1] -> s_out [R, n_out+1] (inverse-CDF resampling, see perf_pdf_resample)."""
+    R, n1 = s_in.shape
+    out = torch.empty(R, n_out + 1, dtype=torch.float32, device=s_in.device)
+    _call('perf_pdf_resample', _p(_f32(s_in.contiguous(), 's_in')), _p(_f32(cdf.contiguous(), 'cdf')), _p(tau), R, n1 - 1,
+          int(n_out), _p(out), _stream())
+    return out

@@ -110,3 +110,55 @@ class NeRFOCCRenderer(nn.Module):
         return {'is_valid': True, 'rgb': colors, 'distance': distances, 'weights': weights, 'opacities': opacities,
                 'trans': trans, 't_starts': t_starts, 't_ends': t_ends, 'ray_indices': ray_indices,
                 'packed_info': packed}
+
+
+class NeRFPropRenderer(nn.Module):
+    """Mirror of modules/scene/nerf_renderer.py:10-102 (proposal-network renderer).  That path is dead in the
+    reference (render_weight_from_alpha is never imported, :73); this is the inference-only counterpart built on the
+    hierarchical resampling kernel: 128 -> 64 proposal samples, 64 final samples, near 1e-2, far 2, dense layout."""
+
+    def __init__(self, max_radius, bg_color):
+        super().__init__()
+        self.max_radius = max_radius
+        self.bg_color = bg_color
+        assert self.bg_color in ['rand_noise', 'black', 'white']
+        self.n_samples = 64
+        self.n_samples_per_prop = [128, 64]
+
+    @torch.no_grad()
+    def render(self, nerf, prop_networks, estimator, rays_o, rays_d, near, far, sampling_requires_grad=False, taus=None):
+        from .nerfacc_impl import render_weight_from_alpha
+        n_rays = rays_o.shape[0]
+        dev = rays_o.device
+
+        def positions(t_starts, t_ends):
+            return rays_o[:, None, :] + rays_d[:, None, :] * (t_starts + t_ends)[..., None] / 2.0
+
+        def prop_sigma_fn(t_starts, t_ends, net):
+            sig = net(positions(t_starts, t_ends)).squeeze(-1)
+            sig[..., -1] = torch.inf                                     # nerf_renderer.py:43
+            return sig
+
+        t_starts, t_ends = estimator.sampling(
+            prop_sigma_fns=[lambda a, b, p=p: prop_sigma_fn(a, b, p) for p in prop_networks],
+            prop_samples=self.n_samples_per_prop, num_samples=self.n_samples, n_rays=n_rays, near_plane=1e-2, far_plane=2.,
+            sampling_type='uniform', stratified=nerf.training, requires_grad=sampling_requires_grad, taus=taus)
+        pos = positions(t_starts, t_ends)
+        rgb, density = nerf(pos.reshape(-1, 3))
+        rgb = rgb.reshape(n_rays, -1, 3); density = density.reshape(n_rays, -1)
+        alphas = 1. - torch.exp(-density * (t_ends - t_starts))
+        weights, trans = render_weight_from_alpha(alphas)
+        colors = (weights[..., None] * rgb).sum(1)
+        opacities = weights.sum(1, keepdim=True)
+        mid = (t_starts + t_ends) / 2.0
+        distances = (weights * mid).sum(1, keepdim=True)
+        if self.bg_color == 'rand_noise':
+            bg = torch.rand(n_rays, 3, device=dev)
+        elif self.bg_color == 'white':
+            bg = torch.ones(n_rays, 3, device=dev)
+        else:
+            bg = torch.zeros(n_rays, 3, device=dev)
+        colors = colors + bg * (1.0 - opacities)
+        distances = distances + torch.rand_like(distances) * (1. - opacities)
+        return {'rgb': colors, 'distance': distances, 'weights': weights, 'opacities': opacities, 'trans': trans,
+                't_starts': t_starts, 't_ends': t_ends, 'sampled_pts': pos}

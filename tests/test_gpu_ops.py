@@ -428,3 +428,20 @@ def test_hashgrid_fwd2_equals_two_single_passes(ops):
     x = torch.rand(4099, 3, generator=g).cuda()
     fa, fb = ops.hashgrid_fwd2(cfg, x, ta, tb)
     assert torch.equal(fa, ops.hashgrid_fwd(cfg, x, ta)) and torch.equal(fb, ops.hashgrid_fwd(cfg, x, tb))
+
+
+def test_pdf_resample_bit_exact(ops):
+    """Hierarchical resampling (a7): inverse-CDF edges, bit-exact against the oracle's unfused fp32 definition."""
+    rng = np.random.RandomState(0)
+    for (R, n_in, n_out, strat) in ((37, 128, 64, False), (500, 64, 64, True), (3, 1, 5, True)):
+        w = rng.rand(R, n_in).astype(np.float32) ** 4 + 1e-6
+        w[0, : n_in // 2] = 0                                  # empty leading intervals (flat CDF)
+        cdf = np.concatenate([np.zeros((R, 1), np.float32), np.cumsum(w, 1) / np.sum(w, 1, keepdims=True)], 1).astype(np.float32)
+        cdf[:, -1] = 1.0
+        s = np.sort(rng.rand(R, n_in + 1).astype(np.float32), 1)
+        tau = rng.rand(R).astype(np.float32) if strat else None
+        ref = O.pdf_resample(s, cdf, n_out, tau)
+        got = ops.pdf_resample(torch.from_numpy(s).cuda(), torch.from_numpy(cdf).cuda(), n_out,
+                               None if tau is None else torch.from_numpy(tau).cuda()).cpu().numpy()
+        assert np.array_equal(got, ref)
+        assert (np.diff(got, axis=1) >= 0).all()               # sorted edges: a size-independent property
