@@ -137,6 +137,11 @@ int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float*
                       float* grad_table, int64_t n, int accumulate, const float* level_absmax,
                       int32_t* overflow_flag, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The integer half of the encoding: idx[(l*n + i)*8 + c] = absolute table entry (level offset included) of corner c
+ * (bit0 = x, bit1 = y, bit2 = z) of sample i at level l.  Used for the arbitrarily-often differentiable composition
+ * behind tcnn.Encoding's double backward (modules/geo_predictors/pano_joint_predictor.py:64-67, create_graph=True). */
+int perf_hashgrid_corners(const perf_grid_desc* grid, const float* x01, int32_t* idx, int64_t n, void* stream);
+
 /* tcnn kernel_grid_backward_input: dL/dx01 [n,3] from dfeat and the table (fp32 table). */
 int perf_hashgrid_bwd_input(const perf_grid_desc* grid, const float* x01, const float* dfeat,
                             const float* table, float* dx, int64_t n, void* stream);

@@ -45,6 +45,7 @@ _SIGS = {
     'perf_hashgrid_fwd_f32': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
     'perf_hashgrid_bwd_workspace_bytes': (c_int64, [POINTER(GridDesc)]),
     'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P, P, P, c_int64, P]),
+    'perf_hashgrid_corners': (c_int, [POINTER(GridDesc), P, P, c_int64, P]),
     'perf_hashgrid_bwd_input': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),
     'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, c_int, P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),

@@ -169,6 +169,19 @@ __global__ __launch_bounds__(256) void hashgrid_fwd2_kernel(GridParams gp, const
     }
 }
 
+// corner table indices (absolute entry index, level offset included) of every (level, sample): the integer half of
+// the encoding, exported so that arbitrarily-often differentiable compositions can be built on top of it
+__global__ __launch_bounds__(256) void hashgrid_corners_kernel(GridParams gp, const float* __restrict__ x01,
+                                                               int32_t* __restrict__ idx_out, int64_t n) {
+    const int l = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || l >= gp.n_levels) return;
+    const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+    int32_t* o = idx_out + ((int64_t)l * n + i) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (int32_t)(gp.offset[l] + c.idx[k]);
+}
+
 __global__ __launch_bounds__(256) void hashgrid_fwd_f32_kernel(GridParams gp, const float* __restrict__ x01,
                                                                const float2* __restrict__ table,
                                                                float2* __restrict__ feat, int64_t n) {
@@ -560,6 +573,18 @@ extern "C" int perf_hashgrid_fwd2(const perf_grid_desc* grid, const float* x01, 
                            (const uint32_t*)table16_b, (uint32_t*)feat16_a, (uint32_t*)feat16_b, n);
     else { set_error("perf_hashgrid_fwd2: bad dtype %d", dtype); return PERF_E_INVALID; }
     PERF_LAUNCH_CHECK("perf_hashgrid_fwd2");
+    return PERF_OK;
+}
+
+extern "C" int perf_hashgrid_corners(const perf_grid_desc* grid, const float* x01, int32_t* idx, int64_t n, void* stream) {
+    GridParams gp;
+    int rc = fill_params(grid, &gp);
+    if (rc) return rc;
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(x01 && idx, "NULL pointer");
+    hipLaunchKernelGGL(hashgrid_corners_kernel, dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream), gp,
+                       x01, idx, n);
+    PERF_LAUNCH_CHECK("perf_hashgrid_corners");
     return PERF_OK;
 }
 

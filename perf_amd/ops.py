@@ -187,6 +187,15 @@ def hashgrid_bwd_into(grid, x01, dfeat, out, level_absmax=None):
     return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False, level_absmax=level_absmax)
 
 
+def hashgrid_corners(grid: GridConfig, x01):
+    """-> int32 [L, n, 8] absolute table entries of the 8 corners (bit0 = x, bit1 = y, bit2 = z)."""
+    n = x01.shape[0]
+    idx = torch.empty(grid.n_levels, n, 8, dtype=torch.int32, device=x01.device)
+    d = grid.desc()
+    _call('perf_hashgrid_corners', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(idx), n, _stream())
+    return idx
+
+
 def hashgrid_bwd_input(grid: GridConfig, x01, dfeat, table):
     n = x01.shape[0]
     dx = torch.empty(n, 3, dtype=torch.float32, device=x01.device)

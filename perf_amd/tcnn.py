@@ -198,12 +198,39 @@ class Encoding(nn.Module):
         self.encoding_config = dict(encoding_config)
         self.grid = GridConfig.from_tcnn(encoding_config)
         self.n_output_dims = self.grid.n_output_dims
-        self.out_dtype = ops.torch_dtype(dtype or 'fp16')      # tcnn hands back half
+        # tcnn hands back half by default; dtype=torch.float32 / 'fp32' keeps the fp32 result
+        self.out_dtype = torch.float32 if dtype in ('fp32', torch.float32) else ops.torch_dtype(dtype or 'fp16')
         self.params = nn.Parameter(_init_params(None, self.grid, seed).to(_default_device()))
 
     def forward(self, x):
         x = x.reshape(-1, self.n_input_dims).contiguous().float()
+        if x.requires_grad and torch.is_grad_enabled():
+            # The caller may differentiate the input gradient again (SphereDistanceField: autograd.grad(...,
+            # create_graph=True), pano_joint_predictor.py:64-67).  Corner indices come from the HIP kernel; weights
+            # and the gather are differentiable torch ops on the device, so every order of derivative w.r.t. x,
+            # params (and incoming gradients) exists.
+            return self._forward_composed(x).to(self.out_dtype)
         return _EncodingFn.apply(x, self.params, self).to(self.out_dtype)
+
+    def _forward_composed(self, x):
+        g = self.grid
+        n = x.shape[0]
+        idx = ops.hashgrid_corners(g, x.detach()).long()                       # [L, n, 8]
+        scale = torch.as_tensor(g.scale, device=x.device)[:, None, None]       # [L, 1, 1]
+        pos = x[None] * scale + 0.5                                            # [L, n, 3]
+        f = pos - torch.floor(pos).detach()
+        if g.interpolation == 'Smoothstep':
+            f = f * f * (3.0 - 2.0 * f)
+        ws = []
+        for c in range(8):
+            wx = f[..., 0] if (c & 1) else 1.0 - f[..., 0]
+            wy = f[..., 1] if (c & 2) else 1.0 - f[..., 1]
+            wz = f[..., 2] if (c & 4) else 1.0 - f[..., 2]
+            ws.append((wx * wy) * wz)
+        w = torch.stack(ws, -1)                                                # [L, n, 8]
+        vals = self.params.view(-1, 2)[idx.reshape(-1)].view(g.n_levels, n, 8, 2)
+        feat = (w[..., None] * vals).sum(2)                                    # [L, n, 2]
+        return feat.permute(1, 0, 2).reshape(n, -1)
 
 
 def _default_device():

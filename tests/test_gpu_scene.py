@@ -280,3 +280,39 @@ def _pad_net(params, spec):
     n_in = spec.lv.n_levels * 2
     w1 = params[:64 * 16].view(64, 16)[:, :n_in].reshape(-1)
     return torch.cat([w1, params[64 * 16:]])
+
+
+def test_encoding_double_backward():
+    """next-1: tcnn.Encoding (Smoothstep) with input gradient and double backward, as SphereDistanceField uses it
+    (pano_joint_predictor.py:22-71): d/dtheta and d/dx of a loss on the input gradient vs autograd through the oracle."""
+    from perf_amd import tcnn
+    cfg = {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 15, "base_resolution": 16,
+           "per_level_scale": 1.5, "interpolation": "Smoothstep"}
+    enc = tcnn.Encoding(3, cfg, dtype='fp32')      # fp32 output: a half cast would overflow the second-order gradients
+    with torch.no_grad():
+        enc.params.mul_(1e4)
+    lv = O.grid_levels(8, 2, 15, 16, 1.5)
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(300, 3, generator=g) * 0.9 + 0.05)
+    proj = torch.randn(16, generator=g)
+    # fast path (no input grad): kernel forward equals the composed forward
+    y_fast = enc(x.cuda()).float().cpu()
+    xg = x.clone().cuda().requires_grad_(True)
+    y = enc(xg).float()
+    assert (y.detach().cpu() - y_fast).abs().max() < 1e-5 * float(y_fast.abs().max())
+    out = torch.tanh(y @ proj.cuda())
+    (gx,) = torch.autograd.grad(out.sum(), xg, create_graph=True)
+    loss2 = (gx ** 2).sum() + out.sum()
+    loss2.backward()
+    # oracle
+    table = enc.params.detach().cpu().view(-1, 2).clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = O.hashgrid_encode(xr, table, lv, interpolation='Smoothstep')
+    outr = torch.tanh(yr @ proj)
+    (gxr,) = torch.autograd.grad(outr.sum(), xr, create_graph=True)
+    l2r = (gxr ** 2).sum() + outr.sum()
+    l2r.backward()
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-12))
+    assert rel(gx.detach().cpu(), gxr.detach()) < 1e-4
+    assert rel(enc.params.grad.cpu(), table.grad.reshape(-1)) < 1e-4
+    assert rel(xg.grad.cpu(), xr.grad) < 1e-4
