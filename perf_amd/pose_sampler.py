@@ -1,0 +1,140 @@
+"""Host-side mirror of PeRF's pose samplers (modules/pose_sampler/circle_pose_sampler.py:44-118,
+dense_travel_pose_sampler.py:26-116).  They run once per scene on the host (scipy filters, a
+10,000-step annealed tour) and only produce the 4x4 poses the ray-generation kernel consumes, so they stay on the
+CPU; the reference's hard-coded .cuda() hops are dropped.  Pinned on golden poses made by the reference
+(tests/golden/poses.npz)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.ndimage import gaussian_filter1d, minimum_filter1d
+
+
+def _odd(n):
+    return n // 2 * 2 + 1
+
+
+def _equator_dirs(width):
+    """unit directions of the panorama's middle row, pixel centres (camera_utils.py:113-147 at y = 0.5)"""
+    x = torch.linspace(.5 / width, 1. - .5 / width, width)
+    alpha = -(x - .5) * 2. * np.pi
+    beta = torch.zeros(width)
+    return torch.stack([torch.cos(alpha) * torch.cos(beta), torch.sin(alpha) * torch.cos(beta), torch.sin(beta)], -1)
+
+
+def resample_closed_curve(pts: torch.Tensor) -> torch.Tensor:
+    """Re-parametrise a closed polyline by arc length: 128x linear upsampling, cumulative chord length, n equally
+    spaced parameters (both samplers use this helper)."""
+    n = len(pts)
+    fine = F.interpolate(pts.t()[None], size=n * 128, mode='linear')[0].t()
+    seg = torch.linalg.norm(torch.roll(fine, -1, 0) - fine, 2, -1)
+    cum = torch.cumsum(seg, 0)
+    cum = cum / cum[-1]
+    return fine[torch.searchsorted(cum, torch.linspace(0., 1. - 1. / n, n))]
+
+
+def look_at(to_vec: torch.Tensor) -> torch.Tensor:
+    """camera_utils.py:79-95 with the default up vector (0,0,1): columns (right, down, forward)."""
+    up = torch.zeros_like(to_vec); up[:, 2] = 1.
+    fwd = to_vec / torch.linalg.norm(to_vec, 2, -1, True)
+    right = torch.linalg.cross(-up, fwd)
+    right = right / torch.linalg.norm(right, 2, -1, True)
+    down = torch.linalg.cross(fwd, right)
+    return torch.stack([right, down, fwd], 2)
+
+
+class CirclePoseSampler:
+    """Anchor camera positions on rings inside the free space around the panorama centre."""
+
+    def __init__(self, distance_map, traverse_ratios, n_anchors_per_ratio, test_z_min_max=(0., 0.)):
+        dm = distance_map.detach().cpu().numpy() if torch.is_tensor(distance_map) else np.asarray(distance_map)
+        dm = dm.squeeze()
+        h, w = dm.shape
+        rows = torch.linspace(.5 / h, 1. - .5 / h, h)
+        beta = (-(rows - .5) * np.pi).numpy()
+        horiz = dm * np.cos(beta)[:, None]                       # distance projected on the horizontal plane
+        band = horiz[h // 2 - 10: h // 2 + 10].copy()
+        band[band < 1e-5] = 1e9
+        free = band.min(axis=0)
+        for i in range(1, w):                                     # fill invalid columns from the left, then from the right
+            if free[i] > 1e8:
+                free[i] = free[i - 1]
+        for i in range(w - 2, -1, -1):
+            if free[i] > 1e8:
+                free[i] = free[i + 1]
+        shrunk = minimum_filter1d(free, size=_odd(w // 16), mode='wrap')
+        smooth = gaussian_filter1d(shrunk, sigma=_odd(w // 8), mode='wrap')
+        ring = gaussian_filter1d(shrunk, sigma=_odd(w // 64), mode='wrap')
+        dirs = _equator_dirs(w)
+        ring_t = torch.from_numpy(ring)
+        z_lo, z_hi = test_z_min_max
+        anchors = []
+        for i, ratio in enumerate(traverse_ratios):
+            loop = resample_closed_curve(dirs * ring_t[:, None] * ratio)
+            n = n_anchors_per_ratio[i]
+            pos = torch.linspace(.5 / n, 1. - .5 / n, n) + (0. if i % 2 == 0 else .5 / n)
+            pts = loop[(pos * w).to(torch.long).clip(0, w - 1)].clone()
+            for j in range(len(pts)):
+                pts[j, 2] = z_lo if (i + j) % 2 == 0 else z_hi
+            anchors.append(pts)
+        self.anchor_pts = torch.cat(anchors, 0).float()
+        self.traverse_pts = resample_closed_curve(dirs * torch.from_numpy(smooth)[:, None] * .3)
+        self.n_anchors = self.n_poses = len(self.anchor_pts)
+
+    def sample_pose(self, idx):
+        pose = torch.eye(4)
+        pose[:3, 3] = self.anchor_pts[idx]
+        return pose
+
+
+def _annealed_tour(positions: torch.Tensor, n_steps=10000):
+    """Random pair swaps with an annealed acceptance ratio (1 - step/n)^5; consumes numpy's global RNG in the
+    reference's order (two randint per step, one rand only when the swap does not shorten the tour)."""
+    n = len(positions)
+    order = torch.arange(n)
+    best = 1e8
+    for it in range(n_steps):
+        a = np.random.randint(n); b = np.random.randint(n)
+        cand = order.clone()
+        cand[a], cand[b] = order[b], order[a]
+        length = torch.linalg.norm(positions[cand[:-1]] - positions[cand[1:]], 2, -1).sum()
+        if length < best or np.random.rand() < (1. - it / n_steps) ** 5:
+            order, best = cand, length
+    return order
+
+
+class DenseTravelPoseSampler:
+    """Smooth dense trajectory through the sparse anchors with look-ahead orientations."""
+
+    def __init__(self, sparse_pose_sampler, n_dense_poses, dir_bias_ratio=-1):
+        sparse = torch.stack([sparse_pose_sampler.sample_pose(i) for i in range(sparse_pose_sampler.n_poses)], 0)
+        tour = sparse[_annealed_tour(sparse[:, :3, 3])][:, :3, 3]
+        total = n_dense_poses * 50
+        seg_len = torch.linalg.norm(tour[1:] - tour[:-1], 2, -1, True)
+        counts = torch.round(total * seg_len / seg_len.sum()).to(torch.int64)
+        chunks = []
+        for i in range(len(counts)):
+            k = counts[i].item()
+            t = torch.linspace(.5 / k, 1. - .5 / k, k)
+            chunks.append(tour[i][None] * (1. - t)[:, None] + tour[i + 1][None] * t[:, None])
+        pts = resample_closed_curve(torch.cat(chunks, 0))[::50].numpy()
+        for a in range(3):
+            pts[:, a] = gaussian_filter1d(pts[:, a], sigma=20)
+        pts = torch.from_numpy(pts)
+        self.sample_poses = torch.eye(4)[None].repeat(len(pts), 1, 1)
+        self.sample_poses[:, :3, 3] = pts
+        self.n_poses = len(pts)
+        fwd = pts.clone()
+        fwd[:-1] = pts[1:] - pts[:-1]
+        fwd[-1] = fwd[-2]
+        for a in range(3):
+            fwd[:, a] = torch.from_numpy(gaussian_filter1d(fwd[:, a].numpy(), sigma=30))
+        fwd = fwd / torch.linalg.norm(fwd, 2, -1, True)
+        up = torch.zeros_like(fwd); up[:, 2] = 1.
+        left = torch.linalg.cross(up, fwd)
+        left = left / torch.linalg.norm(left, 2, -1, True)
+        fwd = fwd + dir_bias_ratio * left
+        fwd = fwd / torch.linalg.norm(fwd, 2, -1, True)
+        self.sample_poses[:, :3, :3] = look_at(fwd)
+
+    def sample_pose(self, idx):
+        return self.sample_poses[idx]

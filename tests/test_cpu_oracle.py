@@ -108,3 +108,18 @@ def test_ops_refuse_cpu_tensors():
     from perf_amd.grid import GridConfig
     with pytest.raises(_lib.PerfError):
         ops.hashgrid_fwd(GridConfig(), torch.rand(4, 3), torch.zeros(8, dtype=torch.bfloat16))
+
+
+def test_pose_samplers_match_reference():
+    """a11: the host-side pose samplers reproduce the reference's anchors and dense trajectory (golden poses.npz)."""
+    from perf_amd.pose_sampler import CirclePoseSampler, DenseTravelPoseSampler
+    g = np.load(f'{G}/poses.npz')
+    s = CirclePoseSampler(torch.from_numpy(g['distance_map']), [.2, .4, .6], [8, 8, 8])
+    anchors = torch.stack([s.sample_pose(i) for i in range(s.n_poses)]).numpy()
+    assert anchors.shape == g['anchors'].shape == (24, 4, 4)
+    assert np.abs(anchors - g['anchors']).max() < 1e-6
+    np.random.seed(0)
+    dense = DenseTravelPoseSampler(s, 180)
+    poses = torch.stack([dense.sample_pose(i) for i in range(dense.n_poses)]).numpy()
+    assert poses.shape == g['dense'].shape
+    assert np.abs(poses - g['dense']).max() < 1e-5
