@@ -53,17 +53,13 @@ class NeRFOCCRenderer(nn.Module):
         self.max_steps = None          # None: ceil((far-near)/step)+1 like the reference; an int fixes the count
         self.sample_capacity = None    # int: sync-free fixed-shape sampling (exactly that many samples per batch)
 
-    def render(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, near, far,
-               geo_inference=False, app_inference=False, rand=None):
-        """`rand` (optional dict with 'jitter' [R], 'bg' [R,3], 'noise' [R,1]) injects the random draws of
-        :152,:185,:193 for tests; by default they are drawn with torch.rand on the device in that order."""
-        assert near.shape[-1] == 1 and len(near.shape) == 2
-        n_rays = rays_o.shape[0]
-        dev = rays_o.device
+    # The render is cut in two stages so that a data-parallel trainer can overlap the gradient all-reduce of step k
+    # with everything of step k+1 that does not depend on the parameters being updated (scene.py).
+    def stage_sample(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, rand=None, with_rgb=False):
+        """Sampling (marching, visibility compaction), sample positions and -- with_rgb -- the colour field without
+        gradient.  Returns a dict consumed by stage_composite, or None when the batch has no sample."""
         rays_o = rays_o.contiguous().float(); rays_d = rays_d.contiguous().float()
         rand = rand or {}
-        grad_geo = torch.is_grad_enabled() and not geo_inference
-        grad_app = torch.is_grad_enabled() and not app_inference
 
         def sigma_fn(t_starts, t_ends, ray_indices):
             x01, sel = nerf.sample_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
@@ -74,23 +70,38 @@ class NeRFOCCRenderer(nn.Module):
             render_step_size=self.render_step_size, early_stop_eps=self.early_stop_eps, stratified=nerf.training,
             cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'), max_steps=self.max_steps, capacity=self.sample_capacity)
         if ray_indices.numel() <= 0:
-            return {'is_valid': False, 'rgb': torch.zeros(n_rays, 3, device=dev), 'distance': torch.zeros(n_rays, 1, device=dev),
-                    'opacities': torch.zeros(n_rays, 1, device=dev)}
-
+            return None
         x01, sel = nerf.sample_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
+        st = {'ray_indices': ray_indices, 't_starts': t_starts, 't_ends': t_ends, 'packed': packed, 'sig0': sig0,
+              'x01': x01, 'sel': sel, 'n_rays': rays_o.shape[0], 'rgbs': None}
+        if with_rgb:
+            with torch.no_grad():
+                st['rgbs'] = nerf.rgb_at(x01, sel)
+        return st
+
+    def stage_composite(self, nerf: NGPNeRF, st, geo_inference=False, app_inference=False, rand=None):
+        rand = rand or {}
+        n_rays = st['n_rays']
+        x01, sel, packed = st['x01'], st['sel'], st['packed']
+        dev = x01.device
+        grad_geo = torch.is_grad_enabled() and not geo_inference
+        grad_app = torch.is_grad_enabled() and not app_inference
         # (A shared-index pass over both grids -- perf_hashgrid_fwd2 -- measured 2x SLOWER than two passes: the
         #  per-XCD working set doubles to 4 MiB = the whole L2.  The fields are therefore queried one after the other.)
         if grad_geo:
             sigmas = nerf.density_at(x01, sel)
-        elif sig0 is not None:
-            sigmas = sig0                                    # same values the reference recomputes under no_grad
+        elif st['sig0'] is not None:
+            sigmas = st['sig0']                              # same values the reference recomputes under no_grad
         else:
             with torch.no_grad():
                 sigmas = nerf.density_at(x01, sel)
-        with torch.set_grad_enabled(grad_app):
-            rgbs = nerf.rgb_at(x01, sel)
+        if st['rgbs'] is not None and not grad_app:
+            rgbs = st['rgbs']
+        else:
+            with torch.set_grad_enabled(grad_app):
+                rgbs = nerf.rgb_at(x01, sel)
 
-        weights, trans, opacities, distances, colors = volume_render(sigmas, rgbs, t_starts, t_ends, packed)
+        weights, trans, opacities, distances, colors = volume_render(sigmas, rgbs, st['t_starts'], st['t_ends'], packed)
 
         if self.bg_color == 'rand_noise':
             bg_color = rand['bg'] if 'bg' in rand else torch.rand(n_rays, 3, device=dev)
@@ -108,8 +119,21 @@ class NeRFOCCRenderer(nn.Module):
             colors = colors + .5 * (1. - opacities).detach()
 
         return {'is_valid': True, 'rgb': colors, 'distance': distances, 'weights': weights, 'opacities': opacities,
-                'trans': trans, 't_starts': t_starts, 't_ends': t_ends, 'ray_indices': ray_indices,
+                'trans': trans, 't_starts': st['t_starts'], 't_ends': st['t_ends'], 'ray_indices': st['ray_indices'],
                 'packed_info': packed}
+
+    def render(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, near, far,
+               geo_inference=False, app_inference=False, rand=None):
+        """`rand` (optional dict with 'jitter' [R], 'bg' [R,3], 'noise' [R,1]) injects the random draws of
+        :152,:185,:193 for tests; by default they are drawn with torch.rand on the device in that order."""
+        assert near.shape[-1] == 1 and len(near.shape) == 2
+        n_rays = rays_o.shape[0]
+        dev = rays_o.device
+        st = self.stage_sample(nerf, estimator, rays_o, rays_d, rand)
+        if st is None:
+            return {'is_valid': False, 'rgb': torch.zeros(n_rays, 3, device=dev), 'distance': torch.zeros(n_rays, 1, device=dev),
+                    'opacities': torch.zeros(n_rays, 1, device=dev)}
+        return self.stage_composite(nerf, st, geo_inference, app_inference, rand)
 
 
 class NeRFPropRenderer(nn.Module):

@@ -176,6 +176,8 @@ class NeRFScene:
         self.loss_scale = 2.0 ** 7
         self.last_losses = {}
         self._capturing = False
+        self.overlap_comm = True       # DP: overlap the gradient all-reduce with the next step's prefetch
+        self._geo_pre = None
         self._ratio_dev = torch.zeros((), dtype=torch.float32, device='cuda')   # distortion-loss ramp min(2*progress, 1)
 
     # ---- distributed helpers ---------------------------------------------------------------------
@@ -266,32 +268,54 @@ class NeRFScene:
         rays, col, dep, nrm = sup_pool.rand_ray_color_data(bs, generator=generator, rank=rank, world_size=world)
         return rays, col, dep, bs, (dist, rank, world)
 
-    def _finish_step(self, loss, net, optimizer, dist_info):
+    def _finish_step(self, loss, net, optimizer, dist_info, overlap=None):
+        """backward -> [one RCCL all-reduce of the flat gradient] -> Adam.  `overlap` (a callable) is run between the
+        launch of the asynchronous all-reduce and the wait for it: the next step's parameter-independent work then
+        executes on the compute stream while RCCL moves the gradient over xGMI on its own stream."""
         dist, rank, world = dist_info
         (loss * self.loss_scale).backward()                   # grad_scaler.scale(loss).backward(), never unscaled
         if dist is not None:
             g = net.params.grad
             if g is None:
                 g = net.params.grad = torch.zeros_like(net.params)
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)           # one RCCL all-reduce of the flat gradient
+            if overlap is not None:
+                work = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+                overlap()
+                work.wait()
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
         optimizer.step()
         self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
         if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY and _tcnn.GRID_GRAD_ACCUM == 'fixed':
             self._steps_since_check = 0
             _tcnn.check_fixed_point_overflow(net.params.device)
 
+    def _geo_prefetch(self, sup_pool, rand, generator):
+        """Everything of a geometry step that does not depend on the geometry parameters: batch draw, and -- when the
+        sampler needs no density pre-pass (early_stop_eps == 0) -- marching, positions and the frozen colour field."""
+        rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
+        st = None
+        if self.renderer.early_stop_eps <= 0:
+            with torch.no_grad():
+                st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=True)
+                st = st if st is not None else False
+        return {'rays': rays, 'gt_depths': gt_depths, 'bs': bs, 'dist_info': dist_info, 'st': st}
+
     def train_one_step_geo(self, optimizer, sup_pool, progress, rand=None, generator=None):
         tc = self.train_conf
         optimizer.zero_grad()
-        rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
-        res = self.render_once(rays, ['rgb', 'distance', 'weights', 't_starts', 't_ends', 'trans', 'ray_indices', 'packed_info'],
-                               app_inference=True, rand=rand)
-        if (res is None) or (not res['is_valid']):
+        pre = getattr(self, '_geo_pre', None) or self._geo_prefetch(sup_pool, rand, generator)
+        self._geo_pre = None
+        rays, gt_depths, bs, dist_info = pre['rays'], pre['gt_depths'], pre['bs'], pre['dist_info']
+        st = pre['st']
+        if st is None:
+            st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand)
+        res = None if (st is None or st is False) else self.renderer.stage_composite(self.nerf, st, app_inference=True, rand=rand)
+        if res is None:
             if dist_info[0] is not None:                      # keep the collective matched across ranks
                 self._finish_step(self.nerf.geo_mlp.params.sum() * 0.0, self.nerf.geo_mlp, optimizer, dist_info)
             self.global_iter_step_geo += 1
             return
-        n_local = len(rays)
         loss = 0.
         if tc.depth_loss_weight > 1e-7:
             # mean over the GLOBAL batch: local sum / global count
@@ -312,7 +336,9 @@ class NeRFScene:
             rand_pts = (torch.rand(8192, 3, device=gt_depths.device) * 2. - 1.) * 0.99
             density_loss = self.nerf.query_density(rand_pts).mean()
             loss = loss + density_loss * tc.density_loss_weight
-        self._finish_step(loss, self.nerf.geo_mlp, optimizer, dist_info)
+        overlap = (lambda: setattr(self, '_geo_pre', self._geo_prefetch(sup_pool, rand, generator))) \
+            if (self.overlap_comm and dist_info[0] is not None) else None
+        self._finish_step(loss, self.nerf.geo_mlp, optimizer, dist_info, overlap)
         self.global_iter_step_geo += 1
 
     def train_one_step_app(self, optimizer, sup_pool, progress, rand=None, generator=None):

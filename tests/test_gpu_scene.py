@@ -316,3 +316,42 @@ def test_encoding_double_backward():
     assert rel(gx.detach().cpu(), gxr.detach()) < 1e-4
     assert rel(enc.params.grad.cpu(), table.grad.reshape(-1)) < 1e-4
     assert rel(xg.grad.cpu(), xr.grad) < 1e-4
+
+
+def test_dp_overlap_path_world1():
+    """The data-parallel step (async RCCL all-reduce overlapped with the next step's prefetch) on a world-size-1
+    process group: same parameters after 3 steps as the plain single-process path with the same seeds."""
+    import os
+    import torch.distributed as dist
+    from perf_amd import synthetic
+    from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+
+    def run(use_dist):
+        torch.manual_seed(0)
+        scene = NeRFScene(dtype='bf16')
+        rays = gen_pano_rays(torch.eye(4), 64, 128)
+        d_, rgb = synthetic.room(rays.d)
+        pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, d_)
+        scene.train_conf.pixel_loss_batch_size = 1024
+        scene.set_train()
+        scene.estimator.set_binaries(torch.ones(256 ** 3, dtype=torch.uint8, device='cuda'))
+        r = scene.renderer
+        r.render_step_size = 0.99 / 32; r.far_plane = 10.0; r.early_stop_eps = 0.0; r.max_steps = 32
+        scene.nerf.reset_geo()
+        opt = scene.make_optimizer(scene.nerf.geo_mlp, 1e-3)
+        gen = torch.Generator(device='cuda'); gen.manual_seed(7)
+        torch.manual_seed(1)
+        for i in range(3):
+            scene.train_one_step_geo(opt, pool, progress=0.3, generator=gen)
+        return scene.nerf.geo_mlp.params.detach().clone()
+
+    ref = run(False)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        got = run(True)
+    finally:
+        dist.destroy_process_group()
+    # identical batches (same generator); the jitter / noise draws come from the default generator in a different
+    # order when the next batch is prefetched early, so compare loosely: parameters moved the same way
+    assert float((got - ref).abs().max()) < 5e-3 and float((got - ref).abs().mean()) < 1e-4
