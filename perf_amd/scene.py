@@ -74,6 +74,7 @@ class SupInfoPool:
         self.all_sup_distances = None
         self.all_sup_normals = None
         self.n_panos = 0
+        self.sup_infos = []            # per panorama: pose, distance_map [H,W,1], mask [H,W,1] (visibility tests)
 
     def register_rays(self, rays_o, rays_d, colors, distances, normals=None):
         o = rays_o.reshape(-1, 3).contiguous().float(); d = rays_d.reshape(-1, 3).contiguous().float()
@@ -94,6 +95,8 @@ class SupInfoPool:
         rays = gen_pano_rays(pose, h, w, device=rgb.device)
         distance = distance.reshape(h, w, 1)
         valid = (mask.reshape(h, w) > .5) & (distance[..., 0] > 1e-5)
+        self.sup_infos.append({'pose': torch.as_tensor(pose, dtype=torch.float32, device=rgb.device), 'distance_map': distance.float(),
+                               'mask': valid[..., None]})
         idx = torch.where(valid)
         self.register_rays(rays.o[idx], rays.d[idx], rgb[idx], distance[idx], None if normal is None else normal[idx])
 
@@ -414,6 +417,12 @@ class NeRFScene:
         lr = self.lr_at(optim_conf, progress)
         for p in optimizer.param_groups:
             p['lr'] = lr
+
+    # ---- visibility (nerf.py:321-358) ---------------------------------------------------------------------
+    def get_pano_visibility_mask(self, sup_pool, rays: Rays):
+        from .visibility import pano_visibility_mask
+        distance = self.render(rays, query_keys=['distance'])['distance'].squeeze(-1)
+        return pano_visibility_mask(rays.o, rays.d, distance, sup_pool.sup_infos)
 
     # ---- state (nerf.py:368-395) --------------------------------------------------------------------
     def state_dict(self):

@@ -123,3 +123,20 @@ def test_pose_samplers_match_reference():
     poses = torch.stack([dense.sample_pose(i) for i in range(dense.n_poses)]).numpy()
     assert poses.shape == g['dense'].shape
     assert np.abs(poses - g['dense']).max() < 1e-5
+
+
+def test_direction_to_img_coord_and_morphology():
+    """a12 helpers: the equirect inverse mapping against the reference's golden vector; ellipse kernels / morphology
+    through their defining properties (plain torch, runs on CPU)."""
+    from perf_amd import visibility as V
+    g = np.load(f'{G}/rays.npz')
+    d = torch.from_numpy(g['pano_eye_32x64_d'])
+    assert np.abs(V.direction_to_img_coord(d).numpy() - g['pano_eye_32x64_imgcoord']).max() < 1e-6
+    k5 = V.ellipse_kernel(5, 5)
+    assert k5.tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]
+    m = torch.zeros(1, 1, 21, 21); m[0, 0, 10, 10] = 1
+    assert torch.equal(V.dilate(m, k5)[0, 0, 8:13, 8:13], k5)                 # dilation of a point = the kernel
+    full = torch.ones(1, 1, 21, 21)
+    assert torch.equal(V.erode(full, V.ellipse_kernel(9, 9)), full)           # borders do not erode
+    hole = full.clone(); hole[0, 0, 10, 10] = 0
+    assert float(V.erode(hole, k5).sum()) == 21 * 21 - float(k5.sum())        # erosion grows a hole by the kernel

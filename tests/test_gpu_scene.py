@@ -355,3 +355,23 @@ def test_dp_overlap_path_world1():
     # identical batches (same generator); the jitter / noise draws come from the default generator in a different
     # order when the next batch is prefetched early, so compare loosely: parameters moved the same way
     assert float((got - ref).abs().max()) < 5e-3 and float((got - ref).abs().mean()) < 1e-4
+
+
+def test_pano_visibility_mask_same_pose_is_visible():
+    """a12: surface points rendered from the pose of a registered panorama are visible in that panorama."""
+    from perf_amd import synthetic
+    from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
+    from perf_amd.visibility import geo_check, pano_visibility_mask
+    rays = gen_pano_rays(torch.eye(4), 64, 128)
+    dist, rgb = synthetic.room(rays.d)
+    pool = SupInfoPool()
+    pool.register_sup_info(torch.eye(4), torch.ones(64, 128, 1, device='cuda'), rgb, dist)
+    assert len(pool) == 64 * 128 and len(pool.sup_infos) == 1
+    vis = pano_visibility_mask(rays.o, rays.d, dist[..., 0], pool.sup_infos)
+    assert vis.shape == (64, 128) and float(vis.mean()) > 0.99
+    # points pushed well behind the observed surface are occluded; points in front conflict with the geo check
+    vis_far = pano_visibility_mask(rays.o, rays.d, dist[..., 0] * 1.5, pool.sup_infos)
+    assert float(vis_far.mean()) < 0.01
+    ok_behind = geo_check(rays.o, rays.d, dist * 1.2, pool.sup_infos)
+    ok_front = geo_check(rays.o, rays.d, dist * 0.5, pool.sup_infos)
+    assert float(ok_behind.mean()) > 0.99 and float(ok_front.mean()) < 0.01
