@@ -187,8 +187,15 @@ int64_t perf_occ_mask_words(int32_t max_steps);
  * (masks [n_rays * mask_words]) and counts [n_rays].  t0 [n_rays] is the lattice origin
  * (near plane plus the stratified jitter); aabb: 6 host floats. */
 int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
-                         const uint32_t* occ_bits, int32_t res, const float* aabb, float far_plane,
-                         float step, int32_t max_steps, uint64_t* masks, int32_t* counts, void* stream);
+                         const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
+                         float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
+                         void* stream);
+
+/* Optional empty-space skip for perf_occ_march_count (what nerfacc's DDA traversal achieves): a dilated 8^3-block
+ * occupancy (perf_occ_coarse_words(res) uint32 words) lets the kernel drop whole 64-interval chunks; conservative,
+ * results are identical with occ_coarse == NULL.  res must be a multiple of 8. */
+int64_t perf_occ_coarse_words(int32_t res);
+int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint32_t* coarse, void* stream);
 
 /* Exclusive prefix sum of int32 (counts -> offsets); total [1] (int64, device) receives the sum.
  * workspace >= perf_scan_workspace_bytes(n). */

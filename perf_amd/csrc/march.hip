@@ -17,13 +17,42 @@ struct MarchParams {
     float hi[3];
     float far_plane, step;
     int32_t res, max_steps, mask_words;
+    int32_t use_coarse;      // 1: skip 64-interval chunks whose midpoint lies in an empty DILATED 8^3 block
 };
 
+// Coarse skip grid: bit b of `coarse` is set iff any fine cell in the 3x3x3 neighbourhood of 8^3-block b is occupied.
+// A chunk of 64 lattice intervals spans at most `span` fine cells; when span/2 + 1 <= 8 every midpoint of the chunk lies
+// within one block of the block that holds the chunk's centre, so an empty dilated block proves the chunk empty
+// (conservative: results are identical to the exhaustive test).
+__global__ __launch_bounds__(256) void coarse_build_kernel(const uint32_t* __restrict__ bits, int res,
+                                                           uint32_t* __restrict__ coarse) {
+    const int cr = res / 8;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= cr * cr * cr) return;
+    const int bx = b / (cr * cr), by = (b / cr) % cr, bz = b % cr;
+    bool any = false;
+    for (int x = max(bx - 1, 0) * 8; x < min(bx + 2, cr) * 8 && !any; ++x)
+        for (int y = max(by - 1, 0) * 8; y < min(by + 2, cr) * 8 && !any; ++y) {
+            // the z run [z0, z1) of a row is contiguous in the bit field
+            const int z0 = max(bz - 1, 0) * 8, z1 = min(bz + 2, cr) * 8;
+            for (int z = z0; z < z1; z += 8) {
+                const uint32_t ci = (uint32_t)((x * res + y) * res + z);
+                if ((bits[ci >> 5] >> (ci & 31)) & 0xffu) { any = true; break; }
+            }
+        }
+    if (any) atomicOr(&coarse[b >> 5], 1u << (b & 31));
+}
+
 __device__ __forceinline__ float lattice(float t0, int k, float step) { return add_rn(t0, mul_rn((float)k, step)); }
+
+// Per-ray record in the mask buffer: [live words | chunk masks]: bit q of the live words says chunk q (lattice
+// intervals 64q..64q+63) may hold samples; only live chunks have their mask word written (and later read).
+__device__ __forceinline__ int n_live_words(int mask_words) { return (mask_words + 63) >> 6; }
 
 __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const float* __restrict__ ro,
                                                           const float* __restrict__ rd, const float* __restrict__ t0s,
                                                           int64_t n_rays, const uint32_t* __restrict__ bits,
+                                                          const uint32_t* __restrict__ coarse,
                                                           uint64_t* __restrict__ masks, int32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -45,13 +74,37 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
     int32_t count = 0;
     const int res = mp.res;
     const float rf = (float)res;
-    for (int q = 0; q < mp.mask_words; ++q) {
-        const int k0 = q * 64;
-        bool keep = false;
-        // chunk entirely past the far bound / before the near bound: nothing to test
-        const bool chunk_live = !(lattice(t0, k0, mp.step) > hi) && !(lattice(t0, k0 + 64, mp.step) < lo);
-        if (chunk_live) {
-            const int k = k0 + lane;
+    const int nlw = n_live_words(mp.mask_words);
+    uint64_t* rec = masks + r * (int64_t)(mp.mask_words + nlw);
+    for (int g = 0; g < nlw; ++g) {
+        // ---- phase A: lane q decides whether chunk 64g+q can hold a sample at all (range + dilated coarse grid):
+        //      one ballot replaces up to 64 sequential chunk visits (what nerfacc's DDA skips cell by cell)
+        const int q = g * 64 + lane;
+        bool maybe = false;
+        if (q < mp.mask_words) {
+            const int k0 = q * 64;
+            maybe = !(lattice(t0, k0, mp.step) > hi) && !(lattice(t0, k0 + 64, mp.step) < lo);
+            if (maybe && mp.use_coarse) {
+                const float tc = lattice(t0, k0 + 32, mp.step);
+                const int cr = res >> 3;
+                int cb[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float p = add_rn(o[a], mul_rn(d[a], tc));
+                    const float u = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
+                    cb[a] = ((int)fminf(fmaxf(floorf(u), 0.0f), rf - 1.0f)) >> 3;
+                }
+                const uint32_t bi = (uint32_t)((cb[0] * cr + cb[1]) * cr + cb[2]);
+                maybe = (coarse[bi >> 5] >> (bi & 31)) & 1u;
+            }
+        }
+        uint64_t live = __ballot(maybe);
+        uint64_t kept = 0;        // chunks that really hold samples
+        // ---- phase B: the 64 lattice intervals of every surviving chunk, one per lane
+        for (uint64_t todo = live; todo; todo &= todo - 1) {
+            const int qq = g * 64 + (__ffsll((unsigned long long)todo) - 1);
+            const int k = qq * 64 + lane;
+            bool keep = false;
             if (k < mp.max_steps) {
                 const float ta = lattice(t0, k, mp.step), tb = lattice(t0, k + 1, mp.step);
                 const float mid = mul_rn(add_rn(ta, tb), 0.5f);
@@ -61,17 +114,20 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                     for (int a = 0; a < 3; ++a) {
                         const float p = add_rn(o[a], mul_rn(d[a], mid));
                         const float u = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
-                        const float f = fminf(fmaxf(floorf(u), 0.0f), rf - 1.0f);
-                        cell[a] = (int)f;
+                        cell[a] = (int)fminf(fmaxf(floorf(u), 0.0f), rf - 1.0f);
                     }
                     const uint32_t ci = (uint32_t)((cell[0] * res + cell[1]) * res + cell[2]);
                     keep = (bits[ci >> 5] >> (ci & 31)) & 1u;
                 }
             }
+            const uint64_t m = __ballot(keep);
+            if (m) {
+                kept |= 1ull << (qq & 63);
+                if (lane == 0) rec[nlw + qq] = m;
+                count += __popcll(m);
+            }
         }
-        const uint64_t m = __ballot(keep);
-        if (lane == 0) masks[r * mp.mask_words + q] = m;
-        count += __popcll(m);
+        if (lane == 0) rec[g] = kept;
     }
     if (lane == 0) counts[r] = count;
 }
@@ -85,25 +141,31 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rays) return;
-    const int32_t cnt = counts[r], off = offsets[r];
+    int32_t cnt = counts[r];
+    const int32_t off = offsets[r];
+    if ((int64_t)off + cnt > capacity) cnt = (int32_t)(capacity > off ? capacity - off : 0);   // truncated batch
     if (lane == 0) { packed[2 * r] = off; packed[2 * r + 1] = cnt; }
     if (cnt == 0) return;
     const float t0 = t0s[r];
     int64_t run = off;
     const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int q = 0; q < mask_words; ++q) {
-        const uint64_t m = masks[r * mask_words + q];
-        if (m == 0) continue;
-        if ((m >> lane) & 1ull) {
-            const int64_t pos = run + __popcll(m & below);
-            if (pos < capacity) {
-                const int k = q * 64 + lane;
-                ts[pos] = lattice(t0, k, step);
-                te[pos] = lattice(t0, k + 1, step);
-                ray_indices[pos] = r;
+    const int nlw = n_live_words(mask_words);
+    const uint64_t* rec = masks + r * (int64_t)(mask_words + nlw);
+    for (int g = 0; g < nlw; ++g) {
+        for (uint64_t todo = rec[g]; todo; todo &= todo - 1) {
+            const int q = g * 64 + (__ffsll((unsigned long long)todo) - 1);
+            const uint64_t m = rec[nlw + q];
+            if ((m >> lane) & 1ull) {
+                const int64_t pos = run + __popcll(m & below);
+                if (pos < capacity) {
+                    const int k = q * 64 + lane;
+                    ts[pos] = lattice(t0, k, step);
+                    te[pos] = lattice(t0, k + 1, step);
+                    ray_indices[pos] = r;
+                }
             }
+            run += __popcll(m);
         }
-        run += __popcll(m);
     }
 }
 
@@ -186,11 +248,36 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
 
 using namespace perf;
 
-extern "C" int64_t perf_occ_mask_words(int32_t max_steps) { return max_steps > 0 ? (max_steps + 63) / 64 : 0; }
+static inline int chunk_words(int32_t max_steps) { return max_steps > 0 ? (max_steps + 63) / 64 : 0; }
+
+// uint64 words per ray in the mask buffer: one mask word per 64-interval chunk plus the live-chunk words
+extern "C" int64_t perf_occ_mask_words(int32_t max_steps) {
+    const int mw = chunk_words(max_steps);
+    return mw + (mw + 63) / 64;
+}
+
+extern "C" int64_t perf_occ_coarse_words(int32_t res) {
+    if (res <= 0 || (res % 8) != 0) return 0;
+    const int64_t cr = res / 8;
+    return (cr * cr * cr + 31) / 32;
+}
+
+extern "C" int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint32_t* coarse, void* stream) {
+    PERF_REQUIRE(occ_bits && coarse && res > 0 && (res % 8) == 0, "perf_occ_build_coarse: res must be a positive multiple of 8");
+    const int64_t words = perf_occ_coarse_words(res);
+    hipError_t e = hipMemsetAsync(coarse, 0, words * sizeof(uint32_t), as_stream(stream));
+    if (e != hipSuccess) { set_error("perf_occ_build_coarse: memset failed"); return PERF_E_LAUNCH; }
+    const int cr = res / 8;
+    hipLaunchKernelGGL(coarse_build_kernel, dim3((unsigned)div_up((int64_t)cr * cr * cr, 256)), dim3(256), 0, as_stream(stream),
+                       occ_bits, (int)res, coarse);
+    PERF_LAUNCH_CHECK("perf_occ_build_coarse");
+    return PERF_OK;
+}
 
 extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
-                                    const uint32_t* occ_bits, int32_t res, const float* aabb, float far_plane, float step,
-                                    int32_t max_steps, uint64_t* masks, int32_t* counts, void* stream) {
+                                    const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
+                                    float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
+                                    void* stream) {
     PERF_REQUIRE(n_rays >= 0 && res > 0 && res <= 1024 && max_steps > 0 && step > 0.f, "perf_occ_march_count: bad arguments");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(rays_o && rays_d && t0 && occ_bits && aabb && masks && counts, "NULL pointer");
@@ -200,9 +287,13 @@ extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, co
         mp.inv_ext[a] = 1.0f / (aabb[3 + a] - aabb[a]);
     }
     mp.far_plane = far_plane; mp.step = step; mp.res = res; mp.max_steps = max_steps;
-    mp.mask_words = (int32_t)perf_occ_mask_words(max_steps);
+    mp.mask_words = chunk_words(max_steps);
+    // the coarse skip is only valid while a 64-interval chunk spans few enough fine cells (see coarse_build_kernel)
+    float span_cells = 0.f;
+    for (int a = 0; a < 3; ++a) span_cells = fmaxf(span_cells, 64.0f * step * mp.inv_ext[a] * (float)res);
+    mp.use_coarse = (occ_coarse != nullptr && (res % 8) == 0 && span_cells * 0.5f + 1.5f <= 8.0f) ? 1 : 0;
     hipLaunchKernelGGL(march_count_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
-                       rays_d, t0, n_rays, occ_bits, masks, counts);
+                       rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts);
     PERF_LAUNCH_CHECK("perf_occ_march_count");
     return PERF_OK;
 }
@@ -236,7 +327,7 @@ extern "C" int perf_occ_march_write(const float* t0, int64_t n_rays, float step,
     PERF_REQUIRE(t0 && masks && counts && offsets && packed_info, "NULL pointer");
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends), "NULL sample arrays");
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), t0, n_rays,
-                       step, (int32_t)perf_occ_mask_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
+                       step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
                        t_ends, packed_info);
     PERF_LAUNCH_CHECK("perf_occ_march_write");
     return PERF_OK;

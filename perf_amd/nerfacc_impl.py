@@ -123,6 +123,7 @@ class OccGridEstimator(nn.Module):
         self._aabb_host = [float(v) for v in roi_aabb.detach().cpu().reshape(-1).tolist()]
         self._diag = math.sqrt(sum((self._aabb_host[3 + i] - self._aabb_host[i]) ** 2 for i in range(3)))
         self._bits = None
+        self._coarse = None
         self._bits_version = None
 
     # -- occupancy bit field used by the marching kernel -------------------------------------------
@@ -130,8 +131,13 @@ class OccGridEstimator(nn.Module):
         key = (self.binaries.data_ptr(), self.binaries._version)
         if self._bits is None or self._bits_version != key:
             self._bits = ops.occ_pack_bits(self.binaries)
+            self._coarse = ops.occ_build_coarse(self._bits, self._res)
             self._bits_version = key
         return self._bits
+
+    def occ_coarse(self):
+        self.occ_bits()
+        return self._coarse
 
     def set_binaries(self, occ_flat):
         """Install a precomputed occupancy (x-major flat uint8/bool [res^3])."""
@@ -173,11 +179,11 @@ class OccGridEstimator(nn.Module):
         if capacity is not None:
             # sync-free fixed-shape mode (hipGraph capture): the caller guarantees exactly `capacity` samples
             ri, ts, te, packed, total = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane),
-                                                      float(render_step_size), max_steps, capacity=capacity)
+                                                      float(render_step_size), max_steps, capacity=capacity, occ_coarse=self.occ_coarse())
             ri._perf_packed = packed
             return ri, ts, te, packed, None
         ri, ts, te, packed = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane),
-                                           float(render_step_size), max_steps)
+                                           float(render_step_size), max_steps, occ_coarse=self.occ_coarse())
         sig = None
         if sigma_fn is not None and early_stop_eps > 0 and ri.numel() > 0:
             ri._perf_packed = packed

@@ -260,7 +260,17 @@ def exclusive_scan_i32(counts: torch.Tensor):
     return out, total
 
 
-def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, capacity=None):
+def occ_build_coarse(occ_bits, res):
+    """Dilated 8^3-block occupancy for the marching kernel's empty-space skip (None when res % 8 != 0)."""
+    words = _lib.load().perf_occ_coarse_words(int(res))
+    if words == 0:
+        return None
+    coarse = torch.empty(words, dtype=torch.int32, device=occ_bits.device)
+    _call('perf_occ_build_coarse', _p(occ_bits), int(res), _p(coarse), _stream())
+    return coarse
+
+
+def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, capacity=None, occ_coarse=None):
     """Returns (ray_indices i64 [S], t_starts, t_ends f32 [S], packed_info i32 [R,2]).
     capacity=None reads the total back (one host sync, like the reference's boolean indexing);
     an int capacity keeps the call sync-free and returns arrays of that length plus `total` on device."""
@@ -272,7 +282,7 @@ def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_step
     counts = torch.empty(R, dtype=torch.int32, device=dev)
     a6 = _aabb6(aabb)
     _call('perf_occ_march_count', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(t0, 't0')), R,
-              _p(occ_bits), int(res), a6, float(far_plane), float(step), int(max_steps), _p(masks), _p(counts), _stream())
+              _p(occ_bits), _p(occ_coarse), int(res), a6, float(far_plane), float(step), int(max_steps), _p(masks), _p(counts), _stream())
     offsets, total = exclusive_scan_i32(counts)
     S = int(total.item()) if capacity is None else int(capacity)
     ri = torch.empty(S, dtype=torch.int64, device=dev)

@@ -193,7 +193,9 @@ class NeRFScene:
 
     # ---- rendering (nerf.py:74-123) --------------------------------------------------------------
     @torch.no_grad()
-    def render(self, rays: Rays, query_keys=('rgb',), batch_size=32768):
+    def render(self, rays: Rays, query_keys=('rgb',), batch_size=262144):
+        # (the reference hard-codes 32,768-ray batches, nerf.py:86; rays are independent and eval has no randomness,
+        #  so the batch size does not change the result -- tests/test_gpu_fullsize.py -- only the launch overhead)
         last_train = self.nerf.training
         self.set_eval()
         rays_o, rays_d = rays.collapse()

@@ -38,6 +38,9 @@ def test_full_batch_march_bookkeeping(room_scene):
     t0 = torch.rand(R, device='cuda') * 5e-4
     max_steps = int(math.ceil(1.5 / 5e-4)) + 1
     ri, ts, te, packed = ops.occ_march(o, d, t0, est.occ_bits(), 256, est._aabb_host, 1.5, 5e-4, max_steps)
+    ri2, ts2, te2, packed2 = ops.occ_march(o, d, t0, est.occ_bits(), 256, est._aabb_host, 1.5, 5e-4, max_steps,
+                                           occ_coarse=est.occ_coarse())
+    assert torch.equal(ri, ri2) and torch.equal(ts, ts2) and torch.equal(te, te2) and torch.equal(packed, packed2)
     S = ri.numel()
     assert S > 100000
     assert bool((ri[1:] >= ri[:-1]).all())                                   # sorted by ray

@@ -273,11 +273,13 @@ def test_occ_march_bit_exact(ops, stratified):
     binaries = occ.reshape(64, 64, 64).bool()
     ri, ts, te, packed = O.occ_march(o.numpy(), d.numpy(), binaries.numpy(), aabb, near, far, step, t0.numpy(), max_steps)
     bits = ops.occ_pack_bits(occ.cuda())
-    gri, gts, gte, gpacked = ops.occ_march(o.cuda(), d.cuda(), t0.cuda(), bits, 64, aabb, far, step, max_steps)
     assert ri.size > 1000
-    assert np.array_equal(gri.cpu().numpy(), ri)
-    assert np.array_equal(gts.cpu().numpy(), ts) and np.array_equal(gte.cpu().numpy(), te)   # bit-exact floats
-    assert np.array_equal(gpacked.cpu().numpy(), packed)
+    coarse = ops.occ_build_coarse(bits, 64)
+    for cz in (None, coarse):            # exhaustive lattice test, and with the conservative empty-space skip
+        gri, gts, gte, gpacked = ops.occ_march(o.cuda(), d.cuda(), t0.cuda(), bits, 64, aabb, far, step, max_steps, occ_coarse=cz)
+        assert np.array_equal(gri.cpu().numpy(), ri)
+        assert np.array_equal(gts.cpu().numpy(), ts) and np.array_equal(gte.cpu().numpy(), te)   # bit-exact floats
+        assert np.array_equal(gpacked.cpu().numpy(), packed)
 
 
 def test_scan_and_empty(ops):

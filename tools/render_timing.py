@@ -40,7 +40,14 @@ out = scene.render(rays, ['rgb', 'distance'])
 torch.cuda.synchronize()
 t_render_plain = time.perf_counter() - t0
 derr = float((out['distance'] - dist).abs().mean())
+batch_times = {}
+for bsz in (32768, 262144, 1048576):
+    scene.render(rays, ['rgb', 'distance'], batch_size=bsz)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    o2 = scene.render(rays, ['rgb', 'distance'], batch_size=bsz)
+    torch.cuda.synchronize(); batch_times[bsz] = time.perf_counter() - t0
+    assert torch.equal(o2['rgb'], out['rgb']) and torch.equal(o2['distance'], out['distance'])
 tot = {k: n * ms for k, (n, ms) in kern.items()}
 print(json.dumps({'train_300_geo_steps_s': t_train, 'faithful_ms_per_geo_step': t_train / n_geo * 1e3, 'train_batch_mean_spp': spp_train,
-                  'full_pano_render_s': t_render_plain, 'rays_per_s': H * W / t_render_plain, 'mean_abs_distance_err': derr,
+                  'full_pano_render_s': t_render_plain, 'rays_per_s': H * W / t_render_plain, 'mean_abs_distance_err': derr, 'full_pano_render_s_by_batch_size': batch_times,
                   'kernel_ms_total': {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}}, indent=1))
