@@ -140,3 +140,30 @@ def test_direction_to_img_coord_and_morphology():
     assert torch.equal(V.erode(full, V.ellipse_kernel(9, 9)), full)           # borders do not erode
     hole = full.clone(); hole[0, 0, 10, 10] = 0
     assert float(V.erode(hole, k5).sum()) == 21 * 21 - float(k5.sum())        # erosion grows a hole by the kernel
+
+
+def test_config1_cpu_plumbing():
+    """BASELINE config 1 (pure-PyTorch field on CPU, 32 samples/ray, no GPU): the oracle's full geometry training
+    step -- sampling, both fields, compositing, losses, backward, Adam -- runs and reduces the loss."""
+    torch.manual_seed(0)
+    gs, as_ = O.geo_spec(), O.app_spec()
+    geo = O.init_field_params(gs).requires_grad_(True); app = O.init_field_params(as_)
+    o, d = O.pano_rays(torch.eye(4), 8, 16)
+    o = o.reshape(-1, 3); d = d.reshape(-1, 3)
+    gt, _ = O.synthetic_room(d)
+    occ = np.ones((8, 8, 8), bool)
+    m = torch.zeros_like(geo); v = torch.zeros_like(geo)
+    losses = []
+    for step in range(1, 4):
+        out = O.occ_render(o, d, geo, app, occ, [-1, -1, -1, 1, 1, 1], training=True, t0=np.zeros(len(o), np.float32),
+                           bg_color=torch.rand(len(o), 3), dist_noise=torch.full((len(o), 1), 0.5), near=0.0, far=10.0,
+                           step=0.99 / 32, early_stop_eps=0.0, max_steps=32)
+        assert out['ray_indices'].numel() == len(o) * 32
+        loss, dl, _ = O.geo_step_loss(out, gt, 0.25)
+        geo.grad = None
+        loss.backward()
+        with torch.no_grad():
+            p, m, v = O.adam_step(geo, geo.grad, m, v, step, 1e-2)
+            geo.copy_(p)
+        losses.append(float(dl))
+    assert losses[-1] < losses[0]

@@ -375,3 +375,39 @@ def test_pano_visibility_mask_same_pose_is_visible():
     ok_behind = geo_check(rays.o, rays.d, dist * 1.2, pool.sup_infos)
     ok_front = geo_check(rays.o, rays.d, dist * 0.5, pool.sup_infos)
     assert float(ok_behind.mean()) > 0.99 and float(ok_front.mean()) < 0.01
+
+
+def test_checkpoint_format_and_render_dense(tmp_path):
+    """next-4 / config 4: the scene state_dict has the reference's checkpoint layout (nerf.py:374-380,
+    core_exp_runner.py:248-256) and round-trips through torch.save; render_dense walks a dense trajectory."""
+    from perf_amd import synthetic
+    from perf_amd.pose_sampler import CirclePoseSampler
+    from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
+    from perf_amd.traverse import render_dense
+    torch.manual_seed(0)
+    scene = NeRFScene(dtype='fp16')
+    rays = gen_pano_rays(torch.eye(4), 64, 128)
+    dist, rgb = synthetic.room(rays.d)
+    pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, dist)
+    scene.set_train(); scene.prepare_occupancy(pool)
+    sd = scene.state_dict()
+    assert set(sd.keys()) == {'render', 'nerf', 'estimator'}
+    assert set(sd['nerf'].keys()) == {'aabb', 'geo_mlp.params', 'app_mlp.params'}
+    assert set(sd['estimator'].keys()) == {'resolution', 'aabbs', 'occs', 'binaries'}
+    assert sd['nerf']['geo_mlp.params'].dtype == torch.float32 and sd['nerf']['geo_mlp.params'].numel() == 3072 + 6641216
+    assert sd['estimator']['binaries'].shape == (1, 256, 256, 256) and sd['estimator']['binaries'].dtype == torch.bool
+    path = tmp_path / 'ckpt.pth'
+    torch.save({'scene': sd, 'phase': 3}, path)
+    before = scene.render(rays, ['rgb', 'distance'])
+    scene2 = NeRFScene(dtype='fp16')
+    with torch.no_grad():
+        scene2.nerf.geo_mlp.params.add_(1.0)                       # make sure loading really restores the weights
+    ck = torch.load(path, map_location='cuda')
+    scene2.load_state_dict(ck['scene'])
+    after = scene2.render(rays, ['rgb', 'distance'])
+    assert torch.equal(before['rgb'], after['rgb']) and torch.equal(before['distance'], after['distance'])
+    sampler = CirclePoseSampler(dist[..., 0].cpu(), [.2, .4, .6], [8, 8, 8])
+    import numpy as np
+    np.random.seed(0)
+    frames = render_dense(scene2, sampler, n_poses=12, height=32, width=64, max_frames=3)
+    assert len(frames) == 3 and frames[0]['rgb'].shape == (32, 64, 3) and torch.isfinite(frames[2]['distance']).all()
