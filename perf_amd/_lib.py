@@ -66,7 +66,9 @@ _SIGS = {
     'perf_accumulate_fwd': (c_int, [P, P, P, c_int64, c_int32, P, P]),
     'perf_pack_info': (c_int, [P, c_int64, c_int64, P, P]),
     'perf_distloss_fwd': (c_int, [P, P, P, P, c_int64, P, P]),
-    'perf_distloss_bwd': (c_int, [P, P, P, P, c_int64, c_float, P, P]),
+    'perf_distloss_bwd': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
+    'perf_geo_loss': (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_float, c_float, P, c_float, P, P, P, P]),
+    'perf_app_loss': (c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, P, P, P]),
     'perf_pdf_resample': (c_int, [P, P, P, c_int64, c_int32, c_int32, P, P]),
     'perf_occ_splat': (c_int, [P, P, P, c_int64, c_int32, P, P]),
 }

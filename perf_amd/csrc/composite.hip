@@ -201,10 +201,12 @@ __global__ __launch_bounds__(256) void distloss_fwd_kernel(const float* __restri
 // d loss / d w_i = scale * ( 2/3 d_i w_i + 2 ( m_i (W_i - Wsuf_i) - (WM_i - WMsuf_i) ) )
 __global__ __launch_bounds__(256) void distloss_bwd_kernel(const float* __restrict__ w, const float* __restrict__ ts,
                                                            const float* __restrict__ te, const int32_t* __restrict__ packed,
-                                                           int64_t n_rays, float scale, float* __restrict__ g_w) {
+                                                           int64_t n_rays, float scale, const float* __restrict__ scale_dev,
+                                                           float* __restrict__ g_w) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rays) return;
+    if (scale_dev) scale *= scale_dev[0];
     const int64_t start = packed[2 * r];
     const int cnt = packed[2 * r + 1];
     float totW = 0.f, totWM = 0.f;
@@ -328,12 +330,12 @@ extern "C" int perf_distloss_fwd(const float* w, const float* t_starts, const fl
 }
 
 extern "C" int perf_distloss_bwd(const float* w, const float* t_starts, const float* t_ends, const int32_t* packed_info,
-                                 int64_t n_rays, float scale, float* g_w, void* stream) {
+                                 int64_t n_rays, float scale, const float* scale_dev, float* g_w, void* stream) {
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && g_w, "NULL pointer");
     hipLaunchKernelGGL(distloss_bwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), w, t_starts, t_ends,
-                       packed_info, n_rays, scale, g_w);
+                       packed_info, n_rays, scale, scale_dev, g_w);
     PERF_LAUNCH_CHECK("perf_distloss_bwd");
     return PERF_OK;
 }
@@ -395,5 +397,111 @@ extern "C" int perf_pdf_resample(const float* s_in, const float* cdf, const floa
     hipLaunchKernelGGL(perf::pdf_resample_kernel, dim3((unsigned)perf::div_up(total, 256)), dim3(256), 0, perf::as_stream(stream),
                        s_in, cdf, tau, n_rays, (int)n_in, (int)n_out, s_out);
     PERF_LAUNCH_CHECK("perf_pdf_resample");
+    return PERF_OK;
+}
+
+// ---- training-step loss heads (modules/scene/nerf.py:208-252 geometry, :281-293 colour), fused ---------------------
+// One single-workgroup kernel replaces ~25 tiny elementwise/reduction launches of the autograd formulation: it applies
+// the training-time noise/background terms of nerf_renderer.py:185-194, the smooth-L1 losses, the loss scale and
+// produces the per-ray gradients the compositing backward consumes plus the scalars the distortion-loss backward needs.
+namespace perf {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// smooth_l1(x, beta): 0.5 x^2 / beta for |x| < beta else |x| - 0.5 beta;  derivative x/beta or sign(x)
+__device__ __forceinline__ float sl1(float x, float beta) { const float a = fabsf(x); return a < beta ? 0.5f * x * x / beta : a - 0.5f * beta; }
+__device__ __forceinline__ float sl1_grad(float x, float beta) { return fabsf(x) < beta ? x / beta : (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f)); }
+
+// scalars out: [0] depth loss (mean over the global batch), [1] distortion loss, [2] scale for perf_distloss_bwd
+__global__ __launch_bounds__(256) void geo_loss_kernel(const float* __restrict__ opacity, const float* __restrict__ distance,
+                                                       const float* __restrict__ gt, const float* __restrict__ noise,
+                                                       const float* __restrict__ dl_per_ray, const int32_t* __restrict__ packed,
+                                                       int64_t n_rays, float inv_bs, float depth_w, float dist_w,
+                                                       const float* __restrict__ ratio_dev, float loss_scale, float n_rays_scale,
+                                                       float* __restrict__ g_op, float* __restrict__ g_dist,
+                                                       float* __restrict__ scalars) {
+    __shared__ float red[4];
+    __shared__ int last_s;
+    if (threadIdx.x == 0) last_s = -1;
+    __syncthreads();
+    float dsum = 0.f, lsum = 0.f;
+    int last = -1;
+    for (int64_t r = threadIdx.x; r < n_rays; r += 256) {
+        const float op = opacity[r];
+        const float nz = noise ? (noise[r] * 2.0f - 1.0f) : 0.0f;
+        const float pre = distance[r] + nz * (1.0f - op);
+        const float d = fmaxf(pre, 0.0f);
+        const float diff = d - gt[r];
+        dsum += sl1(diff, 1e-2f);
+        const float gd = (pre > 0.0f) ? sl1_grad(diff, 1e-2f) * inv_bs * depth_w * loss_scale : 0.0f;
+        g_dist[r] = gd;
+        g_op[r] = -nz * gd;
+        lsum += dl_per_ray[r];
+        if (packed[2 * r + 1] > 0) last = (int)r;
+    }
+    atomicMax(&last_s, last);
+    const float depth = block_sum_256(dsum, red) * inv_bs;
+    const float distl_sum = block_sum_256(lsum, red);
+    if (threadIdx.x == 0) {
+        // flatten_eff_distloss divides by ray_id.max()+1 (the last ray that has samples); n_rays_scale rescales it for
+        // data-parallel runs (local count -> global batch)
+        // data parallel (the local batch is a slice of the global one): normalise by the global batch instead
+        const float inv_n = (n_rays_scale < 0.f) ? inv_bs : 1.0f / (float)(last_s + 1 > 0 ? last_s + 1 : 1);
+        n_rays_scale = 1.0f;
+        const float ratio = ratio_dev ? ratio_dev[0] : 1.0f;
+        scalars[0] = depth;
+        scalars[1] = distl_sum * inv_n * n_rays_scale;
+        scalars[2] = inv_n * n_rays_scale * dist_w * ratio * loss_scale;
+    }
+}
+
+// colour head: colors' = col + bg * (1 - opacity); loss = mean smooth_l1(colors' - gt, 0.05) over bs*3; g_col = d loss / d col
+__global__ __launch_bounds__(256) void app_loss_kernel(const float* __restrict__ opacity, const float* __restrict__ color,
+                                                       const float* __restrict__ bg, const float* __restrict__ gt,
+                                                       int64_t n_rays, float inv_n, float color_w, float loss_scale,
+                                                       float* __restrict__ g_col, float* __restrict__ scalars) {
+    __shared__ float red[4];
+    float sum = 0.f;
+    for (int64_t i = threadIdx.x; i < n_rays * 3; i += 256) {
+        const int64_t r = i / 3;
+        const float c = color[i] + (bg ? bg[i] : 0.0f) * (1.0f - opacity[r]);
+        const float diff = c - gt[i];
+        sum += sl1(diff, 5e-2f);
+        g_col[i] = sl1_grad(diff, 5e-2f) * inv_n * color_w * loss_scale;
+    }
+    const float tot = block_sum_256(sum, red);
+    if (threadIdx.x == 0) scalars[0] = tot * inv_n;
+}
+
+}  // namespace perf
+
+extern "C" int perf_geo_loss(const float* opacity, const float* distance, const float* gt_distance, const float* noise,
+                             const float* distloss_per_ray, const int32_t* packed_info, int64_t n_rays, int64_t global_batch,
+                             float depth_weight, float distortion_weight, const float* ratio_dev, float loss_scale,
+                             float* g_opacity, float* g_distance, float* scalars, void* stream) {
+    PERF_REQUIRE(n_rays > 0 && global_batch > 0, "perf_geo_loss: empty batch");
+    PERF_REQUIRE(opacity && distance && gt_distance && distloss_per_ray && packed_info && g_opacity && g_distance && scalars, "NULL pointer");
+    const float n_rays_scale = (n_rays != global_batch) ? -1.0f : 1.0f;      // < 0: data-parallel normalisation
+    hipLaunchKernelGGL(perf::geo_loss_kernel, dim3(1), dim3(256), 0, perf::as_stream(stream), opacity, distance, gt_distance, noise,
+                       distloss_per_ray, packed_info, n_rays, 1.0f / (float)global_batch, depth_weight, distortion_weight, ratio_dev,
+                       loss_scale, n_rays_scale, g_opacity, g_distance, scalars);
+    PERF_LAUNCH_CHECK("perf_geo_loss");
+    return PERF_OK;
+}
+
+extern "C" int perf_app_loss(const float* opacity, const float* color, const float* bg_color, const float* gt_color,
+                             int64_t n_rays, int64_t global_batch, float color_weight, float loss_scale, float* g_color,
+                             float* scalars, void* stream) {
+    PERF_REQUIRE(n_rays > 0 && global_batch > 0, "perf_app_loss: empty batch");
+    PERF_REQUIRE(opacity && color && gt_color && g_color && scalars, "NULL pointer");
+    hipLaunchKernelGGL(perf::app_loss_kernel, dim3(1), dim3(256), 0, perf::as_stream(stream), opacity, color, bg_color, gt_color,
+                       n_rays, 1.0f / (float)(global_batch * 3), color_weight, loss_scale, g_color, scalars);
+    PERF_LAUNCH_CHECK("perf_app_loss");
     return PERF_OK;
 }

@@ -342,8 +342,8 @@ def composite_bwd(sigmas, t_starts, t_ends, packed, weights, trans, g_weights=No
     R = packed.shape[0]
     S = sigmas.numel()
     dev = sigmas.device
-    ds = torch.empty(S, dtype=torch.float32, device=dev) if want_dsigma else None
-    dr = torch.empty(S, 3, dtype=torch.float32, device=dev) if want_drgb else None
+    ds = torch.zeros(S, dtype=torch.float32, device=dev) if want_dsigma else None
+    dr = torch.zeros(S, 3, dtype=torch.float32, device=dev) if want_drgb else None
     _call('perf_composite_bwd', _p(sigmas), _p(t_starts), _p(t_ends), _p(packed), R, _p(weights), _p(trans),
               _p(g_weights), _p(g_trans), _p(g_alphas), _p(g_opacity), _p(g_distance), _p(g_color), _p(ds), _p(dr), _stream())
     return ds, dr
@@ -370,11 +370,34 @@ def distloss_fwd(w, t_starts, t_ends, packed):
     return loss
 
 
-def distloss_bwd(w, t_starts, t_ends, packed, scale):
+def distloss_bwd(w, t_starts, t_ends, packed, scale, scale_dev=None):
     R = packed.shape[0]
-    g = torch.empty_like(w)
-    _call('perf_distloss_bwd', _p(_f32(w, 'w')), _p(t_starts), _p(t_ends), _p(packed), R, float(scale), _p(g), _stream())
+    g = torch.zeros_like(w)
+    _call('perf_distloss_bwd', _p(_f32(w, 'w')), _p(t_starts), _p(t_ends), _p(packed), R, float(scale), _p(scale_dev), _p(g), _stream())
     return g
+
+
+def geo_loss(opacity, distance, gt_distance, noise, distloss_per_ray, packed, global_batch, depth_weight, distortion_weight,
+             ratio_dev, loss_scale):
+    """-> (g_opacity [R,1], g_distance [R,1], scalars [3] = depth loss, distortion loss, distloss-backward scale)."""
+    R = packed.shape[0]
+    dev = opacity.device
+    g_op = torch.empty(R, 1, dtype=torch.float32, device=dev); g_d = torch.empty(R, 1, dtype=torch.float32, device=dev)
+    sc = torch.empty(3, dtype=torch.float32, device=dev)
+    _call('perf_geo_loss', _p(opacity), _p(distance), _p(_f32(gt_distance.contiguous(), 'gt')), _p(noise), _p(distloss_per_ray), _p(packed), R,
+          int(global_batch), float(depth_weight), float(distortion_weight), _p(ratio_dev), float(loss_scale), _p(g_op), _p(g_d), _p(sc),
+          _stream())
+    return g_op, g_d, sc
+
+
+def app_loss(opacity, color, bg_color, gt_color, global_batch, color_weight, loss_scale):
+    """-> (g_color [R,3], scalars [1] = colour loss)."""
+    R = opacity.shape[0]
+    g_c = torch.empty(R, 3, dtype=torch.float32, device=opacity.device)
+    sc = torch.empty(1, dtype=torch.float32, device=opacity.device)
+    _call('perf_app_loss', _p(opacity), _p(color), _p(bg_color), _p(_f32(gt_color.contiguous(), 'gt')), R, int(global_batch), float(color_weight),
+          float(loss_scale), _p(g_c), _p(sc), _stream())
+    return g_c, sc
 
 
 def occ_splat(rays_o, rays_d, dist, res):

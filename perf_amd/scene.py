@@ -179,6 +179,7 @@ class NeRFScene:
         self.loss_scale = 2.0 ** 7
         self.last_losses = {}
         self._capturing = False
+        self.fused_steps = True        # explicit kernel chains for the two training steps (False: autograd formulation)
         self.overlap_comm = True       # DP: overlap the gradient all-reduce with the next step's prefetch
         self._geo_pre = None
         self._ratio_dev = torch.zeros((), dtype=torch.float32, device='cuda')   # distortion-loss ramp min(2*progress, 1)
@@ -306,7 +307,118 @@ class NeRFScene:
                 st = st if st is not None else False
         return {'rays': rays, 'gt_depths': gt_depths, 'bs': bs, 'dist_info': dist_info, 'st': st}
 
+    # ---- fused steps: explicit kernel chain instead of autograd + ~25 tiny torch ops (same arithmetic) ----------
+    def _field_grad(self, net, x01, w16, feat, sel, dout):
+        n_net = net.mlp.n_params
+        fixed = _tcnn.GRID_GRAD_ACCUM == 'fixed'
+        res = ops.mlp_bwd(net.mlp, w16[:n_net], feat, dout, sel, want_absmax=fixed)
+        grad = torch.empty(n_net + net.grid.n_params, dtype=torch.float32, device=x01.device)
+        grad[:n_net] = res[1]
+        ops.hashgrid_bwd_into(net.grid, x01, res[0], grad[n_net:], level_absmax=res[2] if fixed else None)
+        return grad
+
+    def _apply_grad(self, net, grad, optimizer, dist_info, overlap):
+        dist = dist_info[0]
+        net.params.grad = grad
+        if dist is not None:
+            if overlap is not None:
+                work = dist.all_reduce(grad, op=dist.ReduceOp.SUM, async_op=True)
+                overlap()
+                work.wait()
+            else:
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+        optimizer.step()
+        self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
+        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY and _tcnn.GRID_GRAD_ACCUM == 'fixed':
+            self._steps_since_check = 0
+            _tcnn.check_fixed_point_overflow(net.params.device)
+
+    @torch.no_grad()
+    def _geo_step_fused(self, optimizer, sup_pool, progress, rand, generator):
+        """train_one_step_geo (nerf.py:186-257) as an explicit chain: sampling -> density field (kept features) -> colour
+        field -> compositing -> fused loss head -> distortion / compositing / MLP / grid backward -> [all-reduce] -> Adam."""
+        tc = self.train_conf
+        rand = rand or {}
+        pre = self._geo_pre or self._geo_prefetch(sup_pool, rand, generator)
+        self._geo_pre = None
+        rays, gt_depths, bs, dist_info = pre['rays'], pre['gt_depths'], pre['bs'], pre['dist_info']
+        st = pre['st']
+        if st is None:
+            st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=True)
+        geo = self.nerf.geo_mlp
+        if st is None or st is False:
+            if dist_info[0] is not None:
+                self._apply_grad(geo, torch.zeros_like(geo.params), optimizer, dist_info, None)
+            self.global_iter_step_geo += 1
+            return
+        x01, sel, packed, ts, te = st['x01'], st['sel'], st['packed'], st['t_starts'], st['t_ends']
+        n_net = geo.mlp.n_params
+        w16 = geo.working_copy()
+        feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:])
+        sig = ops.mlp_fwd(geo.mlp, w16[:n_net], feat, sel)
+        rgbs = st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel)
+        w, T, _, op, dist_r, col = ops.composite_fwd(sig.view(-1), rgbs, ts, te, packed)
+        n_rays = op.shape[0]
+        noise = rand['noise'] if 'noise' in rand else torch.rand(n_rays, 1, device=op.device)
+        if self.renderer.bg_color == 'rand_noise' and 'bg' not in rand:
+            torch.rand(n_rays, 3, device=op.device)              # the reference draws the background too (:185)
+        dl = ops.distloss_fwd(w, ts, te, packed)
+        if not self._capturing:
+            self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
+        g_op, g_dist, sc = ops.geo_loss(op, dist_r, gt_depths, noise, dl, packed, bs, tc.depth_loss_weight,
+                                        tc.distortion_loss_weight, self._ratio_dev, self.loss_scale)
+        g_w = ops.distloss_bwd(w, ts, te, packed, 1.0, scale_dev=sc[2:3])
+        dsig, _ = ops.composite_bwd(sig.view(-1), ts, te, packed, w, T, g_weights=g_w, g_opacity=g_op, g_distance=g_dist)
+        grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1))
+        self.last_losses['depth_loss'] = sc[0]; self.last_losses['dist_loss'] = sc[1]
+        overlap = (lambda: setattr(self, '_geo_pre', self._geo_prefetch(sup_pool, rand, generator))) \
+            if (self.overlap_comm and dist_info[0] is not None) else None
+        self._apply_grad(geo, grad, optimizer, dist_info, overlap)
+        self.global_iter_step_geo += 1
+
+    @torch.no_grad()
+    def _app_step_fused(self, optimizer, sup_pool, progress, rand, generator):
+        """train_one_step_app (nerf.py:259-297): density without gradient (reused from the sampler's visibility pass when
+        there is one), colour field with gradient, colour smooth-L1."""
+        tc = self.train_conf
+        rand = rand or {}
+        rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
+        st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand)
+        app = self.nerf.app_mlp
+        if st is None:
+            if dist_info[0] is not None:
+                self._apply_grad(app, torch.zeros_like(app.params), optimizer, dist_info, None)
+            self.global_iter_step_app += 1
+            return
+        x01, sel, packed, ts, te = st['x01'], st['sel'], st['packed'], st['t_starts'], st['t_ends']
+        sig = st['sig0'] if st['sig0'] is not None else self.nerf.density_at(x01, sel)
+        n_net = app.mlp.n_params
+        w16 = app.working_copy()
+        feat = ops.hashgrid_fwd(app.grid, x01, w16[n_net:])
+        rgbs = ops.mlp_fwd(app.mlp, w16[:n_net], feat, sel)
+        w, T, _, op, dist_r, col = ops.composite_fwd(sig.reshape(-1).contiguous(), rgbs, ts, te, packed)
+        n_rays = op.shape[0]
+        bg = None
+        if self.renderer.bg_color == 'rand_noise':
+            bg = rand['bg'] if 'bg' in rand else torch.rand(n_rays, 3, device=op.device)
+        elif self.renderer.bg_color == 'white':
+            bg = torch.ones(n_rays, 3, device=op.device)
+        if 'noise' not in rand:
+            torch.rand(n_rays, 1, device=op.device)               # the distance noise draw of :193 (unused by this loss)
+        g_col, sc = ops.app_loss(op, col, bg, gt_colors, bs, tc.color_loss_weight, self.loss_scale)
+        _, drgb = ops.composite_bwd(sig.reshape(-1).contiguous(), ts, te, packed, w, T, g_color=g_col, want_dsigma=False, want_drgb=True)
+        grad = self._field_grad(app, x01, w16, feat, sel, drgb)
+        self.last_losses['color_loss'] = sc[0]
+        self._apply_grad(app, grad, optimizer, dist_info, None)
+        self.global_iter_step_app += 1
+
+    def _can_fuse(self):
+        tc = self.train_conf
+        return self.fused_steps and tc.density_loss_weight <= 1e-7 and tc.depth_loss_weight > 1e-7 and tc.distortion_loss_weight > 1e-7
+
     def train_one_step_geo(self, optimizer, sup_pool, progress, rand=None, generator=None):
+        if self._can_fuse():
+            return self._geo_step_fused(optimizer, sup_pool, progress, rand, generator)
         tc = self.train_conf
         optimizer.zero_grad()
         pre = getattr(self, '_geo_pre', None) or self._geo_prefetch(sup_pool, rand, generator)
@@ -347,6 +459,8 @@ class NeRFScene:
         self.global_iter_step_geo += 1
 
     def train_one_step_app(self, optimizer, sup_pool, progress, rand=None, generator=None):
+        if self.fused_steps and self.train_conf.color_loss_weight > 1e-7:
+            return self._app_step_fused(optimizer, sup_pool, progress, rand, generator)
         tc = self.train_conf
         optimizer.zero_grad()
         rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)

@@ -440,3 +440,49 @@ def test_training_is_bit_reproducible():
 
     g1, a1 = run(); g2, a2 = run()
     assert torch.equal(g1, g2) and torch.equal(a1, a2)
+
+
+def test_fused_steps_equal_autograd_steps():
+    """The explicit kernel chains of the two training steps give the same parameter updates as the autograd formulation
+    (same seeds, default bit-reproducible accumulation): gradients agree to fp32 rounding of the loss-scale products."""
+    from perf_amd import synthetic
+    from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
+
+    def run(fused, faithful):
+        torch.manual_seed(0)
+        scene = NeRFScene(dtype='fp16')
+        scene.fused_steps = fused
+        rays = gen_pano_rays(torch.eye(4), 64, 128)
+        d_, rgb = synthetic.room(rays.d)
+        pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, d_)
+        scene.train_conf.pixel_loss_batch_size = 1024
+        scene.set_train()
+        if faithful:
+            scene.prepare_occupancy(pool)
+        else:
+            scene.estimator.set_binaries(torch.ones(256 ** 3, dtype=torch.uint8, device='cuda'))
+            r = scene.renderer
+            r.render_step_size = 0.99 / 32; r.far_plane = 10.0; r.early_stop_eps = 0.0; r.max_steps = 32
+        scene.nerf.reset_geo()
+        gen = torch.Generator(device='cuda'); gen.manual_seed(5)
+        g = torch.Generator(device='cuda'); g.manual_seed(9)
+        opt = scene.make_optimizer(scene.nerf.geo_mlp, 1e-3)
+        for i in range(3):
+            rand = {'jitter': torch.rand(1024, device='cuda', generator=g), 'bg': torch.rand(1024, 3, device='cuda', generator=g),
+                    'noise': torch.rand(1024, 1, device='cuda', generator=g)}
+            scene.train_one_step_geo(opt, pool, progress=0.3, rand=rand, generator=gen)
+        dl = float(scene.last_losses['depth_loss']); dd = float(scene.last_losses['dist_loss'])
+        opt2 = scene.make_optimizer(scene.nerf.app_mlp, 1e-3)
+        for i in range(2):
+            rand = {'jitter': torch.rand(1024, device='cuda', generator=g), 'bg': torch.rand(1024, 3, device='cuda', generator=g),
+                    'noise': torch.rand(1024, 1, device='cuda', generator=g)}
+            scene.train_one_step_app(opt2, pool, progress=0.3, rand=rand, generator=gen)
+        return scene.nerf.geo_mlp.params.detach().clone(), scene.nerf.app_mlp.params.detach().clone(), dl, dd, float(scene.last_losses['color_loss'])
+
+    for faithful in (False, True):
+        g0, a0, dl0, dd0, cl0 = run(False, faithful)
+        g1, a1, dl1, dd1, cl1 = run(True, faithful)
+        assert abs(dl0 - dl1) < 1e-5 * max(1, abs(dl0)) and abs(dd0 - dd1) < 1e-4 * max(1e-3, abs(dd0)) and abs(cl0 - cl1) < 1e-5
+        # Adam divides by sqrt(v): tiny gradient differences can flip the sign of a near-zero update, so compare loosely
+        assert float((g0 - g1).abs().max()) < 2.5e-3 and float((g0 - g1).abs().mean()) < 2e-5
+        assert float((a0 - a1).abs().max()) < 2.5e-3 and float((a0 - a1).abs().mean()) < 2e-5
