@@ -131,8 +131,11 @@ int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const fl
  * level_absmax == NULL: fp32 LDS accumulation.  level_absmax != NULL (device, PERF_MAX_LEVELS floats, the
  * per-level max |dfeat| as produced by perf_mlp_bwd): packed fixed-point accumulation with full-rate integer
  * LDS atomics, unit = 2^ceil(log2 absmax) * 2^-19; *overflow_flag (device int32, may be NULL) is OR-ed with 1
- * when any field comes within 2x of the int32 range (then repeat the call with level_absmax == NULL). */
-int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid);
+ * when any field comes within 2x of the int32 range (then repeat the call with level_absmax == NULL).
+ * workspace: 16-byte aligned device scratch of perf_hashgrid_bwd_workspace_bytes(grid, n) bytes (replica slabs of
+ * the coarse levels + 4 bytes per (sample, hashed level) of tile codes; a workspace without room for the codes
+ * is accepted and selects the slower position-streaming owners). */
+int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n);
 int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
                       float* grad_table, int64_t n, int accumulate, const float* level_absmax,
                       int32_t* overflow_flag, void* workspace, int64_t workspace_bytes, void* stream);

@@ -233,7 +233,13 @@ struct TileParams {
     int32_t accumulate;
     int32_t fixed_headroom_log2;           // fixed-point mode: log2 of the assumed max sum / max contribution
     int64_t dbg_off;                       // >0: float2 offset in the workspace where per-block cycle counts go (dev tool)
+    int32_t code_slot[PERF_MAX_LEVELS];    // >=0: the level's tile codes are codes[slot][n_pad] (see tile_codes_kernel)
+    int64_t n_pad;
 };
+
+constexpr int kQueueCap = 384;             // per-wave match queue (entries): <128 left over + 4 x 64 new ones
+constexpr int64_t kDbgBytes = 4096 * 8;
+constexpr int64_t kMaxCodedSamples = (int64_t)1 << 28;
 
 static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
     int nb = 0;
@@ -241,12 +247,13 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->tiles_of[l] = 0; tp->replicas_of[l] = 1; tp->ws_off[l] = 0;
         if (l >= gp.n_levels) continue;
-        const int nt = (int)((gp.size[l] + kTileEntries - 1) / kTileEntries);
-        // replication factors from measured per-workgroup times (tools/exp/bwd_block_times.py, 1 M samples):
-        // hashed tile 0.68 ms; dense tile streaming ALL samples: 1 tile 2.7-4.1 ms, 3 tiles 2.9 ms, 8 tiles 2.2 ms
+        int nt = (int)((gp.size[l] + kTileEntries - 1) / kTileEntries);
+        if (!gp.hashed[l]) { int p = 1; while (p < nt) p <<= 1; nt = p; }     // dense ownership is a bit field of the index
+        // replication factors from measured per-workgroup times (tools/exp/bwd_block_times.py, 1 M samples, fixed):
+        // hashed tile (coded) 0.36-0.39 ms; dense tile streaming ALL samples: 1 tile 2.4 ms, 4 tiles 0.88 ms, 8 tiles 0.68 ms
         // (fp32 mode is bound by ds_add_f32 lane-serialisation instead: equal corner-update counts, r = 16 / nt)
         int r = 1;
-        if (!gp.hashed[l]) r = fixed ? ((nt == 1) ? 8 : (nt <= 4 ? 5 : (nt <= 8 ? 4 : (nt < 16 ? 2 : 1)))) : kMaxReplicas / nt;
+        if (!gp.hashed[l]) r = fixed ? ((nt == 1) ? 8 : (nt <= 4 ? 3 : (nt <= 16 ? 2 : 1))) : kMaxReplicas / nt;
         if (r < 1) r = 1;
         if (r > kMaxReplicas) r = kMaxReplicas;
         tp->tiles_of[l] = nt; tp->replicas_of[l] = r;
@@ -257,25 +264,76 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
 }
 
 // Tile ownership.  Hashed levels: tile = idx / 16384 (the hash already spreads cells uniformly).  Dense levels:
-// ownership is INTERLEAVED in chunks of 32 entries (chunk c = idx/32 belongs to tile c % n_tiles, local slot
-// (c / n_tiles)*32 + idx%32) -- contiguous slabs would be spatial slabs, and samples concentrate near the
+// ownership is INTERLEAVED in chunks of 32 entries over a power-of-two number of tiles (chunk c = idx/32 belongs
+// to tile c % n_tiles, local slot (c / n_tiles)*32 + idx%32) -- contiguous slabs would be spatial slabs, and samples concentrate near the
 // camera / the surfaces, which overloads a few owners.
 constexpr uint32_t kChunk = 32;
 
 struct BwdCtx {
     float scale, to_fixed;
     uint32_t res, r2, size, mask, n_tiles, t;
-    float inv_tiles;
+    uint32_t tile_shift;        // dense levels: log2(n_tiles)
     bool smooth;
 };
 
-// c / n_tiles and c % n_tiles for c < 2^22 through an fp32 reciprocal with a one-step correction
-__device__ __forceinline__ void divmod_small(uint32_t c, uint32_t n, float inv, uint32_t* q, uint32_t* r) {
-    uint32_t qq = (uint32_t)((float)c * inv);
-    int32_t rr = (int32_t)(c - qq * n);
-    if (rr < 0) { --qq; rr += (int32_t)n; }
-    if (rr >= (int32_t)n) { ++qq; rr -= (int32_t)n; }
-    *q = qq; *r = (uint32_t)rr;
+// (y,z)-combination updates of one sample in a hashed tile: both x-corners of every combination in `cm`
+// (bit c: by = c & 1, bz = c >> 1).  Requires gx + 1 < kTileEntries (the tile then depends on (y,z) only).
+template <bool FIXED>
+__device__ __forceinline__ void apply_pairs(const BwdCtx& cx, float* lds_tile, const float2 g, const uint32_t gx, float fx,
+                                            float fy, float fz, const uint32_t ay0, const uint32_t az0, uint32_t cm) {
+    unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
+    if (cx.smooth) { fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz); }
+    const uint32_t tlo = cx.t * (uint32_t)kTileEntries;
+    const float sx = g.x * cx.to_fixed, sy = g.y * cx.to_fixed;
+    while (cm) {
+        const int c = __ffs(cm) - 1;
+        cm &= cm - 1u;
+        const int by = c & 1, bz = c >> 1;
+        const uint32_t h = (by ? ay0 + kPrimeY : ay0) ^ (bz ? az0 + kPrimeZ : az0);
+        const float wyz = (by ? fy : 1.0f - fy) * (bz ? fz : 1.0f - fz);
+        const uint32_t a0 = ((gx ^ h) & cx.mask) - tlo, a1 = (((gx + 1u) ^ h) & cx.mask) - tlo;
+        const float w0 = (1.0f - fx) * wyz, w1 = fx * wyz;
+        if (FIXED) {
+            const long long v0 = ((long long)__float2int_rn(w0 * sy) << 32) + (long long)__float2int_rn(w0 * sx);
+            const long long v1 = ((long long)__float2int_rn(w1 * sy) << 32) + (long long)__float2int_rn(w1 * sx);
+            atomicAdd(&lds64[a0], (unsigned long long)v0);
+            atomicAdd(&lds64[a1], (unsigned long long)v1);
+        } else {
+            unsafeAtomicAdd(&lds_tile[2 * a0], w0 * g.x); unsafeAtomicAdd(&lds_tile[2 * a0 + 1], w0 * g.y);
+            unsafeAtomicAdd(&lds_tile[2 * a1], w1 * g.x); unsafeAtomicAdd(&lds_tile[2 * a1 + 1], w1 * g.y);
+        }
+    }
+}
+
+// Dense-level counterpart (interleaved 32-entry chunks): the two x-corners of a (y,z) combination are tested
+// separately -- they part at a chunk boundary -- and a combination that would wrap past the end of the level
+// (position far outside the unit cube; such a level takes the generic owners, see tile_codes_kernel) is skipped.
+template <bool FIXED>
+__device__ __forceinline__ void apply_pairs_dense(const BwdCtx& cx, float* lds_tile, const float2 g, const uint32_t gx, float fx,
+                                                  float fy, float fz, const uint32_t ay0, const uint32_t az0, uint32_t cm) {
+    unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
+    if (cx.smooth) { fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz); }
+    const float sx = g.x * cx.to_fixed, sy = g.y * cx.to_fixed;
+    const uint32_t tmask = cx.n_tiles - 1u;
+    while (cm) {
+        const int c = __ffs(cm) - 1;
+        cm &= cm - 1u;
+        const int by = c & 1, bz = c >> 1;
+        const uint32_t i0 = gx + (by ? ay0 + cx.res : ay0) + (bz ? az0 + cx.r2 : az0), i1 = i0 + 1u;
+        if (i1 >= cx.size || i1 == 0u) continue;
+        const float wy = by ? fy : 1.0f - fy, wz = bz ? fz : 1.0f - fz;
+        const float w0 = ((1.0f - fx) * wy) * wz, w1 = (fx * wy) * wz;      // association of the generic owners
+        const uint32_t c0 = i0 / kChunk, c1 = i1 / kChunk;
+        const uint32_t a0 = (c0 >> cx.tile_shift) * kChunk + (i0 % kChunk), a1 = (c1 >> cx.tile_shift) * kChunk + (i1 % kChunk);
+        if ((c0 & tmask) == cx.t) {
+            if (FIXED) atomicAdd(&lds64[a0], (unsigned long long)(((long long)__float2int_rn(w0 * sy) << 32) + (long long)__float2int_rn(w0 * sx)));
+            else { unsafeAtomicAdd(&lds_tile[2 * a0], w0 * g.x); unsafeAtomicAdd(&lds_tile[2 * a0 + 1], w0 * g.y); }
+        }
+        if ((c1 & tmask) == cx.t) {
+            if (FIXED) atomicAdd(&lds64[a1], (unsigned long long)(((long long)__float2int_rn(w1 * sy) << 32) + (long long)__float2int_rn(w1 * sx)));
+            else { unsafeAtomicAdd(&lds_tile[2 * a1], w1 * g.x); unsafeAtomicAdd(&lds_tile[2 * a1 + 1], w1 * g.y); }
+        }
+    }
 }
 
 // one sample's contribution to the tile this workgroup owns
@@ -299,27 +357,7 @@ __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, con
             for (int c = 0; c < 4; ++c)
                 cm |= (((((ay[c & 1] ^ az[c >> 1]) & cx.mask) / (uint32_t)kTileEntries) == cx.t) ? 1u : 0u) << c;
             if (cm == 0) return;
-            if (cx.smooth) { fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz); }
-            const uint32_t tlo = cx.t * (uint32_t)kTileEntries;
-            while (cm) {
-                const int c = __ffs(cm) - 1;
-                cm &= cm - 1u;
-                const int by = c & 1, bz = c >> 1;
-                const uint32_t h = (by ? ay[1] : ay[0]) ^ (bz ? az[1] : az[0]);
-                const float wyz = (by ? fy : 1.0f - fy) * (bz ? fz : 1.0f - fz);
-                const uint32_t a0 = ((gx ^ h) & cx.mask) - tlo, a1 = (((gx + 1u) ^ h) & cx.mask) - tlo;
-                const float w0 = (1.0f - fx) * wyz, w1 = fx * wyz;
-                if (FIXED) {
-                    const float sx = g.x * cx.to_fixed, sy = g.y * cx.to_fixed;
-                    const long long v0 = ((long long)__float2int_rn(w0 * sy) << 32) + (long long)__float2int_rn(w0 * sx);
-                    const long long v1 = ((long long)__float2int_rn(w1 * sy) << 32) + (long long)__float2int_rn(w1 * sx);
-                    atomicAdd(&lds64[a0], (unsigned long long)v0);
-                    atomicAdd(&lds64[a1], (unsigned long long)v1);
-                } else {
-                    unsafeAtomicAdd(&lds_tile[2 * a0], w0 * g.x); unsafeAtomicAdd(&lds_tile[2 * a0 + 1], w0 * g.y);
-                    unsafeAtomicAdd(&lds_tile[2 * a1], w1 * g.x); unsafeAtomicAdd(&lds_tile[2 * a1 + 1], w1 * g.y);
-                }
-            }
+            apply_pairs<FIXED>(cx, lds_tile, g, gx, fx, fy, fz, ay[0], az[0], cm);
             return;
         }
 #pragma unroll
@@ -335,9 +373,7 @@ __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, con
             for (int k = 0; k < 8; ++k) {
                 uint32_t idx = (gx + (uint32_t)(k & 1)) + ay[(k >> 1) & 1] + az[k >> 2];
                 if (idx >= cx.size) idx = idx % cx.size;
-                uint32_t q, r;
-                divmod_small(idx / kChunk, cx.n_tiles, cx.inv_tiles, &q, &r);
-                match |= (r == cx.t ? 1u : 0u) << k;
+                match |= (((idx / kChunk) & (cx.n_tiles - 1u)) == cx.t ? 1u : 0u) << k;
             }
         }
     }
@@ -353,9 +389,7 @@ __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, con
         else {
             uint32_t idx = (gx + (uint32_t)bx) + cy + cz;
             if (idx >= cx.size) idx = idx % cx.size;
-            uint32_t q, r;
-            divmod_small(idx / kChunk, cx.n_tiles, cx.inv_tiles, &q, &r);
-            a = q * kChunk + (idx % kChunk);
+            a = ((idx / kChunk) >> cx.tile_shift) * kChunk + (idx % kChunk);
         }
         const float w = ((bx ? fx : 1.0f - fx) * (by ? fy : 1.0f - fy)) * (bz ? fz : 1.0f - fz);
         if (FIXED) {
@@ -369,6 +403,186 @@ __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, con
     }
 }
 
+
+// ---- hashed owners, coded variant ------------------------------------------------------------------------------
+// The owner test of a hashed level depends on (y,z) only, and it is the same for the 16 owners of the level, so a
+// pre-pass (tile_codes_kernel) evaluates it ONCE per (sample, level): one byte per (y,z) combination = the tile the
+// combination's two x-corners fall in.  An owner then streams 4-byte codes instead of positions + gradients, keeps
+// the samples that name its tile in a wave-private LDS queue (one ballot per sample) and applies them 64 at a time
+// at full lane occupancy; positions and gradients are gathered for queued samples only (about 22 % of them), and the
+// gather of one batch is issued one drain ahead of its use.
+constexpr int kCodeSamplesPerBlock = 1024;
+__global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
+                                                         const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
+                                                         uint32_t* __restrict__ escape, int64_t n) {
+    __shared__ uint32_t esc_block;
+    if (threadIdx.x == 0) esc_block = 0u;
+    __syncthreads();
+    uint32_t esc = 0u;                  // bit l: level l must take the generic owners (see below)
+    const int64_t i0 = (int64_t)blockIdx.x * kCodeSamplesPerBlock;
+    for (int64_t i = i0 + threadIdx.x; i < n && i < i0 + kCodeSamplesPerBlock; i += 256) {
+        const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+        for (int l = 0; l < gp.n_levels; ++l) {
+            const int slot = tp.code_slot[l];
+            if (slot < 0) continue;
+            const float py = add_rn(mul_rn(y, gp.scale[l]), 0.5f), pz = add_rn(mul_rn(z, gp.scale[l]), 0.5f);
+            const uint32_t gy = (uint32_t)(int32_t)floorf(py), gz = (uint32_t)(int32_t)floorf(pz);
+            const uint32_t gx = (uint32_t)(int32_t)floorf(add_rn(mul_rn(x, gp.scale[l]), 0.5f));
+            uint32_t code = 0u;
+            bool bad;       // the premise of the code does not hold for this sample
+            if (gp.hashed[l]) {
+                const uint32_t ay0 = gy * kPrimeY, ay1 = ay0 + kPrimeY, az0 = gz * kPrimeZ, az1 = az0 + kPrimeZ;
+                const uint32_t m = gp.size[l] - 1u;
+                code = (((ay0 ^ az0) & m) / (uint32_t)kTileEntries) | ((((ay1 ^ az0) & m) / (uint32_t)kTileEntries) << 8) |
+                       ((((ay0 ^ az1) & m) / (uint32_t)kTileEntries) << 16) | ((((ay1 ^ az1) & m) / (uint32_t)kTileEntries) << 24);
+                // a position so far outside the unit cube that its x-corners leave the first 16384 columns breaks
+                // "(y,z) decides the tile"
+                bad = gx >= (uint32_t)(kTileEntries - 1);
+            } else {
+                // dense level: byte = tile of the x0 corner, bit 7 set when the x1 corner sits in the next chunk (= next
+                // tile); 0x7f (no tile) when the pair would wrap past the end of the level
+                const uint32_t res = gp.res[l], r2 = res * res, tmask = (uint32_t)tp.tiles_of[l] - 1u;
+                bad = false;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t i0 = gx + (gy + (uint32_t)(c & 1)) * res + (gz + (uint32_t)(c >> 1)) * r2, i1 = i0 + 1u;
+                    uint32_t b = 0x7fu;
+                    if (i1 >= gp.size[l] || i1 == 0u) bad = true;
+                    else b = ((i0 / kChunk) & tmask) | ((((i1 / kChunk) & tmask) != ((i0 / kChunk) & tmask)) ? 0x80u : 0u);
+                    code |= b << (8 * c);
+                }
+            }
+            codes[(int64_t)slot * tp.n_pad + i] = code;
+            if (bad) {      // harmless without gradient; with gradient the level's owners take the generic path
+                const float2 g = dfeat[(int64_t)l * n + i];
+                if (!(g.x == 0.f && g.y == 0.f)) esc |= 1u << l;
+            }
+        }
+    }
+    if (esc) atomicOr(&esc_block, esc);
+    __syncthreads();
+    if (threadIdx.x == 0) escape[blockIdx.x] = esc_block;       // every word is written: no zero-fill needed
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// The loads of this loop are issued through inline assembly with hand-placed s_waitcnt: the compiler's own
+// placement waits for a gather right where it is issued (it packs the loaded y,z into a register pair for a packed
+// multiply) and drains vmcnt to 0 around the conditional drain.  VMEM loads return in issue order, so
+// "vmcnt(k)" = "everything but the k youngest loads has landed"; the number of loads issued per step is static
+// (2 code loads, then 3 gather loads per drain, idle lanes gather sample 0).
+template <bool FIXED, bool DENSE>
+__device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_tile, uint32_t* queue,
+                                                 const uint32_t* __restrict__ codes_l, const float* __restrict__ x01,
+                                                 const float2* __restrict__ g_l, int64_t n, int rep, int R) {
+    // (tells the compiler's own wait-count bookkeeping that nothing it knows of is in flight when the loop starts;
+    //  otherwise it drains vmcnt to 0 at the head of every iteration on behalf of the other streaming variants)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t qn = 0;                                    // wave-uniform queue fill
+    const int64_t n_full = n / 4;
+    const int64_t g_lo = n_full * rep / R, g_hi = n_full * (rep + 1) / R;       // this replica's groups of 4 samples
+    // registers written by loads in flight: only ever read through the wait_* copies below
+    float ld_x = 0.f; f32x2 ld_yz = {0.f, 0.f}, ld_g = {0.f, 0.f}; u32x2 ld_c0 = {0u, 0u}, ld_c1 = {0u, 0u};
+    uint32_t bcm = 0;                                   // (y,z) combinations of the batch in flight
+    const uint32_t t_split = 0x80u | cx.t, t_next = 0x80u | ((cx.t - 1u) & (cx.n_tiles - 1u));     // dense codes
+    auto test = [&](uint32_t code) {
+        uint32_t cm = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t b = (code >> (8 * c)) & 0xffu;
+            const bool hit = DENSE ? (b == cx.t || b == t_split || b == t_next) : (b == cx.t);
+            cm |= (hit ? 1u : 0u) << c;
+        }
+        return cm;
+    };
+    auto enqueue = [&](uint32_t cm, uint32_t i) {
+        const unsigned long long b = __ballot(cm != 0u);
+        if (b) {
+            const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (cm) queue[pos] = (i << 4) | cm;
+            qn += (uint32_t)__popcll(b);
+        }
+    };
+    auto load_codes = [&](int64_t grp) {                // 2 loads
+        const uint32_t off = (uint32_t)(grp < g_hi ? grp : g_hi - 1) * 16u;
+        asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dwordx2 %1, %2, %3 offset:8"
+                     : "=&v"(ld_c0), "=&v"(ld_c1) : "v"(off), "s"(codes_l) : "memory");
+    };
+    auto pop_and_gather = [&]() {       // up to 64 queued samples: issue the 3 loads of their position and gradient
+        const uint32_t take = qn < 64u ? qn : 64u;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t e = 0;
+        if (lane < take) e = queue[qn - take + lane];
+        __builtin_amdgcn_wave_barrier();
+        qn -= take;
+        bcm = e & 15u;
+        const uint32_t ox = (e >> 4) * 12u, og = (e >> 4) * 8u;
+        asm volatile("global_load_dword %0, %3, %4\n\tglobal_load_dwordx2 %1, %3, %4 offset:4\n\tglobal_load_dwordx2 %2, %5, %6"
+                     : "=&v"(ld_x), "=&v"(ld_yz), "=&v"(ld_g) : "v"(ox), "s"(x01), "v"(og), "s"(g_l) : "memory");
+    };
+    // wait until at most `younger` loads are in flight, then copy the landed registers (the copy is part of the
+    // asm statement: the compiler must not move a read of those registers above the wait)
+#define PERF_WAIT_BATCH(younger)                                                                                        \
+    float bx; f32x2 byz, bg;                                                                                            \
+    asm volatile("s_waitcnt vmcnt(" #younger ")\n\tv_mov_b32 %0, %3\n\tv_mov_b64 %1, %4\n\tv_mov_b64 %2, %5"           \
+                 : "=&v"(bx), "=&v"(byz), "=&v"(bg) : "v"(ld_x), "v"(ld_yz), "v"(ld_g) : "memory")
+    auto apply_batch = [&](float bx, f32x2 byz, f32x2 bg) {          // the batch gathered one drain ago
+        if (bcm) {
+            const float px = add_rn(mul_rn(bx, cx.scale), 0.5f), py = add_rn(mul_rn(byz.x, cx.scale), 0.5f), pz = add_rn(mul_rn(byz.y, cx.scale), 0.5f);
+            const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+            const uint32_t gx = (uint32_t)(int32_t)flx;
+            if (DENSE)
+                apply_pairs_dense<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz,
+                                         (uint32_t)(int32_t)fly * cx.res, (uint32_t)(int32_t)flz * cx.r2, bcm);
+            else if (gx < (uint32_t)(kTileEntries - 1))      // (else: zero gradient, see tile_codes_kernel)
+                apply_pairs<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz,
+                                   (uint32_t)(int32_t)fly * kPrimeY, (uint32_t)(int32_t)flz * kPrimeZ, bcm);
+        }
+    };
+    if (g_hi > g_lo) {
+        int64_t grp = g_lo + threadIdx.x;
+        load_codes(grp);
+        pop_and_gather();               // empty queue: dummy gather, keeps the in-flight count of the loop static
+        for (int64_t base = g_lo + (int64_t)(threadIdx.x & ~63u); base < g_hi; base += kBwdThreads) {   // wave-uniform trip count
+            u32x2 c0, c1;               // in flight, oldest first: 2 code loads, 3 gather loads
+            asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(c0), "=&v"(c1) : "v"(ld_c0), "v"(ld_c1) : "memory");
+            const int64_t g0 = grp;
+            const bool valid = g0 < g_hi;
+            grp += kBwdThreads;
+            load_codes(grp);
+            const uint32_t cs[4] = {c0.x, c0.y, c1.x, c1.y};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
+            {
+                PERF_WAIT_BATCH(2);     // all but the 2 code loads
+                apply_batch(bx, byz, bg);
+            }
+            pop_and_gather();
+            while (qn >= 128u) {        // bursts (ray-coherent samples at coarse hashed levels)
+                PERF_WAIT_BATCH(0);
+                apply_batch(bx, byz, bg);
+                pop_and_gather();
+            }
+        }
+    }
+    if (threadIdx.x < 64 && rep == 0) {                 // ragged tail (n % 4 samples)
+        const int64_t i = n_full * 4 + lane;
+        enqueue(i < n ? test(codes_l[i]) : 0u, (uint32_t)i);
+    }
+    for (;;) {
+        PERF_WAIT_BATCH(0);
+        apply_batch(bx, byz, bg);
+        bcm = 0;
+        if (qn == 0u) break;
+        pop_and_gather();
+    }
+    asm volatile("" : : "v"(ld_c0), "v"(ld_c1));       // (the last code loads landed with the vmcnt(0) above)
+#undef PERF_WAIT_BATCH
+}
+
 // Streaming loop: a thread owns 4 consecutive samples per iteration -- 3 x 16 B of positions + 2 x 16 B of
 // gradients, all 16-byte loads -- and the next group is in flight while the current one is applied.
 template <bool FIXED, bool HASHED>
@@ -379,7 +593,34 @@ __device__ __forceinline__ void bwd_stream(const BwdCtx& cx, float* lds_tile, co
     const float4* x4 = reinterpret_cast<const float4*>(x01);
     const float4* g4 = reinterpret_cast<const float4*>(g_l);
     const bool aligned = ((reinterpret_cast<uintptr_t>(x01) | reinterpret_cast<uintptr_t>(g_l)) & 15) == 0;
-    if (aligned) {
+    if (aligned && !HASHED) {
+        // Dense levels: samples that follow each other along a ray fall into the same cell, i.e. the lanes of a wave
+        // would all add to the same 8 LDS addresses (measured: ~70 cycles per ds_add instruction).  Each thread
+        // therefore walks its OWN contiguous run of groups, starting at a lane-dependent rotation, so that the lanes
+        // of a wave sit on different rays at different depths.
+        const int64_t g_lo = n_full * rep / R, g_hi = n_full * (rep + 1) / R;
+        const int64_t len = (g_hi - g_lo + kBwdThreads - 1) / kBwdThreads;
+        const int64_t t_lo = g_lo + (int64_t)threadIdx.x * len;
+        const int64_t mine = (t_lo >= g_hi) ? 0 : ((g_hi - t_lo < len) ? g_hi - t_lo : len);
+        int64_t j = (len * (int64_t)(threadIdx.x & 63u)) / 64;        // rotation (wraps inside [0, len))
+        float4 xa = {}, xb = {}, xc = {}, ga = {}, gb = {};
+        auto fetch = [&](int64_t jj) {
+            if (jj < mine) { const int64_t grp = t_lo + jj; xa = x4[3 * grp]; xb = x4[3 * grp + 1]; xc = x4[3 * grp + 2]; ga = g4[2 * grp]; gb = g4[2 * grp + 1]; }
+        };
+        fetch(j);
+        for (int64_t it = 0; it < len; ++it) {
+            const float4 cxa = xa, cxb = xb, cxc = xc, cga = ga, cgb = gb;
+            const bool live = j < mine;
+            j = (j + 1 == len) ? 0 : j + 1;
+            if (it + 1 < len) fetch(j);
+            if (live) {
+                if (!(cga.x == 0.f && cga.y == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, make_float2(cga.x, cga.y), cxa.x, cxa.y, cxa.z);
+                if (!(cga.z == 0.f && cga.w == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, make_float2(cga.z, cga.w), cxa.w, cxb.x, cxb.y);
+                if (!(cgb.x == 0.f && cgb.y == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, make_float2(cgb.x, cgb.y), cxb.z, cxb.w, cxc.x);
+                if (!(cgb.z == 0.f && cgb.w == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, make_float2(cgb.z, cgb.w), cxc.y, cxc.z, cxc.w);
+            }
+        }
+    } else if (aligned) {
         int64_t grp = (int64_t)rep * kBwdThreads + threadIdx.x;
         const int64_t gstride = (int64_t)R * kBwdThreads;
         float4 xa = {}, xb = {}, xc = {}, ga = {}, gb = {};
@@ -393,6 +634,8 @@ __device__ __forceinline__ void bwd_stream(const BwdCtx& cx, float* lds_tile, co
             if (!(cgb.x == 0.f && cgb.y == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, make_float2(cgb.x, cgb.y), cxb.z, cxb.w, cxc.x);
             if (!(cgb.z == 0.f && cgb.w == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, make_float2(cgb.z, cgb.w), cxc.y, cxc.z, cxc.w);
         }
+    }
+    if (aligned) {
         if (rep == 0) {     // ragged tail (n % 4 samples)
             const int64_t i = n_full * kGroup + threadIdx.x;
             if (i < n) { const float2 g = g_l[i]; if (!(g.x == 0.f && g.y == 0.f)) bwd_apply<FIXED, HASHED>(cx, lds_tile, g, x01[3 * i], x01[3 * i + 1], x01[3 * i + 2]); }
@@ -417,8 +660,10 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    const float2* __restrict__ dfeat,
                                                                    float2* __restrict__ grad, float2* __restrict__ ws,
                                                                    const float* __restrict__ level_absmax,
-                                                                   int32_t* __restrict__ overflow_flag, int64_t n) {
-    extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats
+                                                                   int32_t* __restrict__ overflow_flag,
+                                                                   const uint32_t* __restrict__ codes,
+                                                                   const uint32_t* __restrict__ escape, int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats (+ the wave queues)
     unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
     const long long t_start = (tp.dbg_off > 0) ? (long long)wall_clock64() : 0;
     int b = blockIdx.x, l = 0;
@@ -435,7 +680,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     float from_fixed = 1.0f;
     BwdCtx cx;
     cx.scale = gp.scale[l]; cx.res = gp.res[l]; cx.r2 = cx.res * cx.res; cx.size = size; cx.mask = size - 1u;
-    cx.n_tiles = n_tiles; cx.t = t; cx.inv_tiles = 1.0f / (float)n_tiles;
+    cx.n_tiles = n_tiles; cx.t = t; cx.tile_shift = (uint32_t)(__ffs((int)n_tiles) - 1);
     cx.smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     cx.to_fixed = 1.0f;
     if (FIXED) {
@@ -447,7 +692,22 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         from_fixed = ldexpf(1.0f, -sh);
     }
     const float2* g_l = dfeat + (int64_t)l * n;
-    if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n, rep, R);
+    bool coded = codes && tp.code_slot[l] >= 0;
+    if (coded) {                        // any escape bit for this level in the pre-pass blocks' words?
+        __shared__ uint32_t esc_any;
+        if (threadIdx.x == 0) esc_any = 0u;
+        __syncthreads();
+        uint32_t e = 0u;
+        const int64_t n_words = (n + kCodeSamplesPerBlock - 1) / kCodeSamplesPerBlock;
+        for (int64_t w = threadIdx.x; w < n_words; w += kBwdThreads) e |= escape[w];
+        if ((e >> l) & 1u) esc_any = 1u;
+        __syncthreads();
+        coded = esc_any == 0u;
+    }
+    uint32_t* queue = reinterpret_cast<uint32_t*>(lds_tile + 2 * kTileEntries) + (threadIdx.x >> 6) * kQueueCap;
+    if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n, rep, R);
+    else if (coded) bwd_stream_codes<FIXED, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n, rep, R);
+    else if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n, rep, R);
     else bwd_stream<FIXED, false>(cx, lds_tile, x01, g_l, n, rep, R);
     __syncthreads();
     int32_t field_max = 0;
@@ -458,7 +718,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     for (uint32_t j = threadIdx.x; j < (uint32_t)kTileEntries; j += kBwdThreads) {
         uint32_t e;
         if (hashed) e = t * (uint32_t)kTileEntries + j;
-        else e = ((j / kChunk) * n_tiles + t) * kChunk + (j % kChunk);
+        else e = ((j / kChunk) * n_tiles + t) * kChunk + (j % kChunk);      // n_tiles is a power of two
         if (e >= size) continue;
         float2 v;
         if (FIXED) {
@@ -601,14 +861,30 @@ extern "C" int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x0
     return PERF_OK;
 }
 
-extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid) {
+// levels whose owners can run the coded variant (multi-tile levels); returns their number
+static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
+    int slots = 0;
+    for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
+        tp->code_slot[l] = -1;
+        if (l >= gp.n_levels || n >= kMaxCodedSamples) continue;
+        const int64_t nt = tp->tiles_of[l];         // (plan_tiles ran before)
+        if (gp.hashed[l] ? (nt >= 2 && nt <= 255 && gp.res[l] + 2u < (uint32_t)kTileEntries) : (nt >= 2 && nt <= 64))
+            tp->code_slot[l] = slots++;
+    }
+    tp->n_pad = (n + 3) & ~(int64_t)3;
+    return slots;
+}
+
+extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n) {
     GridParams gp;
     if (fill_params(grid, &gp)) return -1;
     TileParams tp; int nb; int64_t ws;
     int64_t ws2;
     plan_tiles(gp, false, &tp, &nb, &ws);
     plan_tiles(gp, true, &tp, &nb, &ws2);
-    return (ws > ws2 ? ws : ws2) * (int64_t)sizeof(float2) + 16;
+    const int slots = plan_codes(gp, n, &tp);
+    return (ws > ws2 ? ws : ws2) * (int64_t)sizeof(float2) + 16 + kDbgBytes + (int64_t)slots * tp.n_pad * 4 +
+           (slots ? div_up(n, kCodeSamplesPerBlock) * 4 : 0);
 }
 
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
@@ -628,8 +904,28 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     tp.accumulate = accumulate;
     tp.fixed_headroom_log2 = 12;
     tp.dbg_off = 0;
-    if (getenv("PERF_BWD_DEBUG") && workspace_bytes >= (ws_entries + 4096) * (int64_t)sizeof(float2)) tp.dbg_off = ws_entries + 1;
-    const int lds_bytes = 2 * kTileEntries * (int)sizeof(float);
+    int64_t slab_entries = ws_entries;      // workspace layout: [replica slabs (larger of both modes)][debug slots][tile codes]
+    { TileParams t2; int nb2; int64_t w2; plan_tiles(gp, level_absmax == nullptr, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2; }
+    const int64_t dbg_at = (slab_entries * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
+    if (getenv("PERF_BWD_DEBUG") && workspace_bytes >= dbg_at + kDbgBytes) tp.dbg_off = dbg_at / (int64_t)sizeof(float2);
+    // tile codes of the hashed levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
+    const int slots = plan_codes(gp, n, &tp);
+    const int64_t codes_at = dbg_at + kDbgBytes;
+    const bool no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
+    uint32_t* codes = nullptr;
+    uint32_t* escape = nullptr;
+    const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
+    if (slots > 0 && n > 0 && !no_codes && workspace && ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0) &&
+        workspace_bytes >= codes_at + (int64_t)slots * tp.n_pad * 4 + esc_words * 4) {
+        codes = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + codes_at);
+        escape = codes + (int64_t)slots * tp.n_pad;
+        tile_codes_kernel<<<dim3((unsigned)esc_words), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
+                                                                                             codes, escape, n);
+        PERF_LAUNCH_CHECK("perf_hashgrid_bwd(codes)");
+    } else {
+        for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.code_slot[l] = -1;
+    }
+    const int lds_bytes = 2 * kTileEntries * (int)sizeof(float) + (kBwdThreads / 64) * kQueueCap * (int)sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hashgrid_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -638,10 +934,10 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     }
     if (level_absmax)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
-            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, n);
+            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, codes, escape, n);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
-            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, n);
+            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, codes, escape, n);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (ws_entries > 0) {
         hashgrid_bwd_reduce_kernel<<<dim3(64, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(gp, tp, (const float2*)workspace,

@@ -175,7 +175,7 @@ def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False, level
         out = torch.empty(grid.n_params, dtype=torch.float32, device=x01.device)
         accumulate = False
     d = grid.desc()
-    ws_bytes = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(d))
+    ws_bytes = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(d), n)
     ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=x01.device)
     flag = overflow_flag(x01.device) if level_absmax is not None else None
     _call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),

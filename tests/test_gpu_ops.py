@@ -447,3 +447,36 @@ def test_pdf_resample_bit_exact(ops):
                                None if tau is None else torch.from_numpy(tau).cuda()).cpu().numpy()
         assert np.array_equal(got, ref)
         assert (np.diff(got, axis=1) >= 0).all()               # sorted edges: a size-independent property
+
+
+def test_hashgrid_bwd_coded_owners_equal_streaming_owners(ops, monkeypatch):
+    """The hashed owners that stream 4-byte tile codes (default) and the ones that stream positions compute the same
+    fixed-point sums: bit-identical tables, also for ragged sizes, ray-coherent bursts and positions outside the unit
+    cube (which send a level back to the generic owners through the escape flag)."""
+    cfg = _grid_cfg()
+    g = torch.Generator().manual_seed(21)
+    for n, kind in ((4099, 'uniform'), (65536 + 3, 'rays'), (30001, 'outside')):
+        if kind == 'rays':
+            R = n // 128 + 1
+            d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+            t = (torch.arange(128) + 0.5) / 128
+            x = ((d[:, None, :] * t[None, :, None]).reshape(-1, 3) * 0.5 + 0.5)[:n].contiguous()
+        else:
+            x = torch.rand(n, 3, generator=g)
+        if kind == 'outside':
+            x[::7, 0] = -0.25
+            x[5::11, 0] = 9.5
+            x[3::13, 1] = -3.0
+        x = x.cuda()
+        dfeat = torch.randn(cfg.n_levels, n, 2, generator=g).cuda()
+        amax = dfeat.abs().amax(dim=(1, 2)).contiguous()
+        amax = torch.cat([amax, torch.zeros(16 - amax.numel(), device='cuda')])
+        monkeypatch.delenv('PERF_BWD_NO_CODES', raising=False)
+        a_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax)
+        a_f32 = ops.hashgrid_bwd(cfg, x, dfeat)
+        monkeypatch.setenv('PERF_BWD_NO_CODES', '1')
+        b_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax)
+        b_f32 = ops.hashgrid_bwd(cfg, x, dfeat)
+        monkeypatch.delenv('PERF_BWD_NO_CODES', raising=False)
+        assert torch.equal(a_fix, b_fix), (kind, float((a_fix - b_fix).abs().max()))
+        assert float((a_f32 - b_f32).abs().max()) <= 1e-4 * float(b_f32.abs().max()), kind

@@ -13,18 +13,23 @@ x = ((d[:, None, :] * t[None, :, None]).reshape(-1, 3) * 0.5 + 0.5).contiguous()
 dfeat = torch.randn(16, n, 2, device=dev)
 amax = dfeat.abs().amax(dim=(1, 2))
 desc = cfg.desc()
-need = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(desc))
-ws = torch.zeros(need // 4 + 4 + 4096 * 2 + 64, dtype=torch.float32, device=dev)
+need = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(desc), n)
+ws = torch.zeros(need // 4 + 64, dtype=torch.float32, device=dev)
 out = torch.empty(cfg.n_params, device=dev)
 for fixed in (False, True):
     for _ in range(2):
         ops._call('perf_hashgrid_bwd', ctypes.byref(desc), ops._p(x), ops._p(dfeat), ops._p(out), n, 0, ops._p(amax) if fixed else None,
                   None, ops._p(ws), ws.numel() * 4, ops._stream())
     torch.cuda.synchronize()
-    off = (need - 16) // 8 + 1
-    cyc = ws.view(torch.int64)[off:off + 300].cpu().numpy() if False else ws[2 * off:2 * off + 600].view(torch.int64).cpu().numpy()
+    need0 = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(desc), 0)
+    off = ((need0 - 16 - 4096 * 8 + 15) // 16 * 16) // 8          # debug slots follow the replica slabs
+    cyc = ws[2 * off:2 * off + 1200].view(torch.int64).cpu().numpy()
     tiles = [max(1, -(-int(s) // 16384)) for s in cfg.size]
-    reps = [max(1, 16 // t_) for t_ in tiles]
+    tiles = [t_ if cfg.hashed[l] else 1 << (t_ - 1).bit_length() for l, t_ in enumerate(tiles)]
+    if fixed:
+        reps = [1 if cfg.hashed[l] else (8 if t_ == 1 else 3 if t_ <= 4 else 2 if t_ <= 16 else 1) for l, t_ in enumerate(tiles)]
+    else:
+        reps = [1 if cfg.hashed[l] else max(1, 16 // t_) for l, t_ in enumerate(tiles)]
     b = 0
     print('fixed' if fixed else 'fp32', '(wall_clock64 ticks @100MHz -> us = ticks/100)')
     for l in range(16):
