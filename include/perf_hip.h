@@ -267,18 +267,27 @@ int perf_distloss_bwd(const float* w, const float* t_starts, const float* t_ends
  * (2 noise - 1)(1 - opacity)); depth loss = smooth_l1(d', gt, beta 1e-2) summed / global_batch; distortion loss =
  * sum(distloss_per_ray) / (last ray with samples + 1).  Writes the per-ray gradients of
  * loss_scale * (depth_weight * depth + distortion_weight * ratio * distortion) w.r.t. opacity and distance, and
- * scalars[3] = {depth loss, distortion loss, scale to pass to perf_distloss_bwd as scale_dev}.  ratio_dev: device float
- * (min(2 progress, 1), nerf.py:235) or NULL (= 1).  noise may be NULL (no noise term). */
+ * scalars[0..2] = {depth loss, distortion loss, scale to pass to perf_distloss_bwd as scale_dev}; `scalars` is
+ * PERF_LOSS_SCALARS floats of device memory (the rest holds per-workgroup partial sums, folded in a fixed order).
+ * ratio_dev: device float (min(2 progress, 1), nerf.py:235) or NULL (= 1).  noise may be NULL (no noise term). */
+#define PERF_LOSS_SCALARS 256
 int perf_geo_loss(const float* opacity, const float* distance, const float* gt_distance, const float* noise,
                   const float* distloss_per_ray, const int32_t* packed_info, int64_t n_rays, int64_t global_batch,
                   float depth_weight, float distortion_weight, const float* ratio_dev, float loss_scale,
                   float* g_opacity, float* g_distance, float* scalars, void* stream);
 
 /* Colour step (nerf.py:281-293 + nerf_renderer.py:194): c' = color + bg (1 - opacity); loss = smooth_l1(c', gt, beta 5e-2)
- * summed / (3 global_batch); g_color [R,3] = d(loss_scale * color_weight * loss)/d color; scalars[0] = loss. */
+ * summed / (3 global_batch); g_color [R,3] = d(loss_scale * color_weight * loss)/d color; scalars[0] = loss
+ * (scalars: PERF_LOSS_SCALARS floats, as above). */
 int perf_app_loss(const float* opacity, const float* color, const float* bg_color, const float* gt_color,
                   int64_t n_rays, int64_t global_batch, float color_weight, float loss_scale, float* g_color,
                   float* scalars, void* stream);
+
+/* Supervision batch (SupInfoPool.rand_ray_color_data, modules/dataset/sup_info.py:236-259): out[i] = all[indices[i]] for
+ * every non-NULL output (origins/directions/colours/normals [n,3], distances [n]) in one launch. */
+int perf_gather_supervision(const int64_t* indices, int64_t n, const float* o_all, const float* d_all,
+                            const float* color_all, const float* dist_all, const float* normal_all, float* o, float* d,
+                            float* color, float* dist, float* normal, void* stream);
 
 /* ---- hierarchical resampling (nerfacc importance_sampling via PropNetEstimator.sampling,
  *      modules/scene/nerf_renderer.py:60-70; dead in the reference, semantics restated in oracle/) ------------- */

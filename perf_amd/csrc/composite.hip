@@ -418,12 +418,15 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 __device__ __forceinline__ float sl1(float x, float beta) { const float a = fabsf(x); return a < beta ? 0.5f * x * x / beta : a - 0.5f * beta; }
 __device__ __forceinline__ float sl1_grad(float x, float beta) { return fabsf(x) < beta ? x / beta : (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f)); }
 
+// Loss heads: per-ray work is spread over kLossBlocks workgroups that leave their partial sums behind the results in
+// `scalars` (PERF_LOSS_SCALARS floats), a one-workgroup kernel then folds them in a fixed order (deterministic).
+constexpr int kLossBlocks = 64;
+
 // scalars out: [0] depth loss (mean over the global batch), [1] distortion loss, [2] scale for perf_distloss_bwd
 __global__ __launch_bounds__(256) void geo_loss_kernel(const float* __restrict__ opacity, const float* __restrict__ distance,
                                                        const float* __restrict__ gt, const float* __restrict__ noise,
                                                        const float* __restrict__ dl_per_ray, const int32_t* __restrict__ packed,
-                                                       int64_t n_rays, float inv_bs, float depth_w, float dist_w,
-                                                       const float* __restrict__ ratio_dev, float loss_scale, float n_rays_scale,
+                                                       int64_t n_rays, float inv_bs, float depth_w, float loss_scale,
                                                        float* __restrict__ g_op, float* __restrict__ g_dist,
                                                        float* __restrict__ scalars) {
     __shared__ float red[4];
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(256) void geo_loss_kernel(const float* __restrict__
     __syncthreads();
     float dsum = 0.f, lsum = 0.f;
     int last = -1;
-    for (int64_t r = threadIdx.x; r < n_rays; r += 256) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * 256) {
         const float op = opacity[r];
         const float nz = noise ? (noise[r] * 2.0f - 1.0f) : 0.0f;
         const float pre = distance[r] + nz * (1.0f - op);
@@ -446,18 +449,33 @@ __global__ __launch_bounds__(256) void geo_loss_kernel(const float* __restrict__
         if (packed[2 * r + 1] > 0) last = (int)r;
     }
     atomicMax(&last_s, last);
-    const float depth = block_sum_256(dsum, red) * inv_bs;
-    const float distl_sum = block_sum_256(lsum, red);
+    const float depth = block_sum_256(dsum, red);
+    const float distl = block_sum_256(lsum, red);
     if (threadIdx.x == 0) {
-        // flatten_eff_distloss divides by ray_id.max()+1 (the last ray that has samples); n_rays_scale rescales it for
-        // data-parallel runs (local count -> global batch)
-        // data parallel (the local batch is a slice of the global one): normalise by the global batch instead
-        const float inv_n = (n_rays_scale < 0.f) ? inv_bs : 1.0f / (float)(last_s + 1 > 0 ? last_s + 1 : 1);
-        n_rays_scale = 1.0f;
+        float* part = scalars + 4 + 3 * blockIdx.x;
+        part[0] = depth; part[1] = distl; part[2] = (float)last_s;      // ray indices < 2^24 are exact in fp32
+    }
+}
+
+__global__ __launch_bounds__(64) void geo_loss_final_kernel(int n_blocks, float inv_bs, float dist_w, const float* __restrict__ ratio_dev,
+                                                            float loss_scale, int data_parallel, float* __restrict__ scalars) {
+    float dsum = 0.f, lsum = 0.f, last = -1.f;
+    if ((int)threadIdx.x < n_blocks) {
+        const float* part = scalars + 4 + 3 * threadIdx.x;
+        dsum = part[0]; lsum = part[1]; last = part[2];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {       // fixed butterfly: deterministic
+        dsum += __shfl_xor(dsum, off); lsum += __shfl_xor(lsum, off); last = fmaxf(last, __shfl_xor(last, off));
+    }
+    if (threadIdx.x == 0) {
+        // flatten_eff_distloss divides by ray_id.max()+1 (the last ray that has samples); data-parallel runs (the local
+        // batch is a slice of the global one) normalise by the global batch instead
+        const float inv_n = data_parallel ? inv_bs : 1.0f / (last + 1.0f > 0.f ? last + 1.0f : 1.0f);
         const float ratio = ratio_dev ? ratio_dev[0] : 1.0f;
-        scalars[0] = depth;
-        scalars[1] = distl_sum * inv_n * n_rays_scale;
-        scalars[2] = inv_n * n_rays_scale * dist_w * ratio * loss_scale;
+        scalars[0] = dsum * inv_bs;
+        scalars[1] = lsum * inv_n;
+        scalars[2] = inv_n * dist_w * ratio * loss_scale;
     }
 }
 
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(256) void app_loss_kernel(const float* __restrict__
                                                        float* __restrict__ g_col, float* __restrict__ scalars) {
     __shared__ float red[4];
     float sum = 0.f;
-    for (int64_t i = threadIdx.x; i < n_rays * 3; i += 256) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rays * 3; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / 3;
         const float c = color[i] + (bg ? bg[i] : 0.0f) * (1.0f - opacity[r]);
         const float diff = c - gt[i];
@@ -476,7 +494,14 @@ __global__ __launch_bounds__(256) void app_loss_kernel(const float* __restrict__
         g_col[i] = sl1_grad(diff, 5e-2f) * inv_n * color_w * loss_scale;
     }
     const float tot = block_sum_256(sum, red);
-    if (threadIdx.x == 0) scalars[0] = tot * inv_n;
+    if (threadIdx.x == 0) scalars[4 + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(64) void app_loss_final_kernel(int n_blocks, float inv_n, float* __restrict__ scalars) {
+    float sum = ((int)threadIdx.x < n_blocks) ? scalars[4 + threadIdx.x] : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (threadIdx.x == 0) scalars[0] = sum * inv_n;
 }
 
 }  // namespace perf
@@ -487,10 +512,12 @@ extern "C" int perf_geo_loss(const float* opacity, const float* distance, const 
                              float* g_opacity, float* g_distance, float* scalars, void* stream) {
     PERF_REQUIRE(n_rays > 0 && global_batch > 0, "perf_geo_loss: empty batch");
     PERF_REQUIRE(opacity && distance && gt_distance && distloss_per_ray && packed_info && g_opacity && g_distance && scalars, "NULL pointer");
-    const float n_rays_scale = (n_rays != global_batch) ? -1.0f : 1.0f;      // < 0: data-parallel normalisation
-    hipLaunchKernelGGL(perf::geo_loss_kernel, dim3(1), dim3(256), 0, perf::as_stream(stream), opacity, distance, gt_distance, noise,
-                       distloss_per_ray, packed_info, n_rays, 1.0f / (float)global_batch, depth_weight, distortion_weight, ratio_dev,
-                       loss_scale, n_rays_scale, g_opacity, g_distance, scalars);
+    const int nb = (int)((n_rays + 255) / 256 < perf::kLossBlocks ? (n_rays + 255) / 256 : perf::kLossBlocks);
+    const float inv_bs = 1.0f / (float)global_batch;
+    hipLaunchKernelGGL(perf::geo_loss_kernel, dim3(nb), dim3(256), 0, perf::as_stream(stream), opacity, distance, gt_distance, noise,
+                       distloss_per_ray, packed_info, n_rays, inv_bs, depth_weight, loss_scale, g_opacity, g_distance, scalars);
+    hipLaunchKernelGGL(perf::geo_loss_final_kernel, dim3(1), dim3(64), 0, perf::as_stream(stream), nb, inv_bs, distortion_weight,
+                       ratio_dev, loss_scale, (int)(n_rays != global_batch), scalars);
     PERF_LAUNCH_CHECK("perf_geo_loss");
     return PERF_OK;
 }
@@ -500,8 +527,11 @@ extern "C" int perf_app_loss(const float* opacity, const float* color, const flo
                              float* scalars, void* stream) {
     PERF_REQUIRE(n_rays > 0 && global_batch > 0, "perf_app_loss: empty batch");
     PERF_REQUIRE(opacity && color && gt_color && g_color && scalars, "NULL pointer");
-    hipLaunchKernelGGL(perf::app_loss_kernel, dim3(1), dim3(256), 0, perf::as_stream(stream), opacity, color, bg_color, gt_color,
-                       n_rays, 1.0f / (float)(global_batch * 3), color_weight, loss_scale, g_color, scalars);
+    const int nb = (int)((n_rays * 3 + 255) / 256 < perf::kLossBlocks ? (n_rays * 3 + 255) / 256 : perf::kLossBlocks);
+    const float inv_n = 1.0f / (float)(global_batch * 3);
+    hipLaunchKernelGGL(perf::app_loss_kernel, dim3(nb), dim3(256), 0, perf::as_stream(stream), opacity, color, bg_color, gt_color,
+                       n_rays, inv_n, color_weight, loss_scale, g_color, scalars);
+    hipLaunchKernelGGL(perf::app_loss_final_kernel, dim3(1), dim3(64), 0, perf::as_stream(stream), nb, inv_n, scalars);
     PERF_LAUNCH_CHECK("perf_app_loss");
     return PERF_OK;
 }

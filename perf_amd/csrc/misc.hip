@@ -291,3 +291,40 @@ extern "C" int perf_occ_splat(const float* rays_o, const float* rays_d, const fl
     PERF_LAUNCH_CHECK("perf_occ_splat");
     return PERF_OK;
 }
+
+// ---- supervision batch ------------------------------------------------------------------------------------------
+// rand_ray_color_data (modules/dataset/sup_info.py:236-259) gathers origins, directions, colours, distances and normals of
+// the drawn pixels with five indexing kernels; here one launch gathers whatever is asked for (NULL = skip).
+namespace perf {
+__global__ __launch_bounds__(256) void gather_supervision_kernel(const int64_t* __restrict__ idx, int64_t n,
+                                                                 const float* __restrict__ o_all, const float* __restrict__ d_all,
+                                                                 const float* __restrict__ c_all, const float* __restrict__ t_all,
+                                                                 const float* __restrict__ n_all, float* __restrict__ o,
+                                                                 float* __restrict__ d, float* __restrict__ c, float* __restrict__ t,
+                                                                 float* __restrict__ nrm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = idx[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (o) o[3 * i + k] = o_all[3 * j + k];
+        if (d) d[3 * i + k] = d_all[3 * j + k];
+        if (c) c[3 * i + k] = c_all[3 * j + k];
+        if (nrm) nrm[3 * i + k] = n_all[3 * j + k];
+    }
+    if (t) t[i] = t_all[j];
+}
+}  // namespace perf
+
+extern "C" int perf_gather_supervision(const int64_t* indices, int64_t n, const float* o_all, const float* d_all,
+                                       const float* color_all, const float* dist_all, const float* normal_all, float* o,
+                                       float* d, float* color, float* dist, float* normal, void* stream) {
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(indices, "NULL pointer");
+    PERF_REQUIRE((!o || o_all) && (!d || d_all) && (!color || color_all) && (!dist || dist_all) && (!normal || normal_all),
+                 "perf_gather_supervision: output without source");
+    hipLaunchKernelGGL(perf::gather_supervision_kernel, dim3((unsigned)perf::div_up(n, 256)), dim3(256), 0, perf::as_stream(stream),
+                       indices, n, o_all, d_all, color_all, dist_all, normal_all, o, d, color, dist, normal);
+    PERF_LAUNCH_CHECK("perf_gather_supervision");
+    return PERF_OK;
+}

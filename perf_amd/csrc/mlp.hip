@@ -225,7 +225,7 @@ __device__ __forceinline__ void pack_masked(const f32x16& acc, uint32_t mask_bit
 }
 
 template <typename T16, int NH, int KS>
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
+__global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
                                                       const uint32_t* __restrict__ feat,
                                                       const uint8_t* __restrict__ sel,
                                                       const float* __restrict__ dout, float2* __restrict__ dfeat,
@@ -509,7 +509,8 @@ static int n_params_rt(int nh, int ks) {
     return ks == 1 ? n_params_of<2, 1>() : n_params_of<2, 2>();
 }
 
-constexpr int kBwdBlocksPerCU = 1;
+// backward workgroups per CU: the one-hidden-layer kernel fits 2 waves per SIMD (<= 256 registers), the two-layer one 1
+static inline int bwd_blocks_per_cu(int nh) { return nh == 1 ? 2 : 1; }
 
 }  // namespace perf
 
@@ -572,7 +573,7 @@ extern "C" int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const voi
 extern "C" int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n) {
     int nh, ks;
     if (check_mlp(mlp, &nh, &ks)) return -1;
-    const int blocks = mlp_blocks(n > 0 ? n : 1, kBwdBlocksPerCU);
+    const int blocks = mlp_blocks(n > 0 ? n : 1, bwd_blocks_per_cu(nh));
     return ((int64_t)blocks * n_params_rt(nh, ks) + (int64_t)blocks * 8) * (int64_t)sizeof(float);
 }
 
@@ -595,7 +596,7 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
     const int64_t need = perf_mlp_bwd_workspace_bytes(mlp, n);
     PERF_REQUIRE(workspace_bytes >= need, "perf_mlp_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     MlpParams mp{mlp->n_levels, mlp->n_out, mlp->out_act, mlp->exp_shift};
-    const int blocks = mlp_blocks(n, kBwdBlocksPerCU);
+    const int blocks = mlp_blocks(n, bwd_blocks_per_cu(nh));
     float* amax_slots = level_absmax ? (float*)workspace + (int64_t)blocks * np : nullptr;
     if (dtype == PERF_DTYPE_BF16)
         dispatch_bwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,

@@ -167,10 +167,13 @@ class OccGridEstimator(nn.Module):
         R = rays_o.shape[0]
         dev = rays_o.device
         rays_o = rays_o.contiguous().float(); rays_d = rays_d.contiguous().float()
-        t0 = torch.full((R,), float(near_plane), dtype=torch.float32, device=dev)
         if stratified:
             u = torch.rand(R, device=dev) if jitter is None else jitter
-            t0 = t0 + u * render_step_size
+            t0 = u * render_step_size                       # near + u * step, without the fill and the add when near == 0
+            if float(near_plane) != 0.0:
+                t0 = t0 + float(near_plane)
+        else:
+            t0 = torch.full((R,), float(near_plane), dtype=torch.float32, device=dev)
         aabb = self._aabb_host
         span = min(float(far_plane) - float(near_plane), self._diag)
         if max_steps is None:

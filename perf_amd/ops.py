@@ -383,7 +383,7 @@ def geo_loss(opacity, distance, gt_distance, noise, distloss_per_ray, packed, gl
     R = packed.shape[0]
     dev = opacity.device
     g_op = torch.empty(R, 1, dtype=torch.float32, device=dev); g_d = torch.empty(R, 1, dtype=torch.float32, device=dev)
-    sc = torch.empty(3, dtype=torch.float32, device=dev)
+    sc = torch.empty(_lib.LOSS_SCALARS, dtype=torch.float32, device=dev)
     _call('perf_geo_loss', _p(opacity), _p(distance), _p(_f32(gt_distance.contiguous(), 'gt')), _p(noise), _p(distloss_per_ray), _p(packed), R,
           int(global_batch), float(depth_weight), float(distortion_weight), _p(ratio_dev), float(loss_scale), _p(g_op), _p(g_d), _p(sc),
           _stream())
@@ -394,7 +394,7 @@ def app_loss(opacity, color, bg_color, gt_color, global_batch, color_weight, los
     """-> (g_color [R,3], scalars [1] = colour loss)."""
     R = opacity.shape[0]
     g_c = torch.empty(R, 3, dtype=torch.float32, device=opacity.device)
-    sc = torch.empty(1, dtype=torch.float32, device=opacity.device)
+    sc = torch.empty(_lib.LOSS_SCALARS, dtype=torch.float32, device=opacity.device)
     _call('perf_app_loss', _p(opacity), _p(color), _p(bg_color), _p(_f32(gt_color.contiguous(), 'gt')), R, int(global_batch), float(color_weight),
           float(loss_scale), _p(g_c), _p(sc), _stream())
     return g_c, sc
@@ -406,6 +406,21 @@ def occ_splat(rays_o, rays_d, dist, res):
     _call('perf_occ_splat', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(dist.reshape(-1), 'dist')), n,
               int(res), _p(occ), _stream())
     return occ
+
+
+def gather_supervision(indices, o_all=None, d_all=None, color_all=None, dist_all=None, normal_all=None):
+    """One-launch supervision batch: -> dict with 'o','d','color','normal' [n,3] and 'dist' [n,1] for the given sources."""
+    n = indices.shape[0]
+    dev = indices.device
+    idx = indices.contiguous()
+    assert idx.dtype == torch.int64
+    out, src = {}, {}
+    for key, all_, width in (('o', o_all, 3), ('d', d_all, 3), ('color', color_all, 3), ('dist', dist_all, 1), ('normal', normal_all, 3)):
+        src[key] = None if all_ is None else _f32(all_, key)
+        out[key] = None if all_ is None else torch.empty(n, width, dtype=torch.float32, device=dev)
+    _call('perf_gather_supervision', _p(idx), n, _p(src['o']), _p(src['d']), _p(src['color']), _p(src['dist']), _p(src['normal']),
+          _p(out['o']), _p(out['d']), _p(out['color']), _p(out['dist']), _p(out['normal']), _stream())
+    return out
 
 
 def pdf_resample(s_in, cdf, n_out, tau=None):

@@ -112,8 +112,12 @@ class SupInfoPool:
         if world_size > 1:
             per = batch_size // world_size
             indices = indices[rank * per:(rank + 1) * per]
-        return (self.all_sup_rays[indices], self.all_sup_colors[indices], self.all_sup_distances[indices],
-                self.all_sup_normals[indices])
+        if not indices.is_cuda:
+            return (self.all_sup_rays[indices], self.all_sup_colors[indices], self.all_sup_distances[indices],
+                    self.all_sup_normals[indices])
+        g = ops.gather_supervision(indices, self.all_sup_rays.o, self.all_sup_rays.d, self.all_sup_colors,
+                                   self.all_sup_distances, self.all_sup_normals)            # one launch instead of five
+        return Rays(g['o'], g['d']), g['color'], g['dist'], g['normal']
 
     def gen_occ_grid(self, res):
         """sup_info.py:304-330 as one splat kernel.  Returns (occ uint8 [res^3], points of occupied cells)."""
