@@ -221,6 +221,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_f32_kernel(GridParams gp, co
 constexpr int kTileEntries = 16384;
 constexpr int kBwdThreads = 1024;
 constexpr int kMaxReplicas = 16;
+constexpr int kMaxWork = 512;              // workgroups the XCD-aware placement table can hold
+constexpr int kXcds = 8;
 
 // Load balance: a hashed level has 16 tiles, each receiving 1/16 of the level's 8 corner updates per
 // sample; a coarse dense level has only 1..8 tiles receiving the same total.  Coarse tiles are therefore
@@ -235,6 +237,12 @@ struct TileParams {
     int64_t dbg_off;                       // >0: float2 offset in the workspace where per-block cycle counts go (dev tool)
     int32_t code_slot[PERF_MAX_LEVELS];    // >=0: the level's tile codes are codes[slot][n_pad] (see tile_codes_kernel)
     int64_t n_pad;
+    // XCD-aware placement: workgroup b runs work[b] = level << 16 | tile << 8 | replica (0xffffffff: idle).  The
+    // dispatcher deals workgroups round-robin over the 8 XCDs, so b % 8 is the XCD: the owners of one level are put on
+    // the same XCD -- they stream the same codes and gather the same position / gradient lines at about the same
+    // time, which then hit that XCD's L2 instead of crossing the fabric 16 times.  use_work == 0: plain level order.
+    int32_t use_work;
+    uint32_t work[kMaxWork];
 };
 
 constexpr int kQueueCap = 384;             // per-wave match queue (entries): <128 left over + 4 x 64 new ones
@@ -261,6 +269,31 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
         nb += nt * r;
     }
     *n_blocks = nb; *ws_entries = ws;
+    // ---- XCD-aware placement (a speed assumption only: results do not depend on it)
+    tp->use_work = 0;
+    if (nb > kMaxWork || getenv("PERF_BWD_NO_XCD_AFFINITY")) return;
+    static uint32_t lists[kXcds][kMaxWork];
+    int len[kXcds] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto least = [&]() { int x = 0; for (int i = 1; i < kXcds; ++i) if (len[i] < len[x]) x = i; return x; };
+    const int per_xcd = (nb + kXcds - 1) / kXcds;
+    for (int pass = 0; pass < 2; ++pass)                    // multi-tile levels first (they are the ones that share), then the rest
+        for (int l = gp.n_levels - 1; l >= 0; --l) {
+            const int nt = tp->tiles_of[l], R = tp->replicas_of[l];
+            if ((nt > 1) != (pass == 0)) continue;
+            int x = least();
+            for (int t = 0; t < nt; ++t)
+                for (int r = 0; r < R; ++r) {
+                    if (len[x] >= per_xcd) x = least();     // the level spills over to the emptiest XCD
+                    lists[x][len[x]++] = ((uint32_t)l << 16) | ((uint32_t)t << 8) | (uint32_t)r;
+                }
+        }
+    int longest = 0;
+    for (int x = 0; x < kXcds; ++x) longest = len[x] > longest ? len[x] : longest;
+    if (longest * kXcds > kMaxWork) return;
+    for (int slot = 0; slot < longest; ++slot)
+        for (int x = 0; x < kXcds; ++x) tp->work[slot * kXcds + x] = slot < len[x] ? lists[x][slot] : 0xffffffffu;
+    tp->use_work = 1;
+    *n_blocks = longest * kXcds;
 }
 
 // Tile ownership.  Hashed levels: tile = idx / 16384 (the hash already spreads cells uniformly).  Dense levels:
@@ -667,11 +700,19 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
     const long long t_start = (tp.dbg_off > 0) ? (long long)wall_clock64() : 0;
     int b = blockIdx.x, l = 0;
-    while (b >= tp.tiles_of[l] * tp.replicas_of[l]) { b -= tp.tiles_of[l] * tp.replicas_of[l]; ++l; }
+    uint32_t t;
+    int rep;
+    if (tp.use_work) {
+        const uint32_t wk = tp.work[blockIdx.x];
+        if (wk == 0xffffffffu) return;
+        l = (int)(wk >> 16); t = (wk >> 8) & 0xffu; rep = (int)(wk & 0xffu);
+    } else {
+        while (b >= tp.tiles_of[l] * tp.replicas_of[l]) { b -= tp.tiles_of[l] * tp.replicas_of[l]; ++l; }
+        t = (uint32_t)(b / tp.replicas_of[l]);
+        rep = b % tp.replicas_of[l];
+    }
     const int R = tp.replicas_of[l];
     const uint32_t n_tiles = (uint32_t)tp.tiles_of[l];
-    const uint32_t t = (uint32_t)(b / R);
-    const int rep = b % R;
     const uint32_t size = gp.size[l];
     const bool hashed = gp.hashed[l] != 0;
     for (int i = threadIdx.x; i < 2 * kTileEntries / 4; i += kBwdThreads)
@@ -735,8 +776,11 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         out[e] = v;
     }
     if (FIXED && overflow_flag && field_max >= (1 << 30)) atomicOr(overflow_flag, 1);
-    if (tp.dbg_off > 0 && threadIdx.x == 0)
-        reinterpret_cast<long long*>(ws + tp.dbg_off)[blockIdx.x] = (long long)wall_clock64() - t_start;
+    if (tp.dbg_off > 0 && threadIdx.x == 0) {      // slot = position in plain level order
+        int slot = (int)t * R + rep;
+        for (int k = 0; k < l; ++k) slot += tp.tiles_of[k] * tp.replicas_of[k];
+        reinterpret_cast<long long*>(ws + tp.dbg_off)[slot] = (long long)wall_clock64() - t_start;
+    }
 }
 
 // sum the replica slabs (ws[level][replica][entry]) of the replicated (coarse) levels into the gradient table

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams
         }
 }
 
-// dw[i] = sum_k partials[k][i]: 64 parameters x 4 partial-segments per block, combined through LDS
+// dw[i] = sum_k partials[k][i] (fixed order: deterministic), combined through LDS
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
                                                          int n_params, int n_partials, const float* __restrict__ amax_slots,
                                                          float* __restrict__ level_absmax, int n_levels) {
@@ -473,14 +473,29 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict
         }
         return;
     }
-    const int pi = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int seg = threadIdx.x >> 6;
-    float s = 0.f;
-    if (pi < n_params)
-        for (int k = seg; k < n_partials; k += 4) s += partials[(int64_t)k * n_params + pi];
-    acc[seg][threadIdx.x & 63] = s;
+    // 16 parameters x 16 partial-segments per block (one 64-byte sector per row), 4 independent loads in flight
+    const int pl = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    const int pi = blockIdx.x * 16 + pl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (pi < n_params) {
+        int k = seg;
+        for (; k + 48 < n_partials; k += 64) {
+            s0 += partials[(int64_t)k * n_params + pi];
+            s1 += partials[(int64_t)(k + 16) * n_params + pi];
+            s2 += partials[(int64_t)(k + 32) * n_params + pi];
+            s3 += partials[(int64_t)(k + 48) * n_params + pi];
+        }
+        for (; k < n_partials; k += 16) s0 += partials[(int64_t)k * n_params + pi];
+    }
+    float* a = &acc[0][0];                          // 256 floats: [seg][param]
+    a[seg * 16 + pl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (seg == 0 && pi < n_params) dw[pi] = acc[0][threadIdx.x] + acc[1][threadIdx.x] + acc[2][threadIdx.x] + acc[3][threadIdx.x];
+    if (seg == 0 && pi < n_params) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += a[q * 16 + pl];
+        dw[pi] = t;
+    }
 }
 
 static inline int mlp_blocks(int64_t n, int per_cu) {
@@ -605,7 +620,7 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
         dispatch_bwd<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,
                            (float2*)dfeat, (float*)workspace, amax_slots, n);
     PERF_LAUNCH_CHECK("perf_mlp_bwd");
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)div_up(np, 64) + 1), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)div_up(np, 16) + 1), dim3(256), 0, as_stream(stream),
                        (const float*)workspace, dw, np, blocks, (const float*)amax_slots, level_absmax, (int)mlp->n_levels);
     PERF_LAUNCH_CHECK("perf_mlp_bwd(reduce)");
     return PERF_OK;
