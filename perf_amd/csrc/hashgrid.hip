@@ -245,7 +245,7 @@ struct TileParams {
     uint32_t work[kMaxWork];
 };
 
-constexpr int kQueueCap = 384;             // per-wave match queue (entries): <128 left over + 4 x 64 new ones
+constexpr int kQueueCap = 448;             // per-wave match queue (entries): <128 left over + 4 x 64 new + 64 re-queued
 constexpr int64_t kDbgBytes = 4096 * 8;
 constexpr int64_t kMaxCodedSamples = (int64_t)1 << 28;
 
@@ -519,7 +519,7 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     const int64_t g_lo = n_full * rep / R, g_hi = n_full * (rep + 1) / R;       // this replica's groups of 4 samples
     // registers written by loads in flight: only ever read through the wait_* copies below
     float ld_x = 0.f; f32x2 ld_yz = {0.f, 0.f}, ld_g = {0.f, 0.f}; u32x2 ld_c0 = {0u, 0u}, ld_c1 = {0u, 0u};
-    uint32_t bcm = 0;                                   // (y,z) combinations of the batch in flight
+    uint32_t bcm = 0, bi = 0;                           // (y,z) combinations and sample index of the batch in flight
     const uint32_t t_split = 0x80u | cx.t, t_next = 0x80u | ((cx.t - 1u) & (cx.n_tiles - 1u));     // dense codes
     auto test = [&](uint32_t code) {
         uint32_t cm = 0;
@@ -552,7 +552,8 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
         __builtin_amdgcn_wave_barrier();
         qn -= take;
         bcm = e & 15u;
-        const uint32_t ox = (e >> 4) * 12u, og = (e >> 4) * 8u;
+        bi = e >> 4;
+        const uint32_t ox = bi * 12u, og = bi * 8u;
         asm volatile("global_load_dword %0, %3, %4\n\tglobal_load_dwordx2 %1, %3, %4 offset:4\n\tglobal_load_dwordx2 %2, %5, %6"
                      : "=&v"(ld_x), "=&v"(ld_yz), "=&v"(ld_g) : "v"(ox), "s"(x01), "v"(og), "s"(g_l) : "memory");
     };
@@ -562,7 +563,11 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     float bx; f32x2 byz, bg;                                                                                            \
     asm volatile("s_waitcnt vmcnt(" #younger ")\n\tv_mov_b32 %0, %3\n\tv_mov_b64 %1, %4\n\tv_mov_b64 %2, %5"           \
                  : "=&v"(bx), "=&v"(byz), "=&v"(bg) : "v"(ld_x), "v"(ld_yz), "v"(ld_g) : "memory")
-    auto apply_batch = [&](float bx, f32x2 byz, f32x2 bg) {          // the batch gathered one drain ago
+    // The batch gathered one drain ago.  Every lane applies ONE combination (loop-free at full occupancy); the 7 % of
+    // samples that name this tile with two or more combinations go back into the queue with the remaining ones.
+    auto apply_batch = [&](float bx, f32x2 byz, f32x2 bg) {
+        const uint32_t rest = DENSE ? 0u : bcm & (bcm - 1u);        // (dense tiles are named by several combinations as a rule)
+        if (!DENSE) bcm &= 0u - bcm;
         if (bcm) {
             const float px = add_rn(mul_rn(bx, cx.scale), 0.5f), py = add_rn(mul_rn(byz.x, cx.scale), 0.5f), pz = add_rn(mul_rn(byz.y, cx.scale), 0.5f);
             const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
@@ -574,6 +579,7 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
                 apply_pairs<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz,
                                    (uint32_t)(int32_t)fly * kPrimeY, (uint32_t)(int32_t)flz * kPrimeZ, bcm);
         }
+        if (!DENSE) enqueue(rest, bi);
     };
     if (g_hi > g_lo) {
         int64_t grp = g_lo + threadIdx.x;
