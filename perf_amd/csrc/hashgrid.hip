@@ -444,7 +444,7 @@ __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, con
 // the samples that name its tile in a wave-private LDS queue (one ballot per sample) and applies them 64 at a time
 // at full lane occupancy; positions and gradients are gathered for queued samples only (about 22 % of them), and the
 // gather of one batch is issued one drain ahead of its use.
-constexpr int kCodeSamplesPerBlock = 1024;
+constexpr int kCodeSamplesPerBlock = 256;
 __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
                                                          const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
                                                          uint32_t* __restrict__ escape, int64_t n) {
