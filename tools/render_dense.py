@@ -1,0 +1,73 @@
+"""BASELINE config 4 (render_dense, core_exp_runner.py:223-247): a dense camera trajectory through a trained scene,
+512x1024 panoramic frames, fp16 inference, reference-faithful variable-count sampling.
+
+  python tools/render_dense.py [--poses 600] [--geo-steps 300] [--app-steps 150]
+
+Frames are rendered back to back on the device (the reference writes PNGs and a video in between: host IO, out of
+scope); prints frames/s, rays/s, ray-samples/s actually evaluated, and a checksum of the frames."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from perf_amd import ops, synthetic
+from perf_amd.pose_sampler import CirclePoseSampler, DenseTravelPoseSampler
+from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--poses', type=int, default=600)
+ap.add_argument('--geo-steps', type=int, default=300)
+ap.add_argument('--app-steps', type=int, default=150)
+ap.add_argument('--dtype', default='fp16')
+args = ap.parse_args()
+
+torch.manual_seed(0); np.random.seed(0)
+scene = NeRFScene(dtype=args.dtype)
+H, W = 1024, 2048
+rays = gen_pano_rays(torch.eye(4), H, W)
+dist, rgb = synthetic.room(rays.d)
+pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, dist)
+scene.set_train(); scene.prepare_occupancy(pool)
+tc = scene.train_conf
+scene.nerf.reset_geo()
+opt = scene.make_optimizer(scene.nerf.geo_mlp, 0.0)
+for i in range(args.geo_steps):
+    scene.update_lr(opt, tc.geo_optimizer, i / args.geo_steps)
+    scene.train_one_step_geo(opt, pool, progress=i / args.geo_steps)
+opt = scene.make_optimizer(scene.nerf.app_mlp, 0.0)
+for i in range(args.app_steps):
+    scene.update_lr(opt, tc.app_optimizer, i / args.app_steps)
+    scene.train_one_step_app(opt, pool, progress=i / args.app_steps)
+torch.cuda.synchronize()
+
+# pose samplers run on the host (utils of the reference, restated in perf_amd/pose_sampler.py)
+sparse = CirclePoseSampler(dist.reshape(H, W).cpu(), traverse_ratios=[.2, .4, .6], n_anchors_per_ratio=[8, 8, 8])
+t0 = time.perf_counter()
+dense = DenseTravelPoseSampler(sparse, n_dense_poses=args.poses)
+t_sampler = time.perf_counter() - t0
+poses = []
+for i in range(dense.n_poses):
+    p = dense.sample_pose(i).clone().float()
+    p[:3, :3] = torch.eye(3)                                        # core_exp_runner.py:232
+    poses.append(p)
+
+fh, fw = 512, 1024
+def frame(p):
+    r = gen_pano_rays(p, fh, fw)
+    return scene.render(r, ['rgb', 'distance'])
+
+for p in poses[:3]:
+    frame(p)
+torch.cuda.synchronize()
+ops.start_kernel_timing()
+frame(poses[0]); torch.cuda.synchronize()
+kern = ops.stop_kernel_timing()
+t0 = time.perf_counter()
+for p in poses:
+    last = frame(p)
+torch.cuda.synchronize()
+t = time.perf_counter() - t0
+checksum = float(last['rgb'].double().sum())
+print(json.dumps({'config': 'render_dense: %d poses, %dx%d panoramic frames, %s, variable-count sampling' % (len(poses), fw, fh, args.dtype),
+                  'frames_per_s': len(poses) / t, 'rays_per_s': len(poses) * fh * fw / t, 'seconds': t,
+                  'pose_sampler_host_s': t_sampler, 'last_frame_rgb_sum': checksum,
+                  'kernel_ms_one_frame': {k: round(n * ms, 3) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])}}, indent=1))
