@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 1
+#define PERF_ABI_VERSION 2
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -46,7 +46,7 @@ extern "C" {
 #define PERF_INTERP_LINEAR 0
 #define PERF_INTERP_SMOOTHSTEP 1
 
-#define PERF_MAX_LEVELS 16
+#define PERF_MAX_LEVELS 24
 
 /* Geometry of a multiresolution hash grid (tcnn "HashGrid", 3 input dims, 2 features/level).
  * Entry e of level l lives at table[(offset[l] + e) * 2 + f].  Levels with hashed[l]==0 are
@@ -57,7 +57,7 @@ typedef struct perf_grid_desc {
     float scale[PERF_MAX_LEVELS];
     uint32_t res[PERF_MAX_LEVELS];
     uint32_t size[PERF_MAX_LEVELS];
-    uint32_t offset[PERF_MAX_LEVELS];
+    uint64_t offset[PERF_MAX_LEVELS];   /* 64-bit: tables beyond 2^32 entries (BASELINE config 5) */
     uint32_t hashed[PERF_MAX_LEVELS];
 } perf_grid_desc;
 

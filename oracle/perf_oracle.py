@@ -103,7 +103,7 @@ def grid_levels(n_levels=16, n_feat=2, log2_hashmap_size=18, base_resolution=16,
     scale = np.zeros(n_levels, F32)
     res = np.zeros(n_levels, np.uint32)
     size = np.zeros(n_levels, np.uint32)
-    offset = np.zeros(n_levels, np.uint32)
+    offset = np.zeros(n_levels, np.uint64)
     hashed = np.zeros(n_levels, bool)
     total = 0
     for l in range(n_levels):

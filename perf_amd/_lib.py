@@ -5,12 +5,12 @@ module raises.  Build the library with `python -m perf_amd.build` (or __graft_en
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libperf_hip.so')
 
-MAX_LEVELS = 16
+MAX_LEVELS = 24
 DTYPE_BF16, DTYPE_FP16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
 INTERP_LINEAR, INTERP_SMOOTHSTEP = 0, 1
@@ -19,7 +19,7 @@ INTERP_LINEAR, INTERP_SMOOTHSTEP = 0, 1
 class GridDesc(Structure):
     _fields_ = [('n_levels', c_int32), ('interpolation', c_int32),
                 ('scale', c_float * MAX_LEVELS), ('res', c_uint32 * MAX_LEVELS), ('size', c_uint32 * MAX_LEVELS),
-                ('offset', c_uint32 * MAX_LEVELS), ('hashed', c_uint32 * MAX_LEVELS)]
+                ('offset', c_uint64 * MAX_LEVELS), ('hashed', c_uint32 * MAX_LEVELS)]
 
 
 class MlpDesc(Structure):

@@ -19,7 +19,7 @@ struct GridParams {
     float scale[PERF_MAX_LEVELS];
     uint32_t res[PERF_MAX_LEVELS];
     uint32_t size[PERF_MAX_LEVELS];
-    uint32_t offset[PERF_MAX_LEVELS];
+    uint64_t offset[PERF_MAX_LEVELS];
     uint32_t hashed[PERF_MAX_LEVELS];
 };
 
@@ -90,9 +90,13 @@ __device__ __forceinline__ void corner_weights(const float f[3], bool smooth, fl
     for (int k = 0; k < 8; ++k) w[k] = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
 }
 
-// level l handled by (group, pass): pass 0 -> g, pass 1 -> L-1-g (if different)
+// level l handled by (group, pass).  L <= 16: pass 0 -> g, pass 1 -> L-1-g (if different) -- a coarse (small) and a
+// fine (large) table per group.  Deeper grids (L <= 24) add pass 2 -> 16+g; their tables exceed the L2 anyway.
+constexpr int kFwdPasses = 3;
 __device__ __forceinline__ int level_of(int group, int pass, int L) {
-    int a = group, b = L - 1 - group;
+    if (pass == 2) return (16 + group < L) ? 16 + group : -1;
+    const int Lc = L < 16 ? L : 16;
+    int a = group, b = Lc - 1 - group;
     if (a > b) return -1;
     if (pass == 0) return a;
     return (b != a) ? b : -1;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const 
     const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < kFwdPasses; ++pass) {
         const int l = level_of(group, pass, gp.n_levels);
         if (l < 0) continue;
         const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd2_kernel(GridParams gp, const
     const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < kFwdPasses; ++pass) {
         const int l = level_of(group, pass, gp.n_levels);
         if (l < 0) continue;
         const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_f32_kernel(GridParams gp, co
     const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < kFwdPasses; ++pass) {
         const int l = level_of(group, pass, gp.n_levels);
         if (l < 0) continue;
         const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
@@ -242,6 +246,7 @@ struct TileParams {
     // the same XCD -- they stream the same codes and gather the same position / gradient lines at about the same
     // time, which then hit that XCD's L2 instead of crossing the fabric 16 times.  use_work == 0: plain level order.
     int32_t use_work;
+    uint32_t atomic_levels;                // bit l: level l is too large for LDS owners (see hashgrid_bwd_atomic_kernel)
     uint32_t work[kMaxWork];
 };
 
@@ -252,11 +257,15 @@ constexpr int64_t kMaxCodedSamples = (int64_t)1 << 28;
 static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
     int nb = 0;
     int64_t ws = 0;
+    tp->atomic_levels = 0u;
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->tiles_of[l] = 0; tp->replicas_of[l] = 1; tp->ws_off[l] = 0;
         if (l >= gp.n_levels) continue;
         int nt = (int)((gp.size[l] + kTileEntries - 1) / kTileEntries);
         if (!gp.hashed[l]) { int p = 1; while (p < nt) p <<= 1; nt = p; }     // dense ownership is a bit field of the index
+        // A level of more than 255 (hashed) / 64 (dense) tiles = 4 M / 1 M entries would need that many owners, each
+        // walking every sample: beyond that the plain global-atomics scatter is cheaper (log2_hashmap_size >= 22).
+        if (nt > (gp.hashed[l] ? 255 : 64)) { tp->atomic_levels |= 1u << l; continue; }
         // replication factors from measured per-workgroup times (tools/exp/bwd_block_times.py, 1 M samples, fixed):
         // hashed tile (coded) 0.36-0.39 ms; dense tile streaming ALL samples: 1 tile 2.4 ms, 4 tiles 0.88 ms, 8 tiles 0.68 ms
         // (fp32 mode is bound by ds_add_f32 lane-serialisation instead: equal corner-update counts, r = 16 / nt)
@@ -789,6 +798,28 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     }
 }
 
+// Levels too large for LDS owners: plain scatter with global fp32 atomics (flat ~2e10/s on gfx950: a fallback for
+// log2_hashmap_size >= 22, where 256+ owners per level would each have to walk every sample).  The level's slice of
+// the gradient table is zeroed by the caller first unless it accumulates.
+__global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(GridParams gp, uint32_t levels, const float* __restrict__ x01,
+                                                                  const float2* __restrict__ dfeat, float* __restrict__ grad,
+                                                                  int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= n || !((levels >> l) & 1u)) return;
+    const float2 g = dfeat[(int64_t)l * n + i];
+    if (g.x == 0.f && g.y == 0.f) return;
+    const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+    float w[8];
+    corner_weights(c.f, gp.interpolation == PERF_INTERP_SMOOTHSTEP, w);
+    float* t = grad + 2 * gp.offset[l];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unsafeAtomicAdd(t + 2 * (uint64_t)c.idx[k], w[k] * g.x);
+        unsafeAtomicAdd(t + 2 * (uint64_t)c.idx[k] + 1, w[k] * g.y);
+    }
+}
+
 // sum the replica slabs (ws[level][replica][entry]) of the replicated (coarse) levels into the gradient table
 __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp, TileParams tp, const float2* __restrict__ ws,
                                                                   float2* __restrict__ grad) {
@@ -892,6 +923,7 @@ extern "C" int perf_hashgrid_corners(const perf_grid_desc* grid, const float* x0
     if (rc) return rc;
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(x01 && idx, "NULL pointer");
+    PERF_REQUIRE(gp.offset[gp.n_levels - 1] + gp.size[gp.n_levels - 1] < ((uint64_t)1 << 31), "perf_hashgrid_corners: table too large for int32 entries");
     hipLaunchKernelGGL(hashgrid_corners_kernel, dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream), gp,
                        x01, idx, n);
     PERF_LAUNCH_CHECK("perf_hashgrid_corners");
@@ -982,13 +1014,28 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hashgrid_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    if (level_absmax)
+    if (n_blocks == 0) {
+        // every level goes through the atomics fallback
+    } else if (level_absmax)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, codes, escape, n);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, codes, escape, n);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
+    if (tp.atomic_levels && n > 0) {
+        if (!accumulate)
+            for (int l = 0; l < gp.n_levels; ++l)
+                if ((tp.atomic_levels >> l) & 1u)
+                    PERF_REQUIRE(hipMemsetAsync(grad_table + 2 * gp.offset[l], 0, (size_t)gp.size[l] * 2 * sizeof(float), as_stream(stream)) == hipSuccess,
+                                 "perf_hashgrid_bwd: memset failed");
+        hashgrid_bwd_atomic_kernel<<<dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
+            gp, tp.atomic_levels, x01, (const float2*)dfeat, grad_table, n);
+        PERF_LAUNCH_CHECK("perf_hashgrid_bwd(atomics)");
+    } else if (tp.atomic_levels && !accumulate) {
+        for (int l = 0; l < gp.n_levels; ++l)
+            if ((tp.atomic_levels >> l) & 1u) (void)hipMemsetAsync(grad_table + 2 * gp.offset[l], 0, (size_t)gp.size[l] * 2 * sizeof(float), as_stream(stream));
+    }
     if (ws_entries > 0) {
         hashgrid_bwd_reduce_kernel<<<dim3(64, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(gp, tp, (const float2*)workspace,
                                                                                               (float2*)grad_table);

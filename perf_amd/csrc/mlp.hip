@@ -507,12 +507,12 @@ static inline int mlp_blocks(int64_t n, int per_cu) {
 
 static int check_mlp(const perf_mlp_desc* m, int* nh, int* ks) {
     PERF_REQUIRE(m != nullptr, "mlp desc is NULL");
-    PERF_REQUIRE(m->n_levels >= 1 && m->n_levels <= 16, "mlp n_levels %d out of range", m->n_levels);
+    PERF_REQUIRE(m->n_levels >= 1 && m->n_levels <= 24, "mlp n_levels %d out of range", m->n_levels);
     PERF_REQUIRE(m->n_hidden_layers == 1 || m->n_hidden_layers == 2, "n_hidden_layers must be 1 or 2");
     PERF_REQUIRE(m->n_out >= 1 && m->n_out <= 16, "n_out out of range");
     PERF_REQUIRE(m->out_act >= 0 && m->out_act <= 2, "bad out_act");
     *nh = m->n_hidden_layers;
-    *ks = m->n_levels > 8 ? 2 : 1;
+    *ks = m->n_levels > 16 ? 3 : (m->n_levels > 8 ? 2 : 1);
     return PERF_OK;
 }
 
@@ -520,8 +520,8 @@ template <int NH, int KS>
 static int n_params_of() { return Layout<NH, KS>::n_params; }
 
 static int n_params_rt(int nh, int ks) {
-    if (nh == 1) return ks == 1 ? n_params_of<1, 1>() : n_params_of<1, 2>();
-    return ks == 1 ? n_params_of<2, 1>() : n_params_of<2, 2>();
+    if (nh == 1) return ks == 1 ? n_params_of<1, 1>() : (ks == 2 ? n_params_of<1, 2>() : n_params_of<1, 3>());
+    return ks == 1 ? n_params_of<2, 1>() : (ks == 2 ? n_params_of<2, 2>() : n_params_of<2, 3>());
 }
 
 // backward workgroups per CU: the one-hidden-layer kernel fits 2 waves per SIMD (<= 256 registers), the two-layer one 1
@@ -554,9 +554,11 @@ static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t*
 template <typename T16, typename... Args>
 static void dispatch_fwd(int nh, int ks, Args... a) {
     if (nh == 1 && ks == 1) launch_fwd<T16, 1, 1>(a...);
-    else if (nh == 1) launch_fwd<T16, 1, 2>(a...);
+    else if (nh == 1 && ks == 2) launch_fwd<T16, 1, 2>(a...);
+    else if (nh == 1) launch_fwd<T16, 1, 3>(a...);
     else if (ks == 1) launch_fwd<T16, 2, 1>(a...);
-    else launch_fwd<T16, 2, 2>(a...);
+    else if (ks == 2) launch_fwd<T16, 2, 2>(a...);
+    else launch_fwd<T16, 2, 3>(a...);
 }
 
 template <typename T16, typename... Args>
@@ -587,7 +589,7 @@ extern "C" int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const voi
 
 extern "C" int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n) {
     int nh, ks;
-    if (check_mlp(mlp, &nh, &ks)) return -1;
+    if (check_mlp(mlp, &nh, &ks) || ks > 2) return -1;
     const int blocks = mlp_blocks(n > 0 ? n : 1, bwd_blocks_per_cu(nh));
     return ((int64_t)blocks * n_params_rt(nh, ks) + (int64_t)blocks * 8) * (int64_t)sizeof(float);
 }
@@ -598,6 +600,7 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
     int nh, ks;
     int rc = check_mlp(mlp, &nh, &ks);
     if (rc) return rc;
+    PERF_REQUIRE(ks <= 2, "perf_mlp_bwd: more than 16 levels (%d) are supported by the forward kernels only", (int)mlp->n_levels);
     PERF_REQUIRE(w16 && dw && workspace, "NULL pointer");
     PERF_REQUIRE(dtype == PERF_DTYPE_BF16 || dtype == PERF_DTYPE_FP16, "bad dtype %d", dtype);
     const int np = n_params_rt(nh, ks);

@@ -42,7 +42,7 @@ class GridConfig:
         self.scale = np.zeros(L, _F)
         self.res = np.zeros(L, np.uint32)
         self.size = np.zeros(L, np.uint32)
-        self.offset = np.zeros(L, np.uint32)
+        self.offset = np.zeros(L, np.uint64)           # 64-bit: tables beyond 2^32 entries (tcnn's own offsets are uint32)
         self.hashed = np.zeros(L, np.uint32)
         total = 0
         for l in range(L):
@@ -109,10 +109,12 @@ class MlpConfig:
             raise ValueError('n_output_dims must be in [1, 16]')
         if self.output_activation not in _ACTS:
             raise ValueError(f'unsupported output activation {self.output_activation!r}')
+        if not (1 <= self.n_levels <= _lib.MAX_LEVELS):
+            raise ValueError(f'n_levels must be in [1, {_lib.MAX_LEVELS}]')
 
     @property
     def n_in_pad(self) -> int:
-        return 32 if self.n_levels > 8 else 16
+        return 16 * (-(-self.n_levels // 8))         # inputs padded to the MFMA k-step: 16, 32, or 48 (inference only)
 
     @property
     def shapes(self):

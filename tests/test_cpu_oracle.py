@@ -99,7 +99,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                      # raises if the .so is missing: no CPU fallback
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.perf_version() == 1
+    assert lib.perf_version() == 2
 
 
 def test_ops_refuse_cpu_tensors():

@@ -419,6 +419,7 @@ def test_hashgrid_bwd_fixed_point_mode(ops):
     feat = torch.rand(16, n, 2, generator=g).to(torch.bfloat16).cuda()
     dfe, dw, am = ops.mlp_bwd(mlp, w, feat, torch.randn(n, 1, generator=g).cuda(), want_absmax=True)
     true = dfe.abs().amax(dim=(1, 2))
+    am = am[:16]
     assert bool((am >= true).all()) and float(am.max()) == float(true.max())      # a bound per level, tight overall
 
 
@@ -480,3 +481,101 @@ def test_hashgrid_bwd_coded_owners_equal_streaming_owners(ops, monkeypatch):
         monkeypatch.delenv('PERF_BWD_NO_CODES', raising=False)
         assert torch.equal(a_fix, b_fix), (kind, float((a_fix - b_fix).abs().max()))
         assert float((a_f32 - b_f32).abs().max()) <= 1e-4 * float(b_f32.abs().max()), kind
+
+
+# ---- deep / large grids (BASELINE config 5: L = 20, tables beyond 2^32 entries; inference only) ----------------------
+def test_deep_grid_forward_20_levels(ops):
+    """L = 20 (three k-steps of MLP input, a third encode pass per level group) against the oracle."""
+    cfg = _grid_cfg(n_levels=20, log2_hashmap_size=15, base_resolution=16, per_level_scale=1.3819)
+    lv = O.grid_levels(20, 2, 15, 16, 1.3819)
+    assert cfg.total == lv.total and np.array_equal(cfg.offset, lv.offset)
+    g = torch.Generator().manual_seed(31)
+    table = torch.rand(cfg.total, 2, generator=g) * 2 - 1
+    n = 2500
+    x = torch.rand(n, 3, generator=g)
+    t16 = table.to(torch.bfloat16)
+    feat = ops.hashgrid_fwd(cfg, x.cuda(), t16.reshape(-1).cuda())
+    assert feat.shape == (20, n, 2)
+    got = feat.float().cpu().permute(1, 0, 2).reshape(n, -1)
+    ref = O.hashgrid_encode(x, table, lv, quant='bf16')
+    assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() * 1.01 + 1e-6).all()
+    # MLP forward on 40 (padded to 48) inputs, both depths
+    for nh, n_out, act in ((1, 1, 'Exponential'), (2, 3, 'Sigmoid')):
+        cfgm, w, f, sel, tdt, ulp = _mlp_case(ops, 'bf16', nh, n_out, act, n=1500, n_levels=20, seed=3)
+        assert cfgm.n_in_pad == 48
+        out = ops.mlp_fwd(cfgm, w.to(tdt).cuda(), f.to(tdt).cuda(), sel.cuda()).cpu()
+        ref = _mlp_oracle(cfgm, w.to(tdt).float(), f.to(tdt).float(), sel, 'bf16')
+        assert (out - ref).abs().max() < 8 * ulp * max(1.0, float(ref.abs().max()))
+    # training such a field is outside this round's kernels and must say so
+    with pytest.raises(Exception):
+        ops.mlp_bwd(cfgm, w.to(tdt).cuda(), f.to(tdt).cuda(), torch.zeros(1500, n_out).cuda(), sel.cuda())
+
+
+def test_table_beyond_32_bit_offsets(ops):
+    """5.6e9 entries (21 GiB of 2x16-bit features): level offsets exceed 2^32.  The table is filled on the device with a
+    function of the global entry index; the expected features of a few points are evaluated on the host from the oracle's
+    corner indices and weights through the same function, so no host copy of the table is needed."""
+    L, T, b = 20, 29, 1.5
+    cfg = _grid_cfg(n_levels=L, log2_hashmap_size=T, base_resolution=16, per_level_scale=b)
+    lv = O.grid_levels(L, 2, T, 16, b)
+    assert cfg.total > 2 ** 32 and np.array_equal(cfg.offset.astype(np.uint64), lv.offset.astype(np.uint64))
+
+    def value(idx):                                      # entry index (int64 tensor) -> feature 0, feature 1 in [-1, 1)
+        h = (idx * 40503 + 12345) % 65521
+        return h.float() / 32760.5 - 1.0, ((h * 7 + 3) % 65521).float() / 32760.5 - 1.0
+
+    table = torch.empty(cfg.total * 2, dtype=torch.float16, device='cuda')
+    step = 1 << 27
+    for lo in range(0, cfg.total, step):
+        idx = torch.arange(lo, min(lo + step, cfg.total), device='cuda', dtype=torch.int64)
+        f0, f1 = value(idx)
+        table[2 * lo: 2 * (lo + idx.numel())] = torch.stack([f0, f1], -1).reshape(-1).half()
+        del idx, f0, f1
+    n = 64
+    x = torch.rand(n, 3, generator=torch.Generator().manual_seed(37))
+    feat = ops.hashgrid_fwd(cfg, x.cuda(), table).float().cpu()          # [L, n, 2]
+    xn = x.numpy()
+    for l in range(L):
+        idx, f = O.grid_corner_indices(xn, lv, l)
+        gi = torch.from_numpy(idx.astype(np.int64)) + int(lv.offset[l])
+        v0, v1 = value(gi)
+        v0 = v0.half().float(); v1 = v1.half().float()
+        w = torch.ones(n, 8)
+        for c in range(8):
+            for a in range(3):
+                fa = torch.from_numpy(f[:, a].astype(np.float32))
+                w[:, c] = w[:, c] * (fa if (c >> a) & 1 else (1.0 - fa))
+        ref = torch.stack([(w * v0).sum(1), (w * v1).sum(1)], -1)
+        assert (feat[l] - ref).abs().max() < 2e-3, (l, float((feat[l] - ref).abs().max()))
+    del table
+    torch.cuda.empty_cache()
+
+
+def test_hashgrid_bwd_large_levels_take_the_atomics_path(ops):
+    """log2_hashmap_size = 23: 512 tiles per hashed level, more than LDS owners are planned for -> global-atomics scatter
+    for those levels, owners for the rest; against the oracle's corner bookkeeping (fp32 atomics: summation-order tolerance)."""
+    cfg = _grid_cfg(n_levels=6, log2_hashmap_size=23, base_resolution=32, per_level_scale=2.0)
+    lv = O.grid_levels(6, 2, 23, 32, 2.0)
+    g = torch.Generator().manual_seed(41)
+    n = 3000
+    x = torch.rand(n, 3, generator=g)
+    dfeat = torch.randn(cfg.n_levels, n, 2, generator=g)
+    for fixed in (False, True):
+        amax = None
+        if fixed:
+            amax = torch.zeros(24, device='cuda'); amax[:6] = dfeat.abs().amax(dim=(1, 2)).cuda()
+        grad = ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), level_absmax=amax).cpu().numpy().reshape(-1, 2)
+        ref = np.zeros((cfg.total, 2), np.float64)
+        xn = x.numpy()
+        for l in range(cfg.n_levels):
+            idx, f = O.grid_corner_indices(xn, lv, l)
+            for c in range(8):
+                w = np.ones(n, np.float32)
+                for a in range(3):
+                    w = w * (f[:, a] if (c >> a) & 1 else (np.float32(1) - f[:, a]))
+                np.add.at(ref, idx[:, c].astype(np.int64) + int(lv.offset[l]), w[:, None].astype(np.float64) * dfeat[l].numpy())
+        assert np.abs(grad - ref).max() < 2e-4 * np.abs(ref).max()
+        # accumulate adds on top
+        acc = torch.from_numpy(grad.reshape(-1).copy()).cuda()
+        ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), out=acc, accumulate=True, level_absmax=amax)
+        assert np.abs(acc.cpu().numpy().reshape(-1, 2) - 2 * ref).max() < 4e-4 * np.abs(ref).max()

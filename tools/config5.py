@@ -1,0 +1,94 @@
+"""BASELINE config 5: 2048x4096 panorama, 256 samples per ray, L = 20 levels, hash tables that no cache holds
+(F = 2, fp16, log2_hashmap_size up to 30: 37 GiB per encoder, 64-bit level offsets), inference.
+
+  python tools/config5.py [--log2 26 28 30] [--rays 16384] [--batches 8]
+
+One batch = `rays` panorama rays x 256 fixed lattice samples: positions -> density field (encode + 40->64->1 MLP)
+-> colour field (encode + 40->64->64->3 MLP) -> compositing.  Only 16-bit tables are allocated (no fp32 master, no
+optimiser state: such a field cannot be trained on one GPU).  Reports ray-samples/s and the encode
+kernel's share; run under `rocprofv3 --pmc FETCH_SIZE` for the moved-bytes roofline (profiles/README.md)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from perf_amd import ops
+from perf_amd.grid import GridConfig, MlpConfig
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--log2', type=int, nargs='+', default=[26, 28, 30])
+ap.add_argument('--rays', type=int, default=16384)
+ap.add_argument('--spp', type=int, default=256)
+ap.add_argument('--batches', type=int, default=8)
+ap.add_argument('--levels', type=int, default=20)
+args = ap.parse_args()
+dev = 'cuda'
+H, W = 2048, 4096
+L = args.levels
+b = float(torch.exp(torch.log(torch.tensor(8192.0 / 16)) / (L - 1)))          # finest resolution 8192
+
+
+def fill_random(n_elems, dtype):
+    t = torch.empty(n_elems, dtype=dtype, device=dev)
+    step = 1 << 28
+    for lo in range(0, n_elems, step):
+        hi = min(lo + step, n_elems)
+        t[lo:hi] = (torch.rand(hi - lo, device=dev) * 2 - 1).to(dtype) * 0.1
+    return t
+
+
+out = {}
+pose = torch.eye(4)
+for T in args.log2:
+    cfg = GridConfig(n_levels=L, log2_hashmap_size=T, base_resolution=16, per_level_scale=b)
+    geo_mlp = MlpConfig(L, 1, 1, 'Exponential')
+    app_mlp = MlpConfig(L, 2, 3, 'Sigmoid')
+    gib = cfg.n_params * 2 / 2 ** 30
+    tg = fill_random(cfg.n_params, torch.float16)
+    ta = fill_random(cfg.n_params, torch.float16)
+    wg = (torch.randn(geo_mlp.n_params, device=dev) * 0.2).half()
+    wa = (torch.randn(app_mlp.n_params, device=dev) * 0.2).half()
+    R, S = args.rays, args.spp
+    rows = R // W if R >= W else 1
+    aabb = torch.tensor([-1., -1, -1, 1, 1, 1])
+    step = 1.4 / S
+
+    def one_batch(k):
+        # a block of panorama rows (ray generation in-kernel), fixed lattice of S samples per ray
+        row0 = min(H - rows, ((2 * (k % args.batches) + 1) * H) // (2 * args.batches))       # rows spread from pole to pole
+        o, d = ops.pano_raygen(pose, H, W, row0=row0, nrows=rows)
+        o = o.reshape(-1, 3)[:R]; d = d.reshape(-1, 3)[:R]
+        n = R * S
+        ri = torch.arange(R, device=dev).repeat_interleave(S)
+        ts = (torch.arange(S, device=dev, dtype=torch.float32) * step).repeat(R)
+        te = ts + step
+        packed = torch.stack([torch.arange(R, device=dev, dtype=torch.int32) * S, torch.full((R,), S, device=dev, dtype=torch.int32)], 1).contiguous()
+        x01, sel = ops.points_from_rays(o.contiguous(), d.contiguous(), ri, ts, te, aabb)
+        fg = ops.hashgrid_fwd(cfg, x01, tg)
+        sig = ops.mlp_fwd(geo_mlp, wg, fg, sel)
+        del fg
+        fa = ops.hashgrid_fwd(cfg, x01, ta)
+        rgb = ops.mlp_fwd(app_mlp, wa, fa, sel)
+        del fa
+        return ops.composite_fwd(sig.view(-1), rgb, ts, te, packed)
+
+    one_batch(0); torch.cuda.synchronize()
+    ops.start_kernel_timing()
+    t0 = time.perf_counter()
+    for k in range(args.batches):
+        res = one_batch(k)
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    kern = ops.stop_kernel_timing()
+    n_samples = args.batches * R * S
+    enc_ms = kern['perf_hashgrid_fwd'][1]
+    enc_sps = R * S / (enc_ms * 1e-3)
+    out[f'T{T}'] = {'levels': L, 'table_GiB_per_encoder': round(gib, 2), 'total_entries': int(cfg.total), 'offsets_exceed_32_bit': bool(cfg.total >= 2 ** 32),
+                    'ray_samples_per_s': n_samples / t, 'ms_per_batch': t / args.batches * 1e3, 'batch': f'{R} rays x {S} spp',
+                    'encode_ms_per_launch': round(enc_ms, 3), 'encode_Gsamples_per_s': round(enc_sps / 1e9, 3),
+                    'encode_algorithmic_GBs': round(enc_sps * L * 8 * 2 * 2 / 1e9, 1),
+                    'kernel_ms_per_batch': {k_: round(c * ms / args.batches, 3) for k_, (c, ms) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])},
+                    'opacity_mean': float(res[3].mean())}
+    print(json.dumps({f'T{T}': out[f'T{T}']}, indent=1), flush=True)
+    del tg, ta
+    torch.cuda.empty_cache()
+os.makedirs('gpurun_out', exist_ok=True)
+json.dump(out, open('gpurun_out/config5.json', 'w'), indent=1)
