@@ -96,12 +96,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    # PERF_BENCH_BACKEND=gloo + PERF_BENCH_ONE_DEVICE=1: smoke-test the multi-rank path on a single-GPU box (dev tool)
+    backend = os.environ.get('PERF_BENCH_BACKEND', 'nccl')
+    if os.environ.get('PERF_BENCH_ONE_DEVICE'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from perf_amd import ops, synthetic
     from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
