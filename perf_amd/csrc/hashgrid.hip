@@ -217,11 +217,12 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_f32_kernel(GridParams gp, co
 // address distribution (tools/exp/atomics.hip), i.e. ~13 ms for the 2.7e8 corner updates of a
 // 1 M-sample batch -- so the scatter is turned inside out: the fp32 gradient table (26.6 MB for
 // L16/T18) is cut into 128 KiB tiles of 16384 entries and each tile is OWNED by one workgroup that
-// keeps it in LDS (203 tiles <= 256 CUs: the whole table is resident in the chip's aggregate LDS).
-// Every owner streams all samples of its level (coalesced x01 + dfeat reads that the sibling owners
-// share through L2), recomputes the 8 corner indices and applies only those that fall in its tile
-// with LDS atomics; at the end the tile is written back with plain coalesced stores.  No global
-// atomics, no zero-fill pass, every table entry written exactly once.
+// keeps it in LDS (the multi-tile levels' 192 + 12 tiles plus the replicated coarse ones <= 256 CUs: the whole
+// table is resident in the chip's aggregate LDS).  Every owner walks all samples of its level and applies only the
+// corner updates that fall in its tile with LDS atomics -- multi-tile levels through a 4-byte tile code per sample
+// that a pre-pass computes once for all owners (bwd_stream_codes), single-tile levels from positions (bwd_stream);
+// at the end the tile is written back with plain coalesced stores.  No global atomics, no zero-fill pass, every
+// table entry written exactly once.
 constexpr int kTileEntries = 16384;
 constexpr int kBwdThreads = 1024;
 constexpr int kMaxReplicas = 16;
@@ -231,7 +232,8 @@ constexpr int kXcds = 8;
 // Load balance: a hashed level has 16 tiles, each receiving 1/16 of the level's 8 corner updates per
 // sample; a coarse dense level has only 1..8 tiles receiving the same total.  Coarse tiles are therefore
 // REPLICATED (R_l copies, each streaming 1/R_l of the samples) so that every workgroup takes about as long as
-// a hashed-tile owner; replicas are summed by a small second kernel.  L16/T18: 8+8+15+32+192 = 255 workgroups.
+// a hashed-tile owner; replicas are summed by a small second kernel.  L16/T18, fixed-point mode:
+// 8 + 8 + 4x3 + 8x2 + 12x16 = 236 workgroups.
 struct TileParams {
     int32_t tiles_of[PERF_MAX_LEVELS];     // tiles per level
     int32_t replicas_of[PERF_MAX_LEVELS];  // replicas per tile
