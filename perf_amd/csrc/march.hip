@@ -244,6 +244,27 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
     }
 }
 
+// n <= kScanSmall: one workgroup, one launch (the three-kernel scan above is launch-latency bound for the
+// 8,192 per-ray counts of a training batch)
+constexpr int kScanSmall = 65536;
+__global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
+                                                          int64_t* __restrict__ total_out) {
+    __shared__ long long wave_sum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (int)((n + 1023) / 1024);
+    const int64_t lo = (int64_t)threadIdx.x * per;
+    int s = 0;
+    for (int k = 0; k < per; ++k) if (lo + k < n) s += in[lo + k];
+    const int inc = wave_incl_scan(s, lane);
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    long long base = 0, tot = 0;
+    for (int w2 = 0; w2 < 16; ++w2) { if (w2 < wave) base += wave_sum[w2]; tot += wave_sum[w2]; }
+    int ex = (int)base + inc - s;
+    for (int k = 0; k < per; ++k) if (lo + k < n) { const int v = in[lo + k]; out[lo + k] = ex; ex += v; }
+    if (threadIdx.x == 0) *total_out = tot;
+}
+
 }  // namespace perf
 
 using namespace perf;
@@ -310,6 +331,12 @@ extern "C" int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t*
     }
     PERF_REQUIRE(in && out && workspace, "NULL pointer");
     PERF_REQUIRE(workspace_bytes >= perf_scan_workspace_bytes(n), "scan workspace too small");
+    PERF_REQUIRE(in != out, "perf_exclusive_scan_i32: in-place scan is not supported");
+    if (n <= kScanSmall) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, as_stream(stream), in, out, n, total);
+        PERF_LAUNCH_CHECK("perf_exclusive_scan_i32");
+        return PERF_OK;
+    }
     const int64_t nb = div_up(n, kScanBlock);
     int64_t* sums = (int64_t*)workspace;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), in, n, sums);

@@ -304,12 +304,16 @@ class NeRFScene:
         """Everything of a geometry step that does not depend on the geometry parameters: batch draw, and -- when the
         sampler needs no density pre-pass (early_stop_eps == 0) -- marching, positions and the frozen colour field."""
         rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
+        rand = dict(rand or {})
+        if self.fused_steps and ('jitter' not in rand or 'noise' not in rand):
+            u = torch.rand(2, rays.o.shape[0], device=rays.o.device)        # the step's two per-ray draws in one launch
+            rand.setdefault('jitter', u[0]); rand.setdefault('noise', u[1].unsqueeze(1))
         st = None
         if self.renderer.early_stop_eps <= 0:
             with torch.no_grad():
                 st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=True)
                 st = st if st is not None else False
-        return {'rays': rays, 'gt_depths': gt_depths, 'bs': bs, 'dist_info': dist_info, 'st': st}
+        return {'rays': rays, 'gt_depths': gt_depths, 'bs': bs, 'dist_info': dist_info, 'st': st, 'rand': rand}
 
     # ---- fused steps: explicit kernel chain instead of autograd + ~25 tiny torch ops (same arithmetic) ----------
     def _field_grad(self, net, x01, w16, feat, sel, dout):
@@ -347,6 +351,7 @@ class NeRFScene:
         self._geo_pre = None
         rays, gt_depths, bs, dist_info = pre['rays'], pre['gt_depths'], pre['bs'], pre['dist_info']
         st = pre['st']
+        rand_in, rand = rand, pre['rand']
         if st is None:
             st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=True)
         geo = self.nerf.geo_mlp
@@ -363,9 +368,7 @@ class NeRFScene:
         rgbs = st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel)
         w, T, _, op, dist_r, col = ops.composite_fwd(sig.view(-1), rgbs, ts, te, packed)
         n_rays = op.shape[0]
-        noise = rand['noise'] if 'noise' in rand else torch.rand(n_rays, 1, device=op.device)
-        if self.renderer.bg_color == 'rand_noise' and 'bg' not in rand:
-            torch.rand(n_rays, 3, device=op.device)              # the reference draws the background too (:185)
+        noise = rand['noise']            # (the background colour the reference also draws, :185, is not used by this step)
         dl = ops.distloss_fwd(w, ts, te, packed)
         if not self._capturing:
             self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
@@ -375,7 +378,7 @@ class NeRFScene:
         dsig, _ = ops.composite_bwd(sig.view(-1), ts, te, packed, w, T, g_weights=g_w, g_opacity=g_op, g_distance=g_dist)
         grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1))
         self.last_losses['depth_loss'] = sc[0]; self.last_losses['dist_loss'] = sc[1]
-        overlap = (lambda: setattr(self, '_geo_pre', self._geo_prefetch(sup_pool, rand, generator))) \
+        overlap = (lambda: setattr(self, '_geo_pre', self._geo_prefetch(sup_pool, rand_in, generator))) \
             if (self.overlap_comm and dist_info[0] is not None) else None
         self._apply_grad(geo, grad, optimizer, dist_info, overlap)
         self.global_iter_step_geo += 1

@@ -284,7 +284,7 @@ def test_occ_march_bit_exact(ops, stratified):
 
 def test_scan_and_empty(ops):
     g = torch.Generator().manual_seed(6)
-    for n in (1, 5, 1024, 1025, 100000):
+    for n in (1, 5, 1024, 1025, 8192, 65536, 65537, 100000):
         c = torch.randint(0, 300, (n,), generator=g, dtype=torch.int32)
         out, total = ops.exclusive_scan_i32(c.cuda())
         ref = torch.cumsum(c.long(), 0) - c.long()
