@@ -246,6 +246,20 @@ int perf_composite_bwd(const float* sigmas, const float* t_starts, const float* 
                        const float* g_opacity, const float* g_distance, const float* g_color,
                        float* d_sigmas, float* d_rgbs, void* stream);
 
+/* The geometry step's pair of compositing + distortion loss (nerf_renderer.py:170-183 + nerf.py:222-236) as ONE kernel
+ * each way.  Forward: perf_composite_fwd plus distloss_per_ray [R] (= perf_distloss_fwd on the weights it forms).
+ * Backward: d_sigmas of perf_composite_bwd with g_weights = distloss_scale * distloss_scale_dev[0] * d(distortion
+ * loss)/d weights formed in the kernel; opacity / distance are the forward's per-ray outputs (they are the totals
+ * sum w and sum w t_mid the distortion gradient needs).  distloss_scale_dev may be NULL. */
+int perf_composite_distloss_fwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+                                const int32_t* packed_info, int64_t n_rays, float* weights, float* trans,
+                                float* opacity, float* distance, float* color, float* distloss_per_ray, void* stream);
+int perf_composite_distloss_bwd(const float* sigmas, const float* t_starts, const float* t_ends,
+                                const int32_t* packed_info, int64_t n_rays, const float* weights, const float* trans,
+                                const float* opacity, const float* distance, const float* g_opacity,
+                                const float* g_distance, float distloss_scale, const float* distloss_scale_dev,
+                                float* d_sigmas, void* stream);
+
 /* nerfacc.accumulate_along_rays forward (nerf_renderer.py:173-183): out[r,c] = sum_i w_i * values[i,c]
  * (values == NULL: n_channels must be 1 and out[r] = sum_i w_i).  One wave per ray, no atomics. */
 int perf_accumulate_fwd(const float* weights, const float* values, const int32_t* packed_info, int64_t n_rays,

@@ -70,6 +70,8 @@ _SIGS = {
     'perf_distloss_bwd': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
     'perf_geo_loss': (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_float, c_float, P, c_float, P, P, P, P]),
     'perf_app_loss': (c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, P, P, P]),
+    'perf_composite_distloss_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
+    'perf_composite_distloss_bwd': (c_int, [P, P, P, P, c_int64, P, P, P, P, P, P, c_float, P, P, P]),
     'perf_gather_supervision': (c_int, [P, c_int64, P, P, P, P, P, P, P, P, P, P, P]),
     'perf_pdf_resample': (c_int, [P, P, P, c_int64, c_int32, c_int32, P, P]),
     'perf_occ_splat': (c_int, [P, P, P, c_int64, c_int32, P, P]),

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
                                                             const int32_t* __restrict__ packed, int64_t n_rays,
                                                             float* __restrict__ weights, float* __restrict__ trans,
                                                             float* __restrict__ alphas, float* __restrict__ opacity,
-                                                            float* __restrict__ distance, float* __restrict__ color) {
+                                                            float* __restrict__ distance, float* __restrict__ color,
+                                                            float* __restrict__ distloss) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rays) return;
@@ -94,16 +95,19 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     const int cnt = packed[2 * r + 1];
     float carry = 0.f;
     float a_op = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
+    float cW = 0.f, cWM = 0.f, a_dl = 0.f;          // distortion loss of the ray (same arithmetic as distloss_fwd_kernel)
     for (int c0 = 0; c0 < cnt; c0 += 64) {
         const int i = c0 + lane;
         const bool valid = i < cnt;
         float sd = 0.f, t0 = 0.f, t1 = 0.f;
         if (valid) { t0 = ts[start + i]; t1 = te[start + i]; sd = mul_rn(sig[start + i], sub_rn(t1, t0)); }
         const float ex = chunk_excl(sd, lane, carry);
+        float w_dl = 0.f;
         if (valid) {
             const float T = expf(-ex);
             const float al = 1.0f - expf(-sd);
             const float w = T * al;
+            w_dl = w;
             if (weights) weights[start + i] = w;
             if (trans) trans[start + i] = T;
             if (alphas) alphas[start + i] = al;
@@ -115,7 +119,14 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
                 a_b += w * rgb[3 * (start + i) + 2];
             }
         }
+        if (distloss) {
+            const float m = (t0 + t1) * 0.5f, d = t1 - t0;
+            const float W = chunk_excl(w_dl, lane, cW);
+            const float WM = chunk_excl(w_dl * m, lane, cWM);
+            if (valid) a_dl += d * w_dl * w_dl * (1.0f / 3.0f) + 2.0f * w_dl * (m * W - WM);
+        }
     }
+    if (distloss) { a_dl = wave_sum(a_dl); if (lane == 0) distloss[r] = a_dl; }
     a_op = wave_sum(a_op); a_d = wave_sum(a_d);
     if (rgb) { a_r = wave_sum(a_r); a_g = wave_sum(a_g); a_b = wave_sum(a_b); }
     if (lane == 0) {
@@ -135,7 +146,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
                                                             const float* __restrict__ g_T, const float* __restrict__ g_al,
                                                             const float* __restrict__ g_op, const float* __restrict__ g_dist,
                                                             const float* __restrict__ g_col, float* __restrict__ d_sig,
-                                                            float* __restrict__ d_rgb) {
+                                                            float* __restrict__ d_rgb, const float* __restrict__ tot_w,
+                                                            const float* __restrict__ tot_wm, float dl_scale,
+                                                            const float* __restrict__ dl_scale_dev) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rays) return;
@@ -143,6 +156,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     const int cnt = packed[2 * r + 1];
     if (cnt == 0) return;
     const float gop = g_op ? g_op[r] : 0.f, gd = g_dist ? g_dist[r] : 0.f;
+    // distortion-loss gradient w.r.t. the weights formed here instead of being read from g_w (tot_w != NULL):
+    // d loss / d w_i = scale ( 2/3 d_i w_i + 2 ( m_i (W_i - Wsuf_i) - (WM_i - WMsuf_i) ) ), prefixes = totals - suffixes
+    const bool with_dl = tot_w != nullptr;
+    const float totW = with_dl ? tot_w[r] : 0.f, totWM = with_dl ? tot_wm[r] : 0.f;
+    if (with_dl && dl_scale_dev) dl_scale *= dl_scale_dev[0];
+    float sufW = 0.f, sufWM = 0.f;                      // sums over all later chunks
     float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
     if (g_col && d_rgb) { gc0 = g_col[3 * r]; gc1 = g_col[3 * r + 1]; gc2 = g_col[3 * r + 2]; }
     float carry = 0.f;   // sum of G_j w_j over all later chunks
@@ -156,6 +175,19 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
             G = gop + gd * ((t0 + t1) * 0.5f) + (g_w ? g_w[start + i] : 0.f);
             if (g_T) gT = g_T[start + i];
             if (g_al) gA = g_al[start + i];
+        }
+        if (with_dl) {
+            const float m = (t0 + t1) * 0.5f, wm = w * m;
+            float sw = w, swm = wm;                     // inclusive suffix sums within the chunk
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float y0 = __shfl_down(sw, off), y1 = __shfl_down(swm, off);
+                if (lane + off < 64) { sw += y0; swm += y1; }
+            }
+            const float Wsuf = sufW + (sw - w), WMsuf = sufWM + (swm - wm);
+            const float W = totW - Wsuf - w, WM = totWM - WMsuf - wm;
+            if (valid) G += dl_scale * ((2.0f / 3.0f) * (t1 - t0) * w + 2.0f * (m * (W - Wsuf) - (WM - WMsuf)));
+            sufW += __shfl(sw, 0); sufWM += __shfl(swm, 0);
         }
         const float qv = G * w + gT * T;
         // inclusive suffix sum within the chunk
@@ -299,8 +331,20 @@ extern "C" int perf_composite_fwd(const float* sigmas, const float* rgbs, const 
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info, "NULL pointer");
     hipLaunchKernelGGL(composite_fwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
-                       t_ends, packed_info, n_rays, weights, trans, alphas, opacity, distance, color);
+                       t_ends, packed_info, n_rays, weights, trans, alphas, opacity, distance, color, (float*)nullptr);
     PERF_LAUNCH_CHECK("perf_composite_fwd");
+    return PERF_OK;
+}
+
+extern "C" int perf_composite_distloss_fwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+                                           const int32_t* packed_info, int64_t n_rays, float* weights, float* trans,
+                                           float* opacity, float* distance, float* color, float* distloss_per_ray, void* stream) {
+    PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_info && distloss_per_ray, "NULL pointer");
+    hipLaunchKernelGGL(composite_fwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
+                       t_ends, packed_info, n_rays, weights, trans, (float*)nullptr, opacity, distance, color, distloss_per_ray);
+    PERF_LAUNCH_CHECK("perf_composite_distloss_fwd");
     return PERF_OK;
 }
 
@@ -313,8 +357,25 @@ extern "C" int perf_composite_bwd(const float* sigmas, const float* t_starts, co
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && weights && trans, "NULL pointer");
     hipLaunchKernelGGL(composite_bwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
-                       packed_info, n_rays, weights, trans, g_weights, g_trans, g_alphas, g_opacity, g_distance, g_color, d_sigmas, d_rgbs);
+                       packed_info, n_rays, weights, trans, g_weights, g_trans, g_alphas, g_opacity, g_distance, g_color, d_sigmas, d_rgbs,
+                       (const float*)nullptr, (const float*)nullptr, 0.0f, (const float*)nullptr);
     PERF_LAUNCH_CHECK("perf_composite_bwd");
+    return PERF_OK;
+}
+
+extern "C" int perf_composite_distloss_bwd(const float* sigmas, const float* t_starts, const float* t_ends,
+                                           const int32_t* packed_info, int64_t n_rays, const float* weights, const float* trans,
+                                           const float* opacity, const float* distance, const float* g_opacity,
+                                           const float* g_distance, float distloss_scale, const float* distloss_scale_dev,
+                                           float* d_sigmas, void* stream) {
+    PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_info && weights && trans && opacity && distance && d_sigmas, "NULL pointer");
+    hipLaunchKernelGGL(composite_bwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
+                       packed_info, n_rays, weights, trans, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       g_opacity, g_distance, (const float*)nullptr, d_sigmas, (float*)nullptr, opacity, distance, distloss_scale,
+                       distloss_scale_dev);
+    PERF_LAUNCH_CHECK("perf_composite_distloss_bwd");
     return PERF_OK;
 }
 

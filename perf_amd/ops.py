@@ -337,6 +337,28 @@ def composite_fwd(sigmas, rgbs, t_starts, t_ends, packed, want_samples=True):
     return w, T, al, op, dist, col
 
 
+def composite_distloss_fwd(sigmas, rgbs, t_starts, t_ends, packed):
+    """composite_fwd + the per-ray distortion-loss sums in one launch -> (weights, trans, opacity, distance, colour, dl)."""
+    R = packed.shape[0]
+    S = sigmas.numel()
+    dev = sigmas.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    w, T, op, dist, dl = f(S), f(S), f(R, 1), f(R, 1), f(R)
+    col = f(R, 3) if rgbs is not None else None
+    _call('perf_composite_distloss_fwd', _p(_f32(sigmas, 'sigmas')), _p(rgbs), _p(t_starts), _p(t_ends), _p(packed), R, _p(w),
+          _p(T), _p(op), _p(dist), _p(col), _p(dl), _stream())
+    return w, T, op, dist, col, dl
+
+
+def composite_distloss_bwd(sigmas, t_starts, t_ends, packed, weights, trans, opacity, distance, g_opacity, g_distance,
+                           scale=1.0, scale_dev=None):
+    """d sigma of compositing with the distortion-loss gradient (scale * scale_dev[0] * d dl / d w) formed in the kernel."""
+    ds = torch.zeros(sigmas.numel(), dtype=torch.float32, device=sigmas.device)
+    _call('perf_composite_distloss_bwd', _p(sigmas), _p(t_starts), _p(t_ends), _p(packed), packed.shape[0], _p(weights), _p(trans),
+          _p(opacity), _p(distance), _p(g_opacity), _p(g_distance), float(scale), _p(scale_dev), _p(ds), _stream())
+    return ds
+
+
 def composite_bwd(sigmas, t_starts, t_ends, packed, weights, trans, g_weights=None, g_opacity=None, g_distance=None,
                   g_color=None, g_trans=None, g_alphas=None, want_dsigma=True, want_drgb=False):
     R = packed.shape[0]

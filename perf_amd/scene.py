@@ -366,16 +366,13 @@ class NeRFScene:
         feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:])
         sig = ops.mlp_fwd(geo.mlp, w16[:n_net], feat, sel)
         rgbs = st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel)
-        w, T, _, op, dist_r, col = ops.composite_fwd(sig.view(-1), rgbs, ts, te, packed)
-        n_rays = op.shape[0]
+        w, T, op, dist_r, col, dl = ops.composite_distloss_fwd(sig.view(-1), rgbs, ts, te, packed)
         noise = rand['noise']            # (the background colour the reference also draws, :185, is not used by this step)
-        dl = ops.distloss_fwd(w, ts, te, packed)
         if not self._capturing:
             self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
         g_op, g_dist, sc = ops.geo_loss(op, dist_r, gt_depths, noise, dl, packed, bs, tc.depth_loss_weight,
                                         tc.distortion_loss_weight, self._ratio_dev, self.loss_scale)
-        g_w = ops.distloss_bwd(w, ts, te, packed, 1.0, scale_dev=sc[2:3])
-        dsig, _ = ops.composite_bwd(sig.view(-1), ts, te, packed, w, T, g_weights=g_w, g_opacity=g_op, g_distance=g_dist)
+        dsig = ops.composite_distloss_bwd(sig.view(-1), ts, te, packed, w, T, op, dist_r, g_op, g_dist, 1.0, scale_dev=sc[2:3])
         grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1))
         self.last_losses['depth_loss'] = sc[0]; self.last_losses['dist_loss'] = sc[1]
         overlap = (lambda: setattr(self, '_geo_pre', self._geo_prefetch(sup_pool, rand_in, generator))) \

@@ -579,3 +579,23 @@ def test_hashgrid_bwd_large_levels_take_the_atomics_path(ops):
         acc = torch.from_numpy(grad.reshape(-1).copy()).cuda()
         ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), out=acc, accumulate=True, level_absmax=amax)
         assert np.abs(acc.cpu().numpy().reshape(-1, 2) - 2 * ref).max() < 4e-4 * np.abs(ref).max()
+
+
+def test_composite_distloss_fused_kernels(ops):
+    """Compositing + distortion loss in one kernel each way equals the two-kernel chain (forward bit-exact; backward to
+    fp32 rounding: prefixes are formed as totals minus suffixes there)."""
+    packed, ri, ts, te, sig, rgb = _packed_case(9)
+    c = lambda t: t.cuda()
+    w, T, al, op, dist, col = ops.composite_fwd(c(sig), c(rgb), c(ts), c(te), c(packed))
+    dl = ops.distloss_fwd(w, c(ts), c(te), c(packed))
+    w2, T2, op2, dist2, col2, dl2 = ops.composite_distloss_fwd(c(sig), c(rgb), c(ts), c(te), c(packed))
+    for a, b in ((w, w2), (T, T2), (op, op2), (dist, dist2), (col, col2), (dl, dl2)):
+        assert torch.equal(a, b)
+    R = packed.shape[0]
+    g = torch.Generator().manual_seed(10)
+    g_op = torch.randn(R, 1, generator=g).cuda(); g_d = torch.randn(R, 1, generator=g).cuda()
+    scale_dev = torch.tensor([0.37], device='cuda')
+    g_w = ops.distloss_bwd(w, c(ts), c(te), c(packed), 2.0, scale_dev=scale_dev)
+    ref, _ = ops.composite_bwd(c(sig), c(ts), c(te), c(packed), w, T, g_weights=g_w, g_opacity=g_op, g_distance=g_d)
+    got = ops.composite_distloss_bwd(c(sig), c(ts), c(te), c(packed), w, T, op, dist, g_op, g_d, 2.0, scale_dev=scale_dev)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7
