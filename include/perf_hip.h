@@ -213,6 +213,14 @@ int perf_occ_march_write(const float* t0, int64_t n_rays, float step, int32_t ma
                          int64_t capacity, int64_t* ray_indices, float* t_starts, float* t_ends,
                          int32_t* packed_info, void* stream);
 
+/* perf_occ_march_write that also emits the sample positions of perf_points_from_rays (x01 [S,3], sel [S] or NULL) for
+ * the samples it writes: one launch and one pass over the samples less when no visibility compaction follows.
+ * aabb6: host pointer, {min xyz, max xyz}. */
+int perf_occ_march_write_points(const float* t0, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
+                                const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
+                                float* t_starts, float* t_ends, int32_t* packed_info, const float* rays_o,
+                                const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, void* stream);
+
 /* ---- compositing (nerfacc render_weight_from_density / accumulate_along_rays /
  *      render_visibility_from_density; nerf_renderer.py:170-183) ---------------------------- */
 

@@ -60,6 +60,7 @@ _SIGS = {
     'perf_scan_workspace_bytes': (c_int64, [c_int64]),
     'perf_exclusive_scan_i32': (c_int, [P, P, P, c_int64, P, c_int64, P]),
     'perf_occ_march_write': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P]),
+    'perf_occ_march_write_points': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P, P, POINTER(c_float), P, P, P]),
     'perf_visibility_count': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
     'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P]),
     'perf_composite_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),

@@ -92,4 +92,27 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 
 static inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+struct Aabb { float lo[3], hi[3]; };
+
+__device__ __forceinline__ void normalize_store(float px, float py, float pz, const Aabb& bb, float* x01, uint8_t* sel,
+                                                int64_t i) {
+    // (x - aabb_min) / (aabb_max - aabb_min), IEEE division like torch
+    float ux = __fdiv_rn(sub_rn(px, bb.lo[0]), sub_rn(bb.hi[0], bb.lo[0]));
+    float uy = __fdiv_rn(sub_rn(py, bb.lo[1]), sub_rn(bb.hi[1], bb.lo[1]));
+    float uz = __fdiv_rn(sub_rn(pz, bb.lo[2]), sub_rn(bb.hi[2], bb.lo[2]));
+    x01[3 * i] = ux; x01[3 * i + 1] = uy; x01[3 * i + 2] = uz;
+    if (sel) sel[i] = (ux > 0.f && ux < 1.f && uy > 0.f && uy < 1.f && uz > 0.f && uz < 1.f) ? 1 : 0;
+}
+
+// sample position of one lattice interval: t_origins + t_dirs * (t0+t1) / 2.0 (nerf_renderer.py:127) -- multiply,
+// divide, add, unfused -- then the aabb normalisation above
+__device__ __forceinline__ void sample_point_store(const float* o, const float* d, float t0, float t1, const Aabb& bb,
+                                                   float* x01, uint8_t* sel, int64_t i) {
+    const float tsum = add_rn(t0, t1);
+    const float px = add_rn(o[0], __fdiv_rn(mul_rn(d[0], tsum), 2.0f));
+    const float py = add_rn(o[1], __fdiv_rn(mul_rn(d[1], tsum), 2.0f));
+    const float pz = add_rn(o[2], __fdiv_rn(mul_rn(d[2], tsum), 2.0f));
+    normalize_store(px, py, pz, bb, x01, sel, i);
+}
+
 }  // namespace perf

@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                                                           const int32_t* __restrict__ counts,
                                                           const int32_t* __restrict__ offsets, int64_t capacity,
                                                           int64_t* __restrict__ ray_indices, float* __restrict__ ts,
-                                                          float* __restrict__ te, int32_t* __restrict__ packed) {
+                                                          float* __restrict__ te, int32_t* __restrict__ packed,
+                                                          const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                          Aabb bb, float* __restrict__ x01, uint8_t* __restrict__ sel) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rays) return;
@@ -159,9 +161,11 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                 const int64_t pos = run + __popcll(m & below);
                 if (pos < capacity) {
                     const int k = q * 64 + lane;
-                    ts[pos] = lattice(t0, k, step);
-                    te[pos] = lattice(t0, k + 1, step);
+                    const float a = lattice(t0, k, step), b = lattice(t0, k + 1, step);
+                    ts[pos] = a;
+                    te[pos] = b;
                     ray_indices[pos] = r;
+                    if (x01) sample_point_store(rays_o + 3 * r, rays_d + 3 * r, a, b, bb, x01, sel, pos);     // (= perf_points_from_rays)
                 }
             }
             run += __popcll(m);
@@ -355,7 +359,24 @@ extern "C" int perf_occ_march_write(const float* t0, int64_t n_rays, float step,
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends), "NULL sample arrays");
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info);
+                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr);
     PERF_LAUNCH_CHECK("perf_occ_march_write");
+    return PERF_OK;
+}
+
+extern "C" int perf_occ_march_write_points(const float* t0, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
+                                           const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
+                                           float* t_starts, float* t_ends, int32_t* packed_info, const float* rays_o,
+                                           const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, void* stream) {
+    PERF_REQUIRE(n_rays >= 0 && max_steps > 0 && capacity >= 0, "perf_occ_march_write_points: bad arguments");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(t0 && masks && counts && offsets && packed_info && rays_o && rays_d && aabb6, "NULL pointer");
+    PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends && x01), "NULL sample arrays");
+    Aabb bb;
+    for (int k = 0; k < 3; ++k) { bb.lo[k] = aabb6[k]; bb.hi[k] = aabb6[3 + k]; }
+    hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), t0, n_rays,
+                       step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
+                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel);
+    PERF_LAUNCH_CHECK("perf_occ_march_write_points");
     return PERF_OK;
 }

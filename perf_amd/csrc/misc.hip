@@ -61,18 +61,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     if (zero_grad) g[i] = 0.f;
 }
 
-struct Aabb { float lo[3], hi[3]; };
-
-__device__ __forceinline__ void normalize_store(float px, float py, float pz, const Aabb& bb, float* x01, uint8_t* sel,
-                                                int64_t i) {
-    // (x - aabb_min) / (aabb_max - aabb_min), IEEE division like torch
-    float ux = __fdiv_rn(sub_rn(px, bb.lo[0]), sub_rn(bb.hi[0], bb.lo[0]));
-    float uy = __fdiv_rn(sub_rn(py, bb.lo[1]), sub_rn(bb.hi[1], bb.lo[1]));
-    float uz = __fdiv_rn(sub_rn(pz, bb.lo[2]), sub_rn(bb.hi[2], bb.lo[2]));
-    x01[3 * i] = ux; x01[3 * i + 1] = uy; x01[3 * i + 2] = uz;
-    if (sel) sel[i] = (ux > 0.f && ux < 1.f && uy > 0.f && uy < 1.f && uz > 0.f && uz < 1.f) ? 1 : 0;
-}
-
 __global__ __launch_bounds__(256) void points_from_rays_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                                                const int64_t* __restrict__ ri, const float* __restrict__ ts,
                                                                const float* __restrict__ te, Aabb bb, float* __restrict__ x01,
@@ -80,12 +68,7 @@ __global__ __launch_bounds__(256) void points_from_rays_kernel(const float* __re
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int64_t r = ri[i];
-    const float tsum = add_rn(ts[i], te[i]);
-    // t_origins + t_dirs * (t0+t1) / 2.0   (nerf_renderer.py:127): multiply, divide, add -- unfused
-    float px = add_rn(o[3 * r], __fdiv_rn(mul_rn(d[3 * r], tsum), 2.0f));
-    float py = add_rn(o[3 * r + 1], __fdiv_rn(mul_rn(d[3 * r + 1], tsum), 2.0f));
-    float pz = add_rn(o[3 * r + 2], __fdiv_rn(mul_rn(d[3 * r + 2], tsum), 2.0f));
-    normalize_store(px, py, pz, bb, x01, sel, i);
+    sample_point_store(o + 3 * r, d + 3 * r, ts[i], te[i], bb, x01, sel, i);
 }
 
 __global__ __launch_bounds__(256) void points_normalize_kernel(const float* __restrict__ x, Aabb bb, float* __restrict__ x01,

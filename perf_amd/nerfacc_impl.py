@@ -157,9 +157,12 @@ class OccGridEstimator(nn.Module):
     @torch.no_grad()
     def sampling_ex(self, rays_o, rays_d, sigma_fn=None, near_plane=0.0, far_plane=1e10, render_step_size=1e-3,
                     early_stop_eps=1e-4, alpha_thre=0.0, stratified=False, cone_angle=0.0, alpha_fn=None,
-                    t_min=None, t_max=None, jitter=None, max_steps=None, capacity=None):
+                    t_min=None, t_max=None, jitter=None, max_steps=None, capacity=None, points_aabb=None):
         """sampling() that also returns (packed_info, sigmas of the kept samples or None).
-        max_steps caps the number of lattice intervals per ray (fixed-count benchmark mode)."""
+        max_steps caps the number of lattice intervals per ray (fixed-count benchmark mode).
+        points_aabb: when no visibility compaction follows the march (capacity mode, or early_stop_eps == 0), the sample
+        positions normalised to that box are produced by the marching kernel itself and left in ray_indices._perf_points
+        = (x01, sel)."""
         if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
             raise NotImplementedError('PeRF samples with cone_angle=0 and a sigma_fn (nerf_renderer.py:145-155)')
         if alpha_thre != 0.0:
@@ -181,12 +184,17 @@ class OccGridEstimator(nn.Module):
         res = self._res
         if capacity is not None:
             # sync-free fixed-shape mode (hipGraph capture): the caller guarantees exactly `capacity` samples
-            ri, ts, te, packed, total = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane),
-                                                      float(render_step_size), max_steps, capacity=capacity, occ_coarse=self.occ_coarse())
+            out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size),
+                                max_steps, capacity=capacity, occ_coarse=self.occ_coarse(), points_aabb=points_aabb)
+            ri, ts, te, packed = out[:4]
             ri._perf_packed = packed
+            ri._perf_points = out[5:] if points_aabb is not None else None
             return ri, ts, te, packed, None
-        ri, ts, te, packed = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane),
-                                           float(render_step_size), max_steps, occ_coarse=self.occ_coarse())
+        compacts = sigma_fn is not None and early_stop_eps > 0
+        out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size), max_steps,
+                            occ_coarse=self.occ_coarse(), points_aabb=None if compacts else points_aabb)
+        ri, ts, te, packed = out[:4]
+        ri._perf_points = out[4:] if (points_aabb is not None and not compacts) else None
         sig = None
         if sigma_fn is not None and early_stop_eps > 0 and ri.numel() > 0:
             ri._perf_packed = packed
@@ -196,6 +204,7 @@ class OccGridEstimator(nn.Module):
             sig = sig.float().contiguous()
             new_counts = ops.visibility_count(sig, ts, te, packed, early_stop_eps)
             ri, ts, te, sig, packed = ops.compact_prefix(packed, new_counts, ts, te, sig)
+            ri._perf_points = None
         ri._perf_packed = packed
         return ri, ts, te, packed, sig
 

@@ -270,10 +270,13 @@ def occ_build_coarse(occ_bits, res):
     return coarse
 
 
-def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, capacity=None, occ_coarse=None):
+def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, capacity=None, occ_coarse=None,
+              points_aabb=None):
     """Returns (ray_indices i64 [S], t_starts, t_ends f32 [S], packed_info i32 [R,2]).
     capacity=None reads the total back (one host sync, like the reference's boolean indexing);
-    an int capacity keeps the call sync-free and returns arrays of that length plus `total` on device."""
+    an int capacity keeps the call sync-free and returns arrays of that length plus `total` on device.
+    points_aabb (6 floats): also return the sample positions (x01 [S,3], sel [S]) normalised to that box, written by
+    the same kernel that writes the samples (appended to the result)."""
     R = rays_o.shape[0]
     dev = rays_o.device
     lib = _lib.load()
@@ -289,11 +292,19 @@ def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_step
     ts = torch.empty(S, dtype=torch.float32, device=dev)
     te = torch.empty(S, dtype=torch.float32, device=dev)
     packed = torch.empty(R, 2, dtype=torch.int32, device=dev)
-    _call('perf_occ_march_write', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
+    pts = ()
+    if points_aabb is not None:
+        x01 = torch.empty(S, 3, dtype=torch.float32, device=dev)
+        sel = torch.empty(S, dtype=torch.uint8, device=dev)
+        _call('perf_occ_march_write_points', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
+              _p(ri), _p(ts), _p(te), _p(packed), _p(rays_o), _p(rays_d), _aabb6(points_aabb), _p(x01), _p(sel), _stream())
+        pts = (x01, sel)
+    else:
+        _call('perf_occ_march_write', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
               _p(ri), _p(ts), _p(te), _p(packed), _stream())
     if capacity is None:
-        return ri, ts, te, packed
-    return ri, ts, te, packed, total
+        return (ri, ts, te, packed) + pts
+    return (ri, ts, te, packed, total) + pts
 
 
 # ---- compositing -----------------------------------------------------------------------------------
@@ -353,7 +364,7 @@ def composite_distloss_fwd(sigmas, rgbs, t_starts, t_ends, packed):
 def composite_distloss_bwd(sigmas, t_starts, t_ends, packed, weights, trans, opacity, distance, g_opacity, g_distance,
                            scale=1.0, scale_dev=None):
     """d sigma of compositing with the distortion-loss gradient (scale * scale_dev[0] * d dl / d w) formed in the kernel."""
-    ds = torch.zeros(sigmas.numel(), dtype=torch.float32, device=sigmas.device)
+    ds = torch.empty(sigmas.numel(), dtype=torch.float32, device=sigmas.device)      # packed_info tiles [0, S): every sample is written
     _call('perf_composite_distloss_bwd', _p(sigmas), _p(t_starts), _p(t_ends), _p(packed), packed.shape[0], _p(weights), _p(trans),
           _p(opacity), _p(distance), _p(g_opacity), _p(g_distance), float(scale), _p(scale_dev), _p(ds), _stream())
     return ds

@@ -68,10 +68,12 @@ class NeRFOCCRenderer(nn.Module):
         ray_indices, t_starts, t_ends, packed, sig0 = estimator.sampling_ex(
             rays_o, rays_d, sigma_fn=sigma_fn, near_plane=self.near_plane, far_plane=self.far_plane,
             render_step_size=self.render_step_size, early_stop_eps=self.early_stop_eps, stratified=nerf.training,
-            cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'), max_steps=self.max_steps, capacity=self.sample_capacity)
+            cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'), max_steps=self.max_steps, capacity=self.sample_capacity,
+            points_aabb=nerf._aabb_host)
         if ray_indices.numel() <= 0:
             return None
-        x01, sel = nerf.sample_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
+        pts = getattr(ray_indices, '_perf_points', None)       # positions written by the marching kernel (no compaction)
+        x01, sel = pts if pts else nerf.sample_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
         st = {'ray_indices': ray_indices, 't_starts': t_starts, 't_ends': t_ends, 'packed': packed, 'sig0': sig0,
               'x01': x01, 'sel': sel, 'n_rays': rays_o.shape[0], 'rgbs': None}
         if with_rgb:

@@ -599,3 +599,19 @@ def test_composite_distloss_fused_kernels(ops):
     ref, _ = ops.composite_bwd(c(sig), c(ts), c(te), c(packed), w, T, g_weights=g_w, g_opacity=g_op, g_distance=g_d)
     got = ops.composite_distloss_bwd(c(sig), c(ts), c(te), c(packed), w, T, op, dist, g_op, g_d, 2.0, scale_dev=scale_dev)
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7
+
+
+def test_march_write_with_points_equals_two_kernels(ops):
+    g = torch.Generator().manual_seed(12)
+    R, res = 500, 32
+    occ = (torch.rand(res ** 3, generator=g) < 0.2).to(torch.uint8)
+    o = (torch.rand(R, 3, generator=g) - 0.5) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    t0 = torch.rand(R, generator=g) * 0.01
+    aabb = [-1., -1, -1, 1, 1, 1]
+    bits = ops.occ_pack_bits(occ.cuda())
+    ri, ts, te, packed = ops.occ_march(o.cuda(), d.cuda(), t0.cuda(), bits, res, aabb, 1.5, 1e-2, 151)
+    x_ref, s_ref = ops.points_from_rays(o.cuda(), d.cuda(), ri, ts, te, aabb)
+    ri2, ts2, te2, packed2, x01, sel = ops.occ_march(o.cuda(), d.cuda(), t0.cuda(), bits, res, aabb, 1.5, 1e-2, 151, points_aabb=aabb)
+    assert torch.equal(ri, ri2) and torch.equal(ts, ts2) and torch.equal(te, te2) and torch.equal(packed, packed2)
+    assert torch.equal(x01, x_ref) and torch.equal(sel, s_ref)
