@@ -253,19 +253,28 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
 constexpr int kScanSmall = 65536;
 __global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
                                                           int64_t* __restrict__ total_out) {
-    __shared__ long long wave_sum[16];
+    // every wave owns one contiguous segment and walks it 64 elements at a time (coalesced): pass 1 sums the segment,
+    // pass 2 (after the 16 segment sums have been exchanged through LDS) rescans it with the right base
+    __shared__ long long seg_sum[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (int)((n + 1023) / 1024);
-    const int64_t lo = (int64_t)threadIdx.x * per;
-    int s = 0;
-    for (int k = 0; k < per; ++k) if (lo + k < n) s += in[lo + k];
-    const int inc = wave_incl_scan(s, lane);
-    if (lane == 63) wave_sum[wave] = inc;
+    const int64_t seg = ((n + 16 * 64 - 1) / (16 * 64)) * 64;
+    const int64_t lo = (int64_t)wave * seg, hi = (lo + seg < n) ? lo + seg : n;
+    long long s = 0;
+    for (int64_t i = lo + lane; i < hi; i += 64) s += in[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) seg_sum[wave] = s;
     __syncthreads();
     long long base = 0, tot = 0;
-    for (int w2 = 0; w2 < 16; ++w2) { if (w2 < wave) base += wave_sum[w2]; tot += wave_sum[w2]; }
-    int ex = (int)base + inc - s;
-    for (int k = 0; k < per; ++k) if (lo + k < n) { const int v = in[lo + k]; out[lo + k] = ex; ex += v; }
+    for (int w2 = 0; w2 < 16; ++w2) { if (w2 < wave) base += seg_sum[w2]; tot += seg_sum[w2]; }
+    int carry = (int)base;
+    for (int64_t c0 = lo; c0 < hi; c0 += 64) {
+        const int64_t i = c0 + lane;
+        const int v = (i < hi) ? in[i] : 0;
+        const int inc = wave_incl_scan(v, lane);
+        if (i < hi) out[i] = carry + inc - v;
+        carry += __shfl(inc, 63);
+    }
     if (threadIdx.x == 0) *total_out = tot;
 }
 
