@@ -130,7 +130,8 @@ int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const fl
  * accumulate == 0 (no zero-fill needed), added to when accumulate != 0.  No global atomics.
  * level_absmax == NULL: fp32 LDS accumulation.  level_absmax != NULL (device, PERF_MAX_LEVELS floats, the
  * per-level max |dfeat| as produced by perf_mlp_bwd): packed fixed-point accumulation with full-rate integer
- * LDS atomics, unit = 2^ceil(log2 absmax) * 2^-19; *overflow_flag (device int32, may be NULL) is OR-ed with 1
+ * LDS atomics, unit_l = 2^ceil(log2 absmax_l) * 2^(h_l - 31) with the headroom h_l = clamp(ceil(log2(8 n / size_l)) + 6,
+ * 12, 24) (64x the average number of contributions an entry of the level sums); *overflow_flag (device int32, may be NULL) is OR-ed with 1
  * when any field comes within 2x of the int32 range (then repeat the call with level_absmax == NULL).
  * workspace: 16-byte aligned device scratch of perf_hashgrid_bwd_workspace_bytes(grid, n) bytes (replica slabs of
  * the coarse levels + 4 bytes per (sample, hashed level) of tile codes; a workspace without room for the codes

@@ -239,7 +239,7 @@ struct TileParams {
     int32_t replicas_of[PERF_MAX_LEVELS];  // replicas per tile
     int64_t ws_off[PERF_MAX_LEVELS];       // float2 offset of the level's replica slabs in the workspace
     int32_t accumulate;
-    int32_t fixed_headroom_log2;           // fixed-point mode: log2 of the assumed max sum / max contribution
+    int32_t headroom_log2[PERF_MAX_LEVELS];// fixed-point mode: log2 of the assumed max |sum| / max |contribution| of an entry
     int64_t dbg_off;                       // >0: float2 offset in the workspace where per-block cycle counts go (dev tool)
     int32_t code_slot[PERF_MAX_LEVELS];    // >=0: the level's tile codes are codes[slot][n_pad] (see tile_codes_kernel)
     int64_t n_pad;
@@ -745,7 +745,8 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         const float am = level_absmax[l];
         int e = 0;
         if (am > 0.f) (void)frexpf(am, &e);                         // am < 2^e
-        const int sh = 31 - tp.fixed_headroom_log2 - e;               // units per 1.0 = 2^sh
+        if (e < -80) e = -80;                                        // (vanishing gradients: keep 2^sh finite)
+        const int sh = 31 - tp.headroom_log2[l] - e;                  // units per 1.0 = 2^sh
         cx.to_fixed = ldexpf(1.0f, sh);
         from_fixed = ldexpf(1.0f, -sh);
     }
@@ -986,7 +987,21 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     PERF_REQUIRE(ws_entries == 0 || (workspace && workspace_bytes >= ws_entries * (int64_t)sizeof(float2)),
                  "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(ws_entries * sizeof(float2)));
     tp.accumulate = accumulate;
-    tp.fixed_headroom_log2 = 12;
+    // Headroom of the fixed-point fields: an entry of level l sums 8 n / size_l contributions on average (1,700 at the
+    // coarsest level of a 1 M-sample batch, 32 at a hashed one); 64x that average before the overflow flag is raised,
+    // never less than 2^12, never more than 2^24 (which still leaves 2^-7 of the largest contribution as the unit).
+    for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
+        int h = 12;
+        if (l < gp.n_levels && n > 0) {
+            const double fan = 8.0 * (double)n / (double)gp.size[l];
+            int lg = 0;
+            while ((double)(1ll << lg) < fan && lg < 40) ++lg;        // ceil(log2(fan)), 0 for fan <= 1
+            h = lg + 6;
+            if (h < 12) h = 12;
+            if (h > 24) h = 24;
+        }
+        tp.headroom_log2[l] = h;
+    }
     tp.dbg_off = 0;
     int64_t slab_entries = ws_entries;      // workspace layout: [replica slabs (larger of both modes)][debug slots][tile codes]
     { TileParams t2; int nb2; int64_t w2; plan_tiles(gp, level_absmax == nullptr, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2; }

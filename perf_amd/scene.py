@@ -184,6 +184,10 @@ class NeRFScene:
         self.last_losses = {}
         self._capturing = False
         self.fused_steps = True        # explicit kernel chains for the two training steps (False: autograd formulation)
+        # The reference's geometry step renders colours (query key 'rgb', nerf.py:197-201) that no loss term of that step
+        # reads (:208-252).  True drops that colour-field forward: identical parameters, ~20 % less work.  Off by default
+        # so that bench.py times the reference's step (one ray-sample = BOTH fields evaluated).
+        self.skip_unused_color = False
         self.overlap_comm = True       # DP: overlap the gradient all-reduce with the next step's prefetch
         self._geo_pre = None
         self._ratio_dev = torch.zeros((), dtype=torch.float32, device='cuda')   # distortion-loss ramp min(2*progress, 1)
@@ -311,7 +315,8 @@ class NeRFScene:
         st = None
         if self.renderer.early_stop_eps <= 0:
             with torch.no_grad():
-                st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=True)
+                st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand,
+                                                with_rgb=not (self.fused_steps and self.skip_unused_color))
                 st = st if st is not None else False
         return {'rays': rays, 'gt_depths': gt_depths, 'bs': bs, 'dist_info': dist_info, 'st': st, 'rand': rand}
 
@@ -353,7 +358,7 @@ class NeRFScene:
         st = pre['st']
         rand_in, rand = rand, pre['rand']
         if st is None:
-            st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=True)
+            st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=not self.skip_unused_color)
         geo = self.nerf.geo_mlp
         if st is None or st is False:
             if dist_info[0] is not None:
@@ -365,7 +370,7 @@ class NeRFScene:
         w16 = geo.working_copy()
         feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:])
         sig = ops.mlp_fwd(geo.mlp, w16[:n_net], feat, sel)
-        rgbs = st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel)
+        rgbs = None if self.skip_unused_color else (st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel))
         w, T, op, dist_r, col, dl = ops.composite_distloss_fwd(sig.view(-1), rgbs, ts, te, packed)
         noise = rand['noise']            # (the background colour the reference also draws, :185, is not used by this step)
         if not self._capturing:

@@ -394,7 +394,7 @@ def test_accumulate_and_pack_info(ops):
 
 
 def test_hashgrid_bwd_fixed_point_mode(ops):
-    """Packed fixed-point accumulation (integer LDS atomics) against the fp32 mode: unit = 2^-19 of the level's
+    """Packed fixed-point accumulation (integer LDS atomics) against the fp32 mode: unit = 2^(h-31) of the level's
     max |dfeat| (rounded up to a power of two), so entry sums agree to ~sqrt(fan-in) units."""
     cfg = _grid_cfg()
     g = torch.Generator().manual_seed(21)
@@ -408,7 +408,8 @@ def test_hashgrid_bwd_fixed_point_mode(ops):
     assert int(ops.overflow_flag(x.device).item()) == 0
     for l in range(cfg.n_levels):
         lo, hi = 2 * int(cfg.offset[l]), 2 * (int(cfg.offset[l]) + int(cfg.size[l]))
-        unit = float(2.0 ** torch.ceil(torch.log2(amax[l])) * 2.0 ** -19)
+        h = min(24, max(12, math.ceil(math.log2(max(8.0 * n / int(cfg.size[l]), 1.0))) + 6))      # headroom rule of perf_hashgrid_bwd
+        unit = float(2.0 ** torch.ceil(torch.log2(amax[l])) * 2.0 ** (h - 31))
         fan = 8.0 * n / int(cfg.size[l]) + 8
         err = float((got[lo:hi] - ref[lo:hi]).abs().max())
         assert err <= unit * (4 * fan ** 0.5 + 4), (l, err, unit)
@@ -615,3 +616,18 @@ def test_march_write_with_points_equals_two_kernels(ops):
     ri2, ts2, te2, packed2, x01, sel = ops.occ_march(o.cuda(), d.cuda(), t0.cuda(), bits, res, aabb, 1.5, 1e-2, 151, points_aabb=aabb)
     assert torch.equal(ri, ri2) and torch.equal(ts, ts2) and torch.equal(te, te2) and torch.equal(packed, packed2)
     assert torch.equal(x01, x_ref) and torch.equal(sel, s_ref)
+
+
+def test_hashgrid_bwd_fixed_point_with_vanishing_gradients(ops):
+    """Gradients of 1e-30 .. 1e-42 (and exactly zero) must neither raise the overflow flag nor produce non-finite sums."""
+    cfg = _grid_cfg()
+    g = torch.Generator().manual_seed(23)
+    n = 3000
+    x = torch.rand(n, 3, generator=g).cuda()
+    for mag in (1e-30, 1e-38, 1e-42, 0.0):
+        dfeat = (torch.randn(cfg.n_levels, n, 2, generator=g) * mag).cuda()
+        amax = torch.zeros(24, device='cuda'); amax[:cfg.n_levels] = dfeat.abs().amax(dim=(1, 2))
+        ops.overflow_flag(x.device).zero_()
+        got = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax)
+        assert int(ops.overflow_flag(x.device).item()) == 0, mag
+        assert bool(torch.isfinite(got).all()) and float(got.abs().max()) <= 8 * n * max(mag, 1e-45) * 10
