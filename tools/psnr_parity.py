@@ -18,8 +18,8 @@ def psnr(a, b):
     return float(-10 * torch.log10(torch.mean((a.float() - b.float()) ** 2)))
 
 
-def make_draws(n_pool):
-    g = torch.Generator().manual_seed(123)
+def make_draws(n_pool, seed=0):
+    g = torch.Generator().manual_seed(123 + seed)
     draws = []
     for _ in range(N_GEO + N_APP):
         draws.append({'idx': torch.randint(0, n_pool, (BATCH,), generator=g), 'jitter': torch.rand(BATCH, generator=g),
@@ -118,6 +118,26 @@ def main():
         print(dtype, accum, [round(r[f'psnr@app{N_APP}'], 3) for r in runs], [round(r[f'psnr@app{N_APP // 2}'], 3) for r in runs], flush=True)
     t = time.time(); res['oracle_fp32_cpu'] = run_oracle(o, d, dist, rgb, occ, geo0, app0, draws); res['oracle_fp32_cpu']['seconds'] = round(time.time() - t, 1)
     print('oracle', res['oracle_fp32_cpu'], flush=True)
+    # SEEDS=k: k further (initialisation, batch/draw stream) seeds, default path only -- is the difference a bias or noise?
+    seeds = int(os.environ.get('SEEDS', 0))
+    if seeds:
+        rows = []
+        for sd in range(1, seeds + 1):
+            g0 = O.init_field_params(O.geo_spec(), 1337 + sd); a0 = O.init_field_params(O.app_spec(), 1337 + sd)
+            dr = make_draws(o.shape[0], sd)
+            ref = run_oracle(o, d, dist, rgb, occ, g0, a0, dr)
+            row = {'seed': sd, 'oracle': ref}
+            for dtype in ('bf16', 'fp16'):
+                row[dtype] = run_hip(o, d, dist, rgb, occ, g0, a0, dr, dtype, 'fixed')
+            rows.append(row)
+            print('seed', sd, {k: round(row['bf16'][k] - ref[k], 3) for k in ref if k.startswith('psnr')},
+                  {k: round(row['fp16'][k] - ref[k], 3) for k in ref if k.startswith('psnr')}, flush=True)
+        res['seeds'] = rows
+        for dtype in ('bf16', 'fp16'):
+            for k in (f'psnr@app{N_APP // 2}', f'psnr@app{N_APP}'):
+                dl = np.array([r[dtype][k] - r['oracle'][k] for r in rows] + [res[f'hip_{dtype}_fixed'][0][k] - res['oracle_fp32_cpu'][k]])
+                res[f'delta_{dtype}_{k}'] = {'mean': float(dl.mean()), 'std': float(dl.std()), 'n': int(dl.size)}
+                print(dtype, k, 'HIP - oracle: mean %.3f dB, std %.3f dB over %d seeds' % (dl.mean(), dl.std(), dl.size), flush=True)
     os.makedirs('gpurun_out', exist_ok=True)
     json.dump(res, open('gpurun_out/psnr_parity.json', 'w'), indent=1)
 
