@@ -578,7 +578,7 @@ extern "C" int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const voi
     PERF_REQUIRE(w16 && feat16 && out, "NULL pointer");
     PERF_REQUIRE(dtype == PERF_DTYPE_BF16 || dtype == PERF_DTYPE_FP16, "bad dtype %d", dtype);
     MlpParams mp{mlp->n_levels, mlp->n_out, mlp->out_act, mlp->exp_shift};
-    const int blocks = mlp_blocks(n, 8);
+    const int blocks = mlp_blocks(n, nh == 1 ? 4 : 3);          // = the waves per SIMD the kernels' registers allow: fragments are staged once per block
     if (dtype == PERF_DTYPE_BF16)
         dispatch_fwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, out, n);
     else
