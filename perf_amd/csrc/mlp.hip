@@ -102,14 +102,21 @@ __device__ __forceinline__ void stage_fragments(const uint16_t* __restrict__ w, 
     }
 }
 
+// max(x, 0) as ONE integer v_max_i32 on the bit pattern (negative floats are negative ints; fmaxf costs a canonicalising
+// v_max_f32 plus the v_max_f32 itself)
+__device__ __forceinline__ float relu(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 template <typename T16>
 __device__ __forceinline__ void relu_pack(const f32x16& acc, u32x4& lo, u32x4& hi, uint32_t& mask_bits, int shift) {
     // regs 0..7 -> k-step t=0, regs 8..15 -> t=1.  mask bit (shift+r) = acc[r] > 0
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float a = acc[2 * i], b = acc[2 * i + 1], c = acc[8 + 2 * i], d = acc[8 + 2 * i + 1];
-        lo[i] = T16::pack(fmaxf(a, 0.f), fmaxf(b, 0.f));
-        hi[i] = T16::pack(fmaxf(c, 0.f), fmaxf(d, 0.f));
+        lo[i] = T16::pack(relu(a), relu(b));
+        hi[i] = T16::pack(relu(c), relu(d));
         mask_bits |= (a > 0.f ? 1u : 0u) << (shift + 2 * i);
         mask_bits |= (b > 0.f ? 1u : 0u) << (shift + 2 * i + 1);
         mask_bits |= (c > 0.f ? 1u : 0u) << (shift + 8 + 2 * i);
@@ -182,11 +189,20 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16
         for (int s = 0; s < 4; ++s) o = T16::mfma(frag[(L::f_ao + s) * 64 + lane], hb[s], o);
         if (valid) {
             const float sv = sel ? (float)sel[si] : 1.0f;
+            // the activation is a kernel argument: branch on it ONCE (scalar), and stop at the last register that can hold
+            // a real output row (rows of register r: d_row(r, 0) < d_row(r, 1)) -- otherwise both exponentials are
+            // evaluated for all 8 registers and selected afterwards (~250 vector instructions per tile)
+            auto emit = [&](auto act) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int row = d_row(r, h);
-                if (row < mp.n_out) out[si * mp.n_out + row] = act_fwd(o[r], mp.out_act, mp.exp_shift) * sv;
-            }
+                for (int r = 0; r < 8; ++r) {
+                    if (d_row(r, 0) >= mp.n_out) break;
+                    const int row = d_row(r, h);
+                    if (row < mp.n_out) out[si * mp.n_out + row] = act(o[r]) * sv;
+                }
+            };
+            if (mp.out_act == PERF_ACT_SIGMOID) emit([](float y) { return 1.0f / (1.0f + expf(-y)); });
+            else if (mp.out_act == PERF_ACT_EXP) emit([&](float y) { return expf(y - mp.exp_shift); });
+            else emit([](float y) { return y; });
         }
     }
 }
@@ -289,11 +305,19 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams
         float dy[8];
         const float sv = (valid && sel) ? (float)sel[si] : (valid ? 1.0f : 0.0f);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int row = d_row(r, h);
-            float g = 0.f;
-            if (valid && row < mp.n_out) g = act_bwd(o[r], dout[si * mp.n_out + row] * sv, mp.out_act, mp.exp_shift);
-            dy[r] = g;
+        for (int r = 0; r < 8; ++r) dy[r] = 0.f;
+        {
+            auto emit = [&](auto dact) {         // (scalar branch on the activation, registers without a real output row skipped)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (d_row(r, 0) >= mp.n_out) break;
+                    const int row = d_row(r, h);
+                    if (valid && row < mp.n_out) dy[r] = dact(o[r], dout[si * mp.n_out + row] * sv);
+                }
+            };
+            if (mp.out_act == PERF_ACT_SIGMOID) emit([](float y, float g) { const float s_ = 1.0f / (1.0f + expf(-y)); return g * s_ * (1.0f - s_); });
+            else if (mp.out_act == PERF_ACT_EXP) emit([&](float y, float g) { return g * expf(fminf(y - mp.exp_shift, 15.0f)); });
+            else emit([](float, float g) { return g; });
         }
         u32x4 dyb;
 #pragma unroll
