@@ -1,0 +1,40 @@
+"""One PeRF training episode at the reference's settings (modules/scene/nerf.py:137-184, configs/nerf.yaml): occupancy
+from the supervision, 3000 geometry + 1500 colour iterations of 8,192 rays drawn from a 1024x2048 panorama, reference-
+faithful variable-count sampling (step 5e-4, early stop 1e-4), then a full-panorama evaluation.
+
+  python tools/train_episode.py [--geo 3000] [--app 1500] [--dtype bf16]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from perf_amd import synthetic, tcnn
+from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays, psnr
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--geo', type=int, default=3000)
+ap.add_argument('--app', type=int, default=1500)
+ap.add_argument('--dtype', default='bf16')
+args = ap.parse_args()
+torch.manual_seed(0)
+scene = NeRFScene(dtype=args.dtype)
+H, W = 1024, 2048
+rays = gen_pano_rays(torch.eye(4), H, W)
+dist, rgb = synthetic.room(rays.d)
+pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, dist)
+marks = {}
+def cb(phase, i):
+    if i == 0:
+        torch.cuda.synchronize(); marks[phase] = time.perf_counter()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+scene.train_one_episode(pool, args.geo, args.app, callback=cb)
+torch.cuda.synchronize(); t1 = time.perf_counter()
+res = scene.render_once(pool.rand_ray_color_data(8192)[0], ['ray_indices'], app_inference=True)
+spp = res['ray_indices'].numel() / 8192
+scene.set_eval()
+torch.cuda.synchronize(); t2 = time.perf_counter()
+out = scene.render(rays, ['rgb', 'distance'])
+torch.cuda.synchronize(); t3 = time.perf_counter()
+print(json.dumps({'config': f'{args.geo} geometry + {args.app} colour iterations, 8192-ray batches, {W}x{H} supervision panorama, {args.dtype}',
+                  'episode_s': t1 - t0, 'occupancy_s': marks['geo'] - t0, 'geo_phase_s': marks['app'] - marks['geo'], 'app_phase_s': t1 - marks['app'],
+                  'ms_per_geo_step': (marks['app'] - marks['geo']) / args.geo * 1e3, 'ms_per_app_step': (t1 - marks['app']) / args.app * 1e3,
+                  'train_batch_mean_samples_per_ray': spp, 'grid_gradient_mode_at_end': tcnn.GRID_GRAD_ACCUM,
+                  'eval_full_pano_s': t3 - t2, 'psnr_dB': psnr(out['rgb'], rgb), 'mean_abs_distance_err': float((out['distance'] - dist).abs().mean())}, indent=1))
