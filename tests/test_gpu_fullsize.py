@@ -91,3 +91,36 @@ def test_encoding_is_linear_in_the_table():
     lhs = float((f1.double() * G.double()).sum())
     rhs = float((t1.double() * ops.hashgrid_bwd(cfg, x, G).double()).sum())
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+def test_training_batch_grid_gradient_properties():
+    """The bench's batch (8,192 rays x 128 samples, ray-coherent) through the default fixed-point owners: every level
+    conserves mass (trilinear weights sum to 1: sum of the level's gradient entries == sum of its dfeat), the backward is
+    the adjoint of the forward, two calls are bit-identical, and the overflow flag stays clear."""
+    from perf_amd import ops
+    from perf_amd.grid import GridConfig
+    cfg = GridConfig()
+    g = torch.Generator(device='cuda').manual_seed(4)
+    R, S = 8192, 128
+    d = torch.nn.functional.normalize(torch.randn(R, 3, device='cuda', generator=g), dim=-1)
+    t = (torch.arange(S, device='cuda') + torch.rand(R, 1, device='cuda', generator=g)) * (0.99 / S)
+    x = ((d[:, None, :] * t[:, :, None]).reshape(-1, 3) * 0.5 + 0.5).contiguous()
+    n = x.shape[0]
+    G = torch.randn(cfg.n_levels, n, 2, device='cuda', generator=g) * torch.logspace(-4, 0, cfg.n_levels, device='cuda')[:, None, None]
+    amax = torch.zeros(24, device='cuda'); amax[:cfg.n_levels] = G.abs().amax(dim=(1, 2))
+    ops.overflow_flag(x.device).zero_()
+    g1 = ops.hashgrid_bwd(cfg, x, G, level_absmax=amax)
+    g2 = ops.hashgrid_bwd(cfg, x, G, level_absmax=amax)
+    assert int(ops.overflow_flag(x.device).item()) == 0
+    assert torch.equal(g1, g2)
+    for l in range(cfg.n_levels):
+        lo, hi = 2 * int(cfg.offset[l]), 2 * (int(cfg.offset[l]) + int(cfg.size[l]))
+        got = g1[lo:hi].view(-1, 2).double().sum(0)
+        ref = G[l].double().sum(0)
+        scale = float(G[l].abs().double().sum())
+        assert float((got - ref).abs().max()) < 2e-4 * scale / math.sqrt(n) + 1e-3 * float(amax[l]), l
+    table = torch.randn(cfg.n_params, device='cuda', generator=g)
+    f = ops.hashgrid_fwd_f32(cfg, x, table)
+    lhs = float((f.double() * G.double()).sum())
+    rhs = float((table.double() * g1.double()).sum())
+    assert abs(lhs - rhs) < 2e-4 * max(1.0, float((f.double() * G.double()).abs().sum()) / math.sqrt(n))
