@@ -1,13 +1,20 @@
 #!/usr/bin/env python
-"""Headline benchmark: ray-samples/s of the panoramic-NeRF TRAINING hot path on MI355X.
+"""Headline benchmark: ray-samples/s of the panoramic-NeRF TRAINING hot path on MI355X (+ PSNR@iter).
 
 Workload (BASELINE.json configs[1]/[2]): synthetic 2048x1024 panorama, 128 samples per ray, hash grid L=16/T=18 +
-64-wide MLPs, 16-bit tables/activations with fp32 accumulation.  One "step" = one geometry-phase training step of
-PeRF's NeRFScene.train_one_step_geo (modules/scene/nerf.py:186-257) on 8192 rays PER GPU: batch gather, stratified
-sampling, density field forward (with grad) + colour field forward (no grad), compositing, depth + distortion loss,
-backward through compositing / MLP / hash grid, [RCCL all-reduce of the flat gradient], Adam.  Every one of the
-R*128 ray-samples is evaluated by both fields and composited (fixed-count mode: all-occupied grid, no early-stop
-pruning), so value = n_gpus * rays_per_gpu * 128 * steps / seconds.
+64-wide MLPs, 16-bit tables/activations with fp32 accumulation.  One "step" = one geometry-phase training step of PeRF's
+NeRFScene.train_one_step_geo (modules/scene/nerf.py:186-257) on 8192 rays PER GPU, with everything the reference's step
+does (modules/scene/nerf_renderer.py:145-183):
+
+  batch gather -> stratified marching (128 lattice intervals per ray) -> density field WITHOUT gradient on every marched
+  sample (the sigma pass inside OccGridEstimator.sampling) -> transmittance scan + visibility compaction (T >= 1e-4)
+  -> density field WITH gradient on the kept samples -> colour field (no grad) -> compositing -> depth + distortion loss
+  -> backward through compositing / MLP / hash grid -> [RCCL all-reduce of the flat gradient] -> Adam.
+
+Sample counts are decided on the GPU and stay there (device-side counts, capacity-sized launches), so the whole step is
+ONE hipGraph.  value = ray-samples that were evaluated by BOTH fields and composited (the KEPT samples, read once from a
+device counter after the timed region) per second -- the extra no-grad density evaluation of every marched sample is
+work the step does on top and is not counted.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -27,13 +34,16 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/fp16 MFMA
 
-# algorithmic bytes / flops per ray-sample of each kernel (DESIGN.md section "Kernels")
-ALGO = {
-    'perf_hashgrid_fwd': ('hbm', 16 * 8 * 2 * 2),             # 16 levels x 8 corners x 2 features x 2 B gathered
-    'perf_hashgrid_bwd': ('hbm', 2 * 16 * 8 * 2 * 4),         # fp32 read-modify-write of every touched entry
-    'perf_mlp_fwd': ('mfma', None),                           # filled per network below
-    'perf_mlp_bwd': ('mfma', None),
-}
+# Algorithmic bytes per ray-sample of the gather/scatter kernels, at SURVEY.md 8(d)'s 16-bit figures:
+#   encode: 16 levels x 8 corners x 2 features x 2 B gathered = 512 B
+#   grid gradient: read-modify-write of every touched entry at 16-bit = 2 x 16 x 8 x 2 x 2 B = 1024 B
+#   (the kernel accumulates in fp32/fixed point in LDS and never does an HBM RMW; the fp32 figure would be 2048 B)
+ALGO_BYTES = {'perf_hashgrid_fwd': 16 * 8 * 2 * 2, 'perf_hashgrid_bwd': 2 * 16 * 8 * 2 * 2}
+# what the counters say limits each kernel (profiles/): `bound` names the roofline the fraction is priced
+# against, `limiter` what actually stalls the kernel
+LIMITER = {'perf_hashgrid_fwd': 'L1/TA request rate of 4-byte random gathers (tables are L2/Infinity-Cache resident)',
+           'perf_hashgrid_bwd': 'VALU issue (owner test + enqueue per sample visit); no HBM read-modify-write happens',
+           'perf_mlp_fwd': 'epilogue VALU + dependency chains', 'perf_mlp_bwd': 'epilogue VALU + LDS transposes'}
 GEO_FWD_FLOP = 2 * (32 * 64 + 64 * 1)
 APP_FWD_FLOP = 2 * (32 * 64 + 64 * 64 + 64 * 3)
 
@@ -43,21 +53,31 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--rays-per-gpu', type=int, default=8192)
+    ap.add_argument('--rays-per-gpu', type=int, default=8192, help='weak scaling: rays per GPU; strong: the GLOBAL batch')
     ap.add_argument('--spp', type=int, default=128)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'])
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'fp16'], help='default: perf_amd.tcnn.DEFAULT_DTYPE')
     ap.add_argument('--mode', default='train_geo', choices=['train_geo', 'train_app', 'render'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak: --rays-per-gpu rays on every GPU; strong: the reference batch (8192 rays) split over the GPUs')
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run the timed steps eagerly instead of replaying a hipGraph')
+    ap.add_argument('--no-prepass', action='store_true',
+                    help="round-1 'fixed-count' line: early_stop_eps = 0, i.e. WITHOUT the sampling-pass density evaluation and the "
+                         'visibility compaction of the reference step (not the headline)')
     ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample')
+    ap.add_argument('--no-psnr', action='store_true')
+    ap.add_argument('--psnr-geo-iters', type=int, default=3000, help='configs/nerf.yaml:25 raw_phase_iter_geo')
+    ap.add_argument('--psnr-app-iters', type=int, default=1500, help='configs/nerf.yaml:26 raw_phase_iter_app')
+    ap.add_argument('--sustain-seconds', type=float, default=1.0, help='length of the second, longer measurement (0 = off)')
     return ap.parse_args()
 
 
 def cpu_baseline(spp, n_rays):
     """The oracle (CPU restatement of the same algorithm, torch fp32) timed on this box's host cores on a bounded
-    sample of the same workload: one geometry training step (forward + backward) on n_rays x spp samples."""
+    sample of the same workload: one geometry training step (sampling-pass sigma + compaction, forward, backward) on
+    n_rays x spp samples."""
     import numpy as np
     from oracle import perf_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
@@ -72,7 +92,7 @@ def cpu_baseline(spp, n_rays):
     def one():
         out = O.occ_render(o, d, geo, app, occ, [-1, -1, -1, 1, 1, 1], training=True,
                            t0=np.zeros(len(o), np.float32), bg_color=torch.rand(len(o), 3), dist_noise=torch.rand(len(o), 1),
-                           near=0.0, far=10.0, step=step, early_stop_eps=0.0, max_steps=spp)
+                           near=0.0, far=10.0, step=step, early_stop_eps=1e-4, max_steps=spp)
         loss, _, _ = O.geo_step_loss(out, gt, 0.25)
         geo.grad = None
         loss.backward()
@@ -87,7 +107,50 @@ def cpu_baseline(spp, n_rays):
             break
     dt = (time.perf_counter() - t0) / reps
     return {'value': n / dt, 'unit': 'ray-samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'oracle geo training step (fwd+bwd), {len(o)} rays x ~{n // len(o)} samples, {reps} reps of {dt:.2f}s'}
+            'sample': f'oracle geo training step (sampling-pass sigma + compaction + fwd + bwd), {len(o)} rays x ~{n // len(o)} kept samples, '
+                      f'{reps} reps of {dt:.2f}s'}
+
+
+def psnr_at_iters(args, dev, dist_mod, rank, world):
+    """PSNR@iter: one training episode at the reference's settings (occupancy from the supervision, step 5e-4,
+    early stop 1e-4, 8192-ray global batch, --psnr-geo-iters geometry then --psnr-app-iters colour iterations) on the
+    synthetic room panorama; PSNR of the eval render against the panorama at colour iterations {0, 1/3, end}."""
+    from perf_amd import synthetic
+    from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays, psnr
+    torch.manual_seed(0)
+    scene = NeRFScene(dtype=args.dtype)
+    rays = gen_pano_rays(torch.eye(4), args.height, args.width, device=dev)
+    dist_map, rgb_map = synthetic.room(rays.d)
+    pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb_map, dist_map)
+    n_app = args.psnr_app_iters
+    marks = sorted({0, n_app // 3, n_app})
+    curve, times = {}, {}
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+
+    def probe(tag):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        if rank == 0:
+            out = scene.render(rays, ['rgb', 'distance'])
+            curve[tag] = {'psnr_db': round(psnr(out['rgb'], rgb_map), 3),
+                          'mean_abs_distance_err': round(float((out['distance'] - dist_map).abs().mean()), 5)}
+            scene.set_train()
+        torch.cuda.synchronize(); times['probe'] = times.get('probe', 0.0) + time.perf_counter() - t
+
+    def cb(phase, i):
+        if phase == 'geo' and i == args.psnr_geo_iters - 1 and 0 in marks:
+            probe('app_iter_0')
+        if phase == 'app' and (i + 1) in marks:
+            probe(f'app_iter_{i + 1}')
+
+    scene.train_one_episode(pool, args.psnr_geo_iters, n_app, callback=cb)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    return {'schedule': f'{args.psnr_geo_iters} geometry + {n_app} colour iterations, global batch {scene.train_conf.pixel_loss_batch_size} rays, '
+                        f'{args.width}x{args.height} synthetic room, reference sampling (step 5e-4, early stop 1e-4), seed 0',
+            'curve': curve, 'train_seconds': round(total - times.get('probe', 0.0), 3), 'render_seconds_total': round(times.get('probe', 0.0), 3),
+            'launch': 'hipGraph replay per step' if (world == 1 and scene.graph_steps) else 'eager',
+            'note': 'the fp32 oracle cannot run this size on a CPU; HIP-vs-oracle PSNR parity after equal iterations is asserted at 256x512 by '
+                    'tests/test_gpu_psnr.py against tests/golden/psnr_curve.json'}
 
 
 def main():
@@ -110,60 +173,58 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from perf_amd import ops, synthetic
+    from perf_amd import ops, synthetic, tcnn
     from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
+    args.dtype = args.dtype or tcnn.DEFAULT_DTYPE
 
     torch.manual_seed(0)
     scene = NeRFScene(dtype=args.dtype)
     tc = scene.train_conf
-    tc.pixel_loss_batch_size = args.rays_per_gpu * world          # weak scaling: 8192 rays on every GPU
+    if args.scaling == 'weak':
+        rays_local = args.rays_per_gpu                               # 8192 rays on every GPU
+    else:
+        assert args.rays_per_gpu % world == 0
+        rays_local = args.rays_per_gpu // world                      # the reference's 8192-ray batch split over the GPUs
+    tc.pixel_loss_batch_size = rays_local * world
     rays = gen_pano_rays(torch.eye(4), args.height, args.width, device=dev)
     dist_map, rgb_map = synthetic.room(rays.d)
     pool = SupInfoPool()
     pool.register_rays(rays.o, rays.d, rgb_map, dist_map)
 
-    # fixed-count sampling: all-occupied grid, 128 lattice intervals of 0.99/128 from the (jittered) origin
+    # fixed-count marching: all-occupied grid, 128 lattice intervals of 0.99/128 from the (jittered) origin; the
+    # reference's early termination (T >= 1e-4 after the no-grad density pass) then prunes what it prunes
     scene.set_train()
     scene.estimator.set_binaries(torch.ones(256 ** 3, dtype=torch.uint8, device=dev))
     r = scene.renderer
     r.render_step_size = 0.99 / args.spp
     r.far_plane = 10.0
-    r.early_stop_eps = 0.0
+    r.early_stop_eps = 0.0 if args.no_prepass else 1e-4
     r.max_steps = args.spp
-    r.sample_capacity = args.rays_per_gpu * args.spp if args.mode != 'render' else None
+    rays_per_step = rays_local if args.mode != 'render' else 32768
+    r.sample_capacity = rays_per_step * args.spp                     # = the marched count: nothing is ever truncated
     scene.nerf.reset_geo()
+    scene.sample_counters = torch.zeros(3, dtype=torch.int64, device=dev)
     gen = torch.Generator(device=dev); gen.manual_seed(1234)          # same index stream on every rank
 
     use_graph = (world == 1) and (not args.no_graph) and args.mode != 'render'
     graphed = None
-    if args.mode == 'train_geo':
-        opt = scene.make_optimizer(scene.nerf.geo_mlp, 0.0)
-        conf = tc.geo_optimizer
+    if args.mode in ('train_geo', 'train_app'):
+        kind = 'geo' if args.mode == 'train_geo' else 'app'
+        net = scene.nerf.geo_mlp if kind == 'geo' else scene.nerf.app_mlp
+        conf = tc.geo_optimizer if kind == 'geo' else tc.app_optimizer
+        n_sched = 3000.0 if kind == 'geo' else 1500.0
+        opt = scene.make_optimizer(net, 0.0)
+        step_fn = scene.train_one_step_geo if kind == 'geo' else scene.train_one_step_app
 
         def eager_step(i):
-            scene.update_lr(opt, conf, min(i / 3000.0, 0.999))
-            scene.train_one_step_geo(opt, pool, progress=0.25, generator=None if world == 1 else gen)
+            scene.update_lr(opt, conf, min(i / n_sched, 0.999))
+            step_fn(opt, pool, progress=0.25, generator=None if world == 1 else gen)
         if use_graph:
-            graphed = scene.make_graphed_step('geo', opt, pool)
+            graphed = scene.make_graphed_step(kind, opt, pool)
 
         def step(i):
             if graphed is not None:
-                graphed(scene.lr_at(conf, min(i / 3000.0, 0.999)), 0.25)
-            else:
-                eager_step(i)
-    elif args.mode == 'train_app':
-        opt = scene.make_optimizer(scene.nerf.app_mlp, 0.0)
-        conf = tc.app_optimizer
-
-        def eager_step(i):
-            scene.update_lr(opt, conf, min(i / 1500.0, 0.999))
-            scene.train_one_step_app(opt, pool, progress=0.25, generator=None if world == 1 else gen)
-        if use_graph:
-            graphed = scene.make_graphed_step('app', opt, pool)
-
-        def step(i):
-            if graphed is not None:
-                graphed(scene.lr_at(conf, min(i / 1500.0, 0.999)), 0.25)
+                graphed(scene.lr_at(conf, min(i / n_sched, 0.999)), 0.25)
             else:
                 eager_step(i)
     else:
@@ -175,92 +236,132 @@ def main():
         def step(i):
             b = i % n_batches
             with torch.no_grad():
-                scene.render_once(Rays(flat_o[b * 32768:(b + 1) * 32768], flat_d[b * 32768:(b + 1) * 32768]), ['rgb', 'distance'])
+                res = scene.render_once(Rays(flat_o[b * 32768:(b + 1) * 32768], flat_d[b * 32768:(b + 1) * 32768]),
+                                        ['rgb', 'distance', 'n_marched_dev', 'n_samples_dev'])
+                ops.step_bookkeeping(None, None, scene.sample_counters, res['n_marched_dev'], res['n_samples_dev'])
         eager_step = step
 
-    rays_per_step = args.rays_per_gpu if args.mode != 'render' else 32768
+    def timed(n_steps, first):
+        """n_steps steps bracketed by barrier + synchronize on both sides; -> (seconds = max over ranks, marched, kept)."""
+        scene.sample_counters.zero_()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(first + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        cnt = scene.sample_counters.clone()
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)                 # whole-job sample counts
+        c = cnt.tolist()
+        return el, int(c[0]), int(c[1])
+
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    # The timed region is never instrumented (HIP events cannot be recorded inside a graph replay, and eager event
-    # pairs would add host work per launch); per-kernel times come from an instrumented re-run of the same steps.
-    instrument_inline = False
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if instrument_inline:
-        kern = ops.stop_kernel_timing()
-    else:
-        # same K steps again, launched eagerly with a HIP event pair around every kernel (same kernels, same shapes)
-        ops.start_kernel_timing()
-        for i in range(args.steps):
-            eager_step(args.warmup + args.steps + i)
-        kern = ops.stop_kernel_timing()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, marched, kept = timed(args.steps, args.warmup)
+    value = kept / elapsed
 
-    samples_per_step = rays_per_step * args.spp
-    value = world * samples_per_step * args.steps / elapsed
+    # a second, longer measurement of the same loop (the K-step region above is only tens of milliseconds long)
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_long = int(min(20000, max(args.steps, args.sustain_seconds / max(elapsed / args.steps, 1e-6))))
+        if world > 1:                                                  # every rank must run the same number of steps
+            t = torch.tensor([n_long], device=dev); dist.broadcast(t, 0); n_long = int(t.item())
+        el2, m2, k2 = timed(n_long, args.warmup + args.steps)
+        sustained = {'steps': n_long, 'seconds': round(el2, 4), 'value': k2 / el2, 'ms_per_step': el2 / n_long * 1e3,
+                     'kept_samples_per_step_per_gpu': k2 / n_long / world, 'marched_samples_per_step_per_gpu': m2 / n_long / world}
+
+    # per-kernel times: the same K steps again, launched eagerly with a HIP event pair around every C-ABI launch on the
+    # launch stream (events cannot be recorded inside a graph replay; same kernels, same shapes, same device-side counts)
+    scene.sample_counters.zero_()
+    ops.start_kernel_timing()
+    first = args.warmup + args.steps + (sustained['steps'] if sustained else 0)
+    for i in range(args.steps):
+        eager_step(first + i)
+    kern = ops.stop_kernel_timing()
+    c_ev = scene.sample_counters.tolist()
+    marched_ev, kept_ev = c_ev[0] / max(args.steps, 1), c_ev[1] / max(args.steps, 1)     # per step, this rank
+
+    psnr_block = None
+    if not args.no_psnr and args.mode == 'train_geo':
+        psnr_block = psnr_at_iters(args, dev, dist, rank, world)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel, from HIP events recorded over the timed region -----------------
         total = {k: n * ms for k, (n, ms) in kern.items()}
         table = {}
+        prepass = r.early_stop_eps > 0 and args.mode != 'render'
         for k, (n, ms) in sorted(kern.items(), key=lambda kv: -total[kv[0]]):
             per_step = n / args.steps
-            table[k] = {'launches_per_step': round(per_step, 2), 'ms_per_launch': round(ms, 4), 'ms_per_step': round(per_step * ms, 4)}
-        dom = max((k for k in total if k in ALGO), key=lambda k: total[k])
-        n_l, ms_l = kern[dom]
-        kind, per_sample = ALGO[dom]
-        if kind == 'hbm':
-            achieved = samples_per_step * per_sample / (ms_l * 1e-3) / 1e9
-            roof = {'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-                    'algorithmic_bytes_per_ray_sample': per_sample, 'ms_per_launch': round(ms_l, 4)}
-        else:
-            flop = (GEO_FWD_FLOP if args.mode != 'train_app' else APP_FWD_FLOP) * (1 if dom == 'perf_mlp_fwd' else 3)
-            achieved = samples_per_step * flop / (ms_l * 1e-3) / 1e12
-            roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / MFMA_PEAK_TFLOPS, 5), 'traffic': None, 'ms_per_launch': round(ms_l, 4)}
+            row = {'launches_per_step': round(per_step, 2), 'ms_per_launch': round(ms, 4), 'ms_per_step': round(per_step * ms, 4)}
+            if k in ALGO_BYTES:
+                # live samples per launch: the sampling-pass encode runs on the marched samples, every other on the kept ones
+                if k == 'perf_hashgrid_fwd' and (prepass or args.mode == 'render'):
+                    live = (marched_ev + (per_step - 1) * kept_ev) / per_step
+                else:
+                    live = kept_ev
+                gbs = ALGO_BYTES[k] * live / (ms * 1e-3) / 1e9
+                row.update({'live_samples_per_launch': round(live), 'algorithmic_bytes_per_sample': ALGO_BYTES[k],
+                            'algorithmic_GBps': round(gbs, 1), 'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4),
+                            'limiter': LIMITER[k]})
+            elif k in ('perf_mlp_fwd', 'perf_mlp_bwd'):
+                row['limiter'] = LIMITER[k]
+            table[k] = row
+        dom = max((k for k in total if k in ALGO_BYTES), key=lambda k: total[k])
+        roof = {'kernel': dom, 'bound': 'hbm', 'achieved': table[dom]['algorithmic_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': table[dom]['frac_of_hbm_peak'], 'traffic': None, 'limiter': LIMITER[dom],
+                'algorithmic_bytes_per_ray_sample': ALGO_BYTES[dom], 'live_samples_per_launch': table[dom]['live_samples_per_launch'],
+                'ms_per_launch': table[dom]['ms_per_launch'],
+                'definition': 'achieved = algorithmic bytes (SURVEY.md 8(d), 16-bit figures) x live samples of a launch / mean launch duration '
+                              '(HIP events on the launch stream)'}
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same workload (profiles/)
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels']
-            if roof['kernel'] in pmc and args.mode == 'train_geo' and args.rays_per_gpu == 8192 and args.spp == 128:
-                roof['traffic'] = pmc[roof['kernel']]['hbm_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 fetch correction)'
-                roof['algorithmic_bytes_per_launch'] = samples_per_step * per_sample if kind == 'hbm' else None
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
+            if (pmc.get('workload') == _workload_key(args) and dom in pmc['kernels']):
+                roof['traffic'] = pmc['kernels'][dom]['hbm_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections)'
         except Exception:
             pass
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.spp, args.cpu_rays)
+        step_desc = {'train_geo': 'geometry training step', 'train_app': 'colour training step', 'render': 'eval render batch (32768 rays)'}[args.mode]
         line = {
-            'metric': 'ray-samples/sec (panoramic NeRF training step: both fields evaluated + composited, fwd+bwd+Adam)',
+            'metric': 'ray-samples/sec (panoramic NeRF ' + step_desc + ': kept samples evaluated by both fields + composited'
+                      + (', fwd+bwd+Adam' if args.mode != 'render' else '') + ') + PSNR@iter',
             'value': value, 'unit': 'ray-samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'{args.width}x{args.height} synthetic room panorama, {args.spp} samples/ray fixed-count, '
-                                   f'hash grid L16/F2/T18 + 64-wide MLPs, mode={args.mode}',
-                       'rays_per_gpu_per_step': rays_per_step, 'ray_samples_per_gpu_per_step': samples_per_step,
-                       'parallelism': f'dp{world} (rays sharded, one RCCL all-reduce of the flat gradient per step)' if world > 1 else 'single GPU',
+            'config': {'workload': f'{args.width}x{args.height} synthetic room panorama, {args.spp} marched samples/ray, '
+                                   f'hash grid L16/F2/T18 + 64-wide MLPs, mode={args.mode}, '
+                                   + ('reference step incl. sampling-pass sigma + visibility compaction (early stop 1e-4)' if r.early_stop_eps > 0
+                                      else 'fixed-count WITHOUT sampling-pass sigma / compaction (early_stop_eps = 0)'),
+                       'rays_per_gpu_per_step': rays_per_step, 'marched_samples_per_gpu_per_step': marched / args.steps / world,
+                       'kept_samples_per_gpu_per_step': kept / args.steps / world,
+                       'counted': 'kept samples (device counter, read once after the timed region); the no-grad density pass over all marched samples is extra work',
+                       'parallelism': (f'dp{world} (rays sharded, one RCCL all-reduce of the flat gradient per step), {args.scaling} scaling, '
+                                       f'global batch {tc.pixel_loss_batch_size} rays') if world > 1 else 'single GPU',
                        'per_gpu_value': value / world,
                        'launch': 'hipGraph replay of the whole step' if graphed is not None else 'eager',
                        'kernel_timing': 'HIP events around every launch in an eager re-run of the same steps right after the timed region'},
+            'sustained': sustained, 'psnr': psnr_block,
             'roofline': roof, 'cpu_baseline': cpu, 'kernels': table,
         }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _workload_key(args):
+    return f'{args.mode}:{args.rays_per_gpu}x{args.spp}:prepass={0 if args.no_prepass else 1}'
 
 
 if __name__ == '__main__':

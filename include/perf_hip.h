@@ -18,6 +18,13 @@
  *  - all work is enqueued on the given stream; no implicit device synchronisation;
  *    fixed-shape call sequences are hipGraph-capturable.
  *  - "16-bit" buffers hold bf16 (PERF_DTYPE_BF16) or IEEE fp16 (PERF_DTYPE_FP16).
+ *  - device-side counts: per-sample entry points take `n` = the CAPACITY of their arrays (also the stride of
+ *    level-major buffers) and `const int64_t* n_dev` (device memory, may be NULL): when given, only the first
+ *    min(n, *n_dev) samples are processed -- the count a preceding perf_exclusive_scan_i32 left on the device.
+ *    A batch whose sample count is only known on the GPU (occupancy marching, early termination) is thus a fixed
+ *    sequence of launches with no host read-back: hipGraph-capturable (BASELINE config 4, and the training step).
+ *  - the library is re-entrant: no mutable global state besides std::call_once-guarded kernel attribute setup and
+ *    environment switches read once at first use.
  */
 #ifndef PERF_HIP_H
 #define PERF_HIP_H
@@ -29,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 2
+#define PERF_ABI_VERSION 3
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -72,8 +79,11 @@ typedef struct perf_mlp_desc {
     float exp_shift;               /* PERF_ACT_EXP only */
 } perf_mlp_desc;
 
-int perf_version(void);
+int perf_version(void);                 /* == PERF_ABI_VERSION of the header the library was built from */
 const char* perf_last_error(void);
+/* sizeof(perf_grid_desc) / sizeof(perf_mlp_desc) as compiled: a binding checks its own struct layout against these. */
+int64_t perf_sizeof_grid_desc(void);
+int64_t perf_sizeof_mlp_desc(void);
 
 /* ---- parameters ------------------------------------------------------------------------ */
 
@@ -89,10 +99,20 @@ int perf_adam_step(float* p, float* m, float* v, float* g, void* w16, int64_t n,
                    void* stream);
 
 /* Same with the step count (int32, >= 1) and the learning rate read from DEVICE memory, so that a captured
- * hipGraph of the training step can be replayed while the schedule advances. */
+ * hipGraph of the training step can be replayed while the schedule advances.  gate_dev (device int64, may be NULL):
+ * the whole update is skipped when *gate_dev <= 0 -- the reference skips the step of a batch without samples
+ * (modules/scene/nerf.py:204-206,277-279); the caller advances *step_dev accordingly. */
 int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype,
-                       const int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float eps,
-                       int zero_grad, void* stream);
+                       const int32_t* step_dev, const float* lr_dev, const int64_t* gate_dev, float beta1, float beta2,
+                       float eps, int zero_grad, void* stream);
+
+/* Device-side bookkeeping of one sync-free training step, one tiny launch: *step_dev += 1 unless *gate_dev <= 0 (the
+ * optimizer step count only advances when the step is taken, like torch.optim.Adam behind the reference's
+ * `if not is_valid: return`, nerf.py:204-206); counters (int64 [3], may be NULL) accumulate {marched samples, kept
+ * samples, steps} so that throughput accounting never reads the device inside the timed loop.  All pointers device
+ * memory; step_dev, gate_dev, n_marched_dev, n_kept_dev may be NULL. */
+int perf_step_bookkeeping(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
+                          const int64_t* n_marched_dev, const int64_t* n_kept_dev, void* stream);
 
 /* ---- sample positions ------------------------------------------------------------------ */
 
@@ -101,7 +121,7 @@ int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_
  * aabb: 6 host floats.  x01 [n,3], sel [n] (uint8).  ray_indices int64 [n]. */
 int perf_points_from_rays(const float* rays_o, const float* rays_d, const int64_t* ray_indices,
                           const float* t_starts, const float* t_ends, const float* aabb,
-                          float* x01, uint8_t* sel, int64_t n, void* stream);
+                          float* x01, uint8_t* sel, int64_t n, const int64_t* n_dev, void* stream);
 
 /* Same normalisation for explicit points x [n,3] (NGPNeRF.query_density/query_rgb called on points). */
 int perf_points_normalize(const float* x, const float* aabb, float* x01, uint8_t* sel, int64_t n,
@@ -112,7 +132,7 @@ int perf_points_normalize(const float* x, const float* aabb, float* x01, uint8_t
 /* tcnn kernel_grid: x01 [n,3] -> features, LEVEL-MAJOR: feat[(l*n + i)*2 + f], 16-bit.
  * Replaces the encoding half of tcnn.NetworkWithInputEncoding.forward (ngp_nerf.py:142,158,258). */
 int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* table16,
-                      void* feat16, int64_t n, int dtype, void* stream);
+                      void* feat16, int64_t n, const int64_t* n_dev, int dtype, void* stream);
 
 /* Two tables of identical geometry (PeRF's density and colour grids) at the same points in one pass:
  * corner indices/weights are shared.  Same layouts as perf_hashgrid_fwd. */
@@ -132,13 +152,13 @@ int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const fl
  * per-level max |dfeat| as produced by perf_mlp_bwd): packed fixed-point accumulation with full-rate integer
  * LDS atomics, unit_l = 2^ceil(log2 absmax_l) * 2^(h_l - 31) with the headroom h_l = clamp(ceil(log2(8 n / size_l)) + 6,
  * 12, 24) (64x the average number of contributions an entry of the level sums); *overflow_flag (device int32, may be NULL) is OR-ed with 1
- * when any field comes within 2x of the int32 range (then repeat the call with level_absmax == NULL).
+ * when any field comes within 4x of the int32 range (then repeat the call with level_absmax == NULL).
  * workspace: 16-byte aligned device scratch of perf_hashgrid_bwd_workspace_bytes(grid, n) bytes (replica slabs of
  * the coarse levels + 4 bytes per (sample, hashed level) of tile codes; a workspace without room for the codes
- * is accepted and selects the slower position-streaming owners). */
+ * is accepted and selects the slower position-streaming owners).  With n_dev the headroom follows the live count. */
 int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n);
 int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
-                      float* grad_table, int64_t n, int accumulate, const float* level_absmax,
+                      float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
                       int32_t* overflow_flag, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* The integer half of the encoding: idx[(l*n + i)*8 + c] = absolute table entry (level offset included) of corner c
@@ -155,7 +175,7 @@ int perf_hashgrid_bwd_input(const perf_grid_desc* grid, const float* x01, const 
 /* tcnn kernel_mlp_fused: feat16 (level-major) -> out [n, n_out] fp32 after out_act, multiplied
  * by sel[i] when sel != NULL (ngp_nerf.py:146-149,161). */
 int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
-                 float* out, int64_t n, int dtype, void* stream);
+                 float* out, int64_t n, const int64_t* n_dev, int dtype, void* stream);
 
 /* Bytes of caller-owned workspace perf_mlp_bwd needs for n samples. */
 int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n);
@@ -169,7 +189,7 @@ int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n);
  * half-wave owns; zeroed by the call). */
 int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
                  const float* dout, float* dfeat, float* dw, float* level_absmax, void* workspace,
-                 int64_t workspace_bytes, int64_t n, int dtype, void* stream);
+                 int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, void* stream);
 
 /* ---- rays ---------------------------------------------------------------------------------- */
 
@@ -177,6 +197,10 @@ int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, 
  * pose: 16 host floats, row major 4x4.  rays_o, rays_d [nrows*W,3]. */
 int perf_pano_raygen(const float* pose, int32_t height, int32_t width, int32_t row0, int32_t nrows,
                      float* rays_o, float* rays_d, void* stream);
+/* Same with the pose (12+ floats, row major) read from DEVICE memory: a hipGraph holding a whole frame of
+ * CoreRunner.render_dense (core_exp_runner.py:223-246) is replayed with a new pose per frame. */
+int perf_pano_raygen_dev(const float* pose_dev, int32_t height, int32_t width, int32_t row0, int32_t nrows,
+                         float* rays_o, float* rays_d, void* stream);
 
 /* ---- occupancy-grid marching (nerfacc traverse_grids; nerf_renderer.py:145-155) ------------ */
 
@@ -233,11 +257,13 @@ int perf_visibility_count(const float* sigmas, const float* t_starts, const floa
                           float* exsum, void* stream);
 
 /* Copy the first new_counts[r] samples of every ray to new_offsets[r] (the boolean-mask
- * compaction of nerfacc's sampling).  sigmas_in/out may be NULL. */
+ * compaction of nerfacc's sampling).  sigmas_in/out may be NULL; so may the sample positions x01 [S,3] / sel [S]
+ * (as written by perf_occ_march_write_points), which are then compacted along instead of being recomputed. */
 int perf_compact_prefix(const int32_t* packed_info, const int32_t* new_counts, const int32_t* new_offsets,
                         int64_t n_rays, const float* ts_in, const float* te_in, const float* sig_in,
                         int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out,
-                        int32_t* packed_out, void* stream);
+                        int32_t* packed_out, const float* x01_in, const uint8_t* sel_in, float* x01_out,
+                        uint8_t* sel_out, void* stream);
 
 /* weights/trans/alphas [S] and per-ray opacity [R], distance [R], colour [R,3] (rgbs may be NULL).
  * One wave per ray: no atomics. */
@@ -268,6 +294,12 @@ int perf_composite_distloss_bwd(const float* sigmas, const float* t_starts, cons
                                 const float* opacity, const float* distance, const float* g_opacity,
                                 const float* g_distance, float distloss_scale, const float* distloss_scale_dev,
                                 float* d_sigmas, void* stream);
+
+/* Eval tail of NeRFOCCRenderer.render (nerf_renderer.py:195-197), in place: distance[r] += 5 (1 - opacity[r]),
+ * color[r,:] += 0.5 (1 - opacity[r]); nothing happens when n_dev != NULL and *n_dev <= 0 (a batch without samples
+ * returns zeros before that tail in the reference, :156-162).  distance / color may be NULL. */
+int perf_render_finish_eval(const float* opacity, float* distance, float* color, int64_t n_rays,
+                            const int64_t* n_dev, void* stream);
 
 /* nerfacc.accumulate_along_rays forward (nerf_renderer.py:173-183): out[r,c] = sum_i w_i * values[i,c]
  * (values == NULL: n_channels must be 1 and out[r] = sum_i w_i).  One wave per ray, no atomics. */

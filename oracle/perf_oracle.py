@@ -18,6 +18,21 @@ Parity status
   algorithms are restated below; the reference holds no
   test or golden vector for them.
 
+Where this restatement DEFINES a rounding order that upstream plausibly does differently
+(neither is checkable here; both would change ray_indices / t_starts against the real packages):
+* grid position: pos = fl(fl(x*scale) + 0.5), two roundings (grid_corner_indices); tiny-cuda-nn's
+  kernel_grid computes it with one fused multiply-add, fmaf(scale, x, 0.5).  A position within half an
+  ulp of a cell boundary can land in the neighbouring cell under the other rule (interpolation is
+  continuous across the boundary, so feature values differ by O(ulp); the touched-entry set differs).
+* marching lattice: t_k = fl(t0 + fl(k*step)) on ONE global lattice per ray anchored at the near plane
+  (+ stratified jitter), an interval being emitted iff its midpoint lies in an occupied cell (occ_march,
+  SURVEY.md A.3).  nerfacc's traverse_grids advances by repeated float addition and, after skipping
+  empty space, restarts its intervals at the cell entry, so its t_starts are not lattice points of a
+  single lattice once a ray has crossed an empty cell.  Sample COUNTS per occupied span agree to +-1;
+  positions differ by < step.
+* early termination: thresholded on the canonical-order exclusive sum (ex <= -ln eps) instead of on
+  T = exp(-ex) >= eps (identical decision up to the rounding of exp).
+
 Conventions
 -----------
 All bookkeeping arithmetic (lattice times, cell indices, hash indices, scans that
@@ -541,10 +556,16 @@ def prop_sampling(sigma_fns, prop_samples, num_samples, n_rays, near, far, taus=
 # --------------------------------------------------------------------------------------
 def occ_render(o, d, geo_params, app_params, binaries, aabb, training, t0=None,
                bg_color=None, dist_noise=None, near=0.0, far=1.5, step=5e-4,
-               early_stop_eps=1e-4, quant=None, geo_grad=True, app_grad=False, max_steps=None):
+               early_stop_eps=1e-4, quant=None, geo_grad=True, app_grad=False, max_steps=None,
+               kept_counts=None, return_pre=False):
     """NeRFOCCRenderer.render restated on the oracle's operators.  o,d torch [R,3].
     bg_color [R,3] and dist_noise [R,1] are the torch.rand draws of :185,:193 (caller
-    supplies them so both sides see the same numbers)."""
+    supplies them so both sides see the same numbers).
+    kept_counts (int [R], tests): keep exactly that many leading samples of every ray instead of applying the
+    early-stop threshold -- a sample whose scan value sits within rounding of the threshold is kept by one
+    implementation and dropped by the other; the test first checks (with return_pre) that every disagreement is such
+    a sample, then compares everything else on the SAME sample set.
+    return_pre: add 'pre' = the marched samples before compaction with their canonical exclusive sums."""
     gs, as_ = geo_spec(), app_spec()
     aabb_t = torch.as_tensor(aabb, dtype=torch.float32)
     R = o.shape[0]
@@ -553,16 +574,23 @@ def occ_render(o, d, geo_params, app_params, binaries, aabb, training, t0=None,
     def positions(ri_t, ts_t, te_t):
         return o[ri_t] + d[ri_t] * ((ts_t + te_t)[:, None] / 2.0)
     ri_t = torch.from_numpy(ri); ts_t = torch.from_numpy(ts); te_t = torch.from_numpy(te)
+    pre = None
     if early_stop_eps > 0 and ri.size:
         with torch.no_grad():
             sig0 = query_density(positions(ri_t, ts_t, te_t), geo_params, gs, aabb_t, quant)[:, 0]
-        keep, _ = visibility_keep_mask(sig0.numpy(), ts, te, packed, early_stop_eps)
+        keep, ex = visibility_keep_mask(sig0.numpy(), ts, te, packed, early_stop_eps)
+        if return_pre:
+            pre = {'ray_indices': ri, 't_starts': ts, 't_ends': te, 'packed_info': packed, 'exsum': ex, 'keep': keep,
+                   'threshold': F32(-math.log(early_stop_eps)), 'sigmas': sig0.numpy()}
+        if kept_counts is not None:
+            pos_in_ray = np.arange(ri.size) - packed[ri, 0]
+            keep = pos_in_ray < np.asarray(kept_counts)[ri]
         ri, ts, te = ri[keep], ts[keep], te[keep]
         packed = packed_info_from_ray_indices(ri, R)
         ri_t = torch.from_numpy(ri); ts_t = torch.from_numpy(ts); te_t = torch.from_numpy(te)
     if ri.size == 0:
         return {'is_valid': False, 'rgb': torch.zeros(R, 3), 'distance': torch.zeros(R, 1),
-                'opacities': torch.zeros(R, 1)}
+                'opacities': torch.zeros(R, 1), 'pre': pre}
     pos = positions(ri_t, ts_t, te_t)
     with torch.set_grad_enabled(geo_grad and torch.is_grad_enabled()):
         sig = query_density(pos, geo_params, gs, aabb_t, quant)[:, 0]
@@ -581,7 +609,7 @@ def occ_render(o, d, geo_params, app_params, binaries, aabb, training, t0=None,
         col = col + .5 * (1. - opac).detach()
     return {'is_valid': True, 'rgb': col, 'distance': dist, 'weights': weights, 'opacities': opac,
             'trans': trans, 't_starts': ts_t, 't_ends': te_t, 'ray_indices': ri_t,
-            'packed_info': packed, 'sigmas': sig, 'rgbs': rgbs}
+            'packed_info': packed, 'sigmas': sig, 'rgbs': rgbs, 'pre': pre}
 
 
 # --------------------------------------------------------------------------------------

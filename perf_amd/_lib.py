@@ -10,6 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libperf_hip.so')
 
+ABI_VERSION = 3          # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
 MAX_LEVELS = 24
 DTYPE_BF16, DTYPE_FP16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
@@ -36,22 +37,26 @@ LOSS_SCALARS = 256       # PERF_LOSS_SCALARS
 _SIGS = {
     'perf_version': (c_int, []),
     'perf_last_error': (c_char_p, []),
+    'perf_sizeof_grid_desc': (c_int64, []),
+    'perf_sizeof_mlp_desc': (c_int64, []),
     'perf_cast_params': (c_int, [P, P, c_int64, c_int, P]),
     'perf_adam_step': (c_int, [P, P, P, P, P, c_int64, c_int, c_int32, c_float, c_float, c_float, c_float, c_int, P]),
-    'perf_adam_step_dev': (c_int, [P, P, P, P, P, c_int64, c_int, P, P, c_float, c_float, c_float, c_int, P]),
-    'perf_points_from_rays': (c_int, [P, P, P, P, P, POINTER(c_float), P, P, c_int64, P]),
+    'perf_adam_step_dev': (c_int, [P, P, P, P, P, c_int64, c_int, P, P, P, c_float, c_float, c_float, c_int, P]),
+    'perf_step_bookkeeping': (c_int, [P, P, P, P, P, P]),
+    'perf_points_from_rays': (c_int, [P, P, P, P, P, POINTER(c_float), P, P, c_int64, P, P]),
     'perf_points_normalize': (c_int, [P, POINTER(c_float), P, P, c_int64, P]),
-    'perf_hashgrid_fwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P]),
+    'perf_hashgrid_fwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P, c_int, P]),
     'perf_hashgrid_fwd2': (c_int, [POINTER(GridDesc), P, P, P, P, P, c_int64, c_int, P]),
     'perf_hashgrid_fwd_f32': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
     'perf_hashgrid_bwd_workspace_bytes': (c_int64, [POINTER(GridDesc), c_int64]),
-    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, c_int, P, P, P, c_int64, P]),
+    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P, c_int, P, P, P, c_int64, P]),
     'perf_hashgrid_corners': (c_int, [POINTER(GridDesc), P, P, c_int64, P]),
     'perf_hashgrid_bwd_input': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),
-    'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, c_int, P]),
+    'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, P, c_int, P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
-    'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, P, P, P, P, P, c_int64, c_int64, c_int, P]),
+    'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, P, P, P, P, P, c_int64, c_int64, P, c_int, P]),
     'perf_pano_raygen': (c_int, [POINTER(c_float), c_int32, c_int32, c_int32, c_int32, P, P, P]),
+    'perf_pano_raygen_dev': (c_int, [P, c_int32, c_int32, c_int32, c_int32, P, P, P]),
     'perf_occ_pack_bits': (c_int, [P, P, c_int64, P]),
     'perf_occ_mask_words': (c_int64, [c_int32]),
     'perf_occ_march_count': (c_int, [P, P, P, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, P, P, P]),
@@ -62,9 +67,10 @@ _SIGS = {
     'perf_occ_march_write': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P]),
     'perf_occ_march_write_points': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P, P, POINTER(c_float), P, P, P]),
     'perf_visibility_count': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
-    'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P]),
+    'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'perf_composite_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     'perf_composite_bwd': (c_int, [P, P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P]),
+    'perf_render_finish_eval': (c_int, [P, P, P, c_int64, P, P]),
     'perf_accumulate_fwd': (c_int, [P, P, P, c_int64, c_int32, P, P]),
     'perf_pack_info': (c_int, [P, c_int64, c_int64, P, P]),
     'perf_distloss_fwd': (c_int, [P, P, P, P, c_int64, P, P]),
@@ -97,6 +103,12 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # the binding and the library must agree on the ABI version and on the layout of the POD descriptors
+    if lib.perf_version() != ABI_VERSION:
+        raise PerfError(f'{LIB_PATH} has ABI version {lib.perf_version()}, this binding expects {ABI_VERSION}: '
+                        'rebuild with `python -m perf_amd.build --force`')
+    if lib.perf_sizeof_grid_desc() != ctypes.sizeof(GridDesc) or lib.perf_sizeof_mlp_desc() != ctypes.sizeof(MlpDesc):
+        raise PerfError('descriptor layout mismatch between perf_amd/_lib.py and include/perf_hip.h')
     _lib = lib
     return lib
 

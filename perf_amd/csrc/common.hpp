@@ -92,6 +92,15 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 
 static inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Device-side sample counts: per-sample kernels are launched for the CAPACITY n of their arrays (which is also the
+// stride of level-major buffers) and process only the first min(n, *n_dev) samples when n_dev != NULL -- the count a
+// preceding scan left in device memory.  No host read-back, so variable-count batches are hipGraph-capturable.
+__device__ __forceinline__ int64_t live_count(int64_t n, const int64_t* __restrict__ n_dev) {
+    if (!n_dev) return n;
+    const int64_t m = *n_dev;
+    return m < n ? (m > 0 ? m : 0) : n;
+}
+
 struct Aabb { float lo[3], hi[3]; };
 
 __device__ __forceinline__ void normalize_store(float px, float py, float pz, const Aabb& bb, float* x01, uint8_t* sel,

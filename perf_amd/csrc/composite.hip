@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void compact_prefix_kernel(const int32_t* __re
                                                              const float* __restrict__ ts_in, const float* __restrict__ te_in,
                                                              const float* __restrict__ sig_in, int64_t* __restrict__ ri_out,
                                                              float* __restrict__ ts_out, float* __restrict__ te_out,
-                                                             float* __restrict__ sig_out, int32_t* __restrict__ packed_out) {
+                                                             float* __restrict__ sig_out, int32_t* __restrict__ packed_out,
+                                                             const float* __restrict__ x01_in, const uint8_t* __restrict__ sel_in,
+                                                             float* __restrict__ x01_out, uint8_t* __restrict__ sel_out) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rays) return;
@@ -78,7 +80,10 @@ __global__ __launch_bounds__(256) void compact_prefix_kernel(const int32_t* __re
         te_out[dst + i] = te_in[src + i];
         ri_out[dst + i] = r;
         if (sig_out) sig_out[dst + i] = sig_in[src + i];
+        if (sel_out) sel_out[dst + i] = sel_in[src + i];
     }
+    if (x01_out)            // positions of the kept samples: 3*cnt contiguous floats
+        for (int i = lane; i < 3 * cnt; i += 64) x01_out[3 * dst + i] = x01_in[3 * src + i];
 }
 
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ sig, const float* __restrict__ rgb,
@@ -313,13 +318,17 @@ extern "C" int perf_visibility_count(const float* sigmas, const float* t_starts,
 extern "C" int perf_compact_prefix(const int32_t* packed_info, const int32_t* new_counts, const int32_t* new_offsets,
                                    int64_t n_rays, const float* ts_in, const float* te_in, const float* sig_in,
                                    int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out,
-                                   int32_t* packed_out, void* stream) {
+                                   int32_t* packed_out, const float* x01_in, const uint8_t* sel_in, float* x01_out,
+                                   uint8_t* sel_out, void* stream) {
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && new_counts && new_offsets && packed_out, "NULL pointer");
     PERF_REQUIRE((sig_in == nullptr) == (sig_out == nullptr), "sig_in/sig_out must both be given or both be NULL");
+    PERF_REQUIRE((x01_in == nullptr) == (x01_out == nullptr) && (sel_in == nullptr) == (sel_out == nullptr),
+                 "x01/sel in and out must both be given or both be NULL");
     hipLaunchKernelGGL(compact_prefix_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), packed_info, new_counts,
-                       new_offsets, n_rays, ts_in, te_in, sig_in, ray_indices_out, ts_out, te_out, sig_out, packed_out);
+                       new_offsets, n_rays, ts_in, te_in, sig_in, ray_indices_out, ts_out, te_out, sig_out, packed_out, x01_in, sel_in,
+                       x01_out, sel_out);
     PERF_LAUNCH_CHECK("perf_compact_prefix");
     return PERF_OK;
 }
@@ -419,6 +428,36 @@ extern "C" int perf_pack_info(const int64_t* ray_indices, int64_t n, int64_t n_r
     hipLaunchKernelGGL(pack_info_kernel, dim3((unsigned)div_up(n_rays, 256)), dim3(256), 0, as_stream(stream), ray_indices, n,
                        n_rays, packed_info);
     PERF_LAUNCH_CHECK("perf_pack_info");
+    return PERF_OK;
+}
+
+// ---- eval tail of NeRFOCCRenderer.render (nerf_renderer.py:195-197): distance += 5 (1 - opacity), rgb += 0.5 (1 - opacity).
+// A batch without any sample returns before that tail in the reference (:156-162: zeros, is_valid False); with device-side
+// counts the same decision is taken here from *n_dev.
+namespace perf {
+__global__ __launch_bounds__(256) void render_finish_eval_kernel(const float* __restrict__ opacity, float* __restrict__ distance,
+                                                                 float* __restrict__ color, int64_t n_rays,
+                                                                 const int64_t* __restrict__ n_dev) {
+    if (n_dev && n_dev[0] <= 0) return;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rays) return;
+    const float rest = 1.0f - opacity[r];
+    if (distance) distance[r] = distance[r] + 5.0f * rest;
+    if (color) {
+        const float c = 0.5f * rest;
+        color[3 * r] += c; color[3 * r + 1] += c; color[3 * r + 2] += c;
+    }
+}
+}  // namespace perf
+
+extern "C" int perf_render_finish_eval(const float* opacity, float* distance, float* color, int64_t n_rays,
+                                       const int64_t* n_dev, void* stream) {
+    PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(opacity, "NULL pointer");
+    hipLaunchKernelGGL(perf::render_finish_eval_kernel, dim3((unsigned)perf::div_up(n_rays, 256)), dim3(256), 0,
+                       perf::as_stream(stream), opacity, distance, color, n_rays, n_dev);
+    PERF_LAUNCH_CHECK("perf_render_finish_eval");
     return PERF_OK;
 }
 

@@ -9,6 +9,7 @@
 // on it.  Features leave the kernel LEVEL-MAJOR (feat[l][sample] as one packed 2x16-bit
 // dword), so every store and the MLP kernel's loads are fully coalesced.
 #include <stdlib.h>
+#include <mutex>
 #include "common.hpp"
 
 namespace perf {
@@ -105,7 +106,8 @@ __device__ __forceinline__ int level_of(int group, int pass, int L) {
 template <typename T16>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const float* __restrict__ x01,
                                                            const uint32_t* __restrict__ table,
-                                                           uint32_t* __restrict__ feat, int64_t n, int xcd_affinity) {
+                                                           uint32_t* __restrict__ feat, int64_t n,
+                                                           const int64_t* __restrict__ n_dev, int xcd_affinity) {
     // xcd_affinity == 0 (experiment only): consecutive blocks of one XCD walk through all level groups, so every L2
     // sees the whole table -- used to measure what the level-group <-> XCD pinning is worth.
     const int nchunks = (int)(gridDim.x >> 3);
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const 
     const int64_t chunk = xcd_affinity ? (int64_t)(blockIdx.x >> 3)
                                        : (int64_t)(blockIdx.x & 7) * ((nchunks + 7) >> 3) + (int64_t)(blockIdx.x >> 6);
     const int64_t i = chunk * 256 + threadIdx.x;
-    if (i >= n || (!xcd_affinity && chunk >= nchunks)) return;
+    if (i >= live_count(n, n_dev) || (!xcd_affinity && chunk >= nchunks)) return;       // (n stays the level stride)
     const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
 #pragma unroll
@@ -239,7 +241,6 @@ struct TileParams {
     int32_t replicas_of[PERF_MAX_LEVELS];  // replicas per tile
     int64_t ws_off[PERF_MAX_LEVELS];       // float2 offset of the level's replica slabs in the workspace
     int32_t accumulate;
-    int32_t headroom_log2[PERF_MAX_LEVELS];// fixed-point mode: log2 of the assumed max |sum| / max |contribution| of an entry
     int64_t dbg_off;                       // >0: float2 offset in the workspace where per-block cycle counts go (dev tool)
     int32_t code_slot[PERF_MAX_LEVELS];    // >=0: the level's tile codes are codes[slot][n_pad] (see tile_codes_kernel)
     int64_t n_pad;
@@ -282,8 +283,9 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
     *n_blocks = nb; *ws_entries = ws;
     // ---- XCD-aware placement (a speed assumption only: results do not depend on it)
     tp->use_work = 0;
-    if (nb > kMaxWork || getenv("PERF_BWD_NO_XCD_AFFINITY")) return;
-    static uint32_t lists[kXcds][kMaxWork];
+    static const bool no_affinity = getenv("PERF_BWD_NO_XCD_AFFINITY") != nullptr;     // read once (thread-safe static init)
+    if (nb > kMaxWork || no_affinity) return;
+    uint32_t lists[kXcds][kMaxWork];                        // 16 KiB of stack: the planner is re-entrant
     int len[kXcds] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto least = [&]() { int x = 0; for (int i = 1; i < kXcds; ++i) if (len[i] < len[x]) x = i; return x; };
     const int per_xcd = (nb + kXcds - 1) / kXcds;
@@ -458,13 +460,15 @@ __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, con
 constexpr int kCodeSamplesPerBlock = 256;
 __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
                                                          const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
-                                                         uint32_t* __restrict__ escape, int64_t n) {
+                                                         uint32_t* __restrict__ escape, int64_t n,
+                                                         const int64_t* __restrict__ n_dev) {
+    const int64_t n_live = live_count(n, n_dev);            // n: capacity = stride of dfeat / codes; n_live: samples present
     __shared__ uint32_t esc_block;
     if (threadIdx.x == 0) esc_block = 0u;
     __syncthreads();
     uint32_t esc = 0u;                  // bit l: level l must take the generic owners (see below)
     const int64_t i0 = (int64_t)blockIdx.x * kCodeSamplesPerBlock;
-    for (int64_t i = i0 + threadIdx.x; i < n && i < i0 + kCodeSamplesPerBlock; i += 256) {
+    for (int64_t i = i0 + threadIdx.x; i < n_live && i < i0 + kCodeSamplesPerBlock; i += 256) {
         const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
         for (int l = 0; l < gp.n_levels; ++l) {
             const int slot = tp.code_slot[l];
@@ -712,7 +716,9 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    const float* __restrict__ level_absmax,
                                                                    int32_t* __restrict__ overflow_flag,
                                                                    const uint32_t* __restrict__ codes,
-                                                                   const uint32_t* __restrict__ escape, int64_t n) {
+                                                                   const uint32_t* __restrict__ escape, int64_t n,
+                                                                   const int64_t* __restrict__ n_dev) {
+    const int64_t n_live = live_count(n, n_dev);            // samples present; n stays the stride of dfeat / codes
     extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats (+ the wave queues)
     unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
     const long long t_start = (tp.dbg_off > 0) ? (long long)wall_clock64() : 0;
@@ -746,7 +752,14 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         int e = 0;
         if (am > 0.f) (void)frexpf(am, &e);                         // am < 2^e
         if (e < -80) e = -80;                                        // (vanishing gradients: keep 2^sh finite)
-        const int sh = 31 - tp.headroom_log2[l] - e;                  // units per 1.0 = 2^sh
+        // Headroom of the fixed-point fields: an entry of level l sums 8 n / size_l contributions on average (1,700 at
+        // the coarsest level of a 1 M-sample batch, 32 at a hashed one); 64x that average before the overflow flag is
+        // raised, never less than 2^12, never more than 2^24 (which still leaves 2^-7 of the largest contribution as the
+        // unit).  Derived from the LIVE sample count, so a capacity-sized launch keeps the resolution of an exact one.
+        const unsigned long long fan = (8ull * (unsigned long long)n_live + size - 1ull) / size;     // ceil(8 n / size)
+        int h = (fan <= 1ull ? 0 : 64 - __clzll((long long)(fan - 1ull))) + 6;                      // ceil(log2(fan)) + 6
+        h = h < 12 ? 12 : (h > 24 ? 24 : h);
+        const int sh = 31 - h - e;                                    // units per 1.0 = 2^sh
         cx.to_fixed = ldexpf(1.0f, sh);
         from_fixed = ldexpf(1.0f, -sh);
     }
@@ -764,10 +777,10 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         coded = esc_any == 0u;
     }
     uint32_t* queue = reinterpret_cast<uint32_t*>(lds_tile + 2 * kTileEntries) + (threadIdx.x >> 6) * kQueueCap;
-    if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n, rep, R);
-    else if (coded) bwd_stream_codes<FIXED, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n, rep, R);
-    else if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n, rep, R);
-    else bwd_stream<FIXED, false>(cx, lds_tile, x01, g_l, n, rep, R);
+    if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
+    else if (coded) bwd_stream_codes<FIXED, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
+    else if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n_live, rep, R);
+    else bwd_stream<FIXED, false>(cx, lds_tile, x01, g_l, n_live, rep, R);
     __syncthreads();
     int32_t field_max = 0;
     // ---- write back: local slot j of tile t is entry e(j)
@@ -793,7 +806,10 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         if (acc) { const float2 o = out[e]; v.x += o.x; v.y += o.y; }
         out[e] = v;
     }
-    if (FIXED && overflow_flag && field_max >= (1 << 30)) atomicOr(overflow_flag, 1);
+    // (a field that wrapped past +-2^31 reads back with an arbitrary value; the flag is global, so such a sum escapes only
+    //  if NO field of ANY tile ends in the band [2^29, 2^32 - 2^29) -- i.e. if the largest sum of the whole table exceeds
+    //  7x the level at which smaller sums already raise the flag while none of them lands there)
+    if (FIXED && overflow_flag && field_max >= (1 << 29)) atomicOr(overflow_flag, 1);
     if (tp.dbg_off > 0 && threadIdx.x == 0) {      // slot = position in plain level order
         int slot = (int)t * R + rep;
         for (int k = 0; k < l; ++k) slot += tp.tiles_of[k] * tp.replicas_of[k];
@@ -806,10 +822,10 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
 // the gradient table is zeroed by the caller first unless it accumulates.
 __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(GridParams gp, uint32_t levels, const float* __restrict__ x01,
                                                                   const float2* __restrict__ dfeat, float* __restrict__ grad,
-                                                                  int64_t n) {
+                                                                  int64_t n, const int64_t* __restrict__ n_dev) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int l = blockIdx.y;
-    if (i >= n || !((levels >> l) & 1u)) return;
+    if (i >= live_count(n, n_dev) || !((levels >> l) & 1u)) return;
     const float2 g = dfeat[(int64_t)l * n + i];
     if (g.x == 0.f && g.y == 0.f) return;
     const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
@@ -882,7 +898,7 @@ static inline unsigned grouped_grid(int64_t n) { return (unsigned)(div_up(n, 256
 using namespace perf;
 
 extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* table16,
-                                 void* feat16, int64_t n, int dtype, void* stream) {
+                                 void* feat16, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
     GridParams gp;
     int rc = fill_params(grid, &gp);
     if (rc) return rc;
@@ -892,9 +908,9 @@ extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, c
     static const int xcd_affinity = getenv("PERF_FWD_NO_XCD_AFFINITY") ? 0 : 1;
     dim3 g(xcd_affinity ? grouped_grid(n) : (unsigned)(div_up(div_up(n, 256), 8) * 64)), b(256);
     if (dtype == PERF_DTYPE_BF16)
-        hipLaunchKernelGGL(hashgrid_fwd_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, xcd_affinity);
+        hipLaunchKernelGGL(hashgrid_fwd_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, xcd_affinity);
     else if (dtype == PERF_DTYPE_FP16)
-        hipLaunchKernelGGL(hashgrid_fwd_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, xcd_affinity);
+        hipLaunchKernelGGL(hashgrid_fwd_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, xcd_affinity);
     else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
     PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
     return PERF_OK;
@@ -973,7 +989,7 @@ extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid,
 }
 
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
-                                 float* grad_table, int64_t n, int accumulate, const float* level_absmax,
+                                 float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
                                  int32_t* overflow_flag, void* workspace, int64_t workspace_bytes, void* stream) {
     GridParams gp;
     int rc = fill_params(grid, &gp);
@@ -987,30 +1003,15 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     PERF_REQUIRE(ws_entries == 0 || (workspace && workspace_bytes >= ws_entries * (int64_t)sizeof(float2)),
                  "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(ws_entries * sizeof(float2)));
     tp.accumulate = accumulate;
-    // Headroom of the fixed-point fields: an entry of level l sums 8 n / size_l contributions on average (1,700 at the
-    // coarsest level of a 1 M-sample batch, 32 at a hashed one); 64x that average before the overflow flag is raised,
-    // never less than 2^12, never more than 2^24 (which still leaves 2^-7 of the largest contribution as the unit).
-    for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
-        int h = 12;
-        if (l < gp.n_levels && n > 0) {
-            const double fan = 8.0 * (double)n / (double)gp.size[l];
-            int lg = 0;
-            while ((double)(1ll << lg) < fan && lg < 40) ++lg;        // ceil(log2(fan)), 0 for fan <= 1
-            h = lg + 6;
-            if (h < 12) h = 12;
-            if (h > 24) h = 24;
-        }
-        tp.headroom_log2[l] = h;
-    }
     tp.dbg_off = 0;
     int64_t slab_entries = ws_entries;      // workspace layout: [replica slabs (larger of both modes)][debug slots][tile codes]
     { TileParams t2; int nb2; int64_t w2; plan_tiles(gp, level_absmax == nullptr, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2; }
     const int64_t dbg_at = (slab_entries * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
-    if (getenv("PERF_BWD_DEBUG") && workspace_bytes >= dbg_at + kDbgBytes) tp.dbg_off = dbg_at / (int64_t)sizeof(float2);
+    static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
+    if (dbg_env && workspace_bytes >= dbg_at + kDbgBytes) tp.dbg_off = dbg_at / (int64_t)sizeof(float2);
     // tile codes of the hashed levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
     const int slots = plan_codes(gp, n, &tp);
     const int64_t codes_at = dbg_at + kDbgBytes;
-    const bool no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
     uint32_t* codes = nullptr;
     uint32_t* escape = nullptr;
     const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
@@ -1019,26 +1020,25 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         codes = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + codes_at);
         escape = codes + (int64_t)slots * tp.n_pad;
         tile_codes_kernel<<<dim3((unsigned)esc_words), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
-                                                                                             codes, escape, n);
+                                                                                             codes, escape, n, n_dev);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(codes)");
     } else {
         for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.code_slot[l] = -1;
     }
     const int lds_bytes = 2 * kTileEntries * (int)sizeof(float) + (kBwdThreads / 64) * kQueueCap * (int)sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;                // one-time kernel attribute setup, safe under concurrent callers
+    std::call_once(attr_once, [&]() {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hashgrid_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hashgrid_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
+    });
     if (n_blocks == 0) {
         // every level goes through the atomics fallback
     } else if (level_absmax)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
-            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, codes, escape, n);
+            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, codes, escape, n, n_dev);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
-            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, codes, escape, n);
+            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, codes, escape, n, n_dev);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (tp.atomic_levels && n > 0) {
         if (!accumulate)
@@ -1047,7 +1047,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
                     PERF_REQUIRE(hipMemsetAsync(grad_table + 2 * gp.offset[l], 0, (size_t)gp.size[l] * 2 * sizeof(float), as_stream(stream)) == hipSuccess,
                                  "perf_hashgrid_bwd: memset failed");
         hashgrid_bwd_atomic_kernel<<<dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
-            gp, tp.atomic_levels, x01, (const float2*)dfeat, grad_table, n);
+            gp, tp.atomic_levels, x01, (const float2*)dfeat, grad_table, n, n_dev);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(atomics)");
     } else if (tp.atomic_levels && !accumulate) {
         for (int l = 0; l < gp.n_levels; ++l)

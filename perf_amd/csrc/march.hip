@@ -18,6 +18,7 @@ struct MarchParams {
     float far_plane, step;
     int32_t res, max_steps, mask_words;
     int32_t use_coarse;      // 1: skip 64-interval chunks whose midpoint lies in an empty DILATED 8^3 block
+    float chunk_cells[3];    // fine cells a 64-interval chunk spans per unit of |d| along each axis (64 step res / extent)
 };
 
 // Coarse skip grid: bit b of `coarse` is set iff any fine cell in the 3x3x3 neighbourhood of 8^3-block b is occupied.
@@ -71,6 +72,12 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         tmax = (a == 0) ? h : fminf(tmax, h);
     }
     const float lo = fmaxf(tmin, t0), hi = fminf(tmax, mp.far_plane);
+    // the coarse skip is only valid while a chunk spans few enough fine cells (see coarse_build_kernel): checked per ray
+    // with its own direction, so unnormalised directions fall back to the exhaustive test instead of skipping cells
+    float span_cells = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) span_cells = fmaxf(span_cells, fabsf(d[a]) * mp.chunk_cells[a]);
+    const bool use_coarse = mp.use_coarse && (span_cells * 0.5f + 1.5f <= 8.0f);
     int32_t count = 0;
     const int res = mp.res;
     const float rf = (float)res;
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         if (q < mp.mask_words) {
             const int k0 = q * 64;
             maybe = !(lattice(t0, k0, mp.step) > hi) && !(lattice(t0, k0 + 64, mp.step) < lo);
-            if (maybe && mp.use_coarse) {
+            if (maybe && use_coarse) {
                 const float tc = lattice(t0, k0 + 32, mp.step);
                 const int cr = res >> 3;
                 int cb[3];
@@ -322,10 +329,8 @@ extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, co
     }
     mp.far_plane = far_plane; mp.step = step; mp.res = res; mp.max_steps = max_steps;
     mp.mask_words = chunk_words(max_steps);
-    // the coarse skip is only valid while a 64-interval chunk spans few enough fine cells (see coarse_build_kernel)
-    float span_cells = 0.f;
-    for (int a = 0; a < 3; ++a) span_cells = fmaxf(span_cells, 64.0f * step * mp.inv_ext[a] * (float)res);
-    mp.use_coarse = (occ_coarse != nullptr && (res % 8) == 0 && span_cells * 0.5f + 1.5f <= 8.0f) ? 1 : 0;
+    for (int a = 0; a < 3; ++a) mp.chunk_cells[a] = 64.0f * step * mp.inv_ext[a] * (float)res;
+    mp.use_coarse = (occ_coarse != nullptr && (res % 8) == 0) ? 1 : 0;      // (+ the per-ray span test in the kernel)
     hipLaunchKernelGGL(march_count_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
                        rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts);
     PERF_LAUNCH_CHECK("perf_occ_march_count");

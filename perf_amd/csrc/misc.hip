@@ -35,8 +35,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float* __restrict__ g, uint16_t* __restrict__ w16, int64_t n,
                                                    float one_minus_b1, float b2, float one_minus_b2, float step_size,
                                                    float inv_bc2_sqrt, float eps, int zero_grad,
-                                                   const int32_t* __restrict__ step_dev, const float* __restrict__ lr_dev) {
+                                                   const int32_t* __restrict__ step_dev, const float* __restrict__ lr_dev,
+                                                   const int64_t* __restrict__ gate_dev) {
     __shared__ float sc[2];
+    if (gate_dev && gate_dev[0] <= 0) return;       // batch without samples: the reference skips the step (nerf.py:204-206)
     if (step_dev) {       // step count and learning rate live on the device (hipGraph replay): derive the scalars here
         if (threadIdx.x == 0) {
             const float t = (float)step_dev[0];
@@ -64,9 +66,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 __global__ __launch_bounds__(256) void points_from_rays_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                                                const int64_t* __restrict__ ri, const float* __restrict__ ts,
                                                                const float* __restrict__ te, Aabb bb, float* __restrict__ x01,
-                                                               uint8_t* __restrict__ sel, int64_t n) {
+                                                               uint8_t* __restrict__ sel, int64_t n,
+                                                               const int64_t* __restrict__ n_dev) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= live_count(n, n_dev)) return;
     const int64_t r = ri[i];
     sample_point_store(o + 3 * r, d + 3 * r, ts[i], te[i], bb, x01, sel, i);
 }
@@ -89,7 +92,12 @@ __device__ __forceinline__ float linspace_at(float start, float end, float step,
     return (idx < n / 2) ? start + step * (float)idx : end - step * (float)(n - 1 - idx);
 }
 
-__global__ __launch_bounds__(256) void pano_raygen_kernel(RayGen rg, float* __restrict__ ro, float* __restrict__ rd) {
+__global__ __launch_bounds__(256) void pano_raygen_kernel(RayGen rg, const float* __restrict__ pose_dev, float* __restrict__ ro,
+                                                          float* __restrict__ rd) {
+    if (pose_dev) {                 // pose read from device memory (a captured hipGraph is replayed with new poses)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) rg.pose[k] = pose_dev[k];
+    }
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)rg.nrows * rg.width;
     if (t >= total) return;
@@ -156,6 +164,8 @@ __global__ __launch_bounds__(256) void occ_splat_kernel(const float* __restrict_
 using namespace perf;
 
 extern "C" int perf_version(void) { return PERF_ABI_VERSION; }
+extern "C" int64_t perf_sizeof_grid_desc(void) { return (int64_t)sizeof(perf_grid_desc); }
+extern "C" int64_t perf_sizeof_mlp_desc(void) { return (int64_t)sizeof(perf_mlp_desc); }
 extern "C" const char* perf_last_error(void) { return g_err; }
 
 extern "C" int perf_cast_params(const float* src, void* dst16, int64_t n, int dtype, void* stream) {
@@ -174,24 +184,24 @@ extern "C" int perf_cast_params(const float* src, void* dst16, int64_t n, int dt
 
 static int adam_launch(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype, int32_t step,
                        float lr, float beta1, float beta2, float eps, int zero_grad, const int32_t* step_dev,
-                       const float* lr_dev, void* stream);
+                       const float* lr_dev, const int64_t* gate_dev, void* stream);
 
 extern "C" int perf_adam_step(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype, int32_t step,
                               float lr, float beta1, float beta2, float eps, int zero_grad, void* stream) {
     PERF_REQUIRE(step >= 1, "perf_adam_step: step < 1");
-    return adam_launch(p, m, v, g, w16, n, dtype, step, lr, beta1, beta2, eps, zero_grad, nullptr, nullptr, stream);
+    return adam_launch(p, m, v, g, w16, n, dtype, step, lr, beta1, beta2, eps, zero_grad, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype,
-                                  const int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float eps,
-                                  int zero_grad, void* stream) {
+                                  const int32_t* step_dev, const float* lr_dev, const int64_t* gate_dev, float beta1,
+                                  float beta2, float eps, int zero_grad, void* stream) {
     PERF_REQUIRE(step_dev && lr_dev, "perf_adam_step_dev: NULL scalar pointers");
-    return adam_launch(p, m, v, g, w16, n, dtype, 1, 0.f, beta1, beta2, eps, zero_grad, step_dev, lr_dev, stream);
+    return adam_launch(p, m, v, g, w16, n, dtype, 1, 0.f, beta1, beta2, eps, zero_grad, step_dev, lr_dev, gate_dev, stream);
 }
 
 static int adam_launch(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype, int32_t step,
                        float lr, float beta1, float beta2, float eps, int zero_grad, const int32_t* step_dev,
-                       const float* lr_dev, void* stream) {
+                       const float* lr_dev, const int64_t* gate_dev, void* stream) {
     PERF_REQUIRE(n >= 0, "perf_adam_step: n < 0");
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(p && m && v && g, "NULL pointer");
@@ -201,9 +211,9 @@ static int adam_launch(float* p, float* m, float* v, float* g, void* w16, int64_
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     dim3 gr((unsigned)div_up(n, 256)), b(256);
     const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
-    if (!w16) hipLaunchKernelGGL((adam_kernel<BF16, false>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev);
-    else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam_kernel<BF16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev);
-    else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam_kernel<FP16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev);
+    if (!w16) hipLaunchKernelGGL((adam_kernel<BF16, false>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
+    else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam_kernel<BF16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
+    else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam_kernel<FP16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
     else { set_error("perf_adam_step: bad dtype %d", dtype); return PERF_E_INVALID; }
     PERF_LAUNCH_CHECK("perf_adam_step");
     return PERF_OK;
@@ -217,12 +227,12 @@ static Aabb make_aabb(const float* a) {
 
 extern "C" int perf_points_from_rays(const float* rays_o, const float* rays_d, const int64_t* ray_indices,
                                      const float* t_starts, const float* t_ends, const float* aabb, float* x01,
-                                     uint8_t* sel, int64_t n, void* stream) {
+                                     uint8_t* sel, int64_t n, const int64_t* n_dev, void* stream) {
     PERF_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(rays_o && rays_d && ray_indices && t_starts && t_ends && aabb && x01, "NULL pointer");
     hipLaunchKernelGGL(points_from_rays_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, as_stream(stream), rays_o,
-                       rays_d, ray_indices, t_starts, t_ends, make_aabb(aabb), x01, sel, n);
+                       rays_d, ray_indices, t_starts, t_ends, make_aabb(aabb), x01, sel, n, n_dev);
     PERF_LAUNCH_CHECK("perf_points_from_rays");
     return PERF_OK;
 }
@@ -237,21 +247,57 @@ extern "C" int perf_points_normalize(const float* x, const float* aabb, float* x
     return PERF_OK;
 }
 
+static int raygen_launch(const float* pose, const float* pose_dev, int32_t height, int32_t width, int32_t row0, int32_t nrows,
+                         float* rays_o, float* rays_d, void* stream);
+
 extern "C" int perf_pano_raygen(const float* pose, int32_t height, int32_t width, int32_t row0, int32_t nrows,
                                 float* rays_o, float* rays_d, void* stream) {
-    PERF_REQUIRE(pose && rays_o && rays_d, "NULL pointer");
+    PERF_REQUIRE(pose, "NULL pointer");
+    return raygen_launch(pose, nullptr, height, width, row0, nrows, rays_o, rays_d, stream);
+}
+
+extern "C" int perf_pano_raygen_dev(const float* pose_dev, int32_t height, int32_t width, int32_t row0, int32_t nrows,
+                                    float* rays_o, float* rays_d, void* stream) {
+    PERF_REQUIRE(pose_dev, "NULL pointer");
+    return raygen_launch(nullptr, pose_dev, height, width, row0, nrows, rays_o, rays_d, stream);
+}
+
+static int raygen_launch(const float* pose, const float* pose_dev, int32_t height, int32_t width, int32_t row0, int32_t nrows,
+                         float* rays_o, float* rays_d, void* stream) {
+    PERF_REQUIRE(rays_o && rays_d, "NULL pointer");
     PERF_REQUIRE(height >= 2 && width >= 2 && row0 >= 0 && nrows >= 0 && row0 + nrows <= height, "bad panorama shape");
     if (nrows == 0) return PERF_OK;
     RayGen rg;
-    for (int i = 0; i < 16; ++i) rg.pose[i] = pose[i];
+    for (int i = 0; i < 16; ++i) rg.pose[i] = pose ? pose[i] : 0.f;
     rg.i_start = (float)(.5 / height); rg.i_end = (float)(1. - .5 / height);
     rg.j_start = (float)(.5 / width); rg.j_end = (float)(1. - .5 / width);
     rg.i_step = (rg.i_end - rg.i_start) / (float)(height - 1);
     rg.j_step = (rg.j_end - rg.j_start) / (float)(width - 1);
     rg.height = height; rg.width = width; rg.row0 = row0; rg.nrows = nrows;
     const int64_t total = (int64_t)nrows * width;
-    hipLaunchKernelGGL(pano_raygen_kernel, dim3((unsigned)div_up(total, 256)), dim3(256), 0, as_stream(stream), rg, rays_o, rays_d);
+    hipLaunchKernelGGL(pano_raygen_kernel, dim3((unsigned)div_up(total, 256)), dim3(256), 0, as_stream(stream), rg, pose_dev, rays_o, rays_d);
     PERF_LAUNCH_CHECK("perf_pano_raygen");
+    return PERF_OK;
+}
+
+// one thread: the bookkeeping of a sync-free training step (see perf_step_bookkeeping in the header)
+namespace perf {
+__global__ void step_bookkeeping_kernel(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
+                                        const int64_t* n_marched_dev, const int64_t* n_kept_dev) {
+    if (step_dev && (!gate_dev || gate_dev[0] > 0)) step_dev[0] += 1;
+    if (counters) {
+        if (n_marched_dev) counters[0] += n_marched_dev[0];
+        if (n_kept_dev) counters[1] += n_kept_dev[0];
+        counters[2] += 1;
+    }
+}
+}  // namespace perf
+
+extern "C" int perf_step_bookkeeping(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
+                                     const int64_t* n_marched_dev, const int64_t* n_kept_dev, void* stream) {
+    hipLaunchKernelGGL(perf::step_bookkeeping_kernel, dim3(1), dim3(1), 0, as_stream(stream), step_dev, gate_dev, counters,
+                       n_marched_dev, n_kept_dev);
+    PERF_LAUNCH_CHECK("perf_step_bookkeeping");
     return PERF_OK;
 }
 

@@ -15,6 +15,7 @@
 // Backward recomputes the forward in registers (only feat is kept from the forward pass), chains
 // dH = W^T dY the same way with transposed weight fragments, and forms the weight gradients
 // dW = dH * H^T (contraction over the 32 samples) through a wave-private LDS transpose.
+#include <mutex>
 #include "common.hpp"
 
 namespace perf {
@@ -142,18 +143,19 @@ template <typename T16, int NH, int KS>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
                                                       const uint32_t* __restrict__ feat,
                                                       const uint8_t* __restrict__ sel, float* __restrict__ out,
-                                                      int64_t n) {
+                                                      int64_t n, const int64_t* __restrict__ n_dev) {
     using L = Layout<NH, KS>;
+    const int64_t n_live = live_count(n, n_dev);        // n stays the stride of the level-major features
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* frag = reinterpret_cast<u32x4*>(smem);
     stage_fragments<NH, KS, false>(w, frag);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int64_t n_tiles = (n + kTile - 1) / kTile;
+    const int64_t n_tiles = (n_live + kTile - 1) / kTile;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t si = tile * kTile + c;
-        const bool valid = si < n;
+        const bool valid = si < n_live;
         u32x4 b1[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s)
@@ -246,8 +248,9 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams
                                                       const uint8_t* __restrict__ sel,
                                                       const float* __restrict__ dout, float2* __restrict__ dfeat,
                                                       float* __restrict__ partials, float* __restrict__ level_absmax,
-                                                      int64_t n) {
+                                                      int64_t n, const int64_t* __restrict__ n_dev) {
     using L = Layout<NH, KS>;
+    const int64_t n_live = live_count(n, n_dev);        // n stays the stride of feat / dfeat
     float amax = 0.f;      // running max |dfeat| over the 8 levels this half-wave owns (one register, not eight)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* frag = reinterpret_cast<u32x4*>(smem);
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams
     stage_fragments<NH, KS, true>(w, frag);
     __syncthreads();
     const int c = lane & 31, h = lane >> 5;
-    const int64_t n_tiles = (n + kTile - 1) / kTile;
+    const int64_t n_tiles = (n_live + kTile - 1) / kTile;
 
     f32x16 gW1[2], gWo[2], gW2[NH == 2 ? 4 : 1];
 #pragma unroll
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams
 
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t si = tile * kTile + c;
-        const bool valid = si < n;
+        const bool valid = si < n_live;
         // ---- recompute forward
         u32x4 b1[KS];
 #pragma unroll
@@ -557,22 +560,21 @@ using namespace perf;
 
 template <typename T16, int NH, int KS>
 static void launch_fwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t* w, const uint32_t* feat, const uint8_t* sel,
-                       float* out, int64_t n) {
+                       float* out, int64_t n, const int64_t* n_dev) {
     constexpr int lds_bytes = Layout<NH, KS>::n_fwd * 1024;
-    mlp_fwd_kernel<T16, NH, KS><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, out, n);
+    mlp_fwd_kernel<T16, NH, KS><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, out, n, n_dev);
 }
 
 template <typename T16, int NH, int KS>
 static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t* w, const uint32_t* feat, const uint8_t* sel,
-                       const float* dout, float2* dfeat, float* partials, float* level_absmax, int64_t n) {
+                       const float* dout, float2* dfeat, float* partials, float* level_absmax, int64_t n, const int64_t* n_dev) {
     constexpr int lds_bytes = Layout<NH, KS>::n_all * 1024 + 4 * 2 * 64 * kPitch * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;            // (one flag per template instance) safe under concurrent callers
+    std::call_once(attr_once, []() {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<T16, NH, KS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
-    mlp_bwd_kernel<T16, NH, KS><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, level_absmax, n);
+    });
+    mlp_bwd_kernel<T16, NH, KS><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, level_absmax, n, n_dev);
 }
 
 template <typename T16, typename... Args>
@@ -594,7 +596,7 @@ static void dispatch_bwd(int nh, int ks, Args... a) {
 }
 
 extern "C" int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
-                            float* out, int64_t n, int dtype, void* stream) {
+                            float* out, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
     int nh, ks;
     int rc = check_mlp(mlp, &nh, &ks);
     if (rc) return rc;
@@ -604,9 +606,9 @@ extern "C" int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const voi
     MlpParams mp{mlp->n_levels, mlp->n_out, mlp->out_act, mlp->exp_shift};
     const int blocks = mlp_blocks(n, nh == 1 ? 4 : 3);          // = the waves per SIMD the kernels' registers allow: fragments are staged once per block
     if (dtype == PERF_DTYPE_BF16)
-        dispatch_fwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, out, n);
+        dispatch_fwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, out, n, n_dev);
     else
-        dispatch_fwd<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, out, n);
+        dispatch_fwd<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, out, n, n_dev);
     PERF_LAUNCH_CHECK("perf_mlp_fwd");
     return PERF_OK;
 }
@@ -620,7 +622,7 @@ extern "C" int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_
 
 extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
                             const float* dout, float* dfeat, float* dw, float* level_absmax, void* workspace,
-                            int64_t workspace_bytes, int64_t n, int dtype, void* stream) {
+                            int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
     int nh, ks;
     int rc = check_mlp(mlp, &nh, &ks);
     if (rc) return rc;
@@ -642,10 +644,10 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
     float* amax_slots = level_absmax ? (float*)workspace + (int64_t)blocks * np : nullptr;
     if (dtype == PERF_DTYPE_BF16)
         dispatch_bwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,
-                           (float2*)dfeat, (float*)workspace, amax_slots, n);
+                           (float2*)dfeat, (float*)workspace, amax_slots, n, n_dev);
     else
         dispatch_bwd<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,
-                           (float2*)dfeat, (float*)workspace, amax_slots, n);
+                           (float2*)dfeat, (float*)workspace, amax_slots, n, n_dev);
     PERF_LAUNCH_CHECK("perf_mlp_bwd");
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)div_up(np, 16) + 1), dim3(256), 0, as_stream(stream),
                        (const float*)workspace, dw, np, blocks, (const float*)amax_slots, level_absmax, (int)mlp->n_levels);

@@ -41,20 +41,17 @@ class _TruncExp(torch.autograd.Function):
 trunc_exp = _TruncExp.apply
 
 
-def contract_to_unisphere(x, aabb, eps: float = 1e-6, derivative: bool = False):
-    """ngp_nerf.py:43-65."""
-    aabb_min, aabb_max = torch.split(aabb, 3, dim=-1)
-    x = (x - aabb_min) / (aabb_max - aabb_min)
-    x = x * 2 - 1
-    mag = x.norm(dim=-1, keepdim=True)
-    mask = mag.squeeze(-1) > 1
-    if derivative:
-        dev = (2 * mag - 1) / mag ** 2 + 2 * x ** 2 * (1 / mag ** 3 - (2 * mag - 1) / mag ** 4)
-        dev[~mask] = 1.0
-        return torch.clamp(dev, min=eps)
-    x = x.clone()
-    x[mask] = (2 - 1 / mag[mask]) * (x[mask] / mag[mask])
-    return x / 4 + 0.5
+def contract_to_unisphere(x, aabb, eps: float = 1e-6):
+    """Scene contraction of mip-NeRF 360 as used by ngp_nerf.py:43-65 for `unbounded=True` (never enabled by PeRF):
+    points of the box map to the inner half of the unit ball, everything beyond to the shell between radius 1 and 2;
+    the result is rescaled to [0, 1]^3.  (The reference's `derivative=True` branch has no caller and is not mirrored.)"""
+    lo, hi = aabb[..., :3], aabb[..., 3:]
+    u = (x - lo) / (hi - lo) * 2.0 - 1.0                      # box -> [-1, 1]^3
+    r = torch.linalg.vector_norm(u, dim=-1, keepdim=True)
+    outside = r > 1.0
+    r_safe = torch.where(outside, r, torch.ones_like(r))
+    u = torch.where(outside, (2.0 - 1.0 / r_safe) * (u / r_safe), u)
+    return u * 0.25 + 0.5
 
 
 class _DensityNet(tcnn.NetworkWithInputEncoding):
@@ -103,11 +100,11 @@ class NGPNeRF(nn.Module):
     def sample_points(self, rays_o, rays_d, ray_indices, t_starts, t_ends):
         return ops.points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, self._aabb_host)
 
-    def density_at(self, x01, sel):
-        return _FieldFn.apply(x01, self.geo_mlp.params, sel, self.geo_mlp)[:, 0]
+    def density_at(self, x01, sel, n_dev=None):
+        return _FieldFn.apply(x01, self.geo_mlp.params, sel, self.geo_mlp, n_dev)[:, 0]
 
-    def rgb_at(self, x01, sel):
-        return _FieldFn.apply(x01, self.app_mlp.params, sel, self.app_mlp)
+    def rgb_at(self, x01, sel, n_dev=None):
+        return _FieldFn.apply(x01, self.app_mlp.params, sel, self.app_mlp, n_dev)
 
     def density_rgb_at(self, x01, sel, geo_grad=True, app_grad=False):
         """sigma [n] and rgb [n,3] at the same points with ONE shared encode pass (both grids have the same geometry).

@@ -98,6 +98,15 @@ def render_transmittance_from_alpha(*args, **kwargs):
     raise NotImplementedError('imported but never called by PeRF (nerf_renderer.py:5)')
 
 
+class Samples:
+    """Packed samples of one ray batch (see OccGridEstimator.sampling_ex)."""
+    __slots__ = ('ray_indices', 't_starts', 't_ends', 'packed', 'sig', 'x01', 'sel', 'n_dev', 'n_marched_dev')
+
+    def __init__(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+
+
 class OccGridEstimator(nn.Module):
     """nerfacc.estimators.occ_grid.OccGridEstimator for levels == 1 (PeRF: nerf.py:68,144)."""
 
@@ -150,19 +159,24 @@ class OccGridEstimator(nn.Module):
     def sampling(self, rays_o, rays_d, sigma_fn=None, alpha_fn=None, near_plane=0.0, far_plane=1e10, t_min=None,
                  t_max=None, render_step_size=1e-3, early_stop_eps=1e-4, alpha_thre=0.0, stratified=False,
                  cone_angle=0.0):
-        ri, ts, te, _, _ = self.sampling_ex(rays_o, rays_d, sigma_fn, near_plane, far_plane, render_step_size,
-                                            early_stop_eps, alpha_thre, stratified, cone_angle, alpha_fn, t_min, t_max)
-        return ri, ts, te
+        sm = self.sampling_ex(rays_o, rays_d, sigma_fn, near_plane, far_plane, render_step_size,
+                              early_stop_eps, alpha_thre, stratified, cone_angle, alpha_fn, t_min, t_max)
+        return sm.ray_indices, sm.t_starts, sm.t_ends
 
     @torch.no_grad()
     def sampling_ex(self, rays_o, rays_d, sigma_fn=None, near_plane=0.0, far_plane=1e10, render_step_size=1e-3,
                     early_stop_eps=1e-4, alpha_thre=0.0, stratified=False, cone_angle=0.0, alpha_fn=None,
-                    t_min=None, t_max=None, jitter=None, max_steps=None, capacity=None, points_aabb=None):
-        """sampling() that also returns (packed_info, sigmas of the kept samples or None).
+                    t_min=None, t_max=None, jitter=None, max_steps=None, capacity=None, points_aabb=None,
+                    sigma_points_fn=None):
+        """sampling() returning a Samples record: ray_indices, t_starts, t_ends, packed (packed_info), sig (sigmas of the
+        kept samples from the visibility pass, or None), x01 / sel (sample positions normalised to points_aabb, or None),
+        n_dev (device int64 [1]: number of live samples when the arrays are capacity-sized, else None), n_marched_dev.
         max_steps caps the number of lattice intervals per ray (fixed-count benchmark mode).
-        points_aabb: when no visibility compaction follows the march (capacity mode, or early_stop_eps == 0), the sample
-        positions normalised to that box are produced by the marching kernel itself and left in ray_indices._perf_points
-        = (x01, sel)."""
+        capacity: sync-free mode (hipGraph-capturable): every array has `capacity` rows, the sample counts stay on the
+          device (n_dev) and no host read-back happens; a batch that marches more than `capacity` samples is truncated ray
+          by ray (n_marched_dev > capacity tells).  Needs points_aabb and, for the visibility pass, sigma_points_fn(x01, sel,
+          n_dev) -> sigmas [capacity].
+        points_aabb: the sample positions normalised to that box are produced by the marching kernel itself."""
         if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
             raise NotImplementedError('PeRF samples with cone_angle=0 and a sigma_fn (nerf_renderer.py:145-155)')
         if alpha_thre != 0.0:
@@ -170,43 +184,70 @@ class OccGridEstimator(nn.Module):
         R = rays_o.shape[0]
         dev = rays_o.device
         rays_o = rays_o.contiguous().float(); rays_d = rays_d.contiguous().float()
+        aabb = self._aabb_host
+        span = min(float(far_plane) - float(near_plane), self._diag)
+        anchor = None
+        if float(far_plane) - float(near_plane) > self._diag:
+            # nerfacc starts a ray's march where it enters the box; with a lattice that is shorter than [near, far] the
+            # origin must be anchored there too, or rays that start outside the box lose their samples.  (PeRF's
+            # far - near = 1.5 < diagonal with cameras inside the box never takes this branch.)
+            lo = torch.tensor(aabb[:3], device=dev); hi = torch.tensor(aabb[3:], device=dev)
+            inv = 1.0 / rays_d
+            t1 = (lo - rays_o) * inv; t2 = (hi - rays_o) * inv
+            t_in = torch.fmin(t1, t2).nan_to_num(nan=-float('inf')).amax(-1)
+            anchor = torch.clamp(t_in, min=float(near_plane)).nan_to_num(posinf=float(near_plane))
         if stratified:
             u = torch.rand(R, device=dev) if jitter is None else jitter
             t0 = u * render_step_size                       # near + u * step, without the fill and the add when near == 0
-            if float(near_plane) != 0.0:
+            if anchor is not None:
+                t0 = t0 + anchor
+            elif float(near_plane) != 0.0:
                 t0 = t0 + float(near_plane)
         else:
-            t0 = torch.full((R,), float(near_plane), dtype=torch.float32, device=dev)
-        aabb = self._aabb_host
-        span = min(float(far_plane) - float(near_plane), self._diag)
+            t0 = anchor if anchor is not None else torch.full((R,), float(near_plane), dtype=torch.float32, device=dev)
         if max_steps is None:
             max_steps = int(math.ceil(span / render_step_size)) + 1
         res = self._res
+        compacts = (sigma_fn is not None or sigma_points_fn is not None) and early_stop_eps > 0
+        sm = Samples()
         if capacity is not None:
-            # sync-free fixed-shape mode (hipGraph capture): the caller guarantees exactly `capacity` samples
+            if compacts and (sigma_points_fn is None or points_aabb is None):
+                raise ValueError('sync-free sampling with a visibility pass needs points_aabb and sigma_points_fn')
             out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size),
                                 max_steps, capacity=capacity, occ_coarse=self.occ_coarse(), points_aabb=points_aabb)
+            ri, ts, te, packed, total = out[:5]
+            x01, sel = out[5:] if points_aabb is not None else (None, None)
+            sm.n_marched_dev = total
+            sig = None
+            if compacts:
+                sig = sigma_points_fn(x01, sel, total).reshape(-1).float().contiguous()
+                new_counts = ops.visibility_count(sig, ts, te, packed, early_stop_eps)
+                ri, ts, te, sig, packed, total, x01, sel = ops.compact_prefix(packed, new_counts, ts, te, sig,
+                                                                              capacity=capacity, x01=x01, sel=sel)
+            sm.n_dev = total
+        else:
+            out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size), max_steps,
+                                occ_coarse=self.occ_coarse(), points_aabb=None if compacts else points_aabb)
             ri, ts, te, packed = out[:4]
-            ri._perf_packed = packed
-            ri._perf_points = out[5:] if points_aabb is not None else None
-            return ri, ts, te, packed, None
-        compacts = sigma_fn is not None and early_stop_eps > 0
-        out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size), max_steps,
-                            occ_coarse=self.occ_coarse(), points_aabb=None if compacts else points_aabb)
-        ri, ts, te, packed = out[:4]
-        ri._perf_points = out[4:] if (points_aabb is not None and not compacts) else None
-        sig = None
-        if sigma_fn is not None and early_stop_eps > 0 and ri.numel() > 0:
-            ri._perf_packed = packed
-            sig = sigma_fn(ts, te, ri)
-            if sig.dim() > 1:
-                sig = sig.squeeze(-1)
-            sig = sig.float().contiguous()
-            new_counts = ops.visibility_count(sig, ts, te, packed, early_stop_eps)
-            ri, ts, te, sig, packed = ops.compact_prefix(packed, new_counts, ts, te, sig)
-            ri._perf_points = None
+            x01, sel = out[4:] if (points_aabb is not None and not compacts) else (None, None)
+            sig = None
+            if compacts and ri.numel() > 0:
+                ri._perf_packed = packed
+                if sigma_points_fn is not None and points_aabb is not None:
+                    x01, sel = ops.points_from_rays(rays_o, rays_d, ri, ts, te, points_aabb)
+                    sig = sigma_points_fn(x01, sel, None)
+                else:
+                    sig = sigma_fn(ts, te, ri)
+                    x01 = sel = None
+                sig = sig.reshape(-1).float().contiguous()
+                new_counts = ops.visibility_count(sig, ts, te, packed, early_stop_eps)
+                if x01 is not None:
+                    ri, ts, te, sig, packed, x01, sel = ops.compact_prefix(packed, new_counts, ts, te, sig, x01=x01, sel=sel)
+                else:
+                    ri, ts, te, sig, packed = ops.compact_prefix(packed, new_counts, ts, te, sig)
         ri._perf_packed = packed
-        return ri, ts, te, packed, sig
+        sm.ray_indices, sm.t_starts, sm.t_ends, sm.packed, sm.sig, sm.x01, sm.sel = ri, ts, te, packed, sig, x01, sel
+        return sm
 
     @torch.no_grad()
     def update_every_n_steps(self, step, occ_eval_fn, occ_thre=1e-2, ema_decay=0.95, warmup_steps=256, n=16):

@@ -68,6 +68,15 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _nd(n_dev):
+    """Device-side sample count (int64 tensor with one element, e.g. the `total` of exclusive_scan_i32) or None."""
+    if n_dev is None:
+        return None
+    if n_dev.dtype != torch.int64 or not n_dev.is_cuda:
+        raise _lib.PerfError('n_dev must be an int64 CUDA tensor')
+    return ctypes.c_void_p(n_dev.data_ptr())
+
+
 def _f32(t, name):
     if t.dtype != torch.float32:
         raise _lib.PerfError(f'{name} must be float32, got {t.dtype}')
@@ -98,21 +107,31 @@ def adam_step(p, m, v, g, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, w16=None, 
               _stream())
 
 
-def adam_step_dev(p, m, v, g, step_dev, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8, w16=None, zero_grad=False):
+def adam_step_dev(p, m, v, g, step_dev, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8, w16=None, zero_grad=False, gate=None):
+    """gate: device int64 [1]; the update is skipped when it holds 0 (a batch without samples)."""
     code = dtype_code(w16.dtype) if w16 is not None else 0
     _call('perf_adam_step_dev', _p(_f32(p, 'p')), _p(_f32(m, 'm')), _p(_f32(v, 'v')), _p(_f32(g, 'g')), _p(w16),
-          p.numel(), code, _p(step_dev), _p(lr_dev), float(beta1), float(beta2), float(eps), int(bool(zero_grad)), _stream())
+          p.numel(), code, _p(step_dev), _p(lr_dev), _nd(gate), float(beta1), float(beta2), float(eps), int(bool(zero_grad)),
+          _stream())
+
+
+def step_bookkeeping(step_dev=None, gate=None, counters=None, n_marched=None, n_kept=None):
+    """One launch: step_dev += (gate > 0 or gate is None); counters[0:3] += (n_marched, n_kept, 1).  All device tensors."""
+    ref = next(t for t in (step_dev, counters) if t is not None)
+    if not ref.is_cuda:
+        raise _lib.PerfError('perf_amd ops need CUDA (HIP) tensors; there is no CPU path')
+    _call('perf_step_bookkeeping', _p(step_dev), _nd(gate), _nd(counters), _nd(n_marched), _nd(n_kept), _stream())
 
 
 # ---- positions -----------------------------------------------------------------------------------
-def points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, aabb):
+def points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, aabb, n_dev=None):
     n = ray_indices.numel()
     if ray_indices.dtype != torch.int64:
         raise _lib.PerfError('ray_indices must be int64')
     x01 = torch.empty(n, 3, dtype=torch.float32, device=rays_o.device)
     sel = torch.empty(n, dtype=torch.uint8, device=rays_o.device)
     _call('perf_points_from_rays', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(ray_indices),
-              _p(_f32(t_starts, 't_starts')), _p(_f32(t_ends, 't_ends')), _aabb6(aabb), _p(x01), _p(sel), n, _stream())
+              _p(_f32(t_starts, 't_starts')), _p(_f32(t_ends, 't_ends')), _aabb6(aabb), _p(x01), _p(sel), n, _nd(n_dev), _stream())
     return x01, sel
 
 
@@ -126,12 +145,13 @@ def points_normalize(x, aabb):
 
 
 # ---- hash grid -----------------------------------------------------------------------------------
-def hashgrid_fwd(grid: GridConfig, x01, table16):
-    """x01 [n,3] f32, table16 [total*2] 16-bit -> feat [L, n, 2] 16-bit (level major)."""
+def hashgrid_fwd(grid: GridConfig, x01, table16, n_dev=None):
+    """x01 [n,3] f32, table16 [total*2] 16-bit -> feat [L, n, 2] 16-bit (level major).  n_dev (device int64 [1]): only the
+    first min(n, n_dev) samples are encoded (n = capacity = level stride)."""
     n = x01.shape[0]
     feat = torch.empty(grid.n_levels, n, 2, dtype=table16.dtype, device=x01.device)
     d = grid.desc()
-    _call('perf_hashgrid_fwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(table16), _p(feat), n,
+    _call('perf_hashgrid_fwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(table16), _p(feat), n, _nd(n_dev),
               dtype_code(table16.dtype), _stream())
     return feat
 
@@ -166,7 +186,7 @@ def overflow_flag(device):
     return _OVERFLOW_FLAG[key]
 
 
-def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False, level_absmax=None):
+def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False, level_absmax=None, n_dev=None, use_codes=True):
     """dfeat [L, n, 2] f32 -> gradient table [total*2] f32.  `out` (a contiguous fp32 view, e.g. the grid
     part of a flat gradient) is overwritten, or added to when accumulate=True.  level_absmax (device, 16 floats
     from mlp_bwd) selects the packed fixed-point accumulation."""
@@ -175,16 +195,17 @@ def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False, level
         out = torch.empty(grid.n_params, dtype=torch.float32, device=x01.device)
         accumulate = False
     d = grid.desc()
-    ws_bytes = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(d), n)
+    # (a workspace without room for the tile codes selects the position-streaming owners: use_codes=False, tests)
+    ws_bytes = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(d), n if use_codes else 0)
     ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=x01.device)
     flag = overflow_flag(x01.device) if level_absmax is not None else None
     _call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),
-              n, int(bool(accumulate)), _p(level_absmax), _p(flag), _p(ws), ws.numel() * 4, _stream())
+              n, _nd(n_dev), int(bool(accumulate)), _p(level_absmax), _p(flag), _p(ws), ws_bytes, _stream())
     return out
 
 
-def hashgrid_bwd_into(grid, x01, dfeat, out, level_absmax=None):
-    return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False, level_absmax=level_absmax)
+def hashgrid_bwd_into(grid, x01, dfeat, out, level_absmax=None, n_dev=None):
+    return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False, level_absmax=level_absmax, n_dev=n_dev)
 
 
 def hashgrid_corners(grid: GridConfig, x01):
@@ -206,15 +227,15 @@ def hashgrid_bwd_input(grid: GridConfig, x01, dfeat, table):
 
 
 # ---- MLP -----------------------------------------------------------------------------------------
-def mlp_fwd(mlp: MlpConfig, w16, feat16, sel=None):
+def mlp_fwd(mlp: MlpConfig, w16, feat16, sel=None, n_dev=None):
     n = feat16.shape[1]
     out = torch.empty(n, mlp.n_output_dims, dtype=torch.float32, device=feat16.device)
     d = mlp.desc()
-    _call('perf_mlp_fwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(out), n, dtype_code(w16.dtype), _stream())
+    _call('perf_mlp_fwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(out), n, _nd(n_dev), dtype_code(w16.dtype), _stream())
     return out
 
 
-def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True, want_absmax=False):
+def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True, want_absmax=False, n_dev=None):
     """Returns (dfeat [L,n,2] f32 or None, dw [n_net_params] f32[, level_absmax [16] f32])."""
     n = feat16.shape[1]
     d = mlp.desc()
@@ -225,7 +246,7 @@ def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True, want_a
     dw = torch.empty(mlp.n_params, dtype=torch.float32, device=feat16.device)
     amax = torch.empty(_lib.MAX_LEVELS, dtype=torch.float32, device=feat16.device) if want_absmax else None
     _call('perf_mlp_bwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(_f32(dout, 'dout')), _p(dfeat), _p(dw), _p(amax),
-              _p(ws), ws.numel() * 4, n, dtype_code(w16.dtype), _stream())
+              _p(ws), ws.numel() * 4, n, _nd(n_dev), dtype_code(w16.dtype), _stream())
     return (dfeat, dw, amax) if want_absmax else (dfeat, dw)
 
 
@@ -236,6 +257,20 @@ def pano_raygen(pose, height, width, row0=0, nrows=None, device='cuda'):
     o = torch.empty(nrows, width, 3, dtype=torch.float32, device=device)
     d = torch.empty(nrows, width, 3, dtype=torch.float32, device=device)
     _call('perf_pano_raygen', pose_h, height, width, row0, nrows, _p(o), _p(d), _stream())
+    return o, d
+
+
+def pano_raygen_dev(pose_dev, height, width, row0=0, nrows=None, out=None):
+    """pano_raygen with the pose (float32 [4,4] or [12+]) in device memory; `out` = (o, d) preallocated [nrows*width,3] buffers
+    (a captured hipGraph writes the same buffers on every replay)."""
+    nrows = height - row0 if nrows is None else nrows
+    dev = pose_dev.device
+    if out is None:
+        o = torch.empty(nrows, width, 3, dtype=torch.float32, device=dev)
+        d = torch.empty(nrows, width, 3, dtype=torch.float32, device=dev)
+    else:
+        o, d = out
+    _call('perf_pano_raygen_dev', _p(_f32(pose_dev, 'pose')), height, width, row0, nrows, _p(o), _p(d), _stream())
     return o, d
 
 
@@ -318,7 +353,10 @@ def visibility_count(sigmas, t_starts, t_ends, packed, early_stop_eps=1e-4, want
     return (new_counts, ex) if want_exsum else new_counts
 
 
-def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=None):
+def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=None, x01=None, sel=None):
+    """-> (ray_indices, t_starts, t_ends, sigmas, packed_info) of the kept prefixes; with capacity (sync-free mode: the
+    arrays keep that length, the kept count stays on the device) also `total` (int64 [1]); with x01/sel also the compacted
+    positions, appended to the result."""
     R = packed.shape[0]
     dev = packed.device
     new_offsets, total = exclusive_scan_i32(new_counts)
@@ -327,10 +365,17 @@ def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=N
     ts = torch.empty(S, dtype=torch.float32, device=dev)
     te = torch.empty(S, dtype=torch.float32, device=dev)
     sg = torch.empty(S, dtype=torch.float32, device=dev) if sigmas is not None else None
+    xo = torch.empty(S, 3, dtype=torch.float32, device=dev) if x01 is not None else None
+    so = torch.empty(S, dtype=torch.uint8, device=dev) if sel is not None else None
     packed_out = torch.empty(R, 2, dtype=torch.int32, device=dev)
     _call('perf_compact_prefix', _p(packed), _p(new_counts), _p(new_offsets), R, _p(t_starts), _p(t_ends), _p(sigmas),
-              _p(ri), _p(ts), _p(te), _p(sg), _p(packed_out), _stream())
-    return ri, ts, te, sg, packed_out
+              _p(ri), _p(ts), _p(te), _p(sg), _p(packed_out), _p(x01), _p(sel), _p(xo), _p(so), _stream())
+    res = (ri, ts, te, sg, packed_out)
+    if capacity is not None:
+        res = res + (total,)
+    if x01 is not None:
+        res = res + (xo, so)
+    return res
 
 
 def composite_fwd(sigmas, rgbs, t_starts, t_ends, packed, want_samples=True):
@@ -380,6 +425,11 @@ def composite_bwd(sigmas, t_starts, t_ends, packed, weights, trans, g_weights=No
     _call('perf_composite_bwd', _p(sigmas), _p(t_starts), _p(t_ends), _p(packed), R, _p(weights), _p(trans),
               _p(g_weights), _p(g_trans), _p(g_alphas), _p(g_opacity), _p(g_distance), _p(g_color), _p(ds), _p(dr), _stream())
     return ds, dr
+
+
+def render_finish_eval(opacity, distance=None, color=None, n_dev=None):
+    """In place: distance += 5 (1 - opacity), color += 0.5 (1 - opacity) unless the batch (n_dev) holds no sample."""
+    _call('perf_render_finish_eval', _p(_f32(opacity, 'opacity')), _p(distance), _p(color), opacity.shape[0], _nd(n_dev), _stream())
 
 
 def accumulate_fwd(weights, values, packed):

@@ -51,34 +51,37 @@ class NeRFOCCRenderer(nn.Module):
         self.render_step_size = 5e-4
         self.early_stop_eps = 1e-4
         self.max_steps = None          # None: ceil((far-near)/step)+1 like the reference; an int fixes the count
-        self.sample_capacity = None    # int: sync-free fixed-shape sampling (exactly that many samples per batch)
+        self.sample_capacity = None    # int: sync-free sampling -- arrays of that many rows, live counts on the device
 
     # The render is cut in two stages so that a data-parallel trainer can overlap the gradient all-reduce of step k
     # with everything of step k+1 that does not depend on the parameters being updated (scene.py).
     def stage_sample(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, rand=None, with_rgb=False):
-        """Sampling (marching, visibility compaction), sample positions and -- with_rgb -- the colour field without
-        gradient.  Returns a dict consumed by stage_composite, or None when the batch has no sample."""
+        """Sampling (marching, the no-grad density pass and visibility compaction of nerf_renderer.py:145-155), sample
+        positions and -- with_rgb -- the colour field without gradient.  Returns a dict consumed by stage_composite, or
+        None when the batch has no sample.  With self.sample_capacity set every per-sample array has that many rows and
+        st['n_dev'] (device int64 [1]) holds the live count: no host read-back, hipGraph-capturable."""
         rays_o = rays_o.contiguous().float(); rays_d = rays_d.contiguous().float()
         rand = rand or {}
 
-        def sigma_fn(t_starts, t_ends, ray_indices):
-            x01, sel = nerf.sample_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
-            return nerf.density_at(x01, sel)
+        def sigma_points_fn(x01, sel, n_dev):
+            return nerf.density_at(x01, sel, n_dev)
 
-        ray_indices, t_starts, t_ends, packed, sig0 = estimator.sampling_ex(
-            rays_o, rays_d, sigma_fn=sigma_fn, near_plane=self.near_plane, far_plane=self.far_plane,
+        sm = estimator.sampling_ex(
+            rays_o, rays_d, sigma_points_fn=sigma_points_fn, near_plane=self.near_plane, far_plane=self.far_plane,
             render_step_size=self.render_step_size, early_stop_eps=self.early_stop_eps, stratified=nerf.training,
             cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'), max_steps=self.max_steps, capacity=self.sample_capacity,
             points_aabb=nerf._aabb_host)
-        if ray_indices.numel() <= 0:
+        if sm.n_dev is None and sm.ray_indices.numel() <= 0:
             return None
-        pts = getattr(ray_indices, '_perf_points', None)       # positions written by the marching kernel (no compaction)
-        x01, sel = pts if pts else nerf.sample_points(rays_o, rays_d, ray_indices, t_starts, t_ends)
-        st = {'ray_indices': ray_indices, 't_starts': t_starts, 't_ends': t_ends, 'packed': packed, 'sig0': sig0,
-              'x01': x01, 'sel': sel, 'n_rays': rays_o.shape[0], 'rgbs': None}
+        x01, sel = sm.x01, sm.sel
+        if x01 is None:
+            x01, sel = nerf.sample_points(rays_o, rays_d, sm.ray_indices, sm.t_starts, sm.t_ends)
+        st = {'ray_indices': sm.ray_indices, 't_starts': sm.t_starts, 't_ends': sm.t_ends, 'packed': sm.packed, 'sig0': sm.sig,
+              'x01': x01, 'sel': sel, 'n_rays': rays_o.shape[0], 'rgbs': None, 'n_dev': sm.n_dev,
+              'n_marched_dev': sm.n_marched_dev}
         if with_rgb:
             with torch.no_grad():
-                st['rgbs'] = nerf.rgb_at(x01, sel)
+                st['rgbs'] = nerf.rgb_at(x01, sel, sm.n_dev)
         return st
 
     def stage_composite(self, nerf: NGPNeRF, st, geo_inference=False, app_inference=False, rand=None):
@@ -90,18 +93,19 @@ class NeRFOCCRenderer(nn.Module):
         grad_app = torch.is_grad_enabled() and not app_inference
         # (A shared-index pass over both grids -- perf_hashgrid_fwd2 -- measured 2x SLOWER than two passes: the
         #  per-XCD working set doubles to 4 MiB = the whole L2.  The fields are therefore queried one after the other.)
+        n_dev = st.get('n_dev')
         if grad_geo:
-            sigmas = nerf.density_at(x01, sel)
+            sigmas = nerf.density_at(x01, sel, n_dev)
         elif st['sig0'] is not None:
             sigmas = st['sig0']                              # same values the reference recomputes under no_grad
         else:
             with torch.no_grad():
-                sigmas = nerf.density_at(x01, sel)
+                sigmas = nerf.density_at(x01, sel, n_dev)
         if st['rgbs'] is not None and not grad_app:
             rgbs = st['rgbs']
         else:
             with torch.set_grad_enabled(grad_app):
-                rgbs = nerf.rgb_at(x01, sel)
+                rgbs = nerf.rgb_at(x01, sel, n_dev)
 
         weights, trans, opacities, distances, colors = volume_render(sigmas, rgbs, st['t_starts'], st['t_ends'], packed)
 
@@ -116,13 +120,16 @@ class NeRFOCCRenderer(nn.Module):
             noise = rand['noise'] if 'noise' in rand else torch.rand_like(distances)
             distances = torch.relu(distances + (noise * 2. - 1.) * (1. - opacities))
             colors = colors + bg_color * (1. - opacities).detach()
-        else:
+        elif torch.is_grad_enabled():
             distances = distances + 5. * (1. - opacities).detach()
             colors = colors + .5 * (1. - opacities).detach()
+        else:
+            ops.render_finish_eval(opacities, distances, colors, n_dev)      # same arithmetic, one launch, in place
 
+        # (capacity mode: per-sample arrays have sample_capacity rows, the first n_samples_dev of them are live)
         return {'is_valid': True, 'rgb': colors, 'distance': distances, 'weights': weights, 'opacities': opacities,
                 'trans': trans, 't_starts': st['t_starts'], 't_ends': st['t_ends'], 'ray_indices': st['ray_indices'],
-                'packed_info': packed}
+                'packed_info': packed, 'n_samples_dev': n_dev, 'n_marched_dev': st.get('n_marched_dev')}
 
     def render(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, near, far,
                geo_inference=False, app_inference=False, rand=None):

@@ -151,16 +151,19 @@ class FusedAdam:
     def zero_grad(self):
         pass                                       # the step consumes the gradient and drops it
 
-    def step(self):
+    def step(self, gate=None, counters=None, n_marched=None):
+        """gate (device int64 [1], optional): the number of samples behind this gradient; the step is skipped -- step count
+        included -- when it is 0, as the reference skips batches without samples (nerf.py:204-206).  counters / n_marched:
+        see ops.step_bookkeeping (sample statistics, accumulated by the same launch that advances the step count)."""
         p = self.net.params
         if p.grad is None:
             return
         g = self.param_groups[0]
         if not self.capturing:
             self.lr_dev.fill_(g['lr'])             # under capture the replay wrapper refreshes lr_dev instead
-        self.step_dev += 1
-        ops.adam_step_dev(p.data, self.exp_avg, self.exp_avg_sq, p.grad, self.step_dev, self.lr_dev, g['betas'][0],
-                          g['betas'][1], g['eps'], w16=self.w16, zero_grad=False)
+        ops.step_bookkeeping(self.step_dev, gate, counters, n_marched, gate)
+        ops.adam_step_dev(p.data, self.exp_avg, self.exp_avg_sq, p.grad[:p.numel()], self.step_dev, self.lr_dev, g['betas'][0],
+                          g['betas'][1], g['eps'], w16=self.w16, zero_grad=False, gate=gate)
         p.grad = None                              # the next backward installs a fresh gradient (no accumulate pass)
         self.net.set_working_copy(self.w16)        # the kernel wrote the refreshed 16-bit copy
 
@@ -189,8 +192,12 @@ class NeRFScene:
         # so that bench.py times the reference's step (one ray-sample = BOTH fields evaluated).
         self.skip_unused_color = False
         self.overlap_comm = True       # DP: overlap the gradient all-reduce with the next step's prefetch
+        self.graph_steps = True        # train_one_episode replays hipGraph-captured steps when it can
         self._geo_pre = None
         self._ratio_dev = torch.zeros((), dtype=torch.float32, device='cuda')   # distortion-loss ramp min(2*progress, 1)
+        # device-side sample statistics {marched, kept, steps} (int64 [3]); None = not collected.  bench.py reads them
+        # once after the timed region: throughput is counted in samples that were really evaluated and composited.
+        self.sample_counters = None
 
     # ---- distributed helpers ---------------------------------------------------------------------
     @staticmethod
@@ -201,20 +208,43 @@ class NeRFScene:
         return None, 0, 1
 
     # ---- rendering (nerf.py:74-123) --------------------------------------------------------------
+    EVAL_SAMPLES_PER_RAY = 64      # initial per-ray sample capacity of the sync-free eval batches (grown on demand)
+
     @torch.no_grad()
-    def render(self, rays: Rays, query_keys=('rgb',), batch_size=262144):
-        # (the reference hard-codes 32,768-ray batches, nerf.py:86; rays are independent and eval has no randomness,
-        #  so the batch size does not change the result -- tests/test_gpu_fullsize.py -- only the launch overhead)
+    def render(self, rays: Rays, query_keys=('rgb',), batch_size=262144, sync_free=True):
+        """NeRFScene.render (nerf.py:74-99).  The reference hard-codes 32,768-ray batches (:86); rays are independent and
+        eval has no randomness, so the batch size does not change the result (tests/test_gpu_fullsize.py), only the launch
+        overhead.  sync_free: every batch runs with capacity-sized sample arrays and device-side counts -- the host never
+        waits for a sample count; ONE read-back at the end checks that no batch marched more samples than its capacity
+        (otherwise the capacity is raised and the panorama rendered again, so results never depend on it)."""
         last_train = self.nerf.training
         self.set_eval()
         rays_o, rays_d = rays.collapse()
         pre_shape = list(rays_o.shape[:-1])
         rays_o = rays_o.reshape(-1, 3); rays_d = rays_d.reshape(-1, 3)
-        ret = {k: [] for k in query_keys}
-        for ro, rd in zip(rays_o.split(batch_size), rays_d.split(batch_size)):
-            cur = self.render_once(Rays(ro, rd), query_keys)
-            for k in query_keys:
-                ret[k].append(cur[k])
+        r = self.renderer
+        saved_capacity = r.sample_capacity
+        try:
+            while True:
+                per_ray = getattr(self, '_eval_spp_cap', self.EVAL_SAMPLES_PER_RAY)
+                ret = {k: [] for k in query_keys}
+                marched = []
+                for ro, rd in zip(rays_o.split(batch_size), rays_d.split(batch_size)):
+                    if sync_free:
+                        r.sample_capacity = int(ro.shape[0]) * per_ray
+                    cur = self.render_once(Rays(ro, rd), list(query_keys) + (['n_marched_dev'] if sync_free else []))
+                    for k in query_keys:
+                        ret[k].append(cur[k])
+                    if sync_free:
+                        marched.append(cur['n_marched_dev'] / float(ro.shape[0]))
+                if not sync_free:
+                    break
+                worst = float(torch.stack(marched).max().item())           # the render's single host read-back
+                if worst <= per_ray:
+                    break
+                self._eval_spp_cap = int(math.ceil(worst * 1.25))          # truncated batch(es): render again with room
+        finally:
+            r.sample_capacity = saved_capacity
         for k in query_keys:
             ret[k] = torch.cat(ret[k], dim=0).reshape(pre_shape + [-1])
         if last_train:
@@ -231,13 +261,14 @@ class NeRFScene:
                                    geo_inference=geo_inference, app_inference=app_inference, rand=rand)
         if (res is None) or (not res['is_valid']):
             return res
-        return {k: res[k] for k in list(query_keys) + ['is_valid']}
+        return {k: res.get(k) for k in list(query_keys) + ['is_valid']}
 
     # ---- training (nerf.py:125-311) ----------------------------------------------------------------
     def fit(self, sup_pool: SupInfoPool, **kw):
         self.train_one_episode(sup_pool, self.train_conf.raw_phase_iter_geo, self.train_conf.raw_phase_iter_app, **kw)
 
     def prepare_occupancy(self, sup_pool, warmup='direct'):
+        self._geo_pre = None           # a batch prefetched under the previous episode's pool / occupancy must not be consumed
         self.estimator = OccGridEstimator(roi_aabb=self.aabb, resolution=256, levels=1).cuda()
         self.estimator.train()
         pre_grid, _ = sup_pool.gen_occ_grid(res=256)
@@ -259,22 +290,47 @@ class NeRFScene:
     def make_optimizer(self, net, lr):
         return FusedAdam(net, lr) if self.fused_adam else torch.optim.Adam(net.parameters(), lr=lr)
 
-    def train_one_episode(self, sup_pool, geo_res_iters, app_res_iters, warmup='direct', callback=None):
+    def train_one_episode(self, sup_pool, geo_res_iters, app_res_iters, warmup='direct', callback=None, use_graphs=None):
+        """nerf.py:137-184.  use_graphs (default: whenever possible = fused Adam, explicit step chains, single process): the
+        first EAGER_HEAD iterations of a phase run eagerly, then the step is captured once and replayed -- same kernels,
+        same order, no host work per step besides the learning-rate value."""
         self.set_train()
         self.prepare_occupancy(sup_pool, warmup)
         self.nerf.reset_geo()
-        geo_optimizer = self.make_optimizer(self.nerf.geo_mlp, self.train_conf.geo_optimizer.init_lr)
-        for iter_i in range(geo_res_iters):
-            self.update_lr(geo_optimizer, self.train_conf.geo_optimizer, iter_i / geo_res_iters)
-            self.train_one_step_geo(geo_optimizer, sup_pool, progress=iter_i / app_res_iters)
+        if use_graphs is None:
+            use_graphs = self.graph_steps
+        use_graphs = bool(use_graphs) and self.fused_adam and self.fused_steps and self._dist()[0] is None
+        saved_capacity = self.renderer.sample_capacity
+        if use_graphs and saved_capacity is None:
+            self.renderer.sample_capacity = self.train_conf.pixel_loss_batch_size * self.TRAIN_SAMPLES_PER_RAY
+        try:
+            geo_optimizer = self.make_optimizer(self.nerf.geo_mlp, self.train_conf.geo_optimizer.init_lr)
+            self._run_phase('geo', geo_optimizer, self.train_conf.geo_optimizer, geo_res_iters, sup_pool, callback,
+                            use_graphs and self._can_fuse(), lambda i: i / app_res_iters)
+            app_optimizer = self.make_optimizer(self.nerf.app_mlp, self.train_conf.app_optimizer.init_lr)
+            self._run_phase('app', app_optimizer, self.train_conf.app_optimizer, app_res_iters, sup_pool, callback,
+                            use_graphs, lambda i: i / app_res_iters)
+        finally:
+            self.renderer.sample_capacity = saved_capacity
+
+    EAGER_HEAD = 3
+
+    def _run_phase(self, kind, optimizer, conf, n_iters, sup_pool, callback, use_graphs, progress_of):
+        step_fn = self.train_one_step_geo if kind == 'geo' else self.train_one_step_app
+        graphed = None
+        for iter_i in range(n_iters):
+            if use_graphs and graphed is None and iter_i >= self.EAGER_HEAD:
+                graphed = self.make_graphed_step(kind, optimizer, sup_pool, warmup=0)
+            if graphed is not None:
+                graphed(self.lr_at(conf, iter_i / n_iters), progress_of(iter_i))
+            else:
+                self.update_lr(optimizer, conf, iter_i / n_iters)
+                if kind == 'geo':
+                    step_fn(optimizer, sup_pool, progress=progress_of(iter_i), prefetch_next=iter_i + 1 < n_iters)
+                else:
+                    step_fn(optimizer, sup_pool, progress=progress_of(iter_i))
             if callback:
-                callback('geo', iter_i)
-        app_optimizer = self.make_optimizer(self.nerf.app_mlp, self.train_conf.app_optimizer.init_lr)
-        for iter_i in range(app_res_iters):
-            self.update_lr(app_optimizer, self.train_conf.app_optimizer, iter_i / app_res_iters)
-            self.train_one_step_app(app_optimizer, sup_pool, progress=iter_i / app_res_iters)
-            if callback:
-                callback('app', iter_i)
+                callback(kind, iter_i)
 
     def _batch(self, sup_pool, generator=None):
         dist, rank, world = self._dist()
@@ -321,35 +377,62 @@ class NeRFScene:
         return {'rays': rays, 'gt_depths': gt_depths, 'bs': bs, 'dist_info': dist_info, 'st': st, 'rand': rand}
 
     # ---- fused steps: explicit kernel chain instead of autograd + ~25 tiny torch ops (same arithmetic) ----------
-    def _field_grad(self, net, x01, w16, feat, sel, dout):
+    def _field_grad(self, net, x01, w16, feat, sel, dout, n_dev=None, extra=0):
+        """Flat gradient [network | grid] (+ `extra` trailing slots: the data-parallel path appends the sample count)."""
         n_net = net.mlp.n_params
         fixed = _tcnn.GRID_GRAD_ACCUM == 'fixed'
-        res = ops.mlp_bwd(net.mlp, w16[:n_net], feat, dout, sel, want_absmax=fixed)
-        grad = torch.empty(n_net + net.grid.n_params, dtype=torch.float32, device=x01.device)
+        res = ops.mlp_bwd(net.mlp, w16[:n_net], feat, dout, sel, want_absmax=fixed, n_dev=n_dev)
+        n_all = n_net + net.grid.n_params
+        grad = torch.empty(n_all + extra, dtype=torch.float32, device=x01.device)
         grad[:n_net] = res[1]
-        ops.hashgrid_bwd_into(net.grid, x01, res[0], grad[n_net:], level_absmax=res[2] if fixed else None)
+        ops.hashgrid_bwd_into(net.grid, x01, res[0], grad[n_net:n_all], level_absmax=res[2] if fixed else None, n_dev=n_dev)
         return grad
 
-    def _apply_grad(self, net, grad, optimizer, dist_info, overlap):
+    def _apply_grad(self, net, grad, optimizer, dist_info, overlap, n_kept=None, n_marched=None):
+        """[one RCCL all-reduce of the flat gradient] -> Adam.  n_kept: number of samples behind `grad` (device int64 [1], or a
+        host int in the eager variable-count path).  Under data parallelism the count travels in the last slot of the
+        gradient buffer, so the one collective also tells every rank whether ANY rank had samples; the optimizer step is
+        skipped when none had (the reference's `if not is_valid: return`, nerf.py:204-206)."""
         dist = dist_info[0]
-        net.params.grad = grad
+        n = net.params.numel()
+        gate = n_kept if torch.is_tensor(n_kept) else None
         if dist is not None:
+            if grad.numel() == n + 1:
+                if torch.is_tensor(n_kept):
+                    grad[n:].copy_(n_kept)
+                else:
+                    grad[n:].fill_(float(n_kept if n_kept is not None else 1))
             if overlap is not None:
                 work = dist.all_reduce(grad, op=dist.ReduceOp.SUM, async_op=True)
                 overlap()
                 work.wait()
             else:
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM)
-        optimizer.step()
+            if grad.numel() == n + 1:
+                gate = grad[n:].to(torch.int64)
+        net.params.grad = grad
+        if isinstance(optimizer, FusedAdam):
+            optimizer.step(gate=gate, counters=self.sample_counters, n_marched=n_marched)
+        else:
+            if gate is None or int(gate.item()) > 0:
+                net.params.grad = grad[:n]
+                optimizer.step()
+            net.params.grad = None
+        self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
+        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY and _tcnn.GRID_GRAD_ACCUM == 'fixed':
+            self._steps_since_check = 0
+            _tcnn.check_fixed_point_overflow(net.params.device)
         self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
         if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY and _tcnn.GRID_GRAD_ACCUM == 'fixed':
             self._steps_since_check = 0
             _tcnn.check_fixed_point_overflow(net.params.device)
 
     @torch.no_grad()
-    def _geo_step_fused(self, optimizer, sup_pool, progress, rand, generator):
-        """train_one_step_geo (nerf.py:186-257) as an explicit chain: sampling -> density field (kept features) -> colour
-        field -> compositing -> fused loss head -> distortion / compositing / MLP / grid backward -> [all-reduce] -> Adam."""
+    def _geo_step_fused(self, optimizer, sup_pool, progress, rand, generator, prefetch_next=True):
+        """train_one_step_geo (nerf.py:186-257) as an explicit chain: sampling (marching + no-grad density pass + visibility
+        compaction) -> density field (kept features) -> colour field -> compositing -> fused loss head -> distortion /
+        compositing / MLP / grid backward -> [all-reduce] -> Adam.  With renderer.sample_capacity set nothing in the chain
+        reads the device: sample counts stay in device memory (st['n_dev'])."""
         tc = self.train_conf
         rand = rand or {}
         pre = self._geo_pre or self._geo_prefetch(sup_pool, rand, generator)
@@ -360,17 +443,19 @@ class NeRFScene:
         if st is None:
             st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=not self.skip_unused_color)
         geo = self.nerf.geo_mlp
+        extra = 1 if dist_info[0] is not None else 0
         if st is None or st is False:
-            if dist_info[0] is not None:
-                self._apply_grad(geo, torch.zeros_like(geo.params), optimizer, dist_info, None)
+            if dist_info[0] is not None:       # keep the collective matched across ranks; the count slot says "no samples here"
+                self._apply_grad(geo, torch.zeros(geo.params.numel() + 1, device=geo.params.device), optimizer, dist_info, None, n_kept=0)
             self.global_iter_step_geo += 1
             return
-        x01, sel, packed, ts, te = st['x01'], st['sel'], st['packed'], st['t_starts'], st['t_ends']
+        x01, sel, packed, ts, te, n_dev = st['x01'], st['sel'], st['packed'], st['t_starts'], st['t_ends'], st['n_dev']
+        self._last_counts = (st['n_marched_dev'], n_dev)
         n_net = geo.mlp.n_params
         w16 = geo.working_copy()
-        feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:])
-        sig = ops.mlp_fwd(geo.mlp, w16[:n_net], feat, sel)
-        rgbs = None if self.skip_unused_color else (st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel))
+        feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:], n_dev=n_dev)
+        sig = ops.mlp_fwd(geo.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
+        rgbs = None if self.skip_unused_color else (st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel, n_dev))
         w, T, op, dist_r, col, dl = ops.composite_distloss_fwd(sig.view(-1), rgbs, ts, te, packed)
         noise = rand['noise']            # (the background colour the reference also draws, :185, is not used by this step)
         if not self._capturing:
@@ -378,11 +463,12 @@ class NeRFScene:
         g_op, g_dist, sc = ops.geo_loss(op, dist_r, gt_depths, noise, dl, packed, bs, tc.depth_loss_weight,
                                         tc.distortion_loss_weight, self._ratio_dev, self.loss_scale)
         dsig = ops.composite_distloss_bwd(sig.view(-1), ts, te, packed, w, T, op, dist_r, g_op, g_dist, 1.0, scale_dev=sc[2:3])
-        grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1))
+        grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1), n_dev=n_dev, extra=extra)
         self.last_losses['depth_loss'] = sc[0]; self.last_losses['dist_loss'] = sc[1]
         overlap = (lambda: setattr(self, '_geo_pre', self._geo_prefetch(sup_pool, rand_in, generator))) \
-            if (self.overlap_comm and dist_info[0] is not None) else None
-        self._apply_grad(geo, grad, optimizer, dist_info, overlap)
+            if (self.overlap_comm and prefetch_next and dist_info[0] is not None) else None
+        self._apply_grad(geo, grad, optimizer, dist_info, overlap, n_kept=n_dev if n_dev is not None else x01.shape[0],
+                         n_marched=st['n_marched_dev'])
         self.global_iter_step_geo += 1
 
     @torch.no_grad()
@@ -394,17 +480,19 @@ class NeRFScene:
         rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
         st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand)
         app = self.nerf.app_mlp
+        extra = 1 if dist_info[0] is not None else 0
         if st is None:
             if dist_info[0] is not None:
-                self._apply_grad(app, torch.zeros_like(app.params), optimizer, dist_info, None)
+                self._apply_grad(app, torch.zeros(app.params.numel() + 1, device=app.params.device), optimizer, dist_info, None, n_kept=0)
             self.global_iter_step_app += 1
             return
-        x01, sel, packed, ts, te = st['x01'], st['sel'], st['packed'], st['t_starts'], st['t_ends']
-        sig = st['sig0'] if st['sig0'] is not None else self.nerf.density_at(x01, sel)
+        x01, sel, packed, ts, te, n_dev = st['x01'], st['sel'], st['packed'], st['t_starts'], st['t_ends'], st['n_dev']
+        self._last_counts = (st['n_marched_dev'], n_dev)
+        sig = st['sig0'] if st['sig0'] is not None else self.nerf.density_at(x01, sel, n_dev)
         n_net = app.mlp.n_params
         w16 = app.working_copy()
-        feat = ops.hashgrid_fwd(app.grid, x01, w16[n_net:])
-        rgbs = ops.mlp_fwd(app.mlp, w16[:n_net], feat, sel)
+        feat = ops.hashgrid_fwd(app.grid, x01, w16[n_net:], n_dev=n_dev)
+        rgbs = ops.mlp_fwd(app.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
         w, T, _, op, dist_r, col = ops.composite_fwd(sig.reshape(-1).contiguous(), rgbs, ts, te, packed)
         n_rays = op.shape[0]
         bg = None
@@ -416,18 +504,19 @@ class NeRFScene:
             torch.rand(n_rays, 1, device=op.device)               # the distance noise draw of :193 (unused by this loss)
         g_col, sc = ops.app_loss(op, col, bg, gt_colors, bs, tc.color_loss_weight, self.loss_scale)
         _, drgb = ops.composite_bwd(sig.reshape(-1).contiguous(), ts, te, packed, w, T, g_color=g_col, want_dsigma=False, want_drgb=True)
-        grad = self._field_grad(app, x01, w16, feat, sel, drgb)
+        grad = self._field_grad(app, x01, w16, feat, sel, drgb, n_dev=n_dev, extra=extra)
         self.last_losses['color_loss'] = sc[0]
-        self._apply_grad(app, grad, optimizer, dist_info, None)
+        self._apply_grad(app, grad, optimizer, dist_info, None, n_kept=n_dev if n_dev is not None else x01.shape[0],
+                         n_marched=st['n_marched_dev'])
         self.global_iter_step_app += 1
 
     def _can_fuse(self):
         tc = self.train_conf
         return self.fused_steps and tc.density_loss_weight <= 1e-7 and tc.depth_loss_weight > 1e-7 and tc.distortion_loss_weight > 1e-7
 
-    def train_one_step_geo(self, optimizer, sup_pool, progress, rand=None, generator=None):
+    def train_one_step_geo(self, optimizer, sup_pool, progress, rand=None, generator=None, prefetch_next=True):
         if self._can_fuse():
-            return self._geo_step_fused(optimizer, sup_pool, progress, rand, generator)
+            return self._geo_step_fused(optimizer, sup_pool, progress, rand, generator, prefetch_next)
         tc = self.train_conf
         optimizer.zero_grad()
         pre = getattr(self, '_geo_pre', None) or self._geo_prefetch(sup_pool, rand, generator)
@@ -463,7 +552,7 @@ class NeRFScene:
             density_loss = self.nerf.query_density(rand_pts).mean()
             loss = loss + density_loss * tc.density_loss_weight
         overlap = (lambda: setattr(self, '_geo_pre', self._geo_prefetch(sup_pool, rand, generator))) \
-            if (self.overlap_comm and dist_info[0] is not None) else None
+            if (self.overlap_comm and prefetch_next and dist_info[0] is not None) else None
         self._finish_step(loss, self.nerf.geo_mlp, optimizer, dist_info, overlap)
         self.global_iter_step_geo += 1
 
@@ -489,21 +578,28 @@ class NeRFScene:
         self.global_iter_step_app += 1
 
     # ---- hipGraph capture of a whole training step (launch-bound inner loop) ---------------------------
+    TRAIN_SAMPLES_PER_RAY = 128    # default per-ray sample capacity of sync-free / graph-captured training batches
+
     def make_graphed_step(self, kind, optimizer, sup_pool, warmup=3):
-        """Capture train_one_step_{geo,app} (batch draw, sampling, both fields, compositing, losses, backward, Adam)
-        into one hipGraph.  Needs fixed shapes: renderer.sample_capacity must be set (exact sample count per batch,
-        e.g. rays*spp in fixed-count mode), a FusedAdam optimizer and a single process.  Returns
-        replay(lr, progress)."""
+        """Capture train_one_step_{geo,app} (batch draw, sampling incl. the no-grad density pass and visibility compaction,
+        both fields, compositing, losses, backward, Adam) into one hipGraph.  Sample arrays are capacity-sized
+        (renderer.sample_capacity; default pixel_loss_batch_size * TRAIN_SAMPLES_PER_RAY) and every count stays on the
+        device, so the reference's variable-count step is a fixed launch sequence.  Needs the fused Adam (device-side
+        step / lr) and a single process.  `warmup` real steps run first (they ARE training steps; pass 0 when the caller has
+        already run the step eagerly).  Returns replay(lr, progress)."""
         assert isinstance(optimizer, FusedAdam), 'graph capture needs the fused Adam (device-side step/lr)'
-        assert self.renderer.sample_capacity is not None, 'graph capture needs a fixed sample capacity'
         assert self._dist()[0] is None, 'graphed steps are single-process (the all-reduce stays eager)'
+        assert self._can_fuse() if kind == 'geo' else self.fused_steps, 'graph capture covers the explicit step chains'
+        if self.renderer.sample_capacity is None:
+            self.renderer.sample_capacity = self.train_conf.pixel_loss_batch_size * self.TRAIN_SAMPLES_PER_RAY
         step_fn = self.train_one_step_geo if kind == 'geo' else self.train_one_step_app
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                step_fn(optimizer, sup_pool, progress=0.0)
-        torch.cuda.current_stream().wait_stream(side)
+        if warmup > 0:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    step_fn(optimizer, sup_pool, progress=0.0)
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         self._capturing = optimizer.capturing = True
@@ -513,7 +609,7 @@ class NeRFScene:
         finally:
             self._capturing = optimizer.capturing = False
 
-        state = {'graph': graph, 'n': 0}
+        state = {'graph': graph, 'n': 0, 'counts': self._last_counts, 'capacity': self.renderer.sample_capacity}
 
         def replay(lr, progress):
             optimizer.lr_dev.fill_(lr)
@@ -521,13 +617,95 @@ class NeRFScene:
                 self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
             state['graph'].replay()
             state['n'] += 1
-            if state['n'] % OVERFLOW_CHECK_EVERY == 0 and _tcnn.GRID_GRAD_ACCUM == 'fixed':
-                if _tcnn.check_fixed_point_overflow(optimizer.net.params.device):
-                    # the accumulation mode is baked into the graph: capture again in fp32 mode
-                    state['graph'] = self.make_graphed_step(kind, optimizer, sup_pool, warmup=1).graph
+            if kind == 'geo':
+                self.global_iter_step_geo += 1
+            else:
+                self.global_iter_step_app += 1
+            if state['n'] % OVERFLOW_CHECK_EVERY == 0:
+                recapture = False
+                if _tcnn.GRID_GRAD_ACCUM == 'fixed' and _tcnn.check_fixed_point_overflow(optimizer.net.params.device):
+                    recapture = True           # the accumulation mode is baked into the graph: capture again in fp32 mode
+                marched = state['counts'][0]
+                if marched is not None and int(marched.item()) > state['capacity']:
+                    import warnings
+                    warnings.warn(f'perf_amd: a training batch marched {int(marched.item())} samples, more than the capacity '
+                                  f'{state["capacity"]} (late rays were truncated); doubling the capacity')
+                    self.renderer.sample_capacity = 2 * int(marched.item())
+                    recapture = True
+                if recapture:
+                    new = self.make_graphed_step(kind, optimizer, sup_pool, warmup=0)
+                    state.update(new.state)
 
         replay.graph = graph
+        replay.state = state
         return replay
+
+    # ---- hipGraph capture of a whole eval frame (BASELINE config 4: render_dense, core_exp_runner.py:223-246) ----------
+    @torch.no_grad()
+    def make_graphed_render(self, height, width, query_keys=('rgb', 'distance'), batch_size=32768, samples_per_ray=None):
+        """One panorama frame -- rays generated from a device-resident pose, then ceil(H*W / batch_size) batches of
+        NeRFScene.render_once (marching, no-grad density pass, visibility compaction, colour field, compositing, eval
+        background) -- captured as ONE hipGraph with capacity-sized sample arrays and device-side counts.  Returns
+        frame(pose [4,4]) -> {key: [H, W, C]} (tensors owned by the graph: valid until the next call).  After a replay the
+        per-batch marched counts are checked against the capacity (one read-back per frame, after the frame is complete);
+        a frame that did not fit is rendered again through a re-captured, larger graph, so results never depend on the
+        capacity."""
+        self.set_eval()
+        dev = self.nerf.aabb.device
+        n = height * width
+        n_batches = (n + batch_size - 1) // batch_size
+        state = {'per_ray': int(samples_per_ray or getattr(self, '_eval_spp_cap', self.EVAL_SAMPLES_PER_RAY))}
+        pose_dev = torch.eye(4, dtype=torch.float32, device=dev)
+        o_buf = torch.empty(height, width, 3, dtype=torch.float32, device=dev)
+        d_buf = torch.empty(height, width, 3, dtype=torch.float32, device=dev)
+        width_of = {'rgb': 3, 'distance': 1, 'opacities': 1}
+        outs = {k: torch.empty(n, width_of[k], dtype=torch.float32, device=dev) for k in query_keys}
+        marched = torch.zeros(n_batches, dtype=torch.int64, device=dev)
+        r = self.renderer
+
+        def body():
+            ops.pano_raygen_dev(pose_dev, height, width, out=(o_buf, d_buf))
+            fo, fd = o_buf.view(-1, 3), d_buf.view(-1, 3)
+            for b in range(n_batches):
+                lo, hi = b * batch_size, min((b + 1) * batch_size, n)
+                r.sample_capacity = (hi - lo) * state['per_ray']
+                cur = self.render_once(Rays(fo[lo:hi], fd[lo:hi]), list(query_keys) + ['n_marched_dev'])
+                for k in query_keys:
+                    outs[k][lo:hi].copy_(cur[k])
+                marched[b:b + 1].copy_(cur['n_marched_dev'])
+
+        def capture():
+            saved = r.sample_capacity
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    body()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body()
+            finally:
+                r.sample_capacity = saved
+            return g
+
+        state['graph'] = capture()
+
+        def frame(pose):
+            pose_dev.copy_(torch.as_tensor(pose, dtype=torch.float32).reshape(4, 4), non_blocking=True)
+            while True:
+                state['graph'].replay()
+                sizes = torch.tensor([min((b + 1) * batch_size, n) - b * batch_size for b in range(n_batches)], device=dev)
+                worst = float((marched.float() / sizes).max().item())
+                if worst <= state['per_ray']:
+                    break
+                state['per_ray'] = self._eval_spp_cap = int(math.ceil(worst * 1.25))
+                state['graph'] = capture()
+            return {k: outs[k].view(height, width, -1) for k in query_keys}
+
+        frame.state = state
+        return frame
 
     @staticmethod
     def lr_at(optim_conf, progress):

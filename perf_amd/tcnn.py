@@ -57,12 +57,14 @@ class _FieldFn(torch.autograd.Function):
     """encode + MLP with the whole backward in two kernels (MLP backward recomputes the forward)."""
 
     @staticmethod
-    def forward(ctx, x01, params, sel, module):
+    def forward(ctx, x01, params, sel, module, n_dev=None):
+        """n_dev (device int64 [1], optional): only the first min(len(x01), n_dev) rows are live (capacity-sized batch)."""
         w16 = module.working_copy(params)
         n_net = module.mlp.n_params
-        feat = ops.hashgrid_fwd(module.grid, x01, w16[n_net:])
-        out = ops.mlp_fwd(module.mlp, w16[:n_net], feat, sel)
+        feat = ops.hashgrid_fwd(module.grid, x01, w16[n_net:], n_dev=n_dev)
+        out = ops.mlp_fwd(module.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
         ctx.module = module
+        ctx.n_dev = n_dev
         ctx.save_for_backward(x01, w16, feat, sel if sel is not None else torch.empty(0, device=x01.device))
         ctx.has_sel = sel is not None
         return out
@@ -72,16 +74,29 @@ class _FieldFn(torch.autograd.Function):
         x01, w16, feat, sel = ctx.saved_tensors
         module = ctx.module
         sel = sel if ctx.has_sel else None
-        return None, _field_backward(module, x01, w16, feat, sel, dout), None, None
+        return None, _field_backward(module, x01, w16, feat, sel, dout, n_dev=ctx.n_dev, poll_overflow=True), None, None, None
 
 
-def _field_backward(module, x01, w16, feat, sel, dout):
+# Autograd (drop-in shim) path: how many backward calls between reads of the fixed-point overflow flag.  1 = every call:
+# the flag costs one host sync per backward, but a hit is repaired in the SAME step (the gradient is recomputed with
+# fp32 LDS accumulation before anything consumes it).  NeRFScene's explicit step chains poll at their own cadence.
+OVERFLOW_POLL_EVERY = int(_os.environ.get('PERF_OVERFLOW_POLL_EVERY', '1'))
+_backward_calls = 0
+
+
+def _field_backward(module, x01, w16, feat, sel, dout, n_dev=None, poll_overflow=False):
+    global _backward_calls
     n_net = module.mlp.n_params
     fixed = GRID_GRAD_ACCUM == 'fixed'          # module-level switch, see check_fixed_point_overflow()
-    res = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout.contiguous().float(), sel, want_absmax=fixed)
+    res = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout.contiguous().float(), sel, want_absmax=fixed, n_dev=n_dev)
     grad = torch.empty(n_net + module.grid.n_params, dtype=torch.float32, device=x01.device)
     grad[:n_net] = res[1]
-    ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=res[2] if fixed else None)
+    ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=res[2] if fixed else None, n_dev=n_dev)
+    if fixed and poll_overflow and OVERFLOW_POLL_EVERY > 0 and not torch.cuda.is_current_stream_capturing():
+        _backward_calls += 1
+        if _backward_calls % OVERFLOW_POLL_EVERY == 0 and check_fixed_point_overflow(x01.device):
+            # the packed fixed-point sums of THIS call came too close to the int32 range: redo it in fp32
+            ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=None, n_dev=n_dev)
     return grad
 
 

@@ -99,7 +99,47 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                      # raises if the .so is missing: no CPU fallback
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.perf_version() == 2
+    assert lib.perf_version() == _lib.ABI_VERSION == int(re.search(r'#define\s+PERF_ABI_VERSION\s+(\d+)', header).group(1))
+    assert lib.perf_sizeof_grid_desc() == ctypes.sizeof(_lib.GridDesc)
+    assert lib.perf_sizeof_mlp_desc() == ctypes.sizeof(_lib.MlpDesc)
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() compiles (or finds) the library and checks header / binding / library agreement."""
+    import __graft_entry__ as G
+    G.build()
+
+
+def test_integration_md_binding_matches_the_header():
+    """The ctypes snippet INTEGRATION.md shows a maintainer is executed as written: its perf_grid_desc mirror must have the
+    size the built library reports, and its argtypes for perf_hashgrid_fwd the arity of the header's declaration."""
+    from perf_amd import _lib
+    _lib.load()
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    code = re.search(r'```python\nimport ctypes, torch\n(.*?)```', text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("perf_amd/libperf_hip.so")', f'ctypes.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec('import ctypes, torch\n' + code, ns)                     # runs the snippet's own load-time asserts too
+    assert ctypes.sizeof(ns['GridDesc']) == ctypes.sizeof(_lib.GridDesc) == ns['lib'].perf_sizeof_grid_desc()
+    for (name, ctype), (name2, ctype2) in zip(ns['GridDesc']._fields_, _lib.GridDesc._fields_):
+        assert name == name2 and ctypes.sizeof(ctype) == ctypes.sizeof(ctype2), name
+    header = open(os.path.join(ROOT, 'include', 'perf_hip.h')).read()
+    decl = re.search(r'int perf_hashgrid_fwd\((.*?)\);', header, re.S).group(1)
+    assert len(ns['lib'].perf_hashgrid_fwd.argtypes) == len(decl.split(',')) == len(_lib._SIGS['perf_hashgrid_fwd'][1])
+
+
+def test_binding_arity_matches_the_header():
+    """Every entry point: the number of ctypes argtypes in perf_amd/_lib.py equals the number of parameters declared in
+    include/perf_hip.h (a drifted signature would otherwise only show up as garbage arguments on the GPU)."""
+    from perf_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'perf_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    for name, (_, args) in _lib._SIGS.items():
+        m = re.search(r'\b' + name + r'\s*\((.*?)\)\s*;', header, re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ('', 'void') else len(params.split(','))
+        assert n == len(args), (name, n, len(args))
 
 
 def test_ops_refuse_cpu_tensors():

@@ -1,0 +1,313 @@
+"""Device-side sample counts (capacity-sized launches + n_dev), the sync-free / hipGraph-captured variable-count paths
+built on them (training step, BASELINE config 4 eval frames), and the boundary's re-entrancy.
+
+Bar: a capacity-sized call with a device-side count must give BIT-IDENTICAL results on the live rows to the exact-size
+call; a graph replay must equal the eager step bit for bit; a graphed 512x1024 frame must equal the eager render."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import perf_oracle as O  # noqa: E402
+
+AABB = [-1., -1, -1, 1, 1, 1]
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    from perf_amd import ops as _ops
+    return _ops
+
+
+def _cfg(**kw):
+    from perf_amd.grid import GridConfig
+    return GridConfig(**kw)
+
+
+def _nd(n):
+    return torch.tensor([n], dtype=torch.int64, device='cuda')
+
+
+def _ray_points(n, g):
+    R = n // 64 + 1
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    t = (torch.arange(64) + 0.5) / 64
+    return ((d[:, None, :] * t[None, :, None]).reshape(-1, 3) * 0.45 + 0.5)[:n].contiguous()
+
+
+@pytest.mark.parametrize('n_live,cap', [(5000, 8192), (4099, 4099), (0, 1024), (33, 70000)])
+def test_per_sample_ops_with_device_counts_equal_exact_calls(ops, n_live, cap):
+    """hashgrid_fwd / mlp_fwd / mlp_bwd / hashgrid_bwd (fp32 and fixed point) / points_from_rays: capacity `cap` with
+    n_dev = n_live  ==  exact call on the first n_live rows (rows beyond n_live hold garbage on purpose)."""
+    from perf_amd.grid import MlpConfig
+    cfg = _cfg()
+    g = torch.Generator().manual_seed(7 + n_live)
+    x_live = _ray_points(max(n_live, 1), g)[:n_live]
+    x = torch.full((cap, 3), float('nan'))
+    x[:n_live] = x_live
+    x = x.cuda()
+    spec = O.geo_spec()
+    params = O.init_field_params(spec); params[spec.n_net:] *= 1e4
+    w16 = ops.cast_params(params.cuda(), 'bf16')
+    nd = _nd(n_live)
+    mlp = MlpConfig(n_levels=16, n_hidden_layers=1, n_output_dims=1, output_activation='Exponential')
+    # ---- forward
+    feat_c = ops.hashgrid_fwd(cfg, x, w16[spec.n_net:], n_dev=nd)
+    feat_e = ops.hashgrid_fwd(cfg, x[:n_live].contiguous(), w16[spec.n_net:])
+    assert torch.equal(feat_c[:, :n_live], feat_e)
+    sel = (torch.rand(cap, generator=g) > 0.1).to(torch.uint8).cuda()
+    out_c = ops.mlp_fwd(mlp, w16[:spec.n_net], feat_c, sel, n_dev=nd)
+    out_e = ops.mlp_fwd(mlp, w16[:spec.n_net], feat_e, sel[:n_live].contiguous())
+    assert torch.equal(out_c[:n_live], out_e)
+    # ---- backward
+    dout = torch.randn(cap, 1, generator=g).cuda()
+    dfc, dwc, amc = ops.mlp_bwd(mlp, w16[:spec.n_net], feat_c, dout, sel, want_absmax=True, n_dev=nd)
+    dfe, dwe, ame = ops.mlp_bwd(mlp, w16[:spec.n_net], feat_e, dout[:n_live].contiguous(), sel[:n_live].contiguous(), want_absmax=True)
+    assert torch.equal(dfc[:, :n_live], dfe) and torch.equal(amc, ame)
+    # (the weight gradient is a two-stage sum whose partial count follows the capacity: equal up to fp32 association)
+    assert float((dwc - dwe).abs().max()) <= 1e-5 * max(1.0, float(dwe.abs().max()))
+    for absmax in (None, amc):
+        gc = ops.hashgrid_bwd(cfg, x, dfc, level_absmax=absmax, n_dev=nd)
+        ge = ops.hashgrid_bwd(cfg, x[:n_live].contiguous(), dfe, level_absmax=absmax)
+        if absmax is None:
+            assert float((gc - ge).abs().max()) <= 1e-5 * max(1e-12, float(ge.abs().max()))     # fp32 LDS atomics: order
+        else:
+            assert torch.equal(gc, ge)                  # fixed point: exact integer sums, headroom from the LIVE count
+    # ---- positions
+    R = 64
+    o = torch.zeros(R, 3).cuda(); d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).cuda()
+    ri = torch.randint(0, R, (cap,), generator=g).cuda()
+    ts = torch.rand(cap, generator=g).cuda(); te = ts + 0.01
+    pc, sc_ = ops.points_from_rays(o, d, ri, ts, te, AABB, n_dev=nd)
+    pe, se = ops.points_from_rays(o, d, ri[:n_live].contiguous(), ts[:n_live].contiguous(), te[:n_live].contiguous(), AABB)
+    assert torch.equal(pc[:n_live], pe) and torch.equal(sc_[:n_live], se)
+
+
+def _room_scene(dtype='fp16', h=64, w=128, batch=2048, train_steps=0):
+    from perf_amd import synthetic
+    from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
+    torch.manual_seed(0)
+    scene = NeRFScene(dtype=dtype)
+    rays = gen_pano_rays(torch.eye(4), h, w)
+    dist, rgb = synthetic.room(rays.d)
+    pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, dist)
+    scene.train_conf.pixel_loss_batch_size = batch
+    scene.set_train(); scene.prepare_occupancy(pool); scene.nerf.reset_geo()
+    if train_steps:
+        opt = scene.make_optimizer(scene.nerf.geo_mlp, 0.0)
+        for i in range(train_steps):
+            scene.update_lr(opt, scene.train_conf.geo_optimizer, 0.05 + 0.15 * i / train_steps)
+            scene.train_one_step_geo(opt, pool, progress=0.5)
+    return scene, pool, rays, dist, rgb
+
+
+def test_sync_free_sampling_equals_synced_sampling():
+    """NeRFOCCRenderer with sample_capacity (device-side counts, no read-back) == the count -> read -> allocate path:
+    same packed_info, same samples on the live rows, same per-ray outputs -- on a trained scene so that the visibility
+    compaction really drops samples."""
+    scene, pool, rays, dist, rgb = _room_scene(train_steps=60)
+    scene.set_eval()
+    o, d = rays.o.reshape(-1, 3)[:4096].contiguous(), rays.d.reshape(-1, 3)[:4096].contiguous()
+    r = scene.renderer
+    near, far = torch.zeros(4096, 1).cuda(), torch.ones(4096, 1).cuda()
+    with torch.no_grad():
+        ref = r.render(scene.nerf, scene.estimator, o, d, near, far)
+        n = ref['ray_indices'].numel()
+        marched_ref = int(scene.estimator.sampling_ex(o, d, near_plane=r.near_plane, far_plane=r.far_plane,
+                                                      render_step_size=r.render_step_size).ray_indices.numel())
+        assert 0 < n < marched_ref, 'the scene must be trained enough for early termination to drop samples'
+        r.sample_capacity = marched_ref + 1000
+        got = r.render(scene.nerf, scene.estimator, o, d, near, far)
+        r.sample_capacity = None
+    assert int(got['n_samples_dev'].item()) == n and int(got['n_marched_dev'].item()) == marched_ref
+    assert torch.equal(got['packed_info'], ref['packed_info'])
+    for k in ('ray_indices', 't_starts', 't_ends', 'weights', 'trans'):
+        assert torch.equal(got[k][:n], ref[k]), k
+    for k in ('rgb', 'distance', 'opacities'):
+        assert torch.equal(got[k], ref[k]), k
+
+
+def test_truncated_capacity_is_detected_and_rendered_again():
+    """NeRFScene.render: a per-ray capacity that is too small truncates batches; the single read-back at the end of the
+    render detects it, raises the capacity and renders again -- the result equals the synced render."""
+    scene, pool, rays, dist, rgb = _room_scene(train_steps=30)
+    ref = scene.render(rays, ['rgb', 'distance'], batch_size=2048, sync_free=False)
+    scene._eval_spp_cap = 2                                       # certainly too small
+    got = scene.render(rays, ['rgb', 'distance'], batch_size=2048)
+    assert scene._eval_spp_cap > 2
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+
+
+def test_graph_replay_of_the_variable_count_step_equals_eager():
+    """The reference-faithful geometry and colour steps (marching, no-grad density pass, visibility compaction with a
+    data-dependent sample count, both fields, losses, backward, Adam) captured as hipGraphs: N replays == N eager steps,
+    bit for bit (same batches: the batch draw is replaced by a fixed slice; same random draws: injected)."""
+    from perf_amd.scene import Rays
+    results = {}
+    for mode in ('eager', 'graph'):
+        scene, pool, rays, dist, rgb = _room_scene(train_steps=40, batch=1024)
+        g = torch.Generator(device='cuda'); g.manual_seed(5)
+        B = 1024
+        idx = torch.randint(0, len(pool), (B,), device='cuda', generator=g)
+        pool.rand_ray_color_data = lambda bs, **kw: (Rays(pool.all_sup_rays.o[idx], pool.all_sup_rays.d[idx]), pool.all_sup_colors[idx],
+                                                      pool.all_sup_distances[idx], pool.all_sup_normals[idx])
+        rand = {'jitter': torch.rand(B, device='cuda', generator=g), 'noise': torch.rand(B, 1, device='cuda', generator=g),
+                'bg': torch.rand(B, 3, device='cuda', generator=g)}
+        scene.renderer.sample_capacity = B * 128
+        scene.sample_counters = torch.zeros(3, dtype=torch.int64, device='cuda')
+        out = {}
+        for kind in ('geo', 'app'):
+            net = scene.nerf.geo_mlp if kind == 'geo' else scene.nerf.app_mlp
+            opt = scene.make_optimizer(net, 0.0)
+            step = scene.train_one_step_geo if kind == 'geo' else scene.train_one_step_app
+            conf = scene.train_conf.geo_optimizer
+            if mode == 'eager':
+                for i in range(6):
+                    scene.update_lr(opt, conf, 0.1)
+                    step(opt, pool, progress=0.5, rand=rand)
+            else:
+                orig = step
+                wrapped = lambda o_, p_, progress, **kw: orig(o_, p_, progress=progress, rand=rand)
+                setattr(scene, 'train_one_step_geo' if kind == 'geo' else 'train_one_step_app', wrapped)
+                scene.update_lr(opt, conf, 0.1)
+                wrapped(opt, pool, progress=0.5)                       # step 1 eagerly (also the warm-up)
+                replay = scene.make_graphed_step(kind, opt, pool, warmup=0)
+                for i in range(5):
+                    replay(scene.lr_at(conf, 0.1), 0.5)
+            out[kind] = (net.params.detach().clone(), opt.exp_avg.clone(), int(opt.step_count))
+        out['counters'] = scene.sample_counters.tolist()
+        results[mode] = out
+    for kind in ('geo', 'app'):
+        pe, me, se = results['eager'][kind]; pg, mg, sg = results['graph'][kind]
+        assert se == sg == 6
+        assert torch.equal(pe, pg) and torch.equal(me, mg), kind
+    ce, cg = results['eager']['counters'], results['graph']['counters']
+    assert ce == cg and ce[2] == 12 and 0 < ce[1] < ce[0], (ce, cg)          # compaction dropped samples; 12 steps counted
+
+
+def test_adam_gate_skips_a_batch_without_samples(ops):
+    """perf_adam_step_dev with a zero gate leaves parameters, moments and (through perf_step_bookkeeping) the step count
+    untouched -- the reference returns before optimizer.step() when a batch has no samples (nerf.py:204-206)."""
+    n = 4096 + 7
+    g = torch.Generator().manual_seed(1)
+    p = torch.randn(n, generator=g).cuda(); m = torch.zeros(n).cuda(); v = torch.zeros(n).cuda()
+    grad = torch.randn(n, generator=g).cuda()
+    step = torch.zeros(1, dtype=torch.int32, device='cuda'); lr = torch.full((1,), 1e-2, device='cuda')
+    counters = torch.zeros(3, dtype=torch.int64, device='cuda')
+    p0 = p.clone()
+    for gate_val, want_step in ((0, 0), (17, 1), (0, 1)):
+        gate = _nd(gate_val)
+        before = p.clone()
+        ops.step_bookkeeping(step, gate, counters, _nd(100), gate)
+        ops.adam_step_dev(p, m, v, grad, step, lr, gate=gate)
+        assert int(step.item()) == want_step
+        assert torch.equal(p, before) == (gate_val == 0)
+    ref = torch.nn.Parameter(p0.clone()); ref.grad = grad.clone()
+    torch.optim.Adam([ref], lr=1e-2).step()
+    assert float((p - ref.detach()).abs().max()) < 2e-6
+    assert counters.tolist() == [300, 17, 3]
+
+
+def test_hashgrid_bwd_is_reentrant(ops):
+    """Two host threads call perf_hashgrid_bwd (+ perf_mlp_bwd) concurrently on two streams, many times; every result equals
+    the serial one bit for bit (fixed-point accumulation is order independent), and each thread sees its own
+    perf_last_error()."""
+    from perf_amd import _lib
+    from perf_amd.grid import MlpConfig
+    cfg = _cfg()
+    mlp = MlpConfig(n_levels=16, n_hidden_layers=1, n_output_dims=1, output_activation='Exponential')
+    g = torch.Generator().manual_seed(3)
+    spec = O.geo_spec()
+    params = O.init_field_params(spec); params[spec.n_net:] *= 1e4
+    w16 = ops.cast_params(params.cuda(), 'bf16')
+    jobs = []
+    for n in (30011, 65536):
+        x = _ray_points(n, g).cuda()
+        feat = ops.hashgrid_fwd(cfg, x, w16[spec.n_net:])
+        dout = torch.randn(n, 1, generator=g).cuda()
+        dfeat, dw, amax = ops.mlp_bwd(mlp, w16[:spec.n_net], feat, dout, want_absmax=True)
+        jobs.append((x, feat, dout, ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax), dw))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            x, feat, dout, ref_g, ref_w = jobs[k]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(25):
+                    dfeat, dw, amax = ops.mlp_bwd(mlp, w16[:spec.n_net], feat, dout, want_absmax=True)
+                    got = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax)
+                    if not (torch.equal(got, ref_g) and torch.equal(dw, ref_w)):
+                        errors.append((k, it, float((got - ref_g).abs().max())))
+                        break
+                # an invalid call in THIS thread must not leak its message into the other thread's error slot
+                bad = _lib.GridDesc(); bad.n_levels = 99 if k == 0 else 0
+                rc = _lib.load().perf_hashgrid_bwd_workspace_bytes(__import__('ctypes').byref(bad), 16)
+                msg = _lib.load().perf_last_error().decode()
+                if rc != -1 or (('99' in msg) != (k == 0)):
+                    errors.append((k, 'error slot', msg))
+            st.synchronize()
+        except Exception as e:           # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_gather_supervision_direct(ops):
+    """SupInfoPool.rand_ray_color_data's gather (sup_info.py:256-259) against torch indexing, incl. repeated indices and
+    skipped (NULL) sources."""
+    g = torch.Generator().manual_seed(11)
+    n_pool, n = 5003, 8192
+    src = {k: torch.randn(n_pool, w, generator=g).cuda() for k, w in (('o', 3), ('d', 3), ('color', 3), ('dist', 1), ('normal', 3))}
+    idx = torch.randint(0, n_pool, (n,), generator=g).cuda()
+    idx[:10] = idx[10:20]
+    out = ops.gather_supervision(idx, src['o'], src['d'], src['color'], src['dist'], src['normal'])
+    for k in src:
+        assert torch.equal(out[k], src[k][idx]), k
+    part = ops.gather_supervision(idx, o_all=src['o'], dist_all=src['dist'])
+    assert part['d'] is None and part['color'] is None and torch.equal(part['dist'], src['dist'][idx])
+    empty = ops.gather_supervision(idx[:0], src['o'], src['d'], src['color'], src['dist'], src['normal'])
+    assert empty['o'].shape == (0, 3)
+
+
+def test_contract_to_unisphere_matches_reference_golden(golden_dir):
+    """The `unbounded` contraction (ngp_nerf.py:43-65; never enabled by PeRF) on the GPU against the vector produced by the
+    reference's own function, and NGPDensityField(unbounded=True) runs through it."""
+    from perf_amd.fields import NGPDensityField, contract_to_unisphere
+    g = np.load(f'{golden_dir}/field_bits.npz')
+    x = torch.from_numpy(g['ct_x']).cuda()
+    y = contract_to_unisphere(x, torch.tensor(AABB).cuda()).cpu().numpy()
+    assert np.abs(y - g['ct_y']).max() <= 1e-6
+    f = NGPDensityField(AABB, unbounded=True, dtype='fp16')
+    out = f(x * 3.0)
+    assert out.shape == (x.shape[0], 1) and torch.isfinite(out).all() and float(out.min()) >= 0.0
+
+
+def test_march_per_ray_span_check_handles_unnormalised_directions(ops):
+    """The coarse empty-space skip assumes a 64-interval chunk spans few cells; a direction of length 4 breaks that, and the
+    kernel must then take the exhaustive test for that ray: results equal the oracle (which has no skip)."""
+    from perf_amd.nerfacc_impl import OccGridEstimator
+    g = torch.Generator().manual_seed(2)
+    res = 64
+    occ = (torch.rand(res, res, res, generator=g) < 0.02).numpy()
+    est = OccGridEstimator(AABB, resolution=res).cuda()
+    est.set_binaries(torch.from_numpy(occ.reshape(-1)).cuda())
+    R = 257
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    d[::3] *= 4.0                                                   # unnormalised
+    o = (torch.rand(R, 3, generator=g) - 0.5) * 0.5
+    step = 2e-3
+    sm = est.sampling_ex(o.cuda(), d.cuda(), near_plane=0.0, far_plane=1.0, render_step_size=step, early_stop_eps=0.0)
+    ri, ts, te, packed = O.occ_march(o.numpy(), d.numpy(), occ, np.asarray(AABB, np.float32), 0.0, 1.0, step, None, None)
+    assert np.array_equal(sm.ray_indices.cpu().numpy(), ri) and np.array_equal(sm.t_starts.cpu().numpy(), ts)

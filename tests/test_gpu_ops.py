@@ -451,7 +451,7 @@ def test_pdf_resample_bit_exact(ops):
         assert (np.diff(got, axis=1) >= 0).all()               # sorted edges: a size-independent property
 
 
-def test_hashgrid_bwd_coded_owners_equal_streaming_owners(ops, monkeypatch):
+def test_hashgrid_bwd_coded_owners_equal_streaming_owners(ops):
     """The hashed owners that stream 4-byte tile codes (default) and the ones that stream positions compute the same
     fixed-point sums: bit-identical tables, also for ragged sizes, ray-coherent bursts and positions outside the unit
     cube (which send a level back to the generic owners through the escape flag)."""
@@ -473,13 +473,11 @@ def test_hashgrid_bwd_coded_owners_equal_streaming_owners(ops, monkeypatch):
         dfeat = torch.randn(cfg.n_levels, n, 2, generator=g).cuda()
         amax = dfeat.abs().amax(dim=(1, 2)).contiguous()
         amax = torch.cat([amax, torch.zeros(16 - amax.numel(), device='cuda')])
-        monkeypatch.delenv('PERF_BWD_NO_CODES', raising=False)
         a_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax)
         a_f32 = ops.hashgrid_bwd(cfg, x, dfeat)
-        monkeypatch.setenv('PERF_BWD_NO_CODES', '1')
-        b_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax)
-        b_f32 = ops.hashgrid_bwd(cfg, x, dfeat)
-        monkeypatch.delenv('PERF_BWD_NO_CODES', raising=False)
+        # a workspace without room for the tile codes selects the position-streaming owners (include/perf_hip.h)
+        b_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, use_codes=False)
+        b_f32 = ops.hashgrid_bwd(cfg, x, dfeat, use_codes=False)
         assert torch.equal(a_fix, b_fix), (kind, float((a_fix - b_fix).abs().max()))
         assert float((a_f32 - b_f32).abs().max()) <= 1e-4 * float(b_f32.abs().max()), kind
 

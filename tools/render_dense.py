@@ -51,15 +51,19 @@ for i in range(dense.n_poses):
     poses.append(p)
 
 fh, fw = 512, 1024
-def frame(p):
+def frame_eager(p):
     r = gen_pano_rays(p, fh, fw)
-    return scene.render(r, ['rgb', 'distance'])
+    return scene.render(r, ['rgb', 'distance'], batch_size=32768)
 
+# ONE hipGraph per frame: ray generation from a device-resident pose + 16 eval batches of 32,768 rays (nerf.py:86)
+frame = scene.make_graphed_render(fh, fw, ('rgb', 'distance'), batch_size=32768)
 for p in poses[:3]:
     frame(p)
 torch.cuda.synchronize()
+ref = frame_eager(poses[1]); got = frame(poses[1])
+same = bool(torch.equal(ref['rgb'], got['rgb']) and torch.equal(ref['distance'], got['distance']))
 ops.start_kernel_timing()
-frame(poses[0]); torch.cuda.synchronize()
+frame_eager(poses[0]); torch.cuda.synchronize()
 kern = ops.stop_kernel_timing()
 t0 = time.perf_counter()
 for p in poses:
@@ -67,7 +71,14 @@ for p in poses:
 torch.cuda.synchronize()
 t = time.perf_counter() - t0
 checksum = float(last['rgb'].double().sum())
-print(json.dumps({'config': 'render_dense: %d poses, %dx%d panoramic frames, %s, variable-count sampling' % (len(poses), fw, fh, args.dtype),
+t0 = time.perf_counter()
+for p in poses[:60]:
+    frame_eager(p)
+torch.cuda.synchronize()
+t_eager = (time.perf_counter() - t0) / 60
+print(json.dumps({'config': 'render_dense: %d poses, %dx%d panoramic frames in 16 hipGraph-captured 32768-ray batches, %s, variable-count sampling' % (len(poses), fw, fh, args.dtype),
                   'frames_per_s': len(poses) / t, 'rays_per_s': len(poses) * fh * fw / t, 'seconds': t,
+                  'eager_sync_free_frames_per_s': 1.0 / t_eager, 'graphed_frame_equals_eager_frame': same,
+                  'per_ray_sample_capacity': frame.state['per_ray'],
                   'pose_sampler_host_s': t_sampler, 'last_frame_rgb_sum': checksum,
                   'kernel_ms_one_frame': {k: round(n * ms, 3) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])}}, indent=1))
