@@ -70,6 +70,7 @@ def parse():
     ap.add_argument('--no-psnr', action='store_true')
     ap.add_argument('--psnr-geo-iters', type=int, default=3000, help='configs/nerf.yaml:25 raw_phase_iter_geo')
     ap.add_argument('--psnr-app-iters', type=int, default=1500, help='configs/nerf.yaml:26 raw_phase_iter_app')
+    ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='payload of the gradient all-reduce (N > 1)')
     ap.add_argument('--sustain-seconds', type=float, default=1.0, help='length of the second, longer measurement (0 = off)')
     return ap.parse_args()
 
@@ -92,7 +93,7 @@ def cpu_baseline(spp, n_rays):
     def one():
         out = O.occ_render(o, d, geo, app, occ, [-1, -1, -1, 1, 1, 1], training=True,
                            t0=np.zeros(len(o), np.float32), bg_color=torch.rand(len(o), 3), dist_noise=torch.rand(len(o), 1),
-                           near=0.0, far=10.0, step=step, early_stop_eps=1e-4, max_steps=spp)
+                           near=0.0, far=1.5, step=step, early_stop_eps=1e-4, max_steps=spp)
         loss, _, _ = O.geo_step_loss(out, gt, 0.25)
         geo.grad = None
         loss.backward()
@@ -180,6 +181,7 @@ def main():
     torch.manual_seed(0)
     scene = NeRFScene(dtype=args.dtype)
     tc = scene.train_conf
+    scene.comm_dtype = args.comm_dtype
     if args.scaling == 'weak':
         rays_local = args.rays_per_gpu                               # 8192 rays on every GPU
     else:
@@ -197,7 +199,7 @@ def main():
     scene.estimator.set_binaries(torch.ones(256 ** 3, dtype=torch.uint8, device=dev))
     r = scene.renderer
     r.render_step_size = 0.99 / args.spp
-    r.far_plane = 10.0
+    r.far_plane = 1.5                                                  # the reference's value (nerf_renderer.py:150); the lattice ends at 0.99
     r.early_stop_eps = 0.0 if args.no_prepass else 1e-4
     r.max_steps = args.spp
     rays_per_step = rays_local if args.mode != 'render' else 32768

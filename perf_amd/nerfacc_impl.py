@@ -191,7 +191,7 @@ class OccGridEstimator(nn.Module):
             # nerfacc starts a ray's march where it enters the box; with a lattice that is shorter than [near, far] the
             # origin must be anchored there too, or rays that start outside the box lose their samples.  (PeRF's
             # far - near = 1.5 < diagonal with cameras inside the box never takes this branch.)
-            lo = torch.tensor(aabb[:3], device=dev); hi = torch.tensor(aabb[3:], device=dev)
+            lo, hi = self.aabbs[0, :3], self.aabbs[0, 3:]            # (device buffer: no host copy, capture safe)
             inv = 1.0 / rays_d
             t1 = (lo - rays_o) * inv; t2 = (hi - rays_o) * inv
             t_in = torch.fmin(t1, t2).nan_to_num(nan=-float('inf')).amax(-1)

@@ -193,6 +193,9 @@ class NeRFScene:
         self.skip_unused_color = False
         self.overlap_comm = True       # DP: overlap the gradient all-reduce with the next step's prefetch
         self.graph_steps = True        # train_one_episode replays hipGraph-captured steps when it can
+        # DP payload of the gradient all-reduce: 'fp32' (exact sum, 26.6 MB) or 'bf16' (13.3 MB: every rank's gradient is
+        # rounded to bf16 and summed in bf16 by RCCL -- ~2^-9 relative noise on a quantity Adam normalises anyway)
+        self.comm_dtype = 'fp32'
         self._geo_pre = None
         self._ratio_dev = torch.zeros((), dtype=torch.float32, device='cuda')   # distortion-loss ramp min(2*progress, 1)
         # device-side sample statistics {marched, kept, steps} (int64 [3]); None = not collected.  bench.py reads them
@@ -402,20 +405,26 @@ class NeRFScene:
                     grad[n:].copy_(n_kept)
                 else:
                     grad[n:].fill_(float(n_kept if n_kept is not None else 1))
+            payload = grad
+            if self.comm_dtype == 'bf16':
+                if grad.numel() == n + 1:
+                    grad[n:].clamp_(max=1.0)               # the count slot only has to say "some / none": exact in bf16
+                payload = grad.to(torch.bfloat16)
             if overlap is not None:
-                work = dist.all_reduce(grad, op=dist.ReduceOp.SUM, async_op=True)
+                work = dist.all_reduce(payload, op=dist.ReduceOp.SUM, async_op=True)
                 overlap()
                 work.wait()
             else:
-                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+            if payload is not grad:
+                grad.copy_(payload)
             if grad.numel() == n + 1:
                 gate = grad[n:].to(torch.int64)
-        net.params.grad = grad
+        net.params.grad = grad[:n]                 # (without the count slot of the data-parallel buffer)
         if isinstance(optimizer, FusedAdam):
             optimizer.step(gate=gate, counters=self.sample_counters, n_marched=n_marched)
         else:
             if gate is None or int(gate.item()) > 0:
-                net.params.grad = grad[:n]
                 optimizer.step()
             net.params.grad = None
         self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
@@ -455,7 +464,11 @@ class NeRFScene:
         w16 = geo.working_copy()
         feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:], n_dev=n_dev)
         sig = ops.mlp_fwd(geo.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
-        rgbs = None if self.skip_unused_color else (st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel, n_dev))
+        # The colour render of this step (query key 'rgb', nerf.py:197-201) feeds no loss term (:208-252).  Under data
+        # parallelism it is therefore issued AFTER the gradient all-reduce has been launched: the colour field's encode +
+        # MLP + accumulation run on the compute stream while RCCL moves the gradient over xGMI on its own stream.
+        defer_color = (dist_info[0] is not None and self.overlap_comm and not self.skip_unused_color and st['rgbs'] is None)
+        rgbs = None if (self.skip_unused_color or defer_color) else (st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel, n_dev))
         w, T, op, dist_r, col, dl = ops.composite_distloss_fwd(sig.view(-1), rgbs, ts, te, packed)
         noise = rand['noise']            # (the background colour the reference also draws, :185, is not used by this step)
         if not self._capturing:
@@ -465,8 +478,13 @@ class NeRFScene:
         dsig = ops.composite_distloss_bwd(sig.view(-1), ts, te, packed, w, T, op, dist_r, g_op, g_dist, 1.0, scale_dev=sc[2:3])
         grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1), n_dev=n_dev, extra=extra)
         self.last_losses['depth_loss'] = sc[0]; self.last_losses['dist_loss'] = sc[1]
-        overlap = (lambda: setattr(self, '_geo_pre', self._geo_prefetch(sup_pool, rand_in, generator))) \
-            if (self.overlap_comm and prefetch_next and dist_info[0] is not None) else None
+        overlap = None
+        if self.overlap_comm and dist_info[0] is not None:
+            def overlap():
+                if defer_color:
+                    self.last_colors = ops.accumulate_fwd(w, self.nerf.rgb_at(x01, sel, n_dev), packed)
+                if prefetch_next:
+                    self._geo_pre = self._geo_prefetch(sup_pool, rand_in, generator)
         self._apply_grad(geo, grad, optimizer, dist_info, overlap, n_kept=n_dev if n_dev is not None else x01.shape[0],
                          n_marched=st['n_marched_dev'])
         self.global_iter_step_geo += 1

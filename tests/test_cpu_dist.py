@@ -70,3 +70,56 @@ def test_pool_slicing_matches_reference_stream():
     assert torch.equal(torch.cat([p[0].d for p in parts]), full[0].d)
     assert torch.equal(torch.cat([p[1] for p in parts]), full[1])
     assert torch.equal(torch.cat([p[2] for p in parts]), full[2])
+
+
+# ---- NeRFScene._apply_grad itself with world_size 2 (gloo, CPU tensors): the real product function ----------------------
+def _apply_worker(rank, world, port, out, comm_dtype):
+    """Both ranks hold the same parameters; rank r contributes gradient g_r and sample count c_r.  Three steps: both ranks
+    have samples; only rank 1 has; none has (the step must be skipped on BOTH ranks)."""
+    import types
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from perf_amd.scene import NeRFScene
+    n = 1000
+    net = types.SimpleNamespace(params=torch.nn.Parameter(torch.linspace(-1, 1, n)))
+    opt = torch.optim.Adam([net.params], lr=1e-2)
+    me = types.SimpleNamespace(comm_dtype=comm_dtype, sample_counters=None, _capturing=False, _steps_since_check=-10 ** 9)
+    hist = []
+    g = torch.Generator().manual_seed(100 + rank)
+    for counts in ((5, 7), (0, 3), (0, 0)):
+        grad = torch.zeros(n + 1)
+        if counts[rank] > 0:
+            grad[:n] = torch.randn(n, generator=g)
+        ran = {'overlap': False}
+        NeRFScene._apply_grad(me, net, grad, opt, (dist, rank, world), lambda: ran.__setitem__('overlap', True), n_kept=counts[rank])
+        assert ran['overlap']
+        hist.append(net.params.detach().clone())
+    if rank == 0:
+        torch.save(hist, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_apply_grad_world2_sums_gradients_and_skips_empty_steps(tmp_path):
+    import pytest
+    for comm_dtype, tol in (('fp32', 1e-6), ('bf16', 2e-2)):
+        out = str(tmp_path / f'h_{comm_dtype}.pt')
+        mp.spawn(_apply_worker, args=(2, _free_port(), out, comm_dtype), nprocs=2, join=True)
+        hist = torch.load(out)
+        # single-process reference: Adam on the summed gradients of the steps that had samples somewhere
+        p = torch.nn.Parameter(torch.linspace(-1, 1, 1000)); opt = torch.optim.Adam([p], lr=1e-2)
+        gens = [torch.Generator().manual_seed(100 + r) for r in range(2)]
+        ref = []
+        for counts in ((5, 7), (0, 3), (0, 0)):
+            total = torch.zeros(1000)
+            for r in range(2):
+                if counts[r] > 0:
+                    total += torch.randn(1000, generator=gens[r])
+            if sum(counts) > 0:
+                p.grad = total
+                opt.step()
+            ref.append(p.detach().clone())
+        for a, b in zip(hist, ref):
+            # Adam's first steps are sign-like: compare the travelled distance, tightly for the exact fp32 payload
+            assert float((a - b).abs().max()) <= tol, (comm_dtype, float((a - b).abs().max()))
+        assert torch.equal(hist[2], hist[1])                        # the all-empty step changed nothing
