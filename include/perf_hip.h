@@ -155,11 +155,17 @@ int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const fl
  * when any field comes within 4x of the int32 range (then repeat the call with level_absmax == NULL).
  * workspace: 16-byte aligned device scratch of perf_hashgrid_bwd_workspace_bytes(grid, n) bytes (replica slabs of
  * the coarse levels + 4 bytes per (sample, hashed level) of tile codes; a workspace without room for the codes
- * is accepted and selects the slower position-streaming owners).  With n_dev the headroom follows the live count. */
+ * is accepted and selects the slower position-streaming owners).  With n_dev the headroom follows the live count.
+ * headroom_state (device, 2*PERF_MAX_LEVELS int32, zero-initialised by the caller and then owned by the sequence of
+ * calls on one table, may be NULL): closes the loop on the headroom -- every call records the largest field each level
+ * reached and the next call's h_l is corrected to keep it between 2^23 and 2^27 units (entries next to a panorama's
+ * common ray origin collect 30x the average number of contributions; hashed levels far fewer than the static guess
+ * allows).  With the state the first call starts 3 bits on the safe side of the static h_l and h_l ranges over [4, 28]. */
 int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n);
 int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
                       float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
-                      int32_t* overflow_flag, void* workspace, int64_t workspace_bytes, void* stream);
+                      int32_t* overflow_flag, int32_t* headroom_state, void* workspace, int64_t workspace_bytes,
+                      void* stream);
 
 /* The integer half of the encoding: idx[(l*n + i)*8 + c] = absolute table entry (level offset included) of corner c
  * (bit0 = x, bit1 = y, bit2 = z) of sample i at level l.  Used for the arbitrarily-often differentiable composition
@@ -169,6 +175,18 @@ int perf_hashgrid_corners(const perf_grid_desc* grid, const float* x01, int32_t*
 /* tcnn kernel_grid_backward_input: dL/dx01 [n,3] from dfeat and the table (fp32 table). */
 int perf_hashgrid_bwd_input(const perf_grid_desc* grid, const float* x01, const float* dfeat,
                             const float* table, float* dx, int64_t n, void* stream);
+
+/* Second order (tcnn kernel_grid_backward_input_backward_*): the backward of perf_hashgrid_bwd_input.  The input gradient
+ * gx = perf_hashgrid_bwd_input(x01, dfeat, table) is linear in dfeat and in the table and non-linear in x01; given
+ * ggx = dL/d gx [n,3] this writes d_dfeat [L,n,2] = dL/d dfeat (may be NULL) and d_x [n,3] = dL/d x01 through gx (the
+ * Hessian-vector product of the interpolation weights; may be NULL; needs dfeat).  fp32 table.  Consumer:
+ * SphereDistanceField, modules/geo_predictors/pano_joint_predictor.py:50-69 (autograd.grad(..., create_graph=True)). */
+int perf_hashgrid_bwd_bwd_input(const perf_grid_desc* grid, const float* x01, const float* dfeat, const float* table,
+                                const float* ggx, float* d_dfeat, float* d_x, int64_t n, void* stream);
+/* ... and its piece w.r.t. the table: grad_table [total*2] fp32 = dL/d table through gx (overwritten: zeroed, then
+ * scattered with global fp32 atomics -- this consumer's batches are ~10^4 points). */
+int perf_hashgrid_bwd_bwd_param(const perf_grid_desc* grid, const float* x01, const float* dfeat, const float* ggx,
+                                float* grad_table, int64_t n, void* stream);
 
 /* ---- 64-wide MLP on MFMA ----------------------------------------------------------------- */
 

@@ -49,9 +49,11 @@ _SIGS = {
     'perf_hashgrid_fwd2': (c_int, [POINTER(GridDesc), P, P, P, P, P, c_int64, c_int, P]),
     'perf_hashgrid_fwd_f32': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
     'perf_hashgrid_bwd_workspace_bytes': (c_int64, [POINTER(GridDesc), c_int64]),
-    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P, c_int, P, P, P, c_int64, P]),
+    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P, c_int, P, P, P, P, c_int64, P]),
     'perf_hashgrid_corners': (c_int, [POINTER(GridDesc), P, P, c_int64, P]),
     'perf_hashgrid_bwd_input': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),
+    'perf_hashgrid_bwd_bwd_input': (c_int, [POINTER(GridDesc), P, P, P, P, P, P, c_int64, P]),
+    'perf_hashgrid_bwd_bwd_param': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),
     'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, P, c_int, P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
     'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, P, P, P, P, P, c_int64, c_int64, P, c_int, P]),

@@ -40,6 +40,7 @@ static int fill_params(const perf_grid_desc* g, GridParams* p) {
     return PERF_OK;
 }
 
+constexpr int kHeadroomStartBias = 3;
 constexpr uint32_t kPrimeY = 2654435761u;
 constexpr uint32_t kPrimeZ = 805459861u;
 
@@ -94,6 +95,7 @@ __device__ __forceinline__ void corner_weights(const float f[3], bool smooth, fl
 // level l handled by (group, pass).  L <= 16: pass 0 -> g, pass 1 -> L-1-g (if different) -- a coarse (small) and a
 // fine (large) table per group.  Deeper grids (L <= 24) add pass 2 -> 16+g; their tables exceed the L2 anyway.
 constexpr int kFwdPasses = 3;
+constexpr int64_t kFwdMaxChunks = 0;        // 0: one workgroup per chunk (uncapped); see perf_hashgrid_fwd
 __device__ __forceinline__ int level_of(int group, int pass, int L) {
     if (pass == 2) return (16 + group < L) ? 16 + group : -1;
     const int Lc = L < 16 ? L : 16;
@@ -112,12 +114,17 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const 
     // sees the whole table -- used to measure what the level-group <-> XCD pinning is worth.
     const int nchunks = (int)(gridDim.x >> 3);
     const int group = xcd_affinity ? (int)(blockIdx.x & 7) : (int)((blockIdx.x >> 3) & 7);
-    const int64_t chunk = xcd_affinity ? (int64_t)(blockIdx.x >> 3)
-                                       : (int64_t)(blockIdx.x & 7) * ((nchunks + 7) >> 3) + (int64_t)(blockIdx.x >> 6);
-    const int64_t i = chunk * 256 + threadIdx.x;
-    if (i >= live_count(n, n_dev) || (!xcd_affinity && chunk >= nchunks)) return;       // (n stays the level stride)
-    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+    const int64_t chunk0 = xcd_affinity ? (int64_t)(blockIdx.x >> 3)
+                                        : (int64_t)(blockIdx.x & 7) * ((nchunks + 7) >> 3) + (int64_t)(blockIdx.x >> 6);
+    if (!xcd_affinity && chunk0 >= nchunks) return;
+    const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+    // chunk-stride loop: a capacity-sized launch (n >> n_live) is capped at `nchunks` chunks per level group, so that
+    // it does not pay for tens of thousands of workgroups that only find out that they have nothing to do
+    for (int64_t chunk = chunk0; chunk * 256 < n_live; chunk += nchunks) {
+    const int64_t i = chunk * 256 + threadIdx.x;
+    if (i >= n_live) break;
+    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
 #pragma unroll
     for (int pass = 0; pass < kFwdPasses; ++pass) {
         const int l = level_of(group, pass, gp.n_levels);
@@ -136,6 +143,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const 
             a1 = fmaf(w[k], T16::hi(v[k]), a1);
         }
         feat[(int64_t)l * n + i] = T16::pack(a0, a1);
+    }
     }
 }
 
@@ -715,6 +723,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    float2* __restrict__ grad, float2* __restrict__ ws,
                                                                    const float* __restrict__ level_absmax,
                                                                    int32_t* __restrict__ overflow_flag,
+                                                                   int32_t* __restrict__ hr_state,
                                                                    const uint32_t* __restrict__ codes,
                                                                    const uint32_t* __restrict__ escape, int64_t n,
                                                                    const int64_t* __restrict__ n_dev) {
@@ -758,7 +767,15 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         // unit).  Derived from the LIVE sample count, so a capacity-sized launch keeps the resolution of an exact one.
         const unsigned long long fan = (8ull * (unsigned long long)n_live + size - 1ull) / size;     // ceil(8 n / size)
         int h = (fan <= 1ull ? 0 : 64 - __clzll((long long)(fan - 1ull))) + 6;                      // ceil(log2(fan)) + 6
-        h = h < 12 ? 12 : (h > 24 ? 24 : h);
+        if (hr_state) {
+            // Closed loop (caller-owned state, see perf_hashgrid_bwd): the static guess is corrected by what the fields of
+            // the PREVIOUS calls really reached -- entries near a panorama's common ray origin sum 30x the average number
+            // of contributions, hashed levels far fewer than the guess allows.  Starts 3 bits on the safe side.
+            h += hr_state[l] + kHeadroomStartBias;
+            h = h < 4 ? 4 : (h > 28 ? 28 : h);
+        } else {
+            h = h < 12 ? 12 : (h > 24 ? 24 : h);
+        }
         const int sh = 31 - h - e;                                    // units per 1.0 = 2^sh
         cx.to_fixed = ldexpf(1.0f, sh);
         from_fixed = ldexpf(1.0f, -sh);
@@ -810,6 +827,11 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     //  if NO field of ANY tile ends in the band [2^29, 2^32 - 2^29) -- i.e. if the largest sum of the whole table exceeds
     //  7x the level at which smaller sums already raise the flag while none of them lands there)
     if (FIXED && overflow_flag && field_max >= (1 << 29)) atomicOr(overflow_flag, 1);
+    if (FIXED && hr_state) {            // largest |field| of the level, for the feedback (one atomic per wave)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) field_max = max(field_max, __shfl_xor(field_max, off));
+        if ((threadIdx.x & 63) == 0 && field_max > 0) atomicMax(&hr_state[PERF_MAX_LEVELS + l], field_max);
+    }
     if (tp.dbg_off > 0 && threadIdx.x == 0) {      // slot = position in plain level order
         int slot = (int)t * R + rep;
         for (int k = 0; k < l; ++k) slot += tp.tiles_of[k] * tp.replicas_of[k];
@@ -841,8 +863,22 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(GridParams gp,
 
 // sum the replica slabs (ws[level][replica][entry]) of the replicated (coarse) levels into the gradient table
 __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp, TileParams tp, const float2* __restrict__ ws,
-                                                                  float2* __restrict__ grad) {
+                                                                  float2* __restrict__ grad, int32_t* __restrict__ hr_state) {
     const int l = blockIdx.y;
+    if (l == gp.n_levels) {
+        // ---- headroom feedback (one thread per level): keep the largest field of a level between 2^23 and 2^27 units.
+        //      Above: add the excess bits at once (+1); below: give one bit back per call.  Deterministic: the state is a
+        //      function of the call history only.
+        if (hr_state && blockIdx.x == 0 && (int)threadIdx.x < gp.n_levels) {
+            const int fm = hr_state[PERF_MAX_LEVELS + threadIdx.x];
+            int adj = hr_state[threadIdx.x];
+            if (fm >= (1 << 27)) adj += (32 - __clz(fm)) - 27 + 1;
+            else if (fm < (1 << 23) && adj > -24) adj -= 1;
+            hr_state[threadIdx.x] = adj;
+            hr_state[PERF_MAX_LEVELS + threadIdx.x] = 0;
+        }
+        return;
+    }
     const int R = tp.replicas_of[l];
     if (l >= gp.n_levels || R <= 1) return;
     const uint32_t size = gp.size[l];
@@ -891,6 +927,97 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_input_kernel(GridParams gp, 
     dx[3 * i] = gx; dx[3 * i + 1] = gy; dx[3 * i + 2] = gz;
 }
 
+// ---- second order: the backward of the input gradient (tcnn kernel_grid_backward_input_backward_*) --------------------
+// The input gradient  gx_i = sum_l sum_c (d w_c / d x_i) (theta[idx_c] . dy_l)  is linear in dy and in the table and
+// non-linear in x.  Given gg = dL/d gx [n,3] its backward has three pieces:
+//   d_dy[l]      = sum_c W'_c theta[idx_c]                     with  W'_c = sum_i gg_i d w_c / d x_i
+//   d_theta[idx] += W'_c dy_l                                  (hashgrid_bwd_bwd_param_kernel)
+//   d_x_j        = sum_l sum_c (sum_i gg_i d^2 w_c / d x_i d x_j) (theta[idx_c] . dy_l)
+// with  w_c = prod_d u_d,  u_d = s_d or 1 - s_d,  s_d = f_d (Linear) or f_d^2 (3 - 2 f_d) (Smoothstep),  d s_d / d x_d = s' scale.
+// Consumer: SphereDistanceField (modules/geo_predictors/pano_joint_predictor.py:50-69: autograd.grad(distance, directions,
+// create_graph=True) followed by a loss on that gradient).
+struct Interp { float s[3], ds[3], dds[3]; };        // per dimension: value, d/dx, d^2/dx^2 (scale folded in)
+
+__device__ __forceinline__ Interp interp_of(const float f[3], bool smooth, float scale) {
+    Interp t;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (smooth) { t.s[d] = f[d] * f[d] * (3.f - 2.f * f[d]); t.ds[d] = 6.f * f[d] * (1.f - f[d]) * scale; t.dds[d] = (6.f - 12.f * f[d]) * scale * scale; }
+        else { t.s[d] = f[d]; t.ds[d] = scale; t.dds[d] = 0.f; }
+    }
+    return t;
+}
+
+// W'_c = sum_i gg_i d w_c / d x_i   for corner c (bit0 = x, bit1 = y, bit2 = z)
+__device__ __forceinline__ float corner_dw_dot(const Interp& t, int c, const float gg[3]) {
+    const float u[3] = {(c & 1) ? t.s[0] : 1.f - t.s[0], (c & 2) ? t.s[1] : 1.f - t.s[1], (c & 4) ? t.s[2] : 1.f - t.s[2]};
+    const float sg[3] = {(c & 1) ? 1.f : -1.f, (c & 2) ? 1.f : -1.f, (c & 4) ? 1.f : -1.f};
+    return gg[0] * sg[0] * t.ds[0] * u[1] * u[2] + gg[1] * sg[1] * t.ds[1] * u[0] * u[2] + gg[2] * sg[2] * t.ds[2] * u[0] * u[1];
+}
+
+__global__ __launch_bounds__(256) void hashgrid_bwd_bwd_input_kernel(GridParams gp, const float* __restrict__ x01,
+                                                                     const float2* __restrict__ dy, const float2* __restrict__ table,
+                                                                     const float* __restrict__ ggx, float2* __restrict__ d_dy,
+                                                                     float* __restrict__ d_x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+    const float gg[3] = {ggx[3 * i], ggx[3 * i + 1], ggx[3 * i + 2]};
+    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+    float hx[3] = {0.f, 0.f, 0.f};
+    for (int l = 0; l < gp.n_levels; ++l) {
+        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+        const Interp t = interp_of(c.f, smooth, gp.scale[l]);
+        const float2* tb = table + gp.offset[l];
+        const float2 g = dy ? dy[(int64_t)l * n + i] : make_float2(0.f, 0.f);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float2 v = tb[c.idx[k]];
+            a0 += corner_dw_dot(t, k, gg) * v.x;
+            a1 += corner_dw_dot(t, k, gg) * v.y;
+            if (d_x) {
+                const float dot = v.x * g.x + v.y * g.y;
+                const float u[3] = {(k & 1) ? t.s[0] : 1.f - t.s[0], (k & 2) ? t.s[1] : 1.f - t.s[1], (k & 4) ? t.s[2] : 1.f - t.s[2]};
+                const float sg[3] = {(k & 1) ? 1.f : -1.f, (k & 2) ? 1.f : -1.f, (k & 4) ? 1.f : -1.f};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int p = (j + 1) % 3, q = (j + 2) % 3;
+                    // sum_i gg_i d^2 w / dx_i dx_j: the diagonal term and the two mixed terms
+                    const float h = gg[j] * sg[j] * t.dds[j] * u[p] * u[q]
+                                  + gg[p] * sg[p] * t.ds[p] * sg[j] * t.ds[j] * u[q]
+                                  + gg[q] * sg[q] * t.ds[q] * sg[j] * t.ds[j] * u[p];
+                    hx[j] += h * dot;
+                }
+            }
+        }
+        if (d_dy) d_dy[(int64_t)l * n + i] = make_float2(a0, a1);
+    }
+    if (d_x) { d_x[3 * i] = hx[0]; d_x[3 * i + 1] = hx[1]; d_x[3 * i + 2] = hx[2]; }
+}
+
+// d_theta[idx_c] += W'_c dy_l   (one thread per (sample, level); global fp32 atomics: this consumer's batches are 10^4
+// points, see the comment on hashgrid_bwd_atomic_kernel for the rate)
+__global__ __launch_bounds__(256) void hashgrid_bwd_bwd_param_kernel(GridParams gp, const float* __restrict__ x01,
+                                                                     const float2* __restrict__ dy, const float* __restrict__ ggx,
+                                                                     float* __restrict__ grad, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= n || l >= gp.n_levels) return;
+    const float2 g = dy[(int64_t)l * n + i];
+    if (g.x == 0.f && g.y == 0.f) return;
+    const float gg[3] = {ggx[3 * i], ggx[3 * i + 1], ggx[3 * i + 2]};
+    const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+    const Interp t = interp_of(c.f, gp.interpolation == PERF_INTERP_SMOOTHSTEP, gp.scale[l]);
+    float* tb = grad + 2 * gp.offset[l];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float w = corner_dw_dot(t, k, gg);
+        unsafeAtomicAdd(tb + 2 * (uint64_t)c.idx[k], w * g.x);
+        unsafeAtomicAdd(tb + 2 * (uint64_t)c.idx[k] + 1, w * g.y);
+    }
+}
+
 static inline unsigned grouped_grid(int64_t n) { return (unsigned)(div_up(n, 256) * 8); }
 
 }  // namespace perf
@@ -906,7 +1033,11 @@ extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, c
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(x01 && table16 && feat16, "NULL pointer");
     static const int xcd_affinity = getenv("PERF_FWD_NO_XCD_AFFINITY") ? 0 : 1;
-    dim3 g(xcd_affinity ? grouped_grid(n) : (unsigned)(div_up(div_up(n, 256), 8) * 64)), b(256);
+    // chunks (of 256 samples) per level group in one launch; beyond that the workgroups loop (experiment knob, read once)
+    static const int64_t max_chunks = getenv("PERF_FWD_MAX_CHUNKS") ? atoll(getenv("PERF_FWD_MAX_CHUNKS")) : kFwdMaxChunks;
+    int64_t chunks = div_up(n, 256);
+    if (xcd_affinity && max_chunks > 0 && chunks > max_chunks) chunks = max_chunks;
+    dim3 g(xcd_affinity ? (unsigned)(chunks * 8) : (unsigned)(div_up(div_up(n, 256), 8) * 64)), b(256);
     if (dtype == PERF_DTYPE_BF16)
         hipLaunchKernelGGL(hashgrid_fwd_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, xcd_affinity);
     else if (dtype == PERF_DTYPE_FP16)
@@ -990,7 +1121,8 @@ extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid,
 
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
                                  float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
-                                 int32_t* overflow_flag, void* workspace, int64_t workspace_bytes, void* stream) {
+                                 int32_t* overflow_flag, int32_t* headroom_state, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
     GridParams gp;
     int rc = fill_params(grid, &gp);
     if (rc) return rc;
@@ -1035,10 +1167,10 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         // every level goes through the atomics fallback
     } else if (level_absmax)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
-            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, codes, escape, n, n_dev);
+            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, headroom_state, codes, escape, n, n_dev);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
-            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, codes, escape, n, n_dev);
+            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, nullptr, codes, escape, n, n_dev);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (tp.atomic_levels && n > 0) {
         if (!accumulate)
@@ -1053,9 +1185,10 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         for (int l = 0; l < gp.n_levels; ++l)
             if ((tp.atomic_levels >> l) & 1u) (void)hipMemsetAsync(grad_table + 2 * gp.offset[l], 0, (size_t)gp.size[l] * 2 * sizeof(float), as_stream(stream));
     }
-    if (ws_entries > 0) {
-        hashgrid_bwd_reduce_kernel<<<dim3(64, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(gp, tp, (const float2*)workspace,
-                                                                                              (float2*)grad_table);
+    const bool adapt = level_absmax && headroom_state && n_blocks > 0;
+    if (ws_entries > 0 || adapt) {      // (+ one row of blocks for the headroom feedback)
+        hashgrid_bwd_reduce_kernel<<<dim3(64, gp.n_levels + 1), dim3(256), 0, as_stream(stream)>>>(
+            gp, tp, (const float2*)workspace, (float2*)grad_table, adapt ? headroom_state : nullptr);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(reduce)");
     }
     return PERF_OK;
@@ -1071,5 +1204,37 @@ extern "C" int perf_hashgrid_bwd_input(const perf_grid_desc* grid, const float* 
     hipLaunchKernelGGL(hashgrid_bwd_input_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, as_stream(stream), gp,
                        x01, (const float2*)dfeat, (const float2*)table, dx, n);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd_input");
+    return PERF_OK;
+}
+
+extern "C" int perf_hashgrid_bwd_bwd_input(const perf_grid_desc* grid, const float* x01, const float* dfeat, const float* table,
+                                           const float* ggx, float* d_dfeat, float* d_x, int64_t n, void* stream) {
+    GridParams gp;
+    int rc = fill_params(grid, &gp);
+    if (rc) return rc;
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(x01 && table && ggx, "NULL pointer");
+    PERF_REQUIRE(d_dfeat || d_x, "perf_hashgrid_bwd_bwd_input: nothing to compute");
+    PERF_REQUIRE(!d_x || dfeat, "perf_hashgrid_bwd_bwd_input: d_x needs dfeat");
+    hipLaunchKernelGGL(hashgrid_bwd_bwd_input_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, as_stream(stream), gp, x01,
+                       (const float2*)dfeat, (const float2*)table, ggx, (float2*)d_dfeat, d_x, n);
+    PERF_LAUNCH_CHECK("perf_hashgrid_bwd_bwd_input");
+    return PERF_OK;
+}
+
+extern "C" int perf_hashgrid_bwd_bwd_param(const perf_grid_desc* grid, const float* x01, const float* dfeat, const float* ggx,
+                                           float* grad_table, int64_t n, void* stream) {
+    GridParams gp;
+    int rc = fill_params(grid, &gp);
+    if (rc) return rc;
+    PERF_REQUIRE(grad_table, "NULL pointer");
+    const uint64_t total = gp.offset[gp.n_levels - 1] + gp.size[gp.n_levels - 1];
+    PERF_REQUIRE(hipMemsetAsync(grad_table, 0, (size_t)total * 2 * sizeof(float), as_stream(stream)) == hipSuccess,
+                 "perf_hashgrid_bwd_bwd_param: memset failed");
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(x01 && dfeat && ggx, "NULL pointer");
+    hipLaunchKernelGGL(hashgrid_bwd_bwd_param_kernel, dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream),
+                       gp, x01, (const float2*)dfeat, ggx, grad_table, n);
+    PERF_LAUNCH_CHECK("perf_hashgrid_bwd_bwd_param");
     return PERF_OK;
 }

@@ -255,34 +255,35 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
     }
 }
 
-// n <= kScanSmall: one workgroup, one launch (the three-kernel scan above is launch-latency bound for the
-// 8,192 per-ray counts of a training batch)
+// n <= kScanSmall: ONE launch of ceil(n / 1024) workgroups.  Block b first sums every element BEFORE its segment itself
+// (redundant, coalesced reads of at most 256 KiB from L2 -- far cheaper than a second launch or a cross-block handshake),
+// then scans its own 1024 elements.  (The 8,192 per-ray counts of a training batch take 8 blocks; a single-workgroup
+// scan of the 32,768 counts of an eval batch cost 27 us per call, 0.86 ms per 512x1024 frame.)
 constexpr int kScanSmall = 65536;
 __global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
                                                           int64_t* __restrict__ total_out) {
-    // every wave owns one contiguous segment and walks it 64 elements at a time (coalesced): pass 1 sums the segment,
-    // pass 2 (after the 16 segment sums have been exchanged through LDS) rescans it with the right base
-    __shared__ long long seg_sum[16];
+    __shared__ long long wave_sum[16];
+    __shared__ int wave_tot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t seg = ((n + 16 * 64 - 1) / (16 * 64)) * 64;
-    const int64_t lo = (int64_t)wave * seg, hi = (lo + seg < n) ? lo + seg : n;
+    const int64_t seg_lo = (int64_t)blockIdx.x * 1024;
+    // ---- sum of everything before the segment
     long long s = 0;
-    for (int64_t i = lo + lane; i < hi; i += 64) s += in[i];
+    for (int64_t i = threadIdx.x; i < seg_lo; i += 1024) s += in[i];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) seg_sum[wave] = s;
+    if (lane == 0) wave_sum[wave] = s;
+    // ---- scan of the segment: wave scans + the 16 wave totals
+    const int64_t i = seg_lo + threadIdx.x;
+    const int v = (i < n) ? in[i] : 0;
+    const int inc = wave_incl_scan(v, lane);
+    if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
-    long long base = 0, tot = 0;
-    for (int w2 = 0; w2 < 16; ++w2) { if (w2 < wave) base += seg_sum[w2]; tot += seg_sum[w2]; }
-    int carry = (int)base;
-    for (int64_t c0 = lo; c0 < hi; c0 += 64) {
-        const int64_t i = c0 + lane;
-        const int v = (i < hi) ? in[i] : 0;
-        const int inc = wave_incl_scan(v, lane);
-        if (i < hi) out[i] = carry + inc - v;
-        carry += __shfl(inc, 63);
-    }
-    if (threadIdx.x == 0) *total_out = tot;
+    long long base = 0;
+    int before = 0, seg_total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) { base += wave_sum[w2]; if (w2 < wave) before += wave_tot[w2]; seg_total += wave_tot[w2]; }
+    if (i < n) out[i] = (int)base + before + inc - v;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = base + seg_total;
 }
 
 }  // namespace perf
@@ -351,7 +352,7 @@ extern "C" int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t*
     PERF_REQUIRE(workspace_bytes >= perf_scan_workspace_bytes(n), "scan workspace too small");
     PERF_REQUIRE(in != out, "perf_exclusive_scan_i32: in-place scan is not supported");
     if (n <= kScanSmall) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, as_stream(stream), in, out, n, total);
+        hipLaunchKernelGGL(scan_small_kernel, dim3((unsigned)div_up(n, 1024)), dim3(1024), 0, as_stream(stream), in, out, n, total);
         PERF_LAUNCH_CHECK("perf_exclusive_scan_i32");
         return PERF_OK;
     }

@@ -186,7 +186,13 @@ def overflow_flag(device):
     return _OVERFLOW_FLAG[key]
 
 
-def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False, level_absmax=None, n_dev=None, use_codes=True):
+def headroom_state(device):
+    """Zeroed state block of the fixed-point headroom feedback (one per table that is trained, see perf_hashgrid_bwd)."""
+    return torch.zeros(2 * _lib.MAX_LEVELS, dtype=torch.int32, device=device)
+
+
+def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False, level_absmax=None, n_dev=None, use_codes=True,
+                 hr_state=None):
     """dfeat [L, n, 2] f32 -> gradient table [total*2] f32.  `out` (a contiguous fp32 view, e.g. the grid
     part of a flat gradient) is overwritten, or added to when accumulate=True.  level_absmax (device, 16 floats
     from mlp_bwd) selects the packed fixed-point accumulation."""
@@ -200,12 +206,13 @@ def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False, level
     ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=x01.device)
     flag = overflow_flag(x01.device) if level_absmax is not None else None
     _call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),
-              n, _nd(n_dev), int(bool(accumulate)), _p(level_absmax), _p(flag), _p(ws), ws_bytes, _stream())
+              n, _nd(n_dev), int(bool(accumulate)), _p(level_absmax), _p(flag), _p(hr_state if level_absmax is not None else None),
+              _p(ws), ws_bytes, _stream())
     return out
 
 
-def hashgrid_bwd_into(grid, x01, dfeat, out, level_absmax=None, n_dev=None):
-    return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False, level_absmax=level_absmax, n_dev=n_dev)
+def hashgrid_bwd_into(grid, x01, dfeat, out, level_absmax=None, n_dev=None, hr_state=None):
+    return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False, level_absmax=level_absmax, n_dev=n_dev, hr_state=hr_state)
 
 
 def hashgrid_corners(grid: GridConfig, x01):
@@ -224,6 +231,27 @@ def hashgrid_bwd_input(grid: GridConfig, x01, dfeat, table):
     _call('perf_hashgrid_bwd_input', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')),
               _p(_f32(table, 'table')), _p(dx), n, _stream())
     return dx
+
+
+def hashgrid_bwd_bwd_input(grid: GridConfig, x01, dfeat, table, ggx, want_ddfeat=True, want_dx=True):
+    """Backward of hashgrid_bwd_input w.r.t. (dfeat, x01) given ggx = dL/d(dx) [n,3] -> (d_dfeat [L,n,2] | None, d_x [n,3] | None)."""
+    n = x01.shape[0]
+    dd = torch.empty(grid.n_levels, n, 2, dtype=torch.float32, device=x01.device) if want_ddfeat else None
+    dx = torch.empty(n, 3, dtype=torch.float32, device=x01.device) if want_dx else None
+    d = grid.desc()
+    _call('perf_hashgrid_bwd_bwd_input', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(table, 'table')),
+          _p(_f32(ggx, 'ggx')), _p(dd), _p(dx), n, _stream())
+    return dd, dx
+
+
+def hashgrid_bwd_bwd_param(grid: GridConfig, x01, dfeat, ggx):
+    """Backward of hashgrid_bwd_input w.r.t. the table given ggx -> grad_table [total*2] f32."""
+    n = x01.shape[0]
+    out = torch.empty(grid.n_params, dtype=torch.float32, device=x01.device)
+    d = grid.desc()
+    _call('perf_hashgrid_bwd_bwd_param', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(ggx, 'ggx')), _p(out), n,
+          _stream())
+    return out
 
 
 # ---- MLP -----------------------------------------------------------------------------------------

@@ -388,7 +388,8 @@ class NeRFScene:
         n_all = n_net + net.grid.n_params
         grad = torch.empty(n_all + extra, dtype=torch.float32, device=x01.device)
         grad[:n_net] = res[1]
-        ops.hashgrid_bwd_into(net.grid, x01, res[0], grad[n_net:n_all], level_absmax=res[2] if fixed else None, n_dev=n_dev)
+        ops.hashgrid_bwd_into(net.grid, x01, res[0], grad[n_net:n_all], level_absmax=res[2] if fixed else None, n_dev=n_dev,
+                              hr_state=net.headroom_state() if fixed else None)
         return grad
 
     def _apply_grad(self, net, grad, optimizer, dist_info, overlap, n_kept=None, n_marched=None):
@@ -641,7 +642,8 @@ class NeRFScene:
                 self.global_iter_step_app += 1
             if state['n'] % OVERFLOW_CHECK_EVERY == 0:
                 recapture = False
-                if _tcnn.GRID_GRAD_ACCUM == 'fixed' and _tcnn.check_fixed_point_overflow(optimizer.net.params.device):
+                if _tcnn.GRID_GRAD_ACCUM == 'fixed' and _tcnn.check_fixed_point_overflow(optimizer.net.params.device) \
+                        and _tcnn.GRID_GRAD_ACCUM != 'fixed':
                     recapture = True           # the accumulation mode is baked into the graph: capture again in fp32 mode
                 marched = state['counts'][0]
                 if marched is not None and int(marched.item()) > state['capacity']:

@@ -28,17 +28,28 @@ import os as _os
 GRID_GRAD_ACCUM = _os.environ.get('PERF_GRID_GRAD_ACCUM', 'fixed')
 
 
-def check_fixed_point_overflow(device=None):
-    """Read (one host sync) and clear the overflow-suspect flag of the fixed-point grid backward.  On overflow the
-    accumulation mode is switched to 'fp32' for the rest of the process and True is returned."""
-    global GRID_GRAD_ACCUM
+_overflow_hits = 0
+
+
+def check_fixed_point_overflow(device=None, sticky_after=3):
+    """Read (one host sync) and clear the overflow-suspect flag of the fixed-point grid backward; True = some field came
+    within 4x of the int32 range since the last check.  The headroom feedback (perf_hashgrid_bwd's headroom_state) has
+    already widened the fields for the following calls by then, so the mode only switches to 'fp32' for the rest of the
+    process when `sticky_after` consecutive checks hit."""
+    global GRID_GRAD_ACCUM, _overflow_hits
     flag = ops.overflow_flag(device or _default_device())
     hit = bool(int(flag.item()))
     if hit:
         flag.zero_()
-        GRID_GRAD_ACCUM = 'fp32'
+        _overflow_hits += 1
         import warnings
-        warnings.warn('perf_amd: fixed-point grid-gradient accumulation came within 2x of its range; falling back to fp32 LDS accumulation')
+        if _overflow_hits >= sticky_after:
+            GRID_GRAD_ACCUM = 'fp32'
+            warnings.warn('perf_amd: fixed-point grid-gradient accumulation keeps coming within 4x of its range; falling back to fp32 LDS accumulation')
+        else:
+            warnings.warn('perf_amd: a fixed-point grid-gradient field came within 4x of its range (headroom widened for the next calls)')
+    else:
+        _overflow_hits = 0
     return hit
 
 
@@ -91,7 +102,8 @@ def _field_backward(module, x01, w16, feat, sel, dout, n_dev=None, poll_overflow
     res = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout.contiguous().float(), sel, want_absmax=fixed, n_dev=n_dev)
     grad = torch.empty(n_net + module.grid.n_params, dtype=torch.float32, device=x01.device)
     grad[:n_net] = res[1]
-    ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=res[2] if fixed else None, n_dev=n_dev)
+    ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=res[2] if fixed else None, n_dev=n_dev,
+                          hr_state=module.headroom_state() if fixed else None)
     if fixed and poll_overflow and OVERFLOW_POLL_EVERY > 0 and not torch.cuda.is_current_stream_capturing():
         _backward_calls += 1
         if _backward_calls % OVERFLOW_POLL_EVERY == 0 and check_fixed_point_overflow(x01.device):
@@ -154,6 +166,7 @@ class NetworkWithInputEncoding(nn.Module):
         self.params = nn.Parameter(_init_params(self.mlp, self.grid, seed).to(_default_device()))
         self._w16 = None
         self._w16_key = None
+        self._hr_state = ops.headroom_state(self.params.device)     # (plain attribute: not part of the checkpoint)
 
     # -- 16-bit working copy, refreshed when the fp32 master changes -------------------------------
     def working_copy(self, params=None):
@@ -163,6 +176,13 @@ class NetworkWithInputEncoding(nn.Module):
             self._w16 = ops.cast_params(p.detach(), self.dtype_name, self._w16 if (self._w16 is not None and self._w16.dtype == ops.torch_dtype(self.dtype_name) and self._w16.numel() == p.numel()) else None)
             self._w16_key = key
         return self._w16
+
+    def headroom_state(self):
+        """Device state of the fixed-point headroom feedback of this network's grid gradient (perf_hashgrid_bwd)."""
+        st = getattr(self, '_hr_state', None)
+        if st is None or st.device != self.params.device:
+            st = self._hr_state = ops.headroom_state(self.params.device)
+        return st
 
     def set_working_copy(self, w16):
         """Adopt a working copy written by the fused Adam kernel (perf_adam_step)."""
@@ -180,6 +200,9 @@ class NetworkWithInputEncoding(nn.Module):
 
 
 class _EncodingFn(torch.autograd.Function):
+    """y = encode(x; table).  Its backward calls _EncodingInputGradFn, itself an autograd Function, so that
+    autograd.grad(y, x, create_graph=True) can be differentiated again (SphereDistanceField, pano_joint_predictor.py:64-67)."""
+
     @staticmethod
     def forward(ctx, x01, params, module):
         feat = ops.hashgrid_fwd_f32(module.grid, x01, params.detach())
@@ -191,14 +214,61 @@ class _EncodingFn(torch.autograd.Function):
     def backward(ctx, dout):
         x01, params = ctx.saved_tensors
         module = ctx.module
-        n = x01.shape[0]
-        dfeat = dout.float().reshape(n, module.grid.n_levels, 2).permute(1, 0, 2).contiguous()
         gx = gp = None
         if ctx.needs_input_grad[0]:
-            gx = ops.hashgrid_bwd_input(module.grid, x01, dfeat, params.detach())
+            gx = _EncodingInputGradFn.apply(x01, params, dout, module)
         if ctx.needs_input_grad[1]:
-            gp = ops.hashgrid_bwd(module.grid, x01, dfeat)
+            gp = _EncodingParamGradFn.apply(x01, dout, module)
         return gx, gp, None
+
+
+def _level_major(dout, module):
+    n = dout.shape[0]
+    return dout.float().reshape(n, module.grid.n_levels, 2).permute(1, 0, 2).contiguous()
+
+
+class _EncodingParamGradFn(torch.autograd.Function):
+    """d y / d table contracted with dout: linear in dout, so its own backward (w.r.t. dout and x) exists in principle; no
+    PeRF consumer differentiates the TABLE gradient again, and asking for it raises instead of returning zeros."""
+
+    @staticmethod
+    def forward(ctx, x01, dout, module):
+        return ops.hashgrid_bwd(module.grid, x01.detach(), _level_major(dout.detach(), module))
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError('second derivatives THROUGH the table gradient of tcnn.Encoding are not implemented '
+                                  '(no consumer in PeRF; the input-gradient path is: _EncodingInputGradFn)')
+
+
+class _EncodingInputGradFn(torch.autograd.Function):
+    """gx = d(y . dout)/dx (kernel perf_hashgrid_bwd_input) with a kernel backward: given ggx = dL/d gx,
+    d_x (Hessian-vector product of the interpolation weights), d_table (scatter) and d_dout (gather) come from
+    perf_hashgrid_bwd_bwd_input / perf_hashgrid_bwd_bwd_param."""
+
+    @staticmethod
+    def forward(ctx, x01, params, dout, module):
+        dfeat = _level_major(dout.detach(), module)
+        ctx.module = module
+        ctx.save_for_backward(x01, params, dfeat)
+        return ops.hashgrid_bwd_input(module.grid, x01.detach(), dfeat, params.detach())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ggx):
+        x01, params, dfeat = ctx.saved_tensors
+        module = ctx.module
+        n = x01.shape[0]
+        ggx = ggx.contiguous().float()
+        want_x, want_p, want_d = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        d_x = d_p = d_dout = None
+        if want_x or want_d:
+            dd, d_x = ops.hashgrid_bwd_bwd_input(module.grid, x01.detach(), dfeat, params.detach(), ggx, want_ddfeat=want_d, want_dx=want_x)
+            if want_d:
+                d_dout = dd.permute(1, 0, 2).reshape(n, -1)
+        if want_p:
+            d_p = ops.hashgrid_bwd_bwd_param(module.grid, x01.detach(), dfeat, ggx)
+        return d_x, d_p, d_dout, None
 
 
 class Encoding(nn.Module):
@@ -219,15 +289,13 @@ class Encoding(nn.Module):
 
     def forward(self, x):
         x = x.reshape(-1, self.n_input_dims).contiguous().float()
-        if x.requires_grad and torch.is_grad_enabled():
-            # The caller may differentiate the input gradient again (SphereDistanceField: autograd.grad(...,
-            # create_graph=True), pano_joint_predictor.py:64-67).  Corner indices come from the HIP kernel; weights
-            # and the gather are differentiable torch ops on the device, so every order of derivative w.r.t. x,
-            # params (and incoming gradients) exists.
-            return self._forward_composed(x).to(self.out_dtype)
+        # First order: kernels.  Second order (the caller differentiates the input gradient again: SphereDistanceField,
+        # autograd.grad(..., create_graph=True), pano_joint_predictor.py:64-67): kernels too -- see _EncodingInputGradFn.
         return _EncodingFn.apply(x, self.params, self).to(self.out_dtype)
 
     def _forward_composed(self, x):
+        """TEST REFERENCE ONLY: the same encoding composed from differentiable torch ops on top of the corner-index kernel
+        (every order of derivative exists through autograd); tests compare the kernel double backward with it."""
         g = self.grid
         n = x.shape[0]
         idx = ops.hashgrid_corners(g, x.detach()).long()                       # [L, n, 8]

@@ -18,6 +18,7 @@ ap.add_argument('--poses', type=int, default=600)
 ap.add_argument('--geo-steps', type=int, default=300)
 ap.add_argument('--app-steps', type=int, default=150)
 ap.add_argument('--dtype', default='fp16')
+ap.add_argument('--batch', type=int, default=32768, help='rays per graph-captured eval batch (the reference hard-codes 32768, nerf.py:86)')
 args = ap.parse_args()
 
 torch.manual_seed(0); np.random.seed(0)
@@ -53,10 +54,10 @@ for i in range(dense.n_poses):
 fh, fw = 512, 1024
 def frame_eager(p):
     r = gen_pano_rays(p, fh, fw)
-    return scene.render(r, ['rgb', 'distance'], batch_size=32768)
+    return scene.render(r, ['rgb', 'distance'], batch_size=args.batch)
 
 # ONE hipGraph per frame: ray generation from a device-resident pose + 16 eval batches of 32,768 rays (nerf.py:86)
-frame = scene.make_graphed_render(fh, fw, ('rgb', 'distance'), batch_size=32768)
+frame = scene.make_graphed_render(fh, fw, ('rgb', 'distance'), batch_size=args.batch)
 for p in poses[:3]:
     frame(p)
 torch.cuda.synchronize()
@@ -76,7 +77,14 @@ for p in poses[:60]:
     frame_eager(p)
 torch.cuda.synchronize()
 t_eager = (time.perf_counter() - t0) / 60
-print(json.dumps({'config': 'render_dense: %d poses, %dx%d panoramic frames in 16 hipGraph-captured 32768-ray batches, %s, variable-count sampling' % (len(poses), fw, fh, args.dtype),
+from perf_amd.scene import Rays as _Rays
+_r0 = gen_pano_rays(poses[0], fh, fw)
+scene.set_eval(); scene.renderer.sample_capacity = fh * fw * 64
+with torch.no_grad():
+    _c = scene.render_once(_Rays(_r0.o.reshape(-1, 3), _r0.d.reshape(-1, 3)), ['n_marched_dev', 'n_samples_dev'])
+scene.renderer.sample_capacity = None
+print(json.dumps({'config': 'render_dense: %d poses, %dx%d panoramic frames in %d hipGraph-captured %d-ray batches, %s, variable-count sampling' % (len(poses), fw, fh, (fh * fw + args.batch - 1) // args.batch, args.batch, args.dtype),
+                  'frame0_marched_samples': int(_c['n_marched_dev'].item()), 'frame0_kept_samples': int(_c['n_samples_dev'].item()),
                   'frames_per_s': len(poses) / t, 'rays_per_s': len(poses) * fh * fw / t, 'seconds': t,
                   'eager_sync_free_frames_per_s': 1.0 / t_eager, 'graphed_frame_equals_eager_frame': same,
                   'per_ray_sample_capacity': frame.state['per_ray'],
