@@ -195,6 +195,16 @@ int perf_hashgrid_bwd_bwd_param(const perf_grid_desc* grid, const float* x01, co
 int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
                  float* out, int64_t n, const int64_t* n_dev, int dtype, void* stream);
 
+/* Field inference in one boundary call: out [n, n_out] = act(MLP(encode(x01))) * sel, i.e. NGPNeRF.query_density /
+ * query_rgb without gradient (modules/fields/ngp_nerf.py:136-162; the no-grad density pass inside
+ * OccGridEstimator.sampling and the eval render are this).  = perf_hashgrid_fwd + perf_mlp_fwd back to back with the
+ * 16-bit level-major features in `scratch` (perf_field_infer_scratch_bytes(grid, n) bytes, caller owned); the encode
+ * stays a level-group kernel pinned to XCDs, see DESIGN.md.  n / n_dev as everywhere. */
+int64_t perf_field_infer_scratch_bytes(const perf_grid_desc* grid, int64_t n);
+int perf_field_infer(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const uint8_t* sel,
+                     const void* table16, const void* w16, float* out, int64_t n, const int64_t* n_dev,
+                     void* scratch, int64_t scratch_bytes, int dtype, void* stream);
+
 /* Bytes of caller-owned workspace perf_mlp_bwd needs for n samples. */
 int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n);
 
@@ -258,11 +268,14 @@ int perf_occ_march_write(const float* t0, int64_t n_rays, float step, int32_t ma
 
 /* perf_occ_march_write that also emits the sample positions of perf_points_from_rays (x01 [S,3], sel [S] or NULL) for
  * the samples it writes: one launch and one pass over the samples less when no visibility compaction follows.
- * aabb6: host pointer, {min xyz, max xyz}. */
+ * aabb6: host pointer, {min xyz, max xyz}.  rank_lo: the samples of rank [rank_lo, rank_lo + counts[r]) of every ray are
+ * written (rank = position among the ray's samples in t order; 0 with the march counts = everything) -- the two-phase
+ * sampler below writes the first K samples of every ray first and the rest of the surviving rays later. */
 int perf_occ_march_write_points(const float* t0, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
                                 const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                 float* t_starts, float* t_ends, int32_t* packed_info, const float* rays_o,
-                                const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, void* stream);
+                                const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, int32_t rank_lo,
+                                void* stream);
 
 /* ---- compositing (nerfacc render_weight_from_density / accumulate_along_rays /
  *      render_visibility_from_density; nerf_renderer.py:170-183) ---------------------------- */
@@ -282,6 +295,29 @@ int perf_compact_prefix(const int32_t* packed_info, const int32_t* new_counts, c
                         int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out,
                         int32_t* packed_out, const float* x01_in, const uint8_t* sel_in, float* x01_out,
                         uint8_t* sel_out, void* stream);
+
+/* ---- two-phase early termination (same results as perf_visibility_count + perf_compact_prefix over all samples) -------
+ * nerfacc's render_visibility_from_density keeps a PREFIX of every ray (the exclusive sum of sigma*delta never decreases),
+ * so the density of samples behind the first one over the threshold never matters.  The sampler evaluates the first K
+ * samples of every ray (head), then only the rest (tail) of the rays whose head survived entirely:
+ *   perf_head_tail_counts(counts, K, NULL) -> head counts;   ... density of the heads, perf_visibility_count -> kept_head;
+ *   perf_head_tail_counts(counts, K, kept_head) -> tail counts (0 for decided rays);   ... density of the tails;
+ *   perf_visibility_count2 / perf_compact_prefix2 over (head, tail) pairs of arrays -> final packed samples.
+ * Sample i of ray r is head sample i for i < packed_h[r].count, tail sample i - packed_h[r].count otherwise; the canonical
+ * scan value of a sample only involves earlier samples, so kept counts are bit-identical to the one-phase path. */
+int perf_head_tail_counts(const int32_t* counts, int64_t n_rays, int32_t head_samples, const int32_t* kept_head,
+                          int32_t* out_counts, void* stream);
+int perf_visibility_count2(const float* sig_h, const float* ts_h, const float* te_h, const int32_t* packed_h,
+                           const float* sig_t, const float* ts_t, const float* te_t, const int32_t* packed_t,
+                           int64_t n_rays, float thr, int32_t* new_counts, void* stream);
+/* capacity: rows of the output arrays (a batch that keeps more is truncated ray by ray, like perf_occ_march_write);
+ * sig/x01/sel outputs (and the matching inputs) may be NULL. */
+int perf_compact_prefix2(const float* sig_h, const float* ts_h, const float* te_h, const int32_t* packed_h,
+                         const float* x01_h, const uint8_t* sel_h, const float* sig_t, const float* ts_t,
+                         const float* te_t, const int32_t* packed_t, const float* x01_t, const uint8_t* sel_t,
+                         const int32_t* new_counts, const int32_t* new_offsets, int64_t n_rays, int64_t capacity,
+                         int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out, float* x01_out,
+                         uint8_t* sel_out, int32_t* packed_out, void* stream);
 
 /* weights/trans/alphas [S] and per-ray opacity [R], distance [R], colour [R,3] (rgbs may be NULL).
  * One wave per ray: no atomics. */

@@ -55,6 +55,8 @@ _SIGS = {
     'perf_hashgrid_bwd_bwd_input': (c_int, [POINTER(GridDesc), P, P, P, P, P, P, c_int64, P]),
     'perf_hashgrid_bwd_bwd_param': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),
     'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, P, c_int, P]),
+    'perf_field_infer_scratch_bytes': (c_int64, [POINTER(GridDesc), c_int64]),
+    'perf_field_infer': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, P, c_int64, P, P, c_int64, c_int, P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
     'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, P, P, P, P, P, c_int64, c_int64, P, c_int, P]),
     'perf_pano_raygen': (c_int, [POINTER(c_float), c_int32, c_int32, c_int32, c_int32, P, P, P]),
@@ -67,7 +69,10 @@ _SIGS = {
     'perf_scan_workspace_bytes': (c_int64, [c_int64]),
     'perf_exclusive_scan_i32': (c_int, [P, P, P, c_int64, P, c_int64, P]),
     'perf_occ_march_write': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P]),
-    'perf_occ_march_write_points': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P, P, POINTER(c_float), P, P, P]),
+    'perf_occ_march_write_points': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P, P, POINTER(c_float), P, P, c_int32, P]),
+    'perf_head_tail_counts': (c_int, [P, c_int64, c_int32, P, P, P]),
+    'perf_visibility_count2': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_float, P, P]),
+    'perf_compact_prefix2': (c_int, [P] * 14 + [c_int64, c_int64] + [P] * 8),
     'perf_visibility_count': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
     'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'perf_composite_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),

@@ -431,6 +431,133 @@ extern "C" int perf_pack_info(const int64_t* ray_indices, int64_t n, int64_t n_r
     return PERF_OK;
 }
 
+// ---- two-phase early termination -----------------------------------------------------------------------------------
+// render_visibility_from_density keeps, per ray, the leading samples whose exclusive sum of sigma*delta stays below
+// -ln(eps): a PREFIX, because the sum never decreases.  Samples behind the first one that exceeds the threshold are dropped
+// whatever their density is -- so their density need not be evaluated.  The sampler therefore evaluates the first K samples
+// of every ray ("head"), decides the rays that terminate inside their head (or have no more samples), and evaluates the
+// rest ("tail") only for the rays that are still alive.  In a trained scene a ray is opaque after a sample or two: the
+// density pass shrinks from ~40 to K samples per ray.  Results are bit-identical to the one-phase path: the canonical scan
+// value of sample i only involves samples <= i.
+namespace perf {
+
+// mode 0: out = min(counts, K)                                             (head counts)
+// mode 1: out = (kept_head == min(counts, K) && counts > K) ? counts - K : 0     (tail counts of the rays still alive)
+__global__ __launch_bounds__(256) void head_tail_counts_kernel(const int32_t* __restrict__ counts, int64_t n_rays, int32_t K,
+                                                               const int32_t* __restrict__ kept_head, int32_t* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rays) return;
+    const int32_t c = counts[r], h = c < K ? c : K;
+    out[r] = kept_head ? ((kept_head[r] == h && c > K) ? c - K : 0) : h;
+}
+
+// sample i of ray r lives in the head arrays for i < head count, in the tail arrays behind that
+struct TwoSource {
+    const float* sig_h; const float* ts_h; const float* te_h; const int32_t* packed_h;
+    const float* sig_t; const float* ts_t; const float* te_t; const int32_t* packed_t;
+};
+
+__global__ __launch_bounds__(256) void visibility_count2_kernel(TwoSource src, int64_t n_rays, float thr, int32_t* __restrict__ new_counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int64_t sh = src.packed_h[2 * r], st = src.packed_t[2 * r];
+    const int ch = src.packed_h[2 * r + 1], ct = src.packed_t[2 * r + 1];
+    const int cnt = ch + ct;
+    float carry = 0.f;
+    int kept = 0;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < cnt;
+        float sd = 0.f;
+        if (valid) {
+            const bool head = i < ch;
+            const int64_t j = head ? sh + i : st + (i - ch);
+            const float s = head ? src.sig_h[j] : src.sig_t[j];
+            const float a = head ? src.ts_h[j] : src.ts_t[j], b = head ? src.te_h[j] : src.te_t[j];
+            sd = mul_rn(s, sub_rn(b, a));
+        }
+        const float ex = chunk_excl(sd, lane, carry);
+        const unsigned long long ok = __ballot(valid && (ex <= thr));
+        kept += __popcll(ok);
+        if (ok != __ballot(valid)) break;            // the prefix ended in this chunk (wave-uniform)
+    }
+    if (lane == 0) new_counts[r] = kept;
+}
+
+__global__ __launch_bounds__(256) void compact_prefix2_kernel(TwoSource src, const float* __restrict__ x01_h, const uint8_t* __restrict__ sel_h,
+                                                              const float* __restrict__ x01_t, const uint8_t* __restrict__ sel_t,
+                                                              const int32_t* __restrict__ new_counts, const int32_t* __restrict__ new_offsets,
+                                                              int64_t n_rays, int64_t capacity, int64_t* __restrict__ ri_out,
+                                                              float* __restrict__ ts_out, float* __restrict__ te_out, float* __restrict__ sig_out,
+                                                              float* __restrict__ x01_out, uint8_t* __restrict__ sel_out,
+                                                              int32_t* __restrict__ packed_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int64_t sh = src.packed_h[2 * r], st = src.packed_t[2 * r];
+    const int ch = src.packed_h[2 * r + 1];
+    int cnt = new_counts[r];
+    const int64_t dst = new_offsets[r];
+    if (dst + cnt > capacity) cnt = (int)(capacity > dst ? capacity - dst : 0);       // truncated batch
+    if (lane == 0) { packed_out[2 * r] = (int32_t)dst; packed_out[2 * r + 1] = cnt; }
+    for (int i = lane; i < cnt; i += 64) {
+        const bool head = i < ch;
+        const int64_t j = head ? sh + i : st + (i - ch);
+        ts_out[dst + i] = head ? src.ts_h[j] : src.ts_t[j];
+        te_out[dst + i] = head ? src.te_h[j] : src.te_t[j];
+        ri_out[dst + i] = r;
+        if (sig_out) sig_out[dst + i] = head ? src.sig_h[j] : src.sig_t[j];
+        if (sel_out) sel_out[dst + i] = head ? sel_h[j] : sel_t[j];
+        if (x01_out) {
+            const float* p = head ? x01_h + 3 * j : x01_t + 3 * j;
+            x01_out[3 * (dst + i)] = p[0]; x01_out[3 * (dst + i) + 1] = p[1]; x01_out[3 * (dst + i) + 2] = p[2];
+        }
+    }
+}
+}  // namespace perf
+
+extern "C" int perf_head_tail_counts(const int32_t* counts, int64_t n_rays, int32_t head_samples, const int32_t* kept_head,
+                                     int32_t* out_counts, void* stream) {
+    PERF_REQUIRE(n_rays >= 0 && head_samples >= 1, "perf_head_tail_counts: bad arguments");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(counts && out_counts, "NULL pointer");
+    hipLaunchKernelGGL(perf::head_tail_counts_kernel, dim3((unsigned)perf::div_up(n_rays, 256)), dim3(256), 0, perf::as_stream(stream),
+                       counts, n_rays, head_samples, kept_head, out_counts);
+    PERF_LAUNCH_CHECK("perf_head_tail_counts");
+    return PERF_OK;
+}
+
+extern "C" int perf_visibility_count2(const float* sig_h, const float* ts_h, const float* te_h, const int32_t* packed_h,
+                                      const float* sig_t, const float* ts_t, const float* te_t, const int32_t* packed_t,
+                                      int64_t n_rays, float thr, int32_t* new_counts, void* stream) {
+    PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_h && packed_t && new_counts, "NULL pointer");
+    perf::TwoSource src{sig_h, ts_h, te_h, packed_h, sig_t, ts_t, te_t, packed_t};
+    hipLaunchKernelGGL(perf::visibility_count2_kernel, perf::ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, n_rays, thr, new_counts);
+    PERF_LAUNCH_CHECK("perf_visibility_count2");
+    return PERF_OK;
+}
+
+extern "C" int perf_compact_prefix2(const float* sig_h, const float* ts_h, const float* te_h, const int32_t* packed_h,
+                                    const float* x01_h, const uint8_t* sel_h, const float* sig_t, const float* ts_t,
+                                    const float* te_t, const int32_t* packed_t, const float* x01_t, const uint8_t* sel_t,
+                                    const int32_t* new_counts, const int32_t* new_offsets, int64_t n_rays, int64_t capacity,
+                                    int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out, float* x01_out,
+                                    uint8_t* sel_out, int32_t* packed_out, void* stream) {
+    PERF_REQUIRE(n_rays >= 0 && capacity >= 0, "perf_compact_prefix2: bad arguments");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(packed_h && packed_t && new_counts && new_offsets && packed_out, "NULL pointer");
+    PERF_REQUIRE(capacity == 0 || (ray_indices_out && ts_out && te_out), "NULL sample arrays");
+    perf::TwoSource src{sig_h, ts_h, te_h, packed_h, sig_t, ts_t, te_t, packed_t};
+    hipLaunchKernelGGL(perf::compact_prefix2_kernel, perf::ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, x01_h, sel_h,
+                       x01_t, sel_t, new_counts, new_offsets, n_rays, capacity, ray_indices_out, ts_out, te_out, sig_out, x01_out,
+                       sel_out, packed_out);
+    PERF_LAUNCH_CHECK("perf_compact_prefix2");
+    return PERF_OK;
+}
+
 // ---- eval tail of NeRFOCCRenderer.render (nerf_renderer.py:195-197): distance += 5 (1 - opacity), rgb += 0.5 (1 - opacity).
 // A batch without any sample returns before that tail in the reference (:156-162: zeros, is_valid False); with device-side
 // counts the same decision is taken here from *n_dev.

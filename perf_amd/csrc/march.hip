@@ -146,7 +146,11 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                                                           int64_t* __restrict__ ray_indices, float* __restrict__ ts,
                                                           float* __restrict__ te, int32_t* __restrict__ packed,
                                                           const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                          Aabb bb, float* __restrict__ x01, uint8_t* __restrict__ sel) {
+                                                          Aabb bb, float* __restrict__ x01, uint8_t* __restrict__ sel,
+                                                          int32_t rank_lo) {
+    // Writes the samples of rank [rank_lo, rank_lo + counts[r]) of every ray (rank = position among the ray's samples in t
+    // order) to offsets[r]...: rank_lo = 0 and counts = the march counts is the plain expansion; the two-phase sampler
+    // writes the first K samples of every ray first and the rest of the rays that are still alive later.
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rays) return;
@@ -156,17 +160,18 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
     if (lane == 0) { packed[2 * r] = off; packed[2 * r + 1] = cnt; }
     if (cnt == 0) return;
     const float t0 = t0s[r];
-    int64_t run = off;
+    int64_t run = (int64_t)off - rank_lo;            // output position of rank 0 (may lie before `off`)
+    const int64_t end = (int64_t)off + cnt;
     const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int nlw = n_live_words(mask_words);
     const uint64_t* rec = masks + r * (int64_t)(mask_words + nlw);
-    for (int g = 0; g < nlw; ++g) {
-        for (uint64_t todo = rec[g]; todo; todo &= todo - 1) {
+    for (int g = 0; g < nlw && run < end; ++g) {
+        for (uint64_t todo = rec[g]; todo && run < end; todo &= todo - 1) {
             const int q = g * 64 + (__ffsll((unsigned long long)todo) - 1);
             const uint64_t m = rec[nlw + q];
             if ((m >> lane) & 1ull) {
                 const int64_t pos = run + __popcll(m & below);
-                if (pos < capacity) {
+                if (pos >= off && pos < end) {
                     const int k = q * 64 + lane;
                     const float a = lattice(t0, k, step), b = lattice(t0, k + 1, step);
                     ts[pos] = a;
@@ -374,7 +379,7 @@ extern "C" int perf_occ_march_write(const float* t0, int64_t n_rays, float step,
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends), "NULL sample arrays");
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr);
+                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0);
     PERF_LAUNCH_CHECK("perf_occ_march_write");
     return PERF_OK;
 }
@@ -382,8 +387,9 @@ extern "C" int perf_occ_march_write(const float* t0, int64_t n_rays, float step,
 extern "C" int perf_occ_march_write_points(const float* t0, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
                                            const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                            float* t_starts, float* t_ends, int32_t* packed_info, const float* rays_o,
-                                           const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, void* stream) {
-    PERF_REQUIRE(n_rays >= 0 && max_steps > 0 && capacity >= 0, "perf_occ_march_write_points: bad arguments");
+                                           const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, int32_t rank_lo,
+                                           void* stream) {
+    PERF_REQUIRE(n_rays >= 0 && max_steps > 0 && capacity >= 0 && rank_lo >= 0, "perf_occ_march_write_points: bad arguments");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(t0 && masks && counts && offsets && packed_info && rays_o && rays_d && aabb6, "NULL pointer");
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends && x01), "NULL sample arrays");
@@ -391,7 +397,7 @@ extern "C" int perf_occ_march_write_points(const float* t0, int64_t n_rays, floa
     for (int k = 0; k < 3; ++k) { bb.lo[k] = aabb6[k]; bb.hi[k] = aabb6[3 + k]; }
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel);
+                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo);
     PERF_LAUNCH_CHECK("perf_occ_march_write_points");
     return PERF_OK;
 }

@@ -654,3 +654,25 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
     PERF_LAUNCH_CHECK("perf_mlp_bwd(reduce)");
     return PERF_OK;
 }
+
+// ---- encode + MLP as ONE boundary call (SURVEY.md 8(b) perf_field_infer; NGPNeRF.query_density / query_rgb without
+// gradient, modules/fields/ngp_nerf.py:136-162).  Two launches inside: the encode is cut by level group and pinned to XCDs
+// (the 13 MB table does not fit one XCD's 4 MiB L2; the pinning is worth 1.9-2.4x on the gathers), while the
+// MLP needs all 32 features of a sample in one wave -- a single kernel would give up the pinning to save a 64 B/sample
+// round trip of 16-bit features through L2 / Infinity Cache.  `scratch` holds those features: 4 * n_levels * n bytes.
+extern "C" int64_t perf_field_infer_scratch_bytes(const perf_grid_desc* grid, int64_t n) {
+    if (!grid || grid->n_levels < 1 || grid->n_levels > PERF_MAX_LEVELS || n < 0) return -1;
+    return (int64_t)grid->n_levels * n * 4;
+}
+
+extern "C" int perf_field_infer(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const uint8_t* sel,
+                                const void* table16, const void* w16, float* out, int64_t n, const int64_t* n_dev,
+                                void* scratch, int64_t scratch_bytes, int dtype, void* stream) {
+    PERF_REQUIRE(grid && mlp, "NULL descriptor");
+    PERF_REQUIRE(mlp->n_levels == grid->n_levels, "perf_field_infer: the MLP takes %d levels, the grid has %d", (int)mlp->n_levels, (int)grid->n_levels);
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(scratch && scratch_bytes >= perf_field_infer_scratch_bytes(grid, n), "perf_field_infer: scratch too small");
+    int rc = perf_hashgrid_fwd(grid, x01, table16, scratch, n, n_dev, dtype, stream);
+    if (rc) return rc;
+    return perf_mlp_fwd(mlp, w16, scratch, sel, out, n, n_dev, dtype, stream);
+}

@@ -167,7 +167,7 @@ class OccGridEstimator(nn.Module):
     def sampling_ex(self, rays_o, rays_d, sigma_fn=None, near_plane=0.0, far_plane=1e10, render_step_size=1e-3,
                     early_stop_eps=1e-4, alpha_thre=0.0, stratified=False, cone_angle=0.0, alpha_fn=None,
                     t_min=None, t_max=None, jitter=None, max_steps=None, capacity=None, points_aabb=None,
-                    sigma_points_fn=None):
+                    sigma_points_fn=None, head_samples=None):
         """sampling() returning a Samples record: ray_indices, t_starts, t_ends, packed (packed_info), sig (sigmas of the
         kept samples from the visibility pass, or None), x01 / sel (sample positions normalised to points_aabb, or None),
         n_dev (device int64 [1]: number of live samples when the arrays are capacity-sized, else None), n_marched_dev.
@@ -176,7 +176,11 @@ class OccGridEstimator(nn.Module):
           device (n_dev) and no host read-back happens; a batch that marches more than `capacity` samples is truncated ray
           by ray (n_marched_dev > capacity tells).  Needs points_aabb and, for the visibility pass, sigma_points_fn(x01, sel,
           n_dev) -> sigmas [capacity].
-        points_aabb: the sample positions normalised to that box are produced by the marching kernel itself."""
+        points_aabb: the sample positions normalised to that box are produced by the marching kernel itself.
+        head_samples (sync-free mode with a visibility pass): two-phase early termination -- the density pass first runs
+          on the first `head_samples` samples of every ray and then only on the rest of the rays that are still alive (a
+          trained scene terminates a ray after a sample or two); same samples, same sigmas as the one-phase path.
+          n_marched_dev then counts the samples whose density was evaluated."""
         if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
             raise NotImplementedError('PeRF samples with cone_angle=0 and a sigma_fn (nerf_renderer.py:145-155)')
         if alpha_thre != 0.0:
@@ -213,6 +217,9 @@ class OccGridEstimator(nn.Module):
         if capacity is not None:
             if compacts and (sigma_points_fn is None or points_aabb is None):
                 raise ValueError('sync-free sampling with a visibility pass needs points_aabb and sigma_points_fn')
+            if compacts and head_samples:
+                return self._sample_two_phase(sm, rays_o, rays_d, t0, float(far_plane), float(render_step_size), max_steps,
+                                              int(capacity), points_aabb, sigma_points_fn, early_stop_eps, int(head_samples))
             out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size),
                                 max_steps, capacity=capacity, occ_coarse=self.occ_coarse(), points_aabb=points_aabb)
             ri, ts, te, packed, total = out[:5]
@@ -247,6 +254,35 @@ class OccGridEstimator(nn.Module):
                     ri, ts, te, sig, packed = ops.compact_prefix(packed, new_counts, ts, te, sig)
         ri._perf_packed = packed
         sm.ray_indices, sm.t_starts, sm.t_ends, sm.packed, sm.sig, sm.x01, sm.sel = ri, ts, te, packed, sig, x01, sel
+        return sm
+
+    def _sample_two_phase(self, sm, rays_o, rays_d, t0, far_plane, step, max_steps, capacity, points_aabb, sigma_points_fn,
+                          early_stop_eps, K):
+        """March once; density + visibility on the first K samples of every ray; then density on the remaining samples of
+        the rays that are still alive; final visibility + compaction over (head, tail).  All counts stay on the device."""
+        R = rays_o.shape[0]
+        masks, counts = ops.occ_march_count(rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step,
+                                            max_steps, self.occ_coarse())
+        # ---- head: rank [0, K) of every ray; R*K rows always suffice
+        ch = ops.head_tail_counts(counts, K)
+        oh, total_h = ops.exclusive_scan_i32(ch)
+        ri_h, ts_h, te_h, pk_h, x_h, s_h = ops.occ_march_write(t0, masks, ch, oh, R * K, step, max_steps, rays_o, rays_d, points_aabb)
+        sig_h = sigma_points_fn(x_h, s_h, total_h).reshape(-1).float().contiguous()
+        kept_h = ops.visibility_count(sig_h, ts_h, te_h, pk_h, early_stop_eps)
+        # ---- tail: rank [K, count) of the rays whose whole head survived
+        ct = ops.head_tail_counts(counts, K, kept_h)
+        ot, total_t = ops.exclusive_scan_i32(ct)
+        ri_t, ts_t, te_t, pk_t, x_t, s_t = ops.occ_march_write(t0, masks, ct, ot, capacity, step, max_steps, rays_o, rays_d, points_aabb,
+                                                               rank_lo=K)
+        sig_t = sigma_points_fn(x_t, s_t, total_t).reshape(-1).float().contiguous()
+        # ---- final decision and compaction over both sample sets
+        head = (sig_h, ts_h, te_h, pk_h, x_h, s_h); tail = (sig_t, ts_t, te_t, pk_t, x_t, s_t)
+        new_counts = ops.visibility_count2(head[:4], tail[:4], early_stop_eps)
+        ri, ts, te, sig, packed, total, x01, sel = ops.compact_prefix2(head, tail, new_counts, capacity)
+        ri._perf_packed = packed
+        sm.ray_indices, sm.t_starts, sm.t_ends, sm.packed, sm.sig, sm.x01, sm.sel = ri, ts, te, packed, sig, x01, sel
+        sm.n_dev = total
+        sm.n_marched_dev = total_h + total_t          # samples whose density was evaluated (what must fit the capacity)
         return sm
 
     @torch.no_grad()

@@ -263,6 +263,19 @@ def mlp_fwd(mlp: MlpConfig, w16, feat16, sel=None, n_dev=None):
     return out
 
 
+def field_infer(grid: GridConfig, mlp: MlpConfig, x01, sel, w16, n_dev=None):
+    """act(MLP(encode(x01))) * sel without gradient in one boundary call; w16 = the network's 16-bit working copy
+    [MLP weights | table]."""
+    n = x01.shape[0]
+    n_net = mlp.n_params
+    out = torch.empty(n, mlp.n_output_dims, dtype=torch.float32, device=x01.device)
+    scratch = torch.empty(grid.n_levels * n, dtype=torch.int32, device=x01.device)
+    gd, md = grid.desc(), mlp.desc()
+    _call('perf_field_infer', ctypes.byref(gd), ctypes.byref(md), _p(_f32(x01, 'x01')), _p(sel), _p(w16[n_net:]), _p(w16[:n_net]),
+          _p(out), n, _nd(n_dev), _p(scratch), scratch.numel() * 4, dtype_code(w16.dtype), _stream())
+    return out
+
+
 def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True, want_absmax=False, n_dev=None):
     """Returns (dfeat [L,n,2] f32 or None, dw [n_net_params] f32[, level_absmax [16] f32])."""
     n = feat16.shape[1]
@@ -333,6 +346,40 @@ def occ_build_coarse(occ_bits, res):
     return coarse
 
 
+def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse=None):
+    """Pass 1 of the marching: -> (keep masks, per-ray counts int32 [R])."""
+    R = rays_o.shape[0]
+    dev = rays_o.device
+    mw = _lib.load().perf_occ_mask_words(max_steps)
+    masks = torch.empty(max(R * mw, 1), dtype=torch.int64, device=dev)
+    counts = torch.empty(R, dtype=torch.int32, device=dev)
+    _call('perf_occ_march_count', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(t0, 't0')), R,
+          _p(occ_bits), _p(occ_coarse), int(res), _aabb6(aabb), float(far_plane), float(step), int(max_steps), _p(masks), _p(counts), _stream())
+    return masks, counts
+
+
+def occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o=None, rays_d=None, points_aabb=None, rank_lo=0):
+    """Pass 2: expand the masks into S-row sample arrays -> (ray_indices, t_starts, t_ends, packed_info[, x01, sel]).
+    counts / offsets: how many samples of every ray to write, starting at rank rank_lo, and where."""
+    R = counts.shape[0]
+    dev = counts.device
+    ri = torch.empty(S, dtype=torch.int64, device=dev)
+    ts = torch.empty(S, dtype=torch.float32, device=dev)
+    te = torch.empty(S, dtype=torch.float32, device=dev)
+    packed = torch.empty(R, 2, dtype=torch.int32, device=dev)
+    if points_aabb is not None:
+        x01 = torch.empty(S, 3, dtype=torch.float32, device=dev)
+        sel = torch.empty(S, dtype=torch.uint8, device=dev)
+        _call('perf_occ_march_write_points', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
+              _p(ri), _p(ts), _p(te), _p(packed), _p(rays_o), _p(rays_d), _aabb6(points_aabb), _p(x01), _p(sel), int(rank_lo), _stream())
+        return ri, ts, te, packed, x01, sel
+    if rank_lo != 0:
+        raise _lib.PerfError('rank_lo needs points_aabb (perf_occ_march_write_points)')
+    _call('perf_occ_march_write', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
+          _p(ri), _p(ts), _p(te), _p(packed), _stream())
+    return ri, ts, te, packed
+
+
 def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, capacity=None, occ_coarse=None,
               points_aabb=None):
     """Returns (ray_indices i64 [S], t_starts, t_ends f32 [S], packed_info i32 [R,2]).
@@ -340,34 +387,50 @@ def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_step
     an int capacity keeps the call sync-free and returns arrays of that length plus `total` on device.
     points_aabb (6 floats): also return the sample positions (x01 [S,3], sel [S]) normalised to that box, written by
     the same kernel that writes the samples (appended to the result)."""
-    R = rays_o.shape[0]
-    dev = rays_o.device
-    lib = _lib.load()
-    mw = lib.perf_occ_mask_words(max_steps)
-    masks = torch.empty(max(R * mw, 1), dtype=torch.int64, device=dev)
-    counts = torch.empty(R, dtype=torch.int32, device=dev)
-    a6 = _aabb6(aabb)
-    _call('perf_occ_march_count', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(t0, 't0')), R,
-              _p(occ_bits), _p(occ_coarse), int(res), a6, float(far_plane), float(step), int(max_steps), _p(masks), _p(counts), _stream())
+    masks, counts = occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse)
     offsets, total = exclusive_scan_i32(counts)
     S = int(total.item()) if capacity is None else int(capacity)
+    out = occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o, rays_d, points_aabb)
+    if capacity is None:
+        return out
+    return out[:4] + (total,) + out[4:]
+
+
+def head_tail_counts(counts, head_samples, kept_head=None):
+    """kept_head None: min(counts, K); else the tail counts of the rays whose whole head survived (0 for decided rays)."""
+    out = torch.empty_like(counts)
+    _call('perf_head_tail_counts', _p(counts), counts.shape[0], int(head_samples), _p(kept_head), _p(out), _stream())
+    return out
+
+
+def visibility_count2(head, tail, early_stop_eps=1e-4):
+    """head / tail = (sigmas, t_starts, t_ends, packed_info) of the two sample sets -> kept counts int32 [R]."""
+    R = head[3].shape[0]
+    thr = float(-math.log(early_stop_eps)) if early_stop_eps > 0 else float('inf')
+    new_counts = torch.empty(R, dtype=torch.int32, device=head[3].device)
+    _call('perf_visibility_count2', _p(head[0]), _p(head[1]), _p(head[2]), _p(head[3]), _p(tail[0]), _p(tail[1]), _p(tail[2]), _p(tail[3]),
+          R, thr, _p(new_counts), _stream())
+    return new_counts
+
+
+def compact_prefix2(head, tail, new_counts, capacity):
+    """head / tail = (sigmas, t_starts, t_ends, packed_info, x01, sel) -> (ray_indices, t_starts, t_ends, sigmas, packed_info,
+    total, x01, sel) with `capacity` rows."""
+    R = new_counts.shape[0]
+    dev = new_counts.device
+    new_offsets, total = exclusive_scan_i32(new_counts)
+    S = int(capacity)
     ri = torch.empty(S, dtype=torch.int64, device=dev)
     ts = torch.empty(S, dtype=torch.float32, device=dev)
     te = torch.empty(S, dtype=torch.float32, device=dev)
-    packed = torch.empty(R, 2, dtype=torch.int32, device=dev)
-    pts = ()
-    if points_aabb is not None:
-        x01 = torch.empty(S, 3, dtype=torch.float32, device=dev)
-        sel = torch.empty(S, dtype=torch.uint8, device=dev)
-        _call('perf_occ_march_write_points', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
-              _p(ri), _p(ts), _p(te), _p(packed), _p(rays_o), _p(rays_d), _aabb6(points_aabb), _p(x01), _p(sel), _stream())
-        pts = (x01, sel)
-    else:
-        _call('perf_occ_march_write', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
-              _p(ri), _p(ts), _p(te), _p(packed), _stream())
-    if capacity is None:
-        return (ri, ts, te, packed) + pts
-    return (ri, ts, te, packed, total) + pts
+    sg = torch.empty(S, dtype=torch.float32, device=dev)
+    xo = torch.empty(S, 3, dtype=torch.float32, device=dev)
+    so = torch.empty(S, dtype=torch.uint8, device=dev)
+    packed_out = torch.empty(R, 2, dtype=torch.int32, device=dev)
+    _call('perf_compact_prefix2', _p(head[0]), _p(head[1]), _p(head[2]), _p(head[3]), _p(head[4]), _p(head[5]),
+          _p(tail[0]), _p(tail[1]), _p(tail[2]), _p(tail[3]), _p(tail[4]), _p(tail[5]), _p(new_counts), _p(new_offsets), R, S,
+          _p(ri), _p(ts), _p(te), _p(sg), _p(xo), _p(so), _p(packed_out), _stream())
+    return ri, ts, te, sg, packed_out, total, xo, so
 
 
 # ---- compositing -----------------------------------------------------------------------------------

@@ -52,6 +52,10 @@ class NeRFOCCRenderer(nn.Module):
         self.early_stop_eps = 1e-4
         self.max_steps = None          # None: ceil((far-near)/step)+1 like the reference; an int fixes the count
         self.sample_capacity = None    # int: sync-free sampling -- arrays of that many rows, live counts on the device
+        # two-phase early termination of the sync-free sampler (None = one phase): density on the first `head_samples`
+        # samples of every ray, then on the rest of the rays still alive; identical results, far fewer density
+        # evaluations once the scene is opaque (nerfacc_impl.OccGridEstimator.sampling_ex)
+        self.head_samples = 8
 
     # The render is cut in two stages so that a data-parallel trainer can overlap the gradient all-reduce of step k
     # with everything of step k+1 that does not depend on the parameters being updated (scene.py).
@@ -70,7 +74,7 @@ class NeRFOCCRenderer(nn.Module):
             rays_o, rays_d, sigma_points_fn=sigma_points_fn, near_plane=self.near_plane, far_plane=self.far_plane,
             render_step_size=self.render_step_size, early_stop_eps=self.early_stop_eps, stratified=nerf.training,
             cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'), max_steps=self.max_steps, capacity=self.sample_capacity,
-            points_aabb=nerf._aabb_host)
+            points_aabb=nerf._aabb_host, head_samples=self.head_samples)
         if sm.n_dev is None and sm.ray_indices.numel() <= 0:
             return None
         x01, sel = sm.x01, sm.sel

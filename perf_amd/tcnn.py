@@ -72,6 +72,8 @@ class _FieldFn(torch.autograd.Function):
         """n_dev (device int64 [1], optional): only the first min(len(x01), n_dev) rows are live (capacity-sized batch)."""
         w16 = module.working_copy(params)
         n_net = module.mlp.n_params
+        if not ctx.needs_input_grad[1]:          # (no_grad, or frozen parameters: the autograd engine asks for nothing)
+            return ops.field_infer(module.grid, module.mlp, x01, sel, w16, n_dev=n_dev)      # inference: nothing is kept
         feat = ops.hashgrid_fwd(module.grid, x01, w16[n_net:], n_dev=n_dev)
         out = ops.mlp_fwd(module.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
         ctx.module = module

@@ -120,15 +120,24 @@ def test_sync_free_sampling_equals_synced_sampling():
         marched_ref = int(scene.estimator.sampling_ex(o, d, near_plane=r.near_plane, far_plane=r.far_plane,
                                                       render_step_size=r.render_step_size).ray_indices.numel())
         assert 0 < n < marched_ref, 'the scene must be trained enough for early termination to drop samples'
-        r.sample_capacity = marched_ref + 1000
-        got = r.render(scene.nerf, scene.estimator, o, d, near, far)
-        r.sample_capacity = None
-    assert int(got['n_samples_dev'].item()) == n and int(got['n_marched_dev'].item()) == marched_ref
-    assert torch.equal(got['packed_info'], ref['packed_info'])
-    for k in ('ray_indices', 't_starts', 't_ends', 'weights', 'trans'):
-        assert torch.equal(got[k][:n], ref[k]), k
-    for k in ('rgb', 'distance', 'opacities'):
-        assert torch.equal(got[k], ref[k]), k
+        evaluated = {}
+        for head in (None, 8, 3, 64, 1000):
+            # head: two-phase early termination -- density on the first `head` samples of every ray, then on the rest of the
+            # rays still alive.  Same kept samples, bit for bit; far fewer density evaluations on an opaque scene.
+            r.sample_capacity = marched_ref + 1000
+            r.head_samples = head
+            got = r.render(scene.nerf, scene.estimator, o, d, near, far)
+            r.sample_capacity = None
+            assert int(got['n_samples_dev'].item()) == n, head
+            evaluated[head] = int(got['n_marched_dev'].item())
+            assert torch.equal(got['packed_info'], ref['packed_info']), head
+            for k in ('ray_indices', 't_starts', 't_ends', 'weights', 'trans'):
+                assert torch.equal(got[k][:n], ref[k]), (head, k)
+            for k in ('rgb', 'distance', 'opacities'):
+                assert torch.equal(got[k], ref[k]), (head, k)
+        r.head_samples = 8
+    assert evaluated[None] == evaluated[1000] == marched_ref            # one phase (or a head that covers every ray): everything
+    assert n <= evaluated[3] <= evaluated[8] <= evaluated[64] <= marched_ref and evaluated[8] < marched_ref
 
 
 def test_truncated_capacity_is_detected_and_rendered_again():
