@@ -37,6 +37,12 @@ def test_psnr_at_iter_matches_the_oracle_curve():
             depth.append(got['geo_end_depth_err'] / row['oracle']['geo_end_depth_err'])
     finally:
         tcnn.GRID_GRAD_ACCUM = mode0
+    other = 'fp16' if tcnn.DEFAULT_DTYPE == 'bf16' else 'bf16'          # informational: the other 16-bit type, first seed only
+    row = golden['seeds'][0]
+    geo0, app0 = P.init_params(row['seed'])
+    draws = P.make_draws(scene[0].shape[0], cfg['batch'], cfg['geo_iters'] + cfg['app_iters'], row['seed'])
+    got = P.run_hip(scene, geo0, app0, draws, cfg['geo_iters'], cfg['app_iters'], tuple(cfg['marks']), other, mode0)
+    print(f'({other}, seed {row["seed"]}: HIP - oracle', {k: round(got[k] - row['oracle'][k], 3) for k in deltas}, ')')
     print('HIP - oracle PSNR [dB]:', {k: [round(v, 3) for v in vs] for k, vs in deltas.items()}, 'depth-error ratio:', [round(v, 3) for v in depth])
     for k, vs in deltas.items():
         assert abs(float(np.mean(vs))) <= 0.1, (k, vs)
