@@ -202,6 +202,10 @@ def main():
     r.far_plane = 1.5                                                  # the reference's value (nerf_renderer.py:150); the lattice ends at 0.99
     r.early_stop_eps = 0.0 if args.no_prepass else 1e-4
     r.max_steps = args.spp
+    # one-phase density pass: fixed-count marching walks through empty space, no ray terminates inside its first few
+    # samples, so the two-phase early-terminating sampler (renderer.head_samples, the default of training / eval on real
+    # scenes) would only add launches here
+    r.head_samples = None
     rays_per_step = rays_local if args.mode != 'render' else 32768
     r.sample_capacity = rays_per_step * args.spp                     # = the marched count: nothing is ever truncated
     scene.nerf.reset_geo()

@@ -272,8 +272,25 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t seg_lo = (int64_t)blockIdx.x * 1024;
     // ---- sum of everything before the segment
+    // (seg_lo is a multiple of 1024: 16-byte loads, four independent accumulators -- the loop is latency bound)
     long long s = 0;
-    for (int64_t i = threadIdx.x; i < seg_lo; i += 1024) s += in[i];
+    {
+        const int4* in4 = reinterpret_cast<const int4*>(in);
+        const int64_t n4 = seg_lo >> 2;
+        long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int64_t i = threadIdx.x;
+        if ((reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+            for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+                const int4 a = in4[i], b = in4[i + 1024], c = in4[i + 2048], d = in4[i + 3072];
+                s0 += (long long)a.x + a.y + a.z + a.w; s1 += (long long)b.x + b.y + b.z + b.w;
+                s2 += (long long)c.x + c.y + c.z + c.w; s3 += (long long)d.x + d.y + d.z + d.w;
+            }
+            for (; i < n4; i += 1024) { const int4 a = in4[i]; s0 += (long long)a.x + a.y + a.z + a.w; }
+        } else {
+            for (int64_t j = threadIdx.x; j < seg_lo; j += 1024) s0 += in[j];
+        }
+        s = (s0 + s1) + (s2 + s3);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) wave_sum[wave] = s;

@@ -18,6 +18,7 @@ ap.add_argument('--poses', type=int, default=600)
 ap.add_argument('--geo-steps', type=int, default=300)
 ap.add_argument('--app-steps', type=int, default=150)
 ap.add_argument('--dtype', default='fp16')
+ap.add_argument('--head', type=int, default=8, help='two-phase sampler: density first on that many samples per ray (0 = one phase)')
 ap.add_argument('--batch', type=int, default=32768, help='rays per graph-captured eval batch (the reference hard-codes 32768, nerf.py:86)')
 args = ap.parse_args()
 
@@ -57,6 +58,7 @@ def frame_eager(p):
     return scene.render(r, ['rgb', 'distance'], batch_size=args.batch)
 
 # ONE hipGraph per frame: ray generation from a device-resident pose + 16 eval batches of 32,768 rays (nerf.py:86)
+scene.renderer.head_samples = args.head or None
 frame = scene.make_graphed_render(fh, fw, ('rgb', 'distance'), batch_size=args.batch)
 for p in poses[:3]:
     frame(p)
@@ -87,6 +89,6 @@ print(json.dumps({'config': 'render_dense: %d poses, %dx%d panoramic frames in %
                   'frame0_marched_samples': int(_c['n_marched_dev'].item()), 'frame0_kept_samples': int(_c['n_samples_dev'].item()),
                   'frames_per_s': len(poses) / t, 'rays_per_s': len(poses) * fh * fw / t, 'seconds': t,
                   'eager_sync_free_frames_per_s': 1.0 / t_eager, 'graphed_frame_equals_eager_frame': same,
-                  'per_ray_sample_capacity': frame.state['per_ray'],
+                  'per_ray_sample_capacity': frame.state['per_ray'], 'head_samples': args.head,
                   'pose_sampler_host_s': t_sampler, 'last_frame_rgb_sum': checksum,
                   'kernel_ms_one_frame': {k: round(n * ms, 3) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])}}, indent=1))
