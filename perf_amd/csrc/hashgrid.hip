@@ -1032,7 +1032,10 @@ extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, c
     PERF_REQUIRE(n >= 0 && n < (int64_t(1) << 31) * 16, "n out of range");
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(x01 && table16 && feat16, "NULL pointer");
-    static const int xcd_affinity = getenv("PERF_FWD_NO_XCD_AFFINITY") ? 0 : 1;
+    // level group <-> XCD pinning only pays when every one of the 8 groups has a level (L >= 15); a grid of a few levels
+    // (a rank's slice of a level-sharded table, the 5-level proposal field) would otherwise keep 1-3 XCDs busy
+    static const int affinity_env = getenv("PERF_FWD_NO_XCD_AFFINITY") ? 0 : 1;
+    const int xcd_affinity = (affinity_env && gp.n_levels >= 15) ? 1 : 0;
     // chunks (of 256 samples) per level group in one launch; beyond that the workgroups loop (experiment knob, read once)
     static const int64_t max_chunks = getenv("PERF_FWD_MAX_CHUNKS") ? atoll(getenv("PERF_FWD_MAX_CHUNKS")) : kFwdMaxChunks;
     int64_t chunks = div_up(n, 256);

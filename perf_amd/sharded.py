@@ -1,0 +1,171 @@
+"""BASELINE config 5 on several GPUs: hash tables cut by LEVEL over the ranks (last row).
+
+A field whose tables are sized to HBM (L = 20 levels up to resolution 8192, log2_hashmap_size 28-31: 9-57 GiB per
+encoder in 16 bits, 7x that with fp32 master + Adam state) is replicated for inference when it fits and sharded when it
+has to be trained.  The shard axis is the level: a level's table lives on exactly one rank, so
+
+  * forward: every rank all-gathers the batch's sample positions (12 B/sample), encodes ALL samples at ITS levels with the
+    same gfx950 kernel (its descriptor simply lists fewer levels), and ONE all-to-all returns to every rank the features
+    of its own samples at all levels (4 B per sample and level); the 64-wide MLP then runs locally on replicated weights;
+  * backward: the transpose -- one all-to-all of the feature gradients, then the local grid backward; table gradients,
+    fp32 masters and Adam state never leave their rank (no gradient all-reduce for 99.9 % of the parameters).
+
+Per sample and pass a rank moves (W-1)/W x (12 + 4 L) bytes over xGMI: 80 B at L = 20, i.e. ~56 GB/s per GPU at the
+7e8 ray-samples/s a single GPU reaches on such tables -- an eighth of the 7 x 64 GB/s a GPU can inject.  The exchange is
+an all-to-all, not a ring: every pair of GPUs has its own xGMI link, so all 7 links carry 1/7 of the traffic each.
+
+Levels are assigned greedily by table size (largest first to the least loaded rank) so that the shards are balanced in
+bytes AND in gather work (every level costs one 8-corner gather per sample whatever its size).
+"""
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .grid import GridConfig
+
+
+@dataclass
+class GridSlice:
+    """The levels `levels` of `full` as a grid of their own (what one rank holds): same per-level geometry, offsets
+    relative to the local table.  Duck-types GridConfig for perf_amd.ops (n_levels, n_params, total, desc())."""
+    full: GridConfig
+    levels: List[int]
+    offset: np.ndarray = field(init=False, repr=False)
+    total: int = field(init=False)
+
+    def __post_init__(self):
+        sizes = [int(self.full.size[l]) for l in self.levels]
+        self.offset = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64) if sizes else np.zeros(0, np.uint64)
+        self.total = int(sum(sizes))
+
+    @property
+    def n_levels(self):
+        return len(self.levels)
+
+    @property
+    def n_params(self):
+        return self.total * 2
+
+    @property
+    def interpolation(self):
+        return self.full.interpolation
+
+    def desc(self):
+        d = _lib.GridDesc()
+        d.n_levels = len(self.levels)
+        d.interpolation = _lib.INTERP_SMOOTHSTEP if self.full.interpolation == 'Smoothstep' else _lib.INTERP_LINEAR
+        for k, l in enumerate(self.levels):
+            d.scale[k] = float(self.full.scale[l]); d.res[k] = int(self.full.res[l]); d.size[k] = int(self.full.size[l])
+            d.offset[k] = int(self.offset[k]); d.hashed[k] = int(self.full.hashed[l])
+        return d
+
+
+def assign_levels(grid: GridConfig, world: int) -> List[List[int]]:
+    """Levels per rank: largest table first to the rank that holds the fewest levels, ties by bytes (deterministic)."""
+    order = sorted(range(grid.n_levels), key=lambda l: (-int(grid.size[l]), l))
+    held = [[] for _ in range(world)]
+    load = [0] * world
+    for l in order:
+        r = min(range(world), key=lambda q: (len(held[q]), load[q], q))
+        held[r].append(l); load[r] += int(grid.size[l])
+    return [sorted(h) for h in held]
+
+
+def _group():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+class LevelShardedEncoder:
+    """One rank's share of a level-sharded hash grid (16-bit table for encoding; `table32` when it is trained)."""
+
+    def __init__(self, grid: GridConfig, dtype='fp16', table16=None, seed=1337):
+        self.dist, self.rank, self.world = _group()
+        self.grid = grid
+        self.assignment = assign_levels(grid, self.world)
+        self.local = GridSlice(grid, self.assignment[self.rank])
+        self.dtype = ops.torch_dtype(dtype)
+        dev = torch.device('cuda', torch.cuda.current_device())
+        if table16 is None:
+            # every rank draws the FULL table's random stream level by level and keeps its own levels: the union equals the
+            # unsharded initialisation (tests compare against it); huge tables would be initialised shard-locally instead
+            g = torch.Generator().manual_seed(seed)
+            parts = []
+            for l in range(grid.n_levels):
+                t = (torch.rand(int(grid.size[l]) * 2, generator=g) * 2 - 1) * 1e-4
+                if l in self.local.levels:
+                    parts.append(t)
+            table16 = torch.cat(parts).to(self.dtype) if parts else torch.zeros(0, dtype=self.dtype)
+        self.table16 = table16.to(dev)
+
+    # ---- collectives (all-to-all on RCCL; gloo -- tests on one GPU -- has none, so it is composed from all_gather) ------
+    def _all_gather(self, t):
+        if self.dist is None or self.world == 1:
+            return t
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1)) if self.dist.get_backend() == 'nccl' else \
+            self.dist.all_gather(list(out.unbind(0)), t.contiguous())
+        return out
+
+    def _exchange(self, send, recv_rows):
+        """send [W, rows_mine, n, C]: block q goes to rank q.  Returns a list over source ranks s of [rows_s, n, C]."""
+        W = self.world
+        n, C = send.shape[2], send.shape[3]
+        if self.dist.get_backend() == 'nccl':
+            out = torch.empty(sum(recv_rows) * n * C, dtype=send.dtype, device=send.device)
+            self.dist.all_to_all_single(out, send.contiguous().view(-1), output_split_sizes=[r * n * C for r in recv_rows],
+                                        input_split_sizes=[send.shape[1] * n * C] * W)
+            return [p.view(r, n, C) for p, r in zip(out.split([r * n * C for r in recv_rows]), recv_rows)]
+        # gloo: everybody gathers everything (padded to the largest block) and keeps what was addressed to it
+        rmax = max(recv_rows)
+        pad = torch.zeros(W, rmax, n, C, dtype=send.dtype, device=send.device)
+        pad[:, :send.shape[1]] = send
+        everything = [torch.empty_like(pad) for _ in range(W)]
+        self.dist.all_gather(everything, pad)
+        return [everything[s][self.rank, :recv_rows[s]] for s in range(W)]
+
+    # ---- forward / backward -----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x01):
+        """x01 [n,3] (this rank's samples; the same n on every rank) -> feat [L, n, 2] 16-bit, level major, global order."""
+        n = x01.shape[0]
+        if self.world == 1:
+            return ops.hashgrid_fwd(self.local, x01, self.table16)
+        x_all = self._all_gather(x01).view(-1, 3)                                   # [W*n, 3]
+        f = ops.hashgrid_fwd(self.local, x_all, self.table16) if self.local.n_levels else \
+            torch.zeros(0, x_all.shape[0], 2, dtype=self.dtype, device=x01.device)
+        send = f.view(self.local.n_levels, self.world, n, 2).permute(1, 0, 2, 3)     # block q = my levels at q's samples
+        rows = [len(a) for a in self.assignment]
+        parts = self._exchange(send, rows)
+        feat = torch.empty(self.grid.n_levels, n, 2, dtype=self.dtype, device=x01.device)
+        for s, p in enumerate(parts):
+            if rows[s]:
+                feat[torch.tensor(self.assignment[s], device=x01.device)] = p
+        self._x_all = x_all                                                          # kept for table_gradient()
+        return feat
+
+    @torch.no_grad()
+    def table_gradient(self, dfeat, level_absmax=None, out=None):
+        """dfeat [L, n, 2] f32 (this rank's samples, global level order) -> fp32 gradient of THIS rank's table
+        [local.n_params]; positions are the ones of the preceding encode()."""
+        n = dfeat.shape[1]
+        if self.world == 1:
+            raise RuntimeError('single rank: use ops.hashgrid_bwd')
+        rows = [len(a) for a in self.assignment]
+        dev = dfeat.device
+        rmax = max(rows)
+        send = torch.zeros(self.world, rmax, n, 2, dtype=torch.float32, device=dev)   # block q = dfeat at q's levels
+        for q in range(self.world):
+            if rows[q]:
+                send[q, :rows[q]] = dfeat[torch.tensor(self.assignment[q], device=dev)]
+        mine = self.local.n_levels
+        parts = self._exchange(send, [rmax] * self.world)
+        d_all = torch.stack([p[:mine] for p in parts], 1).reshape(mine, self.world * n, 2).contiguous()   # [L_r, W*n, 2]
+        if mine == 0:
+            return torch.zeros(0, dtype=torch.float32, device=dev)
+        return ops.hashgrid_bwd(self.local, self._x_all, d_all, out=out)

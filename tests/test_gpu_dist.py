@@ -46,3 +46,21 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(tmp_path):
         assert float((two[k] - one[k]).norm()) < 0.1 * moved, (k, float((two[k] - one[k]).norm()), moved)
     # a batch without samples on any rank: the optimizer step is skipped everywhere (reference: nerf.py:204-206)
     assert one['empty_batch_skipped'] and two['empty_batch_skipped']
+
+
+@pytest.mark.parametrize('n_levels,log2_t', [(16, 18), (20, 20)])
+def test_level_sharded_encode_matches_the_unsharded_kernel(tmp_path, n_levels, log2_t):
+    """BASELINE config 5's multi-GPU split (perf_amd/sharded.py): tables cut by level over the ranks, positions
+    all-gathered, features returned by one all-to-all.  Two ranks on one GPU: the features every rank gets are
+    bit-identical to the unsharded encode, and the sharded table gradient equals the matching slice of the unsharded one."""
+    out = str(tmp_path / 's.pt')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(29600 + n_levels), os.path.join(ROOT, 'tests', 'sharded_worker.py'), out, str(n_levels), str(log2_t)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = torch.load(out)
+    assert res['world'] == 2 and all(res['fwd_equal']), res
+    assert max(res['bwd_rel_err']) < 1e-5, res                       # fp32 LDS atomics: association order only
+    a = res['assignment']
+    assert sorted(a[0] + a[1]) == list(range(n_levels)) and abs(len(a[0]) - len(a[1])) <= 1
