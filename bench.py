@@ -68,6 +68,7 @@ def parse():
                          'visibility compaction of the reference step (not the headline)')
     ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample')
     ap.add_argument('--no-psnr', action='store_true')
+    ap.add_argument('--no-reuse-line', action='store_true', help='skip the extra measurement with NeRFScene.reuse_sampling_features')
     ap.add_argument('--psnr-geo-iters', type=int, default=3000, help='configs/nerf.yaml:25 raw_phase_iter_geo')
     ap.add_argument('--psnr-app-iters', type=int, default=1500, help='configs/nerf.yaml:26 raw_phase_iter_app')
     ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='payload of the gradient all-reduce (N > 1)')
@@ -178,74 +179,79 @@ def main():
     from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
     args.dtype = args.dtype or tcnn.DEFAULT_DTYPE
 
-    torch.manual_seed(0)
-    scene = NeRFScene(dtype=args.dtype)
-    tc = scene.train_conf
-    scene.comm_dtype = args.comm_dtype
-    if args.scaling == 'weak':
-        rays_local = args.rays_per_gpu                               # 8192 rays on every GPU
-    else:
-        assert args.rays_per_gpu % world == 0
-        rays_local = args.rays_per_gpu // world                      # the reference's 8192-ray batch split over the GPUs
-    tc.pixel_loss_batch_size = rays_local * world
+    def build(reuse_features):
+        """Fresh scene + optimizer + (graphed) step of the benchmark workload -> (scene, step, eager_step, rays_per_step, graphed)."""
+        torch.manual_seed(0)
+        scene = NeRFScene(dtype=args.dtype)
+        tc = scene.train_conf
+        scene.comm_dtype = args.comm_dtype
+        scene.reuse_sampling_features = reuse_features
+        if args.scaling == 'weak':
+            rays_local = args.rays_per_gpu                               # 8192 rays on every GPU
+        else:
+            assert args.rays_per_gpu % world == 0
+            rays_local = args.rays_per_gpu // world                      # the reference's 8192-ray batch split over the GPUs
+        tc.pixel_loss_batch_size = rays_local * world
+        # fixed-count marching: all-occupied grid, 128 lattice intervals of 0.99/128 from the (jittered) origin; the
+        # reference's early termination (T >= 1e-4 after the no-grad density pass) then prunes what it prunes
+        scene.set_train()
+        scene.estimator.set_binaries(torch.ones(256 ** 3, dtype=torch.uint8, device=dev))
+        r = scene.renderer
+        r.render_step_size = 0.99 / args.spp
+        r.far_plane = 1.5                                                  # the reference's value (nerf_renderer.py:150); the lattice ends at 0.99
+        r.early_stop_eps = 0.0 if args.no_prepass else 1e-4
+        r.max_steps = args.spp
+        # one-phase density pass: fixed-count marching walks through empty space, no ray terminates inside its first few
+        # samples, so the two-phase early-terminating sampler (renderer.head_samples, the default of training / eval on real
+        # scenes) would only add launches here
+        r.head_samples = None
+        rays_per_step = rays_local if args.mode != 'render' else 32768
+        r.sample_capacity = rays_per_step * args.spp                     # = the marched count: nothing is ever truncated
+        scene.nerf.reset_geo()
+        scene.sample_counters = torch.zeros(3, dtype=torch.int64, device=dev)
+        gen = torch.Generator(device=dev); gen.manual_seed(1234)          # same index stream on every rank
+        use_graph = (world == 1) and (not args.no_graph) and args.mode != 'render'
+        graphed = None
+        if args.mode in ('train_geo', 'train_app'):
+            kind = 'geo' if args.mode == 'train_geo' else 'app'
+            net = scene.nerf.geo_mlp if kind == 'geo' else scene.nerf.app_mlp
+            conf = tc.geo_optimizer if kind == 'geo' else tc.app_optimizer
+            n_sched = 3000.0 if kind == 'geo' else 1500.0
+            opt = scene.make_optimizer(net, 0.0)
+            step_fn = scene.train_one_step_geo if kind == 'geo' else scene.train_one_step_app
+
+            def eager_step(i):
+                scene.update_lr(opt, conf, min(i / n_sched, 0.999))
+                step_fn(opt, pool, progress=0.25, generator=None if world == 1 else gen)
+            if use_graph:
+                graphed = scene.make_graphed_step(kind, opt, pool)
+
+            def step(i):
+                if graphed is not None:
+                    graphed(scene.lr_at(conf, min(i / n_sched, 0.999)), 0.25)
+                else:
+                    eager_step(i)
+        else:
+            scene.set_eval()
+            n_batches = (args.height * args.width) // 32768
+            flat_o = rays.o.reshape(-1, 3); flat_d = rays.d.reshape(-1, 3)
+            from perf_amd.scene import Rays
+
+            def step(i):
+                bb = i % n_batches
+                with torch.no_grad():
+                    res = scene.render_once(Rays(flat_o[bb * 32768:(bb + 1) * 32768], flat_d[bb * 32768:(bb + 1) * 32768]),
+                                            ['rgb', 'distance', 'n_marched_dev', 'n_samples_dev'])
+                    ops.step_bookkeeping(None, None, scene.sample_counters, res['n_marched_dev'], res['n_samples_dev'])
+            eager_step = step
+        return scene, step, eager_step, rays_per_step, graphed
+
     rays = gen_pano_rays(torch.eye(4), args.height, args.width, device=dev)
     dist_map, rgb_map = synthetic.room(rays.d)
     pool = SupInfoPool()
     pool.register_rays(rays.o, rays.d, rgb_map, dist_map)
-
-    # fixed-count marching: all-occupied grid, 128 lattice intervals of 0.99/128 from the (jittered) origin; the
-    # reference's early termination (T >= 1e-4 after the no-grad density pass) then prunes what it prunes
-    scene.set_train()
-    scene.estimator.set_binaries(torch.ones(256 ** 3, dtype=torch.uint8, device=dev))
-    r = scene.renderer
-    r.render_step_size = 0.99 / args.spp
-    r.far_plane = 1.5                                                  # the reference's value (nerf_renderer.py:150); the lattice ends at 0.99
-    r.early_stop_eps = 0.0 if args.no_prepass else 1e-4
-    r.max_steps = args.spp
-    # one-phase density pass: fixed-count marching walks through empty space, no ray terminates inside its first few
-    # samples, so the two-phase early-terminating sampler (renderer.head_samples, the default of training / eval on real
-    # scenes) would only add launches here
-    r.head_samples = None
-    rays_per_step = rays_local if args.mode != 'render' else 32768
-    r.sample_capacity = rays_per_step * args.spp                     # = the marched count: nothing is ever truncated
-    scene.nerf.reset_geo()
-    scene.sample_counters = torch.zeros(3, dtype=torch.int64, device=dev)
-    gen = torch.Generator(device=dev); gen.manual_seed(1234)          # same index stream on every rank
-
-    use_graph = (world == 1) and (not args.no_graph) and args.mode != 'render'
-    graphed = None
-    if args.mode in ('train_geo', 'train_app'):
-        kind = 'geo' if args.mode == 'train_geo' else 'app'
-        net = scene.nerf.geo_mlp if kind == 'geo' else scene.nerf.app_mlp
-        conf = tc.geo_optimizer if kind == 'geo' else tc.app_optimizer
-        n_sched = 3000.0 if kind == 'geo' else 1500.0
-        opt = scene.make_optimizer(net, 0.0)
-        step_fn = scene.train_one_step_geo if kind == 'geo' else scene.train_one_step_app
-
-        def eager_step(i):
-            scene.update_lr(opt, conf, min(i / n_sched, 0.999))
-            step_fn(opt, pool, progress=0.25, generator=None if world == 1 else gen)
-        if use_graph:
-            graphed = scene.make_graphed_step(kind, opt, pool)
-
-        def step(i):
-            if graphed is not None:
-                graphed(scene.lr_at(conf, min(i / n_sched, 0.999)), 0.25)
-            else:
-                eager_step(i)
-    else:
-        scene.set_eval()
-        n_batches = (args.height * args.width) // 32768
-        flat_o = rays.o.reshape(-1, 3); flat_d = rays.d.reshape(-1, 3)
-        from perf_amd.scene import Rays
-
-        def step(i):
-            b = i % n_batches
-            with torch.no_grad():
-                res = scene.render_once(Rays(flat_o[b * 32768:(b + 1) * 32768], flat_d[b * 32768:(b + 1) * 32768]),
-                                        ['rgb', 'distance', 'n_marched_dev', 'n_samples_dev'])
-                ops.step_bookkeeping(None, None, scene.sample_counters, res['n_marched_dev'], res['n_samples_dev'])
-        eager_step = step
+    scene, step, eager_step, rays_per_step, graphed = build(False)
+    tc, r = scene.train_conf, scene.renderer
 
     def timed(n_steps, first):
         """n_steps steps bracketed by barrier + synchronize on both sides; -> (seconds = max over ranks, marched, kept)."""
@@ -296,6 +302,21 @@ def main():
     kern = ops.stop_kernel_timing()
     c_ev = scene.sample_counters.tolist()
     marched_ev, kept_ev = c_ev[0] / max(args.steps, 1), c_ev[1] / max(args.steps, 1)     # per step, this rank
+
+    # the same K steps from the same fresh initialisation with the gradient pass starting from the sampler's encoded
+    # features (NeRFScene.reuse_sampling_features: bit-identical parameters, one encode of the kept samples fewer); reported
+    # NEXT TO the headline, which keeps the reference's two density evaluations
+    reuse_block = None
+    if args.mode == 'train_geo' and not args.no_prepass and not args.no_reuse_line:
+        strict = (scene, step)
+        scene, step, _, _, _ = build(True)
+        for i in range(args.warmup):
+            step(i)
+        el_r, m_r, k_r = timed(args.steps, args.warmup)
+        reuse_block = {'value': k_r / el_r, 'ms_per_step': el_r / args.steps * 1e3, 'steps': args.steps,
+                       'what': 'gradient pass of the density field starts from the features the sampling pass encoded (compacted with the '
+                               'samples) instead of encoding the kept samples a second time; parameters bit-identical to the headline path'}
+        scene, step = strict
 
     psnr_block = None
     if not args.no_psnr and args.mode == 'train_geo':
@@ -358,7 +379,7 @@ def main():
                        'per_gpu_value': value / world,
                        'launch': 'hipGraph replay of the whole step' if graphed is not None else 'eager',
                        'kernel_timing': 'HIP events around every launch in an eager re-run of the same steps right after the timed region'},
-            'sustained': sustained, 'psnr': psnr_block,
+            'sustained': sustained, 'with_feature_reuse': reuse_block, 'psnr': psnr_block,
             'roofline': roof, 'cpu_baseline': cpu, 'kernels': table,
         }
         print(json.dumps(line))

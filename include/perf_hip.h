@@ -289,12 +289,16 @@ int perf_visibility_count(const float* sigmas, const float* t_starts, const floa
 
 /* Copy the first new_counts[r] samples of every ray to new_offsets[r] (the boolean-mask
  * compaction of nerfacc's sampling).  sigmas_in/out may be NULL; so may the sample positions x01 [S,3] / sel [S]
- * (as written by perf_occ_march_write_points), which are then compacted along instead of being recomputed. */
+ * (as written by perf_occ_march_write_points), which are then compacted along instead of being recomputed, and the
+ * level-major 16-bit features of the density pass (feat[l * stride + i], n_levels levels; NULL = none): the reference
+ * evaluates the density field a second time on the kept samples (nerf_renderer.py:166-168) with the same parameters at the
+ * same positions, so the compacted features ARE that evaluation's encoding. */
 int perf_compact_prefix(const int32_t* packed_info, const int32_t* new_counts, const int32_t* new_offsets,
                         int64_t n_rays, const float* ts_in, const float* te_in, const float* sig_in,
                         int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out,
                         int32_t* packed_out, const float* x01_in, const uint8_t* sel_in, float* x01_out,
-                        uint8_t* sel_out, void* stream);
+                        uint8_t* sel_out, const void* feat_in, int64_t feat_stride_in, void* feat_out,
+                        int64_t feat_stride_out, int32_t n_levels, void* stream);
 
 /* ---- two-phase early termination (same results as perf_visibility_count + perf_compact_prefix over all samples) -------
  * nerfacc's render_visibility_from_density keeps a PREFIX of every ray (the exclusive sum of sigma*delta never decreases),
@@ -317,7 +321,9 @@ int perf_compact_prefix2(const float* sig_h, const float* ts_h, const float* te_
                          const float* te_t, const int32_t* packed_t, const float* x01_t, const uint8_t* sel_t,
                          const int32_t* new_counts, const int32_t* new_offsets, int64_t n_rays, int64_t capacity,
                          int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out, float* x01_out,
-                         uint8_t* sel_out, int32_t* packed_out, void* stream);
+                         uint8_t* sel_out, int32_t* packed_out, const void* feat_h, int64_t feat_stride_h,
+                         const void* feat_t, int64_t feat_stride_t, void* feat_out, int64_t feat_stride_out,
+                         int32_t n_levels, void* stream);
 
 /* weights/trans/alphas [S] and per-ray opacity [R], distance [R], colour [R,3] (rgbs may be NULL).
  * One wave per ray: no atomics. */

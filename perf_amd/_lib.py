@@ -72,9 +72,9 @@ _SIGS = {
     'perf_occ_march_write_points': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P, P, POINTER(c_float), P, P, c_int32, P]),
     'perf_head_tail_counts': (c_int, [P, c_int64, c_int32, P, P, P]),
     'perf_visibility_count2': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_float, P, P]),
-    'perf_compact_prefix2': (c_int, [P] * 14 + [c_int64, c_int64] + [P] * 8),
+    'perf_compact_prefix2': (c_int, [P] * 14 + [c_int64, c_int64] + [P] * 7 + [P, c_int64, P, c_int64, P, c_int64, c_int32, P]),
     'perf_visibility_count': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
-    'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, P, c_int64, c_int32, P]),
     'perf_composite_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     'perf_composite_bwd': (c_int, [P, P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P]),
     'perf_render_finish_eval': (c_int, [P, P, P, c_int64, P, P]),

@@ -60,6 +60,16 @@ __global__ __launch_bounds__(256) void visibility_count_kernel(const float* __re
     if (lane == 0) new_counts[r] = kept;
 }
 
+// optional copy of the level-major features the density pass of the sampler produced (reused by the gradient pass: the
+// reference evaluates the density field twice on the kept samples, nerf_renderer.py:145-148 and :166-168 -- same
+// parameters, same positions, bit-identical features)
+struct FeatCopy {
+    const uint32_t* in_h; int64_t stride_h;       // head (or only) source
+    const uint32_t* in_t; int64_t stride_t;       // tail source (two-phase sampler)
+    uint32_t* out; int64_t stride_out;
+    int32_t n_levels;
+};
+
 __global__ __launch_bounds__(256) void compact_prefix_kernel(const int32_t* __restrict__ packed, const int32_t* __restrict__ new_counts,
                                                              const int32_t* __restrict__ new_offsets, int64_t n_rays,
                                                              const float* __restrict__ ts_in, const float* __restrict__ te_in,
@@ -67,7 +77,8 @@ __global__ __launch_bounds__(256) void compact_prefix_kernel(const int32_t* __re
                                                              float* __restrict__ ts_out, float* __restrict__ te_out,
                                                              float* __restrict__ sig_out, int32_t* __restrict__ packed_out,
                                                              const float* __restrict__ x01_in, const uint8_t* __restrict__ sel_in,
-                                                             float* __restrict__ x01_out, uint8_t* __restrict__ sel_out) {
+                                                             float* __restrict__ x01_out, uint8_t* __restrict__ sel_out,
+                                                             FeatCopy fc) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rays) return;
@@ -84,6 +95,9 @@ __global__ __launch_bounds__(256) void compact_prefix_kernel(const int32_t* __re
     }
     if (x01_out)            // positions of the kept samples: 3*cnt contiguous floats
         for (int i = lane; i < 3 * cnt; i += 64) x01_out[3 * dst + i] = x01_in[3 * src + i];
+    if (fc.out)             // level-major encoded features of the kept samples (one packed 2x16-bit dword per level)
+        for (int l = 0; l < fc.n_levels; ++l)
+            for (int i = lane; i < cnt; i += 64) fc.out[(int64_t)l * fc.stride_out + dst + i] = fc.in_h[(int64_t)l * fc.stride_h + src + i];
 }
 
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ sig, const float* __restrict__ rgb,
@@ -319,16 +333,19 @@ extern "C" int perf_compact_prefix(const int32_t* packed_info, const int32_t* ne
                                    int64_t n_rays, const float* ts_in, const float* te_in, const float* sig_in,
                                    int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out,
                                    int32_t* packed_out, const float* x01_in, const uint8_t* sel_in, float* x01_out,
-                                   uint8_t* sel_out, void* stream) {
+                                   uint8_t* sel_out, const void* feat_in, int64_t feat_stride_in, void* feat_out,
+                                   int64_t feat_stride_out, int32_t n_levels, void* stream) {
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && new_counts && new_offsets && packed_out, "NULL pointer");
     PERF_REQUIRE((sig_in == nullptr) == (sig_out == nullptr), "sig_in/sig_out must both be given or both be NULL");
     PERF_REQUIRE((x01_in == nullptr) == (x01_out == nullptr) && (sel_in == nullptr) == (sel_out == nullptr),
                  "x01/sel in and out must both be given or both be NULL");
+    PERF_REQUIRE((feat_in == nullptr) == (feat_out == nullptr), "feat in and out must both be given or both be NULL");
+    FeatCopy fc{(const uint32_t*)feat_in, feat_stride_in, nullptr, 0, (uint32_t*)feat_out, feat_stride_out, n_levels};
     hipLaunchKernelGGL(compact_prefix_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), packed_info, new_counts,
                        new_offsets, n_rays, ts_in, te_in, sig_in, ray_indices_out, ts_out, te_out, sig_out, packed_out, x01_in, sel_in,
-                       x01_out, sel_out);
+                       x01_out, sel_out, fc);
     PERF_LAUNCH_CHECK("perf_compact_prefix");
     return PERF_OK;
 }
@@ -491,7 +508,7 @@ __global__ __launch_bounds__(256) void compact_prefix2_kernel(TwoSource src, con
                                                               int64_t n_rays, int64_t capacity, int64_t* __restrict__ ri_out,
                                                               float* __restrict__ ts_out, float* __restrict__ te_out, float* __restrict__ sig_out,
                                                               float* __restrict__ x01_out, uint8_t* __restrict__ sel_out,
-                                                              int32_t* __restrict__ packed_out) {
+                                                              int32_t* __restrict__ packed_out, FeatCopy fc) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rays) return;
@@ -514,6 +531,11 @@ __global__ __launch_bounds__(256) void compact_prefix2_kernel(TwoSource src, con
             x01_out[3 * (dst + i)] = p[0]; x01_out[3 * (dst + i) + 1] = p[1]; x01_out[3 * (dst + i) + 2] = p[2];
         }
     }
+    if (fc.out)
+        for (int l = 0; l < fc.n_levels; ++l)
+            for (int i = lane; i < cnt; i += 64)
+                fc.out[(int64_t)l * fc.stride_out + dst + i] = (i < ch) ? fc.in_h[(int64_t)l * fc.stride_h + sh + i]
+                                                                        : fc.in_t[(int64_t)l * fc.stride_t + st + (i - ch)];
 }
 }  // namespace perf
 
@@ -545,15 +567,20 @@ extern "C" int perf_compact_prefix2(const float* sig_h, const float* ts_h, const
                                     const float* te_t, const int32_t* packed_t, const float* x01_t, const uint8_t* sel_t,
                                     const int32_t* new_counts, const int32_t* new_offsets, int64_t n_rays, int64_t capacity,
                                     int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out, float* x01_out,
-                                    uint8_t* sel_out, int32_t* packed_out, void* stream) {
+                                    uint8_t* sel_out, int32_t* packed_out, const void* feat_h, int64_t feat_stride_h,
+                                    const void* feat_t, int64_t feat_stride_t, void* feat_out, int64_t feat_stride_out,
+                                    int32_t n_levels, void* stream) {
     PERF_REQUIRE(n_rays >= 0 && capacity >= 0, "perf_compact_prefix2: bad arguments");
+    PERF_REQUIRE(!feat_out || (feat_h && feat_t), "perf_compact_prefix2: feat_out needs both feature sources");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_h && packed_t && new_counts && new_offsets && packed_out, "NULL pointer");
     PERF_REQUIRE(capacity == 0 || (ray_indices_out && ts_out && te_out), "NULL sample arrays");
     perf::TwoSource src{sig_h, ts_h, te_h, packed_h, sig_t, ts_t, te_t, packed_t};
     hipLaunchKernelGGL(perf::compact_prefix2_kernel, perf::ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, x01_h, sel_h,
                        x01_t, sel_t, new_counts, new_offsets, n_rays, capacity, ray_indices_out, ts_out, te_out, sig_out, x01_out,
-                       sel_out, packed_out);
+                       sel_out, packed_out,
+                       perf::FeatCopy{(const uint32_t*)feat_h, feat_stride_h, (const uint32_t*)feat_t, feat_stride_t, (uint32_t*)feat_out,
+                                      feat_stride_out, n_levels});
     PERF_LAUNCH_CHECK("perf_compact_prefix2");
     return PERF_OK;
 }

@@ -103,6 +103,15 @@ class NGPNeRF(nn.Module):
     def density_at(self, x01, sel, n_dev=None):
         return _FieldFn.apply(x01, self.geo_mlp.params, sel, self.geo_mlp, n_dev)[:, 0]
 
+    @torch.no_grad()
+    def density_with_features(self, x01, sel, n_dev=None):
+        """Density without gradient plus the level-major encoded features it was computed from -> (sigma [n], feat [L,n,2])."""
+        net = self.geo_mlp
+        w16 = net.working_copy()
+        n_net = net.mlp.n_params
+        feat = ops.hashgrid_fwd(net.grid, x01, w16[n_net:], n_dev=n_dev)
+        return ops.mlp_fwd(net.mlp, w16[:n_net], feat, sel, n_dev=n_dev)[:, 0], feat
+
     def rgb_at(self, x01, sel, n_dev=None):
         return _FieldFn.apply(x01, self.app_mlp.params, sel, self.app_mlp, n_dev)
 

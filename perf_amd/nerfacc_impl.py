@@ -98,9 +98,15 @@ def render_transmittance_from_alpha(*args, **kwargs):
     raise NotImplementedError('imported but never called by PeRF (nerf_renderer.py:5)')
 
 
+def _sig_feat(res):
+    """sigma_points_fn result -> (sigmas [n] fp32 contiguous, level-major features or None)."""
+    sig, feat = res if isinstance(res, tuple) else (res, None)
+    return sig.reshape(-1).float().contiguous(), feat
+
+
 class Samples:
     """Packed samples of one ray batch (see OccGridEstimator.sampling_ex)."""
-    __slots__ = ('ray_indices', 't_starts', 't_ends', 'packed', 'sig', 'x01', 'sel', 'n_dev', 'n_marched_dev')
+    __slots__ = ('ray_indices', 't_starts', 't_ends', 'packed', 'sig', 'x01', 'sel', 'n_dev', 'n_marched_dev', 'feat')
 
     def __init__(self):
         for k in self.__slots__:
@@ -180,7 +186,9 @@ class OccGridEstimator(nn.Module):
         head_samples (sync-free mode with a visibility pass): two-phase early termination -- the density pass first runs
           on the first `head_samples` samples of every ray and then only on the rest of the rays that are still alive (a
           trained scene terminates a ray after a sample or two); same samples, same sigmas as the one-phase path.
-          n_marched_dev then counts the samples whose density was evaluated."""
+          n_marched_dev then counts the samples whose density was evaluated.
+        sigma_points_fn may return (sigmas, feat): the level-major encoded features of its density pass are then compacted
+          along with the samples (Samples.feat) so that a gradient pass on the kept samples need not encode them again."""
         if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
             raise NotImplementedError('PeRF samples with cone_angle=0 and a sigma_fn (nerf_renderer.py:145-155)')
         if alpha_thre != 0.0:
@@ -227,10 +235,11 @@ class OccGridEstimator(nn.Module):
             sm.n_marched_dev = total
             sig = None
             if compacts:
-                sig = sigma_points_fn(x01, sel, total).reshape(-1).float().contiguous()
+                sig, feat = _sig_feat(sigma_points_fn(x01, sel, total))
                 new_counts = ops.visibility_count(sig, ts, te, packed, early_stop_eps)
-                ri, ts, te, sig, packed, total, x01, sel = ops.compact_prefix(packed, new_counts, ts, te, sig,
-                                                                              capacity=capacity, x01=x01, sel=sel)
+                out = ops.compact_prefix(packed, new_counts, ts, te, sig, capacity=capacity, x01=x01, sel=sel, feat=feat)
+                ri, ts, te, sig, packed, total, x01, sel = out[:8]
+                sm.feat = out[8] if feat is not None else None
             sm.n_dev = total
         else:
             out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size), max_steps,
@@ -267,18 +276,20 @@ class OccGridEstimator(nn.Module):
         ch = ops.head_tail_counts(counts, K)
         oh, total_h = ops.exclusive_scan_i32(ch)
         ri_h, ts_h, te_h, pk_h, x_h, s_h = ops.occ_march_write(t0, masks, ch, oh, R * K, step, max_steps, rays_o, rays_d, points_aabb)
-        sig_h = sigma_points_fn(x_h, s_h, total_h).reshape(-1).float().contiguous()
+        sig_h, feat_h = _sig_feat(sigma_points_fn(x_h, s_h, total_h))
         kept_h = ops.visibility_count(sig_h, ts_h, te_h, pk_h, early_stop_eps)
         # ---- tail: rank [K, count) of the rays whose whole head survived
         ct = ops.head_tail_counts(counts, K, kept_h)
         ot, total_t = ops.exclusive_scan_i32(ct)
         ri_t, ts_t, te_t, pk_t, x_t, s_t = ops.occ_march_write(t0, masks, ct, ot, capacity, step, max_steps, rays_o, rays_d, points_aabb,
                                                                rank_lo=K)
-        sig_t = sigma_points_fn(x_t, s_t, total_t).reshape(-1).float().contiguous()
+        sig_t, feat_t = _sig_feat(sigma_points_fn(x_t, s_t, total_t))
         # ---- final decision and compaction over both sample sets
         head = (sig_h, ts_h, te_h, pk_h, x_h, s_h); tail = (sig_t, ts_t, te_t, pk_t, x_t, s_t)
         new_counts = ops.visibility_count2(head[:4], tail[:4], early_stop_eps)
-        ri, ts, te, sig, packed, total, x01, sel = ops.compact_prefix2(head, tail, new_counts, capacity)
+        out = ops.compact_prefix2(head, tail, new_counts, capacity, feat_h, feat_t)
+        ri, ts, te, sig, packed, total, x01, sel = out[:8]
+        sm.feat = out[8] if feat_h is not None else None
         ri._perf_packed = packed
         sm.ray_indices, sm.t_starts, sm.t_ends, sm.packed, sm.sig, sm.x01, sm.sel = ri, ts, te, packed, sig, x01, sel
         sm.n_dev = total

@@ -413,9 +413,9 @@ def visibility_count2(head, tail, early_stop_eps=1e-4):
     return new_counts
 
 
-def compact_prefix2(head, tail, new_counts, capacity):
+def compact_prefix2(head, tail, new_counts, capacity, feat_h=None, feat_t=None):
     """head / tail = (sigmas, t_starts, t_ends, packed_info, x01, sel) -> (ray_indices, t_starts, t_ends, sigmas, packed_info,
-    total, x01, sel) with `capacity` rows."""
+    total, x01, sel[, feat]) with `capacity` rows; feat_h / feat_t: level-major features of the two sample sets."""
     R = new_counts.shape[0]
     dev = new_counts.device
     new_offsets, total = exclusive_scan_i32(new_counts)
@@ -427,10 +427,14 @@ def compact_prefix2(head, tail, new_counts, capacity):
     xo = torch.empty(S, 3, dtype=torch.float32, device=dev)
     so = torch.empty(S, dtype=torch.uint8, device=dev)
     packed_out = torch.empty(R, 2, dtype=torch.int32, device=dev)
+    fo = torch.empty(feat_h.shape[0], S, 2, dtype=feat_h.dtype, device=dev) if feat_h is not None else None
     _call('perf_compact_prefix2', _p(head[0]), _p(head[1]), _p(head[2]), _p(head[3]), _p(head[4]), _p(head[5]),
           _p(tail[0]), _p(tail[1]), _p(tail[2]), _p(tail[3]), _p(tail[4]), _p(tail[5]), _p(new_counts), _p(new_offsets), R, S,
-          _p(ri), _p(ts), _p(te), _p(sg), _p(xo), _p(so), _p(packed_out), _stream())
-    return ri, ts, te, sg, packed_out, total, xo, so
+          _p(ri), _p(ts), _p(te), _p(sg), _p(xo), _p(so), _p(packed_out),
+          _p(feat_h), feat_h.shape[1] if feat_h is not None else 0, _p(feat_t), feat_t.shape[1] if feat_t is not None else 0,
+          _p(fo), S, feat_h.shape[0] if feat_h is not None else 0, _stream())
+    res = (ri, ts, te, sg, packed_out, total, xo, so)
+    return res + (fo,) if fo is not None else res
 
 
 # ---- compositing -----------------------------------------------------------------------------------
@@ -444,7 +448,7 @@ def visibility_count(sigmas, t_starts, t_ends, packed, early_stop_eps=1e-4, want
     return (new_counts, ex) if want_exsum else new_counts
 
 
-def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=None, x01=None, sel=None):
+def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=None, x01=None, sel=None, feat=None):
     """-> (ray_indices, t_starts, t_ends, sigmas, packed_info) of the kept prefixes; with capacity (sync-free mode: the
     arrays keep that length, the kept count stays on the device) also `total` (int64 [1]); with x01/sel also the compacted
     positions, appended to the result."""
@@ -459,13 +463,17 @@ def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=N
     xo = torch.empty(S, 3, dtype=torch.float32, device=dev) if x01 is not None else None
     so = torch.empty(S, dtype=torch.uint8, device=dev) if sel is not None else None
     packed_out = torch.empty(R, 2, dtype=torch.int32, device=dev)
+    fo = torch.empty(feat.shape[0], S, 2, dtype=feat.dtype, device=dev) if feat is not None else None     # level major like feat
     _call('perf_compact_prefix', _p(packed), _p(new_counts), _p(new_offsets), R, _p(t_starts), _p(t_ends), _p(sigmas),
-              _p(ri), _p(ts), _p(te), _p(sg), _p(packed_out), _p(x01), _p(sel), _p(xo), _p(so), _stream())
+              _p(ri), _p(ts), _p(te), _p(sg), _p(packed_out), _p(x01), _p(sel), _p(xo), _p(so),
+              _p(feat), feat.shape[1] if feat is not None else 0, _p(fo), S, feat.shape[0] if feat is not None else 0, _stream())
     res = (ri, ts, te, sg, packed_out)
     if capacity is not None:
         res = res + (total,)
     if x01 is not None:
         res = res + (xo, so)
+    if feat is not None:
+        res = res + (fo,)
     return res
 
 

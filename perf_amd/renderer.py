@@ -55,19 +55,24 @@ class NeRFOCCRenderer(nn.Module):
         # two-phase early termination of the sync-free sampler (None = one phase): density on the first `head_samples`
         # samples of every ray, then on the rest of the rays still alive; identical results, far fewer density
         # evaluations once the scene is opaque (nerfacc_impl.OccGridEstimator.sampling_ex)
-        self.head_samples = 8
+        self.head_samples = 4
 
     # The render is cut in two stages so that a data-parallel trainer can overlap the gradient all-reduce of step k
     # with everything of step k+1 that does not depend on the parameters being updated (scene.py).
-    def stage_sample(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, rand=None, with_rgb=False):
+    def stage_sample(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, rand=None, with_rgb=False,
+                     keep_features=False):
         """Sampling (marching, the no-grad density pass and visibility compaction of nerf_renderer.py:145-155), sample
         positions and -- with_rgb -- the colour field without gradient.  Returns a dict consumed by stage_composite, or
         None when the batch has no sample.  With self.sample_capacity set every per-sample array has that many rows and
-        st['n_dev'] (device int64 [1]) holds the live count: no host read-back, hipGraph-capturable."""
+        st['n_dev'] (device int64 [1]) holds the live count: no host read-back, hipGraph-capturable.
+        keep_features (sync-free mode): st['feat0'] = the density field's encoded features of the KEPT samples, compacted from
+        the sampler's own density pass."""
         rays_o = rays_o.contiguous().float(); rays_d = rays_d.contiguous().float()
         rand = rand or {}
 
         def sigma_points_fn(x01, sel, n_dev):
+            if keep_features:
+                return nerf.density_with_features(x01, sel, n_dev)
             return nerf.density_at(x01, sel, n_dev)
 
         sm = estimator.sampling_ex(
@@ -82,7 +87,7 @@ class NeRFOCCRenderer(nn.Module):
             x01, sel = nerf.sample_points(rays_o, rays_d, sm.ray_indices, sm.t_starts, sm.t_ends)
         st = {'ray_indices': sm.ray_indices, 't_starts': sm.t_starts, 't_ends': sm.t_ends, 'packed': sm.packed, 'sig0': sm.sig,
               'x01': x01, 'sel': sel, 'n_rays': rays_o.shape[0], 'rgbs': None, 'n_dev': sm.n_dev,
-              'n_marched_dev': sm.n_marched_dev}
+              'n_marched_dev': sm.n_marched_dev, 'feat0': sm.feat}
         if with_rgb:
             with torch.no_grad():
                 st['rgbs'] = nerf.rgb_at(x01, sel, sm.n_dev)

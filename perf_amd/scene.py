@@ -196,6 +196,12 @@ class NeRFScene:
         # DP payload of the gradient all-reduce: 'fp32' (exact sum, 26.6 MB) or 'bf16' (13.3 MB: every rank's gradient is
         # rounded to bf16 and summed in bf16 by RCCL -- ~2^-9 relative noise on a quantity Adam normalises anyway)
         self.comm_dtype = 'fp32'
+        # The reference's geometry step evaluates the density field twice on the kept samples: without gradient inside
+        # OccGridEstimator.sampling and with gradient in the renderer (nerf_renderer.py:145-148, :166-168) -- same parameters,
+        # same positions.  True (sync-free mode): the encoded features of the sampler's pass are compacted along with the
+        # samples and the gradient pass starts from them instead of encoding again: bit-identical parameters
+        # (tests/test_gpu_counts.py), one encode fewer.  Off by default: the default step mirrors the reference op for op.
+        self.reuse_sampling_features = False
         self._geo_pre = None
         self._ratio_dev = torch.zeros((), dtype=torch.float32, device='cuda')   # distortion-loss ramp min(2*progress, 1)
         # device-side sample statistics {marched, kept, steps} (int64 [3]); None = not collected.  bench.py reads them
@@ -451,7 +457,8 @@ class NeRFScene:
         st = pre['st']
         rand_in, rand = rand, pre['rand']
         if st is None:
-            st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=not self.skip_unused_color)
+            st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=not self.skip_unused_color,
+                                            keep_features=self.reuse_sampling_features and self.renderer.sample_capacity is not None)
         geo = self.nerf.geo_mlp
         extra = 1 if dist_info[0] is not None else 0
         if st is None or st is False:
@@ -463,7 +470,9 @@ class NeRFScene:
         self._last_counts = (st['n_marched_dev'], n_dev)
         n_net = geo.mlp.n_params
         w16 = geo.working_copy()
-        feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:], n_dev=n_dev)
+        feat = st.get('feat0')
+        if feat is None:
+            feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:], n_dev=n_dev)
         sig = ops.mlp_fwd(geo.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
         # The colour render of this step (query key 'rgb', nerf.py:197-201) feeds no loss term (:208-252).  Under data
         # parallelism it is therefore issued AFTER the gradient all-reduce has been launched: the colour field's encode +
