@@ -308,10 +308,12 @@ class NeRFScene:
         self.nerf.reset_geo()
         if use_graphs is None:
             use_graphs = self.graph_steps
-        use_graphs = bool(use_graphs) and self.fused_adam and self.fused_steps and self._dist()[0] is None
+        sync_free = self.fused_adam and self.fused_steps          # capacity-sized arrays + device-side counts: no host read-back
+        use_graphs = bool(use_graphs) and sync_free and self._dist()[0] is None      # (the all-reduce of a DP step stays eager)
         saved_capacity = self.renderer.sample_capacity
-        if use_graphs and saved_capacity is None:
-            self.renderer.sample_capacity = self.train_conf.pixel_loss_batch_size * self.TRAIN_SAMPLES_PER_RAY
+        if sync_free and saved_capacity is None:
+            per_rank = self.train_conf.pixel_loss_batch_size // max(self._dist()[2], 1)
+            self.renderer.sample_capacity = per_rank * self.TRAIN_SAMPLES_PER_RAY
         try:
             geo_optimizer = self.make_optimizer(self.nerf.geo_mlp, self.train_conf.geo_optimizer.init_lr)
             self._run_phase('geo', geo_optimizer, self.train_conf.geo_optimizer, geo_res_iters, sup_pool, callback,
@@ -365,9 +367,16 @@ class NeRFScene:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
         optimizer.step()
         self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
-        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY and _tcnn.GRID_GRAD_ACCUM == 'fixed':
-            self._steps_since_check = 0
-            _tcnn.check_fixed_point_overflow(net.params.device)
+        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY:
+            self._steps_since_check = 0                # one host read-back every OVERFLOW_CHECK_EVERY eager steps
+            if _tcnn.GRID_GRAD_ACCUM == 'fixed':
+                _tcnn.check_fixed_point_overflow(net.params.device)
+            cap = self.renderer.sample_capacity
+            if cap is not None and torch.is_tensor(n_marched) and int(n_marched.item()) > cap:
+                import warnings
+                warnings.warn(f'perf_amd: a training batch evaluated {int(n_marched.item())} samples, more than the capacity {cap} '
+                              '(late rays were truncated); doubling the capacity')
+                self.renderer.sample_capacity = 2 * int(n_marched.item())
 
     def _geo_prefetch(self, sup_pool, rand, generator):
         """Everything of a geometry step that does not depend on the geometry parameters: batch draw, and -- when the
@@ -435,13 +444,27 @@ class NeRFScene:
                 optimizer.step()
             net.params.grad = None
         self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
-        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY and _tcnn.GRID_GRAD_ACCUM == 'fixed':
-            self._steps_since_check = 0
-            _tcnn.check_fixed_point_overflow(net.params.device)
+        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY:
+            self._steps_since_check = 0                # one host read-back every OVERFLOW_CHECK_EVERY eager steps
+            if _tcnn.GRID_GRAD_ACCUM == 'fixed':
+                _tcnn.check_fixed_point_overflow(net.params.device)
+            cap = self.renderer.sample_capacity
+            if cap is not None and torch.is_tensor(n_marched) and int(n_marched.item()) > cap:
+                import warnings
+                warnings.warn(f'perf_amd: a training batch evaluated {int(n_marched.item())} samples, more than the capacity {cap} '
+                              '(late rays were truncated); doubling the capacity')
+                self.renderer.sample_capacity = 2 * int(n_marched.item())
         self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
-        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY and _tcnn.GRID_GRAD_ACCUM == 'fixed':
-            self._steps_since_check = 0
-            _tcnn.check_fixed_point_overflow(net.params.device)
+        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY:
+            self._steps_since_check = 0                # one host read-back every OVERFLOW_CHECK_EVERY eager steps
+            if _tcnn.GRID_GRAD_ACCUM == 'fixed':
+                _tcnn.check_fixed_point_overflow(net.params.device)
+            cap = self.renderer.sample_capacity
+            if cap is not None and torch.is_tensor(n_marched) and int(n_marched.item()) > cap:
+                import warnings
+                warnings.warn(f'perf_amd: a training batch evaluated {int(n_marched.item())} samples, more than the capacity {cap} '
+                              '(late rays were truncated); doubling the capacity')
+                self.renderer.sample_capacity = 2 * int(n_marched.item())
 
     @torch.no_grad()
     def _geo_step_fused(self, optimizer, sup_pool, progress, rand, generator, prefetch_next=True):
