@@ -151,17 +151,18 @@ class FusedAdam:
     def zero_grad(self):
         pass                                       # the step consumes the gradient and drops it
 
-    def step(self, gate=None, counters=None, n_marched=None):
+    def step(self, gate=None, counters=None, n_marched=None, n_kept=None):
         """gate (device int64 [1], optional): the number of samples behind this gradient; the step is skipped -- step count
-        included -- when it is 0, as the reference skips batches without samples (nerf.py:204-206).  counters / n_marched:
-        see ops.step_bookkeeping (sample statistics, accumulated by the same launch that advances the step count)."""
+        included -- when it is 0, as the reference skips batches without samples (nerf.py:204-206).  counters / n_marched /
+        n_kept: see ops.step_bookkeeping (THIS rank's sample statistics, accumulated by the same launch that advances the
+        step count; n_kept defaults to the gate, which under data parallelism is the whole job's count instead)."""
         p = self.net.params
         if p.grad is None:
             return
         g = self.param_groups[0]
         if not self.capturing:
             self.lr_dev.fill_(g['lr'])             # under capture the replay wrapper refreshes lr_dev instead
-        ops.step_bookkeeping(self.step_dev, gate, counters, n_marched, gate)
+        ops.step_bookkeeping(self.step_dev, gate, counters, n_marched, n_kept if n_kept is not None else gate)
         ops.adam_step_dev(p.data, self.exp_avg, self.exp_avg_sq, p.grad[:p.numel()], self.step_dev, self.lr_dev, g['betas'][0],
                           g['betas'][1], g['eps'], w16=self.w16, zero_grad=False, gate=gate)
         p.grad = None                              # the next backward installs a fresh gradient (no accumulate pass)
@@ -438,7 +439,8 @@ class NeRFScene:
                 gate = grad[n:].to(torch.int64)
         net.params.grad = grad[:n]                 # (without the count slot of the data-parallel buffer)
         if isinstance(optimizer, FusedAdam):
-            optimizer.step(gate=gate, counters=self.sample_counters, n_marched=n_marched)
+            optimizer.step(gate=gate, counters=self.sample_counters, n_marched=n_marched,
+                           n_kept=n_kept if torch.is_tensor(n_kept) else None)
         else:
             if gate is None or int(gate.item()) > 0:
                 optimizer.step()

@@ -1,145 +1,32 @@
-"""PSNR@iter parity: the HIP path (bf16 / fp16, fixed-point or fp32 gradient accumulation) against the fp32 CPU oracle
-after EQUAL iterations on the same synthetic panorama with identical batches and random draws (north_star: "PSNR within
-0.1 dB of reference after equal iterations"; the reference itself cannot run here, so the oracle stands in).
-Reduced scale so that the CPU oracle finishes in minutes: 48x96 panorama, 512-ray batches."""
+"""PSNR@iter parity as a dev tool: the HIP path (bf16 / fp16, fixed-point or fp32 gradient accumulation) against the fp32
+CPU oracle's committed curve (tests/golden/psnr_curve.json; the harness is tests/psnr_parity_lib.py, the asserted version
+tests/test_gpu_psnr.py).   python tools/psnr_parity.py  ->  gpurun_out/psnr_parity.json"""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch
-from oracle import perf_oracle as O
-
-H, W, BATCH = 48, 96, 512
-N_GEO, N_APP = int(os.environ.get('N_GEO', 120)), int(os.environ.get('N_APP', 80))
-AABB = [-1., -1, -1, 1, 1, 1]
-CONF = dict(init_lr=0.0, peak_lr=1e-2, peak_at=0.2, lr_alpha=1e-2)
-
-
-def psnr(a, b):
-    return float(-10 * torch.log10(torch.mean((a.float() - b.float()) ** 2)))
-
-
-def make_draws(n_pool, seed=0):
-    g = torch.Generator().manual_seed(123 + seed)
-    draws = []
-    for _ in range(N_GEO + N_APP):
-        draws.append({'idx': torch.randint(0, n_pool, (BATCH,), generator=g), 'jitter': torch.rand(BATCH, generator=g),
-                      'bg': torch.rand(BATCH, 3, generator=g), 'noise': torch.rand(BATCH, 1, generator=g)})
-    return draws
-
-
-def run_oracle(o, d, dist, rgb, occ, geo0, app0, draws):
-    geo = geo0.clone().requires_grad_(True); app = app0.clone().requires_grad_(True)
-    curve = {}
-    mg = torch.zeros_like(geo); vg = torch.zeros_like(geo); ma = torch.zeros_like(app); va = torch.zeros_like(app)
-
-    def render_eval():
-        with torch.no_grad():
-            out = O.occ_render(o, d, geo, app, occ, AABB, training=False)
-        return out['rgb'], out['distance']
-
-    for i in range(N_GEO):
-        dr = draws[i]
-        t0 = (dr['jitter'].numpy() * np.float32(5e-4)).astype(np.float32)
-        out = O.occ_render(o[dr['idx']], d[dr['idx']], geo, app, occ, AABB, training=True, t0=t0, bg_color=dr['bg'], dist_noise=dr['noise'])
-        if not out['is_valid']:
-            continue
-        loss, _, _ = O.geo_step_loss(out, dist[dr['idx']], progress=i / N_APP)
-        geo.grad = None; loss.backward()
-        with torch.no_grad():
-            p, mg, vg = O.adam_step(geo, geo.grad, mg, vg, i + 1, O.lr_schedule(i / N_GEO, **CONF)); geo.copy_(p)
-    curve['geo_end_depth_err'] = float((render_eval()[1] - dist).abs().mean())
-    for i in range(N_APP):
-        dr = draws[N_GEO + i]
-        t0 = (dr['jitter'].numpy() * np.float32(5e-4)).astype(np.float32)
-        out = O.occ_render(o[dr['idx']], d[dr['idx']], geo, app, occ, AABB, training=True, t0=t0, bg_color=dr['bg'], dist_noise=dr['noise'],
-                           geo_grad=False, app_grad=True)
-        if not out['is_valid']:
-            continue
-        loss, _ = O.app_step_loss(out, rgb[dr['idx']])
-        app.grad = None; loss.backward()
-        with torch.no_grad():
-            p, ma, va = O.adam_step(app, app.grad, ma, va, i + 1, O.lr_schedule(i / N_APP, **CONF)); app.copy_(p)
-        if (i + 1) in (N_APP // 2, N_APP):
-            curve[f'psnr@app{i + 1}'] = psnr(render_eval()[0], rgb)
-    return curve
-
-
-def run_hip(o, d, dist, rgb, occ, geo0, app0, draws, dtype, accum):
-    from perf_amd import tcnn
-    from perf_amd.scene import NeRFScene, Rays, SupInfoPool
-    tcnn.GRID_GRAD_ACCUM = accum
-    scene = NeRFScene(dtype=dtype)
-    pool = SupInfoPool(); pool.register_rays(o.cuda(), d.cuda(), rgb.cuda(), dist.cuda())
-    scene.train_conf.pixel_loss_batch_size = BATCH
-    scene.set_train()
-    scene.estimator.set_binaries(torch.from_numpy(occ.reshape(-1)).cuda())
-    scene.nerf.reset_geo()
-    with torch.no_grad():
-        scene.nerf.geo_mlp.params.copy_(geo0.cuda()); scene.nerf.app_mlp.params.copy_(app0.cuda())
-    state = {'idx': None}
-    pool.rand_ray_color_data = lambda bs, **kw: (Rays(pool.all_sup_rays.o[state['idx']], pool.all_sup_rays.d[state['idx']]),
-                                                  pool.all_sup_colors[state['idx']], pool.all_sup_distances[state['idx']],
-                                                  pool.all_sup_normals[state['idx']])
-    rays = Rays(o.cuda(), d.cuda())
-    curve = {}
-    opt = scene.make_optimizer(scene.nerf.geo_mlp, 0.0)
-    conf = scene.train_conf.geo_optimizer
-    for i in range(N_GEO):
-        dr = draws[i]; state['idx'] = dr['idx'].cuda()
-        scene.update_lr(opt, conf, i / N_GEO)
-        scene.train_one_step_geo(opt, pool, progress=i / N_APP, rand={k: dr[k].cuda() for k in ('jitter', 'bg', 'noise')})
-    ev = scene.render(rays, ['rgb', 'distance'])
-    curve['geo_end_depth_err'] = float((ev['distance'].cpu() - dist).abs().mean())
-    opt = scene.make_optimizer(scene.nerf.app_mlp, 0.0)
-    for i in range(N_APP):
-        dr = draws[N_GEO + i]; state['idx'] = dr['idx'].cuda()
-        scene.update_lr(opt, conf, i / N_APP)
-        scene.train_one_step_app(opt, pool, progress=i / N_APP, rand={k: dr[k].cuda() for k in ('jitter', 'bg', 'noise')})
-        if (i + 1) in (N_APP // 2, N_APP):
-            scene.set_eval(); curve[f'psnr@app{i + 1}'] = psnr(scene.render(rays, ['rgb'])['rgb'].cpu(), rgb); scene.set_train()
-    return curve
+from tests import psnr_parity_lib as P
 
 
 def main():
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    o, d = O.pano_rays(torch.eye(4), H, W)
-    o = o.reshape(-1, 3).contiguous(); d = d.reshape(-1, 3).contiguous()
-    dist, rgb = O.synthetic_room(d)
-    occ = O.gen_occ_grid(o, d, dist, 256).reshape(256, 256, 256).bool().numpy()
-    geo0 = O.init_field_params(O.geo_spec(), 1337); app0 = O.init_field_params(O.app_spec(), 1337)
-    draws = make_draws(o.shape[0])
-    res = {'config': {'pano': [H, W], 'batch': BATCH, 'geo_iters': N_GEO, 'app_iters': N_APP}}
-    reps = int(os.environ.get('REPEATS', 3))
-    for dtype, accum in (('bf16', 'fixed'), ('fp16', 'fixed'), ('bf16', 'fp32'), ('fp16', 'fp32')):
-        runs = []
-        for _ in range(reps):
-            t = time.time(); r = run_hip(o, d, dist, rgb, occ, geo0, app0, draws, dtype, accum); r['seconds'] = round(time.time() - t, 1); runs.append(r)
-        res[f'hip_{dtype}_{accum}'] = runs
-        print(dtype, accum, [round(r[f'psnr@app{N_APP}'], 3) for r in runs], [round(r[f'psnr@app{N_APP // 2}'], 3) for r in runs], flush=True)
-    t = time.time(); res['oracle_fp32_cpu'] = run_oracle(o, d, dist, rgb, occ, geo0, app0, draws); res['oracle_fp32_cpu']['seconds'] = round(time.time() - t, 1)
-    print('oracle', res['oracle_fp32_cpu'], flush=True)
-    # SEEDS=k: k further (initialisation, batch/draw stream) seeds, default path only -- is the difference a bias or noise?
-    seeds = int(os.environ.get('SEEDS', 0))
-    if seeds:
-        rows = []
-        for sd in range(1, seeds + 1):
-            g0 = O.init_field_params(O.geo_spec(), 1337 + sd); a0 = O.init_field_params(O.app_spec(), 1337 + sd)
-            dr = make_draws(o.shape[0], sd)
-            ref = run_oracle(o, d, dist, rgb, occ, g0, a0, dr)
-            row = {'seed': sd, 'oracle': ref}
-            for dtype in ('bf16', 'fp16'):
-                row[dtype] = run_hip(o, d, dist, rgb, occ, g0, a0, dr, dtype, 'fixed')
-            rows.append(row)
-            print('seed', sd, {k: round(row['bf16'][k] - ref[k], 3) for k in ref if k.startswith('psnr')},
-                  {k: round(row['fp16'][k] - ref[k], 3) for k in ref if k.startswith('psnr')}, flush=True)
-        res['seeds'] = rows
-        for dtype in ('bf16', 'fp16'):
-            for k in (f'psnr@app{N_APP // 2}', f'psnr@app{N_APP}'):
-                dl = np.array([r[dtype][k] - r['oracle'][k] for r in rows] + [res[f'hip_{dtype}_fixed'][0][k] - res['oracle_fp32_cpu'][k]])
-                res[f'delta_{dtype}_{k}'] = {'mean': float(dl.mean()), 'std': float(dl.std()), 'n': int(dl.size)}
-                print(dtype, k, 'HIP - oracle: mean %.3f dB, std %.3f dB over %d seeds' % (dl.mean(), dl.std(), dl.size), flush=True)
-    os.makedirs('gpurun_out', exist_ok=True)
-    json.dump(res, open('gpurun_out/psnr_parity.json', 'w'), indent=1)
+    golden = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'psnr_curve.json')))
+    cfg = golden['config']
+    scene = P.make_scene(*cfg['pano'])
+    res = {'config': cfg, 'runs': []}
+    for row in golden['seeds']:
+        geo0, app0 = P.init_params(row['seed'])
+        draws = P.make_draws(scene[0].shape[0], cfg['batch'], cfg['geo_iters'] + cfg['app_iters'], row['seed'])
+        for dtype, accum in (('bf16', 'fixed'), ('fp16', 'fixed'), ('bf16', 'fp32'), ('fp16', 'fp32')):
+            t = time.time()
+            got = P.run_hip(scene, geo0, app0, draws, cfg['geo_iters'], cfg['app_iters'], tuple(cfg['marks']), dtype, accum)
+            delta = {k: round(got[k] - row['oracle'][k], 4) for k in got if k.startswith('psnr')}
+            res['runs'].append({'seed': row['seed'], 'dtype': dtype, 'accum': accum, 'hip': got, 'hip_minus_oracle': delta,
+                                'seconds': round(time.time() - t, 1)})
+            print(row['seed'], dtype, accum, delta, flush=True)
+    from perf_amd import tcnn
+    tcnn.GRID_GRAD_ACCUM = 'fixed'
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'psnr_parity.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':
