@@ -37,27 +37,84 @@ __device__ __forceinline__ float chunk_excl(float v, int lane, float& carry) {
     return ex;
 }
 
+// ---- ray teams ------------------------------------------------------------------------------------------------------
+// A wave serves FOUR rays.  When all four hold at most 16 samples each gets a quarter wave (16 lanes): a trained scene
+// keeps a sample or two per ray, a whole wavefront per ray then idles 60 of its 64 lanes (eval frames: 5 x 10^5 rays).
+// Otherwise the wave walks its four rays one after the other with all 64 lanes.  Both ways produce the same bits: the
+// canonical scan is Kogge-Stone inside 64-sample chunks, and for <= 16 samples its offsets 16 and 32 -- like the butterfly
+// steps 32 and 16 of the reductions -- only ever add exact zeros.
+template <int W> struct Team { static constexpr int width = W; };
+
+template <int W>
+__device__ __forceinline__ float team_incl_scan_f(float x, int l) {
+#pragma unroll
+    for (int off = 1; off < W; off <<= 1) {
+        const float y = __shfl_up(x, off, W);
+        if (l >= off) x = add_rn(x, y);
+    }
+    return x;
+}
+template <int W>
+__device__ __forceinline__ float team_sum(float x) {
+#pragma unroll
+    for (int off = W / 2; off >= 1; off >>= 1) x += __shfl_xor(x, off, W);
+    return x;
+}
+template <int W>
+__device__ __forceinline__ float team_chunk_excl(float v, int l, float& carry) {
+    const float inc = team_incl_scan_f<W>(v, l);
+    float prev = __shfl_up(inc, 1, W);
+    if (l == 0) prev = 0.f;
+    const float ex = add_rn(carry, prev);
+    carry = add_rn(carry, __shfl(inc, W - 1, W));
+    return ex;
+}
+// ballot restricted to the caller's team (bit k = lane k of the team)
+template <int W>
+__device__ __forceinline__ unsigned long long team_ballot(bool p) {
+    const unsigned long long b = __ballot(p);
+    if (W == 64) return b;
+    return (b >> (((threadIdx.x & 63) / W) * W)) & ((1ull << W) - 1ull);
+}
+
+// calls body(Team<16 or 64>, ray, lane-in-team) for the (up to) four rays of the calling wave
+template <typename CountFn, typename Body>
+__device__ __forceinline__ void for_rays_of_wave(int64_t n_rays, CountFn count_of, Body body) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (r0 >= n_rays) return;
+    const int64_t rq = r0 + (lane >> 4);
+    const int cq = rq < n_rays ? count_of(rq) : 0;
+    if (__ballot(cq > 16) == 0ull) {
+        if (rq < n_rays) body(Team<16>{}, rq, lane & 15);
+    } else {
+        for (int q = 0; q < 4; ++q)
+            if (r0 + q < n_rays) body(Team<64>{}, r0 + q, lane);
+    }
+}
+static inline dim3 team_grid(int64_t n_rays) { return dim3((unsigned)div_up(n_rays, 16)); }     // 4 waves x 4 rays per block
+
 __global__ __launch_bounds__(256) void visibility_count_kernel(const float* __restrict__ sig, const float* __restrict__ ts,
                                                                const float* __restrict__ te, const int32_t* __restrict__ packed,
                                                                int64_t n_rays, float thr, int32_t* __restrict__ new_counts,
                                                                float* __restrict__ exsum) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_rays) return;
-    const int64_t start = packed[2 * r];
-    const int cnt = packed[2 * r + 1];
-    float carry = 0.f;
-    int kept = 0;
-    for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int i = c0 + lane;
-        const bool valid = i < cnt;
-        float sd = 0.f;
-        if (valid) sd = mul_rn(sig[start + i], sub_rn(te[start + i], ts[start + i]));
-        const float ex = chunk_excl(sd, lane, carry);
-        if (valid && exsum) exsum[start + i] = ex;
-        kept += __popcll(__ballot(valid && (ex <= thr)));
-    }
-    if (lane == 0) new_counts[r] = kept;
+    for_rays_of_wave(n_rays, [&](int64_t r) { return packed[2 * r + 1]; }, [&](auto team, int64_t r, int l) {
+        constexpr int W = decltype(team)::width;
+        const int64_t start = packed[2 * r];
+        const int cnt = packed[2 * r + 1];
+        float carry = 0.f;
+        int kept = 0;
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int i = c0 + l;
+            const bool valid = i < cnt;
+            float sd = 0.f;
+            if (valid) sd = mul_rn(sig[start + i], sub_rn(te[start + i], ts[start + i]));
+            const float ex = team_chunk_excl<W>(sd, l, carry);
+            if (valid && exsum) exsum[start + i] = ex;
+            kept += __popcll(team_ballot<W>(valid && (ex <= thr)));
+        }
+        if (l == 0) new_counts[r] = kept;
+    });
 }
 
 // optional copy of the level-major features the density pass of the sampler produced (reused by the gradient pass: the
@@ -107,52 +164,52 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
                                                             float* __restrict__ alphas, float* __restrict__ opacity,
                                                             float* __restrict__ distance, float* __restrict__ color,
                                                             float* __restrict__ distloss) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_rays) return;
-    const int64_t start = packed[2 * r];
-    const int cnt = packed[2 * r + 1];
-    float carry = 0.f;
-    float a_op = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
-    float cW = 0.f, cWM = 0.f, a_dl = 0.f;          // distortion loss of the ray (same arithmetic as distloss_fwd_kernel)
-    for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int i = c0 + lane;
-        const bool valid = i < cnt;
-        float sd = 0.f, t0 = 0.f, t1 = 0.f;
-        if (valid) { t0 = ts[start + i]; t1 = te[start + i]; sd = mul_rn(sig[start + i], sub_rn(t1, t0)); }
-        const float ex = chunk_excl(sd, lane, carry);
-        float w_dl = 0.f;
-        if (valid) {
-            const float T = expf(-ex);
-            const float al = 1.0f - expf(-sd);
-            const float w = T * al;
-            w_dl = w;
-            if (weights) weights[start + i] = w;
-            if (trans) trans[start + i] = T;
-            if (alphas) alphas[start + i] = al;
-            a_op += w;
-            a_d += w * ((t0 + t1) * 0.5f);
-            if (rgb) {
-                a_r += w * rgb[3 * (start + i)];
-                a_g += w * rgb[3 * (start + i) + 1];
-                a_b += w * rgb[3 * (start + i) + 2];
+    for_rays_of_wave(n_rays, [&](int64_t r) { return packed[2 * r + 1]; }, [&](auto team, int64_t r, int l) {
+        constexpr int TW = decltype(team)::width;
+        const int64_t start = packed[2 * r];
+        const int cnt = packed[2 * r + 1];
+        float carry = 0.f;
+        float a_op = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
+        float cW = 0.f, cWM = 0.f, a_dl = 0.f;          // distortion loss of the ray (same arithmetic as distloss_fwd_kernel)
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int i = c0 + l;
+            const bool valid = i < cnt;
+            float sd = 0.f, t0 = 0.f, t1 = 0.f;
+            if (valid) { t0 = ts[start + i]; t1 = te[start + i]; sd = mul_rn(sig[start + i], sub_rn(t1, t0)); }
+            const float ex = team_chunk_excl<TW>(sd, l, carry);
+            float w_dl = 0.f;
+            if (valid) {
+                const float T = expf(-ex);
+                const float al = 1.0f - expf(-sd);
+                const float w = T * al;
+                w_dl = w;
+                if (weights) weights[start + i] = w;
+                if (trans) trans[start + i] = T;
+                if (alphas) alphas[start + i] = al;
+                a_op += w;
+                a_d += w * ((t0 + t1) * 0.5f);
+                if (rgb) {
+                    a_r += w * rgb[3 * (start + i)];
+                    a_g += w * rgb[3 * (start + i) + 1];
+                    a_b += w * rgb[3 * (start + i) + 2];
+                }
+            }
+            if (distloss) {
+                const float m = (t0 + t1) * 0.5f, d = t1 - t0;
+                const float Wp = team_chunk_excl<TW>(w_dl, l, cW);
+                const float WMp = team_chunk_excl<TW>(w_dl * m, l, cWM);
+                if (valid) a_dl += d * w_dl * w_dl * (1.0f / 3.0f) + 2.0f * w_dl * (m * Wp - WMp);
             }
         }
-        if (distloss) {
-            const float m = (t0 + t1) * 0.5f, d = t1 - t0;
-            const float W = chunk_excl(w_dl, lane, cW);
-            const float WM = chunk_excl(w_dl * m, lane, cWM);
-            if (valid) a_dl += d * w_dl * w_dl * (1.0f / 3.0f) + 2.0f * w_dl * (m * W - WM);
+        if (distloss) { a_dl = team_sum<TW>(a_dl); if (l == 0) distloss[r] = a_dl; }
+        a_op = team_sum<TW>(a_op); a_d = team_sum<TW>(a_d);
+        if (rgb) { a_r = team_sum<TW>(a_r); a_g = team_sum<TW>(a_g); a_b = team_sum<TW>(a_b); }
+        if (l == 0) {
+            if (opacity) opacity[r] = a_op;
+            if (distance) distance[r] = a_d;
+            if (rgb && color) { color[3 * r] = a_r; color[3 * r + 1] = a_g; color[3 * r + 2] = a_b; }
         }
-    }
-    if (distloss) { a_dl = wave_sum(a_dl); if (lane == 0) distloss[r] = a_dl; }
-    a_op = wave_sum(a_op); a_d = wave_sum(a_d);
-    if (rgb) { a_r = wave_sum(a_r); a_g = wave_sum(a_g); a_b = wave_sum(a_b); }
-    if (lane == 0) {
-        if (opacity) opacity[r] = a_op;
-        if (distance) distance[r] = a_d;
-        if (rgb && color) { color[3 * r] = a_r; color[3 * r + 1] = a_g; color[3 * r + 2] = a_b; }
-    }
+    });
 }
 
 // d sigma_i = delta_i * ( (G_i T_i + gA_i) (1 - alpha_i) - sum_{j>i} (G_j w_j + gT_j T_j) ),
@@ -323,7 +380,7 @@ extern "C" int perf_visibility_count(const float* sigmas, const float* t_starts,
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && new_counts, "NULL pointer");
-    hipLaunchKernelGGL(visibility_count_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
+    hipLaunchKernelGGL(visibility_count_kernel, team_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
                        packed_info, n_rays, thr, new_counts, exsum);
     PERF_LAUNCH_CHECK("perf_visibility_count");
     return PERF_OK;
@@ -356,7 +413,7 @@ extern "C" int perf_composite_fwd(const float* sigmas, const float* rgbs, const 
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info, "NULL pointer");
-    hipLaunchKernelGGL(composite_fwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
+    hipLaunchKernelGGL(composite_fwd_kernel, team_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
                        t_ends, packed_info, n_rays, weights, trans, alphas, opacity, distance, color, (float*)nullptr);
     PERF_LAUNCH_CHECK("perf_composite_fwd");
     return PERF_OK;
@@ -368,7 +425,7 @@ extern "C" int perf_composite_distloss_fwd(const float* sigmas, const float* rgb
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && distloss_per_ray, "NULL pointer");
-    hipLaunchKernelGGL(composite_fwd_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
+    hipLaunchKernelGGL(composite_fwd_kernel, team_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
                        t_ends, packed_info, n_rays, weights, trans, (float*)nullptr, opacity, distance, color, distloss_per_ray);
     PERF_LAUNCH_CHECK("perf_composite_distloss_fwd");
     return PERF_OK;
@@ -475,31 +532,31 @@ struct TwoSource {
 };
 
 __global__ __launch_bounds__(256) void visibility_count2_kernel(TwoSource src, int64_t n_rays, float thr, int32_t* __restrict__ new_counts) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_rays) return;
-    const int64_t sh = src.packed_h[2 * r], st = src.packed_t[2 * r];
-    const int ch = src.packed_h[2 * r + 1], ct = src.packed_t[2 * r + 1];
-    const int cnt = ch + ct;
-    float carry = 0.f;
-    int kept = 0;
-    for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int i = c0 + lane;
-        const bool valid = i < cnt;
-        float sd = 0.f;
-        if (valid) {
-            const bool head = i < ch;
-            const int64_t j = head ? sh + i : st + (i - ch);
-            const float s = head ? src.sig_h[j] : src.sig_t[j];
-            const float a = head ? src.ts_h[j] : src.ts_t[j], b = head ? src.te_h[j] : src.te_t[j];
-            sd = mul_rn(s, sub_rn(b, a));
+    for_rays_of_wave(n_rays, [&](int64_t r) { return src.packed_h[2 * r + 1] + src.packed_t[2 * r + 1]; }, [&](auto team, int64_t r, int l) {
+        constexpr int TW = decltype(team)::width;
+        const int64_t sh = src.packed_h[2 * r], st = src.packed_t[2 * r];
+        const int ch = src.packed_h[2 * r + 1], ct = src.packed_t[2 * r + 1];
+        const int cnt = ch + ct;
+        float carry = 0.f;
+        int kept = 0;
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int i = c0 + l;
+            const bool valid = i < cnt;
+            float sd = 0.f;
+            if (valid) {
+                const bool head = i < ch;
+                const int64_t j = head ? sh + i : st + (i - ch);
+                const float sg = head ? src.sig_h[j] : src.sig_t[j];
+                const float a = head ? src.ts_h[j] : src.ts_t[j], b = head ? src.te_h[j] : src.te_t[j];
+                sd = mul_rn(sg, sub_rn(b, a));
+            }
+            const float ex = team_chunk_excl<TW>(sd, l, carry);
+            const unsigned long long ok = team_ballot<TW>(valid && (ex <= thr));
+            kept += __popcll(ok);
+            if (ok != team_ballot<TW>(valid)) break;        // the prefix ended in this chunk (uniform over the team)
         }
-        const float ex = chunk_excl(sd, lane, carry);
-        const unsigned long long ok = __ballot(valid && (ex <= thr));
-        kept += __popcll(ok);
-        if (ok != __ballot(valid)) break;            // the prefix ended in this chunk (wave-uniform)
-    }
-    if (lane == 0) new_counts[r] = kept;
+        if (l == 0) new_counts[r] = kept;
+    });
 }
 
 __global__ __launch_bounds__(256) void compact_prefix2_kernel(TwoSource src, const float* __restrict__ x01_h, const uint8_t* __restrict__ sel_h,
@@ -509,33 +566,33 @@ __global__ __launch_bounds__(256) void compact_prefix2_kernel(TwoSource src, con
                                                               float* __restrict__ ts_out, float* __restrict__ te_out, float* __restrict__ sig_out,
                                                               float* __restrict__ x01_out, uint8_t* __restrict__ sel_out,
                                                               int32_t* __restrict__ packed_out, FeatCopy fc) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_rays) return;
-    const int64_t sh = src.packed_h[2 * r], st = src.packed_t[2 * r];
-    const int ch = src.packed_h[2 * r + 1];
-    int cnt = new_counts[r];
-    const int64_t dst = new_offsets[r];
-    if (dst + cnt > capacity) cnt = (int)(capacity > dst ? capacity - dst : 0);       // truncated batch
-    if (lane == 0) { packed_out[2 * r] = (int32_t)dst; packed_out[2 * r + 1] = cnt; }
-    for (int i = lane; i < cnt; i += 64) {
-        const bool head = i < ch;
-        const int64_t j = head ? sh + i : st + (i - ch);
-        ts_out[dst + i] = head ? src.ts_h[j] : src.ts_t[j];
-        te_out[dst + i] = head ? src.te_h[j] : src.te_t[j];
-        ri_out[dst + i] = r;
-        if (sig_out) sig_out[dst + i] = head ? src.sig_h[j] : src.sig_t[j];
-        if (sel_out) sel_out[dst + i] = head ? sel_h[j] : sel_t[j];
-        if (x01_out) {
-            const float* p = head ? x01_h + 3 * j : x01_t + 3 * j;
-            x01_out[3 * (dst + i)] = p[0]; x01_out[3 * (dst + i) + 1] = p[1]; x01_out[3 * (dst + i) + 2] = p[2];
+    for_rays_of_wave(n_rays, [&](int64_t r) { return new_counts[r]; }, [&](auto team, int64_t r, int l) {
+        constexpr int TW = decltype(team)::width;
+        const int64_t sh = src.packed_h[2 * r], st = src.packed_t[2 * r];
+        const int ch = src.packed_h[2 * r + 1];
+        int cnt = new_counts[r];
+        const int64_t dst = new_offsets[r];
+        if (dst + cnt > capacity) cnt = (int)(capacity > dst ? capacity - dst : 0);       // truncated batch
+        if (l == 0) { packed_out[2 * r] = (int32_t)dst; packed_out[2 * r + 1] = cnt; }
+        for (int i = l; i < cnt; i += TW) {
+            const bool head = i < ch;
+            const int64_t j = head ? sh + i : st + (i - ch);
+            ts_out[dst + i] = head ? src.ts_h[j] : src.ts_t[j];
+            te_out[dst + i] = head ? src.te_h[j] : src.te_t[j];
+            ri_out[dst + i] = r;
+            if (sig_out) sig_out[dst + i] = head ? src.sig_h[j] : src.sig_t[j];
+            if (sel_out) sel_out[dst + i] = head ? sel_h[j] : sel_t[j];
+            if (x01_out) {
+                const float* p = head ? x01_h + 3 * j : x01_t + 3 * j;
+                x01_out[3 * (dst + i)] = p[0]; x01_out[3 * (dst + i) + 1] = p[1]; x01_out[3 * (dst + i) + 2] = p[2];
+            }
         }
-    }
-    if (fc.out)
-        for (int l = 0; l < fc.n_levels; ++l)
-            for (int i = lane; i < cnt; i += 64)
-                fc.out[(int64_t)l * fc.stride_out + dst + i] = (i < ch) ? fc.in_h[(int64_t)l * fc.stride_h + sh + i]
-                                                                        : fc.in_t[(int64_t)l * fc.stride_t + st + (i - ch)];
+        if (fc.out)
+            for (int lv = 0; lv < fc.n_levels; ++lv)
+                for (int i = l; i < cnt; i += TW)
+                    fc.out[(int64_t)lv * fc.stride_out + dst + i] = (i < ch) ? fc.in_h[(int64_t)lv * fc.stride_h + sh + i]
+                                                                             : fc.in_t[(int64_t)lv * fc.stride_t + st + (i - ch)];
+    });
 }
 }  // namespace perf
 
@@ -557,7 +614,7 @@ extern "C" int perf_visibility_count2(const float* sig_h, const float* ts_h, con
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_h && packed_t && new_counts, "NULL pointer");
     perf::TwoSource src{sig_h, ts_h, te_h, packed_h, sig_t, ts_t, te_t, packed_t};
-    hipLaunchKernelGGL(perf::visibility_count2_kernel, perf::ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, n_rays, thr, new_counts);
+    hipLaunchKernelGGL(perf::visibility_count2_kernel, perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, n_rays, thr, new_counts);
     PERF_LAUNCH_CHECK("perf_visibility_count2");
     return PERF_OK;
 }
@@ -576,7 +633,7 @@ extern "C" int perf_compact_prefix2(const float* sig_h, const float* ts_h, const
     PERF_REQUIRE(packed_h && packed_t && new_counts && new_offsets && packed_out, "NULL pointer");
     PERF_REQUIRE(capacity == 0 || (ray_indices_out && ts_out && te_out), "NULL sample arrays");
     perf::TwoSource src{sig_h, ts_h, te_h, packed_h, sig_t, ts_t, te_t, packed_t};
-    hipLaunchKernelGGL(perf::compact_prefix2_kernel, perf::ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, x01_h, sel_h,
+    hipLaunchKernelGGL(perf::compact_prefix2_kernel, perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, x01_h, sel_h,
                        x01_t, sel_t, new_counts, new_offsets, n_rays, capacity, ray_indices_out, ts_out, te_out, sig_out, x01_out,
                        sel_out, packed_out,
                        perf::FeatCopy{(const uint32_t*)feat_h, feat_stride_h, (const uint32_t*)feat_t, feat_stride_t, (uint32_t*)feat_out,

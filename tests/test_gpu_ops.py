@@ -629,3 +629,72 @@ def test_hashgrid_bwd_fixed_point_with_vanishing_gradients(ops):
         got = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax)
         assert int(ops.overflow_flag(x.device).item()) == 0, mag
         assert bool(torch.isfinite(got).all()) and float(got.abs().max()) <= 8 * n * max(mag, 1e-45) * 10
+
+
+def test_quarter_wave_ray_teams_equal_full_wave_rays(ops):
+    """Per-ray kernels serve four rays per wave: 16 lanes each when all four hold <= 16 samples, all 64 lanes one ray after
+    the other otherwise.  The same short rays, alone (quarter-wave path) and interleaved with long rays (full-wave path),
+    must give bit-identical visibility counts, exclusive sums, weights and per-ray outputs -- and match the oracle's
+    canonical scan."""
+    g = torch.Generator().manual_seed(31)
+    n_short = 203
+    counts_s = torch.randint(0, 17, (n_short,), generator=g)
+    counts_s[:5] = torch.tensor([0, 1, 16, 16, 2])
+
+    def build(counts):
+        starts = torch.cumsum(counts, 0) - counts
+        S = int(counts.sum())
+        packed = torch.stack([starts, counts], 1).to(torch.int32)
+        return packed, S
+
+    def fill(S):
+        ts = torch.rand(S, generator=g) * 0.5
+        te = ts + 0.01 + 0.01 * torch.rand(S, generator=g)
+        sig = torch.exp(torch.randn(S, generator=g) * 2 + 3)
+        rgb = torch.rand(S, 3, generator=g)
+        return sig, ts, te, rgb
+
+    packed_a, S_a = build(counts_s)
+    sig_a, ts_a, te_a, rgb_a = fill(S_a)
+    # the same rays with a 40-sample ray in front of every group of three
+    long_cnt = 40
+    order = []          # (is_long, index)
+    k = 0
+    while k < n_short:
+        order.append((True, None))
+        for _ in range(3):
+            if k < n_short:
+                order.append((False, k)); k += 1
+    counts_b = torch.tensor([long_cnt if is_long else int(counts_s[i]) for is_long, i in order])
+    packed_b, S_b = build(counts_b)
+    sig_b, ts_b, te_b, rgb_b = fill(S_b)
+    pos_of = {}
+    for j, (is_long, i) in enumerate(order):
+        if not is_long:
+            pos_of[i] = j
+            s0, c = int(packed_b[j, 0]), int(packed_b[j, 1])
+            a0 = int(packed_a[i, 0])
+            sig_b[s0:s0 + c] = sig_a[a0:a0 + c]; ts_b[s0:s0 + c] = ts_a[a0:a0 + c]; te_b[s0:s0 + c] = te_a[a0:a0 + c]
+            rgb_b[s0:s0 + c] = rgb_a[a0:a0 + c]
+    thr = 9.2103
+    res = {}
+    for name, (packed, sig, ts, te, rgb) in {'a': (packed_a, sig_a, ts_a, te_a, rgb_a), 'b': (packed_b, sig_b, ts_b, te_b, rgb_b)}.items():
+        pk = packed.cuda()
+        nc, ex = ops.visibility_count(sig.cuda(), ts.cuda(), te.cuda(), pk, early_stop_eps=1e-4, want_exsum=True)
+        w, T, al, op, dist, col = ops.composite_fwd(sig.cuda(), rgb.cuda().contiguous(), ts.cuda(), te.cuda(), pk)
+        res[name] = dict(nc=nc.cpu(), ex=ex.cpu(), w=w.cpu(), T=T.cpu(), op=op.cpu(), dist=dist.cpu(), col=col.cpu())
+    # oracle: canonical exclusive sums and kept counts of the short rays
+    sd = (sig_a.numpy() * (te_a.numpy() - ts_a.numpy()).astype(np.float32)).astype(np.float32)
+    ex_ref = O.packed_exclusive_sum_canonical(sd, packed_a.numpy())
+    assert np.array_equal(res['a']['ex'].numpy(), ex_ref)
+    keep, _ = O.visibility_keep_mask(sig_a.numpy(), ts_a.numpy(), te_a.numpy(), packed_a.numpy(), 1e-4)
+    kept_ref = np.array([int(keep[s0:s0 + c].sum()) for s0, c in packed_a.numpy()])
+    assert np.array_equal(res['a']['nc'].numpy(), kept_ref)
+    for i in range(n_short):
+        j = pos_of[i]
+        a0, c = int(packed_a[i, 0]), int(packed_a[i, 1]); b0 = int(packed_b[j, 0])
+        assert int(res['a']['nc'][i]) == int(res['b']['nc'][j])
+        for k_ in ('ex', 'w', 'T'):
+            assert torch.equal(res['a'][k_][a0:a0 + c], res['b'][k_][b0:b0 + c]), (i, k_)
+        for k_ in ('op', 'dist', 'col'):
+            assert torch.equal(res['a'][k_][i], res['b'][k_][j]), (i, k_)
