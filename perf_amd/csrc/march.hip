@@ -107,31 +107,47 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         }
         uint64_t live = __ballot(maybe);
         uint64_t kept = 0;        // chunks that really hold samples
-        // ---- phase B: the 64 lattice intervals of every surviving chunk, one per lane
-        for (uint64_t todo = live; todo; todo &= todo - 1) {
-            const int qq = g * 64 + (__ffsll((unsigned long long)todo) - 1);
-            const int k = qq * 64 + lane;
-            bool keep = false;
-            if (k < mp.max_steps) {
-                const float ta = lattice(t0, k, mp.step), tb = lattice(t0, k + 1, mp.step);
-                const float mid = mul_rn(add_rn(ta, tb), 0.5f);
-                if (mid >= lo && mid <= hi) {
-                    int cell[3];
+        // ---- phase B: the 64 lattice intervals of every surviving chunk, one per lane.  Four chunks per round: their
+        //      occupancy words are independent gathers, issued together instead of one L2 latency after the other
+        //      (a ray crosses ~5 live chunks around a surface: the dilated coarse grid is generous)
+        for (uint64_t todo = live; todo;) {
+            int qs[4]; uint32_t cis[4]; bool in_range[4];
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        const float p = add_rn(o[a], mul_rn(d[a], mid));
-                        const float u = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
-                        cell[a] = (int)fminf(fmaxf(floorf(u), 0.0f), rf - 1.0f);
+            for (int u = 0; u < 4; ++u) {
+                qs[u] = -1; cis[u] = 0u; in_range[u] = false;
+                if (todo) {
+                    qs[u] = g * 64 + (__ffsll((unsigned long long)todo) - 1);
+                    todo &= todo - 1;
+                    const int k = qs[u] * 64 + lane;
+                    if (k < mp.max_steps) {
+                        const float ta = lattice(t0, k, mp.step), tb = lattice(t0, k + 1, mp.step);
+                        const float mid = mul_rn(add_rn(ta, tb), 0.5f);
+                        if (mid >= lo && mid <= hi) {
+                            int cell[3];
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) {
+                                const float p = add_rn(o[a], mul_rn(d[a], mid));
+                                const float uu = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
+                                cell[a] = (int)fminf(fmaxf(floorf(uu), 0.0f), rf - 1.0f);
+                            }
+                            cis[u] = (uint32_t)((cell[0] * res + cell[1]) * res + cell[2]);
+                            in_range[u] = true;
+                        }
                     }
-                    const uint32_t ci = (uint32_t)((cell[0] * res + cell[1]) * res + cell[2]);
-                    keep = (bits[ci >> 5] >> (ci & 31)) & 1u;
                 }
             }
-            const uint64_t m = __ballot(keep);
-            if (m) {
-                kept |= 1ull << (qq & 63);
-                if (lane == 0) rec[nlw + qq] = m;
-                count += __popcll(m);
+            uint32_t words[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) words[u] = in_range[u] ? bits[cis[u] >> 5] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (qs[u] < 0) continue;                 // (wave uniform)
+                const uint64_t m = __ballot(in_range[u] && ((words[u] >> (cis[u] & 31)) & 1u));
+                if (m) {
+                    kept |= 1ull << (qs[u] & 63);
+                    if (lane == 0) rec[nlw + qs[u]] = m;
+                    count += __popcll(m);
+                }
             }
         }
         if (lane == 0) rec[g] = kept;
