@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                                                           const uint32_t* __restrict__ coarse,
                                                           uint64_t* __restrict__ masks, int32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (the ray index is wave uniform: saying so turns the loads of the ray's origin, direction and lattice origin into
+    //  scalar loads -- seven vector-memory instructions per ray less; the kernel is bound by VMEM issue, not by bytes)
+    const int64_t r = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (r >= n_rays) return;
     const float o[3] = {ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]};
     const float d[3] = {rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]};
