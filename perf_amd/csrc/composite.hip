@@ -77,27 +77,37 @@ __device__ __forceinline__ unsigned long long team_ballot(bool p) {
     return (b >> (((threadIdx.x & 63) / W) * W)) & ((1ull << W) - 1ull);
 }
 
-// One wave per ray is launched.  The waves of an aligned group of four rays take the same decision: if all four rays
-// hold at most 16 samples the group's first wave serves them with a quarter wave each and the other three retire at once;
-// otherwise every wave serves its own ray with all 64 lanes (long rays keep one wave each: a batch of 8,192 rays x 128
-// samples must not lose three quarters of its waves).
+// Two launch shapes, told apart by the grid size (team_grid):
+//  * packed (n_rays / 4 waves; chosen when that still fills the GPU, i.e. eval batches): wave w serves rays 4w..4w+3 --
+//    a quarter wave each when all four hold <= 16 samples, one after the other with all 64 lanes otherwise;
+//  * one wave per ray (small batches: 8,192 training rays of 128 samples must not lose three quarters of their waves): the
+//    waves of an aligned group of four rays take the same decision; in the quarter-wave case the group's first wave serves
+//    all four rays and the other three retire at once.
 // Calls body(Team<16 or 64>, ray, lane-in-team).
+constexpr int64_t kPackedMinWaves = 8192;       // 256 CUs x 32 waves
+
 template <typename CountFn, typename Body>
 __device__ __forceinline__ void for_rays_of_wave(int64_t n_rays, CountFn count_of, Body body) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t r0 = w & ~(int64_t)3;
+    const bool packed = (int64_t)gridDim.x * 4 < n_rays;
+    const int64_t r0 = packed ? w * 4 : (w & ~(int64_t)3);
     if (r0 >= n_rays) return;
     const int64_t rq = r0 + (lane >> 4);
     const int cq = rq < n_rays ? count_of(rq) : 0;
     if (__ballot(cq > 16) == 0ull) {
-        if ((w & 3) != 0) return;
+        if (!packed && (w & 3) != 0) return;
         if (rq < n_rays) body(Team<16>{}, rq, lane & 15);
+    } else if (packed) {
+        for (int q = 0; q < 4; ++q)
+            if (r0 + q < n_rays) body(Team<64>{}, r0 + q, lane);
     } else if (w < n_rays) {
         body(Team<64>{}, w, lane);
     }
 }
-static inline dim3 team_grid(int64_t n_rays) { return dim3((unsigned)div_up(n_rays, 4)); }      // 4 waves (= rays) per block
+static inline dim3 team_grid(int64_t n_rays) {
+    return dim3((unsigned)(n_rays / 4 >= kPackedMinWaves ? div_up(n_rays, 16) : div_up(n_rays, 4)));
+}
 
 __global__ __launch_bounds__(256) void visibility_count_kernel(const float* __restrict__ sig, const float* __restrict__ ts,
                                                                const float* __restrict__ te, const int32_t* __restrict__ packed,

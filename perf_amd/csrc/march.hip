@@ -172,25 +172,27 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
     // With at most 16 samples to write for each ray of an aligned group of four, every ray gets a quarter wave whose lanes
     // walk the 64 bits of a mask word in four steps; otherwise every ray has its own wave (the kernel has no cross-lane
     // operation: a team is only a lane -> (ray, bit) mapping).
-    // (one wave per ray is launched; in the quarter-wave case the first wave of an aligned group of four rays serves all
-    //  four and the other three retire at once)
+    // (two launch shapes as in composite.hip:for_rays_of_wave: n_rays / 4 waves for large batches -- wave w serves rays
+    //  4w..4w+3 --, one wave per ray for small ones, where in the quarter-wave case the first wave of an aligned group of
+    //  four rays serves all four and the other three retire at once)
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t r0 = w & ~(int64_t)3;
+    const bool four_per_wave = (int64_t)gridDim.x * 4 < n_rays;          // n_rays / 4 waves launched (large batches), else one per ray
+    const int64_t r0 = four_per_wave ? w * 4 : (w & ~(int64_t)3);
     if (r0 >= n_rays) return;
     const int64_t rq = r0 + (lane >> 4);
     const bool small = __ballot(rq < n_rays && counts[rq] > 16) == 0ull;
-    if (small && (w & 3) != 0) return;
+    if (small && !four_per_wave && (w & 3) != 0) return;
     const int W = small ? 16 : 64;
     const int l = small ? (lane & 15) : lane;
-    {
-        const int64_t r = small ? rq : w;
-        if (r >= n_rays) return;
+    for (int q = 0; q < ((four_per_wave && !small) ? 4 : 1); ++q) {
+        const int64_t r = small ? rq : (four_per_wave ? r0 + q : w);
+        if (r >= n_rays) continue;
         int32_t cnt = counts[r];
         const int32_t off = offsets[r];
         if ((int64_t)off + cnt > capacity) cnt = (int32_t)(capacity > off ? capacity - off : 0);   // truncated batch
         if (l == 0) { packed[2 * r] = off; packed[2 * r + 1] = cnt; }
-        if (cnt == 0) return;
+        if (cnt == 0) continue;
         const float t0 = t0s[r];
         int64_t run = (int64_t)off - rank_lo;            // output position of rank 0 (may lie before `off`)
         const int64_t end = (int64_t)off + cnt;
@@ -428,7 +430,7 @@ extern "C" int perf_occ_march_write(const float* t0, int64_t n_rays, float step,
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(t0 && masks && counts && offsets && packed_info, "NULL pointer");
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends), "NULL sample arrays");
-    hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), t0, n_rays,
+    hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
                        t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0);
     PERF_LAUNCH_CHECK("perf_occ_march_write");
@@ -446,7 +448,7 @@ extern "C" int perf_occ_march_write_points(const float* t0, int64_t n_rays, floa
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends && x01), "NULL sample arrays");
     Aabb bb;
     for (int k = 0; k < 3; ++k) { bb.lo[k] = aabb6[k]; bb.hi[k] = aabb6[3 + k]; }
-    hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), t0, n_rays,
+    hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
                        t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo);
     PERF_LAUNCH_CHECK("perf_occ_march_write_points");
