@@ -251,7 +251,6 @@ struct TileParams {
     int32_t accumulate;
     int64_t dbg_off;                       // >0: float2 offset in the workspace where per-block cycle counts go (dev tool)
     int32_t code_slot[PERF_MAX_LEVELS];    // >=0: the level's tile codes are codes[slot][n_pad] (see tile_codes_kernel)
-    uint32_t use_masks;                    // bit l: hashed coded level l (<= 16 tiles): the slot holds per-tile hit bitmaps, not codes
     int64_t n_pad;
     // XCD-aware placement: workgroup b runs work[b] = level << 16 | tile << 8 | replica (0xffffffff: idle).  The
     // dispatcher deals workgroups round-robin over the 8 XCDs, so b % 8 is the XCD: the owners of one level are put on
@@ -477,13 +476,8 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
     __syncthreads();
     uint32_t esc = 0u;                  // bit l: level l must take the generic owners (see below)
     const int64_t i0 = (int64_t)blockIdx.x * kCodeSamplesPerBlock;
-    const int64_t n_chunks = tp.n_pad >> 6;                 // 64-sample chunks (n_pad is padded to a multiple of 64)
-    {
-        // every lane of a wave runs the level loop (the hit bitmaps are wave ballots); lanes past the live count load nothing
-        const int64_t i = i0 + threadIdx.x;
-        const bool valid = i < n_live;
-        const int64_t iv = valid ? i : 0;
-        const float x = x01[3 * iv], y = x01[3 * iv + 1], z = x01[3 * iv + 2];
+    for (int64_t i = i0 + threadIdx.x; i < n_live && i < i0 + kCodeSamplesPerBlock; i += 256) {
+        const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
         for (int l = 0; l < gp.n_levels; ++l) {
             const int slot = tp.code_slot[l];
             if (slot < 0) continue;
@@ -500,30 +494,6 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
                 // a position so far outside the unit cube that its x-corners leave the first 16384 columns breaks
                 // "(y,z) decides the tile"
                 bad = gx >= (uint32_t)(kTileEntries - 1);
-                if ((tp.use_masks >> l) & 1u) {
-                    // Hit bitmaps: for every tile t of the level one 64-bit word per 64-sample chunk, bit k = sample k names
-                    // tile t with at least one (y,z) combination.  An owner then reads ITS word instead of testing 64 codes:
-                    // the compare + ballot per sample visit is paid once here, not once per owner (16x).
-                    uint32_t m16 = 0u;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) m16 |= 1u << ((code >> (8 * c)) & 0xffu);
-                    if (!valid) m16 = 0u;
-                    unsigned long long mine = 0ull;
-                    const int lane = threadIdx.x & 63;
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const unsigned long long b = __ballot((m16 >> t) & 1u);
-                        if (lane == t) mine = b;
-                    }
-                    unsigned long long* masks_l = reinterpret_cast<unsigned long long*>(codes + (int64_t)slot * tp.n_pad);
-                    const int nt = tp.tiles_of[l];
-                    if (lane < nt && i0 + (threadIdx.x & ~63) < n) masks_l[(int64_t)lane * n_chunks + ((i0 + threadIdx.x) >> 6)] = mine;
-                    if (valid && bad) {
-                        const float2 g = dfeat[(int64_t)l * n + i];
-                        if (!(g.x == 0.f && g.y == 0.f)) esc |= 1u << l;
-                    }
-                    continue;
-                }
             } else {
                 // dense level: byte = tile of the x0 corner, bit 7 set when the x1 corner sits in the next chunk (= next
                 // tile); 0x7f (no tile) when the pair would wrap past the end of the level
@@ -538,8 +508,8 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
                     code |= b << (8 * c);
                 }
             }
-            if (valid) codes[(int64_t)slot * tp.n_pad + i] = code;
-            if (valid && bad) {      // harmless without gradient; with gradient the level's owners take the generic path
+            codes[(int64_t)slot * tp.n_pad + i] = code;
+            if (bad) {      // harmless without gradient; with gradient the level's owners take the generic path
                 const float2 g = dfeat[(int64_t)l * n + i];
                 if (!(g.x == 0.f && g.y == 0.f)) esc |= 1u << l;
             }
@@ -673,119 +643,6 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     }
     asm volatile("" : : "v"(ld_c0), "v"(ld_c1));       // (the last code loads landed with the vmcnt(0) above)
 #undef PERF_WAIT_BATCH
-}
-
-// ---- hashed owners, bitmap variant ----------------------------------------------------------------------------------
-// The pre-pass leaves, per tile, one 64-bit hit word per 64-sample chunk (tile_codes_kernel, use_masks).  An owner's wave
-// walks its share of the chunks: the word IS the ballot the coded variant computes from four byte compares per sample, so
-// enqueueing a chunk is two mbcnt, one masked LDS store and a popcount.  Which (y,z) combinations of a queued sample name
-// the tile is recomputed from the hash at application time -- on the 22 % of the samples that are hits, at full lane
-// occupancy.  Queue, gather pipeline and application are those of bwd_stream_codes; results are bit-identical.
-template <bool FIXED>
-__device__ __forceinline__ void bwd_stream_masks(const BwdCtx& cx, float* lds_tile, uint32_t* queue,
-                                                 const unsigned long long* __restrict__ masks_t, const float* __restrict__ x01,
-                                                 const float2* __restrict__ g_l, int64_t n, int rep, int R) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): nothing the compiler knows of is in flight
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    constexpr uint32_t kIdle = 0xffffffffu;
-    uint32_t qn = 0;                                    // wave-uniform queue fill
-    const int64_t n_chunks = (n + 63) >> 6;
-    const int64_t c_lo = n_chunks * rep / R, c_hi = n_chunks * (rep + 1) / R;       // this replica's chunks
-    const int64_t per = (c_hi - c_lo + (kBwdThreads / 64) - 1) / (kBwdThreads / 64);
-    const int64_t w_lo = c_lo + (int64_t)wave * per;
-    const int64_t w_hi = (w_lo + per < c_hi) ? w_lo + per : c_hi;                    // this wave's contiguous share
-    float ld_x = 0.f; f32x2 ld_yz = {0.f, 0.f}, ld_g = {0.f, 0.f};
-    uint32_t be = kIdle;                                // queue entry of the batch in flight: sample << 4 | combinations (0: unknown)
-    auto enqueue_mask = [&](unsigned long long m, uint32_t base) {
-        const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if ((m >> lane) & 1ull) queue[pos] = (base + lane) << 4;
-        qn += (uint32_t)__popcll(m);
-    };
-    auto enqueue_rest = [&](uint32_t cm, uint32_t i) {
-        const unsigned long long b = __ballot(cm != 0u);
-        if (b) {
-            const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-            if (cm) queue[pos] = (i << 4) | cm;
-            qn += (uint32_t)__popcll(b);
-        }
-    };
-    auto pop_and_gather = [&]() {       // up to 64 queued samples: issue the 3 loads of their position and gradient
-        const uint32_t take = qn < 64u ? qn : 64u;
-        __builtin_amdgcn_wave_barrier();
-        uint32_t e = kIdle;
-        if (lane < take) e = queue[qn - take + lane];
-        __builtin_amdgcn_wave_barrier();
-        qn -= take;
-        be = e;
-        const uint32_t bi = (e == kIdle) ? 0u : (e >> 4);
-        const uint32_t ox = bi * 12u, og = bi * 8u;
-        asm volatile("global_load_dword %0, %3, %4\n\tglobal_load_dwordx2 %1, %3, %4 offset:4\n\tglobal_load_dwordx2 %2, %5, %6"
-                     : "=&v"(ld_x), "=&v"(ld_yz), "=&v"(ld_g) : "v"(ox), "s"(x01), "v"(og), "s"(g_l) : "memory");
-    };
-#define PERF_WAIT_BATCH0()                                                                                               \
-    float bx; f32x2 byz, bg;                                                                                            \
-    asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %3\n\tv_mov_b64 %1, %4\n\tv_mov_b64 %2, %5"                       \
-                 : "=&v"(bx), "=&v"(byz), "=&v"(bg) : "v"(ld_x), "v"(ld_yz), "v"(ld_g) : "memory")
-    auto apply_batch = [&](float bx, f32x2 byz, f32x2 bg) {
-        uint32_t cm = 0u, bi = 0u;
-        float px = 0.f, py = 0.f, pz = 0.f, flx = 0.f, fly = 0.f, flz = 0.f;
-        uint32_t gx = 0u, ay0 = 0u, az0 = 0u;
-        const bool live = be != kIdle;
-        if (live) {
-            bi = be >> 4;
-            cm = be & 15u;
-            px = add_rn(mul_rn(bx, cx.scale), 0.5f); py = add_rn(mul_rn(byz.x, cx.scale), 0.5f); pz = add_rn(mul_rn(byz.y, cx.scale), 0.5f);
-            flx = floorf(px); fly = floorf(py); flz = floorf(pz);
-            gx = (uint32_t)(int32_t)flx;
-            ay0 = (uint32_t)(int32_t)fly * kPrimeY; az0 = (uint32_t)(int32_t)flz * kPrimeZ;
-            if (cm == 0u) {             // first visit: which (y,z) combinations fall in this tile (= the pre-pass's rule)
-                const uint32_t ay1 = ay0 + kPrimeY, az1 = az0 + kPrimeZ;
-                cm = (((((ay0 ^ az0) & cx.mask) / (uint32_t)kTileEntries) == cx.t) ? 1u : 0u) |
-                     (((((ay1 ^ az0) & cx.mask) / (uint32_t)kTileEntries) == cx.t) ? 2u : 0u) |
-                     (((((ay0 ^ az1) & cx.mask) / (uint32_t)kTileEntries) == cx.t) ? 4u : 0u) |
-                     (((((ay1 ^ az1) & cx.mask) / (uint32_t)kTileEntries) == cx.t) ? 8u : 0u);
-            }
-        }
-        const uint32_t rest = cm & (cm - 1u);           // every lane applies ONE combination; the others go back into the queue
-        cm &= 0u - cm;
-        if (cm && gx < (uint32_t)(kTileEntries - 1))    // (else: zero gradient, see tile_codes_kernel)
-            apply_pairs<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz, ay0, az0, cm);
-        enqueue_rest(rest, bi);
-    };
-    pop_and_gather();                   // empty queue: dummy gather, keeps the loop shape static
-    for (int64_t cb = w_lo; cb < w_hi; cb += 64) {
-        // hit words of the next 64 chunks, one per lane (a contiguous 512-byte read)
-        unsigned long long mv = 0ull;
-        if (cb + lane < w_hi) mv = masks_t[cb + lane];
-        const int lim = (w_hi - cb < 64) ? (int)(w_hi - cb) : 64;
-        for (int k = 0; k < lim; k += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, k + u);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), k + u);
-                const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-                if (m) enqueue_mask(m, (uint32_t)((cb + k + u) << 6));
-            }
-            {
-                PERF_WAIT_BATCH0();
-                apply_batch(bx, byz, bg);
-            }
-            pop_and_gather();
-            while (qn >= 128u) {        // bursts (ray-coherent samples at coarse hashed levels)
-                PERF_WAIT_BATCH0();
-                apply_batch(bx, byz, bg);
-                pop_and_gather();
-            }
-        }
-    }
-    for (;;) {
-        PERF_WAIT_BATCH0();
-        apply_batch(bx, byz, bg);
-        be = kIdle;
-        if (qn == 0u) break;
-        pop_and_gather();
-    }
-#undef PERF_WAIT_BATCH0
 }
 
 // Streaming loop: a thread owns 4 consecutive samples per iteration -- 3 x 16 B of positions + 2 x 16 B of
@@ -937,11 +794,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         coded = esc_any == 0u;
     }
     uint32_t* queue = reinterpret_cast<uint32_t*>(lds_tile + 2 * kTileEntries) + (threadIdx.x >> 6) * kQueueCap;
-    if (coded && hashed && ((tp.use_masks >> l) & 1u))
-        bwd_stream_masks<FIXED>(cx, lds_tile, queue,
-                                reinterpret_cast<const unsigned long long*>(codes + (int64_t)tp.code_slot[l] * tp.n_pad) + (int64_t)t * (tp.n_pad >> 6),
-                                x01, g_l, n_live, rep, R);
-    else if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
+    if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (coded) bwd_stream_codes<FIXED, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n_live, rep, R);
     else bwd_stream<FIXED, false>(cx, lds_tile, x01, g_l, n_live, rep, R);
@@ -1253,7 +1106,7 @@ static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
         if (gp.hashed[l] ? (nt >= 2 && nt <= 255 && gp.res[l] + 2u < (uint32_t)kTileEntries) : (nt >= 2 && nt <= 64))
             tp->code_slot[l] = slots++;
     }
-    tp->n_pad = (n + 63) & ~(int64_t)63;           // (a multiple of the 64-sample chunk of the hit bitmaps)
+    tp->n_pad = (n + 3) & ~(int64_t)3;
     return slots;
 }
 
@@ -1293,10 +1146,6 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     if (dbg_env && workspace_bytes >= dbg_at + kDbgBytes) tp.dbg_off = dbg_at / (int64_t)sizeof(float2);
     // tile codes of the hashed levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
     const int slots = plan_codes(gp, n, &tp);
-    static const bool no_masks = getenv("PERF_BWD_NO_MASKS") != nullptr;     // experiment switch: byte codes for hashed levels too
-    tp.use_masks = 0u;
-    for (int l = 0; l < gp.n_levels && !no_masks; ++l)
-        if (tp.code_slot[l] >= 0 && gp.hashed[l] && tp.tiles_of[l] <= 16) tp.use_masks |= 1u << l;
     const int64_t codes_at = dbg_at + kDbgBytes;
     uint32_t* codes = nullptr;
     uint32_t* escape = nullptr;
