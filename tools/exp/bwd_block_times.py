@@ -11,15 +11,15 @@ d = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
 t = (torch.arange(128, device=dev) + 0.5) / 128
 x = ((d[:, None, :] * t[None, :, None]).reshape(-1, 3) * 0.5 + 0.5).contiguous()
 dfeat = torch.randn(16, n, 2, device=dev)
-amax = dfeat.abs().amax(dim=(1, 2))
+amax = torch.zeros(24, device=dev); amax[:16] = dfeat.abs().amax(dim=(1, 2))
 desc = cfg.desc()
 need = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(desc), n)
 ws = torch.zeros(need // 4 + 64, dtype=torch.float32, device=dev)
 out = torch.empty(cfg.n_params, device=dev)
 for fixed in (False, True):
     for _ in range(2):
-        ops._call('perf_hashgrid_bwd', ctypes.byref(desc), ops._p(x), ops._p(dfeat), ops._p(out), n, 0, ops._p(amax) if fixed else None,
-                  None, ops._p(ws), ws.numel() * 4, ops._stream())
+        ops._call('perf_hashgrid_bwd', ctypes.byref(desc), ops._p(x), ops._p(dfeat), ops._p(out), n, None, 0, ops._p(amax) if fixed else None,
+                  None, None, ops._p(ws), ws.numel() * 4, ops._stream())
     torch.cuda.synchronize()
     need0 = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(desc), 0)
     off = ((need0 - 16 - 4096 * 8 + 15) // 16 * 16) // 8          # debug slots follow the replica slabs
