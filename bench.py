@@ -175,6 +175,18 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # The library travels prebuilt (in-tree libperf_hip.so); should it be missing or stale (ABI mismatch) it is rebuilt from
+    # the HIP sources -- never replaced by another code path.
+    from perf_amd import _lib
+    try:
+        _lib.load()
+    except _lib.PerfError:
+        if rank == 0:
+            from perf_amd import build as _build
+            _build.build(force=True)
+        if world > 1:
+            dist.barrier()
+        _lib.load()
     from perf_amd import ops, synthetic, tcnn
     from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
     args.dtype = args.dtype or tcnn.DEFAULT_DTYPE
