@@ -95,7 +95,11 @@ __device__ __forceinline__ void corner_weights(const float f[3], bool smooth, fl
 // level l handled by (group, pass).  L <= 16: pass 0 -> g, pass 1 -> L-1-g (if different) -- a coarse (small) and a
 // fine (large) table per group.  Deeper grids (L <= 24) add pass 2 -> 16+g; their tables exceed the L2 anyway.
 constexpr int kFwdPasses = 3;
-constexpr int64_t kFwdMaxChunks = 0;        // 0: one workgroup per chunk (uncapped); see perf_hashgrid_fwd
+// at most this many 256-sample chunks per level group in one launch (the workgroups loop beyond): launches of up to 1 M
+// samples keep one workgroup per chunk (measured equal either way), while a capacity-sized launch of an eval frame -- 33 M
+// rows for a tail pass that holds a few thousand live samples -- no longer dispatches 10^6 workgroups that only read the
+// device-side count and leave (0.25 ms per frame)
+constexpr int64_t kFwdMaxChunks = 4096;
 __device__ __forceinline__ int level_of(int group, int pass, int L) {
     if (pass == 2) return (16 + group < L) ? 16 + group : -1;
     const int Lc = L < 16 ? L : 16;
