@@ -50,148 +50,111 @@ __device__ __forceinline__ float lattice(float t0, int k, float step) { return a
 // intervals 64q..64q+63) may hold samples; only live chunks have their mask word written (and later read).
 __device__ __forceinline__ int n_live_words(int mask_words) { return (mask_words + 63) >> 6; }
 
-// A wave serves kRaysPerWave rays at once.  The kernel is latency bound -- per ray one dependent gather for the coarse test
-// and one per round of fine tests, a few hundred instructions in between -- so the rays of a wave advance in lockstep and
-// their gathers are issued together (4 coarse words, then 8 occupancy words per round) instead of one L2 latency after
-// the other.  Per-ray results are exactly those of the one-ray-per-wave formulation.
-constexpr int kRaysPerWave = 4;
-constexpr int kChunksPerRound = 2;
-
 __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const float* __restrict__ ro,
                                                           const float* __restrict__ rd, const float* __restrict__ t0s,
                                                           int64_t n_rays, const uint32_t* __restrict__ bits,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint64_t* __restrict__ masks, int32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
-    // (the ray indices are wave uniform: saying so turns the loads of origin, direction and lattice origin into scalar loads)
-    const int64_t r0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * kRaysPerWave;
-    if (r0 >= n_rays) return;
+    // (the ray index is wave uniform: saying so turns the loads of the ray's origin, direction and lattice origin into
+    //  scalar loads -- seven vector-memory instructions per ray less; the kernel is bound by VMEM issue, not by bytes)
+    const int64_t r = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (r >= n_rays) return;
+    const float o[3] = {ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]};
+    const float d[3] = {rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]};
+    const float t0 = t0s[r];
+    // slab test (fminf/fmaxf drop NaNs like np.fmin/np.fmax)
+    float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inv = __fdiv_rn(1.0f, d[a]);
+        const float t1 = mul_rn(sub_rn(mp.lo[a], o[a]), inv), t2 = mul_rn(sub_rn(mp.hi[a], o[a]), inv);
+        const float l = fminf(t1, t2), h = fmaxf(t1, t2);
+        tmin = (a == 0) ? l : fmaxf(tmin, l);
+        tmax = (a == 0) ? h : fminf(tmax, h);
+    }
+    const float lo = fmaxf(tmin, t0), hi = fminf(tmax, mp.far_plane);
+    // the coarse skip is only valid while a chunk spans few enough fine cells (see coarse_build_kernel): checked per ray
+    // with its own direction, so unnormalised directions fall back to the exhaustive test instead of skipping cells
+    float span_cells = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) span_cells = fmaxf(span_cells, fabsf(d[a]) * mp.chunk_cells[a]);
+    const bool use_coarse = mp.use_coarse && (span_cells * 0.5f + 1.5f <= 8.0f);
+    int32_t count = 0;
     const int res = mp.res;
     const float rf = (float)res;
     const int nlw = n_live_words(mp.mask_words);
-    float o[kRaysPerWave][3], d[kRaysPerWave][3], t0[kRaysPerWave], lo[kRaysPerWave], hi[kRaysPerWave];
-    bool use_coarse[kRaysPerWave], valid[kRaysPerWave];
-    int32_t count[kRaysPerWave];
-#pragma unroll
-    for (int q = 0; q < kRaysPerWave; ++q) {
-        valid[q] = r0 + q < n_rays;
-        const int64_t r = valid[q] ? r0 + q : r0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { o[q][a] = ro[3 * r + a]; d[q][a] = rd[3 * r + a]; }
-        t0[q] = t0s[r];
-        count[q] = 0;
-    }
-#pragma unroll
-    for (int q = 0; q < kRaysPerWave; ++q) {
-        // slab test (fminf/fmaxf drop NaNs like np.fmin/np.fmax)
-        float tmin = -INFINITY, tmax = INFINITY;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float inv = __fdiv_rn(1.0f, d[q][a]);
-            const float t1 = mul_rn(sub_rn(mp.lo[a], o[q][a]), inv), t2 = mul_rn(sub_rn(mp.hi[a], o[q][a]), inv);
-            const float l = fminf(t1, t2), h = fmaxf(t1, t2);
-            tmin = (a == 0) ? l : fmaxf(tmin, l);
-            tmax = (a == 0) ? h : fminf(tmax, h);
-        }
-        lo[q] = fmaxf(tmin, t0[q]); hi[q] = fminf(tmax, mp.far_plane);
-        // the coarse skip is only valid while a chunk spans few enough fine cells (see coarse_build_kernel): checked per
-        // ray with its own direction, so unnormalised directions fall back to the exhaustive test instead of skipping cells
-        float span_cells = 0.f;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) span_cells = fmaxf(span_cells, fabsf(d[q][a]) * mp.chunk_cells[a]);
-        use_coarse[q] = mp.use_coarse && (span_cells * 0.5f + 1.5f <= 8.0f);
-    }
+    uint64_t* rec = masks + r * (int64_t)(mp.mask_words + nlw);
     for (int g = 0; g < nlw; ++g) {
-        // ---- phase A: lane c decides whether chunk 64g+c of ray q can hold a sample at all (range + dilated coarse grid):
-        //      one ballot per ray replaces up to 64 sequential chunk visits (what nerfacc's DDA skips cell by cell)
-        const int c = g * 64 + lane;
-        bool maybe[kRaysPerWave];
-        uint32_t cbi[kRaysPerWave];
+        // ---- phase A: lane q decides whether chunk 64g+q can hold a sample at all (range + dilated coarse grid):
+        //      one ballot replaces up to 64 sequential chunk visits (what nerfacc's DDA skips cell by cell)
+        const int q = g * 64 + lane;
+        bool maybe = false;
+        if (q < mp.mask_words) {
+            const int k0 = q * 64;
+            maybe = !(lattice(t0, k0, mp.step) > hi) && !(lattice(t0, k0 + 64, mp.step) < lo);
+            if (maybe && use_coarse) {
+                const float tc = lattice(t0, k0 + 32, mp.step);
+                const int cr = res >> 3;
+                int cb[3];
 #pragma unroll
-        for (int q = 0; q < kRaysPerWave; ++q) {
-            maybe[q] = false; cbi[q] = 0u;
-            if (valid[q] && c < mp.mask_words) {
-                const int k0 = c * 64;
-                maybe[q] = !(lattice(t0[q], k0, mp.step) > hi[q]) && !(lattice(t0[q], k0 + 64, mp.step) < lo[q]);
-                if (maybe[q] && use_coarse[q]) {
-                    const float tc = lattice(t0[q], k0 + 32, mp.step);
-                    const int cr = res >> 3;
-                    int cb[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        const float p = add_rn(o[q][a], mul_rn(d[q][a], tc));
-                        const float u = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
-                        cb[a] = ((int)fminf(fmaxf(floorf(u), 0.0f), rf - 1.0f)) >> 3;
-                    }
-                    cbi[q] = (uint32_t)((cb[0] * cr + cb[1]) * cr + cb[2]);
+                for (int a = 0; a < 3; ++a) {
+                    const float p = add_rn(o[a], mul_rn(d[a], tc));
+                    const float u = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
+                    cb[a] = ((int)fminf(fmaxf(floorf(u), 0.0f), rf - 1.0f)) >> 3;
                 }
+                const uint32_t bi = (uint32_t)((cb[0] * cr + cb[1]) * cr + cb[2]);
+                maybe = (coarse[bi >> 5] >> (bi & 31)) & 1u;
             }
         }
-        uint32_t cw[kRaysPerWave];
+        uint64_t live = __ballot(maybe);
+        uint64_t kept = 0;        // chunks that really hold samples
+        // ---- phase B: the 64 lattice intervals of every surviving chunk, one per lane.  Four chunks per round: their
+        //      occupancy words are independent gathers, issued together instead of one L2 latency after the other
+        //      (a ray crosses ~5 live chunks around a surface: the dilated coarse grid is generous)
+        for (uint64_t todo = live; todo;) {
+            int qs[4]; uint32_t cis[4]; bool in_range[4];
 #pragma unroll
-        for (int q = 0; q < kRaysPerWave; ++q) cw[q] = (maybe[q] && use_coarse[q]) ? coarse[cbi[q] >> 5] : 0u;
-        uint64_t todo[kRaysPerWave], kept[kRaysPerWave];
+            for (int u = 0; u < 4; ++u) {
+                qs[u] = -1; cis[u] = 0u; in_range[u] = false;
+                if (todo) {
+                    qs[u] = g * 64 + (__ffsll((unsigned long long)todo) - 1);
+                    todo &= todo - 1;
+                    const int k = qs[u] * 64 + lane;
+                    if (k < mp.max_steps) {
+                        const float ta = lattice(t0, k, mp.step), tb = lattice(t0, k + 1, mp.step);
+                        const float mid = mul_rn(add_rn(ta, tb), 0.5f);
+                        if (mid >= lo && mid <= hi) {
+                            int cell[3];
 #pragma unroll
-        for (int q = 0; q < kRaysPerWave; ++q) {
-            if (maybe[q] && use_coarse[q]) maybe[q] = (cw[q] >> (cbi[q] & 31)) & 1u;
-            todo[q] = __ballot(maybe[q]);
-            kept[q] = 0;        // chunks that really hold samples
-        }
-        // ---- phase B: the 64 lattice intervals of every surviving chunk, one per lane; per round kChunksPerRound chunks
-        //      of every ray of the wave, their occupancy words gathered together
-        while (todo[0] | todo[1] | todo[2] | todo[3]) {
-            int qs[kRaysPerWave][kChunksPerRound]; uint32_t cis[kRaysPerWave][kChunksPerRound]; bool in_range[kRaysPerWave][kChunksPerRound];
-#pragma unroll
-            for (int q = 0; q < kRaysPerWave; ++q)
-#pragma unroll
-                for (int u = 0; u < kChunksPerRound; ++u) {
-                    qs[q][u] = -1; cis[q][u] = 0u; in_range[q][u] = false;
-                    if (todo[q]) {
-                        qs[q][u] = g * 64 + (__ffsll((unsigned long long)todo[q]) - 1);
-                        todo[q] &= todo[q] - 1;
-                        const int k = qs[q][u] * 64 + lane;
-                        if (k < mp.max_steps) {
-                            const float ta = lattice(t0[q], k, mp.step), tb = lattice(t0[q], k + 1, mp.step);
-                            const float mid = mul_rn(add_rn(ta, tb), 0.5f);
-                            if (mid >= lo[q] && mid <= hi[q]) {
-                                int cell[3];
-#pragma unroll
-                                for (int a = 0; a < 3; ++a) {
-                                    const float p = add_rn(o[q][a], mul_rn(d[q][a], mid));
-                                    const float uu = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
-                                    cell[a] = (int)fminf(fmaxf(floorf(uu), 0.0f), rf - 1.0f);
-                                }
-                                cis[q][u] = (uint32_t)((cell[0] * res + cell[1]) * res + cell[2]);
-                                in_range[q][u] = true;
+                            for (int a = 0; a < 3; ++a) {
+                                const float p = add_rn(o[a], mul_rn(d[a], mid));
+                                const float uu = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
+                                cell[a] = (int)fminf(fmaxf(floorf(uu), 0.0f), rf - 1.0f);
                             }
+                            cis[u] = (uint32_t)((cell[0] * res + cell[1]) * res + cell[2]);
+                            in_range[u] = true;
                         }
                     }
                 }
-            uint32_t words[kRaysPerWave][kChunksPerRound];
+            }
+            uint32_t words[4];
 #pragma unroll
-            for (int q = 0; q < kRaysPerWave; ++q)
+            for (int u = 0; u < 4; ++u) words[u] = in_range[u] ? bits[cis[u] >> 5] : 0u;
 #pragma unroll
-                for (int u = 0; u < kChunksPerRound; ++u) words[q][u] = in_range[q][u] ? bits[cis[q][u] >> 5] : 0u;
-#pragma unroll
-            for (int q = 0; q < kRaysPerWave; ++q)
-#pragma unroll
-                for (int u = 0; u < kChunksPerRound; ++u) {
-                    if (qs[q][u] < 0) continue;          // (wave uniform)
-                    const uint64_t m = __ballot(in_range[q][u] && ((words[q][u] >> (cis[q][u] & 31)) & 1u));
-                    if (m) {
-                        kept[q] |= 1ull << (qs[q][u] & 63);
-                        if (lane == 0) masks[(r0 + q) * (int64_t)(mp.mask_words + nlw) + nlw + qs[q][u]] = m;
-                        count[q] += __popcll(m);
-                    }
+            for (int u = 0; u < 4; ++u) {
+                if (qs[u] < 0) continue;                 // (wave uniform)
+                const uint64_t m = __ballot(in_range[u] && ((words[u] >> (cis[u] & 31)) & 1u));
+                if (m) {
+                    kept |= 1ull << (qs[u] & 63);
+                    if (lane == 0) rec[nlw + qs[u]] = m;
+                    count += __popcll(m);
                 }
+            }
         }
-#pragma unroll
-        for (int q = 0; q < kRaysPerWave; ++q)
-            if (lane == 0 && valid[q]) masks[(r0 + q) * (int64_t)(mp.mask_words + nlw) + g] = kept[q];
+        if (lane == 0) rec[g] = kept;
     }
-#pragma unroll
-    for (int q = 0; q < kRaysPerWave; ++q)
-        if (lane == 0 && valid[q]) counts[r0 + q] = count[q];
+    if (lane == 0) counts[r] = count;
 }
 
 __global__ __launch_bounds__(256) void march_write_kernel(const float* __restrict__ t0s, int64_t n_rays, float step,
@@ -427,7 +390,7 @@ extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, co
     mp.mask_words = chunk_words(max_steps);
     for (int a = 0; a < 3; ++a) mp.chunk_cells[a] = 64.0f * step * mp.inv_ext[a] * (float)res;
     mp.use_coarse = (occ_coarse != nullptr && (res % 8) == 0) ? 1 : 0;      // (+ the per-ray span test in the kernel)
-    hipLaunchKernelGGL(march_count_kernel, dim3((unsigned)div_up(n_rays, 16)), dim3(256), 0, as_stream(stream), mp, rays_o,
+    hipLaunchKernelGGL(march_count_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
                        rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts);
     PERF_LAUNCH_CHECK("perf_occ_march_count");
     return PERF_OK;
