@@ -412,6 +412,23 @@ int perf_gather_supervision(const int64_t* indices, int64_t n, const float* o_al
 int perf_pdf_resample(const float* s_in, const float* cdf, const float* tau, int64_t n_rays, int32_t n_in,
                       int32_t n_out, float* s_out, void* stream);
 
+/* ---- reprojection visibility tests (modules/scene/nerf.py:321-358, modules/dataset/sup_info.py:261-302) ---------------
+ * For every point pts[i] (a rendered panorama's back-projected surface point): direction and distance in the frame of a
+ * registered panorama (pose: 16 host floats, row major 4x4, camera-to-world), equirect image coordinate
+ * (utils/camera_utils.py:134-151), bilinear look-up of distance_map [height, width] (the panorama's distance map already
+ * multiplied by its validity mask) with grid_sample(padding_mode='border', align_corners=False) arithmetic, then
+ *   mode 0: mask[i] = max(mask[i], dist < looked-up + eps)      (get_pano_visibility_mask: eps = 1/256)
+ *   mode 1: mask[i] = min(mask[i], looked-up < dist)             (geo_check)
+ * Call once per registered panorama on a mask initialised to 0 (mode 0) / 1 (mode 1). */
+int perf_pano_reproject(const float* pts, int64_t n, const float* pose, const float* distance_map, int32_t height,
+                        int32_t width, int32_t mode, float eps, float* mask, void* stream);
+/* Binary morphology of a 0/1 float image with a structuring element given as row bit masks (bit c of row_bits[r] = element
+ * (r, c); rows <= 16, cols <= 32; OpenCV's MORPH_ELLIPSE elements are built by the caller).  op 0: dilation, pixels outside
+ * the image count as background; op 1: erosion, outside counts as foreground (kornia's geodesic border, nerf.py:354-355).
+ * in != out. */
+int perf_morph_binary(const float* in, float* out, int32_t height, int32_t width, const uint32_t* row_bits, int32_t rows,
+                      int32_t cols, int32_t op, void* stream);
+
 /* ---- occupancy pre-grid (modules/dataset/sup_info.py:304-330) ------------------------------ */
 int perf_occ_splat(const float* rays_o, const float* rays_d, const float* dist, int64_t n,
                    int32_t res, uint8_t* occ, void* stream);

@@ -88,6 +88,8 @@ _SIGS = {
     'perf_composite_distloss_bwd': (c_int, [P, P, P, P, c_int64, P, P, P, P, P, P, c_float, P, P, P]),
     'perf_gather_supervision': (c_int, [P, c_int64, P, P, P, P, P, P, P, P, P, P, P]),
     'perf_pdf_resample': (c_int, [P, P, P, c_int64, c_int32, c_int32, P, P]),
+    'perf_pano_reproject': (c_int, [P, c_int64, POINTER(c_float), P, c_int32, c_int32, c_int32, c_float, P, P]),
+    'perf_morph_binary': (c_int, [P, P, c_int32, c_int32, POINTER(c_uint32), c_int32, c_int32, c_int32, P]),
     'perf_occ_splat': (c_int, [P, P, P, c_int64, c_int32, P, P]),
 }
 

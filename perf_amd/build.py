@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libperf_hip.so')
-SOURCES = ['misc.hip', 'hashgrid.hip', 'mlp.hip', 'march.hip', 'composite.hip']
+SOURCES = ['misc.hip', 'hashgrid.hip', 'mlp.hip', 'march.hip', 'composite.hip', 'visibility.hip']
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read per accumulator register before the epilogues)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
          '-mllvm', '-amdgpu-mfma-vgpr-form=1']

@@ -612,3 +612,24 @@ def pdf_resample(s_in, cdf, n_out, tau=None):
     _call('perf_pdf_resample', _p(_f32(s_in.contiguous(), 's_in')), _p(_f32(cdf.contiguous(), 'cdf')), _p(tau), R, n1 - 1,
           int(n_out), _p(out), _stream())
     return out
+
+
+# ---- reprojection visibility tests ---------------------------------------------------------------------------------
+def pano_reproject(pts, pose, distance_map, mask, mode, eps=1.0 / 256.0):
+    """In place on mask [n] (float 0/1): fold one registered panorama's depth test into it (perf_pano_reproject)."""
+    n = pts.shape[0]
+    h, w = distance_map.shape
+    pose_h = (ctypes.c_float * 16)(*[float(v) for v in torch.as_tensor(pose).detach().cpu().reshape(-1).tolist()])
+    _call('perf_pano_reproject', _p(_f32(pts, 'pts')), n, pose_h, _p(_f32(distance_map, 'distance_map')), int(h), int(w), int(mode),
+          float(eps), _p(_f32(mask, 'mask')), _stream())
+    return mask
+
+
+def morph_binary(img, element, op):
+    """img [H,W] float 0/1, element: 2-D 0/1 array (rows <= 16, cols <= 32), op 'dilate' | 'erode' -> new [H,W] float."""
+    h, w = img.shape
+    rows, cols = int(element.shape[0]), int(element.shape[1])
+    bits = (ctypes.c_uint32 * rows)(*[sum(1 << c for c in range(cols) if float(element[r][c]) > 0.5) for r in range(rows)])
+    out = torch.empty_like(img)
+    _call('perf_morph_binary', _p(_f32(img, 'img')), _p(out), int(h), int(w), bits, rows, cols, 0 if op == 'dilate' else 1, _stream())
+    return out

@@ -2,9 +2,11 @@
 (modules/scene/nerf.py:321-358) and SupInfoPool.geo_check (modules/dataset/sup_info.py:261-302).  They sit directly
 either side of a full-panorama render: back-project the rendered distance, look the point up in every registered
 panorama's distance map (bilinear grid_sample, border padding) and clean the binary result with elliptical
-morphology.  Plain PyTorch on the device; the structuring elements restate OpenCV's MORPH_ELLIPSE rasterisation and
-kornia's geodesic-border dilation/erosion (both packages are absent here, so this part is unpinned except for
-direction_to_img_coord, which is checked against the reference's golden vector)."""
+morphology.  On the device both steps are HIP kernels (perf_pano_reproject: one launch per registered panorama instead of
+~15 torch kernels; perf_morph_binary); the torch formulation below is kept as their test reference (`use_kernels=False`).
+The structuring elements restate OpenCV's MORPH_ELLIPSE rasterisation and kornia's geodesic-border dilation/erosion (both
+packages are absent here: the elements and border rules are checked against scipy.ndimage on the CPU, and
+direction_to_img_coord against the reference's golden vector)."""
 import math
 
 import numpy as np
@@ -61,11 +63,26 @@ def _lookup_distance(pts, info):
     return dist, proj
 
 
-def pano_visibility_mask(rays_o, rays_d, distance, sup_infos):
+def _kernel_path(pts, sup_infos, mode, small, large):
+    from . import ops
+    h, w = pts.shape[:2]
+    flat = pts.reshape(-1, 3).contiguous().float()
+    mask = torch.full((h * w,), 0.0 if mode == 0 else 1.0, device=pts.device)
+    for info in sup_infos:
+        dmap = (info['distance_map'] * info['mask'].float())[..., 0].contiguous().float()
+        ops.pano_reproject(flat, info['pose'], dmap, mask, mode)
+    m = mask.view(h, w)
+    m = ops.morph_binary(m, ellipse_kernel(*small).flip(0, 1), 'dilate')
+    return ops.morph_binary(m, ellipse_kernel(*large), 'erode')
+
+
+def pano_visibility_mask(rays_o, rays_d, distance, sup_infos, use_kernels=True):
     """nerf.py:321-358: 1 where the rendered surface point is seen (not occluded) by at least one registered panorama
     (distance < stored + 1/256), then dilate 5x5 / erode 9x9 ellipses.  rays [H,W,3], distance [H,W] -> [H,W]."""
     h, w = distance.shape
     pts = rays_o + rays_d * distance[..., None]
+    if use_kernels and pts.is_cuda:
+        return _kernel_path(pts, sup_infos, 0, (5, 5), (9, 9))
     mask = torch.zeros(h, w, 1, device=distance.device)
     for info in sup_infos:
         dist, proj = _lookup_distance(pts, info)
@@ -76,11 +93,13 @@ def pano_visibility_mask(rays_o, rays_d, distance, sup_infos):
     return m[0, 0]
 
 
-def geo_check(rays_o, rays_d, distances, sup_infos):
+def geo_check(rays_o, rays_d, distances, sup_infos, use_kernels=True):
     """sup_info.py:261-302: 1 = consistent, 0 = the point lies in front of a surface some panorama already observed
     (stored distance >= distance of the point); dilate 3x3 / erode 9x9."""
     h, w = distances.shape[:2]
     pts = rays_o + rays_d * distances.reshape(h, w)[..., None]
+    if use_kernels and pts.is_cuda:
+        return _kernel_path(pts, sup_infos, 1, (3, 3), (9, 9))
     mask = torch.ones(h, w, 1, device=pts.device)
     for info in sup_infos:
         dist, proj = _lookup_distance(pts, info)

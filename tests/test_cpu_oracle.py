@@ -207,3 +207,23 @@ def test_config1_cpu_plumbing():
             geo.copy_(p)
         losses.append(float(dl))
     assert losses[-1] < losses[0]
+
+
+def test_morphology_matches_scipy():
+    """next-3: ellipse elements and the border rules of dilate / erode (background outside for dilation, foreground
+    outside for erosion) against scipy.ndimage on random masks — the definition the HIP morphology kernel is tested
+    against on the GPU."""
+    from scipy import ndimage
+    from perf_amd import visibility as V
+    rng = np.random.default_rng(3)
+    for shape, p in (((37, 53), 0.15), ((16, 128), 0.6), ((64, 64), 0.95)):
+        m = (rng.random(shape) < p)
+        mt = torch.from_numpy(m.astype(np.float32))[None, None]
+        for rows, cols in ((3, 3), (5, 5), (9, 9), (5, 9)):
+            k = V.ellipse_kernel(rows, cols)
+            kb = k.numpy() > 0.5
+            assert kb[rows // 2].all() and kb[:, cols // 2].all() and (kb == kb[::-1, ::-1]).all()
+            d = ndimage.binary_dilation(m, structure=kb, border_value=0)
+            e = ndimage.binary_erosion(m, structure=kb, border_value=1)
+            assert np.array_equal(V.dilate(mt, k)[0, 0].numpy() > 0.5, d)
+            assert np.array_equal(V.erode(mt, k)[0, 0].numpy() > 0.5, e)

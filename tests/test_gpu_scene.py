@@ -1,6 +1,8 @@
 """GPU parity of the host-side mirror (fields / renderer / training steps) against the CPU oracle, and the
 drop-in shim packages.  Fields are compared with the oracle's 16-bit emulation (quant=...), which rounds the
 same operands the kernels round."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -654,3 +656,62 @@ def test_skipping_the_unused_colour_render_changes_nothing():
         return scene.nerf.geo_mlp.params.detach().clone()
 
     assert torch.equal(run(False), run(True))
+
+
+def test_reprojection_and_morphology_kernels_match_torch_formulation():
+    """next-3: perf_pano_reproject / perf_morph_binary against the torch formulation of nerf.py:321-358 and
+    sup_info.py:261-302 (grid_sample border bilinear + conv morphology).  Morphology is bit-exact; the depth test may differ
+    only on pixels whose |distance - looked-up distance| is within float rounding of the threshold."""
+    from perf_amd import ops, synthetic
+    from perf_amd import visibility as V
+    from perf_amd.scene import SupInfoPool, gen_pano_rays
+    g = torch.Generator(device='cpu').manual_seed(5)
+    for shape, p in (((37, 53), 0.15), ((64, 128), 0.6), ((512, 1024), 0.97)):
+        m = (torch.rand(shape, generator=g) < p).float().cuda()
+        for rows, cols in ((3, 3), (5, 5), (9, 9), (5, 9)):
+            k = V.ellipse_kernel(rows, cols)
+            assert torch.equal(ops.morph_binary(m, k.flip(0, 1), 'dilate'), V.dilate(m[None, None], k.cuda())[0, 0])
+            assert torch.equal(ops.morph_binary(m, k, 'erode'), V.erode(m[None, None], k.cuda())[0, 0])
+    # three registered panoramas at different poses with partly masked distance maps
+    pool = SupInfoPool()
+    poses = []
+    for i, t in enumerate(((0., 0., 0.), (0.25, -0.1, 0.05), (-0.2, 0.3, -0.1))):
+        pose = torch.eye(4)
+        a = 0.4 * i
+        pose[:3, :3] = torch.tensor([[math.cos(a), -math.sin(a), 0.], [math.sin(a), math.cos(a), 0.], [0., 0., 1.]])
+        pose[:3, 3] = torch.tensor(t)
+        rays = gen_pano_rays(pose, 128, 256)
+        dist, rgb = synthetic.room(rays.d)     # not a consistent scene across poses: only the two formulations are compared
+        msk = torch.ones(128, 256, 1, device='cuda')
+        msk[40:60, 30 * i:30 * i + 50] = 0
+        pool.register_sup_info(pose, msk, rgb, dist)
+        poses.append(pose)
+    view = torch.eye(4); view[:3, 3] = torch.tensor([0.1, 0.05, -0.05])
+    rays = gen_pano_rays(view, 192, 384)
+    dist, _ = synthetic.room(rays.d)
+    for scale in (0.6, 1.0, 1.3):
+        d = dist[..., 0] * scale
+        pts = rays.o + rays.d * d[..., None]
+        # raw depth tests (before morphology)
+        flat = pts.reshape(-1, 3).contiguous()
+        vis = torch.zeros(flat.shape[0], device='cuda'); geo = torch.ones(flat.shape[0], device='cuda')
+        vis_t = torch.zeros(192, 384, 1, device='cuda'); geo_t = torch.ones(192, 384, 1, device='cuda')
+        margin = torch.full((192, 384, 1), 1e9, device='cuda')
+        for info in pool.sup_infos:
+            dm = (info['distance_map'] * info['mask'].float())[..., 0].contiguous()
+            ops.pano_reproject(flat, info['pose'], dm, vis, 0)
+            ops.pano_reproject(flat, info['pose'], dm, geo, 1)
+            dd, proj = V._lookup_distance(pts, info)
+            vis_t = torch.maximum(vis_t, (dd < proj + 1 / 256.).float())
+            geo_t = torch.minimum(geo_t, (proj < dd).float())
+            margin = torch.minimum(margin, torch.minimum((dd - proj - 1 / 256.).abs(), (dd - proj).abs()))
+        near = margin[..., 0].reshape(-1) < 2e-5
+        assert float(near.float().mean()) < 0.02
+        assert torch.equal(vis[~near], vis_t.reshape(-1)[~near]) and torch.equal(geo[~near], geo_t.reshape(-1)[~near])
+        # end to end through both public functions
+        a = V.pano_visibility_mask(rays.o, rays.d, d, pool.sup_infos)
+        b = V.pano_visibility_mask(rays.o, rays.d, d, pool.sup_infos, use_kernels=False)
+        assert float((a != b).float().mean()) < 0.01
+        a = V.geo_check(rays.o, rays.d, d[..., None], pool.sup_infos)
+        b = V.geo_check(rays.o, rays.d, d[..., None], pool.sup_infos, use_kernels=False)
+        assert float((a != b).float().mean()) < 0.01
