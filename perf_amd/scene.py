@@ -482,7 +482,9 @@ class NeRFScene:
         st = pre['st']
         rand_in, rand = rand, pre['rand']
         if st is None:
-            st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand, with_rgb=not self.skip_unused_color,
+            # (under data parallelism the colour render is deferred until the gradient all-reduce is in flight, see below)
+            st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand,
+                                            with_rgb=not (self.skip_unused_color or (dist_info[0] is not None and self.overlap_comm)),
                                             keep_features=self.reuse_sampling_features and self.renderer.sample_capacity is not None)
         geo = self.nerf.geo_mlp
         extra = 1 if dist_info[0] is not None else 0
@@ -505,6 +507,8 @@ class NeRFScene:
         defer_color = (dist_info[0] is not None and self.overlap_comm and not self.skip_unused_color and st['rgbs'] is None)
         rgbs = None if (self.skip_unused_color or defer_color) else (st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel, n_dev))
         w, T, op, dist_r, col, dl = ops.composite_distloss_fwd(sig.view(-1), rgbs, ts, te, packed)
+        if rgbs is not None:
+            self.last_colors = col           # the step's (unused) colour render, [n_rays, 3]
         noise = rand['noise']            # (the background colour the reference also draws, :185, is not used by this step)
         if not self._capturing:
             self._ratio_dev.fill_(float(np.min([progress * 2., 1])))

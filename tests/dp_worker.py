@@ -45,6 +45,8 @@ def main():
     for i in range(steps):
         scene.update_lr(opt, scene.train_conf.geo_optimizer, 0.1)
         scene.train_one_step_geo(opt, pool, progress=0.5, rand=rand, generator=gen, prefetch_next=i + 1 < steps)
+        if i == 0:
+            first_colors = scene.last_colors.detach().float().cpu().clone()      # the step's colour render (deferred under DP)
     opt2 = scene.make_optimizer(scene.nerf.app_mlp, 0.0)
     for i in range(steps):
         scene.update_lr(opt2, scene.train_conf.app_optimizer, 0.1)
@@ -59,7 +61,7 @@ def main():
     skipped = bool(torch.equal(before, scene.nerf.geo_mlp.params.detach())) and opt3.step_count == 0
     if rank == 0:
         torch.save({'geo': scene.nerf.geo_mlp.params.detach().cpu(), 'app': scene.nerf.app_mlp.params.detach().cpu(),
-                    'g_geo': first_grad['geo'].cpu(), 'g_app': first_grad['app'].cpu(), 'empty_batch_skipped': skipped,
+                    'g_geo': first_grad['geo'].cpu(), 'g_app': first_grad['app'].cpu(), 'empty_batch_skipped': skipped, 'first_colors': first_colors,
                     'geo_steps': opt.step_count, 'world': world, **init}, out_path)
     if world > 1:
         dist.barrier()

@@ -46,6 +46,11 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(tmp_path):
         assert float((two[k] - one[k]).norm()) < 0.1 * moved, (k, float((two[k] - one[k]).norm()), moved)
     # a batch without samples on any rank: the optimizer step is skipped everywhere (reference: nerf.py:204-206)
     assert one['empty_batch_skipped'] and two['empty_batch_skipped']
+    # the geometry step's colour render (query key 'rgb'; issued while the all-reduce is in flight under DP): rank 0 of
+    # the 2-rank world holds the first half of the global batch
+    per = two['first_colors'].shape[0]
+    assert per * 2 == one['first_colors'].shape[0]
+    assert float((two['first_colors'] - one['first_colors'][:per]).abs().max()) < 2e-3
 
 
 @pytest.mark.parametrize('n_levels,log2_t', [(16, 18), (20, 20)])
