@@ -263,8 +263,14 @@ class FieldSpec:
     output_activation: str
 
     @property
+    def n_in(self):
+        """Input width of the network: the encoding's output padded to a multiple of 16 (tcnn pads the encoding to the
+        network's alignment; the padded columns see zeros).  32 for PeRF's 16 levels, 48 for a 20-level grid."""
+        return (self.lv.n_levels * self.lv.n_feat + 15) // 16 * 16
+
+    @property
     def n_net(self):
-        return n_mlp_params(self.lv.n_levels * self.lv.n_feat, self.n_hidden_layers)
+        return n_mlp_params(self.n_in, self.n_hidden_layers)
 
     @property
     def n_params(self):
@@ -284,8 +290,7 @@ def init_field_params(spec: FieldSpec, seed: int = 1337) -> torch.Tensor:
     (tcnn's own RNG stream is not reproducible here; the same tensor is fed to both sides.)"""
     g = torch.Generator().manual_seed(seed)
     parts = []
-    n_in = spec.lv.n_levels * spec.lv.n_feat
-    for (o, i) in mlp_shapes(n_in, spec.n_hidden_layers):
+    for (o, i) in mlp_shapes(spec.n_in, spec.n_hidden_layers):
         s = math.sqrt(6.0 / (i + o))
         parts.append((torch.rand(o * i, generator=g) * 2 - 1) * s)
     parts.append((torch.rand(spec.lv.n_params, generator=g) * 2 - 1) * 1e-4)
@@ -297,7 +302,9 @@ def network_with_encoding(x01: torch.Tensor, params: torch.Tensor, spec: FieldSp
     n_net = spec.n_net
     table = params[n_net:].view(spec.lv.total, spec.lv.n_feat)
     feat = hashgrid_encode(x01, table, spec.lv, quant=quant)
-    return mlp_forward(feat, params[:n_net], spec.lv.n_levels * spec.lv.n_feat,
+    if spec.n_in > feat.shape[1]:
+        feat = torch.cat([feat, feat.new_zeros(feat.shape[0], spec.n_in - feat.shape[1])], 1)
+    return mlp_forward(feat, params[:n_net], spec.n_in,
                        spec.n_hidden_layers, spec.n_out, spec.output_activation, quant=quant)
 
 

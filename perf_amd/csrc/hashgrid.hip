@@ -394,6 +394,30 @@ __device__ __forceinline__ void apply_pairs_dense(const BwdCtx& cx, float* lds_t
     }
 }
 
+// Scale of the fixed-point gradient fields of level l: one unit = 2^-sh.
+__device__ __forceinline__ int fixed_point_shift(const float am, const int64_t n_live, const uint32_t size,
+                                                 const int32_t* __restrict__ hr_state, const int l) {
+    int e = 0;
+    if (am > 0.f) (void)frexpf(am, &e);                         // am < 2^e
+    if (e < -80) e = -80;                                        // (vanishing gradients: keep 2^sh finite)
+    // Headroom of the fixed-point fields: an entry of level l sums 8 n / size_l contributions on average (1,700 at
+    // the coarsest level of a 1 M-sample batch, 32 at a hashed one); 64x that average before the overflow flag is
+    // raised, never less than 2^12, never more than 2^24 (which still leaves 2^-7 of the largest contribution as the
+    // unit).  Derived from the LIVE sample count, so a capacity-sized launch keeps the resolution of an exact one.
+    const unsigned long long fan = (8ull * (unsigned long long)n_live + size - 1ull) / size;     // ceil(8 n / size)
+    int h = (fan <= 1ull ? 0 : 64 - __clzll((long long)(fan - 1ull))) + 6;                      // ceil(log2(fan)) + 6
+    if (hr_state) {
+        // Closed loop (caller-owned state, see perf_hashgrid_bwd): the static guess is corrected by what the fields of
+        // the PREVIOUS calls really reached -- entries near a panorama's common ray origin sum 30x the average number
+        // of contributions, hashed levels far fewer than the guess allows.  Starts 3 bits on the safe side.
+        h += hr_state[l] + kHeadroomStartBias;
+        h = h < 4 ? 4 : (h > 28 ? 28 : h);
+    } else {
+        h = h < 12 ? 12 : (h > 24 ? 24 : h);
+    }
+    return 31 - h - e;
+}
+
 // one sample's contribution to the tile this workgroup owns
 template <bool FIXED, bool HASHED>
 __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, const float2 g, const float x, const float y,
@@ -761,26 +785,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     cx.smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     cx.to_fixed = 1.0f;
     if (FIXED) {
-        const float am = level_absmax[l];
-        int e = 0;
-        if (am > 0.f) (void)frexpf(am, &e);                         // am < 2^e
-        if (e < -80) e = -80;                                        // (vanishing gradients: keep 2^sh finite)
-        // Headroom of the fixed-point fields: an entry of level l sums 8 n / size_l contributions on average (1,700 at
-        // the coarsest level of a 1 M-sample batch, 32 at a hashed one); 64x that average before the overflow flag is
-        // raised, never less than 2^12, never more than 2^24 (which still leaves 2^-7 of the largest contribution as the
-        // unit).  Derived from the LIVE sample count, so a capacity-sized launch keeps the resolution of an exact one.
-        const unsigned long long fan = (8ull * (unsigned long long)n_live + size - 1ull) / size;     // ceil(8 n / size)
-        int h = (fan <= 1ull ? 0 : 64 - __clzll((long long)(fan - 1ull))) + 6;                      // ceil(log2(fan)) + 6
-        if (hr_state) {
-            // Closed loop (caller-owned state, see perf_hashgrid_bwd): the static guess is corrected by what the fields of
-            // the PREVIOUS calls really reached -- entries near a panorama's common ray origin sum 30x the average number
-            // of contributions, hashed levels far fewer than the guess allows.  Starts 3 bits on the safe side.
-            h += hr_state[l] + kHeadroomStartBias;
-            h = h < 4 ? 4 : (h > 28 ? 28 : h);
-        } else {
-            h = h < 12 ? 12 : (h > 24 ? 24 : h);
-        }
-        const int sh = 31 - h - e;                                    // units per 1.0 = 2^sh
+        const int sh = fixed_point_shift(level_absmax[l], n_live, size, hr_state, l);    // units per 1.0 = 2^sh
         cx.to_fixed = ldexpf(1.0f, sh);
         from_fixed = ldexpf(1.0f, -sh);
     }
@@ -862,6 +867,61 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(GridParams gp,
     for (int k = 0; k < 8; ++k) {
         unsafeAtomicAdd(t + 2 * (uint64_t)c.idx[k], w[k] * g.x);
         unsafeAtomicAdd(t + 2 * (uint64_t)c.idx[k] + 1, w[k] * g.y);
+    }
+}
+
+// Fixed-point flavour of the fallback (the caller provides level_absmax and does not accumulate): the level's slice of the
+// gradient table is used as an array of 64-bit words holding the same two signed 32-bit fixed-point fields as the LDS
+// tiles -- ONE global atomic per corner instead of two, and integer sums: the result does not depend on the order the
+// atomics retire in.  hashgrid_bwd_unfix_kernel turns the words into float2 in place.
+__global__ __launch_bounds__(256) void hashgrid_bwd_atomic_fixed_kernel(GridParams gp, uint32_t levels, const float* __restrict__ x01,
+                                                                        const float2* __restrict__ dfeat, float* __restrict__ grad,
+                                                                        const float* __restrict__ level_absmax,
+                                                                        const int32_t* __restrict__ hr_state, int64_t n,
+                                                                        const int64_t* __restrict__ n_dev) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    const int64_t n_live = live_count(n, n_dev);
+    if (i >= n_live || !((levels >> l) & 1u)) return;
+    const float2 g = dfeat[(int64_t)l * n + i];
+    if (g.x == 0.f && g.y == 0.f) return;
+    const float to_fixed = ldexpf(1.0f, fixed_point_shift(level_absmax[l], n_live, gp.size[l], hr_state, l));
+    const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+    float w[8];
+    corner_weights(c.f, gp.interpolation == PERF_INTERP_SMOOTHSTEP, w);
+    unsigned long long* t = reinterpret_cast<unsigned long long*>(grad) + gp.offset[l];
+    const float sx = g.x * to_fixed, sy = g.y * to_fixed;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long v = ((long long)__float2int_rn(w[k] * sy) << 32) + (long long)__float2int_rn(w[k] * sx);
+        atomicAdd(t + c.idx[k], (unsigned long long)v);
+    }
+}
+
+__global__ __launch_bounds__(256) void hashgrid_bwd_unfix_kernel(GridParams gp, uint32_t levels, float* __restrict__ grad,
+                                                                 const float* __restrict__ level_absmax, int32_t* __restrict__ hr_state,
+                                                                 int32_t* __restrict__ overflow_flag, int64_t n,
+                                                                 const int64_t* __restrict__ n_dev) {
+    const int l = blockIdx.y;
+    if (!((levels >> l) & 1u)) return;
+    const uint32_t size = gp.size[l];
+    const float from_fixed = ldexpf(1.0f, -fixed_point_shift(level_absmax[l], live_count(n, n_dev), size, hr_state, l));
+    unsigned long long* t = reinterpret_cast<unsigned long long*>(grad) + gp.offset[l];
+    int32_t field_max = 0;
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < size; e += gridDim.x * 256) {
+        const long long tot = (long long)t[e];
+        if (tot == 0) continue;                          // (0 is 0.0f, 0.0f: untouched entries need no store)
+        const int32_t lo = (int32_t)(tot & 0xffffffffll);
+        const int32_t hi = (int32_t)((tot - (long long)lo) >> 32);
+        reinterpret_cast<float2*>(t)[e] = make_float2((float)lo * from_fixed, (float)hi * from_fixed);
+        const int32_t alo = lo < 0 ? -(lo + 1) : lo, ahi = hi < 0 ? -(hi + 1) : hi;
+        field_max = max(field_max, max(alo, ahi));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) field_max = max(field_max, __shfl_xor(field_max, off));
+    if ((threadIdx.x & 63) == 0 && field_max > 0) {
+        if (overflow_flag && field_max >= (1 << 29)) atomicOr(overflow_flag, 1);
+        if (hr_state) atomicMax(&hr_state[PERF_MAX_LEVELS + l], field_max);
     }
 }
 
@@ -1185,14 +1245,23 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
                 if ((tp.atomic_levels >> l) & 1u)
                     PERF_REQUIRE(hipMemsetAsync(grad_table + 2 * gp.offset[l], 0, (size_t)gp.size[l] * 2 * sizeof(float), as_stream(stream)) == hipSuccess,
                                  "perf_hashgrid_bwd: memset failed");
-        hashgrid_bwd_atomic_kernel<<<dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
-            gp, tp.atomic_levels, x01, (const float2*)dfeat, grad_table, n, n_dev);
-        PERF_LAUNCH_CHECK("perf_hashgrid_bwd(atomics)");
+        if (level_absmax && !accumulate && (reinterpret_cast<uintptr_t>(grad_table) & 7) == 0) {      // fixed point: one 64-bit atomic per corner, order independent
+            hashgrid_bwd_atomic_fixed_kernel<<<dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
+                gp, tp.atomic_levels, x01, (const float2*)dfeat, grad_table, level_absmax, headroom_state, n, n_dev);
+            PERF_LAUNCH_CHECK("perf_hashgrid_bwd(atomics, fixed point)");
+            hashgrid_bwd_unfix_kernel<<<dim3(1024, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
+                gp, tp.atomic_levels, grad_table, level_absmax, headroom_state, overflow_flag, n, n_dev);
+            PERF_LAUNCH_CHECK("perf_hashgrid_bwd(unfix)");
+        } else {
+            hashgrid_bwd_atomic_kernel<<<dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
+                gp, tp.atomic_levels, x01, (const float2*)dfeat, grad_table, n, n_dev);
+            PERF_LAUNCH_CHECK("perf_hashgrid_bwd(atomics)");
+        }
     } else if (tp.atomic_levels && !accumulate) {
         for (int l = 0; l < gp.n_levels; ++l)
             if ((tp.atomic_levels >> l) & 1u) (void)hipMemsetAsync(grad_table + 2 * gp.offset[l], 0, (size_t)gp.size[l] * 2 * sizeof(float), as_stream(stream));
     }
-    const bool adapt = level_absmax && headroom_state && n_blocks > 0;
+    const bool adapt = level_absmax && headroom_state && (n_blocks > 0 || (tp.atomic_levels && n > 0 && !accumulate));
     if (ws_entries > 0 || adapt) {      // (+ one row of blocks for the headroom feedback)
         hashgrid_bwd_reduce_kernel<<<dim3(64, gp.n_levels + 1), dim3(256), 0, as_stream(stream)>>>(
             gp, tp, (const float2*)workspace, (float2*)grad_table, adapt ? headroom_state : nullptr);

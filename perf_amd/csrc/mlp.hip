@@ -47,11 +47,12 @@ struct Layout {
     static constexpr int f_a2 = 2 * KS;
     static constexpr int f_ao = f_a2 + (NH == 2 ? 8 : 0);
     static constexpr int n_fwd = f_ao + 4;
-    // backward (transposed) fragments: AoT[m] (2), A2T[m][s] (8 if NH==2), A1T[s] (4)
+    // backward (transposed) fragments: AoT[m] (2), A2T[m][s] (8 if NH==2), A1T[mb][s] (4 per block of 32 input features)
+    static constexpr int MB = (n_in_pad + 31) / 32;
     static constexpr int f_aot = n_fwd;
     static constexpr int f_a2t = f_aot + 2;
     static constexpr int f_a1t = f_a2t + (NH == 2 ? 8 : 0);
-    static constexpr int n_all = f_a1t + 4;
+    static constexpr int n_all = f_a1t + 4 * MB;
 };
 
 __device__ __forceinline__ u32x4 pack8(const uint16_t v[8]) {
@@ -93,11 +94,12 @@ __device__ __forceinline__ void stage_fragments(const uint16_t* __restrict__ w, 
             const int m = (f - L::f_a2t) >> 2, s = (f - L::f_a2t) & 3;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = w[L::w2_off + slot_neuron(s, h, j) * 64 + 32 * m + c];
-        } else {                                 // A1T[s]: row = input feature c, slot -> neuron
-            const int s = f - L::f_a1t;
+        } else {                                 // A1T[mb][s]: row = input feature 32*mb + c, slot -> neuron
+            const int mb = (f - L::f_a1t) >> 2, s = (f - L::f_a1t) & 3;
+            const int in = 32 * mb + c;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                v[j] = (c < L::n_in_pad) ? w[L::w1_off + slot_neuron(s, h, j) * L::n_in_pad + c] : (uint16_t)0;
+                v[j] = (in < L::n_in_pad) ? w[L::w1_off + slot_neuron(s, h, j) * L::n_in_pad + in] : (uint16_t)0;
         }
         lds[f * 64 + lane] = pack8(v);
     }
@@ -243,7 +245,7 @@ __device__ __forceinline__ void pack_masked(const f32x16& acc, uint32_t mask_bit
 }
 
 template <typename T16, int NH, int KS>
-__global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
+__global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
                                                       const uint32_t* __restrict__ feat,
                                                       const uint8_t* __restrict__ sel,
                                                       const float* __restrict__ dout, float2* __restrict__ dfeat,
@@ -262,9 +264,12 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams
     const int c = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (n_live + kTile - 1) / kTile;
 
-    f32x16 gW1[2], gWo[2], gW2[NH == 2 ? 4 : 1];
+    constexpr int MB = L::MB;       // blocks of 32 input features (2 for grids of more than 16 levels)
+    f32x16 gW1[2 * MB], gWo[2], gW2[NH == 2 ? 4 : 1];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) { gW1[m] = f32x16{0}; gWo[m] = f32x16{0}; }
+    for (int m = 0; m < 2 * MB; ++m) gW1[m] = f32x16{0};
+#pragma unroll
+    for (int m = 0; m < 2; ++m) gWo[m] = f32x16{0};
 #pragma unroll
     for (int m = 0; m < (NH == 2 ? 4 : 1); ++m) gW2[m] = f32x16{0};
 
@@ -377,16 +382,19 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams
         }
         // ---- dX = W1^T dH1 (rows = input features in natural order 2*level+feat)
         if (dfeat != nullptr) {
-            f32x16 dx = f32x16{0};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) dx = T16::mfma(frag[(L::f_a1t + s) * 64 + lane], dh1[s], dx);
-            if (valid) {
+            for (int mb = 0; mb < MB; ++mb) {
+                f32x16 dx = f32x16{0};
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {      // register pair (2q,2q+1) -> level d_row(2q,h)/2
-                    const int level = d_row(2 * q, h) >> 1;
-                    if (level < mp.n_levels) {
-                        dfeat[(int64_t)level * n + si] = make_float2(dx[2 * q], dx[2 * q + 1]);
-                        amax = fmaxf(amax, fmaxf(fabsf(dx[2 * q]), fabsf(dx[2 * q + 1])));
+                for (int s = 0; s < 4; ++s) dx = T16::mfma(frag[(L::f_a1t + 4 * mb + s) * 64 + lane], dh1[s], dx);
+                if (valid) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {      // register pair (2q,2q+1) -> level 16*mb + d_row(2q,h)/2
+                        const int level = 16 * mb + (d_row(2 * q, h) >> 1);
+                        if (level < mp.n_levels) {
+                            dfeat[(int64_t)level * n + si] = make_float2(dx[2 * q], dx[2 * q + 1]);
+                            amax = fmaxf(amax, fmaxf(fabsf(dx[2 * q]), fabsf(dx[2 * q + 1])));
+                        }
                     }
                 }
             }
@@ -404,11 +412,13 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams
             }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x4 b = (c < L::n_in_pad) ? lds_get_frag(tB, c, s, h) : u32x4{0, 0, 0, 0};
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) gW1[m] = T16::mfma(lds_get_frag(tA, 32 * m + c, s, h), b, gW1[m]);
-        }
+            for (int nb = 0; nb < MB; ++nb) {
+                u32x4 b = (32 * nb + c < L::n_in_pad) ? lds_get_frag(tB, 32 * nb + c, s, h) : u32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int m = 0; m < 2; ++m) gW1[m * MB + nb] = T16::mfma(lds_get_frag(tA, 32 * m + c, s, h), b, gW1[m * MB + nb]);
+            }
     }
     // ---- per-level max |dfeat| (feeds the fixed-point scale of the grid backward): lanes of one half-wave hold the
     //      same 8 levels, non-negative floats order like their bit patterns
@@ -422,31 +432,40 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams
     //      then ONE partial per block -> global (summed by mlp_reduce_kernel)
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
-    constexpr int kAcc = 2 + 2 + (NH == 2 ? 4 : 0);          // f32x16 accumulators per lane
+    constexpr int kW1 = 2 * MB;
+    constexpr int kAcc = kW1 + 2 + (NH == 2 ? 4 : 0);        // f32x16 accumulators per lane
     for (int src = 1; src < 4; ++src) {
         if (wave == src) {
 #pragma unroll
+            for (int m = 0; m < kW1; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((m) * 16 + r) * 64 + lane] = gW1[m][r];
+#pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { red[((m) * 16 + r) * 64 + lane] = gW1[m][r]; red[((2 + m) * 16 + r) * 64 + lane] = gWo[m][r]; }
+                for (int r = 0; r < 16; ++r) red[((kW1 + m) * 16 + r) * 64 + lane] = gWo[m][r];
             if constexpr (NH == 2) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) red[((4 + m) * 16 + r) * 64 + lane] = gW2[m][r];
+                    for (int r = 0; r < 16; ++r) red[((kW1 + 2 + m) * 16 + r) * 64 + lane] = gW2[m][r];
             }
         }
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
+            for (int m = 0; m < kW1; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gW1[m][r] += red[((m) * 16 + r) * 64 + lane];
+#pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { gW1[m][r] += red[((m) * 16 + r) * 64 + lane]; gWo[m][r] += red[((2 + m) * 16 + r) * 64 + lane]; }
+                for (int r = 0; r < 16; ++r) gWo[m][r] += red[((kW1 + m) * 16 + r) * 64 + lane];
             if constexpr (NH == 2) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) gW2[m][r] += red[((4 + m) * 16 + r) * 64 + lane];
+                    for (int r = 0; r < 16; ++r) gW2[m][r] += red[((kW1 + 2 + m) * 16 + r) * 64 + lane];
             }
         }
         __syncthreads();
@@ -457,10 +476,12 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void mlp_bwd_kernel(MlpParams
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * m + d_row(r, h);
-            if (c < L::n_in_pad) p[L::w1_off + row * L::n_in_pad + c] = gW1[m][r];
-        }
+        for (int nb = 0; nb < MB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + d_row(r, h);
+                if (32 * nb + c < L::n_in_pad) p[L::w1_off + row * L::n_in_pad + 32 * nb + c] = gW1[m * MB + nb][r];
+            }
     if constexpr (NH == 2) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -551,8 +572,9 @@ static int n_params_rt(int nh, int ks) {
     return ks == 1 ? n_params_of<2, 1>() : (ks == 2 ? n_params_of<2, 2>() : n_params_of<2, 3>());
 }
 
-// backward workgroups per CU: the one-hidden-layer kernel fits 2 waves per SIMD (<= 256 registers), the two-layer one 1
-static inline int bwd_blocks_per_cu(int nh) { return nh == 1 ? 2 : 1; }
+// backward workgroups per CU: the one-hidden-layer kernel fits 2 waves per SIMD (<= 256 registers) for up to 16 levels,
+// the two-layer one and the 17..24-level variants (two more accumulator tiles for dW1) 1
+static inline int bwd_blocks_per_cu(int nh, int ks) { return (nh == 1 && ks < 3) ? 2 : 1; }
 
 }  // namespace perf
 
@@ -590,9 +612,11 @@ static void dispatch_fwd(int nh, int ks, Args... a) {
 template <typename T16, typename... Args>
 static void dispatch_bwd(int nh, int ks, Args... a) {
     if (nh == 1 && ks == 1) launch_bwd<T16, 1, 1>(a...);
-    else if (nh == 1) launch_bwd<T16, 1, 2>(a...);
+    else if (nh == 1 && ks == 2) launch_bwd<T16, 1, 2>(a...);
+    else if (nh == 1) launch_bwd<T16, 1, 3>(a...);
     else if (ks == 1) launch_bwd<T16, 2, 1>(a...);
-    else launch_bwd<T16, 2, 2>(a...);
+    else if (ks == 2) launch_bwd<T16, 2, 2>(a...);
+    else launch_bwd<T16, 2, 3>(a...);
 }
 
 extern "C" int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
@@ -615,8 +639,8 @@ extern "C" int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const voi
 
 extern "C" int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n) {
     int nh, ks;
-    if (check_mlp(mlp, &nh, &ks) || ks > 2) return -1;
-    const int blocks = mlp_blocks(n > 0 ? n : 1, bwd_blocks_per_cu(nh));
+    if (check_mlp(mlp, &nh, &ks)) return -1;
+    const int blocks = mlp_blocks(n > 0 ? n : 1, bwd_blocks_per_cu(nh, ks));
     return ((int64_t)blocks * n_params_rt(nh, ks) + (int64_t)blocks * 8) * (int64_t)sizeof(float);
 }
 
@@ -626,7 +650,6 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
     int nh, ks;
     int rc = check_mlp(mlp, &nh, &ks);
     if (rc) return rc;
-    PERF_REQUIRE(ks <= 2, "perf_mlp_bwd: more than 16 levels (%d) are supported by the forward kernels only", (int)mlp->n_levels);
     PERF_REQUIRE(w16 && dw && workspace, "NULL pointer");
     PERF_REQUIRE(dtype == PERF_DTYPE_BF16 || dtype == PERF_DTYPE_FP16, "bad dtype %d", dtype);
     const int np = n_params_rt(nh, ks);
@@ -640,7 +663,7 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
     const int64_t need = perf_mlp_bwd_workspace_bytes(mlp, n);
     PERF_REQUIRE(workspace_bytes >= need, "perf_mlp_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     MlpParams mp{mlp->n_levels, mlp->n_out, mlp->out_act, mlp->exp_shift};
-    const int blocks = mlp_blocks(n, bwd_blocks_per_cu(nh));
+    const int blocks = mlp_blocks(n, bwd_blocks_per_cu(nh, ks));
     float* amax_slots = level_absmax ? (float*)workspace + (int64_t)blocks * np : nullptr;
     if (dtype == PERF_DTYPE_BF16)
         dispatch_bwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,

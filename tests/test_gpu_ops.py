@@ -218,6 +218,34 @@ def test_mlp_bwd(ops, dt, nh, n_out, act):
     assert close(dw.cpu(), wr.grad, 16), ((dw.cpu() - wr.grad).abs().max(), wr.grad.abs().max())
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('nh,n_out,act,n_levels', [(1, 1, 'Exponential', 20), (2, 3, 'Sigmoid', 20), (1, 1, 'None', 24), (2, 16, 'None', 17)])
+def test_mlp_more_than_16_levels(ops, dt, nh, n_out, act, n_levels):
+    """BASELINE config 5 trains L = 20 grids: 40 (up to 48) input features = three k-steps forward and two 32-row blocks of
+    dX / dW1 backward.  Same bars as test_mlp_fwd / test_mlp_bwd, plus the per-half level maxima the grid backward scales by."""
+    cfgm, w, feat, sel, tdt, ulp = _mlp_case(ops, dt, nh, n_out, act, n=3000 + 5, n_levels=n_levels, seed=11)
+    w16 = w.to(tdt); f16 = feat.to(tdt)
+    out = ops.mlp_fwd(cfgm, w16.cuda(), f16.cuda(), sel.cuda()).cpu()
+    ref = _mlp_oracle(cfgm, w16.float(), f16.float(), sel, dt)
+    assert (out - ref).abs().max() < 8 * ulp * max(1.0, float(ref.abs().max()))
+    g = torch.Generator().manual_seed(12)
+    dout = torch.randn(feat.shape[1], n_out, generator=g)
+    dfeat, dw, amax = ops.mlp_bwd(cfgm, w16.cuda(), f16.cuda(), dout.cuda(), sel.cuda(), want_absmax=True)
+    wr = w16.float().requires_grad_(True)
+    fr = f16.float().requires_grad_(True)
+    (_mlp_oracle(cfgm, wr, fr, sel, dt) * dout).sum().backward()
+
+    def close(a, b, k):
+        return (a - b).abs().max() <= k * ulp * float(b.abs().max()) + 1e-6
+    assert dfeat.shape == (n_levels, feat.shape[1], 2) and dw.shape == wr.grad.shape
+    assert close(dfeat.cpu(), fr.grad, 16), ((dfeat.cpu() - fr.grad).abs().max(), fr.grad.abs().max())
+    assert close(dw.cpu(), wr.grad, 16), ((dw.cpu() - wr.grad).abs().max(), wr.grad.abs().max())
+    # level l's bound is the maximum over the levels its half-wave owns ((l >> 1) & 1): never below the level's own maximum
+    own = dfeat.abs().amax(dim=(1, 2))
+    assert bool((amax[:n_levels] >= own).all()) and float(amax[n_levels:].abs().sum()) == 0.0
+    assert float(amax.max()) == float(own.max())
+
+
 def test_cast_and_adam(ops):
     g = torch.Generator().manual_seed(9)
     n = 100003
@@ -574,6 +602,9 @@ def test_hashgrid_bwd_large_levels_take_the_atomics_path(ops):
                     w = w * (f[:, a] if (c >> a) & 1 else (np.float32(1) - f[:, a]))
                 np.add.at(ref, idx[:, c].astype(np.int64) + int(lv.offset[l]), w[:, None].astype(np.float64) * dfeat[l].numpy())
         assert np.abs(grad - ref).max() < 2e-4 * np.abs(ref).max()
+        if fixed:       # 64-bit fixed-point global atomics: the sum does not depend on the order they retire in
+            again = ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), level_absmax=amax).cpu().numpy().reshape(-1, 2)
+            assert np.array_equal(grad, again)
         # accumulate adds on top
         acc = torch.from_numpy(grad.reshape(-1).copy()).cuda()
         ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), out=acc, accumulate=True, level_absmax=amax)

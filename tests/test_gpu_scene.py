@@ -715,3 +715,34 @@ def test_reprojection_and_morphology_kernels_match_torch_formulation():
         a = V.geo_check(rays.o, rays.d, d[..., None], pool.sup_infos)
         b = V.geo_check(rays.o, rays.d, d[..., None], pool.sup_infos, use_kernels=False)
         assert float((a != b).float().mean()) < 0.01
+
+
+@pytest.mark.parametrize('nh,n_out,act', [(1, 1, 'None'), (2, 3, 'Sigmoid')])
+def test_network_with_20_level_grid_forward_and_gradient(nh, n_out, act):
+    """BASELINE config 5's field shape (L = 20 levels -> 40 input features) through tcnn.NetworkWithInputEncoding: output and
+    the flat [network | grid] gradient against the oracle's 16-bit emulation -- the MLP backward's second 32-feature block
+    and the grid backward at 20 levels."""
+    from perf_amd import tcnn
+    dtype = 'fp16'
+    enc = {"otype": "HashGrid", "n_levels": 20, "n_features_per_level": 2, "log2_hashmap_size": 15, "base_resolution": 16,
+           "per_level_scale": 1.3}
+    net_cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act, "n_neurons": 64, "n_hidden_layers": nh}
+    net = tcnn.NetworkWithInputEncoding(3, n_out, enc, net_cfg, dtype=dtype)
+    spec = O.FieldSpec(O.grid_levels(n_levels=20, log2_hashmap_size=15, base_resolution=16, per_level_scale=1.3), nh, n_out, act)
+    assert net.params.numel() == spec.n_params
+    g = torch.Generator().manual_seed(21)
+    p0 = O.init_field_params(spec, seed=3)
+    p0[spec.n_net:] *= 3000.0                                    # features of order 0.3: every level matters to the output
+    with torch.no_grad():
+        net.params.copy_(p0.cuda())
+    n = 1500
+    x = torch.rand(n, 3, generator=g) * 0.98 + 0.01
+    dout = torch.randn(n, n_out, generator=g)
+    y = net(x.cuda(), out_fp32=True)
+    (y * dout.cuda()).sum().backward()
+    pr = p0.clone().requires_grad_(True)
+    yr = O.network_with_encoding(x, pr, spec, quant=dtype)
+    (yr * dout).sum().backward()
+    ulp = 2.0 ** -10
+    assert float((y.detach().cpu() - yr.detach()).abs().max()) < 16 * ulp * max(1.0, float(yr.abs().max()))
+    _assert_field_gradient_close(net.params.grad.cpu(), pr.grad, spec)

@@ -14,11 +14,14 @@ from perf_amd import ops
 from perf_amd.grid import GridConfig, MlpConfig
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--log2', type=int, nargs='+', default=[26, 28, 30])
+ap.add_argument('--log2', type=int, nargs='*', default=[26, 28, 30])
 ap.add_argument('--rays', type=int, default=16384)
 ap.add_argument('--spp', type=int, default=256)
 ap.add_argument('--batches', type=int, default=8)
 ap.add_argument('--levels', type=int, default=20)
+ap.add_argument('--train-log2', type=int, nargs='*', default=[],
+                help='also time a TRAINING step of the density field (fp32 master + Adam state + 16-bit copy: 18 B per '
+                     'parameter) at these table sizes: encode, 40->64->1 MLP forward/backward, grid backward, fused Adam')
 args = ap.parse_args()
 dev = 'cuda'
 H, W = 2048, 4096
@@ -89,6 +92,42 @@ for T in args.log2:
                     'opacity_mean': float(res[3].mean())}
     print(json.dumps({f'T{T}': out[f'T{T}']}, indent=1), flush=True)
     del tg, ta
+    torch.cuda.empty_cache()
+for T in args.train_log2:
+    # one trainable L-level density field: the tcnn-layout module, its explicit backward and the fused Adam -- the pieces a
+    # rank of the level-sharded encoder (perf_amd/sharded.py) runs on its slice of the levels
+    from perf_amd import tcnn
+    from perf_amd.scene import FusedAdam
+    enc = {"otype": "HashGrid", "n_levels": L, "n_features_per_level": 2, "log2_hashmap_size": T, "base_resolution": 16, "per_level_scale": b}
+    net = tcnn.NetworkWithInputEncoding(3, 1, enc, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                                                   "n_neurons": 64, "n_hidden_layers": 1}, dtype='fp16')
+    opt = FusedAdam(net, 1e-3)
+    n = 1 << 20
+    x = torch.rand(n, 3, device=dev) * 0.98 + 0.01
+    dout = torch.randn(n, 1, device=dev) * 1e-3
+
+    def step():
+        y = net(x, out_fp32=True)
+        y.backward(dout)
+        opt.step()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    ops.start_kernel_timing()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / reps
+    kern = ops.stop_kernel_timing()
+    out[f'train_T{T}'] = {'levels': L, 'params': int(net.params.numel()), 'state_GiB': round(net.params.numel() * 18 / 2 ** 30, 2),
+                          'samples_per_step': n, 'ms_per_step': round(t * 1e3, 3), 'samples_per_s': n / t,
+                          'grid_gradient_mode': tcnn.GRID_GRAD_ACCUM,
+                          'kernel_ms_per_step': {k_: round(c * ms / reps, 3) for k_, (c, ms) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])}}
+    print(json.dumps({f'train_T{T}': out[f'train_T{T}']}, indent=1), flush=True)
+    del net, opt
     torch.cuda.empty_cache()
 os.makedirs('gpurun_out', exist_ok=True)
 json.dump(out, open('gpurun_out/config5.json', 'w'), indent=1)
