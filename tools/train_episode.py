@@ -13,9 +13,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--geo', type=int, default=3000)
 ap.add_argument('--app', type=int, default=1500)
 ap.add_argument('--dtype', default='bf16')
+ap.add_argument('--head', type=int, default=-1, help='renderer.head_samples for the run (0 = one-phase sampler; default: the renderer default)')
 args = ap.parse_args()
 torch.manual_seed(0)
 scene = NeRFScene(dtype=args.dtype)
+if args.head >= 0:
+    scene.renderer.head_samples = args.head or None
 H, W = 1024, 2048
 rays = gen_pano_rays(torch.eye(4), H, W)
 dist, rgb = synthetic.room(rays.d)
