@@ -19,11 +19,10 @@ Parity status
   test or golden vector for them.
 
 Where this restatement DEFINES a rounding order that upstream plausibly does differently
-(neither is checkable here; both would change ray_indices / t_starts against the real packages):
-* grid position: pos = fl(fl(x*scale) + 0.5), two roundings (grid_corner_indices); tiny-cuda-nn's
-  kernel_grid computes it with one fused multiply-add, fmaf(scale, x, 0.5).  A position within half an
-  ulp of a cell boundary can land in the neighbouring cell under the other rule (interpolation is
-  continuous across the boundary, so feature values differ by O(ulp); the touched-entry set differs).
+(not checkable here; it would change ray_indices / t_starts against the real packages):
+* (grid position: follows tiny-cuda-nn -- ONE rounding, fmaf(scale, x, 0.5), see grid_pos; rounds 1-2 of this
+  repository used fl(fl(x*scale) + 0.5), under which a position within half an ulp of a cell boundary could land in
+  the neighbouring cell.)
 * marching lattice: t_k = fl(t0 + fl(k*step)) on ONE global lattice per ray anchored at the near plane
   (+ stratified jitter), an interval being emitted iff its midpoint lies in an occupied cell (occ_march,
   SURVEY.md A.3).  nerfacc's traverse_grids advances by repeated float addition and, after skipping
@@ -35,9 +34,9 @@ Where this restatement DEFINES a rounding order that upstream plausibly does dif
 
 Conventions
 -----------
-All bookkeeping arithmetic (lattice times, cell indices, hash indices, scans that
-feed a threshold) is defined with *unfused* IEEE fp32 multiplies and adds so that
-numpy and the HIP kernels (built with explicit __fmul_rn/__fadd_rn) agree bit for bit.
+All bookkeeping arithmetic (lattice times, cell indices, scans that feed a threshold) is defined with
+*unfused* IEEE fp32 multiplies and adds so that numpy and the HIP kernels (built with explicit
+__fmul_rn/__fadd_rn) agree bit for bit; the one fused operation is the grid position (grid_pos).
 """
 from __future__ import annotations
 
@@ -142,13 +141,30 @@ def _quant(t: torch.Tensor, quant):
     return t.to(dt).to(torch.float32)
 
 
+def grid_pos(x: np.ndarray, scale) -> np.ndarray:
+    """pos = fl32(x*scale + 0.5) with ONE rounding: tiny-cuda-nn's pos_fract computes fmaf(scale, input, 0.5f).
+    numpy has no fma: the product of two fp32 is exact in fp64, the sum is formed in fp64 with its rounding error e
+    (TwoSum), and the one case where rounding twice differs from rounding once -- the fp64 sum sits exactly half way
+    between two fp32 neighbours while e != 0 -- is resolved by the sign of e."""
+    p = np.asarray(x, F32).astype(np.float64) * np.float64(F32(scale))
+    s = p + 0.5
+    bb = s - p
+    e = (p - (s - bb)) + (0.5 - bb)                       # s + e == p + 0.5 exactly
+    r = s.astype(F32)
+    d = s - r.astype(np.float64)                          # exact
+    toward = np.where(d > 0, np.inf, -np.inf).astype(F32)
+    nb = np.nextafter(r, toward)
+    tie = (d != 0) & (2.0 * d == (nb.astype(np.float64) - r.astype(np.float64)))
+    return np.where(tie & (e * d > 0), nb, r).astype(F32)
+
+
 def grid_corner_indices(x: np.ndarray, lv: GridLevels, level: int):
     """Bit-exact integer bookkeeping of one level: returns (idx u32 [N,8], frac f32 [N,3]).
-    pos = x*scale + 0.5 (unfused fp32); g = floor(pos); corner c: bit0->x, bit1->y, bit2->z.
+    pos = fma(x, scale, 0.5) (grid_pos); g = floor(pos); corner c: bit0->x, bit1->y, bit2->z.
     dense: (gx + gy*res + gz*res^2) mod 2^32 mod size; hashed: gx ^ gy*P1 ^ gz*P2 (uint32) mod size."""
     x = np.ascontiguousarray(x, F32)
     s = lv.scale[level]
-    pos = (x * s).astype(F32) + F32(0.5)
+    pos = grid_pos(x, s)
     g = np.floor(pos)
     frac = (pos - g).astype(F32)
     gi = g.astype(np.int64) & U32_MASK
@@ -180,6 +196,7 @@ def hashgrid_encode(x: torch.Tensor, table: torch.Tensor, lv: GridLevels,
         idx_all.append(torch.from_numpy(idx_np.astype(np.int64)) + int(lv.offset[l]))
         s = float(lv.scale[l])
         pos = x * s + 0.5
+        pos = pos + (torch.from_numpy(grid_pos(xn, lv.scale[l])) - pos).detach()      # value of the fma, gradient s
         f = pos - torch.floor(pos).detach()
         if interpolation == 'Smoothstep':
             f = f * f * (3.0 - 2.0 * f)

@@ -44,8 +44,11 @@ constexpr int kHeadroomStartBias = 3;
 constexpr uint32_t kPrimeY = 2654435761u;
 constexpr uint32_t kPrimeZ = 805459861u;
 
+// Grid position of a coordinate: ONE rounding, pos = fl(x*scale + 0.5), as tiny-cuda-nn's pos_fract computes it
+// (fmaf(scale, input, 0.5f)); oracle/perf_oracle.py:grid_pos restates the same rounding for numpy.
+__device__ __forceinline__ float grid_pos(float x, float scale) { return __builtin_fmaf(x, scale, 0.5f); }
+
 // Corner bookkeeping of one (sample, level): 8 table indices + fractional position.
-// pos = fl(fl(x*scale)+0.5) (unfused, matches oracle/perf_oracle.py:grid_corner_indices).
 struct Corners {
     uint32_t idx[8];
     float f[3];
@@ -54,9 +57,9 @@ struct Corners {
 __device__ __forceinline__ Corners corners_of(float x, float y, float z, float scale, uint32_t res,
                                               uint32_t size, bool hashed) {
     Corners c;
-    float px = add_rn(mul_rn(x, scale), 0.5f);
-    float py = add_rn(mul_rn(y, scale), 0.5f);
-    float pz = add_rn(mul_rn(z, scale), 0.5f);
+    float px = grid_pos(x, scale);
+    float py = grid_pos(y, scale);
+    float pz = grid_pos(z, scale);
     float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
     c.f[0] = px - flx; c.f[1] = py - fly; c.f[2] = pz - flz;
     uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
@@ -423,7 +426,7 @@ template <bool FIXED, bool HASHED>
 __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, const float2 g, const float x, const float y,
                                           const float z) {
     unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
-    const float px = add_rn(mul_rn(x, cx.scale), 0.5f), py = add_rn(mul_rn(y, cx.scale), 0.5f), pz = add_rn(mul_rn(z, cx.scale), 0.5f);
+    const float px = grid_pos(x, cx.scale), py = grid_pos(y, cx.scale), pz = grid_pos(z, cx.scale);
     const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
     float fx = px - flx, fy = py - fly, fz = pz - flz;
     const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
@@ -509,9 +512,9 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
         for (int l = 0; l < gp.n_levels; ++l) {
             const int slot = tp.code_slot[l];
             if (slot < 0) continue;
-            const float py = add_rn(mul_rn(y, gp.scale[l]), 0.5f), pz = add_rn(mul_rn(z, gp.scale[l]), 0.5f);
+            const float py = grid_pos(y, gp.scale[l]), pz = grid_pos(z, gp.scale[l]);
             const uint32_t gy = (uint32_t)(int32_t)floorf(py), gz = (uint32_t)(int32_t)floorf(pz);
-            const uint32_t gx = (uint32_t)(int32_t)floorf(add_rn(mul_rn(x, gp.scale[l]), 0.5f));
+            const uint32_t gx = (uint32_t)(int32_t)floorf(grid_pos(x, gp.scale[l]));
             uint32_t code = 0u;
             bool bad;       // the premise of the code does not hold for this sample
             if (gp.hashed[l]) {
@@ -620,7 +623,7 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
         const uint32_t rest = DENSE ? 0u : bcm & (bcm - 1u);        // (dense tiles are named by several combinations as a rule)
         if (!DENSE) bcm &= 0u - bcm;
         if (bcm) {
-            const float px = add_rn(mul_rn(bx, cx.scale), 0.5f), py = add_rn(mul_rn(byz.x, cx.scale), 0.5f), pz = add_rn(mul_rn(byz.y, cx.scale), 0.5f);
+            const float px = grid_pos(bx, cx.scale), py = grid_pos(byz.x, cx.scale), pz = grid_pos(byz.y, cx.scale);
             const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
             const uint32_t gx = (uint32_t)(int32_t)flx;
             if (DENSE)

@@ -303,6 +303,8 @@ class Encoding(nn.Module):
         idx = ops.hashgrid_corners(g, x.detach()).long()                       # [L, n, 8]
         scale = torch.as_tensor(g.scale, device=x.device)[:, None, None]       # [L, 1, 1]
         pos = x[None] * scale + 0.5                                            # [L, n, 3]
+        # value of the kernels' single-rounding fmaf(x, scale, 0.5) (through float64), gradient of the plain expression
+        pos = pos + ((x.detach()[None].double() * scale.double() + 0.5).float() - pos).detach()
         f = pos - torch.floor(pos).detach()
         if g.interpolation == 'Smoothstep':
             f = f * f * (3.0 - 2.0 * f)

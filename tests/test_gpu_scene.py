@@ -420,11 +420,10 @@ def spec_net_params(spec):
 
 
 def _pad_net(params, spec):
-    """The product stores the first layer with its input width padded to 16 (tcnn layout); the oracle's MLP takes
-    the unpadded 10 inputs: drop the padded columns."""
-    n_in = spec.lv.n_levels * 2
-    w1 = params[:64 * 16].view(64, 16)[:, :n_in].reshape(-1)
-    return torch.cat([w1, params[64 * 16:]])
+    """The product stores the first layer with its input width padded to 16 (tcnn layout); the oracle's FieldSpec has the
+    same layout (spec.n_in), so the parameter vector is shared as it is."""
+    assert params.numel() == spec.n_params
+    return params
 
 
 def test_encoding_double_backward():
