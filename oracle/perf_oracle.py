@@ -25,10 +25,13 @@ Where this restatement DEFINES a rounding order that upstream plausibly does dif
   the neighbouring cell.)
 * marching lattice: t_k = fl(t0 + fl(k*step)) on ONE global lattice per ray anchored at the near plane
   (+ stratified jitter), an interval being emitted iff its midpoint lies in an occupied cell (occ_march,
-  SURVEY.md A.3).  nerfacc's traverse_grids advances by repeated float addition and, after skipping
-  empty space, restarts its intervals at the cell entry, so its t_starts are not lattice points of a
-  single lattice once a ray has crossed an empty cell.  Sample COUNTS per occupied span agree to +-1;
-  positions differ by < step.
+  SURVEY.md A.3).  nerfacc's traverse_grids advances by REPEATED float addition (t_last += dt), so its
+  t_k carry the accumulated rounding of k additions (<= k/2 ulp, ~1e-6 after 3,000 steps of 5e-4) where
+  this lattice rounds once; and whether it keeps stepping on the same lattice through empty cells (our
+  recollection of v0.5.3: "march until t_mid is right after t_traverse") or restarts its intervals at
+  the cell entry cannot be checked here.  Under the first reading sample counts agree and t_starts
+  differ by O(k ulp); under the second, counts per occupied span agree to +-1 and positions differ by
+  < step.
 * early termination: thresholded on the canonical-order exclusive sum (ex <= -ln eps) instead of on
   T = exp(-ex) >= eps (identical decision up to the rounding of exp).
 
