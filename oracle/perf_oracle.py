@@ -146,19 +146,24 @@ def _quant(t: torch.Tensor, quant):
 
 def grid_pos(x: np.ndarray, scale) -> np.ndarray:
     """pos = fl32(x*scale + 0.5) with ONE rounding: tiny-cuda-nn's pos_fract computes fmaf(scale, input, 0.5f).
-    numpy has no fma: the product of two fp32 is exact in fp64, the sum is formed in fp64 with its rounding error e
-    (TwoSum), and the one case where rounding twice differs from rounding once -- the fp64 sum sits exactly half way
-    between two fp32 neighbours while e != 0 -- is resolved by the sign of e."""
+    numpy has no fma: the product of two fp32 is exact in fp64 and the sum is formed in fp64; rounding that to fp32
+    differs from rounding the exact sum only if the fp64 sum sits exactly half way between two fp32 neighbours (its low
+    29 mantissa bits are 1000...0) while the fp64 addition was inexact -- those (rare) entries are resolved by the sign of
+    the addition's rounding error (TwoSum)."""
     p = np.asarray(x, F32).astype(np.float64) * np.float64(F32(scale))
     s = p + 0.5
-    bb = s - p
-    e = (p - (s - bb)) + (0.5 - bb)                       # s + e == p + 0.5 exactly
     r = s.astype(F32)
-    d = s - r.astype(np.float64)                          # exact
-    toward = np.where(d > 0, np.inf, -np.inf).astype(F32)
-    nb = np.nextafter(r, toward)
-    tie = (d != 0) & (2.0 * d == (nb.astype(np.float64) - r.astype(np.float64)))
-    return np.where(tie & (e * d > 0), nb, r).astype(F32)
+    cand = np.flatnonzero((s.view(np.int64) & 0x1FFFFFFF) == 0x10000000)
+    if cand.size:
+        pc, sc = p.reshape(-1)[cand], s.reshape(-1)[cand]
+        bb = sc - pc
+        e = (pc - (sc - bb)) + (0.5 - bb)                 # sc + e == pc + 0.5 exactly
+        rc = sc.astype(F32)
+        d = sc - rc.astype(np.float64)                    # +- half an fp32 gap (a tie, rounded to even)
+        nb = np.nextafter(rc, np.where(d > 0, np.inf, -np.inf).astype(F32))
+        r = r.copy()
+        r.reshape(-1)[cand] = np.where(e * d > 0, nb, rc)
+    return r
 
 
 def grid_corner_indices(x: np.ndarray, lv: GridLevels, level: int):
@@ -195,12 +200,10 @@ def hashgrid_encode(x: torch.Tensor, table: torch.Tensor, lv: GridLevels,
     xn = x.detach().cpu().numpy().astype(F32)
     idx_all, w_all = [], []
     for l in range(lv.n_levels):
-        idx_np, _ = grid_corner_indices(xn, lv, l)
+        idx_np, frac_np = grid_corner_indices(xn, lv, l)
         idx_all.append(torch.from_numpy(idx_np.astype(np.int64)) + int(lv.offset[l]))
         s = float(lv.scale[l])
-        pos = x * s + 0.5
-        pos = pos + (torch.from_numpy(grid_pos(xn, lv.scale[l])) - pos).detach()      # value of the fma, gradient s
-        f = pos - torch.floor(pos).detach()
+        f = torch.from_numpy(frac_np) + (x - x.detach()) * s        # value: the fma's fractional part; d/dx = scale
         if interpolation == 'Smoothstep':
             f = f * f * (3.0 - 2.0 * f)
         ws = []
