@@ -1,5 +1,5 @@
 """Dev tool: hashgrid_bwd (fixed point) on a bench-like batch: 8192 rays x 128 samples from the origin, gradients of a
-plausible dynamic range.  PERF_BWD_NO_MASKS=1 selects the byte-code owners for the hashed levels (A/B).
+plausible dynamic range.  PERF_BWD_NO_LISTS=1 selects the byte-code owners for the hashed levels (A/B).
 Run under `rocprofv3 --kernel-trace --stats --output-format csv` to split pre-pass / owners / reduce."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -33,5 +33,5 @@ a.record()
 for _ in range(30):
     run()
 b.record(); torch.cuda.synchronize()
-print(json.dumps({'PERF_BWD_NO_MASKS': os.environ.get('PERF_BWD_NO_MASKS', ''), 'ms_per_call': a.elapsed_time(b) / 30,
+print(json.dumps({'PERF_BWD_NO_LISTS': os.environ.get('PERF_BWD_NO_LISTS', ''), 'ms_per_call': a.elapsed_time(b) / 30,
                   'checksum': float(ref.double().abs().sum())}))
