@@ -75,6 +75,7 @@ class SupInfoPool:
         self.all_sup_normals = None
         self.n_panos = 0
         self.sup_infos = []            # per panorama: pose, distance_map [H,W,1], mask [H,W,1] (visibility tests)
+        self._ranges = []              # per registration: [start, end) in the flat arrays (rand_mode 'only_first' / 'only_last')
 
     def register_rays(self, rays_o, rays_d, colors, distances, normals=None):
         o = rays_o.reshape(-1, 3).contiguous().float(); d = rays_d.reshape(-1, 3).contiguous().float()
@@ -87,6 +88,7 @@ class SupInfoPool:
             self.all_sup_colors = torch.cat([self.all_sup_colors, c])
             self.all_sup_distances = torch.cat([self.all_sup_distances, t])
             self.all_sup_normals = torch.cat([self.all_sup_normals, n])
+        self._ranges.append((len(self) - len(c), len(self)))
         self.n_panos += 1
 
     def register_sup_info(self, pose, mask, rgb, distance, normal=None):
@@ -106,9 +108,11 @@ class SupInfoPool:
     def rand_ray_color_data(self, batch_size, rand_mode='by_all_pixels', generator=None, rank=0, world_size=1):
         """sup_info.py:236-259.  With world_size > 1 every rank draws the same `batch_size` indices and keeps
         the contiguous slice [rank*b/W, (rank+1)*b/W) -- the union is the 1-GPU batch."""
-        assert rand_mode == 'by_all_pixels'
-        n = len(self)
-        indices = torch.randint(0, n, (batch_size,), device=self.all_sup_colors.device, generator=generator)
+        assert rand_mode in ['by_all_pixels', 'only_first', 'only_last']
+        start, end = (0, len(self)) if rand_mode == 'by_all_pixels' else self._ranges[0 if rand_mode == 'only_first' else -1]
+        indices = torch.randint(0, end - start, (batch_size,), device=self.all_sup_colors.device, generator=generator)
+        if start:
+            indices = indices + start
         if world_size > 1:
             per = batch_size // world_size
             indices = indices[rank * per:(rank + 1) * per]
@@ -193,6 +197,7 @@ class NeRFScene:
         # so that bench.py times the reference's step (one ray-sample = BOTH fields evaluated).
         self.skip_unused_color = False
         self.overlap_comm = True       # DP: overlap the gradient all-reduce with the next step's prefetch
+        self.pixel_sup_rand_mode = 'by_all_pixels'     # what the reference passes everywhere (nerf.py:130,135)
         self.graph_steps = True        # train_one_episode replays hipGraph-captured steps when it can
         # DP payload of the gradient all-reduce: 'fp32' (exact sum, 26.6 MB) or 'bf16' (13.3 MB: every rank's gradient is
         # rounded to bf16 and summed in bf16 by RCCL -- ~2^-9 relative noise on a quantity Adam normalises anyway)
@@ -347,7 +352,8 @@ class NeRFScene:
     def _batch(self, sup_pool, generator=None):
         dist, rank, world = self._dist()
         bs = self.train_conf.pixel_loss_batch_size
-        rays, col, dep, nrm = sup_pool.rand_ray_color_data(bs, generator=generator, rank=rank, world_size=world)
+        rays, col, dep, nrm = sup_pool.rand_ray_color_data(bs, rand_mode=self.pixel_sup_rand_mode, generator=generator,
+                                                            rank=rank, world_size=world)
         return rays, col, dep, bs, (dist, rank, world)
 
     def _finish_step(self, loss, net, optimizer, dist_info, overlap=None):

@@ -745,3 +745,24 @@ def test_network_with_20_level_grid_forward_and_gradient(nh, n_out, act):
     ulp = 2.0 ** -10
     assert float((y.detach().cpu() - yr.detach()).abs().max()) < 16 * ulp * max(1.0, float(yr.abs().max()))
     _assert_field_gradient_close(net.params.grad.cpu(), pr.grad, spec)
+
+
+def test_supervision_sampling_modes():
+    """sup_info.py:236-259: 'by_all_pixels' draws over every registered ray, 'only_first' / 'only_last' over one panorama's."""
+    from perf_amd.scene import SupInfoPool, gen_pano_rays
+    pool = SupInfoPool()
+    for k, (h, w) in enumerate(((8, 16), (4, 8), (6, 12))):
+        rays = gen_pano_rays(torch.eye(4), h, w)
+        pool.register_rays(rays.o, rays.d, torch.full((h * w, 3), float(k), device='cuda'), torch.ones(h * w, 1, device='cuda'))
+    assert len(pool) == 128 + 32 + 72
+    g = torch.Generator(device='cuda')
+    for mode, want in (('only_first', {0.0}), ('only_last', {2.0}), ('by_all_pixels', {0.0, 1.0, 2.0})):
+        g.manual_seed(3)
+        _, col, _, _ = pool.rand_ray_color_data(4096, rand_mode=mode, generator=g)
+        assert set(col[:, 0].unique().tolist()) == want, mode
+    # the index stream of a mode is torch.randint(0, n_mode) of the same generator state, shifted to the panorama's range
+    g.manual_seed(3)
+    _, col_last, _, _ = pool.rand_ray_color_data(64, rand_mode='only_last', generator=g)
+    g.manual_seed(3)
+    idx = torch.randint(0, 72, (64,), device='cuda', generator=g) + 160
+    assert torch.equal(col_last, pool.all_sup_colors[idx])
