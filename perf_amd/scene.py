@@ -65,6 +65,19 @@ def default_train_conf():
         pixel_loss_batch_size=8192)
 
 
+def _edge_free(distance_map):
+    """PanoSupInfo's depth-edge test (sup_info.py:77-82): kornia.filters.laplacian(kernel 3, reflect border, normalised:
+    [[1,1,1],[1,-8,1],[1,1,1]] / 16), |.| < 0.01, erosion then dilation with a 3x3 box.  [H,W,1] -> bool [H,W,1]."""
+    from . import visibility as V
+    x = distance_map.permute(2, 0, 1)[None]
+    k = torch.ones(3, 3, device=x.device); k[1, 1] = -8.0
+    lap = F.conv2d(F.pad(x, (1, 1, 1, 1), mode='reflect'), (k / 16.0)[None, None])
+    e = (lap.abs() < 0.01).float()
+    box = torch.ones(3, 3, device=x.device)
+    e = V.dilate(V.erode(e, box), box)
+    return (e[0] > .5).permute(1, 2, 0)
+
+
 class SupInfoPool:
     """Supervision rays of all registered panoramas (sup_info.py:141-259, 304-330): flat device tensors."""
 
@@ -92,15 +105,54 @@ class SupInfoPool:
         self.n_panos += 1
 
     def register_sup_info(self, pose, mask, rgb, distance, normal=None):
-        """Panorama [H,W,*] maps -> supervision rays of the valid pixels (mask & distance > 1e-5)."""
+        """Panorama [H,W,*] maps -> supervision rays of its valid pixels, with PanoSupInfo's validity rules
+        (sup_info.py:27-120): mask > 0.5 and distance > 1e-5; no depth edge (|normalised 3x3 Laplacian of the distance map|
+        < 0.01, eroded then dilated by a 3x3 box); with a normal map, surfaces seen at cos > 0.15."""
         h, w, _ = rgb.shape
-        rays = gen_pano_rays(pose, h, w, device=rgb.device)
-        distance = distance.reshape(h, w, 1)
-        valid = (mask.reshape(h, w) > .5) & (distance[..., 0] > 1e-5)
-        self.sup_infos.append({'pose': torch.as_tensor(pose, dtype=torch.float32, device=rgb.device), 'distance_map': distance.float(),
-                               'mask': valid[..., None]})
-        idx = torch.where(valid)
-        self.register_rays(rays.o[idx], rays.d[idx], rgb[idx], distance[idx], None if normal is None else normal[idx])
+        dev = rgb.device
+        pose = torch.as_tensor(pose, dtype=torch.float32, device=dev)
+        distance = (torch.ones(h, w, 1, device=dev) if distance is None else distance.reshape(h, w, 1)).float()
+        has_normal = normal is not None
+        normal = normal.reshape(h, w, 3).float() if has_normal else torch.zeros(h, w, 3, device=dev)
+        mask_raw = (mask.reshape(h, w, 1) > .5) & (distance > 1e-5)
+        valid = mask_raw & _edge_free(distance)
+        if has_normal:
+            local = gen_pano_rays(torch.eye(4), h, w, device=dev)
+            valid = valid & (((-local.d) * normal).sum(-1, True).clip(0., 1.) > 0.15)
+        rays = gen_pano_rays(pose, h, w, device=dev)
+        idx = torch.where(valid[..., 0])
+        self.sup_infos.append({'pose': pose, 'height': h, 'width': w, 'mask_raw': mask_raw, 'color_map': rgb.float(),
+                               'distance_map': distance, 'normal_map': normal, 'mask': valid,
+                               'sup_colors': rgb[idx].float(), 'sup_distances': distance[idx], 'sup_normals': normal[idx],
+                               'sup_dirs': rays.d[idx], 'sup_positions': rays.o[idx]})
+        self.register_rays(rays.o[idx], rays.d[idx], rgb[idx], distance[idx], normal[idx] if has_normal else None)
+
+    def geo_check(self, rays, distances):
+        """sup_info.py:261-302: 1 = consistent with every registered panorama, 0 = conflict (perf_amd/visibility.py)."""
+        from .visibility import geo_check
+        return geo_check(rays.o, rays.d, distances, self.sup_infos)
+
+    _INFO_KEYS = ('pose', 'mask_raw', 'color_map', 'distance_map', 'normal_map', 'mask', 'sup_colors', 'sup_distances',
+                  'sup_normals', 'sup_dirs', 'sup_positions')         # PanoSupInfo's buffers, in registration order
+
+    def state_dict(self):
+        """sup_info.py:332-340, key for key (including its unformatted '{}' height / width keys)."""
+        ret = {'n_sup_infos': len(self.sup_infos)}
+        for i, info in enumerate(self.sup_infos):
+            ret['sup_info_{}_height'] = info['height']
+            ret['sup_info_{}_width'] = info['width']
+            ret['sup_info_{}'.format(i)] = {k: info[k] for k in self._INFO_KEYS}
+        return ret
+
+    def load_state_dict(self, state_dict):
+        """Restores what the reference's loader intends (sup_info.py:342-359 rebuilds placeholder PanoSupInfo objects and
+        never copies the saved buffers into them): every panorama's maps and supervision rays."""
+        self.__init__()
+        for i in range(state_dict['n_sup_infos']):
+            info = dict(state_dict['sup_info_{}'.format(i)])
+            info['height'], info['width'] = info['color_map'].shape[:2]
+            self.sup_infos.append(info)
+            self.register_rays(info['sup_positions'], info['sup_dirs'], info['sup_colors'], info['sup_distances'], info['sup_normals'])
 
     def __len__(self):
         return 0 if self.all_sup_colors is None else len(self.all_sup_colors)

@@ -510,9 +510,11 @@ def test_pano_visibility_mask_same_pose_is_visible():
     dist, rgb = synthetic.room(rays.d)
     pool = SupInfoPool()
     pool.register_sup_info(torch.eye(4), torch.ones(64, 128, 1, device='cuda'), rgb, dist)
-    assert len(pool) == 64 * 128 and len(pool.sup_infos) == 1
+    # (PanoSupInfo drops the pixels on depth edges -- the room's wall-to-wall creases at this resolution)
+    assert 0.5 * 64 * 128 < len(pool) <= 64 * 128 and len(pool.sup_infos) == 1
+    assert len(pool) == int(pool.sup_infos[0]['mask'].sum())
     vis = pano_visibility_mask(rays.o, rays.d, dist[..., 0], pool.sup_infos)
-    assert vis.shape == (64, 128) and float(vis.mean()) > 0.99
+    assert vis.shape == (64, 128) and float(vis[pool.sup_infos[0]['mask'][..., 0]].mean()) > 0.9
     # points pushed well behind the observed surface are occluded; points in front conflict with the geo check
     vis_far = pano_visibility_mask(rays.o, rays.d, dist[..., 0] * 1.5, pool.sup_infos)
     assert float(vis_far.mean()) < 0.01
@@ -766,3 +768,50 @@ def test_supervision_sampling_modes():
     g.manual_seed(3)
     idx = torch.randint(0, 72, (64,), device='cuda', generator=g) + 160
     assert torch.equal(col_last, pool.all_sup_colors[idx])
+
+
+def test_pano_sup_info_validity_rules_and_pool_state_dict(tmp_path):
+    """PanoSupInfo (sup_info.py:27-120): supervision skips masked pixels, zero distances, depth edges (normalised 3x3
+    Laplacian >= 0.01, cleaned by a 3x3 erosion + dilation) and -- with normals -- grazing surfaces; SupInfoPool.state_dict
+    keeps the reference's keys and load_state_dict restores the rays."""
+    from perf_amd.scene import SupInfoPool, gen_pano_rays, _edge_free
+    h, w = 32, 64
+    dist = torch.full((h, w, 1), 0.5, device='cuda')
+    dist[:, 40:] = 0.9                                   # a depth step between columns 39 | 40
+    dist[3, 5] = 0.0                                     # a hole
+    mask = torch.ones(h, w, 1, device='cuda'); mask[20:24, 10:14] = 0
+    rgb = torch.rand(h, w, 3, device='cuda')
+    ef = _edge_free(dist)[..., 0]
+    # restated by hand: |lap| with reflect padding, then opening by a 3x3 box
+    x = torch.nn.functional.pad(dist[..., 0][None, None], (1, 1, 1, 1), mode='reflect')
+    lap = (torch.nn.functional.avg_pool2d(x, 3, 1) * 9 - 9 * dist[..., 0][None, None]) / 16
+    smooth = (lap.abs() < 0.01)[0, 0]
+    er = ~(torch.nn.functional.max_pool2d((~smooth).float()[None, None], 3, 1, 1)[0, 0] > 0.5)       # erosion: borders do not erode
+    op = torch.nn.functional.max_pool2d(er.float()[None, None], 3, 1, 1)[0, 0] > 0.5
+    assert torch.equal(ef, op)
+    assert not bool(ef[:, 38:42].any()) and not bool(ef[3, 5]) and bool(ef[8:, 10:36].all())
+    pool = SupInfoPool()
+    pose = torch.eye(4); pose[:3, 3] = torch.tensor([0.1, 0.0, -0.05])
+    pool.register_sup_info(pose, mask, rgb, dist)
+    info = pool.sup_infos[0]
+    want = (mask[..., 0] > .5) & (dist[..., 0] > 1e-5) & ef
+    assert torch.equal(info['mask'][..., 0], want) and len(pool) == int(want.sum())
+    rays = gen_pano_rays(pose, h, w)
+    assert torch.equal(pool.all_sup_rays.d, rays.d[torch.where(want)]) and torch.equal(pool.all_sup_colors, rgb[torch.where(want)])
+    # normals: a surface facing the camera passes, a grazing one does not
+    local = gen_pano_rays(torch.eye(4), h, w)
+    facing = -local.d
+    tilted = torch.nn.functional.normalize(torch.cross(local.d, torch.tensor([0., 0., 1.], device='cuda').expand_as(local.d), dim=-1), dim=-1)
+    flat = torch.full((h, w, 1), 0.7, device='cuda')
+    p2 = SupInfoPool(); p2.register_sup_info(torch.eye(4), torch.ones(h, w, 1, device='cuda'), rgb, flat, facing)
+    p3 = SupInfoPool(); p3.register_sup_info(torch.eye(4), torch.ones(h, w, 1, device='cuda'), rgb, flat, tilted)
+    assert len(p2) == h * w and len(p3) == 0
+    # checkpoint round trip with the reference's keys
+    pool.register_sup_info(torch.eye(4), torch.ones(h, w, 1, device='cuda'), rgb, flat)
+    sd = pool.state_dict()
+    assert sd['n_sup_infos'] == 2 and set(sd['sup_info_0'].keys()) == set(SupInfoPool._INFO_KEYS)
+    assert 'sup_info_{}_height' in sd and 'sup_info_{}_width' in sd
+    torch.save(sd, tmp_path / 'pool.pth')
+    q = SupInfoPool(); q.load_state_dict(torch.load(tmp_path / 'pool.pth'))
+    assert len(q) == len(pool) and torch.equal(q.all_sup_rays.o, pool.all_sup_rays.o) and torch.equal(q.all_sup_distances, pool.all_sup_distances)
+    assert q._ranges == pool._ranges and len(q.sup_infos) == 2
