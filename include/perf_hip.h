@@ -247,7 +247,7 @@ int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* 
                          float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
                          void* stream);
 
-/* Optional empty-space skip for perf_occ_march_count (what nerfacc's DDA traversal achieves): a dilated 8^3-block
+/* Optional empty-space skip for perf_occ_march_count (what nerfacc's DDA traversal achieves): a dilated 4^3-block
  * occupancy (perf_occ_coarse_words(res) uint32 words) lets the kernel drop whole 64-interval chunks; conservative,
  * results are identical with occ_coarse == NULL.  res must be a multiple of 8. */
 int64_t perf_occ_coarse_words(int32_t res);

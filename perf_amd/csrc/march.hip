@@ -17,28 +17,33 @@ struct MarchParams {
     float hi[3];
     float far_plane, step;
     int32_t res, max_steps, mask_words;
-    int32_t use_coarse;      // 1: skip 64-interval chunks whose midpoint lies in an empty DILATED 8^3 block
+    int32_t use_coarse;      // 1: skip 64-interval chunks whose midpoint lies in an empty DILATED block (kCoarseBlock^3 cells)
     float chunk_cells[3];    // fine cells a 64-interval chunk spans per unit of |d| along each axis (64 step res / extent)
 };
 
-// Coarse skip grid: bit b of `coarse` is set iff any fine cell in the 3x3x3 neighbourhood of 8^3-block b is occupied.
-// A chunk of 64 lattice intervals spans at most `span` fine cells; when span/2 + 1 <= 8 every midpoint of the chunk lies
-// within one block of the block that holds the chunk's centre, so an empty dilated block proves the chunk empty
-// (conservative: results are identical to the exhaustive test).
+// Coarse skip grid: bit b of `coarse` is set iff any fine cell in the 3x3x3 neighbourhood of B^3-block b is occupied
+// (B = kCoarseBlock).  A chunk of 64 lattice intervals spans at most `span` fine cells; when span/2 + 1.5 <= B every
+// midpoint of the chunk lies within one block of the block that holds the chunk's centre, so an empty dilated block proves
+// the chunk empty (conservative: results are identical to the exhaustive test).  B = 4: at PeRF's step (5e-4, 4.1 cells per
+// chunk) the condition holds with the smallest power of two, and a thin occupied shell keeps 3 blocks = 12 cells = ~3
+// chunks of a ray alive instead of the ~6 that 8^3 blocks kept -- phase B of march_count is what a frame pays for.
+constexpr int kCoarseShift = 2;
+constexpr int kCoarseBlock = 1 << kCoarseShift;
 __global__ __launch_bounds__(256) void coarse_build_kernel(const uint32_t* __restrict__ bits, int res,
                                                            uint32_t* __restrict__ coarse) {
-    const int cr = res / 8;
+    constexpr int B = kCoarseBlock;
+    const int cr = res / B;
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= cr * cr * cr) return;
     const int bx = b / (cr * cr), by = (b / cr) % cr, bz = b % cr;
     bool any = false;
-    for (int x = max(bx - 1, 0) * 8; x < min(bx + 2, cr) * 8 && !any; ++x)
-        for (int y = max(by - 1, 0) * 8; y < min(by + 2, cr) * 8 && !any; ++y) {
-            // the z run [z0, z1) of a row is contiguous in the bit field
-            const int z0 = max(bz - 1, 0) * 8, z1 = min(bz + 2, cr) * 8;
-            for (int z = z0; z < z1; z += 8) {
+    for (int x = max(bx - 1, 0) * B; x < min(bx + 2, cr) * B && !any; ++x)
+        for (int y = max(by - 1, 0) * B; y < min(by + 2, cr) * B && !any; ++y) {
+            // the z run [z0, z1) of a row is contiguous in the bit field (B divides 32: a block's run never straddles a word)
+            const int z0 = max(bz - 1, 0) * B, z1 = min(bz + 2, cr) * B;
+            for (int z = z0; z < z1; z += B) {
                 const uint32_t ci = (uint32_t)((x * res + y) * res + z);
-                if ((bits[ci >> 5] >> (ci & 31)) & 0xffu) { any = true; break; }
+                if ((bits[ci >> 5] >> (ci & 31)) & ((1u << B) - 1u)) { any = true; break; }
             }
         }
     if (any) atomicOr(&coarse[b >> 5], 1u << (b & 31));
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
     float span_cells = 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) span_cells = fmaxf(span_cells, fabsf(d[a]) * mp.chunk_cells[a]);
-    const bool use_coarse = mp.use_coarse && (span_cells * 0.5f + 1.5f <= 8.0f);
+    const bool use_coarse = mp.use_coarse && (span_cells * 0.5f + 1.5f <= (float)kCoarseBlock);
     int32_t count = 0;
     const int res = mp.res;
     const float rf = (float)res;
@@ -95,13 +100,13 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
             maybe = !(lattice(t0, k0, mp.step) > hi) && !(lattice(t0, k0 + 64, mp.step) < lo);
             if (maybe && use_coarse) {
                 const float tc = lattice(t0, k0 + 32, mp.step);
-                const int cr = res >> 3;
+                const int cr = res >> kCoarseShift;
                 int cb[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     const float p = add_rn(o[a], mul_rn(d[a], tc));
                     const float u = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
-                    cb[a] = ((int)fminf(fmaxf(floorf(u), 0.0f), rf - 1.0f)) >> 3;
+                    cb[a] = ((int)fminf(fmaxf(floorf(u), 0.0f), rf - 1.0f)) >> kCoarseShift;
                 }
                 const uint32_t bi = (uint32_t)((cb[0] * cr + cb[1]) * cr + cb[2]);
                 maybe = (coarse[bi >> 5] >> (bi & 31)) & 1u;
@@ -358,7 +363,7 @@ extern "C" int64_t perf_occ_mask_words(int32_t max_steps) {
 
 extern "C" int64_t perf_occ_coarse_words(int32_t res) {
     if (res <= 0 || (res % 8) != 0) return 0;
-    const int64_t cr = res / 8;
+    const int64_t cr = res / kCoarseBlock;
     return (cr * cr * cr + 31) / 32;
 }
 
@@ -367,7 +372,7 @@ extern "C" int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint
     const int64_t words = perf_occ_coarse_words(res);
     hipError_t e = hipMemsetAsync(coarse, 0, words * sizeof(uint32_t), as_stream(stream));
     if (e != hipSuccess) { set_error("perf_occ_build_coarse: memset failed"); return PERF_E_LAUNCH; }
-    const int cr = res / 8;
+    const int cr = res / kCoarseBlock;
     hipLaunchKernelGGL(coarse_build_kernel, dim3((unsigned)div_up((int64_t)cr * cr * cr, 256)), dim3(256), 0, as_stream(stream),
                        occ_bits, (int)res, coarse);
     PERF_LAUNCH_CHECK("perf_occ_build_coarse");

@@ -337,7 +337,7 @@ def exclusive_scan_i32(counts: torch.Tensor):
 
 
 def occ_build_coarse(occ_bits, res):
-    """Dilated 8^3-block occupancy for the marching kernel's empty-space skip (None when res % 8 != 0)."""
+    """Dilated 4^3-block occupancy for the marching kernel's empty-space skip (None when res % 8 != 0)."""
     words = _lib.load().perf_occ_coarse_words(int(res))
     if words == 0:
         return None
