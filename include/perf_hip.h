@@ -247,6 +247,17 @@ int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* 
                          float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
                          void* stream);
 
+/* perf_occ_march_count that also WRITES the first head_k samples of every ray (the head of the two-phase sampler below):
+ * rows r*head_k .. r*head_k + min(count, head_k) - 1 of arrays of n_rays*head_k rows get the same ray_indices / t_starts /
+ * t_ends / x01 / sel that perf_occ_march_write_points writes for ranks [0, head_k); the remaining rows of a ray are padding
+ * (sel = 0); packed_info[r] = (r*head_k, min(count, head_k)).  Replaces perf_head_tail_counts + perf_exclusive_scan_i32 +
+ * perf_occ_march_write_points for the head.  head_k in [1, 64]. */
+int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
+                              const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
+                              float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
+                              int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
+                              const float* points_aabb6, float* x01, uint8_t* sel, void* stream);
+
 /* Optional empty-space skip for perf_occ_march_count (what nerfacc's DDA traversal achieves): a dilated 4^3-block
  * occupancy (perf_occ_coarse_words(res) uint32 words) lets the kernel drop whole 64-interval chunks; conservative,
  * results are identical with occ_coarse == NULL.  res must be a multiple of 8. */

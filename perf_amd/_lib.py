@@ -64,6 +64,8 @@ _SIGS = {
     'perf_occ_pack_bits': (c_int, [P, P, c_int64, P]),
     'perf_occ_mask_words': (c_int64, [c_int32]),
     'perf_occ_march_count': (c_int, [P, P, P, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, P, P, P]),
+    'perf_occ_march_count_head': (c_int, [P, P, P, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, P, P,
+                                  c_int32, P, P, P, P, POINTER(c_float), P, P, P]),
     'perf_occ_coarse_words': (c_int64, [c_int32]),
     'perf_occ_build_coarse': (c_int, [P, c_int32, P, P]),
     'perf_scan_workspace_bytes': (c_int64, [c_int64]),

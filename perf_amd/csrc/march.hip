@@ -55,11 +55,22 @@ __device__ __forceinline__ float lattice(float t0, int k, float step) { return a
 // intervals 64q..64q+63) may hold samples; only live chunks have their mask word written (and later read).
 __device__ __forceinline__ int n_live_words(int mask_words) { return (mask_words + 63) >> 6; }
 
+// HEAD: the first `K` samples of every ray (the head of the two-phase sampler) are written right here, to rows r*K .. r*K+K-1
+// of arrays of n_rays*K rows (rows beyond a ray's count are padded with sel = 0) -- what used to take a count clamp, a scan
+// over the rays and a pass of march_write_kernel.  Same values as that pass writes (lattice + sample_point_store).
+struct HeadOut {
+    int32_t K;
+    int64_t* ri; float* ts; float* te; int32_t* packed;
+    float* x01; uint8_t* sel;
+    Aabb bb;
+};
+
+template <bool HEAD>
 __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const float* __restrict__ ro,
                                                           const float* __restrict__ rd, const float* __restrict__ t0s,
                                                           int64_t n_rays, const uint32_t* __restrict__ bits,
                                                           const uint32_t* __restrict__ coarse,
-                                                          uint64_t* __restrict__ masks, int32_t* __restrict__ counts) {
+                                                          uint64_t* __restrict__ masks, int32_t* __restrict__ counts, HeadOut ho) {
     const int lane = threadIdx.x & 63;
     // (the ray index is wave uniform: saying so turns the loads of the ray's origin, direction and lattice origin into
     //  scalar loads -- seven vector-memory instructions per ray less; the kernel is bound by VMEM issue, not by bytes)
@@ -149,10 +160,21 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (qs[u] < 0) continue;                 // (wave uniform)
-                const uint64_t m = __ballot(in_range[u] && ((words[u] >> (cis[u] & 31)) & 1u));
+                const bool mine = in_range[u] && ((words[u] >> (cis[u] & 31)) & 1u);
+                const uint64_t m = __ballot(mine);
                 if (m) {
                     kept |= 1ull << (qs[u] & 63);
                     if (lane == 0) rec[nlw + qs[u]] = m;
+                    if (HEAD && count < ho.K && mine) {         // (chunks arrive in t order: `count` = samples before this chunk)
+                        const int rank = count + __popcll(m & ((1ull << lane) - 1ull));
+                        if (rank < ho.K) {
+                            const int64_t pos = r * ho.K + rank;
+                            const int k = qs[u] * 64 + lane;
+                            const float a = lattice(t0, k, mp.step), b = lattice(t0, k + 1, mp.step);
+                            ho.ts[pos] = a; ho.te[pos] = b; ho.ri[pos] = r;
+                            sample_point_store(ro + 3 * r, rd + 3 * r, a, b, ho.bb, ho.x01, ho.sel, pos);
+                        }
+                    }
                     count += __popcll(m);
                 }
             }
@@ -160,6 +182,15 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         if (lane == 0) rec[g] = kept;
     }
     if (lane == 0) counts[r] = count;
+    if (HEAD) {
+        const int have = count < ho.K ? count : ho.K;
+        if (lane == 0) { ho.packed[2 * r] = (int32_t)(r * ho.K); ho.packed[2 * r + 1] = have; }
+        if (lane >= have && lane < ho.K) {                       // padding rows: harmless inputs, selector 0
+            const int64_t pos = r * ho.K + lane;
+            ho.ts[pos] = 0.f; ho.te[pos] = 0.f; ho.ri[pos] = r;
+            ho.x01[3 * pos] = 0.5f; ho.x01[3 * pos + 1] = 0.5f; ho.x01[3 * pos + 2] = 0.5f; ho.sel[pos] = 0;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void march_write_kernel(const float* __restrict__ t0s, int64_t n_rays, float step,
@@ -379,10 +410,9 @@ extern "C" int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint
     return PERF_OK;
 }
 
-extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
-                                    const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
-                                    float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
-                                    void* stream) {
+static int march_count_launch(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays, const uint32_t* occ_bits,
+                              const uint32_t* occ_coarse, int32_t res, const float* aabb, float far_plane, float step,
+                              int32_t max_steps, uint64_t* masks, int32_t* counts, const HeadOut* head, void* stream) {
     PERF_REQUIRE(n_rays >= 0 && res > 0 && res <= 1024 && max_steps > 0 && step > 0.f, "perf_occ_march_count: bad arguments");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(rays_o && rays_d && t0 && occ_bits && aabb && masks && counts, "NULL pointer");
@@ -395,10 +425,37 @@ extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, co
     mp.mask_words = chunk_words(max_steps);
     for (int a = 0; a < 3; ++a) mp.chunk_cells[a] = 64.0f * step * mp.inv_ext[a] * (float)res;
     mp.use_coarse = (occ_coarse != nullptr && (res % 8) == 0) ? 1 : 0;      // (+ the per-ray span test in the kernel)
-    hipLaunchKernelGGL(march_count_kernel, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
-                       rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts);
+    if (head)
+        hipLaunchKernelGGL(march_count_kernel<true>, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
+                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, *head);
+    else
+        hipLaunchKernelGGL(march_count_kernel<false>, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
+                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, HeadOut{});
     PERF_LAUNCH_CHECK("perf_occ_march_count");
     return PERF_OK;
+}
+
+extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
+                                    const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
+                                    float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
+                                    void* stream) {
+    return march_count_launch(rays_o, rays_d, t0, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps, masks, counts,
+                              nullptr, stream);
+}
+
+extern "C" int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
+                                         const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
+                                         float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
+                                         int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
+                                         const float* points_aabb6, float* x01, uint8_t* sel, void* stream) {
+    PERF_REQUIRE(head_k >= 1 && head_k <= 64, "perf_occ_march_count_head: head_k must be in [1, 64]");
+    PERF_REQUIRE(n_rays == 0 || (ray_indices && t_starts && t_ends && packed_info && points_aabb6 && x01 && sel), "NULL pointer");
+    PERF_REQUIRE(n_rays * (int64_t)head_k < ((int64_t)1 << 31), "perf_occ_march_count_head: n_rays * head_k exceeds int32 offsets");
+    HeadOut ho;
+    ho.K = head_k; ho.ri = ray_indices; ho.ts = t_starts; ho.te = t_ends; ho.packed = packed_info; ho.x01 = x01; ho.sel = sel;
+    if (n_rays > 0) for (int a = 0; a < 3; ++a) { ho.bb.lo[a] = points_aabb6[a]; ho.bb.hi[a] = points_aabb6[3 + a]; }
+    return march_count_launch(rays_o, rays_d, t0, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps, masks, counts,
+                              &ho, stream);
 }
 
 extern "C" int64_t perf_scan_workspace_bytes(int64_t n) { return (div_up(n > 0 ? n : 1, kScanBlock) + 1) * (int64_t)sizeof(int64_t); }

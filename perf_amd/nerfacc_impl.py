@@ -265,18 +265,38 @@ class OccGridEstimator(nn.Module):
         sm.ray_indices, sm.t_starts, sm.t_ends, sm.packed, sm.sig, sm.x01, sm.sel = ri, ts, te, packed, sig, x01, sel
         return sm
 
+    STRIDED_HEAD_MAX = 16          # heads of up to this many samples are written by the counting pass, K rows per ray
+
+    def _const_count(self, value, device):
+        """Device int64 [1] holding `value` (cached: created once, outside any graph capture of later calls)."""
+        cache = self.__dict__.setdefault('_count_consts', {})
+        key = (int(value), str(device))
+        if key not in cache:
+            t = torch.full((1,), int(value), dtype=torch.int64, device=device)
+            if torch.cuda.is_current_stream_capturing():
+                return t               # lives in the capturing graph's pool and is filled by its replays: not for the cache
+            cache[key] = t
+        return cache[key]
+
     def _sample_two_phase(self, sm, rays_o, rays_d, t0, far_plane, step, max_steps, capacity, points_aabb, sigma_points_fn,
                           early_stop_eps, K):
         """March once; density + visibility on the first K samples of every ray; then density on the remaining samples of
         the rays that are still alive; final visibility + compaction over (head, tail).  All counts stay on the device."""
         R = rays_o.shape[0]
-        masks, counts = ops.occ_march_count(rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step,
-                                            max_steps, self.occ_coarse())
-        # ---- head: rank [0, K) of every ray; R*K rows always suffice
-        ch = ops.head_tail_counts(counts, K)
-        oh, total_h = ops.exclusive_scan_i32(ch)
-        ri_h, ts_h, te_h, pk_h, x_h, s_h = ops.occ_march_write(t0, masks, ch, oh, R * K, step, max_steps, rays_o, rays_d, points_aabb)
-        sig_h, feat_h = _sig_feat(sigma_points_fn(x_h, s_h, total_h))
+        # ---- head: rank [0, K) of every ray, written by the counting pass itself to rows r*K..r*K+K-1 (rays with fewer
+        #      samples leave padding rows with selector 0: their density is evaluated and ignored)
+        if K <= self.STRIDED_HEAD_MAX:
+            masks, counts, (ri_h, ts_h, te_h, pk_h, x_h, s_h) = ops.occ_march_count_head(
+                rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step, max_steps, self.occ_coarse(), K, points_aabb)
+            total_h = self._const_count(R * K, rays_o.device)
+            sig_h, feat_h = _sig_feat(sigma_points_fn(x_h, s_h, None))
+        else:       # a long head: packed rows (count clamp, scan over the rays, write pass) instead of K rows per ray
+            masks, counts = ops.occ_march_count(rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step,
+                                                max_steps, self.occ_coarse())
+            ch = ops.head_tail_counts(counts, K)
+            oh, total_h = ops.exclusive_scan_i32(ch)
+            ri_h, ts_h, te_h, pk_h, x_h, s_h = ops.occ_march_write(t0, masks, ch, oh, R * K, step, max_steps, rays_o, rays_d, points_aabb)
+            sig_h, feat_h = _sig_feat(sigma_points_fn(x_h, s_h, total_h))
         kept_h = ops.visibility_count(sig_h, ts_h, te_h, pk_h, early_stop_eps)
         # ---- tail: rank [K, count) of the rays whose whole head survived
         ct = ops.head_tail_counts(counts, K, kept_h)
@@ -293,7 +313,7 @@ class OccGridEstimator(nn.Module):
         ri._perf_packed = packed
         sm.ray_indices, sm.t_starts, sm.t_ends, sm.packed, sm.sig, sm.x01, sm.sel = ri, ts, te, packed, sig, x01, sel
         sm.n_dev = total
-        sm.n_marched_dev = total_h + total_t          # samples whose density was evaluated (what must fit the capacity)
+        sm.n_marched_dev = total_h + total_t          # rows whose density was evaluated (what must fit the capacity)
         return sm
 
     @torch.no_grad()

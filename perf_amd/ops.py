@@ -358,6 +358,27 @@ def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, ma
     return masks, counts
 
 
+def occ_march_count_head(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse, head_k, points_aabb):
+    """occ_march_count that also writes the first head_k samples of every ray to rows r*head_k.. of R*head_k-row arrays
+    (padding rows have sel = 0) -> (masks, counts, (ray_indices, t_starts, t_ends, packed_info, x01, sel))."""
+    R = rays_o.shape[0]
+    dev = rays_o.device
+    mw = _lib.load().perf_occ_mask_words(max_steps)
+    masks = torch.empty(max(R * mw, 1), dtype=torch.int64, device=dev)
+    counts = torch.empty(R, dtype=torch.int32, device=dev)
+    S = R * int(head_k)
+    ri = torch.empty(S, dtype=torch.int64, device=dev)
+    ts = torch.empty(S, dtype=torch.float32, device=dev)
+    te = torch.empty(S, dtype=torch.float32, device=dev)
+    packed = torch.empty(R, 2, dtype=torch.int32, device=dev)
+    x01 = torch.empty(S, 3, dtype=torch.float32, device=dev)
+    sel = torch.empty(S, dtype=torch.uint8, device=dev)
+    _call('perf_occ_march_count_head', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(t0, 't0')), R,
+          _p(occ_bits), _p(occ_coarse), int(res), _aabb6(aabb), float(far_plane), float(step), int(max_steps), _p(masks), _p(counts),
+          int(head_k), _p(ri), _p(ts), _p(te), _p(packed), _aabb6(points_aabb), _p(x01), _p(sel), _stream())
+    return masks, counts, (ri, ts, te, packed, x01, sel)
+
+
 def occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o=None, rays_d=None, points_aabb=None, rank_lo=0):
     """Pass 2: expand the masks into S-row sample arrays -> (ray_indices, t_starts, t_ends, packed_info[, x01, sel]).
     counts / offsets: how many samples of every ray to write, starting at rank rank_lo, and where."""

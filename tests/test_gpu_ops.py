@@ -310,6 +310,47 @@ def test_occ_march_bit_exact(ops, stratified):
         assert np.array_equal(gpacked.cpu().numpy(), packed)
 
 
+@pytest.mark.parametrize('K', [1, 4, 16])
+def test_occ_march_count_head_equals_the_three_pass_head(ops, K):
+    """perf_occ_march_count_head: the counting pass writes the first K samples of every ray itself (rows r*K.., padding rows
+    with selector 0) -- same masks / counts as perf_occ_march_count and, per ray, bit for bit the samples and positions that
+    count clamp + scan + perf_occ_march_write_points produce for ranks [0, K); rays that miss the box included."""
+    o, d, dist, rgb, occ = _room(24, 48, 64)
+    o = o + torch.tensor([0.2, -0.1, 0.05])
+    o[:5] = torch.tensor([3.0, 0.0, 0.0]); d[5] = torch.tensor([1.0, 0.0, 0.0]); d[6] = torch.tensor([0.0, 0.0, -1.0])
+    R = o.shape[0]
+    aabb = [-1., -1, -1, 1, 1, 1]
+    step, far = 2e-3, 1.5
+    max_steps = int(math.ceil(far / step)) + 1
+    g = torch.Generator().manual_seed(5)
+    t0 = (torch.rand(R, generator=g) * step).cuda()
+    bits = ops.occ_pack_bits(occ.cuda())
+    coarse = ops.occ_build_coarse(bits, 64)
+    oc, dc = o.cuda(), d.cuda()
+    masks, counts = ops.occ_march_count(oc, dc, t0, bits, 64, aabb, far, step, max_steps, coarse)
+    ch = ops.head_tail_counts(counts, K)
+    oh, total = ops.exclusive_scan_i32(ch)
+    ri, ts, te, pk, x01, sel = ops.occ_march_write(t0, masks, ch, oh, R * K, step, max_steps, oc, dc, aabb)
+    m2, c2, (ri2, ts2, te2, pk2, x2, s2) = ops.occ_march_count_head(oc, dc, t0, bits, 64, aabb, far, step, max_steps, coarse, K, aabb)
+    assert torch.equal(c2, counts) and int((counts == 0).sum()) >= 5 and int((counts >= K).sum()) > 100
+    have = torch.clamp(counts, max=K)
+    assert torch.equal(pk2[:, 1], have) and torch.equal(pk2[:, 0], torch.arange(R, device='cuda', dtype=torch.int32) * K)
+    # strided rows -> packed order
+    row = torch.arange(R * K, device='cuda').view(R, K)
+    live = (torch.arange(K, device='cuda')[None, :] < have[:, None])
+    idx = row[live]
+    n = int(total.item())
+    assert idx.numel() == n
+    for a, b in ((ri2, ri), (ts2, ts), (te2, te), (x2, x01), (s2, sel)):
+        assert torch.equal(a[idx], b[:n])
+    pad = row[~live]
+    assert int(s2[pad].sum()) == 0 and bool((x2[pad] == 0.5).all())
+    # the keep masks of the live chunks are the same records
+    r0 = int(torch.nonzero(counts > 0)[0])
+    mw = masks.numel() // R
+    assert torch.equal(m2.view(R, mw)[r0, :1], masks.view(R, mw)[r0, :1])
+
+
 def test_scan_and_empty(ops):
     g = torch.Generator().manual_seed(6)
     for n in (1, 5, 1024, 1025, 8192, 65536, 65537, 100000):
