@@ -54,8 +54,10 @@ class NeRFOCCRenderer(nn.Module):
         self.sample_capacity = None    # int: sync-free sampling -- arrays of that many rows, live counts on the device
         # two-phase early termination of the sync-free sampler (None = one phase): density on the first `head_samples`
         # samples of every ray, then on the rest of the rays still alive; identical results, far fewer density
-        # evaluations once the scene is opaque (nerfacc_impl.OccGridEstimator.sampling_ex)
-        self.head_samples = 4
+        # evaluations once the scene is opaque (nerfacc_impl.OccGridEstimator.sampling_ex).  2 is the smallest head that can end
+        # a ray (the first sample of a ray is always kept; the second is dropped iff the first made the ray opaque) and the
+        # fastest on a trained scene (512x1024 frames/s: K=2 1140, 3 1070, 4 1010, 6 880; untrained scenes do not care)
+        self.head_samples = 2
 
     # The render is cut in two stages so that a data-parallel trainer can overlap the gradient all-reduce of step k
     # with everything of step k+1 that does not depend on the parameters being updated (scene.py).

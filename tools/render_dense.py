@@ -18,7 +18,7 @@ ap.add_argument('--poses', type=int, default=600)
 ap.add_argument('--geo-steps', type=int, default=300)
 ap.add_argument('--app-steps', type=int, default=150)
 ap.add_argument('--dtype', default='fp16')
-ap.add_argument('--head', type=int, default=4, help='two-phase sampler: density first on that many samples per ray (0 = one phase)')
+ap.add_argument('--head', type=int, default=2, help='two-phase sampler: density first on that many samples per ray (0 = one phase)')
 ap.add_argument('--batch', type=int, default=32768, help='rays per graph-captured eval batch (the reference hard-codes 32768, nerf.py:86)')
 args = ap.parse_args()
 
