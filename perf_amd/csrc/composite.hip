@@ -83,7 +83,7 @@ __device__ __forceinline__ unsigned long long team_ballot(bool p) {
 //  * one wave per ray (small batches: 8,192 training rays of 128 samples must not lose three quarters of their waves): the
 //    waves of an aligned group of four rays take the same decision; in the quarter-wave case the group's first wave serves
 //    all four rays and the other three retire at once.
-// Calls body(Team<16 or 64>, ray, lane-in-team).
+// Calls body(Team<4, 16 or 64>, ray, lane-in-team).
 constexpr int64_t kPackedMinWaves = 8192;       // 256 CUs x 32 waves
 
 template <typename CountFn, typename Body>
@@ -93,6 +93,19 @@ __device__ __forceinline__ void for_rays_of_wave(int64_t n_rays, CountFn count_o
     const bool packed = (int64_t)gridDim.x * 4 < n_rays;
     const int64_t r0 = packed ? w * 4 : (w & ~(int64_t)3);
     if (r0 >= n_rays) return;
+    // sixteen rays of at most 4 samples each (a trained scene renders with one or two kept samples per ray): the first wave
+    // of their aligned group serves all sixteen with 4-lane teams, the other waves of the group retire.  Same bits again:
+    // for <= 4 samples the Kogge-Stone offsets 4..32 and the butterfly steps 32..4 only ever add exact zeros.
+    {
+        const int64_t g16 = packed ? (w >> 2) * 16 : (w & ~(int64_t)15);
+        const bool leader = packed ? (w & 3) == 0 : (w & 15) == 0;
+        const int64_t r16 = g16 + (lane >> 2);
+        const int c16 = r16 < n_rays ? count_of(r16) : 0;
+        if (__ballot(c16 > 4) == 0ull) {
+            if (leader && r16 < n_rays) body(Team<4>{}, r16, lane & 3);
+            return;
+        }
+    }
     const int64_t rq = r0 + (lane >> 4);
     const int cq = rq < n_rays ? count_of(rq) : 0;
     if (__ballot(cq > 16) == 0ull) {

@@ -701,16 +701,18 @@ def test_hashgrid_bwd_fixed_point_with_vanishing_gradients(ops):
         assert bool(torch.isfinite(got).all()) and float(got.abs().max()) <= 8 * n * max(mag, 1e-45) * 10
 
 
+@pytest.mark.parametrize('max_short', [16, 4])
 @pytest.mark.parametrize('n_short', [203, 36001])
-def test_quarter_wave_ray_teams_equal_full_wave_rays(ops, n_short):
+def test_quarter_wave_ray_teams_equal_full_wave_rays(ops, n_short, max_short):
     """Per-ray kernels serve four rays per wave: 16 lanes each when all four hold <= 16 samples, all 64 lanes one ray after
     the other otherwise.  The same short rays, alone (quarter-wave path) and interleaved with long rays (full-wave path),
     must give bit-identical visibility counts, exclusive sums, weights and per-ray outputs -- and match the oracle's
     canonical scan."""
     # (203 rays: one wave per ray is launched; 36001 rays: the packed shape, four rays per wave)
     g = torch.Generator().manual_seed(31)
-    counts_s = torch.randint(0, 17, (n_short,), generator=g)
-    counts_s[:5] = torch.tensor([0, 1, 16, 16, 2])
+    # (max_short = 4: sixteen rays per wave in 4-lane teams)
+    counts_s = torch.randint(0, max_short + 1, (n_short,), generator=g)
+    counts_s[:5] = torch.tensor([0, 1, max_short, max_short, 2])
 
     def build(counts):
         starts = torch.cumsum(counts, 0) - counts
