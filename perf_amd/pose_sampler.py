@@ -88,18 +88,24 @@ class CirclePoseSampler:
 
 def _annealed_tour(positions: torch.Tensor, n_steps=10000):
     """Random pair swaps with an annealed acceptance ratio (1 - step/n)^5; consumes numpy's global RNG in the
-    reference's order (two randint per step, one rand only when the swap does not shorten the tour)."""
+    reference's order (two randint per step, one rand only when the swap does not shorten the tour).
+    (dense_travel_pose_sampler.py:26-48 recomputes 23 difference vectors and norms with five tiny torch ops per step;
+    here the pairwise distances ||p_i - p_j|| are formed once with the same operations, a step gathers 23 of them and adds
+    them with the same torch.sum -- the same float32 tour lengths, hence the same accept / reject decisions, in a quarter
+    of the time.)"""
     n = len(positions)
-    order = torch.arange(n)
+    pos = positions.detach().cpu().float()
+    dmat = torch.linalg.norm(pos[:, None, :] - pos[None, :, :], 2, -1).numpy()        # [n, n] float32
+    order = np.arange(n)
     best = 1e8
     for it in range(n_steps):
         a = np.random.randint(n); b = np.random.randint(n)
-        cand = order.clone()
+        cand = order.copy()
         cand[a], cand[b] = order[b], order[a]
-        length = torch.linalg.norm(positions[cand[:-1]] - positions[cand[1:]], 2, -1).sum()
+        length = float(torch.from_numpy(dmat[cand[:-1], cand[1:]]).sum())
         if length < best or np.random.rand() < (1. - it / n_steps) ** 5:
             order, best = cand, length
-    return order
+    return torch.from_numpy(order)
 
 
 class DenseTravelPoseSampler:
