@@ -425,17 +425,26 @@ class NeRFScene:
             else:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
         optimizer.step()
+        self._poll_health(net)
+
+    def _poll_health(self, net, n_marched=None):
+        """Every OVERFLOW_CHECK_EVERY eager steps: ONE host read-back of the sticky device-side flags -- the fixed-point
+        overflow flag of the grid backward and the over-capacity flag of the sync-free sampler (n_marched: the batch's
+        marched count, device int64 [1], only used when no sticky flag is collected)."""
         self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
-        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY:
-            self._steps_since_check = 0                # one host read-back every OVERFLOW_CHECK_EVERY eager steps
-            if _tcnn.GRID_GRAD_ACCUM == 'fixed':
-                _tcnn.check_fixed_point_overflow(net.params.device)
-            cap = self.renderer.sample_capacity
-            if cap is not None and torch.is_tensor(n_marched) and int(n_marched.item()) > cap:
+        if self._capturing or self._steps_since_check < OVERFLOW_CHECK_EVERY:
+            return
+        self._steps_since_check = 0
+        if _tcnn.GRID_GRAD_ACCUM == 'fixed':
+            _tcnn.check_fixed_point_overflow(net.params.device)
+        cap = self.renderer.sample_capacity
+        if cap is not None and torch.is_tensor(n_marched):
+            worst = int(n_marched.item())
+            if worst > cap:
                 import warnings
-                warnings.warn(f'perf_amd: a training batch evaluated {int(n_marched.item())} samples, more than the capacity {cap} '
+                warnings.warn(f'perf_amd: a training batch evaluated {worst} samples, more than the capacity {cap} '
                               '(late rays were truncated); doubling the capacity')
-                self.renderer.sample_capacity = 2 * int(n_marched.item())
+                self.renderer.sample_capacity = 2 * worst
 
     def _geo_prefetch(self, sup_pool, rand, generator):
         """Everything of a geometry step that does not depend on the geometry parameters: batch draw, and -- when the
@@ -503,28 +512,7 @@ class NeRFScene:
             if gate is None or int(gate.item()) > 0:
                 optimizer.step()
             net.params.grad = None
-        self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
-        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY:
-            self._steps_since_check = 0                # one host read-back every OVERFLOW_CHECK_EVERY eager steps
-            if _tcnn.GRID_GRAD_ACCUM == 'fixed':
-                _tcnn.check_fixed_point_overflow(net.params.device)
-            cap = self.renderer.sample_capacity
-            if cap is not None and torch.is_tensor(n_marched) and int(n_marched.item()) > cap:
-                import warnings
-                warnings.warn(f'perf_amd: a training batch evaluated {int(n_marched.item())} samples, more than the capacity {cap} '
-                              '(late rays were truncated); doubling the capacity')
-                self.renderer.sample_capacity = 2 * int(n_marched.item())
-        self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
-        if not self._capturing and self._steps_since_check >= OVERFLOW_CHECK_EVERY:
-            self._steps_since_check = 0                # one host read-back every OVERFLOW_CHECK_EVERY eager steps
-            if _tcnn.GRID_GRAD_ACCUM == 'fixed':
-                _tcnn.check_fixed_point_overflow(net.params.device)
-            cap = self.renderer.sample_capacity
-            if cap is not None and torch.is_tensor(n_marched) and int(n_marched.item()) > cap:
-                import warnings
-                warnings.warn(f'perf_amd: a training batch evaluated {int(n_marched.item())} samples, more than the capacity {cap} '
-                              '(late rays were truncated); doubling the capacity')
-                self.renderer.sample_capacity = 2 * int(n_marched.item())
+        self._poll_health(net, n_marched)
 
     @torch.no_grad()
     def _geo_step_fused(self, optimizer, sup_pool, progress, rand, generator, prefetch_next=True):
