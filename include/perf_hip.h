@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 3
+#define PERF_ABI_VERSION 4
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -106,13 +106,20 @@ int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_
                        const int32_t* step_dev, const float* lr_dev, const int64_t* gate_dev, float beta1, float beta2,
                        float eps, int zero_grad, void* stream);
 
-/* Device-side bookkeeping of one sync-free training step, one tiny launch: *step_dev += 1 unless *gate_dev <= 0 (the
- * optimizer step count only advances when the step is taken, like torch.optim.Adam behind the reference's
- * `if not is_valid: return`, nerf.py:204-206); counters (int64 [3], may be NULL) accumulate {marched samples, kept
- * samples, steps} so that throughput accounting never reads the device inside the timed loop.  All pointers device
- * memory; step_dev, gate_dev, n_marched_dev, n_kept_dev may be NULL. */
+/* Device-side bookkeeping of one sync-free training step, one tiny launch, issued between the backward and
+ * perf_adam_step_dev.  The step is TAKEN when the batch has samples (*gate_dev > 0 or gate_dev == NULL; the reference skips
+ * batches without samples, nerf.py:204-206), the fixed-point grid backward did not flag an overflow (*overflow_flag != 0,
+ * or *remote_flags > 0: the sum of the other ranks' flags under data parallelism) and the batch was not truncated
+ * (*n_marched_dev > capacity > 0: late rays lost their samples).  *step_dev += 1 and *eff_gate_out = 1 when taken,
+ * *eff_gate_out = 0 otherwise -- pass eff_gate_out to perf_adam_step_dev as its gate: a corrupted or truncated gradient is
+ * never applied.  *overflow_flag is cleared (the event is counted instead).  counters (int64 [PERF_STEP_COUNTERS], may be
+ * NULL) accumulate {marched samples, kept samples, steps, largest marched count of one batch, steps skipped for overflow,
+ * steps skipped for truncation, 0, 0}: throughput and health accounting never read the device inside the training loop.
+ * All pointers device memory; every pointer may be NULL. */
+#define PERF_STEP_COUNTERS 8
 int perf_step_bookkeeping(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
-                          const int64_t* n_marched_dev, const int64_t* n_kept_dev, void* stream);
+                          const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
+                          int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out, void* stream);
 
 /* ---- sample positions ------------------------------------------------------------------ */
 
@@ -156,16 +163,49 @@ int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const fl
  * workspace: 16-byte aligned device scratch of perf_hashgrid_bwd_workspace_bytes(grid, n) bytes (replica slabs of
  * the coarse levels + 4 bytes per (sample, hashed level) of tile codes; a workspace without room for the codes
  * is accepted and selects the slower position-streaming owners).  With n_dev the headroom follows the live count.
- * headroom_state (device, 2*PERF_MAX_LEVELS int32, zero-initialised by the caller and then owned by the sequence of
- * calls on one table, may be NULL): closes the loop on the headroom -- every call records the largest field each level
- * reached and the next call's h_l is corrected to keep it between 2^23 and 2^27 units (entries next to a panorama's
- * common ray origin collect 30x the average number of contributions; hashed levels far fewer than the static guess
- * allows).  With the state the first call starts 3 bits on the safe side of the static h_l and h_l ranges over [4, 28]. */
+ * headroom_state (device, PERF_HEADROOM_STATE_WORDS int32, zero-initialised by the caller and then owned by the sequence
+ * of calls on one table, may be NULL): closes the loop on the headroom -- every call records the largest field each level's
+ * FINAL sums reached and the next call's h_l is corrected to keep it between 2^23 and 2^27 units (entries next to a
+ * panorama's common ray origin collect 30x the average number of contributions; hashed levels far fewer than the static
+ * guess allows).  With the state the first call starts 3 bits on the safe side of the static h_l and h_l ranges over [4, 28].
+ * Integer sums are exact and order independent: replicated (coarse) levels add their replicas as integers, so the table
+ * does not depend on how the samples were dealt to workgroups.
+ * Data-parallel training extends that to ranks:
+ *   shifts_dev (device, PERF_MAX_LEVELS int32, may be NULL): the per-level units (one unit = 2^-shift) are GIVEN -- the
+ *     job-wide ones of perf_dp_units -- instead of being derived from level_absmax / n / headroom_state (which must be
+ *     NULL then; level_absmax may be NULL too);
+ *   raw_fields != 0: grad_table receives the int32 field pairs {feature 0, feature 1} of every entry instead of floats
+ *     (same addresses, reinterpret as int32).  The ranks' tables are then summed exactly by an integer reduce-scatter and
+ *     converted by perf_fixed_unfix: the result equals the single-process table bit for bit.  Needs accumulate == 0 and no
+ *     level beyond 4 M entries. */
+#define PERF_HEADROOM_STATE_WORDS (2 * PERF_MAX_LEVELS + 8)
 int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n);
 int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
                       float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
-                      int32_t* overflow_flag, int32_t* headroom_state, void* workspace, int64_t workspace_bytes,
-                      void* stream);
+                      int32_t* overflow_flag, int32_t* headroom_state, const int32_t* shifts_dev, int raw_fields,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- job-wide fixed-point units of a data-parallel step (no counterpart in the reference, which is single-GPU;
+ *      rays shard over the GPUs, one gradient exchange per step) ------------------------------------------
+ * Between the MLP backward and the grid backward every rank packs PERF_DP_STATS int32 words -- the float bits of its
+ * level_absmax [PERF_MAX_LEVELS], the largest field per level of ITS slice of the previous step's summed table
+ * (field_max_prev, from perf_fixed_unfix; NULL = no previous step), its live sample count min(n, *n_dev) as two words --
+ * the blocks are all-gathered (bitwise), and perf_dp_units derives on every rank the SAME units the single process would
+ * use: max of the absmax, sum of the counts, headroom feedback with the max of the field maxima (applied to
+ * headroom_state first, exactly where the single process applies it: between two calls).  shifts_out: PERF_MAX_LEVELS
+ * int32 for perf_hashgrid_bwd(shifts_dev) / perf_fixed_unfix; n_total_out (int64, may be NULL): the job's sample count
+ * (the gate of the optimizer step). */
+#define PERF_DP_STATS 64
+int perf_dp_stats_pack(const float* level_absmax, const int32_t* field_max_prev, const int64_t* n_dev, int64_t n,
+                       int32_t* stats_out, void* stream);
+int perf_dp_units(const perf_grid_desc* grid, const int32_t* stats_all, int32_t world, int32_t* headroom_state,
+                  int32_t* shifts_out, int64_t* n_total_out, void* stream);
+/* In place: the int32 field pairs of table entries [entry_lo, entry_hi) (a rank's slice after the integer reduce-scatter;
+ * `fields` points at entry_lo) -> fp32 gradients, value = field * 2^-shift of the entry's level.  field_max (device,
+ * PERF_MAX_LEVELS int32, may be NULL) receives the largest |field| per level of the slice; *overflow_flag is OR-ed with 1
+ * when one comes within 4x of the int32 range. */
+int perf_fixed_unfix(const perf_grid_desc* grid, void* fields, int64_t entry_lo, int64_t entry_hi,
+                     const int32_t* shifts_dev, int32_t* field_max, int32_t* overflow_flag, void* stream);
 
 /* The integer half of the encoding: idx[(l*n + i)*8 + c] = absolute table entry (level offset included) of corner c
  * (bit0 = x, bit1 = y, bit2 = z) of sample i at level l.  Used for the arbitrarily-often differentiable composition

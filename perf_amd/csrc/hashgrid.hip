@@ -264,6 +264,7 @@ struct TileParams {
     // the same XCD -- they stream the same codes and gather the same position / gradient lines at about the same
     // time, which then hit that XCD's L2 instead of crossing the fabric 16 times.  use_work == 0: plain level order.
     int32_t use_work;
+    int32_t raw_out;                       // fixed point: the gradient table receives the int32 field pairs themselves (see perf_hashgrid_bwd)
     uint32_t atomic_levels;                // bit l: level l is too large for LDS owners (see hashgrid_bwd_atomic_kernel)
     uint32_t work[kMaxWork];
 };
@@ -419,6 +420,16 @@ __device__ __forceinline__ int fixed_point_shift(const float am, const int64_t n
         h = h < 12 ? 12 : (h > 24 ? 24 : h);
     }
     return 31 - h - e;
+}
+
+// Headroom feedback: keep the largest field of a level between 2^23 and 2^27 units.  Above: add the excess bits at once
+// (+1); below: give one bit back per call.  fm = the largest |field| the level's FINAL sums reached in the previous call
+// (all replicas -- and, under data parallelism, all ranks -- added up), so that every partition of a batch follows the
+// same sequence of units.  Deterministic: the state is a function of the call history only.
+__device__ __forceinline__ int headroom_feedback(int adj, int fm) {
+    if (fm >= (1 << 27)) adj += (32 - __clz(fm)) - 27 + 1;
+    else if (fm < (1 << 23) && adj > -24) adj -= 1;
+    return adj;
 }
 
 // one sample's contribution to the tile this workgroup owns
@@ -755,6 +766,8 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    const float* __restrict__ level_absmax,
                                                                    int32_t* __restrict__ overflow_flag,
                                                                    int32_t* __restrict__ hr_state,
+                                                                   const int32_t* __restrict__ shifts_in,
+                                                                   int32_t* __restrict__ shifts_ws,
                                                                    const uint32_t* __restrict__ codes,
                                                                    const uint32_t* __restrict__ escape, int64_t n,
                                                                    const int64_t* __restrict__ n_dev) {
@@ -788,9 +801,12 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     cx.smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     cx.to_fixed = 1.0f;
     if (FIXED) {
-        const int sh = fixed_point_shift(level_absmax[l], n_live, size, hr_state, l);    // units per 1.0 = 2^sh
+        // units per 1.0 = 2^sh: given by the caller (job-wide units of a data-parallel step) or derived here; the level's
+        // first workgroup leaves it for the replica reduction
+        const int sh = shifts_in ? shifts_in[l] : fixed_point_shift(level_absmax[l], n_live, size, hr_state, l);
         cx.to_fixed = ldexpf(1.0f, sh);
         from_fixed = ldexpf(1.0f, -sh);
+        if (shifts_ws && t == 0u && rep == 0 && threadIdx.x == 0) shifts_ws[l] = sh;
     }
     const float2* g_l = dfeat + (int64_t)l * n;
     bool coded = codes && tp.code_slot[l] >= 0;
@@ -816,6 +832,9 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     const float2* src = reinterpret_cast<const float2*>(lds_tile);
     float2* out = (R > 1) ? ws + tp.ws_off[l] + (int64_t)rep * size : grad + gp.offset[l];
     const bool acc = (R == 1) && tp.accumulate;
+    // fixed point: replica slabs -- and, in raw mode, the table itself -- receive the integer fields, so that replicas
+    // (and the ranks of a data-parallel step) are added up exactly, in any order
+    const bool int_out = FIXED && (R > 1 || tp.raw_out);
     for (uint32_t j = threadIdx.x; j < (uint32_t)kTileEntries; j += kBwdThreads) {
         uint32_t e;
         if (hashed) e = t * (uint32_t)kTileEntries + j;
@@ -826,9 +845,10 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
             const long long tot = (long long)lds64[j];
             const int32_t lo = (int32_t)(tot & 0xffffffffll);
             const int32_t hi = (int32_t)((tot - (long long)lo) >> 32);
-            v = make_float2((float)lo * from_fixed, (float)hi * from_fixed);
             const int32_t alo = lo < 0 ? -(lo + 1) : lo, ahi = hi < 0 ? -(hi + 1) : hi;
             field_max = max(field_max, max(alo, ahi));
+            if (int_out) { reinterpret_cast<int2*>(out)[e] = make_int2(lo, hi); continue; }
+            v = make_float2((float)lo * from_fixed, (float)hi * from_fixed);
         } else {
             v = src[j];
         }
@@ -839,7 +859,8 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     //  if NO field of ANY tile ends in the band [2^29, 2^32 - 2^29) -- i.e. if the largest sum of the whole table exceeds
     //  7x the level at which smaller sums already raise the flag while none of them lands there)
     if (FIXED && overflow_flag && field_max >= (1 << 29)) atomicOr(overflow_flag, 1);
-    if (FIXED && hr_state) {            // largest |field| of the level, for the feedback (one atomic per wave)
+    if (FIXED && hr_state && R == 1) {  // largest |field| of the level, for the feedback (one atomic per wave; replicated
+                                        // levels report the max of their SUMMED fields from the reduction kernel)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) field_max = max(field_max, __shfl_xor(field_max, off));
         if ((threadIdx.x & 63) == 0 && field_max > 0) atomicMax(&hr_state[PERF_MAX_LEVELS + l], field_max);
@@ -928,34 +949,140 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_unfix_kernel(GridParams gp, 
     }
 }
 
-// sum the replica slabs (ws[level][replica][entry]) of the replicated (coarse) levels into the gradient table
+// sum the replica slabs (ws[level][replica][entry]) of the replicated (coarse) levels into the gradient table; the
+// workgroup that finishes last applies the headroom feedback (hr_state: [adjustments][largest fields][done counter])
 __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp, TileParams tp, const float2* __restrict__ ws,
-                                                                  float2* __restrict__ grad, int32_t* __restrict__ hr_state) {
+                                                                  float2* __restrict__ grad, int32_t* __restrict__ hr_state,
+                                                                  const int32_t* __restrict__ shifts, int fixed,
+                                                                  int32_t* __restrict__ overflow_flag) {
     const int l = blockIdx.y;
-    if (l == gp.n_levels) {
-        // ---- headroom feedback (one thread per level): keep the largest field of a level between 2^23 and 2^27 units.
-        //      Above: add the excess bits at once (+1); below: give one bit back per call.  Deterministic: the state is a
-        //      function of the call history only.
-        if (hr_state && blockIdx.x == 0 && (int)threadIdx.x < gp.n_levels) {
-            const int fm = hr_state[PERF_MAX_LEVELS + threadIdx.x];
-            int adj = hr_state[threadIdx.x];
-            if (fm >= (1 << 27)) adj += (32 - __clz(fm)) - 27 + 1;
-            else if (fm < (1 << 23) && adj > -24) adj -= 1;
-            hr_state[threadIdx.x] = adj;
-            hr_state[PERF_MAX_LEVELS + threadIdx.x] = 0;
-        }
-        return;
-    }
     const int R = tp.replicas_of[l];
-    if (l >= gp.n_levels || R <= 1) return;
-    const uint32_t size = gp.size[l];
-    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < size; e += gridDim.x * 256) {
-        const float2* p = ws + tp.ws_off[l] + e;
-        float sx = 0.f, sy = 0.f;
-        for (int r = 0; r < R; ++r) { const float2 v = p[(int64_t)r * size]; sx += v.x; sy += v.y; }
-        float2* o = grad + gp.offset[l] + e;
-        if (tp.accumulate) { float2 c = *o; sx += c.x; sy += c.y; }
-        *o = make_float2(sx, sy);
+    if (R > 1) {
+        const uint32_t size = gp.size[l];
+        const float from_fixed = fixed ? ldexpf(1.0f, -shifts[l]) : 1.0f;
+        int32_t field_max = 0;
+        for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < size; e += gridDim.x * 256) {
+            float2* o = grad + gp.offset[l] + e;
+            if (fixed) {
+                const int2* p = reinterpret_cast<const int2*>(ws + tp.ws_off[l]) + e;
+                int32_t sx = 0, sy = 0;
+                for (int r = 0; r < R; ++r) { const int2 v = p[(int64_t)r * size]; sx += v.x; sy += v.y; }
+                const int32_t ax = sx < 0 ? -(sx + 1) : sx, ay = sy < 0 ? -(sy + 1) : sy;
+                field_max = max(field_max, max(ax, ay));
+                if (tp.raw_out) { *reinterpret_cast<int2*>(o) = make_int2(sx, sy); continue; }
+                float fx = (float)sx * from_fixed, fy = (float)sy * from_fixed;
+                if (tp.accumulate) { const float2 c = *o; fx += c.x; fy += c.y; }
+                *o = make_float2(fx, fy);
+            } else {
+                const float2* p = ws + tp.ws_off[l] + e;
+                float sx = 0.f, sy = 0.f;
+                for (int r = 0; r < R; ++r) { const float2 v = p[(int64_t)r * size]; sx += v.x; sy += v.y; }
+                if (tp.accumulate) { const float2 c = *o; sx += c.x; sy += c.y; }
+                *o = make_float2(sx, sy);
+            }
+        }
+        if (fixed) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) field_max = max(field_max, __shfl_xor(field_max, off));
+            if ((threadIdx.x & 63) == 0 && field_max > 0) {
+                if (overflow_flag && field_max >= (1 << 29)) atomicOr(overflow_flag, 1);
+                if (hr_state) atomicMax(&hr_state[PERF_MAX_LEVELS + l], field_max);
+            }
+        }
+    }
+    if (!hr_state) return;
+    // ---- headroom feedback by the last workgroup to get here (every workgroup of the launch takes a ticket)
+    __shared__ int last_block;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_block = (atomicAdd(&hr_state[2 * PERF_MAX_LEVELS], 1) == (int)(gridDim.x * gridDim.y) - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_block) return;
+    __threadfence();
+    if ((int)threadIdx.x < gp.n_levels) {
+        const int fm = atomicMax(&hr_state[PERF_MAX_LEVELS + threadIdx.x], 0);     // (an atomic read: the value sits in L2)
+        hr_state[threadIdx.x] = headroom_feedback(hr_state[threadIdx.x], fm);
+        hr_state[PERF_MAX_LEVELS + threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) hr_state[2 * PERF_MAX_LEVELS] = 0;
+}
+
+// ---- job-wide fixed-point units for data-parallel training ----------------------------------------------------------------
+// Every rank of a data-parallel step scatters ITS samples into integer fields; the ranks' tables can be added up exactly
+// (an integer reduce-scatter) -- and equal the single-process table bit for bit -- iff all ranks use the units the single
+// process would: derived from the job-wide max |dfeat| per level, the job-wide live sample count and the headroom state
+// driven by the largest field of the SUMMED table of the previous step.  Ranks exchange one small block of statistics
+// (perf_dp_stats_pack -> all-gather -> perf_dp_units) between the MLP backward and the grid backward.
+__global__ void dp_stats_pack_kernel(const float* __restrict__ level_absmax, const int32_t* __restrict__ field_max_prev,
+                                     const int64_t* __restrict__ n_dev, int64_t n, int32_t* __restrict__ stats) {
+    const int i = threadIdx.x;
+    if (i < PERF_MAX_LEVELS) {
+        stats[i] = __float_as_int(level_absmax[i]);
+        stats[PERF_MAX_LEVELS + i] = field_max_prev ? field_max_prev[i] : -1;
+    } else if (i == 2 * PERF_MAX_LEVELS) {
+        const int64_t live = live_count(n, n_dev);
+        stats[i] = (int32_t)(live & 0xffffffffll);
+        stats[i + 1] = (int32_t)(live >> 32);
+    } else if (i > 2 * PERF_MAX_LEVELS + 1 && i < PERF_DP_STATS) {
+        stats[i] = 0;
+    }
+}
+
+__global__ void dp_units_kernel(GridParams gp, const int32_t* __restrict__ stats_all, int world, int32_t* __restrict__ hr_state,
+                                int32_t* __restrict__ shifts, int64_t* __restrict__ n_total_out) {
+    __shared__ long long total_s;
+    if (threadIdx.x == 0) {
+        long long tot = 0;
+        for (int r = 0; r < world; ++r) {
+            const int32_t* st = stats_all + (int64_t)r * PERF_DP_STATS + 2 * PERF_MAX_LEVELS;
+            tot += (long long)(uint32_t)st[0] | ((long long)st[1] << 32);
+        }
+        total_s = tot;
+        if (n_total_out) n_total_out[0] = tot;
+    }
+    __syncthreads();
+    const int l = threadIdx.x;
+    if (l >= gp.n_levels) return;
+    float am = 0.f;
+    int fm = -1;
+    for (int r = 0; r < world; ++r) {
+        const int32_t* st = stats_all + (int64_t)r * PERF_DP_STATS;
+        am = fmaxf(am, __int_as_float(st[l]));
+        fm = max(fm, st[PERF_MAX_LEVELS + l]);
+    }
+    if (fm >= 0) hr_state[l] = headroom_feedback(hr_state[l], fm);        // (-1: no previous call, nothing to feed back)
+    shifts[l] = fixed_point_shift(am, total_s, gp.size[l], hr_state, l);
+}
+
+// int32 field pairs of table entries [entry_lo, entry_hi) -> fp32 gradients, in place; per-level largest |field| of the
+// slice (atomicMax into field_max, zeroed by the caller) and the overflow flag
+__global__ __launch_bounds__(256) void fixed_unfix_kernel(GridParams gp, int32_t* __restrict__ buf, int64_t entry_lo, int64_t entry_hi,
+                                                          const int32_t* __restrict__ shifts, int32_t* __restrict__ field_max,
+                                                          int32_t* __restrict__ overflow_flag) {
+    __shared__ int32_t fm_s[PERF_MAX_LEVELS];
+    if (threadIdx.x < PERF_MAX_LEVELS) fm_s[threadIdx.x] = 0;
+    __syncthreads();
+    int cur_l = 0, cur_m = 0;            // a thread's entries ascend: it stays in one level for long runs
+    float from_fixed = ldexpf(1.0f, -shifts[0]);
+    for (int64_t e = entry_lo + (int64_t)blockIdx.x * 256 + threadIdx.x; e < entry_hi; e += (int64_t)gridDim.x * 256) {
+        if (cur_l + 1 < gp.n_levels && (uint64_t)e >= gp.offset[cur_l + 1]) {
+            if (cur_m > 0) atomicMax(&fm_s[cur_l], cur_m);
+            while (cur_l + 1 < gp.n_levels && (uint64_t)e >= gp.offset[cur_l + 1]) ++cur_l;
+            cur_m = 0;
+            from_fixed = ldexpf(1.0f, -shifts[cur_l]);
+        }
+        int2* p = reinterpret_cast<int2*>(buf) + (e - entry_lo);
+        const int2 v = *p;
+        if (v.x == 0 && v.y == 0) continue;                  // (integer 0 is 0.0f)
+        *reinterpret_cast<float2*>(p) = make_float2((float)v.x * from_fixed, (float)v.y * from_fixed);
+        const int32_t ax = v.x < 0 ? -(v.x + 1) : v.x, ay = v.y < 0 ? -(v.y + 1) : v.y;
+        cur_m = max(cur_m, max(ax, ay));
+    }
+    if (cur_m > 0) atomicMax(&fm_s[cur_l], cur_m);
+    __syncthreads();
+    if (threadIdx.x < PERF_MAX_LEVELS && fm_s[threadIdx.x] > 0) {
+        if (field_max) atomicMax(&field_max[threadIdx.x], fm_s[threadIdx.x]);
+        if (overflow_flag && fm_s[threadIdx.x] >= (1 << 29)) atomicOr(overflow_flag, 1);
     }
 }
 
@@ -1177,6 +1304,8 @@ static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
     return slots;
 }
 
+constexpr int64_t kShiftBytes = 256;        // per-level shifts the owners leave for the replica reduction
+
 extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n) {
     GridParams gp;
     if (fill_params(grid, &gp)) return -1;
@@ -1185,30 +1314,38 @@ extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid,
     plan_tiles(gp, false, &tp, &nb, &ws);
     plan_tiles(gp, true, &tp, &nb, &ws2);
     const int slots = plan_codes(gp, n, &tp);
-    return (ws > ws2 ? ws : ws2) * (int64_t)sizeof(float2) + 16 + kDbgBytes + (int64_t)slots * tp.n_pad * 4 +
+    return (ws > ws2 ? ws : ws2) * (int64_t)sizeof(float2) + 16 + kShiftBytes + kDbgBytes + (int64_t)slots * tp.n_pad * 4 +
            (slots ? div_up(n, kCodeSamplesPerBlock) * 4 : 0);
 }
 
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
                                  float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
-                                 int32_t* overflow_flag, int32_t* headroom_state, void* workspace, int64_t workspace_bytes,
-                                 void* stream) {
+                                 int32_t* overflow_flag, int32_t* headroom_state, const int32_t* shifts_dev, int raw_fields,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
     GridParams gp;
     int rc = fill_params(grid, &gp);
     if (rc) return rc;
     PERF_REQUIRE(grad_table, "NULL pointer");
     PERF_REQUIRE(n == 0 || (x01 && dfeat), "NULL pointer");
+    const bool fixed = level_absmax != nullptr || shifts_dev != nullptr;
+    PERF_REQUIRE(!shifts_dev || !headroom_state, "perf_hashgrid_bwd: given units (shifts_dev) exclude the headroom feedback");
+    PERF_REQUIRE(!raw_fields || (fixed && !accumulate), "perf_hashgrid_bwd: raw fields need the fixed-point mode and accumulate == 0");
     TileParams tp;
     int n_blocks = 0;
     int64_t ws_entries = 0;
-    plan_tiles(gp, level_absmax != nullptr, &tp, &n_blocks, &ws_entries);
-    PERF_REQUIRE(ws_entries == 0 || (workspace && workspace_bytes >= ws_entries * (int64_t)sizeof(float2)),
-                 "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(ws_entries * sizeof(float2)));
+    plan_tiles(gp, fixed, &tp, &n_blocks, &ws_entries);
+    PERF_REQUIRE(!(raw_fields || shifts_dev) || tp.atomic_levels == 0u,
+                 "perf_hashgrid_bwd: raw fields / given units are not available for levels beyond 4 M entries");
     tp.accumulate = accumulate;
+    tp.raw_out = raw_fields ? 1 : 0;
     tp.dbg_off = 0;
-    int64_t slab_entries = ws_entries;      // workspace layout: [replica slabs (larger of both modes)][debug slots][tile codes]
-    { TileParams t2; int nb2; int64_t w2; plan_tiles(gp, level_absmax == nullptr, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2; }
-    const int64_t dbg_at = (slab_entries * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
+    int64_t slab_entries = ws_entries;      // workspace layout: [replica slabs (larger of both modes)][shifts][debug slots][tile codes]
+    { TileParams t2; int nb2; int64_t w2; plan_tiles(gp, !fixed, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2; }
+    const int64_t shifts_at = (slab_entries * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
+    PERF_REQUIRE(workspace && workspace_bytes >= shifts_at + kShiftBytes,
+                 "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(shifts_at + kShiftBytes));
+    int32_t* shifts_ws = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + shifts_at);
+    const int64_t dbg_at = shifts_at + kShiftBytes;
     static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
     if (dbg_env && workspace_bytes >= dbg_at + kDbgBytes) tp.dbg_off = dbg_at / (int64_t)sizeof(float2);
     // tile codes of the hashed levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
@@ -1217,7 +1354,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     uint32_t* codes = nullptr;
     uint32_t* escape = nullptr;
     const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
-    if (slots > 0 && n > 0 && !no_codes && workspace && ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0) &&
+    if (slots > 0 && n > 0 && !no_codes && ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0) &&
         workspace_bytes >= codes_at + (int64_t)slots * tp.n_pad * 4 + esc_words * 4) {
         codes = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + codes_at);
         escape = codes + (int64_t)slots * tp.n_pad;
@@ -1235,12 +1372,14 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     });
     if (n_blocks == 0) {
         // every level goes through the atomics fallback
-    } else if (level_absmax)
+    } else if (fixed)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
-            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, headroom_state, codes, escape, n, n_dev);
+            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, headroom_state,
+            shifts_dev, shifts_ws, codes, escape, n, n_dev);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
-            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, nullptr, codes, escape, n, n_dev);
+            gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, nullptr, nullptr, nullptr,
+            codes, escape, n, n_dev);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (tp.atomic_levels && n > 0) {
         if (!accumulate)
@@ -1265,11 +1404,49 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
             if ((tp.atomic_levels >> l) & 1u) (void)hipMemsetAsync(grad_table + 2 * gp.offset[l], 0, (size_t)gp.size[l] * 2 * sizeof(float), as_stream(stream));
     }
     const bool adapt = level_absmax && headroom_state && (n_blocks > 0 || (tp.atomic_levels && n > 0 && !accumulate));
-    if (ws_entries > 0 || adapt) {      // (+ one row of blocks for the headroom feedback)
-        hashgrid_bwd_reduce_kernel<<<dim3(64, gp.n_levels + 1), dim3(256), 0, as_stream(stream)>>>(
-            gp, tp, (const float2*)workspace, (float2*)grad_table, adapt ? headroom_state : nullptr);
+    if (ws_entries > 0 || adapt) {      // replica sums, and the headroom feedback by the last workgroup
+        hashgrid_bwd_reduce_kernel<<<dim3(64, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
+            gp, tp, (const float2*)workspace, (float2*)grad_table, adapt ? headroom_state : nullptr,
+            shifts_dev ? shifts_dev : shifts_ws, fixed ? 1 : 0, overflow_flag);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(reduce)");
     }
+    return PERF_OK;
+}
+
+extern "C" int perf_dp_stats_pack(const float* level_absmax, const int32_t* field_max_prev, const int64_t* n_dev, int64_t n,
+                                  int32_t* stats_out, void* stream) {
+    PERF_REQUIRE(level_absmax && stats_out, "NULL pointer");
+    dp_stats_pack_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(level_absmax, field_max_prev, n_dev, n, stats_out);
+    PERF_LAUNCH_CHECK("perf_dp_stats_pack");
+    return PERF_OK;
+}
+
+extern "C" int perf_dp_units(const perf_grid_desc* grid, const int32_t* stats_all, int32_t world, int32_t* headroom_state,
+                             int32_t* shifts_out, int64_t* n_total_out, void* stream) {
+    GridParams gp;
+    int rc = fill_params(grid, &gp);
+    if (rc) return rc;
+    PERF_REQUIRE(stats_all && headroom_state && shifts_out && world >= 1, "perf_dp_units: bad arguments");
+    dp_units_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(gp, stats_all, world, headroom_state, shifts_out, n_total_out);
+    PERF_LAUNCH_CHECK("perf_dp_units");
+    return PERF_OK;
+}
+
+extern "C" int perf_fixed_unfix(const perf_grid_desc* grid, void* fields, int64_t entry_lo, int64_t entry_hi,
+                                const int32_t* shifts_dev, int32_t* field_max, int32_t* overflow_flag, void* stream) {
+    GridParams gp;
+    int rc = fill_params(grid, &gp);
+    if (rc) return rc;
+    PERF_REQUIRE(fields && shifts_dev, "NULL pointer");
+    const int64_t total = (int64_t)(gp.offset[gp.n_levels - 1] + gp.size[gp.n_levels - 1]);
+    PERF_REQUIRE(entry_lo >= 0 && entry_lo <= entry_hi && entry_hi <= total, "perf_fixed_unfix: bad entry range");
+    if (field_max) PERF_REQUIRE(hipMemsetAsync(field_max, 0, PERF_MAX_LEVELS * sizeof(int32_t), as_stream(stream)) == hipSuccess, "memset failed");
+    if (entry_hi == entry_lo) return PERF_OK;
+    int64_t blocks = div_up(entry_hi - entry_lo, 256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    fixed_unfix_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(gp, (int32_t*)fields, entry_lo, entry_hi, shifts_dev,
+                                                                                       field_max, overflow_flag);
+    PERF_LAUNCH_CHECK("perf_fixed_unfix");
     return PERF_OK;
 }
 

@@ -283,20 +283,32 @@ static int raygen_launch(const float* pose, const float* pose_dev, int32_t heigh
 // one thread: the bookkeeping of a sync-free training step (see perf_step_bookkeeping in the header)
 namespace perf {
 __global__ void step_bookkeeping_kernel(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
-                                        const int64_t* n_marched_dev, const int64_t* n_kept_dev) {
-    if (step_dev && (!gate_dev || gate_dev[0] > 0)) step_dev[0] += 1;
+                                        const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
+                                        int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out) {
+    const int64_t marched = n_marched_dev ? n_marched_dev[0] : 0;
+    const bool has_samples = !gate_dev || gate_dev[0] > 0;
+    const bool overflow = (overflow_flag && overflow_flag[0] != 0) || (remote_flags && remote_flags[0] > 0.f);
+    const bool truncated = capacity > 0 && marched > capacity;
+    const bool take = has_samples && !overflow && !truncated;
+    if (step_dev && take) step_dev[0] += 1;
+    if (eff_gate_out) eff_gate_out[0] = take ? 1 : 0;
+    if (overflow_flag && overflow_flag[0] != 0) overflow_flag[0] = 0;      // consumed: counted below, the step is skipped
     if (counters) {
-        if (n_marched_dev) counters[0] += n_marched_dev[0];
+        counters[0] += marched;
         if (n_kept_dev) counters[1] += n_kept_dev[0];
         counters[2] += 1;
+        if (marched > counters[3]) counters[3] = marched;
+        if (has_samples && overflow) counters[4] += 1;
+        if (has_samples && truncated) counters[5] += 1;
     }
 }
 }  // namespace perf
 
 extern "C" int perf_step_bookkeeping(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
-                                     const int64_t* n_marched_dev, const int64_t* n_kept_dev, void* stream) {
+                                     const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
+                                     int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out, void* stream) {
     hipLaunchKernelGGL(perf::step_bookkeeping_kernel, dim3(1), dim3(1), 0, as_stream(stream), step_dev, gate_dev, counters,
-                       n_marched_dev, n_kept_dev);
+                       n_marched_dev, n_kept_dev, capacity, overflow_flag, remote_flags, eff_gate_out);
     PERF_LAUNCH_CHECK("perf_step_bookkeeping");
     return PERF_OK;
 }

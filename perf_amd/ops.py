@@ -115,12 +115,22 @@ def adam_step_dev(p, m, v, g, step_dev, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8
           _stream())
 
 
-def step_bookkeeping(step_dev=None, gate=None, counters=None, n_marched=None, n_kept=None):
-    """One launch: step_dev += (gate > 0 or gate is None); counters[0:3] += (n_marched, n_kept, 1).  All device tensors."""
-    ref = next(t for t in (step_dev, counters) if t is not None)
+def step_bookkeeping(step_dev=None, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0, overflow=None,
+                     remote_flags=None, eff_gate=None):
+    """One launch (perf_step_bookkeeping): decides whether the optimizer step is TAKEN (samples present, no fixed-point
+    overflow flag -- local int32 `overflow` or the float sum `remote_flags` of the other ranks' --, batch not truncated at
+    `capacity`), advances step_dev and writes eff_gate (int64 [1]) accordingly, accumulates counters (int64 [8])."""
+    ref = next(t for t in (step_dev, counters, eff_gate) if t is not None)
     if not ref.is_cuda:
         raise _lib.PerfError('perf_amd ops need CUDA (HIP) tensors; there is no CPU path')
-    _call('perf_step_bookkeeping', _p(step_dev), _nd(gate), _nd(counters), _nd(n_marched), _nd(n_kept), _stream())
+    _call('perf_step_bookkeeping', _p(step_dev), _nd(gate), _nd(counters), _nd(n_marched), _nd(n_kept), int(capacity or 0),
+          _p(overflow), _p(remote_flags), _nd(eff_gate), _stream())
+
+
+def step_counters(device):
+    """Zeroed int64 [8] block of perf_step_bookkeeping: {marched, kept, steps, max marched of one batch, steps skipped for
+    fixed-point overflow, steps skipped for truncation, 0, 0}."""
+    return torch.zeros(_lib.STEP_COUNTERS, dtype=torch.int64, device=device)
 
 
 # ---- positions -----------------------------------------------------------------------------------
@@ -188,31 +198,65 @@ def overflow_flag(device):
 
 def headroom_state(device):
     """Zeroed state block of the fixed-point headroom feedback (one per table that is trained, see perf_hashgrid_bwd)."""
-    return torch.zeros(2 * _lib.MAX_LEVELS, dtype=torch.int32, device=device)
+    return torch.zeros(_lib.HEADROOM_STATE_WORDS, dtype=torch.int32, device=device)
 
 
 def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False, level_absmax=None, n_dev=None, use_codes=True,
-                 hr_state=None):
+                 hr_state=None, shifts=None, raw_fields=False):
     """dfeat [L, n, 2] f32 -> gradient table [total*2] f32.  `out` (a contiguous fp32 view, e.g. the grid
     part of a flat gradient) is overwritten, or added to when accumulate=True.  level_absmax (device, 16 floats
-    from mlp_bwd) selects the packed fixed-point accumulation."""
+    from mlp_bwd) selects the packed fixed-point accumulation.  shifts (device int32 [24]): job-wide units of a
+    data-parallel step (dp_units) instead of level_absmax / hr_state; raw_fields: `out` receives the int32 field pairs
+    (same storage; view it as int32) for an integer reduce-scatter followed by fixed_unfix."""
     n = x01.shape[0]
     if out is None:
         out = torch.empty(grid.n_params, dtype=torch.float32, device=x01.device)
         accumulate = False
     d = grid.desc()
+    fixed = level_absmax is not None or shifts is not None
     # (a workspace without room for the tile codes selects the position-streaming owners: use_codes=False, tests)
     ws_bytes = _lib.load().perf_hashgrid_bwd_workspace_bytes(ctypes.byref(d), n if use_codes else 0)
     ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=x01.device)
-    flag = overflow_flag(x01.device) if level_absmax is not None else None
+    flag = overflow_flag(x01.device) if fixed else None
     _call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),
-              n, _nd(n_dev), int(bool(accumulate)), _p(level_absmax), _p(flag), _p(hr_state if level_absmax is not None else None),
+              n, _nd(n_dev), int(bool(accumulate)), _p(level_absmax), _p(flag),
+              _p(hr_state if (level_absmax is not None and shifts is None) else None), _p(shifts), int(bool(raw_fields)),
               _p(ws), ws_bytes, _stream())
     return out
 
 
-def hashgrid_bwd_into(grid, x01, dfeat, out, level_absmax=None, n_dev=None, hr_state=None):
-    return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False, level_absmax=level_absmax, n_dev=n_dev, hr_state=hr_state)
+def hashgrid_bwd_into(grid, x01, dfeat, out, level_absmax=None, n_dev=None, hr_state=None, shifts=None, raw_fields=False):
+    return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False, level_absmax=level_absmax, n_dev=n_dev, hr_state=hr_state,
+                        shifts=shifts, raw_fields=raw_fields)
+
+
+# ---- job-wide fixed-point units of a data-parallel step -------------------------------------------------------------------
+def dp_stats_pack(level_absmax, field_max_prev, n_dev, n, out=None):
+    """-> int32 [PERF_DP_STATS]: this rank's block of the statistics every rank all-gathers before its grid backward."""
+    if out is None:
+        out = torch.empty(_lib.DP_STATS, dtype=torch.int32, device=level_absmax.device)
+    _call('perf_dp_stats_pack', _p(level_absmax), _p(field_max_prev), _nd(n_dev), int(n), _p(out), _stream())
+    return out
+
+
+def dp_units(grid: GridConfig, stats_all, world, hr_state, shifts=None, n_total=None):
+    """stats_all int32 [world, PERF_DP_STATS] -> (shifts int32 [24], n_total int64 [1]); applies the headroom feedback to hr_state."""
+    dev = stats_all.device
+    if shifts is None:
+        shifts = torch.empty(_lib.MAX_LEVELS, dtype=torch.int32, device=dev)
+    if n_total is None:
+        n_total = torch.empty(1, dtype=torch.int64, device=dev)
+    d = grid.desc()
+    _call('perf_dp_units', ctypes.byref(d), _p(stats_all), int(world), _p(hr_state), _p(shifts), _nd(n_total), _stream())
+    return shifts, n_total
+
+
+def fixed_unfix(grid: GridConfig, fields, entry_lo, entry_hi, shifts, field_max=None, flag=None):
+    """In place: int32 field pairs of table entries [entry_lo, entry_hi) (`fields`: a contiguous 4-byte tensor holding them)
+    -> fp32 gradients; field_max int32 [24] receives the slice's largest |field| per level."""
+    d = grid.desc()
+    _call('perf_fixed_unfix', ctypes.byref(d), _p(fields), int(entry_lo), int(entry_hi), _p(shifts), _p(field_max), _p(flag), _stream())
+    return fields
 
 
 def hashgrid_corners(grid: GridConfig, x01):

@@ -197,8 +197,14 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros_like(p.data)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=p.device)
         self.lr_dev = torch.zeros(1, dtype=torch.float32, device=p.device)
+        self.eff_gate = torch.zeros(1, dtype=torch.int64, device=p.device)
         self.capturing = False
         self.w16 = torch.empty(p.numel(), dtype=ops.torch_dtype(net.dtype_name), device=p.device)
+        self.w16.copy_(net.working_copy())         # (a gated-off first step must leave a valid working copy behind)
+
+    @property
+    def p(self):
+        return self.net.params.data
 
     @property
     def step_count(self):
@@ -207,22 +213,54 @@ class FusedAdam:
     def zero_grad(self):
         pass                                       # the step consumes the gradient and drops it
 
-    def step(self, gate=None, counters=None, n_marched=None, n_kept=None):
-        """gate (device int64 [1], optional): the number of samples behind this gradient; the step is skipped -- step count
-        included -- when it is 0, as the reference skips batches without samples (nerf.py:204-206).  counters / n_marched /
-        n_kept: see ops.step_bookkeeping (THIS rank's sample statistics, accumulated by the same launch that advances the
-        step count; n_kept defaults to the gate, which under data parallelism is the whole job's count instead)."""
+    def refresh_lr(self):
+        if not self.capturing:
+            self.lr_dev.fill_(self.param_groups[0]['lr'])      # under capture the replay wrapper refreshes lr_dev instead
+
+    def step(self, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0):
+        """gate (device int64 [1], optional): the number of samples behind this gradient.  The step is TAKEN unless the gate
+        is 0 (the reference skips batches without samples, nerf.py:204-206), the fixed-point grid backward raised its
+        overflow flag, or the batch was truncated at `capacity` samples -- decided on the device by perf_step_bookkeeping,
+        which also advances the step count and accumulates `counters` (THIS rank's statistics; n_kept defaults to the gate)."""
         p = self.net.params
         if p.grad is None:
             return
         g = self.param_groups[0]
-        if not self.capturing:
-            self.lr_dev.fill_(g['lr'])             # under capture the replay wrapper refreshes lr_dev instead
-        ops.step_bookkeeping(self.step_dev, gate, counters, n_marched, n_kept if n_kept is not None else gate)
+        self.refresh_lr()
+        flag = ops.overflow_flag(p.device) if _tcnn.GRID_GRAD_ACCUM == 'fixed' else None
+        ops.step_bookkeeping(self.step_dev, gate, counters, n_marched, n_kept if n_kept is not None else gate, capacity=capacity,
+                             overflow=flag, eff_gate=self.eff_gate)
         ops.adam_step_dev(p.data, self.exp_avg, self.exp_avg_sq, p.grad[:p.numel()], self.step_dev, self.lr_dev, g['betas'][0],
-                          g['betas'][1], g['eps'], w16=self.w16, zero_grad=False, gate=gate)
+                          g['betas'][1], g['eps'], w16=self.w16, zero_grad=False, gate=self.eff_gate)
         p.grad = None                              # the next backward installs a fresh gradient (no accumulate pass)
         self.net.set_working_copy(self.w16)        # the kernel wrote the refreshed 16-bit copy
+
+
+class _HipStepKernels:
+    """The compute steps perf_amd.dp.ShardedExchange injects, on the gfx950 kernels, for one network."""
+
+    def __init__(self, net, optimizer):
+        self.net, self.opt = net, optimizer
+
+    def stats_pack(self, level_absmax, field_max_prev, n_dev, n, out):
+        ops.dp_stats_pack(level_absmax, field_max_prev, n_dev, n, out=out)
+
+    def units(self, stats_all, world, shifts, n_total):
+        ops.dp_units(self.net.grid, stats_all, world, self.net.headroom_state(), shifts, n_total)
+
+    def unfix(self, shard, lo, hi, shifts, field_max, flag):
+        ops.fixed_unfix(self.net.grid, shard, lo, hi, shifts, field_max, flag)
+
+    def bookkeeping(self, step_dev, gate, counters, n_marched, n_kept, capacity, overflow, remote_flags, eff_gate):
+        ops.step_bookkeeping(step_dev, gate, counters, n_marched, n_kept, capacity=capacity, overflow=overflow,
+                             remote_flags=remote_flags, eff_gate=eff_gate)
+
+    def adam(self, p, m, v, g, w16, step_dev, lr_dev, gate):
+        b = self.opt.param_groups[0]
+        ops.adam_step_dev(p, m, v, g, step_dev, lr_dev, b['betas'][0], b['betas'][1], b['eps'], w16=w16, zero_grad=False, gate=gate)
+
+    def overflow_flag(self):
+        return ops.overflow_flag(self.net.params.device)
 
 
 class NeRFScene:
@@ -262,9 +300,15 @@ class NeRFScene:
         self.reuse_sampling_features = False
         self._geo_pre = None
         self._ratio_dev = torch.zeros((), dtype=torch.float32, device='cuda')   # distortion-loss ramp min(2*progress, 1)
-        # device-side sample statistics {marched, kept, steps} (int64 [3]); None = not collected.  bench.py reads them
-        # once after the timed region: throughput is counted in samples that were really evaluated and composited.
-        self.sample_counters = None
+        # device-side statistics of perf_step_bookkeeping (int64 [8]): {marched, kept, steps, largest batch, steps skipped for
+        # fixed-point overflow, steps skipped for truncation}.  bench.py reads them once after the timed region: throughput is
+        # counted in samples that were really evaluated and composited; _poll_health reads them every 64 steps.
+        self.sample_counters = ops.step_counters('cuda')
+        self._health_seen = [0, 0]     # overflow / truncation skips already reported
+        # Data parallelism: 'sharded' = int32 reduce-scatter of the fixed-point gradient fields -> Adam on this rank's slice
+        # -> all-gather of the 16-bit working copy (perf_amd/dp.py; needs the fused Adam, the explicit step chains and the
+        # fixed-point grid backward); 'allreduce' = one all-reduce of the flat fp32 (or bf16) gradient, Adam everywhere.
+        self.dp_mode = 'sharded'
 
     # ---- distributed helpers ---------------------------------------------------------------------
     @staticmethod
@@ -367,7 +411,7 @@ class NeRFScene:
         if use_graphs is None:
             use_graphs = self.graph_steps
         sync_free = self.fused_adam and self.fused_steps          # capacity-sized arrays + device-side counts: no host read-back
-        use_graphs = bool(use_graphs) and sync_free and self._dist()[0] is None      # (the all-reduce of a DP step stays eager)
+        use_graphs = bool(use_graphs) and sync_free and self.dp_graph_ok()
         saved_capacity = self.renderer.sample_capacity
         if sync_free and saved_capacity is None:
             per_rank = self.train_conf.pixel_loss_batch_size // max(self._dist()[2], 1)
@@ -379,10 +423,49 @@ class NeRFScene:
             app_optimizer = self.make_optimizer(self.nerf.app_mlp, self.train_conf.app_optimizer.init_lr)
             self._run_phase('app', app_optimizer, self.train_conf.app_optimizer, app_res_iters, sup_pool, callback,
                             use_graphs, lambda i: i / app_res_iters)
+            self.sync_params()            # (sharded data parallelism: every rank leaves the episode with the full fp32 master)
         finally:
             self.renderer.sample_capacity = saved_capacity
 
     EAGER_HEAD = 3
+
+    def dp_graph_ok(self):
+        """Can a training step be captured in a hipGraph in this process?  Single process: yes.  Data parallel: only the
+        sharded exchange over RCCL, and only after a probe -- a tiny all-reduce on a group of its own, captured and replayed
+        -- came back right on EVERY rank (the verdicts are agreed on with one eager all-reduce).  PERF_DP_GRAPH=0 opts out.
+        Collective: every rank must call it at the same point."""
+        dist, rank, world = self._dist()
+        if dist is None:
+            return True
+        cached = getattr(self, '_dp_graph_verdict', None)
+        if cached is not None:
+            return cached
+        import os
+        ok = (self.dp_mode == 'sharded' and self.fused_adam and _tcnn.GRID_GRAD_ACCUM == 'fixed'
+              and dist.get_backend() == 'nccl' and os.environ.get('PERF_DP_GRAPH', '1') != '0')
+        if ok:
+            try:
+                group = dist.new_group()
+                t = torch.ones(1024, device='cuda')
+                dist.all_reduce(t, group=group)                  # (communicator set-up happens outside the capture)
+                torch.cuda.synchronize()
+                t.fill_(1.0)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    dist.all_reduce(t, group=group)
+                t.fill_(1.0)
+                g.replay()
+                torch.cuda.synchronize()
+                ok = bool(float(t[0].item()) == float(world) and float(t[-1].item()) == float(world))
+            except Exception as e:       # noqa: BLE001 -- any failure means: stay eager
+                import warnings
+                warnings.warn(f'perf_amd: capturing an RCCL collective in a hipGraph failed ({type(e).__name__}: {e}); data-parallel steps stay eager')
+                ok = False
+            v = torch.tensor([1.0 if ok else 0.0], device='cuda')
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            ok = bool(v.item() > 0.5)
+        self._dp_graph_verdict = ok
+        return ok
 
     def _run_phase(self, kind, optimizer, conf, n_iters, sup_pool, callback, use_graphs, progress_of):
         step_fn = self.train_one_step_geo if kind == 'geo' else self.train_one_step_app
@@ -392,6 +475,8 @@ class NeRFScene:
                 graphed = self.make_graphed_step(kind, optimizer, sup_pool, warmup=0)
             if graphed is not None:
                 graphed(self.lr_at(conf, iter_i / n_iters), progress_of(iter_i))
+                if self._dist()[0] is not None:
+                    self._poll_health()            # (single-process replays poll by themselves)
             else:
                 self.update_lr(optimizer, conf, iter_i / n_iters)
                 if kind == 'geo':
@@ -427,24 +512,35 @@ class NeRFScene:
         optimizer.step()
         self._poll_health(net)
 
-    def _poll_health(self, net, n_marched=None):
-        """Every OVERFLOW_CHECK_EVERY eager steps: ONE host read-back of the sticky device-side flags -- the fixed-point
-        overflow flag of the grid backward and the over-capacity flag of the sync-free sampler (n_marched: the batch's
-        marched count, device int64 [1], only used when no sticky flag is collected)."""
+    def _poll_health(self, net=None, n_marched=None, force=False):
+        """Every OVERFLOW_CHECK_EVERY steps: ONE host read-back of the device-side counters (perf_step_bookkeeping).  Steps
+        whose fixed-point grid gradient overflowed or whose batch was truncated at the sample capacity were SKIPPED on the
+        device (never applied); here the host hears about them: it warns, switches the accumulation to fp32 after three
+        polls in a row with overflows, and doubles a capacity that proved too small.  -> {'recapture': bool} for callers
+        that replay a captured graph (mode and capacity are baked into it)."""
         self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
-        if self._capturing or self._steps_since_check < OVERFLOW_CHECK_EVERY:
-            return
+        if self._capturing or (self._steps_since_check < OVERFLOW_CHECK_EVERY and not force):
+            return {'recapture': False}
         self._steps_since_check = 0
-        if _tcnn.GRID_GRAD_ACCUM == 'fixed':
-            _tcnn.check_fixed_point_overflow(net.params.device)
+        import warnings
+        c = self.sample_counters.tolist()
+        seen = self._health_seen
+        new_ovf = c[4] - seen[0] if c[4] >= seen[0] else c[4]          # (bench.py zeroes the counters between regions)
+        new_trunc = c[5] - seen[1] if c[5] >= seen[1] else c[5]
+        self._health_seen = [c[4], c[5]]
+        recapture = False
+        multi = self._dist()[0] is not None
+        # (under data parallelism every rank must keep issuing the same collectives: the accumulation mode never switches)
+        if _tcnn.GRID_GRAD_ACCUM == 'fixed' and _tcnn.note_fixed_point_overflows(new_ovf, sticky_after=10 ** 9 if multi else 3):
+            recapture = True
         cap = self.renderer.sample_capacity
-        if cap is not None and torch.is_tensor(n_marched):
-            worst = int(n_marched.item())
-            if worst > cap:
-                import warnings
-                warnings.warn(f'perf_amd: a training batch evaluated {worst} samples, more than the capacity {cap} '
-                              '(late rays were truncated); doubling the capacity')
-                self.renderer.sample_capacity = 2 * worst
+        if cap is not None and (new_trunc > 0 or c[3] > cap):
+            warnings.warn(f'perf_amd: {new_trunc} training batch(es) marched up to {c[3]} samples, more than the capacity {cap}; '
+                          'their steps were skipped; raising the capacity')
+            self.renderer.sample_capacity = max(2 * cap, int(1.25 * c[3]))
+            self.sample_counters[3] = 0
+            recapture = True
+        return {'recapture': recapture}
 
     def _geo_prefetch(self, sup_pool, rand, generator):
         """Everything of a geometry step that does not depend on the geometry parameters: batch draw, and -- when the
@@ -452,8 +548,11 @@ class NeRFScene:
         rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
         rand = dict(rand or {})
         if self.fused_steps and ('jitter' not in rand or 'noise' not in rand):
-            u = torch.rand(2, rays.o.shape[0], device=rays.o.device)        # the step's two per-ray draws in one launch
-            rand.setdefault('jitter', u[0]); rand.setdefault('noise', u[1].unsqueeze(1))
+            # the step's two per-ray draws in one launch; under data parallelism every rank draws the GLOBAL batch's
+            # values (same seed on every rank) and keeps its slice, like the index stream: the job then trains on the very
+            # batch the single process would
+            u = self._rand_rows(2, rays.o.shape[0], dist_info, rays.o.device)
+            rand.setdefault('jitter', u[0].contiguous()); rand.setdefault('noise', u[1].contiguous().unsqueeze(1))
         st = None
         if self.renderer.early_stop_eps <= 0:
             with torch.no_grad():
@@ -461,6 +560,22 @@ class NeRFScene:
                                                 with_rgb=not (self.fused_steps and self.skip_unused_color))
                 st = st if st is not None else False
         return {'rays': rays, 'gt_depths': gt_depths, 'bs': bs, 'dist_info': dist_info, 'st': st, 'rand': rand}
+
+    @staticmethod
+    def _rand_rows(rows, n_local, dist_info, device):
+        """torch.rand(rows, n_local) single-process; with W ranks the rank's column slice of torch.rand(rows, W * n_local)."""
+        _, rank, world = dist_info
+        if world == 1:
+            return torch.rand(rows, n_local, device=device)
+        return torch.rand(rows, n_local * world, device=device)[:, rank * n_local:(rank + 1) * n_local]
+
+    @staticmethod
+    def _rand_cols(n_local, cols, dist_info, device):
+        """torch.rand(n_local, cols) single-process; with W ranks the rank's row slice of torch.rand(W * n_local, cols)."""
+        _, rank, world = dist_info
+        if world == 1:
+            return torch.rand(n_local, cols, device=device)
+        return torch.rand(n_local * world, cols, device=device)[rank * n_local:(rank + 1) * n_local].contiguous()
 
     # ---- fused steps: explicit kernel chain instead of autograd + ~25 tiny torch ops (same arithmetic) ----------
     def _field_grad(self, net, x01, w16, feat, sel, dout, n_dev=None, extra=0):
@@ -507,12 +622,59 @@ class NeRFScene:
         net.params.grad = grad[:n]                 # (without the count slot of the data-parallel buffer)
         if isinstance(optimizer, FusedAdam):
             optimizer.step(gate=gate, counters=self.sample_counters, n_marched=n_marched,
-                           n_kept=n_kept if torch.is_tensor(n_kept) else None)
+                           n_kept=n_kept if torch.is_tensor(n_kept) else None, capacity=self.renderer.sample_capacity or 0)
         else:
             if gate is None or int(gate.item()) > 0:
                 optimizer.step()
             net.params.grad = None
-        self._poll_health(net, n_marched)
+        self._poll_health(net)
+
+    # ---- data parallelism, sharded mode (perf_amd/dp.py) ---------------------------------------------------------------
+    def _sharded(self, dist_info, optimizer):
+        return (dist_info[0] is not None and self.dp_mode == 'sharded' and isinstance(optimizer, FusedAdam)
+                and _tcnn.GRID_GRAD_ACCUM == 'fixed')
+
+    def _exchange_for(self, net, optimizer, dist_info):
+        ex = getattr(net, '_dp_exchange', None)
+        if ex is None or ex.k.opt is not optimizer:
+            from .dp import Collectives, ShardedExchange
+            dist, rank, world = dist_info
+            ex = ShardedExchange(net.mlp.n_params, net.grid.n_params, world, rank, Collectives(dist), net.params.device,
+                                 ops.torch_dtype(net.dtype_name), _HipStepKernels(net, optimizer))
+            ex.seed_working_copy(net.working_copy())
+            object.__setattr__(net, '_dp_exchange', ex)
+        return ex
+
+    def _dp_sharded_step(self, net, optimizer, dist_info, x01, w16, feat, sel, dout, n_dev, n_marched, early=None, late=None):
+        """Backward + exchange + optimizer of one network under sharded data parallelism: MLP backward -> job-wide units ->
+        grid backward into int32 fields -> reduce-scatter -> Adam on this rank's slice -> all-gather of the 16-bit copy.
+        early / late: callables run while the (tiny) statistics all-gather / the gradient exchange are in flight.
+        x01 None: this rank has no sample at all (it still takes part in every collective)."""
+        ex = self._exchange_for(net, optimizer, dist_info)
+        n_net = net.mlp.n_params
+        if x01 is None:
+            amax = torch.zeros(_tcnn.ops._lib.MAX_LEVELS, dtype=torch.float32, device=net.params.device)
+            dw = torch.zeros(n_net, dtype=torch.float32, device=net.params.device)
+            shifts, _ = ex.exchange_units(amax, None, 0, overlap=early)
+            ex.payload.zero_()
+        else:
+            dfeat, dw, amax = ops.mlp_bwd(net.mlp, w16[:n_net], feat, dout, sel, want_absmax=True, n_dev=n_dev)
+            shifts, _ = ex.exchange_units(amax, n_dev, x01.shape[0], overlap=early)
+            ops.hashgrid_bwd_into(net.grid, x01, dfeat, ex.grid_payload_f32(), n_dev=n_dev, shifts=shifts, raw_fields=True)
+        optimizer.refresh_lr()
+        w16_new = ex.reduce_and_step(dw, optimizer, counters=self.sample_counters, n_marched=n_marched, n_kept=n_dev,
+                                     capacity=self.renderer.sample_capacity or 0, overlap=late)
+        net.set_working_copy(w16_new)
+        net.params.grad = None
+        self._poll_health(net)
+
+    def sync_params(self):
+        """Sharded data parallelism keeps the fp32 master of a table slice only on its owner: refresh the replicas (one fp32
+        all-gather per network; before checkpoints, after an episode).  No-op otherwise."""
+        for net in (self.nerf.geo_mlp, self.nerf.app_mlp):
+            ex = getattr(net, '_dp_exchange', None)
+            if ex is not None and self._dist()[0] is not None:
+                ex.gather_master(net.params.data)
 
     @torch.no_grad()
     def _geo_step_fused(self, optimizer, sup_pool, progress, rand, generator, prefetch_next=True):
@@ -534,8 +696,11 @@ class NeRFScene:
                                             keep_features=self.reuse_sampling_features and self.renderer.sample_capacity is not None)
         geo = self.nerf.geo_mlp
         extra = 1 if dist_info[0] is not None else 0
+        sharded = self._sharded(dist_info, optimizer)
         if st is None or st is False:
-            if dist_info[0] is not None:       # keep the collective matched across ranks; the count slot says "no samples here"
+            if sharded:                        # keep the collectives matched across ranks: this rank contributes nothing
+                self._dp_sharded_step(geo, optimizer, dist_info, None, None, None, None, None, None, None)
+            elif dist_info[0] is not None:     # the count slot says "no samples here"
                 self._apply_grad(geo, torch.zeros(geo.params.numel() + 1, device=geo.params.device), optimizer, dist_info, None, n_kept=0)
             self.global_iter_step_geo += 1
             return
@@ -561,15 +726,30 @@ class NeRFScene:
         g_op, g_dist, sc = ops.geo_loss(op, dist_r, gt_depths, noise, dl, packed, bs, tc.depth_loss_weight,
                                         tc.distortion_loss_weight, self._ratio_dev, self.loss_scale)
         dsig = ops.composite_distloss_bwd(sig.view(-1), ts, te, packed, w, T, op, dist_r, g_op, g_dist, 1.0, scale_dev=sc[2:3])
-        grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1), n_dev=n_dev, extra=extra)
         self.last_losses['depth_loss'] = sc[0]; self.last_losses['dist_loss'] = sc[1]
+
+        def color_now():
+            self.last_colors = ops.accumulate_fwd(w, self.nerf.rgb_at(x01, sel, n_dev), packed)
+
+        def prefetch_now():
+            self._geo_pre = self._geo_prefetch(sup_pool, rand_in, generator)
+
+        if sharded:
+            # the deferred colour render hides the latency of the statistics all-gather, the next step's batch draw runs
+            # while the gradient fields travel
+            self._dp_sharded_step(geo, optimizer, dist_info, x01, w16, feat, sel, dsig.view(-1, 1), n_dev, st['n_marched_dev'],
+                                  early=color_now if defer_color else None,
+                                  late=prefetch_now if (self.overlap_comm and prefetch_next and not self._capturing) else None)
+            self.global_iter_step_geo += 1
+            return
+        grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1), n_dev=n_dev, extra=extra)
         overlap = None
         if self.overlap_comm and dist_info[0] is not None:
             def overlap():
                 if defer_color:
-                    self.last_colors = ops.accumulate_fwd(w, self.nerf.rgb_at(x01, sel, n_dev), packed)
+                    color_now()
                 if prefetch_next:
-                    self._geo_pre = self._geo_prefetch(sup_pool, rand_in, generator)
+                    prefetch_now()
         self._apply_grad(geo, grad, optimizer, dist_info, overlap, n_kept=n_dev if n_dev is not None else x01.shape[0],
                          n_marched=st['n_marched_dev'])
         self.global_iter_step_geo += 1
@@ -584,8 +764,11 @@ class NeRFScene:
         st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand)
         app = self.nerf.app_mlp
         extra = 1 if dist_info[0] is not None else 0
+        sharded = self._sharded(dist_info, optimizer)
         if st is None:
-            if dist_info[0] is not None:
+            if sharded:
+                self._dp_sharded_step(app, optimizer, dist_info, None, None, None, None, None, None, None)
+            elif dist_info[0] is not None:
                 self._apply_grad(app, torch.zeros(app.params.numel() + 1, device=app.params.device), optimizer, dist_info, None, n_kept=0)
             self.global_iter_step_app += 1
             return
@@ -600,15 +783,19 @@ class NeRFScene:
         n_rays = op.shape[0]
         bg = None
         if self.renderer.bg_color == 'rand_noise':
-            bg = rand['bg'] if 'bg' in rand else torch.rand(n_rays, 3, device=op.device)
+            bg = rand['bg'] if 'bg' in rand else self._rand_cols(n_rays, 3, dist_info, op.device)
         elif self.renderer.bg_color == 'white':
             bg = torch.ones(n_rays, 3, device=op.device)
         if 'noise' not in rand:
-            torch.rand(n_rays, 1, device=op.device)               # the distance noise draw of :193 (unused by this loss)
+            self._rand_cols(n_rays, 1, dist_info, op.device)      # the distance noise draw of :193 (unused by this loss)
         g_col, sc = ops.app_loss(op, col, bg, gt_colors, bs, tc.color_loss_weight, self.loss_scale)
         _, drgb = ops.composite_bwd(sig.reshape(-1).contiguous(), ts, te, packed, w, T, g_color=g_col, want_dsigma=False, want_drgb=True)
-        grad = self._field_grad(app, x01, w16, feat, sel, drgb, n_dev=n_dev, extra=extra)
         self.last_losses['color_loss'] = sc[0]
+        if sharded:
+            self._dp_sharded_step(app, optimizer, dist_info, x01, w16, feat, sel, drgb, n_dev, st['n_marched_dev'])
+            self.global_iter_step_app += 1
+            return
+        grad = self._field_grad(app, x01, w16, feat, sel, drgb, n_dev=n_dev, extra=extra)
         self._apply_grad(app, grad, optimizer, dist_info, None, n_kept=n_dev if n_dev is not None else x01.shape[0],
                          n_marched=st['n_marched_dev'])
         self.global_iter_step_app += 1
@@ -688,13 +875,16 @@ class NeRFScene:
         both fields, compositing, losses, backward, Adam) into one hipGraph.  Sample arrays are capacity-sized
         (renderer.sample_capacity; default pixel_loss_batch_size * TRAIN_SAMPLES_PER_RAY) and every count stays on the
         device, so the reference's variable-count step is a fixed launch sequence.  Needs the fused Adam (device-side
-        step / lr) and a single process.  `warmup` real steps run first (they ARE training steps; pass 0 when the caller has
-        already run the step eagerly).  Returns replay(lr, progress)."""
+        step / lr).  Under data parallelism (sharded mode, RCCL) the step's collectives are captured with it -- every rank
+        must capture and replay in lockstep, and draw from identically seeded default generators.  `warmup` real steps run
+        first (they ARE training steps; pass 0 when the caller has already run the step eagerly).  Returns replay(lr, progress)."""
         assert isinstance(optimizer, FusedAdam), 'graph capture needs the fused Adam (device-side step/lr)'
-        assert self._dist()[0] is None, 'graphed steps are single-process (the all-reduce stays eager)'
+        dist_info = self._dist()
+        assert dist_info[0] is None or self._sharded(dist_info, optimizer), \
+            'graphed data-parallel steps need the sharded exchange (dp_mode = "sharded", fixed-point grid backward)'
         assert self._can_fuse() if kind == 'geo' else self.fused_steps, 'graph capture covers the explicit step chains'
         if self.renderer.sample_capacity is None:
-            self.renderer.sample_capacity = self.train_conf.pixel_loss_batch_size * self.TRAIN_SAMPLES_PER_RAY
+            self.renderer.sample_capacity = self.train_conf.pixel_loss_batch_size // dist_info[2] * self.TRAIN_SAMPLES_PER_RAY
         step_fn = self.train_one_step_geo if kind == 'geo' else self.train_one_step_app
         if warmup > 0:
             side = torch.cuda.Stream()
@@ -712,7 +902,8 @@ class NeRFScene:
         finally:
             self._capturing = optimizer.capturing = False
 
-        state = {'graph': graph, 'n': 0, 'counts': self._last_counts, 'capacity': self.renderer.sample_capacity}
+        state = {'graph': graph, 'n': 0, 'counts': self._last_counts, 'capacity': self.renderer.sample_capacity,
+                 'mode': _tcnn.GRID_GRAD_ACCUM}
 
         def replay(lr, progress):
             optimizer.lr_dev.fill_(lr)
@@ -724,19 +915,11 @@ class NeRFScene:
                 self.global_iter_step_geo += 1
             else:
                 self.global_iter_step_app += 1
-            if state['n'] % OVERFLOW_CHECK_EVERY == 0:
-                recapture = False
-                if _tcnn.GRID_GRAD_ACCUM == 'fixed' and _tcnn.check_fixed_point_overflow(optimizer.net.params.device) \
-                        and _tcnn.GRID_GRAD_ACCUM != 'fixed':
-                    recapture = True           # the accumulation mode is baked into the graph: capture again in fp32 mode
-                marched = state['counts'][0]
-                if marched is not None and int(marched.item()) > state['capacity']:
-                    import warnings
-                    warnings.warn(f'perf_amd: a training batch marched {int(marched.item())} samples, more than the capacity '
-                                  f'{state["capacity"]} (late rays were truncated); doubling the capacity')
-                    self.renderer.sample_capacity = 2 * int(marched.item())
-                    recapture = True
-                if recapture:
+            if state['n'] % OVERFLOW_CHECK_EVERY == 0 and dist_info[0] is None:
+                # one read-back of the device-side health counters (flagged / truncated steps were skipped on the device);
+                # accumulation mode and capacity are baked into the graph: capture again when either changed.  (Data-parallel
+                # replays stay in lockstep and leave the counters to the caller: NeRFScene._poll_health(force=True).)
+                if self._poll_health(force=True)['recapture']:
                     new = self.make_graphed_step(kind, optimizer, sup_pool, warmup=0)
                     state.update(new.state)
 

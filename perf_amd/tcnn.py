@@ -33,24 +33,34 @@ _overflow_hits = 0
 
 def check_fixed_point_overflow(device=None, sticky_after=3):
     """Read (one host sync) and clear the overflow-suspect flag of the fixed-point grid backward; True = some field came
-    within 4x of the int32 range since the last check.  The headroom feedback (perf_hashgrid_bwd's headroom_state) has
-    already widened the fields for the following calls by then, so the mode only switches to 'fp32' for the rest of the
-    process when `sticky_after` consecutive checks hit."""
-    global GRID_GRAD_ACCUM, _overflow_hits
+    within 4x of the int32 range since the last check.  Used by the autograd (shim) path, which polls after every backward and
+    repairs a hit in the same step.  NeRFScene's explicit step chains never read the flag on the host: the device-side
+    bookkeeping skips a flagged step (perf_step_bookkeeping) and counts it; see note_fixed_point_overflows()."""
     flag = ops.overflow_flag(device or _default_device())
     hit = bool(int(flag.item()))
     if hit:
         flag.zero_()
-        _overflow_hits += 1
-        import warnings
-        if _overflow_hits >= sticky_after:
-            GRID_GRAD_ACCUM = 'fp32'
-            warnings.warn('perf_amd: fixed-point grid-gradient accumulation keeps coming within 4x of its range; falling back to fp32 LDS accumulation')
-        else:
-            warnings.warn('perf_amd: a fixed-point grid-gradient field came within 4x of its range (headroom widened for the next calls)')
-    else:
-        _overflow_hits = 0
+    note_fixed_point_overflows(1 if hit else 0, sticky_after)
     return hit
+
+
+def note_fixed_point_overflows(n_new, sticky_after=3):
+    """Bookkeeping of overflow events between two polls.  The headroom feedback (perf_hashgrid_bwd's headroom_state) has
+    already widened the fields for the following calls by the time a hit is seen, so the mode only switches to 'fp32' for
+    the rest of the process when `sticky_after` polls in a row saw hits.  -> True when the mode was switched by this call."""
+    global GRID_GRAD_ACCUM, _overflow_hits
+    if n_new <= 0:
+        _overflow_hits = 0
+        return False
+    import warnings
+    _overflow_hits += 1
+    if _overflow_hits >= sticky_after and GRID_GRAD_ACCUM == 'fixed':
+        GRID_GRAD_ACCUM = 'fp32'
+        warnings.warn('perf_amd: fixed-point grid-gradient accumulation keeps coming within 4x of its range; falling back to fp32 LDS accumulation')
+        return True
+    warnings.warn(f'perf_amd: {n_new} fixed-point grid gradient(s) came within 4x of the int32 range (headroom widened for the next calls; '
+                  'steps taken through perf_step_bookkeeping skipped them)')
+    return False
 
 
 def _init_params(mlp: MlpConfig, grid: GridConfig, seed: int) -> torch.Tensor:

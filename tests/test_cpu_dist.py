@@ -83,7 +83,8 @@ def _apply_worker(rank, world, port, out, comm_dtype):
     n = 1000
     net = types.SimpleNamespace(params=torch.nn.Parameter(torch.linspace(-1, 1, n)))
     opt = torch.optim.Adam([net.params], lr=1e-2)
-    me = types.SimpleNamespace(comm_dtype=comm_dtype, sample_counters=None, _capturing=False, _steps_since_check=-10 ** 9)
+    me = types.SimpleNamespace(comm_dtype=comm_dtype, sample_counters=None, _capturing=False, _poll_health=lambda *a, **k: None,
+                               renderer=types.SimpleNamespace(sample_capacity=None))
     hist = []
     g = torch.Generator().manual_seed(100 + rank)
     for counts in ((5, 7), (0, 3), (0, 0)):
@@ -123,3 +124,132 @@ def test_apply_grad_world2_sums_gradients_and_skips_empty_steps(tmp_path):
             # Adam's first steps are sign-like: compare the travelled distance, tightly for the exact fp32 payload
             assert float((a - b).abs().max()) <= tol, (comm_dtype, float((a - b).abs().max()))
         assert torch.equal(hist[2], hist[1])                        # the all-empty step changed nothing
+
+
+# ---- the sharded exchange (perf_amd/dp.py) with world_size 2 over gloo: int32 reduce-scatter -> Adam on the rank's slice ->
+#      all-gather of the 16-bit copy.  The compute steps are torch stand-ins of the HIP kernels (same contracts); what is
+#      tested is the choreography: slices and padding, gates, flags, buffer reuse, master gathering. ---------------------------
+class _CpuKernels:
+    SHIFT = 12
+
+    def __init__(self):
+        self.flag = torch.zeros(1, dtype=torch.int32)
+
+    def stats_pack(self, level_absmax, field_max_prev, n_dev, n, out):
+        out.zero_()
+        out[:24] = level_absmax.view(torch.int32)
+        out[24:48] = -1 if field_max_prev is None else field_max_prev
+        live = n if n_dev is None else min(n, int(n_dev))
+        out[48] = live
+
+    def units(self, stats_all, world, shifts, n_total):
+        st = stats_all.view(world, -1)
+        shifts.fill_(self.SHIFT)
+        n_total.fill_(int(st[:, 48].sum()))
+        self.seen_field_max = st[:, 24:48].max(0).values.clone()
+
+    def unfix(self, shard, lo, hi, shifts, field_max, flag):
+        n = 2 * (hi - lo)
+        ints = shard[:n].clone()
+        field_max.zero_()
+        if n:
+            field_max[0] = int(ints.abs().max())
+        shard.view(torch.float32)[:n] = ints.float() * 2.0 ** -self.SHIFT
+
+    def bookkeeping(self, step_dev, gate, counters, n_marched, n_kept, capacity, overflow, remote_flags, eff_gate):
+        take = int(gate) > 0 and int(overflow) == 0 and float(remote_flags) == 0.0
+        if take:
+            step_dev += 1
+        overflow.zero_()
+        eff_gate.fill_(1 if take else 0)
+
+    def adam(self, p, m, v, g, w16, step_dev, lr_dev, gate):
+        if int(gate) <= 0:
+            return
+        t = int(step_dev)
+        m.mul_(0.9).add_(g, alpha=0.1)
+        v.mul_(0.999).addcmul_(g, g, value=0.001)
+        p.sub_(float(lr_dev) / (1 - 0.9 ** t) * m / ((v / (1 - 0.999 ** t)).sqrt() + 1e-8))
+        w16.copy_(p)
+
+    def overflow_flag(self):
+        return self.flag
+
+
+def _fields_of(step, rank, n_grid):
+    g = torch.Generator().manual_seed(1000 * step + rank)
+    return torch.randint(-2000, 2000, (n_grid,), generator=g, dtype=torch.int32)
+
+
+_DP_STEPS = ((5, 7, False), (0, 3, False), (0, 0, False), (4, 4, True), (2, 2, False))     # (samples rank 0, rank 1, rank 1 flags an overflow)
+
+
+def _run_exchange(ex, kern, rank_fields, rank_counts, flagged, opt, n_net):
+    """One step on one rank: (this rank's fields, its sample count, does it flag an overflow)."""
+    amax = torch.full((24,), 0.5)
+    ex.exchange_units(amax, torch.tensor([rank_counts]), 10 ** 6)
+    ex.payload.zero_()
+    if rank_counts > 0:
+        ex.payload[:ex.n_grid].copy_(rank_fields)
+    if flagged:
+        kern.flag.fill_(1)
+    dw = torch.full((n_net,), float(rank_counts))
+    opt.lr_dev.fill_(1e-2)
+    return ex.reduce_and_step(dw, opt).clone()
+
+
+def _exchange_worker(rank, world, port, out):
+    import types
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from perf_amd.dp import Collectives, ShardedExchange
+    n_net, n_grid = 8, 2 * 37                      # 37 entries: the slices are 20 and 17 entries, with padding behind
+    kern = _CpuKernels()
+    ex = ShardedExchange(n_net, n_grid, world, rank, Collectives(dist), 'cpu', torch.bfloat16, kern)
+    p0 = torch.linspace(-1, 1, n_net + n_grid)
+    opt = types.SimpleNamespace(p=p0.clone(), exp_avg=torch.zeros(n_net + n_grid), exp_avg_sq=torch.zeros(n_net + n_grid),
+                                step_dev=torch.zeros(1, dtype=torch.int32), lr_dev=torch.zeros(1))
+    ex.seed_working_copy(p0.to(torch.bfloat16))
+    hist = []
+    for s_i, (c0, c1, flag1) in enumerate(_DP_STEPS):
+        w16 = _run_exchange(ex, kern, _fields_of(s_i, rank, n_grid), (c0, c1)[rank], flag1 and rank == 1, opt, n_net)
+        hist.append(w16)
+    stale = opt.p.clone()
+    ex.gather_master(opt.p)
+    torch.save({'hist': hist, 'p': opt.p, 'stale': stale, 'steps': int(opt.step_dev), 'lo': ex.lo, 'hi': ex.hi,
+                'prev_field_max_seen': kern.seen_field_max}, out + f'.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_world2_equals_the_single_process_step(tmp_path):
+    import types
+    out = str(tmp_path / 'ex.pt')
+    mp.spawn(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
+    # both ranks hold the same working copy after every step, and the same master after gather_master
+    for a, b in zip(r0['hist'], r1['hist']):
+        assert torch.equal(a, b)
+    assert torch.equal(r0['p'], r1['p']) and r0['steps'] == r1['steps'] == 3
+    assert (r0['lo'], r0['hi'], r1['lo'], r1['hi']) == (0, 20, 20, 37)
+    # before the gather a rank's master of the OTHER slice is stale (never touched), its own slice is current
+    n_net = 8
+    assert torch.equal(r0['stale'][n_net:n_net + 40], r0['p'][n_net:n_net + 40]) and not torch.equal(r0['stale'][n_net + 40:], r0['p'][n_net + 40:])
+    # single-process reference: the same kernels on the summed fields
+    kern = _CpuKernels()
+    n_grid = 74
+    p = torch.linspace(-1, 1, n_net + n_grid)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int32); lr = torch.full((1,), 1e-2)
+    w16 = p.to(torch.bfloat16)
+    for s_i, (c0, c1, flag1) in enumerate(_DP_STEPS):
+        total = sum(_fields_of(s_i, r, n_grid) for r, c in enumerate((c0, c1)) if c > 0) if (c0 + c1) > 0 else torch.zeros(n_grid, dtype=torch.int32)
+        g = torch.cat([torch.full((n_net,), float(c0 + c1)), total.float() * 2.0 ** -kern.SHIFT])
+        gate = torch.tensor([1 if (c0 + c1 > 0 and not flag1) else 0])
+        if int(gate):
+            step += 1
+        kern.adam(p, m, v, g, w16, step, lr, gate)
+        assert torch.equal(r0['hist'][s_i], w16), s_i             # incl. the skipped steps (no samples anywhere; flagged overflow)
+    assert torch.equal(r0['p'], p)
+    # the largest field of the previous step's slices reached the next step's unit exchange
+    assert int(r0['prev_field_max_seen'][0]) > 0

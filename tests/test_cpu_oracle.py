@@ -3,6 +3,7 @@ C-ABI library's loadability / exported symbols."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import torch
@@ -102,6 +103,24 @@ def test_library_exports_every_declared_symbol():
     assert lib.perf_version() == _lib.ABI_VERSION == int(re.search(r'#define\s+PERF_ABI_VERSION\s+(\d+)', header).group(1))
     assert lib.perf_sizeof_grid_desc() == ctypes.sizeof(_lib.GridDesc)
     assert lib.perf_sizeof_mlp_desc() == ctypes.sizeof(_lib.MlpDesc)
+
+
+def test_abi_version_is_bumped_with_every_signature_change():
+    """include/perf_hip.abi.json records (PERF_ABI_VERSION, digest of the header's declarations).  A header whose
+    declarations changed must carry a NEW version (then re-record with `python tools/abi_digest.py --write`): the
+    load-time version check of the binding is what catches a stale libperf_hip.so."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import abi_digest
+    now = abi_digest.digest()
+    rec = json.load(open(abi_digest.RECORD))
+    if now['digest'] != rec['digest']:
+        assert now['version'] > rec['version'], ('include/perf_hip.h changed but PERF_ABI_VERSION is still '
+                                                 f"{rec['version']}: bump it, then `python tools/abi_digest.py --write`")
+        raise AssertionError('include/perf_hip.abi.json is out of date: run `python tools/abi_digest.py --write`')
+    assert now['version'] == rec['version']
+    from perf_amd import _lib
+    assert _lib.ABI_VERSION == now['version']
 
 
 def test_graft_entry_build_runs():
