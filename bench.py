@@ -17,12 +17,20 @@ device counter after the timed region) per second -- the extra no-grad density e
 work the step does on top and is not counted.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N ...            (spawns its own N ranks through torch.distributed.run on 127.0.0.1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1: one process per GPU over RCCL, rays sharded, weights replicated, sharded gradient exchange (perf_amd/dp.py).  The line's
+`value` is WEAK scaling (8192 rays per GPU per step, like N = 1); the `strong` block beside it is BASELINE config 3 as
+SURVEY.md 8(e) defines it: the reference's global batch of 8192 rays split over the GPUs.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -58,7 +66,15 @@ def parse():
     ap.add_argument('--dtype', default=None, choices=['bf16', 'fp16'], help='default: perf_amd.tcnn.DEFAULT_DTYPE')
     ap.add_argument('--mode', default='train_geo', choices=['train_geo', 'train_app', 'render'])
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
-                    help='weak: --rays-per-gpu rays on every GPU; strong: the reference batch (8192 rays) split over the GPUs')
+                    help='scaling mode of the HEADLINE value at N > 1 (the other mode is reported beside it): weak = --rays-per-gpu '
+                         'rays on every GPU; strong = that many rays in total, split over the GPUs')
+    ap.add_argument('--strict-two-evaluations', action='store_true',
+                    help='headline with the density field ENCODED twice per kept sample like the reference (default: the gradient pass '
+                         'starts from the features the sampling pass encoded -- bit-identical parameters; the strict line is reported beside it)')
+    ap.add_argument('--dp-mode', default='sharded', choices=['sharded', 'allreduce'], help='gradient exchange at N > 1 (perf_amd/dp.py)')
+    ap.add_argument('--watchdog-seconds', type=float, default=240.0,
+                    help='N > 1: if the optional measurements after the eager headline (graph-captured step, strong scaling, PSNR episode) '
+                         'take longer than this, print the eager headline and leave')
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -68,7 +84,7 @@ def parse():
                          'visibility compaction of the reference step (not the headline)')
     ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample')
     ap.add_argument('--no-psnr', action='store_true')
-    ap.add_argument('--no-reuse-line', action='store_true', help='skip the extra measurement with NeRFScene.reuse_sampling_features')
+    ap.add_argument('--no-reuse-line', action='store_true', help='skip the extra measurement with the other setting of NeRFScene.reuse_sampling_features')
     ap.add_argument('--psnr-geo-iters', type=int, default=3000, help='configs/nerf.yaml:25 raw_phase_iter_geo')
     ap.add_argument('--psnr-app-iters', type=int, default=1500, help='configs/nerf.yaml:26 raw_phase_iter_app')
     ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='payload of the gradient all-reduce (N > 1)')
@@ -121,6 +137,7 @@ def psnr_at_iters(args, dev, dist_mod, rank, world):
     from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays, psnr
     torch.manual_seed(0)
     scene = NeRFScene(dtype=args.dtype)
+    scene.dp_mode, scene.comm_dtype = args.dp_mode, args.comm_dtype
     rays = gen_pano_rays(torch.eye(4), args.height, args.width, device=dev)
     dist_map, rgb_map = synthetic.room(rays.d)
     pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb_map, dist_map)
@@ -150,18 +167,37 @@ def psnr_at_iters(args, dev, dist_mod, rank, world):
     return {'schedule': f'{args.psnr_geo_iters} geometry + {n_app} colour iterations, global batch {scene.train_conf.pixel_loss_batch_size} rays, '
                         f'{args.width}x{args.height} synthetic room, reference sampling (step 5e-4, early stop 1e-4), seed 0',
             'curve': curve, 'train_seconds': round(total - times.get('probe', 0.0), 3), 'render_seconds_total': round(times.get('probe', 0.0), 3),
-            'launch': 'hipGraph replay per step' if (world == 1 and scene.graph_steps) else 'eager',
+            'launch': 'hipGraph replay per step' if (scene.graph_steps and scene.dp_graph_ok()) else 'eager',
             'note': 'the fp32 oracle cannot run this size on a CPU; HIP-vs-oracle PSNR parity after equal iterations is asserted at 256x512 by '
                     'tests/test_gpu_psnr.py against tests/golden/psnr_curve.json'}
 
 
+def _free_port():
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close(); return port
+
+
+def relaunch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+    127.0.0.1) and pass their output through."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not env.get('PERF_BENCH_ONE_DEVICE'):
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but only {n_dev} HIP device(s) are visible\n')
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(relaunch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    # PERF_BENCH_BACKEND=gloo + PERF_BENCH_ONE_DEVICE=1: smoke-test the multi-rank path on a single-GPU box (dev tool)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    # PERF_BENCH_BACKEND=gloo + PERF_BENCH_ONE_DEVICE=1: smoke-test the multi-rank path on a single-GPU box (dev tool, tests)
     backend = os.environ.get('PERF_BENCH_BACKEND', 'nccl')
     if os.environ.get('PERF_BENCH_ONE_DEVICE'):
         local_rank = 0
@@ -188,17 +224,24 @@ def main():
             dist.barrier()
         _lib.load()
     from perf_amd import ops, synthetic, tcnn
-    from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
+    from perf_amd.scene import NeRFScene, Rays, SupInfoPool, gen_pano_rays
     args.dtype = args.dtype or tcnn.DEFAULT_DTYPE
+    reuse_default = not args.strict_two_evaluations
 
-    def build(reuse_features):
-        """Fresh scene + optimizer + (graphed) step of the benchmark workload -> (scene, step, eager_step, rays_per_step, graphed)."""
-        torch.manual_seed(0)
+    rays = gen_pano_rays(torch.eye(4), args.height, args.width, device=dev)
+    dist_map, rgb_map = synthetic.room(rays.d)
+    pool = SupInfoPool()
+    pool.register_rays(rays.o, rays.d, rgb_map, dist_map)
+
+    def build(reuse_features, scaling, graph=True):
+        """Fresh scene + optimizer + (graphed) step of the benchmark workload -> dict(scene, step, eager_step, rays_per_step, graphed)."""
+        torch.manual_seed(0)                                              # the same random streams on every rank (scene.py)
         scene = NeRFScene(dtype=args.dtype)
         tc = scene.train_conf
         scene.comm_dtype = args.comm_dtype
+        scene.dp_mode = args.dp_mode
         scene.reuse_sampling_features = reuse_features
-        if args.scaling == 'weak':
+        if scaling == 'weak':
             rays_local = args.rays_per_gpu                               # 8192 rays on every GPU
         else:
             assert args.rays_per_gpu % world == 0
@@ -220,9 +263,8 @@ def main():
         rays_per_step = rays_local if args.mode != 'render' else 32768
         r.sample_capacity = rays_per_step * args.spp                     # = the marched count: nothing is ever truncated
         scene.nerf.reset_geo()
-        scene.sample_counters = torch.zeros(3, dtype=torch.int64, device=dev)
-        gen = torch.Generator(device=dev); gen.manual_seed(1234)          # same index stream on every rank
-        use_graph = (world == 1) and (not args.no_graph) and args.mode != 'render'
+        scene.sample_counters.zero_()
+        use_graph = graph and (not args.no_graph) and args.mode != 'render' and scene.dp_graph_ok()
         graphed = None
         if args.mode in ('train_geo', 'train_app'):
             kind = 'geo' if args.mode == 'train_geo' else 'app'
@@ -234,7 +276,7 @@ def main():
 
             def eager_step(i):
                 scene.update_lr(opt, conf, min(i / n_sched, 0.999))
-                step_fn(opt, pool, progress=0.25, generator=None if world == 1 else gen)
+                step_fn(opt, pool, progress=0.25)
             if use_graph:
                 graphed = scene.make_graphed_step(kind, opt, pool)
 
@@ -247,7 +289,6 @@ def main():
             scene.set_eval()
             n_batches = (args.height * args.width) // 32768
             flat_o = rays.o.reshape(-1, 3); flat_d = rays.d.reshape(-1, 3)
-            from perf_amd.scene import Rays
 
             def step(i):
                 bb = i % n_batches
@@ -256,17 +297,12 @@ def main():
                                             ['rgb', 'distance', 'n_marched_dev', 'n_samples_dev'])
                     ops.step_bookkeeping(None, None, scene.sample_counters, res['n_marched_dev'], res['n_samples_dev'])
             eager_step = step
-        return scene, step, eager_step, rays_per_step, graphed
+        return {'scene': scene, 'step': step, 'eager_step': eager_step, 'rays_per_step': rays_per_step, 'graphed': graphed,
+                'scaling': scaling}
 
-    rays = gen_pano_rays(torch.eye(4), args.height, args.width, device=dev)
-    dist_map, rgb_map = synthetic.room(rays.d)
-    pool = SupInfoPool()
-    pool.register_rays(rays.o, rays.d, rgb_map, dist_map)
-    scene, step, eager_step, rays_per_step, graphed = build(False)
-    tc, r = scene.train_conf, scene.renderer
-
-    def timed(n_steps, first):
+    def timed(run, n_steps, first):
         """n_steps steps bracketed by barrier + synchronize on both sides; -> (seconds = max over ranks, marched, kept)."""
+        scene, step = run['scene'], run['step']
         scene.sample_counters.zero_()
         torch.cuda.synchronize()
         if world > 1:
@@ -287,22 +323,63 @@ def main():
             el = float(t.item())
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)                 # whole-job sample counts
         c = cnt.tolist()
-        return el, int(c[0]), int(c[1])
+        return el, int(c[0]), int(c[1]), {'skipped_for_overflow': int(c[4]), 'skipped_for_truncation': int(c[5])}
 
-    for i in range(args.warmup):
-        step(i)
-    elapsed, marched, kept = timed(args.steps, args.warmup)
-    value = kept / elapsed
+    def measure(reuse_features, scaling, graph=True):
+        """Build, W warmup steps, K timed steps -> (run, result dict)."""
+        run = build(reuse_features, scaling, graph)
+        for i in range(args.warmup):
+            run['step'](i)
+        el, marched, kept, health = timed(run, args.steps, args.warmup)
+        tcf = run['scene'].train_conf
+        res = {'value': kept / el, 'ms_per_step': el / args.steps * 1e3, 'steps': args.steps, 'scaling': scaling,
+               'global_batch_rays': tcf.pixel_loss_batch_size, 'rays_per_gpu_per_step': run['rays_per_step'],
+               'marched_samples_per_gpu_per_step': marched / args.steps / world, 'kept_samples_per_gpu_per_step': kept / args.steps / world,
+               'launch': ('hipGraph replay of the whole step' + (' (collectives captured with it)' if world > 1 else ''))
+                         if run['graphed'] is not None else 'eager', **health}
+        return run, res
+
+    other = 'strong' if args.scaling == 'weak' else 'weak'
+    notes = []
+    watchdog = None
+    if world > 1:
+        # N > 1: the eager, collective-by-collective step first -- a line that is safe to print -- then everything optional
+        # (graph capture with the RCCL collectives inside, the other scaling mode, the PSNR episode) under a watchdog that
+        # prints the safe line and leaves should any of it hang on this node
+        run, head = measure(reuse_default, args.scaling, graph=False)
+        safe = _line(args, world, head, run, None, None, None, None, None, None,
+                     notes=['eager data-parallel step only: the optional measurements did not finish within the watchdog'])
+
+        def bail():
+            if rank == 0:
+                print(json.dumps(safe), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.watchdog_seconds, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            if run['scene'].dp_graph_ok() and not args.no_graph and args.mode != 'render':
+                run_g, head_g = measure(reuse_default, args.scaling, graph=True)
+                head_g['eager'] = {'value': head['value'], 'ms_per_step': head['ms_per_step']}
+                run, head = run_g, head_g
+            else:
+                notes.append('data-parallel steps launched eagerly (RCCL graph-capture probe failed or PERF_DP_GRAPH=0 / non-RCCL backend)')
+        except Exception as e:       # noqa: BLE001
+            notes.append(f'graph-captured data-parallel step failed ({type(e).__name__}: {e}); eager line kept')
+    else:
+        run, head = measure(reuse_default, args.scaling)
+    scene, step, eager_step = run['scene'], run['step'], run['eager_step']
+    tc, r = scene.train_conf, scene.renderer
 
     # a second, longer measurement of the same loop (the K-step region above is only tens of milliseconds long)
     sustained = None
     if args.sustain_seconds > 0:
-        n_long = int(min(20000, max(args.steps, args.sustain_seconds / max(elapsed / args.steps, 1e-6))))
+        n_long = int(min(20000, max(args.steps, args.sustain_seconds / max(head['ms_per_step'] * 1e-3, 1e-6))))
         if world > 1:                                                  # every rank must run the same number of steps
             t = torch.tensor([n_long], device=dev); dist.broadcast(t, 0); n_long = int(t.item())
-        el2, m2, k2 = timed(n_long, args.warmup + args.steps)
+        el2, m2, k2, h2 = timed(run, n_long, args.warmup + args.steps)
         sustained = {'steps': n_long, 'seconds': round(el2, 4), 'value': k2 / el2, 'ms_per_step': el2 / n_long * 1e3,
-                     'kept_samples_per_step_per_gpu': k2 / n_long / world, 'marched_samples_per_step_per_gpu': m2 / n_long / world}
+                     'kept_samples_per_step_per_gpu': k2 / n_long / world, 'marched_samples_per_step_per_gpu': m2 / n_long / world, **h2}
 
     # per-kernel times: the same K steps again, launched eagerly with a HIP event pair around every C-ABI launch on the
     # launch stream (events cannot be recorded inside a graph replay; same kernels, same shapes, same device-side counts)
@@ -315,28 +392,53 @@ def main():
     c_ev = scene.sample_counters.tolist()
     marched_ev, kept_ev = c_ev[0] / max(args.steps, 1), c_ev[1] / max(args.steps, 1)     # per step, this rank
 
-    # the same K steps from the same fresh initialisation with the gradient pass starting from the sampler's encoded
-    # features (NeRFScene.reuse_sampling_features: bit-identical parameters, one encode of the kept samples fewer); reported
-    # NEXT TO the headline, which keeps the reference's two density evaluations
+    # the other setting of NeRFScene.reuse_sampling_features, from the same fresh initialisation: the reference evaluates the
+    # density field twice on the kept samples (no-grad inside sampling, with grad in the renderer: same parameters, same
+    # positions); by default the gradient pass starts from the features the sampling pass encoded -- bit-identical parameters
+    # (tests/test_gpu_counts.py), one encode fewer.  Both lines are reported.
     reuse_block = None
-    if args.mode == 'train_geo' and not args.no_prepass and not args.no_reuse_line:
-        strict = (scene, step)
-        scene, step, _, _, _ = build(True)
-        for i in range(args.warmup):
-            step(i)
-        el_r, m_r, k_r = timed(args.steps, args.warmup)
-        reuse_block = {'value': k_r / el_r, 'ms_per_step': el_r / args.steps * 1e3, 'steps': args.steps,
-                       'what': 'gradient pass of the density field starts from the features the sampling pass encoded (compacted with the '
-                               'samples) instead of encoding the kept samples a second time; parameters bit-identical to the headline path'}
-        scene, step = strict
+    if args.mode == 'train_geo' and not args.no_prepass and not args.no_reuse_line and world == 1:
+        _, alt = measure(not reuse_default, args.scaling)
+        reuse_block = dict(alt, what=('strict reference order: the kept samples are encoded a second time for the gradient pass'
+                                      if reuse_default else 'gradient pass starts from the features the sampling pass encoded')
+                                     + '; parameters bit-identical to the headline path')
+
+    other_block = None
+    if world > 1 and args.mode != 'render':
+        try:
+            _, other_block = measure(reuse_default, other, graph=head['launch'] != 'eager')
+        except Exception as e:       # noqa: BLE001
+            notes.append(f'{other}-scaling measurement failed ({type(e).__name__}: {e})')
 
     psnr_block = None
     if not args.no_psnr and args.mode == 'train_geo':
-        psnr_block = psnr_at_iters(args, dev, dist, rank, world)
+        try:
+            psnr_block = psnr_at_iters(args, dev, dist, rank, world)
+        except Exception as e:       # noqa: BLE001
+            if world == 1:
+                raise
+            notes.append(f'PSNR episode failed ({type(e).__name__}: {e})')
+    if watchdog is not None:
+        watchdog.cancel()
 
     if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.spp, args.cpu_rays)
+        line = _line(args, world, head, run, sustained, kern, (marched_ev, kept_ev), reuse_block, other_block, psnr_block, cpu=cpu, notes=notes)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other_block, psnr_block, cpu=None, notes=None):
+    """The JSON line of one run (rank 0)."""
+    scene = run['scene']
+    tc, r = scene.train_conf, scene.renderer
+    table, roof = {}, None
+    if kern:
+        marched_ev, kept_ev = ev_counts
         total = {k: n * ms for k, (n, ms) in kern.items()}
-        table = {}
         prepass = r.early_stop_eps > 0 and args.mode != 'render'
         for k, (n, ms) in sorted(kern.items(), key=lambda kv: -total[kv[0]]):
             per_step = n / args.steps
@@ -355,48 +457,66 @@ def main():
                 row['limiter'] = LIMITER[k]
             table[k] = row
         dom = max((k for k in total if k in ALGO_BYTES), key=lambda k: total[k])
-        roof = {'kernel': dom, 'bound': 'hbm', 'achieved': table[dom]['algorithmic_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        roof = {'kernel': dom, 'bound': BOUND[dom], 'achieved': table[dom]['algorithmic_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': table[dom]['frac_of_hbm_peak'], 'traffic': None, 'limiter': LIMITER[dom],
+                'priced_against': 'hbm (algorithmic bytes / HBM peak, as SURVEY.md 8(d) prescribes); `bound` names what the counters '
+                                  'say limits the kernel',
                 'algorithmic_bytes_per_ray_sample': ALGO_BYTES[dom], 'live_samples_per_launch': table[dom]['live_samples_per_launch'],
                 'ms_per_launch': table[dom]['ms_per_launch'],
                 'definition': 'achieved = algorithmic bytes (SURVEY.md 8(d), 16-bit figures) x live samples of a launch / mean launch duration '
                               '(HIP events on the launch stream)'}
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same workload (profiles/)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
-            if (pmc.get('workload') == _workload_key(args) and dom in pmc['kernels']):
-                roof['traffic'] = pmc['kernels'][dom]['hbm_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections)'
-        except Exception:
-            pass
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.spp, args.cpu_rays)
-        step_desc = {'train_geo': 'geometry training step', 'train_app': 'colour training step', 'render': 'eval render batch (32768 rays)'}[args.mode]
-        line = {
-            'metric': 'ray-samples/sec (panoramic NeRF ' + step_desc + ': kept samples evaluated by both fields + composited'
-                      + (', fwd+bwd+Adam' if args.mode != 'render' else '') + ') + PSNR@iter',
-            'value': value, 'unit': 'ray-samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-            'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'{args.width}x{args.height} synthetic room panorama, {args.spp} marched samples/ray, '
-                                   f'hash grid L16/F2/T18 + 64-wide MLPs, mode={args.mode}, '
-                                   + ('reference step incl. sampling-pass sigma + visibility compaction (early stop 1e-4)' if r.early_stop_eps > 0
-                                      else 'fixed-count WITHOUT sampling-pass sigma / compaction (early_stop_eps = 0)'),
-                       'rays_per_gpu_per_step': rays_per_step, 'marched_samples_per_gpu_per_step': marched / args.steps / world,
-                       'kept_samples_per_gpu_per_step': kept / args.steps / world,
-                       'counted': 'kept samples (device counter, read once after the timed region); the no-grad density pass over all marched samples is extra work',
-                       'parallelism': (f'dp{world} (rays sharded, one RCCL all-reduce of the flat gradient per step), {args.scaling} scaling, '
-                                       f'global batch {tc.pixel_loss_batch_size} rays') if world > 1 else 'single GPU',
-                       'per_gpu_value': value / world,
-                       'launch': 'hipGraph replay of the whole step' if graphed is not None else 'eager',
-                       'kernel_timing': 'HIP events around every launch in an eager re-run of the same steps right after the timed region'},
-            'sustained': sustained, 'with_feature_reuse': reuse_block, 'psnr': psnr_block,
-            'roofline': roof, 'cpu_baseline': cpu, 'kernels': table,
-        }
-        print(json.dumps(line))
+        for name in PMC_FILES:
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
+                if (pmc.get('workload') == _workload_key(args) and dom in pmc['kernels']):
+                    roof['traffic'] = pmc['kernels'][dom]['hbm_bytes_per_launch']
+                    roof['traffic_source'] = f'profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections; raw CSVs beside it)'
+                    break
+            except Exception:      # noqa: BLE001
+                continue
+    step_desc = {'train_geo': 'geometry training step', 'train_app': 'colour training step', 'render': 'eval render batch (32768 rays)'}[args.mode]
+    reuse = scene.reuse_sampling_features and r.early_stop_eps > 0 and args.mode == 'train_geo'
+    line = {
+        'metric': 'ray-samples/sec (panoramic NeRF ' + step_desc + ': kept samples evaluated by both fields + composited'
+                  + (', fwd+bwd+Adam' if args.mode != 'render' else '') + ') + PSNR@iter',
+        'value': head['value'], 'unit': 'ray-samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': head['scaling'], 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': f'{args.width}x{args.height} synthetic room panorama, {args.spp} marched samples/ray, '
+                               f'hash grid L16/F2/T18 + 64-wide MLPs, mode={args.mode}, '
+                               + ('reference step incl. sampling-pass sigma + visibility compaction (early stop 1e-4)' if r.early_stop_eps > 0
+                                  else 'fixed-count WITHOUT sampling-pass sigma / compaction (early_stop_eps = 0)')
+                               + ('; the gradient pass of the density field starts from the features the sampling pass encoded' if reuse else ''),
+                   'rays_per_gpu_per_step': head['rays_per_gpu_per_step'], 'marched_samples_per_gpu_per_step': head['marched_samples_per_gpu_per_step'],
+                   'kept_samples_per_gpu_per_step': head['kept_samples_per_gpu_per_step'],
+                   'counted': 'kept samples (device counter, read once after the timed region); the no-grad density pass over all marched samples is extra work',
+                   'parallelism': (f'dp{world} (rays sharded, weights replicated; per step: int32 reduce-scatter of the fixed-point gradient '
+                                   f'fields -> Adam on 1/{world} of the table -> all-gather of the 16-bit copy), {head["scaling"]} scaling, '
+                                   f'global batch {head["global_batch_rays"]} rays' if args.dp_mode == 'sharded' else
+                                   f'dp{world} (one all-reduce of the flat {args.comm_dtype} gradient per step), {head["scaling"]} scaling, '
+                                   f'global batch {head["global_batch_rays"]} rays') if world > 1 else 'single GPU',
+                   'per_gpu_value': head['value'] / world,
+                   'launch': head['launch'],
+                   'kernel_timing': 'HIP events around every launch in an eager re-run of the same steps right after the timed region'},
+        'health': {k: head[k] for k in ('skipped_for_overflow', 'skipped_for_truncation')},
+        'sustained': sustained,
+        ('strict_two_evaluations' if reuse else 'with_feature_reuse'): reuse_block,
+        'psnr': psnr_block, 'roofline': roof, 'cpu_baseline': cpu, 'kernels': table or None,
+    }
+    if 'eager' in head:
+        line['config']['eager_launch'] = head['eager']
     if world > 1:
-        dist.destroy_process_group()
+        line[('strong' if head['scaling'] == 'weak' else 'weak')] = other_block
+    if notes:
+        line['notes'] = notes
+    return line
+
+
+# what the counters say bounds the dominant kernels (profiles/r03_*): the encode is bound by the L1's request rate, the
+# grid backward by VALU issue; neither by HBM bandwidth -- `frac` is nevertheless priced against HBM
+BOUND = {'perf_hashgrid_fwd': 'l1-request', 'perf_hashgrid_bwd': 'valu'}
+PMC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json')
 
 
 def _workload_key(args):

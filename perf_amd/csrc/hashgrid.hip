@@ -52,6 +52,7 @@ __device__ __forceinline__ float grid_pos(float x, float scale) { return __built
 struct Corners {
     uint32_t idx[8];
     float f[3];
+    uint32_t cell[3];       // integer cell: two samples with equal cells gather the same 8 entries
 };
 
 __device__ __forceinline__ Corners corners_of(float x, float y, float z, float scale, uint32_t res,
@@ -63,6 +64,7 @@ __device__ __forceinline__ Corners corners_of(float x, float y, float z, float s
     float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
     c.f[0] = px - flx; c.f[1] = py - fly; c.f[2] = pz - flz;
     uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+    c.cell[0] = gx; c.cell[1] = gy; c.cell[2] = gz;
     if (hashed) {
         uint32_t hy0 = gy * kPrimeY, hy1 = hy0 + kPrimeY;
         uint32_t hz0 = gz * kPrimeZ, hz1 = hz0 + kPrimeZ;
@@ -151,6 +153,110 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const 
         }
         feat[(int64_t)l * n + i] = T16::pack(a0, a1);
     }
+    }
+}
+
+
+// ---- forward encode, second generation: ticketed (level group, chunk) units + run de-duplication --------------------------
+// The gathers of this kernel are bound by the L1's request rate (one cache-line look-up per active lane and cycle; the
+// tables sit in L2 / Infinity Cache), not by bandwidth.  Two things reduce what the slowest XCD has to issue:
+//  (1) run de-duplication: consecutive samples of a ray (training batches) and equal-rank samples of neighbouring pixels
+//      (eval frames) fall into the SAME cell at the coarse levels, i.e. neighbouring lanes gather the same eight entries.
+//      One DPP compare per level finds the runs; only run heads issue the gathers, the others fetch the head's packed
+//      dwords with ds_bpermute (LDS crossbar, ~2 cycles per 64 lanes instead of 64 L1 look-ups).  Interpolation stays
+//      per lane: features are bit-identical.  A wave whose lanes share little (> kShareMaxHeads heads) gathers as before.
+//  (2) de-duplication makes the level groups unequal (a coarse level costs a fraction of a fine one), and a static
+//      group <-> XCD pinning would leave the kernel as long as its most expensive group.  Work is therefore handed out as
+//      (level group, 256-sample chunk) TICKETS: workgroup b (on XCD b % 8 under round-robin dispatch) first serves its home
+//      group -- each L2 then holds two tables as before -- and, when that is exhausted, takes tickets of the other groups.
+//      tickets: 9 zeroed device words per launch in flight; the last workgroup leaves them zeroed for the next launch.
+constexpr int kShareMaxHeads = 44;
+
+template <typename T16>
+__global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, const float* __restrict__ x01,
+                                                              const uint32_t* __restrict__ table,
+                                                              uint32_t* __restrict__ feat, int64_t n,
+                                                              const int64_t* __restrict__ n_dev, int32_t* __restrict__ tickets,
+                                                              int dedup, int steal) {
+    __shared__ int s_chunk;
+    const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
+    const int64_t nchunks = (n_live + 255) >> 8;
+    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= mine
+    int g = (int)(blockIdx.x & 7);
+    int tries = 0;
+    const int max_tries = steal ? 8 : 1;
+    while (tries < max_tries) {
+        if (threadIdx.x == 0) s_chunk = atomicAdd(&tickets[g], 1);
+        __syncthreads();
+        const int64_t chunk = s_chunk;
+        __syncthreads();                                         // (s_chunk is rewritten in the next round)
+        if (chunk >= nchunks) { ++tries; g = (g + 1) & 7; continue; }
+        const int64_t i = chunk * 256 + threadIdx.x;
+        const bool live = i < n_live;
+        const int64_t ii = live ? i : n_live - 1;                // (idle lanes of the last chunk repeat its last sample)
+        const float x = x01[3 * ii], y = x01[3 * ii + 1], z = x01[3 * ii + 2];
+        // Both levels of the group are set up first, then all their gathers are issued, then shared and interpolated: the
+        // (L1-hit) coarse and the (L2-served) fine level stay in flight together.
+        int lv[2];
+        Corners c[2];
+        bool head[2], share[2];
+        uint32_t src[2];
+        uint32_t v[2][8];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            lv[pass] = level_of(g, pass, gp.n_levels);
+            head[pass] = lv[pass] >= 0; share[pass] = false; src[pass] = lane;
+            if (lv[pass] < 0) continue;
+            const int l = lv[pass];
+            c[pass] = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+            if (dedup) {
+                // lane - 1's cell through DPP (wave_shr:1; lane 0 keeps the `old` operand)
+                const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[0], 0x138, 0xf, 0xf, false);
+                const uint32_t py = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[1], 0x138, 0xf, 0xf, false);
+                const uint32_t pz = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[2], 0x138, 0xf, 0xf, false);
+                const bool same = lane != 0u && px == c[pass].cell[0] && py == c[pass].cell[1] && pz == c[pass].cell[2];
+                const unsigned long long heads = __ballot(!same);
+                share[pass] = __popcll(heads) <= kShareMaxHeads;      // wave-uniform
+                if (share[pass]) {
+                    head[pass] = !same;
+                    src[pass] = 63u - (uint32_t)__clzll((long long)(heads & below));     // the head of my run
+                }
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[pass][k] = 0u;
+            if (head[pass]) {
+                const uint32_t* t = table + gp.offset[lv[pass]];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[pass][k] = t[c[pass].idx[k]];
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (lv[pass] < 0) continue;
+            if (share[pass]) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[pass][k] = (uint32_t)__shfl((int)v[pass][k], (int)src[pass]);
+            }
+            float w[8];
+            corner_weights(c[pass].f, smooth, w);
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a0 = fmaf(w[k], T16::lo(v[pass][k]), a0);
+                a1 = fmaf(w[k], T16::hi(v[pass][k]), a1);
+            }
+            if (live) feat[(int64_t)lv[pass] * n + i] = T16::pack(a0, a1);
+        }
+    }
+    // the last workgroup to run out of work leaves the tickets zeroed for the next launch
+    if (threadIdx.x == 0 && atomicAdd(&tickets[8], 1) == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) tickets[j] = 0;
     }
 }
 
@@ -1219,7 +1325,7 @@ static inline unsigned grouped_grid(int64_t n) { return (unsigned)(div_up(n, 256
 using namespace perf;
 
 extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* table16,
-                                 void* feat16, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
+                                 void* feat16, int64_t n, const int64_t* n_dev, int dtype, int32_t* tickets, void* stream) {
     GridParams gp;
     int rc = fill_params(grid, &gp);
     if (rc) return rc;
@@ -1230,6 +1336,22 @@ extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, c
     // (a rank's slice of a level-sharded table, the 5-level proposal field) would otherwise keep 1-3 XCDs busy
     static const int affinity_env = getenv("PERF_FWD_NO_XCD_AFFINITY") ? 0 : 1;
     const int xcd_affinity = (affinity_env && gp.n_levels >= 15) ? 1 : 0;
+    // ---- ticketed kernel with run de-duplication (16-level class grids, caller-provided tickets)
+    static const int v2_env = getenv("PERF_FWD_V2") ? atoi(getenv("PERF_FWD_V2")) : 1;
+    static const int dedup_env = getenv("PERF_FWD_NO_DEDUP") ? 0 : 1, steal_env = getenv("PERF_FWD_NO_STEAL") ? 0 : 1;
+    if (tickets && v2_env && xcd_affinity && gp.n_levels <= 16) {
+        static const int64_t max_blocks = getenv("PERF_FWD_V2_BLOCKS") ? atoll(getenv("PERF_FWD_V2_BLOCKS")) : 2048;
+        int64_t blocks = div_up(n, 256) * 8;
+        if (blocks > max_blocks) blocks = max_blocks;
+        dim3 g((unsigned)blocks), b(256);
+        if (dtype == PERF_DTYPE_BF16)
+            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, tickets, dedup_env, steal_env);
+        else if (dtype == PERF_DTYPE_FP16)
+            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, tickets, dedup_env, steal_env);
+        else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
+        PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
+        return PERF_OK;
+    }
     // chunks (of 256 samples) per level group in one launch; beyond that the workgroups loop (experiment knob, read once)
     static const int64_t max_chunks = getenv("PERF_FWD_MAX_CHUNKS") ? atoll(getenv("PERF_FWD_MAX_CHUNKS")) : kFwdMaxChunks;
     int64_t chunks = div_up(n, 256);

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import ops
 from . import tcnn
-from .tcnn import _DualFieldFn, _FieldFn
+from .tcnn import _DualFieldFn, field_apply
 
 PER_LEVEL_SCALE = 1.4472692012786865
 
@@ -85,23 +85,24 @@ class NGPNeRF(nn.Module):
             {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "Sigmoid", "n_neurons": 64,
              "n_hidden_layers": 2}, dtype=dtype)
 
-    # -- point queries (ngp_nerf.py:136-162) ---------------------------------------------------------
+    # -- point queries (ngp_nerf.py:136-162).  Like the reference's, they normalise by the aabb whatever `unbounded` says: the
+    #    reference stores that flag (ngp_nerf.py:90) and only NGPDensityField.forward (:251-252) ever contracts. ---------
     def query_density(self, x):
         shape = list(x.shape[:-1])
         x01, sel = ops.points_normalize(x.reshape(-1, 3).contiguous().float(), self._aabb_host)
-        return _FieldFn.apply(x01, self.geo_mlp.params, sel, self.geo_mlp).view(shape + [1])
+        return field_apply(self.geo_mlp, x01, self.geo_mlp.params, sel).view(shape + [1])
 
     def query_rgb(self, x):
         shape = list(x.shape[:-1])
         x01, sel = ops.points_normalize(x.reshape(-1, 3).contiguous().float(), self._aabb_host)
-        return _FieldFn.apply(x01, self.app_mlp.params, sel, self.app_mlp).view(shape + [3])
+        return field_apply(self.app_mlp, x01, self.app_mlp.params, sel).view(shape + [3])
 
     # -- ray-sample queries: positions o + d (t0+t1)/2 are formed in-kernel (nerf_renderer.py:125-127) --
     def sample_points(self, rays_o, rays_d, ray_indices, t_starts, t_ends):
         return ops.points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, self._aabb_host)
 
     def density_at(self, x01, sel, n_dev=None):
-        return _FieldFn.apply(x01, self.geo_mlp.params, sel, self.geo_mlp, n_dev)[:, 0]
+        return field_apply(self.geo_mlp, x01, self.geo_mlp.params, sel, n_dev)[:, 0]
 
     @torch.no_grad()
     def density_with_features(self, x01, sel, n_dev=None):
@@ -113,7 +114,7 @@ class NGPNeRF(nn.Module):
         return ops.mlp_fwd(net.mlp, w16[:n_net], feat, sel, n_dev=n_dev)[:, 0], feat
 
     def rgb_at(self, x01, sel, n_dev=None):
-        return _FieldFn.apply(x01, self.app_mlp.params, sel, self.app_mlp, n_dev)
+        return field_apply(self.app_mlp, x01, self.app_mlp.params, sel, n_dev)
 
     def density_rgb_at(self, x01, sel, geo_grad=True, app_grad=False):
         """sigma [n] and rgb [n,3] at the same points with ONE shared encode pass (both grids have the same geometry).
@@ -162,4 +163,4 @@ class NGPDensityField(nn.Module):
             sel = ((x01 > 0.0) & (x01 < 1.0)).all(dim=-1).to(torch.uint8)
         else:
             x01, sel = ops.points_normalize(positions.reshape(-1, 3).contiguous().float(), self._aabb_host)
-        return _FieldFn.apply(x01, self.mlp_base.params, sel, self.mlp_base).view(shape + [1])
+        return field_apply(self.mlp_base, x01, self.mlp_base.params, sel).view(shape + [1])

@@ -82,8 +82,8 @@ class _FieldFn(torch.autograd.Function):
         """n_dev (device int64 [1], optional): only the first min(len(x01), n_dev) rows are live (capacity-sized batch)."""
         w16 = module.working_copy(params)
         n_net = module.mlp.n_params
-        if not ctx.needs_input_grad[1]:          # (no_grad, or frozen parameters: the autograd engine asks for nothing)
-            return ops.field_infer(module.grid, module.mlp, x01, sel, w16, n_dev=n_dev)      # inference: nothing is kept
+        # (inference -- no_grad, or frozen parameters -- never gets here: field_apply() below routes it to perf_field_infer;
+        #  ctx.needs_input_grad cannot tell, it reports params.requires_grad even under torch.no_grad())
         feat = ops.hashgrid_fwd(module.grid, x01, w16[n_net:], n_dev=n_dev)
         out = ops.mlp_fwd(module.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
         ctx.module = module
@@ -98,6 +98,14 @@ class _FieldFn(torch.autograd.Function):
         module = ctx.module
         sel = sel if ctx.has_sel else None
         return None, _field_backward(module, x01, w16, feat, sel, dout, n_dev=ctx.n_dev, poll_overflow=True), None, None, None
+
+
+def field_apply(module, x01, params, sel=None, n_dev=None):
+    """act(MLP(encode(x01))) * sel of one network: ONE boundary call that keeps nothing when no gradient can be asked for
+    (torch.no_grad(), or frozen parameters), the autograd Function otherwise."""
+    if not (torch.is_grad_enabled() and params.requires_grad):
+        return ops.field_infer(module.grid, module.mlp, x01, sel, module.working_copy(params), n_dev=n_dev)
+    return _FieldFn.apply(x01, params, sel, module, n_dev)
 
 
 # Autograd (drop-in shim) path: how many backward calls between reads of the fixed-point overflow flag.  1 = every call:
@@ -203,7 +211,7 @@ class NetworkWithInputEncoding(nn.Module):
 
     def forward(self, x, selector=None, out_fp32=False):
         x = x.reshape(-1, self.n_input_dims).contiguous().float()
-        out = _FieldFn.apply(x, self.params, selector, self)
+        out = field_apply(self, x, self.params, selector)
         return out if out_fp32 else out.to(ops.torch_dtype(self.dtype_name))
 
     def extra_repr(self):

@@ -168,7 +168,7 @@ def test_graph_replay_of_the_variable_count_step_equals_eager():
         rand = {'jitter': torch.rand(B, device='cuda', generator=g), 'noise': torch.rand(B, 1, device='cuda', generator=g),
                 'bg': torch.rand(B, 3, device='cuda', generator=g)}
         scene.renderer.sample_capacity = B * 128
-        scene.sample_counters = torch.zeros(3, dtype=torch.int64, device='cuda')
+        scene.sample_counters.zero_()
         out = {}
         for kind in ('geo', 'app'):
             net = scene.nerf.geo_mlp if kind == 'geo' else scene.nerf.app_mlp
@@ -197,6 +197,7 @@ def test_graph_replay_of_the_variable_count_step_equals_eager():
         assert torch.equal(pe, pg) and torch.equal(me, mg), kind
     ce, cg = results['eager']['counters'], results['graph']['counters']
     assert ce == cg and ce[2] == 12 and 0 < ce[1] < ce[0], (ce, cg)          # compaction dropped samples; 12 steps counted
+    assert ce[3] <= 1024 * 128 and ce[4] == 0 and ce[5] == 0, ce             # largest batch; nothing skipped
 
 
 def test_adam_gate_skips_a_batch_without_samples(ops):
@@ -207,7 +208,7 @@ def test_adam_gate_skips_a_batch_without_samples(ops):
     p = torch.randn(n, generator=g).cuda(); m = torch.zeros(n).cuda(); v = torch.zeros(n).cuda()
     grad = torch.randn(n, generator=g).cuda()
     step = torch.zeros(1, dtype=torch.int32, device='cuda'); lr = torch.full((1,), 1e-2, device='cuda')
-    counters = torch.zeros(3, dtype=torch.int64, device='cuda')
+    counters = ops.step_counters('cuda')
     p0 = p.clone()
     for gate_val, want_step in ((0, 0), (17, 1), (0, 1)):
         gate = _nd(gate_val)
@@ -219,7 +220,52 @@ def test_adam_gate_skips_a_batch_without_samples(ops):
     ref = torch.nn.Parameter(p0.clone()); ref.grad = grad.clone()
     torch.optim.Adam([ref], lr=1e-2).step()
     assert float((p - ref.detach()).abs().max()) < 2e-6
-    assert counters.tolist() == [300, 17, 3]
+    assert counters.tolist() == [300, 17, 3, 100, 0, 0, 0, 0]
+
+
+def test_step_gate_skips_overflowed_and_truncated_batches(ops):
+    """perf_step_bookkeeping decides on the DEVICE whether the optimizer step is taken: a raised fixed-point overflow flag (local,
+    or the float sum of other ranks' flags) or a batch that marched more samples than the capacity closes the gate that
+    perf_adam_step_dev reads -- a corrupted or truncated gradient is never applied; the events are counted and the local flag
+    is consumed."""
+    n = 1000
+    p = torch.linspace(-1, 1, n).cuda(); m = torch.zeros(n).cuda(); v = torch.zeros(n).cuda()
+    grad = torch.ones(n).cuda()
+    step = torch.zeros(1, dtype=torch.int32, device='cuda'); lr = torch.full((1,), 1e-2, device='cuda')
+    counters = ops.step_counters('cuda')
+    eff = torch.zeros(1, dtype=torch.int64, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    remote = torch.zeros(1, dtype=torch.float32, device='cuda')
+    cases = [  # (local flag, remote flags, marched, capacity, taken)
+        (0, 0.0, 500, 1000, True), (1, 0.0, 500, 1000, False), (0, 2.0, 500, 1000, False), (0, 0.0, 1001, 1000, False),
+        (0, 0.0, 1000, 1000, True), (0, 0.0, 5000, 0, True)]
+    taken = 0
+    for lf, rf, marched, cap, want in cases:
+        flag.fill_(lf); remote.fill_(rf)
+        before = p.clone()
+        ops.step_bookkeeping(step, _nd(10), counters, _nd(marched), _nd(10), capacity=cap, overflow=flag, remote_flags=remote, eff_gate=eff)
+        ops.adam_step_dev(p, m, v, grad, step, lr, gate=eff)
+        taken += int(want)
+        assert int(eff.item()) == int(want) and int(step.item()) == taken and int(flag.item()) == 0
+        assert torch.equal(p, before) == (not want)
+    c = counters.tolist()
+    assert c[2] == len(cases) and c[3] == 5000 and c[4] == 2 and c[5] == 1, c
+
+
+def test_autograd_path_runs_beyond_the_health_poll_with_a_capacity_set():
+    """fused_steps = False (the autograd formulation of the training step, taken e.g. with density_loss_weight > 0) with
+    renderer.sample_capacity set: the health poll after OVERFLOW_CHECK_EVERY steps used to raise a NameError."""
+    from perf_amd import scene as S
+    scene, pool, rays, dist, rgb = _room_scene(batch=256)
+    scene.fused_steps = False
+    scene.renderer.sample_capacity = 256 * 128
+    opt = scene.make_optimizer(scene.nerf.geo_mlp, 0.0)
+    before = scene.nerf.geo_mlp.params.detach().clone()
+    for i in range(S.OVERFLOW_CHECK_EVERY + 2):
+        scene.update_lr(opt, scene.train_conf.geo_optimizer, 0.1)
+        scene.train_one_step_geo(opt, pool, progress=0.5)
+    assert opt.step_count == S.OVERFLOW_CHECK_EVERY + 2
+    assert not torch.equal(before, scene.nerf.geo_mlp.params.detach())
 
 
 def test_hashgrid_bwd_is_reentrant(ops):

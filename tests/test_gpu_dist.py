@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, out, port):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
+def _run(world, out, port, dp_mode='sharded'):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT, PERF_TEST_DP_MODE=dp_mode)
     worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
     if world == 1:
         cmd = [sys.executable, worker, out, '1024', '3']
@@ -27,30 +27,84 @@ def _run(world, out, port):
     return torch.load(out)
 
 
-def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(tmp_path):
-    one = _run(1, str(tmp_path / 'w1.pt'), 0)
-    two = _run(2, str(tmp_path / 'w2.pt'), 29571)
+def _common_checks(one, two):
     assert one['world'] == 1 and two['world'] == 2
-    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-20))
-    # the all-reduced gradient of the first step (identical parameters on both sides): 16-bit forward, fixed-point grid
-    # gradient whose unit follows each rank's own max |dfeat| -> equal up to that quantisation
-    assert rel(two['g_geo'], one['g_geo']) < 2e-3, rel(two['g_geo'], one['g_geo'])
-    assert rel(two['g_app'], one['g_app']) < 2e-3, rel(two['g_app'], one['g_app'])
     assert one['geo_steps'] == two['geo_steps'] == 3
-    # after 3 Adam steps per phase the parameters moved the same way (Adam's early steps are sign-like: an entry whose
-    # tiny gradient rounds differently moves by +-lr, hence a norm test relative to the distance travelled)
     assert torch.equal(one['geo0'], two['geo0']) and torch.equal(one['app0'], two['app0'])
-    for k in ('geo', 'app'):
-        moved = float((one[k] - one[k + '0']).norm())
-        assert moved > 0
-        assert float((two[k] - one[k]).norm()) < 0.1 * moved, (k, float((two[k] - one[k]).norm()), moved)
     # a batch without samples on any rank: the optimizer step is skipped everywhere (reference: nerf.py:204-206)
     assert one['empty_batch_skipped'] and two['empty_batch_skipped']
-    # the geometry step's colour render (query key 'rgb'; issued while the all-reduce is in flight under DP): rank 0 of
+    # the geometry step's colour render (query key 'rgb'; issued while the exchange is in flight under DP): rank 0 of
     # the 2-rank world holds the first half of the global batch
     per = two['first_colors'].shape[0]
     assert per * 2 == one['first_colors'].shape[0]
     assert float((two['first_colors'] - one['first_colors'][:per]).abs().max()) < 2e-3
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_run_bit_for_bit(tmp_path):
+    """Sharded exchange (perf_amd/dp.py): job-wide fixed-point units + integer reduce-scatter make the summed TABLE gradient of
+    two ranks equal the single-process one BIT FOR BIT (integer sums do not depend on how the samples are dealt to
+    workgroups or ranks).  The 3,072 / 7,168 MLP weight gradients are fp32 sums of per-rank MFMA reductions: equal to fp32
+    rounding, not to the bit."""
+    one = _run(1, str(tmp_path / 'w1.pt'), 0)
+    two = _run(2, str(tmp_path / 'w2.pt'), 29571)
+    two_r1 = torch.load(str(tmp_path / 'w2.pt') + '.1')
+    assert two['dp_mode'] == 'sharded'
+    _common_checks(one, two)
+    for key, n_net in (('geo', 3072), ('app', 7168)):
+        g1 = one['g_' + key]
+        (lo0, hi0), (lo1, hi1) = two[key + '_slice'], two_r1[key + '_slice']
+        assert lo0 == 0 and hi0 == lo1 and 2 * hi1 == g1.numel() - n_net
+        table = torch.cat([two['g_' + key][n_net:], two_r1['g_' + key][n_net:]])
+        assert torch.equal(table, g1[n_net:]), (key, float((table - g1[n_net:]).abs().max()))
+        net2, net1 = two['g_' + key][:n_net], g1[:n_net]
+        assert torch.equal(net2, two_r1['g_' + key][:n_net])                       # every rank holds the same summed MLP gradient
+        assert float((net2 - net1).abs().max()) <= 2e-5 * float(net1.abs().max()), key
+    # after ONE step the table part of the parameters is bit-identical as well; the masters agree on both ranks
+    n_net = 3072
+    assert torch.equal(two['geo1'][n_net:], one['geo1'][n_net:])
+    assert torch.equal(two['geo1'], two_r1['geo1']) and torch.equal(two['geo'], two_r1['geo']) and torch.equal(two['app'], two_r1['app'])
+    # later steps start from MLP weights that differ in their last bits: equal to a small fraction of the distance travelled
+    for k in ('geo', 'app'):
+        moved = float((one[k] - one[k + '0']).norm())
+        assert moved > 0
+        assert float((two[k] - one[k]).norm()) < 0.02 * moved, (k, float((two[k] - one[k]).norm()), moved)
+    assert two['counters'][4] == 0 and two['counters'][5] == 0                  # nothing overflowed, nothing was truncated
+
+
+def test_two_ranks_plain_allreduce_mode(tmp_path):
+    """dp_mode = 'allreduce': one all-reduce of the flat fp32 gradient (+ the sample-count slot), Adam on every rank; each
+    rank's fixed-point unit follows its own max |dfeat| -> equal to that quantisation."""
+    one = _run(1, str(tmp_path / 'w1.pt'), 0, 'allreduce')
+    two = _run(2, str(tmp_path / 'w2.pt'), 29573, 'allreduce')
+    assert two['dp_mode'] == 'allreduce'
+    _common_checks(one, two)
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-20))
+    assert rel(two['g_geo'], one['g_geo']) < 2e-3, rel(two['g_geo'], one['g_geo'])
+    assert rel(two['g_app'], one['g_app']) < 2e-3, rel(two['g_app'], one['g_app'])
+    for k in ('geo', 'app'):
+        moved = float((one[k] - one[k + '0']).norm())
+        assert float((two[k] - one[k]).norm()) < 0.1 * moved, (k, float((two[k] - one[k]).norm()), moved)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher (what the driver's scaling run does): bench.py spawns the ranks itself.
+    Two ranks share this box's one GPU over gloo (PERF_BENCH_ONE_DEVICE / PERF_BENCH_BACKEND); the line carries the weak
+    headline and the strong-scaling block of BASELINE config 3."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT, PERF_BENCH_ONE_DEVICE='1', PERF_BENCH_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--rays-per-gpu', '1024',
+           '--sustain-seconds', '0', '--psnr-geo-iters', '40', '--psnr-app-iters', '30', '--height', '128', '--width', '256']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['config']['rays_per_gpu_per_step'] == 1024 and line['config']['launch'] == 'eager'      # (gloo: no graph capture)
+    assert line['strong']['scaling'] == 'strong' and line['strong']['global_batch_rays'] == 1024 and line['strong']['value'] > 0
+    assert line['strong']['rays_per_gpu_per_step'] == 512
+    assert line['psnr'] is not None and line['health'] == {'skipped_for_overflow': 0, 'skipped_for_truncation': 0}
 
 
 @pytest.mark.parametrize('n_levels,log2_t', [(16, 18), (20, 20)])
