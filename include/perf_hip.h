@@ -138,13 +138,11 @@ int perf_points_normalize(const float* x, const float* aabb, float* x01, uint8_t
 
 /* tcnn kernel_grid: x01 [n,3] -> features, LEVEL-MAJOR: feat[(l*n + i)*2 + f], 16-bit.
  * Replaces the encoding half of tcnn.NetworkWithInputEncoding.forward (ngp_nerf.py:142,158,258).
- * tickets (device, PERF_FWD_TICKET_WORDS int32, may be NULL): work-distribution counters of the ticketed kernel (15/16-level
- * grids: (level group, chunk) units handed out on the device, neighbouring lanes that fall into the same cell share one
- * gather).  Zero them once; every call leaves them zeroed.  One block per launch in flight: calls that may run
- * concurrently (different streams) need their own.  NULL selects the statically dealt kernel; same results either way. */
-#define PERF_FWD_TICKET_WORDS 16
+ * 15/16-level grids: level groups are dealt to the XCDs in eight rotating phases (every L2 holds two tables at a time and
+ * every XCD serves every group for an eighth of the samples), and neighbouring lanes whose samples fall into the same cell
+ * of a level share ONE gather (run de-duplication) -- same features, bit for bit, as the plain kernel. */
 int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* table16,
-                      void* feat16, int64_t n, const int64_t* n_dev, int dtype, int32_t* tickets, void* stream);
+                      void* feat16, int64_t n, const int64_t* n_dev, int dtype, void* stream);
 
 /* Two tables of identical geometry (PeRF's density and colour grids) at the same points in one pass:
  * corner indices/weights are shared.  Same layouts as perf_hashgrid_fwd. */
@@ -248,7 +246,7 @@ int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, 
 int64_t perf_field_infer_scratch_bytes(const perf_grid_desc* grid, int64_t n);
 int perf_field_infer(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const uint8_t* sel,
                      const void* table16, const void* w16, float* out, int64_t n, const int64_t* n_dev,
-                     void* scratch, int64_t scratch_bytes, int dtype, int32_t* tickets /* as perf_hashgrid_fwd */, void* stream);
+                     void* scratch, int64_t scratch_bytes, int dtype, void* stream);
 
 /* Bytes of caller-owned workspace perf_mlp_bwd needs for n samples. */
 int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n);

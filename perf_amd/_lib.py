@@ -37,7 +37,6 @@ LOSS_SCALARS = 256       # PERF_LOSS_SCALARS
 STEP_COUNTERS = 8        # PERF_STEP_COUNTERS
 HEADROOM_STATE_WORDS = 2 * MAX_LEVELS + 8    # PERF_HEADROOM_STATE_WORDS
 DP_STATS = 64            # PERF_DP_STATS
-FWD_TICKET_WORDS = 16    # PERF_FWD_TICKET_WORDS
 _SIGS = {
     'perf_version': (c_int, []),
     'perf_last_error': (c_char_p, []),
@@ -49,7 +48,7 @@ _SIGS = {
     'perf_step_bookkeeping': (c_int, [P, P, P, P, P, c_int64, P, P, P, P]),
     'perf_points_from_rays': (c_int, [P, P, P, P, P, POINTER(c_float), P, P, c_int64, P, P]),
     'perf_points_normalize': (c_int, [P, POINTER(c_float), P, P, c_int64, P]),
-    'perf_hashgrid_fwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P, c_int, P, P]),
+    'perf_hashgrid_fwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P, c_int, P]),
     'perf_hashgrid_fwd2': (c_int, [POINTER(GridDesc), P, P, P, P, P, c_int64, c_int, P]),
     'perf_hashgrid_fwd_f32': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
     'perf_hashgrid_bwd_workspace_bytes': (c_int64, [POINTER(GridDesc), c_int64]),
@@ -63,7 +62,7 @@ _SIGS = {
     'perf_hashgrid_bwd_bwd_param': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),
     'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, P, c_int, P]),
     'perf_field_infer_scratch_bytes': (c_int64, [POINTER(GridDesc), c_int64]),
-    'perf_field_infer': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, P, c_int64, P, P, c_int64, c_int, P, P]),
+    'perf_field_infer': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, P, c_int64, P, P, c_int64, c_int, P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
     'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, P, P, P, P, P, c_int64, c_int64, P, c_int, P]),
     'perf_pano_raygen': (c_int, [POINTER(c_float), c_int32, c_int32, c_int32, c_int32, P, P, P]),

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const 
 }
 
 
-// ---- forward encode, second generation: ticketed (level group, chunk) units + run de-duplication --------------------------
+// ---- forward encode, second generation: run de-duplication + rotating level groups -----------------------------------------
 // The gathers of this kernel are bound by the L1's request rate (one cache-line look-up per active lane and cycle; the
 // tables sit in L2 / Infinity Cache), not by bandwidth.  Two things reduce what the slowest XCD has to issue:
 //  (1) run de-duplication: consecutive samples of a ray (training batches) and equal-rank samples of neighbouring pixels
@@ -165,34 +165,31 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const 
 //      One DPP compare per level finds the runs; only run heads issue the gathers, the others fetch the head's packed
 //      dwords with ds_bpermute (LDS crossbar, ~2 cycles per 64 lanes instead of 64 L1 look-ups).  Interpolation stays
 //      per lane: features are bit-identical.  A wave whose lanes share little (> kShareMaxHeads heads) gathers as before.
-//  (2) de-duplication makes the level groups unequal (a coarse level costs a fraction of a fine one), and a static
-//      group <-> XCD pinning would leave the kernel as long as its most expensive group.  Work is therefore handed out as
-//      (level group, 256-sample chunk) TICKETS: workgroup b (on XCD b % 8 under round-robin dispatch) first serves its home
-//      group -- each L2 then holds two tables as before -- and, when that is exhausted, takes tickets of the other groups.
-//      tickets: 9 zeroed device words per launch in flight; the last workgroup leaves them zeroed for the next launch.
-constexpr int kShareMaxHeads = 44;
+//  (2) de-duplication makes the level groups unequal (a coarse level costs a fraction of a fine one), and a fixed
+//      group <-> XCD pinning would leave the kernel as long as its most expensive group.  The pinning therefore ROTATES:
+//      the chunks of a launch are cut into eight phases, and in phase p XCD x serves group (x + p) % 8.  Every XCD serves
+//      every group for an eighth of the samples -- equal work whatever the levels cost -- while its L2 still holds two
+//      tables at a time (refilled from the Infinity Cache at each of the seven phase changes).  (A first attempt handed
+//      out (group, chunk) tickets through one device counter per group: same-address atomics retire at ~105 ns each on
+//      gfx950, 4096 tickets per counter made the kernel three times SLOWER -- tools/exp/fwd_v2.py, profiles/README.md.)
+constexpr int kShareMaxHeads = 56;
 
 template <typename T16>
 __global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, const float* __restrict__ x01,
                                                               const uint32_t* __restrict__ table,
                                                               uint32_t* __restrict__ feat, int64_t n,
-                                                              const int64_t* __restrict__ n_dev, int32_t* __restrict__ tickets,
-                                                              int dedup, int steal) {
-    __shared__ int s_chunk;
+                                                              const int64_t* __restrict__ n_dev, int dedup, int rotate) {
     const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
-    const int64_t nchunks = (n_live + 255) >> 8;
+    const int64_t nchunks_live = (n_live + 255) >> 8;
+    const int64_t nchunks_grid = (int64_t)(gridDim.x >> 3);
+    const int xcd = (int)(blockIdx.x & 7);
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= mine
-    int g = (int)(blockIdx.x & 7);
-    int tries = 0;
-    const int max_tries = steal ? 8 : 1;
-    while (tries < max_tries) {
-        if (threadIdx.x == 0) s_chunk = atomicAdd(&tickets[g], 1);
-        __syncthreads();
-        const int64_t chunk = s_chunk;
-        __syncthreads();                                         // (s_chunk is rewritten in the next round)
-        if (chunk >= nchunks) { ++tries; g = (g + 1) & 7; continue; }
+    // chunk-stride loop: a capacity-sized launch (n >> n_live) is capped at nchunks_grid chunks per XCD
+    for (int64_t chunk = (int64_t)(blockIdx.x >> 3); chunk < nchunks_live; chunk += nchunks_grid) {
+        const int phase = rotate ? (int)((chunk * 8) / nchunks_live) : 0;
+        const int g = (xcd + phase) & 7;
         const int64_t i = chunk * 256 + threadIdx.x;
         const bool live = i < n_live;
         const int64_t ii = live ? i : n_live - 1;                // (idle lanes of the last chunk repeat its last sample)
@@ -252,11 +249,6 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, con
             }
             if (live) feat[(int64_t)lv[pass] * n + i] = T16::pack(a0, a1);
         }
-    }
-    // the last workgroup to run out of work leaves the tickets zeroed for the next launch
-    if (threadIdx.x == 0 && atomicAdd(&tickets[8], 1) == (int)gridDim.x - 1) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j) tickets[j] = 0;
     }
 }
 
@@ -1325,7 +1317,7 @@ static inline unsigned grouped_grid(int64_t n) { return (unsigned)(div_up(n, 256
 using namespace perf;
 
 extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* table16,
-                                 void* feat16, int64_t n, const int64_t* n_dev, int dtype, int32_t* tickets, void* stream) {
+                                 void* feat16, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
     GridParams gp;
     int rc = fill_params(grid, &gp);
     if (rc) return rc;
@@ -1336,26 +1328,23 @@ extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, c
     // (a rank's slice of a level-sharded table, the 5-level proposal field) would otherwise keep 1-3 XCDs busy
     static const int affinity_env = getenv("PERF_FWD_NO_XCD_AFFINITY") ? 0 : 1;
     const int xcd_affinity = (affinity_env && gp.n_levels >= 15) ? 1 : 0;
-    // ---- ticketed kernel with run de-duplication (16-level class grids, caller-provided tickets)
-    static const int v2_env = getenv("PERF_FWD_V2") ? atoi(getenv("PERF_FWD_V2")) : 1;
-    static const int dedup_env = getenv("PERF_FWD_NO_DEDUP") ? 0 : 1, steal_env = getenv("PERF_FWD_NO_STEAL") ? 0 : 1;
-    if (tickets && v2_env && xcd_affinity && gp.n_levels <= 16) {
-        static const int64_t max_blocks = getenv("PERF_FWD_V2_BLOCKS") ? atoll(getenv("PERF_FWD_V2_BLOCKS")) : 2048;
-        int64_t blocks = div_up(n, 256) * 8;
-        if (blocks > max_blocks) blocks = max_blocks;
-        dim3 g((unsigned)blocks), b(256);
-        if (dtype == PERF_DTYPE_BF16)
-            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, tickets, dedup_env, steal_env);
-        else if (dtype == PERF_DTYPE_FP16)
-            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, tickets, dedup_env, steal_env);
-        else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
-        PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
-        return PERF_OK;
-    }
     // chunks (of 256 samples) per level group in one launch; beyond that the workgroups loop (experiment knob, read once)
     static const int64_t max_chunks = getenv("PERF_FWD_MAX_CHUNKS") ? atoll(getenv("PERF_FWD_MAX_CHUNKS")) : kFwdMaxChunks;
     int64_t chunks = div_up(n, 256);
     if (xcd_affinity && max_chunks > 0 && chunks > max_chunks) chunks = max_chunks;
+    // ---- rotating level groups + run de-duplication (15/16-level grids; experiment switches read once)
+    static const int v2_env = getenv("PERF_FWD_V2") ? atoi(getenv("PERF_FWD_V2")) : 1;
+    static const int dedup_env = getenv("PERF_FWD_NO_DEDUP") ? 0 : 1, rotate_env = getenv("PERF_FWD_NO_ROTATE") ? 0 : 1;
+    if (v2_env && xcd_affinity && gp.n_levels <= 16) {
+        dim3 g((unsigned)(chunks * 8)), b(256);
+        if (dtype == PERF_DTYPE_BF16)
+            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, dedup_env, rotate_env);
+        else if (dtype == PERF_DTYPE_FP16)
+            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, dedup_env, rotate_env);
+        else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
+        PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
+        return PERF_OK;
+    }
     dim3 g(xcd_affinity ? (unsigned)(chunks * 8) : (unsigned)(div_up(div_up(n, 256), 8) * 64)), b(256);
     if (dtype == PERF_DTYPE_BF16)
         hipLaunchKernelGGL(hashgrid_fwd_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, xcd_affinity);

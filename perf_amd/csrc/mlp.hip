@@ -690,12 +690,12 @@ extern "C" int64_t perf_field_infer_scratch_bytes(const perf_grid_desc* grid, in
 
 extern "C" int perf_field_infer(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const uint8_t* sel,
                                 const void* table16, const void* w16, float* out, int64_t n, const int64_t* n_dev,
-                                void* scratch, int64_t scratch_bytes, int dtype, int32_t* tickets, void* stream) {
+                                void* scratch, int64_t scratch_bytes, int dtype, void* stream) {
     PERF_REQUIRE(grid && mlp, "NULL descriptor");
     PERF_REQUIRE(mlp->n_levels == grid->n_levels, "perf_field_infer: the MLP takes %d levels, the grid has %d", (int)mlp->n_levels, (int)grid->n_levels);
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(scratch && scratch_bytes >= perf_field_infer_scratch_bytes(grid, n), "perf_field_infer: scratch too small");
-    int rc = perf_hashgrid_fwd(grid, x01, table16, scratch, n, n_dev, dtype, tickets, stream);
+    int rc = perf_hashgrid_fwd(grid, x01, table16, scratch, n, n_dev, dtype, stream);
     if (rc) return rc;
     return perf_mlp_fwd(mlp, w16, scratch, sel, out, n, n_dev, dtype, stream);
 }

@@ -155,23 +155,6 @@ def points_normalize(x, aabb):
 
 
 # ---- hash grid -----------------------------------------------------------------------------------
-_FWD_TICKETS = {}
-
-
-def fwd_tickets(device):
-    """Zeroed ticket block of the ticketed encode kernel, one per (device, stream): launches on one stream are serial, and
-    every launch leaves its block zeroed.  (Under hipGraph capture the block of the capturing stream is baked into the graph;
-    replays are serial on their stream as well.)"""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    t = _FWD_TICKETS.get(key)
-    if t is None:
-        t = torch.zeros(_lib.FWD_TICKET_WORDS, dtype=torch.int32, device=device)
-        if torch.cuda.is_current_stream_capturing():
-            return t               # (allocated inside a capture: lives in the graph's pool, zeroed by the captured fill)
-        _FWD_TICKETS[key] = t
-    return t
-
-
 def hashgrid_fwd(grid: GridConfig, x01, table16, n_dev=None):
     """x01 [n,3] f32, table16 [total*2] 16-bit -> feat [L, n, 2] 16-bit (level major).  n_dev (device int64 [1]): only the
     first min(n, n_dev) samples are encoded (n = capacity = level stride)."""
@@ -179,7 +162,7 @@ def hashgrid_fwd(grid: GridConfig, x01, table16, n_dev=None):
     feat = torch.empty(grid.n_levels, n, 2, dtype=table16.dtype, device=x01.device)
     d = grid.desc()
     _call('perf_hashgrid_fwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(table16), _p(feat), n, _nd(n_dev),
-              dtype_code(table16.dtype), _p(fwd_tickets(x01.device)), _stream())
+              dtype_code(table16.dtype), _stream())
     return feat
 
 
@@ -333,7 +316,7 @@ def field_infer(grid: GridConfig, mlp: MlpConfig, x01, sel, w16, n_dev=None):
     scratch = torch.empty(grid.n_levels * n, dtype=torch.int32, device=x01.device)
     gd, md = grid.desc(), mlp.desc()
     _call('perf_field_infer', ctypes.byref(gd), ctypes.byref(md), _p(_f32(x01, 'x01')), _p(sel), _p(w16[n_net:]), _p(w16[:n_net]),
-          _p(out), n, _nd(n_dev), _p(scratch), scratch.numel() * 4, dtype_code(w16.dtype), _p(fwd_tickets(x01.device)), _stream())
+          _p(out), n, _nd(n_dev), _p(scratch), scratch.numel() * 4, dtype_code(w16.dtype), _stream())
     return out
 
 

@@ -246,3 +246,109 @@ def test_morphology_matches_scipy():
             e = ndimage.binary_erosion(m, structure=kb, border_value=1)
             assert np.array_equal(V.dilate(mt, k)[0, 0].numpy() > 0.5, d)
             assert np.array_equal(V.erode(mt, k)[0, 0].numpy() > 0.5, e)
+
+
+# ---- the reference's training-step and visibility glue (tests/golden/train_glue.npz, visibility.npz: made by running the
+#      reference's own NeRFScene.train_one_step_geo / _app, get_pano_visibility_mask, SupInfoPool.geo_check and PanoSupInfo on
+#      oracle-backed operators, tests/golden/make_fixtures.py) -----------------------------------------------------------------
+def _train_glue_case(g, tag):
+    """Inputs of one recorded step -> (o, d, gt_dist, gt_rgb, occ, geo, app, t0, bg, noise)."""
+    h, w, res = int(g['h']), int(g['w']), int(g['res'])
+    o_all, d_all = O.pano_rays(torch.eye(4), h, w)
+    o_all = o_all.reshape(-1, 3); d_all = d_all.reshape(-1, 3)
+    dist_all, rgb_all = O.synthetic_room(d_all)
+    occ = O.gen_occ_grid(o_all, d_all, dist_all, res).reshape(res, res, res).bool().numpy()
+    idx = torch.from_numpy(g[f'{tag}_idx'])
+    gs, as_ = O.geo_spec(), O.app_spec()
+    geo = O.init_field_params(gs, int(g['geo_seed'])); app = O.init_field_params(as_, int(g['app_seed']))
+    geo[gs.n_net:] *= float(g['grid_gain']); app[as_.n_net:] *= float(g['grid_gain'])
+    geo[:gs.n_net] *= 3.0
+    t0 = (np.zeros(len(idx), np.float32) + g[f'{tag}_jitter'] * np.float32(float(g['step']))).astype(np.float32)
+    return (o_all[idx].contiguous(), d_all[idx].contiguous(), dist_all.reshape(-1, 1)[idx], rgb_all.reshape(-1, 3)[idx], occ, geo, app, t0,
+            torch.from_numpy(g[f'{tag}_bg']), torch.from_numpy(g[f'{tag}_noise']))
+
+
+def _dense_grad(g, tag):
+    out = np.zeros(int(g[f'{tag}_grad_numel']), np.float32)
+    out[g[f'{tag}_grad_idx']] = g[f'{tag}_grad_val']
+    return out
+
+
+def test_train_step_glue_matches_reference():
+    """oracle.occ_render + geo_step_loss / app_step_loss == the reference's train_one_step_geo / train_one_step_app
+    (nerf.py:186-297): the loss terms it logs and the gradient its optimizer.step() sees (128x, never unscaled)."""
+    g = np.load(f'{G}/train_glue.npz')
+    step = float(g['step'])
+    for tag in ('geo_p2', 'geo_p8', 'app_p5'):
+        o, d, gt_d, gt_c, occ, geo, app, t0, bg, noise = _train_glue_case(g, tag)
+        kind = tag[:3]
+        geo.requires_grad_(kind == 'geo'); app.requires_grad_(kind == 'app')
+        out = O.occ_render(o, d, geo, app, occ, [-1, -1, -1, 1, 1, 1], training=True, t0=t0, bg_color=bg, dist_noise=noise,
+                           near=0.0, far=1.5, step=step, geo_grad=(kind == 'geo'), app_grad=(kind == 'app'))
+        if kind == 'geo':
+            loss, dl, distl = O.geo_step_loss(out, gt_d, float(g[f'{tag}_progress']))
+            assert abs(float(dl) - float(g[f'{tag}_depth_loss'])) < 1e-6 * max(1.0, abs(float(g[f'{tag}_depth_loss'])))
+            assert abs(float(distl) - float(g[f'{tag}_dist_loss'])) < 1e-6 * max(1.0, abs(float(g[f'{tag}_dist_loss'])))
+        else:
+            loss, cl = O.app_step_loss(out, gt_c)
+            assert abs(float(cl) - float(g[f'{tag}_color_loss'])) < 1e-6
+        loss.backward()
+        grad = (geo if kind == 'geo' else app).grad.numpy()
+        assert grad.size == int(g[f'{tag}_grad_numel'])
+        ref_norm = float(g[f'{tag}_grad_norm'])
+        assert abs(float(np.sqrt((grad.astype(np.float64) ** 2).sum())) - ref_norm) < 1e-5 * ref_norm
+        pg = np.random.RandomState(123).standard_normal((3, grad.size)).astype(np.float32)
+        proj = pg.astype(np.float64) @ grad.astype(np.float64)
+        assert np.abs(proj - g[f'{tag}_grad_proj']).max() < 1e-4 * ref_norm
+        if f'{tag}_grad_idx' in g.files:
+            ref = _dense_grad(g, tag)
+            assert np.abs(grad - ref).max() <= 2e-5 * np.abs(ref).max(), tag
+
+
+def _vis_infos(g):
+    infos = []
+    for i in range(2):
+        infos.append({'pose': torch.from_numpy(g[f'pano{i}_pose']), 'distance_map': torch.from_numpy(g[f'pano{i}_distance']),
+                      'mask': torch.from_numpy(g[f'pano{i}_mask'])})
+    return infos
+
+
+def test_visibility_and_geo_check_glue_match_reference():
+    """perf_amd.visibility's torch formulation (the test reference of the HIP kernels) == the reference's own
+    get_pano_visibility_mask (nerf.py:321-358) and SupInfoPool.geo_check (sup_info.py:261-302)."""
+    from perf_amd import visibility as V
+    g = np.load(f'{G}/visibility.npz')
+    h, w = int(g['h']), int(g['w'])
+    o, d = O.pano_rays(torch.from_numpy(g['probe_pose']), h, w)
+    dist = torch.from_numpy(g['probe_distance'])
+    infos = _vis_infos(g)
+    vis = V.pano_visibility_mask(o, d, dist, infos, use_kernels=False)
+    chk = V.geo_check(o, d, dist[..., None], infos, use_kernels=False)
+    # the depth test compares two fp32 distances: a pixel may sit on the threshold; the morphology then spreads it
+    assert float((vis.numpy() != g['visibility_mask']).mean()) < 0.01, float((vis.numpy() != g['visibility_mask']).mean())
+    assert float((chk.numpy() != g['geo_check']).mean()) < 0.01
+    assert 0.05 < float(g['visibility_mask'].mean()) < 0.98 and 0.02 < float(g['geo_check'].mean()) < 0.98        # non-trivial masks
+
+
+def test_pano_sup_info_validity_rules_match_reference():
+    """The validity rules SupInfoPool.register_sup_info applies (perf_amd/scene.py:_edge_free + mask / distance / normal tests) ==
+    PanoSupInfo.__init__ (sup_info.py:27-97), and the supervision rays they select == update_sup_info (:99-120)."""
+    from perf_amd.scene import _edge_free
+    g = np.load(f'{G}/visibility.npz')
+    h, w = int(g['h']), int(g['w'])
+    for i in range(2):
+        dist = torch.from_numpy(g[f'pano{i}_distance']); mask_in = torch.from_numpy(g[f'pano{i}_mask_in'])
+        normal = torch.from_numpy(g[f'pano{i}_normal'])
+        mask_raw = (mask_in > .5) & (dist > 1e-5)
+        assert np.array_equal(mask_raw.numpy(), g[f'pano{i}_mask_raw'])
+        valid = mask_raw & _edge_free(dist)
+        _, local_d = O.pano_rays(torch.eye(4), h, w)
+        valid = valid & (((-local_d) * normal).sum(-1, True).clip(0., 1.) > 0.15)
+        assert np.array_equal(valid.numpy(), g[f'pano{i}_mask']), int((valid.numpy() != g[f'pano{i}_mask']).sum())
+        assert 0.3 < float(valid.float().mean()) < 0.99
+        # the rays of the valid pixels, in row-major order
+        o, d = O.pano_rays(torch.from_numpy(g[f'pano{i}_pose']), h, w)
+        idx = torch.where(valid[..., 0])
+        assert np.abs(d[idx].numpy() - g[f'pano{i}_sup_dirs']).max() < 2e-6
+        assert np.array_equal(o[idx].numpy(), g[f'pano{i}_sup_positions'])
+        assert np.array_equal(dist[idx].numpy(), g[f'pano{i}_sup_distances'])

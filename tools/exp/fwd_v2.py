@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Forward-encode A/B: the statically dealt kernel against the ticketed kernel with run de-duplication (hashgrid.hip), on three
+"""Forward-encode A/B: the statically dealt kernel against the kernel with rotating level groups and run de-duplication (hashgrid.hip), on three
 sample distributions -- (train) 8192 rays x 128 lattice samples in ray order, as bench.py's step encodes them; (eval) the
 2-row heads of neighbouring pixels of a 512x1024 frame, as the two-phase sampler of a trained scene encodes them; (random)
 uniform points.  Every variant runs in its own process (the switches are read once); features must be bit-identical.
@@ -18,11 +18,10 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     'static (round 2 kernel)': {'PERF_FWD_V2': '0'},
-    'tickets + dedup': {},
-    'tickets only': {'PERF_FWD_NO_DEDUP': '1'},
-    'dedup only (no stealing)': {'PERF_FWD_NO_STEAL': '1'},
-    'tickets + dedup, 1024 blocks': {'PERF_FWD_V2_BLOCKS': '1024'},
-    'tickets + dedup, 4096 blocks': {'PERF_FWD_V2_BLOCKS': '4096'},
+    'rotate + dedup': {},
+    'rotate only': {'PERF_FWD_NO_DEDUP': '1'},
+    'dedup only (fixed pinning)': {'PERF_FWD_NO_ROTATE': '1'},
+    'neither (new kernel body)': {'PERF_FWD_NO_ROTATE': '1', 'PERF_FWD_NO_DEDUP': '1'},
 }
 
 
@@ -76,8 +75,7 @@ def worker(out_path):
                 ops.hashgrid_fwd(cfg, x, t16)
             b.record(); torch.cuda.synchronize()
             res[kind] = {'n': x.shape[0], 'ms': a.elapsed_time(b) / reps,
-                         'sha': hashlib.sha256(feat.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16],
-                         'tickets_left_zero': bool((ops.fwd_tickets(dev) == 0).all())}
+                         'sha': hashlib.sha256(feat.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]}
     json.dump(res, open(out_path, 'w'))
 
 
@@ -93,7 +91,7 @@ def main():
     for name, env in VARIANTS.items():
         tmp = a.out + '.tmp'
         e = dict(os.environ, **env)
-        for k in ('PERF_FWD_V2', 'PERF_FWD_NO_DEDUP', 'PERF_FWD_NO_STEAL', 'PERF_FWD_V2_BLOCKS'):
+        for k in ('PERF_FWD_V2', 'PERF_FWD_NO_DEDUP', 'PERF_FWD_NO_ROTATE'):
             if k not in env:
                 e.pop(k, None)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--worker', tmp], env=e, capture_output=True, text=True, timeout=600)
