@@ -2,7 +2,18 @@
 dense_travel_pose_sampler.py:26-116).  They run once per scene on the host (scipy filters, a
 10,000-step annealed tour) and only produce the 4x4 poses the ray-generation kernel consumes, so they stay on the
 CPU; the reference's hard-coded .cuda() hops are dropped.  Pinned on golden poses made by the reference
-(tests/golden/poses.npz)."""
+(tests/golden/poses.npz).
+
+The dense trajectory is a pure function of (anchor positions, n_dense_poses, dir_bias_ratio, numpy's global RNG state): its
+10,000 sequential accept/reject decisions consume that stream step by step and compare float32 tour lengths summed by
+torch.sum, so it cannot be vectorised or moved to the GPU without changing the trajectory the golden poses pin.  It is
+taken OFF THE CRITICAL PATH instead: `DenseTravelPoseSampler.start(...)` runs it in a forked worker
+process (CPU only) as soon as the anchors exist -- i.e. while the scene still trains -- and `.result()` hands back the
+sampler plus the RNG state the sequential call would have left behind; results are memoised per input key.  The frame
+loop of render_dense then starts without waiting (perf_amd/traverse.py, tools/render_dense.py reports both wall times)."""
+import hashlib
+import multiprocessing as mp
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -108,11 +119,104 @@ def _annealed_tour(positions: torch.Tensor, n_steps=10000):
     return torch.from_numpy(order)
 
 
+_DENSE_CACHE = {}
+
+
+def _rng_digest():
+    st = np.random.get_state()
+    return hashlib.sha256(st[1].tobytes() + str((st[0], st[2], st[3], st[4])).encode()).hexdigest()
+
+
+def _dense_worker(conn, sparse_poses, n_dense_poses, dir_bias_ratio, rng_state):
+    """Forked worker (never touches the GPU): the sequential construction, from the parent's RNG state."""
+    try:
+        torch.set_num_threads(1)
+        np.random.set_state(rng_state)
+        d = DenseTravelPoseSampler(_Poses(sparse_poses), n_dense_poses, dir_bias_ratio, _cache=False)
+        conn.send((d.sample_poses.numpy(), np.random.get_state(), None))
+    except Exception as e:       # noqa: BLE001
+        conn.send((None, None, repr(e)))
+    conn.close()
+
+
+class _Poses:
+    """Anything with n_poses / sample_pose(i), from a stack of 4x4 poses (what crosses the process boundary)."""
+
+    def __init__(self, poses):
+        self.poses = poses
+        self.n_poses = len(poses)
+
+    def sample_pose(self, idx):
+        return self.poses[idx]
+
+
+class DensePoseFuture:
+    """Handle of a dense trajectory being computed in a worker process (DenseTravelPoseSampler.start)."""
+
+    def __init__(self, key, proc=None, conn=None, ready=None):
+        self.key, self.proc, self.conn, self._ready = key, proc, conn, ready
+
+    def done(self):
+        return self._ready is not None or self.conn.poll()
+
+    def result(self):
+        """The sampler; numpy's global RNG is left in the state the sequential construction would have left it in."""
+        if self._ready is None:
+            poses, rng_state, err = self.conn.recv()
+            self.proc.join()
+            if err is not None:
+                raise RuntimeError(f'dense pose sampler worker failed: {err}')
+            _DENSE_CACHE[self.key] = (torch.from_numpy(poses), rng_state)
+            self._ready = _DENSE_CACHE[self.key]
+        poses, rng_state = self._ready
+        np.random.set_state(rng_state)
+        return DenseTravelPoseSampler._from_poses(poses)
+
+
 class DenseTravelPoseSampler:
     """Smooth dense trajectory through the sparse anchors with look-ahead orientations."""
 
-    def __init__(self, sparse_pose_sampler, n_dense_poses, dir_bias_ratio=-1):
-        sparse = torch.stack([sparse_pose_sampler.sample_pose(i) for i in range(sparse_pose_sampler.n_poses)], 0)
+    @staticmethod
+    def _key(sparse, n_dense_poses, dir_bias_ratio):
+        return (hashlib.sha256(sparse.numpy().tobytes()).hexdigest(), int(n_dense_poses), float(dir_bias_ratio), _rng_digest())
+
+    @classmethod
+    def _from_poses(cls, poses):
+        self = cls.__new__(cls)
+        self.sample_poses = poses.clone()
+        self.n_poses = len(poses)
+        return self
+
+    @classmethod
+    def start(cls, sparse_pose_sampler, n_dense_poses, dir_bias_ratio=-1):
+        """Begin the construction in a forked worker process and return at once -> DensePoseFuture.  Call it as soon as the
+        anchors exist (before / while the scene trains); the worker starts from the CURRENT global numpy RNG state, and
+        .result() restores the state the sequential call would have left, so nothing downstream changes -- provided nobody
+        draws from numpy's global RNG in between."""
+        sparse = torch.stack([sparse_pose_sampler.sample_pose(i) for i in range(sparse_pose_sampler.n_poses)], 0).float()
+        key = cls._key(sparse, n_dense_poses, dir_bias_ratio)
+        if key in _DENSE_CACHE:
+            return DensePoseFuture(key, ready=_DENSE_CACHE[key])
+        ctx = mp.get_context('fork')
+        parent, child = ctx.Pipe(duplex=False)
+        proc = ctx.Process(target=_dense_worker, args=(child, sparse, n_dense_poses, dir_bias_ratio, np.random.get_state()), daemon=True)
+        proc.start()
+        child.close()
+        return DensePoseFuture(key, proc, parent)
+
+    def __init__(self, sparse_pose_sampler, n_dense_poses, dir_bias_ratio=-1, _cache=True):
+        sparse = torch.stack([sparse_pose_sampler.sample_pose(i) for i in range(sparse_pose_sampler.n_poses)], 0).float()
+        key = self._key(sparse, n_dense_poses, dir_bias_ratio) if _cache else None
+        if key is not None and key in _DENSE_CACHE:             # same anchors, same RNG state: same trajectory, same RNG afterwards
+            poses, rng_state = _DENSE_CACHE[key]
+            np.random.set_state(rng_state)
+            self.sample_poses, self.n_poses = poses.clone(), len(poses)
+            return
+        self._build(sparse, n_dense_poses, dir_bias_ratio)
+        if key is not None:
+            _DENSE_CACHE[key] = (self.sample_poses.clone(), np.random.get_state())
+
+    def _build(self, sparse, n_dense_poses, dir_bias_ratio):
         tour = sparse[_annealed_tour(sparse[:, :3, 3])][:, :3, 3]
         total = n_dense_poses * 50
         seg_len = torch.linalg.norm(tour[1:] - tour[:-1], 2, -1, True)

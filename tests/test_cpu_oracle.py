@@ -352,3 +352,27 @@ def test_pano_sup_info_validity_rules_match_reference():
         assert np.abs(d[idx].numpy() - g[f'pano{i}_sup_dirs']).max() < 2e-6
         assert np.array_equal(o[idx].numpy(), g[f'pano{i}_sup_positions'])
         assert np.array_equal(dist[idx].numpy(), g[f'pano{i}_sup_distances'])
+
+
+def test_dense_pose_sampler_in_a_worker_process_equals_the_in_line_call():
+    """DenseTravelPoseSampler.start (forked worker, off the critical path of render_dense) == the in-line construction that
+    is pinned on the reference's golden poses: same trajectory, same numpy RNG state afterwards; a second request with the
+    same inputs is served from the memo."""
+    import time
+    from perf_amd import pose_sampler as PS
+    g = np.load(f'{G}/poses.npz')
+    s = PS.CirclePoseSampler(torch.from_numpy(g['distance_map']), [.2, .4, .6], [8, 8, 8])
+    PS._DENSE_CACHE.clear()
+    np.random.seed(0)
+    fut = PS.DenseTravelPoseSampler.start(s, 180)
+    dense = fut.result()
+    after_async = np.random.rand()
+    assert np.abs(dense.sample_poses.numpy() - g['dense']).max() < 1e-5
+    PS._DENSE_CACHE.clear()
+    np.random.seed(0)
+    ref = PS.DenseTravelPoseSampler(s, 180)
+    assert torch.equal(ref.sample_poses, dense.sample_poses) and np.random.rand() == after_async
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    again = PS.DenseTravelPoseSampler.start(s, 180)
+    assert again.done() and torch.equal(again.result().sample_poses, ref.sample_poses) and time.perf_counter() - t0 < 0.05
