@@ -1052,9 +1052,12 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_unfix_kernel(GridParams gp, 
 __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp, TileParams tp, const float2* __restrict__ ws,
                                                                   float2* __restrict__ grad, int32_t* __restrict__ hr_state,
                                                                   const int32_t* __restrict__ shifts, int fixed,
-                                                                  int32_t* __restrict__ overflow_flag) {
+                                                                  int32_t* __restrict__ overflow_flag, int n_ticket_blocks) {
     const int l = blockIdx.y;
     const int R = tp.replicas_of[l];
+    // (rows of levels without replicas have nothing to add up: they leave at once, without a ticket -- same-address atomics
+    //  retire at ~11 ns each; with no replicated level at all, workgroup (0, 0) applies the feedback)
+    if (R <= 1 && !(n_ticket_blocks == 0 && blockIdx.x == 0 && blockIdx.y == 0)) return;
     if (R > 1) {
         const uint32_t size = gp.size[l];
         const float from_fixed = fixed ? ldexpf(1.0f, -shifts[l]) : 1.0f;
@@ -1089,13 +1092,15 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp,
         }
     }
     if (!hr_state) return;
-    // ---- headroom feedback by the last workgroup to get here (every workgroup of the launch takes a ticket)
+    // ---- headroom feedback by the last workgroup of the replicated rows to get here
     __shared__ int last_block;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last_block = (atomicAdd(&hr_state[2 * PERF_MAX_LEVELS], 1) == (int)(gridDim.x * gridDim.y) - 1) ? 1 : 0;
-    __syncthreads();
-    if (!last_block) return;
+    if (n_ticket_blocks > 0) {
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) last_block = (atomicAdd(&hr_state[2 * PERF_MAX_LEVELS], 1) == n_ticket_blocks - 1) ? 1 : 0;
+        __syncthreads();
+        if (!last_block) return;
+    }
     __threadfence();
     if ((int)threadIdx.x < gp.n_levels) {
         const int fm = atomicMax(&hr_state[PERF_MAX_LEVELS + threadIdx.x], 0);     // (an atomic read: the value sits in L2)
@@ -1336,6 +1341,10 @@ extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, c
     static const int v2_env = getenv("PERF_FWD_V2") ? atoi(getenv("PERF_FWD_V2")) : 1;
     static const int dedup_env = getenv("PERF_FWD_NO_DEDUP") ? 0 : 1, rotate_env = getenv("PERF_FWD_NO_ROTATE") ? 0 : 1;
     if (v2_env && xcd_affinity && gp.n_levels <= 16) {
+        // the workgroups loop over chunks (chunk-stride): a few thousand of them fill the chip, and a capacity-sized launch
+        // with a handful of live samples (eval tails, trained-scene training batches) costs ~1 us instead of ~10
+        static const int64_t v2_chunks = getenv("PERF_FWD_V2_CHUNKS") ? atoll(getenv("PERF_FWD_V2_CHUNKS")) : 512;
+        if (chunks > v2_chunks) chunks = v2_chunks;
         dim3 g((unsigned)(chunks * 8)), b(256);
         if (dtype == PERF_DTYPE_BF16)
             hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, dedup_env, rotate_env);
@@ -1516,9 +1525,12 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     }
     const bool adapt = level_absmax && headroom_state && (n_blocks > 0 || (tp.atomic_levels && n > 0 && !accumulate));
     if (ws_entries > 0 || adapt) {      // replica sums, and the headroom feedback by the last workgroup
-        hashgrid_bwd_reduce_kernel<<<dim3(64, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
+        int n_rep = 0;
+        for (int l = 0; l < gp.n_levels; ++l) n_rep += tp.replicas_of[l] > 1 ? 1 : 0;
+        constexpr int kReduceBlocks = 32;
+        hashgrid_bwd_reduce_kernel<<<dim3(kReduceBlocks, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
             gp, tp, (const float2*)workspace, (float2*)grad_table, adapt ? headroom_state : nullptr,
-            shifts_dev ? shifts_dev : shifts_ws, fixed ? 1 : 0, overflow_flag);
+            shifts_dev ? shifts_dev : shifts_ws, fixed ? 1 : 0, overflow_flag, n_rep * kReduceBlocks);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(reduce)");
     }
     return PERF_OK;

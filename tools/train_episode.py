@@ -36,8 +36,27 @@ scene.set_eval()
 torch.cuda.synchronize(); t2 = time.perf_counter()
 out = scene.render(rays, ['rgb', 'distance'])
 torch.cuda.synchronize(); t3 = time.perf_counter()
+# per-kernel times of the reference-faithful steps on the trained scene: 10 eager steps of each kind with HIP events around
+# every C-ABI launch (the torch glue ops between them are not seen)
+from perf_amd import ops
+kern = {}
+scene.set_train()
+scene.renderer.sample_capacity = 8192 * scene.TRAIN_SAMPLES_PER_RAY
+for kind in ('geo', 'app'):
+    net = scene.nerf.geo_mlp if kind == 'geo' else scene.nerf.app_mlp
+    opt = scene.make_optimizer(net, 0.0)
+    fn = scene.train_one_step_geo if kind == 'geo' else scene.train_one_step_app
+    for _ in range(3):
+        fn(opt, pool, progress=0.9)
+    ops.start_kernel_timing()
+    for _ in range(10):
+        fn(opt, pool, progress=0.9)
+    kern[kind] = {k: (round(n / 10, 1), round(ms * 1e3, 1)) for k, (n, ms) in sorted(ops.stop_kernel_timing().items(), key=lambda kv: -kv[1][0] * kv[1][1])}
+    kern[kind + '_sum_us_per_step'] = round(sum(n * us for n, us in kern[kind].values()), 1)
+    kern[kind + '_launches_per_step'] = round(sum(n for n, us in kern[kind].values()), 1)
 print(json.dumps({'config': f'{args.geo} geometry + {args.app} colour iterations, 8192-ray batches, {W}x{H} supervision panorama, {args.dtype}',
                   'episode_s': t1 - t0, 'occupancy_s': marks['geo'] - t0, 'geo_phase_s': marks['app'] - marks['geo'], 'app_phase_s': t1 - marks['app'],
                   'ms_per_geo_step': (marks['app'] - marks['geo']) / args.geo * 1e3, 'ms_per_app_step': (t1 - marks['app']) / args.app * 1e3,
                   'train_batch_mean_samples_per_ray': spp, 'grid_gradient_mode_at_end': tcnn.GRID_GRAD_ACCUM,
-                  'eval_full_pano_s': t3 - t2, 'psnr_dB': psnr(out['rgb'], rgb), 'mean_abs_distance_err': float((out['distance'] - dist).abs().mean())}, indent=1))
+                  'eval_full_pano_s': t3 - t2, 'psnr_dB': psnr(out['rgb'], rgb), 'mean_abs_distance_err': float((out['distance'] - dist).abs().mean()),
+                  'kernels_per_step (launches, us per launch)': kern}, indent=1))
