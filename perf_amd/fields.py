@@ -68,7 +68,7 @@ class NGPNeRF(nn.Module):
     """Instant-NGP radiance field (ngp_nerf.py:68-198)."""
 
     def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = False,
-                 unbounded: bool = False, n_levels: int = 16, dtype=None):
+                 unbounded: bool = False, n_levels: int = 16, dtype=None, log2_hashmap_size: int = 18):
         super().__init__()
         if not isinstance(aabb, torch.Tensor):
             aabb = torch.tensor(aabb, dtype=torch.float32)
@@ -79,9 +79,10 @@ class NGPNeRF(nn.Module):
         self.unbounded = unbounded
         self.n_levels = n_levels
         self.dtype_name = dtype
-        self.geo_mlp = _DensityNet(_grid_cfg(n_levels), dtype=dtype)
+        # (n_levels / log2_hashmap_size beyond the reference's 16 / 18: BASELINE config 5's tables sized to HBM)
+        self.geo_mlp = _DensityNet(_grid_cfg(n_levels, log2_hashmap_size), dtype=dtype)
         self.app_mlp = tcnn.NetworkWithInputEncoding(
-            3, 3, _grid_cfg(n_levels),
+            3, 3, _grid_cfg(n_levels, log2_hashmap_size),
             {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "Sigmoid", "n_neurons": 64,
              "n_hidden_layers": 2}, dtype=dtype)
 

@@ -169,3 +169,52 @@ class LevelShardedEncoder:
         if mine == 0:
             return torch.zeros(0, dtype=torch.float32, device=dev)
         return ops.hashgrid_bwd(self.local, self._x_all, d_all, out=out)
+
+
+class LevelShardedNeRF:
+    """Inference-side counterpart of NGPNeRF (modules/fields/ngp_nerf.py:68-176) for tables cut by level over the ranks
+    (BASELINE config 5 on several GPUs): the duck type NeRFOCCRenderer uses -- density_at / rgb_at on kernel-made sample
+    positions -- with the two encodes going through LevelShardedEncoder (positions all-gathered, ONE all-to-all of features
+    per field) and the 64-wide MLPs running locally on replicated weights.  Every rank must render batches of the same
+    capacity (sync-free mode: renderer.sample_capacity), so that the collectives match.
+
+    Built from an unsharded NGPNeRF whose parameters every rank can afford to hold once (tests), or from per-rank tables."""
+
+    def __init__(self, nerf, dtype=None):
+        self.training = False
+        self._aabb_host = nerf._aabb_host
+        self.aabb = nerf.aabb
+        self.dtype_name = dtype or nerf.geo_mlp.dtype_name
+        self.nets = {}
+        for name in ('geo_mlp', 'app_mlp'):
+            net = getattr(nerf, name)
+            w16 = net.working_copy()
+            n_net = net.mlp.n_params
+            dist, rank, world = _group()
+            levels = assign_levels(net.grid, world)[rank]
+            local = GridSlice(net.grid, levels)
+            mine = torch.cat([w16[n_net + 2 * int(net.grid.offset[l]): n_net + 2 * int(net.grid.offset[l] + net.grid.size[l])] for l in levels]) \
+                if levels else torch.zeros(0, dtype=w16.dtype, device=w16.device)
+            enc = LevelShardedEncoder(net.grid, dtype=self.dtype_name, table16=mine.clone())
+            assert enc.local.levels == local.levels
+            self.nets[name] = (enc, net.mlp, w16[:n_net].clone())
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def _field(self, name, x01, sel, n_dev):
+        enc, mlp, w_net = self.nets[name]
+        feat = enc.encode(x01)                      # every row of the capacity-sized batch (rows beyond n_dev hold garbage)
+        return ops.mlp_fwd(mlp, w_net, feat, sel, n_dev=n_dev)
+
+    @torch.no_grad()
+    def density_at(self, x01, sel, n_dev=None):
+        return self._field('geo_mlp', x01, sel, n_dev)[:, 0]
+
+    @torch.no_grad()
+    def rgb_at(self, x01, sel, n_dev=None):
+        return self._field('app_mlp', x01, sel, n_dev)
+
+    def sample_points(self, rays_o, rays_d, ray_indices, t_starts, t_ends):
+        return ops.points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, self._aabb_host)

@@ -123,3 +123,23 @@ def test_level_sharded_encode_matches_the_unsharded_kernel(tmp_path, n_levels, l
     assert max(res['bwd_rel_err']) < 1e-5, res                       # fp32 LDS atomics: association order only
     a = res['assignment']
     assert sorted(a[0] + a[1]) == list(range(n_levels)) and abs(len(a[0]) - len(a[1])) <= 1
+
+
+def test_config5_row_shard_through_the_level_sharded_path(tmp_path):
+    """BASELINE config 5's inference batch at its stated shape -- rows of a 4096x2048 panorama, 256 samples per ray, L = 20
+    hash grids (T = 2^20 here: the box is shared by both ranks AND the unsharded comparison copy) -- rendered by two ranks
+    through the level-sharded fields (perf_amd/sharded.py:LevelShardedNeRF): pixels, distances and opacities are bit-identical
+    to the unsharded render of the same rays, on every rank."""
+    out = str(tmp_path / 'c5.pt')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29641', os.path.join(ROOT, 'tests', 'config5_worker.py'), out, '2', '20']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = torch.load(out)
+    assert len(res) == 2
+    for rr in res:
+        assert rr['rays'] == 2 * 4096 and rr['marched'] == 2 * 4096 * 256
+        assert 0 < rr['kept'] <= rr['marched'] and all(rr['same'].values()), rr
+        assert rr['rgb_range'][1] > rr['rgb_range'][0]
+    assert sorted(res[0]['levels'] + res[1]['levels']) == list(range(20))

@@ -81,9 +81,11 @@ def _glue_setup(golden_dir):
     return g, res, occ
 
 
-# absolute tolerance of O(1) renderer outputs / relative tolerances of gradients per 16-bit type (measured: see the prints)
-OUT_TOL = {'fp16': 5e-3, 'bf16': 4e-2}
-GRAD_TOL = {'fp16': (3e-2, 4e-2), 'bf16': (1.2e-1, 1.6e-1)}
+# absolute tolerance of O(1) renderer outputs / relative tolerances (L2, max-abs per grid level) of gradients per 16-bit type.
+# The oracle's quant=... emulation rounds the same 16-bit operands the kernels round, so what is left is accumulation order:
+# measured on MI355X (round 3) -- outputs <= 8e-6 for both types; gradients fp16 2.0e-3 / 7e-4, bf16 4.6e-3 / 6.1e-3.
+OUT_TOL = {'fp16': 5e-5, 'bf16': 1e-4}
+GRAD_TOL = {'fp16': (5e-3, 5e-3), 'bf16': (1.5e-2, 2e-2)}
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
@@ -867,7 +869,10 @@ def test_training_steps_match_the_reference_glue(golden_dir, dtype):
     """NeRFScene.train_one_step_geo / train_one_step_app on the HIP kernels against the gradient and the loss terms the
     REFERENCE's own train_one_step_geo / _app produced (fp32 oracle operators underneath, nerf.py:186-297): same batch, same
     random draws.  The HIP side evaluates 16-bit fields, so the comparison is at 16-bit accuracy: loss terms to a few per
-    cent, the optimizer's gradient by direction and norm (a sample at the early-stop threshold may be kept on one side only)."""
+    cent, the optimizer's gradient by direction and norm (a sample at the early-stop threshold may be kept on one side only).
+    Together with tests/test_cpu_oracle.py::test_train_step_glue_matches_reference (oracle == reference glue, 2e-5) and the
+    oracle-level gradient tests above (HIP == oracle's 16-bit emulation per grid level) this closes the chain
+    reference glue -> oracle -> HIP for the training steps."""
     g = np.load(f'{golden_dir}/train_glue.npz')
     for tag in ('geo_p2', 'app_p5'):
         kind = tag[:3]
@@ -895,13 +900,13 @@ def test_training_steps_match_the_reference_glue(golden_dir, dtype):
         ratio = float(grad.norm() / ref.norm())
         losses = {k: float(v) for k, v in scene.last_losses.items()}
         print(f'[{tag} {dtype}] gradient cosine {cos:.5f}, norm ratio {ratio:.4f}, losses {losses}')
-        lim = (0.995, 0.05) if dtype == 'fp16' else (0.97, 0.12)
+        lim = (0.9999, 0.002) if dtype == 'fp16' else (0.999, 0.005)      # measured: 1.00000 / 0.9998 and 0.99977 / 1.0008
         assert cos > lim[0] and abs(ratio - 1.0) < lim[1], (tag, cos, ratio)
         if kind == 'geo':
-            assert abs(losses['depth_loss'] - float(g[f'{tag}_depth_loss'])) < 0.05 * float(g[f'{tag}_depth_loss'])
-            assert abs(losses['dist_loss'] - float(g[f'{tag}_dist_loss'])) < 0.08 * float(g[f'{tag}_dist_loss'])
+            assert abs(losses['depth_loss'] - float(g[f'{tag}_depth_loss'])) < 5e-3 * float(g[f'{tag}_depth_loss'])
+            assert abs(losses['dist_loss'] - float(g[f'{tag}_dist_loss'])) < 1e-2 * float(g[f'{tag}_dist_loss'])
         else:
-            assert abs(losses['color_loss'] - float(g[f'{tag}_color_loss'])) < 0.05 * float(g[f'{tag}_color_loss'])
+            assert abs(losses['color_loss'] - float(g[f'{tag}_color_loss'])) < 2e-3 * float(g[f'{tag}_color_loss'])
 
 
 def test_sup_info_and_visibility_match_the_reference(golden_dir):

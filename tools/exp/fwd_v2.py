@@ -22,8 +22,7 @@ VARIANTS = {
     'rotate only': {'PERF_FWD_NO_DEDUP': '1'},
     'dedup only (fixed pinning)': {'PERF_FWD_NO_ROTATE': '1'},
     'neither (new kernel body)': {'PERF_FWD_NO_ROTATE': '1', 'PERF_FWD_NO_DEDUP': '1'},
-    'rotate + dedup, 4096 chunks per XCD in the grid': {'PERF_FWD_V2_CHUNKS': '4096'},
-    'rotate + dedup, 256 chunks per XCD in the grid': {'PERF_FWD_V2_CHUNKS': '256'},
+    'rotate + dedup, 512 looping workgroups per XCD': {'PERF_FWD_MAX_CHUNKS': '512'},
 }
 
 
@@ -93,7 +92,7 @@ def main():
     for name, env in VARIANTS.items():
         tmp = a.out + '.tmp'
         e = dict(os.environ, **env)
-        for k in ('PERF_FWD_V2', 'PERF_FWD_NO_DEDUP', 'PERF_FWD_NO_ROTATE', 'PERF_FWD_V2_CHUNKS'):
+        for k in ('PERF_FWD_V2', 'PERF_FWD_NO_DEDUP', 'PERF_FWD_NO_ROTATE', 'PERF_FWD_MAX_CHUNKS'):
             if k not in env:
                 e.pop(k, None)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--worker', tmp], env=e, capture_output=True, text=True, timeout=600)
