@@ -1061,6 +1061,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp,
     // (rows of levels without replicas have nothing to add up: they leave at once, without a ticket -- same-address atomics
     //  retire at ~11 ns each; with no replicated level at all, workgroup (0, 0) applies the feedback)
     if (R <= 1 && !(n_ticket_blocks == 0 && blockIdx.x == 0 && blockIdx.y == 0)) return;
+    int sink = 0;
     if (R > 1) {
         const uint32_t size = gp.size[l];
         const float from_fixed = fixed ? ldexpf(1.0f, -shifts[l]) : 1.0f;
@@ -1090,7 +1091,10 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp,
             for (int off = 32; off >= 1; off >>= 1) field_max = max(field_max, __shfl_xor(field_max, off));
             if ((threadIdx.x & 63) == 0 && field_max > 0) {
                 if (overflow_flag && field_max >= (1 << 29)) atomicOr(overflow_flag, 1);
-                if (hr_state) atomicMax(&hr_state[PERF_MAX_LEVELS + l], field_max);
+                // a RETURNING device-scope atomic: the wave waits until it has been performed at the memory side, so the
+                // ticket below is ordered behind it without an agent-scope fence (which writes back the XCD's L2: ~20 us
+                // over the 128 workgroups of this kernel, measured)
+                if (hr_state) sink = __hip_atomic_fetch_max(&hr_state[PERF_MAX_LEVELS + l], field_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1098,15 +1102,14 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp,
     // ---- headroom feedback by the last workgroup of the replicated rows to get here
     __shared__ int last_block;
     if (n_ticket_blocks > 0) {
-        __threadfence();
+        asm volatile("" : : "v"(sink));                    // (uses the atomic's return value: the wave waits for it)
         __syncthreads();
         if (threadIdx.x == 0) last_block = (atomicAdd(&hr_state[2 * PERF_MAX_LEVELS], 1) == n_ticket_blocks - 1) ? 1 : 0;
         __syncthreads();
         if (!last_block) return;
     }
-    __threadfence();
     if ((int)threadIdx.x < gp.n_levels) {
-        const int fm = atomicMax(&hr_state[PERF_MAX_LEVELS + threadIdx.x], 0);     // (an atomic read: the value sits in L2)
+        const int fm = atomicMax(&hr_state[PERF_MAX_LEVELS + threadIdx.x], 0);     // (an atomic read: the value sits at the memory side)
         hr_state[threadIdx.x] = headroom_feedback(hr_state[threadIdx.x], fm);
         hr_state[PERF_MAX_LEVELS + threadIdx.x] = 0;
     }
@@ -1528,7 +1531,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     if (ws_entries > 0 || adapt) {      // replica sums, and the headroom feedback by the last workgroup
         int n_rep = 0;
         for (int l = 0; l < gp.n_levels; ++l) n_rep += tp.replicas_of[l] > 1 ? 1 : 0;
-        constexpr int kReduceBlocks = 32;
+        constexpr int kReduceBlocks = 64;
         hashgrid_bwd_reduce_kernel<<<dim3(kReduceBlocks, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
             gp, tp, (const float2*)workspace, (float2*)grad_table, adapt ? headroom_state : nullptr,
             shifts_dev ? shifts_dev : shifts_ws, fixed ? 1 : 0, overflow_flag, n_rep * kReduceBlocks);

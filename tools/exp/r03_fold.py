@@ -16,12 +16,17 @@ RAW = os.path.join(DST, 'r03_raw')
 KERNELS = ['hashgrid_fwd_v2_kernel', 'hashgrid_fwd_kernel', 'hashgrid_bwd_kernel', 'tile_codes_kernel', 'hashgrid_bwd_reduce_kernel',
            'mlp_fwd_kernel', 'mlp_bwd_kernel', 'mlp_reduce_kernel', 'adam_kernel', 'march_count_kernel', 'compact_prefix_kernel',
            'composite_distloss_fwd_kernel', 'composite_distloss_bwd_kernel']
+MLP_ENTRY = {'mlp_fwd_kernel': 'perf_mlp_fwd', 'mlp_bwd_kernel': 'perf_mlp_bwd'}
 ENTRY = {'hashgrid_bwd_kernel': 'perf_hashgrid_bwd', 'tile_codes_kernel': 'perf_hashgrid_bwd', 'hashgrid_bwd_reduce_kernel': 'perf_hashgrid_bwd',
          'hashgrid_fwd_v2_kernel': 'perf_hashgrid_fwd', 'hashgrid_fwd_kernel': 'perf_hashgrid_fwd', 'mlp_bwd_kernel': 'perf_mlp_bwd',
          'mlp_reduce_kernel': 'perf_mlp_bwd', 'mlp_fwd_kernel': 'perf_mlp_fwd', 'adam_kernel': 'perf_adam_step_dev'}
 
 
 def kname(full):
+    if 'perf::mlp_fwd_kernel<' in full or 'perf::mlp_bwd_kernel<' in full:        # keep the template arguments apart (density / colour net)
+        base = 'mlp_fwd_kernel' if 'mlp_fwd_kernel' in full else 'mlp_bwd_kernel'
+        args = full.split(base + '<')[1].split('>')[0].replace('perf::', '').replace(' ', '')
+        return f'{base}<{args}>'
     for k in KERNELS:
         if 'perf::' + k + '<' in full or 'perf::' + k + '(' in full or full.strip().endswith(k) or ('perf::' + k) in full:
             return k
@@ -68,10 +73,14 @@ def main():
     copy_raw(ff, 'pmc_fetch'); copy_raw(wf, 'pmc_write')
     kernels = defaultdict(lambda: {'fetch_size_kb_raw': 0.0, 'write_size_kb': 0.0, 'parts': {}})
     main_of = {}
-    for k, e in ENTRY.items():
+    entry = dict(ENTRY)
+    for k in list(f) + list(w):                      # templated MLP kernels: one C-ABI entry per template instance
+        if '<' in k:
+            entry[k] = MLP_ENTRY[k.split('<')[0]] + '<' + k.split('<')[1]
+    for k, e in entry.items():
         if k in f or k in w:
             main_of.setdefault(e, k)
-    for k, e in ENTRY.items():
+    for k, e in entry.items():
         if k in f and e in main_of:
             n = f[k]['launches'] / f[main_of[e]]['launches']
             kernels[e]['fetch_size_kb_raw'] += f[k]['FETCH_SIZE'] * n
@@ -91,16 +100,21 @@ def main():
     m, mf = fold_counters('pmc_mfma/**/*counter_collection.csv')
     copy_raw(mf, 'pmc_mfma')
     out = {'command': 'rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python bench.py '
-                      '--steps 10 --warmup 3 --no-graph ... (tools/exp/r03_profile.sh); durations: rocprofv3 --kernel-trace --stats of the default '
-                      'command (profiles/r03_train_geo_kernel_stats.csv)',
-           'definition': 'mfma_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs x 4): the counter ticks per SIMD quad-cycle... '
-                         'see `calibration`; achieved TFLOP/s = MOPS_BF16 x 512 FLOP / duration', 'kernels': {}}
-    for k in ('mlp_fwd_kernel', 'mlp_bwd_kernel'):
-        if k in m:
-            row = {c: round(v, 1) for c, v in m[k].items()}
-            if k in dur:
-                row['kernel_trace'] = [{'calls': c, 'avg_us': round(a, 2), 'name': n} for c, a, n in dur[k]]
-            out['kernels'][k] = row
+                      '--steps 10 --warmup 3 --no-graph ... (tools/exp/r03_profile.sh; counters of THIS round\'s build, per launch); durations: '
+                      'rocprofv3 --kernel-trace --stats of the default bench command, no counters (profiles/r03_train_geo_kernel_stats.csv)',
+           'definition': 'mfma_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs); achieved = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 FLOP / '
+                         'duration against the 2.5 PFLOP/s dense bf16 peak (one v_mfma_f32_32x32x16_bf16 = 64 MOPS = 32,768 FLOP)', 'kernels': {}}
+    for k in sorted(m):
+        if not k.startswith('mlp_'):
+            continue
+        row = {c: round(v, 1) for c, v in m[k].items()}
+        if k in dur:
+            calls, avg_us, _ = max(dur[k])
+            row['duration_us'] = round(avg_us, 2)
+            row['mfma_utilisation'] = round(m[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / (avg_us * 1e-6 * 2.4e9 * 1024), 4)
+            row['achieved_TFLOPs'] = round(m[k]['SQ_INSTS_VALU_MFMA_MOPS_BF16'] * 512 / (avg_us * 1e-6) / 1e12, 1)
+            row['frac_of_mfma_peak'] = round(row['achieved_TFLOPs'] / 2500.0, 4)
+        out['kernels'][k] = row
     json.dump(out, open(os.path.join(DST, 'r03_mfma_util.json'), 'w'), indent=1)
     # ---- SQ
     s, sf = fold_counters('pmc_sq/**/*counter_collection.csv')
