@@ -278,11 +278,13 @@ def main():
                 scene.update_lr(opt, conf, min(i / n_sched, 0.999))
                 step_fn(opt, pool, progress=0.25)
             if use_graph:
-                graphed = scene.make_graphed_step(kind, opt, pool)
+                n_rows = opt.SCHEDULE_ROWS        # the schedule of every iteration this run can reach, installed on the device
+                graphed = scene.make_graphed_step(kind, opt, pool, schedule=([scene.lr_at(conf, min(i / n_sched, 0.999)) for i in range(n_rows)],
+                                                                             [0.5] * n_rows, 0))
 
             def step(i):
                 if graphed is not None:
-                    graphed(scene.lr_at(conf, min(i / n_sched, 0.999)), 0.25)
+                    graphed()                     # (nothing but the graph: learning rate and ramp come from the device-side schedule)
                 else:
                     eager_step(i)
         else:

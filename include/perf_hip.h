@@ -115,11 +115,17 @@ int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_
  * never applied.  *overflow_flag is cleared (the event is counted instead).  counters (int64 [PERF_STEP_COUNTERS], may be
  * NULL) accumulate {marched samples, kept samples, steps, largest marched count of one batch, steps skipped for overflow,
  * steps skipped for truncation, 0, 0}: throughput and health accounting never read the device inside the training loop.
- * All pointers device memory; every pointer may be NULL. */
+ * schedule (device, n_schedule rows of {learning rate, distortion-loss ramp min(2 progress, 1)}; NULL = none) with iter_dev
+ * (device int32, the iteration counter, advanced by this launch): *lr_out = the current iteration's learning rate (what
+ * perf_adam_step_dev reads next), *ratio_out = the NEXT iteration's ramp (what its perf_geo_loss reads, nerf.py:235) -- the
+ * reference's update_lr (nerf.py:300-311) evaluated ahead of time, so that replaying a captured step needs no host-side scalar
+ * update.  All pointers device memory; every pointer may be NULL. */
 #define PERF_STEP_COUNTERS 8
 int perf_step_bookkeeping(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
                           const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
-                          int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out, void* stream);
+                          int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out,
+                          const float* schedule, int32_t n_schedule, int32_t* iter_dev, float* lr_out, float* ratio_out,
+                          void* stream);
 
 /* ---- sample positions ------------------------------------------------------------------ */
 
@@ -283,20 +289,22 @@ int64_t perf_occ_mask_words(int32_t max_steps);
 
 /* Pass 1: per ray, test lattice intervals k=0..max_steps-1 (t_k = fl(t0 + fl(k*step)), midpoint
  * inside [max(tmin,t0), min(tmax,far)] and in an occupied cell); writes the keep bit masks
- * (masks [n_rays * mask_words]) and counts [n_rays].  t0 [n_rays] is the lattice origin
- * (near plane plus the stratified jitter); aabb: 6 host floats. */
-int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
-                         const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
-                         float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
-                         void* stream);
+ * (masks [n_rays * mask_words]) and counts [n_rays].  aabb: 6 host floats.
+ * Lattice origin of ray r (all four marching entry points): t0 == NULL: t0_base (the near plane); t0_scale == 0: t0[r];
+ * otherwise t0 holds the stratified draws u in [0,1) and the origin is fl(u * t0_scale) (+ t0_base when != 0) --
+ * OccGridEstimator.sampling's `near_plane + u * render_step_size` formed in the kernel instead of by two torch launches. */
+int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
+                         int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res,
+                         const float* aabb, float far_plane, float step, int32_t max_steps, uint64_t* masks,
+                         int32_t* counts, void* stream);
 
 /* perf_occ_march_count that also WRITES the first head_k samples of every ray (the head of the two-phase sampler below):
  * rows r*head_k .. r*head_k + min(count, head_k) - 1 of arrays of n_rays*head_k rows get the same ray_indices / t_starts /
  * t_ends / x01 / sel that perf_occ_march_write_points writes for ranks [0, head_k); the remaining rows of a ray are padding
  * (sel = 0); packed_info[r] = (r*head_k, min(count, head_k)).  Replaces perf_head_tail_counts + perf_exclusive_scan_i32 +
  * perf_occ_march_write_points for the head.  head_k in [1, 64]. */
-int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
-                              const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
+int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
+                              int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
                               float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
                               int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
                               const float* points_aabb6, float* x01, uint8_t* sel, void* stream);
@@ -307,15 +315,16 @@ int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const fl
 int64_t perf_occ_coarse_words(int32_t res);
 int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint32_t* coarse, void* stream);
 
-/* Exclusive prefix sum of int32 (counts -> offsets); total [1] (int64, device) receives the sum.
- * workspace >= perf_scan_workspace_bytes(n). */
+/* Exclusive prefix sum of int32 (counts -> offsets); total [1] (int64, device) receives the sum; total_biased (device
+ * int64, may be NULL) receives sum + total_bias (the two-phase sampler's evaluated-sample count = head rows + tail samples,
+ * without a separate add).  workspace >= perf_scan_workspace_bytes(n). */
 int64_t perf_scan_workspace_bytes(int64_t n);
-int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t* total, int64_t n,
-                            void* workspace, int64_t workspace_bytes, void* stream);
+int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t* total, int64_t n, int64_t total_bias,
+                            int64_t* total_biased, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Pass 2: expand masks into packed samples sorted by ray then t.  packed_info [n_rays,2] =
  * (start,count) int32.  capacity = allocated length of the sample arrays. */
-int perf_occ_march_write(const float* t0, int64_t n_rays, float step, int32_t max_steps,
+int perf_occ_march_write(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps,
                          const uint64_t* masks, const int32_t* counts, const int32_t* offsets,
                          int64_t capacity, int64_t* ray_indices, float* t_starts, float* t_ends,
                          int32_t* packed_info, void* stream);
@@ -325,7 +334,7 @@ int perf_occ_march_write(const float* t0, int64_t n_rays, float step, int32_t ma
  * aabb6: host pointer, {min xyz, max xyz}.  rank_lo: the samples of rank [rank_lo, rank_lo + counts[r]) of every ray are
  * written (rank = position among the ray's samples in t order; 0 with the march counts = everything) -- the two-phase
  * sampler below writes the first K samples of every ray first and the rest of the surviving rays later. */
-int perf_occ_march_write_points(const float* t0, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
+int perf_occ_march_write_points(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
                                 const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                 float* t_starts, float* t_ends, int32_t* packed_info, const float* rays_o,
                                 const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, int32_t rank_lo,
@@ -336,10 +345,13 @@ int perf_occ_march_write_points(const float* t0, int64_t n_rays, float step, int
 
 /* Per-ray exclusive sum of sigma*delta in the canonical 64-chunk Kogge-Stone order, thresholded:
  * new_counts[r] = number of leading samples with exclusive_sum <= thr (thr = -ln(early_stop_eps)).
- * Also writes exsum [S] when not NULL. */
+ * Also writes exsum [S] when not NULL.  tail_counts (may be NULL; with march_counts [R] and head_samples = K): the
+ * two-phase sampler's tail counts in the same launch -- count - K for a ray whose whole head min(count, K) survived, else 0
+ * (= perf_head_tail_counts(counts, K, new_counts)). */
 int perf_visibility_count(const float* sigmas, const float* t_starts, const float* t_ends,
                           const int32_t* packed_info, int64_t n_rays, float thr, int32_t* new_counts,
-                          float* exsum, void* stream);
+                          float* exsum, const int32_t* march_counts, int32_t head_samples, int32_t* tail_counts,
+                          void* stream);
 
 /* Copy the first new_counts[r] samples of every ray to new_offsets[r] (the boolean-mask
  * compaction of nerfacc's sampling).  sigmas_in/out may be NULL; so may the sample positions x01 [S,3] / sel [S]
@@ -437,13 +449,15 @@ int perf_distloss_bwd(const float* w, const float* t_starts, const float* t_ends
  * sum(distloss_per_ray) / (last ray with samples + 1).  Writes the per-ray gradients of
  * loss_scale * (depth_weight * depth + distortion_weight * ratio * distortion) w.r.t. opacity and distance, and
  * scalars[0..2] = {depth loss, distortion loss, scale to pass to perf_distloss_bwd as scale_dev}; `scalars` is
- * PERF_LOSS_SCALARS floats of device memory (the rest holds per-workgroup partial sums, folded in a fixed order).
+ * PERF_LOSS_SCALARS floats of device memory (the rest holds per-workgroup partial sums, folded in a fixed order by the
+ * last workgroup to finish -- one launch).  ticket: one device int32, zero before the first call and left at zero by every
+ * call (not shared by calls that may run concurrently).
  * ratio_dev: device float (min(2 progress, 1), nerf.py:235) or NULL (= 1).  noise may be NULL (no noise term). */
 #define PERF_LOSS_SCALARS 256
 int perf_geo_loss(const float* opacity, const float* distance, const float* gt_distance, const float* noise,
                   const float* distloss_per_ray, const int32_t* packed_info, int64_t n_rays, int64_t global_batch,
                   float depth_weight, float distortion_weight, const float* ratio_dev, float loss_scale,
-                  float* g_opacity, float* g_distance, float* scalars, void* stream);
+                  float* g_opacity, float* g_distance, float* scalars, int32_t* ticket, void* stream);
 
 /* Colour step (nerf.py:281-293 + nerf_renderer.py:194): c' = color + bg (1 - opacity); loss = smooth_l1(c', gt, beta 5e-2)
  * summed / (3 global_batch); g_color [R,3] = d(loss_scale * color_weight * loss)/d color; scalars[0] = loss

@@ -45,7 +45,7 @@ _SIGS = {
     'perf_cast_params': (c_int, [P, P, c_int64, c_int, P]),
     'perf_adam_step': (c_int, [P, P, P, P, P, c_int64, c_int, c_int32, c_float, c_float, c_float, c_float, c_int, P]),
     'perf_adam_step_dev': (c_int, [P, P, P, P, P, c_int64, c_int, P, P, P, c_float, c_float, c_float, c_int, P]),
-    'perf_step_bookkeeping': (c_int, [P, P, P, P, P, c_int64, P, P, P, P]),
+    'perf_step_bookkeeping': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, c_int32, P, P, P, P]),
     'perf_points_from_rays': (c_int, [P, P, P, P, P, POINTER(c_float), P, P, c_int64, P, P]),
     'perf_points_normalize': (c_int, [P, POINTER(c_float), P, P, c_int64, P]),
     'perf_hashgrid_fwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P, c_int, P]),
@@ -69,19 +69,19 @@ _SIGS = {
     'perf_pano_raygen_dev': (c_int, [P, c_int32, c_int32, c_int32, c_int32, P, P, P]),
     'perf_occ_pack_bits': (c_int, [P, P, c_int64, P]),
     'perf_occ_mask_words': (c_int64, [c_int32]),
-    'perf_occ_march_count': (c_int, [P, P, P, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, P, P, P]),
-    'perf_occ_march_count_head': (c_int, [P, P, P, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, P, P,
+    'perf_occ_march_count': (c_int, [P, P, P, c_float, c_float, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, P, P, P]),
+    'perf_occ_march_count_head': (c_int, [P, P, P, c_float, c_float, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, P, P,
                                   c_int32, P, P, P, P, POINTER(c_float), P, P, P]),
     'perf_occ_coarse_words': (c_int64, [c_int32]),
     'perf_occ_build_coarse': (c_int, [P, c_int32, P, P]),
     'perf_scan_workspace_bytes': (c_int64, [c_int64]),
-    'perf_exclusive_scan_i32': (c_int, [P, P, P, c_int64, P, c_int64, P]),
-    'perf_occ_march_write': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P]),
-    'perf_occ_march_write_points': (c_int, [P, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P, P, POINTER(c_float), P, P, c_int32, P]),
+    'perf_exclusive_scan_i32': (c_int, [P, P, P, c_int64, c_int64, P, P, c_int64, P]),
+    'perf_occ_march_write': (c_int, [P, c_float, c_float, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P]),
+    'perf_occ_march_write_points': (c_int, [P, c_float, c_float, c_int64, c_float, c_int32, P, P, P, c_int64, P, P, P, P, P, P, POINTER(c_float), P, P, c_int32, P]),
     'perf_head_tail_counts': (c_int, [P, c_int64, c_int32, P, P, P]),
     'perf_visibility_count2': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_float, P, P]),
     'perf_compact_prefix2': (c_int, [P] * 14 + [c_int64, c_int64] + [P] * 7 + [P, c_int64, P, c_int64, P, c_int64, c_int32, P]),
-    'perf_visibility_count': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
+    'perf_visibility_count': (c_int, [P, P, P, P, c_int64, c_float, P, P, P, c_int32, P, P]),
     'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, P, c_int64, c_int32, P]),
     'perf_composite_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     'perf_composite_bwd': (c_int, [P, P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P]),
@@ -90,7 +90,7 @@ _SIGS = {
     'perf_pack_info': (c_int, [P, c_int64, c_int64, P, P]),
     'perf_distloss_fwd': (c_int, [P, P, P, P, c_int64, P, P]),
     'perf_distloss_bwd': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
-    'perf_geo_loss': (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_float, c_float, P, c_float, P, P, P, P]),
+    'perf_geo_loss': (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_float, c_float, P, c_float, P, P, P, P, P]),
     'perf_app_loss': (c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, P, P, P]),
     'perf_composite_distloss_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     'perf_composite_distloss_bwd': (c_int, [P, P, P, P, c_int64, P, P, P, P, P, P, c_float, P, P, P]),

@@ -125,7 +125,8 @@ static inline dim3 team_grid(int64_t n_rays) {
 __global__ __launch_bounds__(256) void visibility_count_kernel(const float* __restrict__ sig, const float* __restrict__ ts,
                                                                const float* __restrict__ te, const int32_t* __restrict__ packed,
                                                                int64_t n_rays, float thr, int32_t* __restrict__ new_counts,
-                                                               float* __restrict__ exsum) {
+                                                               float* __restrict__ exsum, const int32_t* __restrict__ march_counts,
+                                                               int32_t head_k, int32_t* __restrict__ tail_counts) {
     for_rays_of_wave(n_rays, [&](int64_t r) { return packed[2 * r + 1]; }, [&](auto team, int64_t r, int l) {
         constexpr int W = decltype(team)::width;
         const int64_t start = packed[2 * r];
@@ -141,7 +142,13 @@ __global__ __launch_bounds__(256) void visibility_count_kernel(const float* __re
             if (valid && exsum) exsum[start + i] = ex;
             kept += __popcll(team_ballot<W>(valid && (ex <= thr)));
         }
-        if (l == 0) new_counts[r] = kept;
+        if (l == 0) {
+            new_counts[r] = kept;
+            if (tail_counts) {          // two-phase sampler: the tail of a ray whose whole head survived (perf_head_tail_counts)
+                const int32_t c = march_counts[r], h = c < head_k ? c : head_k;
+                tail_counts[r] = (kept == h && c > head_k) ? c - head_k : 0;
+            }
+        }
     });
 }
 
@@ -404,12 +411,14 @@ using namespace perf;
 
 extern "C" int perf_visibility_count(const float* sigmas, const float* t_starts, const float* t_ends,
                                      const int32_t* packed_info, int64_t n_rays, float thr, int32_t* new_counts,
-                                     float* exsum, void* stream) {
+                                     float* exsum, const int32_t* march_counts, int32_t head_samples, int32_t* tail_counts,
+                                     void* stream) {
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && new_counts, "NULL pointer");
+    PERF_REQUIRE(!tail_counts || (march_counts && head_samples >= 1), "perf_visibility_count: tail counts need the march counts and the head size");
     hipLaunchKernelGGL(visibility_count_kernel, team_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
-                       packed_info, n_rays, thr, new_counts, exsum);
+                       packed_info, n_rays, thr, new_counts, exsum, march_counts, head_samples, tail_counts);
     PERF_LAUNCH_CHECK("perf_visibility_count");
     return PERF_OK;
 }
@@ -767,7 +776,8 @@ __global__ __launch_bounds__(256) void geo_loss_kernel(const float* __restrict__
                                                        const float* __restrict__ dl_per_ray, const int32_t* __restrict__ packed,
                                                        int64_t n_rays, float inv_bs, float depth_w, float loss_scale,
                                                        float* __restrict__ g_op, float* __restrict__ g_dist,
-                                                       float* __restrict__ scalars) {
+                                                       float* __restrict__ scalars, float dist_w, const float* __restrict__ ratio_dev,
+                                                       int data_parallel, int* __restrict__ ticket) {
     __shared__ float red[4];
     __shared__ int last_s;
     if (threadIdx.x == 0) last_s = -1;
@@ -790,31 +800,41 @@ __global__ __launch_bounds__(256) void geo_loss_kernel(const float* __restrict__
     atomicMax(&last_s, last);
     const float depth = block_sum_256(dsum, red);
     const float distl = block_sum_256(lsum, red);
+    // ---- the partial sums go out with returning device-scope atomics (performed at the memory side before the ticket is
+    //      taken: no agent-scope fence, which would write back the XCD's L2); the last workgroup to take a ticket folds them
+    //      in a fixed order (deterministic) and leaves *ticket at 0 for the next call
+    __shared__ int is_last;
     if (threadIdx.x == 0) {
         float* part = scalars + 4 + 3 * blockIdx.x;
-        part[0] = depth; part[1] = distl; part[2] = (float)last_s;      // ray indices < 2^24 are exact in fp32
+        float sink = atomicExch(&part[0], depth) + atomicExch(&part[1], distl) + atomicExch(&part[2], (float)last_s);  // ray indices < 2^24: exact
+        asm volatile("" : : "v"(sink));
+        is_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
     }
-}
-
-__global__ __launch_bounds__(64) void geo_loss_final_kernel(int n_blocks, float inv_bs, float dist_w, const float* __restrict__ ratio_dev,
-                                                            float loss_scale, int data_parallel, float* __restrict__ scalars) {
-    float dsum = 0.f, lsum = 0.f, last = -1.f;
-    if ((int)threadIdx.x < n_blocks) {
-        const float* part = scalars + 4 + 3 * threadIdx.x;
-        dsum = part[0]; lsum = part[1]; last = part[2];
-    }
+    __syncthreads();
+    if (!is_last) return;
+    if (threadIdx.x < 64) {
+        const int n_blocks = (int)gridDim.x;
+        float ds = 0.f, ls = 0.f, lastf = -1.f;
+        if ((int)threadIdx.x < n_blocks) {
+            float* part = scalars + 4 + 3 * threadIdx.x;
+            ds = __hip_atomic_load(&part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ls = __hip_atomic_load(&part[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lastf = __hip_atomic_load(&part[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {       // fixed butterfly: deterministic
-        dsum += __shfl_xor(dsum, off); lsum += __shfl_xor(lsum, off); last = fmaxf(last, __shfl_xor(last, off));
-    }
-    if (threadIdx.x == 0) {
-        // flatten_eff_distloss divides by ray_id.max()+1 (the last ray that has samples); data-parallel runs (the local
-        // batch is a slice of the global one) normalise by the global batch instead
-        const float inv_n = data_parallel ? inv_bs : 1.0f / (last + 1.0f > 0.f ? last + 1.0f : 1.0f);
-        const float ratio = ratio_dev ? ratio_dev[0] : 1.0f;
-        scalars[0] = dsum * inv_bs;
-        scalars[1] = lsum * inv_n;
-        scalars[2] = inv_n * dist_w * ratio * loss_scale;
+        for (int off = 32; off >= 1; off >>= 1) {       // fixed butterfly: deterministic
+            ds += __shfl_xor(ds, off); ls += __shfl_xor(ls, off); lastf = fmaxf(lastf, __shfl_xor(lastf, off));
+        }
+        if (threadIdx.x == 0) {
+            // flatten_eff_distloss divides by ray_id.max()+1 (the last ray that has samples); data-parallel runs (the local
+            // batch is a slice of the global one) normalise by the global batch instead
+            const float inv_n = data_parallel ? inv_bs : 1.0f / (lastf + 1.0f > 0.f ? lastf + 1.0f : 1.0f);
+            const float ratio = ratio_dev ? ratio_dev[0] : 1.0f;
+            scalars[0] = ds * inv_bs;
+            scalars[1] = ls * inv_n;
+            scalars[2] = inv_n * dist_w * ratio * loss_scale;
+            *ticket = 0;
+        }
     }
 }
 
@@ -848,15 +868,14 @@ __global__ __launch_bounds__(64) void app_loss_final_kernel(int n_blocks, float 
 extern "C" int perf_geo_loss(const float* opacity, const float* distance, const float* gt_distance, const float* noise,
                              const float* distloss_per_ray, const int32_t* packed_info, int64_t n_rays, int64_t global_batch,
                              float depth_weight, float distortion_weight, const float* ratio_dev, float loss_scale,
-                             float* g_opacity, float* g_distance, float* scalars, void* stream) {
+                             float* g_opacity, float* g_distance, float* scalars, int32_t* ticket, void* stream) {
     PERF_REQUIRE(n_rays > 0 && global_batch > 0, "perf_geo_loss: empty batch");
-    PERF_REQUIRE(opacity && distance && gt_distance && distloss_per_ray && packed_info && g_opacity && g_distance && scalars, "NULL pointer");
+    PERF_REQUIRE(opacity && distance && gt_distance && distloss_per_ray && packed_info && g_opacity && g_distance && scalars && ticket, "NULL pointer");
     const int nb = (int)((n_rays + 255) / 256 < perf::kLossBlocks ? (n_rays + 255) / 256 : perf::kLossBlocks);
     const float inv_bs = 1.0f / (float)global_batch;
     hipLaunchKernelGGL(perf::geo_loss_kernel, dim3(nb), dim3(256), 0, perf::as_stream(stream), opacity, distance, gt_distance, noise,
-                       distloss_per_ray, packed_info, n_rays, inv_bs, depth_weight, loss_scale, g_opacity, g_distance, scalars);
-    hipLaunchKernelGGL(perf::geo_loss_final_kernel, dim3(1), dim3(64), 0, perf::as_stream(stream), nb, inv_bs, distortion_weight,
-                       ratio_dev, loss_scale, (int)(n_rays != global_batch), scalars);
+                       distloss_per_ray, packed_info, n_rays, inv_bs, depth_weight, loss_scale, g_opacity, g_distance, scalars,
+                       distortion_weight, ratio_dev, (int)(n_rays != global_batch), ticket);
     PERF_LAUNCH_CHECK("perf_geo_loss");
     return PERF_OK;
 }

@@ -916,7 +916,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         if (threadIdx.x == 0) esc_any = 0u;
         __syncthreads();
         uint32_t e = 0u;
-        const int64_t n_words = (n + kCodeSamplesPerBlock - 1) / kCodeSamplesPerBlock;
+        const int64_t n_words = (n_live + kCodeSamplesPerBlock - 1) / kCodeSamplesPerBlock;      // (blocks without live samples wrote 0)
         for (int64_t w = threadIdx.x; w < n_words; w += kBwdThreads) e |= escape[w];
         if ((e >> l) & 1u) esc_any = 1u;
         __syncthreads();

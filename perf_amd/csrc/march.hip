@@ -51,6 +51,19 @@ __global__ __launch_bounds__(256) void coarse_build_kernel(const uint32_t* __res
 
 __device__ __forceinline__ float lattice(float t0, int k, float step) { return add_rn(t0, mul_rn((float)k, step)); }
 
+// Lattice origin of ray r.  t0s == NULL: t0_base (the near plane).  t0_scale == 0: t0s[r] as given.  Otherwise t0s holds the
+// stratified draw u in [0,1) and the origin is fl(u * t0_scale) (+ t0_base when that is not 0) -- the two torch ops of
+// OccGridEstimator.sampling (near_plane + u * render_step_size), formed here so that no separate launch is needed.
+__device__ __forceinline__ float lattice_origin(const float* __restrict__ t0s, int64_t r, float t0_scale, float t0_base) {
+    if (!t0s) return t0_base;
+    float t = t0s[r];
+    if (t0_scale != 0.f) {
+        t = mul_rn(t, t0_scale);
+        if (t0_base != 0.f) t = add_rn(t, t0_base);
+    }
+    return t;
+}
+
 // Per-ray record in the mask buffer: [live words | chunk masks]: bit q of the live words says chunk q (lattice
 // intervals 64q..64q+63) may hold samples; only live chunks have their mask word written (and later read).
 __device__ __forceinline__ int n_live_words(int mask_words) { return (mask_words + 63) >> 6; }
@@ -70,7 +83,8 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                                                           const float* __restrict__ rd, const float* __restrict__ t0s,
                                                           int64_t n_rays, const uint32_t* __restrict__ bits,
                                                           const uint32_t* __restrict__ coarse,
-                                                          uint64_t* __restrict__ masks, int32_t* __restrict__ counts, HeadOut ho) {
+                                                          uint64_t* __restrict__ masks, int32_t* __restrict__ counts, HeadOut ho,
+                                                          float t0_scale, float t0_base) {
     const int lane = threadIdx.x & 63;
     // (the ray index is wave uniform: saying so turns the loads of the ray's origin, direction and lattice origin into
     //  scalar loads -- seven vector-memory instructions per ray less; the kernel is bound by VMEM issue, not by bytes)
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
     if (r >= n_rays) return;
     const float o[3] = {ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]};
     const float d[3] = {rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]};
-    const float t0 = t0s[r];
+    const float t0 = lattice_origin(t0s, r, t0_scale, t0_base);
     // slab test (fminf/fmaxf drop NaNs like np.fmin/np.fmax)
     float tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                                                           float* __restrict__ te, int32_t* __restrict__ packed,
                                                           const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                           Aabb bb, float* __restrict__ x01, uint8_t* __restrict__ sel,
-                                                          int32_t rank_lo) {
+                                                          int32_t rank_lo, float t0_scale, float t0_base) {
     // Writes the samples of rank [rank_lo, rank_lo + counts[r]) of every ray (rank = position among the ray's samples in t
     // order) to offsets[r]...: rank_lo = 0 and counts = the march counts is the plain expansion; the two-phase sampler
     // writes the first K samples of every ray first and the rest of the rays that are still alive later.
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
         if ((int64_t)off + cnt > capacity) cnt = (int32_t)(capacity > off ? capacity - off : 0);   // truncated batch
         if (l == 0) { packed[2 * r] = off; packed[2 * r + 1] = cnt; }
         if (cnt == 0) continue;
-        const float t0 = t0s[r];
+        const float t0 = lattice_origin(t0s, r, t0_scale, t0_base);
         int64_t run = (int64_t)off - rank_lo;            // output position of rank 0 (may lie before `off`)
         const int64_t end = (int64_t)off + cnt;
         const int nlw = n_live_words(mask_words);
@@ -293,7 +307,8 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t* __r
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(256) void scan_sums_kernel(int64_t* __restrict__ sums, int64_t n_blocks, int64_t* __restrict__ total_out) {
+__global__ __launch_bounds__(256) void scan_sums_kernel(int64_t* __restrict__ sums, int64_t n_blocks, int64_t* __restrict__ total_out,
+                                                        int64_t bias, int64_t* __restrict__ total_biased) {
     // single block; sequential over chunks of 256 block sums (n_blocks is small)
     __shared__ int64_t carry_s;
     __shared__ int64_t buf[256];
@@ -312,7 +327,10 @@ __global__ __launch_bounds__(256) void scan_sums_kernel(int64_t* __restrict__ su
         if (i < n_blocks) sums[i] = buf[threadIdx.x];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = carry_s;
+    if (threadIdx.x == 0) {
+        *total_out = carry_s;
+        if (total_biased) *total_biased = carry_s + bias;
+    }
 }
 
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
@@ -338,7 +356,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
 // scan of the 32,768 counts of an eval batch cost 27 us per call, 0.86 ms per 512x1024 frame.)
 constexpr int kScanSmall = 65536;
 __global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
-                                                          int64_t* __restrict__ total_out) {
+                                                          int64_t* __restrict__ total_out, int64_t bias, int64_t* __restrict__ total_biased) {
     __shared__ long long wave_sum[16];
     __shared__ int wave_tot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -377,7 +395,10 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t* __restr
 #pragma unroll
     for (int w2 = 0; w2 < 16; ++w2) { base += wave_sum[w2]; if (w2 < wave) before += wave_tot[w2]; seg_total += wave_tot[w2]; }
     if (i < n) out[i] = (int)base + before + inc - v;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = base + seg_total;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        *total_out = base + seg_total;
+        if (total_biased) *total_biased = base + seg_total + bias;
+    }
 }
 
 }  // namespace perf
@@ -410,12 +431,12 @@ extern "C" int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint
     return PERF_OK;
 }
 
-static int march_count_launch(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays, const uint32_t* occ_bits,
-                              const uint32_t* occ_coarse, int32_t res, const float* aabb, float far_plane, float step,
-                              int32_t max_steps, uint64_t* masks, int32_t* counts, const HeadOut* head, void* stream) {
+static int march_count_launch(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base, int64_t n_rays,
+                              const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb, float far_plane,
+                              float step, int32_t max_steps, uint64_t* masks, int32_t* counts, const HeadOut* head, void* stream) {
     PERF_REQUIRE(n_rays >= 0 && res > 0 && res <= 1024 && max_steps > 0 && step > 0.f, "perf_occ_march_count: bad arguments");
     if (n_rays == 0) return PERF_OK;
-    PERF_REQUIRE(rays_o && rays_d && t0 && occ_bits && aabb && masks && counts, "NULL pointer");
+    PERF_REQUIRE(rays_o && rays_d && occ_bits && aabb && masks && counts, "NULL pointer");
     MarchParams mp;
     for (int a = 0; a < 3; ++a) {
         mp.lo[a] = aabb[a]; mp.hi[a] = aabb[3 + a];
@@ -427,24 +448,24 @@ static int march_count_launch(const float* rays_o, const float* rays_d, const fl
     mp.use_coarse = (occ_coarse != nullptr && (res % 8) == 0) ? 1 : 0;      // (+ the per-ray span test in the kernel)
     if (head)
         hipLaunchKernelGGL(march_count_kernel<true>, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
-                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, *head);
+                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, *head, t0_scale, t0_base);
     else
         hipLaunchKernelGGL(march_count_kernel<false>, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
-                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, HeadOut{});
+                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, HeadOut{}, t0_scale, t0_base);
     PERF_LAUNCH_CHECK("perf_occ_march_count");
     return PERF_OK;
 }
 
-extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
-                                    const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
-                                    float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
-                                    void* stream) {
-    return march_count_launch(rays_o, rays_d, t0, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps, masks, counts,
+extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
+                                    int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res,
+                                    const float* aabb, float far_plane, float step, int32_t max_steps, uint64_t* masks,
+                                    int32_t* counts, void* stream) {
+    return march_count_launch(rays_o, rays_d, t0, t0_scale, t0_base, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps, masks, counts,
                               nullptr, stream);
 }
 
-extern "C" int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const float* t0, int64_t n_rays,
-                                         const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
+extern "C" int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
+                                         int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
                                          float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
                                          int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
                                          const float* points_aabb6, float* x01, uint8_t* sel, void* stream) {
@@ -454,16 +475,17 @@ extern "C" int perf_occ_march_count_head(const float* rays_o, const float* rays_
     HeadOut ho;
     ho.K = head_k; ho.ri = ray_indices; ho.ts = t_starts; ho.te = t_ends; ho.packed = packed_info; ho.x01 = x01; ho.sel = sel;
     if (n_rays > 0) for (int a = 0; a < 3; ++a) { ho.bb.lo[a] = points_aabb6[a]; ho.bb.hi[a] = points_aabb6[3 + a]; }
-    return march_count_launch(rays_o, rays_d, t0, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps, masks, counts,
-                              &ho, stream);
+    return march_count_launch(rays_o, rays_d, t0, t0_scale, t0_base, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps,
+                              masks, counts, &ho, stream);
 }
 
 extern "C" int64_t perf_scan_workspace_bytes(int64_t n) { return (div_up(n > 0 ? n : 1, kScanBlock) + 1) * (int64_t)sizeof(int64_t); }
 
-extern "C" int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t* total, int64_t n, void* workspace,
-                                       int64_t workspace_bytes, void* stream) {
+extern "C" int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t* total, int64_t n, int64_t total_bias,
+                                       int64_t* total_biased, void* workspace, int64_t workspace_bytes, void* stream) {
     PERF_REQUIRE(n >= 0 && total, "perf_exclusive_scan_i32: bad arguments");
     if (n == 0) {
+        PERF_REQUIRE(!total_biased, "perf_exclusive_scan_i32: a biased total needs n > 0");
         hipError_t e = hipMemsetAsync(total, 0, sizeof(int64_t), as_stream(stream));
         if (e != hipSuccess) { set_error("memset failed"); return PERF_E_LAUNCH; }
         return PERF_OK;
@@ -472,47 +494,48 @@ extern "C" int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t*
     PERF_REQUIRE(workspace_bytes >= perf_scan_workspace_bytes(n), "scan workspace too small");
     PERF_REQUIRE(in != out, "perf_exclusive_scan_i32: in-place scan is not supported");
     if (n <= kScanSmall) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3((unsigned)div_up(n, 1024)), dim3(1024), 0, as_stream(stream), in, out, n, total);
+        hipLaunchKernelGGL(scan_small_kernel, dim3((unsigned)div_up(n, 1024)), dim3(1024), 0, as_stream(stream), in, out, n, total, total_bias,
+                           total_biased);
         PERF_LAUNCH_CHECK("perf_exclusive_scan_i32");
         return PERF_OK;
     }
     const int64_t nb = div_up(n, kScanBlock);
     int64_t* sums = (int64_t*)workspace;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), in, n, sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, as_stream(stream), sums, nb, total);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, as_stream(stream), sums, nb, total, total_bias, total_biased);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), in, out, n, sums);
     PERF_LAUNCH_CHECK("perf_exclusive_scan_i32");
     return PERF_OK;
 }
 
-extern "C" int perf_occ_march_write(const float* t0, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
+extern "C" int perf_occ_march_write(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
                                     const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                     float* t_starts, float* t_ends, int32_t* packed_info, void* stream) {
     PERF_REQUIRE(n_rays >= 0 && max_steps > 0 && capacity >= 0, "perf_occ_march_write: bad arguments");
     if (n_rays == 0) return PERF_OK;
-    PERF_REQUIRE(t0 && masks && counts && offsets && packed_info, "NULL pointer");
+    PERF_REQUIRE(masks && counts && offsets && packed_info, "NULL pointer");
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends), "NULL sample arrays");
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0);
+                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0, t0_scale, t0_base);
     PERF_LAUNCH_CHECK("perf_occ_march_write");
     return PERF_OK;
 }
 
-extern "C" int perf_occ_march_write_points(const float* t0, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
+extern "C" int perf_occ_march_write_points(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
                                            const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                            float* t_starts, float* t_ends, int32_t* packed_info, const float* rays_o,
                                            const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, int32_t rank_lo,
                                            void* stream) {
     PERF_REQUIRE(n_rays >= 0 && max_steps > 0 && capacity >= 0 && rank_lo >= 0, "perf_occ_march_write_points: bad arguments");
     if (n_rays == 0) return PERF_OK;
-    PERF_REQUIRE(t0 && masks && counts && offsets && packed_info && rays_o && rays_d && aabb6, "NULL pointer");
+    PERF_REQUIRE(masks && counts && offsets && packed_info && rays_o && rays_d && aabb6, "NULL pointer");
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends && x01), "NULL sample arrays");
     Aabb bb;
     for (int k = 0; k < 3; ++k) { bb.lo[k] = aabb6[k]; bb.hi[k] = aabb6[3 + k]; }
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo);
+                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo, t0_scale, t0_base);
     PERF_LAUNCH_CHECK("perf_occ_march_write_points");
     return PERF_OK;
 }

@@ -284,7 +284,18 @@ static int raygen_launch(const float* pose, const float* pose_dev, int32_t heigh
 namespace perf {
 __global__ void step_bookkeeping_kernel(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
                                         const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
-                                        int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out) {
+                                        int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out,
+                                        const float* schedule, int32_t n_schedule, int32_t* iter_dev, float* lr_out, float* ratio_out) {
+    if (schedule && iter_dev && n_schedule > 0) {
+        // device-side schedule: row i = {learning rate of iteration i, distortion-loss ramp of iteration i}.  This launch sits
+        // between the backward and Adam of iteration `it`: Adam reads lr(it) next, the loss head of iteration it + 1 reads
+        // ratio(it + 1) -- a graph replay then needs no host-side scalar update at all
+        const int it = iter_dev[0];
+        const int cur = it < n_schedule ? it : n_schedule - 1, nxt = it + 1 < n_schedule ? it + 1 : n_schedule - 1;
+        if (lr_out) lr_out[0] = schedule[2 * cur];
+        if (ratio_out) ratio_out[0] = schedule[2 * nxt + 1];
+        iter_dev[0] = it + 1;
+    }
     const int64_t marched = n_marched_dev ? n_marched_dev[0] : 0;
     const bool has_samples = !gate_dev || gate_dev[0] > 0;
     const bool overflow = (overflow_flag && overflow_flag[0] != 0) || (remote_flags && remote_flags[0] > 0.f);
@@ -306,9 +317,12 @@ __global__ void step_bookkeeping_kernel(int32_t* step_dev, const int64_t* gate_d
 
 extern "C" int perf_step_bookkeeping(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
                                      const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
-                                     int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out, void* stream) {
+                                     int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out,
+                                     const float* schedule, int32_t n_schedule, int32_t* iter_dev, float* lr_out, float* ratio_out,
+                                     void* stream) {
     hipLaunchKernelGGL(perf::step_bookkeeping_kernel, dim3(1), dim3(1), 0, as_stream(stream), step_dev, gate_dev, counters,
-                       n_marched_dev, n_kept_dev, capacity, overflow_flag, remote_flags, eff_gate_out);
+                       n_marched_dev, n_kept_dev, capacity, overflow_flag, remote_flags, eff_gate_out, schedule, n_schedule, iter_dev,
+                       lr_out, ratio_out);
     PERF_LAUNCH_CHECK("perf_step_bookkeeping");
     return PERF_OK;
 }

@@ -208,15 +208,13 @@ class OccGridEstimator(nn.Module):
             t1 = (lo - rays_o) * inv; t2 = (hi - rays_o) * inv
             t_in = torch.fmin(t1, t2).nan_to_num(nan=-float('inf')).amax(-1)
             anchor = torch.clamp(t_in, min=float(near_plane)).nan_to_num(posinf=float(near_plane))
+        # lattice origin near + u * step: formed inside the marching kernels from (u, step, near) -- see ops._origin; only the
+        # anchored case (rays that start outside the box, never PeRF's) materialises it
         if stratified:
-            u = torch.rand(R, device=dev) if jitter is None else jitter
-            t0 = u * render_step_size                       # near + u * step, without the fill and the add when near == 0
-            if anchor is not None:
-                t0 = t0 + anchor
-            elif float(near_plane) != 0.0:
-                t0 = t0 + float(near_plane)
+            u = torch.rand(R, device=dev) if jitter is None else jitter.contiguous()
+            t0 = (u, float(render_step_size), float(near_plane)) if anchor is None else u * render_step_size + anchor
         else:
-            t0 = anchor if anchor is not None else torch.full((R,), float(near_plane), dtype=torch.float32, device=dev)
+            t0 = (None, 0.0, float(near_plane)) if anchor is None else anchor
         if max_steps is None:
             max_steps = int(math.ceil(span / render_step_size)) + 1
         res = self._res
@@ -267,17 +265,6 @@ class OccGridEstimator(nn.Module):
 
     STRIDED_HEAD_MAX = 16          # heads of up to this many samples are written by the counting pass, K rows per ray
 
-    def _const_count(self, value, device):
-        """Device int64 [1] holding `value` (cached: created once, outside any graph capture of later calls)."""
-        cache = self.__dict__.setdefault('_count_consts', {})
-        key = (int(value), str(device))
-        if key not in cache:
-            t = torch.full((1,), int(value), dtype=torch.int64, device=device)
-            if torch.cuda.is_current_stream_capturing():
-                return t               # lives in the capturing graph's pool and is filled by its replays: not for the cache
-            cache[key] = t
-        return cache[key]
-
     def _sample_two_phase(self, sm, rays_o, rays_d, t0, far_plane, step, max_steps, capacity, points_aabb, sigma_points_fn,
                           early_stop_eps, K):
         """March once; density + visibility on the first K samples of every ray; then density on the remaining samples of
@@ -288,7 +275,7 @@ class OccGridEstimator(nn.Module):
         if K <= self.STRIDED_HEAD_MAX:
             masks, counts, (ri_h, ts_h, te_h, pk_h, x_h, s_h) = ops.occ_march_count_head(
                 rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step, max_steps, self.occ_coarse(), K, points_aabb)
-            total_h = self._const_count(R * K, rays_o.device)
+            total_h = None                      # R * K rows, a host constant: folded into the tail scan's biased total below
             sig_h, feat_h = _sig_feat(sigma_points_fn(x_h, s_h, None))
         else:       # a long head: packed rows (count clamp, scan over the rays, write pass) instead of K rows per ray
             masks, counts = ops.occ_march_count(rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step,
@@ -297,10 +284,13 @@ class OccGridEstimator(nn.Module):
             oh, total_h = ops.exclusive_scan_i32(ch)
             ri_h, ts_h, te_h, pk_h, x_h, s_h = ops.occ_march_write(t0, masks, ch, oh, R * K, step, max_steps, rays_o, rays_d, points_aabb)
             sig_h, feat_h = _sig_feat(sigma_points_fn(x_h, s_h, total_h))
-        kept_h = ops.visibility_count(sig_h, ts_h, te_h, pk_h, early_stop_eps)
-        # ---- tail: rank [K, count) of the rays whose whole head survived
-        ct = ops.head_tail_counts(counts, K, kept_h)
-        ot, total_t = ops.exclusive_scan_i32(ct)
+        # ---- head decision and the tail counts (rank [K, count) of the rays whose whole head survived) in one launch
+        kept_h, ct = ops.visibility_count(sig_h, ts_h, te_h, pk_h, early_stop_eps, march_counts=counts, head_samples=K)
+        if total_h is None:
+            ot, total_t, n_evaluated = ops.exclusive_scan_i32(ct, bias=R * K)
+        else:
+            ot, total_t = ops.exclusive_scan_i32(ct)
+            n_evaluated = total_h + total_t
         ri_t, ts_t, te_t, pk_t, x_t, s_t = ops.occ_march_write(t0, masks, ct, ot, capacity, step, max_steps, rays_o, rays_d, points_aabb,
                                                                rank_lo=K)
         sig_t, feat_t = _sig_feat(sigma_points_fn(x_t, s_t, total_t))
@@ -313,7 +303,7 @@ class OccGridEstimator(nn.Module):
         ri._perf_packed = packed
         sm.ray_indices, sm.t_starts, sm.t_ends, sm.packed, sm.sig, sm.x01, sm.sel = ri, ts, te, packed, sig, x01, sel
         sm.n_dev = total
-        sm.n_marched_dev = total_h + total_t          # rows whose density was evaluated (what must fit the capacity)
+        sm.n_marched_dev = n_evaluated                # rows whose density was evaluated (what must fit the capacity)
         return sm
 
     @torch.no_grad()

@@ -116,15 +116,19 @@ def adam_step_dev(p, m, v, g, step_dev, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8
 
 
 def step_bookkeeping(step_dev=None, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0, overflow=None,
-                     remote_flags=None, eff_gate=None):
+                     remote_flags=None, eff_gate=None, schedule=None):
     """One launch (perf_step_bookkeeping): decides whether the optimizer step is TAKEN (samples present, no fixed-point
     overflow flag -- local int32 `overflow` or the float sum `remote_flags` of the other ranks' --, batch not truncated at
-    `capacity`), advances step_dev and writes eff_gate (int64 [1]) accordingly, accumulates counters (int64 [8])."""
+    `capacity`), advances step_dev and writes eff_gate (int64 [1]) accordingly, accumulates counters (int64 [8]).
+    schedule = (table f32 [n, 2] = rows of (lr, distortion ramp), iter_dev int32 [1], lr_out f32 [1], ratio_out f32 [1] or None):
+    the device-side schedule of a graph-replayed phase (see perf_step_bookkeeping)."""
     ref = next(t for t in (step_dev, counters, eff_gate) if t is not None)
     if not ref.is_cuda:
         raise _lib.PerfError('perf_amd ops need CUDA (HIP) tensors; there is no CPU path')
+    table, it, lr_out, ratio_out = schedule if schedule is not None else (None, None, None, None)
     _call('perf_step_bookkeeping', _p(step_dev), _nd(gate), _nd(counters), _nd(n_marched), _nd(n_kept), int(capacity or 0),
-          _p(overflow), _p(remote_flags), _nd(eff_gate), _stream())
+          _p(overflow), _p(remote_flags), _nd(eff_gate), _p(table), int(table.shape[0]) if table is not None else 0, _p(it),
+          _p(lr_out), _p(ratio_out), _stream())
 
 
 def step_counters(device):
@@ -320,15 +324,16 @@ def field_infer(grid: GridConfig, mlp: MlpConfig, x01, sel, w16, n_dev=None):
     return out
 
 
-def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True, want_absmax=False, n_dev=None):
-    """Returns (dfeat [L,n,2] f32 or None, dw [n_net_params] f32[, level_absmax [16] f32])."""
+def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True, want_absmax=False, n_dev=None, dw_out=None):
+    """Returns (dfeat [L,n,2] f32 or None, dw [n_net_params] f32[, level_absmax [16] f32]).  dw_out: write the weight gradient
+    there (e.g. the head of a flat [network | grid] gradient) instead of into a fresh tensor."""
     n = feat16.shape[1]
     d = mlp.desc()
     lib = _lib.load()
     ws_bytes = lib.perf_mlp_bwd_workspace_bytes(ctypes.byref(d), n)
     ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=feat16.device)
     dfeat = torch.empty(mlp.n_levels, n, 2, dtype=torch.float32, device=feat16.device) if need_dfeat else None
-    dw = torch.empty(mlp.n_params, dtype=torch.float32, device=feat16.device)
+    dw = dw_out if dw_out is not None else torch.empty(mlp.n_params, dtype=torch.float32, device=feat16.device)
     amax = torch.empty(_lib.MAX_LEVELS, dtype=torch.float32, device=feat16.device) if want_absmax else None
     _call('perf_mlp_bwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(_f32(dout, 'dout')), _p(dfeat), _p(dw), _p(amax),
               _p(ws), ws.numel() * 4, n, _nd(n_dev), dtype_code(w16.dtype), _stream())
@@ -370,14 +375,16 @@ def occ_pack_bits(binaries: torch.Tensor) -> torch.Tensor:
     return bits
 
 
-def exclusive_scan_i32(counts: torch.Tensor):
+def exclusive_scan_i32(counts: torch.Tensor, bias=None):
+    """-> (offsets, total int64 [1]); with `bias` (host int) also total + bias as a third result (same launch)."""
     n = counts.numel()
     lib = _lib.load()
     out = torch.empty_like(counts)
-    total = torch.empty(1, dtype=torch.int64, device=counts.device)
+    totals = torch.empty(2, dtype=torch.int64, device=counts.device)
     ws = torch.empty(lib.perf_scan_workspace_bytes(n) // 8 + 1, dtype=torch.int64, device=counts.device)
-    _call('perf_exclusive_scan_i32', _p(counts), _p(out), _p(total), n, _p(ws), ws.numel() * 8, _stream())
-    return out, total
+    _call('perf_exclusive_scan_i32', _p(counts), _p(out), _p(totals), n, int(bias or 0), _p(totals[1:]) if bias is not None else None,
+          _p(ws), ws.numel() * 8, _stream())
+    return (out, totals[:1]) if bias is None else (out, totals[:1], totals[1:])
 
 
 def occ_build_coarse(occ_bits, res):
@@ -390,14 +397,23 @@ def occ_build_coarse(occ_bits, res):
     return coarse
 
 
+def _origin(t0):
+    """Lattice-origin argument of the marching entry points -> (pointer, t0_scale, t0_base).  t0: a float32 tensor [R] (origins
+    as given), or a tuple (u, scale, base): u = stratified draws [R] or None; origin = u * scale (+ base), resp. base."""
+    if isinstance(t0, tuple):
+        u, scale, base = t0
+        return (_p(_f32(u, 't0')) if u is not None else None), float(scale if u is not None else 0.0), float(base)
+    return _p(_f32(t0, 't0')), 0.0, 0.0
+
+
 def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse=None):
-    """Pass 1 of the marching: -> (keep masks, per-ray counts int32 [R])."""
+    """Pass 1 of the marching: -> (keep masks, per-ray counts int32 [R]).  t0: see _origin."""
     R = rays_o.shape[0]
     dev = rays_o.device
     mw = _lib.load().perf_occ_mask_words(max_steps)
     masks = torch.empty(max(R * mw, 1), dtype=torch.int64, device=dev)
     counts = torch.empty(R, dtype=torch.int32, device=dev)
-    _call('perf_occ_march_count', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(t0, 't0')), R,
+    _call('perf_occ_march_count', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), *_origin(t0), R,
           _p(occ_bits), _p(occ_coarse), int(res), _aabb6(aabb), float(far_plane), float(step), int(max_steps), _p(masks), _p(counts), _stream())
     return masks, counts
 
@@ -417,7 +433,7 @@ def occ_march_count_head(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, ste
     packed = torch.empty(R, 2, dtype=torch.int32, device=dev)
     x01 = torch.empty(S, 3, dtype=torch.float32, device=dev)
     sel = torch.empty(S, dtype=torch.uint8, device=dev)
-    _call('perf_occ_march_count_head', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), _p(_f32(t0, 't0')), R,
+    _call('perf_occ_march_count_head', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), *_origin(t0), R,
           _p(occ_bits), _p(occ_coarse), int(res), _aabb6(aabb), float(far_plane), float(step), int(max_steps), _p(masks), _p(counts),
           int(head_k), _p(ri), _p(ts), _p(te), _p(packed), _aabb6(points_aabb), _p(x01), _p(sel), _stream())
     return masks, counts, (ri, ts, te, packed, x01, sel)
@@ -435,12 +451,12 @@ def occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o=None,
     if points_aabb is not None:
         x01 = torch.empty(S, 3, dtype=torch.float32, device=dev)
         sel = torch.empty(S, dtype=torch.uint8, device=dev)
-        _call('perf_occ_march_write_points', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
+        _call('perf_occ_march_write_points', *_origin(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
               _p(ri), _p(ts), _p(te), _p(packed), _p(rays_o), _p(rays_d), _aabb6(points_aabb), _p(x01), _p(sel), int(rank_lo), _stream())
         return ri, ts, te, packed, x01, sel
     if rank_lo != 0:
         raise _lib.PerfError('rank_lo needs points_aabb (perf_occ_march_write_points)')
-    _call('perf_occ_march_write', _p(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
+    _call('perf_occ_march_write', *_origin(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
           _p(ri), _p(ts), _p(te), _p(packed), _stream())
     return ri, ts, te, packed
 
@@ -503,13 +519,18 @@ def compact_prefix2(head, tail, new_counts, capacity, feat_h=None, feat_t=None):
 
 
 # ---- compositing -----------------------------------------------------------------------------------
-def visibility_count(sigmas, t_starts, t_ends, packed, early_stop_eps=1e-4, want_exsum=False):
+def visibility_count(sigmas, t_starts, t_ends, packed, early_stop_eps=1e-4, want_exsum=False, march_counts=None, head_samples=0):
+    """-> kept counts int32 [R] (+ exsum); with march_counts / head_samples also the two-phase sampler's tail counts (same
+    launch): (kept, tail_counts)."""
     R = packed.shape[0]
     thr = float(-math.log(early_stop_eps)) if early_stop_eps > 0 else float('inf')
     new_counts = torch.empty(R, dtype=torch.int32, device=packed.device)
     ex = torch.empty_like(sigmas) if want_exsum else None
+    tail = torch.empty(R, dtype=torch.int32, device=packed.device) if march_counts is not None else None
     _call('perf_visibility_count', _p(_f32(sigmas, 'sigmas')), _p(t_starts), _p(t_ends), _p(packed), R, thr,
-              _p(new_counts), _p(ex), _stream())
+              _p(new_counts), _p(ex), _p(march_counts), int(head_samples), _p(tail), _stream())
+    if march_counts is not None:
+        return new_counts, tail
     return (new_counts, ex) if want_exsum else new_counts
 
 
@@ -624,6 +645,21 @@ def distloss_bwd(w, t_starts, t_ends, packed, scale, scale_dev=None):
     return g
 
 
+_TICKETS = {}
+
+
+def _ticket(device):
+    """A zeroed device int32 per (device, stream) for kernels that elect their last workgroup (left at zero by every call)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _TICKETS.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            return t               # (created inside a capture: zero-filled by the graph itself on every replay)
+        _TICKETS[key] = t
+    return t
+
+
 def geo_loss(opacity, distance, gt_distance, noise, distloss_per_ray, packed, global_batch, depth_weight, distortion_weight,
              ratio_dev, loss_scale):
     """-> (g_opacity [R,1], g_distance [R,1], scalars [3] = depth loss, distortion loss, distloss-backward scale)."""
@@ -633,7 +669,7 @@ def geo_loss(opacity, distance, gt_distance, noise, distloss_per_ray, packed, gl
     sc = torch.empty(_lib.LOSS_SCALARS, dtype=torch.float32, device=dev)
     _call('perf_geo_loss', _p(opacity), _p(distance), _p(_f32(gt_distance.contiguous(), 'gt')), _p(noise), _p(distloss_per_ray), _p(packed), R,
           int(global_batch), float(depth_weight), float(distortion_weight), _p(ratio_dev), float(loss_scale), _p(g_op), _p(g_d), _p(sc),
-          _stream())
+          _p(_ticket(dev)), _stream())
     return g_op, g_d, sc
 
 

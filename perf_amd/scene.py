@@ -202,6 +202,9 @@ class FusedAdam:
         self.capturing = False
         self.w16 = torch.empty(p.numel(), dtype=ops.torch_dtype(net.dtype_name), device=p.device)
         self.w16.copy_(net.working_copy())         # (a gated-off first step must leave a valid working copy behind)
+        self.sched_table = None                    # device-side schedule of graph-replayed phases (perf_step_bookkeeping)
+        self.sched_iter = None
+        self.sched_ratio_out = None
 
     @property
     def p(self):
@@ -215,8 +218,39 @@ class FusedAdam:
         pass                                       # the step consumes the gradient and drops it
 
     def refresh_lr(self):
-        if not self.capturing:
+        if not self.capturing and self.sched_table is None:
             self.lr_dev.fill_(self.param_groups[0]['lr'])      # under capture the replay wrapper refreshes lr_dev instead
+
+    SCHEDULE_ROWS = 32768
+
+    def load_schedule(self, lrs, ratios=None, first=0, ratio_out=None):
+        """Install the device-side schedule: row i = (learning rate, distortion-loss ramp) of iteration i; the next step is
+        iteration `first`.  From then on perf_step_bookkeeping sets lr_dev (and ratio_out, the loss head's ramp scalar) itself:
+        replaying a captured step needs no host-side scalar update.  The table has a fixed size (the captured launch keeps its
+        pointers): a new phase just loads new rows.  Rows beyond the given ones repeat the last one."""
+        n = min(len(lrs), self.SCHEDULE_ROWS)
+        rows = torch.empty(self.SCHEDULE_ROWS, 2, dtype=torch.float32)
+        rows[:n, 0] = torch.as_tensor(lrs[:n], dtype=torch.float32)
+        rows[:n, 1] = torch.as_tensor(ratios[:n], dtype=torch.float32) if ratios is not None else 1.0
+        rows[n:] = rows[n - 1]
+        dev = self.lr_dev.device
+        if self.sched_table is None:
+            self.sched_table = torch.empty(self.SCHEDULE_ROWS, 2, dtype=torch.float32, device=dev)
+            self.sched_iter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sched_table.copy_(rows)
+        self.sched_iter.fill_(int(first))
+        self.sched_ratio_out = ratio_out
+        self.lr_dev.fill_(float(rows[min(first, n - 1), 0]))
+        if ratio_out is not None:
+            ratio_out.fill_(float(rows[min(first, n - 1), 1]))
+
+    def clear_schedule(self):
+        self.sched_table = self.sched_iter = self.sched_ratio_out = None
+
+    def schedule_args(self):
+        if self.sched_table is None:
+            return None
+        return (self.sched_table, self.sched_iter, self.lr_dev, self.sched_ratio_out)
 
     def step(self, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0):
         """gate (device int64 [1], optional): the number of samples behind this gradient.  The step is TAKEN unless the gate
@@ -230,7 +264,7 @@ class FusedAdam:
         self.refresh_lr()
         flag = ops.overflow_flag(p.device) if _tcnn.GRID_GRAD_ACCUM == 'fixed' else None
         ops.step_bookkeeping(self.step_dev, gate, counters, n_marched, n_kept if n_kept is not None else gate, capacity=capacity,
-                             overflow=flag, eff_gate=self.eff_gate)
+                             overflow=flag, eff_gate=self.eff_gate, schedule=self.schedule_args())
         ops.adam_step_dev(p.data, self.exp_avg, self.exp_avg_sq, p.grad[:p.numel()], self.step_dev, self.lr_dev, g['betas'][0],
                           g['betas'][1], g['eps'], w16=self.w16, zero_grad=False, gate=self.eff_gate)
         p.grad = None                              # the next backward installs a fresh gradient (no accumulate pass)
@@ -254,7 +288,7 @@ class _HipStepKernels:
 
     def bookkeeping(self, step_dev, gate, counters, n_marched, n_kept, capacity, overflow, remote_flags, eff_gate):
         ops.step_bookkeeping(step_dev, gate, counters, n_marched, n_kept, capacity=capacity, overflow=overflow,
-                             remote_flags=remote_flags, eff_gate=eff_gate)
+                             remote_flags=remote_flags, eff_gate=eff_gate, schedule=self.opt.schedule_args())
 
     def adam(self, p, m, v, g, w16, step_dev, lr_dev, gate):
         b = self.opt.param_groups[0]
@@ -473,9 +507,11 @@ class NeRFScene:
         graphed = None
         for iter_i in range(n_iters):
             if use_graphs and graphed is None and iter_i >= self.EAGER_HEAD:
-                graphed = self.make_graphed_step(kind, optimizer, sup_pool, warmup=0)
+                lrs = [self.lr_at(conf, i / n_iters) for i in range(n_iters)]
+                ratios = [float(np.min([progress_of(i) * 2., 1])) for i in range(n_iters)]
+                graphed = self.make_graphed_step(kind, optimizer, sup_pool, warmup=0, schedule=(lrs, ratios, iter_i))
             if graphed is not None:
-                graphed(self.lr_at(conf, iter_i / n_iters), progress_of(iter_i))
+                graphed()
                 if self._dist()[0] is not None:
                     self._poll_health()            # (single-process replays poll by themselves)
             else:
@@ -583,10 +619,9 @@ class NeRFScene:
         """Flat gradient [network | grid] (+ `extra` trailing slots: the data-parallel path appends the sample count)."""
         n_net = net.mlp.n_params
         fixed = _tcnn.GRID_GRAD_ACCUM == 'fixed'
-        res = ops.mlp_bwd(net.mlp, w16[:n_net], feat, dout, sel, want_absmax=fixed, n_dev=n_dev)
         n_all = n_net + net.grid.n_params
         grad = torch.empty(n_all + extra, dtype=torch.float32, device=x01.device)
-        grad[:n_net] = res[1]
+        res = ops.mlp_bwd(net.mlp, w16[:n_net], feat, dout, sel, want_absmax=fixed, n_dev=n_dev, dw_out=grad[:n_net])
         ops.hashgrid_bwd_into(net.grid, x01, res[0], grad[n_net:n_all], level_absmax=res[2] if fixed else None, n_dev=n_dev,
                               hr_state=net.headroom_state() if fixed else None)
         return grad
@@ -722,7 +757,7 @@ class NeRFScene:
         if rgbs is not None:
             self.last_colors = col           # the step's (unused) colour render, [n_rays, 3]
         noise = rand['noise']            # (the background colour the reference also draws, :185, is not used by this step)
-        if not self._capturing:
+        if not self._capturing and getattr(optimizer, 'sched_table', None) is None:
             self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
         g_op, g_dist, sc = ops.geo_loss(op, dist_r, gt_depths, noise, dl, packed, bs, tc.depth_loss_weight,
                                         tc.distortion_loss_weight, self._ratio_dev, self.loss_scale)
@@ -871,14 +906,17 @@ class NeRFScene:
     # ---- hipGraph capture of a whole training step (launch-bound inner loop) ---------------------------
     TRAIN_SAMPLES_PER_RAY = 128    # default per-ray sample capacity of sync-free / graph-captured training batches
 
-    def make_graphed_step(self, kind, optimizer, sup_pool, warmup=3):
+    def make_graphed_step(self, kind, optimizer, sup_pool, warmup=3, schedule=None):
         """Capture train_one_step_{geo,app} (batch draw, sampling incl. the no-grad density pass and visibility compaction,
         both fields, compositing, losses, backward, Adam) into one hipGraph.  Sample arrays are capacity-sized
         (renderer.sample_capacity; default pixel_loss_batch_size * TRAIN_SAMPLES_PER_RAY) and every count stays on the
         device, so the reference's variable-count step is a fixed launch sequence.  Needs the fused Adam (device-side
         step / lr).  Under data parallelism (sharded mode, RCCL) the step's collectives are captured with it -- every rank
         must capture and replay in lockstep, and draw from identically seeded default generators.  `warmup` real steps run
-        first (they ARE training steps; pass 0 when the caller has already run the step eagerly).  Returns replay(lr, progress)."""
+        first (they ARE training steps; pass 0 when the caller has already run the step eagerly).
+        schedule = (lrs, ratios, first): learning rate and distortion ramp min(2 progress, 1) of every iteration of the phase,
+        the first replay being iteration `first` -- installed on the device (FusedAdam.load_schedule), so that replay() needs no
+        argument and issues nothing but the graph.  Without it: replay(lr, progress) refreshes the two scalars per call."""
         assert isinstance(optimizer, FusedAdam), 'graph capture needs the fused Adam (device-side step/lr)'
         dist_info = self._dist()
         assert dist_info[0] is None or self._sharded(dist_info, optimizer), \
@@ -894,6 +932,9 @@ class NeRFScene:
                 for _ in range(warmup):
                     step_fn(optimizer, sup_pool, progress=0.0)
             torch.cuda.current_stream().wait_stream(side)
+        if schedule is not None:
+            lrs, ratios, first = schedule
+            optimizer.load_schedule(lrs, ratios if kind == 'geo' else None, first, ratio_out=self._ratio_dev if kind == 'geo' else None)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         self._capturing = optimizer.capturing = True
@@ -906,10 +947,11 @@ class NeRFScene:
         state = {'graph': graph, 'n': 0, 'counts': self._last_counts, 'capacity': self.renderer.sample_capacity,
                  'mode': _tcnn.GRID_GRAD_ACCUM}
 
-        def replay(lr, progress):
-            optimizer.lr_dev.fill_(lr)
-            if kind == 'geo':
-                self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
+        def replay(lr=None, progress=None):
+            if optimizer.sched_table is None:                    # no device-side schedule: refresh the two scalars
+                optimizer.lr_dev.fill_(lr)
+                if kind == 'geo':
+                    self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
             state['graph'].replay()
             state['n'] += 1
             if kind == 'geo':

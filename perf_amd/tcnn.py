@@ -119,9 +119,8 @@ def _field_backward(module, x01, w16, feat, sel, dout, n_dev=None, poll_overflow
     global _backward_calls
     n_net = module.mlp.n_params
     fixed = GRID_GRAD_ACCUM == 'fixed'          # module-level switch, see check_fixed_point_overflow()
-    res = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout.contiguous().float(), sel, want_absmax=fixed, n_dev=n_dev)
     grad = torch.empty(n_net + module.grid.n_params, dtype=torch.float32, device=x01.device)
-    grad[:n_net] = res[1]
+    res = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout.contiguous().float(), sel, want_absmax=fixed, n_dev=n_dev, dw_out=grad[:n_net])
     ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=res[2] if fixed else None, n_dev=n_dev,
                           hr_state=module.headroom_state() if fixed else None)
     if fixed and poll_overflow and OVERFLOW_POLL_EVERY > 0 and not torch.cuda.is_current_stream_capturing():
