@@ -22,7 +22,7 @@ def _newer(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'common.hpp'),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'grid_device.hpp'),
                                                           os.path.join(HERE, '..', 'include', 'perf_hip.h')]
     if not force and _newer(LIB, deps):
         return LIB
@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
 
     def cc(src):
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
-        if not force and _newer(obj, [os.path.join(CSRC, src), os.path.join(CSRC, 'common.hpp'),
+        if not force and _newer(obj, [os.path.join(CSRC, src), os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'grid_device.hpp'),
                                       os.path.join(HERE, '..', 'include', 'perf_hip.h')]):
             return obj
         cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]

@@ -12,90 +12,11 @@
 #include <mutex>
 #include "common.hpp"
 
+#include "grid_device.hpp"
+
 namespace perf {
 
-struct GridParams {
-    int32_t n_levels;
-    int32_t interpolation;
-    float scale[PERF_MAX_LEVELS];
-    uint32_t res[PERF_MAX_LEVELS];
-    uint32_t size[PERF_MAX_LEVELS];
-    uint64_t offset[PERF_MAX_LEVELS];
-    uint32_t hashed[PERF_MAX_LEVELS];
-};
-
-static int fill_params(const perf_grid_desc* g, GridParams* p) {
-    PERF_REQUIRE(g != nullptr, "grid desc is NULL");
-    PERF_REQUIRE(g->n_levels >= 1 && g->n_levels <= PERF_MAX_LEVELS, "n_levels %d out of range", g->n_levels);
-    p->n_levels = g->n_levels;
-    p->interpolation = g->interpolation;
-    for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
-        p->scale[l] = g->scale[l]; p->res[l] = g->res[l]; p->size[l] = g->size[l];
-        p->offset[l] = g->offset[l]; p->hashed[l] = g->hashed[l];
-        if (l < g->n_levels) {
-            PERF_REQUIRE(g->size[l] > 0, "level %d has size 0", l);
-            if (g->hashed[l]) PERF_REQUIRE((g->size[l] & (g->size[l] - 1)) == 0, "hashed level %d size %u is not a power of two", l, g->size[l]);
-        }
-    }
-    return PERF_OK;
-}
-
 constexpr int kHeadroomStartBias = 3;
-constexpr uint32_t kPrimeY = 2654435761u;
-constexpr uint32_t kPrimeZ = 805459861u;
-
-// Grid position of a coordinate: ONE rounding, pos = fl(x*scale + 0.5), as tiny-cuda-nn's pos_fract computes it
-// (fmaf(scale, input, 0.5f)); oracle/perf_oracle.py:grid_pos restates the same rounding for numpy.
-__device__ __forceinline__ float grid_pos(float x, float scale) { return __builtin_fmaf(x, scale, 0.5f); }
-
-// Corner bookkeeping of one (sample, level): 8 table indices + fractional position.
-struct Corners {
-    uint32_t idx[8];
-    float f[3];
-    uint32_t cell[3];       // integer cell: two samples with equal cells gather the same 8 entries
-};
-
-__device__ __forceinline__ Corners corners_of(float x, float y, float z, float scale, uint32_t res,
-                                              uint32_t size, bool hashed) {
-    Corners c;
-    float px = grid_pos(x, scale);
-    float py = grid_pos(y, scale);
-    float pz = grid_pos(z, scale);
-    float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-    c.f[0] = px - flx; c.f[1] = py - fly; c.f[2] = pz - flz;
-    uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
-    c.cell[0] = gx; c.cell[1] = gy; c.cell[2] = gz;
-    if (hashed) {
-        uint32_t hy0 = gy * kPrimeY, hy1 = hy0 + kPrimeY;
-        uint32_t hz0 = gz * kPrimeZ, hz1 = hz0 + kPrimeZ;
-        uint32_t m = size - 1u;
-        uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) c.idx[k] = ((gx + (uint32_t)(k & 1)) ^ yz[k >> 1]) & m;
-    } else {
-        uint32_t r2 = res * res;
-        uint32_t base = gx + gy * res + gz * r2;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uint32_t i = base + (uint32_t)(k & 1) + ((k & 2) ? res : 0u) + ((k & 4) ? r2 : 0u);
-            if (i >= size) i = i % size;
-            c.idx[k] = i;
-        }
-    }
-    return c;
-}
-
-__device__ __forceinline__ void corner_weights(const float f[3], bool smooth, float w[8]) {
-    float fx = f[0], fy = f[1], fz = f[2];
-    if (smooth) {
-        fx = fx * fx * (3.0f - 2.0f * fx);
-        fy = fy * fy * (3.0f - 2.0f * fy);
-        fz = fz * fz * (3.0f - 2.0f * fz);
-    }
-    float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy}, wz[2] = {1.0f - fz, fz};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
-}
 
 // level l handled by (group, pass).  L <= 16: pass 0 -> g, pass 1 -> L-1-g (if different) -- a coarse (small) and a
 // fine (large) table per group.  Deeper grids (L <= 24) add pass 2 -> 16+g; their tables exceed the L2 anyway.
