@@ -246,13 +246,18 @@ int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, 
 
 /* Field inference in one boundary call: out [n, n_out] = act(MLP(encode(x01))) * sel, i.e. NGPNeRF.query_density /
  * query_rgb without gradient (modules/fields/ngp_nerf.py:136-162; the no-grad density pass inside
- * OccGridEstimator.sampling and the eval render are this).  = perf_hashgrid_fwd + perf_mlp_fwd back to back with the
- * 16-bit level-major features in `scratch` (perf_field_infer_scratch_bytes(grid, n) bytes, caller owned); the encode
- * stays a level-group kernel pinned to XCDs, see DESIGN.md.  n / n_dev as everywhere. */
+ * OccGridEstimator.sampling and the eval render are this).  Batches of up to 65,536 rows (and grids of <= 16 levels) run as
+ * ONE fused kernel: every wave encodes its 32 samples straight into the MFMA B-operand registers of the first layer, the
+ * features never travel through memory.  Larger batches run perf_hashgrid_fwd + perf_mlp_fwd back to back -- the encode of a
+ * large batch is a level-group kernel pinned to XCDs, which a single kernel would have to give up -- with the
+ * 16-bit level-major features in `scratch` (perf_field_infer_scratch_bytes(grid, n) bytes, caller owned; may be NULL when
+ * feat_out is given or the batch takes the fused kernel).  feat_out (may be NULL): receives the level-major features
+ * feat[(l*n + i)*2 + f] as perf_hashgrid_fwd writes them (bit-identical) -- the sampler's density pass keeps them for the
+ * gradient pass.  n / n_dev as everywhere. */
 int64_t perf_field_infer_scratch_bytes(const perf_grid_desc* grid, int64_t n);
 int perf_field_infer(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const uint8_t* sel,
                      const void* table16, const void* w16, float* out, int64_t n, const int64_t* n_dev,
-                     void* scratch, int64_t scratch_bytes, int dtype, void* stream);
+                     void* scratch, int64_t scratch_bytes, void* feat_out, int dtype, void* stream);
 
 /* Bytes of caller-owned workspace perf_mlp_bwd needs for n samples. */
 int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n);
@@ -471,6 +476,20 @@ int perf_app_loss(const float* opacity, const float* color, const float* bg_colo
 int perf_gather_supervision(const int64_t* indices, int64_t n, const float* o_all, const float* d_all,
                             const float* color_all, const float* dist_all, const float* normal_all, float* o, float* d,
                             float* color, float* dist, float* normal, void* stream);
+
+/* The whole batch draw of a training step in ONE launch: SupInfoPool.rand_ray_color_data (sup_info.py:236-259: uniform indices
+ * into the pool range [pool_lo, pool_hi) + the five gathers) and the per-ray uniform draws of the step -- the stratified
+ * jitter (nerf_renderer.py:152, nerfacc), the distance noise (:193) and the background colour (:185) -- from a counter-based
+ * generator (Philox4x32-10, key = seed, counter = {position in the global batch, *counter_dev}).  Position = first_global +
+ * i: the ranks of a data-parallel job pass the same seed, hold the same counter and draw disjoint slices of ONE global
+ * batch.  The last workgroup advances *counter_dev (device int64) through `ticket` (device int32, zero before the first call,
+ * left at zero).  A captured training step then contains no torch random-number op -- whose replays cost two extra launches
+ * (seed / offset refresh of the graph-safe generator).  Outputs may be NULL individually; uniforms are 24-bit, in [0, 1). */
+int perf_draw_train_batch(uint64_t seed, int64_t* counter_dev, int32_t* ticket, int64_t pool_lo, int64_t pool_hi,
+                          int64_t n_local, int64_t first_global, const float* o_all, const float* d_all,
+                          const float* color_all, const float* dist_all, const float* normal_all, float* o, float* d,
+                          float* color, float* dist, float* normal, int64_t* indices_out, float* jitter, float* noise,
+                          float* bg, void* stream);
 
 /* ---- hierarchical resampling (nerfacc importance_sampling via PropNetEstimator.sampling,
  *      modules/scene/nerf_renderer.py:60-70; dead in the reference, semantics restated in oracle/) ------------- */

@@ -62,7 +62,7 @@ _SIGS = {
     'perf_hashgrid_bwd_bwd_param': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),
     'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, P, c_int, P]),
     'perf_field_infer_scratch_bytes': (c_int64, [POINTER(GridDesc), c_int64]),
-    'perf_field_infer': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, P, c_int64, P, P, c_int64, c_int, P]),
+    'perf_field_infer': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, P, c_int64, P, P, c_int64, P, c_int, P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
     'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, P, P, P, P, P, c_int64, c_int64, P, c_int, P]),
     'perf_pano_raygen': (c_int, [POINTER(c_float), c_int32, c_int32, c_int32, c_int32, P, P, P]),
@@ -95,6 +95,7 @@ _SIGS = {
     'perf_composite_distloss_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     'perf_composite_distloss_bwd': (c_int, [P, P, P, P, c_int64, P, P, P, P, P, P, c_float, P, P, P]),
     'perf_gather_supervision': (c_int, [P, c_int64, P, P, P, P, P, P, P, P, P, P, P]),
+    'perf_draw_train_batch': (c_int, [c_uint64, P, P, c_int64, c_int64, c_int64, c_int64] + [P] * 14 + [P]),
     'perf_pdf_resample': (c_int, [P, P, P, c_int64, c_int32, c_int32, P, P]),
     'perf_pano_reproject': (c_int, [P, c_int64, POINTER(c_float), P, c_int32, c_int32, c_int32, c_float, P, P]),
     'perf_morph_binary': (c_int, [P, P, c_int32, c_int32, POINTER(c_uint32), c_int32, c_int32, c_int32, P]),

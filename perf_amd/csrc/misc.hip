@@ -383,3 +383,79 @@ extern "C" int perf_gather_supervision(const int64_t* indices, int64_t n, const 
     PERF_LAUNCH_CHECK("perf_gather_supervision");
     return PERF_OK;
 }
+
+// ---- training batch draw: index stream + per-ray uniforms + supervision gather in one launch --------------------------------
+namespace perf {
+// Philox4x32-10 (Salmon et al., SC'11; the counter-based generator family torch.rand uses on the GPU): 128-bit counter,
+// 64-bit key -> four 32-bit words.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x & 0xffffffu) * (1.0f / 16777216.0f); }   // 24 bits, [0, 1)
+
+__global__ __launch_bounds__(256) void draw_train_batch_kernel(uint32_t seed_lo, uint32_t seed_hi, int64_t* __restrict__ counter,
+                                                               int32_t* __restrict__ ticket, int64_t pool_lo, int64_t pool_n,
+                                                               int64_t n_local, int64_t first_global,
+                                                               const float* __restrict__ o_all, const float* __restrict__ d_all,
+                                                               const float* __restrict__ c_all, const float* __restrict__ t_all,
+                                                               const float* __restrict__ n_all, float* __restrict__ o,
+                                                               float* __restrict__ d, float* __restrict__ c, float* __restrict__ t,
+                                                               float* __restrict__ nrm, int64_t* __restrict__ idx_out,
+                                                               float* __restrict__ jitter, float* __restrict__ noise,
+                                                               float* __restrict__ bg) {
+    const uint64_t draw = (uint64_t)counter[0];              // read by every workgroup BEFORE any of them can advance it
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_local) {
+        const uint64_t g = (uint64_t)(first_global + i);     // position in the GLOBAL batch: ranks draw disjoint slices of one stream
+        uint32_t r[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)draw, (uint32_t)(draw >> 32) & 0x7fffffffu};
+        philox4x32_10(r, seed_lo, seed_hi);
+        const int64_t j = pool_lo + (int64_t)(((uint64_t)r[0] * (uint64_t)pool_n) >> 32);
+        if (idx_out) idx_out[i] = j;
+        if (jitter) jitter[i] = u01(r[1]);
+        if (noise) noise[i] = u01(r[2]);
+        if (bg) {
+            uint32_t q[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)draw, ((uint32_t)(draw >> 32) & 0x7fffffffu) | 0x80000000u};
+            philox4x32_10(q, seed_lo, seed_hi);
+            bg[3 * i] = u01(q[0]); bg[3 * i + 1] = u01(q[1]); bg[3 * i + 2] = u01(q[2]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (o) o[3 * i + k] = o_all[3 * j + k];
+            if (d) d[3 * i + k] = d_all[3 * j + k];
+            if (c) c[3 * i + k] = c_all[3 * j + k];
+            if (nrm) nrm[3 * i + k] = n_all[3 * j + k];
+        }
+        if (t) t[i] = t_all[j];
+    }
+    // the last workgroup to finish advances the draw counter (every workgroup has read it by then) and rearms the ticket
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+        counter[0] = (int64_t)(draw + 1);
+        *ticket = 0;
+    }
+}
+}  // namespace perf
+
+extern "C" int perf_draw_train_batch(uint64_t seed, int64_t* counter_dev, int32_t* ticket, int64_t pool_lo, int64_t pool_hi,
+                                     int64_t n_local, int64_t first_global, const float* o_all, const float* d_all,
+                                     const float* color_all, const float* dist_all, const float* normal_all, float* o, float* d,
+                                     float* color, float* dist, float* normal, int64_t* indices_out, float* jitter, float* noise,
+                                     float* bg, void* stream) {
+    PERF_REQUIRE(counter_dev && ticket, "perf_draw_train_batch: NULL counter / ticket");
+    PERF_REQUIRE(pool_hi > pool_lo && pool_lo >= 0 && pool_hi - pool_lo < ((int64_t)1 << 32), "perf_draw_train_batch: bad pool range");
+    PERF_REQUIRE(n_local > 0 && first_global >= 0, "perf_draw_train_batch: bad batch");
+    PERF_REQUIRE((!o || o_all) && (!d || d_all) && (!color || color_all) && (!dist || dist_all) && (!normal || normal_all),
+                 "perf_draw_train_batch: output without source");
+    hipLaunchKernelGGL(perf::draw_train_batch_kernel, dim3((unsigned)perf::div_up(n_local, 256)), dim3(256), 0, perf::as_stream(stream),
+                       (uint32_t)seed, (uint32_t)(seed >> 32), counter_dev, ticket, pool_lo, pool_hi - pool_lo, n_local, first_global, o_all,
+                       d_all, color_all, dist_all, normal_all, o, d, color, dist, normal, indices_out, jitter, noise, bg);
+    PERF_LAUNCH_CHECK("perf_draw_train_batch");
+    return PERF_OK;
+}

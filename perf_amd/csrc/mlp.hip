@@ -15,8 +15,11 @@
 // Backward recomputes the forward in registers (only feat is kept from the forward pass), chains
 // dH = W^T dY the same way with transposed weight fragments, and forms the weight gradients
 // dW = dH * H^T (contraction over the 32 samples) through a wave-private LDS transpose.
+#include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 #include "common.hpp"
+#include "grid_device.hpp"
 
 namespace perf {
 
@@ -141,11 +144,25 @@ __device__ __forceinline__ float act_bwd(float y, float g, int act, float shift)
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <typename T16, int NH, int KS>
+// FUSED: encode + MLP in one kernel for small batches (no level-group / XCD pinning is at stake below ~64 k samples): the wave
+// forms the B operand of the first layer IN REGISTERS -- lane (sample c, half h) of k-step s owns the levels 8s + 2i + h,
+// i = 0..3, i.e. it gathers and interpolates eight levels of its sample (encode_pair: the very function the level-major
+// encode kernels use, so the packed pairs are bit-identical) -- and the features never travel through memory, unless the
+// caller wants them (feat_out: the density pass of the sampler keeps them for the gradient pass).
+struct FusedIn {
+    GridParams gp;
+    const uint32_t* table;
+    const float* x01;
+    uint32_t* feat_out;
+};
+struct NoFusedIn {};
+
+template <typename T16, int NH, int KS, bool FUSED>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
                                                       const uint32_t* __restrict__ feat,
                                                       const uint8_t* __restrict__ sel, float* __restrict__ out,
-                                                      int64_t n, const int64_t* __restrict__ n_dev) {
+                                                      int64_t n, const int64_t* __restrict__ n_dev,
+                                                      std::conditional_t<FUSED, FusedIn, NoFusedIn> fz) {
     using L = Layout<NH, KS>;
     const int64_t n_live = live_count(n, n_dev);        // n stays the stride of the level-major features
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -159,13 +176,31 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16
         const int64_t si = tile * kTile + c;
         const bool valid = si < n_live;
         u32x4 b1[KS];
+        if constexpr (FUSED) {
+            const bool smooth = fz.gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+            float x = 0.5f, y = 0.5f, z = 0.5f;
+            if (valid) { x = fz.x01[3 * si]; y = fz.x01[3 * si + 1]; z = fz.x01[3 * si + 2]; }
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int level = 8 * s + 2 * i + h;
-                b1[s][i] = (valid && level < mp.n_levels) ? feat[(int64_t)level * n + si] : 0u;
-            }
+                for (int i = 0; i < 4; ++i) {
+                    const int level = 8 * s + 2 * i + h;
+                    uint32_t pair = 0u;
+                    if (valid && level < mp.n_levels) {
+                        pair = encode_pair<T16>(fz.gp, fz.table, level, x, y, z, smooth);
+                        if (fz.feat_out) fz.feat_out[(int64_t)level * n + si] = pair;
+                    }
+                    b1[s][i] = pair;
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int level = 8 * s + 2 * i + h;
+                    b1[s][i] = (valid && level < mp.n_levels) ? feat[(int64_t)level * n + si] : 0u;
+                }
+        }
         f32x16 acc[2];
         uint32_t mask_unused = 0;
         u32x4 hb[4];
@@ -584,7 +619,22 @@ template <typename T16, int NH, int KS>
 static void launch_fwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t* w, const uint32_t* feat, const uint8_t* sel,
                        float* out, int64_t n, const int64_t* n_dev) {
     constexpr int lds_bytes = Layout<NH, KS>::n_fwd * 1024;
-    mlp_fwd_kernel<T16, NH, KS><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, out, n, n_dev);
+    mlp_fwd_kernel<T16, NH, KS, false><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, out, n, n_dev, NoFusedIn{});
+}
+
+template <typename T16, int NH, int KS>
+static void launch_fused(int blocks, hipStream_t st, MlpParams mp, const uint16_t* w, const uint8_t* sel, float* out, int64_t n,
+                         const int64_t* n_dev, FusedIn fz) {
+    constexpr int lds_bytes = Layout<NH, KS>::n_fwd * 1024;
+    mlp_fwd_kernel<T16, NH, KS, true><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, nullptr, sel, out, n, n_dev, fz);
+}
+
+template <typename T16, typename... Args>
+static void dispatch_fused(int nh, int ks, Args... a) {
+    if (nh == 1 && ks == 1) launch_fused<T16, 1, 1>(a...);
+    else if (nh == 1) launch_fused<T16, 1, 2>(a...);
+    else if (ks == 1) launch_fused<T16, 2, 1>(a...);
+    else launch_fused<T16, 2, 2>(a...);
 }
 
 template <typename T16, int NH, int KS>
@@ -688,14 +738,37 @@ extern "C" int64_t perf_field_infer_scratch_bytes(const perf_grid_desc* grid, in
     return (int64_t)grid->n_levels * n * 4;
 }
 
+// Batches of up to this many rows run encode + MLP as ONE kernel (features in registers); larger ones keep the level-group
+// kernel pinned to XCDs followed by the MLP kernel.  (PERF_FUSED_MAX_SAMPLES overrides, 0 = never.)
+constexpr int64_t kFusedMaxSamples = 65536;
+
 extern "C" int perf_field_infer(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const uint8_t* sel,
                                 const void* table16, const void* w16, float* out, int64_t n, const int64_t* n_dev,
-                                void* scratch, int64_t scratch_bytes, int dtype, void* stream) {
+                                void* scratch, int64_t scratch_bytes, void* feat_out, int dtype, void* stream) {
     PERF_REQUIRE(grid && mlp, "NULL descriptor");
     PERF_REQUIRE(mlp->n_levels == grid->n_levels, "perf_field_infer: the MLP takes %d levels, the grid has %d", (int)mlp->n_levels, (int)grid->n_levels);
     if (n == 0) return PERF_OK;
-    PERF_REQUIRE(scratch && scratch_bytes >= perf_field_infer_scratch_bytes(grid, n), "perf_field_infer: scratch too small");
-    int rc = perf_hashgrid_fwd(grid, x01, table16, scratch, n, n_dev, dtype, stream);
+    static const int64_t fused_max = getenv("PERF_FUSED_MAX_SAMPLES") ? atoll(getenv("PERF_FUSED_MAX_SAMPLES")) : kFusedMaxSamples;
+    if (n <= fused_max && grid->n_levels <= 16) {
+        int nh, ks;
+        int rc = check_mlp(mlp, &nh, &ks);
+        if (rc) return rc;
+        PERF_REQUIRE(x01 && table16 && w16 && out, "NULL pointer");
+        PERF_REQUIRE(dtype == PERF_DTYPE_BF16 || dtype == PERF_DTYPE_FP16, "bad dtype %d", dtype);
+        FusedIn fz;
+        rc = fill_params(grid, &fz.gp);
+        if (rc) return rc;
+        fz.table = (const uint32_t*)table16; fz.x01 = x01; fz.feat_out = (uint32_t*)feat_out;
+        MlpParams mp{mlp->n_levels, mlp->n_out, mlp->out_act, mlp->exp_shift};
+        const int blocks = mlp_blocks(n, nh == 1 ? 4 : 3);
+        if (dtype == PERF_DTYPE_BF16) dispatch_fused<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, sel, out, n, n_dev, fz);
+        else dispatch_fused<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, sel, out, n, n_dev, fz);
+        PERF_LAUNCH_CHECK("perf_field_infer(fused)");
+        return PERF_OK;
+    }
+    void* feat = feat_out ? feat_out : scratch;
+    PERF_REQUIRE(feat_out || (scratch && scratch_bytes >= perf_field_infer_scratch_bytes(grid, n)), "perf_field_infer: scratch too small");
+    int rc = perf_hashgrid_fwd(grid, x01, table16, feat, n, n_dev, dtype, stream);
     if (rc) return rc;
-    return perf_mlp_fwd(mlp, w16, scratch, sel, out, n, n_dev, dtype, stream);
+    return perf_mlp_fwd(mlp, w16, feat, sel, out, n, n_dev, dtype, stream);
 }

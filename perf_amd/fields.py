@@ -109,10 +109,8 @@ class NGPNeRF(nn.Module):
     def density_with_features(self, x01, sel, n_dev=None):
         """Density without gradient plus the level-major encoded features it was computed from -> (sigma [n], feat [L,n,2])."""
         net = self.geo_mlp
-        w16 = net.working_copy()
-        n_net = net.mlp.n_params
-        feat = ops.hashgrid_fwd(net.grid, x01, w16[n_net:], n_dev=n_dev)
-        return ops.mlp_fwd(net.mlp, w16[:n_net], feat, sel, n_dev=n_dev)[:, 0], feat
+        sig, feat = ops.field_infer(net.grid, net.mlp, x01, sel, net.working_copy(), n_dev=n_dev, want_features=True)
+        return sig[:, 0], feat
 
     def rgb_at(self, x01, sel, n_dev=None):
         return field_apply(self.app_mlp, x01, self.app_mlp.params, sel, n_dev)

@@ -311,17 +311,23 @@ def mlp_fwd(mlp: MlpConfig, w16, feat16, sel=None, n_dev=None):
     return out
 
 
-def field_infer(grid: GridConfig, mlp: MlpConfig, x01, sel, w16, n_dev=None):
+FUSED_MAX_SAMPLES = 65536      # perf_field_infer runs encode + MLP as one kernel up to this many rows (16-level grids)
+
+
+def field_infer(grid: GridConfig, mlp: MlpConfig, x01, sel, w16, n_dev=None, want_features=False):
     """act(MLP(encode(x01))) * sel without gradient in one boundary call; w16 = the network's 16-bit working copy
-    [MLP weights | table]."""
+    [MLP weights | table].  want_features: also return the level-major 16-bit features [L, n, 2] the result was computed from
+    (-> (out, feat))."""
     n = x01.shape[0]
     n_net = mlp.n_params
     out = torch.empty(n, mlp.n_output_dims, dtype=torch.float32, device=x01.device)
-    scratch = torch.empty(grid.n_levels * n, dtype=torch.int32, device=x01.device)
+    feat = torch.empty(grid.n_levels, n, 2, dtype=w16.dtype, device=x01.device) if want_features else None
+    fused = n <= FUSED_MAX_SAMPLES and grid.n_levels <= 16
+    scratch = None if (fused or want_features) else torch.empty(grid.n_levels * n, dtype=torch.int32, device=x01.device)
     gd, md = grid.desc(), mlp.desc()
     _call('perf_field_infer', ctypes.byref(gd), ctypes.byref(md), _p(_f32(x01, 'x01')), _p(sel), _p(w16[n_net:]), _p(w16[:n_net]),
-          _p(out), n, _nd(n_dev), _p(scratch), scratch.numel() * 4, dtype_code(w16.dtype), _stream())
-    return out
+          _p(out), n, _nd(n_dev), _p(scratch), scratch.numel() * 4 if scratch is not None else 0, _p(feat), dtype_code(w16.dtype), _stream())
+    return (out, feat) if want_features else out
 
 
 def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True, want_absmax=False, n_dev=None, dw_out=None):
@@ -605,8 +611,10 @@ def composite_bwd(sigmas, t_starts, t_ends, packed, weights, trans, g_weights=No
     R = packed.shape[0]
     S = sigmas.numel()
     dev = sigmas.device
-    ds = torch.zeros(S, dtype=torch.float32, device=dev) if want_dsigma else None
-    dr = torch.zeros(S, 3, dtype=torch.float32, device=dev) if want_drgb else None
+    # (every sample of every ray is written by the kernel: no zero fill; rows beyond the live count of a capacity-sized batch
+    #  stay uninitialised like everywhere else)
+    ds = torch.empty(S, dtype=torch.float32, device=dev) if want_dsigma else None
+    dr = torch.empty(S, 3, dtype=torch.float32, device=dev) if want_drgb else None
     _call('perf_composite_bwd', _p(sigmas), _p(t_starts), _p(t_ends), _p(packed), R, _p(weights), _p(trans),
               _p(g_weights), _p(g_trans), _p(g_alphas), _p(g_opacity), _p(g_distance), _p(g_color), _p(ds), _p(dr), _stream())
     return ds, dr
@@ -649,8 +657,9 @@ _TICKETS = {}
 
 
 def _ticket(device):
-    """A zeroed device int32 per (device, stream) for kernels that elect their last workgroup (left at zero by every call)."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    """A zeroed device int32 per device for kernels that elect their last workgroup (left at zero by every call; the callers
+    are serial on their stream)."""
+    key = str(device)
     t = _TICKETS.get(key)
     if t is None:
         t = torch.zeros(1, dtype=torch.int32, device=device)
@@ -703,6 +712,24 @@ def gather_supervision(indices, o_all=None, d_all=None, color_all=None, dist_all
         out[key] = None if all_ is None else torch.empty(n, width, dtype=torch.float32, device=dev)
     _call('perf_gather_supervision', _p(idx), n, _p(src['o']), _p(src['d']), _p(src['color']), _p(src['dist']), _p(src['normal']),
           _p(out['o']), _p(out['d']), _p(out['color']), _p(out['dist']), _p(out['normal']), _stream())
+    return out
+
+
+def draw_train_batch(seed, counter, pool_lo, pool_hi, n_local, first_global, o_all, d_all, color_all, dist_all, normal_all=None,
+                     want_bg=False, want_indices=False):
+    """One launch: the step's batch indices (uniform over [pool_lo, pool_hi)), the gathered supervision rows and the per-ray
+    uniforms (jitter, noise[, bg]) from the counter-based generator (perf_draw_train_batch).  counter: device int64 [1],
+    advanced by the launch.  -> dict(o, d, color, dist, normal, jitter [n], noise [n,1], bg [n,3] | None, indices | None)."""
+    dev = o_all.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    out = {'o': f(n_local, 3), 'd': f(n_local, 3), 'color': f(n_local, 3), 'dist': f(n_local, 1),
+           'normal': f(n_local, 3) if normal_all is not None else None, 'jitter': f(n_local), 'noise': f(n_local, 1),
+           'bg': f(n_local, 3) if want_bg else None,
+           'indices': torch.empty(n_local, dtype=torch.int64, device=dev) if want_indices else None}
+    _call('perf_draw_train_batch', int(seed) & 0xFFFFFFFFFFFFFFFF, _nd(counter), _p(_ticket(dev)), int(pool_lo), int(pool_hi), int(n_local),
+          int(first_global), _p(_f32(o_all, 'o')), _p(_f32(d_all, 'd')), _p(_f32(color_all, 'color')), _p(_f32(dist_all, 'dist')),
+          _p(normal_all), _p(out['o']), _p(out['d']), _p(out['color']), _p(out['dist']), _p(out['normal']), _p(out['indices']),
+          _p(out['jitter']), _p(out['noise']), _p(out['bg']), _stream())
     return out
 
 

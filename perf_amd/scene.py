@@ -176,6 +176,19 @@ class SupInfoPool:
                                    self.all_sup_distances, self.all_sup_normals)            # one launch instead of five
         return Rays(g['o'], g['d']), g['color'], g['dist'], g['normal']
 
+    def draw_batch(self, batch_size, seed, counter, rand_mode='by_all_pixels', rank=0, world_size=1, want_bg=False):
+        """rand_ray_color_data (sup_info.py:236-259) AND the per-ray uniform draws of a training step (stratified jitter, distance
+        noise, background colour: nerf_renderer.py:152,185,193) in one launch from the counter-based device generator
+        (perf_draw_train_batch).  `counter` (device int64 [1]) numbers the draws and is advanced by the launch; with
+        world_size > 1 every rank draws its slice [rank*b/W, (rank+1)*b/W) of the same global batch (same seed, same counter).
+        -> (Rays, colors, distances, normals, {'jitter', 'noise', 'bg'})."""
+        assert rand_mode in ['by_all_pixels', 'only_first', 'only_last']
+        start, end = (0, len(self)) if rand_mode == 'by_all_pixels' else self._ranges[0 if rand_mode == 'only_first' else -1]
+        per = batch_size // world_size
+        g = ops.draw_train_batch(seed, counter, start, end, per, rank * per, self.all_sup_rays.o, self.all_sup_rays.d, self.all_sup_colors,
+                                 self.all_sup_distances, self.all_sup_normals, want_bg=want_bg)
+        return Rays(g['o'], g['d']), g['color'], g['dist'], g['normal'], {'jitter': g['jitter'], 'noise': g['noise'], 'bg': g['bg']}
+
     def gen_occ_grid(self, res):
         """sup_info.py:304-330 as one splat kernel.  Returns (occ uint8 [res^3], points of occupied cells)."""
         rays_o, rays_d = self.all_sup_rays.collapse()
@@ -345,6 +358,14 @@ class NeRFScene:
         # -> all-gather of the 16-bit working copy (perf_amd/dp.py; needs the fused Adam, the explicit step chains and the
         # fixed-point grid backward); 'allreduce' = one all-reduce of the flat fp32 (or bf16) gradient, Adam everywhere.
         self.dp_mode = 'sharded'
+        # Random draws of the explicit training steps (batch indices, stratified jitter, distance noise, background colour):
+        # True = ONE launch of the counter-based device generator per step (SupInfoPool.draw_batch; seeded from
+        # torch.initial_seed() at first use, so torch.manual_seed controls it; the ranks of a data-parallel job must seed
+        # alike) -- a captured step then holds no torch random op, whose graph replays cost two extra launches each.
+        # False, or an explicit `generator` / `rand` argument: torch.randint / torch.rand as in rounds 1-2.
+        self.device_rng = True
+        self._rng_seed = None
+        self._rng_counter = None
 
     # ---- distributed helpers ---------------------------------------------------------------------
     @staticmethod
@@ -530,6 +551,20 @@ class NeRFScene:
                                                             rank=rank, world_size=world)
         return rays, col, dep, bs, (dist, rank, world)
 
+    def _use_device_rng(self, rand, generator):
+        return self.device_rng and self.fused_steps and generator is None and not rand
+
+    def _draw(self, sup_pool, want_bg):
+        """The step's batch and uniform draws from the device generator -> (rays, colors, depths, global batch, dist_info, rand)."""
+        dist, rank, world = self._dist()
+        if self._rng_counter is None:
+            self._rng_seed = int(torch.initial_seed())
+            self._rng_counter = torch.zeros(1, dtype=torch.int64, device=sup_pool.all_sup_colors.device)
+        bs = self.train_conf.pixel_loss_batch_size
+        rays, col, dep, nrm, rand = sup_pool.draw_batch(bs, self._rng_seed, self._rng_counter, rand_mode=self.pixel_sup_rand_mode,
+                                                        rank=rank, world_size=world, want_bg=want_bg)
+        return rays, col, dep, bs, (dist, rank, world), rand
+
     def _finish_step(self, loss, net, optimizer, dist_info, overlap=None):
         """backward -> [one RCCL all-reduce of the flat gradient] -> Adam.  `overlap` (a callable) is run between the
         launch of the asynchronous all-reduce and the wait for it: the next step's parameter-independent work then
@@ -582,8 +617,11 @@ class NeRFScene:
     def _geo_prefetch(self, sup_pool, rand, generator):
         """Everything of a geometry step that does not depend on the geometry parameters: batch draw, and -- when the
         sampler needs no density pre-pass (early_stop_eps == 0) -- marching, positions and the frozen colour field."""
-        rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
         rand = dict(rand or {})
+        if self._use_device_rng(rand, generator):
+            rays, gt_colors, gt_depths, bs, dist_info, rand = self._draw(sup_pool, want_bg=False)
+        else:
+            rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
         if self.fused_steps and ('jitter' not in rand or 'noise' not in rand):
             # the step's two per-ray draws in one launch; under data parallelism every rank draws the GLOBAL batch's
             # values (same seed on every rank) and keeps its slice, like the index stream: the job then trains on the very
@@ -796,7 +834,10 @@ class NeRFScene:
         there is one), colour field with gradient, colour smooth-L1."""
         tc = self.train_conf
         rand = rand or {}
-        rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
+        if self._use_device_rng(rand, generator):
+            rays, gt_colors, gt_depths, bs, dist_info, rand = self._draw(sup_pool, want_bg=self.renderer.bg_color == 'rand_noise')
+        else:
+            rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
         st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand)
         app = self.nerf.app_mlp
         extra = 1 if dist_info[0] is not None else 0

@@ -393,3 +393,56 @@ def test_reusing_the_sampling_features_changes_nothing(head):
         out[reuse] = (scene.nerf.geo_mlp.params.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone())
     for a, b in zip(out[False], out[True]):
         assert torch.equal(a, b)
+
+
+def test_device_batch_draw(ops):
+    """perf_draw_train_batch: one launch = uniform batch indices + the gathered supervision rows + the per-ray uniforms, from a
+    counter-based generator.  Deterministic in (seed, counter); the counter advances by one per launch; two ranks' slices are
+    the halves of the single-process batch; draws are uniform."""
+    g = torch.Generator().manual_seed(11)
+    n_pool, B = 100000, 8192
+    o = torch.randn(n_pool, 3, generator=g).cuda(); d = torch.randn(n_pool, 3, generator=g).cuda()
+    c = torch.rand(n_pool, 3, generator=g).cuda(); t = torch.rand(n_pool, 1, generator=g).cuda(); nrm = torch.randn(n_pool, 3, generator=g).cuda()
+    counter = torch.zeros(1, dtype=torch.int64, device='cuda')
+    a = ops.draw_train_batch(1234, counter, 0, n_pool, B, 0, o, d, c, t, nrm, want_bg=True, want_indices=True)
+    assert int(counter.item()) == 1
+    idx = a['indices']
+    assert int(idx.min()) >= 0 and int(idx.max()) < n_pool
+    assert torch.equal(a['o'], o[idx]) and torch.equal(a['d'], d[idx]) and torch.equal(a['color'], c[idx])
+    assert torch.equal(a['dist'], t[idx]) and torch.equal(a['normal'], nrm[idx])
+    for k in ('jitter', 'noise', 'bg'):
+        u = a[k].float()
+        assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.02, k
+    assert abs(float(idx.float().mean()) / n_pool - 0.5) < 0.02 and idx.unique().numel() > 0.9 * B * (1 - B / (2 * n_pool))
+    # same (seed, counter) -> same draw; the next counter -> another one
+    counter.zero_()
+    b = ops.draw_train_batch(1234, counter, 0, n_pool, B, 0, o, d, c, t, nrm, want_bg=True, want_indices=True)
+    assert all(torch.equal(a[k], b[k]) for k in ('indices', 'jitter', 'noise', 'bg'))
+    nxt = ops.draw_train_batch(1234, counter, 0, n_pool, B, 0, o, d, c, t, nrm, want_bg=True, want_indices=True)
+    assert not torch.equal(nxt['indices'], a['indices']) and int(counter.item()) == 2
+    other_seed = ops.draw_train_batch(99, torch.zeros(1, dtype=torch.int64, device='cuda'), 0, n_pool, B, 0, o, d, c, t, nrm, want_indices=True)
+    assert not torch.equal(other_seed['indices'], a['indices'])
+    # two ranks: slices of the same global batch
+    halves = []
+    for rank in range(2):
+        cnt = torch.zeros(1, dtype=torch.int64, device='cuda')
+        halves.append(ops.draw_train_batch(1234, cnt, 0, n_pool, B // 2, rank * (B // 2), o, d, c, t, nrm, want_bg=True, want_indices=True))
+    for k in ('indices', 'jitter', 'noise', 'bg', 'o'):
+        assert torch.equal(torch.cat([halves[0][k], halves[1][k]]), a[k]), k
+    # a sub-range of the pool (rand_mode 'only_last')
+    r = ops.draw_train_batch(5, torch.zeros(1, dtype=torch.int64, device='cuda'), 70000, n_pool, 4096, 0, o, d, c, t, want_indices=True)
+    assert int(r['indices'].min()) >= 70000 and int(r['indices'].max()) < n_pool and r['normal'] is None
+
+
+def test_device_rng_episode_graph_replay_equals_eager():
+    """A short episode with the device generator (the default): graph-replayed steps == eager steps, bit for bit (same seed,
+    same counter sequence), and the captured step holds no torch random op."""
+    res = {}
+    for mode in ('eager', 'graph'):
+        scene, pool, rays, dist, rgb = _room_scene(batch=1024)
+        assert scene.device_rng
+        scene.graph_steps = (mode == 'graph')
+        scene.train_one_episode(pool, 12, 8)
+        res[mode] = (scene.nerf.geo_mlp.params.detach().clone(), scene.nerf.app_mlp.params.detach().clone(), int(scene._rng_counter.item()))
+    assert res['eager'][2] == res['graph'][2] == 20
+    assert torch.equal(res['eager'][0], res['graph'][0]) and torch.equal(res['eager'][1], res['graph'][1])
