@@ -49,7 +49,8 @@ MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/fp16 MFMA
 ALGO_BYTES = {'perf_hashgrid_fwd': 16 * 8 * 2 * 2, 'perf_hashgrid_bwd': 2 * 16 * 8 * 2 * 2}
 # what the counters say limits each kernel (profiles/): `bound` names the roofline the fraction is priced
 # against, `limiter` what actually stalls the kernel
-LIMITER = {'perf_hashgrid_fwd': 'L1/TA request rate of 4-byte random gathers (tables are L2/Infinity-Cache resident)',
+LIMITER = {'perf_hashgrid_fwd': 'L1 misses in flight: 35 L1->L2 requests per sample at a 160-180 cycle round trip (tables are L2/Infinity-Cache '
+                                'resident; the tag rate is not the limit: -20 % accesses changed nothing, profiles/r03_fwd_l1_counters.json)',
            'perf_hashgrid_bwd': 'VALU issue (owner test + enqueue per sample visit); no HBM read-modify-write happens',
            'perf_mlp_fwd': 'epilogue VALU + dependency chains', 'perf_mlp_bwd': 'epilogue VALU + LDS transposes'}
 GEO_FWD_FLOP = 2 * (32 * 64 + 64 * 1)
@@ -517,7 +518,7 @@ def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other
 
 # what the counters say bounds the dominant kernels (profiles/r03_*): the encode is bound by the L1's request rate, the
 # grid backward by VALU issue; neither by HBM bandwidth -- `frac` is nevertheless priced against HBM
-BOUND = {'perf_hashgrid_fwd': 'l1-request', 'perf_hashgrid_bwd': 'valu'}
+BOUND = {'perf_hashgrid_fwd': 'l1-miss', 'perf_hashgrid_bwd': 'valu'}
 PMC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json')
 
 

@@ -246,9 +246,9 @@ int perf_mlp_fwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, 
 
 /* Field inference in one boundary call: out [n, n_out] = act(MLP(encode(x01))) * sel, i.e. NGPNeRF.query_density /
  * query_rgb without gradient (modules/fields/ngp_nerf.py:136-162; the no-grad density pass inside
- * OccGridEstimator.sampling and the eval render are this).  Batches of up to 65,536 rows (and grids of <= 16 levels) run as
+ * OccGridEstimator.sampling and the eval render are this).  Batches of up to 4,096 rows (and grids of <= 16 levels) run as
  * ONE fused kernel: every wave encodes its 32 samples straight into the MFMA B-operand registers of the first layer, the
- * features never travel through memory.  Larger batches run perf_hashgrid_fwd + perf_mlp_fwd back to back -- the encode of a
+ * features never travel through memory (measured: from ~16 k rows on the two-kernel path is faster).  Larger batches run perf_hashgrid_fwd + perf_mlp_fwd back to back -- the encode of a
  * large batch is a level-group kernel pinned to XCDs, which a single kernel would have to give up -- with the
  * 16-bit level-major features in `scratch` (perf_field_infer_scratch_bytes(grid, n) bytes, caller owned; may be NULL when
  * feat_out is given or the batch takes the fused kernel).  feat_out (may be NULL): receives the level-major features

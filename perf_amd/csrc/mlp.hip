@@ -739,8 +739,12 @@ extern "C" int64_t perf_field_infer_scratch_bytes(const perf_grid_desc* grid, in
 }
 
 // Batches of up to this many rows run encode + MLP as ONE kernel (features in registers); larger ones keep the level-group
-// kernel pinned to XCDs followed by the MLP kernel.  (PERF_FUSED_MAX_SAMPLES overrides, 0 = never.)
-constexpr int64_t kFusedMaxSamples = 65536;
+// kernel pinned to XCDs followed by the MLP kernel.  (PERF_FUSED_MAX_SAMPLES overrides, 0 = never.)  Measured on MI355X
+// (reference-faithful training episode, tools/train_episode.py): with the 16,384-row head pass fused the geometry step takes
+// 0.2514 ms, unfused 0.2461 ms -- at that size a wave's 64 dependent-address gathers per lane cost more than the second
+// launch saves; 512x1024 frames in 32,768-ray batches (65,536-row heads): 491 fused vs 489-500 frames/s unfused.  The
+// fused kernel is therefore kept for what it cannot lose on: batches of a few thousand points.
+constexpr int64_t kFusedMaxSamples = 4096;
 
 extern "C" int perf_field_infer(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const uint8_t* sel,
                                 const void* table16, const void* w16, float* out, int64_t n, const int64_t* n_dev,

@@ -311,7 +311,9 @@ def mlp_fwd(mlp: MlpConfig, w16, feat16, sel=None, n_dev=None):
     return out
 
 
-FUSED_MAX_SAMPLES = 65536      # perf_field_infer runs encode + MLP as one kernel up to this many rows (16-level grids)
+import os as _os
+# perf_field_infer runs encode + MLP as one kernel up to this many rows (16-level grids); the library reads the same switch
+FUSED_MAX_SAMPLES = int(_os.environ.get('PERF_FUSED_MAX_SAMPLES', '4096'))
 
 
 def field_infer(grid: GridConfig, mlp: MlpConfig, x01, sel, w16, n_dev=None, want_features=False):
@@ -323,6 +325,12 @@ def field_infer(grid: GridConfig, mlp: MlpConfig, x01, sel, w16, n_dev=None, wan
     out = torch.empty(n, mlp.n_output_dims, dtype=torch.float32, device=x01.device)
     feat = torch.empty(grid.n_levels, n, 2, dtype=w16.dtype, device=x01.device) if want_features else None
     fused = n <= FUSED_MAX_SAMPLES and grid.n_levels <= 16
+    if _PROF is not None and not fused:
+        # per-kernel timing (bench.py): the same two kernels the boundary call launches, issued one by one so that each gets
+        # its own event pair
+        feat = hashgrid_fwd(grid, x01, w16[n_net:], n_dev=n_dev)
+        out = mlp_fwd(mlp, w16[:n_net], feat, sel, n_dev=n_dev)
+        return (out, feat) if want_features else out
     scratch = None if (fused or want_features) else torch.empty(grid.n_levels * n, dtype=torch.int32, device=x01.device)
     gd, md = grid.desc(), mlp.desc()
     _call('perf_field_infer', ctypes.byref(gd), ctypes.byref(md), _p(_f32(x01, 'x01')), _p(sel), _p(w16[n_net:]), _p(w16[:n_net]),

@@ -18,9 +18,10 @@ def main():
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     scene = P.make_scene(H, W)
-    out_path = os.path.join(ROOT, 'tests', 'golden', 'psnr_curve.json')
+    out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'tests', 'golden', 'psnr_curve.json')
     res = {'config': {'pano': [H, W], 'batch': BATCH, 'geo_iters': N_GEO, 'app_iters': N_APP, 'marks': list(MARKS),
-                      'torch': torch.__version__}, 'seeds': []}
+                      'geo_marks': list(P.GEO_MARKS), 'torch': torch.__version__}, 'seeds': []}
+
     if os.path.exists(out_path):
         old = json.load(open(out_path))
         if old.get('config') == res['config']:

@@ -12,6 +12,7 @@ import torch
 from oracle import perf_oracle as O
 
 AABB = [-1., -1, -1, 1, 1, 1]
+GEO_MARKS = (30, 100, 300)      # geometry iterations at which the training depth loss is compared (window of 10)
 CONF = dict(init_lr=0.0, peak_lr=1e-2, peak_at=0.2, lr_alpha=1e-2)      # configs/nerf.yaml:36-47
 
 
@@ -50,35 +51,45 @@ def init_params(seed):
 
 
 def run_oracle(scene, geo0, app0, draws, n_geo, n_app, marks, log=None):
-    """-> {'geo_end_depth_err', 'psnr@app<k>' for k in marks}."""
+    """-> {'geo_end_depth_err', 'psnr@app<k>' for k in marks} and the geometry phase's learning curve: 'geo_depth_loss@<k>' (mean
+    training depth loss of iterations k-10..k-1, k in GEO_MARKS: falls by two orders of magnitude while the field grows
+    opaque -- unlike the eval depth error, which the occupancy shell fixes from the first iteration) and
+    'geo_end_opacity' (mean eval opacity after the phase)."""
     o, d, dist, rgb, occ = scene
     geo = geo0.clone().requires_grad_(True); app = app0.clone().requires_grad_(True)
     curve = {}
     mg = torch.zeros_like(geo); vg = torch.zeros_like(geo); ma = torch.zeros_like(app); va = torch.zeros_like(app)
 
     def render_eval():
-        outs_rgb, outs_d = [], []
+        outs_rgb, outs_d, outs_o = [], [], []
         with torch.no_grad():
             for lo in range(0, o.shape[0], 16384):
                 out = O.occ_render(o[lo:lo + 16384], d[lo:lo + 16384], geo, app, occ, AABB, training=False)
-                outs_rgb.append(out['rgb']); outs_d.append(out['distance'])
-        return torch.cat(outs_rgb), torch.cat(outs_d)
+                outs_rgb.append(out['rgb']); outs_d.append(out['distance']); outs_o.append(out['opacities'])
+        return torch.cat(outs_rgb), torch.cat(outs_d), torch.cat(outs_o)
 
     step_g = 0
+    dls = []
     for i in range(n_geo):
         dr = draws[i]
         t0 = (dr['jitter'].numpy() * np.float32(5e-4)).astype(np.float32)
         out = O.occ_render(o[dr['idx']], d[dr['idx']], geo, app, occ, AABB, training=True, t0=t0, bg_color=dr['bg'], dist_noise=dr['noise'])
         if not out['is_valid']:
             continue
-        loss, _, _ = O.geo_step_loss(out, dist[dr['idx']], progress=i / n_app)
+        loss, dl_i, _ = O.geo_step_loss(out, dist[dr['idx']], progress=i / n_app)
+        dls.append(float(dl_i))
         geo.grad = None; loss.backward()
         step_g += 1
         with torch.no_grad():
             p, mg, vg = O.adam_step(geo, geo.grad, mg, vg, step_g, O.lr_schedule(i / n_geo, **CONF)); geo.copy_(p)
         if log and (i + 1) % 50 == 0:
             log(f'geo {i + 1}/{n_geo}')
-    curve['geo_end_depth_err'] = float((render_eval()[1] - dist).abs().mean())
+    ev = render_eval()
+    curve['geo_end_depth_err'] = float((ev[1] - dist).abs().mean())
+    curve['geo_end_opacity'] = float(ev[2].mean())
+    for k in GEO_MARKS:
+        if k <= len(dls):
+            curve[f'geo_depth_loss@{k}'] = float(np.mean(dls[k - 10:k]))
     step_a = 0
     for i in range(n_app):
         dr = draws[n_geo + i]
@@ -121,12 +132,19 @@ def run_hip(scene, geo0, app0, draws, n_geo, n_app, marks, dtype, accum='fixed',
     curve = {}
     opt = sc.make_optimizer(sc.nerf.geo_mlp, 0.0)
     conf = sc.train_conf.geo_optimizer
+    dls = []
     for i in range(n_geo):
         dr = draws[i]; state['idx'] = dr['idx'].cuda()
         sc.update_lr(opt, conf, i / n_geo)
         sc.train_one_step_geo(opt, pool, progress=i / n_app, rand={k: dr[k].cuda() for k in ('jitter', 'bg', 'noise')})
-    ev = sc.render(rays, ['rgb', 'distance'])
+        dls.append(sc.last_losses['depth_loss'])
+    dls = [float(v) for v in torch.stack(dls).cpu()]
+    ev = sc.render(rays, ['rgb', 'distance', 'opacities'])
     curve['geo_end_depth_err'] = float((ev['distance'].cpu() - dist).abs().mean())
+    curve['geo_end_opacity'] = float(ev['opacities'].mean())
+    for k in GEO_MARKS:
+        if k <= len(dls):
+            curve[f'geo_depth_loss@{k}'] = float(np.mean(dls[k - 10:k]))
     sc.set_train()
     opt = sc.make_optimizer(sc.nerf.app_mlp, 0.0)
     for i in range(n_app):

@@ -771,3 +771,34 @@ def test_quarter_wave_ray_teams_equal_full_wave_rays(ops, n_short, max_short):
             assert torch.equal(res['a'][k_][a0:a0 + c], res['b'][k_][b0:b0 + c]), (i, k_)
         for k_ in ('op', 'dist', 'col'):
             assert torch.equal(res['a'][k_][i], res['b'][k_][j]), (i, k_)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('net', ['geo', 'app'])
+def test_fused_field_infer_equals_the_two_kernel_path(dtype, net):
+    """perf_field_infer on a small batch = ONE kernel (encode straight into the first layer's MFMA operand registers); same
+    outputs and, when asked for, the same level-major features as perf_hashgrid_fwd + perf_mlp_fwd, bit for bit."""
+    from perf_amd import ops
+    from perf_amd.grid import GridConfig, MlpConfig
+    cfg = GridConfig()
+    spec = O.geo_spec() if net == 'geo' else O.app_spec()
+    params = O.init_field_params(spec); params[spec.n_net:] *= 1e4
+    w16 = ops.cast_params(params.cuda(), dtype)
+    mlp = MlpConfig(n_levels=16, n_hidden_layers=1, n_output_dims=1, output_activation='Exponential') if net == 'geo' else \
+        MlpConfig(n_levels=16, n_hidden_layers=2, n_output_dims=3, output_activation='Sigmoid')
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 37, 3000, ops.FUSED_MAX_SAMPLES):
+        x = torch.rand(n, 3, generator=g).cuda()
+        sel = (torch.rand(n, generator=g) > 0.1).to(torch.uint8).cuda()
+        out, feat = ops.field_infer(cfg, mlp, x, sel, w16, want_features=True)          # fused (n <= FUSED_MAX_SAMPLES)
+        out_only = ops.field_infer(cfg, mlp, x, sel, w16)
+        ref_feat = ops.hashgrid_fwd(cfg, x, w16[spec.n_net:])
+        ref = ops.mlp_fwd(mlp, w16[:spec.n_net], ref_feat, sel)
+        assert torch.equal(feat, ref_feat) and torch.equal(out, ref) and torch.equal(out_only, ref), n
+    # a device-side count below the capacity: only the live rows are produced
+    n, live = 2048, 777
+    x = torch.rand(n, 3, generator=g).cuda()
+    nd = torch.tensor([live], dtype=torch.int64, device='cuda')
+    out = ops.field_infer(cfg, mlp, x, None, w16, n_dev=nd)
+    ref = ops.mlp_fwd(mlp, w16[:spec.n_net], ops.hashgrid_fwd(cfg, x[:live].contiguous(), w16[spec.n_net:]), None)
+    assert torch.equal(out[:live], ref)
