@@ -50,6 +50,14 @@ extern "C" {
 #define PERF_ACT_SIGMOID 1
 #define PERF_ACT_EXP 2        /* y -> exp(y - exp_shift); backward clamps the exponent at 15 (trunc_exp) */
 
+/* Marching lattice t_k of a ray (all four perf_occ_march_* entry points take one): SINGLE = fl(t0 + fl(k*step)), one rounding
+ * per sample (what oracle/perf_oracle.py defines and rounds 1-2 shipped); REPEATED = t_0 = t0, t_{k+1} = fl(t_k + step), the
+ * lattice of a marcher that advances by `t += dt` as nerfacc's traverse_grids is understood to (the package is absent:
+ * unpinned either way) -- the two differ by O(k ulp) in t_starts / t_ends, and in ray_indices where a midpoint sits on a cell
+ * boundary.  A maintainer who holds nerfacc picks the matching one (NeRFOCCRenderer.lattice). */
+#define PERF_LATTICE_SINGLE 0
+#define PERF_LATTICE_REPEATED 1
+
 #define PERF_INTERP_LINEAR 0
 #define PERF_INTERP_SMOOTHSTEP 1
 
@@ -300,8 +308,8 @@ int64_t perf_occ_mask_words(int32_t max_steps);
  * OccGridEstimator.sampling's `near_plane + u * render_step_size` formed in the kernel instead of by two torch launches. */
 int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
                          int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res,
-                         const float* aabb, float far_plane, float step, int32_t max_steps, uint64_t* masks,
-                         int32_t* counts, void* stream);
+                         const float* aabb, float far_plane, float step, int32_t max_steps, int32_t lattice_mode,
+                         uint64_t* masks, int32_t* counts, void* stream);
 
 /* perf_occ_march_count that also WRITES the first head_k samples of every ray (the head of the two-phase sampler below):
  * rows r*head_k .. r*head_k + min(count, head_k) - 1 of arrays of n_rays*head_k rows get the same ray_indices / t_starts /
@@ -310,7 +318,7 @@ int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* 
  * perf_occ_march_write_points for the head.  head_k in [1, 64]. */
 int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
                               int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
-                              float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
+                              float far_plane, float step, int32_t max_steps, int32_t lattice_mode, uint64_t* masks, int32_t* counts,
                               int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
                               const float* points_aabb6, float* x01, uint8_t* sel, void* stream);
 
@@ -329,7 +337,7 @@ int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t* total, int
 
 /* Pass 2: expand masks into packed samples sorted by ray then t.  packed_info [n_rays,2] =
  * (start,count) int32.  capacity = allocated length of the sample arrays. */
-int perf_occ_march_write(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps,
+int perf_occ_march_write(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps, int32_t lattice_mode,
                          const uint64_t* masks, const int32_t* counts, const int32_t* offsets,
                          int64_t capacity, int64_t* ray_indices, float* t_starts, float* t_ends,
                          int32_t* packed_info, void* stream);
@@ -339,7 +347,8 @@ int perf_occ_march_write(const float* t0, float t0_scale, float t0_base, int64_t
  * aabb6: host pointer, {min xyz, max xyz}.  rank_lo: the samples of rank [rank_lo, rank_lo + counts[r]) of every ray are
  * written (rank = position among the ray's samples in t order; 0 with the march counts = everything) -- the two-phase
  * sampler below writes the first K samples of every ray first and the rest of the surviving rays later. */
-int perf_occ_march_write_points(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
+int perf_occ_march_write_points(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps, int32_t lattice_mode,
+                                const uint64_t* masks,
                                 const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                 float* t_starts, float* t_ends, int32_t* packed_info, const float* rays_o,
                                 const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, int32_t rank_lo,

@@ -371,6 +371,14 @@ def lattice_t(t0: np.ndarray, k: np.ndarray, step) -> np.ndarray:
     return (t0 + (k.astype(F32) * F32(step)).astype(F32)).astype(F32)
 
 
+def lattice_table_repeated(t0: np.ndarray, n: int, step) -> np.ndarray:
+    """The alternative lattice of a marcher that advances by repeated addition: T[r, 0] = t0[r], T[r, k+1] = fl(T[r, k] + step),
+    k < n -- np.add.accumulate is strictly sequential, every partial sum rounded to fp32.  [R, n + 1]."""
+    t0 = np.asarray(t0, F32).reshape(-1)
+    seq = np.concatenate([t0[:, None], np.full((t0.shape[0], n), F32(step), F32)], axis=1)
+    return np.add.accumulate(seq, axis=1, dtype=F32)
+
+
 def occ_cell_index(p: np.ndarray, aabb: np.ndarray, res: int) -> np.ndarray:
     """x-major linear cell index (nerf.py:154-156) of points p, clamped to the grid."""
     aabb = aabb.astype(F32)
@@ -380,7 +388,7 @@ def occ_cell_index(p: np.ndarray, aabb: np.ndarray, res: int) -> np.ndarray:
     return c[:, 0] * res * res + c[:, 1] * res + c[:, 2]
 
 
-def occ_march(o, d, binaries, aabb, near, far, step, t0=None, max_steps=None):
+def occ_march(o, d, binaries, aabb, near, far, step, t0=None, max_steps=None, lattice='single'):
     """Sampling of fixed-step intervals whose midpoint lies in an occupied cell (A.3).
 
     o,d [R,3] f32; binaries bool [res,res,res] (x-major); aabb [6]; t0 [R] = lattice origin
@@ -402,10 +410,14 @@ def occ_march(o, d, binaries, aabb, near, far, step, t0=None, max_steps=None):
     hi = np.fmin(tmax, F32(far))
     K = int(max_steps) if max_steps is not None else int(math.ceil((float(far) - float(near)) / float(step))) + 1
     keep_cols = []
+    table = lattice_table_repeated(t0, K, step) if lattice == 'repeated' else None      # (lattice='repeated': see the header)
     for k0 in range(0, K, 256):
         ks = np.arange(k0, min(K, k0 + 256))
-        ta = lattice_t(t0[:, None], ks[None, :], step)
-        tb = lattice_t(t0[:, None], ks[None, :] + 1, step)
+        if table is not None:
+            ta, tb = table[:, ks], table[:, ks + 1]
+        else:
+            ta = lattice_t(t0[:, None], ks[None, :], step)
+            tb = lattice_t(t0[:, None], ks[None, :] + 1, step)
         mid = ((ta + tb).astype(F32) * F32(0.5)).astype(F32)
         ok = (mid >= lo[:, None]) & (mid <= hi[:, None])
         rr, cc = np.nonzero(ok)

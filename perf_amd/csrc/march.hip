@@ -17,6 +17,7 @@ struct MarchParams {
     float hi[3];
     float far_plane, step;
     int32_t res, max_steps, mask_words;
+    int32_t lattice_mode;    // PERF_LATTICE_*
     int32_t use_coarse;      // 1: skip 64-interval chunks whose midpoint lies in an empty DILATED block (kCoarseBlock^3 cells)
     float chunk_cells[3];    // fine cells a 64-interval chunk spans per unit of |d| along each axis (64 step res / extent)
 };
@@ -49,7 +50,38 @@ __global__ __launch_bounds__(256) void coarse_build_kernel(const uint32_t* __res
     if (any) atomicOr(&coarse[b >> 5], 1u << (b & 31));
 }
 
-__device__ __forceinline__ float lattice(float t0, int k, float step) { return add_rn(t0, mul_rn((float)k, step)); }
+__device__ __forceinline__ float lattice_single(float t0, int k, float step) { return add_rn(t0, mul_rn((float)k, step)); }
+
+// PERF_LATTICE_REPEATED: t_0 = t0, t_{j+1} = fl(t_j + step) -- the lattice a marcher that ADVANCES by `t += dt` produces
+// (nerfacc's traverse_grids, as far as it can be read without the package: oracle/perf_oracle.py header).  Evaluated for an
+// arbitrary k without k additions: inside one binade consecutive floats have consecutive bit patterns, and from the second
+// in-binade addition on every addition moves by the same number of ulps (round-to-nearest-even of step / ulp: a tie lands
+// on an even mantissa once and then stays even) -- so the walk jumps binade by binade with two real additions each.
+__device__ __forceinline__ float lattice_repeated(float t0, int k, float step) {
+    float t = t0;
+    int left = k;
+    while (left > 0) {
+        const float t1 = add_rn(t, step);
+        if (--left == 0) return t1;
+        if ((__float_as_uint(t1) >> 23) != (__float_as_uint(t) >> 23)) { t = t1; continue; }   // entered a binade: one more real step first
+        const float t2 = add_rn(t1, step);
+        if (--left == 0) return t2;
+        const uint32_t b1 = __float_as_uint(t1), b2 = __float_as_uint(t2);
+        if ((b2 >> 23) != (b1 >> 23)) { t = t2; continue; }
+        const uint32_t d = b2 - b1;                              // ulps per step from here to the end of the binade
+        if (d == 0u) return t2;                                  // (step below half an ulp: the lattice is stuck)
+        const uint32_t top = (b2 & 0xff800000u) + 0x00800000u;   // first bit pattern of the next binade
+        uint32_t j = (top - 1u - b2) / d;                        // further additions that stay inside
+        if (j > (uint32_t)left) j = (uint32_t)left;
+        t = __uint_as_float(b2 + j * d);
+        left -= (int)j;
+    }
+    return t;
+}
+
+__device__ __forceinline__ float lattice(float t0, int k, float step, int mode) {
+    return mode == PERF_LATTICE_REPEATED ? lattice_repeated(t0, k, step) : lattice_single(t0, k, step);
+}
 
 // Lattice origin of ray r.  t0s == NULL: t0_base (the near plane).  t0_scale == 0: t0s[r] as given.  Otherwise t0s holds the
 // stratified draw u in [0,1) and the origin is fl(u * t0_scale) (+ t0_base when that is not 0) -- the two torch ops of
@@ -122,9 +154,9 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         bool maybe = false;
         if (q < mp.mask_words) {
             const int k0 = q * 64;
-            maybe = !(lattice(t0, k0, mp.step) > hi) && !(lattice(t0, k0 + 64, mp.step) < lo);
+            maybe = !(lattice(t0, k0, mp.step, mp.lattice_mode) > hi) && !(lattice(t0, k0 + 64, mp.step, mp.lattice_mode) < lo);
             if (maybe && use_coarse) {
-                const float tc = lattice(t0, k0 + 32, mp.step);
+                const float tc = lattice(t0, k0 + 32, mp.step, mp.lattice_mode);
                 const int cr = res >> kCoarseShift;
                 int cb[3];
 #pragma unroll
@@ -152,7 +184,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                     todo &= todo - 1;
                     const int k = qs[u] * 64 + lane;
                     if (k < mp.max_steps) {
-                        const float ta = lattice(t0, k, mp.step), tb = lattice(t0, k + 1, mp.step);
+                        const float ta = lattice(t0, k, mp.step, mp.lattice_mode), tb = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(ta, mp.step) : lattice_single(t0, k + 1, mp.step);
                         const float mid = mul_rn(add_rn(ta, tb), 0.5f);
                         if (mid >= lo && mid <= hi) {
                             int cell[3];
@@ -184,7 +216,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                         if (rank < ho.K) {
                             const int64_t pos = r * ho.K + rank;
                             const int k = qs[u] * 64 + lane;
-                            const float a = lattice(t0, k, mp.step), b = lattice(t0, k + 1, mp.step);
+                            const float a = lattice(t0, k, mp.step, mp.lattice_mode), b = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, mp.step) : lattice_single(t0, k + 1, mp.step);
                             ho.ts[pos] = a; ho.te[pos] = b; ho.ri[pos] = r;
                             sample_point_store(ro + 3 * r, rd + 3 * r, a, b, ho.bb, ho.x01, ho.sel, pos);
                         }
@@ -215,7 +247,7 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                                                           float* __restrict__ te, int32_t* __restrict__ packed,
                                                           const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                           Aabb bb, float* __restrict__ x01, uint8_t* __restrict__ sel,
-                                                          int32_t rank_lo, float t0_scale, float t0_base) {
+                                                          int32_t rank_lo, float t0_scale, float t0_base, int lattice_mode) {
     // Writes the samples of rank [rank_lo, rank_lo + counts[r]) of every ray (rank = position among the ray's samples in t
     // order) to offsets[r]...: rank_lo = 0 and counts = the march counts is the plain expansion; the two-phase sampler
     // writes the first K samples of every ray first and the rest of the rays that are still alive later.
@@ -258,7 +290,7 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                     const int64_t pos = run + __popcll(m & below);
                     if (pos >= off && pos < end) {
                         const int k = qq * 64 + bit;
-                        const float a = lattice(t0, k, step), b = lattice(t0, k + 1, step);
+                        const float a = lattice(t0, k, step, lattice_mode), b = lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, step) : lattice_single(t0, k + 1, step);
                         ts[pos] = a;
                         te[pos] = b;
                         ray_indices[pos] = r;
@@ -433,7 +465,9 @@ extern "C" int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint
 
 static int march_count_launch(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base, int64_t n_rays,
                               const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb, float far_plane,
-                              float step, int32_t max_steps, uint64_t* masks, int32_t* counts, const HeadOut* head, void* stream) {
+                              float step, int32_t max_steps, int32_t lattice_mode, uint64_t* masks, int32_t* counts, const HeadOut* head,
+                              void* stream) {
+    PERF_REQUIRE(lattice_mode == PERF_LATTICE_SINGLE || lattice_mode == PERF_LATTICE_REPEATED, "bad lattice mode %d", (int)lattice_mode);
     PERF_REQUIRE(n_rays >= 0 && res > 0 && res <= 1024 && max_steps > 0 && step > 0.f, "perf_occ_march_count: bad arguments");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(rays_o && rays_d && occ_bits && aabb && masks && counts, "NULL pointer");
@@ -442,7 +476,7 @@ static int march_count_launch(const float* rays_o, const float* rays_d, const fl
         mp.lo[a] = aabb[a]; mp.hi[a] = aabb[3 + a];
         mp.inv_ext[a] = 1.0f / (aabb[3 + a] - aabb[a]);
     }
-    mp.far_plane = far_plane; mp.step = step; mp.res = res; mp.max_steps = max_steps;
+    mp.far_plane = far_plane; mp.step = step; mp.res = res; mp.max_steps = max_steps; mp.lattice_mode = lattice_mode;
     mp.mask_words = chunk_words(max_steps);
     for (int a = 0; a < 3; ++a) mp.chunk_cells[a] = 64.0f * step * mp.inv_ext[a] * (float)res;
     mp.use_coarse = (occ_coarse != nullptr && (res % 8) == 0) ? 1 : 0;      // (+ the per-ray span test in the kernel)
@@ -458,16 +492,16 @@ static int march_count_launch(const float* rays_o, const float* rays_d, const fl
 
 extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
                                     int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res,
-                                    const float* aabb, float far_plane, float step, int32_t max_steps, uint64_t* masks,
-                                    int32_t* counts, void* stream) {
-    return march_count_launch(rays_o, rays_d, t0, t0_scale, t0_base, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps, masks, counts,
-                              nullptr, stream);
+                                    const float* aabb, float far_plane, float step, int32_t max_steps, int32_t lattice_mode,
+                                    uint64_t* masks, int32_t* counts, void* stream) {
+    return march_count_launch(rays_o, rays_d, t0, t0_scale, t0_base, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps,
+                              lattice_mode, masks, counts, nullptr, stream);
 }
 
 extern "C" int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
                                          int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
-                                         float far_plane, float step, int32_t max_steps, uint64_t* masks, int32_t* counts,
-                                         int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
+                                         float far_plane, float step, int32_t max_steps, int32_t lattice_mode, uint64_t* masks,
+                                         int32_t* counts, int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
                                          const float* points_aabb6, float* x01, uint8_t* sel, void* stream) {
     PERF_REQUIRE(head_k >= 1 && head_k <= 64, "perf_occ_march_count_head: head_k must be in [1, 64]");
     PERF_REQUIRE(n_rays == 0 || (ray_indices && t_starts && t_ends && packed_info && points_aabb6 && x01 && sel), "NULL pointer");
@@ -476,7 +510,7 @@ extern "C" int perf_occ_march_count_head(const float* rays_o, const float* rays_
     ho.K = head_k; ho.ri = ray_indices; ho.ts = t_starts; ho.te = t_ends; ho.packed = packed_info; ho.x01 = x01; ho.sel = sel;
     if (n_rays > 0) for (int a = 0; a < 3; ++a) { ho.bb.lo[a] = points_aabb6[a]; ho.bb.hi[a] = points_aabb6[3 + a]; }
     return march_count_launch(rays_o, rays_d, t0, t0_scale, t0_base, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps,
-                              masks, counts, &ho, stream);
+                              lattice_mode, masks, counts, &ho, stream);
 }
 
 extern "C" int64_t perf_scan_workspace_bytes(int64_t n) { return (div_up(n > 0 ? n : 1, kScanBlock) + 1) * (int64_t)sizeof(int64_t); }
@@ -508,7 +542,8 @@ extern "C" int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t*
     return PERF_OK;
 }
 
-extern "C" int perf_occ_march_write(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
+extern "C" int perf_occ_march_write(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps,
+                                    int32_t lattice_mode, const uint64_t* masks,
                                     const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                     float* t_starts, float* t_ends, int32_t* packed_info, void* stream) {
     PERF_REQUIRE(n_rays >= 0 && max_steps > 0 && capacity >= 0, "perf_occ_march_write: bad arguments");
@@ -517,12 +552,13 @@ extern "C" int perf_occ_march_write(const float* t0, float t0_scale, float t0_ba
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends), "NULL sample arrays");
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0, t0_scale, t0_base);
+                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0, t0_scale, t0_base, (int)lattice_mode);
     PERF_LAUNCH_CHECK("perf_occ_march_write");
     return PERF_OK;
 }
 
-extern "C" int perf_occ_march_write_points(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps, const uint64_t* masks,
+extern "C" int perf_occ_march_write_points(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps,
+                                           int32_t lattice_mode, const uint64_t* masks,
                                            const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                            float* t_starts, float* t_ends, int32_t* packed_info, const float* rays_o,
                                            const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, int32_t rank_lo,
@@ -535,7 +571,7 @@ extern "C" int perf_occ_march_write_points(const float* t0, float t0_scale, floa
     for (int k = 0; k < 3; ++k) { bb.lo[k] = aabb6[k]; bb.hi[k] = aabb6[3 + k]; }
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo, t0_scale, t0_base);
+                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo, t0_scale, t0_base, (int)lattice_mode);
     PERF_LAUNCH_CHECK("perf_occ_march_write_points");
     return PERF_OK;
 }

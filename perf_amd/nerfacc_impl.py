@@ -173,7 +173,7 @@ class OccGridEstimator(nn.Module):
     def sampling_ex(self, rays_o, rays_d, sigma_fn=None, near_plane=0.0, far_plane=1e10, render_step_size=1e-3,
                     early_stop_eps=1e-4, alpha_thre=0.0, stratified=False, cone_angle=0.0, alpha_fn=None,
                     t_min=None, t_max=None, jitter=None, max_steps=None, capacity=None, points_aabb=None,
-                    sigma_points_fn=None, head_samples=None):
+                    sigma_points_fn=None, head_samples=None, lattice='single'):
         """sampling() returning a Samples record: ray_indices, t_starts, t_ends, packed (packed_info), sig (sigmas of the
         kept samples from the visibility pass, or None), x01 / sel (sample positions normalised to points_aabb, or None),
         n_dev (device int64 [1]: number of live samples when the arrays are capacity-sized, else None), n_marched_dev.
@@ -188,7 +188,8 @@ class OccGridEstimator(nn.Module):
           trained scene terminates a ray after a sample or two); same samples, same sigmas as the one-phase path.
           n_marched_dev then counts the samples whose density was evaluated.
         sigma_points_fn may return (sigmas, feat): the level-major encoded features of its density pass are then compacted
-          along with the samples (Samples.feat) so that a gradient pass on the kept samples need not encode them again."""
+          along with the samples (Samples.feat) so that a gradient pass on the kept samples need not encode them again.
+        lattice: 'single' (t_k = fl(t0 + fl(k step)), the default) or 'repeated' (t_{k+1} = fl(t_k + step)): PERF_LATTICE_*."""
         if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
             raise NotImplementedError('PeRF samples with cone_angle=0 and a sigma_fn (nerf_renderer.py:145-155)')
         if alpha_thre != 0.0:
@@ -225,9 +226,9 @@ class OccGridEstimator(nn.Module):
                 raise ValueError('sync-free sampling with a visibility pass needs points_aabb and sigma_points_fn')
             if compacts and head_samples:
                 return self._sample_two_phase(sm, rays_o, rays_d, t0, float(far_plane), float(render_step_size), max_steps,
-                                              int(capacity), points_aabb, sigma_points_fn, early_stop_eps, int(head_samples))
+                                              int(capacity), points_aabb, sigma_points_fn, early_stop_eps, int(head_samples), lattice)
             out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size),
-                                max_steps, capacity=capacity, occ_coarse=self.occ_coarse(), points_aabb=points_aabb)
+                                max_steps, capacity=capacity, occ_coarse=self.occ_coarse(), points_aabb=points_aabb, lattice=lattice)
             ri, ts, te, packed, total = out[:5]
             x01, sel = out[5:] if points_aabb is not None else (None, None)
             sm.n_marched_dev = total
@@ -241,7 +242,7 @@ class OccGridEstimator(nn.Module):
             sm.n_dev = total
         else:
             out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size), max_steps,
-                                occ_coarse=self.occ_coarse(), points_aabb=None if compacts else points_aabb)
+                                occ_coarse=self.occ_coarse(), points_aabb=None if compacts else points_aabb, lattice=lattice)
             ri, ts, te, packed = out[:4]
             x01, sel = out[4:] if (points_aabb is not None and not compacts) else (None, None)
             sig = None
@@ -266,7 +267,7 @@ class OccGridEstimator(nn.Module):
     STRIDED_HEAD_MAX = 16          # heads of up to this many samples are written by the counting pass, K rows per ray
 
     def _sample_two_phase(self, sm, rays_o, rays_d, t0, far_plane, step, max_steps, capacity, points_aabb, sigma_points_fn,
-                          early_stop_eps, K):
+                          early_stop_eps, K, lattice='single'):
         """March once; density + visibility on the first K samples of every ray; then density on the remaining samples of
         the rays that are still alive; final visibility + compaction over (head, tail).  All counts stay on the device."""
         R = rays_o.shape[0]
@@ -274,15 +275,17 @@ class OccGridEstimator(nn.Module):
         #      samples leave padding rows with selector 0: their density is evaluated and ignored)
         if K <= self.STRIDED_HEAD_MAX:
             masks, counts, (ri_h, ts_h, te_h, pk_h, x_h, s_h) = ops.occ_march_count_head(
-                rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step, max_steps, self.occ_coarse(), K, points_aabb)
+                rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step, max_steps, self.occ_coarse(), K, points_aabb,
+                lattice=lattice)
             total_h = None                      # R * K rows, a host constant: folded into the tail scan's biased total below
             sig_h, feat_h = _sig_feat(sigma_points_fn(x_h, s_h, None))
         else:       # a long head: packed rows (count clamp, scan over the rays, write pass) instead of K rows per ray
             masks, counts = ops.occ_march_count(rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step,
-                                                max_steps, self.occ_coarse())
+                                                max_steps, self.occ_coarse(), lattice=lattice)
             ch = ops.head_tail_counts(counts, K)
             oh, total_h = ops.exclusive_scan_i32(ch)
-            ri_h, ts_h, te_h, pk_h, x_h, s_h = ops.occ_march_write(t0, masks, ch, oh, R * K, step, max_steps, rays_o, rays_d, points_aabb)
+            ri_h, ts_h, te_h, pk_h, x_h, s_h = ops.occ_march_write(t0, masks, ch, oh, R * K, step, max_steps, rays_o, rays_d, points_aabb,
+                                                                   lattice=lattice)
             sig_h, feat_h = _sig_feat(sigma_points_fn(x_h, s_h, total_h))
         # ---- head decision and the tail counts (rank [K, count) of the rays whose whole head survived) in one launch
         kept_h, ct = ops.visibility_count(sig_h, ts_h, te_h, pk_h, early_stop_eps, march_counts=counts, head_samples=K)
@@ -292,7 +295,7 @@ class OccGridEstimator(nn.Module):
             ot, total_t = ops.exclusive_scan_i32(ct)
             n_evaluated = total_h + total_t
         ri_t, ts_t, te_t, pk_t, x_t, s_t = ops.occ_march_write(t0, masks, ct, ot, capacity, step, max_steps, rays_o, rays_d, points_aabb,
-                                                               rank_lo=K)
+                                                               rank_lo=K, lattice=lattice)
         sig_t, feat_t = _sig_feat(sigma_points_fn(x_t, s_t, total_t))
         # ---- final decision and compaction over both sample sets
         head = (sig_h, ts_h, te_h, pk_h, x_h, s_h); tail = (sig_t, ts_t, te_t, pk_t, x_t, s_t)

@@ -420,7 +420,7 @@ def _origin(t0):
     return _p(_f32(t0, 't0')), 0.0, 0.0
 
 
-def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse=None):
+def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse=None, lattice='single'):
     """Pass 1 of the marching: -> (keep masks, per-ray counts int32 [R]).  t0: see _origin."""
     R = rays_o.shape[0]
     dev = rays_o.device
@@ -428,11 +428,13 @@ def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, ma
     masks = torch.empty(max(R * mw, 1), dtype=torch.int64, device=dev)
     counts = torch.empty(R, dtype=torch.int32, device=dev)
     _call('perf_occ_march_count', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), *_origin(t0), R,
-          _p(occ_bits), _p(occ_coarse), int(res), _aabb6(aabb), float(far_plane), float(step), int(max_steps), _p(masks), _p(counts), _stream())
+          _p(occ_bits), _p(occ_coarse), int(res), _aabb6(aabb), float(far_plane), float(step), int(max_steps), _lib.LATTICE[lattice],
+          _p(masks), _p(counts), _stream())
     return masks, counts
 
 
-def occ_march_count_head(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse, head_k, points_aabb):
+def occ_march_count_head(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse, head_k, points_aabb,
+                         lattice='single'):
     """occ_march_count that also writes the first head_k samples of every ray to rows r*head_k.. of R*head_k-row arrays
     (padding rows have sel = 0) -> (masks, counts, (ray_indices, t_starts, t_ends, packed_info, x01, sel))."""
     R = rays_o.shape[0]
@@ -448,12 +450,13 @@ def occ_march_count_head(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, ste
     x01 = torch.empty(S, 3, dtype=torch.float32, device=dev)
     sel = torch.empty(S, dtype=torch.uint8, device=dev)
     _call('perf_occ_march_count_head', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), *_origin(t0), R,
-          _p(occ_bits), _p(occ_coarse), int(res), _aabb6(aabb), float(far_plane), float(step), int(max_steps), _p(masks), _p(counts),
-          int(head_k), _p(ri), _p(ts), _p(te), _p(packed), _aabb6(points_aabb), _p(x01), _p(sel), _stream())
+          _p(occ_bits), _p(occ_coarse), int(res), _aabb6(aabb), float(far_plane), float(step), int(max_steps), _lib.LATTICE[lattice],
+          _p(masks), _p(counts), int(head_k), _p(ri), _p(ts), _p(te), _p(packed), _aabb6(points_aabb), _p(x01), _p(sel), _stream())
     return masks, counts, (ri, ts, te, packed, x01, sel)
 
 
-def occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o=None, rays_d=None, points_aabb=None, rank_lo=0):
+def occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o=None, rays_d=None, points_aabb=None, rank_lo=0,
+                    lattice='single'):
     """Pass 2: expand the masks into S-row sample arrays -> (ray_indices, t_starts, t_ends, packed_info[, x01, sel]).
     counts / offsets: how many samples of every ray to write, starting at rank rank_lo, and where."""
     R = counts.shape[0]
@@ -465,27 +468,27 @@ def occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o=None,
     if points_aabb is not None:
         x01 = torch.empty(S, 3, dtype=torch.float32, device=dev)
         sel = torch.empty(S, dtype=torch.uint8, device=dev)
-        _call('perf_occ_march_write_points', *_origin(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
+        _call('perf_occ_march_write_points', *_origin(t0), R, float(step), int(max_steps), _lib.LATTICE[lattice], _p(masks), _p(counts), _p(offsets), S,
               _p(ri), _p(ts), _p(te), _p(packed), _p(rays_o), _p(rays_d), _aabb6(points_aabb), _p(x01), _p(sel), int(rank_lo), _stream())
         return ri, ts, te, packed, x01, sel
     if rank_lo != 0:
         raise _lib.PerfError('rank_lo needs points_aabb (perf_occ_march_write_points)')
-    _call('perf_occ_march_write', *_origin(t0), R, float(step), int(max_steps), _p(masks), _p(counts), _p(offsets), S,
+    _call('perf_occ_march_write', *_origin(t0), R, float(step), int(max_steps), _lib.LATTICE[lattice], _p(masks), _p(counts), _p(offsets), S,
           _p(ri), _p(ts), _p(te), _p(packed), _stream())
     return ri, ts, te, packed
 
 
 def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, capacity=None, occ_coarse=None,
-              points_aabb=None):
+              points_aabb=None, lattice='single'):
     """Returns (ray_indices i64 [S], t_starts, t_ends f32 [S], packed_info i32 [R,2]).
     capacity=None reads the total back (one host sync, like the reference's boolean indexing);
     an int capacity keeps the call sync-free and returns arrays of that length plus `total` on device.
     points_aabb (6 floats): also return the sample positions (x01 [S,3], sel [S]) normalised to that box, written by
     the same kernel that writes the samples (appended to the result)."""
-    masks, counts = occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse)
+    masks, counts = occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse, lattice=lattice)
     offsets, total = exclusive_scan_i32(counts)
     S = int(total.item()) if capacity is None else int(capacity)
-    out = occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o, rays_d, points_aabb)
+    out = occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o, rays_d, points_aabb, lattice=lattice)
     if capacity is None:
         return out
     return out[:4] + (total,) + out[4:]

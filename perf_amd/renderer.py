@@ -58,6 +58,9 @@ class NeRFOCCRenderer(nn.Module):
         # a ray (the first sample of a ray is always kept; the second is dropped iff the first made the ray opaque) and the
         # fastest on a trained scene (512x1024 frames/s: K=2 1140, 3 1070, 4 1010, 6 880; untrained scenes do not care)
         self.head_samples = 2
+        # marching lattice: 'single' (one rounding per sample: the oracle's definition) or 'repeated' (t += step, as a marcher that
+        # advances by repeated addition produces; include/perf_hip.h PERF_LATTICE_*) -- for maintainers who can compare with nerfacc
+        self.lattice = 'single'
 
     # The render is cut in two stages so that a data-parallel trainer can overlap the gradient all-reduce of step k
     # with everything of step k+1 that does not depend on the parameters being updated (scene.py).
@@ -81,7 +84,7 @@ class NeRFOCCRenderer(nn.Module):
             rays_o, rays_d, sigma_points_fn=sigma_points_fn, near_plane=self.near_plane, far_plane=self.far_plane,
             render_step_size=self.render_step_size, early_stop_eps=self.early_stop_eps, stratified=nerf.training,
             cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'), max_steps=self.max_steps, capacity=self.sample_capacity,
-            points_aabb=nerf._aabb_host, head_samples=self.head_samples)
+            points_aabb=nerf._aabb_host, head_samples=self.head_samples, lattice=self.lattice)
         if sm.n_dev is None and sm.ray_indices.numel() <= 0:
             return None
         x01, sel = sm.x01, sm.sel

@@ -376,3 +376,42 @@ def test_dense_pose_sampler_in_a_worker_process_equals_the_in_line_call():
     t0 = time.perf_counter()
     again = PS.DenseTravelPoseSampler.start(s, 180)
     assert again.done() and torch.equal(again.result().sample_poses, ref.sample_poses) and time.perf_counter() - t0 < 0.05
+
+
+def test_repeated_addition_lattice_closed_form():
+    """The marching kernels evaluate the repeated-addition lattice t_{k+1} = fl(t_k + step) for an arbitrary k in closed form
+    (perf_amd/csrc/march.hip:lattice_repeated: per binade two real additions, then a constant number of ulps per step).  The
+    algorithm, restated here in numpy, equals the oracle's sequential accumulation for every k -- ties (dyadic steps) included."""
+    F = np.float32
+
+    def bits(x):
+        return int(np.array([x], F).view(np.uint32)[0])
+
+    def closed_form(t0, k, step):
+        t, left = F(t0), k
+        while left > 0:
+            t1 = F(t + step); left -= 1
+            if left == 0:
+                return t1
+            if (bits(t1) >> 23) != (bits(t) >> 23):
+                t = t1; continue
+            t2 = F(t1 + step); left -= 1
+            if left == 0:
+                return t2
+            b1, b2 = bits(t1), bits(t2)
+            if (b2 >> 23) != (b1 >> 23):
+                t = t2; continue
+            d = b2 - b1
+            if d == 0:
+                return t2
+            j = min(((b2 & 0xff800000) + 0x00800000 - 1 - b2) // d, left)
+            t = np.array([b2 + j * d], np.uint32).view(F)[0]; left -= j
+        return t
+
+    rng = np.random.RandomState(0)
+    for step in (F(5e-4), F(0.99 / 128), F(1 / 3.), F(0.001953125), F(3e-4)):
+        for t0 in list((rng.rand(4) * step).astype(F)) + [F(0), F(1e-9)]:
+            K = 3100
+            table = O.lattice_table_repeated(np.array([t0], F), K, step)[0]
+            for k in list(range(0, 24)) + list(rng.randint(0, K + 1, 40)) + [K]:
+                assert closed_form(t0, int(k), step) == table[k], (step, t0, k)

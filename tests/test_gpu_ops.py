@@ -802,3 +802,61 @@ def test_fused_field_infer_equals_the_two_kernel_path(dtype, net):
     out = ops.field_infer(cfg, mlp, x, None, w16, n_dev=nd)
     ref = ops.mlp_fwd(mlp, w16[:spec.n_net], ops.hashgrid_fwd(cfg, x[:live].contiguous(), w16[spec.n_net:]), None)
     assert torch.equal(out[:live], ref)
+
+
+@pytest.mark.parametrize('step', [5e-4, 2e-3])
+def test_occ_march_repeated_addition_lattice_bit_exact(ops, step):
+    """PERF_LATTICE_REPEATED (t_0 = t0, t_{k+1} = fl(t_k + step): the lattice of a marcher that advances by `t += dt`): the
+    kernels evaluate t_k in closed form per binade; the oracle accumulates sequentially (np.add.accumulate in fp32).  Samples,
+    interval ends and ray bookkeeping equal bit for bit -- plain and in-kernel origins, with and without the skip grid, the
+    head written by the counting pass included -- and the lattice really differs from the single-rounding one."""
+    o, d, dist, rgb, occ = _room(24, 48, 64)
+    o = o + torch.tensor([0.2, -0.1, 0.05])
+    o[:5] = torch.tensor([3.0, 0.0, 0.0])
+    R = o.shape[0]
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    far, near = 1.5, 0.0
+    max_steps = int(math.ceil((far - near) / step)) + 1
+    g = torch.Generator().manual_seed(5)
+    u = torch.rand(R, generator=g)
+    t0 = (u * step)
+    binaries = occ.reshape(64, 64, 64).bool()
+    ri, ts, te, packed = O.occ_march(o.numpy(), d.numpy(), binaries.numpy(), aabb, near, far, step, t0.numpy(), max_steps, lattice='repeated')
+    ri1, ts1, te1, _ = O.occ_march(o.numpy(), d.numpy(), binaries.numpy(), aabb, near, far, step, t0.numpy(), max_steps)
+    assert ri.size > 1000 and (ts.size != ts1.size or not np.array_equal(ts, ts1))          # a different lattice indeed
+    bits = ops.occ_pack_bits(occ.cuda())
+    coarse = ops.occ_build_coarse(bits, 64)
+    for origin in (t0.cuda(), (u.cuda(), step, near)):
+        for cz in (None, coarse):
+            gri, gts, gte, gpacked = ops.occ_march(o.cuda(), d.cuda(), origin, bits, 64, aabb, far, step, max_steps, occ_coarse=cz,
+                                                   lattice='repeated')
+            assert np.array_equal(gri.cpu().numpy(), ri) and np.array_equal(gpacked.cpu().numpy(), packed)
+            assert np.array_equal(gts.cpu().numpy(), ts) and np.array_equal(gte.cpu().numpy(), te)
+    K = 4
+    m2, c2, (ri2, ts2, te2, pk2, x2, s2) = ops.occ_march_count_head(o.cuda(), d.cuda(), t0.cuda(), bits, 64, list(aabb), far, step, max_steps,
+                                                                    coarse, K, list(aabb), lattice='repeated')
+    assert np.array_equal(c2.cpu().numpy(), packed[:, 1])
+    for r in np.nonzero(packed[:, 1] > 0)[0][:50]:
+        n = min(int(packed[r, 1]), K)
+        assert np.array_equal(ts2[r * K:r * K + n].cpu().numpy(), ts[packed[r, 0]:packed[r, 0] + n])
+        assert np.array_equal(te2[r * K:r * K + n].cpu().numpy(), te[packed[r, 0]:packed[r, 0] + n])
+
+
+def test_renderer_with_the_repeated_lattice_sync_free_equals_synced():
+    """NeRFOCCRenderer.lattice = 'repeated' through the whole sampler: the sync-free two-phase path (device-side counts) and the
+    host-synced path produce the same samples and pixels, as they do on the default lattice."""
+    from perf_amd import synthetic
+    from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
+    torch.manual_seed(0)
+    scene = NeRFScene(dtype='fp16')
+    rays = gen_pano_rays(torch.eye(4), 32, 64)
+    dist, rgb = synthetic.room(rays.d)
+    pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, dist)
+    scene.set_train(); scene.prepare_occupancy(pool); scene.set_eval()
+    scene.renderer.lattice = 'repeated'
+    a = scene.render(rays, ['rgb', 'distance'], sync_free=True)
+    b = scene.render(rays, ['rgb', 'distance'], sync_free=False)
+    assert torch.equal(a['rgb'], b['rgb']) and torch.equal(a['distance'], b['distance'])
+    scene.renderer.lattice = 'single'
+    c = scene.render(rays, ['distance'], sync_free=True)
+    assert not torch.equal(a['distance'], c['distance'])                         # (the lattices differ in the last bits of t)
