@@ -288,6 +288,10 @@ struct TileParams {
     int32_t use_work;
     int32_t raw_out;                       // fixed point: the gradient table receives the int32 field pairs themselves (see perf_hashgrid_bwd)
     uint32_t atomic_levels;                // bit l: level l is too large for LDS owners (see hashgrid_bwd_atomic_kernel)
+    int32_t bin_of[PERF_MAX_LEVELS];       // >=0: first bin of the level's tiles in the sorted records (see tile_sort_kernel)
+    int32_t n_bins;
+    int32_t exp_mode;                      // dev switches of the sorted owners (PERF_BWD_EXP)
+    int32_t run_merge;                     // single-tile dense levels: a thread sums runs of samples in one cell in registers
     uint32_t work[kMaxWork];
 };
 
@@ -295,10 +299,15 @@ constexpr int kQueueCap = 448;             // per-wave match queue (entries): <1
 constexpr int64_t kDbgBytes = 4096 * 8;
 constexpr int64_t kMaxCodedSamples = (int64_t)1 << 28;
 
-static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
+// `sorted`: the multi-tile levels' owners walk pre-sorted records instead of every sample's code (tile_sort_kernel) and
+// single-tile levels merge runs in registers, which changes what a workgroup costs -- and with it the replica counts.
+static void plan_tiles(const GridParams& gp, bool fixed, bool sorted, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
     int nb = 0;
     int64_t ws = 0;
     tp->atomic_levels = 0u;
+    static const char* rep_env = getenv("PERF_BWD_REPLICAS");      // dev: "r1,r4,r16" replicas of dense levels of 1 / <=4 / <=16 tiles
+    int rs[3] = {8, sorted ? 4 : 3, 2};
+    if (rep_env) (void)sscanf(rep_env, "%d,%d,%d", &rs[0], &rs[1], &rs[2]);
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->tiles_of[l] = 0; tp->replicas_of[l] = 1; tp->ws_off[l] = 0;
         if (l >= gp.n_levels) continue;
@@ -311,7 +320,7 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
         // hashed tile (coded) 0.36-0.39 ms; dense tile streaming ALL samples: 1 tile 2.4 ms, 4 tiles 0.88 ms, 8 tiles 0.68 ms
         // (fp32 mode is bound by ds_add_f32 lane-serialisation instead: equal corner-update counts, r = 16 / nt)
         int r = 1;
-        if (!gp.hashed[l]) r = fixed ? ((nt == 1) ? 8 : (nt <= 4 ? 3 : (nt <= 16 ? 2 : 1))) : kMaxReplicas / nt;
+        if (!gp.hashed[l]) r = fixed ? ((nt == 1) ? rs[0] : (nt <= 4 ? rs[1] : (nt <= 16 ? rs[2] : 1))) : kMaxReplicas / nt;
         if (r < 1) r = 1;
         if (r > kMaxReplicas) r = kMaxReplicas;
         tp->tiles_of[l] = nt; tp->replicas_of[l] = r;
@@ -530,16 +539,69 @@ __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, con
 // at full lane occupancy; positions and gradients are gathered for queued samples only (about 22 % of them), and the
 // gather of one batch is issued one drain ahead of its use.
 constexpr int kCodeSamplesPerBlock = 256;
+constexpr int kCodeChunksPerBlock = 4;      // a workgroup of the pre-pass takes 4 x 256 samples (fewer histogram flushes)
+constexpr int kMaxBins = 4096;
+
+// ---- sorted records ---------------------------------------------------------------------------------------------
+// With codes, every owner of a level still LOOKS at every sample (16 owners x 12 levels x 1 M codes: two thirds of the
+// owners' instructions were tests and queue upkeep).  The sorted variant turns the codes into per-tile record lists
+// first: a record = sample << 4 | the (y,z) combinations of the sample that touch the tile; an owner then walks only its
+// own list (about 23 % of the level's samples at 16 tiles), coalesced, at full lane occupancy, with nothing to test.
+// Counting sort in two passes over the codes: the pre-pass histograms records per (level, tile) = bin; tile_sort_kernel
+// reserves, per workgroup of 1024 samples and bin, a contiguous range of the bin with one returning atomic and writes its
+// records there through an LDS staging buffer (coalesced runs).  Order inside a bin is not deterministic -- the
+// fixed-point fields are integer sums, so the gradient is; the fp32 mode was order dependent before.
+//
+// code -> candidates: (tile, combination) pairs; a tile's record carries every combination that names the tile and is
+// emitted by the first candidate naming it.  Hashed: 4 candidates (byte c = tile of combination c).  Dense: 8 (byte c =
+// tile of the x0 corner, bit 7: the x1 corner sits in the next tile; 0x7f: no tile).
+template <bool DENSE, typename F>
+__device__ __forceinline__ void for_each_record(const uint32_t code, const uint32_t tmask, F&& emit) {
+    constexpr int K = DENSE ? 8 : 4;
+    uint32_t tile[K];
+    bool valid[K];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t b = (code >> (8 * c)) & 0xffu;
+        if (DENSE) {
+            tile[2 * c] = b & 0x7fu; valid[2 * c] = b != 0x7fu;
+            tile[2 * c + 1] = ((b & 0x7fu) + 1u) & tmask; valid[2 * c + 1] = (b & 0x80u) != 0u;
+        } else {
+            tile[c] = b; valid[c] = true;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        uint32_t cm = 0u;
+        bool first = valid[k];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool same = valid[j] && tile[j] == tile[k];
+            if (same) cm |= 1u << (DENSE ? (j >> 1) : j);
+            if (same && j < k) first = false;
+        }
+        if (first) emit(k, tile[k], cm);
+    }
+}
+
 __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
                                                          const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
-                                                         uint32_t* __restrict__ escape, int64_t n,
+                                                         uint32_t* __restrict__ escape, uint32_t* __restrict__ hist, int64_t n,
                                                          const int64_t* __restrict__ n_dev) {
     const int64_t n_live = live_count(n, n_dev);            // n: capacity = stride of dfeat / codes; n_live: samples present
     __shared__ uint32_t esc_block;
+    __shared__ uint32_t lhist[kMaxBins];
+    if (hist) {
+        for (int b = threadIdx.x; b < tp.n_bins; b += 256) lhist[b] = 0u;
+    }
+    for (int chunk = 0; chunk < kCodeChunksPerBlock; ++chunk) {
+    __syncthreads();
     if (threadIdx.x == 0) esc_block = 0u;
     __syncthreads();
     uint32_t esc = 0u;                  // bit l: level l must take the generic owners (see below)
-    const int64_t i0 = (int64_t)blockIdx.x * kCodeSamplesPerBlock;
+    const int64_t word = (int64_t)blockIdx.x * kCodeChunksPerBlock + chunk;
+    if (word * kCodeSamplesPerBlock >= n) break;            // (uniform)
+    const int64_t i0 = word * kCodeSamplesPerBlock;
     for (int64_t i = i0 + threadIdx.x; i < n_live && i < i0 + kCodeSamplesPerBlock; i += 256) {
         const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
         for (int l = 0; l < gp.n_levels; ++l) {
@@ -577,11 +639,106 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
                 const float2 g = dfeat[(int64_t)l * n + i];
                 if (!(g.x == 0.f && g.y == 0.f)) esc |= 1u << l;
             }
+            if (hist && tp.bin_of[l] >= 0) {
+                const int bin0 = tp.bin_of[l];
+                if (gp.hashed[l]) for_each_record<false>(code, 0u, [&](int, uint32_t t, uint32_t) { atomicAdd(&lhist[bin0 + (int)t], 1u); });
+                else for_each_record<true>(code, (uint32_t)tp.tiles_of[l] - 1u, [&](int, uint32_t t, uint32_t) { atomicAdd(&lhist[bin0 + (int)t], 1u); });
+            }
         }
     }
     if (esc) atomicOr(&esc_block, esc);
     __syncthreads();
-    if (threadIdx.x == 0) escape[blockIdx.x] = esc_block;       // every word is written: no zero-fill needed
+    if (threadIdx.x == 0) escape[word] = esc_block;             // every word is written: no zero-fill needed
+    }
+    if (hist) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < tp.n_bins; b += 256) { const uint32_t v = lhist[b]; if (v) atomicAdd(&hist[b], v); }
+    }
+}
+
+// sum of v over the workgroup (every thread gets it); `red` = one word per wave
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* red) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t s = 0u;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
+constexpr int kSortSamples = 1024;          // samples (= threads) per workgroup of the sort
+constexpr int kSortMaxRecords = 8;          // records per sample and level (dense worst case; hashed: 4)
+
+// grid (ceil(n / 1024), coded levels): codes of one level's 1024 samples -> records, appended to the level's bins
+__global__ __launch_bounds__(kSortSamples) void tile_sort_kernel(TileParams tp, int hashed_mask, const uint32_t* __restrict__ codes,
+                                                                const uint32_t* __restrict__ hist, uint32_t* __restrict__ fill,
+                                                                uint32_t* __restrict__ records, int64_t n,
+                                                                const int64_t* __restrict__ n_dev) {
+    const int64_t n_live = live_count(n, n_dev);
+    const int64_t i = (int64_t)blockIdx.x * kSortSamples + threadIdx.x;
+    if ((int64_t)blockIdx.x * kSortSamples >= n_live) return;
+    int l = 0;
+    while (tp.code_slot[l] != (int)blockIdx.y) ++l;
+    const int bin0 = tp.bin_of[l], nt = tp.tiles_of[l];
+    if (bin0 < 0) return;
+    const bool hashed = (hashed_mask >> l) & 1;
+    __shared__ uint32_t cnt[256], lstart[256], gbase[256], red[kSortSamples / 64];
+    extern __shared__ uint32_t stage[];         // records [kSortSamples * kSortMaxRecords], then their destinations
+    uint32_t* dst = stage + kSortSamples * kSortMaxRecords;
+    uint32_t part = 0u;                          // records of all bins in front of this level's
+    for (int b = threadIdx.x; b < bin0; b += kSortSamples) part += hist[b];
+    const uint32_t level_base = block_sum_u32(part, red);
+    if (threadIdx.x < 256) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t r_tile[kSortMaxRecords], r_cm[kSortMaxRecords], r_pos[kSortMaxRecords];     // by candidate (static indices)
+#pragma unroll
+    for (int k = 0; k < kSortMaxRecords; ++k) { r_tile[k] = 0u; r_cm[k] = 0u; r_pos[k] = 0u; }
+    if (i < n_live) {
+        const uint32_t code = codes[(int64_t)blockIdx.y * tp.n_pad + i];
+        auto emit = [&](int k, uint32_t t, uint32_t cm) { r_tile[k] = t; r_cm[k] = cm; r_pos[k] = atomicAdd(&cnt[t], 1u); };
+        if (hashed) for_each_record<false>(code, 0u, emit);
+        else for_each_record<true>(code, (uint32_t)nt - 1u, emit);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                     // exclusive scans over the level's (<= 255) bins: local counts and bin sizes
+        uint32_t c[4], h[4], cs = 0u, hs = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = (int)threadIdx.x * 4 + k;
+            c[k] = b < nt ? cnt[b] : 0u; h[k] = b < nt ? hist[bin0 + b] : 0u;
+            cs += c[k]; hs += h[k];
+        }
+        uint32_t ci = cs, hi = hs;              // inclusive over lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t a = __shfl_up(ci, off), bb = __shfl_up(hi, off);
+            if ((int)threadIdx.x >= off) { ci += a; hi += bb; }
+        }
+        uint32_t ce = ci - cs, he = hi - hs;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = (int)threadIdx.x * 4 + k;
+            if (b < nt) {
+                lstart[b] = ce;
+                gbase[b] = level_base + he + (c[k] ? atomicAdd(&fill[bin0 + b], c[k]) : 0u);
+            }
+            ce += c[k]; he += h[k];
+        }
+        if (threadIdx.x == 63) red[0] = ci;     // records of this workgroup
+    }
+    __syncthreads();
+    const uint32_t total = red[0];
+#pragma unroll
+    for (int k = 0; k < kSortMaxRecords; ++k)
+        if (r_cm[k]) {
+            const uint32_t s = lstart[r_tile[k]] + r_pos[k];
+            stage[s] = ((uint32_t)i << 4) | r_cm[k];
+            dst[s] = gbase[r_tile[k]] + r_pos[k];
+        }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < total; s += kSortSamples) records[dst[s]] = stage[s];
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -709,11 +866,140 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
 #undef PERF_WAIT_BATCH
 }
 
+// Sorted variant of the coded owners: the tile's records (tile_sort_kernel) are walked coalesced, 4 per thread and step,
+// software-pipelined three deep -- while the 4 records of step k are applied, the positions / gradients of step k+1 are
+// being gathered and the records of step k+2 loaded (16 loads in flight per lane; the compiler's own wait counts are
+// right for this static pattern).  Replica r of R takes the r-th slice of the list.
+template <bool FIXED, bool DENSE, int U = 4>
+__device__ __forceinline__ void bwd_stream_sorted(const BwdCtx& cx, float* lds_tile, const uint32_t* __restrict__ recs,
+                                                  const uint32_t count, const float* __restrict__ x01,
+                                                  const float2* __restrict__ g_l, int rep, int R, const int exp_mode = 0) {
+    const uint32_t lo = (uint32_t)(((uint64_t)count * (uint32_t)rep) / (uint32_t)R);
+    const uint32_t hi = (uint32_t)(((uint64_t)count * (uint32_t)(rep + 1)) / (uint32_t)R);
+    constexpr uint32_t kStep = U * kBwdThreads;
+    uint32_t eA[U], eB[U];
+    float xB[U], yB[U], zB[U];
+    float2 gB[U];
+    auto load = [&](uint32_t base, uint32_t (&e)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = base + (uint32_t)u * kBwdThreads + threadIdx.x;
+            e[u] = (j < hi && j >= base) ? recs[j] : 0u;        // (0: sample 0, no combination -- gathered, not applied)
+        }
+    };
+    auto gather = [&](const uint32_t (&e)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = e[u] >> 4;
+            if (exp_mode & 2) {     // dev: no gathers
+                xB[u] = (float)(i & 1023u) * (1.0f / 1024.0f); yB[u] = (float)((i >> 10) & 1023u) * (1.0f / 1024.0f); zB[u] = (float)(i >> 20) * (1.0f / 256.0f);
+                gB[u] = make_float2(1e-3f, -1e-3f);
+                continue;
+            }
+            const float* xp = x01 + 3 * (size_t)i;
+            xB[u] = xp[0]; yB[u] = xp[1]; zB[u] = xp[2];
+            gB[u] = g_l[i];
+        }
+    };
+    if (hi <= lo) return;
+    load(lo, eB);
+    load(lo + kStep, eA);
+    gather(eB);
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): nothing in flight at loop entry (keeps the compiler's wait counts in the loop exact)
+    for (uint32_t base = lo; base < hi && base >= lo; base += kStep) {
+        uint32_t eC[U];
+        float xC[U], yC[U], zC[U];
+        float2 gC[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { eC[u] = eB[u]; xC[u] = xB[u]; yC[u] = yB[u]; zC[u] = zB[u]; gC[u] = gB[u]; eB[u] = eA[u]; }
+        gather(eB);
+        load(base + 2u * kStep, eA);
+        if (exp_mode & 1) {         // dev: no apply
+            float d = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) d += xC[u] + yC[u] + zC[u] + gC[u].x + gC[u].y;
+            if (d == 123.456f) lds_tile[threadIdx.x] = d;
+            continue;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t cm = eC[u] & 15u;
+            if (cm) {
+                const float px = grid_pos(xC[u], cx.scale), py = grid_pos(yC[u], cx.scale), pz = grid_pos(zC[u], cx.scale);
+                const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+                const uint32_t gx = (uint32_t)(int32_t)flx;
+                if (DENSE)
+                    apply_pairs_dense<FIXED>(cx, lds_tile, gC[u], gx, px - flx, py - fly, pz - flz,
+                                             (uint32_t)(int32_t)fly * cx.res, (uint32_t)(int32_t)flz * cx.r2, cm);
+                else if (gx < (uint32_t)(kTileEntries - 1))      // (else: zero gradient, see tile_codes_kernel)
+                    apply_pairs<FIXED>(cx, lds_tile, gC[u], gx, px - flx, py - fly, pz - flz,
+                                       (uint32_t)(int32_t)fly * kPrimeY, (uint32_t)(int32_t)flz * kPrimeZ, cm);
+            }
+        }
+    }
+}
+
+// Single-tile dense levels (the coarsest ones: a cell is several sample spacings wide): a thread walks consecutive
+// samples of a ray, so it sums a RUN of samples that share a cell in registers -- 8 packed corner sums -- and touches LDS
+// only when the cell changes.  At res 16 / 23 that is a fifth / a quarter of the LDS atomics, which is what these
+// owners were bound by (the lanes of a wave pile up on the few cells a scene populates).  Fixed point: same integers,
+// same sums; fp32: a different (shorter) summation order.
+template <bool FIXED>
+struct RunAcc {
+    uint32_t base;              // index of the run's (0,0,0) corner; 0xffffffff: empty
+    long long v[8];             // FIXED: packed field pairs; else two floats bit-cast
+};
+
+template <bool FIXED>
+__device__ __forceinline__ void run_flush(const BwdCtx& cx, float* lds_tile, RunAcc<FIXED>& r) {
+    if (r.base == 0xffffffffu) return;
+    unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t idx = r.base + (uint32_t)(k & 1) + ((k >> 1) & 1 ? cx.res : 0u) + ((k >> 2) ? cx.r2 : 0u);
+        if (idx >= cx.size) idx = idx % cx.size;
+        if (FIXED) {
+            if (r.v[k] != 0ll) atomicAdd(&lds64[idx], (unsigned long long)r.v[k]);
+        } else {
+            const float a = __int_as_float((int)(uint32_t)(unsigned long long)r.v[k]), b = __int_as_float((int)(uint32_t)((unsigned long long)r.v[k] >> 32));
+            unsafeAtomicAdd(&lds_tile[2 * idx], a); unsafeAtomicAdd(&lds_tile[2 * idx + 1], b);
+        }
+    }
+}
+
+template <bool FIXED>
+__device__ __forceinline__ void run_apply(const BwdCtx& cx, float* lds_tile, RunAcc<FIXED>& r, const float2 g, const float x,
+                                          const float y, const float z) {
+    const float px = grid_pos(x, cx.scale), py = grid_pos(y, cx.scale), pz = grid_pos(z, cx.scale);
+    const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+    float fx = px - flx, fy = py - fly, fz = pz - flz;
+    const uint32_t base = (uint32_t)(int32_t)flx + (uint32_t)(int32_t)fly * cx.res + (uint32_t)(int32_t)flz * cx.r2;
+    if (cx.smooth) { fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz); }
+    const bool fresh = base != r.base;
+    if (fresh) { run_flush<FIXED>(cx, lds_tile, r); r.base = base; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
+        const float w = ((bx ? fx : 1.0f - fx) * (by ? fy : 1.0f - fy)) * (bz ? fz : 1.0f - fz);        // association of bwd_apply
+        if (FIXED) {
+            const long long lo = (long long)__float2int_rn(w * g.x * cx.to_fixed);
+            const long long hi = (long long)__float2int_rn(w * g.y * cx.to_fixed);
+            const long long v = (hi << 32) + lo;
+            r.v[k] = fresh ? v : r.v[k] + v;
+        } else {
+            const float a = w * g.x, b = w * g.y;
+            const float pa = fresh ? 0.f : __int_as_float((int)(uint32_t)(unsigned long long)r.v[k]);
+            const float pb = fresh ? 0.f : __int_as_float((int)(uint32_t)((unsigned long long)r.v[k] >> 32));
+            r.v[k] = (long long)(((unsigned long long)(uint32_t)__float_as_int(pb + b) << 32) | (unsigned long long)(uint32_t)__float_as_int(pa + a));
+        }
+    }
+}
+
 // Streaming loop: a thread owns 4 consecutive samples per iteration -- 3 x 16 B of positions + 2 x 16 B of
 // gradients, all 16-byte loads -- and the next group is in flight while the current one is applied.
 template <bool FIXED, bool HASHED>
 __device__ __forceinline__ void bwd_stream(const BwdCtx& cx, float* lds_tile, const float* __restrict__ x01,
-                                           const float2* __restrict__ g_l, int64_t n, int rep, int R) {
+                                           const float2* __restrict__ g_l, int64_t n, int rep, int R, const bool run_merge = false) {
     constexpr int kGroup = 4;
     const int64_t n_full = n / kGroup;
     const float4* x4 = reinterpret_cast<const float4*>(x01);
@@ -734,6 +1020,23 @@ __device__ __forceinline__ void bwd_stream(const BwdCtx& cx, float* lds_tile, co
             if (jj < mine) { const int64_t grp = t_lo + jj; xa = x4[3 * grp]; xb = x4[3 * grp + 1]; xc = x4[3 * grp + 2]; ga = g4[2 * grp]; gb = g4[2 * grp + 1]; }
         };
         fetch(j);
+        if (run_merge && cx.n_tiles == 1u) {
+            RunAcc<FIXED> run;
+            run.base = 0xffffffffu;
+            for (int64_t it = 0; it < len; ++it) {
+                const float4 cxa = xa, cxb = xb, cxc = xc, cga = ga, cgb = gb;
+                const bool live = j < mine;
+                j = (j + 1 == len) ? 0 : j + 1;
+                if (it + 1 < len) fetch(j);
+                if (live) {
+                    if (!(cga.x == 0.f && cga.y == 0.f)) run_apply<FIXED>(cx, lds_tile, run, make_float2(cga.x, cga.y), cxa.x, cxa.y, cxa.z);
+                    if (!(cga.z == 0.f && cga.w == 0.f)) run_apply<FIXED>(cx, lds_tile, run, make_float2(cga.z, cga.w), cxa.w, cxb.x, cxb.y);
+                    if (!(cgb.x == 0.f && cgb.y == 0.f)) run_apply<FIXED>(cx, lds_tile, run, make_float2(cgb.x, cgb.y), cxb.z, cxb.w, cxc.x);
+                    if (!(cgb.z == 0.f && cgb.w == 0.f)) run_apply<FIXED>(cx, lds_tile, run, make_float2(cgb.z, cgb.w), cxc.y, cxc.z, cxc.w);
+                }
+            }
+            run_flush<FIXED>(cx, lds_tile, run);
+        } else
         for (int64_t it = 0; it < len; ++it) {
             const float4 cxa = xa, cxb = xb, cxc = xc, cga = ga, cgb = gb;
             const bool live = j < mine;
@@ -791,7 +1094,9 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    const int32_t* __restrict__ shifts_in,
                                                                    int32_t* __restrict__ shifts_ws,
                                                                    const uint32_t* __restrict__ codes,
-                                                                   const uint32_t* __restrict__ escape, int64_t n,
+                                                                   const uint32_t* __restrict__ escape,
+                                                                   const uint32_t* __restrict__ hist,
+                                                                   const uint32_t* __restrict__ records, int64_t n,
                                                                    const int64_t* __restrict__ n_dev) {
     const int64_t n_live = live_count(n, n_dev);            // samples present; n stays the stride of dfeat / codes
     extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats (+ the wave queues)
@@ -844,10 +1149,23 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         coded = esc_any == 0u;
     }
     uint32_t* queue = reinterpret_cast<uint32_t*>(lds_tile + 2 * kTileEntries) + (threadIdx.x >> 6) * kQueueCap;
-    if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
+    if (coded && records && tp.bin_of[l] >= 0) {           // sorted records: this tile's list is [start, start + hist[bin])
+        __shared__ uint32_t red[kBwdThreads / 64];
+        const int bin = tp.bin_of[l] + (int)t;
+        uint32_t part = 0u;
+        for (int b2 = threadIdx.x; b2 < bin; b2 += kBwdThreads) part += hist[b2];
+        const uint32_t start = block_sum_u32(part, red);
+        const int em = tp.exp_mode & 3, eu = (tp.exp_mode >> 2) & 3;
+        if (!hashed) bwd_stream_sorted<FIXED, true>(cx, lds_tile, records + start, hist[bin], x01, g_l, rep, R, em);
+        else if (eu == 0) bwd_stream_sorted<FIXED, false, 4>(cx, lds_tile, records + start, hist[bin], x01, g_l, rep, R, em);
+        else if (eu == 1) bwd_stream_sorted<FIXED, false, 1>(cx, lds_tile, records + start, hist[bin], x01, g_l, rep, R, em);
+        else if (eu == 2) bwd_stream_sorted<FIXED, false, 2>(cx, lds_tile, records + start, hist[bin], x01, g_l, rep, R, em);
+        else bwd_stream_sorted<FIXED, false, 8>(cx, lds_tile, records + start, hist[bin], x01, g_l, rep, R, em);
+    }
+    else if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (coded) bwd_stream_codes<FIXED, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n_live, rep, R);
-    else bwd_stream<FIXED, false>(cx, lds_tile, x01, g_l, n_live, rep, R);
+    else bwd_stream<FIXED, false>(cx, lds_tile, x01, g_l, n_live, rep, R, tp.run_merge != 0);
     __syncthreads();
     int32_t field_max = 0;
     // ---- write back: local slot j of tile t is entry e(j)
@@ -1351,16 +1669,59 @@ static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
 
 constexpr int64_t kShiftBytes = 256;        // per-level shifts the owners leave for the replica reduction
 
+// bins of the sorted records (one per tile of every coded level; plan_codes ran before); returns the worst-case number of
+// records, or 0 when the batch does not take the sorted owners (small batches: two more launches than they save;
+// PERF_BWD_SORT=0 / PERF_BWD_SORT_MIN=<samples> are dev switches)
+static int64_t plan_bins(const GridParams& gp, int64_t n, TileParams* tp) {
+    for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp->bin_of[l] = -1;
+    tp->n_bins = 0;
+    const char* e = getenv("PERF_BWD_SORT");
+    const char* m = getenv("PERF_BWD_SORT_MIN");
+    const int64_t n_min = m ? atoll(m) : 131072;
+    if ((e && atoi(e) == 0) || n < n_min || n >= kMaxCodedSamples) return 0;
+    int bins = 0;
+    int64_t recs = 0;
+    for (int l = 0; l < gp.n_levels; ++l)
+        if (tp->code_slot[l] >= 0) { bins += tp->tiles_of[l]; recs += n * (gp.hashed[l] ? 4 : kSortMaxRecords); }
+    if (bins == 0 || bins > kMaxBins || recs >= ((int64_t)1 << 32)) return 0;
+    bins = 0;
+    for (int l = 0; l < gp.n_levels; ++l)
+        if (tp->code_slot[l] >= 0) { tp->bin_of[l] = bins; bins += tp->tiles_of[l]; }
+    tp->n_bins = bins;
+    return recs;
+}
+
+static bool run_merge_enabled() { const char* e = getenv("PERF_BWD_RUNS"); return !(e && atoi(e) == 0); }
+
+// replica slabs: the largest of the plans a call may pick (fp32 / fixed point, sorted or not)
+static int64_t max_slab_entries(const GridParams& gp) {
+    int64_t best = 0;
+    for (int k = 0; k < 4; ++k) { TileParams t; int nb; int64_t w; plan_tiles(gp, (k & 1) != 0, (k & 2) != 0, &t, &nb, &w); if (w > best) best = w; }
+    return best;
+}
+
+struct BwdLayout { int64_t shifts_at, dbg_at, codes_at, esc_at, bins_at, recs_at, end; };
+
+static BwdLayout bwd_layout(const GridParams& gp, int64_t n, int slots, int64_t n_pad, int n_bins, int64_t recs) {
+    BwdLayout L;
+    L.shifts_at = (max_slab_entries(gp) * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
+    L.dbg_at = L.shifts_at + kShiftBytes;
+    L.codes_at = L.dbg_at + kDbgBytes;
+    L.esc_at = L.codes_at + (int64_t)slots * n_pad * 4;
+    L.bins_at = (L.esc_at + (slots ? div_up(n, kCodeSamplesPerBlock) * 4 : 0) + 15) & ~(int64_t)15;
+    L.recs_at = L.bins_at + 2 * (int64_t)n_bins * 4;
+    L.end = L.recs_at + recs * 4;
+    return L;
+}
+
 extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n) {
     GridParams gp;
     if (fill_params(grid, &gp)) return -1;
     TileParams tp; int nb; int64_t ws;
-    int64_t ws2;
-    plan_tiles(gp, false, &tp, &nb, &ws);
-    plan_tiles(gp, true, &tp, &nb, &ws2);
+    plan_tiles(gp, true, false, &tp, &nb, &ws);
     const int slots = plan_codes(gp, n, &tp);
-    return (ws > ws2 ? ws : ws2) * (int64_t)sizeof(float2) + 16 + kShiftBytes + kDbgBytes + (int64_t)slots * tp.n_pad * 4 +
-           (slots ? div_up(n, kCodeSamplesPerBlock) * 4 : 0);
+    const int64_t recs = plan_bins(gp, n, &tp);
+    return bwd_layout(gp, n, slots, tp.n_pad, tp.n_bins, recs).end + 16;
 }
 
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
@@ -1378,34 +1739,65 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     TileParams tp;
     int n_blocks = 0;
     int64_t ws_entries = 0;
-    plan_tiles(gp, fixed, &tp, &n_blocks, &ws_entries);
+    plan_tiles(gp, fixed, false, &tp, &n_blocks, &ws_entries);
+    static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
+    // workspace layout: [replica slabs (largest plan)][shifts][debug slots][tile codes][escape words][bin counters][records]
+    int slots = plan_codes(gp, n, &tp);
+    int64_t recs = plan_bins(gp, n, &tp);
+    BwdLayout L = bwd_layout(gp, n, slots, tp.n_pad, tp.n_bins, recs);
+    const bool aligned_ws = (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    const bool use_codes = slots > 0 && n > 0 && !no_codes && aligned_ws && workspace_bytes >= L.bins_at;
+    const bool use_sort = use_codes && recs > 0 && workspace_bytes >= L.end;
+    if (use_sort) {                         // the sorted owners cost less per workgroup: other replica counts
+        plan_tiles(gp, fixed, true, &tp, &n_blocks, &ws_entries);
+    } else {
+        for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.bin_of[l] = -1;
+        tp.n_bins = 0;
+    }
+    tp.run_merge = run_merge_enabled() ? 1 : 0;
+    { const char* e = getenv("PERF_BWD_EXP"); tp.exp_mode = e ? atoi(e) : 0; }
     PERF_REQUIRE(!(raw_fields || shifts_dev) || tp.atomic_levels == 0u,
                  "perf_hashgrid_bwd: raw fields / given units are not available for levels beyond 4 M entries");
     tp.accumulate = accumulate;
     tp.raw_out = raw_fields ? 1 : 0;
     tp.dbg_off = 0;
-    int64_t slab_entries = ws_entries;      // workspace layout: [replica slabs (larger of both modes)][shifts][debug slots][tile codes]
-    { TileParams t2; int nb2; int64_t w2; plan_tiles(gp, !fixed, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2; }
-    const int64_t shifts_at = (slab_entries * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
+    const int64_t shifts_at = L.shifts_at;
     PERF_REQUIRE(workspace && workspace_bytes >= shifts_at + kShiftBytes,
                  "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(shifts_at + kShiftBytes));
     int32_t* shifts_ws = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + shifts_at);
-    const int64_t dbg_at = shifts_at + kShiftBytes;
-    static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
+    const int64_t dbg_at = L.dbg_at;
     if (dbg_env && workspace_bytes >= dbg_at + kDbgBytes) tp.dbg_off = dbg_at / (int64_t)sizeof(float2);
-    // tile codes of the hashed levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
-    const int slots = plan_codes(gp, n, &tp);
-    const int64_t codes_at = dbg_at + kDbgBytes;
+    // tile codes of the multi-tile levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
     uint32_t* codes = nullptr;
     uint32_t* escape = nullptr;
-    const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
-    if (slots > 0 && n > 0 && !no_codes && ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0) &&
-        workspace_bytes >= codes_at + (int64_t)slots * tp.n_pad * 4 + esc_words * 4) {
-        codes = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + codes_at);
-        escape = codes + (int64_t)slots * tp.n_pad;
-        tile_codes_kernel<<<dim3((unsigned)esc_words), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
-                                                                                             codes, escape, n, n_dev);
+    uint32_t* hist = nullptr;
+    uint32_t* records = nullptr;
+    if (use_codes) {
+        char* base = reinterpret_cast<char*>(workspace);
+        codes = reinterpret_cast<uint32_t*>(base + L.codes_at);
+        escape = reinterpret_cast<uint32_t*>(base + L.esc_at);
+        if (use_sort) {
+            hist = reinterpret_cast<uint32_t*>(base + L.bins_at);
+            records = reinterpret_cast<uint32_t*>(base + L.recs_at);
+            PERF_REQUIRE(hipMemsetAsync(hist, 0, (size_t)tp.n_bins * 2 * sizeof(uint32_t), as_stream(stream)) == hipSuccess,
+                         "perf_hashgrid_bwd: memset failed");
+        }
+        const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
+        tile_codes_kernel<<<dim3((unsigned)div_up(esc_words, kCodeChunksPerBlock)), dim3(256), 0, as_stream(stream)>>>(
+            gp, tp, x01, (const float2*)dfeat, codes, escape, hist, n, n_dev);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(codes)");
+        if (use_sort) {
+            int hashed_mask = 0;
+            for (int l = 0; l < gp.n_levels; ++l) hashed_mask |= gp.hashed[l] ? (1 << l) : 0;
+            const int sort_lds = 2 * kSortSamples * kSortMaxRecords * (int)sizeof(uint32_t);
+            static std::once_flag sort_once;
+            std::call_once(sort_once, [&]() {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, sort_lds);
+            });
+            tile_sort_kernel<<<dim3((unsigned)div_up(n, kSortSamples), (unsigned)slots), dim3(kSortSamples), sort_lds, as_stream(stream)>>>(
+                tp, hashed_mask, codes, hist, hist + tp.n_bins, records, n, n_dev);
+            PERF_LAUNCH_CHECK("perf_hashgrid_bwd(sort)");
+        }
     } else {
         for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.code_slot[l] = -1;
     }
@@ -1420,11 +1812,11 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     } else if (fixed)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, headroom_state,
-            shifts_dev, shifts_ws, codes, escape, n, n_dev);
+            shifts_dev, shifts_ws, codes, escape, hist, records, n, n_dev);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, nullptr, nullptr, nullptr,
-            codes, escape, n, n_dev);
+            codes, escape, hist, records, n, n_dev);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (tp.atomic_levels && n > 0) {
         if (!accumulate)

@@ -551,6 +551,41 @@ def test_hashgrid_bwd_coded_owners_equal_streaming_owners(ops):
         assert float((a_f32 - b_f32).abs().max()) <= 1e-4 * float(b_f32.abs().max()), kind
 
 
+def test_hashgrid_bwd_sorted_owners_equal_streaming_owners(ops, monkeypatch):
+    """The owners that walk per-tile record lists (counting sort of the tile codes; default from 131,072 samples) and
+    the run-merging coarse owners compute the same fixed-point sums as the position-streaming owners: bit-identical
+    tables -- ragged sizes, ray-coherent runs, positions outside the unit cube (escape to the generic owners), a live
+    count below the capacity, and the full 1 M-sample batch of the benchmark."""
+    cfg = _grid_cfg()
+    g = torch.Generator().manual_seed(22)
+    for n, kind, live in ((4099, 'uniform', None), (65536 + 3, 'rays', None), (30001, 'outside', None), (50000, 'rays', 31111),
+                          (1 << 20, 'rays', None), (1 << 20, 'rays', 700001)):
+        if kind == 'rays':
+            R = n // 128 + 1
+            d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+            t = (torch.arange(128) + 0.5) / 128
+            x = ((d[:, None, :] * t[None, :, None]).reshape(-1, 3) * 0.5 + 0.5)[:n].contiguous()
+        else:
+            x = torch.rand(n, 3, generator=g)
+        if kind == 'outside':
+            x[::7, 0] = -0.25
+            x[5::11, 0] = 9.5
+            x[3::13, 1] = -3.0
+        x = x.cuda()
+        dfeat = torch.randn(cfg.n_levels, n, 2, generator=g).cuda()
+        amax = dfeat.abs().amax(dim=(1, 2)).contiguous()
+        amax = torch.cat([amax, torch.zeros(16 - amax.numel(), device='cuda')])
+        n_dev = None if live is None else torch.tensor([live], dtype=torch.int64, device='cuda')
+        monkeypatch.setenv('PERF_BWD_SORT', '1'); monkeypatch.setenv('PERF_BWD_RUNS', '1'); monkeypatch.setenv('PERF_BWD_SORT_MIN', '0')
+        a_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, n_dev=n_dev)
+        a_f32 = ops.hashgrid_bwd(cfg, x, dfeat, n_dev=n_dev)
+        monkeypatch.setenv('PERF_BWD_SORT', '0'); monkeypatch.setenv('PERF_BWD_RUNS', '0')
+        b_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, use_codes=False, n_dev=n_dev)
+        b_f32 = ops.hashgrid_bwd(cfg, x, dfeat, use_codes=False, n_dev=n_dev)
+        assert torch.equal(a_fix, b_fix), (n, kind, float((a_fix - b_fix).abs().max()))
+        assert float((a_f32 - b_f32).abs().max()) <= 1e-4 * float(b_f32.abs().max()), (n, kind)
+
+
 # ---- deep / large grids (BASELINE config 5: L = 20, tables beyond 2^32 entries; inference only) ----------------------
 def test_deep_grid_forward_20_levels(ops):
     """L = 20 (three k-steps of MLP input, a third encode pass per level group) against the oracle."""
