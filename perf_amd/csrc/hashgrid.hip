@@ -288,9 +288,9 @@ struct TileParams {
     int32_t use_work;
     int32_t raw_out;                       // fixed point: the gradient table receives the int32 field pairs themselves (see perf_hashgrid_bwd)
     uint32_t atomic_levels;                // bit l: level l is too large for LDS owners (see hashgrid_bwd_atomic_kernel)
-    int32_t bin_of[PERF_MAX_LEVELS];       // >=0: first bin of the level's tiles in the sorted records (see tile_sort_kernel)
-    int32_t n_bins;
-    int32_t exp_mode;                      // dev switches of the sorted owners (PERF_BWD_EXP)
+    int32_t bm_row[PERF_MAX_LEVELS];       // >=0: first row of the level's tiles in the per-tile bitmaps (see tile_codes_kernel)
+    int32_t bm_rows;
+    int64_t bm_row_halves;                 // 32-bit words per bitmap row
     int32_t run_merge;                     // single-tile dense levels: a thread sums runs of samples in one cell in registers
     uint32_t work[kMaxWork];
 };
@@ -299,14 +299,14 @@ constexpr int kQueueCap = 448;             // per-wave match queue (entries): <1
 constexpr int64_t kDbgBytes = 4096 * 8;
 constexpr int64_t kMaxCodedSamples = (int64_t)1 << 28;
 
-// `sorted`: the multi-tile levels' owners walk pre-sorted records instead of every sample's code (tile_sort_kernel) and
-// single-tile levels merge runs in registers, which changes what a workgroup costs -- and with it the replica counts.
-static void plan_tiles(const GridParams& gp, bool fixed, bool sorted, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
+// `fast`: the hashed owners read per-tile bitmaps and the single-tile levels merge runs in registers, which changes what a
+// workgroup costs -- and with it the replica counts of the dense levels that keep up with them.
+static void plan_tiles(const GridParams& gp, bool fixed, bool fast, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
     int nb = 0;
     int64_t ws = 0;
     tp->atomic_levels = 0u;
     static const char* rep_env = getenv("PERF_BWD_REPLICAS");      // dev: "r1,r4,r16" replicas of dense levels of 1 / <=4 / <=16 tiles
-    int rs[3] = {8, sorted ? 4 : 3, 2};
+    int rs[3] = {fast ? 10 : 8, fast ? 4 : 3, fast ? 3 : 2};
     if (rep_env) (void)sscanf(rep_env, "%d,%d,%d", &rs[0], &rs[1], &rs[2]);
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->tiles_of[l] = 0; tp->replicas_of[l] = 1; tp->ws_off[l] = 0;
@@ -539,60 +539,30 @@ __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, con
 // at full lane occupancy; positions and gradients are gathered for queued samples only (about 22 % of them), and the
 // gather of one batch is issued one drain ahead of its use.
 constexpr int kCodeSamplesPerBlock = 256;
-constexpr int kCodeChunksPerBlock = 4;      // a workgroup of the pre-pass takes 4 x 256 samples (fewer histogram flushes)
-constexpr int kMaxBins = 4096;
+constexpr int kCodeChunksPerBlock = 4;      // a workgroup of the pre-pass takes 4 x 256 samples
+constexpr int kMaxBitmapRows = 384;         // (rows x 128 bytes of LDS staging in the pre-pass: 48 KiB at most)
 
-// ---- sorted records ---------------------------------------------------------------------------------------------
-// With codes, every owner of a level still LOOKS at every sample (16 owners x 12 levels x 1 M codes: two thirds of the
-// owners' instructions were tests and queue upkeep).  The sorted variant turns the codes into per-tile record lists
-// first: a record = sample << 4 | the (y,z) combinations of the sample that touch the tile; an owner then walks only its
-// own list (about 23 % of the level's samples at 16 tiles), coalesced, at full lane occupancy, with nothing to test.
-// Counting sort in two passes over the codes: the pre-pass histograms records per (level, tile) = bin; tile_sort_kernel
-// reserves, per workgroup of 1024 samples and bin, a contiguous range of the bin with one returning atomic and writes its
-// records there through an LDS staging buffer (coalesced runs).  Order inside a bin is not deterministic -- the
-// fixed-point fields are integer sums, so the gradient is; the fp32 mode was order dependent before.
-//
-// code -> candidates: (tile, combination) pairs; a tile's record carries every combination that names the tile and is
-// emitted by the first candidate naming it.  Hashed: 4 candidates (byte c = tile of combination c).  Dense: 8 (byte c =
-// tile of the x0 corner, bit 7: the x1 corner sits in the next tile; 0x7f: no tile).
-template <bool DENSE, typename F>
-__device__ __forceinline__ void for_each_record(const uint32_t code, const uint32_t tmask, F&& emit) {
-    constexpr int K = DENSE ? 8 : 4;
-    uint32_t tile[K];
-    bool valid[K];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const uint32_t b = (code >> (8 * c)) & 0xffu;
-        if (DENSE) {
-            tile[2 * c] = b & 0x7fu; valid[2 * c] = b != 0x7fu;
-            tile[2 * c + 1] = ((b & 0x7fu) + 1u) & tmask; valid[2 * c + 1] = (b & 0x80u) != 0u;
-        } else {
-            tile[c] = b; valid[c] = true;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        uint32_t cm = 0u;
-        bool first = valid[k];
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const bool same = valid[j] && tile[j] == tile[k];
-            if (same) cm |= 1u << (DENSE ? (j >> 1) : j);
-            if (same && j < k) first = false;
-        }
-        if (first) emit(k, tile[k], cm);
-    }
-}
+// ---- per-tile bitmaps ------------------------------------------------------------------------------------------
+// With codes, every owner of a hashed level still TESTS every sample's four code bytes (16 owners x 12 levels x 1 M
+// samples: two thirds of the owners' instructions were tests and queue upkeep).  For hashed levels the pre-pass
+// therefore leaves one BIT per (tile, sample) instead: row (level, tile) of the bitmap has bit i set when any (y,z)
+// combination of sample i falls in the tile.  An owner reads its own row -- 4 bits per lane and step, 128 KiB per
+// million samples instead of 4 MiB of codes -- turns the set bits into queue entries with one wave scan, and works out
+// WHICH combinations name its tile from the (y,z) it gathers for the queued samples anyway (22 % of them).
+// (Measured and dropped in between: counting-sorted per-tile record lists, so that an owner walks only its records.  The
+//  owners became gather bound -- 0.37-0.43 ms against 0.32 -- because a list that is not in sample order loses the 2-3
+//  samples per 128-byte line that neighbouring lanes share, and the sort itself took longer than the owners.)
 
 __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
                                                          const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
-                                                         uint32_t* __restrict__ escape, uint32_t* __restrict__ hist, int64_t n,
+                                                         uint32_t* __restrict__ escape, uint32_t* __restrict__ bitmaps, int64_t n,
                                                          const int64_t* __restrict__ n_dev) {
     const int64_t n_live = live_count(n, n_dev);            // n: capacity = stride of dfeat / codes; n_live: samples present
     __shared__ uint32_t esc_block;
-    __shared__ uint32_t lhist[kMaxBins];
-    if (hist) {
-        for (int b = threadIdx.x; b < tp.n_bins; b += 256) lhist[b] = 0u;
+    // bitmap staging: [row][kCodeChunksPerBlock * 4 waves] 64-bit words as pairs of 32-bit halves (ds_or_b32)
+    extern __shared__ uint32_t lbits[];     // tp.bm_rows * kCodeChunksPerBlock * 8 words
+    if (bitmaps) {
+        for (int b = threadIdx.x; b < tp.bm_rows * kCodeChunksPerBlock * 8; b += 256) lbits[b] = 0u;
     }
     for (int chunk = 0; chunk < kCodeChunksPerBlock; ++chunk) {
     __syncthreads();
@@ -606,7 +576,8 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
         const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
         for (int l = 0; l < gp.n_levels; ++l) {
             const int slot = tp.code_slot[l];
-            if (slot < 0) continue;
+            const int row0 = bitmaps ? tp.bm_row[l] : -1;
+            if (slot < 0 && row0 < 0) continue;
             const float py = grid_pos(y, gp.scale[l]), pz = grid_pos(z, gp.scale[l]);
             const uint32_t gy = (uint32_t)(int32_t)floorf(py), gz = (uint32_t)(int32_t)floorf(pz);
             const uint32_t gx = (uint32_t)(int32_t)floorf(grid_pos(x, gp.scale[l]));
@@ -634,15 +605,17 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
                     code |= b << (8 * c);
                 }
             }
-            codes[(int64_t)slot * tp.n_pad + i] = code;
+            if (slot >= 0) codes[(int64_t)slot * tp.n_pad + i] = code;
             if (bad) {      // harmless without gradient; with gradient the level's owners take the generic path
                 const float2 g = dfeat[(int64_t)l * n + i];
                 if (!(g.x == 0.f && g.y == 0.f)) esc |= 1u << l;
             }
-            if (hist && tp.bin_of[l] >= 0) {
-                const int bin0 = tp.bin_of[l];
-                if (gp.hashed[l]) for_each_record<false>(code, 0u, [&](int, uint32_t t, uint32_t) { atomicAdd(&lhist[bin0 + (int)t], 1u); });
-                else for_each_record<true>(code, (uint32_t)tp.tiles_of[l] - 1u, [&](int, uint32_t t, uint32_t) { atomicAdd(&lhist[bin0 + (int)t], 1u); });
+            if (row0 >= 0) {        // (hashed level) this sample's bit in the rows of the tiles it names
+                const int half = (chunk * 4 + (int)(threadIdx.x >> 6)) * 2 + (int)((threadIdx.x >> 5) & 1u);
+                const uint32_t bit = 1u << (threadIdx.x & 31u);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    atomicOr(&lbits[(row0 + (int)((code >> (8 * c)) & 0xffu)) * (kCodeChunksPerBlock * 8) + half], bit);
             }
         }
     }
@@ -650,120 +623,52 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
     __syncthreads();
     if (threadIdx.x == 0) escape[word] = esc_block;             // every word is written: no zero-fill needed
     }
-    if (hist) {
+    if (bitmaps) {          // rows are written in runs of 32 halves = 128 bytes per workgroup
         __syncthreads();
-        for (int b = threadIdx.x; b < tp.n_bins; b += 256) { const uint32_t v = lhist[b]; if (v) atomicAdd(&hist[b], v); }
+        constexpr int kHalves = kCodeChunksPerBlock * 8;
+        for (int b = threadIdx.x; b < tp.bm_rows * kHalves; b += 256)
+            bitmaps[(int64_t)(b / kHalves) * tp.bm_row_halves + (int64_t)blockIdx.x * kHalves + (b % kHalves)] = lbits[b];
     }
-}
-
-// sum of v over the workgroup (every thread gets it); `red` = one word per wave
-__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* red) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    uint32_t s = 0u;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
-    return s;
-}
-
-constexpr int kSortSamples = 1024;          // samples (= threads) per workgroup of the sort
-constexpr int kSortMaxRecords = 8;          // records per sample and level (dense worst case; hashed: 4)
-
-// grid (ceil(n / 1024), coded levels): codes of one level's 1024 samples -> records, appended to the level's bins
-__global__ __launch_bounds__(kSortSamples) void tile_sort_kernel(TileParams tp, int hashed_mask, const uint32_t* __restrict__ codes,
-                                                                const uint32_t* __restrict__ hist, uint32_t* __restrict__ fill,
-                                                                uint32_t* __restrict__ records, int64_t n,
-                                                                const int64_t* __restrict__ n_dev) {
-    const int64_t n_live = live_count(n, n_dev);
-    const int64_t i = (int64_t)blockIdx.x * kSortSamples + threadIdx.x;
-    if ((int64_t)blockIdx.x * kSortSamples >= n_live) return;
-    int l = 0;
-    while (tp.code_slot[l] != (int)blockIdx.y) ++l;
-    const int bin0 = tp.bin_of[l], nt = tp.tiles_of[l];
-    if (bin0 < 0) return;
-    const bool hashed = (hashed_mask >> l) & 1;
-    __shared__ uint32_t cnt[256], lstart[256], gbase[256], red[kSortSamples / 64];
-    extern __shared__ uint32_t stage[];         // records [kSortSamples * kSortMaxRecords], then their destinations
-    uint32_t* dst = stage + kSortSamples * kSortMaxRecords;
-    uint32_t part = 0u;                          // records of all bins in front of this level's
-    for (int b = threadIdx.x; b < bin0; b += kSortSamples) part += hist[b];
-    const uint32_t level_base = block_sum_u32(part, red);
-    if (threadIdx.x < 256) cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    uint32_t r_tile[kSortMaxRecords], r_cm[kSortMaxRecords], r_pos[kSortMaxRecords];     // by candidate (static indices)
-#pragma unroll
-    for (int k = 0; k < kSortMaxRecords; ++k) { r_tile[k] = 0u; r_cm[k] = 0u; r_pos[k] = 0u; }
-    if (i < n_live) {
-        const uint32_t code = codes[(int64_t)blockIdx.y * tp.n_pad + i];
-        auto emit = [&](int k, uint32_t t, uint32_t cm) { r_tile[k] = t; r_cm[k] = cm; r_pos[k] = atomicAdd(&cnt[t], 1u); };
-        if (hashed) for_each_record<false>(code, 0u, emit);
-        else for_each_record<true>(code, (uint32_t)nt - 1u, emit);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {                     // exclusive scans over the level's (<= 255) bins: local counts and bin sizes
-        uint32_t c[4], h[4], cs = 0u, hs = 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int b = (int)threadIdx.x * 4 + k;
-            c[k] = b < nt ? cnt[b] : 0u; h[k] = b < nt ? hist[bin0 + b] : 0u;
-            cs += c[k]; hs += h[k];
-        }
-        uint32_t ci = cs, hi = hs;              // inclusive over lanes
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t a = __shfl_up(ci, off), bb = __shfl_up(hi, off);
-            if ((int)threadIdx.x >= off) { ci += a; hi += bb; }
-        }
-        uint32_t ce = ci - cs, he = hi - hs;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int b = (int)threadIdx.x * 4 + k;
-            if (b < nt) {
-                lstart[b] = ce;
-                gbase[b] = level_base + he + (c[k] ? atomicAdd(&fill[bin0 + b], c[k]) : 0u);
-            }
-            ce += c[k]; he += h[k];
-        }
-        if (threadIdx.x == 63) red[0] = ci;     // records of this workgroup
-    }
-    __syncthreads();
-    const uint32_t total = red[0];
-#pragma unroll
-    for (int k = 0; k < kSortMaxRecords; ++k)
-        if (r_cm[k]) {
-            const uint32_t s = lstart[r_tile[k]] + r_pos[k];
-            stage[s] = ((uint32_t)i << 4) | r_cm[k];
-            dst[s] = gbase[r_tile[k]] + r_pos[k];
-        }
-    __syncthreads();
-    for (uint32_t s = threadIdx.x; s < total; s += kSortSamples) records[dst[s]] = stage[s];
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// inclusive prefix sum over the 64 lanes of a wave (DPP: shifts inside rows of 16, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // The loads of this loop are issued through inline assembly with hand-placed s_waitcnt: the compiler's own
 // placement waits for a gather right where it is issued (it packs the loaded y,z into a register pair for a packed
 // multiply) and drains vmcnt to 0 around the conditional drain.  VMEM loads return in issue order, so
 // "vmcnt(k)" = "everything but the k youngest loads has landed"; the number of loads issued per step is static
-// (2 code loads, then 3 gather loads per drain, idle lanes gather sample 0).
-template <bool FIXED, bool DENSE>
+// (2 code loads -- BITMAP: 1 byte load --, then 3 gather loads per drain, idle lanes gather sample 0).
+// BITMAP (hashed levels): codes_l is the tile's bitmap row; a lane takes the 4 bits of its group of 4 samples and queue
+// entries start without combinations (low nibble 0), which the drain derives from the gathered (y,z).
+template <bool FIXED, bool DENSE, bool BITMAP = false>
 __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_tile, uint32_t* queue,
                                                  const uint32_t* __restrict__ codes_l, const float* __restrict__ x01,
                                                  const float2* __restrict__ g_l, int64_t n, int rep, int R) {
+    static_assert(!(BITMAP && DENSE), "bitmaps are for hashed levels");
     // (tells the compiler's own wait-count bookkeeping that nothing it knows of is in flight when the loop starts;
     //  otherwise it drains vmcnt to 0 at the head of every iteration on behalf of the other streaming variants)
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t qn = 0;                                    // wave-uniform queue fill
-    const int64_t n_full = n / 4;
+    const int64_t n_full = BITMAP ? (n + 3) / 4 : n / 4;    // (bits past the last sample are 0: no ragged tail)
     const int64_t g_lo = n_full * rep / R, g_hi = n_full * (rep + 1) / R;       // this replica's groups of 4 samples
     // registers written by loads in flight: only ever read through the wait_* copies below
     float ld_x = 0.f; f32x2 ld_yz = {0.f, 0.f}, ld_g = {0.f, 0.f}; u32x2 ld_c0 = {0u, 0u}, ld_c1 = {0u, 0u};
     uint32_t bcm = 0, bi = 0;                           // (y,z) combinations and sample index of the batch in flight
+    bool blive = false;                                 // this lane holds an entry of the batch in flight
     const uint32_t t_split = 0x80u | cx.t, t_next = 0x80u | ((cx.t - 1u) & (cx.n_tiles - 1u));     // dense codes
     auto test = [&](uint32_t code) {
         uint32_t cm = 0;
@@ -783,10 +688,26 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
             qn += (uint32_t)__popcll(b);
         }
     };
-    auto load_codes = [&](int64_t grp) {                // 2 loads
-        const uint32_t off = (uint32_t)(grp < g_hi ? grp : g_hi - 1) * 16u;
-        asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dwordx2 %1, %2, %3 offset:8"
-                     : "=&v"(ld_c0), "=&v"(ld_c1) : "v"(off), "s"(codes_l) : "memory");
+    // BITMAP: the set bits of every lane's nibble become entries, in sample order (one wave scan per 256 samples)
+    auto enqueue_bits = [&](uint32_t bits, uint32_t i0) {
+        const uint32_t cnt = (uint32_t)__popc(bits);
+        const uint32_t incl = wave_inclusive_sum(cnt);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t base = qn + incl - cnt;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (bits & (1u << b)) queue[base + (uint32_t)__popc(bits & ((1u << b) - 1u))] = (i0 + (uint32_t)b) << 4;
+        qn += total;
+    };
+    auto load_codes = [&](int64_t grp) {                // 2 loads (BITMAP: 1)
+        if (BITMAP) {
+            const uint32_t off = (uint32_t)((grp < g_hi ? grp : g_hi - 1) >> 1);
+            asm volatile("global_load_ubyte %0, %1, %2" : "=&v"(ld_c0.x) : "v"(off), "s"(codes_l) : "memory");
+        } else {
+            const uint32_t off = (uint32_t)(grp < g_hi ? grp : g_hi - 1) * 16u;
+            asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dwordx2 %1, %2, %3 offset:8"
+                         : "=&v"(ld_c0), "=&v"(ld_c1) : "v"(off), "s"(codes_l) : "memory");
+        }
     };
     auto pop_and_gather = [&]() {       // up to 64 queued samples: issue the 3 loads of their position and gradient
         const uint32_t take = qn < 64u ? qn : 64u;
@@ -795,6 +716,7 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
         if (lane < take) e = queue[qn - take + lane];
         __builtin_amdgcn_wave_barrier();
         qn -= take;
+        blive = lane < take;
         bcm = e & 15u;
         bi = e >> 4;
         const uint32_t ox = bi * 12u, og = bi * 8u;
@@ -810,18 +732,26 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     // The batch gathered one drain ago.  Every lane applies ONE combination (loop-free at full occupancy); the 7 % of
     // samples that name this tile with two or more combinations go back into the queue with the remaining ones.
     auto apply_batch = [&](float bx, f32x2 byz, f32x2 bg) {
+        const float py = grid_pos(byz.x, cx.scale), pz = grid_pos(byz.y, cx.scale);
+        const float fly = floorf(py), flz = floorf(pz);
+        const uint32_t ay0 = (uint32_t)(int32_t)fly * (DENSE ? cx.res : kPrimeY), az0 = (uint32_t)(int32_t)flz * (DENSE ? cx.r2 : kPrimeZ);
+        if (BITMAP && blive && bcm == 0u) {     // fresh entry: which of the 4 (y,z) combinations fall in this tile
+            const uint32_t ay1 = ay0 + kPrimeY, az1 = az0 + kPrimeZ;
+            bcm = ((((ay0 ^ az0) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 1u : 0u) |
+                  ((((ay1 ^ az0) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 2u : 0u) |
+                  ((((ay0 ^ az1) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 4u : 0u) |
+                  ((((ay1 ^ az1) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 8u : 0u);
+        }
         const uint32_t rest = DENSE ? 0u : bcm & (bcm - 1u);        // (dense tiles are named by several combinations as a rule)
         if (!DENSE) bcm &= 0u - bcm;
         if (bcm) {
-            const float px = grid_pos(bx, cx.scale), py = grid_pos(byz.x, cx.scale), pz = grid_pos(byz.y, cx.scale);
-            const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+            const float px = grid_pos(bx, cx.scale);
+            const float flx = floorf(px);
             const uint32_t gx = (uint32_t)(int32_t)flx;
             if (DENSE)
-                apply_pairs_dense<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz,
-                                         (uint32_t)(int32_t)fly * cx.res, (uint32_t)(int32_t)flz * cx.r2, bcm);
+                apply_pairs_dense<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz, ay0, az0, bcm);
             else if (gx < (uint32_t)(kTileEntries - 1))      // (else: zero gradient, see tile_codes_kernel)
-                apply_pairs<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz,
-                                   (uint32_t)(int32_t)fly * kPrimeY, (uint32_t)(int32_t)flz * kPrimeZ, bcm);
+                apply_pairs<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz, ay0, az0, bcm);
         }
         if (!DENSE) enqueue(rest, bi);
     };
@@ -830,16 +760,21 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
         load_codes(grp);
         pop_and_gather();               // empty queue: dummy gather, keeps the in-flight count of the loop static
         for (int64_t base = g_lo + (int64_t)(threadIdx.x & ~63u); base < g_hi; base += kBwdThreads) {   // wave-uniform trip count
-            u32x2 c0, c1;               // in flight, oldest first: 2 code loads, 3 gather loads
-            asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(c0), "=&v"(c1) : "v"(ld_c0), "v"(ld_c1) : "memory");
+            u32x2 c0, c1 = {0u, 0u};    // in flight, oldest first: the code loads, 3 gather loads
+            if (BITMAP) asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b32 %0, %1" : "=&v"(c0.x) : "v"(ld_c0.x) : "memory");
+            else asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(c0), "=&v"(c1) : "v"(ld_c0), "v"(ld_c1) : "memory");
             const int64_t g0 = grp;
             const bool valid = g0 < g_hi;
             grp += kBwdThreads;
             load_codes(grp);
-            const uint32_t cs[4] = {c0.x, c0.y, c1.x, c1.y};
+            if (BITMAP) {
+                enqueue_bits(valid ? (c0.x >> (4u * ((uint32_t)g0 & 1u))) & 15u : 0u, (uint32_t)(4 * g0));
+                PERF_WAIT_BATCH(1);     // all but the byte load
+                apply_batch(bx, byz, bg);
+            } else {
+                const uint32_t cs[4] = {c0.x, c0.y, c1.x, c1.y};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
-            {
+                for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
                 PERF_WAIT_BATCH(2);     // all but the 2 code loads
                 apply_batch(bx, byz, bg);
             }
@@ -851,92 +786,19 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
             }
         }
     }
-    if (threadIdx.x < 64 && rep == 0) {                 // ragged tail (n % 4 samples)
+    if (!BITMAP && threadIdx.x < 64 && rep == 0) {      // ragged tail (n % 4 samples)
         const int64_t i = n_full * 4 + lane;
         enqueue(i < n ? test(codes_l[i]) : 0u, (uint32_t)i);
     }
     for (;;) {
         PERF_WAIT_BATCH(0);
         apply_batch(bx, byz, bg);
-        bcm = 0;
+        bcm = 0; blive = false;
         if (qn == 0u) break;
         pop_and_gather();
     }
     asm volatile("" : : "v"(ld_c0), "v"(ld_c1));       // (the last code loads landed with the vmcnt(0) above)
 #undef PERF_WAIT_BATCH
-}
-
-// Sorted variant of the coded owners: the tile's records (tile_sort_kernel) are walked coalesced, 4 per thread and step,
-// software-pipelined three deep -- while the 4 records of step k are applied, the positions / gradients of step k+1 are
-// being gathered and the records of step k+2 loaded (16 loads in flight per lane; the compiler's own wait counts are
-// right for this static pattern).  Replica r of R takes the r-th slice of the list.
-template <bool FIXED, bool DENSE, int U = 4>
-__device__ __forceinline__ void bwd_stream_sorted(const BwdCtx& cx, float* lds_tile, const uint32_t* __restrict__ recs,
-                                                  const uint32_t count, const float* __restrict__ x01,
-                                                  const float2* __restrict__ g_l, int rep, int R, const int exp_mode = 0) {
-    const uint32_t lo = (uint32_t)(((uint64_t)count * (uint32_t)rep) / (uint32_t)R);
-    const uint32_t hi = (uint32_t)(((uint64_t)count * (uint32_t)(rep + 1)) / (uint32_t)R);
-    constexpr uint32_t kStep = U * kBwdThreads;
-    uint32_t eA[U], eB[U];
-    float xB[U], yB[U], zB[U];
-    float2 gB[U];
-    auto load = [&](uint32_t base, uint32_t (&e)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t j = base + (uint32_t)u * kBwdThreads + threadIdx.x;
-            e[u] = (j < hi && j >= base) ? recs[j] : 0u;        // (0: sample 0, no combination -- gathered, not applied)
-        }
-    };
-    auto gather = [&](const uint32_t (&e)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t i = e[u] >> 4;
-            if (exp_mode & 2) {     // dev: no gathers
-                xB[u] = (float)(i & 1023u) * (1.0f / 1024.0f); yB[u] = (float)((i >> 10) & 1023u) * (1.0f / 1024.0f); zB[u] = (float)(i >> 20) * (1.0f / 256.0f);
-                gB[u] = make_float2(1e-3f, -1e-3f);
-                continue;
-            }
-            const float* xp = x01 + 3 * (size_t)i;
-            xB[u] = xp[0]; yB[u] = xp[1]; zB[u] = xp[2];
-            gB[u] = g_l[i];
-        }
-    };
-    if (hi <= lo) return;
-    load(lo, eB);
-    load(lo + kStep, eA);
-    gather(eB);
-    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): nothing in flight at loop entry (keeps the compiler's wait counts in the loop exact)
-    for (uint32_t base = lo; base < hi && base >= lo; base += kStep) {
-        uint32_t eC[U];
-        float xC[U], yC[U], zC[U];
-        float2 gC[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { eC[u] = eB[u]; xC[u] = xB[u]; yC[u] = yB[u]; zC[u] = zB[u]; gC[u] = gB[u]; eB[u] = eA[u]; }
-        gather(eB);
-        load(base + 2u * kStep, eA);
-        if (exp_mode & 1) {         // dev: no apply
-            float d = 0.f;
-#pragma unroll
-            for (int u = 0; u < U; ++u) d += xC[u] + yC[u] + zC[u] + gC[u].x + gC[u].y;
-            if (d == 123.456f) lds_tile[threadIdx.x] = d;
-            continue;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t cm = eC[u] & 15u;
-            if (cm) {
-                const float px = grid_pos(xC[u], cx.scale), py = grid_pos(yC[u], cx.scale), pz = grid_pos(zC[u], cx.scale);
-                const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-                const uint32_t gx = (uint32_t)(int32_t)flx;
-                if (DENSE)
-                    apply_pairs_dense<FIXED>(cx, lds_tile, gC[u], gx, px - flx, py - fly, pz - flz,
-                                             (uint32_t)(int32_t)fly * cx.res, (uint32_t)(int32_t)flz * cx.r2, cm);
-                else if (gx < (uint32_t)(kTileEntries - 1))      // (else: zero gradient, see tile_codes_kernel)
-                    apply_pairs<FIXED>(cx, lds_tile, gC[u], gx, px - flx, py - fly, pz - flz,
-                                       (uint32_t)(int32_t)fly * kPrimeY, (uint32_t)(int32_t)flz * kPrimeZ, cm);
-            }
-        }
-    }
 }
 
 // Single-tile dense levels (the coarsest ones: a cell is several sample spacings wide): a thread walks consecutive
@@ -1095,8 +957,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    int32_t* __restrict__ shifts_ws,
                                                                    const uint32_t* __restrict__ codes,
                                                                    const uint32_t* __restrict__ escape,
-                                                                   const uint32_t* __restrict__ hist,
-                                                                   const uint32_t* __restrict__ records, int64_t n,
+                                                                   const uint32_t* __restrict__ bitmaps, int64_t n,
                                                                    const int64_t* __restrict__ n_dev) {
     const int64_t n_live = live_count(n, n_dev);            // samples present; n stays the stride of dfeat / codes
     extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats (+ the wave queues)
@@ -1136,7 +997,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         if (shifts_ws && t == 0u && rep == 0 && threadIdx.x == 0) shifts_ws[l] = sh;
     }
     const float2* g_l = dfeat + (int64_t)l * n;
-    bool coded = codes && tp.code_slot[l] >= 0;
+    bool coded = (codes && tp.code_slot[l] >= 0) || (bitmaps && tp.bm_row[l] >= 0);
     if (coded) {                        // any escape bit for this level in the pre-pass blocks' words?
         __shared__ uint32_t esc_any;
         if (threadIdx.x == 0) esc_any = 0u;
@@ -1149,19 +1010,9 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         coded = esc_any == 0u;
     }
     uint32_t* queue = reinterpret_cast<uint32_t*>(lds_tile + 2 * kTileEntries) + (threadIdx.x >> 6) * kQueueCap;
-    if (coded && records && tp.bin_of[l] >= 0) {           // sorted records: this tile's list is [start, start + hist[bin])
-        __shared__ uint32_t red[kBwdThreads / 64];
-        const int bin = tp.bin_of[l] + (int)t;
-        uint32_t part = 0u;
-        for (int b2 = threadIdx.x; b2 < bin; b2 += kBwdThreads) part += hist[b2];
-        const uint32_t start = block_sum_u32(part, red);
-        const int em = tp.exp_mode & 3, eu = (tp.exp_mode >> 2) & 3;
-        if (!hashed) bwd_stream_sorted<FIXED, true>(cx, lds_tile, records + start, hist[bin], x01, g_l, rep, R, em);
-        else if (eu == 0) bwd_stream_sorted<FIXED, false, 4>(cx, lds_tile, records + start, hist[bin], x01, g_l, rep, R, em);
-        else if (eu == 1) bwd_stream_sorted<FIXED, false, 1>(cx, lds_tile, records + start, hist[bin], x01, g_l, rep, R, em);
-        else if (eu == 2) bwd_stream_sorted<FIXED, false, 2>(cx, lds_tile, records + start, hist[bin], x01, g_l, rep, R, em);
-        else bwd_stream_sorted<FIXED, false, 8>(cx, lds_tile, records + start, hist[bin], x01, g_l, rep, R, em);
-    }
+    if (coded && hashed && bitmaps && tp.bm_row[l] >= 0)
+        bwd_stream_codes<FIXED, false, true>(cx, lds_tile, queue, reinterpret_cast<const uint32_t*>(bitmaps + (int64_t)(tp.bm_row[l] + (int)t) * tp.bm_row_halves),
+                                             x01, g_l, n_live, rep, R);
     else if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (coded) bwd_stream_codes<FIXED, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n_live, rep, R);
@@ -1669,26 +1520,28 @@ static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
 
 constexpr int64_t kShiftBytes = 256;        // per-level shifts the owners leave for the replica reduction
 
-// bins of the sorted records (one per tile of every coded level; plan_codes ran before); returns the worst-case number of
-// records, or 0 when the batch does not take the sorted owners (small batches: two more launches than they save;
-// PERF_BWD_SORT=0 / PERF_BWD_SORT_MIN=<samples> are dev switches)
-static int64_t plan_bins(const GridParams& gp, int64_t n, TileParams* tp) {
-    for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp->bin_of[l] = -1;
-    tp->n_bins = 0;
-    const char* e = getenv("PERF_BWD_SORT");
-    const char* m = getenv("PERF_BWD_SORT_MIN");
-    const int64_t n_min = m ? atoll(m) : 131072;
-    if ((e && atoi(e) == 0) || n < n_min || n >= kMaxCodedSamples) return 0;
-    int bins = 0;
-    int64_t recs = 0;
+// per-tile bitmaps of the hashed coded levels (plan_codes ran before: those levels give their code slot back); returns the
+// number of rows.  PERF_BWD_BITMAP=0 keeps the codes (dev switch).
+static int plan_bitmaps(const GridParams& gp, int64_t n, TileParams* tp, int* slots) {
+    for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp->bm_row[l] = -1;
+    tp->bm_rows = 0;
+    tp->bm_row_halves = div_up(n, (int64_t)kCodeSamplesPerBlock * kCodeChunksPerBlock) * (kCodeChunksPerBlock * 8);
+    const char* e = getenv("PERF_BWD_BITMAP");
+    if ((e && atoi(e) == 0) || n == 0) return 0;
+    int rows = 0;
     for (int l = 0; l < gp.n_levels; ++l)
-        if (tp->code_slot[l] >= 0) { bins += tp->tiles_of[l]; recs += n * (gp.hashed[l] ? 4 : kSortMaxRecords); }
-    if (bins == 0 || bins > kMaxBins || recs >= ((int64_t)1 << 32)) return 0;
-    bins = 0;
-    for (int l = 0; l < gp.n_levels; ++l)
-        if (tp->code_slot[l] >= 0) { tp->bin_of[l] = bins; bins += tp->tiles_of[l]; }
-    tp->n_bins = bins;
-    return recs;
+        if (tp->code_slot[l] >= 0 && gp.hashed[l]) rows += tp->tiles_of[l];
+    if (rows == 0 || rows > kMaxBitmapRows) return 0;
+    rows = 0;
+    int kept = 0;
+    for (int l = 0; l < gp.n_levels; ++l) {
+        if (tp->code_slot[l] < 0) continue;
+        if (gp.hashed[l]) { tp->bm_row[l] = rows; rows += tp->tiles_of[l]; tp->code_slot[l] = -1; }
+        else tp->code_slot[l] = kept++;
+    }
+    tp->bm_rows = rows;
+    *slots = kept;
+    return rows;
 }
 
 static bool run_merge_enabled() { const char* e = getenv("PERF_BWD_RUNS"); return !(e && atoi(e) == 0); }
@@ -1700,17 +1553,16 @@ static int64_t max_slab_entries(const GridParams& gp) {
     return best;
 }
 
-struct BwdLayout { int64_t shifts_at, dbg_at, codes_at, esc_at, bins_at, recs_at, end; };
+struct BwdLayout { int64_t shifts_at, dbg_at, codes_at, esc_at, bits_at, end; };
 
-static BwdLayout bwd_layout(const GridParams& gp, int64_t n, int slots, int64_t n_pad, int n_bins, int64_t recs) {
+static BwdLayout bwd_layout(const GridParams& gp, int64_t n, int slots, int64_t n_pad, int bm_rows, int64_t bm_row_halves) {
     BwdLayout L;
     L.shifts_at = (max_slab_entries(gp) * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
     L.dbg_at = L.shifts_at + kShiftBytes;
     L.codes_at = L.dbg_at + kDbgBytes;
     L.esc_at = L.codes_at + (int64_t)slots * n_pad * 4;
-    L.bins_at = (L.esc_at + (slots ? div_up(n, kCodeSamplesPerBlock) * 4 : 0) + 15) & ~(int64_t)15;
-    L.recs_at = L.bins_at + 2 * (int64_t)n_bins * 4;
-    L.end = L.recs_at + recs * 4;
+    L.bits_at = (L.esc_at + ((slots || bm_rows) ? div_up(n, kCodeSamplesPerBlock) * 4 : 0) + 15) & ~(int64_t)15;
+    L.end = L.bits_at + (int64_t)bm_rows * bm_row_halves * 4;
     return L;
 }
 
@@ -1719,9 +1571,9 @@ extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid,
     if (fill_params(grid, &gp)) return -1;
     TileParams tp; int nb; int64_t ws;
     plan_tiles(gp, true, false, &tp, &nb, &ws);
-    const int slots = plan_codes(gp, n, &tp);
-    const int64_t recs = plan_bins(gp, n, &tp);
-    return bwd_layout(gp, n, slots, tp.n_pad, tp.n_bins, recs).end + 16;
+    int slots = plan_codes(gp, n, &tp);
+    const int rows = plan_bitmaps(gp, n, &tp, &slots);
+    return bwd_layout(gp, n, slots, tp.n_pad, rows, tp.bm_row_halves).end + 16;
 }
 
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
@@ -1741,21 +1593,28 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     int64_t ws_entries = 0;
     plan_tiles(gp, fixed, false, &tp, &n_blocks, &ws_entries);
     static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
-    // workspace layout: [replica slabs (largest plan)][shifts][debug slots][tile codes][escape words][bin counters][records]
-    int slots = plan_codes(gp, n, &tp);
-    int64_t recs = plan_bins(gp, n, &tp);
-    BwdLayout L = bwd_layout(gp, n, slots, tp.n_pad, tp.n_bins, recs);
+    // workspace layout: [replica slabs (largest plan)][shifts][debug slots][tile codes][escape words][per-tile bitmaps]
+    const int slots_all = plan_codes(gp, n, &tp);
+    int slots = slots_all;
     const bool aligned_ws = (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
-    const bool use_codes = slots > 0 && n > 0 && !no_codes && aligned_ws && workspace_bytes >= L.bins_at;
-    const bool use_sort = use_codes && recs > 0 && workspace_bytes >= L.end;
-    if (use_sort) {                         // the sorted owners cost less per workgroup: other replica counts
+    int rows = (no_codes || !aligned_ws) ? 0 : plan_bitmaps(gp, n, &tp, &slots);
+    BwdLayout L = bwd_layout(gp, n, slots, tp.n_pad, rows, tp.bm_row_halves);
+    if (rows > 0 && workspace_bytes < L.end) {      // no room for the bitmaps: codes for every coded level
+        slots = plan_codes(gp, n, &tp);
+        for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.bm_row[l] = -1;
+        tp.bm_rows = 0; rows = 0;
+        L = bwd_layout(gp, n, slots, tp.n_pad, 0, tp.bm_row_halves);
+    }
+    if (rows == 0) { for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.bm_row[l] = -1; tp.bm_rows = 0; }
+    const bool use_codes = (slots > 0 || rows > 0) && n > 0 && !no_codes && aligned_ws && workspace_bytes >= L.end;
+    const bool fast = use_codes && rows > 0;
+    if (fast) {                             // bitmap owners cost less per workgroup: the dense levels get more replicas
+        const TileParams keep = tp;
         plan_tiles(gp, fixed, true, &tp, &n_blocks, &ws_entries);
-    } else {
-        for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.bin_of[l] = -1;
-        tp.n_bins = 0;
+        for (int l = 0; l < PERF_MAX_LEVELS; ++l) { tp.code_slot[l] = keep.code_slot[l]; tp.bm_row[l] = keep.bm_row[l]; }
+        tp.bm_rows = keep.bm_rows; tp.bm_row_halves = keep.bm_row_halves; tp.n_pad = keep.n_pad;
     }
     tp.run_merge = run_merge_enabled() ? 1 : 0;
-    { const char* e = getenv("PERF_BWD_EXP"); tp.exp_mode = e ? atoi(e) : 0; }
     PERF_REQUIRE(!(raw_fields || shifts_dev) || tp.atomic_levels == 0u,
                  "perf_hashgrid_bwd: raw fields / given units are not available for levels beyond 4 M entries");
     tp.accumulate = accumulate;
@@ -1770,36 +1629,19 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     // tile codes of the multi-tile levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
     uint32_t* codes = nullptr;
     uint32_t* escape = nullptr;
-    uint32_t* hist = nullptr;
-    uint32_t* records = nullptr;
+    uint32_t* bitmaps = nullptr;
     if (use_codes) {
         char* base = reinterpret_cast<char*>(workspace);
         codes = reinterpret_cast<uint32_t*>(base + L.codes_at);
         escape = reinterpret_cast<uint32_t*>(base + L.esc_at);
-        if (use_sort) {
-            hist = reinterpret_cast<uint32_t*>(base + L.bins_at);
-            records = reinterpret_cast<uint32_t*>(base + L.recs_at);
-            PERF_REQUIRE(hipMemsetAsync(hist, 0, (size_t)tp.n_bins * 2 * sizeof(uint32_t), as_stream(stream)) == hipSuccess,
-                         "perf_hashgrid_bwd: memset failed");
-        }
+        if (rows > 0) bitmaps = reinterpret_cast<uint32_t*>(base + L.bits_at);
         const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
-        tile_codes_kernel<<<dim3((unsigned)div_up(esc_words, kCodeChunksPerBlock)), dim3(256), 0, as_stream(stream)>>>(
-            gp, tp, x01, (const float2*)dfeat, codes, escape, hist, n, n_dev);
+        tile_codes_kernel<<<dim3((unsigned)div_up(esc_words, kCodeChunksPerBlock)), dim3(256), (size_t)rows * kCodeChunksPerBlock * 8 * 4, as_stream(stream)>>>(
+            gp, tp, x01, (const float2*)dfeat, codes, escape, bitmaps, n, n_dev);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(codes)");
-        if (use_sort) {
-            int hashed_mask = 0;
-            for (int l = 0; l < gp.n_levels; ++l) hashed_mask |= gp.hashed[l] ? (1 << l) : 0;
-            const int sort_lds = 2 * kSortSamples * kSortMaxRecords * (int)sizeof(uint32_t);
-            static std::once_flag sort_once;
-            std::call_once(sort_once, [&]() {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, sort_lds);
-            });
-            tile_sort_kernel<<<dim3((unsigned)div_up(n, kSortSamples), (unsigned)slots), dim3(kSortSamples), sort_lds, as_stream(stream)>>>(
-                tp, hashed_mask, codes, hist, hist + tp.n_bins, records, n, n_dev);
-            PERF_LAUNCH_CHECK("perf_hashgrid_bwd(sort)");
-        }
     } else {
-        for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.code_slot[l] = -1;
+        for (int l = 0; l < PERF_MAX_LEVELS; ++l) { tp.code_slot[l] = -1; tp.bm_row[l] = -1; }
+        tp.bm_rows = 0;
     }
     const int lds_bytes = 2 * kTileEntries * (int)sizeof(float) + (kBwdThreads / 64) * kQueueCap * (int)sizeof(uint32_t);
     static std::once_flag attr_once;                // one-time kernel attribute setup, safe under concurrent callers
@@ -1812,11 +1654,11 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     } else if (fixed)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, headroom_state,
-            shifts_dev, shifts_ws, codes, escape, hist, records, n, n_dev);
+            shifts_dev, shifts_ws, codes, escape, bitmaps, n, n_dev);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, nullptr, nullptr, nullptr,
-            codes, escape, hist, records, n, n_dev);
+            codes, escape, bitmaps, n, n_dev);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (tp.atomic_levels && n > 0) {
         if (!accumulate)

@@ -1,4 +1,4 @@
-"""Dev tool: the grid backward's owner variants (PERF_BWD_SORT / PERF_BWD_RUNS) -- equality of the fixed-point gradients,
+"""Dev tool: the grid backward's owner variants (PERF_BWD_BITMAP / PERF_BWD_RUNS) -- equality of the fixed-point gradients,
 ms per call, per-workgroup times by level.    python tools/exp/bwd_sort.py [out.json]"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -23,11 +23,11 @@ for kind in ('rays', 'random'):
         ms = timed(lambda: call(x, dfeat, amax, ws=ws, out=out))
         call(x, dfeat, amax, ws=ws, out=out); torch.cuda.synchronize()
         rows = block_times(ws, n, bool(sort))
-        res[kind][f'sort{sort}_runs{runs}'] = {'equal': eq, 'fp32_rel_err': err32, 'ms': ms, 'levels': rows}
-        print(kind, f'sort={sort} runs={runs}: equal={eq} fp32 err {err32:.2e}  {ms:.4f} ms', flush=True)
+        res[kind][f'bitmap{sort}_runs{runs}'] = {'equal': eq, 'fp32_rel_err': err32, 'ms': ms, 'levels': rows}
+        print(kind, f'bitmap={sort} runs={runs}: equal={eq} fp32 err {err32:.2e}  {ms:.4f} ms', flush=True)
         for r in rows:
             print('    level %2d tiles %2d x rep %2d: mean %7.1f us  max %7.1f us' % r)
-    # live count below the capacity, small batch through the sorted path
+    # live count below the capacity, small batches
     setenv(0, 0)
     nd = torch.tensor([700001], dtype=torch.int64, device=dev)
     r2, _ = call(x, dfeat, amax, n_dev=nd); r2 = r2.clone()
@@ -38,12 +38,11 @@ for kind in ('rays', 'random'):
     for m in (5, 1000, 4097, 70001):
         xs, ds, am = batch(kind, max(128, (m + 127) // 128 * 128), seed=m)
         xs, ds = xs[:m].contiguous(), ds[:, :m].contiguous()
-        setenv(0, 0, sort_min=1 << 30)
+        setenv(0, 0)
         a, _ = call(xs, ds, am); a = a.clone()
-        setenv(1, 1, sort_min=0)
+        setenv(1, 1)
         b, _ = call(xs, ds, am)
         print(kind, f'n={m} equal:', bool(torch.equal(a, b)), flush=True)
         res[kind][f'small_{m}_equal'] = bool(torch.equal(a, b))
-    os.environ.pop('PERF_BWD_SORT_MIN')
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], 'w'), indent=1)

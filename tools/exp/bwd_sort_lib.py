@@ -26,10 +26,8 @@ def batch(kind, n, seed=0):
     return x, dfeat, amax
 
 
-def setenv(sort, runs, sort_min=None):
-    os.environ['PERF_BWD_SORT'] = str(sort); os.environ['PERF_BWD_RUNS'] = str(runs)
-    if sort_min is not None:
-        os.environ['PERF_BWD_SORT_MIN'] = str(sort_min)
+def setenv(bitmap, runs):
+    os.environ['PERF_BWD_BITMAP'] = str(bitmap); os.environ['PERF_BWD_RUNS'] = str(runs)
 
 
 def call(x, dfeat, amax, n_dev=None, fixed=True, ws=None, out=None):
@@ -54,13 +52,13 @@ def timed(fn, reps=20):
     return a.elapsed_time(b) / reps
 
 
-def block_times(ws, n, sorted_):
+def block_times(ws, n, fast):
     need0 = lib.perf_hashgrid_bwd_workspace_bytes(ctypes.byref(desc), 0)
     off = (need0 - 16 - 4096 * 8) // 8
     cyc = ws[2 * off:2 * off + 1200].view(torch.int64).cpu().numpy()
     tiles = [max(1, -(-int(s) // 16384)) for s in cfg.size]
     tiles = [t_ if cfg.hashed[l] else 1 << (t_ - 1).bit_length() for l, t_ in enumerate(tiles)]
-    rs = [int(v) for v in os.environ.get('PERF_BWD_REPLICAS', f'8,{4 if sorted_ else 3},2').split(',')]
+    rs = [int(v) for v in os.environ.get('PERF_BWD_REPLICAS', ('10,4,3' if fast else '8,3,2')).split(',')]
     reps = [1 if cfg.hashed[l] else (rs[0] if t_ == 1 else rs[1] if t_ <= 4 else rs[2] if t_ <= 16 else 1) for l, t_ in enumerate(tiles)]
     b = 0; rows = []
     for l in range(16):
