@@ -288,9 +288,6 @@ struct TileParams {
     int32_t use_work;
     int32_t raw_out;                       // fixed point: the gradient table receives the int32 field pairs themselves (see perf_hashgrid_bwd)
     uint32_t atomic_levels;                // bit l: level l is too large for LDS owners (see hashgrid_bwd_atomic_kernel)
-    int32_t bm_row[PERF_MAX_LEVELS];       // >=0: first row of the level's tiles in the per-tile bitmaps (see tile_codes_kernel)
-    int32_t bm_rows;
-    int64_t bm_row_halves;                 // 32-bit words per bitmap row
     int32_t run_merge;                     // single-tile dense levels: a thread sums runs of samples in one cell in registers
     uint32_t work[kMaxWork];
 };
@@ -299,14 +296,12 @@ constexpr int kQueueCap = 448;             // per-wave match queue (entries): <1
 constexpr int64_t kDbgBytes = 4096 * 8;
 constexpr int64_t kMaxCodedSamples = (int64_t)1 << 28;
 
-// `fast`: the hashed owners read per-tile bitmaps and the single-tile levels merge runs in registers, which changes what a
-// workgroup costs -- and with it the replica counts of the dense levels that keep up with them.
-static void plan_tiles(const GridParams& gp, bool fixed, bool fast, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
+static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
     int nb = 0;
     int64_t ws = 0;
     tp->atomic_levels = 0u;
     static const char* rep_env = getenv("PERF_BWD_REPLICAS");      // dev: "r1,r4,r16" replicas of dense levels of 1 / <=4 / <=16 tiles
-    int rs[3] = {fast ? 10 : 8, fast ? 4 : 3, fast ? 3 : 2};
+    int rs[3] = {8, 3, 2};
     if (rep_env) (void)sscanf(rep_env, "%d,%d,%d", &rs[0], &rs[1], &rs[2]);
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->tiles_of[l] = 0; tp->replicas_of[l] = 1; tp->ws_off[l] = 0;
@@ -539,45 +534,32 @@ __device__ __forceinline__ void bwd_apply(const BwdCtx& cx, float* lds_tile, con
 // at full lane occupancy; positions and gradients are gathered for queued samples only (about 22 % of them), and the
 // gather of one batch is issued one drain ahead of its use.
 constexpr int kCodeSamplesPerBlock = 256;
-constexpr int kCodeChunksPerBlock = 4;      // a workgroup of the pre-pass takes 4 x 256 samples
-constexpr int kMaxBitmapRows = 384;         // (rows x 128 bytes of LDS staging in the pre-pass: 48 KiB at most)
-
-// ---- per-tile bitmaps ------------------------------------------------------------------------------------------
-// With codes, every owner of a hashed level still TESTS every sample's four code bytes (16 owners x 12 levels x 1 M
-// samples: two thirds of the owners' instructions were tests and queue upkeep).  For hashed levels the pre-pass
-// therefore leaves one BIT per (tile, sample) instead: row (level, tile) of the bitmap has bit i set when any (y,z)
-// combination of sample i falls in the tile.  An owner reads its own row -- 4 bits per lane and step, 128 KiB per
-// million samples instead of 4 MiB of codes -- turns the set bits into queue entries with one wave scan, and works out
-// WHICH combinations name its tile from the (y,z) it gathers for the queued samples anyway (22 % of them).
-// (Measured and dropped in between: counting-sorted per-tile record lists, so that an owner walks only its records.  The
-//  owners became gather bound -- 0.37-0.43 ms against 0.32 -- because a list that is not in sample order loses the 2-3
-//  samples per 128-byte line that neighbouring lanes share, and the sort itself took longer than the owners.)
+// (Round 3 measured two ways of sparing the owners their tests, both bit-identical, neither kept -- tools/exp/bwd_sort.py,
+//  profiles/r03_bwd_sorted_variants.json, r03_bwd_bitmap_variants.json, the code is in the history:
+//  * counting-sorted per-tile record lists, so that an owner walks only its own records: the owners became GATHER bound
+//    -- 0.37-0.43 ms per workgroup against 0.32; 0.164 ms with the gathers stubbed out -- because a list that is not in
+//    sample order loses the 2-3 queued samples per 128-byte line that neighbouring lanes share, and the sort pass took
+//    0.65 ms;
+//  * one bit per (tile, sample) instead of the codes, expanded to queue entries with a wave scan: owners 0.325 ->
+//    0.277 ms per workgroup, but the kernel ends with its burstiest level (0.31 ms) and the pre-pass grew by 0.085 ms.
+//  What an owner costs is the drain: gather 20 B per queued sample, ~95 instructions and two 64-bit LDS atomics per
+//  combination; tests, gathers and LDS are within 2x of each other, so removing one of them moves little.)
 
 __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
                                                          const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
-                                                         uint32_t* __restrict__ escape, uint32_t* __restrict__ bitmaps, int64_t n,
+                                                         uint32_t* __restrict__ escape, int64_t n,
                                                          const int64_t* __restrict__ n_dev) {
     const int64_t n_live = live_count(n, n_dev);            // n: capacity = stride of dfeat / codes; n_live: samples present
     __shared__ uint32_t esc_block;
-    // bitmap staging: [row][kCodeChunksPerBlock * 4 waves] 64-bit words as pairs of 32-bit halves (ds_or_b32)
-    extern __shared__ uint32_t lbits[];     // tp.bm_rows * kCodeChunksPerBlock * 8 words
-    if (bitmaps) {
-        for (int b = threadIdx.x; b < tp.bm_rows * kCodeChunksPerBlock * 8; b += 256) lbits[b] = 0u;
-    }
-    for (int chunk = 0; chunk < kCodeChunksPerBlock; ++chunk) {
-    __syncthreads();
     if (threadIdx.x == 0) esc_block = 0u;
     __syncthreads();
     uint32_t esc = 0u;                  // bit l: level l must take the generic owners (see below)
-    const int64_t word = (int64_t)blockIdx.x * kCodeChunksPerBlock + chunk;
-    if (word * kCodeSamplesPerBlock >= n) break;            // (uniform)
-    const int64_t i0 = word * kCodeSamplesPerBlock;
+    const int64_t i0 = (int64_t)blockIdx.x * kCodeSamplesPerBlock;
     for (int64_t i = i0 + threadIdx.x; i < n_live && i < i0 + kCodeSamplesPerBlock; i += 256) {
         const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
         for (int l = 0; l < gp.n_levels; ++l) {
             const int slot = tp.code_slot[l];
-            const int row0 = bitmaps ? tp.bm_row[l] : -1;
-            if (slot < 0 && row0 < 0) continue;
+            if (slot < 0) continue;
             const float py = grid_pos(y, gp.scale[l]), pz = grid_pos(z, gp.scale[l]);
             const uint32_t gy = (uint32_t)(int32_t)floorf(py), gz = (uint32_t)(int32_t)floorf(pz);
             const uint32_t gx = (uint32_t)(int32_t)floorf(grid_pos(x, gp.scale[l]));
@@ -605,70 +587,41 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
                     code |= b << (8 * c);
                 }
             }
-            if (slot >= 0) codes[(int64_t)slot * tp.n_pad + i] = code;
+            codes[(int64_t)slot * tp.n_pad + i] = code;
             if (bad) {      // harmless without gradient; with gradient the level's owners take the generic path
                 const float2 g = dfeat[(int64_t)l * n + i];
                 if (!(g.x == 0.f && g.y == 0.f)) esc |= 1u << l;
-            }
-            if (row0 >= 0) {        // (hashed level) this sample's bit in the rows of the tiles it names
-                const int half = (chunk * 4 + (int)(threadIdx.x >> 6)) * 2 + (int)((threadIdx.x >> 5) & 1u);
-                const uint32_t bit = 1u << (threadIdx.x & 31u);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    atomicOr(&lbits[(row0 + (int)((code >> (8 * c)) & 0xffu)) * (kCodeChunksPerBlock * 8) + half], bit);
             }
         }
     }
     if (esc) atomicOr(&esc_block, esc);
     __syncthreads();
-    if (threadIdx.x == 0) escape[word] = esc_block;             // every word is written: no zero-fill needed
-    }
-    if (bitmaps) {          // rows are written in runs of 32 halves = 128 bytes per workgroup
-        __syncthreads();
-        constexpr int kHalves = kCodeChunksPerBlock * 8;
-        for (int b = threadIdx.x; b < tp.bm_rows * kHalves; b += 256)
-            bitmaps[(int64_t)(b / kHalves) * tp.bm_row_halves + (int64_t)blockIdx.x * kHalves + (b % kHalves)] = lbits[b];
-    }
+    if (threadIdx.x == 0) escape[blockIdx.x] = esc_block;       // every word is written: no zero-fill needed
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// inclusive prefix sum over the 64 lanes of a wave (DPP: shifts inside rows of 16, then row broadcasts)
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
-    return v;
-}
-
 // The loads of this loop are issued through inline assembly with hand-placed s_waitcnt: the compiler's own
 // placement waits for a gather right where it is issued (it packs the loaded y,z into a register pair for a packed
 // multiply) and drains vmcnt to 0 around the conditional drain.  VMEM loads return in issue order, so
 // "vmcnt(k)" = "everything but the k youngest loads has landed"; the number of loads issued per step is static
-// (2 code loads -- BITMAP: 1 byte load --, then 3 gather loads per drain, idle lanes gather sample 0).
-// BITMAP (hashed levels): codes_l is the tile's bitmap row; a lane takes the 4 bits of its group of 4 samples and queue
-// entries start without combinations (low nibble 0), which the drain derives from the gathered (y,z).
-template <bool FIXED, bool DENSE, bool BITMAP = false>
+// (2 code loads, then 3 gather loads per drain, idle lanes gather sample 0).
+template <bool FIXED, bool DENSE>
 __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_tile, uint32_t* queue,
                                                  const uint32_t* __restrict__ codes_l, const float* __restrict__ x01,
                                                  const float2* __restrict__ g_l, int64_t n, int rep, int R) {
-    static_assert(!(BITMAP && DENSE), "bitmaps are for hashed levels");
     // (tells the compiler's own wait-count bookkeeping that nothing it knows of is in flight when the loop starts;
     //  otherwise it drains vmcnt to 0 at the head of every iteration on behalf of the other streaming variants)
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t qn = 0;                                    // wave-uniform queue fill
-    const int64_t n_full = BITMAP ? (n + 3) / 4 : n / 4;    // (bits past the last sample are 0: no ragged tail)
+    const int64_t n_full = n / 4;
     const int64_t g_lo = n_full * rep / R, g_hi = n_full * (rep + 1) / R;       // this replica's groups of 4 samples
     // registers written by loads in flight: only ever read through the wait_* copies below
     float ld_x = 0.f; f32x2 ld_yz = {0.f, 0.f}, ld_g = {0.f, 0.f}; u32x2 ld_c0 = {0u, 0u}, ld_c1 = {0u, 0u};
     uint32_t bcm = 0, bi = 0;                           // (y,z) combinations and sample index of the batch in flight
-    bool blive = false;                                 // this lane holds an entry of the batch in flight
     const uint32_t t_split = 0x80u | cx.t, t_next = 0x80u | ((cx.t - 1u) & (cx.n_tiles - 1u));     // dense codes
     auto test = [&](uint32_t code) {
         uint32_t cm = 0;
@@ -688,26 +641,10 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
             qn += (uint32_t)__popcll(b);
         }
     };
-    // BITMAP: the set bits of every lane's nibble become entries, in sample order (one wave scan per 256 samples)
-    auto enqueue_bits = [&](uint32_t bits, uint32_t i0) {
-        const uint32_t cnt = (uint32_t)__popc(bits);
-        const uint32_t incl = wave_inclusive_sum(cnt);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t base = qn + incl - cnt;
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if (bits & (1u << b)) queue[base + (uint32_t)__popc(bits & ((1u << b) - 1u))] = (i0 + (uint32_t)b) << 4;
-        qn += total;
-    };
-    auto load_codes = [&](int64_t grp) {                // 2 loads (BITMAP: 1)
-        if (BITMAP) {
-            const uint32_t off = (uint32_t)((grp < g_hi ? grp : g_hi - 1) >> 1);
-            asm volatile("global_load_ubyte %0, %1, %2" : "=&v"(ld_c0.x) : "v"(off), "s"(codes_l) : "memory");
-        } else {
-            const uint32_t off = (uint32_t)(grp < g_hi ? grp : g_hi - 1) * 16u;
-            asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dwordx2 %1, %2, %3 offset:8"
-                         : "=&v"(ld_c0), "=&v"(ld_c1) : "v"(off), "s"(codes_l) : "memory");
-        }
+    auto load_codes = [&](int64_t grp) {                // 2 loads
+        const uint32_t off = (uint32_t)(grp < g_hi ? grp : g_hi - 1) * 16u;
+        asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dwordx2 %1, %2, %3 offset:8"
+                     : "=&v"(ld_c0), "=&v"(ld_c1) : "v"(off), "s"(codes_l) : "memory");
     };
     auto pop_and_gather = [&]() {       // up to 64 queued samples: issue the 3 loads of their position and gradient
         const uint32_t take = qn < 64u ? qn : 64u;
@@ -716,7 +653,6 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
         if (lane < take) e = queue[qn - take + lane];
         __builtin_amdgcn_wave_barrier();
         qn -= take;
-        blive = lane < take;
         bcm = e & 15u;
         bi = e >> 4;
         const uint32_t ox = bi * 12u, og = bi * 8u;
@@ -732,26 +668,18 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     // The batch gathered one drain ago.  Every lane applies ONE combination (loop-free at full occupancy); the 7 % of
     // samples that name this tile with two or more combinations go back into the queue with the remaining ones.
     auto apply_batch = [&](float bx, f32x2 byz, f32x2 bg) {
-        const float py = grid_pos(byz.x, cx.scale), pz = grid_pos(byz.y, cx.scale);
-        const float fly = floorf(py), flz = floorf(pz);
-        const uint32_t ay0 = (uint32_t)(int32_t)fly * (DENSE ? cx.res : kPrimeY), az0 = (uint32_t)(int32_t)flz * (DENSE ? cx.r2 : kPrimeZ);
-        if (BITMAP && blive && bcm == 0u) {     // fresh entry: which of the 4 (y,z) combinations fall in this tile
-            const uint32_t ay1 = ay0 + kPrimeY, az1 = az0 + kPrimeZ;
-            bcm = ((((ay0 ^ az0) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 1u : 0u) |
-                  ((((ay1 ^ az0) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 2u : 0u) |
-                  ((((ay0 ^ az1) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 4u : 0u) |
-                  ((((ay1 ^ az1) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 8u : 0u);
-        }
         const uint32_t rest = DENSE ? 0u : bcm & (bcm - 1u);        // (dense tiles are named by several combinations as a rule)
         if (!DENSE) bcm &= 0u - bcm;
         if (bcm) {
-            const float px = grid_pos(bx, cx.scale);
-            const float flx = floorf(px);
+            const float px = grid_pos(bx, cx.scale), py = grid_pos(byz.x, cx.scale), pz = grid_pos(byz.y, cx.scale);
+            const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
             const uint32_t gx = (uint32_t)(int32_t)flx;
             if (DENSE)
-                apply_pairs_dense<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz, ay0, az0, bcm);
+                apply_pairs_dense<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz,
+                                         (uint32_t)(int32_t)fly * cx.res, (uint32_t)(int32_t)flz * cx.r2, bcm);
             else if (gx < (uint32_t)(kTileEntries - 1))      // (else: zero gradient, see tile_codes_kernel)
-                apply_pairs<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz, ay0, az0, bcm);
+                apply_pairs<FIXED>(cx, lds_tile, make_float2(bg.x, bg.y), gx, px - flx, py - fly, pz - flz,
+                                   (uint32_t)(int32_t)fly * kPrimeY, (uint32_t)(int32_t)flz * kPrimeZ, bcm);
         }
         if (!DENSE) enqueue(rest, bi);
     };
@@ -760,21 +688,16 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
         load_codes(grp);
         pop_and_gather();               // empty queue: dummy gather, keeps the in-flight count of the loop static
         for (int64_t base = g_lo + (int64_t)(threadIdx.x & ~63u); base < g_hi; base += kBwdThreads) {   // wave-uniform trip count
-            u32x2 c0, c1 = {0u, 0u};    // in flight, oldest first: the code loads, 3 gather loads
-            if (BITMAP) asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b32 %0, %1" : "=&v"(c0.x) : "v"(ld_c0.x) : "memory");
-            else asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(c0), "=&v"(c1) : "v"(ld_c0), "v"(ld_c1) : "memory");
+            u32x2 c0, c1;               // in flight, oldest first: 2 code loads, 3 gather loads
+            asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(c0), "=&v"(c1) : "v"(ld_c0), "v"(ld_c1) : "memory");
             const int64_t g0 = grp;
             const bool valid = g0 < g_hi;
             grp += kBwdThreads;
             load_codes(grp);
-            if (BITMAP) {
-                enqueue_bits(valid ? (c0.x >> (4u * ((uint32_t)g0 & 1u))) & 15u : 0u, (uint32_t)(4 * g0));
-                PERF_WAIT_BATCH(1);     // all but the byte load
-                apply_batch(bx, byz, bg);
-            } else {
-                const uint32_t cs[4] = {c0.x, c0.y, c1.x, c1.y};
+            const uint32_t cs[4] = {c0.x, c0.y, c1.x, c1.y};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
+            for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
+            {
                 PERF_WAIT_BATCH(2);     // all but the 2 code loads
                 apply_batch(bx, byz, bg);
             }
@@ -786,14 +709,14 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
             }
         }
     }
-    if (!BITMAP && threadIdx.x < 64 && rep == 0) {      // ragged tail (n % 4 samples)
+    if (threadIdx.x < 64 && rep == 0) {                 // ragged tail (n % 4 samples)
         const int64_t i = n_full * 4 + lane;
         enqueue(i < n ? test(codes_l[i]) : 0u, (uint32_t)i);
     }
     for (;;) {
         PERF_WAIT_BATCH(0);
         apply_batch(bx, byz, bg);
-        bcm = 0; blive = false;
+        bcm = 0;
         if (qn == 0u) break;
         pop_and_gather();
     }
@@ -957,7 +880,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    int32_t* __restrict__ shifts_ws,
                                                                    const uint32_t* __restrict__ codes,
                                                                    const uint32_t* __restrict__ escape,
-                                                                   const uint32_t* __restrict__ bitmaps, int64_t n,
+                                                                   int64_t n,
                                                                    const int64_t* __restrict__ n_dev) {
     const int64_t n_live = live_count(n, n_dev);            // samples present; n stays the stride of dfeat / codes
     extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats (+ the wave queues)
@@ -997,7 +920,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         if (shifts_ws && t == 0u && rep == 0 && threadIdx.x == 0) shifts_ws[l] = sh;
     }
     const float2* g_l = dfeat + (int64_t)l * n;
-    bool coded = (codes && tp.code_slot[l] >= 0) || (bitmaps && tp.bm_row[l] >= 0);
+    bool coded = codes && tp.code_slot[l] >= 0;
     if (coded) {                        // any escape bit for this level in the pre-pass blocks' words?
         __shared__ uint32_t esc_any;
         if (threadIdx.x == 0) esc_any = 0u;
@@ -1010,10 +933,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         coded = esc_any == 0u;
     }
     uint32_t* queue = reinterpret_cast<uint32_t*>(lds_tile + 2 * kTileEntries) + (threadIdx.x >> 6) * kQueueCap;
-    if (coded && hashed && bitmaps && tp.bm_row[l] >= 0)
-        bwd_stream_codes<FIXED, false, true>(cx, lds_tile, queue, reinterpret_cast<const uint32_t*>(bitmaps + (int64_t)(tp.bm_row[l] + (int)t) * tp.bm_row_halves),
-                                             x01, g_l, n_live, rep, R);
-    else if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
+    if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (coded) bwd_stream_codes<FIXED, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n_live, rep, R);
     else bwd_stream<FIXED, false>(cx, lds_tile, x01, g_l, n_live, rep, R, tp.run_merge != 0);
@@ -1520,60 +1440,16 @@ static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
 
 constexpr int64_t kShiftBytes = 256;        // per-level shifts the owners leave for the replica reduction
 
-// per-tile bitmaps of the hashed coded levels (plan_codes ran before: those levels give their code slot back); returns the
-// number of rows.  PERF_BWD_BITMAP=0 keeps the codes (dev switch).
-static int plan_bitmaps(const GridParams& gp, int64_t n, TileParams* tp, int* slots) {
-    for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp->bm_row[l] = -1;
-    tp->bm_rows = 0;
-    tp->bm_row_halves = div_up(n, (int64_t)kCodeSamplesPerBlock * kCodeChunksPerBlock) * (kCodeChunksPerBlock * 8);
-    const char* e = getenv("PERF_BWD_BITMAP");
-    if ((e && atoi(e) == 0) || n == 0) return 0;
-    int rows = 0;
-    for (int l = 0; l < gp.n_levels; ++l)
-        if (tp->code_slot[l] >= 0 && gp.hashed[l]) rows += tp->tiles_of[l];
-    if (rows == 0 || rows > kMaxBitmapRows) return 0;
-    rows = 0;
-    int kept = 0;
-    for (int l = 0; l < gp.n_levels; ++l) {
-        if (tp->code_slot[l] < 0) continue;
-        if (gp.hashed[l]) { tp->bm_row[l] = rows; rows += tp->tiles_of[l]; tp->code_slot[l] = -1; }
-        else tp->code_slot[l] = kept++;
-    }
-    tp->bm_rows = rows;
-    *slots = kept;
-    return rows;
-}
-
-static bool run_merge_enabled() { const char* e = getenv("PERF_BWD_RUNS"); return !(e && atoi(e) == 0); }
-
-// replica slabs: the largest of the plans a call may pick (fp32 / fixed point, sorted or not)
-static int64_t max_slab_entries(const GridParams& gp) {
-    int64_t best = 0;
-    for (int k = 0; k < 4; ++k) { TileParams t; int nb; int64_t w; plan_tiles(gp, (k & 1) != 0, (k & 2) != 0, &t, &nb, &w); if (w > best) best = w; }
-    return best;
-}
-
-struct BwdLayout { int64_t shifts_at, dbg_at, codes_at, esc_at, bits_at, end; };
-
-static BwdLayout bwd_layout(const GridParams& gp, int64_t n, int slots, int64_t n_pad, int bm_rows, int64_t bm_row_halves) {
-    BwdLayout L;
-    L.shifts_at = (max_slab_entries(gp) * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
-    L.dbg_at = L.shifts_at + kShiftBytes;
-    L.codes_at = L.dbg_at + kDbgBytes;
-    L.esc_at = L.codes_at + (int64_t)slots * n_pad * 4;
-    L.bits_at = (L.esc_at + ((slots || bm_rows) ? div_up(n, kCodeSamplesPerBlock) * 4 : 0) + 15) & ~(int64_t)15;
-    L.end = L.bits_at + (int64_t)bm_rows * bm_row_halves * 4;
-    return L;
-}
-
 extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n) {
     GridParams gp;
     if (fill_params(grid, &gp)) return -1;
     TileParams tp; int nb; int64_t ws;
-    plan_tiles(gp, true, false, &tp, &nb, &ws);
-    int slots = plan_codes(gp, n, &tp);
-    const int rows = plan_bitmaps(gp, n, &tp, &slots);
-    return bwd_layout(gp, n, slots, tp.n_pad, rows, tp.bm_row_halves).end + 16;
+    int64_t ws2;
+    plan_tiles(gp, false, &tp, &nb, &ws);
+    plan_tiles(gp, true, &tp, &nb, &ws2);
+    const int slots = plan_codes(gp, n, &tp);
+    return (ws > ws2 ? ws : ws2) * (int64_t)sizeof(float2) + 16 + kShiftBytes + kDbgBytes + (int64_t)slots * tp.n_pad * 4 +
+           (slots ? div_up(n, kCodeSamplesPerBlock) * 4 : 0);
 }
 
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
@@ -1591,57 +1467,37 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     TileParams tp;
     int n_blocks = 0;
     int64_t ws_entries = 0;
-    plan_tiles(gp, fixed, false, &tp, &n_blocks, &ws_entries);
-    static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
-    // workspace layout: [replica slabs (largest plan)][shifts][debug slots][tile codes][escape words][per-tile bitmaps]
-    const int slots_all = plan_codes(gp, n, &tp);
-    int slots = slots_all;
-    const bool aligned_ws = (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
-    int rows = (no_codes || !aligned_ws) ? 0 : plan_bitmaps(gp, n, &tp, &slots);
-    BwdLayout L = bwd_layout(gp, n, slots, tp.n_pad, rows, tp.bm_row_halves);
-    if (rows > 0 && workspace_bytes < L.end) {      // no room for the bitmaps: codes for every coded level
-        slots = plan_codes(gp, n, &tp);
-        for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.bm_row[l] = -1;
-        tp.bm_rows = 0; rows = 0;
-        L = bwd_layout(gp, n, slots, tp.n_pad, 0, tp.bm_row_halves);
-    }
-    if (rows == 0) { for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.bm_row[l] = -1; tp.bm_rows = 0; }
-    const bool use_codes = (slots > 0 || rows > 0) && n > 0 && !no_codes && aligned_ws && workspace_bytes >= L.end;
-    const bool fast = use_codes && rows > 0;
-    if (fast) {                             // bitmap owners cost less per workgroup: the dense levels get more replicas
-        const TileParams keep = tp;
-        plan_tiles(gp, fixed, true, &tp, &n_blocks, &ws_entries);
-        for (int l = 0; l < PERF_MAX_LEVELS; ++l) { tp.code_slot[l] = keep.code_slot[l]; tp.bm_row[l] = keep.bm_row[l]; }
-        tp.bm_rows = keep.bm_rows; tp.bm_row_halves = keep.bm_row_halves; tp.n_pad = keep.n_pad;
-    }
-    tp.run_merge = run_merge_enabled() ? 1 : 0;
+    plan_tiles(gp, fixed, &tp, &n_blocks, &ws_entries);
     PERF_REQUIRE(!(raw_fields || shifts_dev) || tp.atomic_levels == 0u,
                  "perf_hashgrid_bwd: raw fields / given units are not available for levels beyond 4 M entries");
+    { const char* e = getenv("PERF_BWD_RUNS"); tp.run_merge = (e && atoi(e) == 0) ? 0 : 1; }     // (dev switch)
     tp.accumulate = accumulate;
     tp.raw_out = raw_fields ? 1 : 0;
     tp.dbg_off = 0;
-    const int64_t shifts_at = L.shifts_at;
+    int64_t slab_entries = ws_entries;      // workspace layout: [replica slabs (larger of both modes)][shifts][debug slots][tile codes]
+    { TileParams t2; int nb2; int64_t w2; plan_tiles(gp, !fixed, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2; }
+    const int64_t shifts_at = (slab_entries * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
     PERF_REQUIRE(workspace && workspace_bytes >= shifts_at + kShiftBytes,
                  "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(shifts_at + kShiftBytes));
     int32_t* shifts_ws = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + shifts_at);
-    const int64_t dbg_at = L.dbg_at;
+    const int64_t dbg_at = shifts_at + kShiftBytes;
+    static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
     if (dbg_env && workspace_bytes >= dbg_at + kDbgBytes) tp.dbg_off = dbg_at / (int64_t)sizeof(float2);
-    // tile codes of the multi-tile levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
+    // tile codes of the hashed levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
+    const int slots = plan_codes(gp, n, &tp);
+    const int64_t codes_at = dbg_at + kDbgBytes;
     uint32_t* codes = nullptr;
     uint32_t* escape = nullptr;
-    uint32_t* bitmaps = nullptr;
-    if (use_codes) {
-        char* base = reinterpret_cast<char*>(workspace);
-        codes = reinterpret_cast<uint32_t*>(base + L.codes_at);
-        escape = reinterpret_cast<uint32_t*>(base + L.esc_at);
-        if (rows > 0) bitmaps = reinterpret_cast<uint32_t*>(base + L.bits_at);
-        const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
-        tile_codes_kernel<<<dim3((unsigned)div_up(esc_words, kCodeChunksPerBlock)), dim3(256), (size_t)rows * kCodeChunksPerBlock * 8 * 4, as_stream(stream)>>>(
-            gp, tp, x01, (const float2*)dfeat, codes, escape, bitmaps, n, n_dev);
+    const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
+    if (slots > 0 && n > 0 && !no_codes && ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0) &&
+        workspace_bytes >= codes_at + (int64_t)slots * tp.n_pad * 4 + esc_words * 4) {
+        codes = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + codes_at);
+        escape = codes + (int64_t)slots * tp.n_pad;
+        tile_codes_kernel<<<dim3((unsigned)esc_words), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
+                                                                                             codes, escape, n, n_dev);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(codes)");
     } else {
-        for (int l = 0; l < PERF_MAX_LEVELS; ++l) { tp.code_slot[l] = -1; tp.bm_row[l] = -1; }
-        tp.bm_rows = 0;
+        for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.code_slot[l] = -1;
     }
     const int lds_bytes = 2 * kTileEntries * (int)sizeof(float) + (kBwdThreads / 64) * kQueueCap * (int)sizeof(uint32_t);
     static std::once_flag attr_once;                // one-time kernel attribute setup, safe under concurrent callers
@@ -1654,11 +1510,11 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     } else if (fixed)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, headroom_state,
-            shifts_dev, shifts_ws, codes, escape, bitmaps, n, n_dev);
+            shifts_dev, shifts_ws, codes, escape, n, n_dev);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, nullptr, nullptr, nullptr,
-            codes, escape, bitmaps, n, n_dev);
+            codes, escape, n, n_dev);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (tp.atomic_levels && n > 0) {
         if (!accumulate)

@@ -551,11 +551,11 @@ def test_hashgrid_bwd_coded_owners_equal_streaming_owners(ops):
         assert float((a_f32 - b_f32).abs().max()) <= 1e-4 * float(b_f32.abs().max()), kind
 
 
-def test_hashgrid_bwd_bitmap_owners_equal_streaming_owners(ops, monkeypatch):
-    """The hashed owners that read per-tile bitmaps (default) and the run-merging coarse owners compute the same
-    fixed-point sums as the position-streaming owners and as the code-streaming ones: bit-identical tables -- ragged
-    sizes, ray-coherent runs, positions outside the unit cube (escape to the generic owners), a live count below the
-    capacity, and the full 1 M-sample batch of the benchmark."""
+def test_hashgrid_bwd_run_merging_owners_equal_streaming_owners(ops, monkeypatch):
+    """The coarse owners that sum runs of samples sharing a cell in registers before they touch LDS (default) compute
+    the same fixed-point sums as the plain owners, coded or position streaming: bit-identical tables -- ragged sizes,
+    ray-coherent runs, positions outside the unit cube (index wrap), a live count below the capacity, and the full
+    1 M-sample batch of the benchmark."""
     cfg = _grid_cfg()
     g = torch.Generator().manual_seed(22)
     for n, kind, live in ((4099, 'uniform', None), (65536 + 3, 'rays', None), (30001, 'outside', None), (50000, 'rays', 31111),
@@ -576,10 +576,10 @@ def test_hashgrid_bwd_bitmap_owners_equal_streaming_owners(ops, monkeypatch):
         amax = dfeat.abs().amax(dim=(1, 2)).contiguous()
         amax = torch.cat([amax, torch.zeros(16 - amax.numel(), device='cuda')])
         n_dev = None if live is None else torch.tensor([live], dtype=torch.int64, device='cuda')
-        monkeypatch.setenv('PERF_BWD_BITMAP', '1'); monkeypatch.setenv('PERF_BWD_RUNS', '1')
+        monkeypatch.setenv('PERF_BWD_RUNS', '1')
         a_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, n_dev=n_dev)
         a_f32 = ops.hashgrid_bwd(cfg, x, dfeat, n_dev=n_dev)
-        monkeypatch.setenv('PERF_BWD_BITMAP', '0'); monkeypatch.setenv('PERF_BWD_RUNS', '0')
+        monkeypatch.setenv('PERF_BWD_RUNS', '0')
         c_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, n_dev=n_dev)
         b_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, use_codes=False, n_dev=n_dev)
         b_f32 = ops.hashgrid_bwd(cfg, x, dfeat, use_codes=False, n_dev=n_dev)

@@ -1,4 +1,4 @@
-"""Dev tool: the grid backward's owner variants (PERF_BWD_BITMAP / PERF_BWD_RUNS) -- equality of the fixed-point gradients,
+"""Dev tool: the grid backward's owner variants (PERF_BWD_RUNS; PERF_BWD_SORT / PERF_BWD_BITMAP in the commits that had them) -- equality of the fixed-point gradients,
 ms per call, per-workgroup times by level.    python tools/exp/bwd_sort.py [out.json]"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

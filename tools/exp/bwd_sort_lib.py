@@ -26,8 +26,10 @@ def batch(kind, n, seed=0):
     return x, dfeat, amax
 
 
-def setenv(bitmap, runs):
-    os.environ['PERF_BWD_BITMAP'] = str(bitmap); os.environ['PERF_BWD_RUNS'] = str(runs)
+def setenv(variant, runs):
+    # variant: PERF_BWD_SORT (commit 'counting-sorted per-tile records') / PERF_BWD_BITMAP (commit 'per-tile bitmaps'); the
+    # shipped library only knows PERF_BWD_RUNS
+    os.environ['PERF_BWD_BITMAP'] = str(variant); os.environ['PERF_BWD_SORT'] = str(variant); os.environ['PERF_BWD_RUNS'] = str(runs)
 
 
 def call(x, dfeat, amax, n_dev=None, fixed=True, ws=None, out=None):
@@ -58,7 +60,7 @@ def block_times(ws, n, fast):
     cyc = ws[2 * off:2 * off + 1200].view(torch.int64).cpu().numpy()
     tiles = [max(1, -(-int(s) // 16384)) for s in cfg.size]
     tiles = [t_ if cfg.hashed[l] else 1 << (t_ - 1).bit_length() for l, t_ in enumerate(tiles)]
-    rs = [int(v) for v in os.environ.get('PERF_BWD_REPLICAS', ('10,4,3' if fast else '8,3,2')).split(',')]
+    rs = [int(v) for v in os.environ.get('PERF_BWD_REPLICAS', '8,3,2').split(',')]
     reps = [1 if cfg.hashed[l] else (rs[0] if t_ == 1 else rs[1] if t_ <= 4 else rs[2] if t_ <= 16 else 1) for l, t_ in enumerate(tiles)]
     b = 0; rows = []
     for l in range(16):
