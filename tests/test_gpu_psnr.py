@@ -58,7 +58,7 @@ def test_psnr_at_iter_matches_the_oracle_curve():
     # the geometry phase's LEARNING curve (the eval depth error above is fixed by the occupancy shell from the first
     # iteration and carries no information about learning): mean training depth loss of iterations k-10..k-1 -- 0.41 at
     # k = 30, 0.005 at k = 100 for the oracle -- must follow the oracle's on every seed, and the field must end as opaque
-    print('HIP / oracle training depth loss:', {k: [round(v, 3) for v in vs] for k, vs in geo_ratio.items()}, 'opacity delta:', [round(v, 5) for v in opacity])
+    print('HIP / oracle training depth loss:', {k: [round(v, 5) for v in vs] for k, vs in geo_ratio.items()}, 'opacity delta:', [round(v, 5) for v in opacity])
     for k, vs in geo_ratio.items():
         assert 0.93 <= float(np.mean(vs)) <= 1.07 and all(0.85 <= v <= 1.15 for v in vs), (k, vs)
     assert all(abs(v) < 5e-3 for v in opacity), opacity
