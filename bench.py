@@ -173,6 +173,16 @@ def psnr_at_iters(args, dev, dist_mod, rank, world):
                     'tests/test_gpu_psnr.py against tests/golden/psnr_curve.json'}
 
 
+def _flush_native_stdout():
+    """Python's and the C library's stdout buffers (RCCL writes its banner with printf)."""
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:       # noqa: BLE001 -- cosmetic
+        pass
+
+
 def _free_port():
     sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close(); return port
 
@@ -205,7 +215,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # PERF_DP_SINGLE_RANK=1 (dev): a world of ONE rank on the real RCCL backend takes the data-parallel path -- what the
+    # exchange machinery costs on one GPU, link time excluded
+    single_rank_dp = world == 1 and os.environ.get('PERF_DP_SINGLE_RANK') == '1'
+    if single_rank_dp:
+        for k, v in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', str(_free_port())), ('RANK', '0'), ('WORLD_SIZE', '1')):
+            os.environ.setdefault(k, v)
+    if world > 1 or single_rank_dp:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
@@ -355,6 +371,7 @@ def main():
 
         def bail():
             if rank == 0:
+                _flush_native_stdout()
                 print(json.dumps(safe), flush=True)
             os._exit(0)
         watchdog = threading.Timer(args.watchdog_seconds, bail)
@@ -424,13 +441,20 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
 
+    line = None
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.spp, args.cpu_rays)
         line = _line(args, world, head, run, sustained, kern, (marched_ev, kept_ev), reuse_block, other_block, psnr_block, cpu=cpu, notes=notes)
-        print(json.dumps(line), flush=True)
+    # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which a pipe buffers until the
+    # process exits -- every rank flushes it out first, then rank 0 prints.
+    _flush_native_stdout()
     if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1 or single_rank_dp:
         dist.destroy_process_group()
 
 

@@ -16,6 +16,7 @@ its slice; the local loss is pre-scaled so the summed gradient equals the 1-GPU 
 the active network's flat gradient per step.
 """
 import math
+import os
 from dataclasses import dataclass
 from types import SimpleNamespace
 
@@ -371,8 +372,11 @@ class NeRFScene:
     @staticmethod
     def _dist():
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return dist, dist.get_rank(), dist.get_world_size()
+        if dist.is_available() and dist.is_initialized():
+            # (PERF_DP_SINGLE_RANK=1: a world of ONE rank takes the data-parallel path too -- how a single-GPU box exercises
+            #  the RCCL exchange and its hipGraph capture, tests/test_gpu_dist.py)
+            if dist.get_world_size() > 1 or os.environ.get('PERF_DP_SINGLE_RANK') == '1':
+                return dist, dist.get_rank(), dist.get_world_size()
         return None, 0, 1
 
     # ---- rendering (nerf.py:74-123) --------------------------------------------------------------
@@ -538,7 +542,9 @@ class NeRFScene:
             else:
                 self.update_lr(optimizer, conf, iter_i / n_iters)
                 if kind == 'geo':
-                    step_fn(optimizer, sup_pool, progress=progress_of(iter_i), prefetch_next=iter_i + 1 < n_iters)
+                    # (no prefetch from the step before the capture: the captured step has to draw its own batch)
+                    last_eager = use_graphs and iter_i + 1 >= self.EAGER_HEAD
+                    step_fn(optimizer, sup_pool, progress=progress_of(iter_i), prefetch_next=iter_i + 1 < n_iters and not last_eager)
                 else:
                     step_fn(optimizer, sup_pool, progress=progress_of(iter_i))
             if callback:
@@ -971,11 +977,22 @@ class NeRFScene:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(warmup):
-                    step_fn(optimizer, sup_pool, progress=0.0)
+                    if kind == 'geo':
+                        step_fn(optimizer, sup_pool, progress=0.0, prefetch_next=False)
+                    else:
+                        step_fn(optimizer, sup_pool, progress=0.0)
             torch.cuda.current_stream().wait_stream(side)
         if schedule is not None:
             lrs, ratios, first = schedule
             optimizer.load_schedule(lrs, ratios if kind == 'geo' else None, first, ratio_out=self._ratio_dev if kind == 'geo' else None)
+        if kind == 'geo' and getattr(self, '_geo_pre', None) is not None:
+            # A batch the previous eager step prefetched (data parallelism) would be baked into the graph as constants -- every
+            # replay would train on it again.  The device generator is a pure function of (seed, counter): take the draw back,
+            # the captured step repeats it.
+            if not (self.device_rng and self._rng_counter is not None):
+                raise RuntimeError('make_graphed_step: a prefetched batch is pending; run the last eager geometry step with prefetch_next=False')
+            self._rng_counter -= 1
+            self._geo_pre = None
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         self._capturing = optimizer.capturing = True

@@ -86,6 +86,29 @@ def test_two_ranks_plain_allreduce_mode(tmp_path):
         assert float((two[k] - one[k]).norm()) < 0.1 * moved, (k, float((two[k] - one[k]).norm()), moved)
 
 
+def test_rccl_exchange_on_a_world_of_one(tmp_path):
+    """The real RCCL backend on this box's one GPU: a world of ONE rank takes the sharded data-parallel path
+    (PERF_DP_SINGLE_RANK=1) -- statistics all-gather, int32 reduce-scatter, Adam on the slice, all-gather of the 16-bit copy,
+    captured with the step in one hipGraph when the capture probe passes -- and must leave the episode with exactly the
+    parameters of the plain single process (the table gradient is an integer sum either way; with one rank the MLP
+    gradient is the same fp32 sum too)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
+    worker = os.path.join(ROOT, 'tests', 'rccl_single_worker.py')
+    res = {}
+    for mode in ('plain', 'rccl'):
+        out = str(tmp_path / f'{mode}.pt')
+        r = subprocess.run([sys.executable, worker, out, mode, '29581'], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        res[mode] = torch.load(out)
+    assert not res['plain']['dist'] and res['rccl']['dist']
+    print('RCCL collectives captured in the step graph:', res['rccl']['graph_verdict'])
+    assert res['rccl']['graph_verdict'] is not None                       # the probe ran (its verdict decides graph vs eager)
+    assert res['plain']['rng_counter'] == res['rccl']['rng_counter'] == 23
+    assert torch.equal(res['plain']['geo'], res['rccl']['geo'])
+    assert torch.equal(res['plain']['app'], res['rccl']['app'])
+    assert res['rccl']['counters'][4] == 0 and res['rccl']['counters'][5] == 0
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher (what the driver's scaling run does): bench.py spawns the ranks itself.
     Two ranks share this box's one GPU over gloo (PERF_BENCH_ONE_DEVICE / PERF_BENCH_BACKEND); the line carries the weak
