@@ -11,6 +11,7 @@ python tools/render_dense.py > $O/render_dense_16.json 2> $O/rd.err
 python tools/render_dense.py --batch 524288 > $O/render_dense_frame.json 2>> $O/rd.err
 python tools/train_episode.py > $O/train_episode.json 2> $O/ep.err
 python tools/exp/fwd_v2.py --out $O/fwd_v2.json > $O/fwd_v2.log 2>&1
+bash tools/exp/dp_single.sh > $O/dp_single.log 2>&1
 bash tools/exp/ep_prof.sh > $O/ep_prof.log 2>&1
 bash tools/exp/r03_profile.sh > $O/r03_profile.log 2>&1
 grep -E "passed|failed" $O/tests.log | tail -2; tail -1 $O/smoke.log; python - <<'P'
