@@ -182,7 +182,7 @@ int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const fl
  * is accepted and selects the slower position-streaming owners).  With n_dev the headroom follows the live count.
  * headroom_state (device, PERF_HEADROOM_STATE_WORDS int32, zero-initialised by the caller and then owned by the sequence
  * of calls on one table, may be NULL): closes the loop on the headroom -- every call records the largest field each level's
- * FINAL sums reached and the next call's h_l is corrected to keep it between 2^23 and 2^27 units (entries next to a
+ * FINAL sums reached and the next call's h_l is corrected to keep it between 2^21 and 2^25 units (16x below the level that raises the overflow flag) (entries next to a
  * panorama's common ray origin collect 30x the average number of contributions; hashed levels far fewer than the static
  * guess allows).  With the state the first call starts 3 bits on the safe side of the static h_l and h_l ranges over [4, 28].
  * Integer sums are exact and order independent: replicated (coarse) levels add their replicas as integers, so the table

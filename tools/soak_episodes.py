@@ -1,0 +1,43 @@
+"""Soak: N training episodes back to back on one scene object, the way core_exp_runner.py:170-221 drives NeRFScene (every
+episode resets the geometry field, rebuilds the occupancy and trains 3000 + 1500 iterations) -- watches what a single
+episode cannot show: the closed-loop fixed-point headroom across `reset_geo`, the device-side health counters, graph
+re-capture, memory growth, PSNR drift.
+
+  python tools/soak_episodes.py [--episodes 25] [--dtype bf16]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from perf_amd import synthetic, tcnn
+from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays, psnr
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--episodes', type=int, default=25)
+ap.add_argument('--geo', type=int, default=3000)
+ap.add_argument('--app', type=int, default=1500)
+ap.add_argument('--dtype', default='bf16')
+args = ap.parse_args()
+torch.manual_seed(0)
+scene = NeRFScene(dtype=args.dtype)
+H, W = 512, 1024
+rays = gen_pano_rays(torch.eye(4), H, W)
+dist, rgb = synthetic.room(rays.d)
+pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, dist)
+rows = []
+for ep in range(args.episodes):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    scene.train_one_episode(pool, args.geo, args.app)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    scene.set_eval()
+    out = scene.render(rays, ['rgb', 'distance'])
+    c = scene.sample_counters.tolist()
+    rows.append({'episode': ep, 'seconds': round(t1 - t0, 3), 'psnr_dB': round(psnr(out['rgb'], rgb), 3),
+                 'mean_abs_distance_err': round(float((out['distance'] - dist).abs().mean()), 5),
+                 'skipped_for_overflow': int(c[4]), 'skipped_for_truncation': int(c[5]), 'grid_gradient_mode': tcnn.GRID_GRAD_ACCUM,
+                 'sample_capacity': scene.renderer.sample_capacity, 'mem_alloc_MB': round(torch.cuda.memory_allocated() / 2 ** 20, 1),
+                 'mem_reserved_MB': round(torch.cuda.memory_reserved() / 2 ** 20, 1)})
+    print(json.dumps(rows[-1]), flush=True)
+ps = [r['psnr_dB'] for r in rows]
+print(json.dumps({'config': f'{args.episodes} episodes of {args.geo} + {args.app} iterations, 8192-ray batches, {W}x{H} panorama, {args.dtype}',
+                  'psnr_min_max': [min(ps), max(ps)], 'seconds_min_max': [min(r['seconds'] for r in rows), max(r['seconds'] for r in rows)],
+                  'skipped_for_overflow_total': rows[-1]['skipped_for_overflow'], 'skipped_for_truncation_total': rows[-1]['skipped_for_truncation'],
+                  'mem_reserved_MB_first_last': [rows[0]['mem_reserved_MB'], rows[-1]['mem_reserved_MB']], 'episodes': rows}))
