@@ -722,6 +722,10 @@ class NeRFScene:
             ex = ShardedExchange(net.mlp.n_params, net.grid.n_params, world, rank, Collectives(dist), net.params.device,
                                  ops.torch_dtype(net.dtype_name), _HipStepKernels(net, optimizer))
             ex.seed_working_copy(net.working_copy())
+            old = getattr(net, '_dp_exchange', None)
+            if old is not None and old.have_prev:      # a new optimizer on the same table (next episode): the closed loop on
+                ex.field_max.copy_(old.field_max)       # the headroom carries on, as the single process's state block does
+                ex.have_prev = True
             object.__setattr__(net, '_dp_exchange', ex)
         return ex
 

@@ -26,6 +26,7 @@ def main():
     pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, d_)
     scene.train_conf.pixel_loss_batch_size = 1024
     scene.train_one_episode(pool, 14, 9)
+    scene.train_one_episode(pool, 10, 7)         # a second episode: new geometry field, new optimizers, the colour table's state carries over
     torch.cuda.synchronize()
     info = {'geo': scene.nerf.geo_mlp.params.detach().cpu(), 'app': scene.nerf.app_mlp.params.detach().cpu(), 'mode': mode,
             'dist': scene._dist()[0] is not None, 'graph_verdict': S._DP_GRAPH_VERDICT, 'counters': scene.sample_counters.tolist(),

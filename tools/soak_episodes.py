@@ -3,8 +3,8 @@ episode resets the geometry field, rebuilds the occupancy and trains 3000 + 1500
 episode cannot show: the closed-loop fixed-point headroom across `reset_geo`, the device-side health counters, graph
 re-capture, memory growth, PSNR drift.
 
-  python tools/soak_episodes.py [--episodes 25] [--dtype bf16]"""
-import argparse, json, os, sys, time
+  python tools/soak_episodes.py [--episodes 25] [--dtype bf16] [--rccl-single-rank]"""
+import argparse, hashlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from perf_amd import synthetic, tcnn
@@ -15,7 +15,13 @@ ap.add_argument('--episodes', type=int, default=25)
 ap.add_argument('--geo', type=int, default=3000)
 ap.add_argument('--app', type=int, default=1500)
 ap.add_argument('--dtype', default='bf16')
+ap.add_argument('--rccl-single-rank', action='store_true', help='a world of one rank on the RCCL backend takes the data-parallel path (PERF_DP_SINGLE_RANK)')
 args = ap.parse_args()
+if args.rccl_single_rank:
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29593', RANK='0', WORLD_SIZE='1', PERF_DP_SINGLE_RANK='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
 torch.manual_seed(0)
 scene = NeRFScene(dtype=args.dtype)
 H, W = 512, 1024
@@ -30,14 +36,16 @@ for ep in range(args.episodes):
     scene.set_eval()
     out = scene.render(rays, ['rgb', 'distance'])
     c = scene.sample_counters.tolist()
-    rows.append({'episode': ep, 'seconds': round(t1 - t0, 3), 'psnr_dB': round(psnr(out['rgb'], rgb), 3),
+    digest = hashlib.sha256(scene.nerf.geo_mlp.params.detach().cpu().numpy().tobytes() + scene.nerf.app_mlp.params.detach().cpu().numpy().tobytes()).hexdigest()[:16]
+    rows.append({'episode': ep, 'params_sha256_16': digest, 'seconds': round(t1 - t0, 3), 'psnr_dB': round(psnr(out['rgb'], rgb), 3),
                  'mean_abs_distance_err': round(float((out['distance'] - dist).abs().mean()), 5),
                  'skipped_for_overflow': int(c[4]), 'skipped_for_truncation': int(c[5]), 'grid_gradient_mode': tcnn.GRID_GRAD_ACCUM,
                  'sample_capacity': scene.renderer.sample_capacity, 'mem_alloc_MB': round(torch.cuda.memory_allocated() / 2 ** 20, 1),
                  'mem_reserved_MB': round(torch.cuda.memory_reserved() / 2 ** 20, 1)})
     print(json.dumps(rows[-1]), flush=True)
 ps = [r['psnr_dB'] for r in rows]
-print(json.dumps({'config': f'{args.episodes} episodes of {args.geo} + {args.app} iterations, 8192-ray batches, {W}x{H} panorama, {args.dtype}',
+digest = rows[-1]['params_sha256_16']
+print(json.dumps({'params_sha256_16': digest, 'data_parallel': bool(args.rccl_single_rank), 'config': f'{args.episodes} episodes of {args.geo} + {args.app} iterations, 8192-ray batches, {W}x{H} panorama, {args.dtype}',
                   'psnr_min_max': [min(ps), max(ps)], 'seconds_min_max': [min(r['seconds'] for r in rows), max(r['seconds'] for r in rows)],
                   'skipped_for_overflow_total': rows[-1]['skipped_for_overflow'], 'skipped_for_truncation_total': rows[-1]['skipped_for_truncation'],
                   'mem_reserved_MB_first_last': [rows[0]['mem_reserved_MB'], rows[-1]['mem_reserved_MB']], 'episodes': rows}))
