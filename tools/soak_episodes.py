@@ -15,6 +15,9 @@ ap.add_argument('--episodes', type=int, default=25)
 ap.add_argument('--geo', type=int, default=3000)
 ap.add_argument('--app', type=int, default=1500)
 ap.add_argument('--dtype', default='bf16')
+ap.add_argument('--eager', action='store_true', help='no hipGraph replays (the digests must not change)')
+ap.add_argument('--no-reuse', action='store_true', help='strict two-encode order (the digests must not change)')
+ap.add_argument('--head', type=int, default=-1, help='renderer.head_samples (0: one-phase sampler; the kept samples -- and the digests -- must not change)')
 ap.add_argument('--rccl-single-rank', action='store_true', help='a world of one rank on the RCCL backend takes the data-parallel path (PERF_DP_SINGLE_RANK)')
 args = ap.parse_args()
 if args.rccl_single_rank:
@@ -24,6 +27,10 @@ if args.rccl_single_rank:
     dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
 torch.manual_seed(0)
 scene = NeRFScene(dtype=args.dtype)
+scene.graph_steps = not args.eager
+if args.head >= 0:
+    scene.renderer.head_samples = args.head or None
+scene.reuse_sampling_features = not args.no_reuse
 H, W = 512, 1024
 rays = gen_pano_rays(torch.eye(4), H, W)
 dist, rgb = synthetic.room(rays.d)
