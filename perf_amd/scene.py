@@ -460,6 +460,13 @@ class NeRFScene:
         return pre_grid
 
     def make_optimizer(self, net, lr):
+        # A new optimizer = a new phase on possibly new supervision: the closed loop on the fixed-point headroom starts over
+        # from its safe guess.  At the end of a phase the gradient is noise (an entry's contributions cancel: sums ~ sqrt(N)),
+        # on new data it is coherent (sums ~ N) -- a state tuned to the former lets the first steps of the latter run into the
+        # overflow flag, and the gate drops them (tools/mini_perf_loop.py: one step per newly registered panorama).
+        hr = getattr(net, 'headroom_state', None)
+        if hr is not None:
+            hr().zero_()
         return FusedAdam(net, lr) if self.fused_adam else torch.optim.Adam(net.parameters(), lr=lr)
 
     def train_one_episode(self, sup_pool, geo_res_iters, app_res_iters, warmup='direct', callback=None, use_graphs=None):
@@ -722,10 +729,6 @@ class NeRFScene:
             ex = ShardedExchange(net.mlp.n_params, net.grid.n_params, world, rank, Collectives(dist), net.params.device,
                                  ops.torch_dtype(net.dtype_name), _HipStepKernels(net, optimizer))
             ex.seed_working_copy(net.working_copy())
-            old = getattr(net, '_dp_exchange', None)
-            if old is not None and old.have_prev:      # a new optimizer on the same table (next episode): the closed loop on
-                ex.field_max.copy_(old.field_max)       # the headroom carries on, as the single process's state block does
-                ex.have_prev = True
             object.__setattr__(net, '_dp_exchange', ex)
         return ex
 

@@ -21,3 +21,37 @@ def room(d: torch.Tensor, half=(0.9, 0.7, 0.5)):
     rgb = (base[..., None] * tint) * (0.75 + 0.25 * sgn[..., None])
     scale = dist.max() * 1.05
     return (dist / scale)[..., None], rgb.clamp(0, 1)
+
+
+ROOM_SCALE = 1.05 * (0.9 ** 2 + 0.7 ** 2 + 0.5 ** 2) ** 0.5      # room() normalises distances by (largest distance) * 1.05
+
+
+def room_with_box(o: torch.Tensor, d: torch.Tensor, half=(0.9, 0.7, 0.5), box_c=(0.55, -0.35, -0.15), box_h=(0.12, 0.15, 0.3)):
+    """The room of room() in NORMALISED units (the units of the registered distances and of pose translations) seen from
+    arbitrary origins inside it, with an axis-aligned box standing in it -- so that views from other positions see surfaces
+    the first panorama does not (disocclusion: what PeRF's visibility masks are about).  o, d [..., 3] (d unit) ->
+    (distance [..., 1], rgb [..., 3]).  Same wall texture as room(); the box is textured with a finer pattern."""
+    dev = d.device
+    h = torch.tensor(half, dtype=torch.float32, device=dev) / ROOM_SCALE
+    dd = torch.where(d.abs() < 1e-12, torch.full_like(d, 1e-12), d)
+    t_wall = ((torch.sign(dd) * h - o) / dd)
+    dist_w, axis_w = t_wall.min(-1)
+    bc = torch.tensor(box_c, dtype=torch.float32, device=dev) / ROOM_SCALE
+    bh = torch.tensor(box_h, dtype=torch.float32, device=dev) / ROOM_SCALE
+    t1 = (bc - bh - o) / dd; t2 = (bc + bh - o) / dd
+    tn, tf = torch.minimum(t1, t2), torch.maximum(t1, t2)
+    t_in, axis_b = tn.max(-1)
+    hit = (t_in < tf.min(-1).values) & (t_in > 1e-6)
+    dist = torch.where(hit, t_in, dist_w)
+    axis = torch.where(hit, axis_b, axis_w)
+    p = (o + d * dist[..., None]) * ROOM_SCALE
+    uv = torch.tensor([[1, 2], [0, 2], [0, 1]], device=dev)[axis]
+    u = torch.gather(p, -1, uv[..., :1])[..., 0]
+    v = torch.gather(p, -1, uv[..., 1:])[..., 0]
+    k = torch.where(hit, torch.full_like(dist, 48.), torch.tensor([8., 16., 32.], device=dev)[axis])
+    base = 0.5 + 0.5 * torch.sin(k * u) * torch.sin(k * v)
+    tint = torch.tensor([[1.0, 0.6, 0.4], [0.4, 1.0, 0.6], [0.5, 0.6, 1.0]], device=dev)[axis]
+    tint = torch.where(hit[..., None], tint.flip(-1), tint)
+    sgn = torch.gather(torch.sign(d), -1, axis[..., None])[..., 0]
+    rgb = (base[..., None] * tint) * (0.75 + 0.25 * sgn[..., None])
+    return dist[..., None], rgb.clamp(0, 1)
