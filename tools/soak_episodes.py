@@ -18,6 +18,7 @@ ap.add_argument('--dtype', default='bf16')
 ap.add_argument('--eager', action='store_true', help='no hipGraph replays (the digests must not change)')
 ap.add_argument('--no-reuse', action='store_true', help='strict two-encode order (the digests must not change)')
 ap.add_argument('--head', type=int, default=-1, help='renderer.head_samples (0: one-phase sampler; the kept samples -- and the digests -- must not change)')
+ap.add_argument('--autograd', action='store_true', help='the drop-in path: torch autograd through the tinycudann / nerfacc module API and torch.optim.Adam (what an unmodified PeRF runs)')
 ap.add_argument('--rccl-single-rank', action='store_true', help='a world of one rank on the RCCL backend takes the data-parallel path (PERF_DP_SINGLE_RANK)')
 args = ap.parse_args()
 if args.rccl_single_rank:
@@ -28,6 +29,8 @@ if args.rccl_single_rank:
 torch.manual_seed(0)
 scene = NeRFScene(dtype=args.dtype)
 scene.graph_steps = not args.eager
+if args.autograd:
+    scene.fused_steps = False; scene.fused_adam = False
 if args.head >= 0:
     scene.renderer.head_samples = args.head or None
 scene.reuse_sampling_features = not args.no_reuse
