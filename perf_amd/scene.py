@@ -32,6 +32,19 @@ from .renderer import NeRFOCCRenderer
 from . import tcnn as _tcnn
 
 _DP_GRAPH_VERDICT = None
+
+def _capture(graph):
+    """torch.cuda.graph(graph) -- thread-local capture mode once a process group exists: ProcessGroupNCCL's watchdog thread
+    polls the events of EARLIER collectives (hipEventQuery) while this thread captures; under the default global mode that
+    poll fails with hipErrorStreamCaptureUnsupported and takes the process down (seen once in five runs of
+    tests/test_gpu_dist.py::test_rccl_exchange_on_a_world_of_one).  Thread-local mode checks only the capturing thread."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        torch.cuda.synchronize()                 # nothing of an earlier collective is left for the watchdog to wait for
+        return torch.cuda.graph(graph, capture_error_mode='thread_local')
+    return torch.cuda.graph(graph)
+
+
 OVERFLOW_CHECK_EVERY = 64      # training steps between reads of the fixed-point overflow flag (one host sync each)
 
 
@@ -518,7 +531,7 @@ class NeRFScene:
                 torch.cuda.synchronize()
                 t.fill_(1.0)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     dist.all_reduce(t, group=group)
                 t.fill_(1.0)
                 g.replay()
@@ -1004,7 +1017,7 @@ class NeRFScene:
         graph = torch.cuda.CUDAGraph()
         self._capturing = optimizer.capturing = True
         try:
-            with torch.cuda.graph(graph):
+            with _capture(graph):
                 step_fn(optimizer, sup_pool, progress=0.0)
         finally:
             self._capturing = optimizer.capturing = False
@@ -1079,7 +1092,7 @@ class NeRFScene:
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     body()
             finally:
                 r.sample_capacity = saved
