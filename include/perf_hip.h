@@ -178,8 +178,9 @@ int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const fl
  * 12, 24) (64x the average number of contributions an entry of the level sums); *overflow_flag (device int32, may be NULL) is OR-ed with 1
  * when any field comes within 4x of the int32 range (then repeat the call with level_absmax == NULL).
  * workspace: 16-byte aligned device scratch of perf_hashgrid_bwd_workspace_bytes(grid, n) bytes (replica slabs of
- * the coarse levels + 4 bytes per (sample, hashed level) of tile codes; a workspace without room for the codes
- * is accepted and selects the slower position-streaming owners).  With n_dev the headroom follows the live count.
+ * the coarse levels + 4 bytes per (sample, hashed level) of tile codes + tiles x n / 8 bytes of per-tile bitmaps for levels of
+ * 256-2048 hashed / 32-2048 dense tiles; a workspace without room for the codes is accepted and selects the slower
+ * position-streaming owners, one without room for the bitmaps the global-atomics scatter for those levels).  With n_dev the headroom follows the live count.
  * headroom_state (device, PERF_HEADROOM_STATE_WORDS int32, zero-initialised by the caller and then owned by the sequence
  * of calls on one table, may be NULL): closes the loop on the headroom -- every call records the largest field each level's
  * FINAL sums reached and the next call's h_l is corrected to keep it between 2^21 and 2^25 units (16x below the level that raises the overflow flag) (entries next to a
@@ -194,7 +195,8 @@ int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const fl
  *   raw_fields != 0: grad_table receives the int32 field pairs {feature 0, feature 1} of every entry instead of floats
  *     (same addresses, reinterpret as int32).  The ranks' tables are then summed exactly by an integer reduce-scatter and
  *     converted by perf_fixed_unfix: the result equals the single-process table bit for bit.  Needs accumulate == 0 and no
- *     level beyond 4 M entries. */
+ *     level on the global-atomics scatter (levels beyond 2048 tiles of 16,384 entries, or beyond 255 hashed / 64 dense tiles
+ *     when the workspace cannot hold their per-tile bitmaps: perf_hashgrid_bwd_workspace_bytes includes them up to 2 GiB). */
 #define PERF_HEADROOM_STATE_WORDS (2 * PERF_MAX_LEVELS + 8)
 int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n);
 int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,

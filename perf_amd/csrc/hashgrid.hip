@@ -288,6 +288,12 @@ struct TileParams {
     int32_t use_work;
     int32_t raw_out;                       // fixed point: the gradient table receives the int32 field pairs themselves (see perf_hashgrid_bwd)
     uint32_t atomic_levels;                // bit l: level l is too large for LDS owners (see hashgrid_bwd_atomic_kernel)
+    uint32_t bitmap_levels;                // bit l: hashed level of 256..kBitmapMaxTiles tiles whose owners read per-tile bitmaps (tile_bitmap_kernel)
+    int32_t bm_row[PERF_MAX_LEVELS];       // first bitmap row (= tile 0) of such a level, its index among them in bm_idx
+    int32_t bm_idx[PERF_MAX_LEVELS];
+    int64_t bm_row_words;                  // 32-bit words per bitmap row (bm_samples / 32 per pre-pass block)
+    int64_t bm_blocks;                     // pre-pass blocks = escape words per bitmap level
+    int32_t bm_samples;                    // samples per pre-pass block (256..1024: tiles x bm_samples / 8 bytes of LDS staging <= 64 KiB)
     int32_t run_merge;                     // single-tile dense levels: a thread sums runs of samples in one cell in registers
     uint32_t work[kMaxWork];
 };
@@ -296,10 +302,16 @@ constexpr int kQueueCap = 448;             // per-wave match queue (entries): <1
 constexpr int64_t kDbgBytes = 4096 * 8;
 constexpr int64_t kMaxCodedSamples = (int64_t)1 << 28;
 
-static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_blocks, int64_t* ws_entries) {
+constexpr int kBitmapMinDenseTiles = 32;
+constexpr int kBitmapMaxTiles = 2048;      // (2048 x 32 bytes of LDS staging per pre-pass block; log2_hashmap_size <= 25)
+
+// bitmap_tiles > 0: hashed levels of 256..bitmap_tiles tiles get LDS owners fed by per-tile bitmaps instead of the global
+// atomics (the caller checks that the workspace holds the bitmaps and plans again with 0 otherwise)
+static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_blocks, int64_t* ws_entries, int bitmap_tiles = 0) {
     int nb = 0;
     int64_t ws = 0;
     tp->atomic_levels = 0u;
+    tp->bitmap_levels = 0u;
     static const char* rep_env = getenv("PERF_BWD_REPLICAS");      // dev: "r1,r4,r16" replicas of dense levels of 1 / <=4 / <=16 tiles
     int rs[3] = {8, 3, 2};
     if (rep_env) (void)sscanf(rep_env, "%d,%d,%d", &rs[0], &rs[1], &rs[2]);
@@ -310,7 +322,18 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
         if (!gp.hashed[l]) { int p = 1; while (p < nt) p <<= 1; nt = p; }     // dense ownership is a bit field of the index
         // A level of more than 255 (hashed) / 64 (dense) tiles = 4 M / 1 M entries would need that many owners, each
         // walking every sample: beyond that the plain global-atomics scatter is cheaper (log2_hashmap_size >= 22).
-        if (nt > (gp.hashed[l] ? 255 : 64)) { tp->atomic_levels |= 1u << l; continue; }
+        // (dense levels already from 32 tiles: a sample touches 4-5 of them, and code-streaming owners that each test every
+        //  sample are the long pole of a 20-level grid -- 1.6 ms per 1 M random points at 64 tiles)
+        if (nt > (gp.hashed[l] ? 255 : 64) || (!gp.hashed[l] && nt >= kBitmapMinDenseTiles && nt <= bitmap_tiles)) {
+            if (nt <= bitmap_tiles && (!gp.hashed[l] || gp.res[l] + 2u < (uint32_t)kTileEntries)) {
+                tp->bitmap_levels |= 1u << l;
+                tp->tiles_of[l] = nt;
+                nb += nt;
+            } else {
+                tp->atomic_levels |= 1u << l;
+            }
+            continue;
+        }
         // replication factors from measured per-workgroup times (tools/exp/bwd_block_times.py, 1 M samples, fixed):
         // hashed tile (coded) 0.36-0.39 ms; dense tile streaming ALL samples: 1 tile 2.4 ms, 4 tiles 0.88 ms, 8 tiles 0.68 ms
         // (fp32 mode is bound by ds_add_f32 lane-serialisation instead: equal corner-update counts, r = 16 / nt)
@@ -326,7 +349,7 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
     // ---- XCD-aware placement (a speed assumption only: results do not depend on it)
     tp->use_work = 0;
     static const bool no_affinity = getenv("PERF_BWD_NO_XCD_AFFINITY") != nullptr;     // read once (thread-safe static init)
-    if (nb > kMaxWork || no_affinity) return;
+    if (nb > kMaxWork || no_affinity || tp->bitmap_levels) return;       // (the table packs the tile in 8 bits)
     uint32_t lists[kXcds][kMaxWork];                        // 16 KiB of stack: the planner is re-entrant
     int len[kXcds] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto least = [&]() { int x = 0; for (int i = 1; i < kXcds; ++i) if (len[i] < len[x]) x = i; return x; };
@@ -603,6 +626,67 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
     if (threadIdx.x == 0) escape[blockIdx.x] = esc_block;       // every word is written: no zero-fill needed
 }
 
+// ---- levels of 256..2048 tiles (log2_hashmap_size 22..25): per-tile bitmaps ---------------------------------------
+// Beyond 255 tiles a level used to fall back to global atomics (2.1e10/s: 6.6 ms per 1 M samples at L = 20, T = 2^22): that many
+// owners cannot each TEST every sample.  They do not have to: the pre-pass leaves one BIT per (tile, sample) -- row (level,
+// tile) has bit i set when a (y,z) combination of sample i falls in the tile -- and an owner reads only its own row,
+// 128 KiB per million samples, of which 4/tiles of the bits are set.  Rows are staged in LDS per block of 256 samples
+// (tiles x 32 bytes) and written out whole, so the bitmaps need no zero fill; an owner gathers position and gradient of
+// its few thousand samples lane by lane and works out the combinations from the (y,z) it gathered.  The cost of a level is
+// its bitmap traffic (tiles x n / 8 bytes written and read once) plus 128 KiB of LDS zeroing and write-back per owner.
+__global__ __launch_bounds__(256) void tile_bitmap_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
+                                                          const float2* __restrict__ dfeat, uint32_t* __restrict__ bitmaps,
+                                                          uint32_t* __restrict__ esc_bm, int64_t n, const int64_t* __restrict__ n_dev) {
+    const int64_t n_live = live_count(n, n_dev);
+    int l = 0;
+    while (!((tp.bitmap_levels >> l) & 1u) || tp.bm_idx[l] != (int)blockIdx.y) ++l;
+    const int nt = tp.tiles_of[l];
+    const int seg = tp.bm_samples / 32;         // words of a row this block writes (a block takes bm_samples samples: the larger,
+                                                // the longer the contiguous pieces of the rows -- 128 bytes at 1024)
+    extern __shared__ uint32_t stage[];         // [tile][seg]: the block's bits of every row
+    __shared__ uint32_t esc_block;
+    for (int r = threadIdx.x; r < nt * seg; r += 256) stage[r] = 0u;
+    if (threadIdx.x == 0) esc_block = 0u;
+    __syncthreads();
+    for (int local = threadIdx.x; local < tp.bm_samples; local += 256) {
+        const int64_t i = (int64_t)blockIdx.x * tp.bm_samples + local;
+        if (i >= n_live) break;
+        const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+        const uint32_t gy = (uint32_t)(int32_t)floorf(grid_pos(y, gp.scale[l])), gz = (uint32_t)(int32_t)floorf(grid_pos(z, gp.scale[l]));
+        const uint32_t gx = (uint32_t)(int32_t)floorf(grid_pos(x, gp.scale[l]));
+        const uint32_t word = (uint32_t)local >> 5, bit = 1u << ((uint32_t)local & 31u);
+        const uint32_t useg = (uint32_t)seg;
+        bool bad;
+        if (gp.hashed[l]) {
+            const uint32_t ay0 = gy * kPrimeY, ay1 = ay0 + kPrimeY, az0 = gz * kPrimeZ, az1 = az0 + kPrimeZ;
+            const uint32_t m = gp.size[l] - 1u;
+            atomicOr(&stage[(((ay0 ^ az0) & m) / (uint32_t)kTileEntries) * useg + word], bit);
+            atomicOr(&stage[(((ay1 ^ az0) & m) / (uint32_t)kTileEntries) * useg + word], bit);
+            atomicOr(&stage[(((ay0 ^ az1) & m) / (uint32_t)kTileEntries) * useg + word], bit);
+            atomicOr(&stage[(((ay1 ^ az1) & m) / (uint32_t)kTileEntries) * useg + word], bit);
+            bad = gx >= (uint32_t)(kTileEntries - 1);       // "(y,z) decides the tile" does not hold (see tile_codes_kernel)
+        } else {            // dense: chunk-interleaved ownership; every corner on its own, indices past the end wrap (bwd_apply's rule),
+                            // so these levels never escape
+            const uint32_t res = gp.res[l], r2 = res * res, tmask = (uint32_t)nt - 1u;
+            bad = false;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t idx = (gx + (uint32_t)(k & 1)) + (gy + (uint32_t)((k >> 1) & 1)) * res + (gz + (uint32_t)(k >> 2)) * r2;
+                if (idx >= gp.size[l]) idx = idx % gp.size[l];
+                atomicOr(&stage[((idx / kChunk) & tmask) * useg + word], bit);
+            }
+        }
+        if (bad) {          // with gradient the level's owners take the generic path
+            const float2 g = dfeat[(int64_t)l * n + i];
+            if (!(g.x == 0.f && g.y == 0.f)) atomicOr(&esc_block, 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* rows = bitmaps + (int64_t)tp.bm_row[l] * tp.bm_row_words + (int64_t)blockIdx.x * seg;
+    for (int r = threadIdx.x; r < nt * seg; r += 256) rows[(int64_t)(r / seg) * tp.bm_row_words + (r % seg)] = stage[r];
+    if (threadIdx.x == 0) esc_bm[(int64_t)blockIdx.y * tp.bm_blocks + blockIdx.x] = esc_block;
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -726,6 +810,85 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     }
     asm volatile("" : : "v"(ld_c0), "v"(ld_c1));       // (the last code loads landed with the vmcnt(0) above)
 #undef PERF_WAIT_BATCH
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (DPP: shifts inside rows of 16, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// Owner of one tile of a bitmap level.  A wave reads 64 words of the row per step (2048 samples), turns the set bits into
+// sample indices in its LDS queue with ONE wave scan (a row holds 4-5 / tiles of the samples), and applies the queue 64
+// entries at a time at full lane occupancy: position and gradient gathered, the combinations that fall in this tile
+// worked out from the gathered (y,z).  (Lanes that walk their own bits one after the other instead -- the first version --
+// pay one memory latency per round and as many rounds as the fullest lane has bits: 0.10 ms per owner at 256 hashed
+// tiles, 1.66 ms at 64 dense tiles.)  A step that would overflow the queue -- dense rows -- is fed nibble by nibble.
+template <bool FIXED, bool DENSE>
+__device__ __forceinline__ void bwd_stream_bitmap(const BwdCtx& cx, float* lds_tile, uint32_t* queue, const uint32_t* __restrict__ row,
+                                                  const float* __restrict__ x01, const float2* __restrict__ g_l, int64_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t qn = 0;                                    // wave-uniform queue fill
+    auto drain = [&]() {                                // the youngest min(qn, 64) entries
+        const uint32_t take = qn < 64u ? qn : 64u;
+        __builtin_amdgcn_wave_barrier();
+        const bool live = lane < take;
+        const uint32_t i = live ? queue[qn - take + lane] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        qn -= take;
+        const float2 g = g_l[i];
+        const float x = x01[3 * (size_t)i], y = x01[3 * (size_t)i + 1], z = x01[3 * (size_t)i + 2];
+        if (!live || (g.x == 0.f && g.y == 0.f)) return;
+        if (DENSE) { bwd_apply<FIXED, false>(cx, lds_tile, g, x, y, z); return; }      // (tests the tile of each corner, wraps indices)
+        const float px = grid_pos(x, cx.scale), py = grid_pos(y, cx.scale), pz = grid_pos(z, cx.scale);
+        const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+        const uint32_t gx = (uint32_t)(int32_t)flx;
+        if (gx >= (uint32_t)(kTileEntries - 1)) return;          // (zero gradient or the level escaped, see tile_bitmap_kernel)
+        const uint32_t ay0 = (uint32_t)(int32_t)fly * kPrimeY, az0 = (uint32_t)(int32_t)flz * kPrimeZ;
+        const uint32_t ay1 = ay0 + kPrimeY, az1 = az0 + kPrimeZ;
+        const uint32_t cm = ((((ay0 ^ az0) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 1u : 0u) |
+                            ((((ay1 ^ az0) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 2u : 0u) |
+                            ((((ay0 ^ az1) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 4u : 0u) |
+                            ((((ay1 ^ az1) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 8u : 0u);
+        if (cm) apply_pairs<FIXED>(cx, lds_tile, g, gx, px - flx, py - fly, pz - flz, ay0, az0, cm);
+    };
+    auto enqueue = [&](uint32_t bits, uint32_t s0) {    // set bit b of `bits` = sample s0 + b; the caller made room
+        const uint32_t cnt = (uint32_t)__popc(bits);
+        const uint32_t incl = wave_inclusive_sum(cnt);
+        uint32_t at = qn + incl - cnt;
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            queue[at++] = s0 + (uint32_t)b;
+        }
+        qn += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    };
+    const int64_t n_words = (n + 31) / 32;
+    const int64_t w_first = (int64_t)(threadIdx.x >> 6) * 64 + lane, w_step = (int64_t)(kBwdThreads / 64) * 64;
+    uint32_t next = w_first < n_words ? row[w_first] : 0u;
+    for (int64_t w = w_first; w - lane < n_words; w += w_step) {     // wave-uniform trip count
+        const uint32_t bits = next;
+        next = (w + w_step < n_words) ? row[w + w_step] : 0u;
+        uint32_t total = (uint32_t)__popc(bits);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
+        if (qn + total <= (uint32_t)kQueueCap) {
+            enqueue(bits, (uint32_t)w * 32u);
+            while (qn >= 64u) drain();
+        } else {            // (at most 256 new entries per nibble, fewer than 64 left over from the one before)
+#pragma unroll 1
+            for (int s = 0; s < 8; ++s) {
+                enqueue((bits >> (4 * s)) & 15u, (uint32_t)w * 32u + 4u * (uint32_t)s);
+                while (qn >= 64u) drain();
+            }
+        }
+    }
+    while (qn) drain();
 }
 
 // Single-tile dense levels (the coarsest ones: a cell is several sample spacings wide): a thread walks consecutive
@@ -884,7 +1047,8 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    int32_t* __restrict__ shifts_ws,
                                                                    const uint32_t* __restrict__ codes,
                                                                    const uint32_t* __restrict__ escape,
-                                                                   int64_t n,
+                                                                   const uint32_t* __restrict__ bitmaps,
+                                                                   const uint32_t* __restrict__ esc_bm, int64_t n,
                                                                    const int64_t* __restrict__ n_dev) {
     const int64_t n_live = live_count(n, n_dev);            // samples present; n stays the stride of dfeat / codes
     extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats (+ the wave queues)
@@ -936,8 +1100,23 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         __syncthreads();
         coded = esc_any == 0u;
     }
+    bool by_bitmap = bitmaps && ((tp.bitmap_levels >> l) & 1u);
+    if (by_bitmap) {                    // (same escape rule as the coded levels: one word per pre-pass block and level)
+        __shared__ uint32_t esc_bm_any;
+        if (threadIdx.x == 0) esc_bm_any = 0u;
+        __syncthreads();
+        uint32_t e = 0u;
+        const int64_t n_words = (n_live + tp.bm_samples - 1) / tp.bm_samples;
+        const uint32_t* ew = esc_bm + (int64_t)tp.bm_idx[l] * tp.bm_blocks;
+        for (int64_t w = threadIdx.x; w < n_words; w += kBwdThreads) e |= ew[w];
+        if (e) esc_bm_any = 1u;
+        __syncthreads();
+        by_bitmap = esc_bm_any == 0u;
+    }
     uint32_t* queue = reinterpret_cast<uint32_t*>(lds_tile + 2 * kTileEntries) + (threadIdx.x >> 6) * kQueueCap;
-    if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
+    if (by_bitmap && hashed) bwd_stream_bitmap<FIXED, false>(cx, lds_tile, queue, bitmaps + (int64_t)(tp.bm_row[l] + (int)t) * tp.bm_row_words, x01, g_l, n_live);
+    else if (by_bitmap) bwd_stream_bitmap<FIXED, true>(cx, lds_tile, queue, bitmaps + (int64_t)(tp.bm_row[l] + (int)t) * tp.bm_row_words, x01, g_l, n_live);
+    else if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (coded) bwd_stream_codes<FIXED, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n_live, rep, R);
     else bwd_stream<FIXED, false>(cx, lds_tile, x01, g_l, n_live, rep, R, tp.run_merge != 0);
@@ -983,7 +1162,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     if (tp.dbg_off > 0 && threadIdx.x == 0) {      // slot = position in plain level order
         int slot = (int)t * R + rep;
         for (int k = 0; k < l; ++k) slot += tp.tiles_of[k] * tp.replicas_of[k];
-        reinterpret_cast<long long*>(ws + tp.dbg_off)[slot] = (long long)wall_clock64() - t_start;
+        if (slot < (int)(kDbgBytes / 8)) reinterpret_cast<long long*>(ws + tp.dbg_off)[slot] = (long long)wall_clock64() - t_start;
     }
 }
 
@@ -1028,6 +1207,17 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_fixed_kernel(GridPara
     const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
     float w[8];
     corner_weights(c.f, gp.interpolation == PERF_INTERP_SMOOTHSTEP, w);
+    if (gp.hashed[l] && c.cell[0] < (uint32_t)(kTileEntries - 1)) {
+        // the association of the tile owners (apply_pairs: x-weight times the (y,z) product), so that a level adds up the same
+        // integers whether its owners read bitmaps or -- workspace too small for them -- this scatter runs
+        float fx = c.f[0], fy = c.f[1], fz = c.f[2];
+        if (gp.interpolation == PERF_INTERP_SMOOTHSTEP) { fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float wyz = (((k >> 1) & 1) ? fy : 1.0f - fy) * ((k >> 2) ? fz : 1.0f - fz);
+            w[k] = ((k & 1) ? fx : 1.0f - fx) * wyz;
+        }
+    }
     unsigned long long* t = reinterpret_cast<unsigned long long*>(grad) + gp.offset[l];
     const float sx = g.x * to_fixed, sy = g.y * to_fixed;
 #pragma unroll
@@ -1433,7 +1623,7 @@ static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
     int slots = 0;
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->code_slot[l] = -1;
-        if (l >= gp.n_levels || n >= kMaxCodedSamples) continue;
+        if (l >= gp.n_levels || n >= kMaxCodedSamples || ((tp->bitmap_levels >> l) & 1u)) continue;
         const int64_t nt = tp->tiles_of[l];         // (plan_tiles ran before)
         if (gp.hashed[l] ? (nt >= 2 && nt <= 255 && gp.res[l] + 2u < (uint32_t)kTileEntries) : (nt >= 2 && nt <= 64))
             tp->code_slot[l] = slots++;
@@ -1444,16 +1634,40 @@ static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
 
 constexpr int64_t kShiftBytes = 256;        // per-level shifts the owners leave for the replica reduction
 
+// bitmap rows of the levels plan_tiles marked (bitmap_levels); returns the bytes of [bitmaps][escape words] or 0
+constexpr int64_t kBitmapMaxBytes = (int64_t)2 << 30;
+static int64_t plan_bitmaps(const GridParams& gp, int64_t n, TileParams* tp, int* n_levels_out) {
+    int rows = 0, idx = 0;
+    for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
+        tp->bm_row[l] = -1; tp->bm_idx[l] = -1;
+        if (l < gp.n_levels && ((tp->bitmap_levels >> l) & 1u)) { tp->bm_row[l] = rows; tp->bm_idx[l] = idx++; rows += tp->tiles_of[l]; }
+    }
+    int nt_max = 1;
+    for (int l = 0; l < gp.n_levels; ++l) if ((tp->bitmap_levels >> l) & 1u) nt_max = tp->tiles_of[l] > nt_max ? tp->tiles_of[l] : nt_max;
+    int samples = 1024;
+    while (samples > 256 && (int64_t)nt_max * samples / 8 > 65536) samples >>= 1;
+    tp->bm_samples = samples;
+    tp->bm_blocks = div_up(n, samples);
+    tp->bm_row_words = tp->bm_blocks * (samples / 32);
+    *n_levels_out = idx;
+    return (int64_t)rows * tp->bm_row_words * 4 + (int64_t)idx * tp->bm_blocks * 4;
+}
+
+static bool bitmaps_enabled() { const char* e = getenv("PERF_BWD_BITMAP"); return !(e && atoi(e) == 0); }
+
 extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n) {
     GridParams gp;
     if (fill_params(grid, &gp)) return -1;
     TileParams tp; int nb; int64_t ws;
     int64_t ws2;
     plan_tiles(gp, false, &tp, &nb, &ws);
-    plan_tiles(gp, true, &tp, &nb, &ws2);
+    plan_tiles(gp, true, &tp, &nb, &ws2, (n > 0 && n < kMaxCodedSamples && bitmaps_enabled()) ? kBitmapMaxTiles : 0);
     const int slots = plan_codes(gp, n, &tp);
+    int bm_levels = 0;
+    int64_t bm_bytes = plan_bitmaps(gp, n, &tp, &bm_levels);
+    if (bm_bytes > kBitmapMaxBytes) bm_bytes = 0;
     return (ws > ws2 ? ws : ws2) * (int64_t)sizeof(float2) + 16 + kShiftBytes + kDbgBytes + (int64_t)slots * tp.n_pad * 4 +
-           (slots ? div_up(n, kCodeSamplesPerBlock) * 4 : 0);
+           (slots ? div_up(n, kCodeSamplesPerBlock) * 4 : 0) + (bm_bytes ? bm_bytes + 16 : 0);
 }
 
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
@@ -1471,29 +1685,63 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     TileParams tp;
     int n_blocks = 0;
     int64_t ws_entries = 0;
-    plan_tiles(gp, fixed, &tp, &n_blocks, &ws_entries);
+    static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
+    const bool aligned_ws = (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    // workspace layout: [replica slabs (larger of both modes)][shifts][debug slots][tile codes][escape words][bitmaps][their escape words]
+    int64_t slab_entries = 0;
+    { TileParams t2; int nb2; int64_t w2;
+      plan_tiles(gp, fixed, &t2, &nb2, &w2); slab_entries = w2;
+      plan_tiles(gp, !fixed, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2; }
+    const int64_t shifts_at = (slab_entries * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
+    const int64_t dbg_at = shifts_at + kShiftBytes;
+    const int64_t codes_at = dbg_at + kDbgBytes;
+    const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
+    // levels of 256..2048 tiles take LDS owners fed by per-tile bitmaps when the workspace holds the bitmaps, global atomics otherwise
+    int bitmap_tiles = 0, bm_levels = 0;
+    int64_t bits_at = 0, bm_bytes = 0;
+    if (n > 0 && n < kMaxCodedSamples && !no_codes && aligned_ws && bitmaps_enabled()) {
+        TileParams t0; int nb0; int64_t w0;
+        plan_tiles(gp, fixed, &t0, &nb0, &w0, kBitmapMaxTiles);
+        if (t0.bitmap_levels) {
+            const int slots0 = plan_codes(gp, n, &t0);
+            bm_bytes = plan_bitmaps(gp, n, &t0, &bm_levels);
+            bits_at = (codes_at + (int64_t)slots0 * t0.n_pad * 4 + (slots0 ? esc_words * 4 : 0) + 15) & ~(int64_t)15;
+            if (bm_bytes <= kBitmapMaxBytes && workspace_bytes >= bits_at + bm_bytes) bitmap_tiles = kBitmapMaxTiles;
+        }
+    }
+    plan_tiles(gp, fixed, &tp, &n_blocks, &ws_entries, bitmap_tiles);
     PERF_REQUIRE(!(raw_fields || shifts_dev) || tp.atomic_levels == 0u,
                  "perf_hashgrid_bwd: raw fields / given units are not available for levels beyond 4 M entries");
     { const char* e = getenv("PERF_BWD_RUNS"); tp.run_merge = (e && atoi(e) == 0) ? 0 : 1; }     // (dev switch)
     tp.accumulate = accumulate;
     tp.raw_out = raw_fields ? 1 : 0;
     tp.dbg_off = 0;
-    int64_t slab_entries = ws_entries;      // workspace layout: [replica slabs (larger of both modes)][shifts][debug slots][tile codes]
-    { TileParams t2; int nb2; int64_t w2; plan_tiles(gp, !fixed, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2; }
-    const int64_t shifts_at = (slab_entries * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
     PERF_REQUIRE(workspace && workspace_bytes >= shifts_at + kShiftBytes,
                  "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(shifts_at + kShiftBytes));
     int32_t* shifts_ws = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + shifts_at);
-    const int64_t dbg_at = shifts_at + kShiftBytes;
-    static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
     if (dbg_env && workspace_bytes >= dbg_at + kDbgBytes) tp.dbg_off = dbg_at / (int64_t)sizeof(float2);
     // tile codes of the hashed levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
     const int slots = plan_codes(gp, n, &tp);
-    const int64_t codes_at = dbg_at + kDbgBytes;
     uint32_t* codes = nullptr;
     uint32_t* escape = nullptr;
-    const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
-    if (slots > 0 && n > 0 && !no_codes && ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0) &&
+    uint32_t* bitmaps = nullptr;
+    uint32_t* esc_bm = nullptr;
+    if (tp.bitmap_levels) {
+        (void)plan_bitmaps(gp, n, &tp, &bm_levels);
+        bitmaps = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + bits_at);
+        int rows = 0, nt_max = 0;
+        for (int l = 0; l < gp.n_levels; ++l)
+            if ((tp.bitmap_levels >> l) & 1u) { rows += tp.tiles_of[l]; nt_max = tp.tiles_of[l] > nt_max ? tp.tiles_of[l] : nt_max; }
+        esc_bm = bitmaps + (int64_t)rows * tp.bm_row_words;
+        static std::once_flag bm_once;
+        std::call_once(bm_once, [&]() {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_bitmap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        });
+        tile_bitmap_kernel<<<dim3((unsigned)tp.bm_blocks, (unsigned)bm_levels), dim3(256), (size_t)nt_max * (tp.bm_samples / 8), as_stream(stream)>>>(
+            gp, tp, x01, (const float2*)dfeat, bitmaps, esc_bm, n, n_dev);
+        PERF_LAUNCH_CHECK("perf_hashgrid_bwd(bitmaps)");
+    }
+    if (slots > 0 && n > 0 && !no_codes && aligned_ws &&
         workspace_bytes >= codes_at + (int64_t)slots * tp.n_pad * 4 + esc_words * 4) {
         codes = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + codes_at);
         escape = codes + (int64_t)slots * tp.n_pad;
@@ -1514,11 +1762,11 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     } else if (fixed)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, headroom_state,
-            shifts_dev, shifts_ws, codes, escape, n, n_dev);
+            shifts_dev, shifts_ws, codes, escape, bitmaps, esc_bm, n, n_dev);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, nullptr, nullptr, nullptr,
-            codes, escape, n, n_dev);
+            codes, escape, bitmaps, esc_bm, n, n_dev);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (tp.atomic_levels && n > 0) {
         if (!accumulate)

@@ -654,9 +654,13 @@ def test_table_beyond_32_bit_offsets(ops):
     torch.cuda.empty_cache()
 
 
-def test_hashgrid_bwd_large_levels_take_the_atomics_path(ops):
-    """log2_hashmap_size = 23: 512 tiles per hashed level, more than LDS owners are planned for -> global-atomics scatter
-    for those levels, owners for the rest; against the oracle's corner bookkeeping (fp32 atomics: summation-order tolerance)."""
+@pytest.mark.parametrize('bitmap', ['1', '0'])
+def test_hashgrid_bwd_large_levels(ops, monkeypatch, bitmap):
+    """log2_hashmap_size = 23: 512 tiles per hashed level, more than code-streaming owners are planned for -> LDS owners fed
+    by per-tile bitmaps (default) or the global-atomics scatter (PERF_BWD_BITMAP=0, and whenever the workspace cannot hold
+    the bitmaps) for those levels, the usual owners for the rest; against the oracle's corner bookkeeping (fp32:
+    summation-order tolerance)."""
+    monkeypatch.setenv('PERF_BWD_BITMAP', bitmap)
     cfg = _grid_cfg(n_levels=6, log2_hashmap_size=23, base_resolution=32, per_level_scale=2.0)
     lv = O.grid_levels(6, 2, 23, 32, 2.0)
     g = torch.Generator().manual_seed(41)
@@ -685,6 +689,45 @@ def test_hashgrid_bwd_large_levels_take_the_atomics_path(ops):
         acc = torch.from_numpy(grad.reshape(-1).copy()).cuda()
         ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), out=acc, accumulate=True, level_absmax=amax)
         assert np.abs(acc.cpu().numpy().reshape(-1, 2) - 2 * ref).max() < 4e-4 * np.abs(ref).max()
+
+
+def test_hashgrid_bwd_bitmap_owners_equal_the_atomics_scatter(ops, monkeypatch):
+    """Hashed levels of 256-2048 tiles (log2_hashmap_size 22-25) and dense levels of 32-2048 tiles: the owners that read per-tile
+    bitmaps and what runs without them (64-bit fixed-point global atomics; code-streaming owners up to 64 dense tiles) add up the same integers -- bit-identical tables, for ragged sizes, ray-ordered samples, a live count
+    below the capacity and positions outside the unit cube (which send a level back to the generic owners)."""
+    g = torch.Generator().manual_seed(43)
+    for log2_t, n_levels, n, kind, live, base in ((22, 5, 5003, 'uniform', None, 64), (23, 6, 40000, 'rays', None, 64), (24, 4, 20001, 'uniform', 12345, 64),
+                                                  (22, 5, 9000, 'outside', None, 64), (25, 3, 70000, 'rays', None, 64), (22, 3, 30000, 'rays', None, 96),
+                                                  (22, 3, 8000, 'outside', 7000, 96)):
+        # (base 64: 16 dense tiles with codes, 128 dense tiles, then hashed levels of 256-2048 tiles; base 96: 64 dense tiles --
+        #  bitmaps against the code-streaming dense owners)
+        cfg = _grid_cfg(n_levels=n_levels, log2_hashmap_size=log2_t, base_resolution=base, per_level_scale=2.0)
+        if kind == 'rays':
+            R = n // 128 + 1
+            d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+            t = (torch.arange(128) + 0.5) / 128
+            x = ((d[:, None, :] * t[None, :, None]).reshape(-1, 3) * 0.5 + 0.5)[:n].contiguous()
+        else:
+            x = torch.rand(n, 3, generator=g)
+        if kind == 'outside':
+            x[::7, 0] = -0.25
+            x[5::11, 0] = 9.5
+            x[3::13, 1] = -3.0
+        x = x.cuda()
+        dfeat = torch.randn(cfg.n_levels, n, 2, generator=g).cuda()
+        amax = torch.zeros(24, device='cuda'); amax[:cfg.n_levels] = dfeat.abs().amax(dim=(1, 2))
+        n_dev = None if live is None else torch.tensor([live], dtype=torch.int64, device='cuda')
+        monkeypatch.setenv('PERF_BWD_BITMAP', '1')
+        a = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, n_dev=n_dev)
+        a32 = ops.hashgrid_bwd(cfg, x, dfeat, n_dev=n_dev)
+        monkeypatch.setenv('PERF_BWD_BITMAP', '0')
+        b = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, n_dev=n_dev)
+        b32 = ops.hashgrid_bwd(cfg, x, dfeat, n_dev=n_dev)
+        assert float(b.abs().max()) > 0
+        assert torch.equal(a, b), (log2_t, kind, float((a - b).abs().max()))
+        assert float((a32 - b32).abs().max()) <= 1e-4 * float(b32.abs().max()), (log2_t, kind)
+        del a, b, a32, b32, dfeat
+    torch.cuda.empty_cache()
 
 
 def test_composite_distloss_fused_kernels(ops):
