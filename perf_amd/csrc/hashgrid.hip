@@ -315,6 +315,12 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
     static const char* rep_env = getenv("PERF_BWD_REPLICAS");      // dev: "r1,r4,r16" replicas of dense levels of 1 / <=4 / <=16 tiles
     int rs[3] = {8, 3, 2};
     if (rep_env) (void)sscanf(rep_env, "%d,%d,%d", &rs[0], &rs[1], &rs[2]);
+    bool large_grid = false;        // some level takes bitmap owners
+    for (int l = 0; l < gp.n_levels && bitmap_tiles > 0; ++l) {
+        int nt = (int)((gp.size[l] + kTileEntries - 1) / kTileEntries);
+        if (!gp.hashed[l]) { int p2 = 1; while (p2 < nt) p2 <<= 1; nt = p2; }
+        if (nt <= bitmap_tiles && (gp.hashed[l] ? (nt > 255 && gp.res[l] + 2u < (uint32_t)kTileEntries) : nt >= kBitmapMinDenseTiles)) large_grid = true;
+    }
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->tiles_of[l] = 0; tp->replicas_of[l] = 1; tp->ws_off[l] = 0;
         if (l >= gp.n_levels) continue;
@@ -339,6 +345,10 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
         // (fp32 mode is bound by ds_add_f32 lane-serialisation instead: equal corner-update counts, r = 16 / nt)
         int r = 1;
         if (!gp.hashed[l]) r = fixed ? ((nt == 1) ? rs[0] : (nt <= 4 ? rs[1] : (nt <= 16 ? rs[2] : 1))) : kMaxReplicas / nt;
+        // A grid with bitmap levels launches thousands of short owners anyway: its few-tile dense levels -- where every sample
+        // is an entry of most owners -- get the replicas that keep them from being the kernel's long pole (measured on a
+        // 20-level grid: 2 tiles x 3 replicas 1.1 ms per workgroup, 8 x 2 0.66 ms, against 0.07-0.3 ms everywhere else)
+        if (!gp.hashed[l] && fixed && bitmap_tiles > 0 && large_grid && !rep_env) r = nt == 1 ? 8 : (nt == 2 ? 8 : (nt == 4 ? 6 : (nt == 8 ? 4 : 2)));
         if (r < 1) r = 1;
         if (r > kMaxReplicas) r = kMaxReplicas;
         tp->tiles_of[l] = nt; tp->replicas_of[l] = r;
@@ -615,7 +625,8 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
                 }
             }
             codes[(int64_t)slot * tp.n_pad + i] = code;
-            if (bad) {      // harmless without gradient; with gradient the level's owners take the generic path
+            if (bad && gp.hashed[l]) {      // harmless without gradient; with gradient the level's owners take the generic path
+                                            // (dense: the owners apply such a sample corner by corner, see bwd_stream_codes)
                 const float2 g = dfeat[(int64_t)l * n + i];
                 if (!(g.x == 0.f && g.y == 0.f)) esc |= 1u << l;
             }
@@ -710,22 +721,29 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     // registers written by loads in flight: only ever read through the wait_* copies below
     float ld_x = 0.f; f32x2 ld_yz = {0.f, 0.f}, ld_g = {0.f, 0.f}; u32x2 ld_c0 = {0u, 0u}, ld_c1 = {0u, 0u};
     uint32_t bcm = 0, bi = 0;                           // (y,z) combinations and sample index of the batch in flight
+    bool blive = false;                                 // this lane holds an entry of the batch in flight
     const uint32_t t_split = 0x80u | cx.t, t_next = 0x80u | ((cx.t - 1u) & (cx.n_tiles - 1u));     // dense codes
+    // -> combinations that name this tile; dense: 0x10 when a combination of the sample wraps past the end of the level
+    //    (byte 0x7f) -- such a sample is queued by EVERY owner of the level without combinations and applied corner by
+    //    corner with bwd_apply's wrapping rule (a few per cent of random points, none of a scene that keeps clear of the
+    //    upper faces of its box: no reason to hand the whole level to the generic owners)
     auto test = [&](uint32_t code) {
         uint32_t cm = 0;
+        bool wraps = false;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const uint32_t b = (code >> (8 * c)) & 0xffu;
             const bool hit = DENSE ? (b == cx.t || b == t_split || b == t_next) : (b == cx.t);
             cm |= (hit ? 1u : 0u) << c;
+            if (DENSE) wraps = wraps || b == 0x7fu;
         }
-        return cm;
+        return wraps ? 0x10u : cm;
     };
     auto enqueue = [&](uint32_t cm, uint32_t i) {
         const unsigned long long b = __ballot(cm != 0u);
         if (b) {
             const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-            if (cm) queue[pos] = (i << 4) | cm;
+            if (cm) queue[pos] = (i << 4) | (cm & 15u);
             qn += (uint32_t)__popcll(b);
         }
     };
@@ -741,6 +759,7 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
         if (lane < take) e = queue[qn - take + lane];
         __builtin_amdgcn_wave_barrier();
         qn -= take;
+        blive = lane < take;
         bcm = e & 15u;
         bi = e >> 4;
         const uint32_t ox = bi * 12u, og = bi * 8u;
@@ -756,6 +775,10 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     // The batch gathered one drain ago.  Every lane applies ONE combination (loop-free at full occupancy); the 7 % of
     // samples that name this tile with two or more combinations go back into the queue with the remaining ones.
     auto apply_batch = [&](float bx, f32x2 byz, f32x2 bg) {
+        if (DENSE && blive && bcm == 0u) {      // a sample with a wrapping corner: every corner on its own
+            if (!(bg.x == 0.f && bg.y == 0.f)) bwd_apply<FIXED, false>(cx, lds_tile, make_float2(bg.x, bg.y), bx, byz.x, byz.y);
+            return;
+        }
         const uint32_t rest = DENSE ? 0u : bcm & (bcm - 1u);        // (dense tiles are named by several combinations as a rule)
         if (!DENSE) bcm &= 0u - bcm;
         if (bcm) {
@@ -804,7 +827,7 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     for (;;) {
         PERF_WAIT_BATCH(0);
         apply_batch(bx, byz, bg);
-        bcm = 0;
+        bcm = 0; blive = false;
         if (qn == 0u) break;
         pop_and_gather();
     }
@@ -857,9 +880,9 @@ __device__ __forceinline__ void bwd_stream_bitmap(const BwdCtx& cx, float* lds_t
                             ((((ay1 ^ az1) & cx.mask) / (uint32_t)kTileEntries) == cx.t ? 8u : 0u);
         if (cm) apply_pairs<FIXED>(cx, lds_tile, g, gx, px - flx, py - fly, pz - flz, ay0, az0, cm);
     };
-    auto enqueue = [&](uint32_t bits, uint32_t s0) {    // set bit b of `bits` = sample s0 + b; the caller made room
+    auto enqueue = [&](uint32_t bits, uint32_t s0, uint32_t incl) {    // set bit b of `bits` = sample s0 + b; incl = inclusive wave
+                                                                        // prefix of the popcounts; the caller made room
         const uint32_t cnt = (uint32_t)__popc(bits);
-        const uint32_t incl = wave_inclusive_sum(cnt);
         uint32_t at = qn + incl - cnt;
         while (bits) {
             const int b = __ffs((int)bits) - 1;
@@ -874,16 +897,16 @@ __device__ __forceinline__ void bwd_stream_bitmap(const BwdCtx& cx, float* lds_t
     for (int64_t w = w_first; w - lane < n_words; w += w_step) {     // wave-uniform trip count
         const uint32_t bits = next;
         next = (w + w_step < n_words) ? row[w + w_step] : 0u;
-        uint32_t total = (uint32_t)__popc(bits);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
+        const uint32_t incl = wave_inclusive_sum((uint32_t)__popc(bits));
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (qn + total <= (uint32_t)kQueueCap) {
-            enqueue(bits, (uint32_t)w * 32u);
+            enqueue(bits, (uint32_t)w * 32u, incl);
             while (qn >= 64u) drain();
         } else {            // (at most 256 new entries per nibble, fewer than 64 left over from the one before)
 #pragma unroll 1
             for (int s = 0; s < 8; ++s) {
-                enqueue((bits >> (4 * s)) & 15u, (uint32_t)w * 32u + 4u * (uint32_t)s);
+                const uint32_t nib = (bits >> (4 * s)) & 15u;
+                enqueue(nib, (uint32_t)w * 32u + 4u * (uint32_t)s, wave_inclusive_sum((uint32_t)__popc(nib)));
                 while (qn >= 64u) drain();
             }
         }
@@ -1688,10 +1711,12 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
     const bool aligned_ws = (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
     // workspace layout: [replica slabs (larger of both modes)][shifts][debug slots][tile codes][escape words][bitmaps][their escape words]
-    int64_t slab_entries = 0;
+    const bool want_bitmaps = n > 0 && n < kMaxCodedSamples && !no_codes && aligned_ws && bitmaps_enabled();
+    int64_t slab_entries = 0;       // (the largest of the plans a call may end up with: the offsets below must not depend on the choice)
     { TileParams t2; int nb2; int64_t w2;
       plan_tiles(gp, fixed, &t2, &nb2, &w2); slab_entries = w2;
-      plan_tiles(gp, !fixed, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2; }
+      plan_tiles(gp, !fixed, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2;
+      if (want_bitmaps) { plan_tiles(gp, fixed, &t2, &nb2, &w2, kBitmapMaxTiles); if (w2 > slab_entries) slab_entries = w2; } }
     const int64_t shifts_at = (slab_entries * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
     const int64_t dbg_at = shifts_at + kShiftBytes;
     const int64_t codes_at = dbg_at + kDbgBytes;
@@ -1699,7 +1724,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     // levels of 256..2048 tiles take LDS owners fed by per-tile bitmaps when the workspace holds the bitmaps, global atomics otherwise
     int bitmap_tiles = 0, bm_levels = 0;
     int64_t bits_at = 0, bm_bytes = 0;
-    if (n > 0 && n < kMaxCodedSamples && !no_codes && aligned_ws && bitmaps_enabled()) {
+    if (want_bitmaps) {
         TileParams t0; int nb0; int64_t w0;
         plan_tiles(gp, fixed, &t0, &nb0, &w0, kBitmapMaxTiles);
         if (t0.bitmap_levels) {
