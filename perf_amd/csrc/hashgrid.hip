@@ -1736,7 +1736,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     }
     plan_tiles(gp, fixed, &tp, &n_blocks, &ws_entries, bitmap_tiles);
     PERF_REQUIRE(!(raw_fields || shifts_dev) || tp.atomic_levels == 0u,
-                 "perf_hashgrid_bwd: raw fields / given units are not available for levels beyond 4 M entries");
+                 "perf_hashgrid_bwd: raw fields / given units are not available for levels on the global-atomics scatter (more than 2048 tiles, or no room for the per-tile bitmaps in the workspace)");
     { const char* e = getenv("PERF_BWD_RUNS"); tp.run_merge = (e && atoi(e) == 0) ? 0 : 1; }     // (dev switch)
     tp.accumulate = accumulate;
     tp.raw_out = raw_fields ? 1 : 0;
