@@ -730,6 +730,38 @@ def test_hashgrid_bwd_bitmap_owners_equal_the_atomics_scatter(ops, monkeypatch):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize('large', [False, True])
+def test_job_wide_units_make_two_partial_tables_add_up_to_the_single_call(ops, large):
+    """The data-parallel kernels on their own (perf_amd/dp.py's choreography without a process group): a batch cut in two
+    uneven parts, perf_dp_stats_pack per part, perf_dp_units over both -> the units the single call derives itself; the
+    parts' raw int32 fields added as integers and converted by perf_fixed_unfix equal the single call's table BIT FOR BIT --
+    on the benchmark's grid and on a grid whose large levels take the bitmap owners."""
+    cfg = _grid_cfg(n_levels=5, log2_hashmap_size=22, base_resolution=64, per_level_scale=2.0) if large else _grid_cfg()
+    g = torch.Generator().manual_seed(51)
+    n, cut = 30011, 11003
+    x = torch.rand(n, 3, generator=g).cuda()
+    dfeat = (torch.randn(cfg.n_levels, n, 2, generator=g) * 1e-3).cuda()
+
+    def amax_of(d):
+        a = torch.zeros(24, device='cuda'); a[:cfg.n_levels] = d.abs().amax(dim=(1, 2)); return a
+    ref = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax_of(dfeat), hr_state=ops.headroom_state('cuda'))
+    parts = [(x[:cut].contiguous(), dfeat[:, :cut].contiguous()), (x[cut:].contiguous(), dfeat[:, cut:].contiguous())]
+    stats = torch.stack([ops.dp_stats_pack(amax_of(d), None, None, xs.shape[0]) for xs, d in parts])
+    hr = ops.headroom_state('cuda')
+    shifts, n_total = ops.dp_units(cfg, stats, 2, hr)
+    assert int(n_total.item()) == n
+    total = torch.zeros(cfg.n_params, dtype=torch.int32, device='cuda')
+    for xs, d in parts:
+        f = ops.hashgrid_bwd(cfg, xs, d, shifts=shifts, raw_fields=True)
+        total += f.view(torch.int32)
+    field_max = torch.zeros(24, dtype=torch.int32, device='cuda')
+    ops.fixed_unfix(cfg, total, 0, cfg.total, shifts, field_max=field_max)
+    got = total.view(torch.float32)
+    assert float(ref.abs().max()) > 0
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    assert int(field_max[:cfg.n_levels].min()) > 0
+
+
 def test_composite_distloss_fused_kernels(ops):
     """Compositing + distortion loss in one kernel each way equals the two-kernel chain (forward bit-exact; backward to
     fp32 rounding: prefixes are formed as totals minus suffixes there)."""
