@@ -415,3 +415,33 @@ def test_repeated_addition_lattice_closed_form():
             table = O.lattice_table_repeated(np.array([t0], F), K, step)[0]
             for k in list(range(0, 24)) + list(rng.randint(0, K + 1, 40)) + [K]:
                 assert closed_form(t0, int(k), step) == table[k], (step, t0, k)
+
+
+def test_synthetic_room_with_box_on_cpu():
+    """perf_amd/synthetic.py (pure torch): without the box and from the centre room_with_box is room() up to the normalisation
+    constant; the box hides part of the walls; from another position every ray still ends on a surface inside the room."""
+    import math
+    from perf_amd import synthetic
+
+    def pano(pose, H, W):
+        i = (torch.arange(H) + .5) / H; j = (torch.arange(W) + .5) / W
+        y, x = torch.meshgrid(i, j, indexing='ij')
+        beta = -(y - .5) * math.pi; alpha = -(x - .5) * 2 * math.pi
+        d = torch.stack([torch.cos(alpha) * torch.cos(beta), torch.sin(alpha) * torch.cos(beta), torch.sin(beta)], -1)
+        return pose[:3, 3].expand_as(d), d @ pose[:3, :3].T
+    o, d = pano(torch.eye(4), 64, 128)
+    d0, c0 = synthetic.room(d)
+    d1, c1 = synthetic.room_with_box(o, d, box_h=(0., 0., 0.))
+    ratio = d1 / d0
+    assert float(ratio.max() - ratio.min()) < 1e-5 and 0.98 < float(ratio.mean()) < 1.0
+    assert float((c0 - c1).abs().max()) < 1e-5
+    d2, _ = synthetic.room_with_box(o, d)
+    assert 0.01 < float((d2 < d1 - 1e-6).float().mean()) < 0.2
+    pose = torch.eye(4); pose[:3, 3] = torch.tensor([0.2, 0.1, 0.0])
+    o3, dd3 = pano(pose, 64, 128)
+    d3, c3 = synthetic.room_with_box(o3, dd3)
+    p = (o3 + dd3 * d3) * synthetic.ROOM_SCALE
+    half = torch.tensor([0.9, 0.7, 0.5])
+    assert torch.isfinite(d3).all() and float(d3.min()) > 0
+    assert bool(((p.abs() <= half + 1e-4).all(-1)).all())                       # every hit lies inside the room
+    assert float(c3.min()) >= 0.0 and float(c3.max()) <= 1.0
