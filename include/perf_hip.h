@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 4
+#define PERF_ABI_VERSION 5
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -117,10 +117,13 @@ int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_
 /* Device-side bookkeeping of one sync-free training step, one tiny launch, issued between the backward and
  * perf_adam_step_dev.  The step is TAKEN when the batch has samples (*gate_dev > 0 or gate_dev == NULL; the reference skips
  * batches without samples, nerf.py:204-206), the fixed-point grid backward did not flag an overflow (*overflow_flag != 0,
- * or *remote_flags > 0: the sum of the other ranks' flags under data parallelism) and the batch was not truncated
- * (*n_marched_dev > capacity > 0: late rays lost their samples).  *step_dev += 1 and *eff_gate_out = 1 when taken,
+ * or remote_flags[0] > 0: the sum of ALL ranks' flags under data parallelism) and the batch was not truncated
+ * (*n_marched_dev > capacity > 0: late rays lost their samples; or remote_flags[1] > 0: some rank's batch was).  remote_flags
+ * (device, TWO floats, may be NULL) is what perf_dp_slot_unpack leaves: with it every rank of a job decides alike.  *step_dev += 1 and *eff_gate_out = 1 when taken,
  * *eff_gate_out = 0 otherwise -- pass eff_gate_out to perf_adam_step_dev as its gate: a corrupted or truncated gradient is
- * never applied.  *overflow_flag is cleared (the event is counted instead).  counters (int64 [PERF_STEP_COUNTERS], may be
+ * never applied.  overflow_redone != 0: the caller has REPAIRED a flagged gradient in place (perf_hashgrid_bwd's redo launch,
+ * fp32 accumulation) -- the flag no longer gates, the event is still counted: the single-GPU paths never drop a step for it.
+ * *overflow_flag is cleared (the event is counted instead).  counters (int64 [PERF_STEP_COUNTERS], may be
  * NULL) accumulate {marched samples, kept samples, steps, largest marched count of one batch, steps skipped for overflow,
  * steps skipped for truncation, 0, 0}: throughput and health accounting never read the device inside the training loop.
  * schedule (device, n_schedule rows of {learning rate, distortion-loss ramp min(2 progress, 1)}; NULL = none) with iter_dev
@@ -131,7 +134,7 @@ int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_
 #define PERF_STEP_COUNTERS 8
 int perf_step_bookkeeping(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
                           const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
-                          int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out,
+                          int32_t* overflow_flag, const float* remote_flags, int32_t overflow_redone, int64_t* eff_gate_out,
                           const float* schedule, int32_t n_schedule, int32_t* iter_dev, float* lr_out, float* ratio_out,
                           void* stream);
 
@@ -196,13 +199,20 @@ int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const fl
  *     (same addresses, reinterpret as int32).  The ranks' tables are then summed exactly by an integer reduce-scatter and
  *     converted by perf_fixed_unfix: the result equals the single-process table bit for bit.  Needs accumulate == 0 and no
  *     level on the global-atomics scatter (levels beyond 2048 tiles of 16,384 entries, or beyond 255 hashed / 64 dense tiles
- *     when the workspace cannot hold their per-tile bitmaps: perf_hashgrid_bwd_workspace_bytes includes them up to 2 GiB). */
+ *     when the workspace cannot hold their per-tile bitmaps: perf_hashgrid_bwd_workspace_bytes includes them up to 2 GiB).
+ * redo_flag (device int32, may be NULL): the call is the REPAIR of the fixed-point call issued just before it with the same
+ *   x01 / dfeat / grad_table / n / n_dev: ONE launch that does nothing unless *redo_flag != 0 (pass that call's
+ *   overflow_flag) and otherwise rewrites the whole gradient table with fp32 LDS accumulation (single owners streaming
+ *   positions: slow, and needed a handful of times per million steps).  Fixed launch sequence, so a captured hipGraph of the
+ *   training step never has to drop a step for an overflow.  Requires level_absmax == shifts_dev == NULL, accumulate ==
+ *   raw_fields == 0, no workspace; PERF_E_UNSUPPORTED for grids with levels beyond LDS owners.  headroom_state (may be NULL):
+ *   word [2 * PERF_MAX_LEVELS + 1] counts the repairs that ran. */
 #define PERF_HEADROOM_STATE_WORDS (2 * PERF_MAX_LEVELS + 8)
 int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n);
 int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
                       float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
                       int32_t* overflow_flag, int32_t* headroom_state, const int32_t* shifts_dev, int raw_fields,
-                      void* workspace, int64_t workspace_bytes, void* stream);
+                      const int32_t* redo_flag, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- job-wide fixed-point units of a data-parallel step (no counterpart in the reference, which is single-GPU;
  *      rays shard over the GPUs, one gradient exchange per step) ------------------------------------------
@@ -213,12 +223,28 @@ int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float*
  * use: max of the absmax, sum of the counts, headroom feedback with the max of the field maxima (applied to
  * headroom_state first, exactly where the single process applies it: between two calls).  shifts_out: PERF_MAX_LEVELS
  * int32 for perf_hashgrid_bwd(shifts_dev) / perf_fixed_unfix; n_total_out (int64, may be NULL): the job's sample count
- * (the gate of the optimizer step). */
+ * (the gate of the optimizer step).  margin_bits (0..8): make the units that many bits coarser (see perf_dp_slot_pack). */
 #define PERF_DP_STATS 64
 int perf_dp_stats_pack(const float* level_absmax, const int32_t* field_max_prev, const int64_t* n_dev, int64_t n,
                        int32_t* stats_out, void* stream);
 int perf_dp_units(const perf_grid_desc* grid, const int32_t* stats_all, int32_t world, int32_t* headroom_state,
-                  int32_t* shifts_out, int64_t* n_total_out, void* stream);
+                  int32_t* shifts_out, int64_t* n_total_out, int32_t margin_bits, void* stream);
+/* The small all-reduce of a data-parallel step: behind the MLP weight gradient the buffer holds one slot of PERF_DP_SLOT
+ * floats per rank; every rank fills ITS slot (the others are zeroed), so a SUM all-reduce doubles as an all-gather.  A slot
+ * carries the rank's level_absmax, the largest |field| per level of its slice of THIS step's summed table (field_max of
+ * perf_fixed_unfix; integers travel as 16-bit pieces, exact in fp32), its live sample count, its overflow flag (local grid
+ * backward or its slice of the summed table) and whether its batch was truncated (*n_marched_dev > capacity > 0).
+ * perf_dp_slot_unpack turns the all-reduced slots into (a) job_flags (device, 2 floats) = {overflow, truncated} summed over
+ * the ranks -- perf_step_bookkeeping's remote_flags: the step gate is the SAME on every rank --, (b) n_total_out (int64) = the
+ * job's sample count, (c) stats_all (may be NULL): the block perf_dp_units reads, as if all-gathered.  With (c) the units of
+ * the NEXT step can be derived from THIS step's statistics (perf_dp_units(..., margin_bits = 1): "lagged" units, one bit
+ * coarser): the statistics all-gather between the MLP backward and the grid backward leaves the critical path. */
+#define PERF_DP_SLOT 80
+int perf_dp_slot_pack(const float* level_absmax, const int32_t* field_max, const int64_t* n_dev, int64_t n,
+                      const int32_t* overflow_flag, const int64_t* n_marched_dev, int64_t capacity, int32_t rank,
+                      int32_t world, float* slots, void* stream);
+int perf_dp_slot_unpack(const float* slots, int32_t world, int32_t* stats_all, float* job_flags, int64_t* n_total_out,
+                        void* stream);
 /* In place: the int32 field pairs of table entries [entry_lo, entry_hi) (a rank's slice after the integer reduce-scatter;
  * `fields` points at entry_lo) -> fp32 gradients, value = field * 2^-shift of the entry's level.  field_max (device,
  * PERF_MAX_LEVELS int32, may be NULL) receives the largest |field| per level of the slice; *overflow_flag is OR-ed with 1

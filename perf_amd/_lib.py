@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libperf_hip.so')
 
-ABI_VERSION = 4          # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
+ABI_VERSION = 5          # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
 MAX_LEVELS = 24
 DTYPE_BF16, DTYPE_FP16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
@@ -38,6 +38,7 @@ LOSS_SCALARS = 256       # PERF_LOSS_SCALARS
 STEP_COUNTERS = 8        # PERF_STEP_COUNTERS
 HEADROOM_STATE_WORDS = 2 * MAX_LEVELS + 8    # PERF_HEADROOM_STATE_WORDS
 DP_STATS = 64            # PERF_DP_STATS
+DP_SLOT = 80             # PERF_DP_SLOT
 _SIGS = {
     'perf_version': (c_int, []),
     'perf_last_error': (c_char_p, []),
@@ -46,16 +47,18 @@ _SIGS = {
     'perf_cast_params': (c_int, [P, P, c_int64, c_int, P]),
     'perf_adam_step': (c_int, [P, P, P, P, P, c_int64, c_int, c_int32, c_float, c_float, c_float, c_float, c_int, P]),
     'perf_adam_step_dev': (c_int, [P, P, P, P, P, c_int64, c_int, P, P, P, c_float, c_float, c_float, c_int, P]),
-    'perf_step_bookkeeping': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, c_int32, P, P, P, P]),
+    'perf_step_bookkeeping': (c_int, [P, P, P, P, P, c_int64, P, P, c_int32, P, P, c_int32, P, P, P, P]),
     'perf_points_from_rays': (c_int, [P, P, P, P, P, POINTER(c_float), P, P, c_int64, P, P]),
     'perf_points_normalize': (c_int, [P, POINTER(c_float), P, P, c_int64, P]),
     'perf_hashgrid_fwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P, c_int, P]),
     'perf_hashgrid_fwd2': (c_int, [POINTER(GridDesc), P, P, P, P, P, c_int64, c_int, P]),
     'perf_hashgrid_fwd_f32': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P]),
     'perf_hashgrid_bwd_workspace_bytes': (c_int64, [POINTER(GridDesc), c_int64]),
-    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P, c_int, P, P, P, P, c_int, P, c_int64, P]),
+    'perf_hashgrid_bwd': (c_int, [POINTER(GridDesc), P, P, P, c_int64, P, c_int, P, P, P, P, c_int, P, P, c_int64, P]),
     'perf_dp_stats_pack': (c_int, [P, P, P, c_int64, P, P]),
-    'perf_dp_units': (c_int, [POINTER(GridDesc), P, c_int32, P, P, P, P]),
+    'perf_dp_units': (c_int, [POINTER(GridDesc), P, c_int32, P, P, P, c_int32, P]),
+    'perf_dp_slot_pack': (c_int, [P, P, P, c_int64, P, P, c_int64, c_int32, c_int32, P, P]),
+    'perf_dp_slot_unpack': (c_int, [P, c_int32, P, P, P, P]),
     'perf_fixed_unfix': (c_int, [POINTER(GridDesc), P, c_int64, c_int64, P, P, P, P]),
     'perf_hashgrid_corners': (c_int, [POINTER(GridDesc), P, P, c_int64, P]),
     'perf_hashgrid_bwd_input': (c_int, [POINTER(GridDesc), P, P, P, P, c_int64, P]),

@@ -307,7 +307,8 @@ constexpr int kBitmapMaxTiles = 2048;      // (2048 x 32 bytes of LDS staging pe
 
 // bitmap_tiles > 0: hashed levels of 256..bitmap_tiles tiles get LDS owners fed by per-tile bitmaps instead of the global
 // atomics (the caller checks that the workspace holds the bitmaps and plans again with 0 otherwise)
-static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_blocks, int64_t* ws_entries, int bitmap_tiles = 0) {
+static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_blocks, int64_t* ws_entries, int bitmap_tiles = 0,
+                       bool no_replicas = false) {
     int nb = 0;
     int64_t ws = 0;
     tp->atomic_levels = 0u;
@@ -349,7 +350,7 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
         // is an entry of most owners -- get the replicas that keep them from being the kernel's long pole (measured on a
         // 20-level grid: 2 tiles x 3 replicas 1.1 ms per workgroup, 8 x 2 0.66 ms, against 0.07-0.3 ms everywhere else)
         if (!gp.hashed[l] && fixed && bitmap_tiles > 0 && large_grid && !rep_env) r = nt == 1 ? 8 : (nt == 2 ? 8 : (nt == 4 ? 6 : (nt == 8 ? 4 : 2)));
-        if (r < 1) r = 1;
+        if (r < 1 || no_replicas) r = 1;
         if (r > kMaxReplicas) r = kMaxReplicas;
         tp->tiles_of[l] = nt; tp->replicas_of[l] = r;
         if (r > 1) { tp->ws_off[l] = ws; ws += (int64_t)r * gp.size[l]; }
@@ -1072,7 +1073,12 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    const uint32_t* __restrict__ escape,
                                                                    const uint32_t* __restrict__ bitmaps,
                                                                    const uint32_t* __restrict__ esc_bm, int64_t n,
-                                                                   const int64_t* __restrict__ n_dev) {
+                                                                   const int64_t* __restrict__ n_dev,
+                                                                   const int32_t* __restrict__ redo_flag) {
+    // a predicated REDO launch (perf_hashgrid_bwd, redo_flag): nothing happens unless the fixed-point call before it raised
+    // the flag -- the graph node costs a dispatch, the gradient table is left as that call wrote it
+    if (redo_flag && redo_flag[0] == 0) return;
+    if (redo_flag && hr_state && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&hr_state[2 * PERF_MAX_LEVELS + 1], 1);   // (statistics)
     const int64_t n_live = live_count(n, n_dev);            // samples present; n stays the stride of dfeat / codes
     extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats (+ the wave queues)
     unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
@@ -1365,7 +1371,7 @@ __global__ void dp_stats_pack_kernel(const float* __restrict__ level_absmax, con
 }
 
 __global__ void dp_units_kernel(GridParams gp, const int32_t* __restrict__ stats_all, int world, int32_t* __restrict__ hr_state,
-                                int32_t* __restrict__ shifts, int64_t* __restrict__ n_total_out) {
+                                int32_t* __restrict__ shifts, int64_t* __restrict__ n_total_out, int margin_bits) {
     __shared__ long long total_s;
     if (threadIdx.x == 0) {
         long long tot = 0;
@@ -1387,7 +1393,64 @@ __global__ void dp_units_kernel(GridParams gp, const int32_t* __restrict__ stats
         fm = max(fm, st[PERF_MAX_LEVELS + l]);
     }
     if (fm >= 0) hr_state[l] = headroom_feedback(hr_state[l], fm);        // (-1: no previous call, nothing to feed back)
-    shifts[l] = fixed_point_shift(am, total_s, gp.size[l], hr_state, l);
+    // margin_bits: units derived from the PREVIOUS step's statistics (lagged mode, see perf_dp_slot_pack) are made that many
+    // bits coarser -- room for the step-to-step growth of max |dfeat| the lag cannot see
+    shifts[l] = fixed_point_shift(am, total_s, gp.size[l], hr_state, l) - margin_bits;
+}
+
+// ---- the small all-reduce of a data-parallel step: one slot of PERF_DP_SLOT floats per rank behind the MLP weight gradient ----
+// A SUM all-reduce over a buffer in which every rank fills only ITS slot is an all-gather; integers travel as 16-bit pieces
+// (exact in fp32).  Slot layout: [0,24) max |dfeat| per level; [24,48) / [48,72) low / high 16 bits of the largest |field| per
+// level of the rank's slice of THIS step's summed table; [72,76) the live sample count in 16-bit pieces; [76] overflow flag
+// (local grid backward OR the rank's slice of the summed table); [77] batch truncated at the sample capacity.
+__global__ void dp_slot_pack_kernel(const float* __restrict__ level_absmax, const int32_t* __restrict__ field_max,
+                                    const int64_t* __restrict__ n_dev, int64_t n, const int32_t* __restrict__ overflow_flag,
+                                    const int64_t* __restrict__ n_marched_dev, int64_t capacity, int rank, int world,
+                                    float* __restrict__ slots) {
+    for (int i = threadIdx.x; i < world * PERF_DP_SLOT; i += blockDim.x) {
+        float v = 0.f;
+        const int r = i / PERF_DP_SLOT, k = i % PERF_DP_SLOT;
+        if (r == rank) {
+            if (k < PERF_MAX_LEVELS) v = level_absmax ? level_absmax[k] : 0.f;
+            else if (k < 2 * PERF_MAX_LEVELS) v = field_max ? (float)(field_max[k - PERF_MAX_LEVELS] & 0xffff) : 0.f;
+            else if (k < 3 * PERF_MAX_LEVELS) v = field_max ? (float)((uint32_t)field_max[k - 2 * PERF_MAX_LEVELS] >> 16) : 0.f;
+            else if (k < 3 * PERF_MAX_LEVELS + 4) {
+                const uint64_t live = (uint64_t)live_count(n, n_dev);
+                v = (float)((live >> (16 * (k - 3 * PERF_MAX_LEVELS))) & 0xffffull);
+            } else if (k == 3 * PERF_MAX_LEVELS + 4) v = (overflow_flag && overflow_flag[0] != 0) ? 1.f : 0.f;
+            else if (k == 3 * PERF_MAX_LEVELS + 5) v = (n_marched_dev && capacity > 0 && n_marched_dev[0] > capacity) ? 1.f : 0.f;
+        }
+        slots[i] = v;
+    }
+}
+
+// after the all-reduce: the ranks' slots -> the statistics block perf_dp_units reads (as if all-gathered by
+// perf_dp_stats_pack, with the field maxima of THIS step), the job-wide flags {overflow, truncated} perf_step_bookkeeping
+// reads as remote_flags, and the job's sample count
+__global__ void dp_slot_unpack_kernel(const float* __restrict__ slots, int world, int32_t* __restrict__ stats_all,
+                                      float* __restrict__ job_flags, int64_t* __restrict__ n_total_out) {
+    if (threadIdx.x == 0) {
+        float ovf = 0.f, trunc = 0.f;
+        long long tot = 0;
+        for (int r = 0; r < world; ++r) {
+            const float* s = slots + (int64_t)r * PERF_DP_SLOT + 3 * PERF_MAX_LEVELS;
+            ovf += s[4]; trunc += s[5];
+            tot += (long long)s[0] + ((long long)s[1] << 16) + ((long long)s[2] << 32) + ((long long)s[3] << 48);
+        }
+        if (job_flags) { job_flags[0] = ovf; job_flags[1] = trunc; }
+        if (n_total_out) n_total_out[0] = tot;
+    }
+    if (!stats_all) return;
+    for (int i = threadIdx.x; i < world * PERF_DP_STATS; i += blockDim.x) {
+        const int r = i / PERF_DP_STATS, k = i % PERF_DP_STATS;
+        const float* s = slots + (int64_t)r * PERF_DP_SLOT;
+        int32_t v = 0;
+        if (k < PERF_MAX_LEVELS) v = __float_as_int(s[k]);
+        else if (k < 2 * PERF_MAX_LEVELS) v = (int32_t)s[k] | ((int32_t)s[k + PERF_MAX_LEVELS] << 16);
+        else if (k == 2 * PERF_MAX_LEVELS) v = (int32_t)s[3 * PERF_MAX_LEVELS] | ((int32_t)s[3 * PERF_MAX_LEVELS + 1] << 16);
+        else if (k == 2 * PERF_MAX_LEVELS + 1) v = (int32_t)s[3 * PERF_MAX_LEVELS + 2] | ((int32_t)s[3 * PERF_MAX_LEVELS + 3] << 16);
+        stats_all[i] = v;
+    }
 }
 
 // int32 field pairs of table entries [entry_lo, entry_hi) -> fp32 gradients, in place; per-level largest |field| of the
@@ -1696,13 +1759,37 @@ extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid,
 extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
                                  float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
                                  int32_t* overflow_flag, int32_t* headroom_state, const int32_t* shifts_dev, int raw_fields,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
+                                 const int32_t* redo_flag, void* workspace, int64_t workspace_bytes, void* stream) {
     GridParams gp;
     int rc = fill_params(grid, &gp);
     if (rc) return rc;
     PERF_REQUIRE(grad_table, "NULL pointer");
     PERF_REQUIRE(n == 0 || (x01 && dfeat), "NULL pointer");
     const bool fixed = level_absmax != nullptr || shifts_dev != nullptr;
+    if (redo_flag) {
+        // The repair of a fixed-point call whose fields overflowed: ONE launch, predicated on the device flag, fp32 LDS
+        // accumulation, every tile owned by a single workgroup that streams positions (no pre-pass, no replica reduction: the
+        // slow-but-simple owners; the launch is a no-op dispatch in all but a handful of steps per million).
+        PERF_REQUIRE(!fixed && !accumulate && !raw_fields, "perf_hashgrid_bwd: a redo call is an fp32, overwriting call");
+        TileParams rp;
+        int nb = 0;
+        int64_t wse = 0;
+        plan_tiles(gp, false, &rp, &nb, &wse, 0, true);
+        if (rp.atomic_levels != 0u || nb == 0) { set_error("perf_hashgrid_bwd: the redo launch serves grids whose levels all fit LDS owners (<= 255 hashed / 64 dense tiles)"); return PERF_E_UNSUPPORTED; }
+        rp.accumulate = 0; rp.raw_out = 0; rp.dbg_off = 0; rp.run_merge = 0; rp.n_pad = 0;
+        for (int l = 0; l < PERF_MAX_LEVELS; ++l) rp.code_slot[l] = -1;
+        const int lds_b = 2 * kTileEntries * (int)sizeof(float) + (kBwdThreads / 64) * kQueueCap * (int)sizeof(uint32_t);
+        static std::once_flag redo_once;
+        std::call_once(redo_once, [&]() {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hashgrid_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+        });
+        if (n > 0)
+            hashgrid_bwd_kernel<false><<<dim3(nb), dim3(kBwdThreads), lds_b, as_stream(stream)>>>(
+                gp, rp, x01, (const float2*)dfeat, (float2*)grad_table, nullptr, nullptr, nullptr, headroom_state, nullptr, nullptr,
+                nullptr, nullptr, nullptr, nullptr, n, n_dev, redo_flag);
+        PERF_LAUNCH_CHECK("perf_hashgrid_bwd(redo)");
+        return PERF_OK;
+    }
     PERF_REQUIRE(!shifts_dev || !headroom_state, "perf_hashgrid_bwd: given units (shifts_dev) exclude the headroom feedback");
     PERF_REQUIRE(!raw_fields || (fixed && !accumulate), "perf_hashgrid_bwd: raw fields need the fixed-point mode and accumulate == 0");
     TileParams tp;
@@ -1787,11 +1874,11 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     } else if (fixed)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, headroom_state,
-            shifts_dev, shifts_ws, codes, escape, bitmaps, esc_bm, n, n_dev);
+            shifts_dev, shifts_ws, codes, escape, bitmaps, esc_bm, n, n_dev, nullptr);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, nullptr, nullptr, nullptr,
-            codes, escape, bitmaps, esc_bm, n, n_dev);
+            codes, escape, bitmaps, esc_bm, n, n_dev, nullptr);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (tp.atomic_levels && n > 0) {
         if (!accumulate)
@@ -1837,13 +1924,31 @@ extern "C" int perf_dp_stats_pack(const float* level_absmax, const int32_t* fiel
 }
 
 extern "C" int perf_dp_units(const perf_grid_desc* grid, const int32_t* stats_all, int32_t world, int32_t* headroom_state,
-                             int32_t* shifts_out, int64_t* n_total_out, void* stream) {
+                             int32_t* shifts_out, int64_t* n_total_out, int32_t margin_bits, void* stream) {
     GridParams gp;
     int rc = fill_params(grid, &gp);
     if (rc) return rc;
-    PERF_REQUIRE(stats_all && headroom_state && shifts_out && world >= 1, "perf_dp_units: bad arguments");
-    dp_units_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(gp, stats_all, world, headroom_state, shifts_out, n_total_out);
+    PERF_REQUIRE(stats_all && headroom_state && shifts_out && world >= 1 && margin_bits >= 0 && margin_bits <= 8, "perf_dp_units: bad arguments");
+    dp_units_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(gp, stats_all, world, headroom_state, shifts_out, n_total_out, margin_bits);
     PERF_LAUNCH_CHECK("perf_dp_units");
+    return PERF_OK;
+}
+
+extern "C" int perf_dp_slot_pack(const float* level_absmax, const int32_t* field_max, const int64_t* n_dev, int64_t n,
+                                 const int32_t* overflow_flag, const int64_t* n_marched_dev, int64_t capacity, int32_t rank,
+                                 int32_t world, float* slots, void* stream) {
+    PERF_REQUIRE(slots && world >= 1 && rank >= 0 && rank < world, "perf_dp_slot_pack: bad arguments");
+    dp_slot_pack_kernel<<<dim3(1), dim3(256), 0, as_stream(stream)>>>(level_absmax, field_max, n_dev, n, overflow_flag, n_marched_dev,
+                                                                       capacity, rank, world, slots);
+    PERF_LAUNCH_CHECK("perf_dp_slot_pack");
+    return PERF_OK;
+}
+
+extern "C" int perf_dp_slot_unpack(const float* slots, int32_t world, int32_t* stats_all, float* job_flags, int64_t* n_total_out,
+                                   void* stream) {
+    PERF_REQUIRE(slots && world >= 1, "perf_dp_slot_unpack: bad arguments");
+    dp_slot_unpack_kernel<<<dim3(1), dim3(256), 0, as_stream(stream)>>>(slots, world, stats_all, job_flags, n_total_out);
+    PERF_LAUNCH_CHECK("perf_dp_slot_unpack");
     return PERF_OK;
 }
 

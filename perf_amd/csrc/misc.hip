@@ -284,7 +284,7 @@ static int raygen_launch(const float* pose, const float* pose_dev, int32_t heigh
 namespace perf {
 __global__ void step_bookkeeping_kernel(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
                                         const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
-                                        int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out,
+                                        int32_t* overflow_flag, const float* remote_flags, int overflow_redone, int64_t* eff_gate_out,
                                         const float* schedule, int32_t n_schedule, int32_t* iter_dev, float* lr_out, float* ratio_out) {
     if (schedule && iter_dev && n_schedule > 0) {
         // device-side schedule: row i = {learning rate of iteration i, distortion-loss ramp of iteration i}.  This launch sits
@@ -299,8 +299,12 @@ __global__ void step_bookkeeping_kernel(int32_t* step_dev, const int64_t* gate_d
     const int64_t marched = n_marched_dev ? n_marched_dev[0] : 0;
     const bool has_samples = !gate_dev || gate_dev[0] > 0;
     const bool overflow = (overflow_flag && overflow_flag[0] != 0) || (remote_flags && remote_flags[0] > 0.f);
-    const bool truncated = capacity > 0 && marched > capacity;
-    const bool take = has_samples && !overflow && !truncated;
+    // remote_flags: {overflow, truncated} summed over the ranks of a data-parallel job (this rank's own included): every rank
+    // takes or skips the step alike
+    const bool truncated = (capacity > 0 && marched > capacity) || (remote_flags && remote_flags[1] > 0.f);
+    // overflow_redone: the caller repaired a flagged gradient in place (perf_hashgrid_bwd's redo launch): the event is counted,
+    // the step is taken
+    const bool take = has_samples && (!overflow || overflow_redone) && !truncated;
     if (step_dev && take) step_dev[0] += 1;
     if (eff_gate_out) eff_gate_out[0] = take ? 1 : 0;
     if (overflow_flag && overflow_flag[0] != 0) overflow_flag[0] = 0;      // consumed: counted below, the step is skipped
@@ -317,11 +321,11 @@ __global__ void step_bookkeeping_kernel(int32_t* step_dev, const int64_t* gate_d
 
 extern "C" int perf_step_bookkeeping(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
                                      const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
-                                     int32_t* overflow_flag, const float* remote_flags, int64_t* eff_gate_out,
+                                     int32_t* overflow_flag, const float* remote_flags, int32_t overflow_redone, int64_t* eff_gate_out,
                                      const float* schedule, int32_t n_schedule, int32_t* iter_dev, float* lr_out, float* ratio_out,
                                      void* stream) {
     hipLaunchKernelGGL(perf::step_bookkeeping_kernel, dim3(1), dim3(1), 0, as_stream(stream), step_dev, gate_dev, counters,
-                       n_marched_dev, n_kept_dev, capacity, overflow_flag, remote_flags, eff_gate_out, schedule, n_schedule, iter_dev,
+                       n_marched_dev, n_kept_dev, capacity, overflow_flag, remote_flags, (int)overflow_redone, eff_gate_out, schedule, n_schedule, iter_dev,
                        lr_out, ratio_out);
     PERF_LAUNCH_CHECK("perf_step_bookkeeping");
     return PERF_OK;

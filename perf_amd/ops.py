@@ -116,18 +116,20 @@ def adam_step_dev(p, m, v, g, step_dev, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8
 
 
 def step_bookkeeping(step_dev=None, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0, overflow=None,
-                     remote_flags=None, eff_gate=None, schedule=None):
+                     remote_flags=None, eff_gate=None, schedule=None, overflow_redone=False):
     """One launch (perf_step_bookkeeping): decides whether the optimizer step is TAKEN (samples present, no fixed-point
-    overflow flag -- local int32 `overflow` or the float sum `remote_flags` of the other ranks' --, batch not truncated at
-    `capacity`), advances step_dev and writes eff_gate (int64 [1]) accordingly, accumulates counters (int64 [8]).
+    overflow flag -- local int32 `overflow` or `remote_flags` (float32 [2] = {overflow, truncated} summed over the ranks of a
+    data-parallel job, dp_slot_unpack) --, batch not truncated at `capacity`), advances step_dev and writes eff_gate
+    (int64 [1]) accordingly, accumulates counters (int64 [8]).
     schedule = (table f32 [n, 2] = rows of (lr, distortion ramp), iter_dev int32 [1], lr_out f32 [1], ratio_out f32 [1] or None):
-    the device-side schedule of a graph-replayed phase (see perf_step_bookkeeping)."""
+    the device-side schedule of a graph-replayed phase (see perf_step_bookkeeping).  overflow_redone: the flagged gradient was
+    repaired in place (hashgrid_bwd_redo): count the event, take the step."""
     ref = next(t for t in (step_dev, counters, eff_gate) if t is not None)
     if not ref.is_cuda:
         raise _lib.PerfError('perf_amd ops need CUDA (HIP) tensors; there is no CPU path')
     table, it, lr_out, ratio_out = schedule if schedule is not None else (None, None, None, None)
     _call('perf_step_bookkeeping', _p(step_dev), _nd(gate), _nd(counters), _nd(n_marched), _nd(n_kept), int(capacity or 0),
-          _p(overflow), _p(remote_flags), _nd(eff_gate), _p(table), int(table.shape[0]) if table is not None else 0, _p(it),
+          _p(overflow), _p(remote_flags), int(bool(overflow_redone)), _nd(eff_gate), _p(table), int(table.shape[0]) if table is not None else 0, _p(it),
           _p(lr_out), _p(ratio_out), _stream())
 
 
@@ -225,7 +227,25 @@ def hashgrid_bwd(grid: GridConfig, x01, dfeat, out=None, accumulate=False, level
     _call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),
               n, _nd(n_dev), int(bool(accumulate)), _p(level_absmax), _p(flag),
               _p(hr_state if (level_absmax is not None and shifts is None) else None), _p(shifts), int(bool(raw_fields)),
-              _p(ws), ws_bytes, _stream())
+              None, _p(ws), ws_bytes, _stream())
+    return out
+
+
+def hashgrid_bwd_redo_supported(grid: GridConfig) -> bool:
+    """Grids whose levels all fit LDS owners (<= 255 hashed / 64 dense tiles of 16,384 entries): PeRF's L16/T18 does."""
+    for l in range(grid.n_levels):
+        tiles = -(-int(grid.size[l]) // 16384)
+        if tiles > (255 if grid.hashed[l] else 64):
+            return False
+    return True
+
+
+def hashgrid_bwd_redo(grid: GridConfig, x01, dfeat, out, n_dev=None, hr_state=None):
+    """The repair launch of a fixed-point hashgrid_bwd into the same `out`: a no-op dispatch unless that call raised the
+    overflow flag, else the table gradient again with fp32 LDS accumulation (perf_hashgrid_bwd, redo_flag)."""
+    d = grid.desc()
+    _call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),
+          x01.shape[0], _nd(n_dev), 0, None, None, _p(hr_state), None, 0, _p(overflow_flag(x01.device)), None, 0, _stream())
     return out
 
 
@@ -243,16 +263,31 @@ def dp_stats_pack(level_absmax, field_max_prev, n_dev, n, out=None):
     return out
 
 
-def dp_units(grid: GridConfig, stats_all, world, hr_state, shifts=None, n_total=None):
-    """stats_all int32 [world, PERF_DP_STATS] -> (shifts int32 [24], n_total int64 [1]); applies the headroom feedback to hr_state."""
+def dp_units(grid: GridConfig, stats_all, world, hr_state, shifts=None, n_total=None, margin_bits=0, want_total=True):
+    """stats_all int32 [world, PERF_DP_STATS] -> (shifts int32 [24], n_total int64 [1]); applies the headroom feedback to hr_state.
+    margin_bits: make the units that many bits coarser (lagged units of perf_amd/dp.py)."""
     dev = stats_all.device
     if shifts is None:
         shifts = torch.empty(_lib.MAX_LEVELS, dtype=torch.int32, device=dev)
-    if n_total is None:
+    if n_total is None and want_total:
         n_total = torch.empty(1, dtype=torch.int64, device=dev)
     d = grid.desc()
-    _call('perf_dp_units', ctypes.byref(d), _p(stats_all), int(world), _p(hr_state), _p(shifts), _nd(n_total), _stream())
+    _call('perf_dp_units', ctypes.byref(d), _p(stats_all), int(world), _p(hr_state), _p(shifts), _nd(n_total), int(margin_bits), _stream())
     return shifts, n_total
+
+
+def dp_slot_pack(level_absmax, field_max, n_dev, n, overflow, n_marched, capacity, rank, world, out):
+    """This rank's slot of the small all-reduce (perf_dp_slot_pack); `out`: float32 [world * PERF_DP_SLOT], the other slots are zeroed."""
+    _call('perf_dp_slot_pack', _p(level_absmax), _p(field_max), _nd(n_dev), int(n), _p(overflow), _nd(n_marched), int(capacity or 0),
+          int(rank), int(world), _p(_f32(out, 'slots')), _stream())
+    return out
+
+
+def dp_slot_unpack(slots, world, stats_all=None, job_flags=None, n_total=None):
+    """All-reduced slots -> stats_all (int32 [world, PERF_DP_STATS], optional), job_flags (float32 [2] = {overflow, truncated}
+    summed over the ranks), n_total (int64 [1])."""
+    _call('perf_dp_slot_unpack', _p(_f32(slots, 'slots')), int(world), _p(stats_all), _p(job_flags), _nd(n_total), _stream())
+    return job_flags, n_total
 
 
 def fixed_unfix(grid: GridConfig, fields, entry_lo, entry_hi, shifts, field_max=None, flag=None):

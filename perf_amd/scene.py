@@ -255,15 +255,22 @@ class FusedAdam:
         iteration `first`.  From then on perf_step_bookkeeping sets lr_dev (and ratio_out, the loss head's ramp scalar) itself:
         replaying a captured step needs no host-side scalar update.  The table has a fixed size (the captured launch keeps its
         pointers): a new phase just loads new rows.  Rows beyond the given ones repeat the last one."""
-        n = min(len(lrs), self.SCHEDULE_ROWS)
-        rows = torch.empty(self.SCHEDULE_ROWS, 2, dtype=torch.float32)
+        if len(lrs) < 1:
+            raise ValueError('load_schedule: empty schedule')
+        dev = self.lr_dev.device
+        if self.sched_table is None:                  # sized for the first phase it serves (a captured launch keeps its pointer)
+            self.sched_table = torch.empty(max(self.SCHEDULE_ROWS, len(lrs)), 2, dtype=torch.float32, device=dev)
+            self.sched_iter = torch.zeros(1, dtype=torch.int32, device=dev)
+        total = self.sched_table.shape[0]
+        if len(lrs) > total:
+            import warnings
+            warnings.warn(f'perf_amd: a phase of {len(lrs)} iterations exceeds the device-side schedule of {total} rows; '
+                          'iterations beyond it keep the last row (learning rate / distortion ramp frozen)')
+        n = min(len(lrs), total)
+        rows = torch.empty(total, 2, dtype=torch.float32)
         rows[:n, 0] = torch.as_tensor(lrs[:n], dtype=torch.float32)
         rows[:n, 1] = torch.as_tensor(ratios[:n], dtype=torch.float32) if ratios is not None else 1.0
         rows[n:] = rows[n - 1]
-        dev = self.lr_dev.device
-        if self.sched_table is None:
-            self.sched_table = torch.empty(self.SCHEDULE_ROWS, 2, dtype=torch.float32, device=dev)
-            self.sched_iter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sched_table.copy_(rows)
         self.sched_iter.fill_(int(first))
         self.sched_ratio_out = ratio_out
@@ -279,7 +286,7 @@ class FusedAdam:
             return None
         return (self.sched_table, self.sched_iter, self.lr_dev, self.sched_ratio_out)
 
-    def step(self, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0):
+    def step(self, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0, remote_flags=None):
         """gate (device int64 [1], optional): the number of samples behind this gradient.  The step is TAKEN unless the gate
         is 0 (the reference skips batches without samples, nerf.py:204-206), the fixed-point grid backward raised its
         overflow flag, or the batch was truncated at `capacity` samples -- decided on the device by perf_step_bookkeeping,
@@ -289,9 +296,13 @@ class FusedAdam:
             return
         g = self.param_groups[0]
         self.refresh_lr()
-        flag = ops.overflow_flag(p.device) if _tcnn.GRID_GRAD_ACCUM == 'fixed' else None
+        fixed = getattr(self.net, 'grid_grad_accum', 'fp32') == 'fixed'
+        flag = ops.overflow_flag(p.device) if fixed else None
+        # (a flagged fixed-point gradient was repaired in place by the redo launch behind the backward, NeRFScene._field_grad:
+        #  the event is counted, the step is taken)
         ops.step_bookkeeping(self.step_dev, gate, counters, n_marched, n_kept if n_kept is not None else gate, capacity=capacity,
-                             overflow=flag, eff_gate=self.eff_gate, schedule=self.schedule_args())
+                             overflow=flag, remote_flags=remote_flags, eff_gate=self.eff_gate, schedule=self.schedule_args(),
+                             overflow_redone=fixed and getattr(self.net, 'redo_supported', False))
         ops.adam_step_dev(p.data, self.exp_avg, self.exp_avg_sq, p.grad[:p.numel()], self.step_dev, self.lr_dev, g['betas'][0],
                           g['betas'][1], g['eps'], w16=self.w16, zero_grad=False, gate=self.eff_gate)
         p.grad = None                              # the next backward installs a fresh gradient (no accumulate pass)
@@ -307,8 +318,15 @@ class _HipStepKernels:
     def stats_pack(self, level_absmax, field_max_prev, n_dev, n, out):
         ops.dp_stats_pack(level_absmax, field_max_prev, n_dev, n, out=out)
 
-    def units(self, stats_all, world, shifts, n_total):
-        ops.dp_units(self.net.grid, stats_all, world, self.net.headroom_state(), shifts, n_total)
+    def units(self, stats_all, world, shifts, n_total, margin_bits=0):
+        ops.dp_units(self.net.grid, stats_all, world, self.net.headroom_state(), shifts, n_total, margin_bits=margin_bits,
+                     want_total=n_total is not None)
+
+    def slot_pack(self, level_absmax, field_max, n_dev, n, flag, n_marched, capacity, rank, world, out):
+        ops.dp_slot_pack(level_absmax, field_max, n_dev, n, flag, n_marched, capacity, rank, world, out)
+
+    def slot_unpack(self, slots, world, stats_all, job_flags, n_total):
+        ops.dp_slot_unpack(slots, world, stats_all, job_flags, n_total)
 
     def unfix(self, shard, lo, hi, shifts, field_max, flag):
         ops.fixed_unfix(self.net.grid, shard, lo, hi, shifts, field_max, flag)
@@ -372,6 +390,11 @@ class NeRFScene:
         # -> all-gather of the 16-bit working copy (perf_amd/dp.py; needs the fused Adam, the explicit step chains and the
         # fixed-point grid backward); 'allreduce' = one all-reduce of the flat fp32 (or bf16) gradient, Adam everywhere.
         self.dp_mode = 'sharded'
+        # fixed-point units of the sharded exchange: 'lagged' = from the previous step's statistics (three collectives per
+        # step, none between the MLP backward and the grid backward), 'exact' = statistics all-gather first (the units --
+        # and, bit for bit, the summed table -- of the single process; four collectives).  perf_amd/dp.py.
+        self.dp_units = os.environ.get('PERF_DP_UNITS', 'lagged')
+        self._dp_timing = None         # bench.py: {collective: [(event, event)]} of eager data-parallel steps
         # Random draws of the explicit training steps (batch indices, stratified jitter, distance noise, background colour):
         # True = ONE launch of the counter-based device generator per step (SupInfoPool.draw_batch; seeded from
         # torch.initial_seed() at first use, so torch.manual_seed controls it; the ranks of a data-parallel job must seed
@@ -381,11 +404,16 @@ class NeRFScene:
         self._rng_seed = None
         self._rng_counter = None
 
+    def _fixed_accum(self):
+        return self.nerf.geo_mlp.grid_grad_accum == 'fixed' and self.nerf.app_mlp.grid_grad_accum == 'fixed'
+
     # ---- distributed helpers ---------------------------------------------------------------------
+    _DP_OFF = False        # (class-wide switch, see bench.py: the plain step timed inside a multi-rank job)
+
     @staticmethod
     def _dist():
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
+        if dist.is_available() and dist.is_initialized() and not NeRFScene._DP_OFF:
             # (PERF_DP_SINGLE_RANK=1: a world of ONE rank takes the data-parallel path too -- how a single-GPU box exercises
             #  the RCCL exchange and its hipGraph capture, tests/test_gpu_dist.py)
             if dist.get_world_size() > 1 or os.environ.get('PERF_DP_SINGLE_RANK') == '1':
@@ -520,7 +548,7 @@ class NeRFScene:
             return True
         global _DP_GRAPH_VERDICT
         if _DP_GRAPH_VERDICT is not None:
-            return _DP_GRAPH_VERDICT and self.dp_mode == 'sharded' and self.fused_adam and _tcnn.GRID_GRAD_ACCUM == 'fixed'
+            return _DP_GRAPH_VERDICT and self.dp_mode == 'sharded' and self.fused_adam and self._fixed_accum()
         import os
         ok = dist.get_backend() == 'nccl' and os.environ.get('PERF_DP_GRAPH', '1') != '0'
         if ok:
@@ -545,7 +573,7 @@ class NeRFScene:
             dist.all_reduce(v, op=dist.ReduceOp.MIN)
             ok = bool(v.item() > 0.5)
         _DP_GRAPH_VERDICT = ok            # (one probe per process: the verdict is a property of the node and the backend)
-        return ok and self.dp_mode == 'sharded' and self.fused_adam and _tcnn.GRID_GRAD_ACCUM == 'fixed'
+        return ok and self.dp_mode == 'sharded' and self.fused_adam and self._fixed_accum()
 
     def _run_phase(self, kind, optimizer, conf, n_iters, sup_pool, callback, use_graphs, progress_of):
         step_fn = self.train_one_step_geo if kind == 'geo' else self.train_one_step_app
@@ -557,8 +585,11 @@ class NeRFScene:
                 graphed = self.make_graphed_step(kind, optimizer, sup_pool, warmup=0, schedule=(lrs, ratios, iter_i))
             if graphed is not None:
                 graphed()
-                if self._dist()[0] is not None:
-                    self._poll_health()            # (single-process replays poll by themselves)
+                if self._dist()[0] is not None and self._poll_health()['recapture']:
+                    # (single-process replays poll and re-capture by themselves; data-parallel ones here, on every rank at
+                    #  the same iteration -- the poll's verdict is job-wide.)  The capacity is baked into the captured step:
+                    #  capture again, the device-side schedule carries on where it is.
+                    graphed = self.make_graphed_step(kind, optimizer, sup_pool, warmup=0)
             else:
                 self.update_lr(optimizer, conf, iter_i / n_iters)
                 if kind == 'geo':
@@ -611,11 +642,12 @@ class NeRFScene:
         self._poll_health(net)
 
     def _poll_health(self, net=None, n_marched=None, force=False):
-        """Every OVERFLOW_CHECK_EVERY steps: ONE host read-back of the device-side counters (perf_step_bookkeeping).  Steps
-        whose fixed-point grid gradient overflowed or whose batch was truncated at the sample capacity were SKIPPED on the
-        device (never applied); here the host hears about them: it warns, switches the accumulation to fp32 after three
-        polls in a row with overflows, and doubles a capacity that proved too small.  -> {'recapture': bool} for callers
-        that replay a captured graph (mode and capacity are baked into it)."""
+        """Every OVERFLOW_CHECK_EVERY steps: ONE host read-back of the device-side counters (perf_step_bookkeeping).  A step
+        whose fixed-point grid gradient overflowed was REPAIRED on the device (fp32 redo launch; skipped on every rank alike
+        under data parallelism, where a repair would need a second exchange), a step whose batch was truncated at the sample
+        capacity was skipped; here the host hears about them: it warns and doubles a capacity that proved too small.  Under
+        data parallelism the ranks agree on what they saw (one tiny all-reduce), so they raise the capacity -- and re-capture
+        -- in lockstep.  -> {'recapture': bool} for callers that replay a captured graph (the capacity is baked into it)."""
         self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
         if self._capturing or (self._steps_since_check < OVERFLOW_CHECK_EVERY and not force):
             return {'recapture': False}
@@ -627,10 +659,19 @@ class NeRFScene:
         new_trunc = c[5] - seen[1] if c[5] >= seen[1] else c[5]
         self._health_seen = [c[4], c[5]]
         recapture = False
-        multi = self._dist()[0] is not None
-        # (under data parallelism every rank must keep issuing the same collectives: the accumulation mode never switches)
-        if _tcnn.GRID_GRAD_ACCUM == 'fixed' and _tcnn.note_fixed_point_overflows(new_ovf, sticky_after=10 ** 9 if multi else 3):
-            recapture = True
+        dist = self._dist()[0]
+        multi = dist is not None
+        if multi:
+            # every rank must reach the same decisions (capacity, recapture) at the same step: the polls run in lockstep,
+            # one tiny MAX all-reduce of what the ranks saw
+            t = torch.tensor([new_ovf, new_trunc, c[3]], dtype=torch.int64, device=self.sample_counters.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            new_ovf, new_trunc, c[3] = [int(v) for v in t.tolist()]
+        if new_ovf > 0:
+            # (the headroom feedback has widened the fields by now; nothing to switch: single-GPU steps repaired the gradient
+            #  in fp32 and were taken, data-parallel ones were skipped on every rank alike)
+            warnings.warn(f'perf_amd: {new_ovf} fixed-point grid gradient(s) came within 4x of the int32 range; '
+                          + ('the steps were skipped job-wide' if multi else 'they were redone with fp32 accumulation (no step was dropped)'))
         cap = self.renderer.sample_capacity
         if cap is not None and (new_trunc > 0 or c[3] > cap):
             warnings.warn(f'perf_amd: {new_trunc} training batch(es) marched up to {c[3]} samples, more than the capacity {cap}; '
@@ -682,32 +723,52 @@ class NeRFScene:
     def _field_grad(self, net, x01, w16, feat, sel, dout, n_dev=None, extra=0):
         """Flat gradient [network | grid] (+ `extra` trailing slots: the data-parallel path appends the sample count)."""
         n_net = net.mlp.n_params
-        fixed = _tcnn.GRID_GRAD_ACCUM == 'fixed'
+        fixed = net.grid_grad_accum == 'fixed'
         n_all = n_net + net.grid.n_params
         grad = torch.empty(n_all + extra, dtype=torch.float32, device=x01.device)
         res = ops.mlp_bwd(net.mlp, w16[:n_net], feat, dout, sel, want_absmax=fixed, n_dev=n_dev, dw_out=grad[:n_net])
         ops.hashgrid_bwd_into(net.grid, x01, res[0], grad[n_net:n_all], level_absmax=res[2] if fixed else None, n_dev=n_dev,
                               hr_state=net.headroom_state() if fixed else None)
+        if fixed and net.redo_supported:
+            # never drop a step: should a fixed-point field have neared the int32 range (device flag), this predicated launch
+            # rewrites the table gradient with fp32 LDS accumulation; a no-op dispatch otherwise (perf_hashgrid_bwd, redo_flag)
+            ops.hashgrid_bwd_redo(net.grid, x01, res[0], grad[n_net:n_all], n_dev=n_dev, hr_state=net.headroom_state())
         return grad
+
+    DP_EXTRA = 3           # trailing slots of the data-parallel gradient buffer: [sample count, overflow flag, truncated]
 
     def _apply_grad(self, net, grad, optimizer, dist_info, overlap, n_kept=None, n_marched=None):
         """[one RCCL all-reduce of the flat gradient] -> Adam.  n_kept: number of samples behind `grad` (device int64 [1], or a
-        host int in the eager variable-count path).  Under data parallelism the count travels in the last slot of the
-        gradient buffer, so the one collective also tells every rank whether ANY rank had samples; the optimizer step is
-        skipped when none had (the reference's `if not is_valid: return`, nerf.py:204-206)."""
+        host int in the eager variable-count path).  Under data parallelism three trailing slots of the gradient buffer travel
+        with it: the sample count -- the optimizer step is skipped when NO rank had samples (the reference's
+        `if not is_valid: return`, nerf.py:204-206) --, this rank's fixed-point overflow flag and whether its batch was
+        truncated at the sample capacity: after the one collective every rank holds the same sums and takes or skips the
+        step alike (perf_step_bookkeeping's remote_flags)."""
         dist = dist_info[0]
         n = net.params.numel()
         gate = n_kept if torch.is_tensor(n_kept) else None
+        remote = None
         if dist is not None:
-            if grad.numel() == n + 1:
+            extra = grad.numel() - n
+            if extra >= 1:
                 if torch.is_tensor(n_kept):
-                    grad[n:].copy_(n_kept)
+                    grad[n:n + 1].copy_(n_kept)
                 else:
-                    grad[n:].fill_(float(n_kept if n_kept is not None else 1))
+                    grad[n:n + 1].fill_(float(n_kept if n_kept is not None else 1))
+            if extra >= 3:
+                if net.grid_grad_accum == 'fixed' and isinstance(optimizer, FusedAdam) and not net.redo_supported:
+                    grad[n + 1:n + 2].copy_(ops.overflow_flag(grad.device))
+                else:
+                    grad[n + 1:n + 2].zero_()          # (a flagged local gradient was repaired in fp32 before it got here)
+                cap = self.renderer.sample_capacity or 0
+                if torch.is_tensor(n_marched) and cap > 0:
+                    grad[n + 2:n + 3].copy_(n_marched > cap)
+                else:
+                    grad[n + 2:n + 3].zero_()
             payload = grad
             if self.comm_dtype == 'bf16':
-                if grad.numel() == n + 1:
-                    grad[n:].clamp_(max=1.0)               # the count slot only has to say "some / none": exact in bf16
+                if extra >= 1:
+                    grad[n:n + 1].clamp_(max=1.0)          # the count slot only has to say "some / none": exact in bf16
                 payload = grad.to(torch.bfloat16)
             if overlap is not None:
                 work = dist.all_reduce(payload, op=dist.ReduceOp.SUM, async_op=True)
@@ -717,12 +778,15 @@ class NeRFScene:
                 dist.all_reduce(payload, op=dist.ReduceOp.SUM)
             if payload is not grad:
                 grad.copy_(payload)
-            if grad.numel() == n + 1:
-                gate = grad[n:].to(torch.int64)
-        net.params.grad = grad[:n]                 # (without the count slot of the data-parallel buffer)
+            if extra >= 1:
+                gate = grad[n:n + 1].to(torch.int64)
+            if extra >= 3:
+                remote = grad[n + 1:n + 3]
+        net.params.grad = grad[:n]                 # (without the trailing slots of the data-parallel buffer)
         if isinstance(optimizer, FusedAdam):
             optimizer.step(gate=gate, counters=self.sample_counters, n_marched=n_marched,
-                           n_kept=n_kept if torch.is_tensor(n_kept) else None, capacity=self.renderer.sample_capacity or 0)
+                           n_kept=n_kept if torch.is_tensor(n_kept) else None, capacity=self.renderer.sample_capacity or 0,
+                           remote_flags=remote)
         else:
             if gate is None or int(gate.item()) > 0:
                 optimizer.step()
@@ -732,7 +796,7 @@ class NeRFScene:
     # ---- data parallelism, sharded mode (perf_amd/dp.py) ---------------------------------------------------------------
     def _sharded(self, dist_info, optimizer):
         return (dist_info[0] is not None and self.dp_mode == 'sharded' and isinstance(optimizer, FusedAdam)
-                and _tcnn.GRID_GRAD_ACCUM == 'fixed')
+                and optimizer.net.grid_grad_accum == 'fixed')
 
     def _exchange_for(self, net, optimizer, dist_info):
         ex = getattr(net, '_dp_exchange', None)
@@ -740,7 +804,8 @@ class NeRFScene:
             from .dp import Collectives, ShardedExchange
             dist, rank, world = dist_info
             ex = ShardedExchange(net.mlp.n_params, net.grid.n_params, world, rank, Collectives(dist), net.params.device,
-                                 ops.torch_dtype(net.dtype_name), _HipStepKernels(net, optimizer))
+                                 ops.torch_dtype(net.dtype_name), _HipStepKernels(net, optimizer), units=self.dp_units)
+            ex.timing = self._dp_timing
             ex.seed_working_copy(net.working_copy())
             object.__setattr__(net, '_dp_exchange', ex)
         return ex
@@ -795,13 +860,13 @@ class NeRFScene:
                                             with_rgb=not (self.skip_unused_color or (dist_info[0] is not None and self.overlap_comm)),
                                             keep_features=self.reuse_sampling_features and self.renderer.sample_capacity is not None)
         geo = self.nerf.geo_mlp
-        extra = 1 if dist_info[0] is not None else 0
+        extra = self.DP_EXTRA if dist_info[0] is not None else 0
         sharded = self._sharded(dist_info, optimizer)
         if st is None or st is False:
             if sharded:                        # keep the collectives matched across ranks: this rank contributes nothing
                 self._dp_sharded_step(geo, optimizer, dist_info, None, None, None, None, None, None, None)
             elif dist_info[0] is not None:     # the count slot says "no samples here"
-                self._apply_grad(geo, torch.zeros(geo.params.numel() + 1, device=geo.params.device), optimizer, dist_info, None, n_kept=0)
+                self._apply_grad(geo, torch.zeros(geo.params.numel() + self.DP_EXTRA, device=geo.params.device), optimizer, dist_info, None, n_kept=0)
             self.global_iter_step_geo += 1
             return
         x01, sel, packed, ts, te, n_dev = st['x01'], st['sel'], st['packed'], st['t_starts'], st['t_ends'], st['n_dev']
@@ -835,11 +900,20 @@ class NeRFScene:
             self._geo_pre = self._geo_prefetch(sup_pool, rand_in, generator)
 
         if sharded:
-            # the deferred colour render hides the latency of the statistics all-gather, the next step's batch draw runs
-            # while the gradient fields travel
+            # What runs beside the 26.6 MB reduce-scatter of the gradient fields: the deferred colour render (an encode + MLP +
+            # accumulation that feed no loss term of this step: ~0.2 ms of compute at 1 M samples) and the next step's batch
+            # draw.  Exact units: the colour render hides the statistics all-gather instead (it sits on the critical path there).
+            want_prefetch = self.overlap_comm and prefetch_next and not self._capturing
+            exact = self.dp_units == 'exact'
+
+            def beside_reduce_scatter():
+                if defer_color and not exact:
+                    color_now()
+                if want_prefetch:
+                    prefetch_now()
             self._dp_sharded_step(geo, optimizer, dist_info, x01, w16, feat, sel, dsig.view(-1, 1), n_dev, st['n_marched_dev'],
-                                  early=color_now if defer_color else None,
-                                  late=prefetch_now if (self.overlap_comm and prefetch_next and not self._capturing) else None)
+                                  early=color_now if (defer_color and exact) else None,
+                                  late=beside_reduce_scatter if ((defer_color and not exact) or want_prefetch) else None)
             self.global_iter_step_geo += 1
             return
         grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1), n_dev=n_dev, extra=extra)
@@ -866,13 +940,13 @@ class NeRFScene:
             rays, gt_colors, gt_depths, bs, dist_info = self._batch(sup_pool, generator)
         st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand)
         app = self.nerf.app_mlp
-        extra = 1 if dist_info[0] is not None else 0
+        extra = self.DP_EXTRA if dist_info[0] is not None else 0
         sharded = self._sharded(dist_info, optimizer)
         if st is None:
             if sharded:
                 self._dp_sharded_step(app, optimizer, dist_info, None, None, None, None, None, None, None)
             elif dist_info[0] is not None:
-                self._apply_grad(app, torch.zeros(app.params.numel() + 1, device=app.params.device), optimizer, dist_info, None, n_kept=0)
+                self._apply_grad(app, torch.zeros(app.params.numel() + self.DP_EXTRA, device=app.params.device), optimizer, dist_info, None, n_kept=0)
             self.global_iter_step_app += 1
             return
         x01, sel, packed, ts, te, n_dev = st['x01'], st['sel'], st['packed'], st['t_starts'], st['t_ends'], st['n_dev']
@@ -1023,7 +1097,7 @@ class NeRFScene:
             self._capturing = optimizer.capturing = False
 
         state = {'graph': graph, 'n': 0, 'counts': self._last_counts, 'capacity': self.renderer.sample_capacity,
-                 'mode': _tcnn.GRID_GRAD_ACCUM}
+                 'mode': optimizer.net.grid_grad_accum}
 
         def replay(lr=None, progress=None):
             if optimizer.sched_table is None:                    # no device-side schedule: refresh the two scalars
@@ -1136,15 +1210,31 @@ class NeRFScene:
         return pano_visibility_mask(rays.o, rays.d, distance, sup_pool.sup_infos)
 
     # ---- state (nerf.py:368-395) --------------------------------------------------------------------
+    _STATE_KEY = '_perf_amd'
+
     def state_dict(self):
+        """nerf.py:374-380.  Under sharded data parallelism the fp32 master of a table slice is current only on its owner:
+        the replicas are refreshed first (sync_params: one all-gather per network -- a COLLECTIVE, every rank must call
+        state_dict() at the same point, as with any checkpoint of a data-parallel job)."""
+        self.sync_params()
+        # The fixed-point headroom feedback of the two grid gradients makes results depend on the call history: it travels
+        # with the checkpoint, under a private TOP-LEVEL key -- the reference's loader reads only 'render' / 'nerf' /
+        # 'estimator' (nerf.py:368-380) and its strict nerf.load_state_dict would reject a key inside 'nerf'.
         return {'render': self.renderer.state_dict(), 'nerf': self.nerf.state_dict(),
-                'estimator': self.estimator.state_dict()}
+                'estimator': self.estimator.state_dict(),
+                self._STATE_KEY: {'geo_headroom': self.nerf.geo_mlp.headroom_state().detach().clone(),
+                                  'app_headroom': self.nerf.app_mlp.headroom_state().detach().clone()}}
 
     def load_state_dict(self, state_dict):
         self.renderer.load_state_dict(state_dict['render'])
         self.nerf.load_state_dict(state_dict['nerf'])
         self.estimator.load_state_dict(state_dict['estimator'])
         self.estimator._bits = None
+        extra = state_dict.get(self._STATE_KEY)            # (absent in checkpoints the reference or earlier rounds wrote)
+        if extra:
+            for name, net in (('geo', self.nerf.geo_mlp), ('app', self.nerf.app_mlp)):
+                if name + '_headroom' in extra:
+                    net.headroom_state().copy_(extra[name + '_headroom'].to(net.params.device))
 
     def set_train(self):
         self.nerf.train(); self.estimator.train(); self.renderer.train()

@@ -23,44 +23,10 @@ from .grid import GridConfig, MlpConfig
 DEFAULT_DTYPE = 'bf16'     # BASELINE.json config 2 names bf16; 'fp16' reproduces tcnn's own precision
 DEFAULT_SEED = 1337        # tcnn's torch binding seeds its init with 1337
 # accumulation of the grid gradient: 'fp32' (LDS float atomics) or 'fixed' (packed 2x int32 fixed point, integer LDS
-# atomics, per-level power-of-two unit from max|dfeat| with 2^12 headroom; see hashgrid.hip)
+# atomics, per-level power-of-two unit from max|dfeat| under a closed-loop headroom; see hashgrid.hip).  This is the DEFAULT
+# new modules start with (NetworkWithInputEncoding.grid_grad_accum); nothing in the process mutates it behind a module's back.
 import os as _os
 GRID_GRAD_ACCUM = _os.environ.get('PERF_GRID_GRAD_ACCUM', 'fixed')
-
-
-_overflow_hits = 0
-
-
-def check_fixed_point_overflow(device=None, sticky_after=3):
-    """Read (one host sync) and clear the overflow-suspect flag of the fixed-point grid backward; True = some field came
-    within 4x of the int32 range since the last check.  Used by the autograd (shim) path, which polls after every backward and
-    repairs a hit in the same step.  NeRFScene's explicit step chains never read the flag on the host: the device-side
-    bookkeeping skips a flagged step (perf_step_bookkeeping) and counts it; see note_fixed_point_overflows()."""
-    flag = ops.overflow_flag(device or _default_device())
-    hit = bool(int(flag.item()))
-    if hit:
-        flag.zero_()
-    note_fixed_point_overflows(1 if hit else 0, sticky_after)
-    return hit
-
-
-def note_fixed_point_overflows(n_new, sticky_after=3):
-    """Bookkeeping of overflow events between two polls.  The headroom feedback (perf_hashgrid_bwd's headroom_state) has
-    already widened the fields for the following calls by the time a hit is seen, so the mode only switches to 'fp32' for
-    the rest of the process when `sticky_after` polls in a row saw hits.  -> True when the mode was switched by this call."""
-    global GRID_GRAD_ACCUM, _overflow_hits
-    if n_new <= 0:
-        _overflow_hits = 0
-        return False
-    import warnings
-    _overflow_hits += 1
-    if _overflow_hits >= sticky_after and GRID_GRAD_ACCUM == 'fixed':
-        GRID_GRAD_ACCUM = 'fp32'
-        warnings.warn('perf_amd: fixed-point grid-gradient accumulation keeps coming within 4x of its range; falling back to fp32 LDS accumulation')
-        return True
-    warnings.warn(f'perf_amd: {n_new} fixed-point grid gradient(s) came within 4x of the int32 range (headroom widened for the next calls; '
-                  'steps taken through perf_step_bookkeeping skipped them)')
-    return False
 
 
 def _init_params(mlp: MlpConfig, grid: GridConfig, seed: int) -> torch.Tensor:
@@ -97,7 +63,7 @@ class _FieldFn(torch.autograd.Function):
         x01, w16, feat, sel = ctx.saved_tensors
         module = ctx.module
         sel = sel if ctx.has_sel else None
-        return None, _field_backward(module, x01, w16, feat, sel, dout, n_dev=ctx.n_dev, poll_overflow=True), None, None, None
+        return None, _field_backward(module, x01, w16, feat, sel, dout, n_dev=ctx.n_dev, clear_flag=True), None, None, None
 
 
 def field_apply(module, x01, params, sel=None, n_dev=None):
@@ -108,26 +74,28 @@ def field_apply(module, x01, params, sel=None, n_dev=None):
     return _FieldFn.apply(x01, params, sel, module, n_dev)
 
 
-# Autograd (drop-in shim) path: how many backward calls between reads of the fixed-point overflow flag.  1 = every call:
-# the flag costs one host sync per backward, but a hit is repaired in the SAME step (the gradient is recomputed with
-# fp32 LDS accumulation before anything consumes it).  NeRFScene's explicit step chains poll at their own cadence.
-OVERFLOW_POLL_EVERY = int(_os.environ.get('PERF_OVERFLOW_POLL_EVERY', '1'))
-_backward_calls = 0
-
-
-def _field_backward(module, x01, w16, feat, sel, dout, n_dev=None, poll_overflow=False):
-    global _backward_calls
+def _field_backward(module, x01, w16, feat, sel, dout, n_dev=None, clear_flag=False):
+    """Flat gradient [network | grid] of one field.  Fixed-point accumulation never costs a step: should a field of the
+    grid gradient near the int32 range (device flag), the predicated repair launch right behind the backward rewrites the
+    table gradient with fp32 LDS accumulation -- a no-op dispatch otherwise; the host is not asked (no read-back per
+    backward, capturable).  clear_flag: the autograd (shim) path has no perf_step_bookkeeping behind it to consume the flag."""
     n_net = module.mlp.n_params
-    fixed = GRID_GRAD_ACCUM == 'fixed'          # module-level switch, see check_fixed_point_overflow()
+    fixed = module.grid_grad_accum == 'fixed'
     grad = torch.empty(n_net + module.grid.n_params, dtype=torch.float32, device=x01.device)
     res = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout.contiguous().float(), sel, want_absmax=fixed, n_dev=n_dev, dw_out=grad[:n_net])
     ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=res[2] if fixed else None, n_dev=n_dev,
                           hr_state=module.headroom_state() if fixed else None)
-    if fixed and poll_overflow and OVERFLOW_POLL_EVERY > 0 and not torch.cuda.is_current_stream_capturing():
-        _backward_calls += 1
-        if _backward_calls % OVERFLOW_POLL_EVERY == 0 and check_fixed_point_overflow(x01.device):
-            # the packed fixed-point sums of THIS call came too close to the int32 range: redo it in fp32
-            ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=None, n_dev=n_dev)
+    if fixed:
+        if module.redo_supported:
+            ops.hashgrid_bwd_redo(module.grid, x01, res[0], grad[n_net:], n_dev=n_dev, hr_state=module.headroom_state())
+            if clear_flag:
+                ops.overflow_flag(x01.device).zero_()
+        elif clear_flag and not torch.cuda.is_current_stream_capturing():
+            # (grids with levels beyond LDS owners -- BASELINE config 5 -- have no repair launch: ask the host, redo in fp32)
+            flag = ops.overflow_flag(x01.device)
+            if bool(int(flag.item())):
+                flag.zero_()
+                ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=None, n_dev=n_dev)
     return grad
 
 
@@ -154,9 +122,9 @@ class _DualFieldFn(torch.autograd.Function):
         sel = sel if ctx.has_sel else None
         ga = gb = None
         if ctx.needs_input_grad[1] and da is not None:
-            ga = _field_backward(ctx.mods[0], x01, wa, fa, sel, da)
+            ga = _field_backward(ctx.mods[0], x01, wa, fa, sel, da, clear_flag=True)
         if ctx.needs_input_grad[2] and db is not None:
-            gb = _field_backward(ctx.mods[1], x01, wb, fb, sel, db)
+            gb = _field_backward(ctx.mods[1], x01, wb, fb, sel, db, clear_flag=True)
         return None, ga, gb, None, None, None
 
 
@@ -185,7 +153,9 @@ class NetworkWithInputEncoding(nn.Module):
         self.params = nn.Parameter(_init_params(self.mlp, self.grid, seed).to(_default_device()))
         self._w16 = None
         self._w16_key = None
-        self._hr_state = ops.headroom_state(self.params.device)     # (plain attribute: not part of the checkpoint)
+        self._hr_state = ops.headroom_state(self.params.device)     # (plain attribute; NeRFScene.state_dict() carries it)
+        self.grid_grad_accum = GRID_GRAD_ACCUM                      # this module's accumulation mode ('fixed' | 'fp32')
+        self.redo_supported = ops.hashgrid_bwd_redo_supported(self.grid)
 
     # -- 16-bit working copy, refreshed when the fp32 master changes -------------------------------
     def working_copy(self, params=None):
@@ -202,6 +172,10 @@ class NetworkWithInputEncoding(nn.Module):
         if st is None or st.device != self.params.device:
             st = self._hr_state = ops.headroom_state(self.params.device)
         return st
+
+    def fp32_redo_count(self):
+        """How often the repair launch of the fixed-point grid backward really ran (one host read-back; diagnostics)."""
+        return int(self.headroom_state()[2 * ops._lib.MAX_LEVELS + 1].item())
 
     def set_working_copy(self, w16):
         """Adopt a working copy written by the fused Adam kernel (perf_adam_step)."""

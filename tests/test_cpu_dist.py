@@ -130,10 +130,13 @@ def test_apply_grad_world2_sums_gradients_and_skips_empty_steps(tmp_path):
 #      all-gather of the 16-bit copy.  The compute steps are torch stand-ins of the HIP kernels (same contracts); what is
 #      tested is the choreography: slices and padding, gates, flags, buffer reuse, master gathering. ---------------------------
 class _CpuKernels:
+    """torch stand-ins of the HIP kernels perf_amd.dp.ShardedExchange drives (same contracts, include/perf_hip.h)."""
     SHIFT = 12
+    SLOT = 80
 
     def __init__(self):
         self.flag = torch.zeros(1, dtype=torch.int32)
+        self.units_calls = []
 
     def stats_pack(self, level_absmax, field_max_prev, n_dev, n, out):
         out.zero_()
@@ -142,11 +145,14 @@ class _CpuKernels:
         live = n if n_dev is None else min(n, int(n_dev))
         out[48] = live
 
-    def units(self, stats_all, world, shifts, n_total):
+    def units(self, stats_all, world, shifts, n_total, margin_bits=0):
         st = stats_all.view(world, -1)
-        shifts.fill_(self.SHIFT)
-        n_total.fill_(int(st[:, 48].sum()))
+        shifts.fill_(self.SHIFT)                # (a fixed unit: what is tested is the choreography, not the headroom rule)
+        if n_total is not None:
+            n_total.fill_(int(st[:, 48].sum()))
         self.seen_field_max = st[:, 24:48].max(0).values.clone()
+        self.seen_absmax = st[:, :24].clone().view(torch.float32).max(0).values
+        self.units_calls.append(int(margin_bits))
 
     def unfix(self, shard, lo, hi, shifts, field_max, flag):
         n = 2 * (hi - lo)
@@ -154,10 +160,35 @@ class _CpuKernels:
         field_max.zero_()
         if n:
             field_max[0] = int(ints.abs().max())
+            if int(field_max[0]) >= (1 << 29):
+                flag.fill_(1)
         shard.view(torch.float32)[:n] = ints.float() * 2.0 ** -self.SHIFT
 
+    def slot_pack(self, level_absmax, field_max, n_dev, n, flag, n_marched, capacity, rank, world, out):
+        out.zero_()
+        s = out.view(world, self.SLOT)[rank]
+        s[:24] = level_absmax
+        s[24:48] = (field_max & 0xffff).float(); s[48:72] = (field_max >> 16).float()
+        live = n if n_dev is None else min(n, int(n_dev))
+        for k in range(4):
+            s[72 + k] = float((live >> (16 * k)) & 0xffff)
+        s[76] = 1.0 if int(flag) != 0 else 0.0
+        s[77] = 1.0 if (n_marched is not None and capacity > 0 and int(n_marched) > capacity) else 0.0
+
+    def slot_unpack(self, slots, world, stats_all, job_flags, n_total):
+        s = slots.view(world, self.SLOT)
+        job_flags[0] = s[:, 76].sum(); job_flags[1] = s[:, 77].sum()
+        n_total.fill_(int(sum(int(s[r, 72 + k]) << (16 * k) for r in range(world) for k in range(4))))
+        if stats_all is not None:
+            st = stats_all.view(world, -1)
+            st.zero_()
+            st[:, :24] = s[:, :24].contiguous().view(torch.int32)
+            st[:, 24:48] = s[:, 24:48].int() | (s[:, 48:72].int() << 16)
+            st[:, 48] = (s[:, 72].int() | (s[:, 73].int() << 16))
+
     def bookkeeping(self, step_dev, gate, counters, n_marched, n_kept, capacity, overflow, remote_flags, eff_gate):
-        take = int(gate) > 0 and int(overflow) == 0 and float(remote_flags) == 0.0
+        truncated = (n_marched is not None and capacity > 0 and int(n_marched) > capacity) or float(remote_flags[1]) > 0.0
+        take = int(gate) > 0 and int(overflow) == 0 and float(remote_flags[0]) == 0.0 and not truncated
         if take:
             step_dev += 1
         overflow.zero_()
@@ -181,56 +212,75 @@ def _fields_of(step, rank, n_grid):
     return torch.randint(-2000, 2000, (n_grid,), generator=g, dtype=torch.int32)
 
 
-_DP_STEPS = ((5, 7, False), (0, 3, False), (0, 0, False), (4, 4, True), (2, 2, False))     # (samples rank 0, rank 1, rank 1 flags an overflow)
+# (samples rank 0, samples rank 1, what goes wrong on rank 1 ONLY): a local overflow flag of its grid backward; a batch truncated
+# at the capacity; fields whose SUM reaches 2^29 in rank 1's slice (the flag is raised by unfix, after the reduce-scatter)
+_DP_STEPS = ((5, 7, None), (0, 3, None), (0, 0, None), (4, 4, 'flag'), (2, 2, None), (3, 3, 'truncated'), (6, 1, None),
+             (2, 5, 'sum_overflow'), (1, 1, None))
+_CAPACITY = 100
 
 
-def _run_exchange(ex, kern, rank_fields, rank_counts, flagged, opt, n_net):
-    """One step on one rank: (this rank's fields, its sample count, does it flag an overflow)."""
-    amax = torch.full((24,), 0.5)
+def _step_taken(c0, c1, wrong):
+    return (c0 + c1) > 0 and wrong is None
+
+
+def _run_exchange(ex, kern, step_i, rank, rank_counts, wrong, opt, n_net):
+    """One step on one rank."""
+    amax = torch.full((24,), 0.5 + step_i)
     ex.exchange_units(amax, torch.tensor([rank_counts]), 10 ** 6)
     ex.payload.zero_()
     if rank_counts > 0:
-        ex.payload[:ex.n_grid].copy_(rank_fields)
-    if flagged:
+        ex.payload[:ex.n_grid].copy_(_fields_of(step_i, rank, ex.n_grid))
+    if wrong == 'sum_overflow':
+        ex.payload[2 * 30] = (1 << 28) + 5          # entry 30 lives in rank 1's slice; each rank stays below 2^29, the sum does not
+    if wrong == 'flag' and rank == 1:
         kern.flag.fill_(1)
+    n_marched = torch.tensor([_CAPACITY + 50 if (wrong == 'truncated' and rank == 1) else 10])
     dw = torch.full((n_net,), float(rank_counts))
     opt.lr_dev.fill_(1e-2)
-    return ex.reduce_and_step(dw, opt).clone()
+    return ex.reduce_and_step(dw, opt, n_marched=n_marched, capacity=_CAPACITY).clone()
 
 
-def _exchange_worker(rank, world, port, out):
+def _exchange_worker(rank, world, port, out, units):
     import types
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from perf_amd.dp import Collectives, ShardedExchange
     n_net, n_grid = 8, 2 * 37                      # 37 entries: the slices are 20 and 17 entries, with padding behind
     kern = _CpuKernels()
-    ex = ShardedExchange(n_net, n_grid, world, rank, Collectives(dist), 'cpu', torch.bfloat16, kern)
+    ex = ShardedExchange(n_net, n_grid, world, rank, Collectives(dist), 'cpu', torch.bfloat16, kern, units=units)
     p0 = torch.linspace(-1, 1, n_net + n_grid)
     opt = types.SimpleNamespace(p=p0.clone(), exp_avg=torch.zeros(n_net + n_grid), exp_avg_sq=torch.zeros(n_net + n_grid),
                                 step_dev=torch.zeros(1, dtype=torch.int32), lr_dev=torch.zeros(1))
     ex.seed_working_copy(p0.to(torch.bfloat16))
-    hist = []
-    for s_i, (c0, c1, flag1) in enumerate(_DP_STEPS):
-        w16 = _run_exchange(ex, kern, _fields_of(s_i, rank, n_grid), (c0, c1)[rank], flag1 and rank == 1, opt, n_net)
-        hist.append(w16)
+    hist, steps, gates, mlp = [], [], [], []
+    for s_i, (c0, c1, wrong) in enumerate(_DP_STEPS):
+        w16 = _run_exchange(ex, kern, s_i, rank, (c0, c1)[rank], wrong, opt, n_net)
+        hist.append(w16); steps.append(int(opt.step_dev)); gates.append(int(ex.eff_gate)); mlp.append(opt.p[:n_net].clone())
     stale = opt.p.clone()
     ex.gather_master(opt.p)
-    torch.save({'hist': hist, 'p': opt.p, 'stale': stale, 'steps': int(opt.step_dev), 'lo': ex.lo, 'hi': ex.hi,
-                'prev_field_max_seen': kern.seen_field_max}, out + f'.{rank}')
+    torch.save({'hist': hist, 'p': opt.p, 'stale': stale, 'steps': steps, 'gates': gates, 'mlp': mlp, 'lo': ex.lo, 'hi': ex.hi,
+                'prev_field_max_seen': kern.seen_field_max, 'absmax_seen': kern.seen_absmax, 'units_calls': kern.units_calls,
+                'exp_avg': opt.exp_avg[:n_net].clone()}, out + f'.{rank}')
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_exchange_world2_equals_the_single_process_step(tmp_path):
-    import types
-    out = str(tmp_path / 'ex.pt')
-    mp.spawn(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+def _check_sharded_exchange(tmp_path, units):
+    out = str(tmp_path / f'ex_{units}.pt')
+    mp.spawn(_exchange_worker, args=(2, _free_port(), out, units), nprocs=2, join=True)
     r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
     # both ranks hold the same working copy after every step, and the same master after gather_master
     for a, b in zip(r0['hist'], r1['hist']):
         assert torch.equal(a, b)
-    assert torch.equal(r0['p'], r1['p']) and r0['steps'] == r1['steps'] == 3
+    n_taken = sum(_step_taken(*st) for st in _DP_STEPS)
+    # THE JOB-WIDE GATE: whatever went wrong on rank 1 only (local overflow flag, truncated batch, an overflow that only shows
+    # in its slice of the SUMMED table), both ranks skip the step: equal gates, step counts, MLP weights and moments
+    assert r0['gates'] == r1['gates'] == [1 if _step_taken(*st) else 0 for st in _DP_STEPS]
+    assert r0['steps'] == r1['steps'] and r0['steps'][-1] == n_taken
+    for a, b in zip(r0['mlp'], r1['mlp']):
+        assert torch.equal(a, b)
+    assert torch.equal(r0['exp_avg'], r1['exp_avg'])
+    assert torch.equal(r0['p'], r1['p'])
     assert (r0['lo'], r0['hi'], r1['lo'], r1['hi']) == (0, 20, 20, 37)
     # before the gather a rank's master of the OTHER slice is stale (never touched), its own slice is current
     n_net = 8
@@ -242,14 +292,31 @@ def test_sharded_exchange_world2_equals_the_single_process_step(tmp_path):
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     step = torch.zeros(1, dtype=torch.int32); lr = torch.full((1,), 1e-2)
     w16 = p.to(torch.bfloat16)
-    for s_i, (c0, c1, flag1) in enumerate(_DP_STEPS):
+    for s_i, (c0, c1, wrong) in enumerate(_DP_STEPS):
         total = sum(_fields_of(s_i, r, n_grid) for r, c in enumerate((c0, c1)) if c > 0) if (c0 + c1) > 0 else torch.zeros(n_grid, dtype=torch.int32)
         g = torch.cat([torch.full((n_net,), float(c0 + c1)), total.float() * 2.0 ** -kern.SHIFT])
-        gate = torch.tensor([1 if (c0 + c1 > 0 and not flag1) else 0])
+        gate = torch.tensor([1 if _step_taken(c0, c1, wrong) else 0])
         if int(gate):
             step += 1
         kern.adam(p, m, v, g, w16, step, lr, gate)
-        assert torch.equal(r0['hist'][s_i], w16), s_i             # incl. the skipped steps (no samples anywhere; flagged overflow)
+        assert torch.equal(r0['hist'][s_i], w16), s_i             # incl. the skipped steps
     assert torch.equal(r0['p'], p)
-    # the largest field of the previous step's slices reached the next step's unit exchange
+    # the statistics of a step reach the NEXT step's units: the largest field of the slices, the largest |dfeat|
     assert int(r0['prev_field_max_seen'][0]) > 0
+    n_steps = len(_DP_STEPS)
+    if units == 'lagged':
+        # one exact exchange (the first step: nothing to lag behind), then one derivation per step from its own statistics,
+        # one bit coarser; the last one saw the last step's max |dfeat|
+        assert r0['units_calls'] == [0] + [1] * n_steps
+        assert float(r0['absmax_seen'][0]) == 0.5 + (n_steps - 1)
+    else:
+        assert r0['units_calls'] == [0] * n_steps
+    return r0
+
+
+def test_sharded_exchange_world2_equals_the_single_process_step(tmp_path):
+    _check_sharded_exchange(tmp_path, 'exact')
+
+
+def test_sharded_exchange_world2_with_lagged_units(tmp_path):
+    _check_sharded_exchange(tmp_path, 'lagged')

@@ -225,9 +225,10 @@ def test_adam_gate_skips_a_batch_without_samples(ops):
 
 def test_step_gate_skips_overflowed_and_truncated_batches(ops):
     """perf_step_bookkeeping decides on the DEVICE whether the optimizer step is taken: a raised fixed-point overflow flag (local,
-    or the float sum of other ranks' flags) or a batch that marched more samples than the capacity closes the gate that
-    perf_adam_step_dev reads -- a corrupted or truncated gradient is never applied; the events are counted and the local flag
-    is consumed."""
+    or the job-wide sum remote_flags[0]) or a batch that marched more samples than the capacity (locally, or on any rank:
+    remote_flags[1]) closes the gate that perf_adam_step_dev reads -- a corrupted or truncated gradient is never applied; the
+    events are counted and the local flag is consumed.  overflow_redone: the caller repaired the flagged gradient in place
+    (fp32 redo launch) -- counted, but the step is TAKEN."""
     n = 1000
     p = torch.linspace(-1, 1, n).cuda(); m = torch.zeros(n).cuda(); v = torch.zeros(n).cuda()
     grad = torch.ones(n).cuda()
@@ -235,21 +236,113 @@ def test_step_gate_skips_overflowed_and_truncated_batches(ops):
     counters = ops.step_counters('cuda')
     eff = torch.zeros(1, dtype=torch.int64, device='cuda')
     flag = torch.zeros(1, dtype=torch.int32, device='cuda')
-    remote = torch.zeros(1, dtype=torch.float32, device='cuda')
-    cases = [  # (local flag, remote flags, marched, capacity, taken)
-        (0, 0.0, 500, 1000, True), (1, 0.0, 500, 1000, False), (0, 2.0, 500, 1000, False), (0, 0.0, 1001, 1000, False),
-        (0, 0.0, 1000, 1000, True), (0, 0.0, 5000, 0, True)]
+    remote = torch.zeros(2, dtype=torch.float32, device='cuda')
+    cases = [  # (local flag, remote overflow, remote truncated, marched, capacity, redone, taken)
+        (0, 0.0, 0.0, 500, 1000, False, True), (1, 0.0, 0.0, 500, 1000, False, False), (0, 2.0, 0.0, 500, 1000, False, False),
+        (0, 0.0, 0.0, 1001, 1000, False, False), (0, 0.0, 0.0, 1000, 1000, False, True), (0, 0.0, 0.0, 5000, 0, False, True),
+        (0, 0.0, 1.0, 500, 1000, False, False), (1, 0.0, 0.0, 500, 1000, True, True), (1, 0.0, 0.0, 1001, 1000, True, False)]
     taken = 0
-    for lf, rf, marched, cap, want in cases:
-        flag.fill_(lf); remote.fill_(rf)
+    for lf, ro, rt, marched, cap, redone, want in cases:
+        flag.fill_(lf); remote[0] = ro; remote[1] = rt
         before = p.clone()
-        ops.step_bookkeeping(step, _nd(10), counters, _nd(marched), _nd(10), capacity=cap, overflow=flag, remote_flags=remote, eff_gate=eff)
+        ops.step_bookkeeping(step, _nd(10), counters, _nd(marched), _nd(10), capacity=cap, overflow=flag, remote_flags=remote, eff_gate=eff,
+                             overflow_redone=redone)
         ops.adam_step_dev(p, m, v, grad, step, lr, gate=eff)
         taken += int(want)
         assert int(eff.item()) == int(want) and int(step.item()) == taken and int(flag.item()) == 0
         assert torch.equal(p, before) == (not want)
     c = counters.tolist()
-    assert c[2] == len(cases) and c[3] == 5000 and c[4] == 2 and c[5] == 1, c
+    assert c[2] == len(cases) and c[3] == 5000 and c[4] == 4 and c[5] == 3, c
+
+
+def test_an_overflowed_fixed_point_gradient_is_repaired_not_dropped(ops):
+    """Never drop a step: with the headroom forced down to its floor the packed fixed-point fields of the grid gradient
+    overflow; the predicated repair launch behind the backward (perf_hashgrid_bwd, redo_flag) rewrites the table gradient
+    with fp32 LDS accumulation -- equal to the fp32-mode gradient up to the order of fp32 atomics -- and is a no-op when the
+    flag is clear (the fixed-point table stays, bit for bit).  End to end: the flagged step is TAKEN and counted, eagerly and
+    as a graph replay."""
+    from perf_amd.grid import MlpConfig
+    cfg = _cfg()
+    g = torch.Generator().manual_seed(11)
+    n = 60000
+    x = _ray_points(n, g).cuda()
+    spec = O.geo_spec()
+    params = O.init_field_params(spec); params[spec.n_net:] *= 1e4
+    w16 = ops.cast_params(params.cuda(), 'bf16')
+    mlp = MlpConfig(n_levels=16, n_hidden_layers=1, n_output_dims=1, output_activation='Exponential')
+    feat = ops.hashgrid_fwd(cfg, x, w16[spec.n_net:])
+    dout = (torch.rand(n, 1, generator=g) + 0.5).cuda()        # one sign: an entry's contributions add up coherently
+    dfeat, dw, amax = ops.mlp_bwd(mlp, w16[:spec.n_net], feat, dout, want_absmax=True)
+    flag = ops.overflow_flag(x.device); flag.zero_()
+    ref32 = ops.hashgrid_bwd(cfg, x, dfeat)                                   # fp32 accumulation
+    hr = ops.headroom_state(x.device)
+    fixed = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, hr_state=hr)
+    assert int(flag.item()) == 0
+    kept = fixed.clone()
+    ops.hashgrid_bwd_redo(cfg, x, dfeat, kept, hr_state=hr)                   # flag clear: nothing happens
+    assert torch.equal(kept, fixed) and int(hr[2 * 24 + 1].item()) == 0
+    hr2 = ops.headroom_state(x.device); hr2[:24] = -24                        # headroom at its floor of 4 bits
+    broken = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, hr_state=hr2)
+    assert int(flag.item()) == 1, 'the forced overflow did not raise the flag'
+    ops.hashgrid_bwd_redo(cfg, x, dfeat, broken, hr_state=hr2)
+    assert float((broken - ref32).abs().max()) <= 1e-5 * float(ref32.abs().max())
+    assert int(hr2[2 * 24 + 1].item()) == 1                                   # the repair ran once
+    flag.zero_()
+    # ---- end to end: a geometry step whose gradient overflows is taken (eager, then as a graph replay)
+    results = {}
+    for accum in ('fixed', 'fp32'):
+        scene, pool, rays, dist, rgb = _room_scene(dtype='bf16', batch=1024, train_steps=3)
+        geo = scene.nerf.geo_mlp
+        geo.grid_grad_accum = accum
+        scene.renderer.sample_capacity = 1024 * 128
+        scene.sample_counters.zero_()
+        opt = scene.make_optimizer(geo, 1e-3)
+        torch.manual_seed(3)
+        if accum == 'fixed':
+            geo.headroom_state()[:24] = -24
+        scene.update_lr(opt, scene.train_conf.geo_optimizer, 0.1)
+        scene.train_one_step_geo(opt, pool, progress=0.5)
+        results[accum] = (geo.params.detach().clone(), opt.step_count, scene.sample_counters.tolist())
+        lr = scene.lr_at(scene.train_conf.geo_optimizer, 0.1)
+        if accum == 'fixed':
+            replay = scene.make_graphed_step('geo', opt, pool, warmup=0)
+            geo.headroom_state()[:24] = -24
+            before = geo.params.detach().clone()
+            replay(1e-3, 0.5)
+            torch.cuda.synchronize()
+            c = scene.sample_counters.tolist()
+            assert opt.step_count == 2 and c[4] == 2 and not torch.equal(before, geo.params.detach()), (opt.step_count, c)
+    pf, sf, cf = results['fixed']; p3, s3, c3 = results['fp32']
+    assert sf == s3 == 1 and cf[4] == 1 and c3[4] == 0, (sf, s3, cf, c3)       # taken AND counted
+    # the repaired step equals the fp32-mode step (Adam's first step is lr * sign-like: compare where the gradient is not noise)
+    assert float((pf - p3).abs().max()) <= 2.1 * lr and float((pf - p3).abs().mean()) <= 2e-3 * lr, (float((pf - p3).abs().max()), float((pf - p3).abs().mean()))
+
+
+def test_dp_slots_carry_the_statistics_exactly(ops):
+    """perf_dp_slot_pack / perf_dp_slot_unpack: integers travel as 16-bit pieces in the fp32 all-reduce buffer and come out
+    exactly; the summed slots equal what an all-gather of perf_dp_stats_pack blocks would hold; the job flags add up."""
+    from perf_amd import _lib
+    world = 3
+    dev = 'cuda'
+    slots = [torch.empty(world * _lib.DP_SLOT, device=dev) for _ in range(world)]
+    amax = [torch.rand(24, device=dev) * 10 ** (r - 1) for r in range(world)]
+    fmax = [torch.randint(0, 2 ** 31 - 1, (24,), device=dev, dtype=torch.int32) for r in range(world)]
+    fmax[1][3] = 2 ** 31 - 1; fmax[2][5] = 65535; fmax[0][7] = 65536
+    lives = [123456789012, 0, 77]
+    flags = [0, 1, 0]; marched = [10, 10, 5000]
+    for r in range(world):
+        fl = torch.tensor([flags[r]], dtype=torch.int32, device=dev)
+        ops.dp_slot_pack(amax[r], fmax[r], _nd(lives[r]), 10 ** 13, fl, _nd(marched[r]), 1000, r, world, slots[r])
+    summed = sum(slots)                                                       # what the SUM all-reduce leaves on every rank
+    stats = torch.zeros(world * _lib.DP_STATS, dtype=torch.int32, device=dev)
+    job = torch.zeros(2, device=dev); total = torch.zeros(1, dtype=torch.int64, device=dev)
+    ops.dp_slot_unpack(summed, world, stats, job, total)
+    st = stats.view(world, -1)
+    for r in range(world):
+        assert torch.equal(st[r, :24], amax[r].view(torch.int32)) and torch.equal(st[r, 24:48], fmax[r])
+        ref = ops.dp_stats_pack(amax[r], fmax[r], _nd(lives[r]), 10 ** 13)
+        assert torch.equal(st[r, :50], ref[:50])
+    assert int(total.item()) == sum(lives) and job.tolist() == [1.0, 1.0]
 
 
 def test_autograd_path_runs_beyond_the_health_poll_with_a_capacity_set():

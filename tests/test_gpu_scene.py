@@ -553,7 +553,9 @@ def test_checkpoint_format_and_render_dense(tmp_path):
     pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, dist)
     scene.set_train(); scene.prepare_occupancy(pool)
     sd = scene.state_dict()
-    assert set(sd.keys()) == {'render', 'nerf', 'estimator'}
+    # (+ one private top-level key: the fixed-point headroom state; the reference's loader reads only its own three, nerf.py:368-380)
+    assert set(sd.keys()) == {'render', 'nerf', 'estimator', '_perf_amd'}
+    assert set(sd['_perf_amd'].keys()) == {'geo_headroom', 'app_headroom'}
     assert set(sd['nerf'].keys()) == {'aabb', 'geo_mlp.params', 'app_mlp.params'}
     assert set(sd['estimator'].keys()) == {'resolution', 'aabbs', 'occs', 'binaries'}
     assert sd['nerf']['geo_mlp.params'].dtype == torch.float32 and sd['nerf']['geo_mlp.params'].numel() == 3072 + 6641216
