@@ -85,6 +85,9 @@ def parse():
                          'visibility compaction of the reference step (not the headline)')
     ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample')
     ap.add_argument('--no-psnr', action='store_true')
+    ap.add_argument('--no-render-block', action='store_true', help='skip the full-panorama inference measurement (`render` block)')
+    ap.add_argument('--no-config4', action='store_true', help='skip the render_dense traverse (`config4` block)')
+    ap.add_argument('--config4-poses', type=int, default=600, help='BASELINE config 4: poses of the dense trajectory')
     ap.add_argument('--no-reuse-line', action='store_true', help='skip the extra measurement with the other setting of NeRFScene.reuse_sampling_features')
     ap.add_argument('--psnr-geo-iters', type=int, default=3000, help='configs/nerf.yaml:25 raw_phase_iter_geo')
     ap.add_argument('--psnr-app-iters', type=int, default=1500, help='configs/nerf.yaml:26 raw_phase_iter_app')
@@ -126,37 +129,50 @@ def cpu_baseline(spp, n_rays):
             break
     dt = (time.perf_counter() - t0) / reps
     return {'value': n / dt, 'unit': 'ray-samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'note': "NOT the reference's own CPU path -- it has none: NGPNeRF exits without tiny-cuda-nn (modules/fields/ngp_nerf.py:13-21); "
+                    'this is oracle/perf_oracle.py, the CPU restatement of the same algorithm (torch fp32)',
             'sample': f'oracle geo training step (sampling-pass sigma + compaction + fwd + bwd), {len(o)} rays x ~{n // len(o)} kept samples, '
                       f'{reps} reps of {dt:.2f}s'}
 
 
-def psnr_at_iters(args, dev, dist_mod, rank, world):
+def psnr_at_iters(args, dev, dist_mod, rank, world, start_dense=None):
     """PSNR@iter: one training episode at the reference's settings (occupancy from the supervision, step 5e-4,
     early stop 1e-4, 8192-ray global batch, --psnr-geo-iters geometry then --psnr-app-iters colour iterations) on the
-    synthetic room panorama; PSNR of the eval render against the panorama at colour iterations {0, 1/3, end}."""
+    synthetic room panorama; PSNR of the eval render against the panorama at colour iterations {0, 1/3, end}.
+    -> (block, scene, extras): extras carries what the `faithful` / `config4` blocks are built from (phase wall times, hipGraph
+    node counts, the supervision maps; start_dense(dist_map) is called before the training so that config 4's trajectory
+    sampler runs beside it)."""
     from perf_amd import synthetic
     from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays, psnr
     torch.manual_seed(0)
     scene = NeRFScene(dtype=args.dtype)
     scene.dp_mode, scene.comm_dtype = args.dp_mode, args.comm_dtype
+    scene.count_graph_nodes = True
     rays = gen_pano_rays(torch.eye(4), args.height, args.width, device=dev)
     dist_map, rgb_map = synthetic.room(rays.d)
     pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb_map, dist_map)
+    dense_future = start_dense(dist_map) if start_dense is not None else None
     n_app = args.psnr_app_iters
     marks = sorted({0, n_app // 3, n_app})
     curve, times = {}, {}
+    phase_t = {}
     torch.cuda.synchronize(); t0 = time.perf_counter()
 
     def probe(tag):
         torch.cuda.synchronize(); t = time.perf_counter()
         if rank == 0:
             out = scene.render(rays, ['rgb', 'distance'])
+            torch.cuda.synchronize(); times.setdefault('renders', []).append(time.perf_counter() - t)
             curve[tag] = {'psnr_db': round(psnr(out['rgb'], rgb_map), 3),
                           'mean_abs_distance_err': round(float((out['distance'] - dist_map).abs().mean()), 5)}
             scene.set_train()
         torch.cuda.synchronize(); times['probe'] = times.get('probe', 0.0) + time.perf_counter() - t
 
     def cb(phase, i):
+        n_it = args.psnr_geo_iters if phase == 'geo' else n_app
+        if i == scene.EAGER_HEAD or i == n_it - 1:        # wall time of the graph-replayed part of a phase (one sync at either end)
+            torch.cuda.synchronize()
+            phase_t.setdefault(phase, []).append((i, time.perf_counter(), times.get('probe', 0.0)))
         if phase == 'geo' and i == args.psnr_geo_iters - 1 and 0 in marks:
             probe('app_iter_0')
         if phase == 'app' and (i + 1) in marks:
@@ -165,12 +181,127 @@ def psnr_at_iters(args, dev, dist_mod, rank, world):
     scene.train_one_episode(pool, args.psnr_geo_iters, n_app, callback=cb)
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
-    return {'schedule': f'{args.psnr_geo_iters} geometry + {n_app} colour iterations, global batch {scene.train_conf.pixel_loss_batch_size} rays, '
-                        f'{args.width}x{args.height} synthetic room, reference sampling (step 5e-4, early stop 1e-4), seed 0',
-            'curve': curve, 'train_seconds': round(total - times.get('probe', 0.0), 3), 'render_seconds_total': round(times.get('probe', 0.0), 3),
-            'launch': 'hipGraph replay per step' if (scene.graph_steps and scene.dp_graph_ok()) else 'eager',
-            'note': 'the fp32 oracle cannot run this size on a CPU; HIP-vs-oracle PSNR parity after equal iterations is asserted at 256x512 by '
-                    'tests/test_gpu_psnr.py against tests/golden/psnr_curve.json'}
+    block = {'schedule': f'{args.psnr_geo_iters} geometry + {n_app} colour iterations, global batch {scene.train_conf.pixel_loss_batch_size} rays, '
+                         f'{args.width}x{args.height} synthetic room, reference sampling (step 5e-4, early stop 1e-4), seed 0',
+             'curve': curve, 'train_seconds': round(total - times.get('probe', 0.0), 3), 'render_seconds_total': round(times.get('probe', 0.0), 3),
+             'render_seconds_each': [round(t, 4) for t in times.get('renders', [])],
+             'launch': 'hipGraph replay per step' if (scene.graph_steps and scene.dp_graph_ok()) else 'eager',
+             'note': 'the fp32 oracle cannot run this size on a CPU; HIP-vs-oracle PSNR parity after equal iterations is asserted at 256x512 by '
+                     'tests/test_gpu_psnr.py against tests/golden/psnr_curve.json'}
+    faithful = {}
+    for phase, marks_t in phase_t.items():
+        if len(marks_t) >= 2:
+            (i0, ta, pa), (i1, tb, pb) = marks_t[0], marks_t[-1]
+            if i1 > i0:
+                faithful[f'{phase}_ms_per_step'] = round(((tb - ta) - (pb - pa)) / (i1 - i0) * 1e3, 4)
+    for phase, n_nodes in getattr(scene, 'graph_nodes', {}).items():
+        faithful[f'{phase}_launches_per_step'] = n_nodes
+    if faithful:
+        faithful['what'] = ("the reference-faithful episode above (occupancy from the supervision, step 5e-4, variable sample counts, 8192-ray batches): "
+                            'wall time per hipGraph-replayed step (probe renders excluded); launches = nodes of the captured step graph')
+        ec = scene.sample_counters.tolist()
+        if ec[2] > 0:
+            faithful['mean_kept_samples_per_step'] = round(ec[1] / ec[2], 1)
+            faithful['mean_marched_samples_per_step'] = round(ec[0] / ec[2], 1)
+    return block, scene, {'faithful': faithful or None, 'rays': rays, 'dist_map': dist_map, 'rgb_map': rgb_map, 'pool': pool,
+                          'dense_future': dense_future}
+
+
+def render_block(args, dev, rays):
+    """`north_star`: rays/s on a synthetic 2048x1024 panorama at 128 samples per ray.  Fixed-count eval render (all-occupied
+    grid, 128 lattice intervals per ray, the reference's early stop at T < 1e-4) of the whole panorama from a fresh
+    initialisation (nothing terminates early: every ray-sample is evaluated by both fields and composited), in the reference's
+    32,768-ray batches (nerf.py:86) with device-side counts; warm; no PSNR reduction inside the timed region."""
+    from perf_amd import ops
+    from perf_amd.scene import NeRFScene, Rays
+    torch.manual_seed(0)
+    scene = NeRFScene(dtype=args.dtype)
+    scene.set_eval()
+    scene.estimator.set_binaries(torch.ones(256 ** 3, dtype=torch.uint8, device=dev))
+    r = scene.renderer
+    r.render_step_size = 0.99 / args.spp; r.far_plane = 1.5; r.early_stop_eps = 1e-4; r.max_steps = args.spp; r.head_samples = None
+    B = 32768
+    r.sample_capacity = B * args.spp
+    flat_o = rays.o.reshape(-1, 3); flat_d = rays.d.reshape(-1, 3)
+    n_rays = flat_o.shape[0]
+    n_batches = (n_rays + B - 1) // B
+    outs = {'rgb': torch.empty(n_rays, 3, device=dev), 'distance': torch.empty(n_rays, 1, device=dev)}
+
+    def pano():
+        with torch.no_grad():
+            for b in range(n_batches):
+                lo, hi = b * B, min((b + 1) * B, n_rays)
+                res = scene.render_once(Rays(flat_o[lo:hi], flat_d[lo:hi]), ['rgb', 'distance', 'n_marched_dev', 'n_samples_dev'])
+                outs['rgb'][lo:hi].copy_(res['rgb']); outs['distance'][lo:hi].copy_(res['distance'])
+                ops.step_bookkeeping(None, None, scene.sample_counters, res['n_marched_dev'], res['n_samples_dev'])
+    pano()                                             # warm-up (allocator, kernel attributes)
+    scene.sample_counters.zero_()
+    reps = 2
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        pano()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    c = scene.sample_counters.tolist()
+    marched, kept = c[0] / reps, c[1] / reps
+    ops.start_kernel_timing()
+    pano()
+    kern = ops.stop_kernel_timing()
+    enc = kern.get('perf_hashgrid_fwd')
+    algo = 2 * ALGO_BYTES['perf_hashgrid_fwd']         # one density + one colour encode per ray-sample = 1,024 B (SURVEY.md 8(d))
+    blk = {'what': f'{args.width}x{args.height} fixed-count eval panorama, {args.spp} samples/ray, {n_batches} batches of {B} rays, fresh '
+                   'initialisation (nothing pruned), both fields + compositing, device-side counts; mean of 2 warm renders',
+           'seconds_per_panorama': round(el, 5), 'rays_per_s': n_rays / el, 'ray_samples_per_s': kept / el,
+           'marched_samples': marched, 'kept_samples': kept, 'dtype': args.dtype,
+           'roofline': {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'algorithmic_bytes_per_ray_sample': algo,
+                        'achieved': round(algo * kept / el / 1e9, 1), 'frac': round(algo * kept / el / 1e9 / HBM_PEAK_GBS, 4),
+                        'definition': 'whole render: 1,024 B x kept ray-samples / wall time of the panorama'},
+           'kernel_ms_per_panorama': {k: round(n * ms, 3) for k, (n, ms) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:8]}}
+    if enc:
+        per_launch = ALGO_BYTES['perf_hashgrid_fwd'] * (marched + kept) / 2 / n_batches          # mean live samples of the two encodes of a batch
+        blk['roofline']['encode_kernel'] = {'ms_per_launch': round(enc[1], 4), 'launches': enc[0],
+                                            'algorithmic_GBps': round(per_launch / (enc[1] * 1e-3) / 1e9, 1),
+                                            'frac_of_hbm_peak': round(per_launch / (enc[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return blk
+
+
+def config4_block(args, dev, scene, extras, n_poses=600):
+    """BASELINE config 4: CoreRunner.render_dense (core_exp_runner.py:223-246) -- a 600-pose dense trajectory through the scene the
+    PSNR episode just trained, 512x1024 panoramic frames, fp16 inference, every frame ONE hipGraph replay (rays generated on
+    the device from the pose).  The trajectory sampler (host, annealed tour) was started before the training and ran beside it."""
+    import numpy as np
+    fh, fw = 512, 1024
+    t0 = time.perf_counter()
+    dense = extras['dense_future'].result()
+    t_wait = time.perf_counter() - t0
+    poses = []
+    for i in range(dense.n_poses):
+        p = dense.sample_pose(i).clone().float()
+        p[:3, :3] = torch.eye(3)                                        # core_exp_runner.py:232
+        poses.append(p)
+    for net in (scene.nerf.geo_mlp, scene.nerf.app_mlp):               # fp16 inference of the bf16-trained fields: the 16-bit
+        net.dtype_name = 'fp16'                                         # working copy is re-cast from the fp32 master
+    scene.nerf.dtype_name = 'fp16'
+    scene.set_eval()
+    out = {'what': f'render_dense: {len(poses)} poses, {fw}x{fh} frames, fp16 inference of the scene trained above, reference sampling '
+                   '(step 5e-4, early stop 1e-4, two-phase sampler), one hipGraph replay per frame',
+           'pose_sampler': {'start_call_s': round(extras.get('dense_start_s', 0.0), 4), 'wait_s': round(t_wait, 4),
+                            'where': 'forked host worker, started before the training episode'}}
+    for tag, batch, n_frames in (('frame_as_one_batch', fh * fw, len(poses)), ('reference_batches_of_32768', 32768, max(len(poses) // 5, 1))):
+        frame = scene.make_graphed_render(fh, fw, ('rgb', 'distance'), batch_size=batch)
+        for p in poses[:2]:
+            frame(p)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for p in poses[:n_frames]:
+            last = frame(p)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out[tag] = {'frames': n_frames, 'seconds': round(el, 4), 'frames_per_s': round(n_frames / el, 1), 'rays_per_s': n_frames * fh * fw / el,
+                    'batches_per_frame': (fh * fw + batch - 1) // batch, 'per_ray_sample_capacity': frame.state['per_ray'],
+                    'last_frame_rgb_sum': float(last['rgb'].double().sum())}
+    one = out['frame_as_one_batch']
+    out['wall_s_600_frames_including_sampler'] = round(one['seconds'] * len(poses) / one['frames'] + extras.get('dense_start_s', 0.0) + t_wait, 4)
+    return out
 
 
 def _flush_native_stdout():
@@ -250,20 +381,21 @@ def main():
     pool = SupInfoPool()
     pool.register_rays(rays.o, rays.d, rgb_map, dist_map)
 
-    def build(reuse_features, scaling, graph=True):
+    def build(reuse_features, scaling, graph=True, dp_mode=None):
         """Fresh scene + optimizer + (graphed) step of the benchmark workload -> dict(scene, step, eager_step, rays_per_step, graphed)."""
         torch.manual_seed(0)                                              # the same random streams on every rank (scene.py)
         scene = NeRFScene(dtype=args.dtype)
         tc = scene.train_conf
         scene.comm_dtype = args.comm_dtype
-        scene.dp_mode = args.dp_mode
+        scene.dp_mode = dp_mode or args.dp_mode
         scene.reuse_sampling_features = reuse_features
         if scaling == 'weak':
             rays_local = args.rays_per_gpu                               # 8192 rays on every GPU
         else:
             assert args.rays_per_gpu % world == 0
             rays_local = args.rays_per_gpu // world                      # the reference's 8192-ray batch split over the GPUs
-        tc.pixel_loss_batch_size = rays_local * world
+        # (NeRFScene._DP_OFF: the plain single-GPU step on this rank's share of the workload, every rank for itself)
+        tc.pixel_loss_batch_size = rays_local * (1 if NeRFScene._DP_OFF else world)
         # fixed-count marching: all-occupied grid, 128 lattice intervals of 0.99/128 from the (jittered) origin; the
         # reference's early termination (T >= 1e-4 after the no-grad density pass) then prunes what it prunes
         scene.set_train()
@@ -344,9 +476,9 @@ def main():
         c = cnt.tolist()
         return el, int(c[0]), int(c[1]), {'skipped_for_overflow': int(c[4]), 'skipped_for_truncation': int(c[5])}
 
-    def measure(reuse_features, scaling, graph=True):
+    def measure(reuse_features, scaling, graph=True, dp_mode=None):
         """Build, W warmup steps, K timed steps -> (run, result dict)."""
-        run = build(reuse_features, scaling, graph)
+        run = build(reuse_features, scaling, graph, dp_mode)
         for i in range(args.warmup):
             run['step'](i)
         el, marched, kept, health = timed(run, args.steps, args.warmup)
@@ -357,6 +489,39 @@ def main():
                'launch': ('hipGraph replay of the whole step' + (' (collectives captured with it)' if world > 1 else ''))
                          if run['graphed'] is not None else 'eager', **health}
         return run, res
+
+    def comm_times(r, first, n_steps):
+        """Eager data-parallel steps with every collective issued synchronously between two HIP events on the launch stream
+        (perf_amd/dp.py: ShardedExchange._timed; NeRFScene._apply_grad for the all-reduce mode) -> ms per step per collective."""
+        sc = r['scene']
+        timing = {}
+        sc._dp_timing = timing
+        for net in (sc.nerf.geo_mlp, sc.nerf.app_mlp):
+            ex = getattr(net, '_dp_exchange', None)
+            if ex is not None:
+                ex.timing = timing
+        try:
+            for i in range(n_steps):
+                r['eager_step'](first + i)
+            torch.cuda.synchronize()
+        finally:
+            sc._dp_timing = None
+            for net in (sc.nerf.geo_mlp, sc.nerf.app_mlp):
+                ex = getattr(net, '_dp_exchange', None)
+                if ex is not None:
+                    ex.timing = None
+        per = {k: round(sum(a.elapsed_time(b) for a, b in v) / n_steps, 4) for k, v in timing.items()}
+        t = torch.tensor([per.get(k, 0.0) for k in sorted(per)], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per = {k: round(float(v), 4) for k, v in zip(sorted(per), t.tolist())}
+        sizes = None
+        ex = getattr(sc.nerf.geo_mlp, '_dp_exchange', None)
+        if ex is not None:
+            sizes = {'reduce_scatter_in_bytes': int(ex.payload.numel() * 4), 'all_reduce_small_bytes': int(ex.ar.numel() * 4),
+                     'all_gather_w16_out_bytes': int((ex.w16_full.numel() - ex.n_net) * ex.w16_full.element_size()), 'units': ex.units}
+        return {'dp_mode': sc.dp_mode, 'ms_per_step_per_collective': per, 'comm_ms_per_step': round(sum(per.values()), 4), 'bytes': sizes,
+                'how': 'eager steps, each collective synchronous between two HIP events on the launch stream (nothing overlaps it), max over ranks'}
 
     other = 'strong' if args.scaling == 'weak' else 'weak'
     notes = []
@@ -401,16 +566,34 @@ def main():
         sustained = {'steps': n_long, 'seconds': round(el2, 4), 'value': k2 / el2, 'ms_per_step': el2 / n_long * 1e3,
                      'kept_samples_per_step_per_gpu': k2 / n_long / world, 'marched_samples_per_step_per_gpu': m2 / n_long / world, **h2}
 
-    # per-kernel times: the same K steps again, launched eagerly with a HIP event pair around every C-ABI launch on the
-    # launch stream (events cannot be recorded inside a graph replay; same kernels, same shapes, same device-side counts)
-    scene.sample_counters.zero_()
-    ops.start_kernel_timing()
+    # per-kernel times IN THE STATE THE HEADLINE WAS TIMED IN: a fresh build of the same workload, the same W warm-up steps,
+    # then the same K steps launched eagerly with a HIP event pair around every C-ABI launch on the launch stream (events
+    # cannot be recorded inside a graph replay; same kernels, same shapes, same device-side counts).  `kernels_late`: the same
+    # pass on the scene the sustained loop left behind (the density field has formed: early termination prunes a third of the
+    # samples) -- gather / scatter kernels only.
+    def kernel_pass(r, first):
+        r['scene'].sample_counters.zero_()
+        ops.start_kernel_timing()
+        for i in range(args.steps):
+            r['eager_step'](first + i)
+        k = ops.stop_kernel_timing()
+        c = r['scene'].sample_counters.tolist()
+        return k, (c[0] / max(args.steps, 1), c[1] / max(args.steps, 1))             # per step, this rank
+
     first = args.warmup + args.steps + (sustained['steps'] if sustained else 0)
-    for i in range(args.steps):
-        eager_step(first + i)
-    kern = ops.stop_kernel_timing()
-    c_ev = scene.sample_counters.tolist()
-    marched_ev, kept_ev = c_ev[0] / max(args.steps, 1), c_ev[1] / max(args.steps, 1)     # per step, this rank
+    kern_late, ev_late = kernel_pass(run, first)
+    comm_block = None
+    if world > 1 or single_rank_dp:
+        # per-collective times: eager data-parallel steps with every collective issued synchronously between two events
+        try:
+            comm_block = comm_times(run, first + args.steps, args.steps)
+        except Exception as e:       # noqa: BLE001
+            notes.append(f'per-collective timing failed ({type(e).__name__}: {e})')
+    run_k = build(reuse_default, args.scaling, graph=False)
+    for i in range(args.warmup):
+        run_k['eager_step'](i)
+    kern, ev_counts = kernel_pass(run_k, args.warmup)
+    del run_k
 
     # the other setting of NeRFScene.reuse_sampling_features, from the same fresh initialisation: the reference evaluates the
     # density field twice on the kept samples (no-grad inside sampling, with grad in the renderer: same parameters, same
@@ -429,15 +612,60 @@ def main():
             _, other_block = measure(reuse_default, other, graph=head['launch'] != 'eager')
         except Exception as e:       # noqa: BLE001
             notes.append(f'{other}-scaling measurement failed ({type(e).__name__}: {e})')
+    # N > 1: what the exchange costs.  (a) the SAME per-rank workload as a plain single-GPU step, every rank for itself (no
+    # collective): exposed communication = data-parallel step - this; (b) the single all-reduce of the flat gradient that
+    # `north_star` names (dp_mode = 'allreduce'), for comparison with the sharded exchange of the headline.
+    if (world > 1 or single_rank_dp) and args.mode != 'render':
+        try:
+            NeRFScene._DP_OFF = True
+            _, plain = measure(reuse_default, args.scaling)
+            NeRFScene._DP_OFF = False
+            comm_block = dict(comm_block or {})
+            comm_block['single_rank_step_ms'] = plain['ms_per_step']
+            comm_block['exposed_comm_ms'] = head['ms_per_step'] - plain['ms_per_step']
+            comm_block['exposed_comm_definition'] = ('ms_per_step of the data-parallel step minus ms_per_step of the plain single-GPU step on the same per-rank '
+                                                     'workload (every rank for itself, hipGraph replay, max over ranks)')
+        except Exception as e:       # noqa: BLE001
+            NeRFScene._DP_OFF = False
+            notes.append(f'single-rank reference step failed ({type(e).__name__}: {e})')
+        try:
+            alt_mode = 'allreduce' if args.dp_mode == 'sharded' else 'sharded'
+            _, alt = measure(reuse_default, args.scaling, graph=False, dp_mode=alt_mode)
+            comm_block = dict(comm_block or {})
+            comm_block['other_exchange'] = {'dp_mode': alt_mode, 'value': alt['value'], 'ms_per_step': alt['ms_per_step'], 'launch': alt['launch'],
+                                            'what': 'one all-reduce of the flat fp32 gradient per step, Adam on every rank (the exchange north_star names)'
+                                                    if alt_mode == 'allreduce' else 'int32 reduce-scatter -> sliced Adam -> all-gather'}
+        except Exception as e:       # noqa: BLE001
+            notes.append(f'comparison exchange failed ({type(e).__name__}: {e})')
 
     psnr_block = None
+    faithful_block = render_blk = config4_blk = None
     if not args.no_psnr and args.mode == 'train_geo':
         try:
-            psnr_block = psnr_at_iters(args, dev, dist, rank, world)
+            start_dense = None
+            extras_box = {}
+            if world == 1 and not args.no_config4:
+                def start_dense(dist_map):
+                    from perf_amd.pose_sampler import CirclePoseSampler, DenseTravelPoseSampler
+                    t0 = time.perf_counter()
+                    sparse = CirclePoseSampler(dist_map.reshape(args.height, args.width).cpu(), traverse_ratios=[.2, .4, .6], n_anchors_per_ratio=[8, 8, 8])
+                    fut = DenseTravelPoseSampler.start(sparse, n_dense_poses=args.config4_poses)
+                    extras_box['dense_start_s'] = time.perf_counter() - t0
+                    return fut
+            import numpy as np
+            np.random.seed(0)
+            psnr_block, psnr_scene, extras = psnr_at_iters(args, dev, dist, rank, world, start_dense=start_dense)
+            extras.update(extras_box)
+            faithful_block = extras['faithful']
+            if world == 1 and not args.no_config4 and rank == 0:
+                config4_blk = config4_block(args, dev, psnr_scene, extras, n_poses=args.config4_poses)
+            del psnr_scene, extras
         except Exception as e:       # noqa: BLE001
             if world == 1:
                 raise
             notes.append(f'PSNR episode failed ({type(e).__name__}: {e})')
+    if world == 1 and not args.no_render_block and args.mode == 'train_geo':
+        render_blk = render_block(args, dev, rays)
     if watchdog is not None:
         watchdog.cancel()
 
@@ -446,7 +674,8 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.spp, args.cpu_rays)
-        line = _line(args, world, head, run, sustained, kern, (marched_ev, kept_ev), reuse_block, other_block, psnr_block, cpu=cpu, notes=notes)
+        line = _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other_block, psnr_block, cpu=cpu, notes=notes,
+                     late=(kern_late, ev_late), blocks={'faithful': faithful_block, 'render': render_blk, 'config4': config4_blk, 'comm': comm_block})
     # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which a pipe buffers until the
     # process exits -- every rank flushes it out first, then rank 0 prints.
     _flush_native_stdout()
@@ -458,31 +687,44 @@ def main():
         dist.destroy_process_group()
 
 
-def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other_block, psnr_block, cpu=None, notes=None):
+def _kernel_table(args, kern, ev_counts, prepass, only_priced=False):
+    """Per-kernel rows of an eager timing pass: launches and ms per step; for the gather / scatter kernels also live samples per
+    launch, algorithmic GB/s (SURVEY.md 8(d), 16-bit figures) and the fraction of the HBM peak."""
+    table = {}
+    marched_ev, kept_ev = ev_counts
+    total = {k: n * ms for k, (n, ms) in kern.items()}
+    for k, (n, ms) in sorted(kern.items(), key=lambda kv: -total[kv[0]]):
+        if only_priced and k not in ALGO_BYTES:
+            continue
+        per_step = n / args.steps
+        row = {'launches_per_step': round(per_step, 2), 'ms_per_launch': round(ms, 4), 'ms_per_step': round(per_step * ms, 4)}
+        if k in ALGO_BYTES:
+            # live samples per launch: the sampling-pass encode runs on the marched samples, every other on the kept ones
+            if k == 'perf_hashgrid_fwd' and (prepass or args.mode == 'render'):
+                live = (marched_ev + (per_step - 1) * kept_ev) / per_step
+            else:
+                live = kept_ev
+            gbs = ALGO_BYTES[k] * live / (ms * 1e-3) / 1e9
+            row.update({'live_samples_per_launch': round(live), 'algorithmic_bytes_per_sample': ALGO_BYTES[k],
+                        'algorithmic_GBps': round(gbs, 1), 'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4),
+                        'limiter': LIMITER[k]})
+        elif k in ('perf_mlp_fwd', 'perf_mlp_bwd'):
+            row['limiter'] = LIMITER[k]
+        table[k] = row
+    return table, total
+
+
+def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other_block, psnr_block, cpu=None, notes=None, late=None, blocks=None):
     """The JSON line of one run (rank 0)."""
     scene = run['scene']
     tc, r = scene.train_conf, scene.renderer
     table, roof = {}, None
+    late_table = None
+    prepass = r.early_stop_eps > 0 and args.mode != 'render'
+    if late and late[0]:
+        late_table, _ = _kernel_table(args, late[0], late[1], prepass, only_priced=True)
     if kern:
-        marched_ev, kept_ev = ev_counts
-        total = {k: n * ms for k, (n, ms) in kern.items()}
-        prepass = r.early_stop_eps > 0 and args.mode != 'render'
-        for k, (n, ms) in sorted(kern.items(), key=lambda kv: -total[kv[0]]):
-            per_step = n / args.steps
-            row = {'launches_per_step': round(per_step, 2), 'ms_per_launch': round(ms, 4), 'ms_per_step': round(per_step * ms, 4)}
-            if k in ALGO_BYTES:
-                # live samples per launch: the sampling-pass encode runs on the marched samples, every other on the kept ones
-                if k == 'perf_hashgrid_fwd' and (prepass or args.mode == 'render'):
-                    live = (marched_ev + (per_step - 1) * kept_ev) / per_step
-                else:
-                    live = kept_ev
-                gbs = ALGO_BYTES[k] * live / (ms * 1e-3) / 1e9
-                row.update({'live_samples_per_launch': round(live), 'algorithmic_bytes_per_sample': ALGO_BYTES[k],
-                            'algorithmic_GBps': round(gbs, 1), 'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4),
-                            'limiter': LIMITER[k]})
-            elif k in ('perf_mlp_fwd', 'perf_mlp_bwd'):
-                row['limiter'] = LIMITER[k]
-            table[k] = row
+        table, total = _kernel_table(args, kern, ev_counts, prepass)
         dom = max((k for k in total if k in ALGO_BYTES), key=lambda k: total[k])
         roof = {'kernel': dom, 'bound': BOUND[dom], 'achieved': table[dom]['algorithmic_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': table[dom]['frac_of_hbm_peak'], 'traffic': None, 'limiter': LIMITER[dom],
@@ -491,7 +733,9 @@ def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other
                 'algorithmic_bytes_per_ray_sample': ALGO_BYTES[dom], 'live_samples_per_launch': table[dom]['live_samples_per_launch'],
                 'ms_per_launch': table[dom]['ms_per_launch'],
                 'definition': 'achieved = algorithmic bytes (SURVEY.md 8(d), 16-bit figures) x live samples of a launch / mean launch duration '
-                              '(HIP events on the launch stream)'}
+                              '(HIP events on the launch stream)',
+                'state': 'the state `value` was timed in: a fresh build of the workload, the same warm-up, the same K steps launched eagerly '
+                         '(kept = marched: nothing is pruned yet); `kernels_late` holds the same kernels after the sustained loop'}
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same workload (profiles/)
         for name in PMC_FILES:
             try:
@@ -525,12 +769,16 @@ def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other
                                    f'global batch {head["global_batch_rays"]} rays') if world > 1 else 'single GPU',
                    'per_gpu_value': head['value'] / world,
                    'launch': head['launch'],
-                   'kernel_timing': 'HIP events around every launch in an eager re-run of the same steps right after the timed region'},
+                   'kernel_timing': 'HIP events around every launch of K eager steps from a fresh build + the same warm-up (the state of the timed '
+                                    'region); kernels_late: the same pass after the sustained loop'},
         'health': {k: head[k] for k in ('skipped_for_overflow', 'skipped_for_truncation')},
         'sustained': sustained,
         ('strict_two_evaluations' if reuse else 'with_feature_reuse'): reuse_block,
-        'psnr': psnr_block, 'roofline': roof, 'cpu_baseline': cpu, 'kernels': table or None,
+        'psnr': psnr_block, 'roofline': roof, 'cpu_baseline': cpu, 'kernels': table or None, 'kernels_late': late_table,
     }
+    for k, v in (blocks or {}).items():
+        if v is not None:
+            line[k] = v
     if 'eager' in head:
         line['config']['eager_launch'] = head['eager']
     if world > 1:
@@ -543,7 +791,7 @@ def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other
 # what the counters say bounds the dominant kernels (profiles/r03_*): the encode is bound by the L1's request rate, the
 # grid backward by VALU issue; neither by HBM bandwidth -- `frac` is nevertheless priced against HBM
 BOUND = {'perf_hashgrid_fwd': 'l1-miss', 'perf_hashgrid_bwd': 'valu'}
-PMC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json')
+PMC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
 
 
 def _workload_key(args):

@@ -50,11 +50,12 @@ extern "C" {
 #define PERF_ACT_SIGMOID 1
 #define PERF_ACT_EXP 2        /* y -> exp(y - exp_shift); backward clamps the exponent at 15 (trunc_exp) */
 
-/* Marching lattice t_k of a ray (all four perf_occ_march_* entry points take one): SINGLE = fl(t0 + fl(k*step)), one rounding
- * per sample (what oracle/perf_oracle.py defines and rounds 1-2 shipped); REPEATED = t_0 = t0, t_{k+1} = fl(t_k + step), the
- * lattice of a marcher that advances by `t += dt` as nerfacc's traverse_grids is understood to (the package is absent:
- * unpinned either way) -- the two differ by O(k ulp) in t_starts / t_ends, and in ray_indices where a midpoint sits on a cell
- * boundary.  A maintainer who holds nerfacc picks the matching one (NeRFOCCRenderer.lattice). */
+/* Marching lattice t_k of a ray (all four perf_occ_march_* entry points take one): REPEATED = t_0 = t0, t_{k+1} = fl(t_k + step),
+ * the lattice of a marcher that advances by `t += dt` as nerfacc's traverse_grids is understood to (the package is absent:
+ * unpinned either way) -- the default of the host layers and of oracle/perf_oracle.py since round 4; SINGLE = fl(t0 +
+ * fl(k*step)), one rounding per sample (rounds 1-3).  The two differ by O(k ulp) in t_starts / t_ends, and in ray_indices
+ * where a midpoint sits on a cell boundary.  A maintainer who holds nerfacc checks the choice with tools/pin_upstream.py
+ * (NeRFOCCRenderer.lattice selects). */
 #define PERF_LATTICE_SINGLE 0
 #define PERF_LATTICE_REPEATED 1
 

@@ -23,15 +23,16 @@ Where this restatement DEFINES a rounding order that upstream plausibly does dif
 * (grid position: follows tiny-cuda-nn -- ONE rounding, fmaf(scale, x, 0.5), see grid_pos; rounds 1-2 of this
   repository used fl(fl(x*scale) + 0.5), under which a position within half an ulp of a cell boundary could land in
   the neighbouring cell.)
-* marching lattice: t_k = fl(t0 + fl(k*step)) on ONE global lattice per ray anchored at the near plane
-  (+ stratified jitter), an interval being emitted iff its midpoint lies in an occupied cell (occ_march,
-  SURVEY.md A.3).  nerfacc's traverse_grids advances by REPEATED float addition (t_last += dt), so its
-  t_k carry the accumulated rounding of k additions (<= k/2 ulp, ~1e-6 after 3,000 steps of 5e-4) where
-  this lattice rounds once; and whether it keeps stepping on the same lattice through empty cells (our
-  recollection of v0.5.3: "march until t_mid is right after t_traverse") or restarts its intervals at
-  the cell entry cannot be checked here.  Under the first reading sample counts agree and t_starts
-  differ by O(k ulp); under the second, counts per occupied span agree to +-1 and positions differ by
-  < step.
+* marching lattice: ONE global lattice per ray anchored at the near plane (+ stratified jitter), an interval being
+  emitted iff its midpoint lies in an occupied cell (occ_march).  DEFAULT_LATTICE = 'repeated':
+  t_0 = t0, t_{k+1} = fl(t_k + step) -- nerfacc's traverse_grids advances by REPEATED float addition (t_last += dt, in
+  occupied and in empty cells alike, as v0.5.3 is recalled: "march until t_mid is right after t_traverse"), so its t_k
+  carry the accumulated rounding of k additions (<= k/2 ulp, ~1e-6 after 3,000 steps of 5e-4).  Rounds 1-3 of this
+  repository defaulted to 'single', t_k = fl(t0 + fl(k*step)) (one rounding; still selectable, bit-exact tests for
+  both).  Whether upstream keeps stepping on the same lattice through empty cells or restarts its intervals at the
+  cell entry cannot be checked here: under the first reading (ours) sample counts agree and, with 'repeated',
+  t_starts agree to the bit; under the second, counts per occupied span agree to +-1 and positions differ by < step.
+  tools/pin_upstream.py lets a maintainer who holds nerfacc decide it with one run.
 * early termination: thresholded on the canonical-order exclusive sum (ex <= -ln eps) instead of on
   T = exp(-ex) >= eps (identical decision up to the rounding of exp).
 
@@ -50,6 +51,7 @@ import numpy as np
 import torch
 
 F32 = np.float32
+DEFAULT_LATTICE = 'repeated'       # see the header; 'single' = t_k = fl(t0 + fl(k*step))
 U32_MASK = 0xFFFFFFFF
 PRIME_Y = 2654435761
 PRIME_Z = 805459861
@@ -388,15 +390,17 @@ def occ_cell_index(p: np.ndarray, aabb: np.ndarray, res: int) -> np.ndarray:
     return c[:, 0] * res * res + c[:, 1] * res + c[:, 2]
 
 
-def occ_march(o, d, binaries, aabb, near, far, step, t0=None, max_steps=None, lattice='single'):
+def occ_march(o, d, binaries, aabb, near, far, step, t0=None, max_steps=None, lattice=None):
     """Sampling of fixed-step intervals whose midpoint lies in an occupied cell (A.3).
 
     o,d [R,3] f32; binaries bool [res,res,res] (x-major); aabb [6]; t0 [R] = lattice origin
-    (near, plus U[0,1)*step when stratified).  Interval k is [t_k, t_{k+1}] with
-    t_k = fl(t0 + fl(k*step)); kept iff lo <= mid <= hi where mid = fl(fl(t_k+t_{k+1})*0.5),
+    (near, plus U[0,1)*step when stratified).  Interval k is [t_k, t_{k+1}] on the lattice `lattice`
+    (None: DEFAULT_LATTICE; 'repeated': t_{k+1} = fl(t_k + step), 'single': t_k = fl(t0 + fl(k*step))); kept iff lo <= mid <= hi where mid = fl(fl(t_k+t_{k+1})*0.5),
     [lo,hi] = [max(tmin_aabb, t0), min(tmax_aabb, far)], and the cell of o+d*mid
     (unfused) is occupied.  Returns (ray_indices i64 [S], t_starts f32 [S], t_ends f32 [S],
     packed_info i32 [R,2] = (start, count)); sorted by ray then t."""
+    lattice = lattice or DEFAULT_LATTICE
+    assert lattice in ('single', 'repeated')
     o = np.ascontiguousarray(o, F32); d = np.ascontiguousarray(d, F32)
     aabb = np.asarray(aabb, F32)
     R = o.shape[0]
@@ -599,7 +603,7 @@ def prop_sampling(sigma_fns, prop_samples, num_samples, n_rays, near, far, taus=
 def occ_render(o, d, geo_params, app_params, binaries, aabb, training, t0=None,
                bg_color=None, dist_noise=None, near=0.0, far=1.5, step=5e-4,
                early_stop_eps=1e-4, quant=None, geo_grad=True, app_grad=False, max_steps=None,
-               kept_counts=None, return_pre=False):
+               kept_counts=None, return_pre=False, lattice=None):
     """NeRFOCCRenderer.render restated on the oracle's operators.  o,d torch [R,3].
     bg_color [R,3] and dist_noise [R,1] are the torch.rand draws of :185,:193 (caller
     supplies them so both sides see the same numbers).
@@ -612,7 +616,7 @@ def occ_render(o, d, geo_params, app_params, binaries, aabb, training, t0=None,
     aabb_t = torch.as_tensor(aabb, dtype=torch.float32)
     R = o.shape[0]
     ri, ts, te, packed = occ_march(o.detach().numpy(), d.detach().numpy(), binaries, np.asarray(aabb, F32),
-                                   near, far, step, t0, max_steps)
+                                   near, far, step, t0, max_steps, lattice=lattice)
     def positions(ri_t, ts_t, te_t):
         return o[ri_t] + d[ri_t] * ((ts_t + te_t)[:, None] / 2.0)
     ri_t = torch.from_numpy(ri); ts_t = torch.from_numpy(ts); te_t = torch.from_numpy(te)

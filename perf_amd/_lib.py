@@ -15,7 +15,8 @@ MAX_LEVELS = 24
 DTYPE_BF16, DTYPE_FP16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
 INTERP_LINEAR, INTERP_SMOOTHSTEP = 0, 1
-LATTICE = {'single': 0, 'repeated': 1}          # PERF_LATTICE_*
+LATTICE = {'single': 0, 'repeated': 1, None: 1}          # PERF_LATTICE_*; None = the default
+DEFAULT_LATTICE = 'repeated'                 # t_{k+1} = fl(t_k + step): how nerfacc's traverse_grids is understood to march (include/perf_hip.h)
 
 
 class GridDesc(Structure):

@@ -173,7 +173,7 @@ class OccGridEstimator(nn.Module):
     def sampling_ex(self, rays_o, rays_d, sigma_fn=None, near_plane=0.0, far_plane=1e10, render_step_size=1e-3,
                     early_stop_eps=1e-4, alpha_thre=0.0, stratified=False, cone_angle=0.0, alpha_fn=None,
                     t_min=None, t_max=None, jitter=None, max_steps=None, capacity=None, points_aabb=None,
-                    sigma_points_fn=None, head_samples=None, lattice='single'):
+                    sigma_points_fn=None, head_samples=None, lattice=None):
         """sampling() returning a Samples record: ray_indices, t_starts, t_ends, packed (packed_info), sig (sigmas of the
         kept samples from the visibility pass, or None), x01 / sel (sample positions normalised to points_aabb, or None),
         n_dev (device int64 [1]: number of live samples when the arrays are capacity-sized, else None), n_marched_dev.
@@ -189,7 +189,7 @@ class OccGridEstimator(nn.Module):
           n_marched_dev then counts the samples whose density was evaluated.
         sigma_points_fn may return (sigmas, feat): the level-major encoded features of its density pass are then compacted
           along with the samples (Samples.feat) so that a gradient pass on the kept samples need not encode them again.
-        lattice: 'single' (t_k = fl(t0 + fl(k step)), the default) or 'repeated' (t_{k+1} = fl(t_k + step)): PERF_LATTICE_*."""
+        lattice: 'repeated' (t_{k+1} = fl(t_k + step), the default: None) or 'single' (t_k = fl(t0 + fl(k step))): PERF_LATTICE_*."""
         if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
             raise NotImplementedError('PeRF samples with cone_angle=0 and a sigma_fn (nerf_renderer.py:145-155)')
         if alpha_thre != 0.0:
@@ -267,7 +267,7 @@ class OccGridEstimator(nn.Module):
     STRIDED_HEAD_MAX = 16          # heads of up to this many samples are written by the counting pass, K rows per ray
 
     def _sample_two_phase(self, sm, rays_o, rays_d, t0, far_plane, step, max_steps, capacity, points_aabb, sigma_points_fn,
-                          early_stop_eps, K, lattice='single'):
+                          early_stop_eps, K, lattice=None):
         """March once; density + visibility on the first K samples of every ray; then density on the remaining samples of
         the rays that are still alive; final visibility + compaction over (head, tail).  All counts stay on the device."""
         R = rays_o.shape[0]

@@ -36,14 +36,15 @@ def stop_kernel_timing():
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in (prof or {}).items() if v}
 
 
-def _call(name, *args):
+def _call(name, *args, label=None):
+    """label: the name the launch is timed under when it differs from the entry point (one entry point, two kinds of launch)."""
     if _PROF is None:
         return _lib.call(name, *args)
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record()
     _lib.call(name, *args)
     b.record()
-    _PROF.setdefault(name, []).append((a, b))
+    _PROF.setdefault(label or name, []).append((a, b))
 
 
 def dtype_code(d) -> int:
@@ -245,7 +246,8 @@ def hashgrid_bwd_redo(grid: GridConfig, x01, dfeat, out, n_dev=None, hr_state=No
     overflow flag, else the table gradient again with fp32 LDS accumulation (perf_hashgrid_bwd, redo_flag)."""
     d = grid.desc()
     _call('perf_hashgrid_bwd', ctypes.byref(d), _p(_f32(x01, 'x01')), _p(_f32(dfeat, 'dfeat')), _p(_f32(out, 'grad')),
-          x01.shape[0], _nd(n_dev), 0, None, None, _p(hr_state), None, 0, _p(overflow_flag(x01.device)), None, 0, _stream())
+          x01.shape[0], _nd(n_dev), 0, None, None, _p(hr_state), None, 0, _p(overflow_flag(x01.device)), None, 0, _stream(),
+          label='perf_hashgrid_bwd(redo: predicated no-op)')
     return out
 
 
@@ -455,7 +457,7 @@ def _origin(t0):
     return _p(_f32(t0, 't0')), 0.0, 0.0
 
 
-def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse=None, lattice='single'):
+def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse=None, lattice=None):
     """Pass 1 of the marching: -> (keep masks, per-ray counts int32 [R]).  t0: see _origin."""
     R = rays_o.shape[0]
     dev = rays_o.device
@@ -469,7 +471,7 @@ def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, ma
 
 
 def occ_march_count_head(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse, head_k, points_aabb,
-                         lattice='single'):
+                         lattice=None):
     """occ_march_count that also writes the first head_k samples of every ray to rows r*head_k.. of R*head_k-row arrays
     (padding rows have sel = 0) -> (masks, counts, (ray_indices, t_starts, t_ends, packed_info, x01, sel))."""
     R = rays_o.shape[0]
@@ -491,7 +493,7 @@ def occ_march_count_head(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, ste
 
 
 def occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o=None, rays_d=None, points_aabb=None, rank_lo=0,
-                    lattice='single'):
+                    lattice=None):
     """Pass 2: expand the masks into S-row sample arrays -> (ray_indices, t_starts, t_ends, packed_info[, x01, sel]).
     counts / offsets: how many samples of every ray to write, starting at rank rank_lo, and where."""
     R = counts.shape[0]
@@ -514,7 +516,7 @@ def occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o=None,
 
 
 def occ_march(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, capacity=None, occ_coarse=None,
-              points_aabb=None, lattice='single'):
+              points_aabb=None, lattice=None):
     """Returns (ray_indices i64 [S], t_starts, t_ends f32 [S], packed_info i32 [R,2]).
     capacity=None reads the total back (one host sync, like the reference's boolean indexing);
     an int capacity keeps the call sync-free and returns arrays of that length plus `total` on device.

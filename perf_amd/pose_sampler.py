@@ -153,20 +153,47 @@ class _Poses:
 class DensePoseFuture:
     """Handle of a dense trajectory being computed in a worker process (DenseTravelPoseSampler.start)."""
 
-    def __init__(self, key, proc=None, conn=None, ready=None):
+    def __init__(self, key, proc=None, conn=None, ready=None, fallback=None):
         self.key, self.proc, self.conn, self._ready = key, proc, conn, ready
+        self._fallback = fallback          # (sparse poses, n_dense_poses, dir_bias_ratio, numpy RNG state at start())
 
     def done(self):
         return self._ready is not None or self.conn.poll()
 
-    def result(self):
-        """The sampler; numpy's global RNG is left in the state the sequential construction would have left it in."""
+    TIMEOUT_S = 120.0
+
+    def result(self, timeout=None):
+        """The sampler; numpy's global RNG is left in the state the sequential construction would have left it in.  The
+        worker was forked from a process that holds HIP / RCCL / OpenMP state (a fork-after-threads hazard the single-threaded
+        child sidesteps, but cannot rule out): should it die, fail or not answer within `timeout` seconds, the trajectory is
+        built HERE, sequentially, from the RNG state saved at start() -- same poses, same RNG afterwards."""
         if self._ready is None:
-            poses, rng_state, err = self.conn.recv()
-            self.proc.join()
-            if err is not None:
-                raise RuntimeError(f'dense pose sampler worker failed: {err}')
-            _DENSE_CACHE[self.key] = (torch.from_numpy(poses), rng_state)
+            poses = rng_state = None
+            why = None
+            try:
+                if self.conn.poll(self.TIMEOUT_S if timeout is None else timeout):
+                    poses, rng_state, err = self.conn.recv()
+                    if err is not None:
+                        why, poses = f'worker failed: {err}', None
+                else:
+                    why = 'worker did not answer in time'
+            except (EOFError, OSError) as e:
+                why = f'worker died ({type(e).__name__})'
+            if self.proc is not None:
+                if why is not None and self.proc.is_alive():
+                    self.proc.terminate()
+                self.proc.join(5.0)
+            if poses is None:
+                if self._fallback is None:
+                    raise RuntimeError(f'dense pose sampler: {why}')
+                import warnings
+                warnings.warn(f'perf_amd: dense pose sampler {why}; building the trajectory in line')
+                sparse, n_dense, bias, state0 = self._fallback
+                np.random.set_state(state0)
+                seq = DenseTravelPoseSampler.__new__(DenseTravelPoseSampler)
+                seq._build(sparse, n_dense, bias)
+                poses, rng_state = seq.sample_poses.numpy(), np.random.get_state()
+            _DENSE_CACHE[self.key] = (torch.from_numpy(np.asarray(poses)).clone(), rng_state)
             self._ready = _DENSE_CACHE[self.key]
         poses, rng_state = self._ready
         np.random.set_state(rng_state)
@@ -199,10 +226,11 @@ class DenseTravelPoseSampler:
             return DensePoseFuture(key, ready=_DENSE_CACHE[key])
         ctx = mp.get_context('fork')
         parent, child = ctx.Pipe(duplex=False)
-        proc = ctx.Process(target=_dense_worker, args=(child, sparse, n_dense_poses, dir_bias_ratio, np.random.get_state()), daemon=True)
+        state0 = np.random.get_state()
+        proc = ctx.Process(target=_dense_worker, args=(child, sparse, n_dense_poses, dir_bias_ratio, state0), daemon=True)
         proc.start()
         child.close()
-        return DensePoseFuture(key, proc, parent)
+        return DensePoseFuture(key, proc, parent, fallback=(sparse, n_dense_poses, dir_bias_ratio, state0))
 
     def __init__(self, sparse_pose_sampler, n_dense_poses, dir_bias_ratio=-1, _cache=True):
         sparse = torch.stack([sparse_pose_sampler.sample_pose(i) for i in range(sparse_pose_sampler.n_poses)], 0).float()

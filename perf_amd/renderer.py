@@ -58,9 +58,10 @@ class NeRFOCCRenderer(nn.Module):
         # a ray (the first sample of a ray is always kept; the second is dropped iff the first made the ray opaque) and the
         # fastest on a trained scene (512x1024 frames/s: K=2 1140, 3 1070, 4 1010, 6 880; untrained scenes do not care)
         self.head_samples = 2
-        # marching lattice: 'single' (one rounding per sample: the oracle's definition) or 'repeated' (t += step, as a marcher that
-        # advances by repeated addition produces; include/perf_hip.h PERF_LATTICE_*) -- for maintainers who can compare with nerfacc
-        self.lattice = 'single'
+        # marching lattice: 'repeated' (t_{k+1} = fl(t_k + step): how nerfacc's traverse_grids is understood to march -- the
+        # default since round 4, in the oracle too) or 'single' (t_k = fl(t0 + fl(k step)): one rounding per sample, rounds
+        # 1-3); include/perf_hip.h PERF_LATTICE_*.  tools/pin_upstream.py lets a maintainer who holds nerfacc check it.
+        self.lattice = 'repeated'
 
     # The render is cut in two stages so that a data-parallel trainer can overlap the gradient all-reduce of step k
     # with everything of step k+1 that does not depend on the parameters being updated (scene.py).

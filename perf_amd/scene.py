@@ -45,6 +45,27 @@ def _capture(graph):
     return torch.cuda.graph(graph)
 
 
+def _graph_node_count(graph):
+    """Nodes (kernel launches, copies, fills) of a captured hipGraph -- what one replay issues.  Needs a graph created with
+    keep_graph=True; asks the HIP runtime this process already loaded (hipGraphGetNodes).  None when unavailable."""
+    try:
+        import ctypes
+        raw = graph.raw_cuda_graph()
+        path = None
+        for line in open('/proc/self/maps'):
+            if 'libamdhip64' in line:
+                path = line.split()[-1]
+                break
+        if path is None:
+            return None
+        hip = ctypes.CDLL(path)
+        n = ctypes.c_size_t(0)
+        rc = hip.hipGraphGetNodes(ctypes.c_void_p(int(raw)), None, ctypes.byref(n))
+        return int(n.value) if rc == 0 else None
+    except Exception:      # noqa: BLE001 -- a statistic, never a failure
+        return None
+
+
 OVERFLOW_CHECK_EVERY = 64      # training steps between reads of the fixed-point overflow flag (one host sync each)
 
 
@@ -770,7 +791,15 @@ class NeRFScene:
                 if extra >= 1:
                     grad[n:n + 1].clamp_(max=1.0)          # the count slot only has to say "some / none": exact in bf16
                 payload = grad.to(torch.bfloat16)
-            if overlap is not None:
+            if self._dp_timing is not None:          # (bench.py: the collective alone, synchronous between two events)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+                ev[1].record()
+                self._dp_timing.setdefault('all_reduce_flat_gradient', []).append(ev)
+                if overlap is not None:
+                    overlap()
+            elif overlap is not None:
                 work = dist.all_reduce(payload, op=dist.ReduceOp.SUM, async_op=True)
                 overlap()
                 work.wait()
@@ -1088,13 +1117,19 @@ class NeRFScene:
             self._rng_counter -= 1
             self._geo_pre = None
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        count = getattr(self, 'count_graph_nodes', False)
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if count else torch.cuda.CUDAGraph()
         self._capturing = optimizer.capturing = True
         try:
             with _capture(graph):
                 step_fn(optimizer, sup_pool, progress=0.0)
         finally:
             self._capturing = optimizer.capturing = False
+        if count:          # (bench.py: launches per replayed step)
+            if not hasattr(self, 'graph_nodes'):
+                self.graph_nodes = {}
+            self.graph_nodes[kind] = _graph_node_count(graph)
+            graph.instantiate()
 
         state = {'graph': graph, 'n': 0, 'counts': self._last_counts, 'capacity': self.renderer.sample_capacity,
                  'mode': optimizer.net.grid_grad_accum}

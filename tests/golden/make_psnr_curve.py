@@ -20,7 +20,7 @@ def main():
     scene = P.make_scene(H, W)
     out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'tests', 'golden', 'psnr_curve.json')
     res = {'config': {'pano': [H, W], 'batch': BATCH, 'geo_iters': N_GEO, 'app_iters': N_APP, 'marks': list(MARKS),
-                      'geo_marks': list(P.GEO_MARKS), 'torch': torch.__version__}, 'seeds': []}
+                      'geo_marks': list(P.GEO_MARKS), 'torch': torch.__version__, 'lattice': P.O.DEFAULT_LATTICE}, 'seeds': []}
 
     if os.path.exists(out_path):
         old = json.load(open(out_path))

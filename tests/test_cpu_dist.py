@@ -83,7 +83,7 @@ def _apply_worker(rank, world, port, out, comm_dtype):
     n = 1000
     net = types.SimpleNamespace(params=torch.nn.Parameter(torch.linspace(-1, 1, n)))
     opt = torch.optim.Adam([net.params], lr=1e-2)
-    me = types.SimpleNamespace(comm_dtype=comm_dtype, sample_counters=None, _capturing=False, _poll_health=lambda *a, **k: None,
+    me = types.SimpleNamespace(comm_dtype=comm_dtype, sample_counters=None, _capturing=False, _dp_timing=None, _poll_health=lambda *a, **k: None,
                                renderer=types.SimpleNamespace(sample_capacity=None))
     hist = []
     g = torch.Generator().manual_seed(100 + rank)

@@ -80,9 +80,11 @@ def test_two_ranks_with_lagged_units(tmp_path):
     two = _run(2, str(tmp_path / 'w2.pt'), 29575, units='lagged')
     two_r1 = torch.load(str(tmp_path / 'w2.pt') + '.1')
     _common_checks(one, two)
-    for key, n_net in (('geo', 3072), ('app', 7168)):
-        table = torch.cat([two['g_' + key][n_net:], two_r1['g_' + key][n_net:]])
-        assert torch.equal(table, one['g_' + key][n_net:]), key                     # first step of each network: exact path
+    table = torch.cat([two['g_geo'][3072:], two_r1['g_geo'][3072:]])
+    assert torch.equal(table, one['g_geo'][3072:])                                  # the very first step: exact path
+    # (the colour network's first gradient already sees a density field trained with two lagged steps: equal to that)
+    table = torch.cat([two['g_app'][7168:], two_r1['g_app'][7168:]])
+    assert float((table - one['g_app'][7168:]).norm()) < 2e-2 * float(one['g_app'][7168:].norm())
     assert torch.equal(two['geo'], two_r1['geo']) and torch.equal(two['app'], two_r1['app'])
     for k in ('geo', 'app'):
         moved = float((one[k] - one[k + '0']).norm())

@@ -916,10 +916,12 @@ def test_fused_field_infer_equals_the_two_kernel_path(dtype, net):
     assert torch.equal(out[:live], ref)
 
 
+@pytest.mark.parametrize('lattice', ['repeated', 'single'])
 @pytest.mark.parametrize('step', [5e-4, 2e-3])
-def test_occ_march_repeated_addition_lattice_bit_exact(ops, step):
-    """PERF_LATTICE_REPEATED (t_0 = t0, t_{k+1} = fl(t_k + step): the lattice of a marcher that advances by `t += dt`): the
-    kernels evaluate t_k in closed form per binade; the oracle accumulates sequentially (np.add.accumulate in fp32).  Samples,
+def test_occ_march_both_lattices_bit_exact(ops, step, lattice):
+    """PERF_LATTICE_REPEATED (t_0 = t0, t_{k+1} = fl(t_k + step): the lattice of a marcher that advances by `t += dt`; the
+    default since round 4): the kernels evaluate t_k in closed form per binade; the oracle accumulates sequentially
+    (np.add.accumulate in fp32).  PERF_LATTICE_SINGLE (t_k = fl(t0 + fl(k step)), rounds 1-3) stays selectable.  Samples,
     interval ends and ray bookkeeping equal bit for bit -- plain and in-kernel origins, with and without the skip grid, the
     head written by the counting pass included -- and the lattice really differs from the single-rounding one."""
     o, d, dist, rgb, occ = _room(24, 48, 64)
@@ -933,20 +935,21 @@ def test_occ_march_repeated_addition_lattice_bit_exact(ops, step):
     u = torch.rand(R, generator=g)
     t0 = (u * step)
     binaries = occ.reshape(64, 64, 64).bool()
-    ri, ts, te, packed = O.occ_march(o.numpy(), d.numpy(), binaries.numpy(), aabb, near, far, step, t0.numpy(), max_steps, lattice='repeated')
-    ri1, ts1, te1, _ = O.occ_march(o.numpy(), d.numpy(), binaries.numpy(), aabb, near, far, step, t0.numpy(), max_steps)
+    ri, ts, te, packed = O.occ_march(o.numpy(), d.numpy(), binaries.numpy(), aabb, near, far, step, t0.numpy(), max_steps, lattice=lattice)
+    other = 'single' if lattice == 'repeated' else 'repeated'
+    ri1, ts1, te1, _ = O.occ_march(o.numpy(), d.numpy(), binaries.numpy(), aabb, near, far, step, t0.numpy(), max_steps, lattice=other)
     assert ri.size > 1000 and (ts.size != ts1.size or not np.array_equal(ts, ts1))          # a different lattice indeed
     bits = ops.occ_pack_bits(occ.cuda())
     coarse = ops.occ_build_coarse(bits, 64)
     for origin in (t0.cuda(), (u.cuda(), step, near)):
         for cz in (None, coarse):
             gri, gts, gte, gpacked = ops.occ_march(o.cuda(), d.cuda(), origin, bits, 64, aabb, far, step, max_steps, occ_coarse=cz,
-                                                   lattice='repeated')
+                                                   lattice=lattice)
             assert np.array_equal(gri.cpu().numpy(), ri) and np.array_equal(gpacked.cpu().numpy(), packed)
             assert np.array_equal(gts.cpu().numpy(), ts) and np.array_equal(gte.cpu().numpy(), te)
     K = 4
     m2, c2, (ri2, ts2, te2, pk2, x2, s2) = ops.occ_march_count_head(o.cuda(), d.cuda(), t0.cuda(), bits, 64, list(aabb), far, step, max_steps,
-                                                                    coarse, K, list(aabb), lattice='repeated')
+                                                                    coarse, K, list(aabb), lattice=lattice)
     assert np.array_equal(c2.cpu().numpy(), packed[:, 1])
     for r in np.nonzero(packed[:, 1] > 0)[0][:50]:
         n = min(int(packed[r, 1]), K)
@@ -954,9 +957,9 @@ def test_occ_march_repeated_addition_lattice_bit_exact(ops, step):
         assert np.array_equal(te2[r * K:r * K + n].cpu().numpy(), te[packed[r, 0]:packed[r, 0] + n])
 
 
-def test_renderer_with_the_repeated_lattice_sync_free_equals_synced():
-    """NeRFOCCRenderer.lattice = 'repeated' through the whole sampler: the sync-free two-phase path (device-side counts) and the
-    host-synced path produce the same samples and pixels, as they do on the default lattice."""
+def test_renderer_with_either_lattice_sync_free_equals_synced():
+    """NeRFOCCRenderer.lattice through the whole sampler: on either lattice the sync-free two-phase path (device-side counts) and
+    the host-synced path produce the same samples and pixels; the default is 'repeated'."""
     from perf_amd import synthetic
     from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
     torch.manual_seed(0)
@@ -965,10 +968,12 @@ def test_renderer_with_the_repeated_lattice_sync_free_equals_synced():
     dist, rgb = synthetic.room(rays.d)
     pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, dist)
     scene.set_train(); scene.prepare_occupancy(pool); scene.set_eval()
-    scene.renderer.lattice = 'repeated'
+    assert scene.renderer.lattice == 'repeated'
     a = scene.render(rays, ['rgb', 'distance'], sync_free=True)
     b = scene.render(rays, ['rgb', 'distance'], sync_free=False)
     assert torch.equal(a['rgb'], b['rgb']) and torch.equal(a['distance'], b['distance'])
     scene.renderer.lattice = 'single'
     c = scene.render(rays, ['distance'], sync_free=True)
+    c2 = scene.render(rays, ['distance'], sync_free=False)
+    assert torch.equal(c['distance'], c2['distance'])
     assert not torch.equal(a['distance'], c['distance'])                         # (the lattices differ in the last bits of t)
