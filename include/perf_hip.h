@@ -323,6 +323,18 @@ int perf_pano_raygen_dev(const float* pose_dev, int32_t height, int32_t width, i
 
 /* ---- occupancy-grid marching (nerfacc traverse_grids; nerf_renderer.py:145-155) ------------ */
 
+/* nerfacc OccGridEstimator.update_every_n_steps, the pieces around the caller's occupancy closure (PeRF calls it 256 times
+ * per episode with a look-up closure, modules/scene/nerf.py:147-168): (1) the jittered evaluation points of cells
+ * [cell_lo, cell_lo + n) of a res^3 grid (x-major linear index), x[i] = aabb_lo + ((coord + U[0,1)) / res) * (aabb_hi - aabb_lo),
+ * U from the counter-based generator (Philox4x32-10; key = seed, counter = {cell, call}): chunks of one update draw from
+ * the same stream whatever the chunking; (2) occs[i] = max(occs[i] * ema_decay, occ[i]) in place, *sum_out (device double,
+ * zeroed by the caller before the first chunk) += the new values; (3) binaries[i] = occs[i] > min(*sum / n, occ_thre)
+ * (bool bytes), over all n cells.  aabb: 6 host floats. */
+int perf_occ_jitter_points(uint64_t seed, uint64_t call, int64_t cell_lo, int64_t n, int32_t res, const float* aabb,
+                           float* x, void* stream);
+int perf_occ_ema_update(float* occs, const float* occ, int64_t n, float ema_decay, double* sum_out, void* stream);
+int perf_occ_threshold(const float* occs, int64_t n, const double* sum, float occ_thre, uint8_t* binaries, void* stream);
+
 /* bool bytes [n_cells] -> bit field (uint32 words, bit i of word w = cell 32*w+i). */
 int perf_occ_pack_bits(const uint8_t* binaries, uint32_t* bits, int64_t n_cells, void* stream);
 

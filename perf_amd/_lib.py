@@ -73,6 +73,9 @@ _SIGS = {
     'perf_pano_raygen': (c_int, [POINTER(c_float), c_int32, c_int32, c_int32, c_int32, P, P, P]),
     'perf_pano_raygen_dev': (c_int, [P, c_int32, c_int32, c_int32, c_int32, P, P, P]),
     'perf_occ_pack_bits': (c_int, [P, P, c_int64, P]),
+    'perf_occ_jitter_points': (c_int, [c_uint64, c_uint64, c_int64, c_int64, c_int32, POINTER(c_float), P, P]),
+    'perf_occ_ema_update': (c_int, [P, P, c_int64, c_float, P, P]),
+    'perf_occ_threshold': (c_int, [P, c_int64, P, c_float, P, P]),
     'perf_occ_mask_words': (c_int64, [c_int32]),
     'perf_occ_march_count': (c_int, [P, P, P, c_float, c_float, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, c_int32, P, P, P]),
     'perf_occ_march_count_head': (c_int, [P, P, P, c_float, c_float, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, c_int32, P, P,

@@ -57,6 +57,18 @@ __device__ __forceinline__ float lattice_single(float t0, int k, float step) { r
 // arbitrary k without k additions: inside one binade consecutive floats have consecutive bit patterns, and from the second
 // in-binade addition on every addition moves by the same number of ulps (round-to-nearest-even of step / ulp: a tie lands
 // on an even mantissa once and then stays even) -- so the walk jumps binade by binade with two real additions each.
+// floor(n / d) for n < 2^24, d >= 1: the reciprocal estimate is off by at most one (the compiler's generic 32-bit division is
+// ~4x the instructions, and the walk below divides once per binade)
+__device__ __forceinline__ uint32_t div_u24(uint32_t n, uint32_t d) {
+    uint32_t q = (uint32_t)((float)n * __frcp_rn((float)d));
+    const uint32_t p = q * d;
+    if (p > n) --q;                                              // (estimate one too large)
+    else if (n - p >= d) ++q;                                    // (one too small)
+    return q;
+}
+
+__device__ __forceinline__ float lattice(float t0, int k, float step, int mode);
+
 __device__ __forceinline__ float lattice_repeated(float t0, int k, float step) {
     float t = t0;
     int left = k;
@@ -71,13 +83,65 @@ __device__ __forceinline__ float lattice_repeated(float t0, int k, float step) {
         const uint32_t d = b2 - b1;                              // ulps per step from here to the end of the binade
         if (d == 0u) return t2;                                  // (step below half an ulp: the lattice is stuck)
         const uint32_t top = (b2 & 0xff800000u) + 0x00800000u;   // first bit pattern of the next binade
-        uint32_t j = (top - 1u - b2) / d;                        // further additions that stay inside
+        uint32_t j = div_u24(top - 1u - b2, d);                  // further additions that stay inside
         if (j > (uint32_t)left) j = (uint32_t)left;
         t = __uint_as_float(b2 + j * d);
         left -= (int)j;
     }
     return t;
 }
+
+// The same walk, ONCE per ray, as a table of runs: run i covers lattice indices [ks[i], ks[i+1]) and holds
+// t_k = bits(bs[i] + (k - ks[i]) * dd[i]) -- inside a binade consecutive lattice points are equidistant bit patterns.
+// march_count_kernel evaluates the lattice at 3 indices per chunk in phase A and once per lane and live chunk in phase B,
+// i.e. thousands of per-lane walks per ray at PeRF's 3,000 steps (measured: the kernel went from 13 to 85 us per 8,192
+// rays when the repeated lattice became the default); with the table a ray is walked once -- on values that are uniform
+// over the wave (the float additions run on the vector unit, everything else on the scalar unit) -- and an evaluation is
+// a binary search over <= kMaxRuns run starts in LDS.  Returns the number of runs, or -1 when the table does not reach
+// index k_need (more binades than the table holds: the caller falls back to the per-lane walk).
+constexpr int kMaxRuns = 64;
+
+__device__ __forceinline__ int lattice_runs_build(float t0, float step, int k_need, int32_t* __restrict__ ks, uint32_t* __restrict__ bs,
+                                                  uint32_t* __restrict__ dd, bool writer) {
+    int n = 0;
+    auto emit = [&](int k, uint32_t b, uint32_t d) {
+        if (writer) { ks[n] = k; bs[n] = b; dd[n] = d; }
+        ++n;
+    };
+    uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t0));
+    emit(0, tb, 0u);
+    int K = 0;
+    while (K < k_need) {
+        if (n + 2 > kMaxRuns) return -1;
+        const uint32_t b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(add_rn(__uint_as_float(tb), step)));
+        if ((b1 >> 23) != (tb >> 23)) { emit(K + 1, b1, 0u); tb = b1; K += 1; continue; }    // entered a binade: one more real step first
+        const uint32_t b2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(add_rn(__uint_as_float(b1), step)));
+        if ((b2 >> 23) != (b1 >> 23)) { emit(K + 1, b1, 0u); emit(K + 2, b2, 0u); tb = b2; K += 2; continue; }
+        const uint32_t d = b2 - b1;
+        emit(K + 1, b1, d);                                      // t_{K+1}, t_{K+2}, ... equidistant to the end of the binade
+        if (d == 0u) return n;                                   // (step below half an ulp: the lattice is stuck at t_{K+1} for good)
+        const uint32_t top = (b2 & 0xff800000u) + 0x00800000u;
+        const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)div_u24(top - 1u - b2, d));
+        tb = b2 + j * d;
+        K += 2 + (int)j;
+    }
+    return n;
+}
+
+struct LatticeRuns {
+    int n;                       // > 0: table; <= 0: evaluate directly (single lattice, or a table that did not fit)
+    const int32_t* ks; const uint32_t* bs; const uint32_t* dd;
+    float t0, step; int mode;
+    __device__ __forceinline__ float operator()(int k) const {
+        if (n <= 0) return lattice(t0, k, step, mode);
+        int lo = 0, hi = n - 1;                                  // last run that starts at or before k
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (ks[mid] <= k) lo = mid; else hi = mid - 1;
+        }
+        return __uint_as_float(bs[lo] + (uint32_t)(k - ks[lo]) * dd[lo]);
+    }
+};
 
 __device__ __forceinline__ float lattice(float t0, int k, float step, int mode) {
     return mode == PERF_LATTICE_REPEATED ? lattice_repeated(t0, k, step) : lattice_single(t0, k, step);
@@ -136,6 +200,16 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         tmax = (a == 0) ? h : fminf(tmax, h);
     }
     const float lo = fmaxf(tmin, t0), hi = fminf(tmax, mp.far_plane);
+    // repeated-addition lattice: this ray's walk, once, as a table of runs in LDS (one table per wave)
+    __shared__ int32_t s_ks[4][kMaxRuns];
+    __shared__ uint32_t s_bs[4][kMaxRuns], s_dd[4][kMaxRuns];
+    const int wv = threadIdx.x >> 6;
+    LatticeRuns lat;
+    lat.n = 0; lat.ks = s_ks[wv]; lat.bs = s_bs[wv]; lat.dd = s_dd[wv]; lat.t0 = t0; lat.step = mp.step; lat.mode = mp.lattice_mode;
+    if (mp.lattice_mode == PERF_LATTICE_REPEATED) {
+        lat.n = lattice_runs_build(t0, mp.step, mp.mask_words * 64 + 64, s_ks[wv], s_bs[wv], s_dd[wv], lane == 0);
+        __builtin_amdgcn_wave_barrier();
+    }
     // the coarse skip is only valid while a chunk spans few enough fine cells (see coarse_build_kernel): checked per ray
     // with its own direction, so unnormalised directions fall back to the exhaustive test instead of skipping cells
     float span_cells = 0.f;
@@ -154,9 +228,9 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         bool maybe = false;
         if (q < mp.mask_words) {
             const int k0 = q * 64;
-            maybe = !(lattice(t0, k0, mp.step, mp.lattice_mode) > hi) && !(lattice(t0, k0 + 64, mp.step, mp.lattice_mode) < lo);
+            maybe = !(lat(k0) > hi) && !(lat(k0 + 64) < lo);
             if (maybe && use_coarse) {
-                const float tc = lattice(t0, k0 + 32, mp.step, mp.lattice_mode);
+                const float tc = lat(k0 + 32);
                 const int cr = res >> kCoarseShift;
                 int cb[3];
 #pragma unroll
@@ -184,7 +258,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                     todo &= todo - 1;
                     const int k = qs[u] * 64 + lane;
                     if (k < mp.max_steps) {
-                        const float ta = lattice(t0, k, mp.step, mp.lattice_mode), tb = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(ta, mp.step) : lattice_single(t0, k + 1, mp.step);
+                        const float ta = lat(k), tb = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(ta, mp.step) : lattice_single(t0, k + 1, mp.step);
                         const float mid = mul_rn(add_rn(ta, tb), 0.5f);
                         if (mid >= lo && mid <= hi) {
                             int cell[3];
@@ -216,7 +290,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                         if (rank < ho.K) {
                             const int64_t pos = r * ho.K + rank;
                             const int k = qs[u] * 64 + lane;
-                            const float a = lattice(t0, k, mp.step, mp.lattice_mode), b = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, mp.step) : lattice_single(t0, k + 1, mp.step);
+                            const float a = lat(k), b = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, mp.step) : lattice_single(t0, k + 1, mp.step);
                             ho.ts[pos] = a; ho.te[pos] = b; ho.ri[pos] = r;
                             sample_point_store(ro + 3 * r, rd + 3 * r, a, b, ho.bb, ho.x01, ho.sel, pos);
                         }

@@ -463,3 +463,81 @@ extern "C" int perf_draw_train_batch(uint64_t seed, int64_t* counter_dev, int32_
     PERF_LAUNCH_CHECK("perf_draw_train_batch");
     return PERF_OK;
 }
+
+
+// ---- occupancy-grid update (nerfacc OccGridEstimator.update_every_n_steps; PeRF calls it 256 times per episode with a
+//      look-up closure, modules/scene/nerf.py:147-168) -------------------------------------------------------------------------------
+// The estimator evaluates every cell at a jittered point, folds the result into an exponential moving maximum and thresholds.
+// The closure in the middle is the caller's Python; what surrounds it are two launches instead of ~20 torch element-wise
+// passes over 16.7 M x 3 floats: (1) the jittered points of a range of cells, (2) occs = max(occs * decay, occ) with the
+// range's sum, (3) -- once per update -- the threshold min(mean(occs), occ_thre) applied to all cells, as bool bytes.
+namespace perf {
+__global__ __launch_bounds__(256) void occ_jitter_points_kernel(uint32_t seed_lo, uint32_t seed_hi, uint64_t call, int64_t cell_lo,
+                                                                int64_t n, int32_t res, Aabb bb, float* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t c = cell_lo + i;
+    uint32_t r[4] = {(uint32_t)(c & 0xffffffffll), (uint32_t)(c >> 32), (uint32_t)(call & 0xffffffffull), (uint32_t)(call >> 32) ^ 0x0cc5eedu};
+    philox4x32_10(r, seed_lo, seed_hi);
+    const int32_t cz = (int32_t)(c % res), cy = (int32_t)((c / res) % res), cx = (int32_t)(c / ((int64_t)res * res));
+    const float fr = (float)res;        // (coord + U[0,1)) / res, IEEE division like torch
+    const float u[3] = {__fdiv_rn((float)cx + u01(r[0]), fr), __fdiv_rn((float)cy + u01(r[1]), fr), __fdiv_rn((float)cz + u01(r[2]), fr)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) x[3 * i + a] = bb.lo[a] + u[a] * (bb.hi[a] - bb.lo[a]);
+}
+
+__global__ __launch_bounds__(256) void occ_ema_kernel(float* __restrict__ occs, const float* __restrict__ occ, int64_t n, float decay,
+                                                      double* __restrict__ sum_out) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = fmaxf(occs[i] * decay, occ[i]);
+        occs[i] = v;
+        acc += v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum_out, (double)((part[0] + part[1]) + (part[2] + part[3])));
+}
+
+__global__ __launch_bounds__(256) void occ_threshold_kernel(const float* __restrict__ occs, int64_t n, const double* __restrict__ sum,
+                                                            float occ_thre, uint8_t* __restrict__ binaries) {
+    const float thre = fminf((float)(sum[0] / (double)n), occ_thre);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) binaries[i] = occs[i] > thre ? 1 : 0;
+}
+}  // namespace perf
+
+extern "C" int perf_occ_jitter_points(uint64_t seed, uint64_t call, int64_t cell_lo, int64_t n, int32_t res, const float* aabb,
+                                      float* x, void* stream) {
+    PERF_REQUIRE(res > 0 && cell_lo >= 0 && n >= 0 && aabb, "perf_occ_jitter_points: bad arguments");
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(x, "NULL pointer");
+    perf::Aabb bb;
+    for (int a = 0; a < 3; ++a) { bb.lo[a] = aabb[a]; bb.hi[a] = aabb[3 + a]; }
+    hipLaunchKernelGGL(perf::occ_jitter_points_kernel, dim3((unsigned)perf::div_up(n, 256)), dim3(256), 0, perf::as_stream(stream),
+                       (uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32), call, cell_lo, n, res, bb, x);
+    PERF_LAUNCH_CHECK("perf_occ_jitter_points");
+    return PERF_OK;
+}
+
+extern "C" int perf_occ_ema_update(float* occs, const float* occ, int64_t n, float ema_decay, double* sum_out, void* stream) {
+    PERF_REQUIRE(n >= 0 && sum_out, "perf_occ_ema_update: bad arguments");
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(occs && occ, "NULL pointer");
+    int64_t blocks = perf::div_up(n, 256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(perf::occ_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, perf::as_stream(stream), occs, occ, n, ema_decay, sum_out);
+    PERF_LAUNCH_CHECK("perf_occ_ema_update");
+    return PERF_OK;
+}
+
+extern "C" int perf_occ_threshold(const float* occs, int64_t n, const double* sum, float occ_thre, uint8_t* binaries, void* stream) {
+    PERF_REQUIRE(n > 0 && occs && sum && binaries, "perf_occ_threshold: bad arguments");
+    hipLaunchKernelGGL(perf::occ_threshold_kernel, dim3((unsigned)perf::div_up(n, 256)), dim3(256), 0, perf::as_stream(stream), occs, n, sum,
+                       occ_thre, binaries);
+    PERF_LAUNCH_CHECK("perf_occ_threshold");
+    return PERF_OK;
+}

@@ -321,14 +321,33 @@ class OccGridEstimator(nn.Module):
         res = self._res
         dev = self.occs.device
         if step < warmup_steps:
-            idx = torch.arange(self.cells_per_lvl, device=dev)
-        else:
-            k = self.cells_per_lvl // 4
-            uni = torch.randint(self.cells_per_lvl, (k,), device=dev)
-            occ_idx = torch.nonzero(self.binaries.reshape(-1))[:, 0]
-            if occ_idx.numel() > k:
-                occ_idx = occ_idx[torch.randint(occ_idx.numel(), (k,), device=dev)]
-            idx = torch.cat([uni, occ_idx])
+            # Every cell: two launches around the caller's closure instead of ~20 element-wise torch passes over 16.7 M x 3
+            # floats -- the jittered points (counter-based generator), then the moving maximum with its sum; one more
+            # launch thresholds.  The cells go through the closure in chunks of 2 M, so that whatever element-wise work the
+            # closure itself does (PeRF's look-up closure: ~10 passes, nerf.py:149-158) runs out of the Infinity Cache.
+            if getattr(self, '_upd_seed', None) is None:
+                self._upd_seed = int(torch.initial_seed())
+                self._upd_calls = 0
+                self._upd_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+            self._upd_calls += 1
+            self._upd_sum.zero_()
+            n = self.cells_per_lvl
+            occs = self.occs if self.occs.is_contiguous() else self.occs.contiguous()
+            for lo in range(0, n, self.UPDATE_CHUNK):
+                m = min(self.UPDATE_CHUNK, n - lo)
+                x = ops.occ_jitter_points(self._upd_seed, self._upd_calls, lo, m, res, self._aabb_host, dev)
+                occ = occ_eval_fn(x).reshape(-1).float().contiguous()
+                ops.occ_ema_update(occs[lo:lo + m], occ, ema_decay, self._upd_sum)
+            self.occs = occs
+            self.binaries = ops.occ_threshold(occs, self._upd_sum, occ_thre).reshape(self.binaries.shape)
+            self._bits = None
+            return
+        k = self.cells_per_lvl // 4
+        uni = torch.randint(self.cells_per_lvl, (k,), device=dev)
+        occ_idx = torch.nonzero(self.binaries.reshape(-1))[:, 0]
+        if occ_idx.numel() > k:
+            occ_idx = occ_idx[torch.randint(occ_idx.numel(), (k,), device=dev)]
+        idx = torch.cat([uni, occ_idx])
         cz = idx % res; cy = (idx // res) % res; cx = idx // (res * res)
         coords = torch.stack([cx, cy, cz], -1).float()
         x = (coords + torch.rand_like(coords)) / res
@@ -339,6 +358,8 @@ class OccGridEstimator(nn.Module):
         thre = torch.clamp(self.occs.mean(), max=occ_thre)
         self.binaries = (self.occs > thre).reshape(self.binaries.shape)
         self._bits = None
+
+    UPDATE_CHUNK = 1 << 21
 
 
 class PropNetEstimator(nn.Module):

@@ -426,6 +426,27 @@ def occ_pack_bits(binaries: torch.Tensor) -> torch.Tensor:
     return bits
 
 
+def occ_jitter_points(seed, call, cell_lo, n, res, aabb, device, out=None):
+    """Jittered evaluation points of cells [cell_lo, cell_lo + n) of a res^3 grid -> x [n, 3] (perf_occ_jitter_points)."""
+    x = out if out is not None else torch.empty(n, 3, dtype=torch.float32, device=device)
+    _call('perf_occ_jitter_points', int(seed) & 0xFFFFFFFFFFFFFFFF, int(call), int(cell_lo), int(n), int(res), _aabb6(aabb), _p(x), _stream())
+    return x
+
+
+def occ_ema_update(occs, occ, ema_decay, sum_out):
+    """In place occs = max(occs * ema_decay, occ); sum_out (device float64 [1]) += the new values."""
+    if sum_out.dtype != torch.float64:
+        raise _lib.PerfError('sum_out must be float64')
+    _call('perf_occ_ema_update', _p(_f32(occs, 'occs')), _p(_f32(occ, 'occ')), occs.numel(), float(ema_decay), _p(sum_out), _stream())
+
+
+def occ_threshold(occs, sum_dev, occ_thre, out=None):
+    """-> bool [n]: occs > min(sum / n, occ_thre)."""
+    b = out if out is not None else torch.empty(occs.numel(), dtype=torch.bool, device=occs.device)
+    _call('perf_occ_threshold', _p(_f32(occs, 'occs')), occs.numel(), _p(sum_dev), float(occ_thre), _p(b.view(torch.uint8)), _stream())
+    return b
+
+
 def exclusive_scan_i32(counts: torch.Tensor, bias=None):
     """-> (offsets, total int64 [1]); with `bias` (host int) also total + bias as a third result (same launch)."""
     n = counts.numel()

@@ -441,6 +441,73 @@ def test_repeated_addition_lattice_closed_form():
                 assert closed_form(t0, int(k), step) == table[k], (step, t0, k)
 
 
+def test_repeated_addition_lattice_run_table():
+    """perf_amd/csrc/march.hip:lattice_runs_build / LatticeRuns, restated in numpy: ONE walk per ray leaves a table of runs
+    (first index, first bit pattern, ulps per step); t_k is read off the run that holds k.  Equal to the sequential
+    accumulation for every k, including the reciprocal-estimate division (div_u24) the kernel uses."""
+    F = np.float32
+
+    def bits(x):
+        return int(np.array([x], F).view(np.uint32)[0])
+
+    def flt(b):
+        return np.array([b & 0xffffffff], np.uint32).view(F)[0]
+
+    def div_u24(n, d):
+        q = int(np.uint32(F(F(n) * (F(1.0) / F(d)))))            # (uint32)((float)n * __frcp_rn((float)d)): truncation
+        p = q * d
+        if p > n:
+            q -= 1
+        elif n - p >= d:
+            q += 1
+        assert q == n // d, (n, d, q)
+        return q
+
+    def build(t0, step, k_need, max_runs=64):
+        runs = [(0, bits(t0), 0)]
+        tb, K = bits(t0), 0
+        while K < k_need:
+            if len(runs) + 2 > max_runs:
+                return None
+            b1 = bits(F(flt(tb) + step))
+            if (b1 >> 23) != (tb >> 23):
+                runs.append((K + 1, b1, 0)); tb = b1; K += 1; continue
+            b2 = bits(F(flt(b1) + step))
+            if (b2 >> 23) != (b1 >> 23):
+                runs.append((K + 1, b1, 0)); runs.append((K + 2, b2, 0)); tb = b2; K += 2; continue
+            d = b2 - b1
+            runs.append((K + 1, b1, d))
+            if d == 0:
+                return runs
+            j = div_u24((b2 & 0xff800000) + 0x00800000 - 1 - b2, d)
+            tb = b2 + j * d; K += 2 + j
+        return runs
+
+    def evaluate(runs, k):
+        lo, hi = 0, len(runs) - 1
+        while lo < hi:
+            mid = (lo + hi + 1) >> 1
+            if runs[mid][0] <= k:
+                lo = mid
+            else:
+                hi = mid - 1
+        ks, bs, dd = runs[lo]
+        return flt(bs + (k - ks) * dd)
+
+    rng = np.random.RandomState(1)
+    longest = 0
+    for step in (F(5e-4), F(0.99 / 128), F(1 / 3.), F(0.001953125), F(3e-4), F(4e-3), F(1e-8)):
+        for t0 in list((rng.rand(4) * step).astype(F)) + [F(0), F(1e-9), F(1e-2)]:
+            K = 3100
+            runs = build(t0, step, K + 64)
+            assert runs is not None
+            longest = max(longest, len(runs))
+            table = O.lattice_table_repeated(np.array([t0], F), K + 64, step)[0]
+            for k in list(range(0, 70)) + list(rng.randint(0, K + 65, 120)) + [K, K + 64]:
+                assert evaluate(runs, int(k)) == table[k], (step, t0, k)
+    assert longest <= 48, longest                                   # (the kernel's table holds 64 runs)
+
+
 def test_synthetic_room_with_box_on_cpu():
     """perf_amd/synthetic.py (pure torch): without the box and from the centre room_with_box is room() up to the normalisation
     constant; the box hides part of the walls; from another position every ray still ends on a surface inside the room."""
@@ -500,3 +567,20 @@ def test_oracle_against_upstream_vectors(tmp_path):
         # the two lattices really are different walks at PeRF's step: only one of them reproduces the recorded samples
         assert not rep['nerfacc']['lattice']['perf']['single']
     print('upstream vectors:', 'PINNED' if pinned else 'stand-in (parity of the third-party arithmetic stays unpinned)', rep)
+
+
+def test_scene_shims_against_the_reference_tree():
+    """Build-container only (the reference never travels): tools/check_reference_imports.py -- over the REAL reference tree,
+    install_shims(scene=True) makes `modules.scene.nerf` / `modules.scene.nerf_renderer` / `modules.dataset.sup_info` resolve to
+    the mirrors while the rest of the tree imports as it is; the mirrors bind the runner's constructor call with the reference's
+    own configs/nerf.yaml and offer every method core_exp_runner.py calls on the scene and the pool."""
+    import os
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.isdir('/root/reference/modules'):
+        pytest.skip('needs /root/reference (build container)')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_reference_imports.py')], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+    assert r.returncode == 0 and 'install_shims(scene=True): OK' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

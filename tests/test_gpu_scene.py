@@ -940,3 +940,131 @@ def test_sup_info_and_visibility_match_the_reference(golden_dir):
     bad_v, bad_c = float((vis != g['visibility_mask']).mean()), float((chk != g['geo_check']).mean())
     print(f'[visibility] mismatching pixels: visibility {bad_v:.4f}, geo_check {bad_c:.4f}')
     assert bad_v < 0.01 and bad_c < 0.01
+
+
+def test_unmodified_runner_imports_reach_the_mirrors(tmp_path):
+    """perf_amd.install_shims(scene=True): `from modules.scene.nerf import NeRFScene` / `from modules.dataset.sup_info import
+    SupInfoPool` -- the import statements of core_exp_runner.py:20,24 -- resolve to this package's mirrors even though a
+    `modules` tree with files of those names is on sys.path (here a decoy tree whose files raise when executed; in the build
+    container tools/check_reference_imports.py does the same against the real reference tree), everything else of that tree
+    imports as it is, and the runner's call sequence (core_exp_runner.py:64,77-83,111-113,137-139,174-175,220) runs through
+    those names: construct with the runner's keywords, register, fit, render, visibility mask, geo_check, register again,
+    fit, checkpoint round trip."""
+    import importlib
+    import sys
+    from types import SimpleNamespace
+    import perf_amd
+    from perf_amd import synthetic
+    root = tmp_path / 'tree'
+    for sub in ('modules', 'modules/scene', 'modules/dataset'):
+        (root / sub).mkdir(parents=True)
+    (root / 'modules' / '__init__.py').write_text('')
+    boom = "raise ImportError('the decoy file was executed: the finder did not win')\n"
+    for f in ('scene/nerf.py', 'scene/nerf_renderer.py', 'dataset/sup_info.py'):
+        (root / 'modules' / f).write_text(boom)
+    (root / 'modules' / 'dataset' / 'dataset.py').write_text("MARK = 'decoy dataset module'\n")
+    saved = {k: v for k, v in sys.modules.items() if k == 'modules' or k.startswith('modules.')}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, str(root))
+    try:
+        perf_amd.install_shims(scene=True)
+        from modules.scene.nerf import NeRFScene                      # core_exp_runner.py:24
+        from modules.dataset.sup_info import SupInfoPool               # :20
+        from modules.scene.nerf_renderer import NeRFOCCRenderer
+        import perf_amd.scene as mirror
+        assert NeRFScene is mirror.NeRFScene and SupInfoPool is mirror.SupInfoPool
+        assert importlib.import_module('modules.dataset.dataset').MARK == 'decoy dataset module'     # the rest of the tree is untouched
+        opt = lambda: SimpleNamespace(init_lr=0.0, peak_lr=1e-2, peak_at=0.2, lr_alpha=1e-2)
+        train_conf = SimpleNamespace(raw_phase_iter_geo=60, raw_phase_iter_app=40, geo_optimizer=opt(), app_optimizer=opt(),
+                                     color_loss_weight=1., depth_loss_weight=1., density_loss_weight=0., distortion_loss_weight=0.1,
+                                     pixel_loss_batch_size=2048)
+        torch.manual_seed(0)
+        scene = NeRFScene(str(tmp_path / 'exp'), train_conf=train_conf, estimator_type='occ',
+                          renderer_conf={'max_radius': 2, 'bg_color': 'rand_noise'})       # :64 with configs/nerf.yaml:24-29
+        assert isinstance(scene.renderer, NeRFOCCRenderer)
+        H, W = 64, 128
+        pose0 = torch.eye(4)
+        rays0 = mirror.gen_pano_rays(pose0, H, W)
+        dist0, rgb0 = synthetic.room_with_box(rays0.o, rays0.d)
+        pool = SupInfoPool()
+        pool.register_sup_info(pose=pose0, mask=torch.ones([H, W], device='cuda'), rgb=rgb0, distance=dist0, normal=None)   # :77-82
+        pool.gen_occ_grid(256)                                                                # :83
+        scene.fit(pool)                                                                       # :111
+        out = scene.render(mirror.gen_pano_rays(pose0, 32, 64), query_keys=['rgb', 'distance'])   # :113
+        assert out['rgb'].shape == (32, 64, 3) and torch.isfinite(out['distance']).all()
+        pose1 = torch.eye(4); pose1[:3, 3] = torch.tensor([0.2, 0.1, 0.0])
+        rays1 = mirror.gen_pano_rays(pose1, H, W)
+        visi = scene.get_pano_visibility_mask(pool, rays1)                                    # :137
+        res = scene.render(rays1, query_keys=['rgb', 'distance'])                              # :139
+        d1, c1 = synthetic.room_with_box(rays1.o, rays1.d)
+        ok = pool.geo_check(rays1, d1)                                                        # :155
+        assert visi.shape[:2] == (H, W) and 0.0 < float(visi.float().mean()) <= 1.0 and float(ok.float().mean()) > 0.5
+        sup_mask = (1. - visi.reshape(H, W).float())
+        n_before = len(pool)
+        pool.register_sup_info(pose=pose1, mask=sup_mask, rgb=c1, distance=d1, normal=None)   # :174
+        assert len(pool) > n_before and res['rgb'].shape == (H, W, 3)
+        scene.fit(pool)                                                                       # :175
+        sd = scene.state_dict()                                                               # :250
+        torch.save({'scene': sd, 'phase': 1}, tmp_path / 'ckpt.pth')
+        scene2 = NeRFScene(str(tmp_path / 'exp2'), train_conf=train_conf, estimator_type='occ',
+                           renderer_conf={'max_radius': 2, 'bg_color': 'rand_noise'})
+        scene2.load_state_dict(torch.load(tmp_path / 'ckpt.pth', map_location='cuda')['scene'])   # :220
+        a = scene.render(rays0, query_keys=['rgb']); b = scene2.render(rays0, query_keys=['rgb'])
+        assert torch.equal(a['rgb'], b['rgb'])
+        assert mirror.psnr(a['rgb'], rgb0) > 20.0                       # (100 iterations: it trains)
+    finally:
+        perf_amd.uninstall_scene_shims()
+        sys.path.remove(str(root))
+        for k in [k for k in sys.modules if k == 'modules' or k.startswith('modules.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_occupancy_update_kernels_follow_nerfacc_rule():
+    """OccGridEstimator.update_every_n_steps in its warm-up phase (what the reference's NeRFScene calls 256 times per episode
+    with a look-up closure, nerf.py:147-168): the three launches around the closure (perf_occ_jitter_points,
+    perf_occ_ema_update, perf_occ_threshold) against the rule restated in torch on the SAME points -- occs = max(occs *
+    decay, occ), binaries = occs > min(mean(occs), occ_thre) --, jitter inside its cell, chunking invisible, and the
+    reference's 256-call warm-up leaves binaries == pre_grid up to a handful of cells at occupied boundaries."""
+    from perf_amd import ops
+    from perf_amd.nerfacc_impl import OccGridEstimator
+    res = 64
+    est = OccGridEstimator(roi_aabb=torch.tensor(AABB), resolution=res, levels=1).cuda()
+    est.train()
+    est.UPDATE_CHUNK = 50000                                   # several ragged chunks
+    seen = []
+
+    def closure(x):
+        seen.append(x.clone())
+        return (x.norm(dim=-1) < 0.6).float() * 0.7
+
+    torch.manual_seed(3)
+    est.update_every_n_steps(step=0, occ_eval_fn=closure, occ_thre=1e-2, ema_decay=0.1, warmup_steps=256, n=1)
+    x = torch.cat(seen)
+    assert x.shape == (res ** 3, 3)
+    idx = torch.arange(res ** 3, device='cuda')
+    cell = torch.stack([idx // (res * res), (idx // res) % res, idx % res], -1).float()
+    u = (x + 1.0) * 0.5 * res - cell                          # position inside the cell
+    assert float(u.min()) >= -1e-4 and float(u.max()) <= 1.0 + 1e-4 and 0.45 < float(u.mean()) < 0.55 and float(u.std()) > 0.25
+    occ = (x.norm(dim=-1) < 0.6).float() * 0.7
+    occs_ref = torch.maximum(torch.zeros_like(occ) * 0.1, occ)
+    assert torch.equal(est.occs, occs_ref)
+    thre = min(float(occs_ref.double().mean()), 1e-2)
+    assert torch.equal(est.binaries.reshape(-1), occs_ref > thre)
+    # a second call: the moving maximum decays what is not confirmed; another draw of the jitter
+    seen.clear()
+    est.update_every_n_steps(step=1, occ_eval_fn=lambda p: torch.zeros(p.shape[0], device=p.device), occ_thre=1e-2, ema_decay=0.1,
+                             warmup_steps=256, n=1)
+    assert torch.allclose(est.occs, occs_ref * 0.1)
+    # the reference's warm-up on a pre-grid (ema 0.1, 0/1 results): binaries == pre_grid but for boundary cells the jitter can reach
+    pre = (torch.rand(res ** 3, device='cuda') < 0.02)
+    est2 = OccGridEstimator(roi_aabb=torch.tensor(AABB), resolution=res, levels=1).cuda(); est2.train()
+
+    def occ_eval_fn(p):                                       # nerf.py:149-158
+        q = ((p.clip(-0.999, 0.999) * .5 + .5) * res).to(torch.int64)
+        return pre[q[..., 0] * res * res + q[..., 1] * res + q[..., 2]].float()
+    for i in range(8):
+        est2.update_every_n_steps(step=i, occ_eval_fn=occ_eval_fn, occ_thre=1e-2, ema_decay=0.1, warmup_steps=256, n=1)
+    diff = int((est2.binaries.reshape(-1) != pre).sum())
+    assert int((est2.binaries.reshape(-1) & ~pre).sum()) == diff and diff <= 0.02 * int(pre.sum()) + 8, diff     # only additions, a handful

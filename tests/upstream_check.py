@@ -130,10 +130,23 @@ def hip_vs_tcnn(npz, dtype='fp16'):
         g = m.params.grad.float().cpu().numpy()
         rep[name] = {'y': _rel(y.detach().float().cpu().numpy(), npz[f'{name}_y']), 'grad_net': _rel(g[:n_net], npz[f'{name}_grad_net']),
                      'grad_grid': _rel(g[n_net:], _dense_grid_grad(npz, f'{name}_grad_grid', p.size - n_net))}
-        # 16-bit storage of table, weights and activations against fp32 (stand-in) or against tcnn's fp16 (upstream): the
-        # bounds of tests/test_gpu_ops.py's field tests, relative L2
-        tol = {'fp16': 1e-2, 'bf16': 4e-2}[dtype] * (2.0 if up else 1.0)
-        assert max(rep[name].values()) <= tol, (name, dtype, rep[name])
+        # What 16-bit storage of table, weights and activations costs on THESE inputs is measured, not guessed: the oracle's
+        # 16-bit emulation (operands rounded to the type, fp32 accumulation -- what the MFMA kernels do) against the same
+        # vectors.  The HIP path may be off by twice that (+ 2e-3); against the emulation itself it must be tight.
+        spec = O.geo_spec() if name == 'geo' else O.app_spec()
+        pt = torch.from_numpy(p).requires_grad_(True)
+        yq = O.network_with_encoding(torch.from_numpy(npz[f'{name}_x']), pt, spec, quant=dtype)
+        (yq * torch.from_numpy(npz[f'{name}_dy'])).sum().backward()
+        gq = pt.grad.numpy()
+        emu = {'y': _rel(yq.detach().numpy(), npz[f'{name}_y']), 'grad_net': _rel(gq[:n_net], npz[f'{name}_grad_net']),
+               'grad_grid': _rel(gq[n_net:], _dense_grid_grad(npz, f'{name}_grad_grid', p.size - n_net))}
+        tight = {'y': _rel(y.detach().float().cpu().numpy(), yq.detach().numpy()), 'grad_net': _rel(g[:n_net], gq[:n_net]),
+                 'grad_grid': _rel(g[n_net:], gq[n_net:])}
+        rep[name + '_emulation_vs_vectors'] = emu
+        rep[name + '_hip_vs_emulation'] = tight
+        for k in rep[name]:
+            assert rep[name][k] <= 2.0 * emu[k] + 2e-3, (name, dtype, k, rep[name], emu)
+            assert tight[k] <= {'fp16': 5e-3, 'bf16': 2e-2}[dtype], (name, dtype, k, tight)
     e = tcnn.Encoding(3, dict(PU.ENC_SMOOTH), dtype='fp32')
     p, _ = _params(npz, 'enc')
     with torch.no_grad():
