@@ -280,6 +280,7 @@ struct TileParams {
     int32_t accumulate;
     int64_t dbg_off;                       // >0: float2 offset in the workspace where per-block cycle counts go (dev tool)
     int32_t code_slot[PERF_MAX_LEVELS];    // >=0: the level's tile codes are codes[slot][n_pad] (see tile_codes_kernel)
+    uint32_t code16_levels;                // bit l: hashed level of <= 16 tiles: its codes are 16-bit (one nibble per (y,z) combination)
     int64_t n_pad;
     // XCD-aware placement: workgroup b runs work[b] = level << 16 | tile << 8 | replica (0xffffffff: idle).  The
     // dispatcher deals workgroups round-robin over the 8 XCDs, so b % 8 is the XCD: the owners of one level are put on
@@ -625,7 +626,14 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
                     code |= b << (8 * c);
                 }
             }
-            codes[(int64_t)slot * tp.n_pad + i] = code;
+            if ((tp.code16_levels >> l) & 1u) {
+                // <= 16 tiles: a nibble per combination, two samples per dword -- an owner tests both with four
+                // bit-parallel operations (bwd_stream_codes<.., CODE16>) and streams half the bytes
+                const uint32_t c16 = (code & 0xfu) | ((code >> 4) & 0xf0u) | ((code >> 8) & 0xf00u) | ((code >> 12) & 0xf000u);
+                reinterpret_cast<uint16_t*>(codes + (int64_t)slot * tp.n_pad)[i] = (uint16_t)c16;
+            } else {
+                codes[(int64_t)slot * tp.n_pad + i] = code;
+            }
             if (bad && gp.hashed[l]) {      // harmless without gradient; with gradient the level's owners take the generic path
                                             // (dense: the owners apply such a sample corner by corner, see bwd_stream_codes)
                 const float2 g = dfeat[(int64_t)l * n + i];
@@ -708,17 +716,25 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // multiply) and drains vmcnt to 0 around the conditional drain.  VMEM loads return in issue order, so
 // "vmcnt(k)" = "everything but the k youngest loads has landed"; the number of loads issued per step is static
 // (2 code loads, then 3 gather loads per drain, idle lanes gather sample 0).
-template <bool FIXED, bool DENSE>
+// CODE16 (hashed levels of <= 16 tiles): 16-bit codes, a nibble per (y,z) combination.  A lane takes EIGHT consecutive samples
+// per iteration -- the same two 8-byte code loads -- in two halves of four, each followed by the drain the byte-code loop
+// runs once per iteration (the queue, sized for four new samples per lane and drain, stays as it is).  Two samples are
+// tested at once: x = pair ^ (t * 0x11111111) has a zero nibble where a combination names this tile; OR-folding each
+// nibble into its top bit takes two shift-ors, one bit-field insert leaves the match flags, and a multiplication by
+// 0x249 moves the four flags of a sample into adjacent bits (all partial products land on distinct bits: no carries).
+template <bool FIXED, bool DENSE, bool CODE16 = false>
 __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_tile, uint32_t* queue,
                                                  const uint32_t* __restrict__ codes_l, const float* __restrict__ x01,
                                                  const float2* __restrict__ g_l, int64_t n, int rep, int R) {
     // (tells the compiler's own wait-count bookkeeping that nothing it knows of is in flight when the loop starts;
     //  otherwise it drains vmcnt to 0 at the head of every iteration on behalf of the other streaming variants)
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+    static_assert(!(CODE16 && DENSE), "16-bit codes are for hashed levels");
+    constexpr int kPer = CODE16 ? 8 : 4;                // samples of a lane per iteration (= per pair of code loads)
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t qn = 0;                                    // wave-uniform queue fill
-    const int64_t n_full = n / 4;
-    const int64_t g_lo = n_full * rep / R, g_hi = n_full * (rep + 1) / R;       // this replica's groups of 4 samples
+    const int64_t n_full = n / kPer;
+    const int64_t g_lo = n_full * rep / R, g_hi = n_full * (rep + 1) / R;       // this replica's groups of kPer samples
     // registers written by loads in flight: only ever read through the wait_* copies below
     float ld_x = 0.f; f32x2 ld_yz = {0.f, 0.f}, ld_g = {0.f, 0.f}; u32x2 ld_c0 = {0u, 0u}, ld_c1 = {0u, 0u};
     uint32_t bcm = 0, bi = 0;                           // (y,z) combinations and sample index of the batch in flight
@@ -739,6 +755,15 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
             if (DENSE) wraps = wraps || b == 0x7fu;
         }
         return wraps ? 0x10u : cm;
+    };
+    const uint32_t t_nib = cx.t * 0x11111111u;
+    auto test_pair = [&](uint32_t w, uint32_t& cm_a, uint32_t& cm_b) {      // two 16-bit codes -> their combination masks
+        const uint32_t x = w ^ t_nib;
+        const uint32_t y = (x << 1) | x;
+        const uint32_t z = (y << 2) | y;                                    // bit 3 of a nibble: the nibble of x is not zero
+        const uint32_t m = ~z & 0x88888888u;                                // bit 3 of a nibble: that combination names this tile
+        cm_a = (__umul24(m, 0x249u) >> 12) & 15u;                           // (mul24 reads bits 0..23: the flags above 15 land beyond bit 18)
+        cm_b = (__umul24(m >> 16, 0x249u) >> 12) & 15u;
     };
     auto enqueue = [&](uint32_t cm, uint32_t i) {
         const unsigned long long b = __ballot(cm != 0u);
@@ -808,22 +833,40 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
             load_codes(grp);
             const uint32_t cs[4] = {c0.x, c0.y, c1.x, c1.y};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
-            {
-                PERF_WAIT_BATCH(2);     // all but the 2 code loads
-                apply_batch(bx, byz, bg);
-            }
-            pop_and_gather();
-            while (qn >= 128u) {        // bursts (ray-coherent samples at coarse hashed levels)
-                PERF_WAIT_BATCH(0);
-                apply_batch(bx, byz, bg);
+            for (int half = 0; half < (CODE16 ? 2 : 1); ++half) {
+                if (CODE16) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        uint32_t cm_a, cm_b;
+                        test_pair(cs[2 * half + s], cm_a, cm_b);
+                        enqueue(valid ? cm_a : 0u, (uint32_t)(8 * g0 + 4 * half + 2 * s));
+                        enqueue(valid ? cm_b : 0u, (uint32_t)(8 * g0 + 4 * half + 2 * s + 1));
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
+                }
+                {
+                    PERF_WAIT_BATCH(2);     // all but the 2 code loads
+                    apply_batch(bx, byz, bg);
+                }
                 pop_and_gather();
+                while (qn >= 128u) {        // bursts (ray-coherent samples at coarse hashed levels)
+                    PERF_WAIT_BATCH(0);
+                    apply_batch(bx, byz, bg);
+                    pop_and_gather();
+                }
             }
         }
     }
-    if (threadIdx.x < 64 && rep == 0) {                 // ragged tail (n % 4 samples)
-        const int64_t i = n_full * 4 + lane;
-        enqueue(i < n ? test(codes_l[i]) : 0u, (uint32_t)i);
+    if (threadIdx.x < 64 && rep == 0) {                 // ragged tail (n % kPer samples)
+        const int64_t i = n_full * kPer + lane;
+        uint32_t cm = 0u;
+        if (i < n) {
+            if (CODE16) { uint32_t hi_; test_pair((uint32_t)reinterpret_cast<const uint16_t*>(codes_l)[i], cm, hi_); }
+            else cm = test(codes_l[i]);
+        }
+        enqueue(cm, (uint32_t)i);
     }
     for (;;) {
         PERF_WAIT_BATCH(0);
@@ -1145,6 +1188,7 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     uint32_t* queue = reinterpret_cast<uint32_t*>(lds_tile + 2 * kTileEntries) + (threadIdx.x >> 6) * kQueueCap;
     if (by_bitmap && hashed) bwd_stream_bitmap<FIXED, false>(cx, lds_tile, queue, bitmaps + (int64_t)(tp.bm_row[l] + (int)t) * tp.bm_row_words, x01, g_l, n_live);
     else if (by_bitmap) bwd_stream_bitmap<FIXED, true>(cx, lds_tile, queue, bitmaps + (int64_t)(tp.bm_row[l] + (int)t) * tp.bm_row_words, x01, g_l, n_live);
+    else if (coded && hashed && ((tp.code16_levels >> l) & 1u)) bwd_stream_codes<FIXED, false, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (coded) bwd_stream_codes<FIXED, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n_live, rep, R);
@@ -1707,12 +1751,16 @@ extern "C" int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x0
 // levels whose owners can run the coded variant (multi-tile levels); returns their number
 static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
     int slots = 0;
+    static const bool no_code16 = getenv("PERF_BWD_NO_CODE16") != nullptr;       // (dev switch: byte codes everywhere)
+    tp->code16_levels = 0u;
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->code_slot[l] = -1;
         if (l >= gp.n_levels || n >= kMaxCodedSamples || ((tp->bitmap_levels >> l) & 1u)) continue;
         const int64_t nt = tp->tiles_of[l];         // (plan_tiles ran before)
-        if (gp.hashed[l] ? (nt >= 2 && nt <= 255 && gp.res[l] + 2u < (uint32_t)kTileEntries) : (nt >= 2 && nt <= 64))
+        if (gp.hashed[l] ? (nt >= 2 && nt <= 255 && gp.res[l] + 2u < (uint32_t)kTileEntries) : (nt >= 2 && nt <= 64)) {
             tp->code_slot[l] = slots++;
+            if (gp.hashed[l] && nt <= 16 && !no_code16) tp->code16_levels |= 1u << l;
+        }
     }
     tp->n_pad = (n + 3) & ~(int64_t)3;
     return slots;
@@ -1778,6 +1826,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         if (rp.atomic_levels != 0u || nb == 0) { set_error("perf_hashgrid_bwd: the redo launch serves grids whose levels all fit LDS owners (<= 255 hashed / 64 dense tiles)"); return PERF_E_UNSUPPORTED; }
         rp.accumulate = 0; rp.raw_out = 0; rp.dbg_off = 0; rp.run_merge = 0; rp.n_pad = 0;
         for (int l = 0; l < PERF_MAX_LEVELS; ++l) rp.code_slot[l] = -1;
+        rp.code16_levels = 0u;
         const int lds_b = 2 * kTileEntries * (int)sizeof(float) + (kBwdThreads / 64) * kQueueCap * (int)sizeof(uint32_t);
         static std::once_flag redo_once;
         std::call_once(redo_once, [&]() {
@@ -1862,6 +1911,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(codes)");
     } else {
         for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.code_slot[l] = -1;
+        tp.code16_levels = 0u;
     }
     const int lds_bytes = 2 * kTileEntries * (int)sizeof(float) + (kBwdThreads / 64) * kQueueCap * (int)sizeof(uint32_t);
     static std::once_flag attr_once;                // one-time kernel attribute setup, safe under concurrent callers

@@ -8,6 +8,8 @@
 // gives the packed offsets, pass 2 expands the masks with a per-lane prefix popcount -- the
 // "count -> scan -> write" protocol with bit-exact, t-sorted output and no atomics.
 // All lattice/cell arithmetic is unfused fp32 (mul_rn/add_rn) so it matches numpy bit for bit.
+#include <cstring>
+
 #include "common.hpp"
 
 namespace perf {
@@ -101,51 +103,97 @@ __device__ __forceinline__ float lattice_repeated(float t0, int k, float step) {
 // index k_need (more binades than the table holds: the caller falls back to the per-lane walk).
 constexpr int kMaxRuns = 64;
 
+// (one lane = one ray: march_count_kernel lets lanes 0..3 of its first wave build the tables of the block's four rays, then
+//  the block synchronises -- a quarter of the instructions of every wave walking its own ray)
 __device__ __forceinline__ int lattice_runs_build(float t0, float step, int k_need, int32_t* __restrict__ ks, uint32_t* __restrict__ bs,
-                                                  uint32_t* __restrict__ dd, bool writer) {
+                                                  uint32_t* __restrict__ dd) {
     int n = 0;
-    auto emit = [&](int k, uint32_t b, uint32_t d) {
-        if (writer) { ks[n] = k; bs[n] = b; dd[n] = d; }
-        ++n;
-    };
-    uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t0));
+    auto emit = [&](int k, uint32_t b, uint32_t d) { ks[n] = k; bs[n] = b; dd[n] = d; ++n; };
+    uint32_t tb = __float_as_uint(t0);
     emit(0, tb, 0u);
     int K = 0;
     while (K < k_need) {
         if (n + 2 > kMaxRuns) return -1;
-        const uint32_t b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(add_rn(__uint_as_float(tb), step)));
+        const uint32_t b1 = __float_as_uint(add_rn(__uint_as_float(tb), step));
         if ((b1 >> 23) != (tb >> 23)) { emit(K + 1, b1, 0u); tb = b1; K += 1; continue; }    // entered a binade: one more real step first
-        const uint32_t b2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(add_rn(__uint_as_float(b1), step)));
+        const uint32_t b2 = __float_as_uint(add_rn(__uint_as_float(b1), step));
         if ((b2 >> 23) != (b1 >> 23)) { emit(K + 1, b1, 0u); emit(K + 2, b2, 0u); tb = b2; K += 2; continue; }
         const uint32_t d = b2 - b1;
         emit(K + 1, b1, d);                                      // t_{K+1}, t_{K+2}, ... equidistant to the end of the binade
         if (d == 0u) return n;                                   // (step below half an ulp: the lattice is stuck at t_{K+1} for good)
         const uint32_t top = (b2 & 0xff800000u) + 0x00800000u;
-        const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)div_u24(top - 1u - b2, d));
+        const uint32_t j = div_u24(top - 1u - b2, d);
         tb = b2 + j * d;
         K += 2 + (int)j;
     }
     return n;
 }
 
-struct LatticeRuns {
-    int n;                       // > 0: table; <= 0: evaluate directly (single lattice, or a table that did not fit)
-    const int32_t* ks; const uint32_t* bs; const uint32_t* dd;
-    float t0, step; int mode;
-    __device__ __forceinline__ float operator()(int k) const {
-        if (n <= 0) return lattice(t0, k, step, mode);
-        int lo = 0, hi = n - 1;                                  // last run that starts at or before k
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (ks[mid] <= k) lo = mid; else hi = mid - 1;
-        }
-        return __uint_as_float(bs[lo] + (uint32_t)(k - ks[lo]) * dd[lo]);
-    }
+// The table of a launch whose rays all start their lattice at the same t0 (eval renders: no stratified jitter): built ONCE
+// on the host with the same IEEE single-precision additions and handed to the kernels as an argument.
+struct SharedRuns {
+    int32_t n;                    // 0: none (per-ray origins, or the single-rounding lattice); -1 cannot happen (the host falls back to 0)
+    int32_t ks[kMaxRuns];
+    uint32_t bs[kMaxRuns], dd[kMaxRuns];
 };
+
+static inline uint32_t host_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float host_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static void shared_runs_build(float t0, float step, int k_need, SharedRuns* sr) {
+    sr->n = 0;
+    int n = 0;
+    auto emit = [&](int k, uint32_t b, uint32_t d) { sr->ks[n] = k; sr->bs[n] = b; sr->dd[n] = d; ++n; };
+    uint32_t tb = host_bits(t0);
+    emit(0, tb, 0u);
+    int K = 0;
+    while (K < k_need) {
+        if (n + 2 > kMaxRuns) return;                            // (too many binades for the table: the kernels walk per lane)
+        volatile float s1 = host_float(tb) + step;               // (volatile: one rounding to fp32 per addition, whatever the host compiler does)
+        const uint32_t b1 = host_bits(s1);
+        if ((b1 >> 23) != (tb >> 23)) { emit(K + 1, b1, 0u); tb = b1; K += 1; continue; }
+        volatile float s2 = host_float(b1) + step;
+        const uint32_t b2 = host_bits(s2);
+        if ((b2 >> 23) != (b1 >> 23)) { emit(K + 1, b1, 0u); emit(K + 2, b2, 0u); tb = b2; K += 2; continue; }
+        const uint32_t d = b2 - b1;
+        emit(K + 1, b1, d);
+        if (d == 0u) break;
+        const uint32_t top = (b2 & 0xff800000u) + 0x00800000u;
+        const uint32_t j = (top - 1u - b2) / d;
+        tb = b2 + j * d;
+        K += 2 + (int)j;
+    }
+    sr->n = n;
+}
 
 __device__ __forceinline__ float lattice(float t0, int k, float step, int mode) {
     return mode == PERF_LATTICE_REPEATED ? lattice_repeated(t0, k, step) : lattice_single(t0, k, step);
 }
+
+struct LatticeRuns {
+    int n;                       // > 0: table; <= 0: evaluate directly (single lattice, or a table that did not fit)
+    const int32_t* ks; const uint32_t* bs; const uint32_t* dd;
+    float t0, step; int mode;
+    __device__ __forceinline__ int find(int k) const {           // last run that starts at or before k
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (ks[mid] <= k) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    }
+    __device__ __forceinline__ float at(int r, int k) const { return __uint_as_float(bs[r] + (uint32_t)(k - ks[r]) * dd[r]); }
+    __device__ __forceinline__ float operator()(int k) const {
+        if (n <= 0) return lattice(t0, k, step, mode);
+        return at(find(k), k);
+    }
+    // a little further along the lattice than run r reaches: the next runs are tried before a search
+    __device__ __forceinline__ float after(int& r, int k) const {
+        if (n <= 0) return lattice(t0, k, step, mode);
+        while (r + 1 < n && ks[r + 1] <= k) ++r;
+        return at(r, k);
+    }
+};
 
 // Lattice origin of ray r.  t0s == NULL: t0_base (the near plane).  t0_scale == 0: t0s[r] as given.  Otherwise t0s holds the
 // stratified draw u in [0,1) and the origin is fl(u * t0_scale) (+ t0_base when that is not 0) -- the two torch ops of
@@ -180,11 +228,26 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                                                           int64_t n_rays, const uint32_t* __restrict__ bits,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint64_t* __restrict__ masks, int32_t* __restrict__ counts, HeadOut ho,
-                                                          float t0_scale, float t0_base) {
+                                                          float t0_scale, float t0_base, SharedRuns sr) {
     const int lane = threadIdx.x & 63;
     // (the ray index is wave uniform: saying so turns the loads of the ray's origin, direction and lattice origin into
     //  scalar loads -- seven vector-memory instructions per ray less; the kernel is bound by VMEM issue, not by bytes)
     const int64_t r = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // repeated-addition lattice: the walks of the block's four rays as tables of runs in LDS -- one shared table when all rays
+    // start at the same t0 (built on the host), else lanes 0..3 of the first wave walk one ray each; then the block meets
+    __shared__ int32_t s_ks[4][kMaxRuns];
+    __shared__ uint32_t s_bs[4][kMaxRuns], s_dd[4][kMaxRuns];
+    __shared__ int s_n[4];
+    if (mp.lattice_mode == PERF_LATTICE_REPEATED) {
+        if (sr.n > 0) {
+            if ((int)threadIdx.x < sr.n) { s_ks[0][threadIdx.x] = sr.ks[threadIdx.x]; s_bs[0][threadIdx.x] = sr.bs[threadIdx.x]; s_dd[0][threadIdx.x] = sr.dd[threadIdx.x]; }
+        } else if (threadIdx.x < 4) {
+            const int64_t rr = (int64_t)blockIdx.x * 4 + threadIdx.x;
+            s_n[threadIdx.x] = rr < n_rays ? lattice_runs_build(lattice_origin(t0s, rr, t0_scale, t0_base), mp.step, mp.mask_words * 64 + 64,
+                                                                s_ks[threadIdx.x], s_bs[threadIdx.x], s_dd[threadIdx.x]) : 0;
+        }
+        __syncthreads();
+    }
     if (r >= n_rays) return;
     const float o[3] = {ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]};
     const float d[3] = {rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]};
@@ -200,16 +263,11 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         tmax = (a == 0) ? h : fminf(tmax, h);
     }
     const float lo = fmaxf(tmin, t0), hi = fminf(tmax, mp.far_plane);
-    // repeated-addition lattice: this ray's walk, once, as a table of runs in LDS (one table per wave)
-    __shared__ int32_t s_ks[4][kMaxRuns];
-    __shared__ uint32_t s_bs[4][kMaxRuns], s_dd[4][kMaxRuns];
     const int wv = threadIdx.x >> 6;
+    const int tab = sr.n > 0 ? 0 : wv;
     LatticeRuns lat;
-    lat.n = 0; lat.ks = s_ks[wv]; lat.bs = s_bs[wv]; lat.dd = s_dd[wv]; lat.t0 = t0; lat.step = mp.step; lat.mode = mp.lattice_mode;
-    if (mp.lattice_mode == PERF_LATTICE_REPEATED) {
-        lat.n = lattice_runs_build(t0, mp.step, mp.mask_words * 64 + 64, s_ks[wv], s_bs[wv], s_dd[wv], lane == 0);
-        __builtin_amdgcn_wave_barrier();
-    }
+    lat.n = mp.lattice_mode == PERF_LATTICE_REPEATED ? (sr.n > 0 ? sr.n : s_n[wv]) : 0;
+    lat.ks = s_ks[tab]; lat.bs = s_bs[tab]; lat.dd = s_dd[tab]; lat.t0 = t0; lat.step = mp.step; lat.mode = mp.lattice_mode;
     // the coarse skip is only valid while a chunk spans few enough fine cells (see coarse_build_kernel): checked per ray
     // with its own direction, so unnormalised directions fall back to the exhaustive test instead of skipping cells
     float span_cells = 0.f;
@@ -228,9 +286,12 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         bool maybe = false;
         if (q < mp.mask_words) {
             const int k0 = q * 64;
-            maybe = !(lat(k0) > hi) && !(lat(k0 + 64) < lo);
+            int run = lat.n > 0 ? lat.find(k0) : 0;
+            const float t_first = lat.n > 0 ? lat.at(run, k0) : lat(k0);
+            const float t_mid = lat.after(run, k0 + 32), t_last = lat.after(run, k0 + 64);
+            maybe = !(t_first > hi) && !(t_last < lo);
             if (maybe && use_coarse) {
-                const float tc = lat(k0 + 32);
+                const float tc = t_mid;
                 const int cr = res >> kCoarseShift;
                 int cb[3];
 #pragma unroll
@@ -321,7 +382,16 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                                                           float* __restrict__ te, int32_t* __restrict__ packed,
                                                           const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                           Aabb bb, float* __restrict__ x01, uint8_t* __restrict__ sel,
-                                                          int32_t rank_lo, float t0_scale, float t0_base, int lattice_mode) {
+                                                          int32_t rank_lo, float t0_scale, float t0_base, int lattice_mode, SharedRuns sr) {
+    // (all rays on one lattice -- eval renders --: the host-built table of runs, see march_count_kernel; per-ray origins walk)
+    __shared__ int32_t w_ks[kMaxRuns];
+    __shared__ uint32_t w_bs[kMaxRuns], w_dd[kMaxRuns];
+    if (sr.n > 0) {
+        if ((int)threadIdx.x < sr.n) { w_ks[threadIdx.x] = sr.ks[threadIdx.x]; w_bs[threadIdx.x] = sr.bs[threadIdx.x]; w_dd[threadIdx.x] = sr.dd[threadIdx.x]; }
+        __syncthreads();
+    }
+    LatticeRuns tab;
+    tab.n = sr.n; tab.ks = w_ks; tab.bs = w_bs; tab.dd = w_dd; tab.t0 = 0.f; tab.step = step; tab.mode = lattice_mode;
     // Writes the samples of rank [rank_lo, rank_lo + counts[r]) of every ray (rank = position among the ray's samples in t
     // order) to offsets[r]...: rank_lo = 0 and counts = the march counts is the plain expansion; the two-phase sampler
     // writes the first K samples of every ray first and the rest of the rays that are still alive later.
@@ -364,7 +434,8 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                     const int64_t pos = run + __popcll(m & below);
                     if (pos >= off && pos < end) {
                         const int k = qq * 64 + bit;
-                        const float a = lattice(t0, k, step, lattice_mode), b = lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, step) : lattice_single(t0, k + 1, step);
+                        const float a = tab.n > 0 ? tab.at(tab.find(k), k) : lattice(t0, k, step, lattice_mode);
+                        const float b = lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, step) : lattice_single(t0, k + 1, step);
                         ts[pos] = a;
                         te[pos] = b;
                         ray_indices[pos] = r;
@@ -554,12 +625,15 @@ static int march_count_launch(const float* rays_o, const float* rays_d, const fl
     mp.mask_words = chunk_words(max_steps);
     for (int a = 0; a < 3; ++a) mp.chunk_cells[a] = 64.0f * step * mp.inv_ext[a] * (float)res;
     mp.use_coarse = (occ_coarse != nullptr && (res % 8) == 0) ? 1 : 0;      // (+ the per-ray span test in the kernel)
+    SharedRuns sr;
+    sr.n = 0;
+    if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr) shared_runs_build(t0_base, step, mp.mask_words * 64 + 64, &sr);
     if (head)
         hipLaunchKernelGGL(march_count_kernel<true>, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
-                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, *head, t0_scale, t0_base);
+                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, *head, t0_scale, t0_base, sr);
     else
         hipLaunchKernelGGL(march_count_kernel<false>, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
-                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, HeadOut{}, t0_scale, t0_base);
+                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, HeadOut{}, t0_scale, t0_base, sr);
     PERF_LAUNCH_CHECK("perf_occ_march_count");
     return PERF_OK;
 }
@@ -624,9 +698,12 @@ extern "C" int perf_occ_march_write(const float* t0, float t0_scale, float t0_ba
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(masks && counts && offsets && packed_info, "NULL pointer");
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends), "NULL sample arrays");
+    SharedRuns sr;
+    sr.n = 0;
+    if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr) shared_runs_build(t0_base, step, chunk_words(max_steps) * 64 + 64, &sr);
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0, t0_scale, t0_base, (int)lattice_mode);
+                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0, t0_scale, t0_base, (int)lattice_mode, sr);
     PERF_LAUNCH_CHECK("perf_occ_march_write");
     return PERF_OK;
 }
@@ -643,9 +720,12 @@ extern "C" int perf_occ_march_write_points(const float* t0, float t0_scale, floa
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends && x01), "NULL sample arrays");
     Aabb bb;
     for (int k = 0; k < 3; ++k) { bb.lo[k] = aabb6[k]; bb.hi[k] = aabb6[3 + k]; }
+    SharedRuns sr;
+    sr.n = 0;
+    if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr) shared_runs_build(t0_base, step, chunk_words(max_steps) * 64 + 64, &sr);
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo, t0_scale, t0_base, (int)lattice_mode);
+                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo, t0_scale, t0_base, (int)lattice_mode, sr);
     PERF_LAUNCH_CHECK("perf_occ_march_write_points");
     return PERF_OK;
 }

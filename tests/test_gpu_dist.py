@@ -14,6 +14,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    return port
+
+
 def _run(world, out, port, dp_mode='sharded', units='exact'):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT, PERF_TEST_DP_MODE=dp_mode, PERF_DP_UNITS=units)
     worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
@@ -120,7 +126,7 @@ def test_rccl_exchange_on_a_world_of_one(tmp_path, units):
     res = {}
     for mode in ('plain', 'rccl'):
         out = str(tmp_path / f'{mode}.pt')
-        r = subprocess.run([sys.executable, worker, out, mode, '29581'], env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, worker, out, mode, str(_free_port())], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         res[mode] = torch.load(out)
     assert not res['plain']['dist'] and res['rccl']['dist']
