@@ -830,10 +830,14 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
             const int64_t g0 = grp;
             const bool valid = g0 < g_hi;
             grp += kBwdThreads;
-            load_codes(grp);
+            if (!CODE16) load_codes(grp);
             const uint32_t cs[4] = {c0.x, c0.y, c1.x, c1.y};
 #pragma unroll
             for (int half = 0; half < (CODE16 ? 2 : 1); ++half) {
+                // CODE16: the next code loads are issued between the halves, so that in BOTH halves the gather batch about to be
+                // applied is what is oldest in flight (first half: nothing else is in flight; second half: the 2 code loads are
+                // younger) -- the loop top then finds [2 code loads, 3 gather loads] as the byte-code loop does
+                if (CODE16 && half == 1) load_codes(grp);
                 if (CODE16) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -846,7 +850,10 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
 #pragma unroll
                     for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
                 }
-                {
+                if (CODE16 && half == 0) {
+                    PERF_WAIT_BATCH(0);     // (only the gather batch is in flight)
+                    apply_batch(bx, byz, bg);
+                } else {
                     PERF_WAIT_BATCH(2);     // all but the 2 code loads
                     apply_batch(bx, byz, bg);
                 }
