@@ -1758,7 +1758,11 @@ extern "C" int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x0
 // levels whose owners can run the coded variant (multi-tile levels); returns their number
 static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
     int slots = 0;
-    static const bool no_code16 = getenv("PERF_BWD_NO_CODE16") != nullptr;       // (dev switch: byte codes everywhere)
+    // 16-bit codes (a nibble per combination, bit-parallel owner test, half the code bytes) are bit-identical to the byte codes
+    // and measured SLOWER on the benchmark batch: owners 378.9 vs 361.7 us per 1 M samples, pre-pass unchanged at 22.7
+    // (rocprofv3, same box, tools/exp/bwd_code16_ab.sh) -- the two-half loop waits for its gather batch with nothing else in
+    // flight, and the test was not what bounds an owner.  Off unless PERF_BWD_CODE16=1.
+    static const bool no_code16 = getenv("PERF_BWD_CODE16") == nullptr || atoi(getenv("PERF_BWD_CODE16")) == 0;
     tp->code16_levels = 0u;
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->code_slot[l] = -1;

@@ -103,26 +103,31 @@ __device__ __forceinline__ float lattice_repeated(float t0, int k, float step) {
 // index k_need (more binades than the table holds: the caller falls back to the per-lane walk).
 constexpr int kMaxRuns = 64;
 
-// (one lane = one ray: march_count_kernel lets lanes 0..3 of its first wave build the tables of the block's four rays, then
-//  the block synchronises -- a quarter of the instructions of every wave walking its own ray)
+// (the walk runs on values that are uniform over the wave: the float additions go through the vector unit and come back with
+//  readfirstlane, everything else stays on the scalar unit; lane 0 stores.  Letting lanes 0..3 of one wave walk the block's
+//  four rays and synchronising the block measured SLOWER: 26.9 vs 20.6 us per 8,192 rays -- the other waves wait out the
+//  walk's latency)
 __device__ __forceinline__ int lattice_runs_build(float t0, float step, int k_need, int32_t* __restrict__ ks, uint32_t* __restrict__ bs,
-                                                  uint32_t* __restrict__ dd) {
+                                                  uint32_t* __restrict__ dd, bool writer) {
     int n = 0;
-    auto emit = [&](int k, uint32_t b, uint32_t d) { ks[n] = k; bs[n] = b; dd[n] = d; ++n; };
-    uint32_t tb = __float_as_uint(t0);
+    auto emit = [&](int k, uint32_t b, uint32_t d) {
+        if (writer) { ks[n] = k; bs[n] = b; dd[n] = d; }
+        ++n;
+    };
+    uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t0));
     emit(0, tb, 0u);
     int K = 0;
     while (K < k_need) {
         if (n + 2 > kMaxRuns) return -1;
-        const uint32_t b1 = __float_as_uint(add_rn(__uint_as_float(tb), step));
+        const uint32_t b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(add_rn(__uint_as_float(tb), step)));
         if ((b1 >> 23) != (tb >> 23)) { emit(K + 1, b1, 0u); tb = b1; K += 1; continue; }    // entered a binade: one more real step first
-        const uint32_t b2 = __float_as_uint(add_rn(__uint_as_float(b1), step));
+        const uint32_t b2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(add_rn(__uint_as_float(b1), step)));
         if ((b2 >> 23) != (b1 >> 23)) { emit(K + 1, b1, 0u); emit(K + 2, b2, 0u); tb = b2; K += 2; continue; }
         const uint32_t d = b2 - b1;
         emit(K + 1, b1, d);                                      // t_{K+1}, t_{K+2}, ... equidistant to the end of the binade
         if (d == 0u) return n;                                   // (step below half an ulp: the lattice is stuck at t_{K+1} for good)
         const uint32_t top = (b2 & 0xff800000u) + 0x00800000u;
-        const uint32_t j = div_u24(top - 1u - b2, d);
+        const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)div_u24(top - 1u - b2, d));
         tb = b2 + j * d;
         K += 2 + (int)j;
     }
@@ -233,19 +238,12 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
     // (the ray index is wave uniform: saying so turns the loads of the ray's origin, direction and lattice origin into
     //  scalar loads -- seven vector-memory instructions per ray less; the kernel is bound by VMEM issue, not by bytes)
     const int64_t r = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // repeated-addition lattice: the walks of the block's four rays as tables of runs in LDS -- one shared table when all rays
-    // start at the same t0 (built on the host), else lanes 0..3 of the first wave walk one ray each; then the block meets
+    // repeated-addition lattice: the ray's walk as a table of runs in LDS -- ONE table for the block when all rays start at the
+    // same t0 (built on the host), else every wave walks its own ray
     __shared__ int32_t s_ks[4][kMaxRuns];
     __shared__ uint32_t s_bs[4][kMaxRuns], s_dd[4][kMaxRuns];
-    __shared__ int s_n[4];
-    if (mp.lattice_mode == PERF_LATTICE_REPEATED) {
-        if (sr.n > 0) {
-            if ((int)threadIdx.x < sr.n) { s_ks[0][threadIdx.x] = sr.ks[threadIdx.x]; s_bs[0][threadIdx.x] = sr.bs[threadIdx.x]; s_dd[0][threadIdx.x] = sr.dd[threadIdx.x]; }
-        } else if (threadIdx.x < 4) {
-            const int64_t rr = (int64_t)blockIdx.x * 4 + threadIdx.x;
-            s_n[threadIdx.x] = rr < n_rays ? lattice_runs_build(lattice_origin(t0s, rr, t0_scale, t0_base), mp.step, mp.mask_words * 64 + 64,
-                                                                s_ks[threadIdx.x], s_bs[threadIdx.x], s_dd[threadIdx.x]) : 0;
-        }
+    if (mp.lattice_mode == PERF_LATTICE_REPEATED && sr.n > 0) {
+        if ((int)threadIdx.x < sr.n) { s_ks[0][threadIdx.x] = sr.ks[threadIdx.x]; s_bs[0][threadIdx.x] = sr.bs[threadIdx.x]; s_dd[0][threadIdx.x] = sr.dd[threadIdx.x]; }
         __syncthreads();
     }
     if (r >= n_rays) return;
@@ -266,8 +264,15 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
     const int wv = threadIdx.x >> 6;
     const int tab = sr.n > 0 ? 0 : wv;
     LatticeRuns lat;
-    lat.n = mp.lattice_mode == PERF_LATTICE_REPEATED ? (sr.n > 0 ? sr.n : s_n[wv]) : 0;
+    lat.n = 0;
     lat.ks = s_ks[tab]; lat.bs = s_bs[tab]; lat.dd = s_dd[tab]; lat.t0 = t0; lat.step = mp.step; lat.mode = mp.lattice_mode;
+    if (mp.lattice_mode == PERF_LATTICE_REPEATED) {
+        if (sr.n > 0) lat.n = sr.n;
+        else {
+            lat.n = lattice_runs_build(t0, mp.step, mp.mask_words * 64 + 64, s_ks[wv], s_bs[wv], s_dd[wv], lane == 0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     // the coarse skip is only valid while a chunk spans few enough fine cells (see coarse_build_kernel): checked per ray
     // with its own direction, so unnormalised directions fall back to the exhaustive test instead of skipping cells
     float span_cells = 0.f;
