@@ -74,6 +74,31 @@ def assign_levels(grid: GridConfig, world: int) -> List[List[int]]:
     return [sorted(h) for h in held]
 
 
+def exchange_volume(grid: GridConfig, world: int, n_per_rank: int, feat_bytes: int = 2, training: bool = False):
+    """Bytes a rank moves over xGMI for ONE encode of n_per_rank samples per rank through the level-sharded grid (and, with
+    training, for the transposed exchange of the fp32 feature gradients): per rank and PER LINK -- the exchange is an
+    all-gather of positions plus an all-to-all of features, every pair of GPUs has its own link, so a rank's traffic to
+    peer q uses link (rank, q) only.  -> dict(levels_per_rank, table_GiB_per_rank (16-bit), per_link_bytes_out [W][W],
+    per_rank_bytes_out, per_rank_bytes_in, worst_link_bytes)."""
+    assign = assign_levels(grid, world)
+    rows = [len(a) for a in assign]
+    link = [[0] * world for _ in range(world)]                # link[s][q]: bytes s sends to q
+    for s_ in range(world):
+        for q in range(world):
+            if q == s_:
+                continue
+            b = 12 * n_per_rank                               # positions of s's samples (all-gather)
+            b += rows[s_] * n_per_rank * 2 * feat_bytes       # features of q's samples at s's levels (all-to-all)
+            if training:
+                b += rows[q] * n_per_rank * 2 * 4             # fp32 gradients of s's samples at q's levels (transposed all-to-all)
+            link[s_][q] = b
+    out = [sum(r) for r in link]
+    inn = [sum(link[s_][q] for s_ in range(world)) for q in range(world)]
+    return {'levels_per_rank': assign, 'table_GiB_per_rank': [round(sum(int(grid.size[l]) for l in a) * 2 * feat_bytes / 2 ** 30, 3) for a in assign],
+            'per_link_bytes_out': link, 'per_rank_bytes_out': out, 'per_rank_bytes_in': inn,
+            'worst_link_bytes': max(max(r) for r in link) if world > 1 else 0}
+
+
 def _group():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

@@ -320,3 +320,24 @@ def test_sharded_exchange_world2_equals_the_single_process_step(tmp_path):
 
 def test_sharded_exchange_world2_with_lagged_units(tmp_path):
     _check_sharded_exchange(tmp_path, 'lagged')
+
+
+def test_level_shard_exchange_volume_for_config5():
+    """perf_amd.sharded.exchange_volume: the bytes per link of BASELINE config 5's level-sharded encode (DESIGN.md 5.3 quotes
+    them for 8 ranks): levels are split evenly, every rank sends every peer the same order of magnitude, and the totals follow
+    (W-1)/W x (12 + 4 L) bytes per sample for 16-bit features."""
+    from perf_amd.grid import GridConfig
+    from perf_amd.sharded import exchange_volume
+    L = 20
+    b = float(torch.exp(torch.log(torch.tensor(8192.0 / 16)) / (L - 1)))
+    grid = GridConfig(n_levels=L, log2_hashmap_size=30, base_resolution=16, per_level_scale=b)
+    n = 1 << 20
+    v = exchange_volume(grid, 8, n)
+    rows = [len(a) for a in v['levels_per_rank']]
+    assert sorted(l for a in v['levels_per_rank'] for l in a) == list(range(L)) and max(rows) - min(rows) <= 1
+    total = sum(v['per_rank_bytes_out'])
+    assert total == 8 * 7 * 12 * n + 7 * L * n * 4             # positions to 7 peers; every level's features of the other 7 ranks' samples leave their owner
+    assert abs(total / 8 / n - (7 * 12 + 7 * 4 * L / 8)) < 1e-9    # bytes a rank sends per sample of its own: 84 (positions) + 70 (features)
+    assert v['worst_link_bytes'] <= 12 * n + 3 * n * 4 and max(v['table_GiB_per_rank']) < 6.0
+    vt = exchange_volume(grid, 8, n, training=True)
+    assert sum(vt['per_rank_bytes_out']) == total + 7 * L * n * 8
