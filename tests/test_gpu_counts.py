@@ -527,15 +527,23 @@ def test_device_batch_draw(ops):
     assert int(r['indices'].min()) >= 70000 and int(r['indices'].max()) < n_pool and r['normal'] is None
 
 
-def test_device_rng_episode_graph_replay_equals_eager():
+@pytest.mark.parametrize('head', [2, None])
+def test_device_rng_episode_graph_replay_equals_eager(head):
     """A short episode with the device generator (the default): graph-replayed steps == eager steps, bit for bit (same seed,
-    same counter sequence), and the captured step holds no torch random op."""
+    same counter sequence), and the captured step holds no torch random op.  The replayed geometry steps are PIPELINED (the
+    next step's batch draw and marching run on a second stream beside the backward, NeRFScene.pipeline_marching) -- with the
+    two-phase sampler (head = 2: the counting pass writes the heads) and with the one-phase sampler bench.py uses; the serial
+    capture gives the same bits, and the draw of the batch nobody consumed at the end of the phase is taken back."""
     res = {}
-    for mode in ('eager', 'graph'):
+    for mode in ('eager', 'graph', 'graph_serial'):
         scene, pool, rays, dist, rgb = _room_scene(batch=1024)
-        assert scene.device_rng
-        scene.graph_steps = (mode == 'graph')
+        assert scene.device_rng and scene.pipeline_marching
+        scene.renderer.head_samples = head
+        scene.graph_steps = (mode != 'eager')
+        scene.pipeline_marching = (mode != 'graph_serial')
         scene.train_one_episode(pool, 12, 8)
+        assert scene._geo_pre is None
         res[mode] = (scene.nerf.geo_mlp.params.detach().clone(), scene.nerf.app_mlp.params.detach().clone(), int(scene._rng_counter.item()))
-    assert res['eager'][2] == res['graph'][2] == 20
-    assert torch.equal(res['eager'][0], res['graph'][0]) and torch.equal(res['eager'][1], res['graph'][1])
+    assert res['eager'][2] == res['graph'][2] == res['graph_serial'][2] == 20
+    for mode in ('graph', 'graph_serial'):
+        assert torch.equal(res['eager'][0], res[mode][0]) and torch.equal(res['eager'][1], res[mode][1]), mode
