@@ -454,8 +454,11 @@ class NeRFScene:
         # hipGraph-replayed geometry steps on one GPU: the batch draw and the marching of step k+1 -- nothing in them depends on
         # the field being trained -- are issued on a second stream beside the backward of step k (forked after the loss head,
         # joined behind Adam; the next batch lands in static buffers the following replay reads).  Same draws in the same
-        # order: parameters bit-identical to the serial step (tests/test_gpu_counts.py).
-        self.pipeline_marching = os.environ.get('PERF_PIPELINE_MARCHING', '1') != '0'
+        # order: parameters bit-identical to the serial step (tests/test_gpu_counts.py).  OFF by default: measured SLOWER --
+        # bench step 1.134 vs 1.084 ms, faithful geometry step 0.295 vs 0.268 ms, 40 vs 26 graph nodes
+        # (profiles/r04_pipeline_marching.json): the marching kernels take CUs from the 236 LDS-owner workgroups of the grid
+        # backward, and the copies into the static buffers cost what the overlap saves.
+        self.pipeline_marching = os.environ.get('PERF_PIPELINE_MARCHING', '0') == '1'
         self._after_loss_hook = None
 
     def _fixed_accum(self):

@@ -530,14 +530,14 @@ def test_device_batch_draw(ops):
 @pytest.mark.parametrize('head', [2, None])
 def test_device_rng_episode_graph_replay_equals_eager(head):
     """A short episode with the device generator (the default): graph-replayed steps == eager steps, bit for bit (same seed,
-    same counter sequence), and the captured step holds no torch random op.  The replayed geometry steps are PIPELINED (the
-    next step's batch draw and marching run on a second stream beside the backward, NeRFScene.pipeline_marching) -- with the
+    same counter sequence), and the captured step holds no torch random op.  Also with PIPELINED geometry steps (the next
+    step's batch draw and marching on a second stream beside the backward: NeRFScene.pipeline_marching, off by default) -- with the
     two-phase sampler (head = 2: the counting pass writes the heads) and with the one-phase sampler bench.py uses; the serial
     capture gives the same bits, and the draw of the batch nobody consumed at the end of the phase is taken back."""
     res = {}
     for mode in ('eager', 'graph', 'graph_serial'):
         scene, pool, rays, dist, rgb = _room_scene(batch=1024)
-        assert scene.device_rng and scene.pipeline_marching
+        assert scene.device_rng
         scene.renderer.head_samples = head
         scene.graph_steps = (mode != 'eager')
         scene.pipeline_marching = (mode != 'graph_serial')
