@@ -341,7 +341,14 @@ int perf_occ_pack_bits(const uint8_t* binaries, uint32_t* bits, int64_t n_cells,
 /* number of uint64 mask words per ray for max_steps lattice intervals */
 int64_t perf_occ_mask_words(int32_t max_steps);
 
-/* Pass 1: per ray, test lattice intervals k=0..max_steps-1 (t_k = fl(t0 + fl(k*step)), midpoint
+/* All rays of a launch on ONE lattice (t0 == NULL: eval renders have no stratified jitter): t_k, k = 0 ..
+ * perf_occ_lattice_table_len(max_steps) - 1, written once into a caller-owned device buffer; the four marching entry points
+ * take it as `lattice_table` (may be NULL) and read a lattice point with one load instead of walking the repeated-addition
+ * lattice (without it such launches use a table of runs built on the host; per-ray origins walk on the device). */
+int64_t perf_occ_lattice_table_len(int32_t max_steps);
+int perf_occ_lattice_table(float t0, float step, int32_t max_steps, int32_t lattice_mode, float* table, void* stream);
+
+/* Pass 1: per ray, test lattice intervals k=0..max_steps-1 (t_k on the lattice `lattice_mode`, midpoint
  * inside [max(tmin,t0), min(tmax,far)] and in an occupied cell); writes the keep bit masks
  * (masks [n_rays * mask_words]) and counts [n_rays].  aabb: 6 host floats.
  * Lattice origin of ray r (all four marching entry points): t0 == NULL: t0_base (the near plane); t0_scale == 0: t0[r];
@@ -350,7 +357,7 @@ int64_t perf_occ_mask_words(int32_t max_steps);
 int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
                          int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res,
                          const float* aabb, float far_plane, float step, int32_t max_steps, int32_t lattice_mode,
-                         uint64_t* masks, int32_t* counts, void* stream);
+                         const float* lattice_table, uint64_t* masks, int32_t* counts, void* stream);
 
 /* perf_occ_march_count that also WRITES the first head_k samples of every ray (the head of the two-phase sampler below):
  * rows r*head_k .. r*head_k + min(count, head_k) - 1 of arrays of n_rays*head_k rows get the same ray_indices / t_starts /
@@ -359,8 +366,8 @@ int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* 
  * perf_occ_march_write_points for the head.  head_k in [1, 64]. */
 int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
                               int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
-                              float far_plane, float step, int32_t max_steps, int32_t lattice_mode, uint64_t* masks, int32_t* counts,
-                              int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
+                              float far_plane, float step, int32_t max_steps, int32_t lattice_mode, const float* lattice_table,
+                              uint64_t* masks, int32_t* counts, int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
                               const float* points_aabb6, float* x01, uint8_t* sel, void* stream);
 
 /* Optional empty-space skip for perf_occ_march_count (what nerfacc's DDA traversal achieves): a dilated 4^3-block
@@ -379,7 +386,7 @@ int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t* total, int
 /* Pass 2: expand masks into packed samples sorted by ray then t.  packed_info [n_rays,2] =
  * (start,count) int32.  capacity = allocated length of the sample arrays. */
 int perf_occ_march_write(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps, int32_t lattice_mode,
-                         const uint64_t* masks, const int32_t* counts, const int32_t* offsets,
+                         const float* lattice_table, const uint64_t* masks, const int32_t* counts, const int32_t* offsets,
                          int64_t capacity, int64_t* ray_indices, float* t_starts, float* t_ends,
                          int32_t* packed_info, void* stream);
 
@@ -389,7 +396,7 @@ int perf_occ_march_write(const float* t0, float t0_scale, float t0_base, int64_t
  * written (rank = position among the ray's samples in t order; 0 with the march counts = everything) -- the two-phase
  * sampler below writes the first K samples of every ray first and the rest of the surviving rays later. */
 int perf_occ_march_write_points(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps, int32_t lattice_mode,
-                                const uint64_t* masks,
+                                const float* lattice_table, const uint64_t* masks,
                                 const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                 float* t_starts, float* t_ends, int32_t* packed_info, const float* rays_o,
                                 const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, int32_t rank_lo,

@@ -77,15 +77,17 @@ _SIGS = {
     'perf_occ_ema_update': (c_int, [P, P, c_int64, c_float, P, P]),
     'perf_occ_threshold': (c_int, [P, c_int64, P, c_float, P, P]),
     'perf_occ_mask_words': (c_int64, [c_int32]),
-    'perf_occ_march_count': (c_int, [P, P, P, c_float, c_float, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, c_int32, P, P, P]),
-    'perf_occ_march_count_head': (c_int, [P, P, P, c_float, c_float, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, c_int32, P, P,
+    'perf_occ_lattice_table_len': (c_int64, [c_int32]),
+    'perf_occ_lattice_table': (c_int, [c_float, c_float, c_int32, c_int32, P, P]),
+    'perf_occ_march_count': (c_int, [P, P, P, c_float, c_float, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, c_int32, P, P, P, P]),
+    'perf_occ_march_count_head': (c_int, [P, P, P, c_float, c_float, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, c_int32, P, P, P,
                                   c_int32, P, P, P, P, POINTER(c_float), P, P, P]),
     'perf_occ_coarse_words': (c_int64, [c_int32]),
     'perf_occ_build_coarse': (c_int, [P, c_int32, P, P]),
     'perf_scan_workspace_bytes': (c_int64, [c_int64]),
     'perf_exclusive_scan_i32': (c_int, [P, P, P, c_int64, c_int64, P, P, c_int64, P]),
-    'perf_occ_march_write': (c_int, [P, c_float, c_float, c_int64, c_float, c_int32, c_int32, P, P, P, c_int64, P, P, P, P, P]),
-    'perf_occ_march_write_points': (c_int, [P, c_float, c_float, c_int64, c_float, c_int32, c_int32, P, P, P, c_int64, P, P, P, P, P, P, POINTER(c_float), P, P, c_int32, P]),
+    'perf_occ_march_write': (c_int, [P, c_float, c_float, c_int64, c_float, c_int32, c_int32, P, P, P, P, c_int64, P, P, P, P, P]),
+    'perf_occ_march_write_points': (c_int, [P, c_float, c_float, c_int64, c_float, c_int32, c_int32, P, P, P, P, c_int64, P, P, P, P, P, P, POINTER(c_float), P, P, c_int32, P]),
     'perf_head_tail_counts': (c_int, [P, c_int64, c_int32, P, P, P]),
     'perf_visibility_count2': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_float, P, P]),
     'perf_compact_prefix2': (c_int, [P] * 14 + [c_int64, c_int64] + [P] * 7 + [P, c_int64, P, c_int64, P, c_int64, c_int32, P]),

@@ -179,6 +179,7 @@ struct LatticeRuns {
     int n;                       // > 0: table; <= 0: evaluate directly (single lattice, or a table that did not fit)
     const int32_t* ks; const uint32_t* bs; const uint32_t* dd;
     float t0, step; int mode;
+    const float* full;           // != NULL: t_k for every k of the launch (all rays on one lattice, perf_occ_lattice_table): one load
     __device__ __forceinline__ int find(int k) const {           // last run that starts at or before k
         int lo = 0, hi = n - 1;
         while (lo < hi) {
@@ -189,11 +190,13 @@ struct LatticeRuns {
     }
     __device__ __forceinline__ float at(int r, int k) const { return __uint_as_float(bs[r] + (uint32_t)(k - ks[r]) * dd[r]); }
     __device__ __forceinline__ float operator()(int k) const {
+        if (full) return full[k];
         if (n <= 0) return lattice(t0, k, step, mode);
         return at(find(k), k);
     }
     // a little further along the lattice than run r reaches: the next runs are tried before a search
     __device__ __forceinline__ float after(int& r, int k) const {
+        if (full) return full[k];
         if (n <= 0) return lattice(t0, k, step, mode);
         while (r + 1 < n && ks[r + 1] <= k) ++r;
         return at(r, k);
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                                                           int64_t n_rays, const uint32_t* __restrict__ bits,
                                                           const uint32_t* __restrict__ coarse,
                                                           uint64_t* __restrict__ masks, int32_t* __restrict__ counts, HeadOut ho,
-                                                          float t0_scale, float t0_base, SharedRuns sr) {
+                                                          float t0_scale, float t0_base, SharedRuns sr, const float* __restrict__ lat_full) {
     const int lane = threadIdx.x & 63;
     // (the ray index is wave uniform: saying so turns the loads of the ray's origin, direction and lattice origin into
     //  scalar loads -- seven vector-memory instructions per ray less; the kernel is bound by VMEM issue, not by bytes)
@@ -266,7 +269,8 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
     LatticeRuns lat;
     lat.n = 0;
     lat.ks = s_ks[tab]; lat.bs = s_bs[tab]; lat.dd = s_dd[tab]; lat.t0 = t0; lat.step = mp.step; lat.mode = mp.lattice_mode;
-    if (mp.lattice_mode == PERF_LATTICE_REPEATED) {
+    lat.full = lat_full;
+    if (mp.lattice_mode == PERF_LATTICE_REPEATED && !lat_full) {
         if (sr.n > 0) lat.n = sr.n;
         else {
             lat.n = lattice_runs_build(t0, mp.step, mp.mask_words * 64 + 64, s_ks[wv], s_bs[wv], s_dd[wv], lane == 0);
@@ -291,8 +295,8 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         bool maybe = false;
         if (q < mp.mask_words) {
             const int k0 = q * 64;
-            int run = lat.n > 0 ? lat.find(k0) : 0;
-            const float t_first = lat.n > 0 ? lat.at(run, k0) : lat(k0);
+            int run = (lat.n > 0 && !lat.full) ? lat.find(k0) : 0;
+            const float t_first = (lat.n > 0 && !lat.full) ? lat.at(run, k0) : lat(k0);
             const float t_mid = lat.after(run, k0 + 32), t_last = lat.after(run, k0 + 64);
             maybe = !(t_first > hi) && !(t_last < lo);
             if (maybe && use_coarse) {
@@ -387,7 +391,8 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                                                           float* __restrict__ te, int32_t* __restrict__ packed,
                                                           const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                           Aabb bb, float* __restrict__ x01, uint8_t* __restrict__ sel,
-                                                          int32_t rank_lo, float t0_scale, float t0_base, int lattice_mode, SharedRuns sr) {
+                                                          int32_t rank_lo, float t0_scale, float t0_base, int lattice_mode, SharedRuns sr,
+                                                          const float* __restrict__ lat_full) {
     // (all rays on one lattice -- eval renders --: the host-built table of runs, see march_count_kernel; per-ray origins walk)
     __shared__ int32_t w_ks[kMaxRuns];
     __shared__ uint32_t w_bs[kMaxRuns], w_dd[kMaxRuns];
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
         __syncthreads();
     }
     LatticeRuns tab;
-    tab.n = sr.n; tab.ks = w_ks; tab.bs = w_bs; tab.dd = w_dd; tab.t0 = 0.f; tab.step = step; tab.mode = lattice_mode;
+    tab.n = sr.n; tab.ks = w_ks; tab.bs = w_bs; tab.dd = w_dd; tab.t0 = 0.f; tab.step = step; tab.mode = lattice_mode; tab.full = lat_full;
     // Writes the samples of rank [rank_lo, rank_lo + counts[r]) of every ray (rank = position among the ray's samples in t
     // order) to offsets[r]...: rank_lo = 0 and counts = the march counts is the plain expansion; the two-phase sampler
     // writes the first K samples of every ray first and the rest of the rays that are still alive later.
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                     const int64_t pos = run + __popcll(m & below);
                     if (pos >= off && pos < end) {
                         const int k = qq * 64 + bit;
-                        const float a = tab.n > 0 ? tab.at(tab.find(k), k) : lattice(t0, k, step, lattice_mode);
+                        const float a = lat_full ? lat_full[k] : (tab.n > 0 ? tab.at(tab.find(k), k) : lattice(t0, k, step, lattice_mode));
                         const float b = lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, step) : lattice_single(t0, k + 1, step);
                         ts[pos] = a;
                         te[pos] = b;
@@ -615,8 +620,8 @@ extern "C" int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint
 
 static int march_count_launch(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base, int64_t n_rays,
                               const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb, float far_plane,
-                              float step, int32_t max_steps, int32_t lattice_mode, uint64_t* masks, int32_t* counts, const HeadOut* head,
-                              void* stream) {
+                              float step, int32_t max_steps, int32_t lattice_mode, const float* lattice_table, uint64_t* masks, int32_t* counts,
+                              const HeadOut* head, void* stream) {
     PERF_REQUIRE(lattice_mode == PERF_LATTICE_SINGLE || lattice_mode == PERF_LATTICE_REPEATED, "bad lattice mode %d", (int)lattice_mode);
     PERF_REQUIRE(n_rays >= 0 && res > 0 && res <= 1024 && max_steps > 0 && step > 0.f, "perf_occ_march_count: bad arguments");
     if (n_rays == 0) return PERF_OK;
@@ -632,13 +637,14 @@ static int march_count_launch(const float* rays_o, const float* rays_d, const fl
     mp.use_coarse = (occ_coarse != nullptr && (res % 8) == 0) ? 1 : 0;      // (+ the per-ray span test in the kernel)
     SharedRuns sr;
     sr.n = 0;
-    if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr) shared_runs_build(t0_base, step, mp.mask_words * 64 + 64, &sr);
+    PERF_REQUIRE(!lattice_table || t0 == nullptr, "a lattice table serves launches whose rays all start at t0_base (t0 == NULL)");
+    if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr && !lattice_table) shared_runs_build(t0_base, step, mp.mask_words * 64 + 64, &sr);
     if (head)
         hipLaunchKernelGGL(march_count_kernel<true>, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
-                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, *head, t0_scale, t0_base, sr);
+                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, *head, t0_scale, t0_base, sr, lattice_table);
     else
         hipLaunchKernelGGL(march_count_kernel<false>, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
-                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, HeadOut{}, t0_scale, t0_base, sr);
+                           rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, HeadOut{}, t0_scale, t0_base, sr, lattice_table);
     PERF_LAUNCH_CHECK("perf_occ_march_count");
     return PERF_OK;
 }
@@ -646,15 +652,15 @@ static int march_count_launch(const float* rays_o, const float* rays_d, const fl
 extern "C" int perf_occ_march_count(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
                                     int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res,
                                     const float* aabb, float far_plane, float step, int32_t max_steps, int32_t lattice_mode,
-                                    uint64_t* masks, int32_t* counts, void* stream) {
+                                    const float* lattice_table, uint64_t* masks, int32_t* counts, void* stream) {
     return march_count_launch(rays_o, rays_d, t0, t0_scale, t0_base, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps,
-                              lattice_mode, masks, counts, nullptr, stream);
+                              lattice_mode, lattice_table, masks, counts, nullptr, stream);
 }
 
 extern "C" int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const float* t0, float t0_scale, float t0_base,
                                          int64_t n_rays, const uint32_t* occ_bits, const uint32_t* occ_coarse, int32_t res, const float* aabb,
-                                         float far_plane, float step, int32_t max_steps, int32_t lattice_mode, uint64_t* masks,
-                                         int32_t* counts, int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
+                                         float far_plane, float step, int32_t max_steps, int32_t lattice_mode, const float* lattice_table,
+                                         uint64_t* masks, int32_t* counts, int32_t head_k, int64_t* ray_indices, float* t_starts, float* t_ends, int32_t* packed_info,
                                          const float* points_aabb6, float* x01, uint8_t* sel, void* stream) {
     PERF_REQUIRE(head_k >= 1 && head_k <= 64, "perf_occ_march_count_head: head_k must be in [1, 64]");
     PERF_REQUIRE(n_rays == 0 || (ray_indices && t_starts && t_ends && packed_info && points_aabb6 && x01 && sel), "NULL pointer");
@@ -663,7 +669,7 @@ extern "C" int perf_occ_march_count_head(const float* rays_o, const float* rays_
     ho.K = head_k; ho.ri = ray_indices; ho.ts = t_starts; ho.te = t_ends; ho.packed = packed_info; ho.x01 = x01; ho.sel = sel;
     if (n_rays > 0) for (int a = 0; a < 3; ++a) { ho.bb.lo[a] = points_aabb6[a]; ho.bb.hi[a] = points_aabb6[3 + a]; }
     return march_count_launch(rays_o, rays_d, t0, t0_scale, t0_base, n_rays, occ_bits, occ_coarse, res, aabb, far_plane, step, max_steps,
-                              lattice_mode, masks, counts, &ho, stream);
+                              lattice_mode, lattice_table, masks, counts, &ho, stream);
 }
 
 extern "C" int64_t perf_scan_workspace_bytes(int64_t n) { return (div_up(n > 0 ? n : 1, kScanBlock) + 1) * (int64_t)sizeof(int64_t); }
@@ -696,7 +702,7 @@ extern "C" int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t*
 }
 
 extern "C" int perf_occ_march_write(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps,
-                                    int32_t lattice_mode, const uint64_t* masks,
+                                    int32_t lattice_mode, const float* lattice_table, const uint64_t* masks,
                                     const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                     float* t_starts, float* t_ends, int32_t* packed_info, void* stream) {
     PERF_REQUIRE(n_rays >= 0 && max_steps > 0 && capacity >= 0, "perf_occ_march_write: bad arguments");
@@ -705,16 +711,17 @@ extern "C" int perf_occ_march_write(const float* t0, float t0_scale, float t0_ba
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends), "NULL sample arrays");
     SharedRuns sr;
     sr.n = 0;
-    if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr) shared_runs_build(t0_base, step, chunk_words(max_steps) * 64 + 64, &sr);
+    PERF_REQUIRE(!lattice_table || t0 == nullptr, "a lattice table serves launches whose rays all start at t0_base (t0 == NULL)");
+    if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr && !lattice_table) shared_runs_build(t0_base, step, chunk_words(max_steps) * 64 + 64, &sr);
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0, t0_scale, t0_base, (int)lattice_mode, sr);
+                       t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0, t0_scale, t0_base, (int)lattice_mode, sr, lattice_table);
     PERF_LAUNCH_CHECK("perf_occ_march_write");
     return PERF_OK;
 }
 
 extern "C" int perf_occ_march_write_points(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps,
-                                           int32_t lattice_mode, const uint64_t* masks,
+                                           int32_t lattice_mode, const float* lattice_table, const uint64_t* masks,
                                            const int32_t* counts, const int32_t* offsets, int64_t capacity, int64_t* ray_indices,
                                            float* t_starts, float* t_ends, int32_t* packed_info, const float* rays_o,
                                            const float* rays_d, const float* aabb6, float* x01, uint8_t* sel, int32_t rank_lo,
@@ -727,10 +734,33 @@ extern "C" int perf_occ_march_write_points(const float* t0, float t0_scale, floa
     for (int k = 0; k < 3; ++k) { bb.lo[k] = aabb6[k]; bb.hi[k] = aabb6[3 + k]; }
     SharedRuns sr;
     sr.n = 0;
-    if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr) shared_runs_build(t0_base, step, chunk_words(max_steps) * 64 + 64, &sr);
+    PERF_REQUIRE(!lattice_table || t0 == nullptr, "a lattice table serves launches whose rays all start at t0_base (t0 == NULL)");
+    if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr && !lattice_table) shared_runs_build(t0_base, step, chunk_words(max_steps) * 64 + 64, &sr);
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
-                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo, t0_scale, t0_base, (int)lattice_mode, sr);
+                       t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo, t0_scale, t0_base, (int)lattice_mode, sr, lattice_table);
     PERF_LAUNCH_CHECK("perf_occ_march_write_points");
+    return PERF_OK;
+}
+
+// t_k, k = 0 .. n-1, of the lattice that starts at t0 -- for launches whose rays all share it (eval renders: no stratified jitter).
+// The marching entry points take the table as `lattice_table`: a lattice point is then ONE load instead of a walk (repeated
+// addition) -- a 512x1024 eval frame marches 0.5 M rays on the same 3,000 points.
+namespace perf {
+__global__ __launch_bounds__(256) void lattice_table_kernel(float t0, float step, int32_t n, int mode, float* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) out[k] = lattice(t0, k, step, mode);
+}
+}  // namespace perf
+
+extern "C" int64_t perf_occ_lattice_table_len(int32_t max_steps) { return (int64_t)chunk_words(max_steps) * 64 + 66; }
+
+extern "C" int perf_occ_lattice_table(float t0, float step, int32_t max_steps, int32_t lattice_mode, float* table, void* stream) {
+    PERF_REQUIRE(table && max_steps > 0 && step > 0.f, "perf_occ_lattice_table: bad arguments");
+    PERF_REQUIRE(lattice_mode == PERF_LATTICE_SINGLE || lattice_mode == PERF_LATTICE_REPEATED, "bad lattice mode %d", (int)lattice_mode);
+    const int32_t n = (int32_t)perf_occ_lattice_table_len(max_steps);
+    hipLaunchKernelGGL(perf::lattice_table_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, as_stream(stream), t0, step, n,
+                       (int)lattice_mode, table);
+    PERF_LAUNCH_CHECK("perf_occ_lattice_table");
     return PERF_OK;
 }

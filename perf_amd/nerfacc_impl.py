@@ -104,6 +104,11 @@ def _sig_feat(res):
     return sig.reshape(-1).float().contiguous(), feat
 
 
+def _lib_default_lattice():
+    from . import _lib
+    return _lib.DEFAULT_LATTICE
+
+
 class Samples:
     """Packed samples of one ray batch (see OccGridEstimator.sampling_ex)."""
     __slots__ = ('ray_indices', 't_starts', 't_ends', 'packed', 'sig', 'x01', 'sel', 'n_dev', 'n_marched_dev', 'feat')
@@ -222,6 +227,9 @@ class OccGridEstimator(nn.Module):
             t0 = (None, 0.0, float(near_plane)) if anchor is None else anchor
         if max_steps is None:
             max_steps = int(math.ceil(span / render_step_size)) + 1
+        if isinstance(t0, tuple) and t0[0] is None:
+            # every ray on the same lattice (no jitter): its points are computed once and read by the kernels with one load
+            t0 = t0 + (self._shared_lattice(float(near_plane), float(render_step_size), int(max_steps), lattice, dev),)
         res = self._res
         compacts = (sigma_fn is not None or sigma_points_fn is not None) and early_stop_eps > 0
         sm = Samples()
@@ -277,6 +285,18 @@ class OccGridEstimator(nn.Module):
         ri._perf_packed = packed
         sm.ray_indices, sm.t_starts, sm.t_ends, sm.packed, sm.sig, sm.x01, sm.sel = ri, ts, te, packed, sig, x01, sel
         return sm
+
+    def _shared_lattice(self, t0_base, step, max_steps, lattice, device):
+        """The precomputed lattice table of jitter-free launches (ops.lattice_table), memoised per (origin, step, steps, lattice).
+        (Created outside a capture when possible: a table first made INSIDE a captured render belongs to that graph's pool.)"""
+        key = (t0_base, step, max_steps, lattice or _lib_default_lattice(), str(device))
+        cache = self.__dict__.setdefault('_lattice_tables', {})
+        tab = cache.get(key)
+        if tab is None:
+            tab = ops.lattice_table(t0_base, step, max_steps, lattice, device)
+            if not torch.cuda.is_current_stream_capturing():
+                cache[key] = tab
+        return tab
 
     STRIDED_HEAD_MAX = 16          # heads of up to this many samples are written by the counting pass, K rows per ray
 

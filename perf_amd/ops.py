@@ -471,11 +471,28 @@ def occ_build_coarse(occ_bits, res):
 
 def _origin(t0):
     """Lattice-origin argument of the marching entry points -> (pointer, t0_scale, t0_base).  t0: a float32 tensor [R] (origins
-    as given), or a tuple (u, scale, base): u = stratified draws [R] or None; origin = u * scale (+ base), resp. base."""
+    as given), or a tuple (u, scale, base[, table]): u = stratified draws [R] or None; origin = u * scale (+ base), resp. base."""
     if isinstance(t0, tuple):
-        u, scale, base = t0
+        u, scale, base = t0[:3]
         return (_p(_f32(u, 't0')) if u is not None else None), float(scale if u is not None else 0.0), float(base)
     return _p(_f32(t0, 't0')), 0.0, 0.0
+
+
+def _lat_table(t0):
+    """The precomputed lattice of a launch whose rays all start at the same origin: t0 = (None, scale, base, table) -- see
+    lattice_table(); None otherwise."""
+    if isinstance(t0, tuple) and len(t0) > 3 and t0[0] is None and t0[3] is not None:
+        return _p(_f32(t0[3], 'lattice_table'))
+    return None
+
+
+def lattice_table(t0_base, step, max_steps, lattice=None, device='cuda'):
+    """t_k of the lattice that starts at t0_base, for every k a marching launch of `max_steps` intervals can ask for
+    (perf_occ_lattice_table) -- pass it as the fourth element of a (None, 0.0, t0_base, table) origin."""
+    n = _lib.load().perf_occ_lattice_table_len(int(max_steps))
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    _call('perf_occ_lattice_table', float(t0_base), float(step), int(max_steps), _lib.LATTICE[lattice], _p(out), _stream())
+    return out
 
 
 def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, max_steps, occ_coarse=None, lattice=None):
@@ -487,7 +504,7 @@ def occ_march_count(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, step, ma
     counts = torch.empty(R, dtype=torch.int32, device=dev)
     _call('perf_occ_march_count', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), *_origin(t0), R,
           _p(occ_bits), _p(occ_coarse), int(res), _aabb6(aabb), float(far_plane), float(step), int(max_steps), _lib.LATTICE[lattice],
-          _p(masks), _p(counts), _stream())
+          _lat_table(t0), _p(masks), _p(counts), _stream())
     return masks, counts
 
 
@@ -509,7 +526,7 @@ def occ_march_count_head(rays_o, rays_d, t0, occ_bits, res, aabb, far_plane, ste
     sel = torch.empty(S, dtype=torch.uint8, device=dev)
     _call('perf_occ_march_count_head', _p(_f32(rays_o, 'rays_o')), _p(_f32(rays_d, 'rays_d')), *_origin(t0), R,
           _p(occ_bits), _p(occ_coarse), int(res), _aabb6(aabb), float(far_plane), float(step), int(max_steps), _lib.LATTICE[lattice],
-          _p(masks), _p(counts), int(head_k), _p(ri), _p(ts), _p(te), _p(packed), _aabb6(points_aabb), _p(x01), _p(sel), _stream())
+          _lat_table(t0), _p(masks), _p(counts), int(head_k), _p(ri), _p(ts), _p(te), _p(packed), _aabb6(points_aabb), _p(x01), _p(sel), _stream())
     return masks, counts, (ri, ts, te, packed, x01, sel)
 
 
@@ -526,12 +543,12 @@ def occ_march_write(t0, masks, counts, offsets, S, step, max_steps, rays_o=None,
     if points_aabb is not None:
         x01 = torch.empty(S, 3, dtype=torch.float32, device=dev)
         sel = torch.empty(S, dtype=torch.uint8, device=dev)
-        _call('perf_occ_march_write_points', *_origin(t0), R, float(step), int(max_steps), _lib.LATTICE[lattice], _p(masks), _p(counts), _p(offsets), S,
+        _call('perf_occ_march_write_points', *_origin(t0), R, float(step), int(max_steps), _lib.LATTICE[lattice], _lat_table(t0), _p(masks), _p(counts), _p(offsets), S,
               _p(ri), _p(ts), _p(te), _p(packed), _p(rays_o), _p(rays_d), _aabb6(points_aabb), _p(x01), _p(sel), int(rank_lo), _stream())
         return ri, ts, te, packed, x01, sel
     if rank_lo != 0:
         raise _lib.PerfError('rank_lo needs points_aabb (perf_occ_march_write_points)')
-    _call('perf_occ_march_write', *_origin(t0), R, float(step), int(max_steps), _lib.LATTICE[lattice], _p(masks), _p(counts), _p(offsets), S,
+    _call('perf_occ_march_write', *_origin(t0), R, float(step), int(max_steps), _lib.LATTICE[lattice], _lat_table(t0), _p(masks), _p(counts), _p(offsets), S,
           _p(ri), _p(ts), _p(te), _p(packed), _stream())
     return ri, ts, te, packed
 
