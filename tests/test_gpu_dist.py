@@ -162,6 +162,13 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line['strong']['scaling'] == 'strong' and line['strong']['global_batch_rays'] == 1024 and line['strong']['value'] > 0
     assert line['strong']['rays_per_gpu_per_step'] == 512
     assert line['psnr'] is not None and line['health'] == {'skipped_for_overflow': 0, 'skipped_for_truncation': 0}
+    # the `comm` block a reader attributes a missed scaling target with: per-collective times of the sharded exchange, the plain
+    # single-GPU step on the same per-rank workload, the difference, and the single all-reduce exchange for comparison
+    comm = line['comm']
+    assert set(comm['ms_per_step_per_collective']) == {'reduce_scatter', 'all_reduce_small', 'all_gather_w16'} and comm['bytes']['units'] == 'lagged'
+    assert comm['single_rank_step_ms'] > 0 and abs(comm['exposed_comm_ms'] - (line['ms_per_step'] - comm['single_rank_step_ms'])) < 1e-9
+    assert comm['other_exchange']['dp_mode'] == 'allreduce' and comm['other_exchange']['value'] > 0
+    assert line['faithful'] is None or 'geo_ms_per_step' in line['faithful']
 
 
 @pytest.mark.parametrize('n_levels,log2_t', [(16, 18), (20, 20)])

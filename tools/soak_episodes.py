@@ -49,7 +49,8 @@ for ep in range(args.episodes):
     digest = hashlib.sha256(scene.nerf.geo_mlp.params.detach().cpu().numpy().tobytes() + scene.nerf.app_mlp.params.detach().cpu().numpy().tobytes()).hexdigest()[:16]
     rows.append({'episode': ep, 'params_sha256_16': digest, 'seconds': round(t1 - t0, 3), 'psnr_dB': round(psnr(out['rgb'], rgb), 3),
                  'mean_abs_distance_err': round(float((out['distance'] - dist).abs().mean()), 5),
-                 'skipped_for_overflow': int(c[4]), 'skipped_for_truncation': int(c[5]), 'grid_gradient_mode': tcnn.GRID_GRAD_ACCUM,
+                 'skipped_for_overflow': int(c[4]), 'skipped_for_truncation': int(c[5]), 'grid_gradient_mode': scene.nerf.app_mlp.grid_grad_accum,
+                 'fp32_repairs_app_net': scene.nerf.app_mlp.fp32_redo_count(),
                  'sample_capacity': scene.renderer.sample_capacity, 'mem_alloc_MB': round(torch.cuda.memory_allocated() / 2 ** 20, 1),
                  'mem_reserved_MB': round(torch.cuda.memory_reserved() / 2 ** 20, 1)})
     print(json.dumps(rows[-1]), flush=True)
