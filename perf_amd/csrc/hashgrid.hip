@@ -491,6 +491,7 @@ __device__ __forceinline__ int fixed_point_shift(const float am, const int64_t n
 // step: a soak of 25 episodes with the band at [2^23, 2^27] (4x) lost 8 of 112,500 steps to flags that were not
 // overflows -- the colour table's largest sum quadrupling from one batch to the next (tools/soak_episodes.py).
 constexpr int kHeadroomTopBit = 25, kHeadroomLowBit = 21;
+constexpr int kLaggedMinHeadroom = 12;     // (dp_units_kernel, lagged units)
 __device__ __forceinline__ int headroom_feedback(int adj, int fm) {
     if (fm >= (1 << kHeadroomTopBit)) adj += (32 - __clz(fm)) - kHeadroomTopBit + 1;
     else if (fm < (1 << kHeadroomLowBit) && adj > -24) adj -= 1;
@@ -1444,9 +1445,23 @@ __global__ void dp_units_kernel(GridParams gp, const int32_t* __restrict__ stats
         fm = max(fm, st[PERF_MAX_LEVELS + l]);
     }
     if (fm >= 0) hr_state[l] = headroom_feedback(hr_state[l], fm);        // (-1: no previous call, nothing to feed back)
-    // margin_bits: units derived from the PREVIOUS step's statistics (lagged mode, see perf_dp_slot_pack) are made that many
-    // bits coarser -- room for the step-to-step growth of max |dfeat| the lag cannot see
-    shifts[l] = fixed_point_shift(am, total_s, gp.size[l], hr_state, l) - margin_bits;
+    // margin_bits > 0: the units come from the PREVIOUS step's statistics (lagged mode, see perf_dp_slot_pack).  The closed loop
+    // lets the headroom h of a level sink to 4 bits where an entry's contributions cancel (late in a phase the gradient is
+    // noise): ONE contribution of a sample whose |dfeat| is 2^(h-2) times last step's maximum then reaches the flag level --
+    // |dfeat| is heavy tailed, and a two-episode soak with h as the exact units have it lost 33 of 9,000 steps to such
+    // outliers (tools/exp/dp_lag_diag.py: sporadic, in the second half of the geometry phase).  Lagged units therefore keep at
+    // least kLaggedMinHeadroom bits (a single contribution needs 2^11 times last step's maximum to flag; the unit stays below
+    // 2^-18 of that maximum) and add margin_bits on top.
+    int sh = fixed_point_shift(am, total_s, gp.size[l], hr_state, l);
+    if (margin_bits > 0) {
+        int e = 0;
+        if (am > 0.f) (void)frexpf(am, &e);
+        if (e < -80) e = -80;
+        int h = 31 - e - sh;
+        if (h < kLaggedMinHeadroom) h = kLaggedMinHeadroom;
+        sh = 31 - e - (h + margin_bits);
+    }
+    shifts[l] = sh;
 }
 
 // ---- the small all-reduce of a data-parallel step: one slot of PERF_DP_SLOT floats per rank behind the MLP weight gradient ----
