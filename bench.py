@@ -70,8 +70,8 @@ def parse():
                     help='scaling mode of the HEADLINE value at N > 1 (the other mode is reported beside it): weak = --rays-per-gpu '
                          'rays on every GPU; strong = that many rays in total, split over the GPUs')
     ap.add_argument('--strict-two-evaluations', action='store_true',
-                    help='headline with the density field ENCODED twice per kept sample like the reference (default: the gradient pass '
-                         'starts from the features the sampling pass encoded -- bit-identical parameters; the strict line is reported beside it)')
+                    help='headline with the density field ENCODED AND EVALUATED twice per kept sample like the reference (default: the gradient pass '
+                         'starts from the features and densities the sampling pass computed -- bit-identical parameters; the strict line is reported beside it)')
     ap.add_argument('--dp-mode', default='sharded', choices=['sharded', 'allreduce'], help='gradient exchange at N > 1 (perf_amd/dp.py)')
     ap.add_argument('--watchdog-seconds', type=float, default=240.0,
                     help='N > 1: if the optional measurements after the eager headline (graph-captured step, strong scaling, PSNR episode) '
@@ -602,8 +602,8 @@ def main():
     reuse_block = None
     if args.mode == 'train_geo' and not args.no_prepass and not args.no_reuse_line and world == 1:
         _, alt = measure(not reuse_default, args.scaling)
-        reuse_block = dict(alt, what=('strict reference order: the kept samples are encoded a second time for the gradient pass'
-                                      if reuse_default else 'gradient pass starts from the features the sampling pass encoded')
+        reuse_block = dict(alt, what=('strict reference order: the kept samples are encoded and their density evaluated a second time for the gradient pass'
+                                      if reuse_default else 'gradient pass starts from the features and densities the sampling pass computed')
                                      + '; parameters bit-identical to the headline path')
 
     other_block = None
@@ -758,7 +758,7 @@ def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other
                                f'hash grid L16/F2/T18 + 64-wide MLPs, mode={args.mode}, '
                                + ('reference step incl. sampling-pass sigma + visibility compaction (early stop 1e-4)' if r.early_stop_eps > 0
                                   else 'fixed-count WITHOUT sampling-pass sigma / compaction (early_stop_eps = 0)')
-                               + ('; the gradient pass of the density field starts from the features the sampling pass encoded' if reuse else ''),
+                               + ('; the gradient pass of the density field starts from the features (and densities) the sampling pass computed' if reuse else ''),
                    'rays_per_gpu_per_step': head['rays_per_gpu_per_step'], 'marched_samples_per_gpu_per_step': head['marched_samples_per_gpu_per_step'],
                    'kept_samples_per_gpu_per_step': head['kept_samples_per_gpu_per_step'],
                    'counted': 'kept samples (device counter, read once after the timed region); the no-grad density pass over all marched samples is extra work',

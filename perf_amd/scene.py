@@ -423,8 +423,8 @@ class NeRFScene:
         # The reference's geometry step evaluates the density field twice on the kept samples: without gradient inside
         # OccGridEstimator.sampling and with gradient in the renderer (nerf_renderer.py:145-148, :166-168) -- same parameters,
         # same positions.  True (sync-free mode): the encoded features of the sampler's pass are compacted along with the
-        # samples and the gradient pass starts from them instead of encoding again: bit-identical parameters
-        # (tests/test_gpu_counts.py), one encode fewer.  On by default; False is the strict two-encode order of the reference
+        # samples -- together with the densities computed from them -- and the gradient pass starts from those instead of
+        # encoding and evaluating again: bit-identical parameters (tests/test_gpu_counts.py), one encode and one MLP forward fewer.  On by default; False is the strict two-encode order of the reference
         # (bench.py reports both).
         self.reuse_sampling_features = True
         self._geo_pre = None
@@ -955,9 +955,16 @@ class NeRFScene:
         n_net = geo.mlp.n_params
         w16 = geo.working_copy()
         feat = st.get('feat0')
-        if feat is None:
-            feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:], n_dev=n_dev)
-        sig = ops.mlp_fwd(geo.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
+        if feat is not None and st.get('sig0') is not None:
+            # reuse_sampling_features: the sampler's density pass left the kept samples' features AND the densities it computed
+            # from them (compacted together).  The gradient pass would compute the very same numbers -- same kernel, same
+            # weights, same features, sample by sample -- and the MLP backward recomputes its forward in registers anyway:
+            # the second forward launch is dropped (bit-identical parameters, tests/test_gpu_counts.py).
+            sig = st['sig0'].reshape(-1, 1)
+        else:
+            if feat is None:
+                feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:], n_dev=n_dev)
+            sig = ops.mlp_fwd(geo.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
         # The colour render of this step (query key 'rgb', nerf.py:197-201) feeds no loss term (:208-252).  Under data
         # parallelism it is therefore issued AFTER the gradient all-reduce has been launched: the colour field's encode +
         # MLP + accumulation run on the compute stream while RCCL moves the gradient over xGMI on its own stream.
