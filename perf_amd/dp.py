@@ -119,6 +119,7 @@ class ShardedExchange:
         self.job_flags = z(2, torch.float32)                       # {overflow, truncated} summed over the ranks
         self.have_prev = False                                     # a previous step left field maxima (exact mode) ...
         self.have_units = False                                    # ... and units for the next one (lagged mode)
+        self._live = (None, 0)
         self.ar = z(n_net + DP_SLOT * world, torch.float32)        # [MLP weight gradient | one slot per rank]
         self.w16_slice = z(2 * self.per, w16_dtype)
         self.w16_full = z(n_net + 2 * self.per * world, w16_dtype)  # [MLP | table (+ padding)]: the network's working copy
@@ -154,7 +155,7 @@ class ShardedExchange:
         """The units of this step's grid backward (self.shifts).  Lagged mode with a previous step: they are there already
         (derived at the end of that step), nothing is exchanged.  Otherwise: statistics all-gather -> job-wide units."""
         self.level_absmax.copy_(level_absmax)
-        self._n_dev, self._n = n_dev, n
+        self._live = (n_dev, n)                 # this step's live-sample count: travels in the slot (reduce_and_step)
         if self.units == 'lagged' and self.have_units:
             if overlap is not None:
                 overlap()
@@ -184,8 +185,8 @@ class ShardedExchange:
         self.k.unfix(self.shard, self.lo, self.hi, self.shifts, self.field_max, flag)      # (ORs the slice's flag into `flag`)
         self.have_prev = True
         self.ar[:n_net].copy_(dw)
-        self.k.slot_pack(self.level_absmax, self.field_max, getattr(self, '_n_dev', None), getattr(self, '_n', 0), flag, n_marched,
-                         capacity, self.rank, self.world, self.ar[n_net:])
+        n_dev, n = self._live
+        self.k.slot_pack(self.level_absmax, self.field_max, n_dev, n, flag, n_marched, capacity, self.rank, self.world, self.ar[n_net:])
         self._timed('all_reduce_small', lambda sync: self.coll.all_reduce(self.ar))
         lagged = self.units == 'lagged'
         self.k.slot_unpack(self.ar[n_net:], self.world, self.stats_all if lagged else None, self.job_flags, self.n_total)
