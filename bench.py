@@ -147,7 +147,7 @@ def psnr_at_iters(args, dev, dist_mod, rank, world, start_dense=None):
     torch.manual_seed(0)
     scene = NeRFScene(dtype=args.dtype)
     scene.dp_mode, scene.comm_dtype = args.dp_mode, args.comm_dtype
-    scene.count_graph_nodes = True
+    scene.count_graph_nodes = world == 1 and not os.environ.get('PERF_DP_SINGLE_RANK')      # (graphs that hold RCCL collectives are left alone)
     rays = gen_pano_rays(torch.eye(4), args.height, args.width, device=dev)
     dist_map, rgb_map = synthetic.room(rays.d)
     pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb_map, dist_map)
