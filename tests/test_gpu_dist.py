@@ -77,6 +77,32 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_run_bit_for_bit(tmp_p
     assert two['counters'][4] == 0 and two['counters'][5] == 0                  # nothing overflowed, nothing was truncated
 
 
+def test_eight_ranks_on_one_gpu_sharded_exchange(tmp_path):
+    """The world size the scaling run uses: EIGHT ranks (sharing this box's one GPU over gloo) through the sharded exchange with
+    exact units -- slices of 415,076 table entries per rank, 128 rays per rank of the 1,024-ray global batch -- reproduce the
+    single process's table gradient bit for bit, hold identical parameters on every rank after three steps of each network, and
+    skip the all-empty step alike."""
+    one = _run(1, str(tmp_path / 'w1.pt'), 0)
+    eight = _run(8, str(tmp_path / 'w8.pt'), _free_port())
+    others = [torch.load(str(tmp_path / 'w8.pt') + f'.{r}') for r in range(1, 8)]
+    assert eight['world'] == 8 and eight['geo_steps'] == one['geo_steps'] == 3 and eight['empty_batch_skipped']
+    for key, n_net in (('geo', 3072), ('app', 7168)):
+        ranks = [eight] + others
+        bounds = [r[key + '_slice'] for r in ranks]
+        assert bounds[0][0] == 0 and all(bounds[i][1] == bounds[i + 1][0] for i in range(7)) and 2 * bounds[7][1] == one['g_' + key].numel() - n_net
+        table, ref = torch.cat([r['g_' + key][n_net:] for r in ranks]), one['g_' + key][n_net:]
+        if key == 'geo':                  # the first geometry step starts from identical parameters: integer sums, to the bit
+            assert torch.equal(table, ref)
+        else:                             # the colour field's first step follows three geometry steps (fp32-rounding apart)
+            assert float((table - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    for r in others:
+        assert torch.equal(r['geo'], eight['geo']) and torch.equal(r['app'], eight['app'])
+    for k in ('geo', 'app'):
+        moved = float((one[k] - one[k + '0']).norm())
+        assert float((eight[k] - one[k]).norm()) < 0.02 * moved, (k, float((eight[k] - one[k]).norm()), moved)
+    assert eight['counters'][4] == 0 and eight['counters'][5] == 0
+
+
 def test_two_ranks_with_lagged_units(tmp_path):
     """The default exchange: the units of step t come from the statistics of step t-1 (no collective between the MLP backward
     and the grid backward), one bit coarser.  The first step has nothing to lag behind and takes the exact path -- its summed
