@@ -141,6 +141,12 @@ __device__ __forceinline__ float act_bwd(float y, float g, int act, float shift)
     return g;
 }
 
+// Features and their gradient are level-major: element (level, sample) at level * n + sample.  A lane's level is
+// (a compile-time part) + (its half h) * const, so the address is a UNIFORM base per access plus ONE 32-bit lane offset per
+// tile -- the saddr + voffset form of global_load / global_store -- instead of a 64-bit multiply-add and a branch per level
+// (which was more than half of the kernel's vector instructions).  Holds while the offsets fit 32 bits.
+constexpr int64_t kMaxFastStride = (int64_t)1 << 27;
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -191,6 +197,16 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16
                         if (fz.feat_out) fz.feat_out[(int64_t)level * n + si] = pair;
                     }
                     b1[s][i] = pair;
+                }
+        } else if (n <= kMaxFastStride && mp.n_levels == 8 * KS) {      // (uniform) see kMaxFastStride; lanes past the end
+            // compute on the LAST sample's features (finite values, results discarded) rather than on zeros
+            const uint32_t off = 4u * (uint32_t)((valid ? si : n_live - 1) + (int64_t)h * n);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned char* base = reinterpret_cast<const unsigned char*>(feat) + (int64_t)(8 * s + 2 * i) * n * 4;
+                    b1[s][i] = *reinterpret_cast<const uint32_t*>(base + off);
                 }
         } else {
 #pragma unroll
@@ -279,7 +295,33 @@ __device__ __forceinline__ void pack_masked(const f32x16& acc, uint32_t mask_bit
     }
 }
 
-template <typename T16, int NH, int KS>
+// The same two steps with the ReLU mask of the LAST hidden layer held as sixteen predicates: an i1 that stays live is a wave
+// mask in an SGPR pair -- one v_cmp writes it, one v_cndmask reads it -- where the packed per-lane bit field costs a compare, a
+// select and an or to build and an and, a compare and a select to apply (six vector instructions per element instead of two;
+// the mask of the layer before lives too long for the scalar file and stays a bit field).
+template <typename T16>
+__device__ __forceinline__ void relu_pack_pred(const f32x16& acc, u32x4& lo, u32x4& hi, bool* pos) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pos[r] = acc[r] > 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] = T16::pack(relu(acc[2 * i]), relu(acc[2 * i + 1]));
+        hi[i] = T16::pack(relu(acc[8 + 2 * i]), relu(acc[8 + 2 * i + 1]));
+    }
+}
+
+template <typename T16>
+__device__ __forceinline__ void pack_pred(const f32x16& acc, const bool* pos, u32x4& lo, u32x4& hi) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] = T16::pack(pos[2 * i] ? acc[2 * i] : 0.f, pos[2 * i + 1] ? acc[2 * i + 1] : 0.f);
+        hi[i] = T16::pack(pos[8 + 2 * i] ? acc[8 + 2 * i] : 0.f, pos[8 + 2 * i + 1] ? acc[8 + 2 * i + 1] : 0.f);
+    }
+}
+
+// FAST (chosen by the launcher): every level slot of the first layer is a real level (n_levels == 8 * KS) and the level-major
+// offsets fit 32 bits -- the addressing above, and a FIXED number of loads per request (below).
+template <typename T16, int NH, int KS, bool FAST>
 __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
                                                       const uint32_t* __restrict__ feat,
                                                       const uint8_t* __restrict__ sel,
@@ -300,35 +342,75 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
     const int64_t n_tiles = (n_live + kTile - 1) / kTile;
 
     constexpr int MB = L::MB;       // blocks of 32 input features (2 for grids of more than 16 levels)
-    f32x16 gW1[2 * MB], gWo[2], gW2[NH == 2 ? 4 : 1];
+    // dWo is 16 x 64: four 16x16x32 products (ONE k-step covers the tile's 32 samples) in 16 accumulator registers; as two
+    // 32x32x16 tiles half of 32 registers held the zero rows 16..31
+    f32x16 gW1[2 * MB], gW2[NH == 2 ? 4 : 1];
+    f32x4 gWo[4];
 #pragma unroll
     for (int m = 0; m < 2 * MB; ++m) gW1[m] = f32x16{0};
 #pragma unroll
-    for (int m = 0; m < 2; ++m) gWo[m] = f32x16{0};
+    for (int m = 0; m < 4; ++m) gWo[m] = f32x4{0};
 #pragma unroll
     for (int m = 0; m < (NH == 2 ? 4 : 1); ++m) gW2[m] = f32x16{0};
 
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    // One tile AHEAD: the inputs of the next tile (features, upstream gradient, selector) are requested before this tile's
+    // work and, above all, before this tile's dfeat stores.  Loads and stores retire through ONE in-order counter, so a load
+    // issued behind the stores is only known to have landed once they are acknowledged: the chain per tile was
+    // store-acknowledge + load + compute; now it is compute.  What makes the compiler's s_waitcnt exact rather than "everything":
+    // a request is UNCONDITIONAL and issues the same number of loads on every path (clamped indices instead of predicates, a
+    // dummy byte when there is no selector), nothing is computed from a requested value before its tile's turn, and the two
+    // register sets alternate (a copy at the end of the iteration would wait for the loads it copies).
+    struct TileIn { u32x4 b1[KS]; float g[8]; uint8_t sv; };
+    const int64_t last_tile = n_tiles - 1;
+    auto request = [&](int64_t tile_unclamped, TileIn& t) {
+        const int64_t tile = tile_unclamped < last_tile ? tile_unclamped : last_tile;     // past the end: re-read the last tile
+        const int64_t si = tile * kTile + c;
+        const bool valid = si < n_live;
+        const int64_t sc = valid ? si : n_live - 1;      // lanes past the end read the LAST sample: finite values, zero dY
+        if constexpr (FAST) {
+            const uint32_t off = 4u * (uint32_t)(sc + (int64_t)h * n);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned char* base = reinterpret_cast<const unsigned char*>(feat) + (int64_t)(8 * s + 2 * i) * n * 4;
+                    t.b1[s][i] = *reinterpret_cast<const uint32_t*>(base + off);
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int level = 8 * s + 2 * i + h;
+                    t.b1[s][i] = (valid && level < mp.n_levels) ? feat[(int64_t)level * n + si] : 0u;
+                }
+        }
+        const float* drow = dout + sc * mp.n_out;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {                    // RAW values: any arithmetic here would wait for the load
+            const int row = d_row(r, h);
+            t.g[r] = drow[row < mp.n_out ? row : mp.n_out - 1];
+        }
+        t.sv = *(sel ? sel + sc : reinterpret_cast<const uint8_t*>(drow));
+    };
+    auto process = [&](int64_t tile, const TileIn& cur) __attribute__((always_inline)) {
         const int64_t si = tile * kTile + c;
         const bool valid = si < n_live;
         // ---- recompute forward
         u32x4 b1[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int level = 8 * s + 2 * i + h;
-                b1[s][i] = (valid && level < mp.n_levels) ? feat[(int64_t)level * n + si] : 0u;
-            }
+        for (int s = 0; s < KS; ++s) b1[s] = cur.b1[s];
         f32x16 acc[2];
         u32x4 hb1[4], hb2[4];
-        uint32_t mask1 = 0, mask2 = 0;
+        uint32_t mask1 = 0;
+        bool pos[32];               // ReLU mask of the last hidden layer (wave masks)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             acc[m] = f32x16{0};
 #pragma unroll
             for (int s = 0; s < KS; ++s) acc[m] = T16::mfma(frag[(L::f_a1 + m * KS + s) * 64 + lane], b1[s], acc[m]);
-            relu_pack<T16>(acc[m], hb1[2 * m], hb1[2 * m + 1], mask1, 16 * m);
+            if constexpr (NH == 2) relu_pack<T16>(acc[m], hb1[2 * m], hb1[2 * m + 1], mask1, 16 * m);
+            else relu_pack_pred<T16>(acc[m], hb1[2 * m], hb1[2 * m + 1], pos + 16 * m);
         }
         if constexpr (NH == 2) {
 #pragma unroll
@@ -336,17 +418,16 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
                 acc[m] = f32x16{0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc[m] = T16::mfma(frag[(L::f_a2 + m * 4 + s) * 64 + lane], hb1[s], acc[m]);
-                relu_pack<T16>(acc[m], hb2[2 * m], hb2[2 * m + 1], mask2, 16 * m);
+                relu_pack_pred<T16>(acc[m], hb2[2 * m], hb2[2 * m + 1], pos + 16 * m);
             }
         }
         const u32x4* hlast = (NH == 2) ? hb2 : hb1;
-        const uint32_t mask_last = (NH == 2) ? mask2 : mask1;
         f32x16 o = f32x16{0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) o = T16::mfma(frag[(L::f_ao + s) * 64 + lane], hlast[s], o);
         // ---- output gradient (activation derivative and selector applied here)
         float dy[8];
-        const float sv = (valid && sel) ? (float)sel[si] : (valid ? 1.0f : 0.0f);
+        const float sv = sel ? (float)cur.sv : 1.0f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) dy[r] = 0.f;
         {
@@ -355,7 +436,7 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
                 for (int r = 0; r < 8; ++r) {
                     if (d_row(r, 0) >= mp.n_out) break;
                     const int row = d_row(r, h);
-                    if (valid && row < mp.n_out) dy[r] = dact(o[r], dout[si * mp.n_out + row] * sv);
+                    if (valid && row < mp.n_out) dy[r] = dact(o[r], cur.g[r] * sv);
                 }
             };
             if (mp.out_act == PERF_ACT_SIGMOID) emit([](float y, float g) { const float s_ = 1.0f / (1.0f + expf(-y)); return g * s_ * (1.0f - s_); });
@@ -370,7 +451,7 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             f32x16 d = T16::mfma(frag[(L::f_aot + m) * 64 + lane], dyb, f32x16{0});
-            pack_masked<T16>(d, mask_last, 16 * m, dhl[2 * m], dhl[2 * m + 1]);
+            pack_pred<T16>(d, pos + 16 * m, dhl[2 * m], dhl[2 * m + 1]);
         }
         // ---- weight gradient of the output layer: dWo[16 x 64] += dY * Hlast^T
         __builtin_amdgcn_wave_barrier();
@@ -381,11 +462,12 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
         }
         lds_put_hidden(tB, hlast, c, h);
         __builtin_amdgcn_wave_barrier();
+        {   // operands of the 16x16x32 form: lane (row lane & 15, k-block lane >> 4) holds samples 8 * (lane >> 4) .. + 7
+            const int r16 = lane & 15, kb = lane >> 4;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(tA + r16 * kPitch + 8 * kb);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x4 a = (c < 16) ? lds_get_frag(tA, c, s, h) : u32x4{0, 0, 0, 0};
-#pragma unroll
-            for (int nn = 0; nn < 2; ++nn) gWo[nn] = T16::mfma(a, lds_get_frag(tB, 32 * nn + c, s, h), gWo[nn]);
+            for (int nb = 0; nb < 4; ++nb)
+                gWo[nb] = T16::mfma16(a, *reinterpret_cast<const u32x4*>(tB + (16 * nb + r16) * kPitch + 8 * kb), gWo[nb]);
         }
         u32x4 dh1[4];
         if constexpr (NH == 2) {
@@ -422,9 +504,18 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
                 f32x16 dx = f32x16{0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) dx = T16::mfma(frag[(L::f_a1t + 4 * mb + s) * 64 + lane], dh1[s], dx);
-                if (valid) {
+                if (valid && FAST && 16 * mb + 16 <= mp.n_levels) {
+                    // register pair (2q,2q+1) -> level 16*mb + d_row(2q,h)/2 = 16*mb + 4*(q>>1) + (q&1) + 2*h: all real levels
+                    const uint32_t off = 8u * (uint32_t)(si + (int64_t)(2 * h) * n);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {      // register pair (2q,2q+1) -> level 16*mb + d_row(2q,h)/2
+                    for (int q = 0; q < 8; ++q) {
+                        unsigned char* base = reinterpret_cast<unsigned char*>(dfeat) + (int64_t)(16 * mb + 4 * (q >> 1) + (q & 1)) * n * 8;
+                        *reinterpret_cast<float2*>(base + off) = make_float2(dx[2 * q], dx[2 * q + 1]);
+                        amax = fmaxf(amax, fmaxf(fabsf(dx[2 * q]), fabsf(dx[2 * q + 1])));
+                    }
+                } else if (valid) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
                         const int level = 16 * mb + (d_row(2 * q, h) >> 1);
                         if (level < mp.n_levels) {
                             dfeat[(int64_t)level * n + si] = make_float2(dx[2 * q], dx[2 * q + 1]);
@@ -454,6 +545,22 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
 #pragma unroll
                 for (int m = 0; m < 2; ++m) gW1[m * MB + nb] = T16::mfma(lds_get_frag(tA, 32 * m + c, s, h), b, gW1[m * MB + nb]);
             }
+    };
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < n_tiles) {
+        TileIn ta, tb;
+        request(tile, ta);
+        for (;;) {
+            request(tile + tile_step, tb);
+            process(tile, ta);
+            tile += tile_step;
+            if (tile >= n_tiles) break;
+            request(tile + tile_step, ta);
+            process(tile, tb);
+            tile += tile_step;
+            if (tile >= n_tiles) break;
+        }
     }
     // ---- per-level max |dfeat| (feeds the fixed-point scale of the grid backward): lanes of one half-wave hold the
     //      same 8 levels, non-negative floats order like their bit patterns
@@ -468,7 +575,7 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
     constexpr int kW1 = 2 * MB;
-    constexpr int kAcc = kW1 + 2 + (NH == 2 ? 4 : 0);        // f32x16 accumulators per lane
+    constexpr int kAcc = kW1 + 1 + (NH == 2 ? 4 : 0);        // accumulators per lane, in units of 16 registers
     for (int src = 1; src < 4; ++src) {
         if (wave == src) {
 #pragma unroll
@@ -476,14 +583,14 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
 #pragma unroll
                 for (int r = 0; r < 16; ++r) red[((m) * 16 + r) * 64 + lane] = gW1[m][r];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[((kW1 + m) * 16 + r) * 64 + lane] = gWo[m][r];
+                for (int r = 0; r < 4; ++r) red[(kW1 * 16 + 4 * m + r) * 64 + lane] = gWo[m][r];
             if constexpr (NH == 2) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) red[((kW1 + 2 + m) * 16 + r) * 64 + lane] = gW2[m][r];
+                    for (int r = 0; r < 16; ++r) red[((kW1 + 1 + m) * 16 + r) * 64 + lane] = gW2[m][r];
             }
         }
         __syncthreads();
@@ -493,14 +600,14 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gW1[m][r] += red[((m) * 16 + r) * 64 + lane];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) gWo[m][r] += red[((kW1 + m) * 16 + r) * 64 + lane];
+                for (int r = 0; r < 4; ++r) gWo[m][r] += red[(kW1 * 16 + 4 * m + r) * 64 + lane];
             if constexpr (NH == 2) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) gW2[m][r] += red[((kW1 + 2 + m) * 16 + r) * 64 + lane];
+                    for (int r = 0; r < 16; ++r) gW2[m][r] += red[((kW1 + 1 + m) * 16 + r) * 64 + lane];
             }
         }
         __syncthreads();
@@ -527,12 +634,9 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
                     p[L::w2_off + (32 * m + d_row(r, h)) * 64 + 32 * nn + c] = gW2[2 * m + nn][r];
     }
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
+    for (int nb = 0; nb < 4; ++nb)            // 16x16 result: row = 4 * (lane >> 4) + register, column = lane & 15
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = d_row(r, h);
-            if (row < 16) p[L::wo_off + row * 64 + 32 * nn + c] = gWo[nn][r];
-        }
+        for (int r = 0; r < 4; ++r) p[L::wo_off + (4 * (lane >> 4) + r) * 64 + 16 * nb + (lane & 15)] = gWo[nb][r];
 }
 
 // dw[i] = sum_k partials[k][i] (fixed order: deterministic), combined through LDS
@@ -643,10 +747,15 @@ static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t*
     constexpr int lds_bytes = Layout<NH, KS>::n_all * 1024 + 4 * 2 * 64 * kPitch * 2;
     static std::once_flag attr_once;            // (one flag per template instance) safe under concurrent callers
     std::call_once(attr_once, []() {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<T16, NH, KS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<T16, NH, KS, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<T16, NH, KS, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     });
-    mlp_bwd_kernel<T16, NH, KS><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, level_absmax, n, n_dev);
+    if (n <= kMaxFastStride && mp.n_levels == 8 * KS)
+        mlp_bwd_kernel<T16, NH, KS, true><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, level_absmax, n, n_dev);
+    else
+        mlp_bwd_kernel<T16, NH, KS, false><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, level_absmax, n, n_dev);
 }
 
 template <typename T16, typename... Args>
