@@ -178,45 +178,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (n_live + kTile - 1) / kTile;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-        const int64_t si = tile * kTile + c;
-        const bool valid = si < n_live;
-        u32x4 b1[KS];
-        if constexpr (FUSED) {
-            const bool smooth = fz.gp.interpolation == PERF_INTERP_SMOOTHSTEP;
-            float x = 0.5f, y = 0.5f, z = 0.5f;
-            if (valid) { x = fz.x01[3 * si]; y = fz.x01[3 * si + 1]; z = fz.x01[3 * si + 2]; }
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int level = 8 * s + 2 * i + h;
-                    uint32_t pair = 0u;
-                    if (valid && level < mp.n_levels) {
-                        pair = encode_pair<T16>(fz.gp, fz.table, level, x, y, z, smooth);
-                        if (fz.feat_out) fz.feat_out[(int64_t)level * n + si] = pair;
-                    }
-                    b1[s][i] = pair;
-                }
-        } else if (n <= kMaxFastStride && mp.n_levels == 8 * KS) {      // (uniform) see kMaxFastStride; lanes past the end
-            // compute on the LAST sample's features (finite values, results discarded) rather than on zeros
-            const uint32_t off = 4u * (uint32_t)((valid ? si : n_live - 1) + (int64_t)h * n);
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned char* base = reinterpret_cast<const unsigned char*>(feat) + (int64_t)(8 * s + 2 * i) * n * 4;
-                    b1[s][i] = *reinterpret_cast<const uint32_t*>(base + off);
-                }
-        } else {
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int level = 8 * s + 2 * i + h;
-                    b1[s][i] = (valid && level < mp.n_levels) ? feat[(int64_t)level * n + si] : 0u;
-                }
-        }
+    struct TileIn { u32x4 b1[KS]; uint8_t sv; };
+    // the layers and the store of one tile, given the packed first-layer operand
+    auto layers = [&](int64_t si, bool valid, const u32x4 (&b1)[KS], float sv) __attribute__((always_inline)) {
         f32x16 acc[2];
         uint32_t mask_unused = 0;
         u32x4 hb[4];
@@ -243,11 +207,16 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16
 #pragma unroll
         for (int s = 0; s < 4; ++s) o = T16::mfma(frag[(L::f_ao + s) * 64 + lane], hb[s], o);
         if (valid) {
-            const float sv = sel ? (float)sel[si] : 1.0f;
             // the activation is a kernel argument: branch on it ONCE (scalar), and stop at the last register that can hold
             // a real output row (rows of register r: d_row(r, 0) < d_row(r, 1)) -- otherwise both exponentials are
             // evaluated for all 8 registers and selected afterwards (~250 vector instructions per tile)
             auto emit = [&](auto act) {
+                if (mp.n_out == 16 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {   // registers 0..3 / 4..7 are rows 4h..4h+3 / 8+4h..: two 16-byte stores
+                    float* row0 = out + si * 16 + 4 * h;
+                    *reinterpret_cast<float4*>(row0) = make_float4(act(o[0]) * sv, act(o[1]) * sv, act(o[2]) * sv, act(o[3]) * sv);
+                    *reinterpret_cast<float4*>(row0 + 8) = make_float4(act(o[4]) * sv, act(o[5]) * sv, act(o[6]) * sv, act(o[7]) * sv);
+                    return;
+                }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     if (d_row(r, 0) >= mp.n_out) break;
@@ -258,6 +227,81 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16
             if (mp.out_act == PERF_ACT_SIGMOID) emit([](float y) { return 1.0f / (1.0f + expf(-y)); });
             else if (mp.out_act == PERF_ACT_EXP) emit([&](float y) { return expf(y - mp.exp_shift); });
             else emit([](float y) { return y; });
+        }
+    };
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if constexpr (FUSED) {
+        const bool smooth = fz.gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+        for (; tile < n_tiles; tile += tile_step) {
+            const int64_t si = tile * kTile + c;
+            const bool valid = si < n_live;
+            u32x4 b1[KS];
+            float x = 0.5f, y = 0.5f, z = 0.5f;
+            if (valid) { x = fz.x01[3 * si]; y = fz.x01[3 * si + 1]; z = fz.x01[3 * si + 2]; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int level = 8 * s + 2 * i + h;
+                    uint32_t pair = 0u;
+                    if (valid && level < mp.n_levels) {
+                        pair = encode_pair<T16>(fz.gp, fz.table, level, x, y, z, smooth);
+                        if (fz.feat_out) fz.feat_out[(int64_t)level * n + si] = pair;
+                    }
+                    b1[s][i] = pair;
+                }
+            layers(si, valid, b1, (valid && sel) ? (float)sel[si] : 1.0f);
+        }
+    } else if (n <= kMaxFastStride && mp.n_levels == 8 * KS) {      // (uniform) see kMaxFastStride
+        // one tile ahead on alternating register sets, as in mlp_bwd_kernel: a request is unconditional, issues a fixed number
+        // of loads and computes nothing from them; lanes past the end work on the LAST sample's features (finite values,
+        // results discarded) rather than on zeros
+        if (tile >= n_tiles) return;
+        const int64_t last_tile = n_tiles - 1;
+        auto request = [&](int64_t tile_unclamped, TileIn& t) {
+            const int64_t tl = tile_unclamped < last_tile ? tile_unclamped : last_tile;
+            const int64_t si = tl * kTile + c;
+            const int64_t sc = si < n_live ? si : n_live - 1;
+            const uint32_t off = 4u * (uint32_t)(sc + (int64_t)h * n);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned char* base = reinterpret_cast<const unsigned char*>(feat) + (int64_t)(8 * s + 2 * i) * n * 4;
+                    t.b1[s][i] = *reinterpret_cast<const uint32_t*>(base + off);
+                }
+            t.sv = *(sel ? sel + sc : reinterpret_cast<const uint8_t*>(feat));
+        };
+        auto process = [&](int64_t tl, const TileIn& t) __attribute__((always_inline)) {
+            const int64_t si = tl * kTile + c;
+            layers(si, si < n_live, t.b1, sel ? (float)t.sv : 1.0f);
+        };
+        TileIn ta, tb;
+        request(tile, ta);
+        for (;;) {
+            request(tile + tile_step, tb);
+            process(tile, ta);
+            tile += tile_step;
+            if (tile >= n_tiles) break;
+            request(tile + tile_step, ta);
+            process(tile, tb);
+            tile += tile_step;
+            if (tile >= n_tiles) break;
+        }
+    } else {
+        for (; tile < n_tiles; tile += tile_step) {
+            const int64_t si = tile * kTile + c;
+            const bool valid = si < n_live;
+            u32x4 b1[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int level = 8 * s + 2 * i + h;
+                    b1[s][i] = (valid && level < mp.n_levels) ? feat[(int64_t)level * n + si] : 0u;
+                }
+            layers(si, valid, b1, (valid && sel) ? (float)sel[si] : 1.0f);
         }
     }
 }
