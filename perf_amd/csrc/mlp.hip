@@ -65,46 +65,59 @@ __device__ __forceinline__ u32x4 pack8(const uint16_t v[8]) {
     return r;
 }
 
-// Stage permuted weight fragments into LDS: frag f occupies lds[f*64 + lane] (16 B per lane).
+// Element of the weight vector that slot j of lane (c, h) of fragment f holds, or -1 for a zero.
+template <int NH, int KS>
+__device__ __forceinline__ int frag_src(int f, int c, int h, int j) {
+    using L = Layout<NH, KS>;
+    if (f < L::f_a2) {                           // A1[m][s]: row = neuron 32m+c, slot -> input feature
+        const int m = (f - L::f_a1) / KS, s = (f - L::f_a1) % KS;
+        return L::w1_off + (32 * m + c) * L::n_in_pad + 2 * (8 * s + 2 * (j >> 1) + h) + (j & 1);
+    }
+    if (f < L::f_ao) {                           // A2[m][s]
+        const int m = (f - L::f_a2) >> 2, s = (f - L::f_a2) & 3;
+        return L::w2_off + (32 * m + c) * 64 + slot_neuron(s, h, j);
+    }
+    if (f < L::n_fwd)                            // Ao[s]: rows 0..15 = output layer, 16..31 zero
+        return (c < 16) ? L::wo_off + c * 64 + slot_neuron(f - L::f_ao, h, j) : -1;
+    if (f < L::f_a2t)                            // AoT[m]: row = neuron 32m+c, slot (h,j) -> output row d_row(j,h)
+        return L::wo_off + d_row(j, h) * 64 + 32 * (f - L::f_aot) + c;
+    if (f < L::f_a1t) {                          // A2T[m][s]: row = input neuron 32m+c, slot -> output neuron
+        const int m = (f - L::f_a2t) >> 2, s = (f - L::f_a2t) & 3;
+        return L::w2_off + slot_neuron(s, h, j) * 64 + 32 * m + c;
+    }
+    const int mb = (f - L::f_a1t) >> 2, s = (f - L::f_a1t) & 3;      // A1T[mb][s]: row = input feature 32*mb + c, slot -> neuron
+    const int in = 32 * mb + c;
+    return (in < L::n_in_pad) ? L::w1_off + slot_neuron(s, h, j) * L::n_in_pad + in : -1;
+}
+
+// Stage permuted weight fragments into LDS: frag f occupies lds[f*64 + lane] (16 B per lane).  The elements of ALL of a wave's
+// fragments are requested before any is packed: one memory round trip per block instead of one per fragment.
 template <int NH, int KS, bool BWD>
 __device__ __forceinline__ void stage_fragments(const uint16_t* __restrict__ w, u32x4* lds) {
     using L = Layout<NH, KS>;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;     // (blocks of four waves)
     const int c = lane & 31, h = lane >> 5;
-    const int nf = BWD ? L::n_all : L::n_fwd;
-    for (int f = wave; f < nf; f += nw) {
-        uint16_t v[8];
-        if (f < L::f_a2) {                       // A1[m][s]: row = neuron 32m+c, slot -> input feature
-            const int m = (f - L::f_a1) / KS, s = (f - L::f_a1) % KS;
+    constexpr int nf = BWD ? L::n_all : L::n_fwd;
+    constexpr int per_wave = (nf + 3) / 4;
+    uint16_t v[per_wave][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int col = 2 * (8 * s + 2 * (j >> 1) + h) + (j & 1);
-                v[j] = w[L::w1_off + (32 * m + c) * L::n_in_pad + col];
-            }
-        } else if (f < L::f_ao) {                // A2[m][s]
-            const int m = (f - L::f_a2) >> 2, s = (f - L::f_a2) & 3;
+    for (int k = 0; k < per_wave; ++k) {
+        const int f = wave + 4 * k < nf ? wave + 4 * k : nf - 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = w[L::w2_off + (32 * m + c) * 64 + slot_neuron(s, h, j)];
-        } else if (f < L::n_fwd) {               // Ao[s]: rows 0..15 = output layer, 16..31 zero
-            const int s = f - L::f_ao;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (c < 16) ? w[L::wo_off + c * 64 + slot_neuron(s, h, j)] : (uint16_t)0;
-        } else if (f < L::f_a2t) {               // AoT[m]: row = neuron 32m+c, slot (h,j) -> output row d_row(j,h)
-            const int m = f - L::f_aot;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = w[L::wo_off + d_row(j, h) * 64 + 32 * m + c];
-        } else if (f < L::f_a1t) {               // A2T[m][s]: row = input neuron 32m+c, slot -> output neuron
-            const int m = (f - L::f_a2t) >> 2, s = (f - L::f_a2t) & 3;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = w[L::w2_off + slot_neuron(s, h, j) * 64 + 32 * m + c];
-        } else {                                 // A1T[mb][s]: row = input feature 32*mb + c, slot -> neuron
-            const int mb = (f - L::f_a1t) >> 2, s = (f - L::f_a1t) & 3;
-            const int in = 32 * mb + c;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                v[j] = (in < L::n_in_pad) ? w[L::w1_off + slot_neuron(s, h, j) * L::n_in_pad + in] : (uint16_t)0;
+        for (int j = 0; j < 8; ++j) {
+            const int src = frag_src<NH, KS>(f, c, h, j);
+            v[k][j] = w[src < 0 ? 0 : src];
         }
-        lds[f * 64 + lane] = pack8(v);
+    }
+#pragma unroll
+    for (int k = 0; k < per_wave; ++k) {
+        const int f = wave + 4 * k;
+        if (f < nf) {
+            uint16_t z[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = frag_src<NH, KS>(f, c, h, j) < 0 ? (uint16_t)0 : v[k][j];
+            lds[f * 64 + lane] = pack8(z);
+        }
     }
 }
 
@@ -437,9 +450,13 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
         }
         t.sv = *(sel ? sel + sc : reinterpret_cast<const uint8_t*>(drow));
     };
-    auto process = [&](int64_t tile, const TileIn& cur) __attribute__((always_inline)) {
+    // FULL (a tag type): all 32 samples of the tile are live -- every tile but possibly the last; the loop below handles FULL tiles
+    // only, so that (with FAST) a tile's eight dfeat stores are unconditional and the counter arithmetic above stays exact:
+    // the wait for a tile's inputs then lets the stores of the tile before and the next request stay in flight.
+    auto process = [&](auto full_tag, int64_t tile, const TileIn& cur) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const int64_t si = tile * kTile + c;
-        const bool valid = si < n_live;
+        const bool valid = FULL || si < n_live;
         // ---- recompute forward
         u32x4 b1[KS];
 #pragma unroll
@@ -542,13 +559,13 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
             for (int s = 0; s < 4; ++s) dh1[s] = dhl[s];
         }
         // ---- dX = W1^T dH1 (rows = input features in natural order 2*level+feat)
-        if (dfeat != nullptr) {
+        if (FAST || dfeat != nullptr) {         // (the launcher sends a call without dfeat to the kernel without FAST)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 f32x16 dx = f32x16{0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) dx = T16::mfma(frag[(L::f_a1t + 4 * mb + s) * 64 + lane], dh1[s], dx);
-                if (valid && FAST && 16 * mb + 16 <= mp.n_levels) {
+                if (FAST && 16 * mb + 16 <= 8 * KS && valid) {
                     // register pair (2q,2q+1) -> level 16*mb + d_row(2q,h)/2 = 16*mb + 4*(q>>1) + (q&1) + 2*h: all real levels
                     const uint32_t off = 8u * (uint32_t)(si + (int64_t)(2 * h) * n);
 #pragma unroll
@@ -592,19 +609,27 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
     };
     const int64_t tile_step = (int64_t)gridDim.x * 4;
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    if (tile < n_tiles) {
-        TileIn ta, tb;
+    const int64_t n_full = n_live / kTile;            // tiles without a lane past the end
+    TileIn ta, tb;
+    if (tile < n_full) {
+        // (the first tile is peeled so that the loop is entered, like its back edge, with one request and one tile's stores in flight)
         request(tile, ta);
-        for (;;) {
-            request(tile + tile_step, tb);
-            process(tile, ta);
-            tile += tile_step;
-            if (tile >= n_tiles) break;
+        request(tile + tile_step, tb);
+        process(std::true_type{}, tile, ta);
+        tile += tile_step;
+        while (tile < n_full) {
             request(tile + tile_step, ta);
-            process(tile, tb);
+            process(std::true_type{}, tile, tb);
             tile += tile_step;
-            if (tile >= n_tiles) break;
+            if (tile >= n_full) break;
+            request(tile + tile_step, tb);
+            process(std::true_type{}, tile, ta);
+            tile += tile_step;
         }
+    }
+    if (tile == n_full && n_full < n_tiles) {         // the ragged last tile, on the wave whose turn it is
+        request(tile, ta);
+        process(std::false_type{}, tile, ta);
     }
     // ---- per-level max |dfeat| (feeds the fixed-point scale of the grid backward): lanes of one half-wave hold the
     //      same 8 levels, non-negative floats order like their bit patterns
@@ -796,7 +821,7 @@ static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t*
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<T16, NH, KS, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     });
-    if (n <= kMaxFastStride && mp.n_levels == 8 * KS)
+    if (n <= kMaxFastStride && mp.n_levels == 8 * KS && dfeat != nullptr)
         mlp_bwd_kernel<T16, NH, KS, true><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, level_absmax, n, n_dev);
     else
         mlp_bwd_kernel<T16, NH, KS, false><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, level_absmax, n, n_dev);

@@ -218,6 +218,40 @@ def test_mlp_bwd(ops, dt, nh, n_out, act):
     assert close(dw.cpu(), wr.grad, 16), ((dw.cpu() - wr.grad).abs().max(), wr.grad.abs().max())
 
 
+@pytest.mark.parametrize('nh,n_out,act,n_levels,n,with_sel', [
+    (1, 16, 'None', 16, 300_000 + 17, True),     # the geometry step's network; every wave goes round its two input sets > 4 times
+    (2, 3, 'Sigmoid', 16, 150_000 + 1, False),   # the colour network, no selector (the request reads a dummy byte)
+    (1, 16, 'None', 8, 4000 + 3, True),          # one k-step: scalar-base loads, per-level stores
+    (1, 1, 'Exponential', 16, 40, False),        # two tiles: most waves have none
+    (2, 16, 'None', 16, 1, True)])               # one sample
+def test_mlp_tiles_ahead(ops, nh, n_out, act, n_levels, n, with_sel):
+    """mlp_fwd / mlp_bwd request a tile's inputs one tile ahead on alternating register sets, re-reading the last tile (and its last
+    sample) where there is nothing to request: same bars as test_mlp_fwd / test_mlp_bwd at the sizes that exercise that."""
+    dt = 'bf16'
+    cfgm, w, feat, sel, tdt, ulp = _mlp_case(ops, dt, nh, n_out, act, n=n, n_levels=n_levels, seed=21)
+    if not with_sel:
+        sel = torch.ones(n, dtype=torch.uint8)
+    sel_dev = sel.cuda() if with_sel else None
+    w16 = w.to(tdt); f16 = feat.to(tdt)
+    out = ops.mlp_fwd(cfgm, w16.cuda(), f16.cuda(), sel_dev).cpu()
+    ref = _mlp_oracle(cfgm, w16.float(), f16.float(), sel, dt)
+    assert (out - ref).abs().max() < 8 * ulp * max(1.0, float(ref.abs().max()))
+    g = torch.Generator().manual_seed(22)
+    dout = torch.randn(n, n_out, generator=g)
+    dfeat, dw, amax = ops.mlp_bwd(cfgm, w16.cuda(), f16.cuda(), dout.cuda(), sel_dev, want_absmax=True)
+    wr = w16.float().requires_grad_(True)
+    fr = f16.float().requires_grad_(True)
+    (_mlp_oracle(cfgm, wr, fr, sel, dt) * dout).sum().backward()
+
+    def close(a, b, k):
+        return (a - b).abs().max() <= k * ulp * float(b.abs().max()) + 1e-6
+    assert close(dfeat.cpu(), fr.grad, 16), ((dfeat.cpu() - fr.grad).abs().max(), fr.grad.abs().max())
+    # dW sums n products rounded to 16 bits each: the bound grows like sqrt(n) rounding errors of the largest product
+    k = 16 * max(1.0, math.sqrt(n / 2000.0))
+    assert close(dw.cpu(), wr.grad, k), ((dw.cpu() - wr.grad).abs().max(), wr.grad.abs().max())
+    assert float(amax.max()) == float(dfeat.abs().max())
+
+
 @pytest.mark.parametrize('dt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('nh,n_out,act,n_levels', [(1, 1, 'Exponential', 20), (2, 3, 'Sigmoid', 20), (1, 1, 'None', 24), (2, 16, 'None', 17)])
 def test_mlp_more_than_16_levels(ops, dt, nh, n_out, act, n_levels):
