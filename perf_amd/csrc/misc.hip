@@ -120,9 +120,18 @@ __global__ __launch_bounds__(256) void occ_pack_kernel(const uint8_t* __restrict
     const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (wi * 32 >= n_cells) return;
     uint32_t word = 0;
-    for (int k = 0; k < 32; ++k) {
-        const int64_t c = wi * 32 + k;
-        if (c < n_cells && b[c]) word |= 1u << k;
+    if (wi * 32 + 32 <= n_cells && (reinterpret_cast<uintptr_t>(b) & 15) == 0) {      // 32 cells = two 16-byte loads
+        const uint4 lo = *reinterpret_cast<const uint4*>(b + wi * 32), hi = *reinterpret_cast<const uint4*>(b + wi * 32 + 16);
+        const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) word |= ((q[k] >> (8 * j)) & 0xffu) ? 1u << (4 * k + j) : 0u;
+    } else {
+        for (int k = 0; k < 32; ++k) {
+            const int64_t c = wi * 32 + k;
+            if (c < n_cells && b[c]) word |= 1u << k;
+        }
     }
     bits[wi] = word;
 }
@@ -286,35 +295,50 @@ __global__ void step_bookkeeping_kernel(int32_t* step_dev, const int64_t* gate_d
                                         const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
                                         int32_t* overflow_flag, const float* remote_flags, int overflow_redone, int64_t* eff_gate_out,
                                         const float* schedule, int32_t n_schedule, int32_t* iter_dev, float* lr_out, float* ratio_out) {
-    if (schedule && iter_dev && n_schedule > 0) {
-        // device-side schedule: row i = {learning rate of iteration i, distortion-loss ramp of iteration i}.  This launch sits
-        // between the backward and Adam of iteration `it`: Adam reads lr(it) next, the loss head of iteration it + 1 reads
-        // ratio(it + 1) -- a graph replay then needs no host-side scalar update at all
-        const int it = iter_dev[0];
-        const int cur = it < n_schedule ? it : n_schedule - 1, nxt = it + 1 < n_schedule ? it + 1 : n_schedule - 1;
-        if (lr_out) lr_out[0] = schedule[2 * cur];
-        if (ratio_out) ratio_out[0] = schedule[2 * nxt + 1];
-        iter_dev[0] = it + 1;
-    }
+    // every input is READ before anything is written (the pointers may alias as far as the compiler knows: interleaved, each
+    // load waits for the store before it and the one thread walks a dozen round trips one after the other)
+    const bool sched = schedule && iter_dev && n_schedule > 0;
+    const int it = sched ? iter_dev[0] : 0;
     const int64_t marched = n_marched_dev ? n_marched_dev[0] : 0;
-    const bool has_samples = !gate_dev || gate_dev[0] > 0;
-    const bool overflow = (overflow_flag && overflow_flag[0] != 0) || (remote_flags && remote_flags[0] > 0.f);
+    const int64_t gate = gate_dev ? gate_dev[0] : 1;
+    const int32_t own_flag = overflow_flag ? overflow_flag[0] : 0;
+    const float remote_overflow = remote_flags ? remote_flags[0] : 0.f, remote_truncated = remote_flags ? remote_flags[1] : 0.f;
+    const int32_t step_now = step_dev ? step_dev[0] : 0;
+    const int64_t kept = (counters && n_kept_dev) ? n_kept_dev[0] : 0;
+    int64_t cnt[6] = {0, 0, 0, 0, 0, 0};
+    if (counters) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cnt[k] = counters[k];
+    }
+    // device-side schedule: row i = {learning rate of iteration i, distortion-loss ramp of iteration i}.  This launch sits
+    // between the backward and Adam of iteration `it`: Adam reads lr(it) next, the loss head of iteration it + 1 reads
+    // ratio(it + 1) -- a graph replay then needs no host-side scalar update at all
+    const int cur = it < n_schedule ? it : n_schedule - 1, nxt = it + 1 < n_schedule ? it + 1 : n_schedule - 1;
+    const float lr = sched ? schedule[2 * cur] : 0.f, ratio = sched ? schedule[2 * nxt + 1] : 0.f;
+
+    const bool has_samples = gate > 0;
+    const bool overflow = own_flag != 0 || remote_overflow > 0.f;
     // remote_flags: {overflow, truncated} summed over the ranks of a data-parallel job (this rank's own included): every rank
     // takes or skips the step alike
-    const bool truncated = (capacity > 0 && marched > capacity) || (remote_flags && remote_flags[1] > 0.f);
+    const bool truncated = (capacity > 0 && marched > capacity) || remote_truncated > 0.f;
     // overflow_redone: the caller repaired a flagged gradient in place (perf_hashgrid_bwd's redo launch): the event is counted,
     // the step is taken
     const bool take = has_samples && (!overflow || overflow_redone) && !truncated;
-    if (step_dev && take) step_dev[0] += 1;
+    if (sched) {
+        if (lr_out) lr_out[0] = lr;
+        if (ratio_out) ratio_out[0] = ratio;
+        iter_dev[0] = it + 1;
+    }
+    if (step_dev && take) step_dev[0] = step_now + 1;
     if (eff_gate_out) eff_gate_out[0] = take ? 1 : 0;
-    if (overflow_flag && overflow_flag[0] != 0) overflow_flag[0] = 0;      // consumed: counted below, the step is skipped
+    if (own_flag != 0) overflow_flag[0] = 0;      // consumed: counted below, the step is skipped
     if (counters) {
-        counters[0] += marched;
-        if (n_kept_dev) counters[1] += n_kept_dev[0];
-        counters[2] += 1;
-        if (marched > counters[3]) counters[3] = marched;
-        if (has_samples && overflow) counters[4] += 1;
-        if (has_samples && truncated) counters[5] += 1;
+        counters[0] = cnt[0] + marched;
+        if (n_kept_dev) counters[1] = cnt[1] + kept;
+        counters[2] = cnt[2] + 1;
+        if (marched > cnt[3]) counters[3] = marched;
+        if (has_samples && overflow) counters[4] = cnt[4] + 1;
+        if (has_samples && truncated) counters[5] = cnt[5] + 1;
     }
 }
 }  // namespace perf
@@ -355,6 +379,26 @@ extern "C" int perf_occ_splat(const float* rays_o, const float* rays_d, const fl
 // rand_ray_color_data (modules/dataset/sup_info.py:236-259) gathers origins, directions, colours, distances and normals of
 // the drawn pixels with five indexing kernels; here one launch gathers whatever is asked for (NULL = skip).
 namespace perf {
+// The rows of pixel j -> slot i of whatever outputs are asked for.  ALL the loads are issued before the first store: written as
+// "if (o) o[..] = o_all[..]" per element, every load is waited for on its own before the store that follows it -- thirteen
+// dependent round trips to random rows for what is one (11 us -> the latency of one gather, measured on the draw kernel).
+__device__ __forceinline__ void gather_rows(int64_t i, int64_t j, const float* __restrict__ o_all, const float* __restrict__ d_all,
+                                            const float* __restrict__ c_all, const float* __restrict__ t_all,
+                                            const float* __restrict__ n_all, float* __restrict__ o, float* __restrict__ d,
+                                            float* __restrict__ c, float* __restrict__ t, float* __restrict__ nrm) {
+    float vo[3] = {0.f, 0.f, 0.f}, vd[3] = {0.f, 0.f, 0.f}, vc[3] = {0.f, 0.f, 0.f}, vn[3] = {0.f, 0.f, 0.f}, vt = 0.f;
+    if (o) { vo[0] = o_all[3 * j]; vo[1] = o_all[3 * j + 1]; vo[2] = o_all[3 * j + 2]; }
+    if (d) { vd[0] = d_all[3 * j]; vd[1] = d_all[3 * j + 1]; vd[2] = d_all[3 * j + 2]; }
+    if (c) { vc[0] = c_all[3 * j]; vc[1] = c_all[3 * j + 1]; vc[2] = c_all[3 * j + 2]; }
+    if (nrm) { vn[0] = n_all[3 * j]; vn[1] = n_all[3 * j + 1]; vn[2] = n_all[3 * j + 2]; }
+    if (t) vt = t_all[j];
+    if (o) { o[3 * i] = vo[0]; o[3 * i + 1] = vo[1]; o[3 * i + 2] = vo[2]; }
+    if (d) { d[3 * i] = vd[0]; d[3 * i + 1] = vd[1]; d[3 * i + 2] = vd[2]; }
+    if (c) { c[3 * i] = vc[0]; c[3 * i + 1] = vc[1]; c[3 * i + 2] = vc[2]; }
+    if (nrm) { nrm[3 * i] = vn[0]; nrm[3 * i + 1] = vn[1]; nrm[3 * i + 2] = vn[2]; }
+    if (t) t[i] = vt;
+}
+
 __global__ __launch_bounds__(256) void gather_supervision_kernel(const int64_t* __restrict__ idx, int64_t n,
                                                                  const float* __restrict__ o_all, const float* __restrict__ d_all,
                                                                  const float* __restrict__ c_all, const float* __restrict__ t_all,
@@ -363,15 +407,7 @@ __global__ __launch_bounds__(256) void gather_supervision_kernel(const int64_t* 
                                                                  float* __restrict__ nrm) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t j = idx[i];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (o) o[3 * i + k] = o_all[3 * j + k];
-        if (d) d[3 * i + k] = d_all[3 * j + k];
-        if (c) c[3 * i + k] = c_all[3 * j + k];
-        if (nrm) nrm[3 * i + k] = n_all[3 * j + k];
-    }
-    if (t) t[i] = t_all[j];
+    gather_rows(i, idx[i], o_all, d_all, c_all, t_all, n_all, o, d, c, t, nrm);
 }
 }  // namespace perf
 
@@ -421,6 +457,7 @@ __global__ __launch_bounds__(256) void draw_train_batch_kernel(uint32_t seed_lo,
         uint32_t r[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)draw, (uint32_t)(draw >> 32) & 0x7fffffffu};
         philox4x32_10(r, seed_lo, seed_hi);
         const int64_t j = pool_lo + (int64_t)(((uint64_t)r[0] * (uint64_t)pool_n) >> 32);
+        gather_rows(i, j, o_all, d_all, c_all, t_all, n_all, o, d, c, t, nrm);     // (first: its loads fly during the second Philox)
         if (idx_out) idx_out[i] = j;
         if (jitter) jitter[i] = u01(r[1]);
         if (noise) noise[i] = u01(r[2]);
@@ -429,14 +466,6 @@ __global__ __launch_bounds__(256) void draw_train_batch_kernel(uint32_t seed_lo,
             philox4x32_10(q, seed_lo, seed_hi);
             bg[3 * i] = u01(q[0]); bg[3 * i + 1] = u01(q[1]); bg[3 * i + 2] = u01(q[2]);
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (o) o[3 * i + k] = o_all[3 * j + k];
-            if (d) d[3 * i + k] = d_all[3 * j + k];
-            if (c) c[3 * i + k] = c_all[3 * j + k];
-            if (nrm) nrm[3 * i + k] = n_all[3 * j + k];
-        }
-        if (t) t[i] = t_all[j];
     }
     // the last workgroup to finish advances the draw counter (every workgroup has read it by then) and rearms the ticket
     __syncthreads();
