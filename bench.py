@@ -52,7 +52,8 @@ ALGO_BYTES = {'perf_hashgrid_fwd': 16 * 8 * 2 * 2, 'perf_hashgrid_bwd': 2 * 16 *
 LIMITER = {'perf_hashgrid_fwd': 'L1 misses in flight: 35 L1->L2 requests per sample at a 160-180 cycle round trip (tables are L2/Infinity-Cache '
                                 'resident; the tag rate is not the limit: -20 % accesses changed nothing, profiles/r03_fwd_l1_counters.json)',
            'perf_hashgrid_bwd': 'VALU issue (owner test + enqueue per sample visit); no HBM read-modify-write happens',
-           'perf_mlp_fwd': 'epilogue VALU + dependency chains', 'perf_mlp_bwd': 'epilogue VALU + LDS transposes'}
+           'perf_mlp_fwd': 'HBM: features in, outputs out (inputs requested one tile ahead)',
+           'perf_mlp_bwd': 'per-tile dependency chain at two waves per SIMD (MFMA -> pack -> LDS transpose -> MFMA) beside the 137 MB dfeat store'}
 GEO_FWD_FLOP = 2 * (32 * 64 + 64 * 1)
 APP_FWD_FLOP = 2 * (32 * 64 + 64 * 64 + 64 * 3)
 

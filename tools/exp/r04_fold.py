@@ -121,8 +121,8 @@ def main():
     # ---- SQ
     s, sf = fold_counters('pmc_sq/**/*counter_collection.csv')
     copy_raw(sf, 'pmc_sq')
-    json.dump({'command': 'rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -- python bench.py --steps 10 --warmup 3 --no-graph ...',
-               'note': 'mean per launch over the run', 'kernels': {k: {c: round(v, 1) for c, v in d.items()} for k, d in s.items()}},
+    json.dump({'command': 'rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_ANY -- python bench.py --steps 10 --warmup 3 --no-graph ...',
+               'note': 'mean per launch over the run; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)', 'kernels': {k: {c: round(v, 1) for c, v in d.items()} for k, d in s.items()}},
               open(os.path.join(DST, 'r04_sq_counters.json'), 'w'), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
