@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 5
+#define PERF_ABI_VERSION 6
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -305,9 +305,13 @@ int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n);
  * sel and the activation derivative itself).  Outputs: dfeat fp32 level-major (may be NULL),
  * dw fp32 [n_net_params] (overwritten; deterministic two-stage reduction), level_absmax (may be NULL):
  * PERF_MAX_LEVELS floats, an upper bound of max |dfeat| of every level (the max over the group of 8 levels a
- * half-wave owns; zeroed by the call). */
-int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
-                 const float* dout, float* dfeat, float* dw, float* level_absmax, void* workspace,
+ * half-wave owns; zeroed by the call).
+ * feat_index (device int32 [n], may be NULL) / feat_stride: the features of sample i are row feat_index[i] of a level-major
+ * array of feat_stride rows per level (feat16[(l * feat_stride + feat_index[i]) * 2 + f]) -- the kept samples of a batch read
+ * straight from the features the sampler's density pass wrote for ALL marched samples (perf_compact_prefix's
+ * src_index_out) instead of from a compacted copy; NULL: row i of n rows (feat_stride is ignored). */
+int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const int32_t* feat_index, int64_t feat_stride,
+                 const uint8_t* sel, const float* dout, float* dfeat, float* dw, float* level_absmax, void* workspace,
                  int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, void* stream);
 
 /* ---- rays ---------------------------------------------------------------------------------- */
@@ -420,13 +424,15 @@ int perf_visibility_count(const float* sigmas, const float* t_starts, const floa
  * (as written by perf_occ_march_write_points), which are then compacted along instead of being recomputed, and the
  * level-major 16-bit features of the density pass (feat[l * stride + i], n_levels levels; NULL = none): the reference
  * evaluates the density field a second time on the kept samples (nerf_renderer.py:166-168) with the same parameters at the
- * same positions, so the compacted features ARE that evaluation's encoding. */
+ * same positions, so the compacted features ARE that evaluation's encoding.  src_index_out (int32 [S], may be NULL): the
+ * source row of every kept sample instead -- perf_mlp_bwd(feat_index) then reads the uncompacted features in place and the
+ * 128 B per sample of feature copy (two thirds of this call's traffic) do not happen. */
 int perf_compact_prefix(const int32_t* packed_info, const int32_t* new_counts, const int32_t* new_offsets,
                         int64_t n_rays, const float* ts_in, const float* te_in, const float* sig_in,
                         int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out,
                         int32_t* packed_out, const float* x01_in, const uint8_t* sel_in, float* x01_out,
                         uint8_t* sel_out, const void* feat_in, int64_t feat_stride_in, void* feat_out,
-                        int64_t feat_stride_out, int32_t n_levels, void* stream);
+                        int64_t feat_stride_out, int32_t n_levels, int32_t* src_index_out, void* stream);
 
 /* ---- two-phase early termination (same results as perf_visibility_count + perf_compact_prefix over all samples) -------
  * nerfacc's render_visibility_from_density keeps a PREFIX of every ray (the exclusive sum of sigma*delta never decreases),

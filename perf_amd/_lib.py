@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libperf_hip.so')
 
-ABI_VERSION = 5          # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
+ABI_VERSION = 6          # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
 MAX_LEVELS = 24
 DTYPE_BF16, DTYPE_FP16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
@@ -69,7 +69,7 @@ _SIGS = {
     'perf_field_infer_scratch_bytes': (c_int64, [POINTER(GridDesc), c_int64]),
     'perf_field_infer': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, P, c_int64, P, P, c_int64, P, c_int, P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
-    'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, P, P, P, P, P, c_int64, c_int64, P, c_int, P]),
+    'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, c_int64, P, P, P, P, P, P, c_int64, c_int64, P, c_int, P]),
     'perf_pano_raygen': (c_int, [POINTER(c_float), c_int32, c_int32, c_int32, c_int32, P, P, P]),
     'perf_pano_raygen_dev': (c_int, [P, c_int32, c_int32, c_int32, c_int32, P, P, P]),
     'perf_occ_pack_bits': (c_int, [P, P, c_int64, P]),
@@ -92,7 +92,7 @@ _SIGS = {
     'perf_visibility_count2': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_float, P, P]),
     'perf_compact_prefix2': (c_int, [P] * 14 + [c_int64, c_int64] + [P] * 7 + [P, c_int64, P, c_int64, P, c_int64, c_int32, P]),
     'perf_visibility_count': (c_int, [P, P, P, P, c_int64, c_float, P, P, P, c_int32, P, P]),
-    'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, P, c_int64, c_int32, P]),
+    'perf_compact_prefix': (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, P, c_int64, c_int32, P, P]),
     'perf_composite_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     'perf_composite_bwd': (c_int, [P, P, P, P, c_int64, P, P, P, P, P, P, P, P, P, P, P]),
     'perf_render_finish_eval': (c_int, [P, P, P, c_int64, P, P]),

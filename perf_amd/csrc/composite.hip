@@ -160,6 +160,7 @@ struct FeatCopy {
     const uint32_t* in_t; int64_t stride_t;       // tail source (two-phase sampler)
     uint32_t* out; int64_t stride_out;
     int32_t n_levels;
+    int32_t* src_index_out;                       // instead of a copy: the source row of every kept sample (one-phase compaction)
 };
 
 __global__ __launch_bounds__(256) void compact_prefix_kernel(const int32_t* __restrict__ packed, const int32_t* __restrict__ new_counts,
@@ -190,6 +191,8 @@ __global__ __launch_bounds__(256) void compact_prefix_kernel(const int32_t* __re
     if (fc.out)             // level-major encoded features of the kept samples (one packed 2x16-bit dword per level)
         for (int l = 0; l < fc.n_levels; ++l)
             for (int i = lane; i < cnt; i += 64) fc.out[(int64_t)l * fc.stride_out + dst + i] = fc.in_h[(int64_t)l * fc.stride_h + src + i];
+    if (fc.src_index_out)   // ... or where they are (perf_mlp_bwd reads them in place)
+        for (int i = lane; i < cnt; i += 64) fc.src_index_out[dst + i] = (int32_t)(src + i);
 }
 
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ sig, const float* __restrict__ rgb,
@@ -428,7 +431,7 @@ extern "C" int perf_compact_prefix(const int32_t* packed_info, const int32_t* ne
                                    int64_t* ray_indices_out, float* ts_out, float* te_out, float* sig_out,
                                    int32_t* packed_out, const float* x01_in, const uint8_t* sel_in, float* x01_out,
                                    uint8_t* sel_out, const void* feat_in, int64_t feat_stride_in, void* feat_out,
-                                   int64_t feat_stride_out, int32_t n_levels, void* stream) {
+                                   int64_t feat_stride_out, int32_t n_levels, int32_t* src_index_out, void* stream) {
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && new_counts && new_offsets && packed_out, "NULL pointer");
@@ -436,7 +439,7 @@ extern "C" int perf_compact_prefix(const int32_t* packed_info, const int32_t* ne
     PERF_REQUIRE((x01_in == nullptr) == (x01_out == nullptr) && (sel_in == nullptr) == (sel_out == nullptr),
                  "x01/sel in and out must both be given or both be NULL");
     PERF_REQUIRE((feat_in == nullptr) == (feat_out == nullptr), "feat in and out must both be given or both be NULL");
-    FeatCopy fc{(const uint32_t*)feat_in, feat_stride_in, nullptr, 0, (uint32_t*)feat_out, feat_stride_out, n_levels};
+    FeatCopy fc{(const uint32_t*)feat_in, feat_stride_in, nullptr, 0, (uint32_t*)feat_out, feat_stride_out, n_levels, src_index_out};
     hipLaunchKernelGGL(compact_prefix_kernel, ray_grid(n_rays), dim3(256), 0, as_stream(stream), packed_info, new_counts,
                        new_offsets, n_rays, ts_in, te_in, sig_in, ray_indices_out, ts_out, te_out, sig_out, packed_out, x01_in, sel_in,
                        x01_out, sel_out, fc);

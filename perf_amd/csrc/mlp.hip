@@ -381,12 +381,13 @@ __device__ __forceinline__ void pack_pred(const f32x16& acc, const bool* pos, u3
 template <typename T16, int NH, int KS, bool FAST>
 __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
                                                       const uint32_t* __restrict__ feat,
+                                                      const int32_t* __restrict__ feat_index, int64_t feat_stride,
                                                       const uint8_t* __restrict__ sel,
                                                       const float* __restrict__ dout, float2* __restrict__ dfeat,
                                                       float* __restrict__ partials, float* __restrict__ level_absmax,
                                                       int64_t n, const int64_t* __restrict__ n_dev) {
     using L = Layout<NH, KS>;
-    const int64_t n_live = live_count(n, n_dev);        // n stays the stride of feat / dfeat
+    const int64_t n_live = live_count(n, n_dev);        // n stays the stride of dfeat (and of feat, unless feat_index is given)
     float amax = 0.f;      // running max |dfeat| over the 8 levels this half-wave owns (one register, not eight)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* frag = reinterpret_cast<u32x4*>(smem);
@@ -417,20 +418,34 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
     // a request is UNCONDITIONAL and issues the same number of loads on every path (clamped indices instead of predicates, a
     // dummy byte when there is no selector), nothing is computed from a requested value before its tile's turn, and the two
     // register sets alternate (a copy at the end of the iteration would wait for the loads it copies).
-    struct TileIn { u32x4 b1[KS]; float g[8]; uint8_t sv; };
+    // feat_index: a sample's features are row feat_index[i] of feat_stride rows per level.  The row of the NEXT request travels
+    // with the current one (TileIn::row_next: requested a tile earlier, so that the feature addresses of a request never wait
+    // for a load of the same request); without an index the same slot carries a dummy word and the row is the sample itself.
+    struct TileIn { u32x4 b1[KS]; float g[8]; uint8_t sv; int32_t row_next; };
     const int64_t last_tile = n_tiles - 1;
-    auto request = [&](int64_t tile_unclamped, TileIn& t) {
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    const bool indexed = feat_index != nullptr;         // (uniform)
+    const int64_t fstride = indexed ? feat_stride : n;
+    const int32_t* index_or_dummy = indexed ? feat_index : reinterpret_cast<const int32_t*>(dout);
+    auto sample_of = [&](int64_t tile_unclamped) {      // (in-range sample of this lane in a tile; past the end: the last ones)
+        const int64_t tile = tile_unclamped < last_tile ? tile_unclamped : last_tile;
+        const int64_t si = tile * kTile + c;
+        return si < n_live ? si : n_live - 1;
+    };
+    auto request = [&](int64_t tile_unclamped, TileIn& t, int32_t row_in) {
         const int64_t tile = tile_unclamped < last_tile ? tile_unclamped : last_tile;     // past the end: re-read the last tile
         const int64_t si = tile * kTile + c;
         const bool valid = si < n_live;
         const int64_t sc = valid ? si : n_live - 1;      // lanes past the end read the LAST sample: finite values, zero dY
+        t.row_next = index_or_dummy[indexed ? sample_of(tile_unclamped + tile_step) : 0];
+        const int64_t row = indexed ? (int64_t)row_in : sc;
         if constexpr (FAST) {
-            const uint32_t off = 4u * (uint32_t)(sc + (int64_t)h * n);
+            const uint32_t off = 4u * (uint32_t)(row + (int64_t)h * fstride);
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const unsigned char* base = reinterpret_cast<const unsigned char*>(feat) + (int64_t)(8 * s + 2 * i) * n * 4;
+                    const unsigned char* base = reinterpret_cast<const unsigned char*>(feat) + (int64_t)(8 * s + 2 * i) * fstride * 4;
                     t.b1[s][i] = *reinterpret_cast<const uint32_t*>(base + off);
                 }
         } else {
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int level = 8 * s + 2 * i + h;
-                    t.b1[s][i] = (valid && level < mp.n_levels) ? feat[(int64_t)level * n + si] : 0u;
+                    t.b1[s][i] = (valid && level < mp.n_levels) ? feat[(int64_t)level * fstride + row] : 0u;
                 }
         }
         const float* drow = dout + sc * mp.n_out;
@@ -607,28 +622,28 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
                 for (int m = 0; m < 2; ++m) gW1[m * MB + nb] = T16::mfma(lds_get_frag(tA, 32 * m + c, s, h), b, gW1[m * MB + nb]);
             }
     };
-    const int64_t tile_step = (int64_t)gridDim.x * 4;
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     const int64_t n_full = n_live / kTile;            // tiles without a lane past the end
     TileIn ta, tb;
+    auto first_row = [&](int64_t tl) { return indexed ? feat_index[sample_of(tl)] : 0; };
     if (tile < n_full) {
         // (the first tile is peeled so that the loop is entered, like its back edge, with one request and one tile's stores in flight)
-        request(tile, ta);
-        request(tile + tile_step, tb);
+        request(tile, ta, first_row(tile));
+        request(tile + tile_step, tb, ta.row_next);
         process(std::true_type{}, tile, ta);
         tile += tile_step;
         while (tile < n_full) {
-            request(tile + tile_step, ta);
+            request(tile + tile_step, ta, tb.row_next);
             process(std::true_type{}, tile, tb);
             tile += tile_step;
             if (tile >= n_full) break;
-            request(tile + tile_step, tb);
+            request(tile + tile_step, tb, ta.row_next);
             process(std::true_type{}, tile, ta);
             tile += tile_step;
         }
     }
     if (tile == n_full && n_full < n_tiles) {         // the ragged last tile, on the wave whose turn it is
-        request(tile, ta);
+        request(tile, ta, first_row(tile));
         process(std::false_type{}, tile, ta);
     }
     // ---- per-level max |dfeat| (feeds the fixed-point scale of the grid backward): lanes of one half-wave hold the
@@ -811,8 +826,9 @@ static void dispatch_fused(int nh, int ks, Args... a) {
 }
 
 template <typename T16, int NH, int KS>
-static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t* w, const uint32_t* feat, const uint8_t* sel,
-                       const float* dout, float2* dfeat, float* partials, float* level_absmax, int64_t n, const int64_t* n_dev) {
+static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t* w, const uint32_t* feat, const int32_t* feat_index,
+                       int64_t feat_stride, const uint8_t* sel, const float* dout, float2* dfeat, float* partials, float* level_absmax,
+                       int64_t n, const int64_t* n_dev) {
     constexpr int lds_bytes = Layout<NH, KS>::n_all * 1024 + 4 * 2 * 64 * kPitch * 2;
     static std::once_flag attr_once;            // (one flag per template instance) safe under concurrent callers
     std::call_once(attr_once, []() {
@@ -821,10 +837,10 @@ static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t*
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<T16, NH, KS, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     });
-    if (n <= kMaxFastStride && mp.n_levels == 8 * KS && dfeat != nullptr)
-        mlp_bwd_kernel<T16, NH, KS, true><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, level_absmax, n, n_dev);
+    if (n <= kMaxFastStride && (feat_index == nullptr || feat_stride <= kMaxFastStride) && mp.n_levels == 8 * KS && dfeat != nullptr)
+        mlp_bwd_kernel<T16, NH, KS, true><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, feat_index, feat_stride, sel, dout, dfeat, partials, level_absmax, n, n_dev);
     else
-        mlp_bwd_kernel<T16, NH, KS, false><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, sel, dout, dfeat, partials, level_absmax, n, n_dev);
+        mlp_bwd_kernel<T16, NH, KS, false><<<dim3(blocks), dim3(256), lds_bytes, st>>>(mp, w, feat, feat_index, feat_stride, sel, dout, dfeat, partials, level_absmax, n, n_dev);
 }
 
 template <typename T16, typename... Args>
@@ -872,8 +888,8 @@ extern "C" int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_
     return ((int64_t)blocks * n_params_rt(nh, ks) + (int64_t)blocks * 8) * (int64_t)sizeof(float);
 }
 
-extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const uint8_t* sel,
-                            const float* dout, float* dfeat, float* dw, float* level_absmax, void* workspace,
+extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const int32_t* feat_index, int64_t feat_stride,
+                            const uint8_t* sel, const float* dout, float* dfeat, float* dw, float* level_absmax, void* workspace,
                             int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
     int nh, ks;
     int rc = check_mlp(mlp, &nh, &ks);
@@ -888,17 +904,18 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
         return PERF_OK;
     }
     PERF_REQUIRE(feat16 && dout, "NULL pointer");
+    PERF_REQUIRE(feat_index == nullptr || feat_stride > 0, "perf_mlp_bwd: feat_index needs feat_stride > 0");
     const int64_t need = perf_mlp_bwd_workspace_bytes(mlp, n);
     PERF_REQUIRE(workspace_bytes >= need, "perf_mlp_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     MlpParams mp{mlp->n_levels, mlp->n_out, mlp->out_act, mlp->exp_shift};
     const int blocks = mlp_blocks(n, bwd_blocks_per_cu(nh, ks));
     float* amax_slots = level_absmax ? (float*)workspace + (int64_t)blocks * np : nullptr;
     if (dtype == PERF_DTYPE_BF16)
-        dispatch_bwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,
-                           (float2*)dfeat, (float*)workspace, amax_slots, n, n_dev);
+        dispatch_bwd<BF16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, feat_index, feat_stride, sel,
+                           dout, (float2*)dfeat, (float*)workspace, amax_slots, n, n_dev);
     else
-        dispatch_bwd<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, sel, dout,
-                           (float2*)dfeat, (float*)workspace, amax_slots, n, n_dev);
+        dispatch_bwd<FP16>(nh, ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, feat_index, feat_stride, sel,
+                           dout, (float2*)dfeat, (float*)workspace, amax_slots, n, n_dev);
     PERF_LAUNCH_CHECK("perf_mlp_bwd");
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)div_up(np, 16) + 1), dim3(256), 0, as_stream(stream),
                        (const float*)workspace, dw, np, blocks, (const float*)amax_slots, level_absmax, (int)mlp->n_levels);

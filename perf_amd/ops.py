@@ -6,6 +6,8 @@ or a missing libperf_hip.so raises.
 """
 import ctypes
 import math
+import os
+from typing import NamedTuple
 
 import torch
 
@@ -375,10 +377,28 @@ def field_infer(grid: GridConfig, mlp: MlpConfig, x01, sel, w16, n_dev=None, wan
     return (out, feat) if want_features else out
 
 
+class IndexedFeat(NamedTuple):
+    """Level-major features [L, n_src, 2] of MORE samples than the caller means, and the row of each sample it does mean
+    (int32 [n]; rows past the live count are not read): what compact_prefix(index_features=True) hands to the gradient pass
+    instead of a compacted copy (perf_mlp_bwd's feat_index)."""
+    feat: torch.Tensor
+    index: torch.Tensor
+
+    def materialize(self):
+        """The compacted copy after all ([L, n, 2]; rows past the live count repeat a valid row)."""
+        return self.feat.index_select(1, self.index.long().clamp_(0, self.feat.shape[1] - 1))
+
+
 def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True, want_absmax=False, n_dev=None, dw_out=None):
     """Returns (dfeat [L,n,2] f32 or None, dw [n_net_params] f32[, level_absmax [16] f32]).  dw_out: write the weight gradient
-    there (e.g. the head of a flat [network | grid] gradient) instead of into a fresh tensor."""
-    n = feat16.shape[1]
+    there (e.g. the head of a flat [network | grid] gradient) instead of into a fresh tensor.  feat16: [L, n, 2] or an
+    IndexedFeat (n = its index's length)."""
+    index, stride = None, 0
+    if isinstance(feat16, IndexedFeat):
+        feat16, index = feat16.feat, feat16.index
+        assert index.dtype == torch.int32 and index.is_contiguous() and feat16.is_contiguous()
+        stride = feat16.shape[1]
+    n = index.shape[0] if index is not None else feat16.shape[1]
     d = mlp.desc()
     lib = _lib.load()
     ws_bytes = lib.perf_mlp_bwd_workspace_bytes(ctypes.byref(d), n)
@@ -386,8 +406,8 @@ def mlp_bwd(mlp: MlpConfig, w16, feat16, dout, sel=None, need_dfeat=True, want_a
     dfeat = torch.empty(mlp.n_levels, n, 2, dtype=torch.float32, device=feat16.device) if need_dfeat else None
     dw = dw_out if dw_out is not None else torch.empty(mlp.n_params, dtype=torch.float32, device=feat16.device)
     amax = torch.empty(_lib.MAX_LEVELS, dtype=torch.float32, device=feat16.device) if want_absmax else None
-    _call('perf_mlp_bwd', ctypes.byref(d), _p(w16), _p(feat16), _p(sel), _p(_f32(dout, 'dout')), _p(dfeat), _p(dw), _p(amax),
-              _p(ws), ws.numel() * 4, n, _nd(n_dev), dtype_code(w16.dtype), _stream())
+    _call('perf_mlp_bwd', ctypes.byref(d), _p(w16), _p(feat16), _p(index), stride, _p(sel), _p(_f32(dout, 'dout')), _p(dfeat), _p(dw),
+          _p(amax), _p(ws), ws.numel() * 4, n, _nd(n_dev), dtype_code(w16.dtype), _stream())
     return (dfeat, dw, amax) if want_absmax else (dfeat, dw)
 
 
@@ -626,10 +646,15 @@ def visibility_count(sigmas, t_starts, t_ends, packed, early_stop_eps=1e-4, want
     return (new_counts, ex) if want_exsum else new_counts
 
 
-def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=None, x01=None, sel=None, feat=None):
+INDEX_FEATURES = os.environ.get('PERF_INDEX_FEATURES', '1') != '0'      # compact_prefix: rows instead of a feature copy
+
+
+def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=None, x01=None, sel=None, feat=None,
+                   index_features=None):
     """-> (ray_indices, t_starts, t_ends, sigmas, packed_info) of the kept prefixes; with capacity (sync-free mode: the
     arrays keep that length, the kept count stays on the device) also `total` (int64 [1]); with x01/sel also the compacted
-    positions, appended to the result."""
+    positions, appended to the result; with feat (level-major features of all input samples) their compacted copy or --
+    index_features (default: PERF_INDEX_FEATURES, on) -- an IndexedFeat that points into `feat` (which must then outlive it)."""
     R = packed.shape[0]
     dev = packed.device
     new_offsets, total = exclusive_scan_i32(new_counts)
@@ -641,10 +666,15 @@ def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=N
     xo = torch.empty(S, 3, dtype=torch.float32, device=dev) if x01 is not None else None
     so = torch.empty(S, dtype=torch.uint8, device=dev) if sel is not None else None
     packed_out = torch.empty(R, 2, dtype=torch.int32, device=dev)
-    fo = torch.empty(feat.shape[0], S, 2, dtype=feat.dtype, device=dev) if feat is not None else None     # level major like feat
+    by_index = feat is not None and (INDEX_FEATURES if index_features is None else index_features)
+    fo = torch.empty(feat.shape[0], S, 2, dtype=feat.dtype, device=dev) if (feat is not None and not by_index) else None     # level major like feat
+    fi = torch.empty(S, dtype=torch.int32, device=dev) if by_index else None
     _call('perf_compact_prefix', _p(packed), _p(new_counts), _p(new_offsets), R, _p(t_starts), _p(t_ends), _p(sigmas),
-              _p(ri), _p(ts), _p(te), _p(sg), _p(packed_out), _p(x01), _p(sel), _p(xo), _p(so),
-              _p(feat), feat.shape[1] if feat is not None else 0, _p(fo), S, feat.shape[0] if feat is not None else 0, _stream())
+          _p(ri), _p(ts), _p(te), _p(sg), _p(packed_out), _p(x01), _p(sel), _p(xo), _p(so),
+          _p(feat if fo is not None else None), feat.shape[1] if fo is not None else 0, _p(fo), S, feat.shape[0] if fo is not None else 0,
+          _p(fi), _stream())
+    if by_index:
+        fo = IndexedFeat(feat, fi)
     res = (ri, ts, te, sg, packed_out)
     if capacity is not None:
         res = res + (total,)

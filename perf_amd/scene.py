@@ -964,6 +964,8 @@ class NeRFScene:
         else:
             if feat is None:
                 feat = ops.hashgrid_fwd(geo.grid, x01, w16[n_net:], n_dev=n_dev)
+            elif isinstance(feat, ops.IndexedFeat):       # (features without densities: no caller does that today)
+                feat = feat.materialize()
             sig = ops.mlp_fwd(geo.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
         # The colour render of this step (query key 'rgb', nerf.py:197-201) feeds no loss term (:208-252).  Under data
         # parallelism it is therefore issued AFTER the gradient all-reduce has been launched: the colour field's encode +

@@ -429,6 +429,48 @@ def test_visibility_and_compaction_bit_exact(ops):
     assert np.array_equal(gpacked.cpu().numpy(), O.packed_info_from_ray_indices(ri.numpy()[keep], packed.shape[0]))
 
 
+def test_compaction_hands_out_rows_instead_of_a_feature_copy(ops):
+    """perf_compact_prefix(src_index_out) + perf_mlp_bwd(feat_index): the kept samples' features are read where the sampler's
+    density pass wrote them.  The rows are the kept positions of the input order; the MLP backward through them is bit-identical
+    to the one on the compacted copy -- with a device-side live count below the capacity, too."""
+    packed, ri, ts, te, sig, rgb = _packed_case(5, R=700, maxc=150)
+    S = ts.shape[0]
+    g = torch.Generator().manual_seed(6)
+    feat = ((torch.rand(16, S, 2, generator=g) * 2 - 1)).to(torch.bfloat16).cuda()
+    x01 = torch.rand(S, 3, generator=g).cuda(); sel = (torch.rand(S, generator=g) > 0.1).to(torch.uint8).cuda()
+    keep, _ = O.visibility_keep_mask(sig.numpy(), ts.numpy(), te.numpy(), packed.numpy(), 1e-4)
+    nc = ops.visibility_count(sig.cuda(), ts.cuda(), te.cuda(), packed.cuda(), 1e-4)
+    cap = S + 77
+    args = (packed.cuda(), nc, ts.cuda(), te.cuda(), sig.cuda())
+    copy = ops.compact_prefix(*args, capacity=cap, x01=x01, sel=sel, feat=feat, index_features=False)
+    rows = ops.compact_prefix(*args, capacity=cap, x01=x01, sel=sel, feat=feat, index_features=True)
+    n_kept = int(copy[5].item())
+    assert n_kept == int(keep.sum()) and int(rows[5].item()) == n_kept
+    fi = rows[8]
+    assert isinstance(fi, ops.IndexedFeat) and fi.feat is feat and fi.index.dtype == torch.int32 and fi.index.shape == (cap,)
+    assert np.array_equal(fi.index[:n_kept].cpu().numpy(), np.nonzero(keep)[0])
+    assert torch.equal(fi.materialize()[:, :n_kept], copy[8][:, :n_kept])
+    for a, b in zip(copy[:8], rows[:8]):                       # everything else is compacted as before
+        assert torch.equal(a[:n_kept] if a.shape[0] == cap else a, b[:n_kept] if b.shape[0] == cap else b)
+    from perf_amd.grid import MlpConfig
+    for nh, n_out, act in ((1, 1, 'Exponential'), (1, 16, 'None'), (2, 3, 'Sigmoid')):
+        cfgm = MlpConfig(n_levels=16, n_hidden_layers=nh, n_output_dims=n_out, output_activation=act, exp_shift=1.0 if act == 'Exponential' else 0.0)
+        w = torch.cat([(torch.rand(o * i, generator=g) * 2 - 1) * math.sqrt(6.0 / (i + o)) for o, i in cfgm.shapes]).to(torch.bfloat16).cuda()
+        dout = torch.randn(cap, n_out, generator=g).cuda()
+        a = ops.mlp_bwd(cfgm, w, copy[8], dout, copy[7], want_absmax=True, n_dev=copy[5])
+        b = ops.mlp_bwd(cfgm, w, fi, dout, rows[7], want_absmax=True, n_dev=rows[5])
+        assert torch.equal(a[0][:, :n_kept], b[0][:, :n_kept]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (nh, n_out)
+    # (a grid of another depth takes the kernel without the scalar-base addressing: same contract)
+    cfgm = MlpConfig(n_levels=12, n_hidden_layers=1, n_output_dims=1, output_activation='None', exp_shift=0.0)
+    w = torch.cat([(torch.rand(o * i, generator=g) * 2 - 1) * math.sqrt(6.0 / (i + o)) for o, i in cfgm.shapes]).to(torch.bfloat16).cuda()
+    f12 = feat[:12].contiguous()
+    idx = fi.index[:n_kept].contiguous()
+    dout = torch.randn(n_kept, 1, generator=g).cuda()
+    a = ops.mlp_bwd(cfgm, w, f12.index_select(1, idx.long()), dout)
+    b = ops.mlp_bwd(cfgm, w, ops.IndexedFeat(f12, idx), dout)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_composite_fwd_bwd(ops):
     packed, ri, ts, te, sig, rgb = _packed_case(2)
     sig = sig * 0.05
