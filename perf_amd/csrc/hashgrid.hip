@@ -1351,22 +1351,57 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp,
         const uint32_t size = gp.size[l];
         const float from_fixed = fixed ? ldexpf(1.0f, -shifts[l]) : 1.0f;
         int32_t field_max = 0;
-        for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < size; e += gridDim.x * 256) {
-            float2* o = grad + gp.offset[l] + e;
-            if (fixed) {
-                const int2* p = reinterpret_cast<const int2*>(ws + tp.ws_off[l]) + e;
-                int32_t sx = 0, sy = 0;
-                for (int r = 0; r < R; ++r) { const int2 v = p[(int64_t)r * size]; sx += v.x; sy += v.y; }
-                const int32_t ax = sx < 0 ? -(sx + 1) : sx, ay = sy < 0 ? -(sy + 1) : sy;
-                field_max = max(field_max, max(ax, ay));
-                if (tp.raw_out) { *reinterpret_cast<int2*>(o) = make_int2(sx, sy); continue; }
-                float fx = (float)sx * from_fixed, fy = (float)sy * from_fixed;
-                if (tp.accumulate) { const float2 c = *o; fx += c.x; fy += c.y; }
-                *o = make_float2(fx, fy);
-            } else {
+        const uint32_t stride = gridDim.x * 256;
+        if (fixed) {
+            // Four entries x four slabs per round trip: a thread of the largest replicated level owns a dozen entries, and
+            // written as "for entry: for slab: load, add" every one of its 4 R loads was a round trip of its own (14 us for a
+            // few megabytes).  Indices are clamped so that all sixteen loads are unconditional; integer sums, any order.
+            const int2* p = reinterpret_cast<const int2*>(ws + tp.ws_off[l]);
+            for (uint32_t e0 = blockIdx.x * 256 + threadIdx.x; e0 < size; e0 += 4 * stride) {
+                int32_t sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0};
+                uint32_t ej[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ej[j] = min(e0 + (uint32_t)j * stride, size - 1u);
+                for (int r = 0; r < R; r += 4) {
+                    int2 v[4][4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t slab = (int64_t)min(r + q, R - 1) * size;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[q][j] = p[slab + ej[j]];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (r + q < R) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { sx[j] += v[q][j].x; sy[j] += v[q][j].y; }
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t e = e0 + (uint32_t)j * stride;
+                    if (e >= size) break;
+                    float2* o = grad + gp.offset[l] + e;
+                    const int32_t ax = sx[j] < 0 ? -(sx[j] + 1) : sx[j], ay = sy[j] < 0 ? -(sy[j] + 1) : sy[j];
+                    field_max = max(field_max, max(ax, ay));
+                    if (tp.raw_out) { *reinterpret_cast<int2*>(o) = make_int2(sx[j], sy[j]); continue; }
+                    float fx = (float)sx[j] * from_fixed, fy = (float)sy[j] * from_fixed;
+                    if (tp.accumulate) { const float2 c = *o; fx += c.x; fy += c.y; }
+                    *o = make_float2(fx, fy);
+                }
+            }
+        } else {
+            for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < size; e += stride) {
+                float2* o = grad + gp.offset[l] + e;
                 const float2* p = ws + tp.ws_off[l] + e;
                 float sx = 0.f, sy = 0.f;
-                for (int r = 0; r < R; ++r) { const float2 v = p[(int64_t)r * size]; sx += v.x; sy += v.y; }
+                int r = 0;
+                for (; r + 4 <= R; r += 4) {        // (loads in flight together, additions in slab order as before)
+                    const float2 v0 = p[(int64_t)r * size], v1 = p[(int64_t)(r + 1) * size], v2 = p[(int64_t)(r + 2) * size],
+                                 v3 = p[(int64_t)(r + 3) * size];
+                    sx += v0.x; sy += v0.y; sx += v1.x; sy += v1.y; sx += v2.x; sy += v2.y; sx += v3.x; sy += v3.y;
+                }
+                for (; r < R; ++r) { const float2 v = p[(int64_t)r * size]; sx += v.x; sy += v.y; }
                 if (tp.accumulate) { const float2 c = *o; sx += c.x; sy += c.y; }
                 *o = make_float2(sx, sy);
             }
@@ -1378,8 +1413,10 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp,
                 if (overflow_flag && field_max >= (1 << 29)) atomicOr(overflow_flag, 1);
                 // a RETURNING device-scope atomic: the wave waits until it has been performed at the memory side, so the
                 // ticket below is ordered behind it without an agent-scope fence (which writes back the XCD's L2: ~20 us
-                // over the 128 workgroups of this kernel, measured)
-                if (hr_state) sink = __hip_atomic_fetch_max(&hr_state[PERF_MAX_LEVELS + l], field_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // over the 128 workgroups of this kernel, measured).  Only a wave that RAISES the level's maximum needs it
+                // (same-address read-modify-writes retire one at a time, ~11 ns each; a look costs an L2 read).
+                if (hr_state && field_max > __hip_atomic_load(&hr_state[PERF_MAX_LEVELS + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    sink = __hip_atomic_fetch_max(&hr_state[PERF_MAX_LEVELS + l], field_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1525,28 +1562,60 @@ __global__ __launch_bounds__(256) void fixed_unfix_kernel(GridParams gp, int32_t
                                                           const int32_t* __restrict__ shifts, int32_t* __restrict__ field_max,
                                                           int32_t* __restrict__ overflow_flag) {
     __shared__ int32_t fm_s[PERF_MAX_LEVELS];
-    if (threadIdx.x < PERF_MAX_LEVELS) fm_s[threadIdx.x] = 0;
+    // level starts and units in LDS: gp.offset[l] with a per-lane l is a vector load from the kernel-argument segment, waited for
+    // with vmcnt(0) -- i.e. behind the data loads, once per entry (this kernel took 44 us for 53 MB)
+    __shared__ uint64_t start_s[PERF_MAX_LEVELS + 1];
+    __shared__ float unit_s[PERF_MAX_LEVELS];
+    if (threadIdx.x < PERF_MAX_LEVELS) {
+        fm_s[threadIdx.x] = 0;
+        start_s[threadIdx.x] = (int)threadIdx.x < gp.n_levels ? gp.offset[threadIdx.x] : ~0ull;
+        unit_s[threadIdx.x] = (int)threadIdx.x < gp.n_levels ? ldexpf(1.0f, -shifts[threadIdx.x]) : 0.f;
+    }
+    if (threadIdx.x == 0) start_s[PERF_MAX_LEVELS] = ~0ull;
     __syncthreads();
     int cur_l = 0, cur_m = 0;            // a thread's entries ascend: it stays in one level for long runs
-    float from_fixed = ldexpf(1.0f, -shifts[0]);
-    for (int64_t e = entry_lo + (int64_t)blockIdx.x * 256 + threadIdx.x; e < entry_hi; e += (int64_t)gridDim.x * 256) {
-        if (cur_l + 1 < gp.n_levels && (uint64_t)e >= gp.offset[cur_l + 1]) {
-            if (cur_m > 0) atomicMax(&fm_s[cur_l], cur_m);
-            while (cur_l + 1 < gp.n_levels && (uint64_t)e >= gp.offset[cur_l + 1]) ++cur_l;
-            cur_m = 0;
-            from_fixed = ldexpf(1.0f, -shifts[cur_l]);
+    float from_fixed = unit_s[0];
+    // The walk is "load, convert, store IN PLACE": a load behind a store through the same pointer waits for it, so eight entries
+    // are loaded before the first of them is stored (a load per iteration was a round trip per entry).
+    // (a workgroup takes 2,048 consecutive entries at a time: its threads change level together, and rarely)
+    for (int64_t e0 = entry_lo + (int64_t)blockIdx.x * 2048 + threadIdx.x; e0 < entry_hi; e0 += (int64_t)gridDim.x * 2048) {
+        int2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t e = e0 + j * 256;
+            v[j] = reinterpret_cast<const int2*>(buf)[(e < entry_hi ? e : entry_hi - 1) - entry_lo];
         }
-        int2* p = reinterpret_cast<int2*>(buf) + (e - entry_lo);
-        const int2 v = *p;
-        if (v.x == 0 && v.y == 0) continue;                  // (integer 0 is 0.0f)
-        *reinterpret_cast<float2*>(p) = make_float2((float)v.x * from_fixed, (float)v.y * from_fixed);
-        const int32_t ax = v.x < 0 ? -(v.x + 1) : v.x, ay = v.y < 0 ? -(v.y + 1) : v.y;
-        cur_m = max(cur_m, max(ax, ay));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t e = e0 + j * 256;
+            if (e >= entry_hi) break;
+            if ((uint64_t)e >= start_s[cur_l + 1]) {
+                if (cur_m > 0) atomicMax(&fm_s[cur_l], cur_m);
+                while ((uint64_t)e >= start_s[cur_l + 1]) ++cur_l;
+                cur_m = 0;
+                from_fixed = unit_s[cur_l];
+            }
+            if (v[j].x == 0 && v[j].y == 0) continue;                  // (integer 0 is 0.0f)
+            reinterpret_cast<float2*>(buf)[e - entry_lo] = make_float2((float)v[j].x * from_fixed, (float)v[j].y * from_fixed);
+            const int32_t ax = v[j].x < 0 ? -(v[j].x + 1) : v[j].x, ay = v[j].y < 0 ? -(v[j].y + 1) : v[j].y;
+            cur_m = max(cur_m, max(ax, ay));
+        }
     }
-    if (cur_m > 0) atomicMax(&fm_s[cur_l], cur_m);
+    // (a wave's lanes nearly always end in the same level: one LDS atomic per wave instead of 64 on one address)
+    const int l0 = __shfl(cur_l, 0);
+    if (__all(cur_l == l0)) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cur_m = max(cur_m, __shfl_xor(cur_m, off));
+        if ((threadIdx.x & 63) == 0 && cur_m > 0) atomicMax(&fm_s[cur_l], cur_m);
+    } else if (cur_m > 0) {
+        atomicMax(&fm_s[cur_l], cur_m);
+    }
     __syncthreads();
     if (threadIdx.x < PERF_MAX_LEVELS && fm_s[threadIdx.x] > 0) {
-        if (field_max) atomicMax(&field_max[threadIdx.x], fm_s[threadIdx.x]);
+        // same-address read-modify-writes retire one after the other (~11 ns each): a maximum only needs the workgroups that
+        // RAISE it -- a handful of thousands -- so look first (an atomic load is served by the L2 like any other)
+        if (field_max && fm_s[threadIdx.x] > __hip_atomic_load(&field_max[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&field_max[threadIdx.x], fm_s[threadIdx.x]);
         if (overflow_flag && fm_s[threadIdx.x] >= (1 << 29)) atomicOr(overflow_flag, 1);
     }
 }
@@ -1982,7 +2051,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     if (ws_entries > 0 || adapt) {      // replica sums, and the headroom feedback by the last workgroup
         int n_rep = 0;
         for (int l = 0; l < gp.n_levels; ++l) n_rep += tp.replicas_of[l] > 1 ? 1 : 0;
-        constexpr int kReduceBlocks = 64;
+        static const int kReduceBlocks = []() { const char* e = getenv("PERF_BWD_REDUCE_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 1024 ? v : 32; }();
         hashgrid_bwd_reduce_kernel<<<dim3(kReduceBlocks, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
             gp, tp, (const float2*)workspace, (float2*)grad_table, adapt ? headroom_state : nullptr,
             shifts_dev ? shifts_dev : shifts_ws, fixed ? 1 : 0, overflow_flag, n_rep * kReduceBlocks);
@@ -2038,8 +2107,11 @@ extern "C" int perf_fixed_unfix(const perf_grid_desc* grid, void* fields, int64_
     PERF_REQUIRE(entry_lo >= 0 && entry_lo <= entry_hi && entry_hi <= total, "perf_fixed_unfix: bad entry range");
     if (field_max) PERF_REQUIRE(hipMemsetAsync(field_max, 0, PERF_MAX_LEVELS * sizeof(int32_t), as_stream(stream)) == hipSuccess, "memset failed");
     if (entry_hi == entry_lo) return PERF_OK;
+    // few workgroups: each ends with atomics on the 24 maxima, which share one cache line and retire one at a time (~11 ns):
+    // 4,096 workgroups spent 30 us there (tools/exp/unfix_probe.py: 56 / 40 / 35 / 39 us at 4096 / 1024 / 512 / 256)
+    static const int64_t kMaxBlocks = []() { const char* e = getenv("PERF_UNFIX_BLOCKS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 512); }();
     int64_t blocks = div_up(entry_hi - entry_lo, 256 * 8);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     fixed_unfix_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(gp, (int32_t*)fields, entry_lo, entry_hi, shifts_dev,
                                                                                        field_max, overflow_flag);
     PERF_LAUNCH_CHECK("perf_fixed_unfix");

@@ -41,6 +41,14 @@ def _capture(graph):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         torch.cuda.synchronize()                 # nothing of an earlier collective is left for the watchdog to wait for
+        if dist.get_backend() == 'nccl':
+            # ... but the watchdog only FORGETS a finished collective at its next poll (every 100 ms).  Until then it keeps
+            # querying that collective's end event -- recorded on RCCL's stream, which joins the capture with the first captured
+            # collective; HIP then answers hipErrorCapturedEvent ("event last recorded in a capturing stream") and the watchdog
+            # takes the process down (1 in ~10 runs of tests/test_gpu_dist.py; never when the capture came > 100 ms after the
+            # last eager collective).  Captures are rare (one per phase): give the watchdog three polls.
+            import time
+            time.sleep(float(os.environ.get('PERF_DP_CAPTURE_DRAIN_S', '0.3')))
         return torch.cuda.graph(graph, capture_error_mode='thread_local')
     return torch.cuda.graph(graph)
 
