@@ -355,6 +355,10 @@ def main():
             os.environ.setdefault(k, v)
     if world > 1 or single_rank_dp:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # Second line of defence behind perf_amd.scene._capture's drain: should ProcessGroupNCCL's watchdog thread still query
+        # the end event of an eager collective while RCCL's stream is part of a capture (HIP: hipErrorCapturedEvent), let it log
+        # and retire instead of rethrowing -- a rethrow in that thread is std::terminate for the rank, and the job's line is lost.
+        os.environ.setdefault('TORCH_NCCL_RETHROW_CUDA_ERRORS', '0')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:

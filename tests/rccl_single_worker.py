@@ -16,6 +16,7 @@ def main():
     if mode == 'rccl':
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK='0', WORLD_SIZE='1', PERF_DP_SINGLE_RANK='1')
+        os.environ.setdefault('TORCH_NCCL_RETHROW_CUDA_ERRORS', '0')       # (as bench.py: see the note there)
         dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
     from perf_amd import synthetic, scene as S
     from perf_amd.scene import NeRFScene, SupInfoPool, gen_pano_rays
