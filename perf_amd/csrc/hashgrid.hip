@@ -1238,7 +1238,11 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                         // levels report the max of their SUMMED fields from the reduction kernel)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) field_max = max(field_max, __shfl_xor(field_max, off));
-        if ((threadIdx.x & 63) == 0 && field_max > 0) atomicMax(&hr_state[PERF_MAX_LEVELS + l], field_max);
+        // (the 24 maxima share a cache line, and read-modify-writes on one line retire one at a time, ~11 ns each: 192 hashed
+        //  owners x 16 waves ending together would queue for tens of microseconds -- only a wave that RAISES the maximum needs one)
+        if ((threadIdx.x & 63) == 0 && field_max > 0 &&
+            field_max > __hip_atomic_load(&hr_state[PERF_MAX_LEVELS + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&hr_state[PERF_MAX_LEVELS + l], field_max);
     }
     if (tp.dbg_off > 0 && threadIdx.x == 0) {      // slot = position in plain level order
         int slot = (int)t * R + rep;
