@@ -63,6 +63,64 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     if (zero_grad) g[i] = 0.f;
 }
 
+// The same step, four consecutive elements per thread (16-byte loads and stores) when the arrays allow it, and with the loads
+// issued BEFORE the scalar prologue (gate, step count -> bias corrections, learning rate: a dependent chain of device reads and
+// two powf that every workgroup repeats): the 199 MB of a 3.3 M-entry table's step stream while it runs.  Element for element
+// the arithmetic of adam_kernel.
+template <typename T16, bool W16>
+__global__ __launch_bounds__(256) void adam4_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                    float* __restrict__ g, uint16_t* __restrict__ w16, int64_t n,
+                                                    float one_minus_b1, float b2, float one_minus_b2, float step_size,
+                                                    float inv_bc2_sqrt, float eps, int zero_grad,
+                                                    const int32_t* __restrict__ step_dev, const float* __restrict__ lr_dev,
+                                                    const int64_t* __restrict__ gate_dev) {
+    __shared__ float sc[2];
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int cnt = i + 3 < n ? 4 : (i < n ? (int)(n - i) : 0);
+    float gi[4] = {0.f, 0.f, 0.f, 0.f}, mi[4] = {0.f, 0.f, 0.f, 0.f}, vi[4] = {0.f, 0.f, 0.f, 0.f}, pi[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cnt == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(g + i), b = *reinterpret_cast<const float4*>(m + i),
+                     c = *reinterpret_cast<const float4*>(v + i), d = *reinterpret_cast<const float4*>(p + i);
+        gi[0] = a.x; gi[1] = a.y; gi[2] = a.z; gi[3] = a.w; mi[0] = b.x; mi[1] = b.y; mi[2] = b.z; mi[3] = b.w;
+        vi[0] = c.x; vi[1] = c.y; vi[2] = c.z; vi[3] = c.w; pi[0] = d.x; pi[1] = d.y; pi[2] = d.z; pi[3] = d.w;
+    } else {
+        for (int k = 0; k < cnt; ++k) { gi[k] = g[i + k]; mi[k] = m[i + k]; vi[k] = v[i + k]; pi[k] = p[i + k]; }
+    }
+    if (gate_dev && gate_dev[0] <= 0) return;       // batch without samples: the reference skips the step (nerf.py:204-206)
+    if (step_dev) {
+        if (threadIdx.x == 0) {
+            const float t = (float)step_dev[0];
+            const float bc1 = 1.0f - powf(1.0f - one_minus_b1, t), bc2 = 1.0f - powf(b2, t);
+            sc[0] = lr_dev[0] / bc1;
+            sc[1] = 1.0f / sqrtf(bc2);
+        }
+        __syncthreads();
+        step_size = sc[0];
+        inv_bc2_sqrt = sc[1];
+    }
+    if (cnt == 0) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mi[k] = mi[k] + one_minus_b1 * (gi[k] - mi[k]);
+        vi[k] = vi[k] * b2 + one_minus_b2 * gi[k] * gi[k];
+        const float denom = sqrtf(vi[k]) * inv_bc2_sqrt + eps;
+        pi[k] = pi[k] - step_size * (mi[k] / denom);
+    }
+    if (cnt == 4) {
+        *reinterpret_cast<float4*>(m + i) = make_float4(mi[0], mi[1], mi[2], mi[3]);
+        *reinterpret_cast<float4*>(v + i) = make_float4(vi[0], vi[1], vi[2], vi[3]);
+        *reinterpret_cast<float4*>(p + i) = make_float4(pi[0], pi[1], pi[2], pi[3]);
+        if (W16) *reinterpret_cast<uint2*>(w16 + i) = make_uint2(T16::pack(pi[0], pi[1]), T16::pack(pi[2], pi[3]));
+        if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (int k = 0; k < cnt; ++k) {
+            m[i + k] = mi[k]; v[i + k] = vi[k]; p[i + k] = pi[k];
+            if (W16) w16[i + k] = T16::one(pi[k]);
+            if (zero_grad) g[i + k] = 0.f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void points_from_rays_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                                                const int64_t* __restrict__ ri, const float* __restrict__ ts,
                                                                const float* __restrict__ te, Aabb bb, float* __restrict__ x01,
@@ -220,6 +278,17 @@ static int adam_launch(float* p, float* m, float* v, float* g, void* w16, int64_
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     dim3 gr((unsigned)div_up(n, 256)), b(256);
     const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+    const uintptr_t align = reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                            reinterpret_cast<uintptr_t>(g) | (reinterpret_cast<uintptr_t>(w16) << 1);
+    if ((align & 15) == 0 && n >= 1024) {       // four elements per thread
+        dim3 g4((unsigned)div_up(div_up(n, 4), 256));
+        if (!w16) hipLaunchKernelGGL((adam4_kernel<BF16, false>), g4, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
+        else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam4_kernel<BF16, true>), g4, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
+        else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam4_kernel<FP16, true>), g4, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
+        else { set_error("perf_adam_step: bad dtype %d", dtype); return PERF_E_INVALID; }
+        PERF_LAUNCH_CHECK("perf_adam_step");
+        return PERF_OK;
+    }
     if (!w16) hipLaunchKernelGGL((adam_kernel<BF16, false>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
     else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam_kernel<BF16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
     else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam_kernel<FP16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
