@@ -76,7 +76,7 @@ class NeRFOCCRenderer(nn.Module):
             points_aabb=nerf._aabb_host, head_samples=self.head_samples, lattice=self.lattice, march_only=True)
 
     def stage_sample(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, rand=None, with_rgb=False,
-                     keep_features=False, marched=None):
+                     keep_features=False, marched=None, before_color=None):
         """Sampling (marching, the no-grad density pass and visibility compaction of nerf_renderer.py:145-155), sample
         positions and -- with_rgb -- the colour field without gradient.  Returns a dict consumed by stage_composite, or
         None when the batch has no sample.  With self.sample_capacity set every per-sample array has that many rows and
@@ -104,6 +104,8 @@ class NeRFOCCRenderer(nn.Module):
         st = {'ray_indices': sm.ray_indices, 't_starts': sm.t_starts, 't_ends': sm.t_ends, 'packed': sm.packed, 'sig0': sm.sig,
               'x01': x01, 'sel': sel, 'n_rays': rays_o.shape[0], 'rgbs': None, 'n_dev': sm.n_dev,
               'n_marched_dev': sm.n_marched_dev, 'feat0': sm.feat}
+        if before_color is not None:
+            before_color()                   # (captured steps: everything that reads the marched batch has been issued by now)
         if with_rgb:
             with torch.no_grad():
                 st['rgbs'] = nerf.rgb_at(x01, sel, sm.n_dev)

@@ -466,8 +466,11 @@ class NeRFScene:
         # bench step 1.134 vs 1.084 ms, faithful geometry step 0.295 vs 0.268 ms, 40 vs 26 graph nodes
         # (profiles/r04_pipeline_marching.json): the marching kernels take CUs from the 236 LDS-owner workgroups of the grid
         # backward, and the copies into the static buffers cost what the overlap saves.
-        self.pipeline_marching = os.environ.get('PERF_PIPELINE_MARCHING', '0') == '1'
+        # PERF_PIPELINE_MARCHING=2: fork BEFORE the colour field's encode instead (a kernel bound by the latency of its L1 misses,
+        # with the vector units idle) -- see DESIGN.md 6.1 for what that measured.
+        self.pipeline_marching = int(os.environ.get('PERF_PIPELINE_MARCHING', '0') or 0)
         self._after_loss_hook = None
+        self._before_color_hook = None
 
     def _fixed_accum(self):
         return self.nerf.geo_mlp.grid_grad_accum == 'fixed' and self.nerf.app_mlp.grid_grad_accum == 'fixed'
@@ -943,11 +946,15 @@ class NeRFScene:
         st = pre['st']
         rand_in, rand = rand, pre['rand']
         if st is None:
+            if self._before_color_hook is not None:
+                # (the static batch is refilled from the hook on: what the loss head reads of it gets a copy of its own)
+                gt_depths = gt_depths.clone()
+                rand = dict(rand); rand['noise'] = rand['noise'].clone()
             # (under data parallelism the colour render is deferred until the gradient all-reduce is in flight, see below)
             st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand,
                                             with_rgb=not (self.skip_unused_color or (dist_info[0] is not None and self.overlap_comm)),
                                             keep_features=self.reuse_sampling_features and self.renderer.sample_capacity is not None,
-                                            marched=pre.get('marched'))
+                                            marched=pre.get('marched'), before_color=self._before_color_hook)
         geo = self.nerf.geo_mlp
         extra = self.DP_EXTRA if dist_info[0] is not None else 0
         sharded = self._sharded(dist_info, optimizer)
@@ -1215,13 +1222,16 @@ class NeRFScene:
                         side.wait_stream(main)                       # everything that reads the static batch has been issued
                         with torch.cuda.stream(side), torch.no_grad():
                             _copy_tree(static_pre, self._geo_prefetch(sup_pool, None, None, with_marching=True))
-                    self._after_loss_hook = produce_next
+                    if self.pipeline_marching == 2 and not self.skip_unused_color:
+                        self._before_color_hook = produce_next
+                    else:
+                        self._after_loss_hook = produce_next
                 step_fn(optimizer, sup_pool, progress=0.0)
                 if pipelined:
                     torch.cuda.current_stream().wait_stream(side)
         finally:
             self._capturing = optimizer.capturing = False
-            self._after_loss_hook = None
+            self._after_loss_hook = self._before_color_hook = None
         if count:          # (bench.py: launches per replayed step)
             if not hasattr(self, 'graph_nodes'):
                 self.graph_nodes = {}

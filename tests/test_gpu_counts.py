@@ -535,15 +535,15 @@ def test_device_rng_episode_graph_replay_equals_eager(head):
     two-phase sampler (head = 2: the counting pass writes the heads) and with the one-phase sampler bench.py uses; the serial
     capture gives the same bits, and the draw of the batch nobody consumed at the end of the phase is taken back."""
     res = {}
-    for mode in ('eager', 'graph', 'graph_serial'):
+    for mode in ('eager', 'graph', 'graph_early', 'graph_serial'):       # (graph_early: the fork sits before the colour field's encode)
         scene, pool, rays, dist, rgb = _room_scene(batch=1024)
         assert scene.device_rng
         scene.renderer.head_samples = head
         scene.graph_steps = (mode != 'eager')
-        scene.pipeline_marching = (mode != 'graph_serial')
+        scene.pipeline_marching = {'graph_serial': 0, 'graph_early': 2}.get(mode, 1)
         scene.train_one_episode(pool, 12, 8)
         assert scene._geo_pre is None
         res[mode] = (scene.nerf.geo_mlp.params.detach().clone(), scene.nerf.app_mlp.params.detach().clone(), int(scene._rng_counter.item()))
-    assert res['eager'][2] == res['graph'][2] == res['graph_serial'][2] == 20
-    for mode in ('graph', 'graph_serial'):
+    assert res['eager'][2] == res['graph'][2] == res['graph_early'][2] == res['graph_serial'][2] == 20
+    for mode in ('graph', 'graph_early', 'graph_serial'):
         assert torch.equal(res['eager'][0], res[mode][0]) and torch.equal(res['eager'][1], res[mode][1]), mode
