@@ -585,6 +585,37 @@ constexpr int kCodeSamplesPerBlock = 256;
 //  What an owner costs is the drain: gather 20 B per queued sample, ~95 instructions and two 64-bit LDS atomics per
 //  combination; tests, gathers and LDS are within 2x of each other, so removing one of them moves little.)
 
+// The tile code of sample (x, y, z) at level l (see tile_codes_kernel); bad: the premise of the code does not hold.
+__device__ __forceinline__ uint32_t tile_code_of(const GridParams& gp, const TileParams& tp, int l, float x, float y, float z, bool& bad) {
+    const float py = grid_pos(y, gp.scale[l]), pz = grid_pos(z, gp.scale[l]);
+    const uint32_t gy = (uint32_t)(int32_t)floorf(py), gz = (uint32_t)(int32_t)floorf(pz);
+    const uint32_t gx = (uint32_t)(int32_t)floorf(grid_pos(x, gp.scale[l]));
+    uint32_t code = 0u;
+    if (gp.hashed[l]) {
+        const uint32_t ay0 = gy * kPrimeY, ay1 = ay0 + kPrimeY, az0 = gz * kPrimeZ, az1 = az0 + kPrimeZ;
+        const uint32_t m = gp.size[l] - 1u;
+        code = (((ay0 ^ az0) & m) / (uint32_t)kTileEntries) | ((((ay1 ^ az0) & m) / (uint32_t)kTileEntries) << 8) |
+               ((((ay0 ^ az1) & m) / (uint32_t)kTileEntries) << 16) | ((((ay1 ^ az1) & m) / (uint32_t)kTileEntries) << 24);
+        // a position so far outside the unit cube that its x-corners leave the first 16384 columns breaks
+        // "(y,z) decides the tile"
+        bad = gx >= (uint32_t)(kTileEntries - 1);
+    } else {
+        // dense level: byte = tile of the x0 corner, bit 7 set when the x1 corner sits in the next chunk (= next
+        // tile); 0x7f (no tile) when the pair would wrap past the end of the level
+        const uint32_t res = gp.res[l], r2 = res * res, tmask = (uint32_t)tp.tiles_of[l] - 1u;
+        bad = false;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t i0 = gx + (gy + (uint32_t)(c & 1)) * res + (gz + (uint32_t)(c >> 1)) * r2, i1 = i0 + 1u;
+            uint32_t b = 0x7fu;
+            if (i1 >= gp.size[l] || i1 == 0u) bad = true;
+            else b = ((i0 / kChunk) & tmask) | ((((i1 / kChunk) & tmask) != ((i0 / kChunk) & tmask)) ? 0x80u : 0u);
+            code |= b << (8 * c);
+        }
+    }
+    return code;
+}
+
 __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
                                                          const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
                                                          uint32_t* __restrict__ escape, int64_t n,
@@ -600,33 +631,8 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
         for (int l = 0; l < gp.n_levels; ++l) {
             const int slot = tp.code_slot[l];
             if (slot < 0) continue;
-            const float py = grid_pos(y, gp.scale[l]), pz = grid_pos(z, gp.scale[l]);
-            const uint32_t gy = (uint32_t)(int32_t)floorf(py), gz = (uint32_t)(int32_t)floorf(pz);
-            const uint32_t gx = (uint32_t)(int32_t)floorf(grid_pos(x, gp.scale[l]));
-            uint32_t code = 0u;
             bool bad;       // the premise of the code does not hold for this sample
-            if (gp.hashed[l]) {
-                const uint32_t ay0 = gy * kPrimeY, ay1 = ay0 + kPrimeY, az0 = gz * kPrimeZ, az1 = az0 + kPrimeZ;
-                const uint32_t m = gp.size[l] - 1u;
-                code = (((ay0 ^ az0) & m) / (uint32_t)kTileEntries) | ((((ay1 ^ az0) & m) / (uint32_t)kTileEntries) << 8) |
-                       ((((ay0 ^ az1) & m) / (uint32_t)kTileEntries) << 16) | ((((ay1 ^ az1) & m) / (uint32_t)kTileEntries) << 24);
-                // a position so far outside the unit cube that its x-corners leave the first 16384 columns breaks
-                // "(y,z) decides the tile"
-                bad = gx >= (uint32_t)(kTileEntries - 1);
-            } else {
-                // dense level: byte = tile of the x0 corner, bit 7 set when the x1 corner sits in the next chunk (= next
-                // tile); 0x7f (no tile) when the pair would wrap past the end of the level
-                const uint32_t res = gp.res[l], r2 = res * res, tmask = (uint32_t)tp.tiles_of[l] - 1u;
-                bad = false;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t i0 = gx + (gy + (uint32_t)(c & 1)) * res + (gz + (uint32_t)(c >> 1)) * r2, i1 = i0 + 1u;
-                    uint32_t b = 0x7fu;
-                    if (i1 >= gp.size[l] || i1 == 0u) bad = true;
-                    else b = ((i0 / kChunk) & tmask) | ((((i1 / kChunk) & tmask) != ((i0 / kChunk) & tmask)) ? 0x80u : 0u);
-                    code |= b << (8 * c);
-                }
-            }
+            const uint32_t code = tile_code_of(gp, tp, l, x, y, z, bad);
             if ((tp.code16_levels >> l) & 1u) {
                 // <= 16 tiles: a nibble per combination, two samples per dword -- an owner tests both with four
                 // bit-parallel operations (bwd_stream_codes<.., CODE16>) and streams half the bytes
@@ -645,6 +651,67 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
     if (esc) atomicOr(&esc_block, esc);
     __syncthreads();
     if (threadIdx.x == 0) escape[blockIdx.x] = esc_block;       // every word is written: no zero-fill needed
+}
+
+// The same codes, four consecutive samples per thread: 48 bytes of positions in three 16-byte loads and one 16-byte store per
+// level instead of four 4-byte ones (the byte-code kernel spent most of a wave's life queueing stores: 16 per sample).  A wave
+// covers the 256 samples of one escape word.  32-bit codes only (the 16-bit variant keeps the kernel above).
+__global__ __launch_bounds__(256) void tile_codes4_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
+                                                          const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
+                                                          uint32_t* __restrict__ escape, int64_t n, int64_t n_words,
+                                                          const int64_t* __restrict__ n_dev) {
+    const int64_t n_live = live_count(n, n_dev);
+    __shared__ uint32_t esc_w[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) esc_w[wave] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t word = (int64_t)blockIdx.x * 4 + wave;
+    if (word >= n_words) return;                            // (whole waves leave)
+    const int64_t i0 = word * kCodeSamplesPerBlock + 4 * lane;
+    uint32_t esc = 0u;
+    if (i0 < n_live) {
+        const int cnt = (n_live - i0) < 4 ? (int)(n_live - i0) : 4;
+        float p[12];
+        if (cnt == 4 && (reinterpret_cast<uintptr_t>(x01) & 15) == 0) {
+            const float4 a = reinterpret_cast<const float4*>(x01 + 3 * i0)[0], b = reinterpret_cast<const float4*>(x01 + 3 * i0)[1],
+                         c = reinterpret_cast<const float4*>(x01 + 3 * i0)[2];
+            p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z; p[7] = b.w;
+            p[8] = c.x; p[9] = c.y; p[10] = c.z; p[11] = c.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = i0 + (k < cnt ? k : cnt - 1);
+                p[3 * k] = x01[3 * i]; p[3 * k + 1] = x01[3 * i + 1]; p[3 * k + 2] = x01[3 * i + 2];
+            }
+        }
+        for (int l = 0; l < gp.n_levels; ++l) {
+            const int slot = tp.code_slot[l];
+            if (slot < 0) continue;
+            uint32_t code[4];
+            bool bad[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) code[k] = tile_code_of(gp, tp, l, p[3 * k], p[3 * k + 1], p[3 * k + 2], bad[k]);
+            uint32_t* row = codes + (int64_t)slot * tp.n_pad + i0;
+            if (cnt == 4) {
+                *reinterpret_cast<uint4*>(row) = make_uint4(code[0], code[1], code[2], code[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cnt) row[k] = code[k];
+            }
+            if (gp.hashed[l]) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (bad[k] && k < cnt) {   // harmless without gradient; with gradient the level's owners take the generic path
+                        const float2 g = dfeat[(int64_t)l * n + i0 + k];
+                        if (!(g.x == 0.f && g.y == 0.f)) esc |= 1u << l;
+                    }
+            }
+        }
+    }
+    if (esc) atomicOr(&esc_w[wave], esc);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) escape[word] = esc_w[wave];              // every word is written: no zero-fill needed
 }
 
 // ---- levels of 256..2048 tiles (log2_hashmap_size 22..25): per-tile bitmaps ---------------------------------------
@@ -2005,8 +2072,13 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         workspace_bytes >= codes_at + (int64_t)slots * tp.n_pad * 4 + esc_words * 4) {
         codes = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + codes_at);
         escape = codes + (int64_t)slots * tp.n_pad;
-        tile_codes_kernel<<<dim3((unsigned)esc_words), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
-                                                                                             codes, escape, n, n_dev);
+        static const bool kCodes4 = []() { const char* e = getenv("PERF_BWD_CODES4"); return !(e && e[0] == '0'); }();
+        if (kCodes4 && tp.code16_levels == 0u && (reinterpret_cast<uintptr_t>(codes) & 15) == 0)
+            tile_codes4_kernel<<<dim3((unsigned)div_up(esc_words, 4)), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
+                                                                                                            codes, escape, n, esc_words, n_dev);
+        else
+            tile_codes_kernel<<<dim3((unsigned)esc_words), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
+                                                                                                 codes, escape, n, n_dev);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(codes)");
     } else {
         for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.code_slot[l] = -1;
