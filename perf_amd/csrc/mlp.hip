@@ -522,14 +522,8 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
         u32x4 dyb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) dyb[i] = T16::pack(dy[2 * i], dy[2 * i + 1]);
-        // ---- dH_last = Wo^T dY, masked
-        u32x4 dhl[4];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            f32x16 d = T16::mfma(frag[(L::f_aot + m) * 64 + lane], dyb, f32x16{0});
-            pack_pred<T16>(d, pos + 16 * m, dhl[2 * m], dhl[2 * m + 1]);
-        }
-        // ---- weight gradient of the output layer: dWo[16 x 64] += dY * Hlast^T
+        // ---- the transposes of the output layer's weight gradient (dWo[16 x 64] += dY * Hlast^T) go to LDS FIRST: the
+        //      products below do not need them and cover the round trip
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {   // dY rows d_row(2i,h), d_row(2i+1,h) -> tile A rows 0..15
@@ -537,6 +531,14 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
             tA[d_row(2 * i + 1, h) * kPitch + c] = (uint16_t)(dyb[i] >> 16);
         }
         lds_put_hidden(tB, hlast, c, h);
+        __builtin_amdgcn_wave_barrier();
+        // ---- dH_last = Wo^T dY, masked
+        u32x4 dhl[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f32x16 d = T16::mfma(frag[(L::f_aot + m) * 64 + lane], dyb, f32x16{0});
+            pack_pred<T16>(d, pos + 16 * m, dhl[2 * m], dhl[2 * m + 1]);
+        }
         __builtin_amdgcn_wave_barrier();
         {   // operands of the 16x16x32 form: lane (row lane & 15, k-block lane >> 4) holds samples 8 * (lane >> 4) .. + 7
             const int r16 = lane & 15, kb = lane >> 4;
@@ -573,6 +575,18 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
 #pragma unroll
             for (int s = 0; s < 4; ++s) dh1[s] = dhl[s];
         }
+        // ---- the transposes of dW1[64 x n_in_pad] += dH1 * X^T first, the dX products and stores cover their round trip
+        __builtin_amdgcn_wave_barrier();
+        lds_put_hidden(tA, dh1, c, h);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = 2 * (8 * s + 2 * i + h);
+                tB[ch * kPitch + c] = (uint16_t)(b1[s][i] & 0xffffu);
+                tB[(ch + 1) * kPitch + c] = (uint16_t)(b1[s][i] >> 16);
+            }
+        __builtin_amdgcn_wave_barrier();
         // ---- dX = W1^T dH1 (rows = input features in natural order 2*level+feat)
         if (FAST || dfeat != nullptr) {         // (the launcher sends a call without dfeat to the kernel without FAST)
 #pragma unroll
@@ -601,17 +615,7 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
                 }
             }
         }
-        // ---- dW1[64 x n_in_pad] += dH1 * X^T
-        __builtin_amdgcn_wave_barrier();
-        lds_put_hidden(tA, dh1, c, h);
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ch = 2 * (8 * s + 2 * i + h);
-                tB[ch * kPitch + c] = (uint16_t)(b1[s][i] & 0xffffu);
-                tB[(ch + 1) * kPitch + c] = (uint16_t)(b1[s][i] >> 16);
-            }
+        // ---- dW1
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < 2; ++s)
