@@ -1406,6 +1406,11 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_unfix_kernel(GridParams gp, 
     }
 }
 
+__host__ __device__ inline int reduce_blocks_of(uint32_t size, int width) {
+    const uint32_t want = (size + 1023u) / 1024u;
+    return (int)(want < (uint32_t)width ? (want > 0u ? want : 1u) : (uint32_t)width);
+}
+
 // sum the replica slabs (ws[level][replica][entry]) of the replicated (coarse) levels into the gradient table; the
 // workgroup that finishes last applies the headroom feedback (hr_state: [adjustments][largest fields][done counter])
 __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp, TileParams tp, const float2* __restrict__ ws,
@@ -1417,12 +1422,15 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp,
     // (rows of levels without replicas have nothing to add up: they leave at once, without a ticket -- same-address atomics
     //  retire at ~11 ns each; with no replicated level at all, workgroup (0, 0) applies the feedback)
     if (R <= 1 && !(n_ticket_blocks == 0 && blockIdx.x == 0 && blockIdx.y == 0)) return;
+    // a replicated level takes one workgroup per 1,024 entries (at most the grid's width): the smallest ones must not pay -- in
+    // tickets -- for the width the largest one needs (reduce_blocks_of() is what the host counted)
+    if (R > 1 && (int)blockIdx.x >= reduce_blocks_of(gp.size[l], (int)gridDim.x)) return;
     int sink = 0;
     if (R > 1) {
         const uint32_t size = gp.size[l];
         const float from_fixed = fixed ? ldexpf(1.0f, -shifts[l]) : 1.0f;
         int32_t field_max = 0;
-        const uint32_t stride = gridDim.x * 256;
+        const uint32_t stride = (uint32_t)reduce_blocks_of(size, (int)gridDim.x) * 256;
         if (fixed) {
             // Four entries x four slabs per round trip: a thread of the largest replicated level owns a dozen entries, and
             // written as "for entry: for slab: load, add" every one of its 4 R loads was a round trip of its own (14 us for a
@@ -2125,12 +2133,12 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     }
     const bool adapt = level_absmax && headroom_state && (n_blocks > 0 || (tp.atomic_levels && n > 0 && !accumulate));
     if (ws_entries > 0 || adapt) {      // replica sums, and the headroom feedback by the last workgroup
-        int n_rep = 0;
-        for (int l = 0; l < gp.n_levels; ++l) n_rep += tp.replicas_of[l] > 1 ? 1 : 0;
-        static const int kReduceBlocks = []() { const char* e = getenv("PERF_BWD_REDUCE_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 1024 ? v : 32; }();
+        static const int kReduceBlocks = []() { const char* e = getenv("PERF_BWD_REDUCE_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 1024 ? v : 64; }();
+        int n_tickets = 0;
+        for (int l = 0; l < gp.n_levels; ++l) n_tickets += tp.replicas_of[l] > 1 ? reduce_blocks_of(gp.size[l], kReduceBlocks) : 0;
         hashgrid_bwd_reduce_kernel<<<dim3(kReduceBlocks, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
             gp, tp, (const float2*)workspace, (float2*)grad_table, adapt ? headroom_state : nullptr,
-            shifts_dev ? shifts_dev : shifts_ws, fixed ? 1 : 0, overflow_flag, n_rep * kReduceBlocks);
+            shifts_dev ? shifts_dev : shifts_ws, fixed ? 1 : 0, overflow_flag, n_tickets);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(reduce)");
     }
     return PERF_OK;
