@@ -192,8 +192,10 @@ class OccGridEstimator(nn.Module):
           on the first `head_samples` samples of every ray and then only on the rest of the rays that are still alive (a
           trained scene terminates a ray after a sample or two); same samples, same sigmas as the one-phase path.
           n_marched_dev then counts the samples whose density was evaluated.
-        sigma_points_fn may return (sigmas, feat): the level-major encoded features of its density pass are then compacted
-          along with the samples (Samples.feat) so that a gradient pass on the kept samples need not encode them again.
+        sigma_points_fn may return (sigmas, feat): the level-major encoded features of its density pass then travel with the
+          samples (Samples.feat) so that a gradient pass on the kept samples need not encode them again -- compacted along
+          (two-phase sampler) or, from the one-phase sampler, as an ops.IndexedFeat: the uncompacted array plus the row of
+          every kept sample, which ops.mlp_bwd reads in place (.materialize() gives the compacted copy; PERF_INDEX_FEATURES=0).
         lattice: 'repeated' (t_{k+1} = fl(t_k + step), the default: None) or 'single' (t_k = fl(t0 + fl(k step))): PERF_LATTICE_*.
         march_only / marched (sync-free mode): the marching -- everything that does not depend on the density field -- as a stage
           of its own.  march_only=True returns its record (a tuple of tensors and host scalars) instead of Samples; a later call
