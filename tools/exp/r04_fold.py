@@ -13,13 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 SRC = os.path.join(ROOT, 'gpurun_out', 'r04')
 DST = os.path.join(ROOT, 'profiles')
 RAW = os.path.join(DST, 'r04_raw')
-KERNELS = ['march_write_kernel', 'hashgrid_fwd_v2_kernel', 'hashgrid_fwd_kernel', 'hashgrid_bwd_kernel', 'tile_codes_kernel', 'hashgrid_bwd_reduce_kernel',
-           'mlp_fwd_kernel', 'mlp_bwd_kernel', 'mlp_reduce_kernel', 'adam_kernel', 'march_count_kernel', 'compact_prefix_kernel',
+KERNELS = ['march_write_kernel', 'hashgrid_fwd_v2_kernel', 'hashgrid_fwd_kernel', 'hashgrid_bwd_kernel', 'tile_codes4_kernel', 'tile_codes_kernel', 'hashgrid_bwd_reduce_kernel',
+           'mlp_fwd_kernel', 'mlp_bwd_kernel', 'mlp_reduce_kernel', 'adam4_kernel', 'adam_kernel', 'march_count_kernel', 'compact_prefix_kernel',
            'composite_distloss_fwd_kernel', 'composite_distloss_bwd_kernel']
 MLP_ENTRY = {'mlp_fwd_kernel': 'perf_mlp_fwd', 'mlp_bwd_kernel': 'perf_mlp_bwd'}
-ENTRY = {'hashgrid_bwd_kernel': 'perf_hashgrid_bwd', 'tile_codes_kernel': 'perf_hashgrid_bwd', 'hashgrid_bwd_reduce_kernel': 'perf_hashgrid_bwd',
+ENTRY = {'hashgrid_bwd_kernel': 'perf_hashgrid_bwd', 'tile_codes_kernel': 'perf_hashgrid_bwd', 'tile_codes4_kernel': 'perf_hashgrid_bwd', 'hashgrid_bwd_reduce_kernel': 'perf_hashgrid_bwd',
          'hashgrid_fwd_v2_kernel': 'perf_hashgrid_fwd', 'hashgrid_fwd_kernel': 'perf_hashgrid_fwd', 'mlp_bwd_kernel': 'perf_mlp_bwd',
-         'mlp_reduce_kernel': 'perf_mlp_bwd', 'mlp_fwd_kernel': 'perf_mlp_fwd', 'adam_kernel': 'perf_adam_step_dev'}
+         'mlp_reduce_kernel': 'perf_mlp_bwd', 'mlp_fwd_kernel': 'perf_mlp_fwd', 'adam_kernel': 'perf_adam_step_dev', 'adam4_kernel': 'perf_adam_step_dev'}
 
 
 def kname(full):
