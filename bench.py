@@ -89,6 +89,9 @@ def parse():
     ap.add_argument('--no-render-block', action='store_true', help='skip the full-panorama inference measurement (`render` block)')
     ap.add_argument('--no-config4', action='store_true', help='skip the render_dense traverse (`config4` block)')
     ap.add_argument('--config4-poses', type=int, default=600, help='BASELINE config 4: poses of the dense trajectory')
+    ap.add_argument('--no-config5', action='store_true', help='skip the BASELINE config 5 panorama (`config5` block)')
+    ap.add_argument('--config5-log2', type=int, nargs='*', default=[28, 30],
+                    help='BASELINE config 5: log2 of the hashed levels\' table size(s); the whole 4096x2048x256 panorama is rendered once per size')
     ap.add_argument('--no-reuse-line', action='store_true', help='skip the extra measurement with the other setting of NeRFScene.reuse_sampling_features')
     ap.add_argument('--psnr-geo-iters', type=int, default=3000, help='configs/nerf.yaml:25 raw_phase_iter_geo')
     ap.add_argument('--psnr-app-iters', type=int, default=1500, help='configs/nerf.yaml:26 raw_phase_iter_app')
@@ -302,6 +305,31 @@ def config4_block(args, dev, scene, extras, n_poses=600):
                     'last_frame_rgb_sum': float(last['rgb'].double().sum())}
     one = out['frame_as_one_batch']
     out['wall_s_600_frames_including_sampler'] = round(one['seconds'] * len(poses) / one['frames'] + extras.get('dense_start_s', 0.0) + t_wait, 4)
+    return out
+
+
+def config5_block(args):
+    """BASELINE config 5 as far as ONE GPU goes (the run the >= 50 % HBM criterion is judged on): the whole
+    4096x2048 panorama x 256 samples per ray through both L = 20 fields whose 16-bit tables exceed every cache (T = 2^28: 9.2 GiB
+    per encoder; 2^30: 31 GiB, 64-bit entry offsets), NeRFOCCRenderer.render per batch of 4 rows, + compositing.  Per table size:
+    ray-samples/s and the encode kernel's algorithmic and MOVED fraction of the HBM peak (the latter from the committed
+    rocprofv3 PMC pass of the same batches, profiles/r05_config5_pmc.json).  tests/test_gpu_config5.py checks the same workload
+    through size-independent properties."""
+    from tools import config5 as C
+    pmc = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r05_config5_pmc.json')))
+    except Exception:      # noqa: BLE001
+        pass
+    out = {}
+    for log2_t in args.config5_log2:
+        torch.cuda.empty_cache()
+        free, _total = torch.cuda.mem_get_info()
+        need = 2 * (C.LEVELS5 << (log2_t + 2)) + (8 << 30)            # upper bound: two encoders of L x 2^T entries x 2 x 2 B, + working set
+        if need > free:
+            out[f'T{log2_t}'] = {'skipped': f'needs ~{need >> 30} GiB, {free >> 30} GiB free'}
+            continue
+        out[f'T{log2_t}'] = C.render_panorama_block(log2_t, pmc=pmc)
     return out
 
 
@@ -671,6 +699,9 @@ def main():
             notes.append(f'PSNR episode failed ({type(e).__name__}: {e})')
     if world == 1 and not args.no_render_block and args.mode == 'train_geo':
         render_blk = render_block(args, dev, rays)
+    config5_blk = None
+    if world == 1 and not args.no_config5 and args.mode == 'train_geo' and args.config5_log2:
+        config5_blk = config5_block(args)
     if watchdog is not None:
         watchdog.cancel()
 
@@ -680,7 +711,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.spp, args.cpu_rays)
         line = _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other_block, psnr_block, cpu=cpu, notes=notes,
-                     late=(kern_late, ev_late), blocks={'faithful': faithful_block, 'render': render_blk, 'config4': config4_blk, 'comm': comm_block})
+                     late=(kern_late, ev_late), blocks={'faithful': faithful_block, 'render': render_blk, 'config4': config4_blk, 'config5': config5_blk, 'comm': comm_block})
     # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which a pipe buffers until the
     # process exits -- every rank flushes it out first, then rank 0 prints.
     _flush_native_stdout()

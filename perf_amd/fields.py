@@ -135,6 +135,61 @@ class NGPNeRF(nn.Module):
         self.geo_mlp = _DensityNet(_grid_cfg(16), dtype=self.dtype_name)
 
 
+class InferenceNeRF:
+    """NGPNeRF for inference only, for fields whose tables are sized to HBM (BASELINE config 5: L = 20, log2_hashmap_size
+    28-30; SURVEY.md 8(e): "inference-only replicated fp16"): each network exists ONLY as its 16-bit working copy
+    [MLP weights | table] -- no fp32 master, no optimizer state -- and is initialised on the device (tcnn's rule: Xavier-uniform
+    MLP weights, tables U(-1e-4, 1e-4); the 10^9-entry tables are filled in chunks from a seeded device generator).  The duck
+    type NeRFOCCRenderer uses (density_at / rgb_at / sample_points on kernel-made positions), like sharded.LevelShardedNeRF."""
+
+    def __init__(self, aabb, n_levels=20, log2_hashmap_size=28, per_level_scale=PER_LEVEL_SCALE, dtype='fp16', seed=tcnn.DEFAULT_SEED,
+                 table_scale=1e-4, device=None):
+        from .grid import GridConfig, MlpConfig
+        import math
+        if not isinstance(aabb, torch.Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.aabb = aabb.float().to(dev)
+        self._aabb_host = [float(v) for v in aabb.reshape(-1).tolist()]
+        self.training = False
+        self.dtype_name = dtype
+        self.grid = GridConfig(n_levels=n_levels, log2_hashmap_size=log2_hashmap_size, base_resolution=16, per_level_scale=per_level_scale)
+        t16 = ops.torch_dtype(dtype)
+        self.nets = {}
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        cg = torch.Generator().manual_seed(seed)
+        for name, mlp in (('geo_mlp', MlpConfig(n_levels, 1, 1, 'Exponential')), ('app_mlp', MlpConfig(n_levels, 2, 3, 'Sigmoid'))):
+            n_net = mlp.n_params
+            w16 = torch.empty(n_net + self.grid.n_params, dtype=t16, device=dev)
+            parts = [(torch.rand(o * i, generator=cg) * 2 - 1) * math.sqrt(6.0 / (i + o)) for (o, i) in mlp.shapes]
+            w16[:n_net].copy_(torch.cat(parts))
+            chunk = 1 << 28
+            for lo in range(n_net, w16.numel(), chunk):
+                hi = min(lo + chunk, w16.numel())
+                w16[lo:hi].copy_((torch.rand(hi - lo, device=dev, generator=gen) * 2 - 1) * table_scale)
+            self.nets[name] = (mlp, w16)
+
+    def eval(self):
+        return self
+
+    def table_bytes(self):
+        """Bytes of ONE encoder's 16-bit table."""
+        return self.grid.n_params * 2
+
+    @torch.no_grad()
+    def density_at(self, x01, sel, n_dev=None):
+        mlp, w16 = self.nets['geo_mlp']
+        return ops.field_infer(self.grid, mlp, x01, sel, w16, n_dev=n_dev)[:, 0]
+
+    @torch.no_grad()
+    def rgb_at(self, x01, sel, n_dev=None):
+        mlp, w16 = self.nets['app_mlp']
+        return ops.field_infer(self.grid, mlp, x01, sel, w16, n_dev=n_dev)
+
+    def sample_points(self, rays_o, rays_d, ray_indices, t_starts, t_ends):
+        return ops.points_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, self._aabb_host)
+
+
 class NGPDensityField(nn.Module):
     """Proposal density field (ngp_nerf.py:200-265): sigma = trunc_exp(net(x) - 1) * selector."""
 

@@ -169,25 +169,35 @@ def test_rccl_exchange_on_a_world_of_one(tmp_path, units):
     assert res['rccl']['counters'][4] == 0 and res['rccl']['counters'][5] == 0
 
 
-def test_bench_launches_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2` without a launcher (what the driver's scaling run does): bench.py spawns the ranks itself.
-    Two ranks share this box's one GPU over gloo (PERF_BENCH_ONE_DEVICE / PERF_BENCH_BACKEND); the line carries the weak
-    headline and the strong-scaling block of BASELINE config 3."""
+@pytest.mark.parametrize('n_ranks', [2, 8])
+def test_bench_launches_its_own_ranks(tmp_path, n_ranks):
+    """`python bench.py --gpus N` without a launcher (what the driver's scaling run does): bench.py spawns the ranks itself.
+    N = 2 and N = 8 (the node the scaling run uses) ranks share this box's one GPU over gloo (PERF_BENCH_ONE_DEVICE /
+    PERF_BENCH_BACKEND): a dry run of the whole N > 1 line -- argument plumbing, the eager headline, the strong-scaling block of
+    BASELINE config 3, `comm`, the data-parallel PSNR episode -- so that the first contact with an 8-GPU node cannot die in
+    anything but RCCL itself."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT, PERF_BENCH_ONE_DEVICE='1', PERF_BENCH_BACKEND='gloo')
     env.pop('WORLD_SIZE', None); env.pop('RANK', None)
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--rays-per-gpu', '1024',
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n_ranks), '--steps', '3', '--warmup', '1', '--rays-per-gpu', '1024',
            '--sustain-seconds', '0', '--psnr-geo-iters', '40', '--psnr-app-iters', '30', '--height', '128', '--width', '256']
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['n_gpus'] == n_ranks and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['metric'].startswith('ray-samples/sec') and line['unit'] == 'ray-samples/s' and line['higher_is_better'] is True
+    assert line['steps'] == 3 and line['warmup'] == 1 and line['ms_per_step'] > 0 and line['data'] == 'synthetic'
     assert line['config']['rays_per_gpu_per_step'] == 1024 and line['config']['launch'] == 'eager'      # (gloo: no graph capture)
+    assert f'dp{n_ranks}' in line['config']['parallelism'] and abs(line['config']['per_gpu_value'] * n_ranks - line['value']) < 1e-6 * line['value']
+    assert line['config']['kept_samples_per_gpu_per_step'] > 0
     assert line['strong']['scaling'] == 'strong' and line['strong']['global_batch_rays'] == 1024 and line['strong']['value'] > 0
-    assert line['strong']['rays_per_gpu_per_step'] == 512
+    assert line['strong']['rays_per_gpu_per_step'] == 1024 // n_ranks
     assert line['psnr'] is not None and line['health'] == {'skipped_for_overflow': 0, 'skipped_for_truncation': 0}
+    assert set(line['psnr']['curve']) == {'app_iter_0', 'app_iter_10', 'app_iter_30'} and line['psnr']['launch'] == 'eager'
+    assert not any(' failed (' in n for n in line.get('notes', [])), line.get('notes')          # no optional measurement fell over
+    assert line['roofline'] is not None and line['roofline']['kernel'] in ('perf_hashgrid_fwd', 'perf_hashgrid_bwd') and 0 < line['roofline']['frac'] < 1
     # the `comm` block a reader attributes a missed scaling target with: per-collective times of the sharded exchange, the plain
     # single-GPU step on the same per-rank workload, the difference, and the single all-reduce exchange for comparison
     comm = line['comm']

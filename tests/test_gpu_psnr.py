@@ -62,3 +62,41 @@ def test_psnr_at_iter_matches_the_oracle_curve():
     for k, vs in geo_ratio.items():
         assert 0.93 <= float(np.mean(vs)) <= 1.07 and all(0.85 <= v <= 1.15 for v in vs), (k, vs)
     assert all(abs(v) < 5e-3 for v in opacity), opacity
+
+
+def test_data_parallel_psnr_at_iter_matches_the_oracle_curve(tmp_path):
+    """`north_star` asks for scaling AND "PSNR within 0.1 dB after equal iterations".  The data-parallel DEFAULT (sharded
+    exchange with lagged fixed-point units, perf_amd/dp.py) is not bit-identical to the single process, so it replays the
+    oracle's schedule itself: two ranks on this box's one GPU (gloo), each taking its half of every golden batch and of the
+    batch's random draws -- three seeds of tests/golden/psnr_curve.json (a step costs ~50 ms through gloo's host copies): the
+    mean of (data-parallel HIP - fp32 oracle) within 0.1 dB at both marks, single seeds within 0.35 dB, the geometry phase's
+    learning curve on the oracle's, no step skipped by the job-wide gate."""
+    import subprocess
+    import sys
+    golden = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'psnr_curve.json')))
+    cfg = golden['config']
+    seeds = [row['seed'] for row in golden['seeds']][:3]
+    out = str(tmp_path / 'dp_psnr.json')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
+    env.pop('PERF_DP_UNITS', None)
+    import socket
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'psnr_dp_worker.py'), out] + [str(s) for s in seeds]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.load(open(out))
+    assert res['world'] == 2 and sorted(res['curves']) == sorted(str(s) for s in seeds)
+    rows = {str(row['seed']): row['oracle'] for row in golden['seeds']}
+    deltas = {f'psnr@app{m}': [res['curves'][str(s)][f'psnr@app{m}'] - rows[str(s)][f'psnr@app{m}'] for s in seeds] for m in cfg['marks']}
+    print('data-parallel (2 ranks, lagged units) HIP - oracle PSNR [dB]:', {k: [round(v, 3) for v in vs] for k, vs in deltas.items()})
+    for k, vs in deltas.items():
+        assert abs(float(np.mean(vs))) <= 0.1, (k, vs)
+        assert max(abs(v) for v in vs) <= 0.35, (k, vs)
+    for k in cfg.get('geo_marks', []):
+        ratio = [res['curves'][str(s)][f'geo_depth_loss@{k}'] / rows[str(s)][f'geo_depth_loss@{k}'] for s in seeds]
+        assert 0.93 <= float(np.mean(ratio)) <= 1.07 and all(0.85 <= v <= 1.15 for v in ratio), (k, ratio)
+    for s in seeds:
+        c = res['curves'][str(s)]
+        assert c['skipped_for_overflow'] == 0 and c['skipped_for_truncation'] == 0, c
+        assert abs(c['geo_end_opacity'] - rows[str(s)]['geo_end_opacity']) < 5e-3
