@@ -89,6 +89,7 @@ def parse():
     ap.add_argument('--no-render-block', action='store_true', help='skip the full-panorama inference measurement (`render` block)')
     ap.add_argument('--no-config4', action='store_true', help='skip the render_dense traverse (`config4` block)')
     ap.add_argument('--config4-poses', type=int, default=600, help='BASELINE config 4: poses of the dense trajectory')
+    ap.add_argument('--no-train-app', action='store_true', help='skip the colour-phase training step at bench scale (`train_app` block)')
     ap.add_argument('--no-config5', action='store_true', help='skip the BASELINE config 5 panorama (`config5` block)')
     ap.add_argument('--config5-log2', type=int, nargs='*', default=[28, 30],
                     help='BASELINE config 5: log2 of the hashed levels\' table size(s); the whole 4096x2048x256 panorama is rendered once per size')
@@ -414,8 +415,9 @@ def main():
     pool = SupInfoPool()
     pool.register_rays(rays.o, rays.d, rgb_map, dist_map)
 
-    def build(reuse_features, scaling, graph=True, dp_mode=None):
+    def build(reuse_features, scaling, graph=True, dp_mode=None, mode=None):
         """Fresh scene + optimizer + (graphed) step of the benchmark workload -> dict(scene, step, eager_step, rays_per_step, graphed)."""
+        mode = mode or args.mode
         torch.manual_seed(0)                                              # the same random streams on every rank (scene.py)
         scene = NeRFScene(dtype=args.dtype)
         tc = scene.train_conf
@@ -442,14 +444,14 @@ def main():
         # samples, so the two-phase early-terminating sampler (renderer.head_samples, the default of training / eval on real
         # scenes) would only add launches here
         r.head_samples = None
-        rays_per_step = rays_local if args.mode != 'render' else 32768
+        rays_per_step = rays_local if mode != 'render' else 32768
         r.sample_capacity = rays_per_step * args.spp                     # = the marched count: nothing is ever truncated
         scene.nerf.reset_geo()
         scene.sample_counters.zero_()
-        use_graph = graph and (not args.no_graph) and args.mode != 'render' and scene.dp_graph_ok()
+        use_graph = graph and (not args.no_graph) and mode != 'render' and scene.dp_graph_ok()
         graphed = None
-        if args.mode in ('train_geo', 'train_app'):
-            kind = 'geo' if args.mode == 'train_geo' else 'app'
+        if mode in ('train_geo', 'train_app'):
+            kind = 'geo' if mode == 'train_geo' else 'app'
             net = scene.nerf.geo_mlp if kind == 'geo' else scene.nerf.app_mlp
             conf = tc.geo_optimizer if kind == 'geo' else tc.app_optimizer
             n_sched = 3000.0 if kind == 'geo' else 1500.0
@@ -509,9 +511,9 @@ def main():
         c = cnt.tolist()
         return el, int(c[0]), int(c[1]), {'skipped_for_overflow': int(c[4]), 'skipped_for_truncation': int(c[5])}
 
-    def measure(reuse_features, scaling, graph=True, dp_mode=None):
+    def measure(reuse_features, scaling, graph=True, dp_mode=None, mode=None):
         """Build, W warmup steps, K timed steps -> (run, result dict)."""
-        run = build(reuse_features, scaling, graph, dp_mode)
+        run = build(reuse_features, scaling, graph, dp_mode, mode)
         for i in range(args.warmup):
             run['step'](i)
         el, marched, kept, health = timed(run, args.steps, args.warmup)
@@ -639,6 +641,27 @@ def main():
                                       if reuse_default else 'gradient pass starts from the features and densities the sampling pass computed')
                                      + '; parameters bit-identical to the headline path')
 
+    # the COLOUR phase's step (train_one_step_app, nerf.py:259-297: a third of every episode's iterations) at the same scale: the
+    # same 8192 x 128 fixed-count batch from a fresh initialisation (kept = marched), W warm-up + K timed hipGraph replays, and
+    # its own per-kernel table from an eager pass in the same state
+    app_block = None
+    if world == 1 and args.mode == 'train_geo' and not args.no_train_app and not args.no_prepass:
+        run_a, res_a = measure(reuse_default, args.scaling, mode='train_app')
+        del run_a
+        run_ak = build(reuse_default, args.scaling, graph=False, mode='train_app')
+        for i in range(args.warmup):
+            run_ak['eager_step'](i)
+        kern_a, ev_a = kernel_pass(run_ak, args.warmup)
+        del run_ak
+        table_a, _ = _kernel_table(args, kern_a, ev_a, True)
+        app_block = {'what': 'train_one_step_app (nerf.py:259-297) on the benchmark batch: batch draw -> marching -> density field WITHOUT gradient on every '
+                             'marched sample -> transmittance scan + compaction -> colour field WITH gradient (encode + 32->64->64->3 MLP) -> compositing -> '
+                             'colour smooth-L1 -> backward through compositing / MLP / hash grid -> Adam; one hipGraph replay per step',
+                     'value': res_a['value'], 'unit': 'ray-samples/s', 'ms_per_step': res_a['ms_per_step'], 'steps': res_a['steps'], 'warmup': args.warmup,
+                     'marched_samples_per_step': res_a['marched_samples_per_gpu_per_step'], 'kept_samples_per_step': res_a['kept_samples_per_gpu_per_step'],
+                     'launch': res_a['launch'], 'skipped_for_overflow': res_a['skipped_for_overflow'], 'skipped_for_truncation': res_a['skipped_for_truncation'],
+                     'kernels': table_a}
+
     other_block = None
     if world > 1 and args.mode != 'render':
         try:
@@ -711,7 +734,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.spp, args.cpu_rays)
         line = _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other_block, psnr_block, cpu=cpu, notes=notes,
-                     late=(kern_late, ev_late), blocks={'faithful': faithful_block, 'render': render_blk, 'config4': config4_blk, 'config5': config5_blk, 'comm': comm_block})
+                     late=(kern_late, ev_late), blocks={'train_app': app_block, 'faithful': faithful_block, 'render': render_blk, 'config4': config4_blk, 'config5': config5_blk, 'comm': comm_block})
     # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which a pipe buffers until the
     # process exits -- every rank flushes it out first, then rank 0 prints.
     _flush_native_stdout()
@@ -762,10 +785,10 @@ def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other
     if kern:
         table, total = _kernel_table(args, kern, ev_counts, prepass)
         dom = max((k for k in total if k in ALGO_BYTES), key=lambda k: total[k])
-        roof = {'kernel': dom, 'bound': BOUND[dom], 'achieved': table[dom]['algorithmic_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        roof = {'kernel': dom, 'bound': 'hbm', 'stalls_on': BOUND[dom], 'achieved': table[dom]['algorithmic_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': table[dom]['frac_of_hbm_peak'], 'traffic': None, 'limiter': LIMITER[dom],
-                'priced_against': 'hbm (algorithmic bytes / HBM peak, as SURVEY.md 8(d) prescribes); `bound` names what the counters '
-                                  'say limits the kernel',
+                'priced_against': 'hbm (algorithmic bytes / HBM peak, as SURVEY.md 8(d) prescribes: a gather / scatter kernel); `stalls_on` '
+                                  'names what the counters say the kernel actually waits for',
                 'algorithmic_bytes_per_ray_sample': ALGO_BYTES[dom], 'live_samples_per_launch': table[dom]['live_samples_per_launch'],
                 'ms_per_launch': table[dom]['ms_per_launch'],
                 'definition': 'achieved = algorithmic bytes (SURVEY.md 8(d), 16-bit figures) x live samples of a launch / mean launch duration '

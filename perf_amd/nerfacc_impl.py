@@ -109,6 +109,9 @@ def _lib_default_lattice():
     return _lib.DEFAULT_LATTICE
 
 
+_UPDATE_CALLS = [0]      # calls of OccGridEstimator.update_every_n_steps' warm-up branch in this process (jitter counter)
+
+
 class Samples:
     """Packed samples of one ray batch (see OccGridEstimator.sampling_ex)."""
     __slots__ = ('ray_indices', 't_starts', 't_ends', 'packed', 'sig', 'x01', 'sel', 'n_dev', 'n_marched_dev', 'feat')
@@ -381,9 +384,11 @@ class OccGridEstimator(nn.Module):
             # closure itself does (PeRF's look-up closure: ~10 passes, nerf.py:149-158) runs out of the Infinity Cache.
             if getattr(self, '_upd_seed', None) is None:
                 self._upd_seed = int(torch.initial_seed())
-                self._upd_calls = 0
                 self._upd_sum = torch.zeros(1, dtype=torch.float64, device=dev)
-            self._upd_calls += 1
+            # the jitter stream continues ACROSS estimators, like the torch.rand stream of the reference does across episodes
+            # (PeRF builds a fresh OccGridEstimator per fit, nerf.py:144): a process-wide call counter, not a per-instance one
+            _UPDATE_CALLS[0] += 1
+            self._upd_calls = _UPDATE_CALLS[0]
             self._upd_sum.zero_()
             n = self.cells_per_lvl
             occs = self.occs if self.occs.is_contiguous() else self.occs.contiguous()

@@ -12,6 +12,8 @@ process (CPU only) as soon as the anchors exist -- i.e. while the scene still tr
 sampler plus the RNG state the sequential call would have left behind; results are memoised per input key.  The frame
 loop of render_dense then starts without waiting (perf_amd/traverse.py, tools/render_dense.py reports both wall times)."""
 import hashlib
+import os
+import time
 import multiprocessing as mp
 
 import numpy as np
@@ -160,23 +162,34 @@ class DensePoseFuture:
     def done(self):
         return self._ready is not None or self.conn.poll()
 
-    TIMEOUT_S = 120.0
+    # Ceiling of the wait for a LIVING worker (a dead or failed one is noticed at once): generous and configurable -- the in-line
+    # fallback of a slow but healthy worker would pay the whole construction a second time.
+    TIMEOUT_S = float(os.environ.get('PERF_DENSE_POSES_TIMEOUT_S', '1800'))
 
     def result(self, timeout=None):
         """The sampler; numpy's global RNG is left in the state the sequential construction would have left it in.  The
         worker was forked from a process that holds HIP / RCCL / OpenMP state (a fork-after-threads hazard the single-threaded
-        child sidesteps, but cannot rule out): should it die, fail or not answer within `timeout` seconds, the trajectory is
-        built HERE, sequentially, from the RNG state saved at start() -- same poses, same RNG afterwards."""
+        child sidesteps, but cannot rule out): should it die or fail -- or still be running after `timeout` seconds (default:
+        PERF_DENSE_POSES_TIMEOUT_S, 30 min) -- the trajectory is built HERE, sequentially, from the RNG state saved at
+        start(): same poses, same RNG afterwards.  A slow but living worker is waited for (polled every 0.25 s)."""
         if self._ready is None:
             poses = rng_state = None
             why = None
+            limit = self.TIMEOUT_S if timeout is None else timeout
+            t_start = time.monotonic()
             try:
-                if self.conn.poll(self.TIMEOUT_S if timeout is None else timeout):
-                    poses, rng_state, err = self.conn.recv()
-                    if err is not None:
-                        why, poses = f'worker failed: {err}', None
-                else:
-                    why = 'worker did not answer in time'
+                while True:
+                    if self.conn.poll(0.25):
+                        poses, rng_state, err = self.conn.recv()
+                        if err is not None:
+                            why, poses = f'worker failed: {err}', None
+                        break
+                    if self.proc is not None and not self.proc.is_alive() and not self.conn.poll(0):
+                        why = 'worker died'
+                        break
+                    if time.monotonic() - t_start >= limit:
+                        why = f'worker still running after {limit:.0f} s'
+                        break
             except (EOFError, OSError) as e:
                 why = f'worker died ({type(e).__name__})'
             if self.proc is not None:

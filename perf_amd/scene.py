@@ -816,6 +816,10 @@ class NeRFScene:
             # never drop a step: should a fixed-point field have neared the int32 range (device flag), this predicated launch
             # rewrites the table gradient with fp32 LDS accumulation; a no-op dispatch otherwise (perf_hashgrid_bwd, redo_flag)
             ops.hashgrid_bwd_redo(net.grid, x01, res[0], grad[n_net:n_all], n_dev=n_dev, hr_state=net.headroom_state())
+            if not self.fused_adam:
+                # torch.optim.Adam has no perf_step_bookkeeping behind it to consume the flag: left set, every later backward
+                # would run its (slow) fp32 repair as well
+                ops.overflow_flag(x01.device).zero_()
         return grad
 
     DP_EXTRA = 3           # trailing slots of the data-parallel gradient buffer: [sample count, overflow flag, truncated]
@@ -1183,6 +1187,15 @@ class NeRFScene:
                     else:
                         step_fn(optimizer, sup_pool, progress=0.0)
             torch.cuda.current_stream().wait_stream(side)
+        if dist_info[0] is not None and self.dp_units == 'lagged':
+            # The exchange's FIRST step has no previous statistics and takes the exact path (statistics all-gather + units
+            # before the grid backward): captured, that prologue would be baked into every replay -- four collectives, and the
+            # lagged units derived at the tail overwritten by the next replay's own.  The choice is made at capture time: make
+            # sure it is the steady-state one.
+            ex = getattr(optimizer.net, '_dp_exchange', None)
+            if ex is None or ex.k.opt is not optimizer or not ex.have_units:
+                raise RuntimeError('make_graphed_step: under data parallelism with lagged units the step must have run eagerly at least once '
+                                   'with this optimizer before it is captured (warmup >= 1, or EAGER_HEAD eager iterations as _run_phase does)')
         if schedule is not None:
             lrs, ratios, first = schedule
             optimizer.load_schedule(lrs, ratios if kind == 'geo' else None, first, ratio_out=self._ratio_dev if kind == 'geo' else None)
@@ -1358,11 +1371,15 @@ class NeRFScene:
     # ---- state (nerf.py:368-395) --------------------------------------------------------------------
     _STATE_KEY = '_perf_amd'
 
-    def state_dict(self):
+    def state_dict(self, sync=True):
         """nerf.py:374-380.  Under sharded data parallelism the fp32 master of a table slice is current only on its owner:
         the replicas are refreshed first (sync_params: one all-gather per network -- a COLLECTIVE, every rank must call
-        state_dict() at the same point, as with any checkpoint of a data-parallel job)."""
-        self.sync_params()
+        state_dict() at the same point, as with any checkpoint of a data-parallel job).  The reference's own
+        `if rank == 0: save(...)`-style checkpointing on ONE rank would therefore hang: call sync_params() on every rank first
+        (train_one_episode does so at the end of each episode) and then state_dict(sync=False) on the saving rank
+        (INTEGRATION.md 3)."""
+        if sync:
+            self.sync_params()
         # The fixed-point headroom feedback of the two grid gradients makes results depend on the call history: it travels
         # with the checkpoint, under a private TOP-LEVEL key -- the reference's loader reads only 'render' / 'nerf' /
         # 'estimator' (nerf.py:368-380) and its strict nerf.load_state_dict would reject a key inside 'nerf'.
