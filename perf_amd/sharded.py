@@ -54,12 +54,15 @@ class GridSlice:
         return self.full.interpolation
 
     def desc(self):
+        if getattr(self, '_desc', None) is not None:
+            return self._desc
         d = _lib.GridDesc()
         d.n_levels = len(self.levels)
         d.interpolation = _lib.INTERP_SMOOTHSTEP if self.full.interpolation == 'Smoothstep' else _lib.INTERP_LINEAR
         for k, l in enumerate(self.levels):
             d.scale[k] = float(self.full.scale[l]); d.res[k] = int(self.full.res[l]); d.size[k] = int(self.full.size[l])
             d.offset[k] = int(self.offset[k]); d.hashed[k] = int(self.full.hashed[l])
+        self._desc = d
         return d
 
 

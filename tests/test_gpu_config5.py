@@ -4,20 +4,21 @@ offsets beyond 32 bit) -- the same workload bench.py's `config5` block times (to
 size-independent properties: packed bookkeeping (sortedness, counts), compositing bounds, determinism, and equality of a
 row shard rendered on its own with the same rows of the full render (the multi-GPU eval partitioning of SURVEY.md 8(e):
 rank r of G renders rows [r H/G, (r+1) H/G), no communication).  The fields are NOT at their fresh initialisation here
-(tables U(-0.5, 0.5)): densities vary, early termination prunes, the compaction is exercised."""
+(tables U(-4, 4)): densities vary, early termination prunes, the compaction is exercised."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 H, W, SPP = 2048, 4096, 256
+TABLE_SCALE = 4.0      # tables U(-4, 4): densities exp(+-several), rays terminate early, the compaction is exercised
 
 
 def _field(log2_t):
     from perf_amd.fields import InferenceNeRF
     from tools import config5 as C
     nerf = InferenceNeRF([-1., -1, -1, 1, 1, 1], n_levels=20, log2_hashmap_size=log2_t, per_level_scale=C.per_level_scale(20),
-                         dtype='fp16', table_scale=0.5)
+                         dtype='fp16', table_scale=TABLE_SCALE)
     est, rend = C.make_renderer(SPP)
     return nerf, est, rend
 
