@@ -99,7 +99,7 @@ template <typename T16>
 __global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, const float* __restrict__ x01,
                                                               const uint32_t* __restrict__ table,
                                                               uint32_t* __restrict__ feat, int64_t n,
-                                                              const int64_t* __restrict__ n_dev, int dedup, int rotate) {
+                                                              const int64_t* __restrict__ n_dev) {
     const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
     const int64_t nchunks_live = (n_live + 255) >> 8;
     const int64_t nchunks_grid = (int64_t)(gridDim.x >> 3);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, con
         // phase of a chunk: its position within the pass of the grid over the chunks (any function of the chunk alone keeps
         // the eight workgroups of a chunk on eight different groups)
         const int64_t in_pass = chunk % nchunks_grid, pass_len = nchunks_live < nchunks_grid ? nchunks_live : nchunks_grid;
-        const int phase = rotate ? (int)((in_pass * 8) / pass_len) & 7 : 0;
+        const int phase = (int)((in_pass * 8) / pass_len) & 7;
         const int g = (xcd + phase) & 7;
         const int64_t i = chunk * 256 + threadIdx.x;
         const bool live = i < n_live;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, con
             if (lv[pass] < 0) continue;
             const int l = lv[pass];
             c[pass] = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
-            if (dedup) {
+            {
                 // lane - 1's cell through DPP (wave_shr:1; lane 0 keeps the `old` operand)
                 const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[0], 0x138, 0xf, 0xf, false);
                 const uint32_t py = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[1], 0x138, 0xf, 0xf, false);
@@ -278,9 +278,7 @@ struct TileParams {
     int32_t replicas_of[PERF_MAX_LEVELS];  // replicas per tile
     int64_t ws_off[PERF_MAX_LEVELS];       // float2 offset of the level's replica slabs in the workspace
     int32_t accumulate;
-    int64_t dbg_off;                       // >0: float2 offset in the workspace where per-block cycle counts go (dev tool)
     int32_t code_slot[PERF_MAX_LEVELS];    // >=0: the level's tile codes are codes[slot][n_pad] (see tile_codes_kernel)
-    uint32_t code16_levels;                // bit l: hashed level of <= 16 tiles: its codes are 16-bit (one nibble per (y,z) combination)
     int64_t n_pad;
     // XCD-aware placement: workgroup b runs work[b] = level << 16 | tile << 8 | replica (0xffffffff: idle).  The
     // dispatcher deals workgroups round-robin over the 8 XCDs, so b % 8 is the XCD: the owners of one level are put on
@@ -300,7 +298,6 @@ struct TileParams {
 };
 
 constexpr int kQueueCap = 448;             // per-wave match queue (entries): <128 left over + 4 x 64 new + 64 re-queued
-constexpr int64_t kDbgBytes = 4096 * 8;
 constexpr int64_t kMaxCodedSamples = (int64_t)1 << 28;
 
 constexpr int kBitmapMinDenseTiles = 32;
@@ -314,9 +311,7 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
     int64_t ws = 0;
     tp->atomic_levels = 0u;
     tp->bitmap_levels = 0u;
-    static const char* rep_env = getenv("PERF_BWD_REPLICAS");      // dev: "r1,r4,r16" replicas of dense levels of 1 / <=4 / <=16 tiles
-    int rs[3] = {8, 3, 2};
-    if (rep_env) (void)sscanf(rep_env, "%d,%d,%d", &rs[0], &rs[1], &rs[2]);
+    const int rs[3] = {8, 3, 2};       // replicas of dense levels of 1 / <= 4 / <= 16 tiles
     bool large_grid = false;        // some level takes bitmap owners
     for (int l = 0; l < gp.n_levels && bitmap_tiles > 0; ++l) {
         int nt = (int)((gp.size[l] + kTileEntries - 1) / kTileEntries);
@@ -350,7 +345,7 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
         // A grid with bitmap levels launches thousands of short owners anyway: its few-tile dense levels -- where every sample
         // is an entry of most owners -- get the replicas that keep them from being the kernel's long pole (measured on a
         // 20-level grid: 2 tiles x 3 replicas 1.1 ms per workgroup, 8 x 2 0.66 ms, against 0.07-0.3 ms everywhere else)
-        if (!gp.hashed[l] && fixed && bitmap_tiles > 0 && large_grid && !rep_env) r = nt == 1 ? 8 : (nt == 2 ? 8 : (nt == 4 ? 6 : (nt == 8 ? 4 : 2)));
+        if (!gp.hashed[l] && fixed && bitmap_tiles > 0 && large_grid) r = nt == 1 ? 8 : (nt == 2 ? 8 : (nt == 4 ? 6 : (nt == 8 ? 4 : 2)));
         if (r < 1 || no_replicas) r = 1;
         if (r > kMaxReplicas) r = kMaxReplicas;
         tp->tiles_of[l] = nt; tp->replicas_of[l] = r;
@@ -360,8 +355,7 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
     *n_blocks = nb; *ws_entries = ws;
     // ---- XCD-aware placement (a speed assumption only: results do not depend on it)
     tp->use_work = 0;
-    static const bool no_affinity = getenv("PERF_BWD_NO_XCD_AFFINITY") != nullptr;     // read once (thread-safe static init)
-    if (nb > kMaxWork || no_affinity || tp->bitmap_levels) return;       // (the table packs the tile in 8 bits)
+    if (nb > kMaxWork || tp->bitmap_levels) return;       // (the table packs the tile in 8 bits)
     uint32_t lists[kXcds][kMaxWork];                        // 16 KiB of stack: the planner is re-entrant
     int len[kXcds] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto least = [&]() { int x = 0; for (int i = 1; i < kXcds; ++i) if (len[i] < len[x]) x = i; return x; };
@@ -492,6 +486,7 @@ __device__ __forceinline__ int fixed_point_shift(const float am, const int64_t n
 // overflows -- the colour table's largest sum quadrupling from one batch to the next (tools/soak_episodes.py).
 constexpr int kHeadroomTopBit = 25, kHeadroomLowBit = 21;
 constexpr int kLaggedMinHeadroom = 12;     // (dp_units_kernel, lagged units)
+constexpr int kLaggedMaxFinerBits = 2;
 __device__ __forceinline__ int headroom_feedback(int adj, int fm) {
     if (fm >= (1 << kHeadroomTopBit)) adj += (32 - __clz(fm)) - kHeadroomTopBit + 1;
     else if (fm < (1 << kHeadroomLowBit) && adj > -24) adj -= 1;
@@ -633,14 +628,7 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
             if (slot < 0) continue;
             bool bad;       // the premise of the code does not hold for this sample
             const uint32_t code = tile_code_of(gp, tp, l, x, y, z, bad);
-            if ((tp.code16_levels >> l) & 1u) {
-                // <= 16 tiles: a nibble per combination, two samples per dword -- an owner tests both with four
-                // bit-parallel operations (bwd_stream_codes<.., CODE16>) and streams half the bytes
-                const uint32_t c16 = (code & 0xfu) | ((code >> 4) & 0xf0u) | ((code >> 8) & 0xf00u) | ((code >> 12) & 0xf000u);
-                reinterpret_cast<uint16_t*>(codes + (int64_t)slot * tp.n_pad)[i] = (uint16_t)c16;
-            } else {
-                codes[(int64_t)slot * tp.n_pad + i] = code;
-            }
+            codes[(int64_t)slot * tp.n_pad + i] = code;
             if (bad && gp.hashed[l]) {      // harmless without gradient; with gradient the level's owners take the generic path
                                             // (dense: the owners apply such a sample corner by corner, see bwd_stream_codes)
                 const float2 g = dfeat[(int64_t)l * n + i];
@@ -655,7 +643,7 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
 
 // The same codes, four consecutive samples per thread: 48 bytes of positions in three 16-byte loads and one 16-byte store per
 // level instead of four 4-byte ones (the byte-code kernel spent most of a wave's life queueing stores: 16 per sample).  A wave
-// covers the 256 samples of one escape word.  32-bit codes only (the 16-bit variant keeps the kernel above).
+// covers the 256 samples of one escape word.  (The kernel above serves workspaces whose code rows are not 16-byte aligned.)
 __global__ __launch_bounds__(256) void tile_codes4_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
                                                           const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
                                                           uint32_t* __restrict__ escape, int64_t n, int64_t n_words,
@@ -784,21 +772,16 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // multiply) and drains vmcnt to 0 around the conditional drain.  VMEM loads return in issue order, so
 // "vmcnt(k)" = "everything but the k youngest loads has landed"; the number of loads issued per step is static
 // (2 code loads, then 3 gather loads per drain, idle lanes gather sample 0).
-// CODE16 (hashed levels of <= 16 tiles): 16-bit codes, a nibble per (y,z) combination.  A lane takes EIGHT consecutive samples
-// per iteration -- the same two 8-byte code loads -- in two halves of four, each followed by the drain the byte-code loop
-// runs once per iteration (the queue, sized for four new samples per lane and drain, stays as it is).  Two samples are
-// tested at once: x = pair ^ (t * 0x11111111) has a zero nibble where a combination names this tile; OR-folding each
-// nibble into its top bit takes two shift-ors, one bit-field insert leaves the match flags, and a multiplication by
-// 0x249 moves the four flags of a sample into adjacent bits (all partial products land on distinct bits: no carries).
-template <bool FIXED, bool DENSE, bool CODE16 = false>
+// (Round 4 also built 16-bit nibble codes -- two samples tested with four bit-parallel operations --: bit-identical, owners 378.9
+//  vs 361.7 us per 1 M samples, profiles/r04_bwd_code16_ab.json; the variant is tools/exp/r05_retired_variants.diff.)
+template <bool FIXED, bool DENSE>
 __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_tile, uint32_t* queue,
                                                  const uint32_t* __restrict__ codes_l, const float* __restrict__ x01,
                                                  const float2* __restrict__ g_l, int64_t n, int rep, int R) {
     // (tells the compiler's own wait-count bookkeeping that nothing it knows of is in flight when the loop starts;
     //  otherwise it drains vmcnt to 0 at the head of every iteration on behalf of the other streaming variants)
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
-    static_assert(!(CODE16 && DENSE), "16-bit codes are for hashed levels");
-    constexpr int kPer = CODE16 ? 8 : 4;                // samples of a lane per iteration (= per pair of code loads)
+    constexpr int kPer = 4;                             // samples of a lane per iteration (= per pair of code loads)
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t qn = 0;                                    // wave-uniform queue fill
     const int64_t n_full = n / kPer;
@@ -823,15 +806,6 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
             if (DENSE) wraps = wraps || b == 0x7fu;
         }
         return wraps ? 0x10u : cm;
-    };
-    const uint32_t t_nib = cx.t * 0x11111111u;
-    auto test_pair = [&](uint32_t w, uint32_t& cm_a, uint32_t& cm_b) {      // two 16-bit codes -> their combination masks
-        const uint32_t x = w ^ t_nib;
-        const uint32_t y = (x << 1) | x;
-        const uint32_t z = (y << 2) | y;                                    // bit 3 of a nibble: the nibble of x is not zero
-        const uint32_t m = ~z & 0x88888888u;                                // bit 3 of a nibble: that combination names this tile
-        cm_a = (__umul24(m, 0x249u) >> 12) & 15u;                           // (mul24 reads bits 0..23: the flags above 15 land beyond bit 18)
-        cm_b = (__umul24(m >> 16, 0x249u) >> 12) & 15u;
     };
     auto enqueue = [&](uint32_t cm, uint32_t i) {
         const unsigned long long b = __ballot(cm != 0u);
@@ -898,49 +872,26 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
             const int64_t g0 = grp;
             const bool valid = g0 < g_hi;
             grp += kBwdThreads;
-            if (!CODE16) load_codes(grp);
+            load_codes(grp);
             const uint32_t cs[4] = {c0.x, c0.y, c1.x, c1.y};
 #pragma unroll
-            for (int half = 0; half < (CODE16 ? 2 : 1); ++half) {
-                // CODE16: the next code loads are issued between the halves, so that in BOTH halves the gather batch about to be
-                // applied is what is oldest in flight (first half: nothing else is in flight; second half: the 2 code loads are
-                // younger) -- the loop top then finds [2 code loads, 3 gather loads] as the byte-code loop does
-                if (CODE16 && half == 1) load_codes(grp);
-                if (CODE16) {
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        uint32_t cm_a, cm_b;
-                        test_pair(cs[2 * half + s], cm_a, cm_b);
-                        enqueue(valid ? cm_a : 0u, (uint32_t)(8 * g0 + 4 * half + 2 * s));
-                        enqueue(valid ? cm_b : 0u, (uint32_t)(8 * g0 + 4 * half + 2 * s + 1));
-                    }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
-                }
-                if (CODE16 && half == 0) {
-                    PERF_WAIT_BATCH(0);     // (only the gather batch is in flight)
-                    apply_batch(bx, byz, bg);
-                } else {
-                    PERF_WAIT_BATCH(2);     // all but the 2 code loads
-                    apply_batch(bx, byz, bg);
-                }
+            for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
+            {
+                PERF_WAIT_BATCH(2);         // all but the 2 code loads
+                apply_batch(bx, byz, bg);
+            }
+            pop_and_gather();
+            while (qn >= 128u) {            // bursts (ray-coherent samples at coarse hashed levels)
+                PERF_WAIT_BATCH(0);
+                apply_batch(bx, byz, bg);
                 pop_and_gather();
-                while (qn >= 128u) {        // bursts (ray-coherent samples at coarse hashed levels)
-                    PERF_WAIT_BATCH(0);
-                    apply_batch(bx, byz, bg);
-                    pop_and_gather();
-                }
             }
         }
     }
     if (threadIdx.x < 64 && rep == 0) {                 // ragged tail (n % kPer samples)
         const int64_t i = n_full * kPer + lane;
         uint32_t cm = 0u;
-        if (i < n) {
-            if (CODE16) { uint32_t hi_; test_pair((uint32_t)reinterpret_cast<const uint16_t*>(codes_l)[i], cm, hi_); }
-            else cm = test(codes_l[i]);
-        }
+        if (i < n) cm = test(codes_l[i]);
         enqueue(cm, (uint32_t)i);
     }
     for (;;) {
@@ -1200,7 +1151,6 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     const int64_t n_live = live_count(n, n_dev);            // samples present; n stays the stride of dfeat / codes
     extern __shared__ __attribute__((aligned(16))) float lds_tile[];   // 2 * kTileEntries floats (+ the wave queues)
     unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds_tile);
-    const long long t_start = (tp.dbg_off > 0) ? (long long)wall_clock64() : 0;
     int b = blockIdx.x, l = 0;
     uint32_t t;
     int rep;
@@ -1263,7 +1213,6 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     uint32_t* queue = reinterpret_cast<uint32_t*>(lds_tile + 2 * kTileEntries) + (threadIdx.x >> 6) * kQueueCap;
     if (by_bitmap && hashed) bwd_stream_bitmap<FIXED, false>(cx, lds_tile, queue, bitmaps + (int64_t)(tp.bm_row[l] + (int)t) * tp.bm_row_words, x01, g_l, n_live);
     else if (by_bitmap) bwd_stream_bitmap<FIXED, true>(cx, lds_tile, queue, bitmaps + (int64_t)(tp.bm_row[l] + (int)t) * tp.bm_row_words, x01, g_l, n_live);
-    else if (coded && hashed && ((tp.code16_levels >> l) & 1u)) bwd_stream_codes<FIXED, false, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (coded && hashed) bwd_stream_codes<FIXED, false>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (coded) bwd_stream_codes<FIXED, true>(cx, lds_tile, queue, codes + (int64_t)tp.code_slot[l] * tp.n_pad, x01, g_l, n_live, rep, R);
     else if (hashed) bwd_stream<FIXED, true>(cx, lds_tile, x01, g_l, n_live, rep, R);
@@ -1310,11 +1259,6 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
         if ((threadIdx.x & 63) == 0 && field_max > 0 &&
             field_max > __hip_atomic_load(&hr_state[PERF_MAX_LEVELS + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(&hr_state[PERF_MAX_LEVELS + l], field_max);
-    }
-    if (tp.dbg_off > 0 && threadIdx.x == 0) {      // slot = position in plain level order
-        int slot = (int)t * R + rep;
-        for (int k = 0; k < l; ++k) slot += tp.tiles_of[k] * tp.replicas_of[k];
-        if (slot < (int)(kDbgBytes / 8)) reinterpret_cast<long long*>(ws + tp.dbg_off)[slot] = (long long)wall_clock64() - t_start;
     }
 }
 
@@ -1576,6 +1520,14 @@ __global__ void dp_units_kernel(GridParams gp, const int32_t* __restrict__ stats
         int h = 31 - e - sh;
         if (h < kLaggedMinHeadroom) h = kLaggedMinHeadroom;
         sh = 31 - e - (h + margin_bits);
+        // ... and never get more than kLaggedMaxFinerBits finer than the units of the step before (shifts[] still holds them: a
+        // lagged call always follows a call that set it).  max |dfeat| is heavy tailed DOWNWARDS too: the depth loss of a batch the
+        // field already fits vanishes (1e-21, 3e-38, 0 observed), units derived from that are 2^50 times too fine for the
+        // ordinary batch that follows, and the job-wide gate dropped that step -- 10-12 of the 300 geometry steps of
+        // tests/golden/psnr_curve.json's schedule at every margin from 1 to 6 bits (tools/exp/dp_margin_sweep.py).  Units may get
+        // coarser at once.
+        const int prev = shifts[l];
+        if (sh > prev + kLaggedMaxFinerBits) sh = prev + kLaggedMaxFinerBits;
     }
     shifts[l] = sh;
 }
@@ -1841,23 +1793,20 @@ extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, c
     PERF_REQUIRE(x01 && table16 && feat16, "NULL pointer");
     // level group <-> XCD pinning only pays when every one of the 8 groups has a level (L >= 15); a grid of a few levels
     // (a rank's slice of a level-sharded table, the 5-level proposal field) would otherwise keep 1-3 XCDs busy
-    static const int affinity_env = getenv("PERF_FWD_NO_XCD_AFFINITY") ? 0 : 1;
-    const int xcd_affinity = (affinity_env && gp.n_levels >= 15) ? 1 : 0;
-    // chunks (of 256 samples) per level group in one launch; beyond that the workgroups loop (experiment knob, read once)
-    static const int64_t max_chunks = getenv("PERF_FWD_MAX_CHUNKS") ? atoll(getenv("PERF_FWD_MAX_CHUNKS")) : kFwdMaxChunks;
+    const int xcd_affinity = gp.n_levels >= 15 ? 1 : 0;
+    // chunks (of 256 samples) per level group in one launch; beyond that the workgroups loop
     int64_t chunks = div_up(n, 256);
-    if (xcd_affinity && max_chunks > 0 && chunks > max_chunks) chunks = max_chunks;
-    // ---- rotating level groups + run de-duplication (15/16-level grids; experiment switches read once)
-    static const int v2_env = getenv("PERF_FWD_V2") ? atoi(getenv("PERF_FWD_V2")) : 1;
-    static const int dedup_env = getenv("PERF_FWD_NO_DEDUP") ? 0 : 1, rotate_env = getenv("PERF_FWD_NO_ROTATE") ? 0 : 1;
-    if (v2_env && xcd_affinity && gp.n_levels <= 16) {
+    if (xcd_affinity && chunks > kFwdMaxChunks) chunks = kFwdMaxChunks;
+    // ---- rotating level groups + run de-duplication (15/16-level grids).  (The measured-slower settings of this path -- no
+    //      rotation, no de-duplication, the round-2 kernel for these grids, looping workgroups -- are tools/exp/r05_retired_variants.diff.)
+    if (xcd_affinity && gp.n_levels <= 16) {
         // (one workgroup per chunk up to 4096 chunks per XCD: the rotation relies on chunks being served in dispatch order --
         //  512 looping workgroups per XCD measured 0.307 instead of 0.177 ms per 1 M samples: phases mix, every L2 sees every table)
         dim3 g((unsigned)(chunks * 8)), b(256);
         if (dtype == PERF_DTYPE_BF16)
-            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, dedup_env, rotate_env);
+            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev);
         else if (dtype == PERF_DTYPE_FP16)
-            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, dedup_env, rotate_env);
+            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev);
         else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
         PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
         return PERF_OK;
@@ -1921,19 +1870,12 @@ extern "C" int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x0
 // levels whose owners can run the coded variant (multi-tile levels); returns their number
 static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
     int slots = 0;
-    // 16-bit codes (a nibble per combination, bit-parallel owner test, half the code bytes) are bit-identical to the byte codes
-    // and measured SLOWER on the benchmark batch: owners 378.9 vs 361.7 us per 1 M samples, pre-pass unchanged at 22.7
-    // (rocprofv3, same box, tools/exp/bwd_code16_ab.sh) -- the two-half loop waits for its gather batch with nothing else in
-    // flight, and the test was not what bounds an owner.  Off unless PERF_BWD_CODE16=1.
-    static const bool no_code16 = getenv("PERF_BWD_CODE16") == nullptr || atoi(getenv("PERF_BWD_CODE16")) == 0;
-    tp->code16_levels = 0u;
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
         tp->code_slot[l] = -1;
         if (l >= gp.n_levels || n >= kMaxCodedSamples || ((tp->bitmap_levels >> l) & 1u)) continue;
         const int64_t nt = tp->tiles_of[l];         // (plan_tiles ran before)
         if (gp.hashed[l] ? (nt >= 2 && nt <= 255 && gp.res[l] + 2u < (uint32_t)kTileEntries) : (nt >= 2 && nt <= 64)) {
             tp->code_slot[l] = slots++;
-            if (gp.hashed[l] && nt <= 16 && !no_code16) tp->code16_levels |= 1u << l;
         }
     }
     tp->n_pad = (n + 3) & ~(int64_t)3;
@@ -1961,20 +1903,18 @@ static int64_t plan_bitmaps(const GridParams& gp, int64_t n, TileParams* tp, int
     return (int64_t)rows * tp->bm_row_words * 4 + (int64_t)idx * tp->bm_blocks * 4;
 }
 
-static bool bitmaps_enabled() { const char* e = getenv("PERF_BWD_BITMAP"); return !(e && atoi(e) == 0); }
-
 extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid, int64_t n) {
     GridParams gp;
     if (fill_params(grid, &gp)) return -1;
     TileParams tp; int nb; int64_t ws;
     int64_t ws2;
     plan_tiles(gp, false, &tp, &nb, &ws);
-    plan_tiles(gp, true, &tp, &nb, &ws2, (n > 0 && n < kMaxCodedSamples && bitmaps_enabled()) ? kBitmapMaxTiles : 0);
+    plan_tiles(gp, true, &tp, &nb, &ws2, (n > 0 && n < kMaxCodedSamples) ? kBitmapMaxTiles : 0);
     const int slots = plan_codes(gp, n, &tp);
     int bm_levels = 0;
     int64_t bm_bytes = plan_bitmaps(gp, n, &tp, &bm_levels);
     if (bm_bytes > kBitmapMaxBytes) bm_bytes = 0;
-    return (ws > ws2 ? ws : ws2) * (int64_t)sizeof(float2) + 16 + kShiftBytes + kDbgBytes + (int64_t)slots * tp.n_pad * 4 +
+    return (ws > ws2 ? ws : ws2) * (int64_t)sizeof(float2) + 16 + kShiftBytes + (int64_t)slots * tp.n_pad * 4 +
            (slots ? div_up(n, kCodeSamplesPerBlock) * 4 : 0) + (bm_bytes ? bm_bytes + 16 : 0);
 }
 
@@ -1998,9 +1938,8 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         int64_t wse = 0;
         plan_tiles(gp, false, &rp, &nb, &wse, 0, true);
         if (rp.atomic_levels != 0u || nb == 0) { set_error("perf_hashgrid_bwd: the redo launch serves grids whose levels all fit LDS owners (<= 255 hashed / 64 dense tiles)"); return PERF_E_UNSUPPORTED; }
-        rp.accumulate = 0; rp.raw_out = 0; rp.dbg_off = 0; rp.run_merge = 0; rp.n_pad = 0;
+        rp.accumulate = 0; rp.raw_out = 0; rp.run_merge = 0; rp.n_pad = 0;
         for (int l = 0; l < PERF_MAX_LEVELS; ++l) rp.code_slot[l] = -1;
-        rp.code16_levels = 0u;
         const int lds_b = 2 * kTileEntries * (int)sizeof(float) + (kBwdThreads / 64) * kQueueCap * (int)sizeof(uint32_t);
         static std::once_flag redo_once;
         std::call_once(redo_once, [&]() {
@@ -2018,18 +1957,18 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     TileParams tp;
     int n_blocks = 0;
     int64_t ws_entries = 0;
-    static const bool dbg_env = getenv("PERF_BWD_DEBUG") != nullptr, no_codes = getenv("PERF_BWD_NO_CODES") != nullptr;
     const bool aligned_ws = (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
-    // workspace layout: [replica slabs (larger of both modes)][shifts][debug slots][tile codes][escape words][bitmaps][their escape words]
-    const bool want_bitmaps = n > 0 && n < kMaxCodedSamples && !no_codes && aligned_ws && bitmaps_enabled();
+    // workspace layout: [replica slabs (larger of both modes)][shifts][tile codes][escape words][bitmaps][their escape words]
+    // (a workspace WITHOUT room for the codes / bitmaps selects the position-streaming owners / the global-atomics scatter: how the
+    //  tests reach those paths)
+    const bool want_bitmaps = n > 0 && n < kMaxCodedSamples && aligned_ws;
     int64_t slab_entries = 0;       // (the largest of the plans a call may end up with: the offsets below must not depend on the choice)
     { TileParams t2; int nb2; int64_t w2;
       plan_tiles(gp, fixed, &t2, &nb2, &w2); slab_entries = w2;
       plan_tiles(gp, !fixed, &t2, &nb2, &w2); if (w2 > slab_entries) slab_entries = w2;
       if (want_bitmaps) { plan_tiles(gp, fixed, &t2, &nb2, &w2, kBitmapMaxTiles); if (w2 > slab_entries) slab_entries = w2; } }
     const int64_t shifts_at = (slab_entries * (int64_t)sizeof(float2) + 15) & ~(int64_t)15;
-    const int64_t dbg_at = shifts_at + kShiftBytes;
-    const int64_t codes_at = dbg_at + kDbgBytes;
+    const int64_t codes_at = shifts_at + kShiftBytes;
     const int64_t esc_words = div_up(n, kCodeSamplesPerBlock);
     // levels of 256..2048 tiles take LDS owners fed by per-tile bitmaps when the workspace holds the bitmaps, global atomics otherwise
     int bitmap_tiles = 0, bm_levels = 0;
@@ -2047,15 +1986,13 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     plan_tiles(gp, fixed, &tp, &n_blocks, &ws_entries, bitmap_tiles);
     PERF_REQUIRE(!(raw_fields || shifts_dev) || tp.atomic_levels == 0u,
                  "perf_hashgrid_bwd: raw fields / given units are not available for levels on the global-atomics scatter (more than 2048 tiles, or no room for the per-tile bitmaps in the workspace)");
-    { const char* e = getenv("PERF_BWD_RUNS"); tp.run_merge = (e && atoi(e) == 0) ? 0 : 1; }     // (dev switch)
+    tp.run_merge = 1;
     tp.accumulate = accumulate;
     tp.raw_out = raw_fields ? 1 : 0;
-    tp.dbg_off = 0;
     PERF_REQUIRE(workspace && workspace_bytes >= shifts_at + kShiftBytes,
                  "perf_hashgrid_bwd: workspace too small (need %lld bytes)", (long long)(shifts_at + kShiftBytes));
     int32_t* shifts_ws = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + shifts_at);
-    if (dbg_env && workspace_bytes >= dbg_at + kDbgBytes) tp.dbg_off = dbg_at / (int64_t)sizeof(float2);
-    // tile codes of the hashed levels (workspace permitting; PERF_BWD_NO_CODES=1 keeps the position-streaming owners)
+    // tile codes of the multi-tile levels (workspace permitting)
     const int slots = plan_codes(gp, n, &tp);
     uint32_t* codes = nullptr;
     uint32_t* escape = nullptr;
@@ -2076,12 +2013,11 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
             gp, tp, x01, (const float2*)dfeat, bitmaps, esc_bm, n, n_dev);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(bitmaps)");
     }
-    if (slots > 0 && n > 0 && !no_codes && aligned_ws &&
+    if (slots > 0 && n > 0 && aligned_ws &&
         workspace_bytes >= codes_at + (int64_t)slots * tp.n_pad * 4 + esc_words * 4) {
         codes = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + codes_at);
         escape = codes + (int64_t)slots * tp.n_pad;
-        static const bool kCodes4 = []() { const char* e = getenv("PERF_BWD_CODES4"); return !(e && e[0] == '0'); }();
-        if (kCodes4 && tp.code16_levels == 0u && (reinterpret_cast<uintptr_t>(codes) & 15) == 0)
+        if ((reinterpret_cast<uintptr_t>(codes) & 15) == 0)
             tile_codes4_kernel<<<dim3((unsigned)div_up(esc_words, 4)), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
                                                                                                             codes, escape, n, esc_words, n_dev);
         else
@@ -2090,7 +2026,6 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(codes)");
     } else {
         for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.code_slot[l] = -1;
-        tp.code16_levels = 0u;
     }
     const int lds_bytes = 2 * kTileEntries * (int)sizeof(float) + (kBwdThreads / 64) * kQueueCap * (int)sizeof(uint32_t);
     static std::once_flag attr_once;                // one-time kernel attribute setup, safe under concurrent callers
@@ -2133,7 +2068,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
     }
     const bool adapt = level_absmax && headroom_state && (n_blocks > 0 || (tp.atomic_levels && n > 0 && !accumulate));
     if (ws_entries > 0 || adapt) {      // replica sums, and the headroom feedback by the last workgroup
-        static const int kReduceBlocks = []() { const char* e = getenv("PERF_BWD_REDUCE_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 1024 ? v : 64; }();
+        constexpr int kReduceBlocks = 64;
         int n_tickets = 0;
         for (int l = 0; l < gp.n_levels; ++l) n_tickets += tp.replicas_of[l] > 1 ? reduce_blocks_of(gp.size[l], kReduceBlocks) : 0;
         hashgrid_bwd_reduce_kernel<<<dim3(kReduceBlocks, gp.n_levels), dim3(256), 0, as_stream(stream)>>>(
@@ -2193,7 +2128,7 @@ extern "C" int perf_fixed_unfix(const perf_grid_desc* grid, void* fields, int64_
     if (entry_hi == entry_lo) return PERF_OK;
     // few workgroups: each ends with atomics on the 24 maxima, which share one cache line and retire one at a time (~11 ns):
     // 4,096 workgroups spent 30 us there (tools/exp/unfix_probe.py: 56 / 40 / 35 / 39 us at 4096 / 1024 / 512 / 256)
-    static const int64_t kMaxBlocks = []() { const char* e = getenv("PERF_UNFIX_BLOCKS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 512); }();
+    constexpr int64_t kMaxBlocks = 512;       // (more workgroups only queue at the 24 same-line maxima: tools/exp/unfix_probe.py)
     int64_t blocks = div_up(entry_hi - entry_lo, 256 * 8);
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     fixed_unfix_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(gp, (int32_t*)fields, entry_lo, entry_hi, shifts_dev,

@@ -143,7 +143,9 @@ class InferenceNeRF:
     type NeRFOCCRenderer uses (density_at / rgb_at / sample_points on kernel-made positions), like sharded.LevelShardedNeRF."""
 
     def __init__(self, aabb, n_levels=20, log2_hashmap_size=28, per_level_scale=PER_LEVEL_SCALE, dtype='fp16', seed=tcnn.DEFAULT_SEED,
-                 table_scale=1e-4, device=None):
+                 table_scale=1e-4, density_bias=0.0, device=None):
+        """table_scale / density_bias (tests): tables U(-table_scale, table_scale) and sigma = exp(y + density_bias) instead of the
+        fresh initialisation's near-constant sigma = exp(y ~ 0) -- a field with structure, dense enough for rays to terminate."""
         from .grid import GridConfig, MlpConfig
         import math
         if not isinstance(aabb, torch.Tensor):
@@ -158,7 +160,8 @@ class InferenceNeRF:
         self.nets = {}
         gen = torch.Generator(device=dev).manual_seed(seed)
         cg = torch.Generator().manual_seed(seed)
-        for name, mlp in (('geo_mlp', MlpConfig(n_levels, 1, 1, 'Exponential')), ('app_mlp', MlpConfig(n_levels, 2, 3, 'Sigmoid'))):
+        for name, mlp in (('geo_mlp', MlpConfig(n_levels, 1, 1, 'Exponential', exp_shift=-float(density_bias))),
+                          ('app_mlp', MlpConfig(n_levels, 2, 3, 'Sigmoid'))):
             n_net = mlp.n_params
             w16 = torch.empty(n_net + self.grid.n_params, dtype=t16, device=dev)
             parts = [(torch.rand(o * i, generator=cg) * 2 - 1) * math.sqrt(6.0 / (i + o)) for (o, i) in mlp.shapes]

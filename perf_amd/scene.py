@@ -1213,7 +1213,7 @@ class NeRFScene:
         # them for the replay after it.
         # (a REPLACED step function -- tests inject their own batches and draws -- is captured serially: the pipeline draws from
         #  the device generator)
-        pipelined = (kind == 'geo' and self.pipeline_marching and dist_info[0] is None and self.device_rng and self.fused_steps
+        pipelined = (kind == 'geo' and self.pipeline_marching and (dist_info[0] is None or os.environ.get('PERF_PIPELINE_MARCHING_DP')) and self.device_rng and self.fused_steps
                      and self.renderer.early_stop_eps > 0 and self.renderer.sample_capacity is not None
                      and getattr(step_fn, '__func__', None) is NeRFScene.train_one_step_geo)
         static_pre = side = None

@@ -45,12 +45,33 @@ def run_dp(scene_data, geo0, app0, draws, n_geo, n_app, marks, dtype, rank, worl
     opt = sc.make_optimizer(sc.nerf.geo_mlp, 0.0)
     conf = sc.train_conf.geo_optimizer
     dls = []
+    skipped, seen = [], 0
+
+    diag = os.environ.get('PERF_DP_DIAG') == '1' and rank == 0
+    hist = []
+
+    def note(tag):                                                   # (one read-back per step: nothing next to gloo's host copies)
+        nonlocal seen
+        now = int(sc.sample_counters[4].item())
+        if diag:                                                     # what the exchange saw in this step (tools/exp/dp_margin_sweep.py)
+            net = sc.nerf.geo_mlp if tag.startswith('geo') else sc.nerf.app_mlp
+            ex = getattr(net, '_dp_exchange', None)
+            if ex is not None:
+                hist.append((tag, ex.level_absmax[:16].tolist(), ex.shifts[:16].tolist(), ex.field_max[:16].tolist(), ex.job_flags.tolist(),
+                             int(ex.n_total.item())))
+                if now != seen and len(hist) >= 2:
+                    for h in hist[-2:]:
+                        print('DIAG', h[0], 'flags', h[4], 'n', h[5], '\n   absmax', ['%.2e' % v for v in h[1]], '\n   shifts', h[2], '\n   field_max(log2)',
+                              [0 if v <= 0 else v.bit_length() for v in h[3]], flush=True)
+        if now != seen:
+            skipped.append(tag); seen = now
     for i in range(n_geo):
         dr = draws[i]; state['idx'] = dr['idx'].cuda()
         sc.update_lr(opt, conf, i / n_geo)
         # (no prefetch: the next batch is injected, not drawn)
         sc.train_one_step_geo(opt, pool, progress=i / n_app, rand=cut(dr), prefetch_next=False)
         dls.append(sc.last_losses['depth_loss'])
+        note(f'geo{i}')
     # the loss head normalises by the GLOBAL batch: a rank's depth loss is its share of the job's
     dl = torch.stack(dls).double()
     dist.all_reduce(dl)
@@ -68,11 +89,13 @@ def run_dp(scene_data, geo0, app0, draws, n_geo, n_app, marks, dtype, rank, worl
         dr = draws[n_geo + i]; state['idx'] = dr['idx'].cuda()
         sc.update_lr(opt, conf, i / n_app)
         sc.train_one_step_app(opt, pool, progress=i / n_app, rand=cut(dr))
+        note(f'app{i}')
         if (i + 1) in marks:
             curve[f'psnr@app{i + 1}'] = P.psnr(sc.render(rays, ['rgb'])['rgb'].cpu(), rgb); sc.set_train()
     c = sc.sample_counters.tolist()
     curve['skipped_for_overflow'], curve['skipped_for_truncation'] = int(c[4]), int(c[5])
     curve['collectives_per_step'] = 3
+    curve['steps_skipped_for_overflow'] = skipped
     return curve
 
 

@@ -4,21 +4,21 @@ offsets beyond 32 bit) -- the same workload bench.py's `config5` block times (to
 size-independent properties: packed bookkeeping (sortedness, counts), compositing bounds, determinism, and equality of a
 row shard rendered on its own with the same rows of the full render (the multi-GPU eval partitioning of SURVEY.md 8(e):
 rank r of G renders rows [r H/G, (r+1) H/G), no communication).  The fields are NOT at their fresh initialisation here
-(tables U(-4, 4)): densities vary, early termination prunes, the compaction is exercised."""
+(tables U(-4, 4), densities exp(y + 4)): densities vary, rays terminate early, the compaction is exercised."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 H, W, SPP = 2048, 4096, 256
-TABLE_SCALE = 4.0      # tables U(-4, 4): densities exp(+-several), rays terminate early, the compaction is exercised
+TABLE_SCALE, DENSITY_BIAS = 4.0, 4.0      # tables U(-4, 4), sigma = exp(y + 4): y ~ N(0, 1), optical depth ~ 80 per ray -- rays end early
 
 
 def _field(log2_t):
     from perf_amd.fields import InferenceNeRF
     from tools import config5 as C
     nerf = InferenceNeRF([-1., -1, -1, 1, 1, 1], n_levels=20, log2_hashmap_size=log2_t, per_level_scale=C.per_level_scale(20),
-                         dtype='fp16', table_scale=TABLE_SCALE)
+                         dtype='fp16', table_scale=TABLE_SCALE, density_bias=DENSITY_BIAS)
     est, rend = C.make_renderer(SPP)
     return nerf, est, rend
 
@@ -63,7 +63,7 @@ def test_config5_full_panorama_properties():
     assert float(op.min()) >= 0.0 and float(op.max()) <= 1.0 + 1e-5
     assert float(outs['rgb'].min()) >= 0.0 and float(outs['rgb'].max()) <= 1.0 + 1e-5
     assert float(outs['distance'].min()) >= 0.0 and float(outs['distance'].max()) <= 0.99 + 5.0 + 1e-4
-    assert float(outs['rgb'].std()) > 1e-3 and float(op.std()) > 1e-3           # the fields are not constant
+    assert float(outs['rgb'].std()) > 1e-3 and float(outs['distance'].std()) > 1e-4     # the fields are not constant (every ray ends opaque)
     # row sharding: rank 5 of 8 renders its 256 rows on its own, in batches of another size
     r0, nr = 5 * H // 8, H // 8
     shard = C.render_rows(nerf, est, rend, r0, nr, 2, SPP, H, W)

@@ -627,9 +627,10 @@ def test_hashgrid_bwd_coded_owners_equal_streaming_owners(ops):
         assert float((a_f32 - b_f32).abs().max()) <= 1e-4 * float(b_f32.abs().max()), kind
 
 
-def test_hashgrid_bwd_run_merging_owners_equal_streaming_owners(ops, monkeypatch):
-    """The coarse owners that sum runs of samples sharing a cell in registers before they touch LDS (default) compute
-    the same fixed-point sums as the plain owners, coded or position streaming: bit-identical tables -- ragged sizes,
+def test_hashgrid_bwd_run_merging_owners_equal_streaming_owners(ops):
+    """The coarse owners that sum runs of samples sharing a cell in registers before they touch LDS compute the same
+    fixed-point sums whatever the runs are -- the batch in ray order (long runs) and in a random order (no runs) -- and as the
+    position-streaming owners: bit-identical tables -- ragged sizes,
     ray-coherent runs, positions outside the unit cube (index wrap), a live count below the capacity, and the full
     1 M-sample batch of the benchmark."""
     cfg = _grid_cfg()
@@ -652,11 +653,15 @@ def test_hashgrid_bwd_run_merging_owners_equal_streaming_owners(ops, monkeypatch
         amax = dfeat.abs().amax(dim=(1, 2)).contiguous()
         amax = torch.cat([amax, torch.zeros(16 - amax.numel(), device='cuda')])
         n_dev = None if live is None else torch.tensor([live], dtype=torch.int64, device='cuda')
-        monkeypatch.setenv('PERF_BWD_RUNS', '1')
         a_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, n_dev=n_dev)
         a_f32 = ops.hashgrid_bwd(cfg, x, dfeat, n_dev=n_dev)
-        monkeypatch.setenv('PERF_BWD_RUNS', '0')
-        c_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, n_dev=n_dev)
+        # the same live samples in a RANDOM order: runs of samples that share a cell fall apart (nothing is merged in registers),
+        # the replicas of the coarse levels get other samples, the queues fill differently -- integer sums must not notice
+        m = n if live is None else live
+        perm = torch.randperm(m, generator=g).cuda()
+        xp = x.clone(); xp[:m] = x[perm]
+        dp = dfeat.clone(); dp[:, :m] = dfeat[:, perm]
+        c_fix = ops.hashgrid_bwd(cfg, xp, dp, level_absmax=amax, n_dev=n_dev)
         b_fix = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, use_codes=False, n_dev=n_dev)
         b_f32 = ops.hashgrid_bwd(cfg, x, dfeat, use_codes=False, n_dev=n_dev)
         assert torch.equal(a_fix, b_fix), (n, kind, float((a_fix - b_fix).abs().max()))
@@ -731,12 +736,12 @@ def test_table_beyond_32_bit_offsets(ops):
 
 
 @pytest.mark.parametrize('bitmap', ['1', '0'])
-def test_hashgrid_bwd_large_levels(ops, monkeypatch, bitmap):
+def test_hashgrid_bwd_large_levels(ops, bitmap):
     """log2_hashmap_size = 23: 512 tiles per hashed level, more than code-streaming owners are planned for -> LDS owners fed
-    by per-tile bitmaps (default) or the global-atomics scatter (PERF_BWD_BITMAP=0, and whenever the workspace cannot hold
+    by per-tile bitmaps (default) or the global-atomics scatter (bitmap '0': whenever the workspace cannot hold
     the bitmaps) for those levels, the usual owners for the rest; against the oracle's corner bookkeeping (fp32:
     summation-order tolerance)."""
-    monkeypatch.setenv('PERF_BWD_BITMAP', bitmap)
+    no_bitmaps = bitmap == '0'          # (a workspace without room for codes / bitmaps: atomics scatter for the large levels)
     cfg = _grid_cfg(n_levels=6, log2_hashmap_size=23, base_resolution=32, per_level_scale=2.0)
     lv = O.grid_levels(6, 2, 23, 32, 2.0)
     g = torch.Generator().manual_seed(41)
@@ -747,7 +752,7 @@ def test_hashgrid_bwd_large_levels(ops, monkeypatch, bitmap):
         amax = None
         if fixed:
             amax = torch.zeros(24, device='cuda'); amax[:6] = dfeat.abs().amax(dim=(1, 2)).cuda()
-        grad = ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), level_absmax=amax).cpu().numpy().reshape(-1, 2)
+        grad = ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), level_absmax=amax, use_codes=not no_bitmaps).cpu().numpy().reshape(-1, 2)
         ref = np.zeros((cfg.total, 2), np.float64)
         xn = x.numpy()
         for l in range(cfg.n_levels):
@@ -759,15 +764,15 @@ def test_hashgrid_bwd_large_levels(ops, monkeypatch, bitmap):
                 np.add.at(ref, idx[:, c].astype(np.int64) + int(lv.offset[l]), w[:, None].astype(np.float64) * dfeat[l].numpy())
         assert np.abs(grad - ref).max() < 2e-4 * np.abs(ref).max()
         if fixed:       # 64-bit fixed-point global atomics: the sum does not depend on the order they retire in
-            again = ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), level_absmax=amax).cpu().numpy().reshape(-1, 2)
+            again = ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), level_absmax=amax, use_codes=not no_bitmaps).cpu().numpy().reshape(-1, 2)
             assert np.array_equal(grad, again)
         # accumulate adds on top
         acc = torch.from_numpy(grad.reshape(-1).copy()).cuda()
-        ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), out=acc, accumulate=True, level_absmax=amax)
+        ops.hashgrid_bwd(cfg, x.cuda(), dfeat.cuda(), out=acc, accumulate=True, level_absmax=amax, use_codes=not no_bitmaps)
         assert np.abs(acc.cpu().numpy().reshape(-1, 2) - 2 * ref).max() < 4e-4 * np.abs(ref).max()
 
 
-def test_hashgrid_bwd_bitmap_owners_equal_the_atomics_scatter(ops, monkeypatch):
+def test_hashgrid_bwd_bitmap_owners_equal_the_atomics_scatter(ops):
     """Hashed levels of 256-2048 tiles (log2_hashmap_size 22-25) and dense levels of 32-2048 tiles: the owners that read per-tile
     bitmaps and what runs without them (64-bit fixed-point global atomics; code-streaming owners up to 64 dense tiles) add up the same integers -- bit-identical tables, for ragged sizes, ray-ordered samples, a live count
     below the capacity and positions outside the unit cube (which send a level back to the generic owners)."""
@@ -793,12 +798,11 @@ def test_hashgrid_bwd_bitmap_owners_equal_the_atomics_scatter(ops, monkeypatch):
         dfeat = torch.randn(cfg.n_levels, n, 2, generator=g).cuda()
         amax = torch.zeros(24, device='cuda'); amax[:cfg.n_levels] = dfeat.abs().amax(dim=(1, 2))
         n_dev = None if live is None else torch.tensor([live], dtype=torch.int64, device='cuda')
-        monkeypatch.setenv('PERF_BWD_BITMAP', '1')
         a = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, n_dev=n_dev)
         a32 = ops.hashgrid_bwd(cfg, x, dfeat, n_dev=n_dev)
-        monkeypatch.setenv('PERF_BWD_BITMAP', '0')
-        b = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, n_dev=n_dev)
-        b32 = ops.hashgrid_bwd(cfg, x, dfeat, n_dev=n_dev)
+        # (a workspace without room for the codes and the bitmaps: global atomics for the large levels, position-streaming owners for the rest)
+        b = ops.hashgrid_bwd(cfg, x, dfeat, level_absmax=amax, n_dev=n_dev, use_codes=False)
+        b32 = ops.hashgrid_bwd(cfg, x, dfeat, n_dev=n_dev, use_codes=False)
         assert float(b.abs().max()) > 0
         assert torch.equal(a, b), (log2_t, kind, float((a - b).abs().max()))
         assert float((a32 - b32).abs().max()) <= 1e-4 * float(b32.abs().max()), (log2_t, kind)
@@ -1053,3 +1057,30 @@ def test_renderer_with_either_lattice_sync_free_equals_synced():
     c2 = scene.render(rays, ['distance'], sync_free=False)
     assert torch.equal(c['distance'], c2['distance'])
     assert not torch.equal(a['distance'], c['distance'])                         # (the lattices differ in the last bits of t)
+
+
+def test_lagged_units_do_not_follow_a_vanishing_gradient(ops):
+    """perf_dp_units with a margin (the lagged units of perf_amd/dp.py): the units of the next step may get coarser at once but
+    only two bits finer per step -- max |dfeat| of a batch the field already fits vanishes (1e-21 observed), and units derived
+    from THAT would overflow on the ordinary batch that follows (the job-wide gate then drops the step)."""
+    cfg = _grid_cfg()
+    hr = ops.headroom_state('cuda')
+    n = 30000
+
+    def stats(scale):
+        am = torch.zeros(24, device='cuda'); am[:cfg.n_levels] = scale * torch.linspace(1.0, 2.0, cfg.n_levels, device='cuda')
+        return ops.dp_stats_pack(am, None, None, n).view(1, -1)
+    shifts, _ = ops.dp_units(cfg, stats(1e-5), 1, hr)                              # an exact call sets the units
+    s0 = shifts.clone()
+    ops.dp_units(cfg, stats(1e-5), 1, hr, shifts=shifts, want_total=False, margin_bits=1)
+    s1 = shifts.clone()
+    assert bool((s1[:cfg.n_levels] <= s0[:cfg.n_levels] + 2).all())
+    ops.dp_units(cfg, stats(1e-21), 1, hr, shifts=shifts, want_total=False, margin_bits=1)     # the gradient vanishes ...
+    s2 = shifts.clone()
+    assert bool((s2[:cfg.n_levels] <= s1[:cfg.n_levels] + 2).all()) and bool((s2[:cfg.n_levels] >= s1[:cfg.n_levels]).all())
+    ops.dp_units(cfg, stats(0.0), 1, hr, shifts=shifts, want_total=False, margin_bits=1)       # ... entirely
+    s3 = shifts.clone()
+    assert bool((s3[:cfg.n_levels] <= s2[:cfg.n_levels] + 2).all())
+    ops.dp_units(cfg, stats(1e-2), 1, hr, shifts=shifts, want_total=False, margin_bits=1)      # a large gradient: coarser at once
+    s4 = shifts.clone()
+    assert bool((s4[:cfg.n_levels] < s1[:cfg.n_levels] - 6).all())

@@ -98,5 +98,5 @@ def test_data_parallel_psnr_at_iter_matches_the_oracle_curve(tmp_path):
         assert 0.93 <= float(np.mean(ratio)) <= 1.07 and all(0.85 <= v <= 1.15 for v in ratio), (k, ratio)
     for s in seeds:
         c = res['curves'][str(s)]
-        assert c['skipped_for_overflow'] == 0 and c['skipped_for_truncation'] == 0, c
+        assert c['skipped_for_overflow'] == 0 and c['skipped_for_truncation'] == 0, (s, c['skipped_for_overflow'], c['steps_skipped_for_overflow'])
         assert abs(c['geo_end_opacity'] - rows[str(s)]['geo_end_opacity']) < 5e-3
