@@ -181,7 +181,7 @@ class OccGridEstimator(nn.Module):
     def sampling_ex(self, rays_o, rays_d, sigma_fn=None, near_plane=0.0, far_plane=1e10, render_step_size=1e-3,
                     early_stop_eps=1e-4, alpha_thre=0.0, stratified=False, cone_angle=0.0, alpha_fn=None,
                     t_min=None, t_max=None, jitter=None, max_steps=None, capacity=None, points_aabb=None,
-                    sigma_points_fn=None, head_samples=None, lattice=None, marched=None, march_only=False):
+                    sigma_points_fn=None, head_samples=None, lattice=None):
         """sampling() returning a Samples record: ray_indices, t_starts, t_ends, packed (packed_info), sig (sigmas of the
         kept samples from the visibility pass, or None), x01 / sel (sample positions normalised to points_aabb, or None),
         n_dev (device int64 [1]: number of live samples when the arrays are capacity-sized, else None), n_marched_dev.
@@ -199,11 +199,7 @@ class OccGridEstimator(nn.Module):
           samples (Samples.feat) so that a gradient pass on the kept samples need not encode them again -- compacted along
           (two-phase sampler) or, from the one-phase sampler, as an ops.IndexedFeat: the uncompacted array plus the row of
           every kept sample, which ops.mlp_bwd reads in place (.materialize() gives the compacted copy; PERF_INDEX_FEATURES=0).
-        lattice: 'repeated' (t_{k+1} = fl(t_k + step), the default: None) or 'single' (t_k = fl(t0 + fl(k step))): PERF_LATTICE_*.
-        march_only / marched (sync-free mode): the marching -- everything that does not depend on the density field -- as a stage
-          of its own.  march_only=True returns its record (a tuple of tensors and host scalars) instead of Samples; a later call
-          with marched=<that record> and the same arguments continues from it.  NeRFScene issues the marching of step k+1
-          beside the backward of step k (scene.py: pipeline_marching)."""
+        lattice: 'repeated' (t_{k+1} = fl(t_k + step), the default: None) or 'single' (t_k = fl(t0 + fl(k step))): PERF_LATTICE_*."""
         if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
             raise NotImplementedError('PeRF samples with cone_angle=0 and a sigma_fn (nerf_renderer.py:145-155)')
         if alpha_thre != 0.0:
@@ -238,27 +234,17 @@ class OccGridEstimator(nn.Module):
         res = self._res
         compacts = (sigma_fn is not None or sigma_points_fn is not None) and early_stop_eps > 0
         sm = Samples()
-        if (march_only or marched is not None) and capacity is None:
-            raise ValueError('the marching stage exists in sync-free mode only (capacity)')
         if capacity is not None:
             if compacts and (sigma_points_fn is None or points_aabb is None):
                 raise ValueError('sync-free sampling with a visibility pass needs points_aabb and sigma_points_fn')
             if compacts and head_samples:
                 return self._sample_two_phase(sm, rays_o, rays_d, t0, float(far_plane), float(render_step_size), max_steps,
-                                              int(capacity), points_aabb, sigma_points_fn, early_stop_eps, int(head_samples), lattice,
-                                              marched=marched, march_only=march_only)
-            if marched is not None:
-                out = marched[1]
-            else:
-                out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size),
-                                    max_steps, capacity=capacity, occ_coarse=self.occ_coarse(), points_aabb=points_aabb, lattice=lattice)
-            if march_only:
-                return ('one', tuple(out))
+                                              int(capacity), points_aabb, sigma_points_fn, early_stop_eps, int(head_samples), lattice)
+            out = ops.occ_march(rays_o, rays_d, t0, self.occ_bits(), res, aabb, float(far_plane), float(render_step_size),
+                                max_steps, capacity=capacity, occ_coarse=self.occ_coarse(), points_aabb=points_aabb, lattice=lattice)
             ri, ts, te, packed, total = out[:5]
             x01, sel = out[5:] if points_aabb is not None else (None, None)
-            # (a marching record lives in buffers the NEXT step's marching overwrites while this step's backward runs; the
-            #  marched count is read once more behind it, by the step's bookkeeping: keep a copy)
-            sm.n_marched_dev = total.clone() if marched is not None else total
+            sm.n_marched_dev = total
             sig = None
             if compacts:
                 sig, feat = _sig_feat(sigma_points_fn(x01, sel, total))
@@ -306,39 +292,21 @@ class OccGridEstimator(nn.Module):
     STRIDED_HEAD_MAX = 16          # heads of up to this many samples are written by the counting pass, K rows per ray
 
     def _sample_two_phase(self, sm, rays_o, rays_d, t0, far_plane, step, max_steps, capacity, points_aabb, sigma_points_fn,
-                          early_stop_eps, K, lattice=None, marched=None, march_only=False):
+                          early_stop_eps, K, lattice=None):
         """March once; density + visibility on the first K samples of every ray; then density on the remaining samples of
         the rays that are still alive; final visibility + compaction over (head, tail).  All counts stay on the device."""
         R = rays_o.shape[0]
-        if marched is not None:
-            # (the stage that needs no density: issued earlier -- marched[2] is the lattice origin it used: the tail's write
-            #  pass must walk the same lattice)
-            _, payload, t0 = marched
-            if K <= self.STRIDED_HEAD_MAX:
-                masks, counts, (ri_h, ts_h, te_h, pk_h, x_h, s_h) = payload
-            else:
-                masks, counts = payload
-        if march_only:
-            if K <= self.STRIDED_HEAD_MAX:
-                payload = ops.occ_march_count_head(rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step, max_steps,
-                                                   self.occ_coarse(), K, points_aabb, lattice=lattice)
-            else:
-                payload = ops.occ_march_count(rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step,
-                                              max_steps, self.occ_coarse(), lattice=lattice)
-            return ('two', payload, t0)
         # ---- head: rank [0, K) of every ray, written by the counting pass itself to rows r*K..r*K+K-1 (rays with fewer
         #      samples leave padding rows with selector 0: their density is evaluated and ignored)
         if K <= self.STRIDED_HEAD_MAX:
-            if marched is None:
-                masks, counts, (ri_h, ts_h, te_h, pk_h, x_h, s_h) = ops.occ_march_count_head(
-                    rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step, max_steps, self.occ_coarse(), K, points_aabb,
-                    lattice=lattice)
+            masks, counts, (ri_h, ts_h, te_h, pk_h, x_h, s_h) = ops.occ_march_count_head(
+                rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step, max_steps, self.occ_coarse(), K, points_aabb,
+                lattice=lattice)
             total_h = None                      # R * K rows, a host constant: folded into the tail scan's biased total below
             sig_h, feat_h = _sig_feat(sigma_points_fn(x_h, s_h, None))
         else:       # a long head: packed rows (count clamp, scan over the rays, write pass) instead of K rows per ray
-            if marched is None:
-                masks, counts = ops.occ_march_count(rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step,
-                                                    max_steps, self.occ_coarse(), lattice=lattice)
+            masks, counts = ops.occ_march_count(rays_o, rays_d, t0, self.occ_bits(), self._res, self._aabb_host, far_plane, step,
+                                                max_steps, self.occ_coarse(), lattice=lattice)
             ch = ops.head_tail_counts(counts, K)
             oh, total_h = ops.exclusive_scan_i32(ch)
             ri_h, ts_h, te_h, pk_h, x_h, s_h = ops.occ_march_write(t0, masks, ch, oh, R * K, step, max_steps, rays_o, rays_d, points_aabb,

@@ -646,7 +646,7 @@ def visibility_count(sigmas, t_starts, t_ends, packed, early_stop_eps=1e-4, want
     return (new_counts, ex) if want_exsum else new_counts
 
 
-INDEX_FEATURES = os.environ.get('PERF_INDEX_FEATURES', '1') != '0'      # compact_prefix: rows instead of a feature copy
+INDEX_FEATURES = True      # compact_prefix: rows instead of a feature copy (index_features=False: the copy, tests)
 
 
 def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=None, x01=None, sel=None, feat=None,
@@ -654,7 +654,7 @@ def compact_prefix(packed, new_counts, t_starts, t_ends, sigmas=None, capacity=N
     """-> (ray_indices, t_starts, t_ends, sigmas, packed_info) of the kept prefixes; with capacity (sync-free mode: the
     arrays keep that length, the kept count stays on the device) also `total` (int64 [1]); with x01/sel also the compacted
     positions, appended to the result; with feat (level-major features of all input samples) their compacted copy or --
-    index_features (default: PERF_INDEX_FEATURES, on) -- an IndexedFeat that points into `feat` (which must then outlive it)."""
+    index_features (the default) -- an IndexedFeat that points into `feat` (which must then outlive it)."""
     R = packed.shape[0]
     dev = packed.device
     new_offsets, total = exclusive_scan_i32(new_counts)

@@ -65,18 +65,8 @@ class NeRFOCCRenderer(nn.Module):
 
     # The render is cut in two stages so that a data-parallel trainer can overlap the gradient all-reduce of step k
     # with everything of step k+1 that does not depend on the parameters being updated (scene.py).
-    def stage_march(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, rand=None):
-        """The part of stage_sample that does not depend on any field: the marching (sync-free mode only).  -> a record for
-        stage_sample(marched=...), which must get the same rays and draws."""
-        rand = rand or {}
-        return estimator.sampling_ex(
-            rays_o.contiguous().float(), rays_d.contiguous().float(), sigma_points_fn=lambda *a: None, near_plane=self.near_plane,
-            far_plane=self.far_plane, render_step_size=self.render_step_size, early_stop_eps=self.early_stop_eps, stratified=nerf.training,
-            cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'), max_steps=self.max_steps, capacity=self.sample_capacity,
-            points_aabb=nerf._aabb_host, head_samples=self.head_samples, lattice=self.lattice, march_only=True)
-
     def stage_sample(self, nerf: NGPNeRF, estimator: OccGridEstimator, rays_o, rays_d, rand=None, with_rgb=False,
-                     keep_features=False, marched=None, before_color=None):
+                     keep_features=False):
         """Sampling (marching, the no-grad density pass and visibility compaction of nerf_renderer.py:145-155), sample
         positions and -- with_rgb -- the colour field without gradient.  Returns a dict consumed by stage_composite, or
         None when the batch has no sample.  With self.sample_capacity set every per-sample array has that many rows and
@@ -95,7 +85,7 @@ class NeRFOCCRenderer(nn.Module):
             rays_o, rays_d, sigma_points_fn=sigma_points_fn, near_plane=self.near_plane, far_plane=self.far_plane,
             render_step_size=self.render_step_size, early_stop_eps=self.early_stop_eps, stratified=nerf.training,
             cone_angle=0., alpha_thre=0., jitter=rand.get('jitter'), max_steps=self.max_steps, capacity=self.sample_capacity,
-            points_aabb=nerf._aabb_host, head_samples=self.head_samples, lattice=self.lattice, marched=marched)
+            points_aabb=nerf._aabb_host, head_samples=self.head_samples, lattice=self.lattice)
         if sm.n_dev is None and sm.ray_indices.numel() <= 0:
             return None
         x01, sel = sm.x01, sm.sel
@@ -104,8 +94,6 @@ class NeRFOCCRenderer(nn.Module):
         st = {'ray_indices': sm.ray_indices, 't_starts': sm.t_starts, 't_ends': sm.t_ends, 'packed': sm.packed, 'sig0': sm.sig,
               'x01': x01, 'sel': sel, 'n_rays': rays_o.shape[0], 'rgbs': None, 'n_dev': sm.n_dev,
               'n_marched_dev': sm.n_marched_dev, 'feat0': sm.feat}
-        if before_color is not None:
-            before_color()                   # (captured steps: everything that reads the marched batch has been issued by now)
         if with_rgb:
             with torch.no_grad():
                 st['rgbs'] = nerf.rgb_at(x01, sel, sm.n_dev)

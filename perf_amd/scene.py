@@ -74,33 +74,6 @@ def _graph_node_count(graph):
         return None
 
 
-def _clone_tree(x):
-    """Deep copy of a (nested dict / tuple / list / Rays of) tensors; everything else is kept as it is."""
-    if torch.is_tensor(x):
-        return x.clone()
-    if isinstance(x, dict):
-        return {k: _clone_tree(v) for k, v in x.items()}
-    if isinstance(x, Rays):
-        return Rays(_clone_tree(x.o), _clone_tree(x.d))
-    if isinstance(x, (tuple, list)):
-        return type(x)(_clone_tree(v) for v in x)
-    return x
-
-
-def _copy_tree(dst, src):
-    """dst <- src for two trees of the same shape (see _clone_tree): device-to-device copies into EXISTING storage."""
-    if torch.is_tensor(dst):
-        dst.copy_(src)
-    elif isinstance(dst, dict):
-        for k in dst:
-            _copy_tree(dst[k], src[k])
-    elif isinstance(dst, Rays):
-        _copy_tree(dst.o, src.o); _copy_tree(dst.d, src.d)
-    elif isinstance(dst, (tuple, list)):
-        for a, b in zip(dst, src):
-            _copy_tree(a, b)
-
-
 OVERFLOW_CHECK_EVERY = 64      # training steps between reads of the fixed-point overflow flag (one host sync each)
 
 
@@ -459,18 +432,6 @@ class NeRFScene:
         self.device_rng = True
         self._rng_seed = None
         self._rng_counter = None
-        # hipGraph-replayed geometry steps on one GPU: the batch draw and the marching of step k+1 -- nothing in them depends on
-        # the field being trained -- are issued on a second stream beside the backward of step k (forked after the loss head,
-        # joined behind Adam; the next batch lands in static buffers the following replay reads).  Same draws in the same
-        # order: parameters bit-identical to the serial step (tests/test_gpu_counts.py).  OFF by default: measured SLOWER --
-        # bench step 1.134 vs 1.084 ms, faithful geometry step 0.295 vs 0.268 ms, 40 vs 26 graph nodes
-        # (profiles/r04_pipeline_marching.json): the marching kernels take CUs from the 236 LDS-owner workgroups of the grid
-        # backward, and the copies into the static buffers cost what the overlap saves.
-        # PERF_PIPELINE_MARCHING=2: fork BEFORE the colour field's encode instead (a kernel bound by the latency of its L1 misses,
-        # with the vector units idle) -- see DESIGN.md 6.1 for what that measured.
-        self.pipeline_marching = int(os.environ.get('PERF_PIPELINE_MARCHING', '0') or 0)
-        self._after_loss_hook = None
-        self._before_color_hook = None
 
     def _fixed_accum(self):
         return self.nerf.geo_mlp.grid_grad_accum == 'fixed' and self.nerf.app_mlp.grid_grad_accum == 'fixed'
@@ -668,17 +629,6 @@ class NeRFScene:
                     step_fn(optimizer, sup_pool, progress=progress_of(iter_i))
             if callback:
                 callback(kind, iter_i)
-        self._drop_pending_batch(graphed)
-
-    def _drop_pending_batch(self, graphed=None):
-        """A pipelined replay leaves the NEXT step's batch behind (drawn and marched beside its backward).  When nothing will
-        consume it -- the phase is over -- the draw is taken back: the device generator is a pure function of (seed, counter),
-        so whatever runs next draws exactly what it would have drawn after serial steps."""
-        st = getattr(graphed, 'state', None) if graphed is not None else None
-        pending = st.get('static_pre') if st else None
-        if pending is not None and self._geo_pre is pending:
-            self._rng_counter -= 1
-            self._geo_pre = None
 
     def _batch(self, sup_pool, generator=None):
         dist, rank, world = self._dist()
@@ -760,7 +710,7 @@ class NeRFScene:
             recapture = True
         return {'recapture': recapture}
 
-    def _geo_prefetch(self, sup_pool, rand, generator, with_marching=False):
+    def _geo_prefetch(self, sup_pool, rand, generator):
         """Everything of a geometry step that does not depend on the geometry parameters: batch draw, and -- when the
         sampler needs no density pre-pass (early_stop_eps == 0) -- marching, positions and the frozen colour field."""
         rand = dict(rand or {})
@@ -775,16 +725,12 @@ class NeRFScene:
             u = self._rand_rows(2, rays.o.shape[0], dist_info, rays.o.device)
             rand.setdefault('jitter', u[0].contiguous()); rand.setdefault('noise', u[1].contiguous().unsqueeze(1))
         st = None
-        marched = None
         if self.renderer.early_stop_eps <= 0:
             with torch.no_grad():
                 st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand,
                                                 with_rgb=not (self.fused_steps and self.skip_unused_color))
                 st = st if st is not None else False
-        elif with_marching:
-            with torch.no_grad():
-                marched = self.renderer.stage_march(self.nerf, self.estimator, rays.o, rays.d, rand)
-        return {'rays': rays, 'gt_depths': gt_depths, 'bs': bs, 'dist_info': dist_info, 'st': st, 'rand': rand, 'marched': marched}
+        return {'rays': rays, 'gt_depths': gt_depths, 'bs': bs, 'dist_info': dist_info, 'st': st, 'rand': rand}
 
     @staticmethod
     def _rand_rows(rows, n_local, dist_info, device):
@@ -950,15 +896,10 @@ class NeRFScene:
         st = pre['st']
         rand_in, rand = rand, pre['rand']
         if st is None:
-            if self._before_color_hook is not None:
-                # (the static batch is refilled from the hook on: what the loss head reads of it gets a copy of its own)
-                gt_depths = gt_depths.clone()
-                rand = dict(rand); rand['noise'] = rand['noise'].clone()
             # (under data parallelism the colour render is deferred until the gradient all-reduce is in flight, see below)
             st = self.renderer.stage_sample(self.nerf, self.estimator, rays.o, rays.d, rand,
                                             with_rgb=not (self.skip_unused_color or (dist_info[0] is not None and self.overlap_comm)),
-                                            keep_features=self.reuse_sampling_features and self.renderer.sample_capacity is not None,
-                                            marched=pre.get('marched'), before_color=self._before_color_hook)
+                                            keep_features=self.reuse_sampling_features and self.renderer.sample_capacity is not None)
         geo = self.nerf.geo_mlp
         extra = self.DP_EXTRA if dist_info[0] is not None else 0
         sharded = self._sharded(dist_info, optimizer)
@@ -999,8 +940,6 @@ class NeRFScene:
             self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
         g_op, g_dist, sc = ops.geo_loss(op, dist_r, gt_depths, noise, dl, packed, bs, tc.depth_loss_weight,
                                         tc.distortion_loss_weight, self._ratio_dev, self.loss_scale)
-        if self._after_loss_hook is not None:
-            self._after_loss_hook()          # (captured steps: the next step's draw + marching fork off here, make_graphed_step)
         dsig = ops.composite_distloss_bwd(sig.view(-1), ts, te, packed, w, T, op, dist_r, g_op, g_dist, 1.0, scale_dev=sc[2:3])
         self.last_losses['depth_loss'] = sc[0]; self.last_losses['dist_loss'] = sc[1]
 
@@ -1207,44 +1146,15 @@ class NeRFScene:
                 raise RuntimeError('make_graphed_step: a prefetched batch is pending; run the last eager geometry step with prefetch_next=False')
             self._rng_counter -= 1
             self._geo_pre = None
-        # Software pipeline (single GPU, geometry steps with a density pre-pass): the batch of the NEXT step -- draw + marching,
-        # nothing in them depends on the parameters -- is produced on a second stream beside this step's backward.  The first
-        # batch is produced here, eagerly, into buffers that stay: every replay reads them and, behind its loss head, refills
-        # them for the replay after it.
-        # (a REPLACED step function -- tests inject their own batches and draws -- is captured serially: the pipeline draws from
-        #  the device generator)
-        pipelined = (kind == 'geo' and self.pipeline_marching and (dist_info[0] is None or os.environ.get('PERF_PIPELINE_MARCHING_DP')) and self.device_rng and self.fused_steps
-                     and self.renderer.early_stop_eps > 0 and self.renderer.sample_capacity is not None
-                     and getattr(step_fn, '__func__', None) is NeRFScene.train_one_step_geo)
-        static_pre = side = None
-        if pipelined:
-            with torch.no_grad():
-                static_pre = _clone_tree(self._geo_prefetch(sup_pool, None, None, with_marching=True))
-            side = torch.cuda.Stream()
         torch.cuda.synchronize()
         count = getattr(self, 'count_graph_nodes', False)
         graph = torch.cuda.CUDAGraph(keep_graph=True) if count else torch.cuda.CUDAGraph()
         self._capturing = optimizer.capturing = True
         try:
             with _capture(graph):
-                if pipelined:
-                    self._geo_pre = static_pre
-
-                    def produce_next():
-                        main = torch.cuda.current_stream()
-                        side.wait_stream(main)                       # everything that reads the static batch has been issued
-                        with torch.cuda.stream(side), torch.no_grad():
-                            _copy_tree(static_pre, self._geo_prefetch(sup_pool, None, None, with_marching=True))
-                    if self.pipeline_marching == 2 and not self.skip_unused_color:
-                        self._before_color_hook = produce_next
-                    else:
-                        self._after_loss_hook = produce_next
                 step_fn(optimizer, sup_pool, progress=0.0)
-                if pipelined:
-                    torch.cuda.current_stream().wait_stream(side)
         finally:
             self._capturing = optimizer.capturing = False
-            self._after_loss_hook = self._before_color_hook = None
         if count:          # (bench.py: launches per replayed step)
             if not hasattr(self, 'graph_nodes'):
                 self.graph_nodes = {}
@@ -1252,9 +1162,7 @@ class NeRFScene:
             graph.instantiate()
 
         state = {'graph': graph, 'n': 0, 'counts': self._last_counts, 'capacity': self.renderer.sample_capacity,
-                 'mode': optimizer.net.grid_grad_accum, 'static_pre': static_pre, 'side_stream': side}
-        if pipelined:
-            self._geo_pre = static_pre                   # pending: the eagerly produced first batch
+                 'mode': optimizer.net.grid_grad_accum}
 
         def replay(lr=None, progress=None):
             if optimizer.sched_table is None:                    # no device-side schedule: refresh the two scalars
@@ -1263,8 +1171,6 @@ class NeRFScene:
                     self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
             state['graph'].replay()
             state['n'] += 1
-            if state.get('static_pre') is not None:
-                self._geo_pre = state['static_pre']      # the batch the replay left behind: what the next step (replayed or eager) consumes
             if kind == 'geo':
                 self.global_iter_step_geo += 1
             else:

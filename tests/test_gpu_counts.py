@@ -530,20 +530,17 @@ def test_device_batch_draw(ops):
 @pytest.mark.parametrize('head', [2, None])
 def test_device_rng_episode_graph_replay_equals_eager(head):
     """A short episode with the device generator (the default): graph-replayed steps == eager steps, bit for bit (same seed,
-    same counter sequence), and the captured step holds no torch random op.  Also with PIPELINED geometry steps (the next
-    step's batch draw and marching on a second stream beside the backward: NeRFScene.pipeline_marching, off by default) -- with the
-    two-phase sampler (head = 2: the counting pass writes the heads) and with the one-phase sampler bench.py uses; the serial
-    capture gives the same bits, and the draw of the batch nobody consumed at the end of the phase is taken back."""
+    same counter sequence), and the captured step holds no torch random op -- with the two-phase sampler (head = 2: the
+    counting pass writes the heads) and with the one-phase sampler bench.py uses."""
     res = {}
-    for mode in ('eager', 'graph', 'graph_early', 'graph_serial'):       # (graph_early: the fork sits before the colour field's encode)
+    for mode in ('eager', 'graph'):
         scene, pool, rays, dist, rgb = _room_scene(batch=1024)
         assert scene.device_rng
         scene.renderer.head_samples = head
         scene.graph_steps = (mode != 'eager')
-        scene.pipeline_marching = {'graph_serial': 0, 'graph_early': 2}.get(mode, 1)
         scene.train_one_episode(pool, 12, 8)
         assert scene._geo_pre is None
         res[mode] = (scene.nerf.geo_mlp.params.detach().clone(), scene.nerf.app_mlp.params.detach().clone(), int(scene._rng_counter.item()))
-    assert res['eager'][2] == res['graph'][2] == res['graph_early'][2] == res['graph_serial'][2] == 20
-    for mode in ('graph', 'graph_early', 'graph_serial'):
+    assert res['eager'][2] == res['graph'][2] == 20
+    for mode in ('graph',):
         assert torch.equal(res['eager'][0], res[mode][0]) and torch.equal(res['eager'][1], res[mode][1]), mode
