@@ -1,256 +1,11 @@
-// Multiresolution hash-grid encoding for gfx950 (tcnn "HashGrid" semantics).
-//
-// Design (MI355X-first): the encode is a random 4-byte-gather kernel whose working set
-// (13 MB of 16-bit tables per encoder) exceeds one XCD's 4 MiB L2.  Work is therefore cut
-// by LEVEL GROUP, not by sample alone: block b serves level group (b % 8) -- with the
-// dispatcher's round-robin block->XCD placement each XCD's private L2 then only ever sees
-// the two levels {g, L-1-g} of its group (<= 2 MiB), so gathers are L2 hits instead of
-// Infinity-Cache round trips.  Placement is a speed assumption only: results do not depend
-// on it.  Features leave the kernel LEVEL-MAJOR (feat[l][sample] as one packed 2x16-bit
-// dword), so every store and the MLP kernel's loads are fully coalesced.
+// Hash-grid parameter gradient for gfx950 (tcnn kernel_grid_backward semantics): LDS tile owners, no global atomics.
 #include <stdlib.h>
 #include <mutex>
 #include "common.hpp"
-
 #include "grid_device.hpp"
+#include "grid_fixed_point.hpp"
 
 namespace perf {
-
-constexpr int kHeadroomStartBias = 3;
-
-// level l handled by (group, pass).  L <= 16: pass 0 -> g, pass 1 -> L-1-g (if different) -- a coarse (small) and a
-// fine (large) table per group.  Deeper grids (L <= 24) add pass 2 -> 16+g; their tables exceed the L2 anyway.
-constexpr int kFwdPasses = 3;
-// at most this many 256-sample chunks per level group in one launch (the workgroups loop beyond): launches of up to 1 M
-// samples keep one workgroup per chunk (measured equal either way), while a capacity-sized launch of an eval frame -- 33 M
-// rows for a tail pass that holds a few thousand live samples -- no longer dispatches 10^6 workgroups that only read the
-// device-side count and leave (0.25 ms per frame)
-constexpr int64_t kFwdMaxChunks = 4096;
-__device__ __forceinline__ int level_of(int group, int pass, int L) {
-    if (pass == 2) return (16 + group < L) ? 16 + group : -1;
-    const int Lc = L < 16 ? L : 16;
-    int a = group, b = Lc - 1 - group;
-    if (a > b) return -1;
-    if (pass == 0) return a;
-    return (b != a) ? b : -1;
-}
-
-template <typename T16>
-__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const float* __restrict__ x01,
-                                                           const uint32_t* __restrict__ table,
-                                                           uint32_t* __restrict__ feat, int64_t n,
-                                                           const int64_t* __restrict__ n_dev, int xcd_affinity) {
-    // xcd_affinity == 0 (experiment only): consecutive blocks of one XCD walk through all level groups, so every L2
-    // sees the whole table -- used to measure what the level-group <-> XCD pinning is worth.
-    const int nchunks = (int)(gridDim.x >> 3);
-    const int group = xcd_affinity ? (int)(blockIdx.x & 7) : (int)((blockIdx.x >> 3) & 7);
-    const int64_t chunk0 = xcd_affinity ? (int64_t)(blockIdx.x >> 3)
-                                        : (int64_t)(blockIdx.x & 7) * ((nchunks + 7) >> 3) + (int64_t)(blockIdx.x >> 6);
-    if (!xcd_affinity && chunk0 >= nchunks) return;
-    const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
-    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
-    // chunk-stride loop: a capacity-sized launch (n >> n_live) is capped at `nchunks` chunks per level group, so that
-    // it does not pay for tens of thousands of workgroups that only find out that they have nothing to do
-    for (int64_t chunk = chunk0; chunk * 256 < n_live; chunk += nchunks) {
-    const int64_t i = chunk * 256 + threadIdx.x;
-    if (i >= n_live) break;
-    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
-#pragma unroll
-    for (int pass = 0; pass < kFwdPasses; ++pass) {
-        const int l = level_of(group, pass, gp.n_levels);
-        if (l < 0) continue;
-        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
-        const uint32_t* t = table + gp.offset[l];
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = t[c.idx[k]];
-        float w[8];
-        corner_weights(c.f, smooth, w);
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            a0 = fmaf(w[k], T16::lo(v[k]), a0);
-            a1 = fmaf(w[k], T16::hi(v[k]), a1);
-        }
-        feat[(int64_t)l * n + i] = T16::pack(a0, a1);
-    }
-    }
-}
-
-
-// ---- forward encode, second generation: run de-duplication + rotating level groups -----------------------------------------
-// The gathers of this kernel are bound by the L1's request rate (one cache-line look-up per active lane and cycle; the
-// tables sit in L2 / Infinity Cache), not by bandwidth.  Two things reduce what the slowest XCD has to issue:
-//  (1) run de-duplication: consecutive samples of a ray (training batches) and equal-rank samples of neighbouring pixels
-//      (eval frames) fall into the SAME cell at the coarse levels, i.e. neighbouring lanes gather the same eight entries.
-//      One DPP compare per level finds the runs; only run heads issue the gathers, the others fetch the head's packed
-//      dwords with ds_bpermute (LDS crossbar, ~2 cycles per 64 lanes instead of 64 L1 look-ups).  Interpolation stays
-//      per lane: features are bit-identical.  A wave whose lanes share little (> kShareMaxHeads heads) gathers as before.
-//  (2) de-duplication makes the level groups unequal (a coarse level costs a fraction of a fine one), and a fixed
-//      group <-> XCD pinning would leave the kernel as long as its most expensive group.  The pinning therefore ROTATES:
-//      the chunks of a launch are cut into eight phases, and in phase p XCD x serves group (x + p) % 8.  Every XCD serves
-//      every group for an eighth of the samples -- equal work whatever the levels cost -- while its L2 still holds two
-//      tables at a time (refilled from the Infinity Cache at each of the seven phase changes).  (A first attempt handed
-//      out (group, chunk) tickets through one device counter per group: same-address atomics retire at ~105 ns each on
-//      gfx950, 4096 tickets per counter made the kernel three times SLOWER -- tools/exp/fwd_v2.py, profiles/README.md.)
-constexpr int kShareMaxHeads = 56;
-
-template <typename T16>
-__global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, const float* __restrict__ x01,
-                                                              const uint32_t* __restrict__ table,
-                                                              uint32_t* __restrict__ feat, int64_t n,
-                                                              const int64_t* __restrict__ n_dev) {
-    const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
-    const int64_t nchunks_live = (n_live + 255) >> 8;
-    const int64_t nchunks_grid = (int64_t)(gridDim.x >> 3);
-    const int xcd = (int)(blockIdx.x & 7);
-    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long below = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= mine
-    // chunk-stride loop: a capacity-sized launch (n >> n_live) is capped at nchunks_grid chunks per XCD
-    for (int64_t chunk = (int64_t)(blockIdx.x >> 3); chunk < nchunks_live; chunk += nchunks_grid) {
-        // phase of a chunk: its position within the pass of the grid over the chunks (any function of the chunk alone keeps
-        // the eight workgroups of a chunk on eight different groups)
-        const int64_t in_pass = chunk % nchunks_grid, pass_len = nchunks_live < nchunks_grid ? nchunks_live : nchunks_grid;
-        const int phase = (int)((in_pass * 8) / pass_len) & 7;
-        const int g = (xcd + phase) & 7;
-        const int64_t i = chunk * 256 + threadIdx.x;
-        const bool live = i < n_live;
-        const int64_t ii = live ? i : n_live - 1;                // (idle lanes of the last chunk repeat its last sample)
-        const float x = x01[3 * ii], y = x01[3 * ii + 1], z = x01[3 * ii + 2];
-        // Both levels of the group are set up first, then all their gathers are issued, then shared and interpolated: the
-        // (L1-hit) coarse and the (L2-served) fine level stay in flight together.
-        int lv[2];
-        Corners c[2];
-        bool head[2], share[2];
-        uint32_t src[2];
-        uint32_t v[2][8];
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            lv[pass] = level_of(g, pass, gp.n_levels);
-            head[pass] = lv[pass] >= 0; share[pass] = false; src[pass] = lane;
-            if (lv[pass] < 0) continue;
-            const int l = lv[pass];
-            c[pass] = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
-            {
-                // lane - 1's cell through DPP (wave_shr:1; lane 0 keeps the `old` operand)
-                const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[0], 0x138, 0xf, 0xf, false);
-                const uint32_t py = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[1], 0x138, 0xf, 0xf, false);
-                const uint32_t pz = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[2], 0x138, 0xf, 0xf, false);
-                const bool same = lane != 0u && px == c[pass].cell[0] && py == c[pass].cell[1] && pz == c[pass].cell[2];
-                const unsigned long long heads = __ballot(!same);
-                share[pass] = __popcll(heads) <= kShareMaxHeads;      // wave-uniform
-                if (share[pass]) {
-                    head[pass] = !same;
-                    src[pass] = 63u - (uint32_t)__clzll((long long)(heads & below));     // the head of my run
-                }
-            }
-        }
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[pass][k] = 0u;
-            if (head[pass]) {
-                const uint32_t* t = table + gp.offset[lv[pass]];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[pass][k] = t[c[pass].idx[k]];
-            }
-        }
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            if (lv[pass] < 0) continue;
-            if (share[pass]) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[pass][k] = (uint32_t)__shfl((int)v[pass][k], (int)src[pass]);
-            }
-            float w[8];
-            corner_weights(c[pass].f, smooth, w);
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                a0 = fmaf(w[k], T16::lo(v[pass][k]), a0);
-                a1 = fmaf(w[k], T16::hi(v[pass][k]), a1);
-            }
-            if (live) feat[(int64_t)lv[pass] * n + i] = T16::pack(a0, a1);
-        }
-    }
-}
-
-// Two tables with the SAME grid geometry (PeRF's density and colour fields, ngp_nerf.py:96-134) evaluated at the
-// same points: corner indices and weights are computed once, 16 gathers are in flight per (sample, level).
-template <typename T16>
-__global__ __launch_bounds__(256) void hashgrid_fwd2_kernel(GridParams gp, const float* __restrict__ x01,
-                                                            const uint32_t* __restrict__ table_a,
-                                                            const uint32_t* __restrict__ table_b,
-                                                            uint32_t* __restrict__ feat_a, uint32_t* __restrict__ feat_b,
-                                                            int64_t n) {
-    const int group = blockIdx.x & 7;
-    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
-    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
-#pragma unroll
-    for (int pass = 0; pass < kFwdPasses; ++pass) {
-        const int l = level_of(group, pass, gp.n_levels);
-        if (l < 0) continue;
-        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
-        const uint32_t* ta = table_a + gp.offset[l];
-        const uint32_t* tb = table_b + gp.offset[l];
-        uint32_t va[8], vb[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { va[k] = ta[c.idx[k]]; vb[k] = tb[c.idx[k]]; }
-        float w[8];
-        corner_weights(c.f, smooth, w);
-        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            a0 = fmaf(w[k], T16::lo(va[k]), a0); a1 = fmaf(w[k], T16::hi(va[k]), a1);
-            b0 = fmaf(w[k], T16::lo(vb[k]), b0); b1 = fmaf(w[k], T16::hi(vb[k]), b1);
-        }
-        feat_a[(int64_t)l * n + i] = T16::pack(a0, a1);
-        feat_b[(int64_t)l * n + i] = T16::pack(b0, b1);
-    }
-}
-
-// corner table indices (absolute entry index, level offset included) of every (level, sample): the integer half of
-// the encoding, exported so that arbitrarily-often differentiable compositions can be built on top of it
-__global__ __launch_bounds__(256) void hashgrid_corners_kernel(GridParams gp, const float* __restrict__ x01,
-                                                               int32_t* __restrict__ idx_out, int64_t n) {
-    const int l = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || l >= gp.n_levels) return;
-    const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
-    int32_t* o = idx_out + ((int64_t)l * n + i) * 8;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (int32_t)(gp.offset[l] + c.idx[k]);
-}
-
-__global__ __launch_bounds__(256) void hashgrid_fwd_f32_kernel(GridParams gp, const float* __restrict__ x01,
-                                                               const float2* __restrict__ table,
-                                                               float2* __restrict__ feat, int64_t n) {
-    const int group = blockIdx.x & 7;
-    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
-    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
-#pragma unroll
-    for (int pass = 0; pass < kFwdPasses; ++pass) {
-        const int l = level_of(group, pass, gp.n_levels);
-        if (l < 0) continue;
-        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
-        const float2* t = table + gp.offset[l];
-        float w[8];
-        corner_weights(c.f, smooth, w);
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float2 v = t[c.idx[k]];
-            a0 = fmaf(w[k], v.x, a0);
-            a1 = fmaf(w[k], v.y, a1);
-        }
-        feat[(int64_t)l * n + i] = make_float2(a0, a1);
-    }
-}
 
 // Parameter gradient.  gfx950 global fp32 atomics retire at a flat ~2e10/s whatever their scope or
 // address distribution (tools/exp/atomics.hip), i.e. ~13 ms for the 2.7e8 corner updates of a
@@ -451,46 +206,6 @@ __device__ __forceinline__ void apply_pairs_dense(const BwdCtx& cx, float* lds_t
             else { unsafeAtomicAdd(&lds_tile[2 * a1], w1 * g.x); unsafeAtomicAdd(&lds_tile[2 * a1 + 1], w1 * g.y); }
         }
     }
-}
-
-// Scale of the fixed-point gradient fields of level l: one unit = 2^-sh.
-__device__ __forceinline__ int fixed_point_shift(const float am, const int64_t n_live, const uint32_t size,
-                                                 const int32_t* __restrict__ hr_state, const int l) {
-    int e = 0;
-    if (am > 0.f) (void)frexpf(am, &e);                         // am < 2^e
-    if (e < -80) e = -80;                                        // (vanishing gradients: keep 2^sh finite)
-    // Headroom of the fixed-point fields: an entry of level l sums 8 n / size_l contributions on average (1,700 at
-    // the coarsest level of a 1 M-sample batch, 32 at a hashed one); 64x that average before the overflow flag is
-    // raised, never less than 2^12, never more than 2^24 (which still leaves 2^-7 of the largest contribution as the
-    // unit).  Derived from the LIVE sample count, so a capacity-sized launch keeps the resolution of an exact one.
-    const unsigned long long fan = (8ull * (unsigned long long)n_live + size - 1ull) / size;     // ceil(8 n / size)
-    int h = (fan <= 1ull ? 0 : 64 - __clzll((long long)(fan - 1ull))) + 6;                      // ceil(log2(fan)) + 6
-    if (hr_state) {
-        // Closed loop (caller-owned state, see perf_hashgrid_bwd): the static guess is corrected by what the fields of
-        // the PREVIOUS calls really reached -- entries near a panorama's common ray origin sum 30x the average number
-        // of contributions, hashed levels far fewer than the guess allows.  Starts 3 bits on the safe side.
-        h += hr_state[l] + kHeadroomStartBias;
-        h = h < 4 ? 4 : (h > 28 ? 28 : h);
-    } else {
-        h = h < 12 ? 12 : (h > 24 ? 24 : h);
-    }
-    return 31 - h - e;
-}
-
-// Headroom feedback: keep the largest field of a level between 2^21 and 2^25 units.  Above: add the excess bits at once
-// (+1); below: give one bit back per call.  fm = the largest |field| the level's FINAL sums reached in the previous call
-// (all replicas -- and, under data parallelism, all ranks -- added up), so that every partition of a batch follows the
-// same sequence of units.  Deterministic: the state is a function of the call history only.
-// The top of the band sits 16x below the level at which the overflow flag is raised (2^29) and the step gate drops the
-// step: a soak of 25 episodes with the band at [2^23, 2^27] (4x) lost 8 of 112,500 steps to flags that were not
-// overflows -- the colour table's largest sum quadrupling from one batch to the next (tools/soak_episodes.py).
-constexpr int kHeadroomTopBit = 25, kHeadroomLowBit = 21;
-constexpr int kLaggedMinHeadroom = 12;     // (dp_units_kernel, lagged units)
-constexpr int kLaggedMaxFinerBits = 2;
-__device__ __forceinline__ int headroom_feedback(int adj, int fm) {
-    if (fm >= (1 << kHeadroomTopBit)) adj += (32 - __clz(fm)) - kHeadroomTopBit + 1;
-    else if (fm < (1 << kHeadroomLowBit) && adj > -24) adj -= 1;
-    return adj;
 }
 
 // one sample's contribution to the tile this workgroup owns
@@ -1461,411 +1176,9 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp,
     if (threadIdx.x == 0) hr_state[2 * PERF_MAX_LEVELS] = 0;
 }
 
-// ---- job-wide fixed-point units for data-parallel training ----------------------------------------------------------------
-// Every rank of a data-parallel step scatters ITS samples into integer fields; the ranks' tables can be added up exactly
-// (an integer reduce-scatter) -- and equal the single-process table bit for bit -- iff all ranks use the units the single
-// process would: derived from the job-wide max |dfeat| per level, the job-wide live sample count and the headroom state
-// driven by the largest field of the SUMMED table of the previous step.  Ranks exchange one small block of statistics
-// (perf_dp_stats_pack -> all-gather -> perf_dp_units) between the MLP backward and the grid backward.
-__global__ void dp_stats_pack_kernel(const float* __restrict__ level_absmax, const int32_t* __restrict__ field_max_prev,
-                                     const int64_t* __restrict__ n_dev, int64_t n, int32_t* __restrict__ stats) {
-    const int i = threadIdx.x;
-    if (i < PERF_MAX_LEVELS) {
-        stats[i] = __float_as_int(level_absmax[i]);
-        stats[PERF_MAX_LEVELS + i] = field_max_prev ? field_max_prev[i] : -1;
-    } else if (i == 2 * PERF_MAX_LEVELS) {
-        const int64_t live = live_count(n, n_dev);
-        stats[i] = (int32_t)(live & 0xffffffffll);
-        stats[i + 1] = (int32_t)(live >> 32);
-    } else if (i > 2 * PERF_MAX_LEVELS + 1 && i < PERF_DP_STATS) {
-        stats[i] = 0;
-    }
-}
-
-__global__ void dp_units_kernel(GridParams gp, const int32_t* __restrict__ stats_all, int world, int32_t* __restrict__ hr_state,
-                                int32_t* __restrict__ shifts, int64_t* __restrict__ n_total_out, int margin_bits) {
-    __shared__ long long total_s;
-    if (threadIdx.x == 0) {
-        long long tot = 0;
-        for (int r = 0; r < world; ++r) {
-            const int32_t* st = stats_all + (int64_t)r * PERF_DP_STATS + 2 * PERF_MAX_LEVELS;
-            tot += (long long)(uint32_t)st[0] | ((long long)st[1] << 32);
-        }
-        total_s = tot;
-        if (n_total_out) n_total_out[0] = tot;
-    }
-    __syncthreads();
-    const int l = threadIdx.x;
-    if (l >= gp.n_levels) return;
-    float am = 0.f;
-    int fm = -1;
-    for (int r = 0; r < world; ++r) {
-        const int32_t* st = stats_all + (int64_t)r * PERF_DP_STATS;
-        am = fmaxf(am, __int_as_float(st[l]));
-        fm = max(fm, st[PERF_MAX_LEVELS + l]);
-    }
-    if (fm >= 0) hr_state[l] = headroom_feedback(hr_state[l], fm);        // (-1: no previous call, nothing to feed back)
-    // margin_bits > 0: the units come from the PREVIOUS step's statistics (lagged mode, see perf_dp_slot_pack).  The closed loop
-    // lets the headroom h of a level sink to 4 bits where an entry's contributions cancel (late in a phase the gradient is
-    // noise): ONE contribution of a sample whose |dfeat| is 2^(h-2) times last step's maximum then reaches the flag level --
-    // |dfeat| is heavy tailed, and a two-episode soak with h as the exact units have it lost 33 of 9,000 steps to such
-    // outliers (tools/exp/dp_lag_diag.py: sporadic, in the second half of the geometry phase).  Lagged units therefore keep at
-    // least kLaggedMinHeadroom bits (a single contribution needs 2^11 times last step's maximum to flag; the unit stays below
-    // 2^-18 of that maximum) and add margin_bits on top.
-    int sh = fixed_point_shift(am, total_s, gp.size[l], hr_state, l);
-    if (margin_bits > 0) {
-        int e = 0;
-        if (am > 0.f) (void)frexpf(am, &e);
-        if (e < -80) e = -80;
-        int h = 31 - e - sh;
-        if (h < kLaggedMinHeadroom) h = kLaggedMinHeadroom;
-        sh = 31 - e - (h + margin_bits);
-        // ... and never get more than kLaggedMaxFinerBits finer than the units of the step before (shifts[] still holds them: a
-        // lagged call always follows a call that set it).  max |dfeat| is heavy tailed DOWNWARDS too: the depth loss of a batch the
-        // field already fits vanishes (1e-21, 3e-38, 0 observed), units derived from that are 2^50 times too fine for the
-        // ordinary batch that follows, and the job-wide gate dropped that step -- 10-12 of the 300 geometry steps of
-        // tests/golden/psnr_curve.json's schedule at every margin from 1 to 6 bits (tools/exp/dp_margin_sweep.py).  Units may get
-        // coarser at once.
-        const int prev = shifts[l];
-        if (sh > prev + kLaggedMaxFinerBits) sh = prev + kLaggedMaxFinerBits;
-    }
-    shifts[l] = sh;
-}
-
-// ---- the small all-reduce of a data-parallel step: one slot of PERF_DP_SLOT floats per rank behind the MLP weight gradient ----
-// A SUM all-reduce over a buffer in which every rank fills only ITS slot is an all-gather; integers travel as 16-bit pieces
-// (exact in fp32).  Slot layout: [0,24) max |dfeat| per level; [24,48) / [48,72) low / high 16 bits of the largest |field| per
-// level of the rank's slice of THIS step's summed table; [72,76) the live sample count in 16-bit pieces; [76] overflow flag
-// (local grid backward OR the rank's slice of the summed table); [77] batch truncated at the sample capacity.
-__global__ void dp_slot_pack_kernel(const float* __restrict__ level_absmax, const int32_t* __restrict__ field_max,
-                                    const int64_t* __restrict__ n_dev, int64_t n, const int32_t* __restrict__ overflow_flag,
-                                    const int64_t* __restrict__ n_marched_dev, int64_t capacity, int rank, int world,
-                                    float* __restrict__ slots) {
-    for (int i = threadIdx.x; i < world * PERF_DP_SLOT; i += blockDim.x) {
-        float v = 0.f;
-        const int r = i / PERF_DP_SLOT, k = i % PERF_DP_SLOT;
-        if (r == rank) {
-            if (k < PERF_MAX_LEVELS) v = level_absmax ? level_absmax[k] : 0.f;
-            else if (k < 2 * PERF_MAX_LEVELS) v = field_max ? (float)(field_max[k - PERF_MAX_LEVELS] & 0xffff) : 0.f;
-            else if (k < 3 * PERF_MAX_LEVELS) v = field_max ? (float)((uint32_t)field_max[k - 2 * PERF_MAX_LEVELS] >> 16) : 0.f;
-            else if (k < 3 * PERF_MAX_LEVELS + 4) {
-                const uint64_t live = (uint64_t)live_count(n, n_dev);
-                v = (float)((live >> (16 * (k - 3 * PERF_MAX_LEVELS))) & 0xffffull);
-            } else if (k == 3 * PERF_MAX_LEVELS + 4) v = (overflow_flag && overflow_flag[0] != 0) ? 1.f : 0.f;
-            else if (k == 3 * PERF_MAX_LEVELS + 5) v = (n_marched_dev && capacity > 0 && n_marched_dev[0] > capacity) ? 1.f : 0.f;
-        }
-        slots[i] = v;
-    }
-}
-
-// after the all-reduce: the ranks' slots -> the statistics block perf_dp_units reads (as if all-gathered by
-// perf_dp_stats_pack, with the field maxima of THIS step), the job-wide flags {overflow, truncated} perf_step_bookkeeping
-// reads as remote_flags, and the job's sample count
-__global__ void dp_slot_unpack_kernel(const float* __restrict__ slots, int world, int32_t* __restrict__ stats_all,
-                                      float* __restrict__ job_flags, int64_t* __restrict__ n_total_out) {
-    if (threadIdx.x == 0) {
-        float ovf = 0.f, trunc = 0.f;
-        long long tot = 0;
-        for (int r = 0; r < world; ++r) {
-            const float* s = slots + (int64_t)r * PERF_DP_SLOT + 3 * PERF_MAX_LEVELS;
-            ovf += s[4]; trunc += s[5];
-            tot += (long long)s[0] + ((long long)s[1] << 16) + ((long long)s[2] << 32) + ((long long)s[3] << 48);
-        }
-        if (job_flags) { job_flags[0] = ovf; job_flags[1] = trunc; }
-        if (n_total_out) n_total_out[0] = tot;
-    }
-    if (!stats_all) return;
-    for (int i = threadIdx.x; i < world * PERF_DP_STATS; i += blockDim.x) {
-        const int r = i / PERF_DP_STATS, k = i % PERF_DP_STATS;
-        const float* s = slots + (int64_t)r * PERF_DP_SLOT;
-        int32_t v = 0;
-        if (k < PERF_MAX_LEVELS) v = __float_as_int(s[k]);
-        else if (k < 2 * PERF_MAX_LEVELS) v = (int32_t)s[k] | ((int32_t)s[k + PERF_MAX_LEVELS] << 16);
-        else if (k == 2 * PERF_MAX_LEVELS) v = (int32_t)s[3 * PERF_MAX_LEVELS] | ((int32_t)s[3 * PERF_MAX_LEVELS + 1] << 16);
-        else if (k == 2 * PERF_MAX_LEVELS + 1) v = (int32_t)s[3 * PERF_MAX_LEVELS + 2] | ((int32_t)s[3 * PERF_MAX_LEVELS + 3] << 16);
-        stats_all[i] = v;
-    }
-}
-
-// int32 field pairs of table entries [entry_lo, entry_hi) -> fp32 gradients, in place; per-level largest |field| of the
-// slice (atomicMax into field_max, zeroed by the caller) and the overflow flag
-__global__ __launch_bounds__(256) void fixed_unfix_kernel(GridParams gp, int32_t* __restrict__ buf, int64_t entry_lo, int64_t entry_hi,
-                                                          const int32_t* __restrict__ shifts, int32_t* __restrict__ field_max,
-                                                          int32_t* __restrict__ overflow_flag) {
-    __shared__ int32_t fm_s[PERF_MAX_LEVELS];
-    // level starts and units in LDS: gp.offset[l] with a per-lane l is a vector load from the kernel-argument segment, waited for
-    // with vmcnt(0) -- i.e. behind the data loads, once per entry (this kernel took 44 us for 53 MB)
-    __shared__ uint64_t start_s[PERF_MAX_LEVELS + 1];
-    __shared__ float unit_s[PERF_MAX_LEVELS];
-    if (threadIdx.x < PERF_MAX_LEVELS) {
-        fm_s[threadIdx.x] = 0;
-        start_s[threadIdx.x] = (int)threadIdx.x < gp.n_levels ? gp.offset[threadIdx.x] : ~0ull;
-        unit_s[threadIdx.x] = (int)threadIdx.x < gp.n_levels ? ldexpf(1.0f, -shifts[threadIdx.x]) : 0.f;
-    }
-    if (threadIdx.x == 0) start_s[PERF_MAX_LEVELS] = ~0ull;
-    __syncthreads();
-    int cur_l = 0, cur_m = 0;            // a thread's entries ascend: it stays in one level for long runs
-    float from_fixed = unit_s[0];
-    // The walk is "load, convert, store IN PLACE": a load behind a store through the same pointer waits for it, so eight entries
-    // are loaded before the first of them is stored (a load per iteration was a round trip per entry).
-    // (a workgroup takes 2,048 consecutive entries at a time: its threads change level together, and rarely)
-    for (int64_t e0 = entry_lo + (int64_t)blockIdx.x * 2048 + threadIdx.x; e0 < entry_hi; e0 += (int64_t)gridDim.x * 2048) {
-        int2 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t e = e0 + j * 256;
-            v[j] = reinterpret_cast<const int2*>(buf)[(e < entry_hi ? e : entry_hi - 1) - entry_lo];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t e = e0 + j * 256;
-            if (e >= entry_hi) break;
-            if ((uint64_t)e >= start_s[cur_l + 1]) {
-                if (cur_m > 0) atomicMax(&fm_s[cur_l], cur_m);
-                while ((uint64_t)e >= start_s[cur_l + 1]) ++cur_l;
-                cur_m = 0;
-                from_fixed = unit_s[cur_l];
-            }
-            if (v[j].x == 0 && v[j].y == 0) continue;                  // (integer 0 is 0.0f)
-            reinterpret_cast<float2*>(buf)[e - entry_lo] = make_float2((float)v[j].x * from_fixed, (float)v[j].y * from_fixed);
-            const int32_t ax = v[j].x < 0 ? -(v[j].x + 1) : v[j].x, ay = v[j].y < 0 ? -(v[j].y + 1) : v[j].y;
-            cur_m = max(cur_m, max(ax, ay));
-        }
-    }
-    // (a wave's lanes nearly always end in the same level: one LDS atomic per wave instead of 64 on one address)
-    const int l0 = __shfl(cur_l, 0);
-    if (__all(cur_l == l0)) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) cur_m = max(cur_m, __shfl_xor(cur_m, off));
-        if ((threadIdx.x & 63) == 0 && cur_m > 0) atomicMax(&fm_s[cur_l], cur_m);
-    } else if (cur_m > 0) {
-        atomicMax(&fm_s[cur_l], cur_m);
-    }
-    __syncthreads();
-    if (threadIdx.x < PERF_MAX_LEVELS && fm_s[threadIdx.x] > 0) {
-        // same-address read-modify-writes retire one after the other (~11 ns each): a maximum only needs the workgroups that
-        // RAISE it -- a handful of thousands -- so look first (an atomic load is served by the L2 like any other)
-        if (field_max && fm_s[threadIdx.x] > __hip_atomic_load(&field_max[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(&field_max[threadIdx.x], fm_s[threadIdx.x]);
-        if (overflow_flag && fm_s[threadIdx.x] >= (1 << 29)) atomicOr(overflow_flag, 1);
-    }
-}
-
-// Input gradient dL/dx (fp32 table).  One thread walks all levels of its sample.
-__global__ __launch_bounds__(256) void hashgrid_bwd_input_kernel(GridParams gp, const float* __restrict__ x01,
-                                                                 const float2* __restrict__ dfeat,
-                                                                 const float2* __restrict__ table,
-                                                                 float* __restrict__ dx, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
-    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int l = 0; l < gp.n_levels; ++l) {
-        const float2 g = dfeat[(int64_t)l * n + i];
-        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
-        const float2* t = table + gp.offset[l];
-        float f[3] = {c.f[0], c.f[1], c.f[2]};
-        float s[3], ds[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if (smooth) { s[d] = f[d] * f[d] * (3.f - 2.f * f[d]); ds[d] = 6.f * f[d] * (1.f - f[d]); }
-            else { s[d] = f[d]; ds[d] = 1.f; }
-        }
-        float ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float2 v = t[c.idx[k]];
-            float dot = v.x * g.x + v.y * g.y;
-            float wx = (k & 1) ? s[0] : 1.f - s[0], wy = (k & 2) ? s[1] : 1.f - s[1], wz = (k & 4) ? s[2] : 1.f - s[2];
-            float sx = (k & 1) ? 1.f : -1.f, sy = (k & 2) ? 1.f : -1.f, sz = (k & 4) ? 1.f : -1.f;
-            ax += sx * wy * wz * dot; ay += wx * sy * wz * dot; az += wx * wy * sz * dot;
-        }
-        gx += ax * ds[0] * gp.scale[l]; gy += ay * ds[1] * gp.scale[l]; gz += az * ds[2] * gp.scale[l];
-    }
-    dx[3 * i] = gx; dx[3 * i + 1] = gy; dx[3 * i + 2] = gz;
-}
-
-// ---- second order: the backward of the input gradient (tcnn kernel_grid_backward_input_backward_*) --------------------
-// The input gradient  gx_i = sum_l sum_c (d w_c / d x_i) (theta[idx_c] . dy_l)  is linear in dy and in the table and
-// non-linear in x.  Given gg = dL/d gx [n,3] its backward has three pieces:
-//   d_dy[l]      = sum_c W'_c theta[idx_c]                     with  W'_c = sum_i gg_i d w_c / d x_i
-//   d_theta[idx] += W'_c dy_l                                  (hashgrid_bwd_bwd_param_kernel)
-//   d_x_j        = sum_l sum_c (sum_i gg_i d^2 w_c / d x_i d x_j) (theta[idx_c] . dy_l)
-// with  w_c = prod_d u_d,  u_d = s_d or 1 - s_d,  s_d = f_d (Linear) or f_d^2 (3 - 2 f_d) (Smoothstep),  d s_d / d x_d = s' scale.
-// Consumer: SphereDistanceField (modules/geo_predictors/pano_joint_predictor.py:50-69: autograd.grad(distance, directions,
-// create_graph=True) followed by a loss on that gradient).
-struct Interp { float s[3], ds[3], dds[3]; };        // per dimension: value, d/dx, d^2/dx^2 (scale folded in)
-
-__device__ __forceinline__ Interp interp_of(const float f[3], bool smooth, float scale) {
-    Interp t;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        if (smooth) { t.s[d] = f[d] * f[d] * (3.f - 2.f * f[d]); t.ds[d] = 6.f * f[d] * (1.f - f[d]) * scale; t.dds[d] = (6.f - 12.f * f[d]) * scale * scale; }
-        else { t.s[d] = f[d]; t.ds[d] = scale; t.dds[d] = 0.f; }
-    }
-    return t;
-}
-
-// W'_c = sum_i gg_i d w_c / d x_i   for corner c (bit0 = x, bit1 = y, bit2 = z)
-__device__ __forceinline__ float corner_dw_dot(const Interp& t, int c, const float gg[3]) {
-    const float u[3] = {(c & 1) ? t.s[0] : 1.f - t.s[0], (c & 2) ? t.s[1] : 1.f - t.s[1], (c & 4) ? t.s[2] : 1.f - t.s[2]};
-    const float sg[3] = {(c & 1) ? 1.f : -1.f, (c & 2) ? 1.f : -1.f, (c & 4) ? 1.f : -1.f};
-    return gg[0] * sg[0] * t.ds[0] * u[1] * u[2] + gg[1] * sg[1] * t.ds[1] * u[0] * u[2] + gg[2] * sg[2] * t.ds[2] * u[0] * u[1];
-}
-
-__global__ __launch_bounds__(256) void hashgrid_bwd_bwd_input_kernel(GridParams gp, const float* __restrict__ x01,
-                                                                     const float2* __restrict__ dy, const float2* __restrict__ table,
-                                                                     const float* __restrict__ ggx, float2* __restrict__ d_dy,
-                                                                     float* __restrict__ d_x, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
-    const float gg[3] = {ggx[3 * i], ggx[3 * i + 1], ggx[3 * i + 2]};
-    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
-    float hx[3] = {0.f, 0.f, 0.f};
-    for (int l = 0; l < gp.n_levels; ++l) {
-        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
-        const Interp t = interp_of(c.f, smooth, gp.scale[l]);
-        const float2* tb = table + gp.offset[l];
-        const float2 g = dy ? dy[(int64_t)l * n + i] : make_float2(0.f, 0.f);
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float2 v = tb[c.idx[k]];
-            a0 += corner_dw_dot(t, k, gg) * v.x;
-            a1 += corner_dw_dot(t, k, gg) * v.y;
-            if (d_x) {
-                const float dot = v.x * g.x + v.y * g.y;
-                const float u[3] = {(k & 1) ? t.s[0] : 1.f - t.s[0], (k & 2) ? t.s[1] : 1.f - t.s[1], (k & 4) ? t.s[2] : 1.f - t.s[2]};
-                const float sg[3] = {(k & 1) ? 1.f : -1.f, (k & 2) ? 1.f : -1.f, (k & 4) ? 1.f : -1.f};
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int p = (j + 1) % 3, q = (j + 2) % 3;
-                    // sum_i gg_i d^2 w / dx_i dx_j: the diagonal term and the two mixed terms
-                    const float h = gg[j] * sg[j] * t.dds[j] * u[p] * u[q]
-                                  + gg[p] * sg[p] * t.ds[p] * sg[j] * t.ds[j] * u[q]
-                                  + gg[q] * sg[q] * t.ds[q] * sg[j] * t.ds[j] * u[p];
-                    hx[j] += h * dot;
-                }
-            }
-        }
-        if (d_dy) d_dy[(int64_t)l * n + i] = make_float2(a0, a1);
-    }
-    if (d_x) { d_x[3 * i] = hx[0]; d_x[3 * i + 1] = hx[1]; d_x[3 * i + 2] = hx[2]; }
-}
-
-// d_theta[idx_c] += W'_c dy_l   (one thread per (sample, level); global fp32 atomics: this consumer's batches are 10^4
-// points, see the comment on hashgrid_bwd_atomic_kernel for the rate)
-__global__ __launch_bounds__(256) void hashgrid_bwd_bwd_param_kernel(GridParams gp, const float* __restrict__ x01,
-                                                                     const float2* __restrict__ dy, const float* __restrict__ ggx,
-                                                                     float* __restrict__ grad, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int l = blockIdx.y;
-    if (i >= n || l >= gp.n_levels) return;
-    const float2 g = dy[(int64_t)l * n + i];
-    if (g.x == 0.f && g.y == 0.f) return;
-    const float gg[3] = {ggx[3 * i], ggx[3 * i + 1], ggx[3 * i + 2]};
-    const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
-    const Interp t = interp_of(c.f, gp.interpolation == PERF_INTERP_SMOOTHSTEP, gp.scale[l]);
-    float* tb = grad + 2 * gp.offset[l];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float w = corner_dw_dot(t, k, gg);
-        unsafeAtomicAdd(tb + 2 * (uint64_t)c.idx[k], w * g.x);
-        unsafeAtomicAdd(tb + 2 * (uint64_t)c.idx[k] + 1, w * g.y);
-    }
-}
-
-static inline unsigned grouped_grid(int64_t n) { return (unsigned)(div_up(n, 256) * 8); }
-
 }  // namespace perf
 
 using namespace perf;
-
-extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* table16,
-                                 void* feat16, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
-    GridParams gp;
-    int rc = fill_params(grid, &gp);
-    if (rc) return rc;
-    PERF_REQUIRE(n >= 0 && n < (int64_t(1) << 31) * 16, "n out of range");
-    if (n == 0) return PERF_OK;
-    PERF_REQUIRE(x01 && table16 && feat16, "NULL pointer");
-    // level group <-> XCD pinning only pays when every one of the 8 groups has a level (L >= 15); a grid of a few levels
-    // (a rank's slice of a level-sharded table, the 5-level proposal field) would otherwise keep 1-3 XCDs busy
-    const int xcd_affinity = gp.n_levels >= 15 ? 1 : 0;
-    // chunks (of 256 samples) per level group in one launch; beyond that the workgroups loop
-    int64_t chunks = div_up(n, 256);
-    if (xcd_affinity && chunks > kFwdMaxChunks) chunks = kFwdMaxChunks;
-    // ---- rotating level groups + run de-duplication (15/16-level grids).  (The measured-slower settings of this path -- no
-    //      rotation, no de-duplication, the round-2 kernel for these grids, looping workgroups -- are tools/exp/r05_retired_variants.diff.)
-    if (xcd_affinity && gp.n_levels <= 16) {
-        // (one workgroup per chunk up to 4096 chunks per XCD: the rotation relies on chunks being served in dispatch order --
-        //  512 looping workgroups per XCD measured 0.307 instead of 0.177 ms per 1 M samples: phases mix, every L2 sees every table)
-        dim3 g((unsigned)(chunks * 8)), b(256);
-        if (dtype == PERF_DTYPE_BF16)
-            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev);
-        else if (dtype == PERF_DTYPE_FP16)
-            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev);
-        else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
-        PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
-        return PERF_OK;
-    }
-    dim3 g(xcd_affinity ? (unsigned)(chunks * 8) : (unsigned)(div_up(div_up(n, 256), 8) * 64)), b(256);
-    if (dtype == PERF_DTYPE_BF16)
-        hipLaunchKernelGGL(hashgrid_fwd_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, xcd_affinity);
-    else if (dtype == PERF_DTYPE_FP16)
-        hipLaunchKernelGGL(hashgrid_fwd_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, xcd_affinity);
-    else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
-    PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
-    return PERF_OK;
-}
-
-extern "C" int perf_hashgrid_fwd2(const perf_grid_desc* grid, const float* x01, const void* table16_a,
-                                  const void* table16_b, void* feat16_a, void* feat16_b, int64_t n, int dtype,
-                                  void* stream) {
-    GridParams gp;
-    int rc = fill_params(grid, &gp);
-    if (rc) return rc;
-    if (n == 0) return PERF_OK;
-    PERF_REQUIRE(x01 && table16_a && table16_b && feat16_a && feat16_b, "NULL pointer");
-    dim3 g(grouped_grid(n)), b(256);
-    if (dtype == PERF_DTYPE_BF16)
-        hipLaunchKernelGGL(hashgrid_fwd2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16_a,
-                           (const uint32_t*)table16_b, (uint32_t*)feat16_a, (uint32_t*)feat16_b, n);
-    else if (dtype == PERF_DTYPE_FP16)
-        hipLaunchKernelGGL(hashgrid_fwd2_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16_a,
-                           (const uint32_t*)table16_b, (uint32_t*)feat16_a, (uint32_t*)feat16_b, n);
-    else { set_error("perf_hashgrid_fwd2: bad dtype %d", dtype); return PERF_E_INVALID; }
-    PERF_LAUNCH_CHECK("perf_hashgrid_fwd2");
-    return PERF_OK;
-}
-
-extern "C" int perf_hashgrid_corners(const perf_grid_desc* grid, const float* x01, int32_t* idx, int64_t n, void* stream) {
-    GridParams gp;
-    int rc = fill_params(grid, &gp);
-    if (rc) return rc;
-    if (n == 0) return PERF_OK;
-    PERF_REQUIRE(x01 && idx, "NULL pointer");
-    PERF_REQUIRE(gp.offset[gp.n_levels - 1] + gp.size[gp.n_levels - 1] < ((uint64_t)1 << 31), "perf_hashgrid_corners: table too large for int32 entries");
-    hipLaunchKernelGGL(hashgrid_corners_kernel, dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream), gp,
-                       x01, idx, n);
-    PERF_LAUNCH_CHECK("perf_hashgrid_corners");
-    return PERF_OK;
-}
-
-extern "C" int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const float* table,
-                                     float* feat, int64_t n, void* stream) {
-    GridParams gp;
-    int rc = fill_params(grid, &gp);
-    if (rc) return rc;
-    if (n == 0) return PERF_OK;
-    PERF_REQUIRE(x01 && table && feat, "NULL pointer");
-    hipLaunchKernelGGL(hashgrid_fwd_f32_kernel, dim3(grouped_grid(n)), dim3(256), 0, as_stream(stream), gp, x01,
-                       (const float2*)table, (float2*)feat, n);
-    PERF_LAUNCH_CHECK("perf_hashgrid_fwd_f32");
-    return PERF_OK;
-}
 
 // levels whose owners can run the coded variant (multi-tile levels); returns their number
 static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
@@ -2076,108 +1389,5 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
             shifts_dev ? shifts_dev : shifts_ws, fixed ? 1 : 0, overflow_flag, n_tickets);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(reduce)");
     }
-    return PERF_OK;
-}
-
-extern "C" int perf_dp_stats_pack(const float* level_absmax, const int32_t* field_max_prev, const int64_t* n_dev, int64_t n,
-                                  int32_t* stats_out, void* stream) {
-    PERF_REQUIRE(level_absmax && stats_out, "NULL pointer");
-    dp_stats_pack_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(level_absmax, field_max_prev, n_dev, n, stats_out);
-    PERF_LAUNCH_CHECK("perf_dp_stats_pack");
-    return PERF_OK;
-}
-
-extern "C" int perf_dp_units(const perf_grid_desc* grid, const int32_t* stats_all, int32_t world, int32_t* headroom_state,
-                             int32_t* shifts_out, int64_t* n_total_out, int32_t margin_bits, void* stream) {
-    GridParams gp;
-    int rc = fill_params(grid, &gp);
-    if (rc) return rc;
-    PERF_REQUIRE(stats_all && headroom_state && shifts_out && world >= 1 && margin_bits >= 0 && margin_bits <= 8, "perf_dp_units: bad arguments");
-    dp_units_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(gp, stats_all, world, headroom_state, shifts_out, n_total_out, margin_bits);
-    PERF_LAUNCH_CHECK("perf_dp_units");
-    return PERF_OK;
-}
-
-extern "C" int perf_dp_slot_pack(const float* level_absmax, const int32_t* field_max, const int64_t* n_dev, int64_t n,
-                                 const int32_t* overflow_flag, const int64_t* n_marched_dev, int64_t capacity, int32_t rank,
-                                 int32_t world, float* slots, void* stream) {
-    PERF_REQUIRE(slots && world >= 1 && rank >= 0 && rank < world, "perf_dp_slot_pack: bad arguments");
-    dp_slot_pack_kernel<<<dim3(1), dim3(256), 0, as_stream(stream)>>>(level_absmax, field_max, n_dev, n, overflow_flag, n_marched_dev,
-                                                                       capacity, rank, world, slots);
-    PERF_LAUNCH_CHECK("perf_dp_slot_pack");
-    return PERF_OK;
-}
-
-extern "C" int perf_dp_slot_unpack(const float* slots, int32_t world, int32_t* stats_all, float* job_flags, int64_t* n_total_out,
-                                   void* stream) {
-    PERF_REQUIRE(slots && world >= 1, "perf_dp_slot_unpack: bad arguments");
-    dp_slot_unpack_kernel<<<dim3(1), dim3(256), 0, as_stream(stream)>>>(slots, world, stats_all, job_flags, n_total_out);
-    PERF_LAUNCH_CHECK("perf_dp_slot_unpack");
-    return PERF_OK;
-}
-
-extern "C" int perf_fixed_unfix(const perf_grid_desc* grid, void* fields, int64_t entry_lo, int64_t entry_hi,
-                                const int32_t* shifts_dev, int32_t* field_max, int32_t* overflow_flag, void* stream) {
-    GridParams gp;
-    int rc = fill_params(grid, &gp);
-    if (rc) return rc;
-    PERF_REQUIRE(fields && shifts_dev, "NULL pointer");
-    const int64_t total = (int64_t)(gp.offset[gp.n_levels - 1] + gp.size[gp.n_levels - 1]);
-    PERF_REQUIRE(entry_lo >= 0 && entry_lo <= entry_hi && entry_hi <= total, "perf_fixed_unfix: bad entry range");
-    if (field_max) PERF_REQUIRE(hipMemsetAsync(field_max, 0, PERF_MAX_LEVELS * sizeof(int32_t), as_stream(stream)) == hipSuccess, "memset failed");
-    if (entry_hi == entry_lo) return PERF_OK;
-    // few workgroups: each ends with atomics on the 24 maxima, which share one cache line and retire one at a time (~11 ns):
-    // 4,096 workgroups spent 30 us there (tools/exp/unfix_probe.py: 56 / 40 / 35 / 39 us at 4096 / 1024 / 512 / 256)
-    constexpr int64_t kMaxBlocks = 512;       // (more workgroups only queue at the 24 same-line maxima: tools/exp/unfix_probe.py)
-    int64_t blocks = div_up(entry_hi - entry_lo, 256 * 8);
-    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
-    fixed_unfix_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(gp, (int32_t*)fields, entry_lo, entry_hi, shifts_dev,
-                                                                                       field_max, overflow_flag);
-    PERF_LAUNCH_CHECK("perf_fixed_unfix");
-    return PERF_OK;
-}
-
-extern "C" int perf_hashgrid_bwd_input(const perf_grid_desc* grid, const float* x01, const float* dfeat,
-                                       const float* table, float* dx, int64_t n, void* stream) {
-    GridParams gp;
-    int rc = fill_params(grid, &gp);
-    if (rc) return rc;
-    if (n == 0) return PERF_OK;
-    PERF_REQUIRE(x01 && dfeat && table && dx, "NULL pointer");
-    hipLaunchKernelGGL(hashgrid_bwd_input_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, as_stream(stream), gp,
-                       x01, (const float2*)dfeat, (const float2*)table, dx, n);
-    PERF_LAUNCH_CHECK("perf_hashgrid_bwd_input");
-    return PERF_OK;
-}
-
-extern "C" int perf_hashgrid_bwd_bwd_input(const perf_grid_desc* grid, const float* x01, const float* dfeat, const float* table,
-                                           const float* ggx, float* d_dfeat, float* d_x, int64_t n, void* stream) {
-    GridParams gp;
-    int rc = fill_params(grid, &gp);
-    if (rc) return rc;
-    if (n == 0) return PERF_OK;
-    PERF_REQUIRE(x01 && table && ggx, "NULL pointer");
-    PERF_REQUIRE(d_dfeat || d_x, "perf_hashgrid_bwd_bwd_input: nothing to compute");
-    PERF_REQUIRE(!d_x || dfeat, "perf_hashgrid_bwd_bwd_input: d_x needs dfeat");
-    hipLaunchKernelGGL(hashgrid_bwd_bwd_input_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, as_stream(stream), gp, x01,
-                       (const float2*)dfeat, (const float2*)table, ggx, (float2*)d_dfeat, d_x, n);
-    PERF_LAUNCH_CHECK("perf_hashgrid_bwd_bwd_input");
-    return PERF_OK;
-}
-
-extern "C" int perf_hashgrid_bwd_bwd_param(const perf_grid_desc* grid, const float* x01, const float* dfeat, const float* ggx,
-                                           float* grad_table, int64_t n, void* stream) {
-    GridParams gp;
-    int rc = fill_params(grid, &gp);
-    if (rc) return rc;
-    PERF_REQUIRE(grad_table, "NULL pointer");
-    const uint64_t total = gp.offset[gp.n_levels - 1] + gp.size[gp.n_levels - 1];
-    PERF_REQUIRE(hipMemsetAsync(grad_table, 0, (size_t)total * 2 * sizeof(float), as_stream(stream)) == hipSuccess,
-                 "perf_hashgrid_bwd_bwd_param: memset failed");
-    if (n == 0) return PERF_OK;
-    PERF_REQUIRE(x01 && dfeat && ggx, "NULL pointer");
-    hipLaunchKernelGGL(hashgrid_bwd_bwd_param_kernel, dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream),
-                       gp, x01, (const float2*)dfeat, ggx, grad_table, n);
-    PERF_LAUNCH_CHECK("perf_hashgrid_bwd_bwd_param");
     return PERF_OK;
 }

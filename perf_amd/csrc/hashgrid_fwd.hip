@@ -1,0 +1,343 @@
+// Multiresolution hash-grid encoding for gfx950 (tcnn "HashGrid" semantics).
+//
+// Design (MI355X-first): the encode is a random 4-byte-gather kernel whose working set
+// (13 MB of 16-bit tables per encoder) exceeds one XCD's 4 MiB L2.  Work is therefore cut
+// by LEVEL GROUP, not by sample alone: block b serves level group (b % 8) -- with the
+// dispatcher's round-robin block->XCD placement each XCD's private L2 then only ever sees
+// the two levels {g, L-1-g} of its group (<= 2 MiB), so gathers are L2 hits instead of
+// Infinity-Cache round trips.  Placement is a speed assumption only: results do not depend
+// on it.  Features leave the kernel LEVEL-MAJOR (feat[l][sample] as one packed 2x16-bit
+// dword), so every store and the MLP kernel's loads are fully coalesced.
+//
+// This unit: the forward encode (perf_hashgrid_fwd / _fwd2 / _corners / _fwd_f32).  The parameter gradient is hashgrid_bwd.hip;
+// input gradient, second order and the data-parallel unit / slot kernels are hashgrid_aux.hip.
+#include <stdlib.h>
+#include "common.hpp"
+#include "grid_device.hpp"
+
+namespace perf {
+
+
+// level l handled by (group, pass).  L <= 16: pass 0 -> g, pass 1 -> L-1-g (if different) -- a coarse (small) and a
+// fine (large) table per group.  Deeper grids (L <= 24) add pass 2 -> 16+g; their tables exceed the L2 anyway.
+constexpr int kFwdPasses = 3;
+// at most this many 256-sample chunks per level group in one launch (the workgroups loop beyond): launches of up to 1 M
+// samples keep one workgroup per chunk (measured equal either way), while a capacity-sized launch of an eval frame -- 33 M
+// rows for a tail pass that holds a few thousand live samples -- no longer dispatches 10^6 workgroups that only read the
+// device-side count and leave (0.25 ms per frame)
+constexpr int64_t kFwdMaxChunks = 4096;
+__device__ __forceinline__ int level_of(int group, int pass, int L) {
+    if (pass == 2) return (16 + group < L) ? 16 + group : -1;
+    const int Lc = L < 16 ? L : 16;
+    int a = group, b = Lc - 1 - group;
+    if (a > b) return -1;
+    if (pass == 0) return a;
+    return (b != a) ? b : -1;
+}
+
+template <typename T16>
+__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridParams gp, const float* __restrict__ x01,
+                                                           const uint32_t* __restrict__ table,
+                                                           uint32_t* __restrict__ feat, int64_t n,
+                                                           const int64_t* __restrict__ n_dev, int xcd_affinity) {
+    // xcd_affinity == 0 (experiment only): consecutive blocks of one XCD walk through all level groups, so every L2
+    // sees the whole table -- used to measure what the level-group <-> XCD pinning is worth.
+    const int nchunks = (int)(gridDim.x >> 3);
+    const int group = xcd_affinity ? (int)(blockIdx.x & 7) : (int)((blockIdx.x >> 3) & 7);
+    const int64_t chunk0 = xcd_affinity ? (int64_t)(blockIdx.x >> 3)
+                                        : (int64_t)(blockIdx.x & 7) * ((nchunks + 7) >> 3) + (int64_t)(blockIdx.x >> 6);
+    if (!xcd_affinity && chunk0 >= nchunks) return;
+    const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
+    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+    // chunk-stride loop: a capacity-sized launch (n >> n_live) is capped at `nchunks` chunks per level group, so that
+    // it does not pay for tens of thousands of workgroups that only find out that they have nothing to do
+    for (int64_t chunk = chunk0; chunk * 256 < n_live; chunk += nchunks) {
+    const int64_t i = chunk * 256 + threadIdx.x;
+    if (i >= n_live) break;
+    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+#pragma unroll
+    for (int pass = 0; pass < kFwdPasses; ++pass) {
+        const int l = level_of(group, pass, gp.n_levels);
+        if (l < 0) continue;
+        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+        const uint32_t* t = table + gp.offset[l];
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = t[c.idx[k]];
+        float w[8];
+        corner_weights(c.f, smooth, w);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a0 = fmaf(w[k], T16::lo(v[k]), a0);
+            a1 = fmaf(w[k], T16::hi(v[k]), a1);
+        }
+        feat[(int64_t)l * n + i] = T16::pack(a0, a1);
+    }
+    }
+}
+
+
+// ---- forward encode, second generation: run de-duplication + rotating level groups -----------------------------------------
+// The gathers of this kernel are bound by the L1's request rate (one cache-line look-up per active lane and cycle; the
+// tables sit in L2 / Infinity Cache), not by bandwidth.  Two things reduce what the slowest XCD has to issue:
+//  (1) run de-duplication: consecutive samples of a ray (training batches) and equal-rank samples of neighbouring pixels
+//      (eval frames) fall into the SAME cell at the coarse levels, i.e. neighbouring lanes gather the same eight entries.
+//      One DPP compare per level finds the runs; only run heads issue the gathers, the others fetch the head's packed
+//      dwords with ds_bpermute (LDS crossbar, ~2 cycles per 64 lanes instead of 64 L1 look-ups).  Interpolation stays
+//      per lane: features are bit-identical.  A wave whose lanes share little (> kShareMaxHeads heads) gathers as before.
+//  (2) de-duplication makes the level groups unequal (a coarse level costs a fraction of a fine one), and a fixed
+//      group <-> XCD pinning would leave the kernel as long as its most expensive group.  The pinning therefore ROTATES:
+//      the chunks of a launch are cut into eight phases, and in phase p XCD x serves group (x + p) % 8.  Every XCD serves
+//      every group for an eighth of the samples -- equal work whatever the levels cost -- while its L2 still holds two
+//      tables at a time (refilled from the Infinity Cache at each of the seven phase changes).  (A first attempt handed
+//      out (group, chunk) tickets through one device counter per group: same-address atomics retire at ~105 ns each on
+//      gfx950, 4096 tickets per counter made the kernel three times SLOWER -- tools/exp/fwd_v2.py, profiles/README.md.)
+constexpr int kShareMaxHeads = 56;
+
+template <typename T16>
+__global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, const float* __restrict__ x01,
+                                                              const uint32_t* __restrict__ table,
+                                                              uint32_t* __restrict__ feat, int64_t n,
+                                                              const int64_t* __restrict__ n_dev) {
+    const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
+    const int64_t nchunks_live = (n_live + 255) >> 8;
+    const int64_t nchunks_grid = (int64_t)(gridDim.x >> 3);
+    const int xcd = (int)(blockIdx.x & 7);
+    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= mine
+    // chunk-stride loop: a capacity-sized launch (n >> n_live) is capped at nchunks_grid chunks per XCD
+    for (int64_t chunk = (int64_t)(blockIdx.x >> 3); chunk < nchunks_live; chunk += nchunks_grid) {
+        // phase of a chunk: its position within the pass of the grid over the chunks (any function of the chunk alone keeps
+        // the eight workgroups of a chunk on eight different groups)
+        const int64_t in_pass = chunk % nchunks_grid, pass_len = nchunks_live < nchunks_grid ? nchunks_live : nchunks_grid;
+        const int phase = (int)((in_pass * 8) / pass_len) & 7;
+        const int g = (xcd + phase) & 7;
+        const int64_t i = chunk * 256 + threadIdx.x;
+        const bool live = i < n_live;
+        const int64_t ii = live ? i : n_live - 1;                // (idle lanes of the last chunk repeat its last sample)
+        const float x = x01[3 * ii], y = x01[3 * ii + 1], z = x01[3 * ii + 2];
+        // Both levels of the group are set up first, then all their gathers are issued, then shared and interpolated: the
+        // (L1-hit) coarse and the (L2-served) fine level stay in flight together.
+        int lv[2];
+        Corners c[2];
+        bool head[2], share[2];
+        uint32_t src[2];
+        uint32_t v[2][8];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            lv[pass] = level_of(g, pass, gp.n_levels);
+            head[pass] = lv[pass] >= 0; share[pass] = false; src[pass] = lane;
+            if (lv[pass] < 0) continue;
+            const int l = lv[pass];
+            c[pass] = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+            {
+                // lane - 1's cell through DPP (wave_shr:1; lane 0 keeps the `old` operand)
+                const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[0], 0x138, 0xf, 0xf, false);
+                const uint32_t py = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[1], 0x138, 0xf, 0xf, false);
+                const uint32_t pz = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)c[pass].cell[2], 0x138, 0xf, 0xf, false);
+                const bool same = lane != 0u && px == c[pass].cell[0] && py == c[pass].cell[1] && pz == c[pass].cell[2];
+                const unsigned long long heads = __ballot(!same);
+                share[pass] = __popcll(heads) <= kShareMaxHeads;      // wave-uniform
+                if (share[pass]) {
+                    head[pass] = !same;
+                    src[pass] = 63u - (uint32_t)__clzll((long long)(heads & below));     // the head of my run
+                }
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[pass][k] = 0u;
+            if (head[pass]) {
+                const uint32_t* t = table + gp.offset[lv[pass]];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[pass][k] = t[c[pass].idx[k]];
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (lv[pass] < 0) continue;
+            if (share[pass]) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[pass][k] = (uint32_t)__shfl((int)v[pass][k], (int)src[pass]);
+            }
+            float w[8];
+            corner_weights(c[pass].f, smooth, w);
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a0 = fmaf(w[k], T16::lo(v[pass][k]), a0);
+                a1 = fmaf(w[k], T16::hi(v[pass][k]), a1);
+            }
+            if (live) feat[(int64_t)lv[pass] * n + i] = T16::pack(a0, a1);
+        }
+    }
+}
+
+// Two tables with the SAME grid geometry (PeRF's density and colour fields, ngp_nerf.py:96-134) evaluated at the
+// same points: corner indices and weights are computed once, 16 gathers are in flight per (sample, level).
+template <typename T16>
+__global__ __launch_bounds__(256) void hashgrid_fwd2_kernel(GridParams gp, const float* __restrict__ x01,
+                                                            const uint32_t* __restrict__ table_a,
+                                                            const uint32_t* __restrict__ table_b,
+                                                            uint32_t* __restrict__ feat_a, uint32_t* __restrict__ feat_b,
+                                                            int64_t n) {
+    const int group = blockIdx.x & 7;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+#pragma unroll
+    for (int pass = 0; pass < kFwdPasses; ++pass) {
+        const int l = level_of(group, pass, gp.n_levels);
+        if (l < 0) continue;
+        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+        const uint32_t* ta = table_a + gp.offset[l];
+        const uint32_t* tb = table_b + gp.offset[l];
+        uint32_t va[8], vb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { va[k] = ta[c.idx[k]]; vb[k] = tb[c.idx[k]]; }
+        float w[8];
+        corner_weights(c.f, smooth, w);
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a0 = fmaf(w[k], T16::lo(va[k]), a0); a1 = fmaf(w[k], T16::hi(va[k]), a1);
+            b0 = fmaf(w[k], T16::lo(vb[k]), b0); b1 = fmaf(w[k], T16::hi(vb[k]), b1);
+        }
+        feat_a[(int64_t)l * n + i] = T16::pack(a0, a1);
+        feat_b[(int64_t)l * n + i] = T16::pack(b0, b1);
+    }
+}
+
+// corner table indices (absolute entry index, level offset included) of every (level, sample): the integer half of
+// the encoding, exported so that arbitrarily-often differentiable compositions can be built on top of it
+__global__ __launch_bounds__(256) void hashgrid_corners_kernel(GridParams gp, const float* __restrict__ x01,
+                                                               int32_t* __restrict__ idx_out, int64_t n) {
+    const int l = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || l >= gp.n_levels) return;
+    const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+    int32_t* o = idx_out + ((int64_t)l * n + i) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (int32_t)(gp.offset[l] + c.idx[k]);
+}
+
+__global__ __launch_bounds__(256) void hashgrid_fwd_f32_kernel(GridParams gp, const float* __restrict__ x01,
+                                                               const float2* __restrict__ table,
+                                                               float2* __restrict__ feat, int64_t n) {
+    const int group = blockIdx.x & 7;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+#pragma unroll
+    for (int pass = 0; pass < kFwdPasses; ++pass) {
+        const int l = level_of(group, pass, gp.n_levels);
+        if (l < 0) continue;
+        const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+        const float2* t = table + gp.offset[l];
+        float w[8];
+        corner_weights(c.f, smooth, w);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float2 v = t[c.idx[k]];
+            a0 = fmaf(w[k], v.x, a0);
+            a1 = fmaf(w[k], v.y, a1);
+        }
+        feat[(int64_t)l * n + i] = make_float2(a0, a1);
+    }
+}
+
+static inline unsigned grouped_grid(int64_t n) { return (unsigned)(div_up(n, 256) * 8); }
+
+}  // namespace perf
+
+using namespace perf;
+
+extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* table16,
+                                 void* feat16, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
+    GridParams gp;
+    int rc = fill_params(grid, &gp);
+    if (rc) return rc;
+    PERF_REQUIRE(n >= 0 && n < (int64_t(1) << 31) * 16, "n out of range");
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(x01 && table16 && feat16, "NULL pointer");
+    // level group <-> XCD pinning only pays when every one of the 8 groups has a level (L >= 15); a grid of a few levels
+    // (a rank's slice of a level-sharded table, the 5-level proposal field) would otherwise keep 1-3 XCDs busy
+    const int xcd_affinity = gp.n_levels >= 15 ? 1 : 0;
+    // chunks (of 256 samples) per level group in one launch; beyond that the workgroups loop
+    int64_t chunks = div_up(n, 256);
+    if (xcd_affinity && chunks > kFwdMaxChunks) chunks = kFwdMaxChunks;
+    // ---- rotating level groups + run de-duplication (15/16-level grids).  (The measured-slower settings of this path -- no
+    //      rotation, no de-duplication, the round-2 kernel for these grids, looping workgroups -- are tools/exp/r05_retired_variants.diff.)
+    if (xcd_affinity && gp.n_levels <= 16) {
+        // (one workgroup per chunk up to 4096 chunks per XCD: the rotation relies on chunks being served in dispatch order --
+        //  512 looping workgroups per XCD measured 0.307 instead of 0.177 ms per 1 M samples: phases mix, every L2 sees every table)
+        dim3 g((unsigned)(chunks * 8)), b(256);
+        if (dtype == PERF_DTYPE_BF16)
+            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev);
+        else if (dtype == PERF_DTYPE_FP16)
+            hipLaunchKernelGGL(hashgrid_fwd_v2_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev);
+        else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
+        PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
+        return PERF_OK;
+    }
+    dim3 g(xcd_affinity ? (unsigned)(chunks * 8) : (unsigned)(div_up(div_up(n, 256), 8) * 64)), b(256);
+    if (dtype == PERF_DTYPE_BF16)
+        hipLaunchKernelGGL(hashgrid_fwd_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, xcd_affinity);
+    else if (dtype == PERF_DTYPE_FP16)
+        hipLaunchKernelGGL(hashgrid_fwd_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, xcd_affinity);
+    else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
+    PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
+    return PERF_OK;
+}
+
+extern "C" int perf_hashgrid_fwd2(const perf_grid_desc* grid, const float* x01, const void* table16_a,
+                                  const void* table16_b, void* feat16_a, void* feat16_b, int64_t n, int dtype,
+                                  void* stream) {
+    GridParams gp;
+    int rc = fill_params(grid, &gp);
+    if (rc) return rc;
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(x01 && table16_a && table16_b && feat16_a && feat16_b, "NULL pointer");
+    dim3 g(grouped_grid(n)), b(256);
+    if (dtype == PERF_DTYPE_BF16)
+        hipLaunchKernelGGL(hashgrid_fwd2_kernel<BF16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16_a,
+                           (const uint32_t*)table16_b, (uint32_t*)feat16_a, (uint32_t*)feat16_b, n);
+    else if (dtype == PERF_DTYPE_FP16)
+        hipLaunchKernelGGL(hashgrid_fwd2_kernel<FP16>, g, b, 0, as_stream(stream), gp, x01, (const uint32_t*)table16_a,
+                           (const uint32_t*)table16_b, (uint32_t*)feat16_a, (uint32_t*)feat16_b, n);
+    else { set_error("perf_hashgrid_fwd2: bad dtype %d", dtype); return PERF_E_INVALID; }
+    PERF_LAUNCH_CHECK("perf_hashgrid_fwd2");
+    return PERF_OK;
+}
+
+extern "C" int perf_hashgrid_corners(const perf_grid_desc* grid, const float* x01, int32_t* idx, int64_t n, void* stream) {
+    GridParams gp;
+    int rc = fill_params(grid, &gp);
+    if (rc) return rc;
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(x01 && idx, "NULL pointer");
+    PERF_REQUIRE(gp.offset[gp.n_levels - 1] + gp.size[gp.n_levels - 1] < ((uint64_t)1 << 31), "perf_hashgrid_corners: table too large for int32 entries");
+    hipLaunchKernelGGL(hashgrid_corners_kernel, dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream), gp,
+                       x01, idx, n);
+    PERF_LAUNCH_CHECK("perf_hashgrid_corners");
+    return PERF_OK;
+}
+
+extern "C" int perf_hashgrid_fwd_f32(const perf_grid_desc* grid, const float* x01, const float* table,
+                                     float* feat, int64_t n, void* stream) {
+    GridParams gp;
+    int rc = fill_params(grid, &gp);
+    if (rc) return rc;
+    if (n == 0) return PERF_OK;
+    PERF_REQUIRE(x01 && table && feat, "NULL pointer");
+    hipLaunchKernelGGL(hashgrid_fwd_f32_kernel, dim3(grouped_grid(n)), dim3(256), 0, as_stream(stream), gp, x01,
+                       (const float2*)table, (float2*)feat, n);
+    PERF_LAUNCH_CHECK("perf_hashgrid_fwd_f32");
+    return PERF_OK;
+}
