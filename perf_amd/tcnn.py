@@ -23,7 +23,7 @@ from .grid import GridConfig, MlpConfig
 DEFAULT_DTYPE = 'bf16'     # BASELINE.json config 2 names bf16; 'fp16' reproduces tcnn's own precision
 DEFAULT_SEED = 1337        # tcnn's torch binding seeds its init with 1337
 # accumulation of the grid gradient: 'fp32' (LDS float atomics) or 'fixed' (packed 2x int32 fixed point, integer LDS
-# atomics, per-level power-of-two unit from max|dfeat| under a closed-loop headroom; see hashgrid.hip).  This is the DEFAULT
+# atomics, per-level power-of-two unit from max|dfeat| under a closed-loop headroom; see hashgrid_bwd.hip).  This is the DEFAULT
 # new modules start with (NetworkWithInputEncoding.grid_grad_accum); nothing in the process mutates it behind a module's back.
 import os as _os
 GRID_GRAD_ACCUM = _os.environ.get('PERF_GRID_GRAD_ACCUM', 'fixed')
