@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 6
+#define PERF_ABI_VERSION 7
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -351,6 +351,16 @@ int64_t perf_occ_mask_words(int32_t max_steps);
  * lattice (without it such launches use a table of runs built on the host; per-ray origins walk on the device). */
 int64_t perf_occ_lattice_table_len(int32_t max_steps);
 int perf_occ_lattice_table(float t0, float step, int32_t max_steps, int32_t lattice_mode, float* table, void* stream);
+
+/* Per-ray origins (t0 != NULL: the stratified batches of training) on the repeated-addition lattice: the walk of every ray as a
+ * table of runs -- inside a binade consecutive lattice points are equidistant bit patterns --, built by ONE launch that gives
+ * every ray a lane (the marching kernels would otherwise spend a whole wavefront per ray on it: 13 of march_count's 27 us on a
+ * batch of 8,192 rays).  runs: perf_occ_lattice_runs_len(n_rays) 32-bit words, caller-owned; t0 / t0_scale / t0_base as the marching
+ * entry points take them.  Those take the buffer as `lattice_table` TOGETHER with t0 != NULL (lattice_mode must be
+ * PERF_LATTICE_REPEATED); results are identical with and without it. */
+int64_t perf_occ_lattice_runs_len(int64_t n_rays);
+int perf_occ_lattice_runs(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps,
+                          int32_t* runs, void* stream);
 
 /* Pass 1: per ray, test lattice intervals k=0..max_steps-1 (t_k on the lattice `lattice_mode`, midpoint
  * inside [max(tmin,t0), min(tmax,far)] and in an occupied cell); writes the keep bit masks

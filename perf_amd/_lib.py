@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libperf_hip.so')
 
-ABI_VERSION = 6          # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
+ABI_VERSION = 7          # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
 MAX_LEVELS = 24
 DTYPE_BF16, DTYPE_FP16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
@@ -79,6 +79,8 @@ _SIGS = {
     'perf_occ_mask_words': (c_int64, [c_int32]),
     'perf_occ_lattice_table_len': (c_int64, [c_int32]),
     'perf_occ_lattice_table': (c_int, [c_float, c_float, c_int32, c_int32, P, P]),
+    'perf_occ_lattice_runs_len': (c_int64, [c_int64]),
+    'perf_occ_lattice_runs': (c_int, [P, c_float, c_float, c_int64, c_float, c_int32, P, P]),
     'perf_occ_march_count': (c_int, [P, P, P, c_float, c_float, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, c_int32, P, P, P, P]),
     'perf_occ_march_count_head': (c_int, [P, P, P, c_float, c_float, c_int64, P, P, c_int32, POINTER(c_float), c_float, c_float, c_int32, c_int32, P, P, P,
                                   c_int32, P, P, P, P, POINTER(c_float), P, P, P]),

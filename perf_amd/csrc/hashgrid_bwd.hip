@@ -326,11 +326,10 @@ __device__ __forceinline__ uint32_t tile_code_of(const GridParams& gp, const Til
     return code;
 }
 
-__global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
-                                                         const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
-                                                         uint32_t* __restrict__ escape, int64_t n,
-                                                         const int64_t* __restrict__ n_dev) {
-    const int64_t n_live = live_count(n, n_dev);            // n: capacity = stride of dfeat / codes; n_live: samples present
+// one workgroup = the 256 samples of one escape word, a sample per thread
+__device__ __forceinline__ void tile_codes_block(const GridParams& gp, const TileParams& tp, const float* __restrict__ x01,
+                                                 const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
+                                                 uint32_t* __restrict__ escape, int64_t n, int64_t n_live) {
     __shared__ uint32_t esc_block;
     if (threadIdx.x == 0) esc_block = 0u;
     __syncthreads();
@@ -356,14 +355,31 @@ __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TilePara
     if (threadIdx.x == 0) escape[blockIdx.x] = esc_block;       // every word is written: no zero-fill needed
 }
 
+__global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
+                                                         const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
+                                                         uint32_t* __restrict__ escape, int64_t n,
+                                                         const int64_t* __restrict__ n_dev) {
+    tile_codes_block(gp, tp, x01, dfeat, codes, escape, n, live_count(n, n_dev));       // n: capacity = stride of dfeat / codes
+}
+
 // The same codes, four consecutive samples per thread: 48 bytes of positions in three 16-byte loads and one 16-byte store per
 // level instead of four 4-byte ones (the byte-code kernel spent most of a wave's life queueing stores: 16 per sample).  A wave
 // covers the 256 samples of one escape word.  (The kernel above serves workspaces whose code rows are not 16-byte aligned.)
+// The launch has one workgroup per escape word; with many live samples only the first quarter of them works (four words each).
+// With FEW live samples (the reference-faithful training step: 16-35 k live rows of a 1 M-row capacity) four samples per thread
+// leave a handful of waves walking 4 x 16 levels each -- 13.5 us against 7 for the one-sample-per-thread shape, which those
+// launches therefore take (the count is on the device: the shape is chosen here, not by the host).
+constexpr int64_t kCodes4MinLive = 65536;
 __global__ __launch_bounds__(256) void tile_codes4_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
                                                           const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
                                                           uint32_t* __restrict__ escape, int64_t n, int64_t n_words,
                                                           const int64_t* __restrict__ n_dev) {
     const int64_t n_live = live_count(n, n_dev);
+    if (n_live < kCodes4MinLive) {                         // (uniform)
+        tile_codes_block(gp, tp, x01, dfeat, codes, escape, n, n_live);
+        return;
+    }
+    if ((int64_t)blockIdx.x * 4 >= n_words) return;
     __shared__ uint32_t esc_w[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) esc_w[wave] = 0u;
@@ -1223,6 +1239,11 @@ extern "C" int64_t perf_hashgrid_bwd_workspace_bytes(const perf_grid_desc* grid,
     int64_t ws2;
     plan_tiles(gp, false, &tp, &nb, &ws);
     plan_tiles(gp, true, &tp, &nb, &ws2, (n > 0 && n < kMaxCodedSamples) ? kBitmapMaxTiles : 0);
+    if (n == 0) {       // (the minimal workspace -- no codes, no bitmaps -- must still hold the replica slabs of whatever plan a call picks)
+        TileParams t3; int nb3; int64_t ws3;
+        plan_tiles(gp, true, &t3, &nb3, &ws3, kBitmapMaxTiles);
+        if (ws3 > ws2) ws2 = ws3;
+    }
     const int slots = plan_codes(gp, n, &tp);
     int bm_levels = 0;
     int64_t bm_bytes = plan_bitmaps(gp, n, &tp, &bm_levels);
@@ -1331,7 +1352,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         codes = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + codes_at);
         escape = codes + (int64_t)slots * tp.n_pad;
         if ((reinterpret_cast<uintptr_t>(codes) & 15) == 0)
-            tile_codes4_kernel<<<dim3((unsigned)div_up(esc_words, 4)), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
+            tile_codes4_kernel<<<dim3((unsigned)esc_words), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
                                                                                                             codes, escape, n, esc_words, n_dev);
         else
             tile_codes_kernel<<<dim3((unsigned)esc_words), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,

@@ -107,6 +107,9 @@ constexpr int kMaxRuns = 64;
 //  readfirstlane, everything else stays on the scalar unit; lane 0 stores.  Letting lanes 0..3 of one wave walk the block's
 //  four rays and synchronising the block measured SLOWER: 26.9 vs 20.6 us per 8,192 rays -- the other waves wait out the
 //  walk's latency)
+// UNIFORM: one ray per WAVE (values uniform over the wave, kept on the scalar unit through readfirstlane; lane 0 stores);
+// otherwise one ray per LANE (lattice_runs_kernel) -- the same arithmetic either way, so the tables are identical.
+template <bool UNIFORM>
 __device__ __forceinline__ int lattice_runs_build(float t0, float step, int k_need, int32_t* __restrict__ ks, uint32_t* __restrict__ bs,
                                                   uint32_t* __restrict__ dd, bool writer) {
     int n = 0;
@@ -114,25 +117,32 @@ __device__ __forceinline__ int lattice_runs_build(float t0, float step, int k_ne
         if (writer) { ks[n] = k; bs[n] = b; dd[n] = d; }
         ++n;
     };
-    uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t0));
+    auto uni = [](uint32_t v) { return UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v; };
+    uint32_t tb = uni(__float_as_uint(t0));
     emit(0, tb, 0u);
     int K = 0;
     while (K < k_need) {
         if (n + 2 > kMaxRuns) return -1;
-        const uint32_t b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(add_rn(__uint_as_float(tb), step)));
+        const uint32_t b1 = uni(__float_as_uint(add_rn(__uint_as_float(tb), step)));
         if ((b1 >> 23) != (tb >> 23)) { emit(K + 1, b1, 0u); tb = b1; K += 1; continue; }    // entered a binade: one more real step first
-        const uint32_t b2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(add_rn(__uint_as_float(b1), step)));
+        const uint32_t b2 = uni(__float_as_uint(add_rn(__uint_as_float(b1), step)));
         if ((b2 >> 23) != (b1 >> 23)) { emit(K + 1, b1, 0u); emit(K + 2, b2, 0u); tb = b2; K += 2; continue; }
         const uint32_t d = b2 - b1;
         emit(K + 1, b1, d);                                      // t_{K+1}, t_{K+2}, ... equidistant to the end of the binade
         if (d == 0u) return n;                                   // (step below half an ulp: the lattice is stuck at t_{K+1} for good)
         const uint32_t top = (b2 & 0xff800000u) + 0x00800000u;
-        const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)div_u24(top - 1u - b2, d));
+        const uint32_t j = uni(div_u24(top - 1u - b2, d));
         tb = b2 + j * d;
         K += 2 + (int)j;
     }
     return n;
 }
+
+// Per-ray tables in device memory (perf_occ_lattice_runs): row r = [n | ks[kMaxRuns] | bs[kMaxRuns] | dd[kMaxRuns]] of
+// kRunsStride 32-bit words (n = -1: the table did not fit, walk per lane).  The uniform build above costs a whole WAVE per ray --
+// ~840 dependent vector instructions on uniform values, x 8,192 rays x 4 cycles each: 13 of the 27 us march_count took on a
+// jittered training batch -- the kernel below gives every ray a LANE instead (128 waves for 8,192 rays).
+constexpr int kRunsStride = 3 * kMaxRuns + 4;
 
 // The table of a launch whose rays all start their lattice at the same t0 (eval renders: no stratified jitter): built ONCE
 // on the host with the same IEEE single-precision additions and handed to the kernels as an argument.
@@ -203,6 +213,19 @@ struct LatticeRuns {
     }
 };
 
+// t_k from a ray's row of the per-ray tables (device memory, L2 resident): binary search over the run starts
+__device__ __forceinline__ float runs_row_at(const int32_t* __restrict__ row, int k, float t0, float step) {
+    const int n = row[0];
+    if (n <= 0) return lattice_repeated(t0, k, step);
+    const int32_t* ks = row + 1;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ks[mid] <= k) lo = mid; else hi = mid - 1;
+    }
+    return __uint_as_float((uint32_t)row[1 + kMaxRuns + lo] + (uint32_t)(k - ks[lo]) * (uint32_t)row[1 + 2 * kMaxRuns + lo]);
+}
+
 // Lattice origin of ray r.  t0s == NULL: t0_base (the near plane).  t0_scale == 0: t0s[r] as given.  Otherwise t0s holds the
 // stratified draw u in [0,1) and the origin is fl(u * t0_scale) (+ t0_base when that is not 0) -- the two torch ops of
 // OccGridEstimator.sampling (near_plane + u * render_step_size), formed here so that no separate launch is needed.
@@ -245,6 +268,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
     // same t0 (built on the host), else every wave walks its own ray
     __shared__ int32_t s_ks[4][kMaxRuns];
     __shared__ uint32_t s_bs[4][kMaxRuns], s_dd[4][kMaxRuns];
+    __shared__ int32_t s_head[HEAD ? 4 : 1][64];       // HEAD: lattice indices of the ray's first K samples (written after the chunk loop)
     if (mp.lattice_mode == PERF_LATTICE_REPEATED && sr.n > 0) {
         if ((int)threadIdx.x < sr.n) { s_ks[0][threadIdx.x] = sr.ks[threadIdx.x]; s_bs[0][threadIdx.x] = sr.bs[threadIdx.x]; s_dd[0][threadIdx.x] = sr.dd[threadIdx.x]; }
         __syncthreads();
@@ -269,11 +293,19 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
     LatticeRuns lat;
     lat.n = 0;
     lat.ks = s_ks[tab]; lat.bs = s_bs[tab]; lat.dd = s_dd[tab]; lat.t0 = t0; lat.step = mp.step; lat.mode = mp.lattice_mode;
-    lat.full = lat_full;
-    if (mp.lattice_mode == PERF_LATTICE_REPEATED && !lat_full) {
+    // per-ray origins with a table argument: the rows of perf_occ_lattice_runs (not a shared t_k array)
+    const int32_t* ray_row = (t0s && lat_full) ? reinterpret_cast<const int32_t*>(lat_full) + r * (int64_t)kRunsStride : nullptr;
+    lat.full = ray_row ? nullptr : lat_full;
+    if (ray_row) {
+        if (mp.lattice_mode == PERF_LATTICE_REPEATED) {
+            s_ks[wv][lane] = ray_row[1 + lane]; s_bs[wv][lane] = (uint32_t)ray_row[1 + kMaxRuns + lane]; s_dd[wv][lane] = (uint32_t)ray_row[1 + 2 * kMaxRuns + lane];
+            lat.n = ray_row[0];
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else if (mp.lattice_mode == PERF_LATTICE_REPEATED && !lat_full) {
         if (sr.n > 0) lat.n = sr.n;
         else {
-            lat.n = lattice_runs_build(t0, mp.step, mp.mask_words * 64 + 64, s_ks[wv], s_bs[wv], s_dd[wv], lane == 0);
+            lat.n = lattice_runs_build<true>(t0, mp.step, mp.mask_words * 64 + 64, s_ks[wv], s_bs[wv], s_dd[wv], lane == 0);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -293,9 +325,11 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
         //      one ballot replaces up to 64 sequential chunk visits (what nerfacc's DDA skips cell by cell)
         const int q = g * 64 + lane;
         bool maybe = false;
+        int run_at_chunk = 0;           // table of runs: the run that holds this lane's chunk start (phase B starts its look-ups there)
         if (q < mp.mask_words) {
             const int k0 = q * 64;
             int run = (lat.n > 0 && !lat.full) ? lat.find(k0) : 0;
+            run_at_chunk = run;
             const float t_first = (lat.n > 0 && !lat.full) ? lat.at(run, k0) : lat(k0);
             const float t_mid = lat.after(run, k0 + 32), t_last = lat.after(run, k0 + 64);
             maybe = !(t_first > hi) && !(t_last < lo);
@@ -327,8 +361,15 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                     qs[u] = g * 64 + (__ffsll((unsigned long long)todo) - 1);
                     todo &= todo - 1;
                     const int k = qs[u] * 64 + lane;
+                    // (the chunk is wave uniform: ONE lane's run index for all -- v_readlane, whatever the exec mask)
+                    int r_lo = __builtin_amdgcn_readlane(run_at_chunk, qs[u] & 63);
                     if (k < mp.max_steps) {
-                        const float ta = lat(k), tb = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(ta, mp.step) : lattice_single(t0, k + 1, mp.step);
+                        float ta;
+                        // table of runs: look-ups start at the run of the chunk's first index instead of a binary search per lane (the
+                        // ray's FIRST chunk crosses a dozen runs -- one or two per binade from 2^-11 up -- and keeps the search)
+                        if (lat.n > 0 && !lat.full && qs[u] != 0) ta = lat.after(r_lo, k);
+                        else ta = lat(k);
+                        const float tb = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(ta, mp.step) : lattice_single(t0, k + 1, mp.step);
                         const float mid = mul_rn(add_rn(ta, tb), 0.5f);
                         if (mid >= lo && mid <= hi) {
                             int cell[3];
@@ -357,13 +398,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                     if (lane == 0) rec[nlw + qs[u]] = m;
                     if (HEAD && count < ho.K && mine) {         // (chunks arrive in t order: `count` = samples before this chunk)
                         const int rank = count + __popcll(m & ((1ull << lane) - 1ull));
-                        if (rank < ho.K) {
-                            const int64_t pos = r * ho.K + rank;
-                            const int k = qs[u] * 64 + lane;
-                            const float a = lat(k), b = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, mp.step) : lattice_single(t0, k + 1, mp.step);
-                            ho.ts[pos] = a; ho.te[pos] = b; ho.ri[pos] = r;
-                            sample_point_store(ro + 3 * r, rd + 3 * r, a, b, ho.bb, ho.x01, ho.sel, pos);
-                        }
+                        if (rank < ho.K) s_head[wv][rank] = qs[u] * 64 + lane;
                     }
                     count += __popcll(m);
                 }
@@ -375,6 +410,14 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
     if (HEAD) {
         const int have = count < ho.K ? count : ho.K;
         if (lane == 0) { ho.packed[2 * r] = (int32_t)(r * ho.K); ho.packed[2 * r + 1] = have; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < have) {                                       // the head rows: ONE copy of this code, outside the (unrolled) chunk loop
+            const int64_t pos = r * ho.K + lane;
+            const int k = s_head[wv][lane];
+            const float a = lat(k), b = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, mp.step) : lattice_single(t0, k + 1, mp.step);
+            ho.ts[pos] = a; ho.te[pos] = b; ho.ri[pos] = r;
+            sample_point_store(ro + 3 * r, rd + 3 * r, a, b, ho.bb, ho.x01, ho.sel, pos);
+        }
         if (lane >= have && lane < ho.K) {                       // padding rows: harmless inputs, selector 0
             const int64_t pos = r * ho.K + lane;
             ho.ts[pos] = 0.f; ho.te[pos] = 0.f; ho.ri[pos] = r;
@@ -400,6 +443,8 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
         if ((int)threadIdx.x < sr.n) { w_ks[threadIdx.x] = sr.ks[threadIdx.x]; w_bs[threadIdx.x] = sr.bs[threadIdx.x]; w_dd[threadIdx.x] = sr.dd[threadIdx.x]; }
         __syncthreads();
     }
+    const int32_t* ray_rows = (t0s && lat_full) ? reinterpret_cast<const int32_t*>(lat_full) : nullptr;      // per-ray tables (see march_count_kernel)
+    if (ray_rows) lat_full = nullptr;
     LatticeRuns tab;
     tab.n = sr.n; tab.ks = w_ks; tab.bs = w_bs; tab.dd = w_dd; tab.t0 = 0.f; tab.step = step; tab.mode = lattice_mode; tab.full = lat_full;
     // Writes the samples of rank [rank_lo, rank_lo + counts[r]) of every ray (rank = position among the ray's samples in t
@@ -444,7 +489,10 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
                     const int64_t pos = run + __popcll(m & below);
                     if (pos >= off && pos < end) {
                         const int k = qq * 64 + bit;
-                        const float a = lat_full ? lat_full[k] : (tab.n > 0 ? tab.at(tab.find(k), k) : lattice(t0, k, step, lattice_mode));
+                        const float a = lat_full ? lat_full[k]
+                                                 : (tab.n > 0 ? tab.at(tab.find(k), k)
+                                                              : ((ray_rows && lattice_mode == PERF_LATTICE_REPEATED) ? runs_row_at(ray_rows + r * (int64_t)kRunsStride, k, t0, step)
+                                                                                                                     : lattice(t0, k, step, lattice_mode)));
                         const float b = lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, step) : lattice_single(t0, k + 1, step);
                         ts[pos] = a;
                         te[pos] = b;
@@ -637,7 +685,7 @@ static int march_count_launch(const float* rays_o, const float* rays_d, const fl
     mp.use_coarse = (occ_coarse != nullptr && (res % 8) == 0) ? 1 : 0;      // (+ the per-ray span test in the kernel)
     SharedRuns sr;
     sr.n = 0;
-    PERF_REQUIRE(!lattice_table || t0 == nullptr, "a lattice table serves launches whose rays all start at t0_base (t0 == NULL)");
+    PERF_REQUIRE(!lattice_table || t0 == nullptr || lattice_mode == PERF_LATTICE_REPEATED, "per-ray lattice tables (t0 != NULL) exist for the repeated lattice only");
     if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr && !lattice_table) shared_runs_build(t0_base, step, mp.mask_words * 64 + 64, &sr);
     if (head)
         hipLaunchKernelGGL(march_count_kernel<true>, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
@@ -711,7 +759,7 @@ extern "C" int perf_occ_march_write(const float* t0, float t0_scale, float t0_ba
     PERF_REQUIRE(capacity == 0 || (ray_indices && t_starts && t_ends), "NULL sample arrays");
     SharedRuns sr;
     sr.n = 0;
-    PERF_REQUIRE(!lattice_table || t0 == nullptr, "a lattice table serves launches whose rays all start at t0_base (t0 == NULL)");
+    PERF_REQUIRE(!lattice_table || t0 == nullptr || lattice_mode == PERF_LATTICE_REPEATED, "per-ray lattice tables (t0 != NULL) exist for the repeated lattice only");
     if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr && !lattice_table) shared_runs_build(t0_base, step, chunk_words(max_steps) * 64 + 64, &sr);
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
@@ -734,12 +782,38 @@ extern "C" int perf_occ_march_write_points(const float* t0, float t0_scale, floa
     for (int k = 0; k < 3; ++k) { bb.lo[k] = aabb6[k]; bb.hi[k] = aabb6[3 + k]; }
     SharedRuns sr;
     sr.n = 0;
-    PERF_REQUIRE(!lattice_table || t0 == nullptr, "a lattice table serves launches whose rays all start at t0_base (t0 == NULL)");
+    PERF_REQUIRE(!lattice_table || t0 == nullptr || lattice_mode == PERF_LATTICE_REPEATED, "per-ray lattice tables (t0 != NULL) exist for the repeated lattice only");
     if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr && !lattice_table) shared_runs_build(t0_base, step, chunk_words(max_steps) * 64 + 64, &sr);
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
                        t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo, t0_scale, t0_base, (int)lattice_mode, sr, lattice_table);
     PERF_LAUNCH_CHECK("perf_occ_march_write_points");
+    return PERF_OK;
+}
+
+// ---- per-ray tables of runs: one LANE per ray ------------------------------------------------------------------------------
+namespace perf {
+__global__ __launch_bounds__(256) void lattice_runs_kernel(const float* __restrict__ t0s, float t0_scale, float t0_base, int64_t n_rays,
+                                                           float step, int32_t k_need, int32_t* __restrict__ rows) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rays) return;
+    int32_t* row = rows + r * (int64_t)kRunsStride;
+    const float t0 = lattice_origin(t0s, r, t0_scale, t0_base);
+    row[0] = lattice_runs_build<false>(t0, step, k_need, row + 1, reinterpret_cast<uint32_t*>(row + 1 + kMaxRuns),
+                                       reinterpret_cast<uint32_t*>(row + 1 + 2 * kMaxRuns), true);
+}
+}  // namespace perf
+
+extern "C" int64_t perf_occ_lattice_runs_len(int64_t n_rays) { return (n_rays > 0 ? n_rays : 0) * (int64_t)kRunsStride; }
+
+extern "C" int perf_occ_lattice_runs(const float* t0, float t0_scale, float t0_base, int64_t n_rays, float step, int32_t max_steps,
+                                     int32_t* runs, void* stream) {
+    PERF_REQUIRE(n_rays >= 0 && max_steps > 0 && step > 0.f, "perf_occ_lattice_runs: bad arguments");
+    if (n_rays == 0) return PERF_OK;
+    PERF_REQUIRE(t0 && runs, "NULL pointer");
+    hipLaunchKernelGGL(perf::lattice_runs_kernel, dim3((unsigned)div_up(n_rays, 256)), dim3(256), 0, as_stream(stream), t0, t0_scale, t0_base, n_rays,
+                       step, (int32_t)(chunk_words(max_steps) * 64 + 64), runs);
+    PERF_LAUNCH_CHECK("perf_occ_lattice_runs");
     return PERF_OK;
 }
 

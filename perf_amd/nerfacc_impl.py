@@ -231,6 +231,10 @@ class OccGridEstimator(nn.Module):
         if isinstance(t0, tuple) and t0[0] is None:
             # every ray on the same lattice (no jitter): its points are computed once and read by the kernels with one load
             t0 = t0 + (self._shared_lattice(float(near_plane), float(render_step_size), int(max_steps), lattice, dev),)
+        elif isinstance(t0, tuple) and (lattice or _lib_default_lattice()) == 'repeated':
+            # per-ray origins on the repeated-addition lattice: every ray's table of runs from ONE launch that gives each ray a lane
+            # (the marching kernels would spend a wavefront per ray on it)
+            t0 = t0 + (ops.lattice_runs(t0, float(render_step_size), int(max_steps)),)
         res = self._res
         compacts = (sigma_fn is not None or sigma_points_fn is not None) and early_stop_eps > 0
         sm = Samples()

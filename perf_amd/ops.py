@@ -499,11 +499,27 @@ def _origin(t0):
 
 
 def _lat_table(t0):
-    """The precomputed lattice of a launch whose rays all start at the same origin: t0 = (None, scale, base, table) -- see
-    lattice_table(); None otherwise."""
-    if isinstance(t0, tuple) and len(t0) > 3 and t0[0] is None and t0[3] is not None:
-        return _p(_f32(t0[3], 'lattice_table'))
+    """The `lattice_table` argument of the marching entry points: t0 = (None, scale, base, table): the precomputed lattice of a
+    launch whose rays all start at the same origin (lattice_table()); t0 = (u, scale, base, runs): the per-ray tables of runs of
+    a stratified batch (lattice_runs(), int32); None otherwise."""
+    if isinstance(t0, tuple) and len(t0) > 3 and t0[3] is not None:
+        if t0[0] is None:
+            return _p(_f32(t0[3], 'lattice_table'))
+        if t0[3].dtype != torch.int32:
+            raise _lib.PerfError('per-ray lattice runs must be int32 (ops.lattice_runs)')
+        return _p(t0[3])
     return None
+
+
+def lattice_runs(t0, step, max_steps, n_rays=None):
+    """Per-ray tables of runs of the repeated-addition lattice for a batch with per-ray origins (perf_occ_lattice_runs: one lane per
+    ray).  t0: a float32 tensor of origins or a tuple (u, scale, base) -- see _origin.  -> int32 tensor to append to the tuple as its
+    fourth element: (u, scale, base, runs)."""
+    u = t0[0] if isinstance(t0, tuple) else t0
+    n = int(u.shape[0]) if n_rays is None else int(n_rays)
+    out = torch.empty(_lib.load().perf_occ_lattice_runs_len(n), dtype=torch.int32, device=u.device)
+    _call('perf_occ_lattice_runs', *_origin(t0), n, float(step), int(max_steps), _p(out), _stream())
+    return out
 
 
 def lattice_table(t0_base, step, max_steps, lattice=None, device='cuda'):

@@ -55,3 +55,59 @@ def room_with_box(o: torch.Tensor, d: torch.Tensor, half=(0.9, 0.7, 0.5), box_c=
     sgn = torch.gather(torch.sign(d), -1, axis[..., None])[..., 0]
     rgb = (base[..., None] * tint) * (0.75 + 0.25 * sgn[..., None])
     return dist[..., None], rgb.clamp(0, 1)
+
+
+# ---- two more scene families (camera at the origin, one panorama): what the room does not exercise -------------------------
+def _room_and_boxes(d: torch.Tensor, half, boxes):
+    """The box room of room() with axis-aligned boxes (centre, half size) standing in it, seen from the origin.  d [..., 3] unit
+    directions -> (distance [..., 1] normalised by max * 1.05 as dataset.py:97-101, rgb [..., 3]); walls textured like room()'s,
+    boxes with a finer pattern and the tints flipped."""
+    dev = d.device
+    h = torch.tensor(half, dtype=torch.float32, device=dev)
+    dd = torch.where(d.abs() < 1e-12, torch.full_like(d, 1e-12), d)
+    dist, axis = (h / dd.abs()).min(-1)
+    hit_any = torch.zeros_like(dist, dtype=torch.bool)
+    for c, hs in boxes:
+        c = torch.tensor(c, dtype=torch.float32, device=dev); hs = torch.tensor(hs, dtype=torch.float32, device=dev)
+        t1 = (c - hs) / dd; t2 = (c + hs) / dd
+        tn, tf = torch.minimum(t1, t2), torch.maximum(t1, t2)
+        t_in, ax = tn.max(-1)
+        hit = (t_in < tf.min(-1).values) & (t_in > 1e-6) & (t_in < dist)
+        dist = torch.where(hit, t_in, dist)
+        axis = torch.where(hit, ax, axis)
+        hit_any = torch.where(hit, torch.ones_like(hit_any), hit_any)
+    p = d * dist[..., None]
+    uv = torch.tensor([[1, 2], [0, 2], [0, 1]], device=dev)[axis]
+    u = torch.gather(p, -1, uv[..., :1])[..., 0]
+    v = torch.gather(p, -1, uv[..., 1:])[..., 0]
+    k = torch.where(hit_any, torch.full_like(dist, 48.), torch.tensor([8., 16., 32.], device=dev)[axis])
+    base = 0.5 + 0.5 * torch.sin(k * u) * torch.sin(k * v)
+    tint = torch.tensor([[1.0, 0.6, 0.4], [0.4, 1.0, 0.6], [0.5, 0.6, 1.0]], device=dev)[axis]
+    tint = torch.where(hit_any[..., None], tint.flip(-1), tint)
+    sgn = torch.gather(torch.sign(d), -1, axis[..., None])[..., 0]
+    rgb = (base[..., None] * tint) * (0.75 + 0.25 * sgn[..., None])
+    return (dist / (dist.max() * 1.05))[..., None], rgb.clamp(0, 1)
+
+
+def doorway(d: torch.Tensor):
+    """Two rooms joined by a doorway: the camera stands in the smaller one, a partition wall at x = 0.30 (3 cm thick) has a door
+    opening (0.30 wide, from the floor to z = 0.2) through which rays run on into the second room -- a long thin free space behind
+    an occluder, depth discontinuities of 3x along the door frame, a thin wall seen edge-on from grazing rays."""
+    part = [((0.315, -0.425, 0.0), (0.015, 0.275, 0.5)), ((0.315, 0.425, 0.0), (0.015, 0.275, 0.5)), ((0.315, 0.0, 0.35), (0.015, 0.15, 0.15))]
+    return _room_and_boxes(d, (0.95, 0.7, 0.5), part)
+
+
+def pillars(d: torch.Tensor):
+    """The room with fourteen thin square pillars (6 cm wide, floor to ceiling) on two rings around the camera: high-frequency
+    occupancy, many short free spans, most rays pass several pillar edges within a few occupancy cells."""
+    import math
+    boxes = []
+    for ring, (rad, n, ph) in enumerate(((0.32, 6, 0.2), (0.55, 8, 0.55))):
+        for i in range(n):
+            a = ph + 2 * math.pi * i / n
+            x, y = rad * math.cos(a), rad * 0.78 * math.sin(a)
+            boxes.append(((x, y, 0.0), (0.03, 0.03, 0.5)))
+    return _room_and_boxes(d, (0.9, 0.7, 0.5), boxes)
+
+
+SCENES = {'room': room, 'doorway': doorway, 'pillars': pillars}

@@ -20,10 +20,16 @@ def psnr(a, b):
     return float(-10 * torch.log10(torch.mean((a.float() - b.float()) ** 2)))
 
 
-def make_scene(h, w):
+def make_scene(h, w, scene='room'):
+    """scene: 'room' (the oracle's own synthetic room) or one of the other families of perf_amd.synthetic ('doorway', 'pillars':
+    pure torch functions of the ray directions, evaluated here on the CPU)."""
     o, d = O.pano_rays(torch.eye(4), h, w)
     o = o.reshape(-1, 3).contiguous(); d = d.reshape(-1, 3).contiguous()
-    dist, rgb = O.synthetic_room(d)
+    if scene == 'room':
+        dist, rgb = O.synthetic_room(d)
+    else:
+        from perf_amd import synthetic
+        dist, rgb = synthetic.SCENES[scene](d)
     occ = O.gen_occ_grid(o, d, dist, 256).reshape(256, 256, 256).bool().numpy()
     return o, d, dist, rgb, occ
 

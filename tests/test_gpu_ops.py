@@ -1027,9 +1027,23 @@ def test_occ_march_both_lattices_bit_exact(ops, step, lattice):
                                                    lattice=lattice)
             assert np.array_equal(gri.cpu().numpy(), ri) and np.array_equal(gpacked.cpu().numpy(), packed)
             assert np.array_equal(gts.cpu().numpy(), ts) and np.array_equal(gte.cpu().numpy(), te)
+    if lattice == 'repeated':
+        # per-ray tables of runs built one LANE per ray (perf_occ_lattice_runs) and handed to the marching kernels: same bits
+        for origin in (t0.cuda(), (u.cuda(), step, near)):
+            runs = ops.lattice_runs(origin, step, max_steps)
+            assert runs.dtype == torch.int32 and int(runs.view(R, -1)[:, 0].min()) > 0                 # every table fits
+            with_runs = origin + (runs,) if isinstance(origin, tuple) else (origin, 0.0, 0.0, runs)
+            gri, gts, gte, gpacked = ops.occ_march(o.cuda(), d.cuda(), with_runs, bits, 64, aabb, far, step, max_steps, occ_coarse=coarse, lattice=lattice)
+            assert np.array_equal(gri.cpu().numpy(), ri) and np.array_equal(gpacked.cpu().numpy(), packed)
+            assert np.array_equal(gts.cpu().numpy(), ts) and np.array_equal(gte.cpu().numpy(), te)
     K = 4
     m2, c2, (ri2, ts2, te2, pk2, x2, s2) = ops.occ_march_count_head(o.cuda(), d.cuda(), t0.cuda(), bits, 64, list(aabb), far, step, max_steps,
                                                                     coarse, K, list(aabb), lattice=lattice)
+    if lattice == 'repeated':
+        runs = ops.lattice_runs(t0.cuda(), step, max_steps)
+        m3, c3, head3 = ops.occ_march_count_head(o.cuda(), d.cuda(), (t0.cuda(), 0.0, 0.0, runs), bits, 64, list(aabb), far, step, max_steps,
+                                                 coarse, K, list(aabb), lattice=lattice)
+        assert torch.equal(c3, c2) and all(torch.equal(a, b) for a, b in zip(head3, (ri2, ts2, te2, pk2, x2, s2)))
     assert np.array_equal(c2.cpu().numpy(), packed[:, 1])
     for r in np.nonzero(packed[:, 1] > 0)[0][:50]:
         n = min(int(packed[r, 1]), K)
