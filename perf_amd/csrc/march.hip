@@ -793,14 +793,45 @@ extern "C" int perf_occ_march_write_points(const float* t0, float t0_scale, floa
 
 // ---- per-ray tables of runs: one LANE per ray ------------------------------------------------------------------------------
 namespace perf {
-__global__ __launch_bounds__(256) void lattice_runs_kernel(const float* __restrict__ t0s, float t0_scale, float t0_base, int64_t n_rays,
-                                                           float step, int32_t k_need, int32_t* __restrict__ rows) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// One LANE per ray.  The walk as a loop WITHOUT long divergent bodies: every iteration makes the two real additions and the
+// division whatever happens next (lanes cross their binades at different indices; with the three cases as branches a wave
+// executed all three bodies in nearly every iteration: 31 us for 8,192 rays), then advances by one of the three cases.  Same
+// arithmetic, same tables as lattice_runs_build.
+__device__ __forceinline__ int lattice_runs_build_lane(float t0, float step, int k_need, int32_t* __restrict__ row) {
+    int32_t* ks = row + 1;
+    uint32_t* bs = reinterpret_cast<uint32_t*>(row + 1 + kMaxRuns);
+    uint32_t* dd = reinterpret_cast<uint32_t*>(row + 1 + 2 * kMaxRuns);
+    int n = 0;
+    uint32_t tb = __float_as_uint(t0);
+    ks[0] = 0; bs[0] = tb; dd[0] = 0u; n = 1;
+    int K = 0;
+    bool stuck = false;
+    while (K < k_need && !stuck) {
+        if (n + 2 > kMaxRuns) return -1;
+        const uint32_t b1 = __float_as_uint(add_rn(__uint_as_float(tb), step));
+        const uint32_t b2 = __float_as_uint(add_rn(__uint_as_float(b1), step));
+        const bool c1 = (b1 >> 23) != (tb >> 23);            // the first addition entered a binade: one more real step first
+        const bool c2 = (b2 >> 23) != (b1 >> 23);
+        const uint32_t d = b2 - b1;
+        const uint32_t top = (b2 & 0xff800000u) + 0x00800000u;
+        const uint32_t j = div_u24(top - 1u - b2, d ? d : 1u);
+        // run K+1 (always emitted): a single point (c1, c2) or the arithmetic run to the end of the binade
+        ks[n] = K + 1; bs[n] = b1; dd[n] = (c1 || c2) ? 0u : d;
+        ++n;
+        if (!c1 && c2) { ks[n] = K + 2; bs[n] = b2; dd[n] = 0u; ++n; }
+        stuck = !c1 && !c2 && d == 0u;                       // (step below half an ulp: the lattice stays at t_{K+1} for good)
+        tb = c1 ? b1 : (c2 ? b2 : b2 + j * d);
+        K += c1 ? 1 : (c2 ? 2 : 2 + (int)j);
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(64) void lattice_runs_kernel(const float* __restrict__ t0s, float t0_scale, float t0_base, int64_t n_rays,
+                                                          float step, int32_t k_need, int32_t* __restrict__ rows) {
+    const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rays) return;
     int32_t* row = rows + r * (int64_t)kRunsStride;
-    const float t0 = lattice_origin(t0s, r, t0_scale, t0_base);
-    row[0] = lattice_runs_build<false>(t0, step, k_need, row + 1, reinterpret_cast<uint32_t*>(row + 1 + kMaxRuns),
-                                       reinterpret_cast<uint32_t*>(row + 1 + 2 * kMaxRuns), true);
+    row[0] = lattice_runs_build_lane(lattice_origin(t0s, r, t0_scale, t0_base), step, k_need, row);
 }
 }  // namespace perf
 
@@ -811,7 +842,7 @@ extern "C" int perf_occ_lattice_runs(const float* t0, float t0_scale, float t0_b
     PERF_REQUIRE(n_rays >= 0 && max_steps > 0 && step > 0.f, "perf_occ_lattice_runs: bad arguments");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(t0 && runs, "NULL pointer");
-    hipLaunchKernelGGL(perf::lattice_runs_kernel, dim3((unsigned)div_up(n_rays, 256)), dim3(256), 0, as_stream(stream), t0, t0_scale, t0_base, n_rays,
+    hipLaunchKernelGGL(perf::lattice_runs_kernel, dim3((unsigned)div_up(n_rays, 64)), dim3(64), 0, as_stream(stream), t0, t0_scale, t0_base, n_rays,
                        step, (int32_t)(chunk_words(max_steps) * 64 + 64), runs);
     PERF_LAUNCH_CHECK("perf_occ_lattice_runs");
     return PERF_OK;

@@ -2,7 +2,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05k
 rm -rf $O; mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests -m gpu -q -x -k "march or sampling or lattice or head or counts or graph or renderer or scene or fullsize" 2>&1 | tail -4
+timeout 900 python -m pytest tests -m gpu -q -x -k "march or sampling or lattice or head or counts or graph or renderer or scene or fullsize" > $O/pytest.log 2>&1; tail -3 $O/pytest.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
 MARCH_PROBE_REPS=20 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -o m -- python $R/tools/exp/march_probe.py > $O/probe.log 2>&1
 grep -v amdgpu $O/probe.log | grep "jittered\|lattice_runs" | cut -c1-260
