@@ -981,15 +981,25 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     //  if NO field of ANY tile ends in the band [2^29, 2^32 - 2^29) -- i.e. if the largest sum of the whole table exceeds
     //  7x the level at which smaller sums already raise the flag while none of them lands there)
     if (FIXED && overflow_flag && field_max >= (1 << 29)) atomicOr(overflow_flag, 1);
-    if (FIXED && hr_state && R == 1) {  // largest |field| of the level, for the feedback (one atomic per wave; replicated
+    if (FIXED && hr_state && R == 1) {  // largest |field| of the level, for the feedback (ONE atomic per workgroup; replicated
                                         // levels report the max of their SUMMED fields from the reduction kernel)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) field_max = max(field_max, __shfl_xor(field_max, off));
-        // (the 24 maxima share a cache line, and read-modify-writes on one line retire one at a time, ~11 ns each: 192 hashed
-        //  owners x 16 waves ending together would queue for tens of microseconds -- only a wave that RAISES the maximum needs one)
-        if ((threadIdx.x & 63) == 0 && field_max > 0 &&
-            field_max > __hip_atomic_load(&hr_state[PERF_MAX_LEVELS + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(&hr_state[PERF_MAX_LEVELS + l], field_max);
+        // The 24 maxima share a cache line, and read-modify-writes on one line retire one at a time, ~11 ns each.  A wave only
+        // needs one when it RAISES the maximum -- but the look does not help when everybody finishes together: with a few
+        // thousand live samples (the reference-faithful step) all 192 hashed owners end within a microsecond, their 3,072 waves
+        // all read the stale zero and all queue: the launch took 41 us at 1,024 live samples against 12 us at none (rocprofv3,
+        // tools/exp/bwd_live_sweep.py).  The workgroup's waves therefore agree on ONE value first (LDS) -- at most 192 atomics.
+        __shared__ int32_t wave_max[kBwdThreads / 64];
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = field_max;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int32_t m = 0;
+#pragma unroll
+            for (int w = 0; w < kBwdThreads / 64; ++w) m = max(m, wave_max[w]);
+            if (m > 0 && m > __hip_atomic_load(&hr_state[PERF_MAX_LEVELS + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&hr_state[PERF_MAX_LEVELS + l], m);
+        }
     }
 }
 

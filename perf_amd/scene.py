@@ -430,6 +430,8 @@ class NeRFScene:
         # alike) -- a captured step then holds no torch random op, whose graph replays cost two extra launches each.
         # False, or an explicit `generator` / `rand` argument: torch.randint / torch.rand as in rounds 1-2.
         self.device_rng = True
+        # sync-free training: let the health poll lower a sample capacity that proved far too large (see _poll_health)
+        self.auto_shrink_capacity = True
         self._rng_seed = None
         self._rng_counter = None
 
@@ -708,7 +710,25 @@ class NeRFScene:
             self.renderer.sample_capacity = max(2 * cap, int(1.25 * c[3]))
             self.sample_counters[3] = 0
             recapture = True
+        elif cap is not None and self.auto_shrink_capacity and c[3] > 0:
+            # The capacity is the launch size of every per-sample kernel of the step (and the stride of the level-major
+            # buffers): PeRF's 8,192-ray batches march 300 k samples while the density field is transparent and 35 k once it
+            # has formed -- against a capacity of 8,192 x 128 rows.  Launches sized for a million rows that hold 35 k cost
+            # their dispatch (the encode's 32,768 workgroups that read the count and leave: 10 us each, twice per step).
+            # c[3] is the largest marched count SINCE THE LAST POLL (a window of 64 steps): when the capacity is more than
+            # SHRINK_AT times that, it drops to SHRINK_TO times it -- far above anything the window saw; a batch that still
+            # exceeded it would be truncated, its step skipped and the capacity raised again (above).  Results do not depend on
+            # the capacity (tests/test_gpu_counts.py); the captured step is captured again.
+            if cap > self.CAPACITY_SHRINK_AT * c[3]:
+                new = max(int(self.CAPACITY_SHRINK_TO * c[3]), self.CAPACITY_MIN_ROWS)
+                new = (new + 4095) // 4096 * 4096
+                if new < cap:
+                    self.renderer.sample_capacity = new
+                    recapture = True
+            self.sample_counters[3] = 0               # the window starts over
         return {'recapture': recapture}
+
+    CAPACITY_SHRINK_AT, CAPACITY_SHRINK_TO, CAPACITY_MIN_ROWS = 8, 4, 65536
 
     def _geo_prefetch(self, sup_pool, rand, generator):
         """Everything of a geometry step that does not depend on the geometry parameters: batch draw, and -- when the
