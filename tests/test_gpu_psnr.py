@@ -15,13 +15,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_psnr_at_iter_matches_the_oracle_curve():
+@pytest.mark.parametrize('scene_name', ['room', 'doorway', 'pillars'])
+def test_psnr_at_iter_matches_the_oracle_curve(scene_name):
+    """Three scene families (perf_amd/synthetic.py): the box room every constant of the fixed-point machinery was tuned on, two rooms
+    joined by a doorway (thin wall, 3x depth discontinuities, a long free space behind an occluder) and a room with fourteen thin
+    pillars (high-frequency occupancy, many short free spans) -- each against ITS oracle curve (tests/golden/psnr_curve[_<scene>].json)."""
     from perf_amd import tcnn
     from tests import psnr_parity_lib as P
-    golden = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'psnr_curve.json')))
+    name = 'psnr_curve.json' if scene_name == 'room' else f'psnr_curve_{scene_name}.json'
+    golden = json.load(open(os.path.join(ROOT, 'tests', 'golden', name)))
     cfg = golden['config']
+    assert cfg.get('scene', 'room') == scene_name
     h, w = cfg['pano']
-    scene = P.make_scene(h, w)
+    scene = P.make_scene(h, w, scene_name)
     deltas = {f'psnr@app{m}': [] for m in cfg['marks']}
     depth = []
     geo_marks = cfg.get('geo_marks', [])

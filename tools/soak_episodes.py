@@ -3,7 +3,7 @@ episode resets the geometry field, rebuilds the occupancy and trains 3000 + 1500
 episode cannot show: the closed-loop fixed-point headroom across `reset_geo`, the device-side health counters, graph
 re-capture, memory growth, PSNR drift.
 
-  python tools/soak_episodes.py [--episodes 25] [--dtype bf16] [--rccl-single-rank]"""
+  python tools/soak_episodes.py [--episodes 25] [--dtype bf16] [--scene room|doorway|pillars] [--no-shrink] [--rccl-single-rank]"""
 import argparse, hashlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,6 +15,8 @@ ap.add_argument('--episodes', type=int, default=25)
 ap.add_argument('--geo', type=int, default=3000)
 ap.add_argument('--app', type=int, default=1500)
 ap.add_argument('--dtype', default='bf16')
+ap.add_argument('--scene', default='room', choices=sorted(synthetic.SCENES), help='synthetic scene family (perf_amd/synthetic.py)')
+ap.add_argument('--no-shrink', action='store_true', help='keep the sample capacity where the phase starts it (NeRFScene.auto_shrink_capacity = False; the digests must not change)')
 ap.add_argument('--eager', action='store_true', help='no hipGraph replays (the digests must not change)')
 ap.add_argument('--no-reuse', action='store_true', help='strict two-encode order (the digests must not change)')
 ap.add_argument('--head', type=int, default=-1, help='renderer.head_samples (0: one-phase sampler; the kept samples -- and the digests -- must not change)')
@@ -34,9 +36,10 @@ if args.autograd:
 if args.head >= 0:
     scene.renderer.head_samples = args.head or None
 scene.reuse_sampling_features = not args.no_reuse
+scene.auto_shrink_capacity = not args.no_shrink
 H, W = 512, 1024
 rays = gen_pano_rays(torch.eye(4), H, W)
-dist, rgb = synthetic.room(rays.d)
+dist, rgb = synthetic.SCENES[args.scene](rays.d)
 pool = SupInfoPool(); pool.register_rays(rays.o, rays.d, rgb, dist)
 rows = []
 for ep in range(args.episodes):
@@ -56,7 +59,7 @@ for ep in range(args.episodes):
     print(json.dumps(rows[-1]), flush=True)
 ps = [r['psnr_dB'] for r in rows]
 digest = rows[-1]['params_sha256_16']
-print(json.dumps({'params_sha256_16': digest, 'data_parallel': bool(args.rccl_single_rank), 'config': f'{args.episodes} episodes of {args.geo} + {args.app} iterations, 8192-ray batches, {W}x{H} panorama, {args.dtype}',
+print(json.dumps({'params_sha256_16': digest, 'data_parallel': bool(args.rccl_single_rank), 'scene': args.scene, 'auto_shrink_capacity': not args.no_shrink, 'config': f'{args.episodes} episodes of {args.geo} + {args.app} iterations, 8192-ray batches, {W}x{H} panorama, {args.dtype}',
                   'psnr_min_max': [min(ps), max(ps)], 'seconds_min_max': [min(r['seconds'] for r in rows), max(r['seconds'] for r in rows)],
                   'skipped_for_overflow_total': rows[-1]['skipped_for_overflow'], 'skipped_for_truncation_total': rows[-1]['skipped_for_truncation'],
                   'mem_reserved_MB_first_last': [rows[0]['mem_reserved_MB'], rows[-1]['mem_reserved_MB']], 'episodes': rows}))
