@@ -426,6 +426,165 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
     }
 }
 
+// ---- large launches on ONE lattice (eval frames: no jitter, t_k precomputed): a ray per LANE for everything that is uniform
+// per ray.  The wave-per-ray kernel above is VALU bound on such launches -- 488 vector instructions per ray on a 524,288-ray
+// frame (SQ_ACTIVE_INST_VALU 95 %), of which ~140 are the ray's set-up (slab test with three IEEE divisions, skip-grid validity)
+// executed by 64 lanes on uniform values and ~100 the chunk ballot that uses 47 of 64 lanes.  Here a wave takes 64 rays: set-up
+// and the chunk decisions (range + dilated coarse grid; the chunk's lattice points are the same for every ray: scalar loads)
+// run lane-parallel -- the coarse-grid words of eight chunks in flight per round --, then the wave walks its rays' surviving
+// chunks exactly as above (64 intervals of a chunk, one per lane).  Same arithmetic per ray, same masks, counts and head rows.
+// Needs enough rays to fill the chip with 64-ray waves (the host picks it from kSharedMinRays rays on) and one live word per
+// ray (max_steps <= 4096).
+constexpr int64_t kSharedMinRays = 262144;
+template <bool HEAD>
+__global__ __launch_bounds__(64) void march_count_shared_kernel(MarchParams mp, const float* __restrict__ ro, const float* __restrict__ rd,
+                                                                int64_t n_rays, const uint32_t* __restrict__ bits,
+                                                                const uint32_t* __restrict__ coarse, uint64_t* __restrict__ masks,
+                                                                int32_t* __restrict__ counts, HeadOut ho, float t0_base,
+                                                                const float* __restrict__ lat_full) {
+    __shared__ int32_t s_head[64];
+    const int lane = threadIdx.x;
+    const int64_t r_base = (int64_t)blockIdx.x * 64;
+    const int res = mp.res;
+    const float rf = (float)res;
+    // ---- per lane: the ray's range and its chunk decisions
+    uint64_t live_mine = 0;
+    float lo_mine = 0.f, hi_mine = 0.f;
+    {
+        const int64_t r = r_base + lane;
+        if (r < n_rays) {
+            const float o[3] = {ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]};
+            const float d[3] = {rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]};
+            float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float inv = __fdiv_rn(1.0f, d[a]);
+                const float t1 = mul_rn(sub_rn(mp.lo[a], o[a]), inv), t2 = mul_rn(sub_rn(mp.hi[a], o[a]), inv);
+                const float l = fminf(t1, t2), h = fmaxf(t1, t2);
+                tmin = (a == 0) ? l : fmaxf(tmin, l);
+                tmax = (a == 0) ? h : fminf(tmax, h);
+            }
+            lo_mine = fmaxf(tmin, t0_base); hi_mine = fminf(tmax, mp.far_plane);
+            float span_cells = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) span_cells = fmaxf(span_cells, fabsf(d[a]) * mp.chunk_cells[a]);
+            const bool use_coarse = mp.use_coarse && (span_cells * 0.5f + 1.5f <= (float)kCoarseBlock);
+            const int cr = res >> kCoarseShift;
+            for (int q0 = 0; q0 < mp.mask_words; q0 += 8) {
+                uint32_t bi[8]; bool in[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = q0 + u;
+                    bi[u] = 0u; in[u] = false;
+                    if (q < mp.mask_words) {                                 // (uniform)
+                        const int k0 = q * 64;
+                        const float t_first = lat_full[k0], t_mid = lat_full[k0 + 32], t_last = lat_full[k0 + 64];     // (uniform addresses)
+                        in[u] = !(t_first > hi_mine) && !(t_last < lo_mine);
+                        if (in[u] && use_coarse) {
+                            int cb[3];
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) {
+                                const float p = add_rn(o[a], mul_rn(d[a], t_mid));
+                                const float uu = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
+                                cb[a] = ((int)fminf(fmaxf(floorf(uu), 0.0f), rf - 1.0f)) >> kCoarseShift;
+                            }
+                            bi[u] = (uint32_t)((cb[0] * cr + cb[1]) * cr + cb[2]);
+                        }
+                    }
+                }
+                uint32_t w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = (in[u] && use_coarse) ? coarse[bi[u] >> 5] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (in[u] && (!use_coarse || ((w[u] >> (bi[u] & 31u)) & 1u))) live_mine |= 1ull << (q0 + u);
+            }
+        }
+    }
+    // ---- the wave walks its rays
+    const uint32_t live_lo32 = (uint32_t)live_mine, live_hi32 = (uint32_t)(live_mine >> 32);
+    for (int s = 0; s < 64; ++s) {
+        const int64_t r = r_base + s;
+        if (r >= n_rays) break;
+        const uint64_t live = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)live_lo32, s) |
+                              ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)live_hi32, s) << 32);
+        const float lo = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lo_mine), s));
+        const float hi = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(hi_mine), s));
+        uint64_t* rec = masks + r * (int64_t)(mp.mask_words + 1);
+        int32_t count = 0;
+        uint64_t kept = 0;
+        if (live) {
+            const float o[3] = {ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]};
+            const float d[3] = {rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]};
+            for (uint64_t todo = live; todo;) {
+                int qs[4]; uint32_t cis[4]; bool in_range[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    qs[u] = -1; cis[u] = 0u; in_range[u] = false;
+                    if (todo) {
+                        qs[u] = __ffsll((unsigned long long)todo) - 1;
+                        todo &= todo - 1;
+                        const int k = qs[u] * 64 + lane;
+                        if (k < mp.max_steps) {
+                            const float ta = lat_full[k];
+                            const float tb = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(ta, mp.step) : lattice_single(t0_base, k + 1, mp.step);
+                            const float mid = mul_rn(add_rn(ta, tb), 0.5f);
+                            if (mid >= lo && mid <= hi) {
+                                int cell[3];
+#pragma unroll
+                                for (int a = 0; a < 3; ++a) {
+                                    const float p = add_rn(o[a], mul_rn(d[a], mid));
+                                    const float uu = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
+                                    cell[a] = (int)fminf(fmaxf(floorf(uu), 0.0f), rf - 1.0f);
+                                }
+                                cis[u] = (uint32_t)((cell[0] * res + cell[1]) * res + cell[2]);
+                                in_range[u] = true;
+                            }
+                        }
+                    }
+                }
+                uint32_t words[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) words[u] = in_range[u] ? bits[cis[u] >> 5] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (qs[u] < 0) continue;                 // (wave uniform)
+                    const bool mine = in_range[u] && ((words[u] >> (cis[u] & 31)) & 1u);
+                    const uint64_t m = __ballot(mine);
+                    if (m) {
+                        kept |= 1ull << qs[u];
+                        if (lane == 0) rec[1 + qs[u]] = m;
+                        if (HEAD && count < ho.K && mine) {
+                            const int rank = count + __popcll(m & ((1ull << lane) - 1ull));
+                            if (rank < ho.K) s_head[rank] = qs[u] * 64 + lane;
+                        }
+                        count += __popcll(m);
+                    }
+                }
+            }
+        }
+        if (lane == 0) { rec[0] = kept; counts[r] = count; }
+        if (HEAD) {
+            const int have = count < ho.K ? count : ho.K;
+            if (lane == 0) { ho.packed[2 * r] = (int32_t)(r * ho.K); ho.packed[2 * r + 1] = have; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < have) {
+                const int64_t pos = r * ho.K + lane;
+                const int k = s_head[lane];
+                const float a = lat_full[k], b = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, mp.step) : lattice_single(t0_base, k + 1, mp.step);
+                ho.ts[pos] = a; ho.te[pos] = b; ho.ri[pos] = r;
+                sample_point_store(ro + 3 * r, rd + 3 * r, a, b, ho.bb, ho.x01, ho.sel, pos);
+            }
+            if (lane >= have && lane < ho.K) {               // padding rows: harmless inputs, selector 0
+                const int64_t pos = r * ho.K + lane;
+                ho.ts[pos] = 0.f; ho.te[pos] = 0.f; ho.ri[pos] = r;
+                ho.x01[3 * pos] = 0.5f; ho.x01[3 * pos + 1] = 0.5f; ho.x01[3 * pos + 2] = 0.5f; ho.sel[pos] = 0;
+            }
+            __builtin_amdgcn_wave_barrier();                 // (s_head is reused by the next ray)
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void march_write_kernel(const float* __restrict__ t0s, int64_t n_rays, float step,
                                                           int32_t mask_words, const uint64_t* __restrict__ masks,
                                                           const int32_t* __restrict__ counts,
@@ -687,6 +846,16 @@ static int march_count_launch(const float* rays_o, const float* rays_d, const fl
     sr.n = 0;
     PERF_REQUIRE(!lattice_table || t0 == nullptr || lattice_mode == PERF_LATTICE_REPEATED, "per-ray lattice tables (t0 != NULL) exist for the repeated lattice only");
     if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr && !lattice_table) shared_runs_build(t0_base, step, mp.mask_words * 64 + 64, &sr);
+    if (t0 == nullptr && lattice_table != nullptr && mp.mask_words <= 64 && n_rays >= kSharedMinRays) {      // (see march_count_shared_kernel)
+        if (head)
+            hipLaunchKernelGGL(march_count_shared_kernel<true>, dim3((unsigned)div_up(n_rays, 64)), dim3(64), 0, as_stream(stream), mp, rays_o, rays_d,
+                               n_rays, occ_bits, occ_coarse, masks, counts, *head, t0_base, lattice_table);
+        else
+            hipLaunchKernelGGL(march_count_shared_kernel<false>, dim3((unsigned)div_up(n_rays, 64)), dim3(64), 0, as_stream(stream), mp, rays_o, rays_d,
+                               n_rays, occ_bits, occ_coarse, masks, counts, HeadOut{}, t0_base, lattice_table);
+        PERF_LAUNCH_CHECK("perf_occ_march_count");
+        return PERF_OK;
+    }
     if (head)
         hipLaunchKernelGGL(march_count_kernel<true>, dim3((unsigned)div_up(n_rays, 4)), dim3(256), 0, as_stream(stream), mp, rays_o,
                            rays_d, t0, n_rays, occ_bits, occ_coarse, masks, counts, *head, t0_scale, t0_base, sr, lattice_table);

@@ -1098,3 +1098,45 @@ def test_lagged_units_do_not_follow_a_vanishing_gradient(ops):
     ops.dp_units(cfg, stats(1e-2), 1, hr, shifts=shifts, want_total=False, margin_bits=1)      # a large gradient: coarser at once
     s4 = shifts.clone()
     assert bool((s4[:cfg.n_levels] < s1[:cfg.n_levels] - 6).all())
+
+
+def test_lane_per_ray_marching_of_large_shared_lattice_launches_equals_wave_per_ray(ops):
+    """Launches of >= 262,144 rays that share one lattice (eval frames) take march_count_shared_kernel (a ray per LANE for the set-up
+    and the chunk decisions, then the wave walks its 64 rays); smaller ones the wave-per-ray kernel.  The same rays in one large launch
+    and in two halves: keep masks, counts and the head rows the counting pass writes are identical, on both lattices."""
+    from perf_amd import synthetic
+    from perf_amd.scene import SupInfoPool, gen_pano_rays
+    rays = gen_pano_rays(torch.eye(4), 384, 768)                     # 294,912 rays
+    o = rays.o.reshape(-1, 3).contiguous() + torch.tensor([0.05, -0.1, 0.02], device='cuda'); d = rays.d.reshape(-1, 3).contiguous()
+    dist, rgb = synthetic.pillars(d)
+    pool = SupInfoPool(); pool.register_rays(rays.o.reshape(-1, 3), d, rgb.reshape(-1, 3), dist.reshape(-1, 1))
+    occ, _ = pool.gen_occ_grid(256)
+    bits = ops.occ_pack_bits(occ)
+    coarse = ops.occ_build_coarse(bits, 256)
+    aabb = [-1., -1, -1, 1, 1, 1]
+    step, far, max_steps, K = 5e-4, 1.5, 3001, 2
+    R = o.shape[0]
+    assert R >= 262144 and R // 2 < 262144
+    for lattice in ('repeated', 'single'):
+        t0 = (None, 0.0, 0.0, ops.lattice_table(0.0, step, max_steps, lattice))
+        for cz in (coarse, None):
+            m_all, c_all, head_all = ops.occ_march_count_head(o, d, t0, bits, 256, aabb, far, step, max_steps, cz, K, aabb, lattice=lattice)
+            m2, c2 = ops.occ_march_count(o, d, t0, bits, 256, aabb, far, step, max_steps, cz, lattice=lattice)
+            assert torch.equal(c_all, c2)
+            h = R // 2
+            mw = m_all.numel() // R
+            for lo, hi in ((0, h), (h, R)):
+                m, c, head = ops.occ_march_count_head(o[lo:hi].contiguous(), d[lo:hi].contiguous(), t0, bits, 256, aabb, far, step, max_steps, cz, K, aabb,
+                                                      lattice=lattice)
+                assert torch.equal(c, c_all[lo:hi])
+                # (mask words of chunks without samples are never written: compare the live words and the masks they announce)
+                ma, mb = m_all.view(R, mw)[lo:hi], m.view(hi - lo, mw)
+                assert torch.equal(ma[:, 0], mb[:, 0])
+                for q in range(mw - 1):
+                    on = ((ma[:, 0] >> q) & 1).bool()
+                    assert torch.equal(ma[on, 1 + q], mb[on, 1 + q]), (lattice, q)
+                ri, ts, te, pk, x01, sel = head
+                ri_a, ts_a, te_a, pk_a, x_a, s_a = head_all
+                assert torch.equal(ts, ts_a[lo * K:hi * K]) and torch.equal(te, te_a[lo * K:hi * K]) and torch.equal(sel, s_a[lo * K:hi * K])
+                assert torch.equal(x01, x_a[lo * K:hi * K]) and torch.equal(pk[:, 1], pk_a[lo:hi, 1]) and torch.equal(ri + lo, ri_a[lo * K:hi * K])
+            assert int(c_all.sum()) > 100000
