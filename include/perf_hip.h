@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 7
+#define PERF_ABI_VERSION 8
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -543,6 +543,28 @@ int perf_geo_loss(const float* opacity, const float* distance, const float* gt_d
 int perf_app_loss(const float* opacity, const float* color, const float* bg_color, const float* gt_color,
                   int64_t n_rays, int64_t global_batch, float color_weight, float loss_scale, float* g_color,
                   float* scalars, void* stream);
+
+/* ---- the whole ray head of a training step in one launch -----------------------------------------------------------
+ * perf_composite_distloss_fwd -> perf_geo_loss -> perf_composite_distloss_bwd (geometry step, nerf.py:195-252) and
+ * perf_composite_fwd -> perf_app_loss -> perf_composite_bwd (colour step, nerf.py:268-293) as ONE kernel each, one wavefront per
+ * ray, the same arithmetic expression by expression: nothing in either loss couples two rays except the batch size (an argument)
+ * and, for the distortion loss, "the last ray that holds a sample", which every wavefront reads off the end of packed_info.
+ * Outputs: weights / trans [n_samples], opacity / distance [R], color [R,3] (geometry: only with rgbs), the per-ray loss TERMS
+ * (geometry: depth_terms[r] = smooth_l1(d' - gt), distloss_per_ray[r]; colour: color_terms[r] = sum over the three channels) and
+ * the gradient the field backward starts from (d_sigmas [n_samples]; colour: d_rgbs [n_samples,3]).  The loss values are reports:
+ * depth = sum(depth_terms) / global_batch, distortion = sum(distloss_per_ray) * inv_n_out[0], colour = sum(color_terms) /
+ * (3 global_batch) -- left to whoever reads them.  A local batch smaller than global_batch (data parallel) normalises the
+ * distortion loss by the global batch like perf_geo_loss.  noise, ratio_dev, bg_color, rgbs (geometry), color (geometry),
+ * inv_n_out may be NULL. */
+int perf_train_head_geo(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+                        const int32_t* packed_info, int64_t n_rays, const float* gt_distance, const float* noise,
+                        int64_t global_batch, float depth_weight, float distortion_weight, const float* ratio_dev,
+                        float loss_scale, float* weights, float* trans, float* opacity, float* distance, float* color,
+                        float* depth_terms, float* distloss_per_ray, float* inv_n_out, float* d_sigmas, void* stream);
+int perf_train_head_app(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+                        const int32_t* packed_info, int64_t n_rays, const float* bg_color, const float* gt_color,
+                        int64_t global_batch, float color_weight, float loss_scale, float* weights, float* trans,
+                        float* opacity, float* distance, float* color, float* color_terms, float* d_rgbs, void* stream);
 
 /* Supervision batch (SupInfoPool.rand_ray_color_data, modules/dataset/sup_info.py:236-259): out[i] = all[indices[i]] for
  * every non-NULL output (origins/directions/colours/normals [n,3], distances [n]) in one launch. */

@@ -866,6 +866,169 @@ __global__ __launch_bounds__(64) void app_loss_final_kernel(int n_blocks, float 
     if (threadIdx.x == 0) scalars[0] = sum * inv_n;
 }
 
+
+// ---- the whole ray head of a training step in ONE launch -------------------------------------------------------------------
+// compositing forward (+ the per-ray distortion-loss sums) -> the loss head of the ray -> compositing backward, one wavefront
+// per ray.  Nothing in the loss couples two rays except two normalisers: the batch size (a launch argument) and, for the
+// distortion loss, flatten_eff_distloss's "last ray that holds a sample" -- which every wave finds for itself with one load
+// from the end of packed_info (a ballot over the last 64 rays; it walks further back only over rays without samples).  The
+// loss VALUES are reports: their per-ray terms are left in memory for the caller to sum when somebody asks.  Same arithmetic,
+// expression by expression, as composite_fwd_kernel (Team<64>) -> geo_loss_kernel / app_loss_kernel -> composite_bwd_kernel;
+// the last chunk of the forward loop is the first of the backward loop and stays in registers.
+struct HeadLoss {
+    const float* gt;            // geometry: distances [R]; colour: colours [R, 3]
+    const float* noise;         // geometry: U[0,1) per ray or NULL
+    const float* bg;            // colour: background [R, 3] or NULL
+    const float* ratio_dev;     // geometry: the distortion-loss ramp (device scalar) or NULL
+    float inv_bs;               // 1 / global batch (colour: 1 / (3 global batch))
+    float w0;                   // depth_weight (colour: color_weight)
+    float dist_w;
+    float loss_scale;
+    int data_parallel;
+};
+
+template <bool APP>
+__global__ __launch_bounds__(256) void train_head_kernel(const float* __restrict__ sig, const float* __restrict__ rgb,
+                                                         const float* __restrict__ ts, const float* __restrict__ te,
+                                                         const int32_t* __restrict__ packed, int64_t n_rays, HeadLoss hl,
+                                                         float* __restrict__ weights, float* __restrict__ trans,
+                                                         float* __restrict__ opacity, float* __restrict__ distance,
+                                                         float* __restrict__ color, float* __restrict__ terms,
+                                                         float* __restrict__ distloss, float* __restrict__ inv_n_out,
+                                                         float* __restrict__ d_sig, float* __restrict__ d_rgb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int64_t start = packed[2 * r];
+    const int cnt = packed[2 * r + 1];
+    const int n_chunks = (cnt + 63) / 64;
+    // ---- forward
+    float carry = 0.f;
+    float a_op = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
+    float cW = 0.f, cWM = 0.f, a_dl = 0.f;
+    float w_l = 0.f, T_l = 0.f, t0_l = 0.f, t1_l = 0.f, s_l = 0.f;       // the last chunk's sample of this lane
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < cnt;
+        float sd = 0.f, t0 = 0.f, t1 = 0.f, s = 0.f;
+        if (valid) { t0 = ts[start + i]; t1 = te[start + i]; s = sig[start + i]; sd = mul_rn(s, sub_rn(t1, t0)); }
+        const float ex = team_chunk_excl<64>(sd, lane, carry);
+        float w_dl = 0.f, T = 0.f;
+        if (valid) {
+            T = expf(-ex);
+            const float al = 1.0f - expf(-sd);
+            const float w = T * al;
+            w_dl = w;
+            weights[start + i] = w;
+            trans[start + i] = T;
+            a_op += w;
+            a_d += w * ((t0 + t1) * 0.5f);
+            if (rgb) {
+                a_r += w * rgb[3 * (start + i)];
+                a_g += w * rgb[3 * (start + i) + 1];
+                a_b += w * rgb[3 * (start + i) + 2];
+            }
+        }
+        if (!APP) {
+            const float m = (t0 + t1) * 0.5f, d = t1 - t0;
+            const float Wp = team_chunk_excl<64>(w_dl, lane, cW);
+            const float WMp = team_chunk_excl<64>(w_dl * m, lane, cWM);
+            if (valid) a_dl += d * w_dl * w_dl * (1.0f / 3.0f) + 2.0f * w_dl * (m * Wp - WMp);
+        }
+        w_l = w_dl; T_l = T; t0_l = t0; t1_l = t1; s_l = s;
+    }
+    if (!APP) a_dl = team_sum<64>(a_dl);
+    a_op = team_sum<64>(a_op); a_d = team_sum<64>(a_d);
+    if (rgb) { a_r = team_sum<64>(a_r); a_g = team_sum<64>(a_g); a_b = team_sum<64>(a_b); }
+    if (lane == 0) {
+        if (!APP) distloss[r] = a_dl;
+        opacity[r] = a_op;
+        distance[r] = a_d;
+        if (rgb && color) { color[3 * r] = a_r; color[3 * r + 1] = a_g; color[3 * r + 2] = a_b; }
+    }
+    // ---- the ray's loss head
+    float gop = 0.f, gd = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, dl_scale = 0.f;
+    if (!APP) {
+        const float op = a_op;
+        const float nz = hl.noise ? (hl.noise[r] * 2.0f - 1.0f) : 0.0f;
+        const float pre = a_d + nz * (1.0f - op);
+        const float d = fmaxf(pre, 0.0f);
+        const float diff = d - hl.gt[r];
+        gd = (pre > 0.0f) ? sl1_grad(diff, 1e-2f) * hl.inv_bs * hl.w0 * hl.loss_scale : 0.0f;
+        gop = -nz * gd;
+        if (lane == 0) terms[r] = sl1(diff, 1e-2f);
+        float inv_n = hl.inv_bs;
+        if (!hl.data_parallel) {                  // 1 / (last ray that holds a sample + 1)
+            float lastf = -1.f;
+            for (int64_t hi = n_rays; hi > 0; hi -= 64) {
+                const int64_t q = hi - 1 - lane;
+                const unsigned long long m = __ballot(q >= 0 && packed[2 * q + 1] > 0);
+                if (m) { lastf = (float)(hi - 1 - __builtin_ctzll(m)); break; }
+            }
+            inv_n = 1.0f / (lastf + 1.0f > 0.f ? lastf + 1.0f : 1.0f);
+        }
+        const float ratio = hl.ratio_dev ? hl.ratio_dev[0] : 1.0f;
+        dl_scale = inv_n * hl.dist_w * ratio * hl.loss_scale;
+        if (r == 0 && lane == 0 && inv_n_out) inv_n_out[0] = inv_n;
+    } else {
+        const float om = 1.0f - a_op;
+        const float acc[3] = {a_r, a_g, a_b};
+        float g[3], term = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float c = acc[k] + (hl.bg ? hl.bg[3 * r + k] : 0.0f) * om;
+            const float diff = c - hl.gt[3 * r + k];
+            term += sl1(diff, 5e-2f);
+            g[k] = sl1_grad(diff, 5e-2f) * hl.inv_bs * hl.w0 * hl.loss_scale;
+        }
+        gc0 = g[0]; gc1 = g[1]; gc2 = g[2];
+        if (lane == 0) terms[r] = term;
+    }
+    if (cnt == 0) return;
+    // ---- backward (composite_bwd_kernel; geometry: with the distortion-loss gradient formed here, colour: d rgb only)
+    const float totW = a_op, totWM = a_d;
+    float sufW = 0.f, sufWM = 0.f, bcarry = 0.f;
+    for (int q = n_chunks - 1; q >= 0; --q) {
+        const int i = q * 64 + lane;
+        const bool valid = i < cnt;
+        float w = 0.f, T = 0.f, t0 = 0.f, t1 = 0.f, s = 0.f;
+        if (q == n_chunks - 1) { w = w_l; T = T_l; t0 = t0_l; t1 = t1_l; s = s_l; }
+        else if (valid) { w = weights[start + i]; T = trans[start + i]; t0 = ts[start + i]; t1 = te[start + i]; s = sig[start + i]; }
+        if (APP) {
+            if (valid) { d_rgb[3 * (start + i)] = w * gc0; d_rgb[3 * (start + i) + 1] = w * gc1; d_rgb[3 * (start + i) + 2] = w * gc2; }
+            continue;
+        }
+        float G = 0.f;
+        if (valid) G = gop + gd * ((t0 + t1) * 0.5f);
+        {
+            const float m = (t0 + t1) * 0.5f, wm = w * m;
+            float sw = w, swm = wm;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float y0 = __shfl_down(sw, off), y1 = __shfl_down(swm, off);
+                if (lane + off < 64) { sw += y0; swm += y1; }
+            }
+            const float Wsuf = sufW + (sw - w), WMsuf = sufWM + (swm - wm);
+            const float W = totW - Wsuf - w, WM = totWM - WMsuf - wm;
+            if (valid) G += dl_scale * ((2.0f / 3.0f) * (t1 - t0) * w + 2.0f * (m * (W - Wsuf) - (WM - WMsuf)));
+            sufW += __shfl(sw, 0); sufWM += __shfl(swm, 0);
+        }
+        const float qv = G * w;
+        float suf = qv;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float y = __shfl_down(suf, off);
+            if (lane + off < 64) suf += y;
+        }
+        const float later = bcarry + (suf - qv);
+        if (valid) {
+            const float delta = t1 - t0;
+            d_sig[start + i] = delta * ((G * T) * expf(-s * delta) - later);
+        }
+        bcarry += __shfl(suf, 0);
+    }
+}
+
 }  // namespace perf
 
 extern "C" int perf_geo_loss(const float* opacity, const float* distance, const float* gt_distance, const float* noise,
@@ -894,5 +1057,38 @@ extern "C" int perf_app_loss(const float* opacity, const float* color, const flo
                        n_rays, inv_n, color_weight, loss_scale, g_color, scalars);
     hipLaunchKernelGGL(perf::app_loss_final_kernel, dim3(1), dim3(64), 0, perf::as_stream(stream), nb, inv_n, scalars);
     PERF_LAUNCH_CHECK("perf_app_loss");
+    return PERF_OK;
+}
+
+extern "C" int perf_train_head_geo(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+                                   const int32_t* packed_info, int64_t n_rays, const float* gt_distance, const float* noise,
+                                   int64_t global_batch, float depth_weight, float distortion_weight, const float* ratio_dev,
+                                   float loss_scale, float* weights, float* trans, float* opacity, float* distance, float* color,
+                                   float* depth_terms, float* distloss_per_ray, float* inv_n_out, float* d_sigmas, void* stream) {
+    PERF_REQUIRE(n_rays > 0 && global_batch > 0, "perf_train_head_geo: empty batch");
+    PERF_REQUIRE(sigmas && t_starts && t_ends && packed_info && gt_distance && weights && trans && opacity && distance && depth_terms &&
+                 distloss_per_ray && d_sigmas, "NULL pointer");
+    PERF_REQUIRE(!rgbs || color, "perf_train_head_geo: rgbs without a colour output");
+    perf::HeadLoss hl{gt_distance, noise, nullptr, ratio_dev, 1.0f / (float)global_batch, depth_weight, distortion_weight, loss_scale,
+                      (int)(n_rays != global_batch)};
+    hipLaunchKernelGGL(perf::train_head_kernel<false>, ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
+                       t_ends, packed_info, n_rays, hl, weights, trans, opacity, distance, color, depth_terms, distloss_per_ray, inv_n_out,
+                       d_sigmas, (float*)nullptr);
+    PERF_LAUNCH_CHECK("perf_train_head_geo");
+    return PERF_OK;
+}
+
+extern "C" int perf_train_head_app(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+                                   const int32_t* packed_info, int64_t n_rays, const float* bg_color, const float* gt_color,
+                                   int64_t global_batch, float color_weight, float loss_scale, float* weights, float* trans,
+                                   float* opacity, float* distance, float* color, float* color_terms, float* d_rgbs, void* stream) {
+    PERF_REQUIRE(n_rays > 0 && global_batch > 0, "perf_train_head_app: empty batch");
+    PERF_REQUIRE(sigmas && rgbs && t_starts && t_ends && packed_info && gt_color && weights && trans && opacity && distance && color &&
+                 color_terms && d_rgbs, "NULL pointer");
+    perf::HeadLoss hl{gt_color, nullptr, bg_color, nullptr, 1.0f / (float)(global_batch * 3), color_weight, 0.0f, loss_scale, 0};
+    hipLaunchKernelGGL(perf::train_head_kernel<true>, ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
+                       t_ends, packed_info, n_rays, hl, weights, trans, opacity, distance, color, color_terms, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, d_rgbs);
+    PERF_LAUNCH_CHECK("perf_train_head_app");
     return PERF_OK;
 }

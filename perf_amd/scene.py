@@ -77,6 +77,24 @@ def _graph_node_count(graph):
 OVERFLOW_CHECK_EVERY = 64      # training steps between reads of the fixed-point overflow flag (one host sync each)
 
 
+class _Losses(dict):
+    """last_losses of a scene: an entry may be a thunk (the fused steps leave per-ray loss terms on the device and sum them
+    only when somebody reads the value); reading evaluates it."""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        return v() if callable(v) else v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
 @dataclass
 class Rays:
     """utils/camera_utils.py:9-21"""
@@ -388,7 +406,7 @@ class NeRFScene:
         self.global_iter_step_geo = 0
         self.global_iter_step_app = 0
         self.loss_scale = 2.0 ** 7
-        self.last_losses = {}
+        self.last_losses = _Losses()
         self._capturing = False
         self.fused_steps = True        # explicit kernel chains for the two training steps (False: autograd formulation)
         # The reference's geometry step renders colours (query key 'rgb', nerf.py:197-201) that no loss term of that step
@@ -952,16 +970,18 @@ class NeRFScene:
         # MLP + accumulation run on the compute stream while RCCL moves the gradient over xGMI on its own stream.
         defer_color = (dist_info[0] is not None and self.overlap_comm and not self.skip_unused_color and st['rgbs'] is None)
         rgbs = None if (self.skip_unused_color or defer_color) else (st['rgbs'] if st['rgbs'] is not None else self.nerf.rgb_at(x01, sel, n_dev))
-        w, T, op, dist_r, col, dl = ops.composite_distloss_fwd(sig.view(-1), rgbs, ts, te, packed)
-        if rgbs is not None:
-            self.last_colors = col           # the step's (unused) colour render, [n_rays, 3]
         noise = rand['noise']            # (the background colour the reference also draws, :185, is not used by this step)
         if not self._capturing and getattr(optimizer, 'sched_table', None) is None:
             self._ratio_dev.fill_(float(np.min([progress * 2., 1])))
-        g_op, g_dist, sc = ops.geo_loss(op, dist_r, gt_depths, noise, dl, packed, bs, tc.depth_loss_weight,
-                                        tc.distortion_loss_weight, self._ratio_dev, self.loss_scale)
-        dsig = ops.composite_distloss_bwd(sig.view(-1), ts, te, packed, w, T, op, dist_r, g_op, g_dist, 1.0, scale_dev=sc[2:3])
-        self.last_losses['depth_loss'] = sc[0]; self.last_losses['dist_loss'] = sc[1]
+        # compositing forward -> loss head -> compositing backward: ONE launch, a wavefront per ray (perf_train_head_geo)
+        hd = ops.train_head_geo(sig.view(-1), rgbs, ts, te, packed, gt_depths, noise, bs, tc.depth_loss_weight, tc.distortion_loss_weight,
+                                self._ratio_dev, self.loss_scale)
+        w, dsig = hd['weights'], hd['d_sigma']
+        if rgbs is not None:
+            self.last_colors = hd['color']   # the step's (unused) colour render, [n_rays, 3]
+        # (the loss VALUES are reports: summed from the per-ray terms when somebody reads them)
+        self.last_losses['depth_loss'] = lambda t=hd['depth_terms'], s=1.0 / bs: t.sum() * s
+        self.last_losses['dist_loss'] = lambda t=hd['distloss_per_ray'], s=hd['inv_n']: t.sum() * s[0]
 
         def color_now():
             self.last_colors = ops.accumulate_fwd(w, self.nerf.rgb_at(x01, sel, n_dev), packed)
@@ -1026,18 +1046,18 @@ class NeRFScene:
         w16 = app.working_copy()
         feat = ops.hashgrid_fwd(app.grid, x01, w16[n_net:], n_dev=n_dev)
         rgbs = ops.mlp_fwd(app.mlp, w16[:n_net], feat, sel, n_dev=n_dev)
-        w, T, _, op, dist_r, col = ops.composite_fwd(sig.reshape(-1).contiguous(), rgbs, ts, te, packed)
-        n_rays = op.shape[0]
+        n_rays = packed.shape[0]
         bg = None
         if self.renderer.bg_color == 'rand_noise':
-            bg = rand['bg'] if 'bg' in rand else self._rand_cols(n_rays, 3, dist_info, op.device)
+            bg = rand['bg'] if 'bg' in rand else self._rand_cols(n_rays, 3, dist_info, x01.device)
         elif self.renderer.bg_color == 'white':
-            bg = torch.ones(n_rays, 3, device=op.device)
+            bg = torch.ones(n_rays, 3, device=x01.device)
         if 'noise' not in rand:
-            self._rand_cols(n_rays, 1, dist_info, op.device)      # the distance noise draw of :193 (unused by this loss)
-        g_col, sc = ops.app_loss(op, col, bg, gt_colors, bs, tc.color_loss_weight, self.loss_scale)
-        _, drgb = ops.composite_bwd(sig.reshape(-1).contiguous(), ts, te, packed, w, T, g_color=g_col, want_dsigma=False, want_drgb=True)
-        self.last_losses['color_loss'] = sc[0]
+            self._rand_cols(n_rays, 1, dist_info, x01.device)      # the distance noise draw of :193 (unused by this loss)
+        # compositing forward -> colour loss -> compositing backward: ONE launch (perf_train_head_app)
+        hd = ops.train_head_app(sig.reshape(-1).contiguous(), rgbs, ts, te, packed, bg, gt_colors, bs, tc.color_loss_weight, self.loss_scale)
+        drgb = hd['d_rgb']
+        self.last_losses['color_loss'] = lambda t=hd['color_terms'], s=1.0 / (3 * bs): t.sum() * s
         if sharded:
             self._dp_sharded_step(app, optimizer, dist_info, x01, w16, feat, sel, drgb, n_dev, st['n_marched_dev'])
             self.global_iter_step_app += 1

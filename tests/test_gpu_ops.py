@@ -1140,3 +1140,56 @@ def test_lane_per_ray_marching_of_large_shared_lattice_launches_equals_wave_per_
                 assert torch.equal(ts, ts_a[lo * K:hi * K]) and torch.equal(te, te_a[lo * K:hi * K]) and torch.equal(sel, s_a[lo * K:hi * K])
                 assert torch.equal(x01, x_a[lo * K:hi * K]) and torch.equal(pk[:, 1], pk_a[lo:hi, 1]) and torch.equal(ri + lo, ri_a[lo * K:hi * K])
             assert int(c_all.sum()) > 100000
+
+
+@pytest.mark.parametrize('tail_empty,data_parallel', [(False, False), (True, False), (False, True)])
+def test_train_head_in_one_launch_equals_the_three_launch_chains(ops, tail_empty, data_parallel):
+    """perf_train_head_geo / _app (compositing forward -> loss head -> compositing backward, one wavefront per ray, ONE launch)
+    against the chains they replace, on rays of 0 / 1 / 64 / 65 / up to 200 samples: every per-sample and per-ray output and the
+    gradient the field backward starts from bit for bit; the loss values (now summed by the reader from per-ray terms) to
+    summation order.  tail_empty: the last rays hold no sample (flatten_eff_distloss's normaliser is the last ray that does)."""
+    packed, ri, ts, te, sig, rgb = _packed_case(21)
+    R = packed.shape[0]
+    if tail_empty:          # rays R-70.. lose their samples: the normaliser sits more than one ballot back from the end
+        keep = R - 70
+        S = int(packed[keep, 0])
+        packed = packed.clone(); packed[keep:, 1] = 0; packed[keep:, 0] = S
+        ts, te, sig, rgb = ts[:S], te[:S], sig[:S], rgb[:S]
+    c = lambda t: t.cuda().contiguous()
+    g = torch.Generator().manual_seed(22)
+    gt_d = torch.rand(R, generator=g) * 1.5; noise = torch.rand(R, generator=g)
+    gt_c = torch.rand(R, 3, generator=g); bg = torch.rand(R, 3, generator=g)
+    ratio = torch.tensor([0.6], device='cuda')
+    bs = 4 * R if data_parallel else R
+    # ---- geometry
+    w, T, op, dist, col, dl = ops.composite_distloss_fwd(c(sig), c(rgb), c(ts), c(te), c(packed))
+    g_op, g_d, sc = ops.geo_loss(op, dist, c(gt_d), c(noise), dl, c(packed), bs, 1.0, 0.5, ratio, 128.0)
+    ds = ops.composite_distloss_bwd(c(sig), c(ts), c(te), c(packed), w, T, op, dist, g_op, g_d, 1.0, scale_dev=sc[2:3])
+    hd = ops.train_head_geo(c(sig), c(rgb), c(ts), c(te), c(packed), c(gt_d), c(noise), bs, 1.0, 0.5, ratio, 128.0)
+    for a, b, name in ((w, hd['weights'], 'w'), (T, hd['trans'], 'T'), (op, hd['opacity'], 'op'), (dist, hd['distance'], 'dist'),
+                       (col, hd['color'], 'col'), (dl, hd['distloss_per_ray'], 'dl'), (ds, hd['d_sigma'], 'd_sigma')):
+        assert torch.equal(a, b), name
+    depth = hd['depth_terms'].sum() / bs
+    dloss = hd['distloss_per_ray'].sum() * hd['inv_n'][0]
+    assert abs(float(depth) - float(sc[0])) <= 1e-5 * abs(float(sc[0]))
+    assert abs(float(dloss) - float(sc[1])) <= 1e-5 * abs(float(sc[1]))
+    last = int(torch.nonzero(packed[:, 1] > 0).max())
+    assert float(hd['inv_n'][0]) == (np.float32(1.0) / np.float32(bs if data_parallel else last + 1))
+    # without noise / ramp / colour
+    hd0 = ops.train_head_geo(c(sig), None, c(ts), c(te), c(packed), c(gt_d), None, bs, 1.0, 0.5, None, 128.0)
+    g_op0, g_d0, sc0 = ops.geo_loss(op, dist, c(gt_d), None, dl, c(packed), bs, 1.0, 0.5, None, 128.0)
+    ds0 = ops.composite_distloss_bwd(c(sig), c(ts), c(te), c(packed), w, T, op, dist, g_op0, g_d0, 1.0, scale_dev=sc0[2:3])
+    assert torch.equal(ds0, hd0['d_sigma']) and hd0['color'] is None
+    # ---- colour
+    w, T, _, op, dist, col = ops.composite_fwd(c(sig), c(rgb), c(ts), c(te), c(packed))
+    for bgc in (c(bg), None):
+        g_col, sca = ops.app_loss(op, col, bgc, c(gt_c), bs, 1.0, 128.0)
+        _, drgb = ops.composite_bwd(c(sig), c(ts), c(te), c(packed), w, T, g_color=g_col, want_dsigma=False, want_drgb=True)
+        ha = ops.train_head_app(c(sig), c(rgb), c(ts), c(te), c(packed), bgc, c(gt_c), bs, 1.0, 128.0)
+        for a, b, name in ((w, ha['weights'], 'w'), (T, ha['trans'], 'T'), (op, ha['opacity'], 'op'), (dist, ha['distance'], 'dist'),
+                           (col, ha['color'], 'col')):
+            assert torch.equal(a, b), name
+        live = int(packed[:, 1].sum())
+        assert torch.equal(drgb[:live], ha['d_rgb'][:live])
+        closs = ha['color_terms'].sum() / (3 * bs)
+        assert abs(float(closs) - float(sca[0])) <= 1e-5 * abs(float(sca[0]))
