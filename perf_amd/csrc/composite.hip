@@ -902,6 +902,19 @@ __global__ __launch_bounds__(256) void train_head_kernel(const float* __restrict
     const int64_t start = packed[2 * r];
     const int cnt = packed[2 * r + 1];
     const int n_chunks = (cnt + 63) / 64;
+    // what the loss head reads is requested NOW: the kernel is a chain of dependent round trips (packed_info -> samples ->
+    // loss inputs -> backward) for a few samples per ray, and these do not depend on the forward pass
+    float in_noise = 0.f, in_gt[3] = {0.f, 0.f, 0.f}, in_bg[3] = {0.f, 0.f, 0.f}, in_ratio = 1.0f;
+    int in_tail = 0;              // sample count of ray n_rays - 1 - lane: the first ballot of the search for the last ray with samples
+    if (!APP) {
+        if (hl.noise) in_noise = hl.noise[r];
+        in_gt[0] = hl.gt[r];
+        if (hl.ratio_dev) in_ratio = hl.ratio_dev[0];
+        if (!hl.data_parallel && n_rays - 1 - lane >= 0) in_tail = packed[2 * (n_rays - 1 - lane) + 1];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { in_gt[k] = hl.gt[3 * r + k]; if (hl.bg) in_bg[k] = hl.bg[3 * r + k]; }
+    }
     // ---- forward
     float carry = 0.f;
     float a_op = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
@@ -950,24 +963,27 @@ __global__ __launch_bounds__(256) void train_head_kernel(const float* __restrict
     float gop = 0.f, gd = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, dl_scale = 0.f;
     if (!APP) {
         const float op = a_op;
-        const float nz = hl.noise ? (hl.noise[r] * 2.0f - 1.0f) : 0.0f;
+        const float nz = hl.noise ? (in_noise * 2.0f - 1.0f) : 0.0f;
         const float pre = a_d + nz * (1.0f - op);
         const float d = fmaxf(pre, 0.0f);
-        const float diff = d - hl.gt[r];
+        const float diff = d - in_gt[0];
         gd = (pre > 0.0f) ? sl1_grad(diff, 1e-2f) * hl.inv_bs * hl.w0 * hl.loss_scale : 0.0f;
         gop = -nz * gd;
         if (lane == 0) terms[r] = sl1(diff, 1e-2f);
         float inv_n = hl.inv_bs;
         if (!hl.data_parallel) {                  // 1 / (last ray that holds a sample + 1)
             float lastf = -1.f;
-            for (int64_t hi = n_rays; hi > 0; hi -= 64) {
-                const int64_t q = hi - 1 - lane;
-                const unsigned long long m = __ballot(q >= 0 && packed[2 * q + 1] > 0);
+            unsigned long long m = __ballot(in_tail > 0);
+            for (int64_t hi = n_rays; ; ) {
                 if (m) { lastf = (float)(hi - 1 - __builtin_ctzll(m)); break; }
+                hi -= 64;
+                if (hi <= 0) break;
+                const int64_t q = hi - 1 - lane;
+                m = __ballot(q >= 0 && packed[2 * q + 1] > 0);
             }
             inv_n = 1.0f / (lastf + 1.0f > 0.f ? lastf + 1.0f : 1.0f);
         }
-        const float ratio = hl.ratio_dev ? hl.ratio_dev[0] : 1.0f;
+        const float ratio = in_ratio;
         dl_scale = inv_n * hl.dist_w * ratio * hl.loss_scale;
         if (r == 0 && lane == 0 && inv_n_out) inv_n_out[0] = inv_n;
     } else {
@@ -976,8 +992,8 @@ __global__ __launch_bounds__(256) void train_head_kernel(const float* __restrict
         float g[3], term = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float c = acc[k] + (hl.bg ? hl.bg[3 * r + k] : 0.0f) * om;
-            const float diff = c - hl.gt[3 * r + k];
+            const float c = acc[k] + (hl.bg ? in_bg[k] : 0.0f) * om;
+            const float diff = c - in_gt[k];
             term += sl1(diff, 5e-2f);
             g[k] = sl1_grad(diff, 5e-2f) * hl.inv_bs * hl.w0 * hl.loss_scale;
         }

@@ -701,46 +701,36 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t* __r
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(256) void scan_sums_kernel(int64_t* __restrict__ sums, int64_t n_blocks, int64_t* __restrict__ total_out,
-                                                        int64_t bias, int64_t* __restrict__ total_biased) {
-    // single block; sequential over chunks of 256 block sums (n_blocks is small)
-    __shared__ int64_t carry_s;
-    __shared__ int64_t buf[256];
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t c0 = 0; c0 < n_blocks; c0 += 256) {
-        const int64_t i = c0 + threadIdx.x;
-        buf[threadIdx.x] = (i < n_blocks) ? sums[i] : 0;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int64_t run = carry_s;
-            for (int k = 0; k < 256; ++k) { int64_t v = buf[k]; buf[k] = run; run += v; }
-            carry_s = run;
-        }
-        __syncthreads();
-        if (i < n_blocks) sums[i] = buf[threadIdx.x];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        *total_out = carry_s;
-        if (total_biased) *total_biased = carry_s + bias;
-    }
-}
-
+// Second (and last) launch of the large scan: block b adds up the sums of the blocks before it itself (at most a few thousand
+// 8-byte values from L2 -- a third launch that scans them cost 7.4 us, twice per 512x1024 frame), then scans its own 1024
+// elements; the last block leaves the total.
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
-                                                         const int64_t* __restrict__ sums) {
+                                                         const int64_t* __restrict__ sums, int64_t* __restrict__ total_out,
+                                                         int64_t bias, int64_t* __restrict__ total_biased) {
     __shared__ int lds4[4];
+    __shared__ long long pre4[4];
+    long long before = 0;
+    for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += 256) before += sums[j];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off);
+    if ((threadIdx.x & 63) == 0) pre4[threadIdx.x >> 6] = before;
     const int64_t base = (int64_t)blockIdx.x * kScanBlock + threadIdx.x * 4;
     int v[4];
     int s = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
     int total;
-    int ex = block_excl_scan(s, lds4, &total) + (int)sums[blockIdx.x];
+    const int ex0 = block_excl_scan(s, lds4, &total);       // (its barriers order pre4 as well)
+    const long long prefix = (pre4[0] + pre4[1]) + (pre4[2] + pre4[3]);
+    int ex = ex0 + (int)prefix;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (base + k < n) out[base + k] = ex;
         ex += v[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        *total_out = prefix + total;
+        if (total_biased) *total_biased = prefix + total + bias;
     }
 }
 
@@ -912,8 +902,8 @@ extern "C" int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t*
     const int64_t nb = div_up(n, kScanBlock);
     int64_t* sums = (int64_t*)workspace;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), in, n, sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, as_stream(stream), sums, nb, total, total_bias, total_biased);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), in, out, n, sums);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), in, out, n, sums, total, total_bias,
+                       total_biased);
     PERF_LAUNCH_CHECK("perf_exclusive_scan_i32");
     return PERF_OK;
 }
