@@ -35,7 +35,13 @@ struct MlpParams {
 };
 
 constexpr int kTile = 32;      // samples per wave tile
-constexpr int kPitch = 40;     // 16-bit elements per LDS transpose row (32 samples + pad, 16-B aligned)
+// LDS tiles of the backward pass: [sample][channel position], kPitchT 16-bit elements per sample row (64 channels + pad: the
+// four sample rows one transposing read touches then fall on disjoint banks).  A lane WRITES the eight channels of a k-step it
+// holds for its sample with one 16-byte store; the weight-gradient products READ them channel-major -- eight consecutive
+// samples of one channel per lane -- with ds_read_b64_tr_b16 (two per operand).  Round 4 stored the tiles channel-major with
+// 2-byte stores: 152 of the ~200 LDS instructions per tile of the colour network, and the LDS pipe was the busiest unit of the
+// kernel (SQ_ACTIVE_INST_LDS: 78 % of the density network's backward).
+constexpr int kPitchT = 80;
 
 __device__ __forceinline__ int slot_neuron(int s, int h, int j) {
     return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
@@ -132,18 +138,32 @@ __device__ __forceinline__ float relu(float x) {
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
+// ReLU masks of the backward pass come from the PACKED activations themselves (what tcnn's backward does too: it masks with the
+// stored 16-bit forward activation): a post-ReLU 16-bit value is non-negative, so "active" is "bits != 0", and a pair of them
+// turns into a pair of 0xffff / 0 half-word masks with two packed 16-bit instructions (negate, arithmetic shift by 15).  Rounds 1-4 kept the
+// masks of the last hidden layer as 32 wave predicates (64 scalar registers: more than the file holds beside everything else --
+// the kernel spilled them to vector lanes, ~400 v_readlane / v_writelane in the colour network's loop) and those of the layer
+// before as a per-lane bit field (a compare, a select and an or per element to build, an and, a compare and a select to apply).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t nonzero_halves(uint32_t packed) {      // (halves in [0, 0x7fff]: 0 - x is negative iff x != 0)
+    const s16x2 t = (s16x2){0, 0} - __builtin_bit_cast(s16x2, packed);
+    return __builtin_bit_cast(uint32_t, (s16x2)(t >> (s16x2){15, 15}));
+}
 template <typename T16>
-__device__ __forceinline__ void relu_pack(const f32x16& acc, u32x4& lo, u32x4& hi, uint32_t& mask_bits, int shift) {
-    // regs 0..7 -> k-step t=0, regs 8..15 -> t=1.  mask bit (shift+r) = acc[r] > 0
+__device__ __forceinline__ void relu_pack_plain(const f32x16& acc, u32x4& lo, u32x4& hi) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float a = acc[2 * i], b = acc[2 * i + 1], c = acc[8 + 2 * i], d = acc[8 + 2 * i + 1];
-        lo[i] = T16::pack(relu(a), relu(b));
-        hi[i] = T16::pack(relu(c), relu(d));
-        mask_bits |= (a > 0.f ? 1u : 0u) << (shift + 2 * i);
-        mask_bits |= (b > 0.f ? 1u : 0u) << (shift + 2 * i + 1);
-        mask_bits |= (c > 0.f ? 1u : 0u) << (shift + 8 + 2 * i);
-        mask_bits |= (d > 0.f ? 1u : 0u) << (shift + 8 + 2 * i + 1);
+        lo[i] = T16::pack(relu(acc[2 * i]), relu(acc[2 * i + 1]));
+        hi[i] = T16::pack(relu(acc[8 + 2 * i]), relu(acc[8 + 2 * i + 1]));
+    }
+}
+// pack d where the forward activation (same rows, same lanes: hlo / hhi) is active
+template <typename T16>
+__device__ __forceinline__ void pack_active(const f32x16& d, const u32x4& hlo, const u32x4& hhi, u32x4& lo, u32x4& hi) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] = T16::pack(d[2 * i], d[2 * i + 1]) & nonzero_halves(hlo[i]);
+        hi[i] = T16::pack(d[8 + 2 * i], d[8 + 2 * i + 1]) & nonzero_halves(hhi[i]);
     }
 }
 
@@ -199,14 +219,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16
     // the layers and the store of one tile, given the packed first-layer operand
     auto layers = [&](int64_t si, bool valid, const u32x4 (&b1)[KS], float sv) __attribute__((always_inline)) {
         f32x16 acc[2];
-        uint32_t mask_unused = 0;
         u32x4 hb[4];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             acc[m] = f32x16{0};
 #pragma unroll
             for (int s = 0; s < KS; ++s) acc[m] = T16::mfma(frag[(L::f_a1 + m * KS + s) * 64 + lane], b1[s], acc[m]);
-            relu_pack<T16>(acc[m], hb[2 * m], hb[2 * m + 1], mask_unused, 0);
+            relu_pack_plain<T16>(acc[m], hb[2 * m], hb[2 * m + 1]);
         }
         if constexpr (NH == 2) {
             u32x4 hb2[4];
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16
                 acc[m] = f32x16{0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc[m] = T16::mfma(frag[(L::f_a2 + m * 4 + s) * 64 + lane], hb[s], acc[m]);
-                relu_pack<T16>(acc[m], hb2[2 * m], hb2[2 * m + 1], mask_unused, 0);
+                relu_pack_plain<T16>(acc[m], hb2[2 * m], hb2[2 * m + 1]);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
@@ -326,64 +345,44 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams mp, const uint16
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-// scatter a packed B-fragment set (4 k-steps x 4 dwords: the 32 channels this lane owns of a
-// 64-channel tensor) into the [channel][sample] LDS transpose tile
+// a packed B-fragment set (4 k-steps x 4 dwords: the 32 channels this lane owns of a 64-channel tensor, for its sample c) ->
+// row c of the [sample][channel position] tile; channel POSITION p = 16 s + 8 h + j holds neuron slot_neuron(s, h, j)
 __device__ __forceinline__ void lds_put_hidden(uint16_t* tile, const u32x4 fr[4], int c, int h) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = slot_neuron(s, h, 2 * i);
-            tile[ch * kPitch + c] = (uint16_t)(fr[s][i] & 0xffffu);
-            tile[(ch + 1) * kPitch + c] = (uint16_t)(fr[s][i] >> 16);
-        }
+    for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4*>(tile + c * kPitchT + 16 * s + 8 * h) = fr[s];
 }
+__device__ __forceinline__ int position_neuron(int p) { return slot_neuron(p >> 4, (p >> 3) & 1, p & 7); }
 
-__device__ __forceinline__ u32x4 lds_get_frag(const uint16_t* tile, int row, int s, int h) {
-    return *reinterpret_cast<const u32x4*>(tile + row * kPitch + 16 * s + 8 * h);
+// ds_read_b64_tr_b16 (lane map measured with tools/exp/tr_probe.hip): within a group of 16 lanes, lane i receives element
+// (i & 3) of the 8 bytes addressed by lanes (i >> 2), (i >> 2) + 4, (i >> 2) + 8, (i >> 2) + 12 of the group.  With lane
+// 4 k + q of the group addressing &tile[sample s0 + k][channel c0 + 4 q], lane i receives channel c0 + i of samples s0 .. s0 + 3.
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 lds_tr8(const uint16_t* p) {       // samples s0 .. s0 + 7 of the lane's channel
+    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p));
+    const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * kPitchT)));
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
-
-template <typename T16>
-__device__ __forceinline__ void pack_masked(const f32x16& acc, uint32_t mask_bits, int shift, u32x4& lo, u32x4& hi) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float a = ((mask_bits >> (shift + 2 * i)) & 1u) ? acc[2 * i] : 0.f;
-        float b = ((mask_bits >> (shift + 2 * i + 1)) & 1u) ? acc[2 * i + 1] : 0.f;
-        float c = ((mask_bits >> (shift + 8 + 2 * i)) & 1u) ? acc[8 + 2 * i] : 0.f;
-        float d = ((mask_bits >> (shift + 8 + 2 * i + 1)) & 1u) ? acc[8 + 2 * i + 1] : 0.f;
-        lo[i] = T16::pack(a, b);
-        hi[i] = T16::pack(c, d);
-    }
+// Operand of a 32x32x16 product over samples 16 s16 .. + 15: lane (cl = lane & 31, h = lane >> 5) gets samples 16 s16 + 8 h .. + 7
+// of channel position 32 m + cl.  off32: the lane's part of the address (tr_offset32), computed once.
+__device__ __forceinline__ int tr_offset32(int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    return (8 * (g >> 1) + (i >> 2)) * kPitchT + 16 * (g & 1) + 4 * (i & 3);
 }
-
-// The same two steps with the ReLU mask of the LAST hidden layer held as sixteen predicates: an i1 that stays live is a wave
-// mask in an SGPR pair -- one v_cmp writes it, one v_cndmask reads it -- where the packed per-lane bit field costs a compare, a
-// select and an or to build and an and, a compare and a select to apply (six vector instructions per element instead of two;
-// the mask of the layer before lives too long for the scalar file and stays a bit field).
-template <typename T16>
-__device__ __forceinline__ void relu_pack_pred(const f32x16& acc, u32x4& lo, u32x4& hi, bool* pos) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pos[r] = acc[r] > 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        lo[i] = T16::pack(relu(acc[2 * i]), relu(acc[2 * i + 1]));
-        hi[i] = T16::pack(relu(acc[8 + 2 * i]), relu(acc[8 + 2 * i + 1]));
-    }
+__device__ __forceinline__ u32x4 lds_get_frag(const uint16_t* tile, int off32, int m, int s16) {
+    return lds_tr8(tile + off32 + 16 * s16 * kPitchT + 32 * m);
 }
-
-template <typename T16>
-__device__ __forceinline__ void pack_pred(const f32x16& acc, const bool* pos, u32x4& lo, u32x4& hi) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        lo[i] = T16::pack(pos[2 * i] ? acc[2 * i] : 0.f, pos[2 * i + 1] ? acc[2 * i + 1] : 0.f);
-        hi[i] = T16::pack(pos[8 + 2 * i] ? acc[8 + 2 * i] : 0.f, pos[8 + 2 * i + 1] ? acc[8 + 2 * i + 1] : 0.f);
-    }
+// Operand of a 16x16x32 product over the tile's 32 samples: lane (r16 = lane & 15, kb = lane >> 4) gets samples 8 kb .. + 7 of
+// channel position cbase + r16.
+__device__ __forceinline__ int tr_offset16(int lane) {
+    const int i = lane & 15;
+    return (8 * (lane >> 4) + (i >> 2)) * kPitchT + 4 * (i & 3);
 }
 
 // FAST (chosen by the launcher): every level slot of the first layer is a real level (n_levels == 8 * KS) and the level-major
 // offsets fit 32 bits -- the addressing above, and a FIXED number of loads per request (below).
 template <typename T16, int NH, int KS, bool FAST>
-__global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
+__global__ __launch_bounds__(256, (KS < 3) ? 2 : 1) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
                                                       const uint32_t* __restrict__ feat,
                                                       const int32_t* __restrict__ feat_index, int64_t feat_stride,
                                                       const uint8_t* __restrict__ sel,
@@ -396,8 +395,9 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* frag = reinterpret_cast<u32x4*>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint16_t* tA = reinterpret_cast<uint16_t*>(smem + L::n_all * 1024) + wave * (2 * 64 * kPitch);
-    uint16_t* tB = tA + 64 * kPitch;
+    uint16_t* tA = reinterpret_cast<uint16_t*>(smem + L::n_all * 1024) + wave * (2 * kTile * kPitchT);
+    uint16_t* tB = tA + kTile * kPitchT;
+    const int off32 = tr_offset32(lane), off16 = tr_offset16(lane);
     stage_fragments<NH, KS, true>(w, frag);
     __syncthreads();
     const int c = lane & 31, h = lane >> 5;
@@ -482,15 +482,12 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
         for (int s = 0; s < KS; ++s) b1[s] = cur.b1[s];
         f32x16 acc[2];
         u32x4 hb1[4], hb2[4];
-        uint32_t mask1 = 0;
-        bool pos[32];               // ReLU mask of the last hidden layer (wave masks)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             acc[m] = f32x16{0};
 #pragma unroll
             for (int s = 0; s < KS; ++s) acc[m] = T16::mfma(frag[(L::f_a1 + m * KS + s) * 64 + lane], b1[s], acc[m]);
-            if constexpr (NH == 2) relu_pack<T16>(acc[m], hb1[2 * m], hb1[2 * m + 1], mask1, 16 * m);
-            else relu_pack_pred<T16>(acc[m], hb1[2 * m], hb1[2 * m + 1], pos + 16 * m);
+            relu_pack_plain<T16>(acc[m], hb1[2 * m], hb1[2 * m + 1]);
         }
         if constexpr (NH == 2) {
 #pragma unroll
@@ -498,7 +495,7 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
                 acc[m] = f32x16{0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc[m] = T16::mfma(frag[(L::f_a2 + m * 4 + s) * 64 + lane], hb1[s], acc[m]);
-                relu_pack_pred<T16>(acc[m], hb2[2 * m], hb2[2 * m + 1], pos + 16 * m);
+                relu_pack_plain<T16>(acc[m], hb2[2 * m], hb2[2 * m + 1]);
             }
         }
         const u32x4* hlast = (NH == 2) ? hb2 : hb1;
@@ -529,11 +526,7 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
         // ---- the transposes of the output layer's weight gradient (dWo[16 x 64] += dY * Hlast^T) go to LDS FIRST: the
         //      products below do not need them and cover the round trip
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {   // dY rows d_row(2i,h), d_row(2i+1,h) -> tile A rows 0..15
-            tA[d_row(2 * i, h) * kPitch + c] = (uint16_t)(dyb[i] & 0xffffu);
-            tA[d_row(2 * i + 1, h) * kPitch + c] = (uint16_t)(dyb[i] >> 16);
-        }
+        *reinterpret_cast<u32x4*>(tA + c * kPitchT + 8 * h) = dyb;     // position 8 h + j holds output row d_row(j, h)
         lds_put_hidden(tB, hlast, c, h);
         __builtin_amdgcn_wave_barrier();
         // ---- dH_last = Wo^T dY, masked
@@ -541,15 +534,13 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             f32x16 d = T16::mfma(frag[(L::f_aot + m) * 64 + lane], dyb, f32x16{0});
-            pack_pred<T16>(d, pos + 16 * m, dhl[2 * m], dhl[2 * m + 1]);
+            pack_active<T16>(d, hlast[2 * m], hlast[2 * m + 1], dhl[2 * m], dhl[2 * m + 1]);
         }
         __builtin_amdgcn_wave_barrier();
         {   // operands of the 16x16x32 form: lane (row lane & 15, k-block lane >> 4) holds samples 8 * (lane >> 4) .. + 7
-            const int r16 = lane & 15, kb = lane >> 4;
-            const u32x4 a = *reinterpret_cast<const u32x4*>(tA + r16 * kPitch + 8 * kb);
+            const u32x4 a = lds_tr8(tA + off16);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                gWo[nb] = T16::mfma16(a, *reinterpret_cast<const u32x4*>(tB + (16 * nb + r16) * kPitch + 8 * kb), gWo[nb]);
+            for (int nb = 0; nb < 4; ++nb) gWo[nb] = T16::mfma16(a, lds_tr8(tB + off16 + 16 * nb), gWo[nb]);
         }
         u32x4 dh1[4];
         if constexpr (NH == 2) {
@@ -559,7 +550,7 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
                 f32x16 d = f32x16{0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) d = T16::mfma(frag[(L::f_a2t + m * 4 + s) * 64 + lane], dhl[s], d);
-                pack_masked<T16>(d, mask1, 16 * m, dh1[2 * m], dh1[2 * m + 1]);
+                pack_active<T16>(d, hb1[2 * m], hb1[2 * m + 1], dh1[2 * m], dh1[2 * m + 1]);
             }
             // ---- dW2[64 x 64] += dH2 * H1^T
             __builtin_amdgcn_wave_barrier();
@@ -567,14 +558,15 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
             lds_put_hidden(tB, hb1, c, h);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s) {
+                const u32x4 b0 = lds_get_frag(tB, off32, 0, s), b1t = lds_get_frag(tB, off32, 1, s);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    u32x4 a = lds_get_frag(tA, 32 * m + c, s, h);
-#pragma unroll
-                    for (int nn = 0; nn < 2; ++nn)
-                        gW2[2 * m + nn] = T16::mfma(a, lds_get_frag(tB, 32 * nn + c, s, h), gW2[2 * m + nn]);
+                    const u32x4 a = lds_get_frag(tA, off32, m, s);
+                    gW2[2 * m] = T16::mfma(a, b0, gW2[2 * m]);
+                    gW2[2 * m + 1] = T16::mfma(a, b1t, gW2[2 * m + 1]);
                 }
+            }
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) dh1[s] = dhl[s];
@@ -583,13 +575,8 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
         __builtin_amdgcn_wave_barrier();
         lds_put_hidden(tA, dh1, c, h);
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ch = 2 * (8 * s + 2 * i + h);
-                tB[ch * kPitch + c] = (uint16_t)(b1[s][i] & 0xffffu);
-                tB[(ch + 1) * kPitch + c] = (uint16_t)(b1[s][i] >> 16);
-            }
+        for (int s = 0; s < KS; ++s)       // position 16 s + 8 h + j holds input feature 2 (8 s + 2 (j >> 1) + h) + (j & 1)
+            *reinterpret_cast<u32x4*>(tB + c * kPitchT + 16 * s + 8 * h) = b1[s];
         __builtin_amdgcn_wave_barrier();
         // ---- dX = W1^T dH1 (rows = input features in natural order 2*level+feat)
         if (FAST || dfeat != nullptr) {         // (the launcher sends a call without dfeat to the kernel without FAST)
@@ -625,9 +612,10 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int nb = 0; nb < MB; ++nb) {
-                u32x4 b = (32 * nb + c < L::n_in_pad) ? lds_get_frag(tB, 32 * nb + c, s, h) : u32x4{0, 0, 0, 0};
+                u32x4 b = lds_get_frag(tB, off32, nb, s);            // (every lane takes part in the transposing read)
+                if (32 * nb + c >= L::n_in_pad) b = u32x4{0, 0, 0, 0};
 #pragma unroll
-                for (int m = 0; m < 2; ++m) gW1[m * MB + nb] = T16::mfma(lds_get_frag(tA, 32 * m + c, s, h), b, gW1[m * MB + nb]);
+                for (int m = 0; m < 2; ++m) gW1[m * MB + nb] = T16::mfma(lds_get_frag(tA, off32, m, s), b, gW1[m * MB + nb]);
             }
     };
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -704,7 +692,7 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
         }
         __syncthreads();
     }
-    static_assert(kAcc * 16 * 64 * 4 <= Layout<NH, KS>::n_all * 1024 + 4 * 2 * 64 * kPitch * 2, "reduction scratch exceeds LDS");
+    static_assert(kAcc * 16 * 64 * 4 <= Layout<NH, KS>::n_all * 1024 + 4 * 2 * kTile * kPitchT * 2, "reduction scratch exceeds LDS");
     if (wave != 0) return;
     float* p = partials + (int64_t)blockIdx.x * L::n_params;
 #pragma unroll
@@ -712,9 +700,10 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
 #pragma unroll
         for (int nb = 0; nb < MB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * m + d_row(r, h);
-                if (32 * nb + c < L::n_in_pad) p[L::w1_off + row * L::n_in_pad + 32 * nb + c] = gW1[m * MB + nb][r];
+            for (int r = 0; r < 16; ++r) {       // rows and columns of the products are channel POSITIONS of the tiles
+                const int row = position_neuron(32 * m + d_row(r, h));
+                const int pc = 32 * nb + c, in = (pc & ~15) + 4 * ((pc & 7) >> 1) + 2 * ((pc >> 3) & 1) + (pc & 1);
+                if (pc < L::n_in_pad) p[L::w1_off + row * L::n_in_pad + in] = gW1[m * MB + nb][r];
             }
     if constexpr (NH == 2) {
 #pragma unroll
@@ -723,12 +712,15 @@ __global__ __launch_bounds__(256, (NH == 1 && KS < 3) ? 2 : 1) void mlp_bwd_kern
             for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    p[L::w2_off + (32 * m + d_row(r, h)) * 64 + 32 * nn + c] = gW2[2 * m + nn][r];
+                    p[L::w2_off + position_neuron(32 * m + d_row(r, h)) * 64 + position_neuron(32 * nn + c)] = gW2[2 * m + nn][r];
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)            // 16x16 result: row = 4 * (lane >> 4) + register, column = lane & 15
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[L::wo_off + (4 * (lane >> 4) + r) * 64 + 16 * nb + (lane & 15)] = gWo[nb][r];
+        for (int r = 0; r < 4; ++r) {
+            const int op = 4 * (lane >> 4) + r;                   // position 8 h + j of the dY tile holds output row d_row(j, h)
+            p[L::wo_off + d_row(op & 7, op >> 3) * 64 + position_neuron(16 * nb + (lane & 15))] = gWo[nb][r];
+        }
 }
 
 static inline int mlp_blocks(int64_t n, int per_cu) {
@@ -759,7 +751,7 @@ static int n_params_rt(int nh, int ks) {
 
 // backward workgroups per CU: the one-hidden-layer kernel fits 2 waves per SIMD (<= 256 registers) for up to 16 levels,
 // the two-layer one and the 17..24-level variants (two more accumulator tiles for dW1) 1
-static inline int bwd_blocks_per_cu(int nh, int ks) { return (nh == 1 && ks < 3) ? 2 : 1; }
+static inline int bwd_blocks_per_cu(int nh, int ks) { (void)nh; return ks < 3 ? 2 : 1; }      // (mlp_bwd_kernel's launch bounds)
 
 }  // namespace perf
 
@@ -791,7 +783,7 @@ template <typename T16, int NH, int KS>
 static void launch_bwd(int blocks, hipStream_t st, MlpParams mp, const uint16_t* w, const uint32_t* feat, const int32_t* feat_index,
                        int64_t feat_stride, const uint8_t* sel, const float* dout, float2* dfeat, float* partials, float* level_absmax,
                        int64_t n, const int64_t* n_dev) {
-    constexpr int lds_bytes = Layout<NH, KS>::n_all * 1024 + 4 * 2 * 64 * kPitch * 2;
+    constexpr int lds_bytes = Layout<NH, KS>::n_all * 1024 + 4 * 2 * kTile * kPitchT * 2;
     static std::once_flag attr_once;            // (one flag per template instance) safe under concurrent callers
     std::call_once(attr_once, []() {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<T16, NH, KS, true>),
