@@ -35,13 +35,13 @@ struct MlpParams {
 };
 
 constexpr int kTile = 32;      // samples per wave tile
-// LDS tiles of the backward pass: [sample][channel position], kPitchT 16-bit elements per sample row (64 channels + pad: the
-// four sample rows one transposing read touches then fall on disjoint banks).  A lane WRITES the eight channels of a k-step it
+// LDS tiles of the backward pass: [sample][channel position], kPitchT 16-bit elements per sample row (64 channels + pad; 72
+// and 80 measured alike: 78.0 / 79.5 us for the colour network).  A lane WRITES the eight channels of a k-step it
 // holds for its sample with one 16-byte store; the weight-gradient products READ them channel-major -- eight consecutive
 // samples of one channel per lane -- with ds_read_b64_tr_b16 (two per operand).  Round 4 stored the tiles channel-major with
 // 2-byte stores: 152 of the ~200 LDS instructions per tile of the colour network, and the LDS pipe was the busiest unit of the
 // kernel (SQ_ACTIVE_INST_LDS: 78 % of the density network's backward).
-constexpr int kPitchT = 80;
+constexpr int kPitchT = 72;
 
 __device__ __forceinline__ int slot_neuron(int s, int h, int j) {
     return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3);

@@ -15,7 +15,7 @@ DST = os.path.join(ROOT, 'profiles')
 RAW = os.path.join(DST, 'r05_raw')
 KERNELS = ['lattice_runs_kernel', 'march_write_kernel', 'hashgrid_fwd_v2_kernel', 'hashgrid_fwd_kernel', 'hashgrid_bwd_kernel', 'tile_codes4_kernel', 'tile_codes_kernel', 'hashgrid_bwd_reduce_kernel',
            'mlp_fwd_kernel', 'mlp_bwd_kernel', 'mlp_reduce_kernel', 'adam4_kernel', 'adam_kernel', 'march_count_kernel', 'compact_prefix_kernel',
-           'composite_distloss_fwd_kernel', 'composite_distloss_bwd_kernel']
+           'composite_distloss_fwd_kernel', 'composite_distloss_bwd_kernel', 'train_head_kernel', 'march_count_shared_kernel']
 MLP_ENTRY = {'mlp_fwd_kernel': 'perf_mlp_fwd', 'mlp_bwd_kernel': 'perf_mlp_bwd'}
 ENTRY = {'hashgrid_bwd_kernel': 'perf_hashgrid_bwd', 'tile_codes_kernel': 'perf_hashgrid_bwd', 'tile_codes4_kernel': 'perf_hashgrid_bwd', 'hashgrid_bwd_reduce_kernel': 'perf_hashgrid_bwd',
          'hashgrid_fwd_v2_kernel': 'perf_hashgrid_fwd', 'hashgrid_fwd_kernel': 'perf_hashgrid_fwd', 'mlp_bwd_kernel': 'perf_mlp_bwd',
@@ -151,6 +151,10 @@ def main():
     json.dump({'command': 'rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_ANY -- python bench.py --steps 10 --warmup 3 --no-graph ...',
                'note': 'mean per launch over the run; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)', 'kernels': {k: {c: round(v, 1) for c, v in d.items()} for k, d in s.items()}},
               open(os.path.join(DST, 'r05_sq_counters.json'), 'w'), indent=1)
+    sa, saf = fold_counters('pmc_sq_app/**/*counter_collection.csv')
+    copy_raw(saf, 'pmc_sq_app')
+    json.dump({'command': 'as r05_sq_counters.json, with --mode train_app', 'kernels': {k: {c: round(v, 1) for c, v in d.items()} for k, d in sa.items()}},
+              open(os.path.join(DST, 'r05_sq_counters_train_app.json'), 'w'), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
 
