@@ -198,7 +198,7 @@ class OccGridEstimator(nn.Module):
         sigma_points_fn may return (sigmas, feat): the level-major encoded features of its density pass then travel with the
           samples (Samples.feat) so that a gradient pass on the kept samples need not encode them again -- compacted along
           (two-phase sampler) or, from the one-phase sampler, as an ops.IndexedFeat: the uncompacted array plus the row of
-          every kept sample, which ops.mlp_bwd reads in place (.materialize() gives the compacted copy; PERF_INDEX_FEATURES=0).
+          every kept sample, which ops.mlp_bwd reads in place (.materialize() gives the compacted copy).
         lattice: 'repeated' (t_{k+1} = fl(t_k + step), the default: None) or 'single' (t_k = fl(t0 + fl(k step))): PERF_LATTICE_*."""
         if cone_angle != 0.0 or alpha_fn is not None or t_min is not None or t_max is not None:
             raise NotImplementedError('PeRF samples with cone_angle=0 and a sigma_fn (nerf_renderer.py:145-155)')

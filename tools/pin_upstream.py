@@ -14,7 +14,9 @@ A maintainer who HAS the packages (any CUDA box with the reference's environment
 It imports whatever `tinycudann`, `nerfacc` and `torch_efficient_distloss` resolve to, feeds them SEEDED inputs -- flat
 fp32 `params` in tcnn's own layout ([network | grid], which is also this repository's), points, rays, an occupancy grid,
 densities -- and records their outputs and gradients.  Commit the three files: `pytest -m gpu tests/test_gpu_upstream.py`
-then compares this repository's HIP path with them (the tests skip while the files are absent), and
+then compares this repository's HIP path with them (while the files are absent the same tests RUN over vectors the script
+produces from an oracle-backed stand-in, tests/upstream_standin.py: format, seeded inputs and checkers are exercised, nothing is
+pinned by that), and
 `tests/test_cpu_oracle.py::test_oracle_against_upstream_vectors` does the same for the oracle -- including WHICH marching
 lattice upstream walks (include/perf_hip.h PERF_LATTICE_*).
 
