@@ -29,15 +29,27 @@ import os as _os
 GRID_GRAD_ACCUM = _os.environ.get('PERF_GRID_GRAD_ACCUM', 'fixed')
 
 
-def _init_params(mlp: MlpConfig, grid: GridConfig, seed: int) -> torch.Tensor:
+def _init_params(mlp: MlpConfig, grid: GridConfig, seed: int, device=None) -> torch.Tensor:
+    """tcnn's initialisation: Xavier-uniform network weights, U(-1e-4, 1e-4) table entries, [network | grid].  On a GPU the
+    table (millions of entries; the network is ~10 k) is drawn by the DEVICE generator seeded with `seed` -- tcnn initialises on
+    the device too, and PeRF re-instantiates the density field every episode (reset_geo, nerf.py:136-141): the host draw +
+    copy cost 65 ms of a 1.1 s episode.  Same seed -> same values on every run and every rank."""
     g = torch.Generator().manual_seed(seed)
     parts = []
     if mlp is not None:
         for (o, i) in mlp.shapes:
             s = math.sqrt(6.0 / (i + o))                 # Xavier uniform
             parts.append((torch.rand(o * i, generator=g) * 2 - 1) * s)
-    parts.append((torch.rand(grid.n_params, generator=g) * 2 - 1) * 1e-4)
-    return torch.cat(parts)
+    device = torch.device(device) if device is not None else torch.device('cpu')
+    if device.type != 'cuda':
+        parts.append((torch.rand(grid.n_params, generator=g) * 2 - 1) * 1e-4)
+        return torch.cat(parts).to(device)
+    n_net = sum(p.numel() for p in parts)
+    out = torch.empty(n_net + grid.n_params, dtype=torch.float32, device=device)
+    if n_net:
+        out[:n_net] = torch.cat(parts).to(device)
+    out[n_net:].uniform_(-1e-4, 1e-4, generator=torch.Generator(device=device).manual_seed(seed))
+    return out
 
 
 class _FieldFn(torch.autograd.Function):
@@ -150,7 +162,7 @@ class NetworkWithInputEncoding(nn.Module):
                              n_output_dims=n_output_dims,
                              output_activation=network_config.get('output_activation', 'None'),
                              n_neurons=int(network_config.get('n_neurons', 64)))
-        self.params = nn.Parameter(_init_params(self.mlp, self.grid, seed).to(_default_device()))
+        self.params = nn.Parameter(_init_params(self.mlp, self.grid, seed, _default_device()))
         self._w16 = None
         self._w16_key = None
         self._hr_state = ops.headroom_state(self.params.device)     # (plain attribute; NeRFScene.state_dict() carries it)
@@ -278,7 +290,7 @@ class Encoding(nn.Module):
         self.n_output_dims = self.grid.n_output_dims
         # tcnn hands back half by default; dtype=torch.float32 / 'fp32' keeps the fp32 result
         self.out_dtype = torch.float32 if dtype in ('fp32', torch.float32) else ops.torch_dtype(dtype or 'fp16')
-        self.params = nn.Parameter(_init_params(None, self.grid, seed).to(_default_device()))
+        self.params = nn.Parameter(_init_params(None, self.grid, seed, _default_device()))
 
     def forward(self, x):
         x = x.reshape(-1, self.n_input_dims).contiguous().float()
