@@ -1193,3 +1193,28 @@ def test_train_head_in_one_launch_equals_the_three_launch_chains(ops, tail_empty
         assert torch.equal(drgb[:live], ha['d_rgb'][:live])
         closs = ha['color_terms'].sum() / (3 * bs)
         assert abs(float(closs) - float(sca[0])) <= 1e-5 * abs(float(sca[0]))
+
+
+def test_train_head_on_a_batch_without_samples(ops):
+    """A capacity-sized batch whose rays all came back empty (a transparent field, or everything pruned): the one-launch ray head
+    equals the chains on the per-ray outputs, the distortion normaliser falls back to 1 like perf_geo_loss's, no per-sample row is
+    written, and a ray count that is not a multiple of four is served."""
+    R, cap = 37, 256
+    c = lambda t: t.cuda().contiguous()
+    packed = torch.zeros(R, 2, dtype=torch.int32)
+    g = torch.Generator().manual_seed(3)
+    sig, ts, rgb = torch.rand(cap, generator=g), torch.rand(cap, generator=g), torch.rand(cap, 3, generator=g)
+    te = ts + 1e-3
+    gt_d, noise, gt_c, bg = torch.rand(R, generator=g), torch.rand(R, generator=g), torch.rand(R, 3, generator=g), torch.rand(R, 3, generator=g)
+    w, T, op, dist, col, dl = ops.composite_distloss_fwd(c(sig), c(rgb), c(ts), c(te), c(packed))
+    g_op, g_d, sc = ops.geo_loss(op, dist, c(gt_d), c(noise), dl, c(packed), R, 1.0, 0.5, None, 128.0)
+    hd = ops.train_head_geo(c(sig), c(rgb), c(ts), c(te), c(packed), c(gt_d), c(noise), R, 1.0, 0.5, None, 128.0)
+    hd['d_sigma'].fill_(7.0); hd2 = ops.train_head_geo(c(sig), c(rgb), c(ts), c(te), c(packed), c(gt_d), c(noise), R, 1.0, 0.5, None, 128.0)
+    for a, b in ((op, hd['opacity']), (dist, hd['distance']), (col, hd['color']), (dl, hd['distloss_per_ray'])):
+        assert torch.equal(a, b) and float(a.abs().max()) == 0.0
+    assert float(hd['inv_n'][0]) == 1.0
+    assert abs(float(hd['depth_terms'].sum() / R) - float(sc[0])) <= 1e-6 * abs(float(sc[0])) and float(sc[1]) == 0.0
+    assert torch.equal(hd['depth_terms'], hd2['depth_terms'])
+    ha = ops.train_head_app(c(sig), c(rgb), c(ts), c(te), c(packed), c(bg), c(gt_c), R, 1.0, 128.0)
+    _, sca = ops.app_loss(op, col, c(bg), c(gt_c), R, 1.0, 128.0)
+    assert abs(float(ha['color_terms'].sum() / (3 * R)) - float(sca[0])) <= 1e-6 * abs(float(sca[0]))
