@@ -584,3 +584,35 @@ def test_scene_shims_against_the_reference_tree():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_reference_imports.py')], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
     assert r.returncode == 0 and 'install_shims(scene=True): OK' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_synthetic_scene_families_are_what_their_oracle_curves_were_made_on():
+    """perf_amd/synthetic.py SCENES (pure torch): the doorway family shows depth discontinuities of ~3x along the door frame and rays
+    that run on through the opening; the pillar family hides a sizeable part of the walls behind fourteen thin occluders; all
+    distances are normalised into (0, 1/1.05], colours into [0, 1] -- and the committed oracle curves name their family."""
+    import json
+    import math
+    from perf_amd import synthetic
+    H, W = 128, 256
+    i = (torch.arange(H) + .5) / H; j = (torch.arange(W) + .5) / W
+    y, x = torch.meshgrid(i, j, indexing='ij')
+    beta = -(y - .5) * math.pi; alpha = -(x - .5) * 2 * math.pi
+    d = torch.stack([torch.cos(alpha) * torch.cos(beta), torch.sin(alpha) * torch.cos(beta), torch.sin(beta)], -1)
+    room_d, _ = synthetic.room(d)
+    for name, fn in synthetic.SCENES.items():
+        dist, rgb = fn(d)
+        assert dist.shape == (H, W, 1) and rgb.shape == (H, W, 3) and torch.isfinite(dist).all()
+        assert float(dist.min()) > 0 and abs(float(dist.max()) - 1 / 1.05) < 1e-5 and 0.0 <= float(rgb.min()) and float(rgb.max()) <= 1.0
+    door, _ = synthetic.doorway(d)
+    ratio = door[:, 1:, 0] / door[:, :-1, 0]
+    assert float(torch.maximum(ratio, 1 / ratio).max()) > 2.5                    # the door frame: neighbouring pixels 3x apart in depth
+    row = door[H // 2 + 8, :, 0]                                                 # a row below the horizon, through the opening
+    assert float(row.max()) > 2.0 * float(row.min())
+    pil, _ = synthetic.pillars(d)
+    hidden = float((pil[..., 0] * float(pil.max() / room_d.max()) < room_d[..., 0] * 0.9).float().mean())
+    assert 0.1 < hidden < 0.6, hidden
+    jumps = ((pil[H // 2, 1:, 0] / pil[H // 2, :-1, 0] - 1).abs() > 0.2).sum()
+    assert int(jumps) >= 16                                                      # the horizon row crosses many pillar edges
+    for name in ('doorway', 'pillars'):
+        cfg = json.load(open(os.path.join(ROOT, 'tests', 'golden', f'psnr_curve_{name}.json')))
+        assert cfg['config']['scene'] == name and len(cfg['seeds']) == 3
