@@ -316,7 +316,7 @@ def config5_block(args):
     ray-samples/s and the encode kernel's algorithmic and MOVED fraction of the HBM peak (the latter from the committed
     rocprofv3 PMC pass of the same batches, profiles/r05_config5_pmc.json).  tests/test_gpu_config5.py checks the same workload
     through size-independent properties."""
-    from tools import config5 as C
+    from perf_amd import panorama as C
     pmc = None
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r05_config5_pmc.json')))

@@ -71,7 +71,7 @@ class NGPNeRF(nn.Module):
                  unbounded: bool = False, n_levels: int = 16, dtype=None, log2_hashmap_size: int = 18):
         super().__init__()
         if not isinstance(aabb, torch.Tensor):
-            aabb = torch.tensor(aabb, dtype=torch.float32)
+            aabb = torch.tensor(aabb, dtype=torch.float32, device='cpu')
         self.register_buffer("aabb", aabb.float().cuda())
         self._aabb_host = [float(v) for v in aabb.reshape(-1).tolist()]
         self.num_dim = num_dim
@@ -149,7 +149,7 @@ class InferenceNeRF:
         from .grid import GridConfig, MlpConfig
         import math
         if not isinstance(aabb, torch.Tensor):
-            aabb = torch.tensor(aabb, dtype=torch.float32)
+            aabb = torch.tensor(aabb, dtype=torch.float32, device='cpu')
         dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.aabb = aabb.float().to(dev)
         self._aabb_host = [float(v) for v in aabb.reshape(-1).tolist()]
@@ -159,12 +159,12 @@ class InferenceNeRF:
         t16 = ops.torch_dtype(dtype)
         self.nets = {}
         gen = torch.Generator(device=dev).manual_seed(seed)
-        cg = torch.Generator().manual_seed(seed)
+        cg = torch.Generator(device='cpu').manual_seed(seed)
         for name, mlp in (('geo_mlp', MlpConfig(n_levels, 1, 1, 'Exponential', exp_shift=-float(density_bias))),
                           ('app_mlp', MlpConfig(n_levels, 2, 3, 'Sigmoid'))):
             n_net = mlp.n_params
             w16 = torch.empty(n_net + self.grid.n_params, dtype=t16, device=dev)
-            parts = [(torch.rand(o * i, generator=cg) * 2 - 1) * math.sqrt(6.0 / (i + o)) for (o, i) in mlp.shapes]
+            parts = [(torch.rand(o * i, generator=cg, device='cpu') * 2 - 1) * math.sqrt(6.0 / (i + o)) for (o, i) in mlp.shapes]
             w16[:n_net].copy_(torch.cat(parts))
             chunk = 1 << 28
             for lo in range(n_net, w16.numel(), chunk):
@@ -200,7 +200,7 @@ class NGPDensityField(nn.Module):
                  max_resolution: int = 128, n_levels: int = 5, log2_hashmap_size: int = 17, dtype=None):
         super().__init__()
         if not isinstance(aabb, torch.Tensor):
-            aabb = torch.tensor(aabb, dtype=torch.float32)
+            aabb = torch.tensor(aabb, dtype=torch.float32, device='cpu')
         self.register_buffer("aabb", aabb.float().cuda())
         self._aabb_host = [float(v) for v in aabb.reshape(-1).tolist()]
         self.num_dim = num_dim

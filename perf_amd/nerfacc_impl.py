@@ -109,7 +109,9 @@ def _lib_default_lattice():
     return _lib.DEFAULT_LATTICE
 
 
-_UPDATE_CALLS = [0]      # calls of OccGridEstimator.update_every_n_steps' warm-up branch in this process (jitter counter)
+# calls of OccGridEstimator.update_every_n_steps' warm-up branch in this process, per torch seed (the jitter counter): the
+# reference's torch.rand stream continues across estimators and starts over with torch.manual_seed(another seed)
+_UPDATE_CALLS = {}
 
 
 class Samples:
@@ -354,13 +356,14 @@ class OccGridEstimator(nn.Module):
             # floats -- the jittered points (counter-based generator), then the moving maximum with its sum; one more
             # launch thresholds.  The cells go through the closure in chunks of 2 M, so that whatever element-wise work the
             # closure itself does (PeRF's look-up closure: ~10 passes, nerf.py:149-158) runs out of the Infinity Cache.
-            if getattr(self, '_upd_seed', None) is None:
+            if getattr(self, '_upd_seed', None) != int(torch.initial_seed()):
                 self._upd_seed = int(torch.initial_seed())
+            if getattr(self, '_upd_sum', None) is None:
                 self._upd_sum = torch.zeros(1, dtype=torch.float64, device=dev)
             # the jitter stream continues ACROSS estimators, like the torch.rand stream of the reference does across episodes
             # (PeRF builds a fresh OccGridEstimator per fit, nerf.py:144): a process-wide call counter, not a per-instance one
-            _UPDATE_CALLS[0] += 1
-            self._upd_calls = _UPDATE_CALLS[0]
+            _UPDATE_CALLS[self._upd_seed] = _UPDATE_CALLS.get(self._upd_seed, 0) + 1
+            self._upd_calls = _UPDATE_CALLS[self._upd_seed]
             self._upd_sum.zero_()
             n = self.cells_per_lvl
             occs = self.occs if self.occs.is_contiguous() else self.occs.contiguous()

@@ -28,9 +28,9 @@ def _odd(n):
 
 def _equator_dirs(width):
     """unit directions of the panorama's middle row, pixel centres (camera_utils.py:113-147 at y = 0.5)"""
-    x = torch.linspace(.5 / width, 1. - .5 / width, width)
+    x = torch.linspace(.5 / width, 1. - .5 / width, width, device='cpu')
     alpha = -(x - .5) * 2. * np.pi
-    beta = torch.zeros(width)
+    beta = torch.zeros(width, device='cpu')
     return torch.stack([torch.cos(alpha) * torch.cos(beta), torch.sin(alpha) * torch.cos(beta), torch.sin(beta)], -1)
 
 
@@ -42,7 +42,7 @@ def resample_closed_curve(pts: torch.Tensor) -> torch.Tensor:
     seg = torch.linalg.norm(torch.roll(fine, -1, 0) - fine, 2, -1)
     cum = torch.cumsum(seg, 0)
     cum = cum / cum[-1]
-    return fine[torch.searchsorted(cum, torch.linspace(0., 1. - 1. / n, n))]
+    return fine[torch.searchsorted(cum, torch.linspace(0., 1. - 1. / n, n, device=pts.device))]
 
 
 def look_at(to_vec: torch.Tensor) -> torch.Tensor:
@@ -62,7 +62,7 @@ class CirclePoseSampler:
         dm = distance_map.detach().cpu().numpy() if torch.is_tensor(distance_map) else np.asarray(distance_map)
         dm = dm.squeeze()
         h, w = dm.shape
-        rows = torch.linspace(.5 / h, 1. - .5 / h, h)
+        rows = torch.linspace(.5 / h, 1. - .5 / h, h, device='cpu')
         beta = (-(rows - .5) * np.pi).numpy()
         horiz = dm * np.cos(beta)[:, None]                       # distance projected on the horizontal plane
         band = horiz[h // 2 - 10: h // 2 + 10].copy()
@@ -84,7 +84,7 @@ class CirclePoseSampler:
         for i, ratio in enumerate(traverse_ratios):
             loop = resample_closed_curve(dirs * ring_t[:, None] * ratio)
             n = n_anchors_per_ratio[i]
-            pos = torch.linspace(.5 / n, 1. - .5 / n, n) + (0. if i % 2 == 0 else .5 / n)
+            pos = torch.linspace(.5 / n, 1. - .5 / n, n, device='cpu') + (0. if i % 2 == 0 else .5 / n)
             pts = loop[(pos * w).to(torch.long).clip(0, w - 1)].clone()
             for j in range(len(pts)):
                 pts[j, 2] = z_lo if (i + j) % 2 == 0 else z_hi
@@ -94,7 +94,7 @@ class CirclePoseSampler:
         self.n_anchors = self.n_poses = len(self.anchor_pts)
 
     def sample_pose(self, idx):
-        pose = torch.eye(4)
+        pose = torch.eye(4, device='cpu')
         pose[:3, 3] = self.anchor_pts[idx]
         return pose
 
@@ -233,7 +233,7 @@ class DenseTravelPoseSampler:
         anchors exist (before / while the scene trains); the worker starts from the CURRENT global numpy RNG state, and
         .result() restores the state the sequential call would have left, so nothing downstream changes -- provided nobody
         draws from numpy's global RNG in between."""
-        sparse = torch.stack([sparse_pose_sampler.sample_pose(i) for i in range(sparse_pose_sampler.n_poses)], 0).float()
+        sparse = torch.stack([sparse_pose_sampler.sample_pose(i) for i in range(sparse_pose_sampler.n_poses)], 0).float().cpu()
         key = cls._key(sparse, n_dense_poses, dir_bias_ratio)
         if key in _DENSE_CACHE:
             return DensePoseFuture(key, ready=_DENSE_CACHE[key])
@@ -246,7 +246,7 @@ class DenseTravelPoseSampler:
         return DensePoseFuture(key, proc, parent, fallback=(sparse, n_dense_poses, dir_bias_ratio, state0))
 
     def __init__(self, sparse_pose_sampler, n_dense_poses, dir_bias_ratio=-1, _cache=True):
-        sparse = torch.stack([sparse_pose_sampler.sample_pose(i) for i in range(sparse_pose_sampler.n_poses)], 0).float()
+        sparse = torch.stack([sparse_pose_sampler.sample_pose(i) for i in range(sparse_pose_sampler.n_poses)], 0).float().cpu()
         key = self._key(sparse, n_dense_poses, dir_bias_ratio) if _cache else None
         if key is not None and key in _DENSE_CACHE:             # same anchors, same RNG state: same trajectory, same RNG afterwards
             poses, rng_state = _DENSE_CACHE[key]
@@ -265,13 +265,13 @@ class DenseTravelPoseSampler:
         chunks = []
         for i in range(len(counts)):
             k = counts[i].item()
-            t = torch.linspace(.5 / k, 1. - .5 / k, k)
+            t = torch.linspace(.5 / k, 1. - .5 / k, k, device='cpu')
             chunks.append(tour[i][None] * (1. - t)[:, None] + tour[i + 1][None] * t[:, None])
         pts = resample_closed_curve(torch.cat(chunks, 0))[::50].numpy()
         for a in range(3):
             pts[:, a] = gaussian_filter1d(pts[:, a], sigma=20)
         pts = torch.from_numpy(pts)
-        self.sample_poses = torch.eye(4)[None].repeat(len(pts), 1, 1)
+        self.sample_poses = torch.eye(4, device='cpu')[None].repeat(len(pts), 1, 1)
         self.sample_poses[:, :3, 3] = pts
         self.n_poses = len(pts)
         fwd = pts.clone()

@@ -94,6 +94,18 @@ class _Losses(dict):
     def values(self):
         return [self[k] for k in self.keys()]
 
+    def resolved(self):
+        """A plain dict of evaluated values (each thunk costs a device reduction; float() of a value a host read-back).
+        dict(losses) / {**losses} / json.dumps(losses) take dict's C fast path and would see the raw thunks: use this, .copy()
+        or pickling instead."""
+        return {k: self[k] for k in self.keys()}
+
+    def copy(self):
+        return self.resolved()
+
+    def __reduce__(self):
+        return (dict, (self.resolved(),))
+
 
 @dataclass
 class Rays:
@@ -179,7 +191,7 @@ class SupInfoPool:
         mask_raw = (mask.reshape(h, w, 1) > .5) & (distance > 1e-5)
         valid = mask_raw & _edge_free(distance)
         if has_normal:
-            local = gen_pano_rays(torch.eye(4), h, w, device=dev)
+            local = gen_pano_rays(torch.eye(4, device='cpu'), h, w, device=dev)
             valid = valid & (((-local.d) * normal).sum(-1, True).clip(0., 1.) > 0.15)
         rays = gen_pano_rays(pose, h, w, device=dev)
         idx = torch.where(valid[..., 0])
@@ -314,9 +326,9 @@ class FusedAdam:
             warnings.warn(f'perf_amd: a phase of {len(lrs)} iterations exceeds the device-side schedule of {total} rows; '
                           'iterations beyond it keep the last row (learning rate / distortion ramp frozen)')
         n = min(len(lrs), total)
-        rows = torch.empty(total, 2, dtype=torch.float32)
-        rows[:n, 0] = torch.as_tensor(lrs[:n], dtype=torch.float32)
-        rows[:n, 1] = torch.as_tensor(ratios[:n], dtype=torch.float32) if ratios is not None else 1.0
+        rows = torch.empty(total, 2, dtype=torch.float32, device='cpu')
+        rows[:n, 0] = torch.as_tensor(lrs[:n], dtype=torch.float32, device='cpu')
+        rows[:n, 1] = torch.as_tensor(ratios[:n], dtype=torch.float32, device='cpu') if ratios is not None else 1.0
         rows[n:] = rows[n - 1]
         self.sched_table.copy_(rows)
         self.sched_iter.fill_(int(first))
@@ -395,9 +407,21 @@ class NeRFScene:
                  fused_adam=True, writer=None):
         if estimator_type != 'occ':
             raise NotImplementedError("estimator_type 'prop' is dead code in the reference (nerf_renderer.py:73)")
-        self.aabb = torch.tensor([-1.0, -1.0, -1.0, 1.0, 1.0, 1.0])
+        self.aabb = torch.tensor([-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], device='cpu')
         self.base_exp_dir = base_exp_dir
+        # The reference builds a tensorboard SummaryWriter under base_exp_dir/ts_log itself (nerf.py:37) and logs five scalars
+        # per step (:213,238,255,286,295).  Here: any object with add_scalar(tag, value, step) -- the caller's, or, when the
+        # scene is constructed the runner's way (a base_exp_dir, no writer) and tensorboard is importable, the same
+        # SummaryWriter; None otherwise.  Scalars are written every `writer_every`-th step (a logged loss is a device
+        # reduction + a host read-back; the reference pays that on every step).
+        if writer is None and base_exp_dir is not None:
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                writer = SummaryWriter(log_dir=os.path.join(base_exp_dir, 'ts_log'))
+            except Exception:      # noqa: BLE001 -- tensorboard absent (or unusable): train without scalars, as before
+                writer = None
         self.writer = writer
+        self.writer_every = 16
         self.train_conf = train_conf or default_train_conf()
         self.nerf = NGPNeRF(aabb=self.aabb, dtype=dtype)
         self.estimator = OccGridEstimator(roi_aabb=self.aabb, resolution=256, levels=1).cuda()
@@ -448,8 +472,11 @@ class NeRFScene:
         # alike) -- a captured step then holds no torch random op, whose graph replays cost two extra launches each.
         # False, or an explicit `generator` / `rand` argument: torch.randint / torch.rand as in rounds 1-2.
         self.device_rng = True
-        # sync-free training: let the health poll lower a sample capacity that proved far too large (see _poll_health)
+        # sync-free training: let the health poll lower a sample capacity that proved far too large (see _poll_health).  The
+        # lowered value lives as long as the density field it was measured on: a fresh geometry network or a new occupancy
+        # (make_optimizer / prepare_occupancy) brings back the capacity the shrink started from (_capacity_unshrunk).
         self.auto_shrink_capacity = True
+        self._capacity_unshrunk = None
         self._rng_seed = None
         self._rng_counter = None
 
@@ -529,8 +556,18 @@ class NeRFScene:
     def fit(self, sup_pool: SupInfoPool, **kw):
         self.train_one_episode(sup_pool, self.train_conf.raw_phase_iter_geo, self.train_conf.raw_phase_iter_app, **kw)
 
+    def _restore_capacity(self):
+        """Undo _poll_health's capacity shrink: the marched counts it was sized on belong to a density field / occupancy that is
+        being replaced (a fresh field is transparent: PeRF's batches march ~300 k samples against ~35 k late in a phase)."""
+        if self._capacity_unshrunk is not None:
+            if self.renderer.sample_capacity is not None:
+                self.renderer.sample_capacity = max(self.renderer.sample_capacity, self._capacity_unshrunk)
+            self._capacity_unshrunk = None
+            self.sample_counters[3] = 0               # the shrink window starts over
+
     def prepare_occupancy(self, sup_pool, warmup='direct'):
         self._geo_pre = None           # a batch prefetched under the previous episode's pool / occupancy must not be consumed
+        self._restore_capacity()
         self.estimator = OccGridEstimator(roi_aabb=self.aabb, resolution=256, levels=1).cuda()
         self.estimator.train()
         pre_grid, _ = sup_pool.gen_occ_grid(res=256)
@@ -557,6 +594,8 @@ class NeRFScene:
         hr = getattr(net, 'headroom_state', None)
         if hr is not None:
             hr().zero_()
+        if net is self.nerf.geo_mlp:
+            self._restore_capacity()      # (callers of make_graphed_step / train_one_step_geo outside train_one_episode too)
         return FusedAdam(net, lr) if self.fused_adam else torch.optim.Adam(net.parameters(), lr=lr)
 
     def train_one_episode(self, sup_pool, geo_res_iters, app_res_iters, warmup='direct', callback=None, use_graphs=None):
@@ -584,6 +623,7 @@ class NeRFScene:
             self.sync_params()            # (sharded data parallelism: every rank leaves the episode with the full fp32 master)
         finally:
             self.renderer.sample_capacity = saved_capacity
+            self._capacity_unshrunk = None
 
     EAGER_HEAD = 3
 
@@ -647,8 +687,25 @@ class NeRFScene:
                     step_fn(optimizer, sup_pool, progress=progress_of(iter_i), prefetch_next=iter_i + 1 < n_iters and not last_eager)
                 else:
                     step_fn(optimizer, sup_pool, progress=progress_of(iter_i))
+            self._log_scalars(kind, self.lr_at(conf, iter_i / n_iters))
             if callback:
                 callback(kind, iter_i)
+
+    def _log_scalars(self, kind, lr):
+        """nerf.py:213,238,255 (geometry step) / :286,295 (colour step): the step's loss terms and learning rate, tagged with the
+        index of the step just taken (the reference logs before it increments its counter)."""
+        w = self.writer
+        if w is None:
+            return
+        step = (self.global_iter_step_geo if kind == 'geo' else self.global_iter_step_app) - 1
+        if step < 0 or step % max(int(self.writer_every), 1) != 0:
+            return
+        tags = (('depth_loss', 'nerf_loss/depth_loss'), ('dist_loss', 'nerf_loss/dist_loss')) if kind == 'geo' \
+            else (('color_loss', 'nerf_loss/color_loss'),)
+        for key, tag in tags:
+            if key in self.last_losses:
+                w.add_scalar(tag, float(self.last_losses[key]), step)
+        w.add_scalar('others/lr_' + kind, float(lr), step)
 
     def _batch(self, sup_pool, generator=None):
         dist, rank, world = self._dist()
@@ -741,6 +798,8 @@ class NeRFScene:
                 new = max(int(self.CAPACITY_SHRINK_TO * c[3]), self.CAPACITY_MIN_ROWS)
                 new = (new + 4095) // 4096 * 4096
                 if new < cap:
+                    if self._capacity_unshrunk is None:
+                        self._capacity_unshrunk = cap
                     self.renderer.sample_capacity = new
                     recapture = True
             self.sample_counters[3] = 0               # the window starts over
@@ -1190,11 +1249,13 @@ class NeRFScene:
         count = getattr(self, 'count_graph_nodes', False)
         graph = torch.cuda.CUDAGraph(keep_graph=True) if count else torch.cuda.CUDAGraph()
         self._capturing = optimizer.capturing = True
+        iters = (self.global_iter_step_geo, self.global_iter_step_app)
         try:
             with _capture(graph):
                 step_fn(optimizer, sup_pool, progress=0.0)
         finally:
             self._capturing = optimizer.capturing = False
+            self.global_iter_step_geo, self.global_iter_step_app = iters       # (the capture pass executes nothing: no step was taken)
         if count:          # (bench.py: launches per replayed step)
             if not hasattr(self, 'graph_nodes'):
                 self.graph_nodes = {}
@@ -1280,7 +1341,7 @@ class NeRFScene:
         state['graph'] = capture()
 
         def frame(pose):
-            pose_dev.copy_(torch.as_tensor(pose, dtype=torch.float32).reshape(4, 4), non_blocking=True)
+            pose_dev.copy_(torch.as_tensor(pose, dtype=torch.float32, device=pose.device if torch.is_tensor(pose) else 'cpu').reshape(4, 4), non_blocking=True)
             while True:
                 state['graph'].replay()
                 sizes = torch.tensor([min((b + 1) * batch_size, n) - b * batch_size for b in range(n_batches)], device=dev)

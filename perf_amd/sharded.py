@@ -122,13 +122,13 @@ class LevelShardedEncoder:
         if table16 is None:
             # every rank draws the FULL table's random stream level by level and keeps its own levels: the union equals the
             # unsharded initialisation (tests compare against it); huge tables would be initialised shard-locally instead
-            g = torch.Generator().manual_seed(seed)
+            g = torch.Generator(device='cpu').manual_seed(seed)
             parts = []
             for l in range(grid.n_levels):
-                t = (torch.rand(int(grid.size[l]) * 2, generator=g) * 2 - 1) * 1e-4
+                t = (torch.rand(int(grid.size[l]) * 2, generator=g, device='cpu') * 2 - 1) * 1e-4
                 if l in self.local.levels:
                     parts.append(t)
-            table16 = torch.cat(parts).to(self.dtype) if parts else torch.zeros(0, dtype=self.dtype)
+            table16 = torch.cat(parts).to(self.dtype) if parts else torch.zeros(0, dtype=self.dtype, device='cpu')
         self.table16 = table16.to(dev)
 
     # ---- collectives (all-to-all on RCCL; gloo -- tests on one GPU -- has none, so it is composed from all_gather) ------

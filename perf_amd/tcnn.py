@@ -34,15 +34,17 @@ def _init_params(mlp: MlpConfig, grid: GridConfig, seed: int, device=None) -> to
     table (millions of entries; the network is ~10 k) is drawn by the DEVICE generator seeded with `seed` -- tcnn initialises on
     the device too, and PeRF re-instantiates the density field every episode (reset_geo, nerf.py:136-141): the host draw +
     copy cost 65 ms of a 1.1 s episode.  Same seed -> same values on every run and every rank."""
-    g = torch.Generator().manual_seed(seed)
+    # (every host-side draw names its device: PeRF's runner makes CUDA the default tensor type, core_exp_runner.py:266, and a
+    #  device-less torch.rand would then be handed this CPU generator)
+    g = torch.Generator(device='cpu').manual_seed(seed)
     parts = []
     if mlp is not None:
         for (o, i) in mlp.shapes:
             s = math.sqrt(6.0 / (i + o))                 # Xavier uniform
-            parts.append((torch.rand(o * i, generator=g) * 2 - 1) * s)
+            parts.append((torch.rand(o * i, generator=g, device='cpu') * 2 - 1) * s)
     device = torch.device(device) if device is not None else torch.device('cpu')
     if device.type != 'cuda':
-        parts.append((torch.rand(grid.n_params, generator=g) * 2 - 1) * 1e-4)
+        parts.append((torch.rand(grid.n_params, generator=g, device='cpu') * 2 - 1) * 1e-4)
         return torch.cat(parts).to(device)
     n_net = sum(p.numel() for p in parts)
     out = torch.empty(n_net + grid.n_params, dtype=torch.float32, device=device)

@@ -25,7 +25,7 @@ def render_dense(scene, pose_sampler, n_poses=180, height=512, width=1024, query
     n = dense.n_poses if max_frames is None else min(dense.n_poses, max_frames)
     for i in range(n):
         pose = dense.sample_pose(i).clone().float()
-        pose[:3, :3] = torch.eye(3)                                # core_exp_runner.py:232
+        pose[:3, :3] = torch.eye(3, device=pose.device)                                # core_exp_runner.py:232
         if frame_fn is not None:
             res = frame_fn(pose)
         else:

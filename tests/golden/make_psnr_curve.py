@@ -3,7 +3,13 @@
 Runs in the build container (CPU, minutes per seed); tests/test_gpu_psnr.py replays the same schedule on the HIP path on
 the GPU box and asserts |mean delta PSNR| <= 0.1 dB for the default dtype (north_star).
 
-  python tests/golden/make_psnr_curve.py [n_seeds] [out_path] [scene]      (scene: room | doorway | pillars -> psnr_curve[_<scene>].json)"""
+  python tests/golden/make_psnr_curve.py [n_seeds] [out_path] [scene]      (scene: room | doorway | pillars -> psnr_curve[_<scene>].json)
+  python tests/golden/make_psnr_curve.py spread - [scene]                  (adds the oracle's OWN sensitivity to the same file)
+
+`spread`: the same fp32 CPU schedule of seed 0 run twice more from an initialisation moved by ONE ULP (every parameter of both
+networks to its fp32 neighbour above / below): what a perturbation far below any 16-bit effect does to PSNR@iter of this chaotic
+optimisation.  Stored as `oracle_spread` = {runs: [curve, curve], per mark the largest pairwise |difference| among (seed 0,
+above, below)}; tests/test_gpu_psnr.py asserts single seeds against max(0.1 dB, that spread)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -14,7 +20,39 @@ H, W, BATCH, N_GEO, N_APP = 256, 512, 1024, 300, 300
 MARKS = (150, 300)
 
 
+def spread_main():
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    scene_name = sys.argv[3] if len(sys.argv) > 3 else 'room'
+    default = 'psnr_curve.json' if scene_name == 'room' else f'psnr_curve_{scene_name}.json'
+    out_path = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != '-' else os.path.join(ROOT, 'tests', 'golden', default)
+    res = json.load(open(out_path))
+    cfg = res['config']
+    assert cfg.get('scene', 'room') == scene_name and cfg['lattice'] == P.O.DEFAULT_LATTICE
+    scene = P.make_scene(*cfg['pano'], scene_name)
+    base = next(r for r in res['seeds'] if r['seed'] == 0)
+    draws = P.make_draws(scene[0].shape[0], cfg['batch'], cfg['geo_iters'] + cfg['app_iters'], 0)
+    assert P.draws_digest(draws) == base['draws_digest']
+    sp = res.get('oracle_spread') or {'seed': 0, 'perturbation': 'every parameter of both networks moved to its fp32 neighbour (one ulp) above / below', 'runs': []}
+    for k, towards in enumerate((float('inf'), -float('inf'))):
+        if k < len(sp['runs']):
+            continue
+        geo0, app0 = P.init_params(0)
+        geo0 = torch.nextafter(geo0, torch.full_like(geo0, towards)); app0 = torch.nextafter(app0, torch.full_like(app0, towards))
+        t = time.time()
+        curve = P.run_oracle(scene, geo0, app0, draws, cfg['geo_iters'], cfg['app_iters'], tuple(cfg['marks']),
+                             log=lambda m: print(f'{scene_name} spread run {k}: {m}', flush=True))
+        curve['seconds'] = round(time.time() - t, 1)
+        sp['runs'].append(curve)
+        curves = [base['oracle']] + sp['runs']
+        sp['max_abs_delta_db'] = {f'psnr@app{m}': max(abs(a[f'psnr@app{m}'] - b[f'psnr@app{m}']) for a in curves for b in curves) for m in cfg['marks']}
+        res['oracle_spread'] = sp
+        json.dump(res, open(out_path, 'w'), indent=1)
+        print(scene_name, 'spread so far', sp['max_abs_delta_db'], flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'spread':
+        return spread_main()
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     scene_name = sys.argv[3] if len(sys.argv) > 3 else 'room'

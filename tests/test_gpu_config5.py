@@ -16,7 +16,7 @@ TABLE_SCALE, DENSITY_BIAS = 4.0, 4.0      # tables U(-4, 4), sigma = exp(y + 4):
 
 def _field(log2_t):
     from perf_amd.fields import InferenceNeRF
-    from tools import config5 as C
+    from perf_amd import panorama as C
     nerf = InferenceNeRF([-1., -1, -1, 1, 1, 1], n_levels=20, log2_hashmap_size=log2_t, per_level_scale=C.per_level_scale(20),
                          dtype='fp16', table_scale=TABLE_SCALE, density_bias=DENSITY_BIAS)
     est, rend = C.make_renderer(SPP)
@@ -43,7 +43,7 @@ def _check_batch(res, R):
 def test_config5_full_panorama_properties():
     """T = 2^28, the whole 4096x2048x256 panorama (2.1e9 marched ray-samples)."""
     from perf_amd import ops
-    from tools import config5 as C
+    from perf_amd import panorama as C
     nerf, est, rend = _field(28)
     assert nerf.grid.n_levels == 20 and nerf.grid.n_params >= 2 ** 32            # parameter offsets do not fit 32 bits
     assert int(nerf.grid.res[-1]) in (8192, 8193)
@@ -78,7 +78,7 @@ def test_config5_full_panorama_properties():
 def test_config5_tables_beyond_32_bit_entry_offsets():
     """T = 2^30 (31 GiB per encoder, 8.4e9 entries: 64-bit level offsets in entries, not only in parameters): a band of rows
     around the equator and one at the pole, batch-size independence, bounds."""
-    from tools import config5 as C
+    from perf_amd import panorama as C
     nerf, est, rend = _field(30)
     assert nerf.grid.total >= 2 ** 32
     for r0 in (0, H // 2 - 8):

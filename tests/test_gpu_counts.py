@@ -544,3 +544,41 @@ def test_device_rng_episode_graph_replay_equals_eager(head):
     assert res['eager'][2] == res['graph'][2] == 20
     for mode in ('graph',):
         assert torch.equal(res['eager'][0], res[mode][0]) and torch.equal(res['eager'][1], res[mode][1]), mode
+
+
+def test_a_shrunk_capacity_does_not_outlive_the_density_field_it_was_measured_on():
+    """ADVICE-5: the health poll lowers a sample capacity that proved far too large and the captured step is captured again;
+    the lowered value belongs to THAT density field.  A caller that drives make_graphed_step itself (bench.py,
+    tools/mini_perf_loop.py -- not train_one_episode, which restores the capacity on its own) and then starts a new phase on a
+    fresh geometry network (reset_geo + make_optimizer: transparent again, marching several times more samples) must get the
+    capacity back: no batch of the new phase is truncated, none of its steps skipped."""
+    from perf_amd import scene as S
+    scene, pool, rays, dist, rgb = _room_scene(h=128, w=256, batch=4096)
+    scene.CAPACITY_MIN_ROWS = 8192                 # (the default floor of 65,536 rows is above this small batch's counts)
+    opt = scene.make_optimizer(scene.nerf.geo_mlp, 1e-2)
+    replay = scene.make_graphed_step('geo', opt, pool, warmup=3)
+    cap0 = scene.renderer.sample_capacity
+    assert cap0 == 4096 * scene.TRAIN_SAMPLES_PER_RAY
+    first = None
+    for i in range(10 * S.OVERFLOW_CHECK_EVERY):
+        replay(1e-2, 0.5)
+        if i == 0:
+            first = int(scene._last_counts[0].item())
+    late = int(replay.state['counts'][0].item())
+    shrunk = scene.renderer.sample_capacity
+    print(f'[capacity] marched: first step {first}, late {late}; capacity {cap0} -> {shrunk}')
+    assert shrunk < cap0 and scene._capacity_unshrunk == cap0, 'the field must have formed far enough for the poll to shrink'
+    assert first > shrunk, 'a fresh field must march more than the shrunk capacity holds, or this test shows nothing'
+    c = scene.sample_counters.tolist()
+    assert c[5] == 0
+    # -- a new phase on a fresh geometry network, driven by hand
+    scene.nerf.reset_geo()
+    opt = scene.make_optimizer(scene.nerf.geo_mlp, 1e-2)
+    assert scene.renderer.sample_capacity == cap0 and scene._capacity_unshrunk is None
+    replay = scene.make_graphed_step('geo', opt, pool, warmup=3)
+    for i in range(2 * S.OVERFLOW_CHECK_EVERY):
+        replay(1e-2, 0.5)
+    scene._poll_health(force=True)
+    c2 = scene.sample_counters.tolist()
+    assert c2[5] == 0, f'{c2[5]} steps of the new phase were skipped for truncation'
+    assert c2[2] - c[2] == 3 + 2 * S.OVERFLOW_CHECK_EVERY          # every step of the new phase was taken

@@ -1,5 +1,5 @@
 """perf_hashgrid_bwd (fixed-point owners, capacity 1 M rows) against the LIVE sample count: what the reference-faithful step (16-35 k live
-samples) pays in fixed cost.  Run under rocprofv3 --kernel-trace (tools/exp/r05_call15.sh folds the trace by group)."""
+samples) pays in fixed cost.  Run under rocprofv3 --kernel-trace (profiles/r05_gpurun_calls.md, call 15, folds the trace by group)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Fold the config-5 PMC passes (tools/exp/r05_call1.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs, of
+"""Fold the config-5 PMC passes (profiles/r05_gpurun_calls.md, call 1: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs, of
 `python tools/config5.py --pano-log2 28 30 --pano-batches 8`) into profiles/r05_config5_pmc.json -- HBM bytes per launch of the
 L = 20 encode kernel at each table size -- and copy the raw CSVs next to it (profiles/r05_raw/).  bench.py's `config5` block
 reads the fold for `roofline.traffic` / `moved_frac`.
