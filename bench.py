@@ -314,23 +314,27 @@ def config5_block(args):
     4096x2048 panorama x 256 samples per ray through both L = 20 fields whose 16-bit tables exceed every cache (T = 2^28: 9.2 GiB
     per encoder; 2^30: 31 GiB, 64-bit entry offsets), NeRFOCCRenderer.render per batch of 4 rows, + compositing.  Per table size:
     ray-samples/s and the encode kernel's algorithmic and MOVED fraction of the HBM peak (the latter from the committed
-    rocprofv3 PMC pass of the same batches, profiles/r05_config5_pmc.json).  tests/test_gpu_config5.py checks the same workload
-    through size-independent properties."""
+    rocprofv3 PMC pass of the same batches, profiles/r06_config5_pmc.json).  Each table size TWICE: with tcnn's table layout
+    (`T<k>`) and with the opt-in line-local layout (`T<k>_line_local`, perf_amd.grid.GridConfig: no reference result exists for
+    these grids, the layout is this build's to choose).  tests/test_gpu_config5.py checks the same workload through
+    size-independent properties."""
     from perf_amd import panorama as C
     pmc = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r05_config5_pmc.json')))
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r06_config5_pmc.json')))
     except Exception:      # noqa: BLE001
         pass
     out = {}
     for log2_t in args.config5_log2:
-        torch.cuda.empty_cache()
-        free, _total = torch.cuda.mem_get_info()
-        need = 2 * (C.LEVELS5 << (log2_t + 2)) + (8 << 30)            # upper bound: two encoders of L x 2^T entries x 2 x 2 B, + working set
-        if need > free:
-            out[f'T{log2_t}'] = {'skipped': f'needs ~{need >> 30} GiB, {free >> 30} GiB free'}
-            continue
-        out[f'T{log2_t}'] = C.render_panorama_block(log2_t, pmc=pmc)
+        for layout in ('tcnn', 'line_local'):
+            key = f'T{log2_t}' + ('' if layout == 'tcnn' else '_' + layout)
+            torch.cuda.empty_cache()
+            free, _total = torch.cuda.mem_get_info()
+            need = 2 * (C.LEVELS5 << (log2_t + 2)) + (8 << 30)            # upper bound: two encoders of L x 2^T entries x 2 x 2 B, + working set
+            if need > free:
+                out[key] = {'skipped': f'needs ~{need >> 30} GiB, {free >> 30} GiB free'}
+                continue
+            out[key] = C.render_panorama_block(log2_t, pmc=pmc, layout=layout)
     return out
 
 

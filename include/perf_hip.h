@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 8
+#define PERF_ABI_VERSION 9
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -64,6 +64,16 @@ extern "C" {
 
 #define PERF_MAX_LEVELS 24
 
+/* Table layout of a grid.  TCNN: tiny-cuda-nn's -- what every grid of the reference uses (modules/fields/ngp_nerf.py:96-134), the
+ * only layout the gradient / second-order / fused entry points accept.  LINE_LOCAL: opt-in, inference only (perf_hashgrid_fwd,
+ * perf_hashgrid_corners, perf_field_infer), for grids the reference never defines (BASELINE.json configs[4]: L = 20 tables sized to
+ * HBM): a level with local[l] != 0 stores the vertices of a 4 x 4 x 2 block as one 128-byte line (entry x%4 + 4 (y%4) + 16 (z%2)),
+ * the blocks of a super-block of 2^sb_shift[0] x 2^sb_shift[1] x 2^sb_shift[2] vertices contiguously (x-major), and addresses the
+ * SUPER-BLOCK densely (sx + sy*nsx[l] + sz*nsxy[l], hashed[l] == 0) or by the prime-XOR hash of its coordinates modulo
+ * size[l] >> (sb_shift[0] + sb_shift[1] + sb_shift[2]).  Levels with local[l] == 0 keep the TCNN rule. */
+#define PERF_LAYOUT_TCNN 0
+#define PERF_LAYOUT_LINE_LOCAL 1
+
 /* Geometry of a multiresolution hash grid (tcnn "HashGrid", 3 input dims, 2 features/level).
  * Entry e of level l lives at table[(offset[l] + e) * 2 + f].  Levels with hashed[l]==0 are
  * dense (index x + y*res + z*res^2), the others use the prime-XOR hash; both modulo size[l]. */
@@ -75,6 +85,11 @@ typedef struct perf_grid_desc {
     uint32_t size[PERF_MAX_LEVELS];
     uint64_t offset[PERF_MAX_LEVELS];   /* 64-bit: tables beyond 2^32 entries (BASELINE config 5) */
     uint32_t hashed[PERF_MAX_LEVELS];
+    int32_t layout;                /* PERF_LAYOUT_* */
+    uint32_t sb_shift[3];          /* LINE_LOCAL: log2 vertices of a super-block along x, y (>= 2) and z (>= 1) */
+    uint32_t local[PERF_MAX_LEVELS];    /* LINE_LOCAL: level stored line-local */
+    uint32_t nsx[PERF_MAX_LEVELS];      /* dense line-local levels: super-blocks per row ... */
+    uint32_t nsxy[PERF_MAX_LEVELS];     /* ... and per z-slice */
 } perf_grid_desc;
 
 /* Bias-free 64-wide MLP (tcnn "FullyFusedMLP"): n_levels*2 inputs (zero padded to a multiple

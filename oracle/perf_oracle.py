@@ -108,35 +108,64 @@ class GridLevels:
     offset: np.ndarray     # u32 [L]  first entry of the level
     hashed: np.ndarray     # bool [L]
     total: int             # entries in all levels
+    layout: str = 'tcnn'   # 'tcnn' | 'line_local' (see grid_levels)
+    sb_shift: tuple = (6, 6, 7)
+    local: np.ndarray = None   # bool [L]  level stored line-local
+    nsx: np.ndarray = None     # u32 [L]   dense line-local levels: super-blocks per row
+    nsxy: np.ndarray = None    # u32 [L]   ... per z-slice
 
     @property
     def n_params(self):
         return self.total * self.n_feat
 
 
+LOCAL_MIN_RES = 64          # line_local grids: levels of at least this resolution are stored line-local
+
+
 def grid_levels(n_levels=16, n_feat=2, log2_hashmap_size=18, base_resolution=16,
-                per_level_scale=1.4472692012786865) -> GridLevels:
+                per_level_scale=1.4472692012786865, layout='tcnn', sb_shift=(6, 6, 7)) -> GridLevels:
     """Per-level geometry of a tcnn HashGrid (A.1): scale_l = N_min*b^l - 1 (fp32),
-    res_l = ceil(scale_l)+1, size_l = min(align8(res_l^3), 2^T), offsets = prefix sums."""
+    res_l = ceil(scale_l)+1, size_l = min(align8(res_l^3), 2^T), offsets = prefix sums.
+
+    layout='line_local' (NOT tcnn's; an opt-in table layout of this build for grids the reference never defines -- BASELINE
+    config 5's L = 20 tables sized to HBM, inference only; no reference result exists to stay compatible with): levels with
+    res >= LOCAL_MIN_RES store the vertices of a 4 x 4 x 2 block as ONE 128-byte line (entry x%4 + 4 (y%4) + 16 (z%2)),
+    the blocks of a 2^sx x 2^sy x 2^sz-vertex SUPER-BLOCK contiguously (x-major; default 64 x 64 x 128 vertices = 2 MiB), and
+    address the super-block either densely (index sx + sy*nx + sz*nx*ny when all n_d = (res + 2^s_d) >> s_d super-blocks per
+    dimension fit 2^T entries) or through tcnn's prime-XOR hash OF THE SUPER-BLOCK COORDINATES modulo the number of
+    super-blocks in 2^T entries.  A sample's eight corners then lie in (1+1/4)(1+1/4)(1+1/2) = 2.3 lines of ONE page instead
+    of four lines on four pages.  Coarser levels keep tcnn's rule.  Same scale / res / interpolation as tcnn's grid."""
+    assert layout in ('tcnn', 'line_local')
+    per_sb = 1 << sum(sb_shift)
     log2_b = F32(np.log2(F32(per_level_scale)))
     scale = np.zeros(n_levels, F32)
     res = np.zeros(n_levels, np.uint32)
     size = np.zeros(n_levels, np.uint32)
     offset = np.zeros(n_levels, np.uint64)
     hashed = np.zeros(n_levels, bool)
+    local = np.zeros(n_levels, bool)
+    nsx = np.zeros(n_levels, np.uint32)
+    nsxy = np.zeros(n_levels, np.uint32)
     total = 0
     for l in range(n_levels):
         e = F32(np.exp2(np.float64(F32(l) * log2_b)))
         s = F32(F32(e * F32(base_resolution)) - F32(1.0))
         r = int(math.ceil(float(s))) + 1
-        full = r ** 3
-        n = min(full, U32_MASK // 2)
-        n = (n + 7) // 8 * 8
-        n = min(n, 1 << log2_hashmap_size)
+        if layout == 'line_local' and r >= LOCAL_MIN_RES:
+            nd = [(r + (1 << sh)) >> sh for sh in sb_shift]          # super-blocks per dimension: vertices 0..res
+            full = nd[0] * nd[1] * nd[2] * per_sb
+            n = min(full, 1 << log2_hashmap_size)
+            assert n >= per_sb, 'line_local: 2^log2_hashmap_size must hold at least one super-block'
+            local[l], nsx[l], nsxy[l] = True, nd[0], nd[0] * nd[1]
+        else:
+            full = r ** 3
+            n = min(full, U32_MASK // 2)
+            n = (n + 7) // 8 * 8
+            n = min(n, 1 << log2_hashmap_size)
         scale[l], res[l], size[l], offset[l] = s, r, n, total
         hashed[l] = full > n
         total += n
-    return GridLevels(n_levels, n_feat, scale, res, size, offset, hashed, total)
+    return GridLevels(n_levels, n_feat, scale, res, size, offset, hashed, total, layout, tuple(sb_shift), local, nsx, nsxy)
 
 
 def _quant(t: torch.Tensor, quant):
@@ -184,6 +213,18 @@ def grid_corner_indices(x: np.ndarray, lv: GridLevels, level: int):
         cx = (gi[:, 0] + (c & 1)) & U32_MASK
         cy = (gi[:, 1] + ((c >> 1) & 1)) & U32_MASK
         cz = (gi[:, 2] + ((c >> 2) & 1)) & U32_MASK
+        if lv.local is not None and lv.local[level]:
+            shx, shy, shz = lv.sb_shift
+            per_sb = 1 << (shx + shy + shz)
+            sx, sy, sz = cx >> shx, cy >> shy, cz >> shz
+            if lv.hashed[level]:
+                slot = (sx ^ ((sy * PRIME_Y) & U32_MASK) ^ ((sz * PRIME_Z) & U32_MASK)) % (n // per_sb)
+            else:
+                slot = sx + sy * int(lv.nsx[level]) + sz * int(lv.nsxy[level])
+            blk = ((cx >> 2) & ((1 << (shx - 2)) - 1)) + (((cy >> 2) & ((1 << (shy - 2)) - 1)) << (shx - 2)) \
+                + (((cz >> 1) & ((1 << (shz - 1)) - 1)) << (shx - 2 + shy - 2))
+            idx[:, c] = (slot * per_sb + (blk << 5) + (cx & 3) + ((cy & 3) << 2) + ((cz & 1) << 4)).astype(np.uint32)
+            continue
         if lv.hashed[level]:
             h = cx ^ ((cy * PRIME_Y) & U32_MASK) ^ ((cz * PRIME_Z) & U32_MASK)
         else:

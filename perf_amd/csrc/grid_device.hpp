@@ -15,9 +15,39 @@ struct GridParams {
     uint32_t hashed[PERF_MAX_LEVELS];
 };
 
-static int fill_params(const perf_grid_desc* g, GridParams* p) {
+// the line-local part of a descriptor (PERF_LAYOUT_LINE_LOCAL), handed to the kernels that understand it beside GridParams
+struct GridLocal {
+    uint32_t any;                       // 1: some level is line-local
+    uint32_t shx, shy, shz;
+    uint32_t local[PERF_MAX_LEVELS];
+    uint32_t nsx[PERF_MAX_LEVELS];
+    uint32_t nsxy[PERF_MAX_LEVELS];
+};
+
+// loc == nullptr: the caller only understands tcnn's layout (gradients, second order, the fused encode + MLP kernel, the
+// 16-level forward kernel): a line-local descriptor is refused
+static int fill_params(const perf_grid_desc* g, GridParams* p, GridLocal* loc = nullptr) {
     PERF_REQUIRE(g != nullptr, "grid desc is NULL");
     PERF_REQUIRE(g->n_levels >= 1 && g->n_levels <= PERF_MAX_LEVELS, "n_levels %d out of range", g->n_levels);
+    PERF_REQUIRE(g->layout == PERF_LAYOUT_TCNN || g->layout == PERF_LAYOUT_LINE_LOCAL, "unknown table layout %d", (int)g->layout);
+    PERF_REQUIRE(g->layout == PERF_LAYOUT_TCNN || loc != nullptr,
+                 "this entry point takes tcnn-layout grids only (PERF_LAYOUT_LINE_LOCAL is inference only: perf_hashgrid_fwd, perf_hashgrid_corners, perf_field_infer)");
+    if (loc) {
+        loc->any = 0; loc->shx = loc->shy = 2; loc->shz = 1;
+        for (int l = 0; l < PERF_MAX_LEVELS; ++l) loc->local[l] = loc->nsx[l] = loc->nsxy[l] = 0;
+        if (g->layout == PERF_LAYOUT_LINE_LOCAL) {
+            loc->shx = g->sb_shift[0]; loc->shy = g->sb_shift[1]; loc->shz = g->sb_shift[2];
+            PERF_REQUIRE(loc->shx >= 2 && loc->shy >= 2 && loc->shz >= 1 && loc->shx + loc->shy + loc->shz <= 24, "bad super-block shape");
+            const uint32_t per_sb = 1u << (loc->shx + loc->shy + loc->shz);
+            for (int l = 0; l < g->n_levels; ++l) {
+                loc->local[l] = g->local[l] ? 1u : 0u; loc->nsx[l] = g->nsx[l]; loc->nsxy[l] = g->nsxy[l];
+                if (!g->local[l]) continue;
+                loc->any = 1;
+                PERF_REQUIRE(g->size[l] >= per_sb && g->size[l] % per_sb == 0, "line-local level %d: size %u is not a whole number of super-blocks", l, g->size[l]);
+                if (g->hashed[l]) { const uint32_t ns = g->size[l] / per_sb; PERF_REQUIRE((ns & (ns - 1)) == 0, "line-local hashed level %d: %u super-blocks is not a power of two", l, ns); }
+            }
+        }
+    }
     p->n_levels = g->n_levels;
     p->interpolation = g->interpolation;
     for (int l = 0; l < PERF_MAX_LEVELS; ++l) {
@@ -25,7 +55,8 @@ static int fill_params(const perf_grid_desc* g, GridParams* p) {
         p->offset[l] = g->offset[l]; p->hashed[l] = g->hashed[l];
         if (l < g->n_levels) {
             PERF_REQUIRE(g->size[l] > 0, "level %d has size 0", l);
-            if (g->hashed[l]) PERF_REQUIRE((g->size[l] & (g->size[l] - 1)) == 0, "hashed level %d size %u is not a power of two", l, g->size[l]);
+            if (g->hashed[l] && !(g->layout == PERF_LAYOUT_LINE_LOCAL && g->local[l]))
+                PERF_REQUIRE((g->size[l] & (g->size[l] - 1)) == 0, "hashed level %d size %u is not a power of two", l, g->size[l]);
         }
     }
     return PERF_OK;
@@ -72,6 +103,32 @@ __device__ __forceinline__ Corners corners_of(float x, float y, float z, float s
             c.idx[k] = i;
         }
     }
+    return c;
+}
+
+// ---- PERF_LAYOUT_LINE_LOCAL (include/perf_hip.h): entry index of vertex (vx, vy, vz) of a line-local level ----------------------
+__device__ __forceinline__ uint32_t local_vertex_index(const GridLocal& gl, int l, uint32_t size, bool hashed, uint32_t vx, uint32_t vy, uint32_t vz) {
+    const uint32_t shx = gl.shx, shy = gl.shy, shz = gl.shz;
+    const uint32_t sx = vx >> shx, sy = vy >> shy, sz = vz >> shz;
+    const uint32_t sh = shx + shy + shz;
+    const uint32_t slot = hashed ? ((sx ^ (sy * kPrimeY) ^ (sz * kPrimeZ)) & ((size >> sh) - 1u)) : (sx + sy * gl.nsx[l] + sz * gl.nsxy[l]);
+    const uint32_t blk = ((vx >> 2) & ((1u << (shx - 2)) - 1u)) + (((vy >> 2) & ((1u << (shy - 2)) - 1u)) << (shx - 2))
+                       + (((vz >> 1) & ((1u << (shz - 1)) - 1u)) << (shx - 2 + shy - 2));
+    return (slot << sh) + (blk << 5) + (vx & 3u) + ((vy & 3u) << 2) + ((vz & 1u) << 4);
+}
+
+// corners_of for either layout
+__device__ __forceinline__ Corners corners_of_any(const GridParams& gp, const GridLocal& gl, int l, float x, float y, float z) {
+    if (!gl.local[l]) return corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+    Corners c;
+    const float s = gp.scale[l];
+    const float px = grid_pos(x, s), py = grid_pos(y, s), pz = grid_pos(z, s);
+    const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+    c.f[0] = px - flx; c.f[1] = py - fly; c.f[2] = pz - flz;
+    const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+    c.cell[0] = gx; c.cell[1] = gy; c.cell[2] = gz;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.idx[k] = local_vertex_index(gl, l, gp.size[l], gp.hashed[l] != 0, gx + (uint32_t)(k & 1), gy + (uint32_t)((k >> 1) & 1), gz + (uint32_t)(k >> 2));
     return c;
 }
 

@@ -176,6 +176,84 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, con
     }
 }
 
+
+// ---- forward encode of DEEP grids (L > 16: BASELINE config 5's L = 20 tables sized to HBM) and of line-local tables ------------
+// The tables of such a grid exceed every cache, so there is nothing to pin: what the level-group kernel above pins to an XCD --
+// levels {g, 15-g, 16+g} one after the other -- leaves XCDs 0-3 with two HBM-bound levels each and XCDs 4-7 with none (measured,
+// tools/exp/c5_encode_probe.hip, 4.2 M panorama samples: 2.36 ms at T = 2^28, 5.29 ms at 2^30).  Here a workgroup is ONE level of
+// one 256-sample chunk, and the work items are dealt so that
+//   * XCD x = b % 8 serves level l for EIGHT CONSECUTIVE chunks (= neighbouring rays of a panorama batch) back to back: their
+//     gathers meet in one L2 (a level's consecutive rays share cells at the coarse levels and 128-byte lines at the fine ones);
+//   * which eighth of a 64-chunk stripe an XCD serves rotates with the level ((x - l) & 7): every XCD serves every level for an
+//     eighth of the samples -- balance whatever a level costs.                                      1.66 / 2.44 ms, tcnn layout
+// Line-local levels (PERF_LAYOUT_LINE_LOCAL) fetch, per (y, z) corner pair, the ALIGNED 16-byte x-run that holds the cell's first
+// vertex -- both x corners unless the cell starts at a block's last vertex (a quarter of the lanes: a 4-byte gather for those) --
+// i.e. 4 + 4 * 1/4 L1 look-ups per lane instead of 8.                                 1.01 / 1.13 ms with 64 x 64 x 128 super-blocks
+// Placement is a speed assumption only; results do not depend on it.
+constexpr int64_t kBigMaxStripes = 1 << 16;
+
+template <typename T16>
+__global__ __launch_bounds__(256) void hashgrid_fwd_big_kernel(GridParams gp, GridLocal gl, const float* __restrict__ x01,
+                                                               const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
+                                                               int64_t n, const int64_t* __restrict__ n_dev, int64_t grid_stripes) {
+    const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
+    const int64_t nchunks = (n_live + 255) >> 8;
+    const int L = gp.n_levels;
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int64_t j = (int64_t)(blockIdx.x >> 3);
+    const int cr = (int)(j & 7);
+    const int64_t t = j >> 3;
+    const int l = (int)(t % L);
+    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+    const uint32_t* tl = table + gp.offset[l];
+    for (int64_t Q = t / L; (Q << 6) < nchunks; Q += grid_stripes) {
+        const int64_t chunk = (((Q << 3) + ((xcd - l) & 7)) << 3) + cr;
+        const int64_t i = chunk * 256 + threadIdx.x;
+        if (i >= n_live) continue;
+        const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+        uint32_t v[8];
+        float f[3];
+        if (!gl.local[l]) {
+            const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tl[c.idx[k]];
+            f[0] = c.f[0]; f[1] = c.f[1]; f[2] = c.f[2];
+        } else {
+            const float s = gp.scale[l];
+            const float px = grid_pos(x, s), py = grid_pos(y, s), pz = grid_pos(z, s);
+            const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+            f[0] = px - flx; f[1] = py - fly; f[2] = pz - flz;
+            const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+            const uint32_t lx = gx & 3u;
+            const uint32_t size = gp.size[l];
+            const bool hashed = gp.hashed[l] != 0;
+            uint4 q[4];
+            uint32_t e[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)          // (an x-run of four vertices is 16-byte aligned by construction)
+                q[k] = *reinterpret_cast<const uint4*>(tl + local_vertex_index(gl, l, size, hashed, gx & ~3u, gy + (uint32_t)(k & 1), gz + (uint32_t)(k >> 1)));
+            if (lx == 3u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = tl[local_vertex_index(gl, l, size, hashed, gx + 1u, gy + (uint32_t)(k & 1), gz + (uint32_t)(k >> 1))];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[2 * k] = lx == 0u ? q[k].x : (lx == 1u ? q[k].y : (lx == 2u ? q[k].z : q[k].w));
+                v[2 * k + 1] = lx == 0u ? q[k].y : (lx == 1u ? q[k].z : (lx == 2u ? q[k].w : e[k]));
+            }
+        }
+        float w[8];
+        corner_weights(f, smooth, w);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a0 = fmaf(w[k], T16::lo(v[k]), a0);
+            a1 = fmaf(w[k], T16::hi(v[k]), a1);
+        }
+        feat[(int64_t)l * n + i] = T16::pack(a0, a1);
+    }
+}
+
 // Two tables with the SAME grid geometry (PeRF's density and colour fields, ngp_nerf.py:96-134) evaluated at the
 // same points: corner indices and weights are computed once, 16 gathers are in flight per (sample, level).
 template <typename T16>
@@ -214,12 +292,12 @@ __global__ __launch_bounds__(256) void hashgrid_fwd2_kernel(GridParams gp, const
 
 // corner table indices (absolute entry index, level offset included) of every (level, sample): the integer half of
 // the encoding, exported so that arbitrarily-often differentiable compositions can be built on top of it
-__global__ __launch_bounds__(256) void hashgrid_corners_kernel(GridParams gp, const float* __restrict__ x01,
+__global__ __launch_bounds__(256) void hashgrid_corners_kernel(GridParams gp, GridLocal gl, const float* __restrict__ x01,
                                                                int32_t* __restrict__ idx_out, int64_t n) {
     const int l = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || l >= gp.n_levels) return;
-    const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+    const Corners c = corners_of_any(gp, gl, l, x01[3 * i], x01[3 * i + 1], x01[3 * i + 2]);
     int32_t* o = idx_out + ((int64_t)l * n + i) * 8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = (int32_t)(gp.offset[l] + c.idx[k]);
@@ -261,11 +339,26 @@ using namespace perf;
 extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, const void* table16,
                                  void* feat16, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
     GridParams gp;
-    int rc = fill_params(grid, &gp);
+    GridLocal gl;
+    int rc = fill_params(grid, &gp, &gl);
     if (rc) return rc;
     PERF_REQUIRE(n >= 0 && n < (int64_t(1) << 31) * 16, "n out of range");
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(x01 && table16 && feat16, "NULL pointer");
+    if (gl.any || gp.n_levels > 16) {
+        // deep grids and line-local tables: one level per workgroup, XCD-stable balanced (hashgrid_fwd_big_kernel)
+        PERF_REQUIRE(!gl.any || ((uintptr_t)table16 & 15u) == 0, "perf_hashgrid_fwd: a line-local table must be 16-byte aligned");
+        int64_t stripes = div_up(div_up(n, 256), 64);
+        if (stripes > kBigMaxStripes) stripes = kBigMaxStripes;
+        dim3 g((unsigned)(stripes * gp.n_levels * 64)), b(256);
+        if (dtype == PERF_DTYPE_BF16)
+            hipLaunchKernelGGL(hashgrid_fwd_big_kernel<BF16>, g, b, 0, as_stream(stream), gp, gl, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes);
+        else if (dtype == PERF_DTYPE_FP16)
+            hipLaunchKernelGGL(hashgrid_fwd_big_kernel<FP16>, g, b, 0, as_stream(stream), gp, gl, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes);
+        else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
+        PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
+        return PERF_OK;
+    }
     // level group <-> XCD pinning only pays when every one of the 8 groups has a level (L >= 15); a grid of a few levels
     // (a rank's slice of a level-sharded table, the 5-level proposal field) would otherwise keep 1-3 XCDs busy
     const int xcd_affinity = gp.n_levels >= 15 ? 1 : 0;
@@ -318,12 +411,13 @@ extern "C" int perf_hashgrid_fwd2(const perf_grid_desc* grid, const float* x01, 
 
 extern "C" int perf_hashgrid_corners(const perf_grid_desc* grid, const float* x01, int32_t* idx, int64_t n, void* stream) {
     GridParams gp;
-    int rc = fill_params(grid, &gp);
+    GridLocal gl;
+    int rc = fill_params(grid, &gp, &gl);
     if (rc) return rc;
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(x01 && idx, "NULL pointer");
     PERF_REQUIRE(gp.offset[gp.n_levels - 1] + gp.size[gp.n_levels - 1] < ((uint64_t)1 << 31), "perf_hashgrid_corners: table too large for int32 entries");
-    hipLaunchKernelGGL(hashgrid_corners_kernel, dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream), gp,
+    hipLaunchKernelGGL(hashgrid_corners_kernel, dim3((unsigned)div_up(n, 256), gp.n_levels), dim3(256), 0, as_stream(stream), gp, gl,
                        x01, idx, n);
     PERF_LAUNCH_CHECK("perf_hashgrid_corners");
     return PERF_OK;

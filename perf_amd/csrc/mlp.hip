@@ -139,7 +139,7 @@ extern "C" int perf_field_infer(const perf_grid_desc* grid, const perf_mlp_desc*
     PERF_REQUIRE(mlp->n_levels == grid->n_levels, "perf_field_infer: the MLP takes %d levels, the grid has %d", (int)mlp->n_levels, (int)grid->n_levels);
     if (n == 0) return PERF_OK;
     static const int64_t fused_max = getenv("PERF_FUSED_MAX_SAMPLES") ? atoll(getenv("PERF_FUSED_MAX_SAMPLES")) : kFusedMaxSamples;
-    if (n <= fused_max && grid->n_levels <= 16) {
+    if (n <= fused_max && grid->n_levels <= 16 && grid->layout == PERF_LAYOUT_TCNN) {
         int nh, ks;
         int rc = check_mlp(mlp, &nh, &ks);
         if (rc) return rc;

@@ -13,6 +13,7 @@ import numpy as np
 from . import _lib
 
 _F = np.float32
+LOCAL_MIN_RES = 64          # line_local grids: levels of at least this resolution are stored line-local
 
 
 @dataclass
@@ -23,11 +24,21 @@ class GridConfig:
     base_resolution: int = 16
     per_level_scale: float = 1.4472692012786865
     interpolation: str = 'Linear'
+    # Table layout.  'tcnn': tiny-cuda-nn's (dense x + y res + z res^2, or the prime-XOR hash of the vertex) -- the only layout of
+    # every grid the reference defines.  'line_local' (opt-in, inference only; BASELINE config 5's L = 20 tables sized to HBM, for
+    # which no reference result exists): levels with res >= LOCAL_MIN_RES store a 4 x 4 x 2 block of vertices as one 128-byte
+    # line, the blocks of a 2^sb_shift-vertex super-block (default 64 x 64 x 128 = 2 MiB) contiguously, and hash (or densely
+    # index) the SUPER-BLOCK: a sample's eight corners lie in ~2.3 lines of one page.  include/perf_hip.h PERF_LAYOUT_*.
+    layout: str = 'tcnn'
+    sb_shift: tuple = (6, 6, 7)
     scale: np.ndarray = field(init=False, repr=False)
     res: np.ndarray = field(init=False, repr=False)
     size: np.ndarray = field(init=False, repr=False)
     offset: np.ndarray = field(init=False, repr=False)
     hashed: np.ndarray = field(init=False, repr=False)
+    local: np.ndarray = field(init=False, repr=False)
+    nsx: np.ndarray = field(init=False, repr=False)
+    nsxy: np.ndarray = field(init=False, repr=False)
     total: int = field(init=False)
 
     def __post_init__(self):
@@ -44,15 +55,32 @@ class GridConfig:
         self.size = np.zeros(L, np.uint32)
         self.offset = np.zeros(L, np.uint64)           # 64-bit: tables beyond 2^32 entries (tcnn's own offsets are uint32)
         self.hashed = np.zeros(L, np.uint32)
+        self.local = np.zeros(L, np.uint32)
+        self.nsx = np.zeros(L, np.uint32)
+        self.nsxy = np.zeros(L, np.uint32)
+        if self.layout not in ('tcnn', 'line_local'):
+            raise ValueError(f'unsupported table layout {self.layout!r}')
+        self.sb_shift = tuple(int(v) for v in self.sb_shift)
+        if len(self.sb_shift) != 3 or self.sb_shift[0] < 2 or self.sb_shift[1] < 2 or self.sb_shift[2] < 1 or sum(self.sb_shift) > 24:
+            raise ValueError(f'sb_shift {self.sb_shift}: a super-block holds at least one 4 x 4 x 2 block and at most 2^24 entries')
+        per_sb = 1 << sum(self.sb_shift)
         total = 0
         for l in range(L):
             growth = _F(np.exp2(np.float64(_F(l) * log2_b)))
             s = _F(_F(growth * _F(self.base_resolution)) - _F(1.0))
             r = int(math.ceil(float(s))) + 1
-            cells = r ** 3
-            n = min(cells, 0xFFFFFFFF // 2)
-            n = -(-n // 8) * 8
-            n = min(n, 1 << self.log2_hashmap_size)
+            if self.layout == 'line_local' and r >= LOCAL_MIN_RES:
+                nd = [(r + (1 << sh)) >> sh for sh in self.sb_shift]          # super-blocks per dimension (vertices 0..res)
+                cells = nd[0] * nd[1] * nd[2] * per_sb
+                n = min(cells, 1 << self.log2_hashmap_size)
+                if n < per_sb:
+                    raise ValueError(f'line_local: 2^{self.log2_hashmap_size} entries hold no {self.sb_shift} super-block')
+                self.local[l], self.nsx[l], self.nsxy[l] = 1, nd[0], nd[0] * nd[1]
+            else:
+                cells = r ** 3
+                n = min(cells, 0xFFFFFFFF // 2)
+                n = -(-n // 8) * 8
+                n = min(n, 1 << self.log2_hashmap_size)
             self.scale[l], self.res[l], self.size[l], self.offset[l] = s, r, n, total
             self.hashed[l] = 1 if cells > n else 0
             total += n
@@ -81,7 +109,7 @@ class GridConfig:
     def desc(self) -> '_lib.GridDesc':
         """The C-ABI descriptor (perf_grid_desc).  Built once per configuration: filling the ctypes arrays costs ~30 us of host
         time, and an eager step passes it to half a dozen entry points (the library only reads it)."""
-        key = (self.n_levels, self.interpolation, self.log2_hashmap_size, self.base_resolution, self.per_level_scale)
+        key = (self.n_levels, self.interpolation, self.log2_hashmap_size, self.base_resolution, self.per_level_scale, self.layout, self.sb_shift)
         cached = self.__dict__.get('_desc')
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -91,6 +119,10 @@ class GridConfig:
         for l in range(self.n_levels):
             d.scale[l] = float(self.scale[l]); d.res[l] = int(self.res[l]); d.size[l] = int(self.size[l])
             d.offset[l] = int(self.offset[l]); d.hashed[l] = int(self.hashed[l])
+            d.local[l] = int(self.local[l]); d.nsx[l] = int(self.nsx[l]); d.nsxy[l] = int(self.nsxy[l])
+        d.layout = _lib.LAYOUT_LINE_LOCAL if self.layout == 'line_local' else _lib.LAYOUT_TCNN
+        for k in range(3):
+            d.sb_shift[k] = self.sb_shift[k]
         self.__dict__['_desc'] = (key, d)
         return d
 

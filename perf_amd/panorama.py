@@ -66,7 +66,7 @@ def render_rows(nerf, est, rend, row0, nrows, rows_per_batch=4, spp=SPP5, height
 
 
 def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W5, levels=LEVELS5, dtype='fp16', timing_batches=8,
-                          pmc=None):
+                          pmc=None, layout='tcnn'):
     """BASELINE config 5 on ONE GPU, whole panorama: height x width rays x spp samples through both L-level fields (16-bit tables
     of 2^log2_t entries per hashed level, inference only: perf_amd.fields.InferenceNeRF) + compositing.  -> dict for bench.py's
     `config5` block: ray-samples/s, the encode kernel's algorithmic fraction of the HBM peak, and -- from the committed PMC pass
@@ -74,7 +74,8 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
     from perf_amd import ops
     from perf_amd.fields import InferenceNeRF
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    nerf = InferenceNeRF([-1., -1, -1, 1, 1, 1], n_levels=levels, log2_hashmap_size=log2_t, per_level_scale=per_level_scale(levels), dtype=dtype)
+    nerf = InferenceNeRF([-1., -1, -1, 1, 1, 1], n_levels=levels, log2_hashmap_size=log2_t, per_level_scale=per_level_scale(levels), dtype=dtype,
+                         layout=layout)
     est, rend = make_renderer(spp)
     torch.cuda.synchronize(); t_build = time.perf_counter() - t0
     counters = ops.step_counters('cuda')
@@ -99,7 +100,7 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
     blk = {'what': f'BASELINE config 5 on one GPU: {width}x{height} panorama x {spp} samples/ray, L = {levels} hash grids up to resolution '
                    f'{int(FINEST5)}, T = 2^{log2_t} ({dtype} tables only: inference), both fields + compositing through NeRFOCCRenderer.render, '
                    f'{height // rows_per_batch} batches of {rows_per_batch * width} rays, fresh initialisation (nothing pruned), device-side counts',
-           'log2_hashmap_size': log2_t, 'table_GiB_per_encoder': round(nerf.table_bytes() / 2 ** 30, 2),
+           'log2_hashmap_size': log2_t, 'table_layout': layout, 'table_GiB_per_encoder': round(nerf.table_bytes() / 2 ** 30, 2),
            'table_entries': int(nerf.grid.total), 'offsets_exceed_32_bit': bool(nerf.grid.n_params >= 2 ** 32),
            'build_seconds': round(t_build, 3), 'seconds_per_panorama': round(el, 4), 'rays_per_s': height * width / el,
            'ray_samples_per_s': kept / el, 'marched_samples': marched, 'kept_samples': kept,
@@ -113,7 +114,7 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
                                       '(HIP events); whole_render = 2 encodes x 640 B x kept ray-samples / wall time of the panorama'},
            'kernel_ms_per_batch': {k: round(n_ * ms / nb, 3) for k, (n_, ms) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:6]}}
     if pmc:
-        row = (pmc.get('tables') or {}).get(f'T{log2_t}')
+        row = (pmc.get('tables') or {}).get(f'T{log2_t}' + ('' if layout == 'tcnn' else '_' + layout))
         if row and row.get('samples_per_launch') == per_launch:
             moved = row['hbm_bytes_per_launch']
             blk['roofline']['traffic'] = moved

@@ -1,6 +1,7 @@
 """BASELINE config 5 at its stated size on ONE GPU (4096x2048 panorama, 256 samples per ray, L = 20 hash grids whose 16-bit
 tables no cache holds: T = 2^28 -> 9.2 GiB per encoder, parameter offsets beyond 32 bit; T = 2^30 -> 31 GiB per encoder, ENTRY
-offsets beyond 32 bit) -- the same workload bench.py's `config5` block times (tools/config5.py), checked through
+offsets beyond 32 bit) -- the same workload bench.py's `config5` block times (perf_amd/panorama.py), with tcnn's table layout and
+with the opt-in line-local one (perf_amd.grid.GridConfig; values against the oracle: tests/test_gpu_ops.py), checked through
 size-independent properties: packed bookkeeping (sortedness, counts), compositing bounds, determinism, and equality of a
 row shard rendered on its own with the same rows of the full render (the multi-GPU eval partitioning of SURVEY.md 8(e):
 rank r of G renders rows [r H/G, (r+1) H/G), no communication).  The fields are NOT at their fresh initialisation here
@@ -14,11 +15,11 @@ H, W, SPP = 2048, 4096, 256
 TABLE_SCALE, DENSITY_BIAS = 4.0, 4.0      # tables U(-4, 4), sigma = exp(y + 4): y ~ N(0, 1), optical depth ~ 80 per ray -- rays end early
 
 
-def _field(log2_t):
+def _field(log2_t, layout='tcnn'):
     from perf_amd.fields import InferenceNeRF
     from perf_amd import panorama as C
     nerf = InferenceNeRF([-1., -1, -1, 1, 1, 1], n_levels=20, log2_hashmap_size=log2_t, per_level_scale=C.per_level_scale(20),
-                         dtype='fp16', table_scale=TABLE_SCALE, density_bias=DENSITY_BIAS)
+                         dtype='fp16', table_scale=TABLE_SCALE, density_bias=DENSITY_BIAS, layout=layout)
     est, rend = C.make_renderer(SPP)
     return nerf, est, rend
 
@@ -40,11 +41,13 @@ def _check_batch(res, R):
     return n
 
 
-def test_config5_full_panorama_properties():
+@pytest.mark.parametrize('layout', ['tcnn', 'line_local'])
+def test_config5_full_panorama_properties(layout):
     """T = 2^28, the whole 4096x2048x256 panorama (2.1e9 marched ray-samples)."""
     from perf_amd import ops
     from perf_amd import panorama as C
-    nerf, est, rend = _field(28)
+    nerf, est, rend = _field(28, layout)
+    assert nerf.grid.layout == layout and (layout == 'tcnn') == (int(nerf.grid.local.sum()) == 0)
     assert nerf.grid.n_levels == 20 and nerf.grid.n_params >= 2 ** 32            # parameter offsets do not fit 32 bits
     assert int(nerf.grid.res[-1]) in (8192, 8193)
     counters = ops.step_counters('cuda')
@@ -75,11 +78,12 @@ def test_config5_full_panorama_properties():
         assert torch.equal(again[k], outs[k][r0 * W:(r0 + 16) * W]), k
 
 
-def test_config5_tables_beyond_32_bit_entry_offsets():
+@pytest.mark.parametrize('layout', ['tcnn', 'line_local'])
+def test_config5_tables_beyond_32_bit_entry_offsets(layout):
     """T = 2^30 (31 GiB per encoder, 8.4e9 entries: 64-bit level offsets in entries, not only in parameters): a band of rows
     around the equator and one at the pole, batch-size independence, bounds."""
     from perf_amd import panorama as C
-    nerf, est, rend = _field(30)
+    nerf, est, rend = _field(30, layout)
     assert nerf.grid.total >= 2 ** 32
     for r0 in (0, H // 2 - 8):
         a = C.render_rows(nerf, est, rend, r0, 16, 4, SPP, H, W)

@@ -26,7 +26,7 @@ def _grid_cfg(**kw):
 
 
 def _lv_of(cfg):
-    return O.grid_levels(cfg.n_levels, 2, cfg.log2_hashmap_size, cfg.base_resolution, cfg.per_level_scale)
+    return O.grid_levels(cfg.n_levels, 2, cfg.log2_hashmap_size, cfg.base_resolution, cfg.per_level_scale, layout=cfg.layout, sb_shift=cfg.sb_shift)
 
 
 DT = {'bf16': (torch.bfloat16, 2.0 ** -8), 'fp16': (torch.float16, 2.0 ** -11)}
@@ -695,13 +695,64 @@ def test_deep_grid_forward_20_levels(ops):
     # (the backward of such a field: test_mlp_more_than_16_levels, test_network_with_20_level_grid_forward_and_gradient)
 
 
-def test_table_beyond_32_bit_offsets(ops):
+@pytest.mark.parametrize('layout', ['tcnn', 'line_local'])
+@pytest.mark.parametrize('log2_t,sb_shift', [(15, (2, 2, 1)), (20, (3, 3, 2)), (24, (6, 6, 7))])
+def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift):
+    """The deep-grid forward kernel (one level per workgroup, XCD-stable balanced; 16-byte x-runs on line-local levels) against
+    the oracle -- corner indices bit-exact, features within an ulp of the storage type -- for tcnn's layout and for the opt-in
+    line-local one (oracle/perf_oracle.py:grid_levels), at table sizes where the line-local levels are all hashed (2^15, super-blocks
+    of one block), mixed dense / hashed (2^20) and with the shipped 64 x 64 x 128 super-blocks (2^24); ragged n, points on cell and
+    block boundaries, a device-side live count."""
+    L, b = 20, 1.3819
+    cfg = _grid_cfg(n_levels=L, log2_hashmap_size=log2_t, base_resolution=16, per_level_scale=b, layout=layout, sb_shift=sb_shift)
+    lv = _lv_of(cfg)
+    assert cfg.total == lv.total and np.array_equal(cfg.offset, lv.offset) and np.array_equal(cfg.size, lv.size)
+    if layout == 'line_local':
+        assert int(cfg.local.sum()) == int((cfg.res >= 64).sum()) > 0
+        assert log2_t == 15 or (int(((cfg.local == 1) & (cfg.hashed == 0)).sum()) > 0 and int(((cfg.local == 1) & (cfg.hashed == 1)).sum()) > 0)
+    g = torch.Generator().manual_seed(41 + log2_t)
+    n = 3001
+    x = torch.rand(n, 3, generator=g)
+    # points ON vertices of several levels (fraction 0: the cell's first vertex; x-runs that start at a block's last vertex)
+    for k, l in enumerate((5, 9, 14, 19)):
+        v = torch.randint(0, int(cfg.res[l]) - 1, (40, 3), generator=g).float()
+        v[:20, 0] = (v[:20, 0] // 4) * 4 + 3                                   # first vertex = last of its block along x
+        x[100 * k: 100 * k + 40] = ((v - 0.5) / float(cfg.scale[l])).clamp(0.0, 0.999999)
+    x[-1] = torch.tensor([0.9999999, 0.9999999, 0.9999999])                      # the last cell of every level
+    xd = x.cuda()
+    idx = ops.hashgrid_corners(cfg, xd).cpu().numpy()                            # [L, n, 8] absolute entries
+    xn = x.numpy()
+    for l in range(L):
+        ref, _ = O.grid_corner_indices(xn, lv, l)
+        assert np.array_equal(idx[l].astype(np.int64), ref.astype(np.int64) + int(lv.offset[l])), (layout, l)
+        assert ref.max() < lv.size[l]
+    for dt in ('fp16', 'bf16'):
+        tdt, ulp = DT[dt]
+        table = (torch.rand(cfg.total, 2, generator=g) * 2 - 1)
+        feat = ops.hashgrid_fwd(cfg, xd, table.to(tdt).reshape(-1).cuda())
+        assert feat.shape == (L, n, 2)
+        got = feat.float().cpu().permute(1, 0, 2).reshape(n, -1)
+        ref = O.hashgrid_encode(x, table, lv, quant=dt)
+        assert ((got - ref).abs() <= ulp * ref.abs() * 1.01 + 1e-6).all(), (layout, dt, float((got - ref).abs().max()))
+        # capacity-sized launch with a device-side live count: the live rows are the same bits
+        live = 1777
+        part = ops.hashgrid_fwd(cfg, xd, table.to(tdt).reshape(-1).cuda(), n_dev=torch.tensor([live], dtype=torch.int64, device='cuda'))
+        assert torch.equal(part[:, :live], feat[:, :live])
+    if layout == 'line_local':
+        # inference only: the gradient entry points refuse the layout instead of scattering into the wrong entries
+        from perf_amd._lib import PerfError
+        with pytest.raises(PerfError):
+            ops.hashgrid_bwd(cfg, xd, torch.zeros(L, n, 2, device='cuda'))
+
+
+@pytest.mark.parametrize('layout', ['tcnn', 'line_local'])
+def test_table_beyond_32_bit_offsets(ops, layout):
     """5.6e9 entries (21 GiB of 2x16-bit features): level offsets exceed 2^32.  The table is filled on the device with a
     function of the global entry index; the expected features of a few points are evaluated on the host from the oracle's
-    corner indices and weights through the same function, so no host copy of the table is needed."""
+    corner indices and weights through the same function, so no host copy of the table is needed.  Both table layouts."""
     L, T, b = 20, 29, 1.5
-    cfg = _grid_cfg(n_levels=L, log2_hashmap_size=T, base_resolution=16, per_level_scale=b)
-    lv = O.grid_levels(L, 2, T, 16, b)
+    cfg = _grid_cfg(n_levels=L, log2_hashmap_size=T, base_resolution=16, per_level_scale=b, layout=layout)
+    lv = _lv_of(cfg)
     assert cfg.total > 2 ** 32 and np.array_equal(cfg.offset.astype(np.uint64), lv.offset.astype(np.uint64))
 
     def value(idx):                                      # entry index (int64 tensor) -> feature 0, feature 1 in [-1, 1)
@@ -715,7 +766,7 @@ def test_table_beyond_32_bit_offsets(ops):
         f0, f1 = value(idx)
         table[2 * lo: 2 * (lo + idx.numel())] = torch.stack([f0, f1], -1).reshape(-1).half()
         del idx, f0, f1
-    n = 64
+    n = 640
     x = torch.rand(n, 3, generator=torch.Generator().manual_seed(37))
     feat = ops.hashgrid_fwd(cfg, x.cuda(), table).float().cpu()          # [L, n, 2]
     xn = x.numpy()

@@ -4,7 +4,7 @@
 // Layouts:  0 = tcnn (x + y*res + z*res^2 dense; prime-XOR hash of the vertex otherwise)
 //           1 = line blocks: a 4x4x2 block of vertices = 32 entries = one 128-byte line; blocks hashed one by one
 //           2 = line blocks inside 64 KiB super-blocks (8x8x8 blocks = 32x32x16 vertices contiguous); super-blocks hashed
-//           3 = line blocks inside 2 MiB super-blocks (32x32x16 blocks = 128x128x32 vertices)
+//           3 = line blocks inside 2 MiB super-blocks (32x32x16 blocks = 128x128x32 vertices); 4: 64x64x128; 5: 64x64x64 (1 MiB); 6: 128x64x64
 // Mappings: 0 = shipped generic kernel (block -> level group b % 8, levels {g, 15-g, 16+g} one after the other)
 //           1 = one level per workgroup, levels cycling with the block index (every XCD serves every level)
 //           2 = shipped groups, all of a thread's gathers issued before the first is consumed
@@ -158,12 +158,86 @@ __global__ __launch_bounds__(256) void enc_levels(GP gp, const float* __restrict
     }
 }
 
-// panorama sample positions: rows [row0, row0 + nrows) of a 2048 x 4096 panorama, 256 lattice midpoints of 0.99 / 256 per ray
-__global__ void positions(float* __restrict__ x01, int row0, int nrows) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t n = (int64_t)nrows * 4096 * 256;
+
+// work item of block b under the XCD-stable balanced mapping: XCD x = b % 8 serves level l for EIGHT CONSECUTIVE rays (256-sample
+// chunks) back to back, then the next level of the same 64-ray stripe; which eighth of a stripe an XCD serves rotates with the
+// level, so every XCD serves every level for an eighth of the rays (balance) and a level's neighbouring rays meet in one L2.
+__device__ __forceinline__ bool stable_item(int64_t b, int64_t nchunks, int* l, int64_t* chunk) {
+    const int x = (int)(b & 7);
+    const int64_t j = b >> 3;
+    const int cr = (int)(j & 7);
+    const int64_t t = j >> 3;
+    *l = (int)(t % L);
+    const int64_t Q = t / L;
+    *chunk = (((Q << 3) + ((x - *l) & 7)) << 3) + cr;
+    return *chunk < nchunks;
+}
+
+// mapping 3: XCD-stable balanced, eight 4-byte gathers
+__global__ __launch_bounds__(256) void enc_stable(GP gp, const float* __restrict__ x01, const uint32_t* __restrict__ table, uint32_t* __restrict__ feat, int64_t n) {
+    int l; int64_t chunk;
+    if (!stable_item(blockIdx.x, (n + 255) >> 8, &l, &chunk)) return;
+    const int64_t i = chunk * 256 + threadIdx.x;
     if (i >= n) return;
-    const int k = (int)(i & 255), col = (int)((i >> 8) & 4095), row = row0 + (int)(i >> 20);
+    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+    const Cor c = corners(gp, l, x, y, z);
+    const uint32_t* t = table + gp.offset[l];
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = t[c.idx[k]];
+    feat[(int64_t)l * n + i] = interp(c, v);
+}
+
+// mapping 4: XCD-stable balanced; line-local levels fetch the aligned 16-byte x-run of every (y, z) corner pair (both x corners
+// unless the cell starts at the last vertex of a block: a fifth..eighth 4-byte gather for those lanes only)
+__global__ __launch_bounds__(256) void enc_stable_quad(GP gp, const float* __restrict__ x01, const uint32_t* __restrict__ table, uint32_t* __restrict__ feat, int64_t n) {
+    int l; int64_t chunk;
+    if (!stable_item(blockIdx.x, (n + 255) >> 8, &l, &chunk)) return;
+    const int64_t i = chunk * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+    const uint32_t* t = table + gp.offset[l];
+    uint32_t v[8];
+    Cor c;
+    if (!gp.local[l]) {
+        c = corners(gp, l, x, y, z);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = t[c.idx[k]];
+    } else {
+        const float s = gp.scale[l];
+        const float px = __builtin_fmaf(x, s, 0.5f), py = __builtin_fmaf(y, s, 0.5f), pz = __builtin_fmaf(z, s, 0.5f);
+        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+        c.f[0] = px - fx; c.f[1] = py - fy; c.f[2] = pz - fz;
+        const uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
+        const uint32_t lx = gx & 3u;
+        uint4 q[4]; uint32_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t base = vertex_index(gp, l, gx & ~3u, gy + (k & 1), gz + (k >> 1));        // 16-byte aligned by construction
+            q[k] = *reinterpret_cast<const uint4*>(t + base);
+        }
+        if (lx == 3u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = t[vertex_index(gp, l, gx + 1u, gy + (k & 1), gz + (k >> 1))];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t a0 = lx == 0u ? q[k].x : (lx == 1u ? q[k].y : (lx == 2u ? q[k].z : q[k].w));
+            const uint32_t a1 = lx == 0u ? q[k].y : (lx == 1u ? q[k].z : (lx == 2u ? q[k].w : e[k]));
+            v[2 * k] = a0; v[2 * k + 1] = a1;
+        }
+    }
+    feat[(int64_t)l * n + i] = interp(c, v);
+}
+
+// panorama sample positions: rows [row0, row0 + nrows) of a 2048 x 4096 panorama, 256 lattice midpoints of 0.99 / 256 per ray
+__global__ void positions(float* __restrict__ x01, int row0, int tile) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = 4ll * 4096 * 256;
+    if (i >= n) return;
+    const int k = (int)(i & 255);
+    const int ray = (int)(i >> 8);                       // 16,384 rays: 4 rows x 4096 columns, or a 128 x 128 pixel tile
+    const int row = tile ? row0 + (ray >> 7) : row0 + (ray >> 12), col = tile ? 1984 + (ray & 127) : (ray & 4095);
     const float yy = (row + .5f) / 2048.f, xx = (col + .5f) / 4096.f;
     const float beta = -(yy - .5f) * 3.14159265358979f, alpha = -(xx - .5f) * 6.28318530717959f;
     const float t = (k + .5f) * (0.99f / 256.f);
@@ -180,7 +254,7 @@ static GP make_grid(int log2_t, int layout, uint64_t* total) {
     GP g{};
     const double b = std::exp(std::log(8192.0 / 16.0) / (L - 1));
     const uint64_t T = 1ull << log2_t;
-    const int sh[4][3] = {{0, 0, 0}, {2, 2, 1}, {5, 5, 4}, {7, 7, 5}};
+    const int sh[7][3] = {{0, 0, 0}, {2, 2, 1}, {5, 5, 4}, {7, 7, 5}, {6, 6, 7}, {6, 6, 6}, {7, 6, 6}};
     for (int d = 0; d < 3; ++d) g.sb_shift[d] = sh[layout][d];
     uint64_t off = 0;
     for (int l = 0; l < L; ++l) {
@@ -215,41 +289,59 @@ int main(int argc, char** argv) {
     float* x01; uint32_t* feat;
     CHECK(hipMalloc(&x01, n * 12)); CHECK(hipMalloc(&feat, n * 4 * L));
     const int rows[] = {1022, 512, 0};
-    const char* mnames[] = {"groups (shipped)", "one level per workgroup", "groups, 24 gathers in flight"};
-    kern_t kerns[] = {enc_groups, enc_levels, enc_groups_deep};
+    const char* mnames[] = {"groups (shipped)", "one level per workgroup", "groups, 24 gathers in flight", "XCD-stable balanced", "XCD-stable balanced, 16-byte x-runs"};
+    kern_t kerns[] = {enc_groups, enc_levels, enc_groups_deep, enc_stable, enc_stable_quad};
+    const int nchunks = (int)(n >> 8);
+    const unsigned grids[] = {4096u * 8, 4096u * L, 4096u * 8, (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64)};
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    // (layout, mapping, tile) triples of this run
+    const int variants[][3] = {{0, 3, 0}, {2, 4, 0}, {3, 4, 0}, {4, 4, 0}, {5, 4, 0}, {6, 4, 0}, {4, 3, 0}};
     for (int a = 1; a < argc; ++a) {
         const int log2_t = atoi(argv[a]);
         uint64_t maxtot = 0;
-        for (int layout = 0; layout < 4; ++layout) { uint64_t t; make_grid(log2_t, layout, &t); if (t > maxtot) maxtot = t; }
+        for (int layout = 0; layout < 7; ++layout) { uint64_t t; make_grid(log2_t, layout, &t); if (t > maxtot) maxtot = t; }
         uint32_t* table;
         CHECK(hipMalloc(&table, maxtot * 4));
         fill<<<65536, 256>>>(table, maxtot);
         CHECK(hipDeviceSynchronize());
-        for (int layout = 0; layout < 4; ++layout) {
+        {   // the 16-byte x-run kernel must produce what the 4-byte gathers produce (same layout, same positions)
+            uint32_t* feat2; CHECK(hipMalloc(&feat2, n * 4 * L));
+            uint64_t tot; const GP gp = make_grid(log2_t, 2, &tot);
+            positions<<<(unsigned)((n + 255) / 256), 256>>>(x01, 1022, 0);
+            enc_stable<<<grids[3], 256>>>(gp, x01, table, feat, n);
+            enc_stable_quad<<<grids[4], 256>>>(gp, x01, table, feat2, n);
+            enc_levels<<<grids[1], 256>>>(gp, x01, table, feat2 + 0, n);      // (third opinion, overwrites: compared against feat as well)
+            CHECK(hipDeviceSynchronize());
+            std::vector<uint32_t> ha((size_t)n * L), hb((size_t)n * L);
+            CHECK(hipMemcpy(ha.data(), feat, n * 4 * L, hipMemcpyDeviceToHost));
+            enc_stable_quad<<<grids[4], 256>>>(gp, x01, table, feat2, n);
+            CHECK(hipMemcpy(hb.data(), feat2, n * 4 * L, hipMemcpyDeviceToHost));
+            size_t bad = 0; for (size_t k = 0; k < ha.size(); ++k) bad += ha[k] != hb[k];
+            printf("{\"check\": \"16-byte x-runs == 4-byte gathers\", \"log2_T\": %d, \"mismatching_features\": %zu, \"of\": %zu}\n", log2_t, bad, ha.size());
+            CHECK(hipFree(feat2));
+        }
+        for (const auto& var : variants) {
+            const int layout = var[0], m = var[1], tile = var[2];
             uint64_t tot;
             const GP gp = make_grid(log2_t, layout, &tot);
             int nh = 0, nl = 0; for (int l = 0; l < L; ++l) { nh += gp.hashed[l]; nl += gp.local[l]; }
-            for (int m = 0; m < 3; ++m) {
-                double sum = 0; double per_row[3];
-                for (int r = 0; r < 3; ++r) {
-                    positions<<<(unsigned)((n + 255) / 256), 256>>>(x01, rows[r], 4);
-                    const unsigned grid = m == 1 ? 4096u * L : 4096u * 8;
-                    kerns[m]<<<grid, 256>>>(gp, x01, table, feat, n);             // warm-up
-                    CHECK(hipDeviceSynchronize());
-                    CHECK(hipEventRecord(e0));
-                    for (int rep = 0; rep < 3; ++rep) kerns[m]<<<grid, 256>>>(gp, x01, table, feat, n);
-                    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
-                    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-                    per_row[r] = ms / 3; sum += ms / 3;
-                }
-                const double ms = sum / 3;
-                printf("{\"log2_T\": %d, \"layout\": %d, \"mapping\": \"%s\", \"table_GiB\": %.2f, \"hashed_levels\": %d, \"local_levels\": %d, "
-                       "\"ms_equator\": %.3f, \"ms_mid\": %.3f, \"ms_pole\": %.3f, \"ms_mean\": %.3f, \"algorithmic_frac_of_8TBps\": %.3f}\n",
-                       log2_t, layout, mnames[m], tot * 4 / 1073741824.0, nh, nl, per_row[0], per_row[1], per_row[2], ms,
-                       640.0 * n / (ms * 1e-3) / 8e12);
-                fflush(stdout);
+            double sum = 0; double per_row[3];
+            for (int r = 0; r < 3; ++r) {
+                positions<<<(unsigned)((n + 255) / 256), 256>>>(x01, tile ? (rows[r] < 64 ? 0 : rows[r] - 62) : rows[r], tile);
+                kerns[m]<<<grids[m], 256>>>(gp, x01, table, feat, n);             // warm-up
+                CHECK(hipDeviceSynchronize());
+                CHECK(hipEventRecord(e0));
+                for (int rep = 0; rep < 3; ++rep) kerns[m]<<<grids[m], 256>>>(gp, x01, table, feat, n);
+                CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                per_row[r] = ms / 3; sum += ms / 3;
             }
+            const double ms = sum / 3;
+            printf("{\"log2_T\": %d, \"layout\": %d, \"mapping\": \"%s\", \"rays\": \"%s\", \"table_GiB\": %.2f, \"hashed_levels\": %d, \"local_levels\": %d, "
+                   "\"ms_equator\": %.3f, \"ms_mid\": %.3f, \"ms_pole\": %.3f, \"ms_mean\": %.3f, \"algorithmic_frac_of_8TBps\": %.3f}\n",
+                   log2_t, layout, mnames[m], tile ? "128x128 tile" : "4x4096 strip", tot * 4 / 1073741824.0, nh, nl, per_row[0], per_row[1], per_row[2], ms,
+                   640.0 * n / (ms * 1e-3) / 8e12);
+            fflush(stdout);
         }
         CHECK(hipFree(table));
     }
