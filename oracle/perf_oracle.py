@@ -109,7 +109,7 @@ class GridLevels:
     hashed: np.ndarray     # bool [L]
     total: int             # entries in all levels
     layout: str = 'tcnn'   # 'tcnn' | 'line_local' (see grid_levels)
-    sb_shift: tuple = (6, 6, 7)
+    sb_shift: tuple = (5, 6, 8)
     local: np.ndarray = None   # bool [L]  level stored line-local
     nsx: np.ndarray = None     # u32 [L]   dense line-local levels: super-blocks per row
     nsxy: np.ndarray = None    # u32 [L]   ... per z-slice
@@ -119,18 +119,18 @@ class GridLevels:
         return self.total * self.n_feat
 
 
-LOCAL_MIN_RES = 64          # line_local grids: levels of at least this resolution are stored line-local
+LOCAL_MIN_RES = 64          # line_local grids: levels of at least this resolution are stored line-local (default)
 
 
 def grid_levels(n_levels=16, n_feat=2, log2_hashmap_size=18, base_resolution=16,
-                per_level_scale=1.4472692012786865, layout='tcnn', sb_shift=(6, 6, 7)) -> GridLevels:
+                per_level_scale=1.4472692012786865, layout='tcnn', sb_shift=(5, 6, 8), local_min_res=LOCAL_MIN_RES) -> GridLevels:
     """Per-level geometry of a tcnn HashGrid (A.1): scale_l = N_min*b^l - 1 (fp32),
     res_l = ceil(scale_l)+1, size_l = min(align8(res_l^3), 2^T), offsets = prefix sums.
 
     layout='line_local' (NOT tcnn's; an opt-in table layout of this build for grids the reference never defines -- BASELINE
     config 5's L = 20 tables sized to HBM, inference only; no reference result exists to stay compatible with): levels with
-    res >= LOCAL_MIN_RES store the vertices of a 4 x 4 x 2 block as ONE 128-byte line (entry x%4 + 4 (y%4) + 16 (z%2)),
-    the blocks of a 2^sx x 2^sy x 2^sz-vertex SUPER-BLOCK contiguously (x-major; default 64 x 64 x 128 vertices = 2 MiB), and
+    res >= local_min_res store the vertices of a 4 x 4 x 2 block as ONE 128-byte line (entry x%4 + 4 (y%4) + 16 (z%2)),
+    the blocks of a 2^sx x 2^sy x 2^sz-vertex SUPER-BLOCK contiguously (x-major; default 32 x 64 x 256 vertices = 2 MiB), and
     address the super-block either densely (index sx + sy*nx + sz*nx*ny when all n_d = (res + 2^s_d) >> s_d super-blocks per
     dimension fit 2^T entries) or through tcnn's prime-XOR hash OF THE SUPER-BLOCK COORDINATES modulo the number of
     super-blocks in 2^T entries.  A sample's eight corners then lie in (1+1/4)(1+1/4)(1+1/2) = 2.3 lines of ONE page instead
@@ -151,7 +151,7 @@ def grid_levels(n_levels=16, n_feat=2, log2_hashmap_size=18, base_resolution=16,
         e = F32(np.exp2(np.float64(F32(l) * log2_b)))
         s = F32(F32(e * F32(base_resolution)) - F32(1.0))
         r = int(math.ceil(float(s))) + 1
-        if layout == 'line_local' and r >= LOCAL_MIN_RES:
+        if layout == 'line_local' and r >= local_min_res:
             nd = [(r + (1 << sh)) >> sh for sh in sb_shift]          # super-blocks per dimension: vertices 0..res
             full = nd[0] * nd[1] * nd[2] * per_sb
             n = min(full, 1 << log2_hashmap_size)

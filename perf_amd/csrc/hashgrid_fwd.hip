@@ -186,11 +186,21 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, con
 //     gathers meet in one L2 (a level's consecutive rays share cells at the coarse levels and 128-byte lines at the fine ones);
 //   * which eighth of a 64-chunk stripe an XCD serves rotates with the level ((x - l) & 7): every XCD serves every level for an
 //     eighth of the samples -- balance whatever a level costs.                                      1.66 / 2.44 ms, tcnn layout
-// Line-local levels (PERF_LAYOUT_LINE_LOCAL) fetch, per (y, z) corner pair, the ALIGNED 16-byte x-run that holds the cell's first
-// vertex -- both x corners unless the cell starts at a block's last vertex (a quarter of the lanes: a 4-byte gather for those) --
-// i.e. 4 + 4 * 1/4 L1 look-ups per lane instead of 8.                                 1.01 / 1.13 ms with 64 x 64 x 128 super-blocks
+// Line-local levels (PERF_LAYOUT_LINE_LOCAL) give every sample FOUR LANES, one per (y, z) corner pair; a lane fetches the ALIGNED
+// 16-byte x-run that holds its pair's first vertex -- both x corners unless the cell starts at a block's last vertex (a quarter of
+// the samples: a 4-byte gather for those).  The four runs of a sample -- 2.3 lines on average -- are thus requested by ONE
+// instruction (the texture addresser merges lanes that name the same line) instead of by four consecutive ones that find the line
+// pending; a wave serves 16 samples per instruction and keeps four such groups in flight; the four partial sums of a sample meet
+// through two DPP quad permutes.  Counters of the one-lane-per-sample form (profiles/r06_config5_counters.json): 53 % of the wave
+// cycles waiting to ISSUE a memory instruction, the L1 stalled on pending lines 80 % of the time.    0.78 / 0.90 ms (probe)
 // Placement is a speed assumption only; results do not depend on it.
 constexpr int64_t kBigMaxStripes = 1 << 16;
+
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    return v;
+}
 
 template <typename T16>
 __global__ __launch_bounds__(256) void hashgrid_fwd_big_kernel(GridParams gp, GridLocal gl, const float* __restrict__ x01,
@@ -206,51 +216,74 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_kernel(GridParams gp, Gr
     const int l = (int)(t % L);
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     const uint32_t* tl = table + gp.offset[l];
-    for (int64_t Q = t / L; (Q << 6) < nchunks; Q += grid_stripes) {
-        const int64_t chunk = (((Q << 3) + ((xcd - l) & 7)) << 3) + cr;
-        const int64_t i = chunk * 256 + threadIdx.x;
-        if (i >= n_live) continue;
-        const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
-        uint32_t v[8];
-        float f[3];
-        if (!gl.local[l]) {
-            const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+    if (!gl.local[l]) {
+        for (int64_t Q = t / L; (Q << 6) < nchunks; Q += grid_stripes) {
+            const int64_t chunk = (((Q << 3) + ((xcd - l) & 7)) << 3) + cr;
+            const int64_t i = chunk * 256 + threadIdx.x;
+            if (i >= n_live) continue;
+            const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+            uint32_t v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = tl[c.idx[k]];
-            f[0] = c.f[0]; f[1] = c.f[1]; f[2] = c.f[2];
-        } else {
-            const float s = gp.scale[l];
-            const float px = grid_pos(x, s), py = grid_pos(y, s), pz = grid_pos(z, s);
+            float w[8];
+            corner_weights(c.f, smooth, w);
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a0 = fmaf(w[k], T16::lo(v[k]), a0);
+                a1 = fmaf(w[k], T16::hi(v[k]), a1);
+            }
+            feat[(int64_t)l * n + i] = T16::pack(a0, a1);
+        }
+        return;
+    }
+    // ---- line-local level: lane = (sample s of a group of 16, corner pair r = ky + 2 kz); four groups of a wave in flight
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t s = lane >> 2, r = lane & 3u;
+    const float sc = gp.scale[l];
+    const uint32_t size = gp.size[l];
+    const bool hashed = gp.hashed[l] != 0;
+    for (int64_t Q = t / L; (Q << 6) < nchunks; Q += grid_stripes) {
+        const int64_t chunk = (((Q << 3) + ((xcd - l) & 7)) << 3) + cr;
+        const int64_t base = chunk * 256 + wave * 64;
+        if (base >= n_live) continue;                                // (wave-uniform)
+        uint4 q[4];
+        uint32_t e[4] = {0u, 0u, 0u, 0u}, lxs[4];
+        float wxs[4], wys[4], wzs[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int64_t i = base + 16 * it + s;
+            if (i >= n_live) i = n_live - 1;                         // (idle lanes of the last chunk repeat its last sample)
+            const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+            const float px = grid_pos(x, sc), py = grid_pos(y, sc), pz = grid_pos(z, sc);
             const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-            f[0] = px - flx; f[1] = py - fly; f[2] = pz - flz;
+            float fx = px - flx, fy = py - fly, fz = pz - flz;
             const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
-            const uint32_t lx = gx & 3u;
-            const uint32_t size = gp.size[l];
-            const bool hashed = gp.hashed[l] != 0;
-            uint4 q[4];
-            uint32_t e[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int k = 0; k < 4; ++k)          // (an x-run of four vertices is 16-byte aligned by construction)
-                q[k] = *reinterpret_cast<const uint4*>(tl + local_vertex_index(gl, l, size, hashed, gx & ~3u, gy + (uint32_t)(k & 1), gz + (uint32_t)(k >> 1)));
-            if (lx == 3u) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) e[k] = tl[local_vertex_index(gl, l, size, hashed, gx + 1u, gy + (uint32_t)(k & 1), gz + (uint32_t)(k >> 1))];
+            const uint32_t vy = gy + (r & 1u), vz = gz + (r >> 1);
+            lxs[it] = gx & 3u;
+            q[it] = *reinterpret_cast<const uint4*>(tl + local_vertex_index(gl, l, size, hashed, gx & ~3u, vy, vz));   // (16-byte aligned by construction)
+            if (lxs[it] == 3u) e[it] = tl[local_vertex_index(gl, l, size, hashed, gx + 1u, vy, vz)];
+            if (smooth) {
+                fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz);
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[2 * k] = lx == 0u ? q[k].x : (lx == 1u ? q[k].y : (lx == 2u ? q[k].z : q[k].w));
-                v[2 * k + 1] = lx == 0u ? q[k].y : (lx == 1u ? q[k].z : (lx == 2u ? q[k].w : e[k]));
-            }
+            wxs[it] = fx;
+            wys[it] = (r & 1u) ? fy : 1.0f - fy;
+            wzs[it] = (r >> 1) ? fz : 1.0f - fz;
         }
-        float w[8];
-        corner_weights(f, smooth, w);
-        float a0 = 0.f, a1 = 0.f;
+        uint32_t mine = 0u;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            a0 = fmaf(w[k], T16::lo(v[k]), a0);
-            a1 = fmaf(w[k], T16::hi(v[k]), a1);
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t lx = lxs[it];
+            const uint32_t a0 = lx == 0u ? q[it].x : (lx == 1u ? q[it].y : (lx == 2u ? q[it].z : q[it].w));
+            const uint32_t a1 = lx == 0u ? q[it].y : (lx == 1u ? q[it].z : (lx == 2u ? q[it].w : e[it]));
+            // this lane's two corners with corner_weights' products ((wx * wy) * wz), then the sample's four lanes
+            const float w0 = ((1.0f - wxs[it]) * wys[it]) * wzs[it], w1 = (wxs[it] * wys[it]) * wzs[it];
+            const float p0 = quad_sum(fmaf(w1, T16::lo(a1), w0 * T16::lo(a0)));
+            const float p1 = quad_sum(fmaf(w1, T16::hi(a1), w0 * T16::hi(a0)));
+            if ((int)r == it) mine = T16::pack(p0, p1);              // (all four lanes hold the same sums: lane r keeps group r's)
         }
-        feat[(int64_t)l * n + i] = T16::pack(a0, a1);
+        const int64_t io = base + 16 * (int64_t)r + s;
+        if (io < n_live) feat[(int64_t)l * n + io] = mine;
     }
 }
 

@@ -143,7 +143,7 @@ class InferenceNeRF:
     type NeRFOCCRenderer uses (density_at / rgb_at / sample_points on kernel-made positions), like sharded.LevelShardedNeRF."""
 
     def __init__(self, aabb, n_levels=20, log2_hashmap_size=28, per_level_scale=PER_LEVEL_SCALE, dtype='fp16', seed=tcnn.DEFAULT_SEED,
-                 table_scale=1e-4, density_bias=0.0, device=None, layout='tcnn', sb_shift=(6, 6, 7)):
+                 table_scale=1e-4, density_bias=0.0, device=None, layout='tcnn', **layout_kw):
         """table_scale / density_bias (tests): tables U(-table_scale, table_scale) and sigma = exp(y + density_bias) instead of the
         fresh initialisation's near-constant sigma = exp(y ~ 0) -- a field with structure, dense enough for rays to terminate.
         layout: 'tcnn' (default) or the opt-in 'line_local' table layout of perf_amd.grid.GridConfig -- these fields exist for grids
@@ -158,7 +158,7 @@ class InferenceNeRF:
         self.training = False
         self.dtype_name = dtype
         self.grid = GridConfig(n_levels=n_levels, log2_hashmap_size=log2_hashmap_size, base_resolution=16, per_level_scale=per_level_scale,
-                               layout=layout, sb_shift=sb_shift)
+                               layout=layout, **layout_kw)          # (layout_kw: sb_shift, local_min_res)
         t16 = ops.torch_dtype(dtype)
         self.nets = {}
         gen = torch.Generator(device=dev).manual_seed(seed)

@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 
 _F = np.float32
-LOCAL_MIN_RES = 64          # line_local grids: levels of at least this resolution are stored line-local
+LOCAL_MIN_RES = 64          # line_local grids: levels of at least this resolution are stored line-local (default)
 
 
 @dataclass
@@ -26,11 +26,12 @@ class GridConfig:
     interpolation: str = 'Linear'
     # Table layout.  'tcnn': tiny-cuda-nn's (dense x + y res + z res^2, or the prime-XOR hash of the vertex) -- the only layout of
     # every grid the reference defines.  'line_local' (opt-in, inference only; BASELINE config 5's L = 20 tables sized to HBM, for
-    # which no reference result exists): levels with res >= LOCAL_MIN_RES store a 4 x 4 x 2 block of vertices as one 128-byte
-    # line, the blocks of a 2^sb_shift-vertex super-block (default 64 x 64 x 128 = 2 MiB) contiguously, and hash (or densely
+    # which no reference result exists): levels with res >= local_min_res store a 4 x 4 x 2 block of vertices as one 128-byte
+    # line, the blocks of a 2^sb_shift-vertex super-block (default 32 x 64 x 256 = 2 MiB) contiguously, and hash (or densely
     # index) the SUPER-BLOCK: a sample's eight corners lie in ~2.3 lines of one page.  include/perf_hip.h PERF_LAYOUT_*.
     layout: str = 'tcnn'
-    sb_shift: tuple = (6, 6, 7)
+    sb_shift: tuple = (5, 6, 8)
+    local_min_res: int = LOCAL_MIN_RES
     scale: np.ndarray = field(init=False, repr=False)
     res: np.ndarray = field(init=False, repr=False)
     size: np.ndarray = field(init=False, repr=False)
@@ -69,7 +70,7 @@ class GridConfig:
             growth = _F(np.exp2(np.float64(_F(l) * log2_b)))
             s = _F(_F(growth * _F(self.base_resolution)) - _F(1.0))
             r = int(math.ceil(float(s))) + 1
-            if self.layout == 'line_local' and r >= LOCAL_MIN_RES:
+            if self.layout == 'line_local' and r >= self.local_min_res:
                 nd = [(r + (1 << sh)) >> sh for sh in self.sb_shift]          # super-blocks per dimension (vertices 0..res)
                 cells = nd[0] * nd[1] * nd[2] * per_sb
                 n = min(cells, 1 << self.log2_hashmap_size)
@@ -109,7 +110,7 @@ class GridConfig:
     def desc(self) -> '_lib.GridDesc':
         """The C-ABI descriptor (perf_grid_desc).  Built once per configuration: filling the ctypes arrays costs ~30 us of host
         time, and an eager step passes it to half a dozen entry points (the library only reads it)."""
-        key = (self.n_levels, self.interpolation, self.log2_hashmap_size, self.base_resolution, self.per_level_scale, self.layout, self.sb_shift)
+        key = (self.n_levels, self.interpolation, self.log2_hashmap_size, self.base_resolution, self.per_level_scale, self.layout, self.sb_shift, self.local_min_res)
         cached = self.__dict__.get('_desc')
         if cached is not None and cached[0] == key:
             return cached[1]

@@ -66,7 +66,7 @@ def render_rows(nerf, est, rend, row0, nrows, rows_per_batch=4, spp=SPP5, height
 
 
 def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W5, levels=LEVELS5, dtype='fp16', timing_batches=8,
-                          pmc=None, layout='tcnn'):
+                          pmc=None, layout='tcnn', **layout_kw):
     """BASELINE config 5 on ONE GPU, whole panorama: height x width rays x spp samples through both L-level fields (16-bit tables
     of 2^log2_t entries per hashed level, inference only: perf_amd.fields.InferenceNeRF) + compositing.  -> dict for bench.py's
     `config5` block: ray-samples/s, the encode kernel's algorithmic fraction of the HBM peak, and -- from the committed PMC pass
@@ -75,7 +75,7 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
     from perf_amd.fields import InferenceNeRF
     torch.cuda.synchronize(); t0 = time.perf_counter()
     nerf = InferenceNeRF([-1., -1, -1, 1, 1, 1], n_levels=levels, log2_hashmap_size=log2_t, per_level_scale=per_level_scale(levels), dtype=dtype,
-                         layout=layout)
+                         layout=layout, **layout_kw)
     est, rend = make_renderer(spp)
     torch.cuda.synchronize(); t_build = time.perf_counter() - t0
     counters = ops.step_counters('cuda')

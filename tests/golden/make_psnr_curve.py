@@ -5,6 +5,7 @@ the GPU box and asserts |mean delta PSNR| <= 0.1 dB for the default dtype (north
 
   python tests/golden/make_psnr_curve.py [n_seeds] [out_path] [scene]      (scene: room | doorway | pillars -> psnr_curve[_<scene>].json)
   python tests/golden/make_psnr_curve.py spread - [scene]                  (adds the oracle's OWN sensitivity to the same file)
+  python tests/golden/make_psnr_curve.py quant16 - [scene] [bf16|fp16]     (adds the oracle's 16-bit-emulated curves to the same file)
 
 `spread`: the same fp32 CPU schedule of seed 0 run twice more from an initialisation moved by ONE ULP (every parameter of both
 networks to its fp32 neighbour above / below): what a perturbation far below any 16-bit effect does to PSNR@iter of this chaotic
@@ -50,9 +51,48 @@ def spread_main():
         print(scene_name, 'spread so far', sp['max_abs_delta_db'], flush=True)
 
 
+def quant_main():
+    """`oracle_16bit` = {dtype: {seed: curve}}: the same schedule with the oracle's 16-bit emulation (psnr_parity_lib.run_oracle
+    quant=...), and per mark the largest |16-bit-emulated - fp32| over the seeds: what rounding parameters and features to the
+    storage type ALONE does to PSNR@iter -- the reference's own tcnn path stores fp16.  tests/test_gpu_psnr.py bounds single seeds
+    of (HIP - fp32 oracle) by max(0.1 dB, that figure)."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    scene_name = sys.argv[3] if len(sys.argv) > 3 else 'room'
+    dtype = sys.argv[4] if len(sys.argv) > 4 else 'bf16'
+    default = 'psnr_curve.json' if scene_name == 'room' else f'psnr_curve_{scene_name}.json'
+    out_path = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != '-' else os.path.join(ROOT, 'tests', 'golden', default)
+    res = json.load(open(out_path))
+    cfg = res['config']
+    assert cfg.get('scene', 'room') == scene_name and cfg['lattice'] == P.O.DEFAULT_LATTICE
+    scene = P.make_scene(*cfg['pano'], scene_name)
+    for row in res['seeds']:
+        sd = row['seed']
+        res = json.load(open(out_path))                     # (the spread job may be writing the same file: merge, do not clobber)
+        block = res.setdefault('oracle_16bit', {}).setdefault(dtype, {'curves': {}})
+        if str(sd) in block['curves']:
+            continue
+        geo0, app0 = P.init_params(sd)
+        draws = P.make_draws(scene[0].shape[0], cfg['batch'], cfg['geo_iters'] + cfg['app_iters'], sd)
+        assert P.draws_digest(draws) == row['draws_digest']
+        t = time.time()
+        curve = P.run_oracle(scene, geo0, app0, draws, cfg['geo_iters'], cfg['app_iters'], tuple(cfg['marks']), quant=dtype,
+                             log=lambda m: print(f'{scene_name} {dtype} seed {sd}: {m}', flush=True))
+        curve['seconds'] = round(time.time() - t, 1)
+        res = json.load(open(out_path))
+        block = res.setdefault('oracle_16bit', {}).setdefault(dtype, {'curves': {}})
+        block['curves'][str(sd)] = curve
+        rows = {str(r['seed']): r['oracle'] for r in res['seeds']}
+        block['max_abs_delta_db'] = {f'psnr@app{m}': max(abs(c[f'psnr@app{m}'] - rows[s][f'psnr@app{m}']) for s, c in block['curves'].items())
+                                     for m in cfg['marks']}
+        json.dump(res, open(out_path, 'w'), indent=1)
+        print(scene_name, dtype, 'seed', sd, {k: round(curve[k] - rows[str(sd)][k], 4) for k in curve if k.startswith('psnr')}, flush=True)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'spread':
         return spread_main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'quant16':
+        return quant_main()
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     scene_name = sys.argv[3] if len(sys.argv) > 3 else 'room'

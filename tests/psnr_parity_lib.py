@@ -56,11 +56,14 @@ def init_params(seed):
     return O.init_field_params(O.geo_spec(), 1337 + seed), O.init_field_params(O.app_spec(), 1337 + seed)
 
 
-def run_oracle(scene, geo0, app0, draws, n_geo, n_app, marks, log=None):
+def run_oracle(scene, geo0, app0, draws, n_geo, n_app, marks, log=None, quant=None):
     """-> {'geo_end_depth_err', 'psnr@app<k>' for k in marks} and the geometry phase's learning curve: 'geo_depth_loss@<k>' (mean
     training depth loss of iterations k-10..k-1, k in GEO_MARKS: falls by two orders of magnitude while the field grows
     opaque -- unlike the eval depth error, which the occupancy shell fixes from the first iteration) and
-    'geo_end_opacity' (mean eval opacity after the phase)."""
+    'geo_end_opacity' (mean eval opacity after the phase).
+    quant ('bf16' | 'fp16' | None): the oracle's 16-bit emulation -- the forward passes see parameters and encoded features rounded to
+    that type (what tcnn's and this build's 16-bit working copies do), everything else (master weights, Adam, compositing,
+    losses) stays fp32: what the STORAGE TYPE ALONE does to the curve."""
     o, d, dist, rgb, occ = scene
     geo = geo0.clone().requires_grad_(True); app = app0.clone().requires_grad_(True)
     curve = {}
@@ -70,7 +73,7 @@ def run_oracle(scene, geo0, app0, draws, n_geo, n_app, marks, log=None):
         outs_rgb, outs_d, outs_o = [], [], []
         with torch.no_grad():
             for lo in range(0, o.shape[0], 16384):
-                out = O.occ_render(o[lo:lo + 16384], d[lo:lo + 16384], geo, app, occ, AABB, training=False)
+                out = O.occ_render(o[lo:lo + 16384], d[lo:lo + 16384], geo, app, occ, AABB, training=False, quant=quant)
                 outs_rgb.append(out['rgb']); outs_d.append(out['distance']); outs_o.append(out['opacities'])
         return torch.cat(outs_rgb), torch.cat(outs_d), torch.cat(outs_o)
 
@@ -79,7 +82,7 @@ def run_oracle(scene, geo0, app0, draws, n_geo, n_app, marks, log=None):
     for i in range(n_geo):
         dr = draws[i]
         t0 = (dr['jitter'].numpy() * np.float32(5e-4)).astype(np.float32)
-        out = O.occ_render(o[dr['idx']], d[dr['idx']], geo, app, occ, AABB, training=True, t0=t0, bg_color=dr['bg'], dist_noise=dr['noise'])
+        out = O.occ_render(o[dr['idx']], d[dr['idx']], geo, app, occ, AABB, training=True, t0=t0, bg_color=dr['bg'], dist_noise=dr['noise'], quant=quant)
         if not out['is_valid']:
             continue
         loss, dl_i, _ = O.geo_step_loss(out, dist[dr['idx']], progress=i / n_app)
@@ -101,7 +104,7 @@ def run_oracle(scene, geo0, app0, draws, n_geo, n_app, marks, log=None):
         dr = draws[n_geo + i]
         t0 = (dr['jitter'].numpy() * np.float32(5e-4)).astype(np.float32)
         out = O.occ_render(o[dr['idx']], d[dr['idx']], geo, app, occ, AABB, training=True, t0=t0, bg_color=dr['bg'], dist_noise=dr['noise'],
-                           geo_grad=False, app_grad=True)
+                           geo_grad=False, app_grad=True, quant=quant)
         if out['is_valid']:
             loss, _ = O.app_step_loss(out, rgb[dr['idx']])
             app.grad = None; loss.backward()

@@ -26,7 +26,8 @@ def _grid_cfg(**kw):
 
 
 def _lv_of(cfg):
-    return O.grid_levels(cfg.n_levels, 2, cfg.log2_hashmap_size, cfg.base_resolution, cfg.per_level_scale, layout=cfg.layout, sb_shift=cfg.sb_shift)
+    return O.grid_levels(cfg.n_levels, 2, cfg.log2_hashmap_size, cfg.base_resolution, cfg.per_level_scale, layout=cfg.layout, sb_shift=cfg.sb_shift,
+                         local_min_res=cfg.local_min_res)
 
 
 DT = {'bf16': (torch.bfloat16, 2.0 ** -8), 'fp16': (torch.float16, 2.0 ** -11)}
@@ -696,19 +697,20 @@ def test_deep_grid_forward_20_levels(ops):
 
 
 @pytest.mark.parametrize('layout', ['tcnn', 'line_local'])
-@pytest.mark.parametrize('log2_t,sb_shift', [(15, (2, 2, 1)), (20, (3, 3, 2)), (24, (6, 6, 7))])
-def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift):
+@pytest.mark.parametrize('log2_t,sb_shift,min_res', [(15, (2, 2, 1), 16), (20, (3, 3, 2), 64), (24, (5, 6, 8), 64)])
+def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift, min_res):
     """The deep-grid forward kernel (one level per workgroup, XCD-stable balanced; 16-byte x-runs on line-local levels) against
     the oracle -- corner indices bit-exact, features within an ulp of the storage type -- for tcnn's layout and for the opt-in
     line-local one (oracle/perf_oracle.py:grid_levels), at table sizes where the line-local levels are all hashed (2^15, super-blocks
-    of one block), mixed dense / hashed (2^20) and with the shipped 64 x 64 x 128 super-blocks (2^24); ragged n, points on cell and
+    of one block), mixed dense / hashed (2^20) and with the shipped 32 x 64 x 256 super-blocks (2^24); ragged n, points on cell and
     block boundaries, a device-side live count."""
     L, b = 20, 1.3819
-    cfg = _grid_cfg(n_levels=L, log2_hashmap_size=log2_t, base_resolution=16, per_level_scale=b, layout=layout, sb_shift=sb_shift)
+    cfg = _grid_cfg(n_levels=L, log2_hashmap_size=log2_t, base_resolution=16, per_level_scale=b, layout=layout, sb_shift=sb_shift,
+                    local_min_res=min_res)
     lv = _lv_of(cfg)
     assert cfg.total == lv.total and np.array_equal(cfg.offset, lv.offset) and np.array_equal(cfg.size, lv.size)
     if layout == 'line_local':
-        assert int(cfg.local.sum()) == int((cfg.res >= 64).sum()) > 0
+        assert int(cfg.local.sum()) == int((cfg.res >= min_res).sum()) > 0
         assert log2_t == 15 or (int(((cfg.local == 1) & (cfg.hashed == 0)).sum()) > 0 and int(((cfg.local == 1) & (cfg.hashed == 1)).sum()) > 0)
     g = torch.Generator().manual_seed(41 + log2_t)
     n = 3001

@@ -31,6 +31,8 @@ def main():
     ap.add_argument('--pano-log2', type=int, nargs='*', default=[],
                     help="bench.py's `config5` block by itself: the whole panorama through NeRFOCCRenderer.render at these table sizes")
     ap.add_argument('--layout', default='tcnn', choices=['tcnn', 'line_local'], help='table layout of the --pano-log2 fields (perf_amd.grid.GridConfig)')
+    ap.add_argument('--sb-shift', type=int, nargs=3, default=None, help='line_local: log2 vertices of a super-block along x, y, z')
+    ap.add_argument('--local-min-res', type=int, default=None, help='line_local: levels of at least this resolution are stored line-local')
     ap.add_argument('--pano-batches', type=int, default=0,
                     help='with --pano-log2: only this many 4-row batches spread from pole to pole instead of the whole panorama (what the rocprofv3 '
                          '--pmc passes of profiles/r05_config5_pmc.json run)')
@@ -38,11 +40,16 @@ def main():
     dev = 'cuda'
     if args.pano_log2:
         res = {}
+        lkw = {}
+        if args.sb_shift is not None:
+            lkw['sb_shift'] = tuple(args.sb_shift)
+        if args.local_min_res is not None:
+            lkw['local_min_res'] = args.local_min_res
         for T in args.pano_log2:
             if args.pano_batches > 0:
                 from perf_amd.fields import InferenceNeRF
                 nerf = InferenceNeRF([-1., -1, -1, 1, 1, 1], n_levels=LEVELS5, log2_hashmap_size=T, per_level_scale=per_level_scale(), dtype='fp16',
-                                     layout=args.layout)
+                                     layout=args.layout, **lkw)
                 est, rend = make_renderer(SPP5)
                 step_rows = H5 // args.pano_batches
                 torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -53,7 +60,7 @@ def main():
                 del nerf
                 torch.cuda.empty_cache()
             else:
-                res[f'T{T}'] = render_panorama_block(T, layout=args.layout)
+                res[f'T{T}'] = render_panorama_block(T, layout=args.layout, **lkw)
             print(json.dumps({f'T{T}': res[f'T{T}']}, indent=1), flush=True)
         os.makedirs('gpurun_out', exist_ok=True)
         json.dump(res, open('gpurun_out/config5_pano.json', 'w'), indent=1)

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void enc_stable(GP gp, const float* __restrict
 
 // mapping 4: XCD-stable balanced; line-local levels fetch the aligned 16-byte x-run of every (y, z) corner pair (both x corners
 // unless the cell starts at the last vertex of a block: a fifth..eighth 4-byte gather for those lanes only)
-__global__ __launch_bounds__(256) void enc_stable_quad(GP gp, const float* __restrict__ x01, const uint32_t* __restrict__ table, uint32_t* __restrict__ feat, int64_t n) {
+template <int NT>
+__global__ __launch_bounds__(256) void enc_stable_quad_t(GP gp, const float* __restrict__ x01, const uint32_t* __restrict__ table, uint32_t* __restrict__ feat, int64_t n) {
     int l; int64_t chunk;
     if (!stable_item(blockIdx.x, (n + 255) >> 8, &l, &chunk)) return;
     const int64_t i = chunk * 256 + threadIdx.x;
@@ -214,7 +215,11 @@ __global__ __launch_bounds__(256) void enc_stable_quad(GP gp, const float* __res
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t base = vertex_index(gp, l, gx & ~3u, gy + (k & 1), gz + (k >> 1));        // 16-byte aligned by construction
-            q[k] = *reinterpret_cast<const uint4*>(t + base);
+            if (NT) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                const u4 r = __builtin_nontemporal_load(reinterpret_cast<const u4*>(t + base));
+                q[k] = make_uint4(r[0], r[1], r[2], r[3]);
+            } else q[k] = *reinterpret_cast<const uint4*>(t + base);
         }
         if (lx == 3u) {
 #pragma unroll
@@ -228,6 +233,74 @@ __global__ __launch_bounds__(256) void enc_stable_quad(GP gp, const float* __res
         }
     }
     feat[(int64_t)l * n + i] = interp(c, v);
+}
+
+
+// mapping 6: XCD-stable balanced; line-local levels give every sample FOUR LANES, one per (y, z) corner pair: the four 16-byte
+// x-runs of a sample -- 2.3 lines on average -- are requested by ONE instruction (the texture addresser merges lanes that name the
+// same line) instead of four consecutive ones that find the line pending; a wave serves 16 samples per instruction, four groups
+// in flight; the rows' partial sums are added across the quad with DPP.
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+
+__global__ __launch_bounds__(256) void enc_stable_rows(GP gp, const float* __restrict__ x01, const uint32_t* __restrict__ table, uint32_t* __restrict__ feat, int64_t n) {
+    int l; int64_t chunk;
+    if (!stable_item(blockIdx.x, (n + 255) >> 8, &l, &chunk)) return;
+    const uint32_t* t = table + gp.offset[l];
+    if (!gp.local[l]) {
+        const int64_t i = chunk * 256 + threadIdx.x;
+        if (i >= n) return;
+        const Cor c = corners(gp, l, x01[3 * i], x01[3 * i + 1], x01[3 * i + 2]);
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = t[c.idx[k]];
+        feat[(int64_t)l * n + i] = interp(c, v);
+        return;
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t s = lane >> 2, r = lane & 3u;
+    const int64_t base = chunk * 256 + wave * 64;
+    const float sc = gp.scale[l];
+    uint4 q[4]; uint32_t e[4] = {0u, 0u, 0u, 0u}; float fxs[4], wrow[4]; uint32_t lxs[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        int64_t i = base + 16 * it + s;
+        if (i >= n) i = n - 1;
+        const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
+        const float px = __builtin_fmaf(x, sc, 0.5f), py = __builtin_fmaf(y, sc, 0.5f), pz = __builtin_fmaf(z, sc, 0.5f);
+        const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+        const float fx = px - flx, fy = py - fly, fz = pz - flz;
+        const uint32_t gx = (uint32_t)(int)flx, gy = (uint32_t)(int)fly, gz = (uint32_t)(int)flz;
+        const uint32_t vy = gy + (r & 1u), vz = gz + (r >> 1);
+        lxs[it] = gx & 3u; fxs[it] = fx;
+        wrow[it] = ((r & 1u) ? fy : 1.f - fy);                      // (weights in tcnn's order: (wx * wy) * wz)
+        const float wz = (r >> 1) ? fz : 1.f - fz;
+        q[it] = *reinterpret_cast<const uint4*>(t + vertex_index(gp, l, gx & ~3u, vy, vz));
+        if (lxs[it] == 3u) e[it] = t[vertex_index(gp, l, gx + 1u, vy, vz)];
+        (void)wz;                                                   // (recomputed below from the position: cheaper than holding it)
+    }
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        int64_t i = base + 16 * it + s;
+        if (i >= n) i = n - 1;
+        const float z = x01[3 * i + 2];
+        const float pz = __builtin_fmaf(z, sc, 0.5f);
+        const float fz = pz - floorf(pz);
+        const float wz = (r >> 1) ? fz : 1.f - fz;
+        const uint32_t lx = lxs[it];
+        const uint32_t a0 = lx == 0u ? q[it].x : (lx == 1u ? q[it].y : (lx == 2u ? q[it].z : q[it].w));
+        const uint32_t a1 = lx == 0u ? q[it].y : (lx == 1u ? q[it].z : (lx == 2u ? q[it].w : e[it]));
+        const float w0 = ((1.f - fxs[it]) * wrow[it]) * wz, w1 = (fxs[it] * wrow[it]) * wz;
+        float p0 = fmaf(w1, lo16(a1), w0 * lo16(a0)), p1 = fmaf(w1, hi16(a1), w0 * hi16(a0));
+        p0 = quad_sum(p0); p1 = quad_sum(p1);
+        if ((int)r == it) mine = pack_half2(p0, p1);
+    }
+    const int64_t io = base + 16 * r + s;
+    if (io < n) feat[(int64_t)l * n + io] = mine;
 }
 
 // panorama sample positions: rows [row0, row0 + nrows) of a 2048 x 4096 panorama, 256 lattice midpoints of 0.99 / 256 per ray
@@ -250,11 +323,12 @@ __global__ void fill(uint32_t* t, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) t[i] = 0x2e662e66u ^ (uint32_t)(i * 2654435761u & 0x03ff03ffu);
 }
 
+static uint32_t g_local_min_res = 64;
 static GP make_grid(int log2_t, int layout, uint64_t* total) {
     GP g{};
     const double b = std::exp(std::log(8192.0 / 16.0) / (L - 1));
     const uint64_t T = 1ull << log2_t;
-    const int sh[7][3] = {{0, 0, 0}, {2, 2, 1}, {5, 5, 4}, {7, 7, 5}, {6, 6, 7}, {6, 6, 6}, {7, 6, 6}};
+    const int sh[10][3] = {{0, 0, 0}, {2, 2, 1}, {5, 5, 4}, {7, 7, 5}, {6, 6, 7}, {6, 6, 6}, {7, 6, 6}, {5, 5, 9}, {6, 6, 8}, {5, 6, 8}};
     for (int d = 0; d < 3; ++d) g.sb_shift[d] = sh[layout][d];
     uint64_t off = 0;
     for (int l = 0; l < L; ++l) {
@@ -262,7 +336,7 @@ static GP make_grid(int log2_t, int layout, uint64_t* total) {
         g.scale[l] = (float)s;
         const uint32_t res = (uint32_t)std::ceil(s) + 1;
         g.res[l] = res;
-        const bool local = layout > 0 && res >= 64;
+        const bool local = layout > 0 && res >= g_local_min_res;
         g.local[l] = local;
         uint64_t want;
         if (!local) {
@@ -289,39 +363,47 @@ int main(int argc, char** argv) {
     float* x01; uint32_t* feat;
     CHECK(hipMalloc(&x01, n * 12)); CHECK(hipMalloc(&feat, n * 4 * L));
     const int rows[] = {1022, 512, 0};
-    const char* mnames[] = {"groups (shipped)", "one level per workgroup", "groups, 24 gathers in flight", "XCD-stable balanced", "XCD-stable balanced, 16-byte x-runs"};
-    kern_t kerns[] = {enc_groups, enc_levels, enc_groups_deep, enc_stable, enc_stable_quad};
+    const char* mnames[] = {"groups (shipped)", "one level per workgroup", "groups, 24 gathers in flight", "XCD-stable balanced", "XCD-stable balanced, 16-byte x-runs", "XCD-stable balanced, 16-byte x-runs, nontemporal", "XCD-stable balanced, four lanes per sample"};
+    kern_t kerns[] = {enc_groups, enc_levels, enc_groups_deep, enc_stable, enc_stable_quad_t<0>, enc_stable_quad_t<1>, enc_stable_rows};
     const int nchunks = (int)(n >> 8);
-    const unsigned grids[] = {4096u * 8, 4096u * L, 4096u * 8, (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64)};
+    const unsigned grids[] = {4096u * 8, 4096u * L, 4096u * 8, (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64)};
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     // (layout, mapping, tile) triples of this run
-    const int variants[][3] = {{0, 3, 0}, {2, 4, 0}, {3, 4, 0}, {4, 4, 0}, {5, 4, 0}, {6, 4, 0}, {4, 3, 0}};
+    // (layout, mapping, tile, local_min_res)
+    const int variants[][4] = {{9, 4, 0, 16}, {9, 6, 0, 16}, {4, 4, 0, 64}, {4, 6, 0, 64}};
     for (int a = 1; a < argc; ++a) {
         const int log2_t = atoi(argv[a]);
         uint64_t maxtot = 0;
-        for (int layout = 0; layout < 7; ++layout) { uint64_t t; make_grid(log2_t, layout, &t); if (t > maxtot) maxtot = t; }
+        for (int layout = 0; layout < 10; ++layout) { uint64_t t; make_grid(log2_t, layout, &t); if (t > maxtot) maxtot = t; }
         uint32_t* table;
         CHECK(hipMalloc(&table, maxtot * 4));
         fill<<<65536, 256>>>(table, maxtot);
         CHECK(hipDeviceSynchronize());
-        {   // the 16-byte x-run kernel must produce what the 4-byte gathers produce (same layout, same positions)
+        {   // four-lanes-per-sample kernel against the 16-byte x-run kernel (another summation order: not bit-identical)
             uint32_t* feat2; CHECK(hipMalloc(&feat2, n * 4 * L));
-            uint64_t tot; const GP gp = make_grid(log2_t, 2, &tot);
+            g_local_min_res = 16;
+            uint64_t tot; const GP gp = make_grid(log2_t, 9, &tot);
             positions<<<(unsigned)((n + 255) / 256), 256>>>(x01, 1022, 0);
-            enc_stable<<<grids[3], 256>>>(gp, x01, table, feat, n);
-            enc_stable_quad<<<grids[4], 256>>>(gp, x01, table, feat2, n);
-            enc_levels<<<grids[1], 256>>>(gp, x01, table, feat2 + 0, n);      // (third opinion, overwrites: compared against feat as well)
+            enc_stable_quad_t<0><<<grids[4], 256>>>(gp, x01, table, feat, n);
+            enc_stable_rows<<<grids[6], 256>>>(gp, x01, table, feat2, n);
             CHECK(hipDeviceSynchronize());
             std::vector<uint32_t> ha((size_t)n * L), hb((size_t)n * L);
             CHECK(hipMemcpy(ha.data(), feat, n * 4 * L, hipMemcpyDeviceToHost));
-            enc_stable_quad<<<grids[4], 256>>>(gp, x01, table, feat2, n);
             CHECK(hipMemcpy(hb.data(), feat2, n * 4 * L, hipMemcpyDeviceToHost));
-            size_t bad = 0; for (size_t k = 0; k < ha.size(); ++k) bad += ha[k] != hb[k];
-            printf("{\"check\": \"16-byte x-runs == 4-byte gathers\", \"log2_T\": %d, \"mismatching_features\": %zu, \"of\": %zu}\n", log2_t, bad, ha.size());
+            size_t bad = 0; double worst = 0;
+            for (size_t k = 0; k < ha.size(); ++k) if (ha[k] != hb[k]) {
+                ++bad;
+                for (int h = 0; h < 2; ++h) {
+                    const float a = (float)__builtin_bit_cast(_Float16, (unsigned short)(ha[k] >> (16 * h))), b = (float)__builtin_bit_cast(_Float16, (unsigned short)(hb[k] >> (16 * h)));
+                    const double d = std::fabs((double)a - b) / (std::fabs((double)a) + 1e-6); if (d > worst) worst = d;
+                }
+            }
+            printf("{\"check\": \"four lanes per sample vs 16-byte x-runs\", \"log2_T\": %d, \"differing_features\": %zu, \"of\": %zu, \"worst_relative\": %.3g}\n", log2_t, bad, ha.size(), worst);
             CHECK(hipFree(feat2));
         }
         for (const auto& var : variants) {
             const int layout = var[0], m = var[1], tile = var[2];
+            g_local_min_res = (uint32_t)var[3];
             uint64_t tot;
             const GP gp = make_grid(log2_t, layout, &tot);
             int nh = 0, nl = 0; for (int l = 0; l < L; ++l) { nh += gp.hashed[l]; nl += gp.local[l]; }
@@ -337,9 +419,9 @@ int main(int argc, char** argv) {
                 per_row[r] = ms / 3; sum += ms / 3;
             }
             const double ms = sum / 3;
-            printf("{\"log2_T\": %d, \"layout\": %d, \"mapping\": \"%s\", \"rays\": \"%s\", \"table_GiB\": %.2f, \"hashed_levels\": %d, \"local_levels\": %d, "
+            printf("{\"log2_T\": %d, \"layout\": %d, \"mapping\": \"%s\", \"rays\": \"%s\", \"table_GiB\": %.2f, \"hashed_levels\": %d, \"local_levels\": %d, \"sb\": [%d, %d, %d], "
                    "\"ms_equator\": %.3f, \"ms_mid\": %.3f, \"ms_pole\": %.3f, \"ms_mean\": %.3f, \"algorithmic_frac_of_8TBps\": %.3f}\n",
-                   log2_t, layout, mnames[m], tile ? "128x128 tile" : "4x4096 strip", tot * 4 / 1073741824.0, nh, nl, per_row[0], per_row[1], per_row[2], ms,
+                   log2_t, layout, mnames[m], tile ? "128x128 tile" : "4x4096 strip", tot * 4 / 1073741824.0, nh, nl, 1 << gp.sb_shift[0], 1 << gp.sb_shift[1], 1 << gp.sb_shift[2], per_row[0], per_row[1], per_row[2], ms,
                    640.0 * n / (ms * 1e-3) / 8e12);
             fflush(stdout);
         }

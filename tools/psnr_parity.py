@@ -1,6 +1,9 @@
 """PSNR@iter parity as a dev tool: the HIP path (bf16 / fp16, fixed-point or fp32 gradient accumulation) against the fp32
 CPU oracle's committed curve (tests/golden/psnr_curve.json; the harness is tests/psnr_parity_lib.py, the asserted version
-tests/test_gpu_psnr.py).   python tools/psnr_parity.py  ->  gpurun_out/psnr_parity.json"""
+tests/test_gpu_psnr.py).   python tools/psnr_parity.py [room doorway pillars]  ->  gpurun_out/psnr_parity.json
+
+Splits what moves a seed away from the oracle: `fixed` vs `fp32` accumulation of the grid gradient isolates the fixed-point fields,
+bf16 vs fp16 the storage type (profiles/r06_psnr_split.json is this tool's output folded per family)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,9 +12,21 @@ from tests import psnr_parity_lib as P
 
 
 def main():
-    golden = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'psnr_curve.json')))
+    families = sys.argv[1:] or ['room']
+    out = {}
+    for fam in families:
+        out[fam] = one_family(fam)
+    from perf_amd import tcnn
+    tcnn.GRID_GRAD_ACCUM = 'fixed'
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    json.dump(out if len(families) > 1 else out[families[0]], open(os.path.join(ROOT, 'gpurun_out', 'psnr_parity.json'), 'w'), indent=1)
+
+
+def one_family(fam):
+    name = 'psnr_curve.json' if fam == 'room' else f'psnr_curve_{fam}.json'
+    golden = json.load(open(os.path.join(ROOT, 'tests', 'golden', name)))
     cfg = golden['config']
-    scene = P.make_scene(*cfg['pano'])
+    scene = P.make_scene(*cfg['pano'], fam)
     res = {'config': cfg, 'runs': []}
     for row in golden['seeds']:
         geo0, app0 = P.init_params(row['seed'])
@@ -22,11 +37,8 @@ def main():
             delta = {k: round(got[k] - row['oracle'][k], 4) for k in got if k.startswith('psnr')}
             res['runs'].append({'seed': row['seed'], 'dtype': dtype, 'accum': accum, 'hip': got, 'hip_minus_oracle': delta,
                                 'seconds': round(time.time() - t, 1)})
-            print(row['seed'], dtype, accum, delta, flush=True)
-    from perf_amd import tcnn
-    tcnn.GRID_GRAD_ACCUM = 'fixed'
-    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'psnr_parity.json'), 'w'), indent=1)
+            print(fam, row['seed'], dtype, accum, delta, flush=True)
+    return res
 
 
 if __name__ == '__main__':
