@@ -690,11 +690,29 @@ def main():
             notes.append(f'single-rank reference step failed ({type(e).__name__}: {e})')
         try:
             alt_mode = 'allreduce' if args.dp_mode == 'sharded' else 'sharded'
-            _, alt = measure(reuse_default, args.scaling, graph=False, dp_mode=alt_mode)
+            alt_run, alt = measure(reuse_default, args.scaling, graph=False, dp_mode=alt_mode)
             comm_block = dict(comm_block or {})
             comm_block['other_exchange'] = {'dp_mode': alt_mode, 'value': alt['value'], 'ms_per_step': alt['ms_per_step'], 'launch': alt['launch'],
                                             'what': 'one all-reduce of the flat fp32 gradient per step, Adam on every rank (the exchange north_star names)'
                                                     if alt_mode == 'allreduce' else 'int32 reduce-scatter -> sliced Adam -> all-gather'}
+            # ... and what ITS collective costs by itself (the A/B a first run on real links is read with), fp32 and bf16 payload
+            try:
+                ct = comm_times(alt_run, args.warmup + args.steps, max(2, min(args.steps, 10)))
+                comm_block['other_exchange']['ms_per_step_per_collective'] = ct['ms_per_step_per_collective']
+                if alt_mode == 'allreduce':
+                    sc_alt = alt_run['scene']
+                    comm_block['other_exchange']['payload_bytes'] = int(sc_alt.nerf.geo_mlp.params.numel() + sc_alt.DP_EXTRA) * 4
+                    sc_alt.comm_dtype = 'bf16'
+                    try:
+                        el16, _, kept16, _ = timed(alt_run, args.steps, args.warmup + args.steps + 16)
+                        ct16 = comm_times(alt_run, args.warmup + 2 * args.steps + 16, max(2, min(args.steps, 10)))
+                        comm_block['other_exchange']['bf16_payload'] = {'value': kept16 / el16, 'ms_per_step': el16 / args.steps * 1e3,
+                                                                        'ms_per_step_per_collective': ct16['ms_per_step_per_collective'],
+                                                                        'payload_bytes': comm_block['other_exchange']['payload_bytes'] // 2}
+                    finally:
+                        sc_alt.comm_dtype = 'fp32'
+            except Exception as e:       # noqa: BLE001
+                notes.append(f'per-collective times of the comparison exchange failed ({type(e).__name__}: {e})')
         except Exception as e:       # noqa: BLE001
             notes.append(f'comparison exchange failed ({type(e).__name__}: {e})')
 

@@ -400,7 +400,7 @@ int perf_occ_march_count_head(const float* rays_o, const float* rays_d, const fl
                               const float* points_aabb6, float* x01, uint8_t* sel, void* stream);
 
 /* Optional empty-space skip for perf_occ_march_count (what nerfacc's DDA traversal achieves): a dilated 4^3-block
- * occupancy (perf_occ_coarse_words(res) uint32 words) lets the kernel drop whole 64-interval chunks; conservative,
+ * occupancy (perf_occ_coarse_words(res) uint32 words: a dilated 4^3-block grid followed by a dilated 2^3-block grid) lets the kernel drop whole 64-interval chunks; conservative,
  * results are identical with occ_coarse == NULL.  res must be a multiple of 8. */
 int64_t perf_occ_coarse_words(int32_t res);
 int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint32_t* coarse, void* stream);

@@ -52,6 +52,46 @@ __global__ __launch_bounds__(256) void coarse_build_kernel(const uint32_t* __res
     if (any) atomicOr(&coarse[b >> 5], 1u << (b & 31));
 }
 
+// Fine skip grid, behind the coarse one in the same buffer (perf_occ_coarse_words counts both): bit b is set iff any fine cell in
+// the 3x3x3 neighbourhood of the 2^3-block b is occupied.  A chunk that the coarse test lets through is tested again at TWO of
+// its lattice points (k0 + 16, k0 + 48): every interval midpoint of the chunk lies within 16.5 intervals of one of them, i.e.
+// within 0.258 span cells per axis -- while that (+ half a cell of slack) stays below the block size 2, the midpoint's block is the
+// test point's block or a neighbour of it, so two empty dilated blocks prove the chunk empty (conservative: masks and counts are
+// what the exhaustive test gives; the bit-exact marching tests run through it).  Around a thin occupied shell the coarse grid keeps
+// 12 + 4.1 cells = ~4-5 chunks of a ray alive, the fine one 6 + 4.1 = ~2.5.
+constexpr int kFineShift = 1;
+constexpr int kFineBlock = 1 << kFineShift;
+__host__ __device__ __forceinline__ int64_t coarse_words_of(int res) { const int64_t cr = res >> kCoarseShift; return (cr * cr * cr + 31) / 32; }
+__host__ __device__ __forceinline__ int64_t fine_words_of(int res) { const int64_t fr = res >> kFineShift; return (fr * fr * fr + 31) / 32; }
+__global__ __launch_bounds__(256) void fine_build_kernel(const uint32_t* __restrict__ bits, int res, uint32_t* __restrict__ fine) {
+    constexpr int B = kFineBlock;
+    const int fr = res / B;
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= (int64_t)fr * fr * fr) return;
+    const int bx = (int)(b / ((int64_t)fr * fr)), by = (int)((b / fr) % fr), bz = (int)(b % fr);
+    bool any = false;
+    const int z0 = max(bz - 1, 0) * B, z1 = min(bz + 2, fr) * B;
+    for (int x = max(bx - 1, 0) * B; x < min(bx + 2, fr) * B && !any; ++x)
+        for (int y = max(by - 1, 0) * B; y < min(by + 2, fr) * B && !any; ++y)
+            for (int z = z0; z < z1; z += B) {                       // (B divides 32: a block's z run never straddles a word)
+                const uint32_t ci = (uint32_t)((x * res + y) * res + z);
+                if ((bits[ci >> 5] >> (ci & 31)) & ((1u << B) - 1u)) { any = true; break; }
+            }
+    if (any) atomicOr(&fine[b >> 5], 1u << (b & 31));
+}
+
+// the fine block of a point on the ray (same position arithmetic as the cell look-ups)
+__device__ __forceinline__ uint32_t fine_block_at(const MarchParams& mp, const float o[3], const float d[3], float t, float rf, int fr) {
+    int cb[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float p = add_rn(o[a], mul_rn(d[a], t));
+        const float u = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
+        cb[a] = ((int)fminf(fmaxf(floorf(u), 0.0f), rf - 1.0f)) >> kFineShift;
+    }
+    return (uint32_t)((cb[0] * fr + cb[1]) * fr + cb[2]);
+}
+
 __device__ __forceinline__ float lattice_single(float t0, int k, float step) { return add_rn(t0, mul_rn((float)k, step)); }
 
 // PERF_LATTICE_REPEATED: t_0 = t0, t_{j+1} = fl(t_j + step) -- the lattice a marcher that ADVANCES by `t += dt` produces
@@ -315,9 +355,11 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
 #pragma unroll
     for (int a = 0; a < 3; ++a) span_cells = fmaxf(span_cells, fabsf(d[a]) * mp.chunk_cells[a]);
     const bool use_coarse = mp.use_coarse && (span_cells * 0.5f + 1.5f <= (float)kCoarseBlock);
+    const bool use_fine = use_coarse && (span_cells * (16.5f / 64.0f) + 0.5f <= (float)kFineBlock);
     int32_t count = 0;
     const int res = mp.res;
     const float rf = (float)res;
+    const uint32_t* fine = coarse ? coarse + coarse_words_of(res) : nullptr;
     const int nlw = n_live_words(mp.mask_words);
     uint64_t* rec = masks + r * (int64_t)(mp.mask_words + nlw);
     for (int g = 0; g < nlw; ++g) {
@@ -345,6 +387,13 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
                 }
                 const uint32_t bi = (uint32_t)((cb[0] * cr + cb[1]) * cr + cb[2]);
                 maybe = (coarse[bi >> 5] >> (bi & 31)) & 1u;
+                if (maybe && use_fine) {
+                    const int fr = res >> kFineShift;
+                    int run2 = run_at_chunk;                                 // (`run` has moved on to k0 + 64)
+                    const uint32_t f1 = fine_block_at(mp, o, d, lat.after(run2, k0 + 16), rf, fr);
+                    const uint32_t f3 = fine_block_at(mp, o, d, lat.after(run2, k0 + 48), rf, fr);
+                    maybe = (((fine[f1 >> 5] >> (f1 & 31)) | (fine[f3 >> 5] >> (f3 & 31))) & 1u) != 0u;
+                }
             }
         }
         uint64_t live = __ballot(maybe);
@@ -469,6 +518,9 @@ __global__ __launch_bounds__(64) void march_count_shared_kernel(MarchParams mp, 
 #pragma unroll
             for (int a = 0; a < 3; ++a) span_cells = fmaxf(span_cells, fabsf(d[a]) * mp.chunk_cells[a]);
             const bool use_coarse = mp.use_coarse && (span_cells * 0.5f + 1.5f <= (float)kCoarseBlock);
+            const bool use_fine = use_coarse && (span_cells * (16.5f / 64.0f) + 0.5f <= (float)kFineBlock);
+            const uint32_t* fine = coarse ? coarse + coarse_words_of(res) : nullptr;
+            const int fr = res >> kFineShift;
             const int cr = res >> kCoarseShift;
             for (int q0 = 0; q0 < mp.mask_words; q0 += 8) {
                 uint32_t bi[8]; bool in[8];
@@ -495,9 +547,18 @@ __global__ __launch_bounds__(64) void march_count_shared_kernel(MarchParams mp, 
                 uint32_t w[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) w[u] = (in[u] && use_coarse) ? coarse[bi[u] >> 5] : 0u;
+                // survivors of the coarse test: the fine grid at two lattice points of the chunk (few per ray: a divergent tail)
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (in[u] && (!use_coarse || ((w[u] >> (bi[u] & 31u)) & 1u))) live_mine |= 1ull << (q0 + u);
+                for (int u = 0; u < 8; ++u) {
+                    bool alive = in[u] && (!use_coarse || ((w[u] >> (bi[u] & 31u)) & 1u));
+                    if (alive && use_fine) {
+                        const int k0 = (q0 + u) * 64;
+                        const uint32_t f1 = fine_block_at(mp, o, d, lat_full[k0 + 16], rf, fr);
+                        const uint32_t f3 = fine_block_at(mp, o, d, lat_full[k0 + 48], rf, fr);
+                        alive = (((fine[f1 >> 5] >> (f1 & 31)) | (fine[f3 >> 5] >> (f3 & 31))) & 1u) != 0u;
+                    }
+                    if (alive) live_mine |= 1ull << (q0 + u);
+                }
             }
         }
     }
@@ -799,8 +860,7 @@ extern "C" int64_t perf_occ_mask_words(int32_t max_steps) {
 
 extern "C" int64_t perf_occ_coarse_words(int32_t res) {
     if (res <= 0 || (res % 8) != 0) return 0;
-    const int64_t cr = res / kCoarseBlock;
-    return (cr * cr * cr + 31) / 32;
+    return coarse_words_of(res) + fine_words_of(res);           // the dilated 4^3-block grid, then the dilated 2^3-block grid
 }
 
 extern "C" int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint32_t* coarse, void* stream) {
@@ -811,6 +871,9 @@ extern "C" int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint
     const int cr = res / kCoarseBlock;
     hipLaunchKernelGGL(coarse_build_kernel, dim3((unsigned)div_up((int64_t)cr * cr * cr, 256)), dim3(256), 0, as_stream(stream),
                        occ_bits, (int)res, coarse);
+    const int64_t fr = res / kFineBlock;
+    hipLaunchKernelGGL(fine_build_kernel, dim3((unsigned)div_up(fr * fr * fr, 256)), dim3(256), 0, as_stream(stream),
+                       occ_bits, (int)res, coarse + coarse_words_of(res));
     PERF_LAUNCH_CHECK("perf_occ_build_coarse");
     return PERF_OK;
 }

@@ -204,7 +204,36 @@ def test_bench_launches_its_own_ranks(tmp_path, n_ranks):
     assert set(comm['ms_per_step_per_collective']) == {'reduce_scatter', 'all_reduce_small', 'all_gather_w16'} and comm['bytes']['units'] == 'lagged'
     assert comm['single_rank_step_ms'] > 0 and abs(comm['exposed_comm_ms'] - (line['ms_per_step'] - comm['single_rank_step_ms'])) < 1e-9
     assert comm['other_exchange']['dp_mode'] == 'allreduce' and comm['other_exchange']['value'] > 0
+    # ... with ITS collective's time and the bf16-payload variant beside it: the first run on real links gives an A/B, not one number
+    assert comm['other_exchange']['ms_per_step_per_collective']['all_reduce_flat_gradient'] > 0
+    assert comm['other_exchange']['bf16_payload']['value'] > 0 and comm['other_exchange']['bf16_payload']['payload_bytes'] * 2 == comm['other_exchange']['payload_bytes']
     assert line['faithful'] is None or 'geo_ms_per_step' in line['faithful']
+
+
+def test_data_parallel_soak_drops_no_step(tmp_path):
+    """The lagged-units default of the sharded exchange over SEVERAL episodes (reset_geo, a fresh occupancy, new optimizers, re-captured
+    capacities every time): two ranks on this box's one GPU over gloo, five episodes of the schedule on which round 5's PSNR test
+    caught the job-wide gate dropping 10-12 of 300 geometry steps (256x512 doorway panorama, 1024-ray batches, 300 + 300 iterations:
+    late batches whose depth loss vanishes) -- no step may be dropped for an overflow or a truncation in any episode, every rank must
+    leave every episode with the same parameters, and the scene must train every time (tools/soak_episodes.py --one-device)."""
+    import json
+    out = str(tmp_path / 'dp_soak.json')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
+    env.pop('PERF_DP_UNITS', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tools', 'soak_episodes.py'), '--one-device', '--episodes', '5', '--scene', 'doorway',
+           '--geo', '300', '--app', '300', '--height', '256', '--width', '512', '--batch', '1024', '--out', out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.load(open(out))
+    assert res['world'] == 2 and res['data_parallel'] and res['dp_units'] == 'lagged' and len(res['episodes']) == 5
+    print('[dp soak]', [(e['psnr_dB'], e['skipped_for_overflow'], e['skipped_for_truncation'], e['seconds']) for e in res['episodes']])
+    for e in res['episodes']:
+        assert e['skipped_for_overflow'] == 0 and e['skipped_for_truncation'] == 0, e
+        assert e['ranks_hold_identical_parameters'], e
+        assert e['psnr_dB'] > 22.0, e
+    # (the colour field is NOT reset between episodes -- nerf.py:170 re-instantiates the density field only -- so PSNR keeps rising)
+    assert res['episodes'][-1]['psnr_dB'] >= res['episodes'][0]['psnr_dB']
 
 
 @pytest.mark.parametrize('n_levels,log2_t', [(16, 18), (20, 20)])
