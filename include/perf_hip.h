@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 9
+#define PERF_ABI_VERSION 10
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -310,6 +310,19 @@ int64_t perf_field_infer_scratch_bytes(const perf_grid_desc* grid, int64_t n);
 int perf_field_infer(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const uint8_t* sel,
                      const void* table16, const void* w16, float* out, int64_t n, const int64_t* n_dev,
                      void* scratch, int64_t scratch_bytes, void* feat_out, int dtype, void* stream);
+
+/* The whole backward of one field as ONE boundary call (the backward of a tcnn.NetworkWithInputEncoding forward:
+ * modules/fields/ngp_nerf.py:142,158 under modules/scene/nerf.py:252-253): perf_mlp_bwd -> perf_hashgrid_bwd into the table part of the
+ * same flat gradient -> (fixed != 0 && redo != 0) the predicated fp32 repair launch -- chained on the stream, nothing else runs.
+ * grad: fp32 [n_net | 2 * table entries], overwritten.  w16_net: the network part of the 16-bit working copy.  fixed != 0: packed
+ * fixed-point accumulation (overflow_flag / headroom_state as in perf_hashgrid_bwd).  workspace: perf_field_bwd_workspace_bytes(...)
+ * bytes, 16-byte aligned, caller owned (holds the MLP partials, the tile codes, dfeat [L, n, 2] fp32 and the per-level maxima). */
+int64_t perf_field_bwd_workspace_bytes(const perf_grid_desc* grid, const perf_mlp_desc* mlp, int64_t n, int64_t* mlp_ws_bytes,
+                                       int64_t* grid_ws_bytes, int64_t* dfeat_bytes);
+int perf_field_bwd(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const void* w16_net,
+                   const void* feat16, const int32_t* feat_index, int64_t feat_stride, const uint8_t* sel, const float* dout,
+                   float* grad, int32_t fixed, int32_t redo, int32_t* overflow_flag, int32_t* headroom_state,
+                   void* workspace, int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, void* stream);
 
 /* Bytes of caller-owned workspace perf_mlp_bwd needs for n samples. */
 int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n);

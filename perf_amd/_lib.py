@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libperf_hip.so')
 
-ABI_VERSION = 9          # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
+ABI_VERSION = 10         # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
 MAX_LEVELS = 24
 DTYPE_BF16, DTYPE_FP16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
@@ -71,6 +71,8 @@ _SIGS = {
     'perf_mlp_fwd': (c_int, [POINTER(MlpDesc), P, P, P, P, c_int64, P, c_int, P]),
     'perf_field_infer_scratch_bytes': (c_int64, [POINTER(GridDesc), c_int64]),
     'perf_field_infer': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, P, c_int64, P, P, c_int64, P, c_int, P]),
+    'perf_field_bwd_workspace_bytes': (c_int64, [POINTER(GridDesc), POINTER(MlpDesc), c_int64, P, P, P]),
+    'perf_field_bwd': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, c_int64, P, P, P, c_int32, c_int32, P, P, P, c_int64, c_int64, P, c_int, P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
     'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, c_int64, P, P, P, P, P, P, c_int64, c_int64, P, c_int, P]),
     'perf_pano_raygen': (c_int, [POINTER(c_float), c_int32, c_int32, c_int32, c_int32, P, P, P]),

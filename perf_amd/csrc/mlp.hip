@@ -162,3 +162,50 @@ extern "C" int perf_field_infer(const perf_grid_desc* grid, const perf_mlp_desc*
     if (rc) return rc;
     return perf_mlp_fwd(mlp, w16, feat, sel, out, n, n_dev, dtype, stream);
 }
+
+// ---- the whole backward of one field as ONE boundary call (what a tcnn.NetworkWithInputEncoding backward is to its caller:
+// modules/fields/ngp_nerf.py:142,158 under loss.backward(), modules/scene/nerf.py:252-253): MLP backward (weight gradient, feature
+// gradient, per-level max |dfeat|) -> grid backward into the table part of the same flat gradient -> [the predicated fp32 repair
+// launch of a fixed-point call].  Nothing new runs on the device -- the three entry points are chained on the stream -- but a
+// binding crosses the boundary once per backward instead of three times (the operator-shim step is host bound:
+// profiles/r06_shim_step_host.json).  grad: [n_net | 2 * table entries] fp32, overwritten.  level_absmax != NULL selects the packed
+// fixed-point accumulation (then overflow_flag / headroom_state as in perf_hashgrid_bwd); redo != 0 appends the repair launch.
+extern "C" int64_t perf_field_bwd_workspace_bytes(const perf_grid_desc* grid, const perf_mlp_desc* mlp, int64_t n, int64_t* mlp_ws_bytes,
+                                                 int64_t* grid_ws_bytes, int64_t* dfeat_bytes) {
+    if (!grid || !mlp || n < 0) return -1;
+    const int64_t a = perf_mlp_bwd_workspace_bytes(mlp, n), b = perf_hashgrid_bwd_workspace_bytes(grid, n);
+    if (a < 0 || b < 0) return -1;
+    const int64_t a16 = (a + 15) & ~(int64_t)15, b16 = (b + 31) & ~(int64_t)15, c = (int64_t)grid->n_levels * n * 8;
+    if (mlp_ws_bytes) *mlp_ws_bytes = a16;
+    if (grid_ws_bytes) *grid_ws_bytes = b16;
+    if (dfeat_bytes) *dfeat_bytes = c;
+    return a16 + b16 + ((c + 15) & ~(int64_t)15) + PERF_MAX_LEVELS * (int64_t)sizeof(float);
+}
+
+extern "C" int perf_field_bwd(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const void* w16_net,
+                              const void* feat16, const int32_t* feat_index, int64_t feat_stride, const uint8_t* sel, const float* dout,
+                              float* grad, int32_t fixed, int32_t redo, int32_t* overflow_flag, int32_t* headroom_state,
+                              void* workspace, int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
+    PERF_REQUIRE(grid && mlp && grad && workspace, "NULL pointer");
+    PERF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "perf_field_bwd: the workspace must be 16-byte aligned");
+    int nh, ks;
+    int rc = check_mlp(mlp, &nh, &ks);
+    if (rc) return rc;
+    int64_t a16 = 0, b16 = 0, c = 0;
+    const int64_t need = perf_field_bwd_workspace_bytes(grid, mlp, n, &a16, &b16, &c);
+    PERF_REQUIRE(need >= 0 && workspace_bytes >= need, "perf_field_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    char* ws = reinterpret_cast<char*>(workspace);
+    void* mlp_ws = ws;
+    void* grid_ws = ws + a16;
+    float* dfeat = reinterpret_cast<float*>(ws + a16 + b16);
+    float* amax = reinterpret_cast<float*>(ws + a16 + b16 + ((c + 15) & ~(int64_t)15));
+    const int n_net = n_params_rt(nh, ks);
+    rc = perf_mlp_bwd(mlp, w16_net, feat16, feat_index, feat_stride, sel, dout, dfeat, grad, fixed ? amax : nullptr, mlp_ws, a16, n, n_dev, dtype, stream);
+    if (rc) return rc;
+    rc = perf_hashgrid_bwd(grid, x01, dfeat, grad + n_net, n, n_dev, 0, fixed ? amax : nullptr, fixed ? overflow_flag : nullptr,
+                           fixed ? headroom_state : nullptr, nullptr, 0, nullptr, grid_ws, b16, stream);
+    if (rc) return rc;
+    if (fixed && redo)
+        rc = perf_hashgrid_bwd(grid, x01, dfeat, grad + n_net, n, n_dev, 0, nullptr, nullptr, headroom_state, nullptr, 0, overflow_flag, nullptr, 0, stream);
+    return rc;
+}

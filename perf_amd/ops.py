@@ -253,6 +253,53 @@ def hashgrid_bwd_redo(grid: GridConfig, x01, dfeat, out, n_dev=None, hr_state=No
     return out
 
 
+_FIELD_BWD_WS = {}
+FIELD_BWD_ONE_CALL = True       # False: the three entry points one by one (tools/shim_step_profile.py --three-calls: the A/B of the host cost)
+
+
+def field_bwd(grid: GridConfig, mlp: MlpConfig, x01, w16_net, feat16, dout, sel=None, fixed=True, redo=True, hr_state=None, n_dev=None,
+              grad=None, extra=0):
+    """The whole backward of one field in ONE boundary call (perf_field_bwd: MLP backward -> grid backward -> predicated fp32 repair)
+    -> flat fp32 gradient [network | grid (+ `extra` trailing slots)].  feat16: [L, n, 2] or an IndexedFeat.  The workspace (MLP
+    partials, tile codes, dfeat) is cached per (device, n, grid, network): consecutive backwards on one stream reuse it -- do not
+    overlap two backwards of the same shape on different streams."""
+    index, stride = None, 0
+    if isinstance(feat16, IndexedFeat):
+        feat16, index = feat16.feat, feat16.index
+        stride = feat16.shape[1]
+    n = index.shape[0] if index is not None else feat16.shape[1]
+    dev = x01.device
+    n_all = mlp.n_params + grid.n_params
+    if grad is None:
+        grad = torch.empty(n_all + extra, dtype=torch.float32, device=dev)
+    if _PROF is not None or not FIELD_BWD_ONE_CALL:
+        # per-launch timing (start_kernel_timing: bench.py's `kernels` / `roofline` blocks): the same three entry points one by one,
+        # so that each is bracketed by its own pair of events
+        res = mlp_bwd(mlp, w16_net, IndexedFeat(feat16, index) if index is not None else feat16, dout, sel, want_absmax=fixed, n_dev=n_dev,
+                      dw_out=grad[:mlp.n_params])
+        hashgrid_bwd_into(grid, x01, res[0], grad[mlp.n_params:n_all], level_absmax=res[2] if fixed else None, n_dev=n_dev,
+                          hr_state=hr_state if fixed else None)
+        if fixed and redo:
+            hashgrid_bwd_redo(grid, x01, res[0], grad[mlp.n_params:n_all], n_dev=n_dev, hr_state=hr_state)
+        return grad
+    gd, md = grid.desc(), mlp.desc()
+    key = (str(dev), n, id(gd), mlp.n_levels, mlp.n_hidden_layers, mlp.n_output_dims)
+    ws = _FIELD_BWD_WS.get(key)
+    if ws is None:
+        nbytes = _lib.load().perf_field_bwd_workspace_bytes(ctypes.byref(gd), ctypes.byref(md), n, None, None, None)
+        if nbytes < 0:
+            raise _lib.PerfError('perf_field_bwd_workspace_bytes: bad arguments')
+        ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=dev)
+        if not torch.cuda.is_current_stream_capturing():       # (a block first made INSIDE a capture belongs to that graph's pool: not kept)
+            if len(_FIELD_BWD_WS) >= 8:      # (a handful of shapes per process: a phase's capacity, the shim path's exact sizes)
+                _FIELD_BWD_WS.pop(next(iter(_FIELD_BWD_WS)))
+            _FIELD_BWD_WS[key] = ws
+    _call('perf_field_bwd', ctypes.byref(gd), ctypes.byref(md), _p(_f32(x01, 'x01')), _p(w16_net), _p(feat16), _p(index), stride, _p(sel),
+          _p(_f32(dout, 'dout')), _p(grad), int(bool(fixed)), int(bool(fixed and redo)), _p(overflow_flag(dev)) if fixed else None,
+          _p(hr_state) if fixed else None, _p(ws), ws.numel() * 4, n, _nd(n_dev), dtype_code(w16_net.dtype), _stream())
+    return grad
+
+
 def hashgrid_bwd_into(grid, x01, dfeat, out, level_absmax=None, n_dev=None, hr_state=None, shifts=None, raw_fields=False):
     return hashgrid_bwd(grid, x01, dfeat, out=out, accumulate=False, level_absmax=level_absmax, n_dev=n_dev, hr_state=hr_state,
                         shifts=shifts, raw_fields=raw_fields)

@@ -851,6 +851,16 @@ class NeRFScene:
         n_net = net.mlp.n_params
         fixed = net.grid_grad_accum == 'fixed'
         n_all = n_net + net.grid.n_params
+        if not fixed or net.redo_supported:
+            # ONE boundary call (perf_field_bwd): MLP backward -> grid backward -> the predicated fp32 repair launch that keeps a
+            # flagged fixed-point step from being dropped (a no-op dispatch otherwise)
+            grad = ops.field_bwd(net.grid, net.mlp, x01, w16[:n_net], feat, dout, sel, fixed=fixed, redo=True,
+                                 hr_state=net.headroom_state() if fixed else None, n_dev=n_dev, extra=extra)
+            if fixed and not self.fused_adam:
+                # torch.optim.Adam has no perf_step_bookkeeping behind it to consume the flag: left set, every later backward
+                # would run its (slow) fp32 repair as well
+                ops.overflow_flag(x01.device).zero_()
+            return grad
         grad = torch.empty(n_all + extra, dtype=torch.float32, device=x01.device)
         res = ops.mlp_bwd(net.mlp, w16[:n_net], feat, dout, sel, want_absmax=fixed, n_dev=n_dev, dw_out=grad[:n_net])
         ops.hashgrid_bwd_into(net.grid, x01, res[0], grad[n_net:n_all], level_absmax=res[2] if fixed else None, n_dev=n_dev,

@@ -95,6 +95,13 @@ def _field_backward(module, x01, w16, feat, sel, dout, n_dev=None, clear_flag=Fa
     backward, capturable).  clear_flag: the autograd (shim) path has no perf_step_bookkeeping behind it to consume the flag."""
     n_net = module.mlp.n_params
     fixed = module.grid_grad_accum == 'fixed'
+    if not fixed or module.redo_supported:
+        # ONE boundary call: MLP backward -> grid backward -> predicated repair launch (perf_field_bwd), cached workspace
+        grad = ops.field_bwd(module.grid, module.mlp, x01, w16[:n_net], feat, dout.contiguous().float(), sel, fixed=fixed, redo=True,
+                             hr_state=module.headroom_state() if fixed else None, n_dev=n_dev)
+        if fixed and clear_flag:
+            ops.overflow_flag(x01.device).zero_()
+        return grad
     grad = torch.empty(n_net + module.grid.n_params, dtype=torch.float32, device=x01.device)
     res = ops.mlp_bwd(module.mlp, w16[:n_net], feat, dout.contiguous().float(), sel, want_absmax=fixed, n_dev=n_dev, dw_out=grad[:n_net])
     ops.hashgrid_bwd_into(module.grid, x01, res[0], grad[n_net:], level_absmax=res[2] if fixed else None, n_dev=n_dev,

@@ -1271,3 +1271,43 @@ def test_train_head_on_a_batch_without_samples(ops):
     ha = ops.train_head_app(c(sig), c(rgb), c(ts), c(te), c(packed), c(bg), c(gt_c), R, 1.0, 128.0)
     _, sca = ops.app_loss(op, col, c(bg), c(gt_c), R, 1.0, 128.0)
     assert abs(float(ha['color_terms'].sum() / (3 * R)) - float(sca[0])) <= 1e-6 * abs(float(sca[0]))
+
+
+@pytest.mark.parametrize('fixed', [True, False])
+@pytest.mark.parametrize('nh,n_out,act', [(1, 1, 'Exponential'), (2, 3, 'Sigmoid')])
+def test_field_backward_in_one_boundary_call_equals_the_three_calls(ops, fixed, nh, n_out, act):
+    """perf_field_bwd (MLP backward -> grid backward -> predicated repair launch, one workspace) against the three entry points
+    called one by one: the same flat gradient (bit for bit with the order-independent fixed-point fields), with plain features, with an IndexedFeat, with a device-side live count,
+    and on a second call that reuses the cached workspace; the headroom feedback state ends in the same place."""
+    cfg = _grid_cfg()
+    cfgm, w, feat, sel, tdt, _ = _mlp_case(ops, 'bf16', nh, n_out, act, n=20011, seed=5)
+    g = torch.Generator().manual_seed(11)
+    n = feat.shape[1]
+    x = torch.rand(n, 3, generator=g).cuda()
+    dout = (torch.randn(n, n_out, generator=g) * 1e-2).cuda()
+    w16, f16, selc = w.to(tdt).cuda(), feat.to(tdt).cuda(), sel.cuda()
+    n_net = cfgm.n_params
+
+    def three(feat_arg, n_dev, hr):
+        grad = torch.empty(n_net + cfg.n_params, dtype=torch.float32, device='cuda')
+        res = ops.mlp_bwd(cfgm, w16, feat_arg, dout, selc, want_absmax=fixed, n_dev=n_dev, dw_out=grad[:n_net])
+        ops.hashgrid_bwd_into(cfg, x, res[0], grad[n_net:], level_absmax=res[2] if fixed else None, n_dev=n_dev, hr_state=hr if fixed else None)
+        if fixed:
+            ops.hashgrid_bwd_redo(cfg, x, res[0], grad[n_net:], n_dev=n_dev, hr_state=hr)
+        return grad
+
+    idx = torch.randperm(n, generator=g).to(torch.int32).cuda()
+    src = torch.empty_like(f16); src[:, idx.long()] = f16                       # features stored in another order + the row of every sample
+    for feat_arg, n_dev in ((f16, None), (ops.IndexedFeat(src, idx), None), (f16, torch.tensor([12345], dtype=torch.int64, device='cuda'))):
+        hr_a, hr_b = ops.headroom_state('cuda'), ops.headroom_state('cuda')
+        for rep in range(2):                                                     # (second pass: cached workspace, evolved headroom state)
+            ops.overflow_flag('cuda').zero_()
+            a = three(feat_arg, n_dev, hr_a)
+            ops.overflow_flag('cuda').zero_()
+            b = ops.field_bwd(cfg, cfgm, x, w16, feat_arg, dout, selc, fixed=fixed, redo=True, hr_state=hr_b if fixed else None, n_dev=n_dev)
+            if fixed:
+                assert torch.equal(a, b), (nh, rep, float((a - b).abs().max()))
+                assert torch.equal(hr_a, hr_b)
+            else:       # fp32 LDS atomics add in arrival order: two runs of the SAME call differ in the last bits
+                assert torch.equal(a[:n_net], b[:n_net]) and float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), (nh, rep)
+    assert float(b.abs().max()) > 0

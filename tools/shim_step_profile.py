@@ -21,9 +21,13 @@ ap.add_argument('--warm-geo', type=int, default=600)
 ap.add_argument('--dtype', default='bf16')
 ap.add_argument('--out', default='gpurun_out/r05_shim')
 ap.add_argument('--no-profiler', action='store_true')
+ap.add_argument('--three-calls', action='store_true', help="a field's backward as three boundary calls (round 5) instead of perf_field_bwd: the host-cost A/B")
 ap.add_argument('--fused-adam', action='store_true', help='the shim-level autograd step with the fused Adam kernel instead of torch.optim.Adam')
 args = ap.parse_args()
 
+if args.three_calls:
+    from perf_amd import ops as _ops
+    _ops.FIELD_BWD_ONE_CALL = False
 H, W = 1024, 2048
 rays = gen_pano_rays(torch.eye(4), H, W)
 dist, rgb = synthetic.room(rays.d)
