@@ -4,6 +4,7 @@
 #include "common.hpp"
 #include "grid_device.hpp"
 #include "grid_fixed_point.hpp"
+#include "mlp_reduce_device.hpp"
 
 namespace perf {
 
@@ -355,10 +356,13 @@ __device__ __forceinline__ void tile_codes_block(const GridParams& gp, const Til
     if (threadIdx.x == 0) escape[blockIdx.x] = esc_block;       // every word is written: no zero-fill needed
 }
 
+// (both pre-pass kernels can carry the MLP backward's second stage in workgroups of their own behind the `own_blocks` that compute
+//  codes: mlp_reduce_device.hpp)
 __global__ __launch_bounds__(256) void tile_codes_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
                                                          const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
                                                          uint32_t* __restrict__ escape, int64_t n,
-                                                         const int64_t* __restrict__ n_dev) {
+                                                         const int64_t* __restrict__ n_dev, MlpReduceJob job, unsigned own_blocks) {
+    if (blockIdx.x >= own_blocks) { mlp_reduce_block(job, (int)(blockIdx.x - own_blocks)); return; }
     tile_codes_block(gp, tp, x01, dfeat, codes, escape, n, live_count(n, n_dev));       // n: capacity = stride of dfeat / codes
 }
 
@@ -373,7 +377,8 @@ constexpr int64_t kCodes4MinLive = 65536;
 __global__ __launch_bounds__(256) void tile_codes4_kernel(GridParams gp, TileParams tp, const float* __restrict__ x01,
                                                           const float2* __restrict__ dfeat, uint32_t* __restrict__ codes,
                                                           uint32_t* __restrict__ escape, int64_t n, int64_t n_words,
-                                                          const int64_t* __restrict__ n_dev) {
+                                                          const int64_t* __restrict__ n_dev, MlpReduceJob job, unsigned own_blocks) {
+    if (blockIdx.x >= own_blocks) { mlp_reduce_block(job, (int)(blockIdx.x - own_blocks)); return; }
     const int64_t n_live = live_count(n, n_dev);
     if (n_live < kCodes4MinLive) {                         // (uniform)
         tile_codes_block(gp, tp, x01, dfeat, codes, escape, n, n_live);
@@ -1266,9 +1271,22 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
                                  float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
                                  int32_t* overflow_flag, int32_t* headroom_state, const int32_t* shifts_dev, int raw_fields,
                                  const int32_t* redo_flag, void* workspace, int64_t workspace_bytes, void* stream) {
+    return perf_internal_hashgrid_bwd(grid, x01, dfeat, grad_table, n, n_dev, accumulate, level_absmax, overflow_flag, headroom_state, shifts_dev,
+                                      raw_fields, redo_flag, workspace, workspace_bytes, stream, nullptr);
+}
+
+// job (perf_field_bwd): the deferred second stage of the MLP backward that produced `dfeat` / `level_absmax`; it rides in the
+// tile-code launch when there is one and gets a launch of its own otherwise -- in either case BEFORE the owners, which read level_absmax
+int perf_internal_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
+                               float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
+                               int32_t* overflow_flag, int32_t* headroom_state, const int32_t* shifts_dev, int raw_fields,
+                               const int32_t* redo_flag, void* workspace, int64_t workspace_bytes, void* stream, const MlpReduceJob* job_in) {
+    MlpReduceJob job{};
+    if (job_in) job = *job_in;
     GridParams gp;
     int rc = fill_params(grid, &gp);
     if (rc) return rc;
+    PERF_REQUIRE(!(redo_flag && job.n_blocks), "perf_hashgrid_bwd: a redo call carries no deferred work");
     PERF_REQUIRE(grad_table, "NULL pointer");
     PERF_REQUIRE(n == 0 || (x01 && dfeat), "NULL pointer");
     const bool fixed = level_absmax != nullptr || shifts_dev != nullptr;
@@ -1361,15 +1379,20 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
         workspace_bytes >= codes_at + (int64_t)slots * tp.n_pad * 4 + esc_words * 4) {
         codes = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + codes_at);
         escape = codes + (int64_t)slots * tp.n_pad;
+        const unsigned own = (unsigned)esc_words, all = own + (unsigned)job.n_blocks;
         if ((reinterpret_cast<uintptr_t>(codes) & 15) == 0)
-            tile_codes4_kernel<<<dim3((unsigned)esc_words), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
-                                                                                                            codes, escape, n, esc_words, n_dev);
+            tile_codes4_kernel<<<dim3(all), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat, codes, escape, n, esc_words, n_dev,
+                                                                                job, own);
         else
-            tile_codes_kernel<<<dim3((unsigned)esc_words), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat,
-                                                                                                 codes, escape, n, n_dev);
+            tile_codes_kernel<<<dim3(all), dim3(256), 0, as_stream(stream)>>>(gp, tp, x01, (const float2*)dfeat, codes, escape, n, n_dev, job, own);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(codes)");
+        job.n_blocks = 0;                          // (done)
     } else {
         for (int l = 0; l < PERF_MAX_LEVELS; ++l) tp.code_slot[l] = -1;
+    }
+    if (job.n_blocks) {                            // no tile-code launch to ride in
+        perf_internal_launch_mlp_reduce(job, stream);
+        PERF_LAUNCH_CHECK("perf_hashgrid_bwd(deferred MLP reduce)");
     }
     const int lds_bytes = 2 * kTileEntries * (int)sizeof(float) + (kBwdThreads / 64) * kQueueCap * (int)sizeof(uint32_t);
     static std::once_flag attr_once;                // one-time kernel attribute setup, safe under concurrent callers

@@ -1,54 +1,12 @@
 // C-ABI entry points of the 64-wide MLP (perf_mlp_fwd / perf_mlp_bwd / perf_field_infer).  The kernels live in mlp_device.hpp and are
 // instantiated in mlp_fwd_{bf16,fp16}.hip and mlp_bwd_{bf16,fp16}_nh{1,2}.hip.
 #include "mlp_device.hpp"
+#include "mlp_reduce_device.hpp"
 
 namespace perf {
 
-// dw[i] = sum_k partials[k][i] (fixed order: deterministic), combined through LDS
-__global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
-                                                         int n_params, int n_partials, const float* __restrict__ amax_slots,
-                                                         float* __restrict__ level_absmax, int n_levels) {
-    __shared__ float acc[4][64];
-    if (blockIdx.x == gridDim.x - 1) {
-        // extra block: level_absmax[l] = max over all (wave, half) slots of the half that owns level l
-        if (level_absmax == nullptr) return;
-        float m0 = 0.f, m1 = 0.f;
-        for (int k = threadIdx.x; k < n_partials * 4; k += 256) { m0 = fmaxf(m0, amax_slots[2 * k]); m1 = fmaxf(m1, amax_slots[2 * k + 1]); }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, off)); m1 = fmaxf(m1, __shfl_xor(m1, off)); }
-        if ((threadIdx.x & 63) == 0) { acc[0][threadIdx.x >> 6] = m0; acc[1][threadIdx.x >> 6] = m1; }
-        __syncthreads();
-        if (threadIdx.x < PERF_MAX_LEVELS) {
-            const int h = (threadIdx.x >> 1) & 1;          // levels {0,1,4,5,..} live in half 0, {2,3,6,7,..} in half 1
-            const float v = fmaxf(fmaxf(acc[h][0], acc[h][1]), fmaxf(acc[h][2], acc[h][3]));
-            level_absmax[threadIdx.x] = (int)threadIdx.x < n_levels ? v : 0.f;
-        }
-        return;
-    }
-    // 16 parameters x 16 partial-segments per block (one 64-byte sector per row), 4 independent loads in flight
-    const int pl = threadIdx.x & 15, seg = threadIdx.x >> 4;
-    const int pi = blockIdx.x * 16 + pl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (pi < n_params) {
-        int k = seg;
-        for (; k + 48 < n_partials; k += 64) {
-            s0 += partials[(int64_t)k * n_params + pi];
-            s1 += partials[(int64_t)(k + 16) * n_params + pi];
-            s2 += partials[(int64_t)(k + 32) * n_params + pi];
-            s3 += partials[(int64_t)(k + 48) * n_params + pi];
-        }
-        for (; k < n_partials; k += 16) s0 += partials[(int64_t)k * n_params + pi];
-    }
-    float* a = &acc[0][0];                          // 256 floats: [seg][param]
-    a[seg * 16 + pl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (seg == 0 && pi < n_params) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t += a[q * 16 + pl];
-        dw[pi] = t;
-    }
-}
+// dw[i] = sum_k partials[k][i] (fixed order: deterministic), combined through LDS (mlp_reduce_device.hpp)
+__global__ __launch_bounds__(256) void mlp_reduce_kernel(MlpReduceJob job) { mlp_reduce_block(job, (int)blockIdx.x); }
 
 }  // namespace perf
 
@@ -79,9 +37,23 @@ extern "C" int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_
     return ((int64_t)blocks * n_params_rt(nh, ks) + (int64_t)blocks * 8) * (int64_t)sizeof(float);
 }
 
+void perf_internal_launch_mlp_reduce(const MlpReduceJob& job, void* stream) {
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)job.n_blocks), dim3(256), 0, as_stream(stream), job);
+}
+
 extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const int32_t* feat_index, int64_t feat_stride,
                             const uint8_t* sel, const float* dout, float* dfeat, float* dw, float* level_absmax, void* workspace,
                             int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
+    return perf_internal_mlp_bwd(mlp, w16, feat16, feat_index, feat_stride, sel, dout, dfeat, dw, level_absmax, workspace, workspace_bytes, n, n_dev,
+                                 dtype, stream, nullptr);
+}
+
+// defer != NULL: the second stage is NOT launched; *defer describes it (n_blocks == 0 when there is nothing to reduce) and the caller
+// lets it ride in a later launch of the same stream (perf_field_bwd: the tile-code pre-pass of the grid backward)
+int perf_internal_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const void* feat16, const int32_t* feat_index, int64_t feat_stride,
+                          const uint8_t* sel, const float* dout, float* dfeat, float* dw, float* level_absmax, void* workspace,
+                          int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, void* stream, MlpReduceJob* defer) {
+    if (defer) defer->n_blocks = 0;
     int nh, ks;
     int rc = check_mlp(mlp, &nh, &ks);
     if (rc) return rc;
@@ -108,8 +80,9 @@ extern "C" int perf_mlp_bwd(const perf_mlp_desc* mlp, const void* w16, const voi
         (nh == 1 ? mlp_bwd_fp16_nh1 : mlp_bwd_fp16_nh2)(ks, blocks, as_stream(stream), mp, (const uint16_t*)w16, (const uint32_t*)feat16, feat_index, feat_stride, sel,
                            dout, (float2*)dfeat, (float*)workspace, amax_slots, n, n_dev);
     PERF_LAUNCH_CHECK("perf_mlp_bwd");
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)div_up(np, 16) + 1), dim3(256), 0, as_stream(stream),
-                       (const float*)workspace, dw, np, blocks, (const float*)amax_slots, level_absmax, (int)mlp->n_levels);
+    MlpReduceJob job{(const float*)workspace, dw, (const float*)amax_slots, level_absmax, np, blocks, (int32_t)mlp->n_levels, (int32_t)div_up(np, 16) + 1};
+    if (defer) { *defer = job; return PERF_OK; }
+    perf_internal_launch_mlp_reduce(job, stream);
     PERF_LAUNCH_CHECK("perf_mlp_bwd(reduce)");
     return PERF_OK;
 }
@@ -200,10 +173,13 @@ extern "C" int perf_field_bwd(const perf_grid_desc* grid, const perf_mlp_desc* m
     float* dfeat = reinterpret_cast<float*>(ws + a16 + b16);
     float* amax = reinterpret_cast<float*>(ws + a16 + b16 + ((c + 15) & ~(int64_t)15));
     const int n_net = n_params_rt(nh, ks);
-    rc = perf_mlp_bwd(mlp, w16_net, feat16, feat_index, feat_stride, sel, dout, dfeat, grad, fixed ? amax : nullptr, mlp_ws, a16, n, n_dev, dtype, stream);
+    // (the MLP backward's second stage -- weight-gradient partials, per-level maxima -- rides in the grid backward's tile-code launch)
+    MlpReduceJob job;
+    rc = perf_internal_mlp_bwd(mlp, w16_net, feat16, feat_index, feat_stride, sel, dout, dfeat, grad, fixed ? amax : nullptr, mlp_ws, a16, n, n_dev, dtype,
+                               stream, &job);
     if (rc) return rc;
-    rc = perf_hashgrid_bwd(grid, x01, dfeat, grad + n_net, n, n_dev, 0, fixed ? amax : nullptr, fixed ? overflow_flag : nullptr,
-                           fixed ? headroom_state : nullptr, nullptr, 0, nullptr, grid_ws, b16, stream);
+    rc = perf_internal_hashgrid_bwd(grid, x01, dfeat, grad + n_net, n, n_dev, 0, fixed ? amax : nullptr, fixed ? overflow_flag : nullptr,
+                                    fixed ? headroom_state : nullptr, nullptr, 0, nullptr, grid_ws, b16, stream, &job);
     if (rc) return rc;
     if (fixed && redo)
         rc = perf_hashgrid_bwd(grid, x01, dfeat, grad + n_net, n, n_dev, 0, nullptr, nullptr, headroom_state, nullptr, 0, overflow_flag, nullptr, 0, stream);

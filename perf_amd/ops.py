@@ -261,8 +261,8 @@ def field_bwd(grid: GridConfig, mlp: MlpConfig, x01, w16_net, feat16, dout, sel=
               grad=None, extra=0):
     """The whole backward of one field in ONE boundary call (perf_field_bwd: MLP backward -> grid backward -> predicated fp32 repair)
     -> flat fp32 gradient [network | grid (+ `extra` trailing slots)].  feat16: [L, n, 2] or an IndexedFeat.  The workspace (MLP
-    partials, tile codes, dfeat) is cached per (device, n, grid, network): consecutive backwards on one stream reuse it -- do not
-    overlap two backwards of the same shape on different streams."""
+    partials, tile codes, dfeat) is cached per (device, grid, network) and grown on demand: consecutive backwards on one stream reuse
+    it -- do not overlap two backwards of the same field on different streams."""
     index, stride = None, 0
     if isinstance(feat16, IndexedFeat):
         feat16, index = feat16.feat, feat16.index
@@ -283,15 +283,19 @@ def field_bwd(grid: GridConfig, mlp: MlpConfig, x01, w16_net, feat16, dout, sel=
             hashgrid_bwd_redo(grid, x01, res[0], grad[mlp.n_params:n_all], n_dev=n_dev, hr_state=hr_state)
         return grad
     gd, md = grid.desc(), mlp.desc()
-    key = (str(dev), n, id(gd), mlp.n_levels, mlp.n_hidden_layers, mlp.n_output_dims)
+    nbytes = _lib.load().perf_field_bwd_workspace_bytes(ctypes.byref(gd), ctypes.byref(md), n, None, None, None)
+    if nbytes < 0:
+        raise _lib.PerfError('perf_field_bwd_workspace_bytes: bad arguments')
+    # ONE workspace per (device, field), grown geometrically: the operator-shim path calls with a different exact n every step -- a
+    # buffer per size would pin a pool of differently sized blocks and push the caching allocator into hipMalloc (measured: +0.3 ms
+    # per step); any buffer that is large enough serves (the library lays it out from n)
+    key = (str(dev), id(gd), mlp.n_levels, mlp.n_hidden_layers, mlp.n_output_dims)
     ws = _FIELD_BWD_WS.get(key)
-    if ws is None:
-        nbytes = _lib.load().perf_field_bwd_workspace_bytes(ctypes.byref(gd), ctypes.byref(md), n, None, None, None)
-        if nbytes < 0:
-            raise _lib.PerfError('perf_field_bwd_workspace_bytes: bad arguments')
-        ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=dev)
+    if ws is None or ws.numel() * 4 < nbytes:
+        grown = max(nbytes, int(1.5 * ws.numel() * 4) if ws is not None else 0)
+        ws = torch.empty(grown // 4 + 4, dtype=torch.float32, device=dev)
         if not torch.cuda.is_current_stream_capturing():       # (a block first made INSIDE a capture belongs to that graph's pool: not kept)
-            if len(_FIELD_BWD_WS) >= 8:      # (a handful of shapes per process: a phase's capacity, the shim path's exact sizes)
+            if len(_FIELD_BWD_WS) >= 16 and key not in _FIELD_BWD_WS:
                 _FIELD_BWD_WS.pop(next(iter(_FIELD_BWD_WS)))
             _FIELD_BWD_WS[key] = ws
     _call('perf_field_bwd', ctypes.byref(gd), ctypes.byref(md), _p(_f32(x01, 'x01')), _p(w16_net), _p(feat16), _p(index), stride, _p(sel),

@@ -1,15 +1,17 @@
 # Round 6 GPU call (rewritten per call; the log of calls is profiles/r06_gpurun_calls.md)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06n
+O=$R/gpurun_out/r06p
 rm -rf $O; mkdir -p $O
 cd $R
-( time timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 ) > $O/pytest.log 2>&1
+( time timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_scene.py tests/test_gpu_counts.py -m gpu -x -q ) > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log
-timeout 600 python tools/shim_step_profile.py --steps 200 --out $O/shim > $O/shim.log 2>&1
-( time timeout 900 python bench.py --no-config5 ) > $O/bench.log 2> $O/bench.err
-tail -1 $O/bench.log > $O/bench_line.json
-du -sh $O; tail -6 $O/pytest.log; tail -5 $O/shim.log; python -c "
+for T in three_a one_a three_b one_b; do
+  F=""; case $T in three*) F="--three-calls";; esac
+  timeout 600 python tools/shim_step_profile.py --steps 200 $F --out $O/shim_$T > $O/shim_$T.log 2>&1
+done
+rm -f $O/*trace.json
+du -sh $O; tail -4 $O/pytest.log; python -c "
 import json
-d=json.load(open('$O/bench_line.json'))
-print(d['value'], d['ms_per_step']); print(d['faithful']); print(d['psnr']['train_seconds'])
+for t in ('three_a','one_a','three_b','one_b'):
+    d=json.load(open('$O/shim_%s_host.json' % t)); print(t, d['geo_ms_per_step'], d['app_ms_per_step'], d['geo']['host_self_cpu_us_per_step'].get('_FieldFnBackward'), d['geo']['host_self_cpu_us_per_step'].get('hipLaunchKernel'))
 "
