@@ -872,7 +872,7 @@ def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other
 # what the counters say bounds the dominant kernels (profiles/r03_*): the encode is bound by the L1's request rate, the
 # grid backward by VALU issue; neither by HBM bandwidth -- `frac` is nevertheless priced against HBM
 BOUND = {'perf_hashgrid_fwd': 'l1-miss', 'perf_hashgrid_bwd': 'valu'}
-PMC_FILES = ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
+PMC_FILES = ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
 
 
 def _workload_key(args):
