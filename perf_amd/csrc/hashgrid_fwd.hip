@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_kernel(GridParams gp, Gr
                 a0 = fmaf(w[k], T16::lo(v[k]), a0);
                 a1 = fmaf(w[k], T16::hi(v[k]), a1);
             }
-            feat[(int64_t)l * n + i] = T16::pack(a0, a1);
+            __builtin_nontemporal_store(T16::pack(a0, a1), &feat[(int64_t)l * n + i]);      // (streamed: read next by the MLP kernel, not here)
         }
         return;
     }
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_kernel(GridParams gp, Gr
             if ((int)r == it) mine = T16::pack(p0, p1);              // (all four lanes hold the same sums: lane r keeps group r's)
         }
         const int64_t io = base + 16 * (int64_t)r + s;
-        if (io < n_live) feat[(int64_t)l * n + io] = mine;
+        if (io < n_live) __builtin_nontemporal_store(mine, &feat[(int64_t)l * n + io]);
     }
 }
 
