@@ -62,6 +62,10 @@ class GridSlice:
         for k, l in enumerate(self.levels):
             d.scale[k] = float(self.full.scale[l]); d.res[k] = int(self.full.res[l]); d.size[k] = int(self.full.size[l])
             d.offset[k] = int(self.offset[k]); d.hashed[k] = int(self.full.hashed[l])
+            d.local[k] = int(self.full.local[l]); d.nsx[k] = int(self.full.nsx[l]); d.nsxy[k] = int(self.full.nsxy[l])
+        d.layout = _lib.LAYOUT_LINE_LOCAL if self.full.layout == 'line_local' else _lib.LAYOUT_TCNN       # (a level keeps its layout on its rank)
+        for k in range(3):
+            d.sb_shift[k] = int(self.full.sb_shift[k])
         self._desc = d
         return d
 
@@ -212,20 +216,24 @@ class LevelShardedNeRF:
         self.training = False
         self._aabb_host = nerf._aabb_host
         self.aabb = nerf.aabb
-        self.dtype_name = dtype or nerf.geo_mlp.dtype_name
+        self.dtype_name = dtype or (nerf.dtype_name if hasattr(nerf, 'nets') else nerf.geo_mlp.dtype_name)
         self.nets = {}
         for name in ('geo_mlp', 'app_mlp'):
-            net = getattr(nerf, name)
-            w16 = net.working_copy()
-            n_net = net.mlp.n_params
+            if hasattr(nerf, 'nets'):              # fields.InferenceNeRF: 16-bit tables only, either table layout
+                mlp, w16 = nerf.nets[name]
+                grid = nerf.grid
+            else:
+                net = getattr(nerf, name)
+                mlp, w16, grid = net.mlp, net.working_copy(), net.grid
+            n_net = mlp.n_params
             dist, rank, world = _group()
-            levels = assign_levels(net.grid, world)[rank]
-            local = GridSlice(net.grid, levels)
-            mine = torch.cat([w16[n_net + 2 * int(net.grid.offset[l]): n_net + 2 * int(net.grid.offset[l] + net.grid.size[l])] for l in levels]) \
+            levels = assign_levels(grid, world)[rank]
+            local = GridSlice(grid, levels)
+            mine = torch.cat([w16[n_net + 2 * int(grid.offset[l]): n_net + 2 * int(grid.offset[l] + grid.size[l])] for l in levels]) \
                 if levels else torch.zeros(0, dtype=w16.dtype, device=w16.device)
-            enc = LevelShardedEncoder(net.grid, dtype=self.dtype_name, table16=mine.clone())
+            enc = LevelShardedEncoder(grid, dtype=self.dtype_name, table16=mine.clone())
             assert enc.local.levels == local.levels
-            self.nets[name] = (enc, net.mlp, w16[:n_net].clone())
+            self.nets[name] = (enc, mlp, w16[:n_net].clone())
 
     def eval(self):
         self.training = False

@@ -3,7 +3,7 @@
 L = 20 hash grids -- rendered by every rank through the LEVEL-SHARDED fields (tables cut by level over the ranks, positions
 all-gathered, one all-to-all of features per field) and, for comparison, through the unsharded fields on the same rays.
 
-    python -m torch.distributed.run --nproc-per-node 2 ... tests/config5_worker.py <out.pt> <rows_per_rank> <log2_T>"""
+    python -m torch.distributed.run --nproc-per-node 2 ... tests/config5_worker.py <out.pt> <rows_per_rank> <log2_T> [tcnn|line_local]"""
 import os
 import sys
 
@@ -15,6 +15,7 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     out_path, rows, log2_t = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    layout = sys.argv[4] if len(sys.argv) > 4 else 'tcnn'
     world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0'))
     torch.cuda.set_device(0)
     dist.init_process_group('gloo')
@@ -30,6 +31,12 @@ def main():
         for net in (nerf.geo_mlp, nerf.app_mlp):
             net.params[net.mlp.n_params:] *= 1e4
     nerf.eval()
+    if layout != 'tcnn':
+        # the opt-in line-local table layout exists for the 16-bit-only inference fields (same seed on every rank: same tables)
+        from perf_amd.fields import InferenceNeRF
+        from perf_amd.panorama import per_level_scale
+        nerf = InferenceNeRF(AABB, n_levels=20, log2_hashmap_size=log2_t, per_level_scale=per_level_scale(20), dtype='fp16', table_scale=1.0,
+                             density_bias=2.0, layout=layout)
     sharded = LevelShardedNeRF(nerf).eval()
     est = OccGridEstimator(AABB, resolution=256).cuda(); est.eval()
     est.set_binaries(torch.ones(256 ** 3, dtype=torch.uint8, device='cuda'))

@@ -22,7 +22,7 @@ MARKS = (150, 300)
 
 
 def spread_main():
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(int(os.environ.get('PERF_ORACLE_THREADS', min(os.cpu_count() or 1, 32))))
     scene_name = sys.argv[3] if len(sys.argv) > 3 else 'room'
     default = 'psnr_curve.json' if scene_name == 'room' else f'psnr_curve_{scene_name}.json'
     out_path = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != '-' else os.path.join(ROOT, 'tests', 'golden', default)
@@ -56,7 +56,7 @@ def quant_main():
     quant=...), and per mark the largest |16-bit-emulated - fp32| over the seeds: what rounding parameters and features to the
     storage type ALONE does to PSNR@iter -- the reference's own tcnn path stores fp16.  tests/test_gpu_psnr.py bounds single seeds
     of (HIP - fp32 oracle) by max(0.1 dB, that figure)."""
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(int(os.environ.get('PERF_ORACLE_THREADS', min(os.cpu_count() or 1, 32))))
     scene_name = sys.argv[3] if len(sys.argv) > 3 else 'room'
     dtype = sys.argv[4] if len(sys.argv) > 4 else 'bf16'
     default = 'psnr_curve.json' if scene_name == 'room' else f'psnr_curve_{scene_name}.json'
@@ -94,7 +94,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'quant16':
         return quant_main()
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(int(os.environ.get('PERF_ORACLE_THREADS', min(os.cpu_count() or 1, 32))))
     scene_name = sys.argv[3] if len(sys.argv) > 3 else 'room'
     scene = P.make_scene(H, W, scene_name)
     default = 'psnr_curve.json' if scene_name == 'room' else f'psnr_curve_{scene_name}.json'

@@ -254,8 +254,8 @@ def test_level_sharded_encode_matches_the_unsharded_kernel(tmp_path, n_levels, l
     assert sorted(a[0] + a[1]) == list(range(n_levels)) and abs(len(a[0]) - len(a[1])) <= 1
 
 
-@pytest.mark.parametrize('world,log2_t,rows', [(2, 20, 2), (4, 22, 1)])
-def test_config5_row_shard_through_the_level_sharded_path(tmp_path, world, log2_t, rows):
+@pytest.mark.parametrize('world,log2_t,rows,layout', [(2, 20, 2, 'tcnn'), (4, 22, 1, 'tcnn'), (2, 21, 2, 'line_local')])
+def test_config5_row_shard_through_the_level_sharded_path(tmp_path, world, log2_t, rows, layout):
     """BASELINE config 5's inference batch at its stated shape -- rows of a 4096x2048 panorama, 256 samples per ray, L = 20
     hash grids (T = 2^20 / 2^22 here: the box is shared by all ranks AND the unsharded comparison copies) -- rendered by two
     and by FOUR ranks through the level-sharded fields (perf_amd/sharded.py:LevelShardedNeRF: greedy level split of a
@@ -264,7 +264,7 @@ def test_config5_row_shard_through_the_level_sharded_path(tmp_path, world, log2_
     out = str(tmp_path / 'c5.pt')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'config5_worker.py'), out, str(rows), str(log2_t)]
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'config5_worker.py'), out, str(rows), str(log2_t), layout]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = torch.load(out)

@@ -1,8 +1,16 @@
 """PSNR@iter parity (north_star: "PSNR within 0.1 dB of reference after equal iterations"): the HIP path replays the
 schedule of tests/golden/psnr_curve.json -- the fp32 CPU oracle's curve, generated in the build container by
 tests/golden/make_psnr_curve.py (256x512 panorama, 1024-ray batches, 300 geometry + 300 colour iterations, identical
-batches and random draws) -- and the MEAN over the seeds of (HIP - oracle) must be within 0.1 dB for the DEFAULT dtype
-at every mark.  A single run of this chaotic optimisation scatters by ~0.1 dB, so individual seeds get 0.35 dB."""
+batches and random draws) -- and the MEAN over the seeds of (HIP - oracle) must be within 0.1 dB at every mark, for the default
+dtype (bf16: BASELINE config 2) and for fp16 (tcnn's own storage type).  SINGLE seeds are held to max(0.1 dB, what the oracle itself
+moves by under perturbations no implementation can avoid) -- both measured on the oracle and committed with its curves
+(tests/golden/make_psnr_curve.py):
+  * `oracle_spread`: the fp32 CPU curve again from an initialisation moved by ONE ULP (two runs per family): 0.006 dB on the room,
+    0.14 dB on the doorway -- whether this optimisation amplifies rounding noise depends on the scene (depth discontinuities);
+  * `oracle_16bit`: the oracle with parameters and features rounded to the 16-bit storage type in its forward passes (its quant
+    emulation), everything else fp32, per seed: what the STORAGE TYPE ALONE does -- the reference's own tcnn path stores fp16.
+profiles/r06_psnr_split.json has the HIP deviations split over {bf16, fp16} x {fixed-point, fp32 accumulation}: no combination is
+systematically off, none is the cause of a single seed's deviation."""
 import json
 import os
 
@@ -50,16 +58,26 @@ def test_psnr_at_iter_matches_the_oracle_curve(scene_name):
                 opacity.append(got['geo_end_opacity'] - row['oracle']['geo_end_opacity'])
     finally:
         tcnn.GRID_GRAD_ACCUM = mode0
-    other = 'fp16' if tcnn.DEFAULT_DTYPE == 'bf16' else 'bf16'          # informational: the other 16-bit type, first seed only
-    row = golden['seeds'][0]
-    geo0, app0 = P.init_params(row['seed'])
-    draws = P.make_draws(scene[0].shape[0], cfg['batch'], cfg['geo_iters'] + cfg['app_iters'], row['seed'])
-    got = P.run_hip(scene, geo0, app0, draws, cfg['geo_iters'], cfg['app_iters'], tuple(cfg['marks']), other, mode0)
-    print(f'({other}, seed {row["seed"]}: HIP - oracle', {k: round(got[k] - row['oracle'][k], 3) for k in deltas}, ')')
-    print('HIP - oracle PSNR [dB]:', {k: [round(v, 3) for v in vs] for k, vs in deltas.items()}, 'depth-error ratio:', [round(v, 3) for v in depth])
-    for k, vs in deltas.items():
-        assert abs(float(np.mean(vs))) <= 0.1, (k, vs)
-        assert max(abs(v) for v in vs) <= 0.35, (k, vs)
+    # the other 16-bit type (fp16 = tcnn's own storage type when the default is bf16): every seed, same bounds
+    other = 'fp16' if tcnn.DEFAULT_DTYPE == 'bf16' else 'bf16'
+    deltas_other = {k: [] for k in deltas}
+    try:
+        for row in golden['seeds']:
+            geo0, app0 = P.init_params(row['seed'])
+            draws = P.make_draws(scene[0].shape[0], cfg['batch'], cfg['geo_iters'] + cfg['app_iters'], row['seed'])
+            got = P.run_hip(scene, geo0, app0, draws, cfg['geo_iters'], cfg['app_iters'], tuple(cfg['marks']), other, mode0)
+            for k in deltas_other:
+                deltas_other[k].append(got[k] - row['oracle'][k])
+    finally:
+        tcnn.GRID_GRAD_ACCUM = mode0
+    tol = _seed_tolerance(golden)
+    print('single-seed tolerance [dB]:', {k: (round(v[0], 3), v[1]) for k, v in tol.items()})
+    for name, dd in ((tcnn.DEFAULT_DTYPE, deltas), (other, deltas_other)):
+        print(f'{name}: HIP - oracle PSNR [dB]:', {k: [round(v, 3) for v in vs] for k, vs in dd.items()})
+        for k, vs in dd.items():
+            assert abs(float(np.mean(vs))) <= 0.1, (name, k, vs)
+            assert max(abs(v) for v in vs) <= tol[k][0], (name, k, vs, tol[k])
+    print('depth-error ratio:', [round(v, 3) for v in depth])
     assert 0.85 <= float(np.mean(depth)) <= 1.15, depth
     # the geometry phase's LEARNING curve (the eval depth error above is fixed by the occupancy shell from the first
     # iteration and carries no information about learning): mean training depth loss of iterations k-10..k-1 -- 0.41 at
@@ -70,12 +88,28 @@ def test_psnr_at_iter_matches_the_oracle_curve(scene_name):
     assert all(abs(v) < 5e-3 for v in opacity), opacity
 
 
+def _seed_tolerance(golden):
+    """Per mark: (max(0.1 dB, the oracle's own one-ulp spread, the oracle's 16-bit-storage deviation), which of them set it)."""
+    out = {}
+    for m in golden['config']['marks']:
+        k = f'psnr@app{m}'
+        cands = [(0.1, 'north_star 0.1 dB')]
+        sp = (golden.get('oracle_spread') or {}).get('max_abs_delta_db')
+        if sp:
+            cands.append((float(sp[k]), 'oracle_spread (fp32 oracle, initialisation moved by one ulp)'))
+        for dt, blk in (golden.get('oracle_16bit') or {}).items():
+            if blk.get('max_abs_delta_db'):
+                cands.append((float(blk['max_abs_delta_db'][k]), f'oracle_16bit[{dt}] (fp32 oracle with {dt} storage emulated)'))
+        out[k] = max(cands)
+    return out
+
+
 def test_data_parallel_psnr_at_iter_matches_the_oracle_curve(tmp_path):
     """`north_star` asks for scaling AND "PSNR within 0.1 dB after equal iterations".  The data-parallel DEFAULT (sharded
     exchange with lagged fixed-point units, perf_amd/dp.py) is not bit-identical to the single process, so it replays the
     oracle's schedule itself: two ranks on this box's one GPU (gloo), each taking its half of every golden batch and of the
     batch's random draws -- three seeds of tests/golden/psnr_curve.json (a step costs ~50 ms through gloo's host copies): the
-    mean of (data-parallel HIP - fp32 oracle) within 0.1 dB at both marks, single seeds within 0.35 dB, the geometry phase's
+    mean of (data-parallel HIP - fp32 oracle) within 0.1 dB at both marks, single seeds within the single-process bound (_seed_tolerance), the geometry phase's
     learning curve on the oracle's, no step skipped by the job-wide gate."""
     import subprocess
     import sys
@@ -96,9 +130,10 @@ def test_data_parallel_psnr_at_iter_matches_the_oracle_curve(tmp_path):
     rows = {str(row['seed']): row['oracle'] for row in golden['seeds']}
     deltas = {f'psnr@app{m}': [res['curves'][str(s)][f'psnr@app{m}'] - rows[str(s)][f'psnr@app{m}'] for s in seeds] for m in cfg['marks']}
     print('data-parallel (2 ranks, lagged units) HIP - oracle PSNR [dB]:', {k: [round(v, 3) for v in vs] for k, vs in deltas.items()})
+    tol = _seed_tolerance(golden)
     for k, vs in deltas.items():
         assert abs(float(np.mean(vs))) <= 0.1, (k, vs)
-        assert max(abs(v) for v in vs) <= 0.35, (k, vs)
+        assert max(abs(v) for v in vs) <= tol[k][0], (k, vs, tol[k])
     for k in cfg.get('geo_marks', []):
         ratio = [res['curves'][str(s)][f'geo_depth_loss@{k}'] / rows[str(s)][f'geo_depth_loss@{k}'] for s in seeds]
         assert 0.93 <= float(np.mean(ratio)) <= 1.07 and all(0.85 <= v <= 1.15 for v in ratio), (k, ratio)
