@@ -35,18 +35,44 @@ def make_renderer(spp=SPP5):
 
 @torch.no_grad()
 def render_rows(nerf, est, rend, row0, nrows, rows_per_batch=4, spp=SPP5, height=H5, width=W5, outs=None, counters=None,
-                keep=('rgb', 'distance', 'opacities'), bookkeeping=None):
+                keep=('rgb', 'distance', 'opacities'), bookkeeping=None, tile=None, max_batches=None):
     """Rows [row0, row0 + nrows) of the height x width panorama through NeRFOCCRenderer.render (marching, no-grad density pass,
     visibility compaction, colour field, compositing), `rows_per_batch` rows (x width rays x spp samples) per batch, rays
     generated in-kernel, device-side counts.  outs: {key: [nrows * width, C]} preallocated (or None: allocated);
-    counters: int64 [8] device block accumulating {marched, kept} (perf_step_bookkeeping).  bookkeeping(st) is called per batch
-    with the renderer's result dict (tests)."""
+    counters: int64 [8] device block accumulating {marched, kept} (perf_step_bookkeeping).  bookkeeping(res, lo, R) is called per
+    batch with the renderer's result dict (tests; lo = batch number x R).
+    tile = (rows, columns): the batches are 2-D TILES of pixels instead of full-width strips (same pixels, same values: rays are
+    independent; what changes is which rays share a launch -- the neighbours of a ray in BOTH image directions, whose samples
+    meet in the same table lines).  max_batches: stop after that many batches (timing passes)."""
     from perf_amd import ops
     pose = torch.eye(4, device='cpu')
     n = nrows * width
     if outs is None:
         cw = {'rgb': 3, 'distance': 1, 'opacities': 1}
         outs = {k: torch.empty(n, cw[k], dtype=torch.float32, device='cuda') for k in keep}
+    if tile is not None:
+        th, tw = tile
+        b = 0
+        for r in range(row0, row0 + nrows, th):
+            nr = min(th, row0 + nrows - r)
+            o_band, d_band = ops.pano_raygen(pose, height, width, row0=r, nrows=nr)              # [nr, width, 3]
+            for c in range(0, width, tw):
+                nc = min(tw, width - c)
+                o = o_band[:, c:c + nc].reshape(-1, 3).contiguous(); d = d_band[:, c:c + nc].reshape(-1, 3).contiguous()
+                R = o.shape[0]
+                rend.sample_capacity = R * spp
+                near = torch.zeros(R, 1, device='cuda'); far = torch.ones(R, 1, device='cuda')
+                res = rend.render(nerf, est, o, d, near, far)
+                for k in outs:
+                    outs[k].view(nrows, width, -1)[r - row0:r - row0 + nr, c:c + nc].copy_(res[k].view(nr, nc, -1))
+                if counters is not None:
+                    ops.step_bookkeeping(None, None, counters, res['n_marched_dev'], res['n_samples_dev'])
+                if bookkeeping is not None:
+                    bookkeeping(res, b * R, R)
+                b += 1
+                if max_batches is not None and b >= max_batches:
+                    return outs
+        return outs
     for r in range(row0, row0 + nrows, rows_per_batch):
         nr = min(rows_per_batch, row0 + nrows - r)
         o, d = ops.pano_raygen(pose, height, width, row0=r, nrows=nr)
@@ -66,7 +92,7 @@ def render_rows(nerf, est, rend, row0, nrows, rows_per_batch=4, spp=SPP5, height
 
 
 def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W5, levels=LEVELS5, dtype='fp16', timing_batches=8,
-                          pmc=None, layout='tcnn', **layout_kw):
+                          pmc=None, layout='tcnn', tile=(128, 128), **layout_kw):
     """BASELINE config 5 on ONE GPU, whole panorama: height x width rays x spp samples through both L-level fields (16-bit tables
     of 2^log2_t entries per hashed level, inference only: perf_amd.fields.InferenceNeRF) + compositing.  -> dict for bench.py's
     `config5` block: ray-samples/s, the encode kernel's algorithmic fraction of the HBM peak, and -- from the committed PMC pass
@@ -79,10 +105,12 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
     est, rend = make_renderer(spp)
     torch.cuda.synchronize(); t_build = time.perf_counter() - t0
     counters = ops.step_counters('cuda')
+    if tile is not None and tile[0] * tile[1] != rows_per_batch * width:
+        raise ValueError('render_panorama_block: a tile holds as many rays as a strip batch (the launches are compared at equal size)')
     outs = render_rows(nerf, est, rend, height // 2, rows_per_batch, rows_per_batch, spp, height, width)          # warm-up: one batch
     outs = {k: torch.empty(height * width, v.shape[1], dtype=torch.float32, device='cuda') for k, v in outs.items()}
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    render_rows(nerf, est, rend, 0, height, rows_per_batch, spp, height, width, outs=outs, counters=counters)
+    render_rows(nerf, est, rend, 0, height, rows_per_batch, spp, height, width, outs=outs, counters=counters, tile=tile)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     c = counters.tolist()
     marched, kept = int(c[0]), int(c[1])
@@ -91,7 +119,12 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
     step_rows = max(height // timing_batches, rows_per_batch)
     nb = 0
     for r in range(step_rows // 2, height - rows_per_batch + 1, step_rows):
-        render_rows(nerf, est, rend, r, rows_per_batch, rows_per_batch, spp, height, width); nb += 1
+        if tile is None:
+            render_rows(nerf, est, rend, r, rows_per_batch, rows_per_batch, spp, height, width); nb += 1
+        else:       # one tile of the band at that latitude (a fresh one: another column range each time)
+            r0 = min(r, height - tile[0])
+            keep1 = render_rows(nerf, est, rend, r0, tile[0], rows_per_batch, spp, height, width, tile=tile, max_batches=2); nb += 2
+            del keep1
     kern = ops.stop_kernel_timing()
     enc_n, enc_ms = kern['perf_hashgrid_fwd']
     per_launch = rows_per_batch * width * spp                    # nothing is pruned at a fresh initialisation: kept = marched
@@ -99,8 +132,9 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
     enc_gbs = algo * per_launch / (enc_ms * 1e-3) / 1e9
     blk = {'what': f'BASELINE config 5 on one GPU: {width}x{height} panorama x {spp} samples/ray, L = {levels} hash grids up to resolution '
                    f'{int(FINEST5)}, T = 2^{log2_t} ({dtype} tables only: inference), both fields + compositing through NeRFOCCRenderer.render, '
-                   f'{height // rows_per_batch} batches of {rows_per_batch * width} rays, fresh initialisation (nothing pruned), device-side counts',
-           'log2_hashmap_size': log2_t, 'table_layout': layout, 'table_GiB_per_encoder': round(nerf.table_bytes() / 2 ** 30, 2),
+                   f'{height // rows_per_batch} batches of {rows_per_batch * width} rays ' + ('(full-width strips of %d rows)' % rows_per_batch if tile is None else
+                                                                                            '(%d x %d-pixel tiles)' % tile) + ', fresh initialisation (nothing pruned), device-side counts',
+           'log2_hashmap_size': log2_t, 'table_layout': layout, 'batch_shape': 'strip' if tile is None else list(tile), 'table_GiB_per_encoder': round(nerf.table_bytes() / 2 ** 30, 2),
            'table_entries': int(nerf.grid.total), 'offsets_exceed_32_bit': bool(nerf.grid.n_params >= 2 ** 32),
            'build_seconds': round(t_build, 3), 'seconds_per_panorama': round(el, 4), 'rays_per_s': height * width / el,
            'ray_samples_per_s': kept / el, 'marched_samples': marched, 'kept_samples': kept,

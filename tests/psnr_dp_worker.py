@@ -119,6 +119,13 @@ def main():
         draws = P.make_draws(scene_data[0].shape[0], cfg['batch'], cfg['geo_iters'] + cfg['app_iters'], sd)
         assert P.draws_digest(draws) == row['draws_digest']
         res[str(sd)] = run_dp(scene_data, geo0, app0, draws, cfg['geo_iters'], cfg['app_iters'], tuple(cfg['marks']), tcnn.DEFAULT_DTYPE, rank, world)
+        # the same seed from the initialisation moved by one fp32 ulp up / down (tests/test_gpu_psnr.py: a seed's statistic is the mean
+        # of the three members)
+        res[str(sd)]['one_ulp_members'] = []
+        for towards in (float('inf'), -float('inf')):
+            g = torch.nextafter(geo0, torch.full_like(geo0, towards)); a = torch.nextafter(app0, torch.full_like(app0, towards))
+            c = run_dp(scene_data, g, a, draws, cfg['geo_iters'], cfg['app_iters'], tuple(cfg['marks']), tcnn.DEFAULT_DTYPE, rank, world)
+            res[str(sd)]['one_ulp_members'].append({k: c[k] for k in c if k.startswith('psnr') or k.startswith('skipped')})
     if rank == 0:
         json.dump({'world': world, 'curves': res}, open(out_path, 'w'))
     dist.barrier(); dist.destroy_process_group()

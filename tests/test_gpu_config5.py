@@ -72,6 +72,11 @@ def test_config5_full_panorama_properties(layout):
     shard = C.render_rows(nerf, est, rend, r0, nr, 2, SPP, H, W)
     for k in outs:
         assert torch.equal(shard[k], outs[k][r0 * W:(r0 + nr) * W]), k
+    # batches as 2-D tiles of pixels (what bench.py's config5 block renders: neighbouring rays in both image directions share a
+    # launch) give the same pixels
+    tiled = C.render_rows(nerf, est, rend, r0, 128, 4, SPP, H, W, tile=(128, 128))
+    for k in outs:
+        assert torch.equal(tiled[k], outs[k][r0 * W:(r0 + 128) * W]), k
     # determinism: the same rows again, bit for bit
     again = C.render_rows(nerf, est, rend, r0, 16, 4, SPP, H, W)
     for k in outs:

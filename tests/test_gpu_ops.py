@@ -738,8 +738,14 @@ def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift, min_res):
         assert ((got - ref).abs() <= ulp * ref.abs() * 1.01 + 1e-6).all(), (layout, dt, float((got - ref).abs().max()))
         # capacity-sized launch with a device-side live count: the live rows are the same bits
         live = 1777
-        part = ops.hashgrid_fwd(cfg, xd, table.to(tdt).reshape(-1).cuda(), n_dev=torch.tensor([live], dtype=torch.int64, device='cuda'))
+        t16 = table.to(tdt).reshape(-1).cuda()
+        part = ops.hashgrid_fwd(cfg, xd, t16, n_dev=torch.tensor([live], dtype=torch.int64, device='cuda'))
         assert torch.equal(part[:, :live], feat[:, :live])
+        # tiny and ragged launches (one sample; less than a 16-sample group; one group short of a wave), an empty live count
+        for m in (1, 15, 70):
+            assert torch.equal(ops.hashgrid_fwd(cfg, xd[:m].contiguous(), t16), feat[:, :m]), (layout, dt, m)
+        canary = ops.hashgrid_fwd(cfg, xd[:300].contiguous(), t16, n_dev=torch.tensor([0], dtype=torch.int64, device='cuda'))
+        assert canary.shape == (L, 300, 2)
     if layout == 'line_local':
         # inference only: the gradient entry points refuse the layout instead of scattering into the wrong entries
         from perf_amd._lib import PerfError

@@ -33,6 +33,8 @@ def main():
     ap.add_argument('--layout', default='tcnn', choices=['tcnn', 'line_local'], help='table layout of the --pano-log2 fields (perf_amd.grid.GridConfig)')
     ap.add_argument('--sb-shift', type=int, nargs=3, default=None, help='line_local: log2 vertices of a super-block along x, y, z')
     ap.add_argument('--local-min-res', type=int, default=None, help='line_local: levels of at least this resolution are stored line-local')
+    ap.add_argument('--strips', action='store_true', help='--pano-log2: 4-row strips instead of the default 128 x 128-pixel tiles')
+    ap.add_argument('--tile', type=int, nargs=2, default=None, help='batches are tiles of ROWS x COLUMNS pixels instead of 4-row strips')
     ap.add_argument('--pano-batches', type=int, default=0,
                     help='with --pano-log2: only this many 4-row batches spread from pole to pole instead of the whole panorama (what the rocprofv3 '
                          '--pmc passes of profiles/r05_config5_pmc.json run)')
@@ -54,13 +56,16 @@ def main():
                 step_rows = H5 // args.pano_batches
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for r in range(step_rows // 2, H5 - 3, step_rows):
-                    render_rows(nerf, est, rend, r, 4, 4)
+                    if args.tile:
+                        render_rows(nerf, est, rend, min(r, H5 - args.tile[0]), args.tile[0], 4, tile=tuple(args.tile), max_batches=1)
+                    else:
+                        render_rows(nerf, est, rend, r, 4, 4)
                 torch.cuda.synchronize()
                 res[f'T{T}'] = {'batches': args.pano_batches, 'seconds': time.perf_counter() - t0, 'samples_per_launch': 4 * W5 * SPP5}
                 del nerf
                 torch.cuda.empty_cache()
             else:
-                res[f'T{T}'] = render_panorama_block(T, layout=args.layout, **lkw)
+                res[f'T{T}'] = render_panorama_block(T, layout=args.layout, tile=tuple(args.tile) if args.tile else (None if args.strips else (128, 128)), **lkw)
             print(json.dumps({f'T{T}': res[f'T{T}']}, indent=1), flush=True)
         os.makedirs('gpurun_out', exist_ok=True)
         json.dump(res, open('gpurun_out/config5_pano.json', 'w'), indent=1)

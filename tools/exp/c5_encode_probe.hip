@@ -246,27 +246,33 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void enc_stable_rows(GP gp, const float* __restrict__ x01, const uint32_t* __restrict__ table, uint32_t* __restrict__ feat, int64_t n) {
+template <int G>
+__global__ __launch_bounds__(256) void enc_stable_rows_t(GP gp, const float* __restrict__ x01, const uint32_t* __restrict__ table, uint32_t* __restrict__ feat, int64_t n) {
     int l; int64_t chunk;
-    if (!stable_item(blockIdx.x, (n + 255) >> 8, &l, &chunk)) return;
+    constexpr int CH = 64 * G;          // samples per workgroup (4 waves x 16 G)
+    if (!stable_item(blockIdx.x, (n + CH - 1) / CH, &l, &chunk)) return;
     const uint32_t* t = table + gp.offset[l];
     if (!gp.local[l]) {
-        const int64_t i = chunk * 256 + threadIdx.x;
-        if (i >= n) return;
-        const Cor c = corners(gp, l, x01[3 * i], x01[3 * i + 1], x01[3 * i + 2]);
-        uint32_t v[8];
+        for (int rep = 0; rep < CH / 256; ++rep) {
+            const int64_t i = chunk * CH + rep * 256 + threadIdx.x;
+            if (i >= n) return;
+            const Cor c = corners(gp, l, x01[3 * i], x01[3 * i + 1], x01[3 * i + 2]);
+            uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = t[c.idx[k]];
-        feat[(int64_t)l * n + i] = interp(c, v);
+            for (int k = 0; k < 8; ++k) v[k] = t[c.idx[k]];
+            feat[(int64_t)l * n + i] = interp(c, v);
+        }
         return;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t s = lane >> 2, r = lane & 3u;
-    const int64_t base = chunk * 256 + wave * 64;
+    const int64_t base = chunk * CH + wave * (16 * G);
     const float sc = gp.scale[l];
-    uint4 q[4]; uint32_t e[4] = {0u, 0u, 0u, 0u}; float fxs[4], wrow[4]; uint32_t lxs[4];
+    uint4 q[G]; uint32_t e[G]; float fxs[G], wrow[G]; uint32_t lxs[G];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < G; ++it) e[it] = 0u;
+#pragma unroll
+    for (int it = 0; it < G; ++it) {
         int64_t i = base + 16 * it + s;
         if (i >= n) i = n - 1;
         const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
@@ -282,9 +288,11 @@ __global__ __launch_bounds__(256) void enc_stable_rows(GP gp, const float* __res
         if (lxs[it] == 3u) e[it] = t[vertex_index(gp, l, gx + 1u, vy, vz)];
         (void)wz;                                                   // (recomputed below from the position: cheaper than holding it)
     }
-    uint32_t mine = 0u;
+    uint32_t mine[G / 4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int k = 0; k < G / 4; ++k) mine[k] = 0u;
+#pragma unroll
+    for (int it = 0; it < G; ++it) {
         int64_t i = base + 16 * it + s;
         if (i >= n) i = n - 1;
         const float z = x01[3 * i + 2];
@@ -297,11 +305,15 @@ __global__ __launch_bounds__(256) void enc_stable_rows(GP gp, const float* __res
         const float w0 = ((1.f - fxs[it]) * wrow[it]) * wz, w1 = (fxs[it] * wrow[it]) * wz;
         float p0 = fmaf(w1, lo16(a1), w0 * lo16(a0)), p1 = fmaf(w1, hi16(a1), w0 * hi16(a0));
         p0 = quad_sum(p0); p1 = quad_sum(p1);
-        if ((int)r == it) mine = pack_half2(p0, p1);
+        if ((int)r == (it & 3)) mine[it >> 2] = pack_half2(p0, p1);
     }
-    const int64_t io = base + 16 * r + s;
-    if (io < n) feat[(int64_t)l * n + io] = mine;
+#pragma unroll
+    for (int k = 0; k < G / 4; ++k) {
+        const int64_t io = base + 64 * k + 16 * r + s;
+        if (io < n) feat[(int64_t)l * n + io] = mine[k];
+    }
 }
+
 
 // panorama sample positions: rows [row0, row0 + nrows) of a 2048 x 4096 panorama, 256 lattice midpoints of 0.99 / 256 per ray
 __global__ void positions(float* __restrict__ x01, int row0, int tile) {
@@ -363,14 +375,14 @@ int main(int argc, char** argv) {
     float* x01; uint32_t* feat;
     CHECK(hipMalloc(&x01, n * 12)); CHECK(hipMalloc(&feat, n * 4 * L));
     const int rows[] = {1022, 512, 0};
-    const char* mnames[] = {"groups (shipped)", "one level per workgroup", "groups, 24 gathers in flight", "XCD-stable balanced", "XCD-stable balanced, 16-byte x-runs", "XCD-stable balanced, 16-byte x-runs, nontemporal", "XCD-stable balanced, four lanes per sample"};
-    kern_t kerns[] = {enc_groups, enc_levels, enc_groups_deep, enc_stable, enc_stable_quad_t<0>, enc_stable_quad_t<1>, enc_stable_rows};
+    const char* mnames[] = {"groups (shipped)", "one level per workgroup", "groups, 24 gathers in flight", "XCD-stable balanced", "XCD-stable balanced, 16-byte x-runs", "XCD-stable balanced, 16-byte x-runs, nontemporal", "XCD-stable balanced, four lanes per sample", "XCD-stable balanced, four lanes per sample, 8 groups in flight"};
+    kern_t kerns[] = {enc_groups, enc_levels, enc_groups_deep, enc_stable, enc_stable_quad_t<0>, enc_stable_quad_t<1>, enc_stable_rows_t<4>, enc_stable_rows_t<8>};
     const int nchunks = (int)(n >> 8);
-    const unsigned grids[] = {4096u * 8, 4096u * L, 4096u * 8, (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64)};
+    const unsigned grids[] = {4096u * 8, 4096u * L, 4096u * 8, (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks + 63) / 64 * L * 64), (unsigned)((nchunks / 2 + 63) / 64 * L * 64)};
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     // (layout, mapping, tile) triples of this run
     // (layout, mapping, tile, local_min_res)
-    const int variants[][4] = {{9, 4, 0, 16}, {9, 6, 0, 16}, {4, 4, 0, 64}, {4, 6, 0, 64}};
+    const int variants[][4] = {{9, 6, 0, 64}, {9, 7, 0, 64}, {9, 6, 1, 64}, {9, 7, 1, 64}};
     for (int a = 1; a < argc; ++a) {
         const int log2_t = atoi(argv[a]);
         uint64_t maxtot = 0;
@@ -385,7 +397,7 @@ int main(int argc, char** argv) {
             uint64_t tot; const GP gp = make_grid(log2_t, 9, &tot);
             positions<<<(unsigned)((n + 255) / 256), 256>>>(x01, 1022, 0);
             enc_stable_quad_t<0><<<grids[4], 256>>>(gp, x01, table, feat, n);
-            enc_stable_rows<<<grids[6], 256>>>(gp, x01, table, feat2, n);
+            enc_stable_rows_t<8><<<grids[7], 256>>>(gp, x01, table, feat2, n);
             CHECK(hipDeviceSynchronize());
             std::vector<uint32_t> ha((size_t)n * L), hb((size_t)n * L);
             CHECK(hipMemcpy(ha.data(), feat, n * 4 * L, hipMemcpyDeviceToHost));
