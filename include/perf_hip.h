@@ -420,7 +420,8 @@ int perf_occ_build_coarse(const uint32_t* occ_bits, int32_t res, uint32_t* coars
 
 /* Exclusive prefix sum of int32 (counts -> offsets); total [1] (int64, device) receives the sum; total_biased (device
  * int64, may be NULL) receives sum + total_bias (the two-phase sampler's evaluated-sample count = head rows + tail samples,
- * without a separate add).  workspace >= perf_scan_workspace_bytes(n). */
+ * without a separate add).  workspace >= perf_scan_workspace_bytes(n).  The offsets are int32 (nerfacc's packed_info contract):
+ * the caller keeps the sum below 2^31 (sample capacities are); `total` itself is exact in int64. */
 int64_t perf_scan_workspace_bytes(int64_t n);
 int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t* total, int64_t n, int64_t total_bias,
                             int64_t* total_biased, void* workspace, int64_t workspace_bytes, void* stream);

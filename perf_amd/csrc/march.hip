@@ -765,13 +765,40 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t* __r
 // Second (and last) launch of the large scan: block b adds up the sums of the blocks before it itself (at most a few thousand
 // 8-byte values from L2 -- a third launch that scans them cost 7.4 us, twice per 512x1024 frame), then scans its own 1024
 // elements; the last block leaves the total.
+// (Beyond kScanApplyMaxBlocks blocks -- more than 2 M elements -- the re-summing would grow quadratically: 8 M elements = 8,192 blocks =
+//  33 M loads.  A middle launch then turns the block sums into exclusive prefixes once (scan_sums_kernel) and every block reads its own.)
+constexpr int64_t kScanApplyMaxBlocks = 2048;
+__global__ __launch_bounds__(1024) void scan_sums_kernel(int64_t* __restrict__ sums, int64_t nb) {
+    __shared__ long long wave_tot[16];
+    __shared__ long long carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
+        const int64_t j = b0 + threadIdx.x;
+        const long long v = j < nb ? sums[j] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const long long t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        long long before = carry_s;
+        for (int w2 = 0; w2 < wave; ++w2) before += wave_tot[w2];
+        if (j < nb) sums[j] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
                                                          const int64_t* __restrict__ sums, int64_t* __restrict__ total_out,
-                                                         int64_t bias, int64_t* __restrict__ total_biased) {
+                                                         int64_t bias, int64_t* __restrict__ total_biased, int sums_are_prefixes) {
     __shared__ int lds4[4];
     __shared__ long long pre4[4];
     long long before = 0;
-    for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += 256) before += sums[j];
+    if (sums_are_prefixes) { if (threadIdx.x == 0) before = sums[blockIdx.x]; }
+    else for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += 256) before += sums[j];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off);
     if ((threadIdx.x & 63) == 0) pre4[threadIdx.x >> 6] = before;
@@ -965,8 +992,10 @@ extern "C" int perf_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t*
     const int64_t nb = div_up(n, kScanBlock);
     int64_t* sums = (int64_t*)workspace;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), in, n, sums);
+    const int prefixes = nb > kScanApplyMaxBlocks ? 1 : 0;
+    if (prefixes) hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, as_stream(stream), sums, nb);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), in, out, n, sums, total, total_bias,
-                       total_biased);
+                       total_biased, prefixes);
     PERF_LAUNCH_CHECK("perf_exclusive_scan_i32");
     return PERF_OK;
 }

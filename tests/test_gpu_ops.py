@@ -388,8 +388,9 @@ def test_occ_march_count_head_equals_the_three_pass_head(ops, K):
 
 def test_scan_and_empty(ops):
     g = torch.Generator().manual_seed(6)
-    for n in (1, 5, 1024, 1025, 8192, 65536, 65537, 100000):
-        c = torch.randint(0, 300, (n,), generator=g, dtype=torch.int32)
+    # (beyond 2,097,152 elements the block sums get a scan launch of their own: the last two sizes)
+    for n in (1, 5, 1024, 1025, 8192, 65536, 65537, 100000, 2097152, 2097153 + 1024 * 1500 + 7, 8388608):
+        c = torch.randint(0, 100 if n > 2 ** 20 else 300, (n,), generator=g, dtype=torch.int32)
         out, total = ops.exclusive_scan_i32(c.cuda())
         ref = torch.cumsum(c.long(), 0) - c.long()
         assert torch.equal(out.cpu().long(), ref) and int(total.item()) == int(c.sum())

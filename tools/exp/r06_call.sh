@@ -1,18 +1,13 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06v
+O=$R/gpurun_out/r06w
 rm -rf $O; mkdir -p $O
 cd $R
-( time timeout 1200 python -m pytest tests/test_gpu_config5.py -m gpu -x -q ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-cd /tmp && export TMPDIR=/tmp
-for LAY in tcnn line_local; do
-  for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --pmc $C --output-format csv -d $O/c5_${LAY}_$C -o c -- python $R/tools/config5.py --pano-log2 28 30 --pano-batches 8 --layout $LAY --tile 128 128 > $O/c5_${LAY}_$C.log 2>&1
-  done
+for SC in room doorway pillars; do
+  timeout 900 python tools/soak_episodes.py --episodes 25 --scene $SC > $O/soak_$SC.log 2>&1
+  tail -1 $O/soak_$SC.log > $O/soak_$SC.json
 done
-for SET in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum"; do
-  N=$(echo $SET | cut -d' ' -f1)
-  timeout 600 rocprofv3 --pmc $SET --output-format csv -d $O/pmc_$N -o c -- python $R/tools/config5.py --pano-log2 28 --pano-batches 8 --layout line_local --tile 128 128 > $O/pmc_$N.log 2>&1
-done
-cd $R
-find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete
-du -sh $O
+timeout 900 python tools/shim_level_episode.py > $O/shim_level.log 2>&1
+cp gpurun_out/shim_level_episode.json $O/ 2>/dev/null
+python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29711 tools/soak_episodes.py --one-device --episodes 5 --scene doorway --geo 300 --app 300 --height 256 --width 512 --batch 1024 --out $O/dp_soak.json > $O/dp_soak.log 2>&1
+du -sh $O; for SC in room doorway pillars; do python -c "
+import json; d=json.load(open('$O/soak_$SC.json')); print('$SC', d['psnr_min_max'], d['seconds_min_max'], d['skipped_for_overflow_total'], d['skipped_for_truncation_total'], [e['fp32_repairs_app_net'] for e in d['episodes']][-1])"; done; tail -3 $O/shim_level.log | cut -c1-300
