@@ -860,6 +860,36 @@ def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other
     for k, v in (blocks or {}).items():
         if v is not None:
             line[k] = v
+    # the scalars a reader of a TRUNCATED line needs, flat and early (the blocks they come from follow in full)
+    summ = {}
+    try:
+        if psnr_block:
+            summ['episode_train_seconds'] = psnr_block.get('train_seconds')
+            last = sorted(psnr_block.get('curve', {}).items(), key=lambda kv: int(kv[0].rsplit('_', 1)[1]))
+            if last:
+                summ['episode_psnr_db'] = last[-1][1].get('psnr_db')
+        fb = (blocks or {}).get('faithful')
+        if fb:
+            summ.update(faithful_geo_ms=fb.get('geo_ms_per_step'), faithful_app_ms=fb.get('app_ms_per_step'), faithful_geo_graph_nodes=fb.get('geo_launches_per_step'))
+        c4 = (blocks or {}).get('config4')
+        if c4 and c4.get('frame_as_one_batch'):
+            summ['config4_frames_per_s'] = round(c4['frame_as_one_batch']['frames_per_s'], 1)
+        rb = (blocks or {}).get('render')
+        if rb and rb.get('ray_samples_per_s'):
+            summ['render_ray_samples_per_s'] = rb['ray_samples_per_s']
+        ta = (blocks or {}).get('train_app')
+        if ta and ta.get('ms_per_step'):
+            summ['train_app_ms_per_step'] = ta['ms_per_step']
+        for key, blk in ((blocks or {}).get('config5') or {}).items():
+            if isinstance(blk, dict) and 'roofline' in blk:
+                summ[f'config5_{key}'] = {'seconds_per_panorama': blk['seconds_per_panorama'], 'ray_samples_per_s': round(blk['ray_samples_per_s']),
+                                          'encode_ms': blk['roofline']['ms_per_launch'], 'encode_algorithmic_frac': blk['roofline']['frac'],
+                                          'encode_moved_frac': blk['roofline'].get('moved_frac')}
+    except Exception:       # noqa: BLE001 -- a convenience copy, never a failure
+        pass
+    if summ:
+        line = {**{k: line[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step')}, 'summary': summ,
+                **{k: v for k, v in line.items() if k not in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step')}}
     if 'eager' in head:
         line['config']['eager_launch'] = head['eager']
     if world > 1:
