@@ -12,6 +12,7 @@
 // This unit: the forward encode (perf_hashgrid_fwd / _fwd2 / _corners / _fwd_f32).  The parameter gradient is hashgrid_bwd.hip;
 // input gradient, second order and the data-parallel unit / slot kernels are hashgrid_aux.hip.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 #include "grid_device.hpp"
 
@@ -181,18 +182,23 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, con
 // The tables of such a grid exceed every cache, so there is nothing to pin: what the level-group kernel above pins to an XCD --
 // levels {g, 15-g, 16+g} one after the other -- leaves XCDs 0-3 with two HBM-bound levels each and XCDs 4-7 with none (measured,
 // tools/exp/c5_encode_probe.hip, 4.2 M panorama samples: 2.36 ms at T = 2^28, 5.29 ms at 2^30).  Here a workgroup is ONE level of
-// one 256-sample chunk, and the work items are dealt so that
-//   * XCD x = b % 8 serves level l for EIGHT CONSECUTIVE chunks (= neighbouring rays of a panorama batch) back to back: their
-//     gathers meet in one L2 (a level's consecutive rays share cells at the coarse levels and 128-byte lines at the fine ones);
-//   * which eighth of a 64-chunk stripe an XCD serves rotates with the level ((x - l) & 7): every XCD serves every level for an
-//     eighth of the samples -- balance whatever a level costs.                                      1.66 / 2.44 ms, tcnn layout
+// 256 x STEPS consecutive samples, and the work items are dealt so that
+//   * XCD x = b % 8 serves level l for a TURN of consecutive samples (4,096: the neighbouring rays of a panorama batch) back to
+//     back: their gathers meet in one L2 (a level's consecutive rays share cells at the coarse levels and 128-byte lines at the fine ones);
+//   * which eighth of a stripe of eight turns an XCD serves rotates with the level ((x - l) & 7): every XCD serves every level for an
+//     eighth of the samples -- balance whatever a level costs.                                      1.50 / 2.37 ms, tcnn layout
 // Line-local levels (PERF_LAYOUT_LINE_LOCAL) give every sample FOUR LANES, one per (y, z) corner pair; a lane fetches the ALIGNED
 // 16-byte x-run that holds its pair's first vertex -- both x corners unless the cell starts at a block's last vertex (a quarter of
 // the samples: a 4-byte gather for those).  The four runs of a sample -- 2.3 lines on average -- are thus requested by ONE
 // instruction (the texture addresser merges lanes that name the same line) instead of by four consecutive ones that find the line
 // pending; a wave serves 16 samples per instruction and keeps four such groups in flight; the four partial sums of a sample meet
 // through two DPP quad permutes.  Counters of the one-lane-per-sample form (profiles/r06_config5_counters.json): 53 % of the wave
-// cycles waiting to ISSUE a memory instruction, the L1 stalled on pending lines 80 % of the time.    0.78 / 0.90 ms (probe)
+// cycles waiting to ISSUE a memory instruction, the L1 stalled on pending lines 80 % of the time.
+// Waves are LONG-LIVED: a wave serves 64 x STEPS samples in STEPS steps and requests the coordinates of the next step while the table
+// lines of this one are in flight (a wave that serves 64 samples and retires spends a third of its life on start-up + the coordinate
+// fetch with no table line requested: 0.89 ms per 4.2 M samples at T = 2^28 line-local; four steps: 0.74 ms).  Measured and not kept
+// (profiles/r06_config5_long_waves.json): a ring of request slots refilled group by group (3-4 groups in flight at all times, but 95
+// registers = 5 waves per SIMD: 0.90 ms; two slots at 7 waves: 0.80), eight waves forced with 5 spilled registers (0.79).
 // Placement is a speed assumption only; results do not depend on it.
 constexpr int64_t kBigMaxStripes = 1 << 16;
 
@@ -202,89 +208,184 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
-template <typename T16>
-__global__ __launch_bounds__(256) void hashgrid_fwd_big_kernel(GridParams gp, GridLocal gl, const float* __restrict__ x01,
-                                                               const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
-                                                               int64_t n, const int64_t* __restrict__ n_dev, int64_t grid_stripes) {
-    const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
-    const int64_t nchunks = (n_live + 255) >> 8;
-    const int L = gp.n_levels;
-    const int xcd = (int)(blockIdx.x & 7u);
+// The two kinds of level are two kernels (each keeps its own register budget: 7-8 waves per SIMD), launched one after the other
+// over their own lists of levels.
+struct BigLevels { int32_t count; int32_t level[PERF_MAX_LEVELS]; };
+
+// work item of workgroup b: XCD x = b % 8, its turn's sub-group, the level and the first stripe
+struct BigItem { int xcd, sub, l; int64_t q0; };
+__device__ __forceinline__ BigItem big_item(const BigLevels& lv, int bpt) {
+    BigItem it;
+    it.xcd = (int)(blockIdx.x & 7u);
     const int64_t j = (int64_t)(blockIdx.x >> 3);
-    const int cr = (int)(j & 7);
-    const int64_t t = j >> 3;
-    const int l = (int)(t % L);
+    it.sub = (int)(j % bpt);                                     // a turn of an XCD = bpt workgroups = bpt x 256 x STEPS consecutive samples
+    const int64_t t = j / bpt;
+    it.l = lv.level[(int)(t % lv.count)];
+    it.q0 = t / lv.count;
+    return it;
+}
+
+template <typename T16, int STEPS>
+__global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams gp, BigLevels lv, const float* __restrict__ x01,
+                                                                      const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
+                                                                      int64_t n, const int64_t* __restrict__ n_dev, int64_t grid_stripes, int bpt) {
+    const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
+    const BigItem w = big_item(lv, bpt);
+    const int l = w.l;
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     const uint32_t* tl = table + gp.offset[l];
-    if (!gl.local[l]) {
-        for (int64_t Q = t / L; (Q << 6) < nchunks; Q += grid_stripes) {
-            const int64_t chunk = (((Q << 3) + ((xcd - l) & 7)) << 3) + cr;
-            const int64_t i = chunk * 256 + threadIdx.x;
-            if (i >= n_live) continue;
-            const Corners c = corners_of(x01[3 * i], x01[3 * i + 1], x01[3 * i + 2], gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
+    constexpr int64_t kGroup = 256 * STEPS;
+    const int64_t stripe = 8 * (int64_t)bpt * kGroup;            // samples of one turn of all eight XCDs
+    for (int64_t Q = w.q0; Q * stripe < n_live; Q += grid_stripes) {
+        const int64_t base = (((Q << 3) + ((w.xcd - l) & 7)) * bpt + w.sub) * kGroup + threadIdx.x;
+        if (base - threadIdx.x >= n_live) continue;
+        int64_t i0 = base < n_live ? base : n_live - 1;
+        float x = x01[3 * i0], y = x01[3 * i0 + 1], z = x01[3 * i0 + 2];
+#pragma unroll
+        for (int it = 0; it < STEPS; ++it) {
+            const int64_t i = base + 256 * it;
+            if (i - threadIdx.x >= n_live) break;                // (workgroup-uniform)
+            const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
             uint32_t v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = tl[c.idx[k]];
-            float w[8];
-            corner_weights(c.f, smooth, w);
+            if (it + 1 < STEPS) {                                // the next step's coordinates, behind this step's gathers
+                int64_t i1 = i + 256;
+                if (i1 >= n_live) i1 = n_live - 1;
+                x = x01[3 * i1]; y = x01[3 * i1 + 1]; z = x01[3 * i1 + 2];
+            }
+            float wt[8];
+            corner_weights(c.f, smooth, wt);
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                a0 = fmaf(w[k], T16::lo(v[k]), a0);
-                a1 = fmaf(w[k], T16::hi(v[k]), a1);
+                a0 = fmaf(wt[k], T16::lo(v[k]), a0);
+                a1 = fmaf(wt[k], T16::hi(v[k]), a1);
             }
-            __builtin_nontemporal_store(T16::pack(a0, a1), &feat[(int64_t)l * n + i]);      // (streamed: read next by the MLP kernel, not here)
+            if (i < n_live) __builtin_nontemporal_store(T16::pack(a0, a1), &feat[(int64_t)l * n + i]);      // (streamed: read next by the MLP kernel, not here)
         }
-        return;
     }
-    // ---- line-local level: lane = (sample s of a group of 16, corner pair r = ky + 2 kz); four groups of a wave in flight
+}
+
+// line-local levels: lane = (sample s of a group of 16, corner pair r = ky + 2 kz); four groups of a wave in flight.  The four lanes
+// of a quad fetch the coordinates of ONE sample each (group r's) one step ahead and hand them round by quad broadcasts: three
+// registers per lane instead of twelve keep the kernel at eight waves per SIMD.
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));   // quad_perm [K,K,K,K]
+}
+template <int K> struct QuadStep {
+    template <typename F> static __device__ __forceinline__ void run(F&& f) { QuadStep<K - 1>::run(f); f(std::integral_constant<int, K - 1>{}); }
+};
+template <> struct QuadStep<0> { template <typename F> static __device__ __forceinline__ void run(F&&) {} };
+
+template <typename T16, int STEPS>
+__global__ __launch_bounds__(256) void hashgrid_fwd_big_local_kernel(GridParams gp, GridLocal gl, BigLevels lv, const float* __restrict__ x01,
+                                                                     const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
+                                                                     int64_t n, const int64_t* __restrict__ n_dev, int64_t grid_stripes, int bpt) {
+    const int64_t n_live = live_count(n, n_dev);
+    const BigItem w = big_item(lv, bpt);
+    const int l = w.l;
+    const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
+    const uint32_t* tl = table + gp.offset[l];
+    constexpr int64_t kGroup = 256 * STEPS;
+    const int64_t stripe = 8 * (int64_t)bpt * kGroup;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t s = lane >> 2, r = lane & 3u;
     const float sc = gp.scale[l];
     const uint32_t size = gp.size[l];
     const bool hashed = gp.hashed[l] != 0;
-    for (int64_t Q = t / L; (Q << 6) < nchunks; Q += grid_stripes) {
-        const int64_t chunk = (((Q << 3) + ((xcd - l) & 7)) << 3) + cr;
-        const int64_t base = chunk * 256 + wave * 64;
+    for (int64_t Q = w.q0; Q * stripe < n_live; Q += grid_stripes) {
+        const int64_t base = (((Q << 3) + ((w.xcd - l) & 7)) * bpt + w.sub) * kGroup + (int64_t)wave * (64 * STEPS);
         if (base >= n_live) continue;                                // (wave-uniform)
-        uint4 q[4];
-        uint32_t e[4] = {0u, 0u, 0u, 0u}, lxs[4];
-        float wxs[4], wys[4], wzs[4];
+        // (wave-uniform bases + 32-bit lane offsets: addresses cost one register, not two)
+        const float* __restrict__ xb = x01 + 3 * base;
+        uint32_t* __restrict__ fb = feat + (int64_t)l * n + base;
+        const int64_t left64 = n_live - base;
+        const uint32_t left = left64 < 64 * STEPS ? (uint32_t)left64 : 64u * STEPS;      // live samples of this wave's share
+        const uint32_t mo = 16u * r + s;                             // this lane's sample of a step: coordinates fetched, feature stored
+        float nx, ny, nz;                                            // this lane's share of the next step's coordinates
+        {
+            const uint32_t o = 3u * (mo < left ? mo : left - 1u);    // (idle lanes of the last step repeat the last sample)
+            nx = xb[o]; ny = xb[o + 1u]; nz = xb[o + 2u];
+        }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            int64_t i = base + 16 * it + s;
-            if (i >= n_live) i = n_live - 1;                         // (idle lanes of the last chunk repeat its last sample)
-            const float x = x01[3 * i], y = x01[3 * i + 1], z = x01[3 * i + 2];
-            const float px = grid_pos(x, sc), py = grid_pos(y, sc), pz = grid_pos(z, sc);
-            const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-            float fx = px - flx, fy = py - fly, fz = pz - flz;
-            const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
-            const uint32_t vy = gy + (r & 1u), vz = gz + (r >> 1);
-            lxs[it] = gx & 3u;
-            q[it] = *reinterpret_cast<const uint4*>(tl + local_vertex_index(gl, l, size, hashed, gx & ~3u, vy, vz));   // (16-byte aligned by construction)
-            if (lxs[it] == 3u) e[it] = tl[local_vertex_index(gl, l, size, hashed, gx + 1u, vy, vz)];
-            if (smooth) {
-                fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz);
+        for (int step = 0; step < STEPS; ++step) {
+            if (64u * step >= left) break;                            // (wave-uniform)
+            uint4 q[4];
+            uint32_t e[4] = {0u, 0u, 0u, 0u}, lxp = 0u;               // (lxp: the four groups' x positions inside their runs, two bits each)
+            float w0s[4], w1s[4];
+            QuadStep<4>::run([&](auto itc) {
+                constexpr int it = decltype(itc)::value;
+                const float x = quad_bcast<it>(nx), y = quad_bcast<it>(ny), z = quad_bcast<it>(nz);
+                const float px = grid_pos(x, sc), py = grid_pos(y, sc), pz = grid_pos(z, sc);
+                const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+                float fx = px - flx, fy = py - fly, fz = pz - flz;
+                const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+                const uint32_t vy = gy + (r & 1u), vz = gz + (r >> 1);
+                lxp |= (gx & 3u) << (2 * it);
+                // (a level holds at most 2^30 entries: 32-bit BYTE offsets from the wave-uniform level base, one address register per request)
+                const char* tb = reinterpret_cast<const char*>(tl);
+                q[it] = *reinterpret_cast<const uint4*>(tb + (local_vertex_index(gl, l, size, hashed, gx & ~3u, vy, vz) << 2));   // (16-byte aligned by construction)
+                if ((gx & 3u) == 3u) e[it] = *reinterpret_cast<const uint32_t*>(tb + (local_vertex_index(gl, l, size, hashed, gx + 1u, vy, vz) << 2));
+                if (smooth) {
+                    fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz);
+                }
+                const float wy = (r & 1u) ? fy : 1.0f - fy, wz = (r >> 1) ? fz : 1.0f - fz;
+                w0s[it] = ((1.0f - fx) * wy) * wz; w1s[it] = (fx * wy) * wz;      // this lane's two corners with corner_weights' products ((wx * wy) * wz)
+            });
+            if (step + 1 < STEPS) {                                  // the next step's coordinates, behind this step's table lines
+                const uint32_t i = 64u * (step + 1) + mo;
+                const uint32_t o = 3u * (i < left ? i : left - 1u);
+                nx = xb[o]; ny = xb[o + 1u]; nz = xb[o + 2u];
             }
-            wxs[it] = fx;
-            wys[it] = (r & 1u) ? fy : 1.0f - fy;
-            wzs[it] = (r >> 1) ? fz : 1.0f - fz;
-        }
-        uint32_t mine = 0u;
+            uint32_t mine = 0u;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const uint32_t lx = lxs[it];
-            const uint32_t a0 = lx == 0u ? q[it].x : (lx == 1u ? q[it].y : (lx == 2u ? q[it].z : q[it].w));
-            const uint32_t a1 = lx == 0u ? q[it].y : (lx == 1u ? q[it].z : (lx == 2u ? q[it].w : e[it]));
-            // this lane's two corners with corner_weights' products ((wx * wy) * wz), then the sample's four lanes
-            const float w0 = ((1.0f - wxs[it]) * wys[it]) * wzs[it], w1 = (wxs[it] * wys[it]) * wzs[it];
-            const float p0 = quad_sum(fmaf(w1, T16::lo(a1), w0 * T16::lo(a0)));
-            const float p1 = quad_sum(fmaf(w1, T16::hi(a1), w0 * T16::hi(a0)));
-            if ((int)r == it) mine = T16::pack(p0, p1);              // (all four lanes hold the same sums: lane r keeps group r's)
+            for (int it = 0; it < 4; ++it) {
+                const uint32_t lx = (lxp >> (2 * it)) & 3u;
+                const uint32_t a0 = lx == 0u ? q[it].x : (lx == 1u ? q[it].y : (lx == 2u ? q[it].z : q[it].w));
+                const uint32_t a1 = lx == 0u ? q[it].y : (lx == 1u ? q[it].z : (lx == 2u ? q[it].w : e[it]));
+                const float p0 = quad_sum(fmaf(w1s[it], T16::lo(a1), w0s[it] * T16::lo(a0)));     // ... then the sample's four lanes
+                const float p1 = quad_sum(fmaf(w1s[it], T16::hi(a1), w0s[it] * T16::hi(a0)));
+                if ((int)r == it) mine = T16::pack(p0, p1);          // (all four lanes hold the same sums: lane r keeps group r's)
+            }
+            const uint32_t io = 64u * step + mo;
+            if (io < left) __builtin_nontemporal_store(mine, &fb[io]);
         }
-        const int64_t io = base + 16 * (int64_t)r + s;
-        if (io < n_live) __builtin_nontemporal_store(mine, &feat[(int64_t)l * n + io]);
     }
+}
+
+// turns of kBigTurn consecutive samples: 4 steps x 256 samples x 4 workgroups (measured at T = 2^28, line-local: 1 / 2 / 4 / 8
+// workgroups per turn 0.760 / 0.750 / 0.738 / 0.742 ms; 1 / 2 / 4 / 8 steps per wave 0.838 / 0.767 / 0.734 / 0.783 ms)
+constexpr int kBigSteps = 4;
+constexpr int kBigTurnGroups = 4;
+
+template <typename T16>
+static void launch_big(const GridParams& gp, const GridLocal& gl, const float* x01, const void* table16, void* feat16, int64_t n,
+                       const int64_t* n_dev, void* stream) {
+    const int64_t stripe = 8 * (int64_t)kBigTurnGroups * 256 * kBigSteps;
+    int64_t stripes = div_up(n, stripe);
+    if (stripes > kBigMaxStripes) stripes = kBigMaxStripes;
+    BigLevels gather, local;
+    gather.count = local.count = 0;
+    for (int l = 0; l < PERF_MAX_LEVELS; ++l) gather.level[l] = local.level[l] = 0;
+    for (int l = 0; l < gp.n_levels; ++l) {
+        if (gl.local[l]) local.level[local.count++] = l; else gather.level[gather.count++] = l;
+    }
+    // (line-local levels first: the long launch; the few coarse levels' gathers find the coordinates in the caches)
+    if (local.count)
+        hipLaunchKernelGGL((hashgrid_fwd_big_local_kernel<T16, kBigSteps>), dim3((unsigned)(stripes * local.count * 8 * kBigTurnGroups)), dim3(256), 0, as_stream(stream),
+                           gp, gl, local, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes, kBigTurnGroups);
+    if (!gather.count) return;
+    // tables beyond the caches in tcnn's layout (no line-local level) are served best by waves of ONE step -- measured at T = 2^28 with
+    // every level in tcnn's layout: 1.50 ms at one step, 1.58 at four, 1.87 at eight -- over the same turns; the coarse, cache-resident
+    // levels beside line-local ones take the four steps
+    if (local.count)
+        hipLaunchKernelGGL((hashgrid_fwd_big_gather_kernel<T16, kBigSteps>), dim3((unsigned)(stripes * gather.count * 8 * kBigTurnGroups)), dim3(256), 0, as_stream(stream),
+                           gp, gather, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes, kBigTurnGroups);
+    else
+        hipLaunchKernelGGL((hashgrid_fwd_big_gather_kernel<T16, 1>), dim3((unsigned)(stripes * gather.count * 8 * kBigTurnGroups * kBigSteps)), dim3(256), 0, as_stream(stream),
+                           gp, gather, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes, kBigTurnGroups * kBigSteps);
 }
 
 // Two tables with the SAME grid geometry (PeRF's density and colour fields, ngp_nerf.py:96-134) evaluated at the
@@ -381,14 +482,9 @@ extern "C" int perf_hashgrid_fwd(const perf_grid_desc* grid, const float* x01, c
     if (gl.any || gp.n_levels > 16) {
         // deep grids and line-local tables: one level per workgroup, XCD-stable balanced (hashgrid_fwd_big_kernel)
         PERF_REQUIRE(!gl.any || ((uintptr_t)table16 & 15u) == 0, "perf_hashgrid_fwd: a line-local table must be 16-byte aligned");
-        int64_t stripes = div_up(div_up(n, 256), 64);
-        if (stripes > kBigMaxStripes) stripes = kBigMaxStripes;
-        dim3 g((unsigned)(stripes * gp.n_levels * 64)), b(256);
-        if (dtype == PERF_DTYPE_BF16)
-            hipLaunchKernelGGL(hashgrid_fwd_big_kernel<BF16>, g, b, 0, as_stream(stream), gp, gl, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes);
-        else if (dtype == PERF_DTYPE_FP16)
-            hipLaunchKernelGGL(hashgrid_fwd_big_kernel<FP16>, g, b, 0, as_stream(stream), gp, gl, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes);
-        else { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
+        if (dtype != PERF_DTYPE_BF16 && dtype != PERF_DTYPE_FP16) { set_error("perf_hashgrid_fwd: bad dtype %d", dtype); return PERF_E_INVALID; }
+        if (dtype == PERF_DTYPE_BF16) launch_big<BF16>(gp, gl, x01, table16, feat16, n, n_dev, stream);
+        else launch_big<FP16>(gp, gl, x01, table16, feat16, n, n_dev, stream);
         PERF_LAUNCH_CHECK("perf_hashgrid_fwd");
         return PERF_OK;
     }

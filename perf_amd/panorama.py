@@ -35,7 +35,7 @@ def make_renderer(spp=SPP5):
 
 @torch.no_grad()
 def render_rows(nerf, est, rend, row0, nrows, rows_per_batch=4, spp=SPP5, height=H5, width=W5, outs=None, counters=None,
-                keep=('rgb', 'distance', 'opacities'), bookkeeping=None, tile=None, max_batches=None):
+                keep=('rgb', 'distance', 'opacities'), bookkeeping=None, tile=None, max_batches=None, ray_order='row'):
     """Rows [row0, row0 + nrows) of the height x width panorama through NeRFOCCRenderer.render (marching, no-grad density pass,
     visibility compaction, colour field, compositing), `rows_per_batch` rows (x width rays x spp samples) per batch, rays
     generated in-kernel, device-side counts.  outs: {key: [nrows * width, C]} preallocated (or None: allocated);
@@ -43,7 +43,9 @@ def render_rows(nerf, est, rend, row0, nrows, rows_per_batch=4, spp=SPP5, height
     batch with the renderer's result dict (tests; lo = batch number x R).
     tile = (rows, columns): the batches are 2-D TILES of pixels instead of full-width strips (same pixels, same values: rays are
     independent; what changes is which rays share a launch -- the neighbours of a ray in BOTH image directions, whose samples
-    meet in the same table lines).  max_batches: stop after that many batches (timing passes)."""
+    meet in the same table lines).  ray_order ('row' | 'morton', tiles only): the order of a tile's rays inside its batch -- row by row,
+    or along the Z-order curve (consecutive rays = a compact 2-D patch of pixels: the 2 x 2 rays of a workgroup and the 2 x 4 of an
+    XCD's turn in the deep-grid encode kernel are neighbours in both directions).  max_batches: stop after that many batches (timing passes)."""
     from perf_amd import ops
     pose = torch.eye(4, device='cpu')
     n = nrows * width
@@ -60,11 +62,15 @@ def render_rows(nerf, est, rend, row0, nrows, rows_per_batch=4, spp=SPP5, height
                 nc = min(tw, width - c)
                 o = o_band[:, c:c + nc].reshape(-1, 3).contiguous(); d = d_band[:, c:c + nc].reshape(-1, 3).contiguous()
                 R = o.shape[0]
+                inv = None
+                if ray_order == 'morton':
+                    perm, inv = _morton_order(nr, nc)
+                    o = o[perm]; d = d[perm]
                 rend.sample_capacity = R * spp
                 near = torch.zeros(R, 1, device='cuda'); far = torch.ones(R, 1, device='cuda')
                 res = rend.render(nerf, est, o, d, near, far)
                 for k in outs:
-                    outs[k].view(nrows, width, -1)[r - row0:r - row0 + nr, c:c + nc].copy_(res[k].view(nr, nc, -1))
+                    outs[k].view(nrows, width, -1)[r - row0:r - row0 + nr, c:c + nc].copy_((res[k] if inv is None else res[k][inv]).view(nr, nc, -1))
                 if counters is not None:
                     ops.step_bookkeeping(None, None, counters, res['n_marched_dev'], res['n_samples_dev'])
                 if bookkeeping is not None:
@@ -91,8 +97,27 @@ def render_rows(nerf, est, rend, row0, nrows, rows_per_batch=4, spp=SPP5, height
     return outs
 
 
+_MORTON = {}
+
+
+def _morton_order(nr, nc):
+    """(perm, inv) int64 device tensors: perm[m] = row-major index of the m-th pixel of an nr x nc tile along the Z-order curve
+    (bits of row and column interleaved; any shape: pixels sorted by their Z-order key), inv its inverse."""
+    key = (nr, nc)
+    if key not in _MORTON:
+        rr, cc = torch.meshgrid(torch.arange(nr), torch.arange(nc), indexing='ij')
+        z = torch.zeros(nr, nc, dtype=torch.int64)
+        for b in range(16):
+            z |= ((cc >> b) & 1) << (2 * b)
+            z |= ((rr >> b) & 1) << (2 * b + 1)
+        perm = torch.argsort(z.reshape(-1), stable=True)
+        inv = torch.empty_like(perm); inv[perm] = torch.arange(perm.numel())
+        _MORTON[key] = (perm.cuda(), inv.cuda())
+    return _MORTON[key]
+
+
 def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W5, levels=LEVELS5, dtype='fp16', timing_batches=8,
-                          pmc=None, layout='tcnn', tile=(128, 128), **layout_kw):
+                          pmc=None, layout='tcnn', tile=(128, 128), ray_order='row', **layout_kw):
     """BASELINE config 5 on ONE GPU, whole panorama: height x width rays x spp samples through both L-level fields (16-bit tables
     of 2^log2_t entries per hashed level, inference only: perf_amd.fields.InferenceNeRF) + compositing.  -> dict for bench.py's
     `config5` block: ray-samples/s, the encode kernel's algorithmic fraction of the HBM peak, and -- from the committed PMC pass
@@ -110,7 +135,7 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
     outs = render_rows(nerf, est, rend, height // 2, rows_per_batch, rows_per_batch, spp, height, width)          # warm-up: one batch
     outs = {k: torch.empty(height * width, v.shape[1], dtype=torch.float32, device='cuda') for k, v in outs.items()}
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    render_rows(nerf, est, rend, 0, height, rows_per_batch, spp, height, width, outs=outs, counters=counters, tile=tile)
+    render_rows(nerf, est, rend, 0, height, rows_per_batch, spp, height, width, outs=outs, counters=counters, tile=tile, ray_order=ray_order)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     c = counters.tolist()
     marched, kept = int(c[0]), int(c[1])
@@ -123,7 +148,7 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
             render_rows(nerf, est, rend, r, rows_per_batch, rows_per_batch, spp, height, width); nb += 1
         else:       # one tile of the band at that latitude (a fresh one: another column range each time)
             r0 = min(r, height - tile[0])
-            keep1 = render_rows(nerf, est, rend, r0, tile[0], rows_per_batch, spp, height, width, tile=tile, max_batches=2); nb += 2
+            keep1 = render_rows(nerf, est, rend, r0, tile[0], rows_per_batch, spp, height, width, tile=tile, max_batches=2, ray_order=ray_order); nb += 2
             del keep1
     kern = ops.stop_kernel_timing()
     enc_n, enc_ms = kern['perf_hashgrid_fwd']
@@ -134,7 +159,7 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
                    f'{int(FINEST5)}, T = 2^{log2_t} ({dtype} tables only: inference), both fields + compositing through NeRFOCCRenderer.render, '
                    f'{height // rows_per_batch} batches of {rows_per_batch * width} rays ' + ('(full-width strips of %d rows)' % rows_per_batch if tile is None else
                                                                                             '(%d x %d-pixel tiles)' % tile) + ', fresh initialisation (nothing pruned), device-side counts',
-           'log2_hashmap_size': log2_t, 'table_layout': layout, 'batch_shape': 'strip' if tile is None else list(tile), 'table_GiB_per_encoder': round(nerf.table_bytes() / 2 ** 30, 2),
+           'log2_hashmap_size': log2_t, 'table_layout': layout, 'batch_shape': 'strip' if tile is None else list(tile), 'ray_order': ray_order if tile is not None else 'row', 'table_GiB_per_encoder': round(nerf.table_bytes() / 2 ** 30, 2),
            'table_entries': int(nerf.grid.total), 'offsets_exceed_32_bit': bool(nerf.grid.n_params >= 2 ** 32),
            'build_seconds': round(t_build, 3), 'seconds_per_panorama': round(el, 4), 'rays_per_s': height * width / el,
            'ray_samples_per_s': kept / el, 'marched_samples': marched, 'kept_samples': kept,

@@ -755,11 +755,13 @@ def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift, min_res):
 
 
 @pytest.mark.parametrize('layout', ['tcnn', 'line_local'])
-def test_table_beyond_32_bit_offsets(ops, layout):
-    """5.6e9 entries (21 GiB of 2x16-bit features): level offsets exceed 2^32.  The table is filled on the device with a
-    function of the global entry index; the expected features of a few points are evaluated on the host from the oracle's
-    corner indices and weights through the same function, so no host copy of the table is needed.  Both table layouts."""
-    L, T, b = 20, 29, 1.5
+@pytest.mark.parametrize('T', [29, 30])
+def test_table_beyond_32_bit_offsets(ops, layout, T):
+    """5.6e9 entries (21 GiB of 2x16-bit features; T = 30: 1.1e10 entries, 41 GiB -- beyond BASELINE config 5's 31 GiB per encoder):
+    level offsets exceed 2^32.  The table is filled on the device with a function of the global entry index; the expected
+    features of 640 points are evaluated on the host from the oracle's corner indices and weights through the same function, so
+    no host copy of the table is needed.  Both table layouts."""
+    L, b = 20, 1.5
     cfg = _grid_cfg(n_levels=L, log2_hashmap_size=T, base_resolution=16, per_level_scale=b, layout=layout)
     lv = _lv_of(cfg)
     assert cfg.total > 2 ** 32 and np.array_equal(cfg.offset.astype(np.uint64), lv.offset.astype(np.uint64))

@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--sb-shift', type=int, nargs=3, default=None, help='line_local: log2 vertices of a super-block along x, y, z')
     ap.add_argument('--local-min-res', type=int, default=None, help='line_local: levels of at least this resolution are stored line-local')
     ap.add_argument('--strips', action='store_true', help='--pano-log2: 4-row strips instead of the default 128 x 128-pixel tiles')
+    ap.add_argument('--ray-order', default='row', choices=['row', 'morton'], help='order of a tile\'s rays inside its batch (perf_amd.panorama.render_rows)')
     ap.add_argument('--tile', type=int, nargs=2, default=None, help='batches are tiles of ROWS x COLUMNS pixels instead of 4-row strips')
     ap.add_argument('--pano-batches', type=int, default=0,
                     help='with --pano-log2: only this many 4-row batches spread from pole to pole instead of the whole panorama (what the rocprofv3 '
@@ -57,7 +58,7 @@ def main():
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for r in range(step_rows // 2, H5 - 3, step_rows):
                     if args.tile:
-                        render_rows(nerf, est, rend, min(r, H5 - args.tile[0]), args.tile[0], 4, tile=tuple(args.tile), max_batches=1)
+                        render_rows(nerf, est, rend, min(r, H5 - args.tile[0]), args.tile[0], 4, tile=tuple(args.tile), max_batches=1, ray_order=args.ray_order)
                     else:
                         render_rows(nerf, est, rend, r, 4, 4)
                 torch.cuda.synchronize()
@@ -65,7 +66,7 @@ def main():
                 del nerf
                 torch.cuda.empty_cache()
             else:
-                res[f'T{T}'] = render_panorama_block(T, layout=args.layout, tile=tuple(args.tile) if args.tile else (None if args.strips else (128, 128)), **lkw)
+                res[f'T{T}'] = render_panorama_block(T, layout=args.layout, tile=tuple(args.tile) if args.tile else (None if args.strips else (128, 128)), ray_order=args.ray_order, **lkw)
             print(json.dumps({f'T{T}': res[f'T{T}']}, indent=1), flush=True)
         os.makedirs('gpurun_out', exist_ok=True)
         json.dump(res, open('gpurun_out/config5_pano.json', 'w'), indent=1)

@@ -6,7 +6,7 @@
                                    for both table layouts: HBM bytes per launch of hashgrid_fwd_big_kernel (bench.py's config5 block reads it)
   r06_config5_counters.json        SQ / TA / TCP / TCC counters of the line-local encode at T = 2^28, one lane per sample (r06f) and four lanes per
                                    sample (r06j)
-  python tools/exp/r06_fold_config5.py      (reads gpurun_out/r06a, r06f, r06j, r06v; copies the raw CSVs to profiles/r06_raw/)"""
+  python tools/exp/r06_fold_config5.py      (reads gpurun_out/r06a, r06f, r06j, r06v, r06ad; copies the raw CSVs to profiles/r06_raw/)"""
 import collections, csv, glob, json, os, shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -56,16 +56,34 @@ json.dump(cal, open(os.path.join(DST, 'r06_fetch_size_calibration.json'), 'w'), 
 
 
 # ---- FETCH / WRITE of the encode, both layouts -----------------------------------------------------------------------------------
-def rows(path, counter):
-    out = []
+def encodes(path, counters):
+    """Per ENCODE (one perf_hashgrid_fwd call = the line-local launch + the gather launch of the other levels, or the gather launch alone
+    with tcnn's layout): {counter: value summed over its launches, 'ns': summed duration}, in dispatch order."""
+    per = collections.defaultdict(dict)
     for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] == counter and 'hashgrid_fwd_big' in r['Kernel_Name']:
-            out.append((int(r['Dispatch_Id']), float(r['Counter_Value']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
-    return [(v, ns) for _, v, ns in sorted(out)]
+        if r['Counter_Name'] in counters and 'hashgrid_fwd_big' in r['Kernel_Name']:
+            d = per[int(r['Dispatch_Id'])]
+            d['name'] = r['Kernel_Name']; d[r['Counter_Name']] = float(r['Counter_Value']); d['ns'] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    out = []
+    for _, d in sorted(per.items()):
+        follows_local = bool(out) and out[-1]['_open'] and 'big_gather' in d['name']
+        if follows_local:
+            g = out[-1]; g['_open'] = False
+        else:
+            g = {'ns': 0, '_open': 'big_local' in d['name']}
+            out.append(g)
+        g['ns'] += d['ns']
+        for c in counters:
+            g[c] = g.get(c, 0.0) + d.get(c, 0.0)
+    return out
+
+
+def rows(path, counter):
+    return [(g[counter], g['ns']) for g in encodes(path, [counter])]
 
 
 tables = {}
-for layout, call in (('tcnn', 'r06v'), ('line_local', 'r06v')):
+for layout, call in (('tcnn', 'r06ad'), ('line_local', 'r06ad')):
     f = rows(os.path.join(G, call, f'c5_{layout}_FETCH_SIZE', 'c_counter_collection.csv'), 'FETCH_SIZE')
     w = rows(os.path.join(G, call, f'c5_{layout}_WRITE_SIZE', 'c_counter_collection.csv'), 'WRITE_SIZE')
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -84,7 +102,9 @@ for layout, call in (('tcnn', 'r06v'), ('line_local', 'r06v')):
 json.dump({'source': 'profiles/r06_config5_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python tools/config5.py --pano-log2 28 30 '
                      '--pano-batches 8 --layout <tcnn|line_local> --tile 128 128` (8 batches of 128 x 128 pixels spread from pole to pole, 2 encodes each); moved = 2 x FETCH_SIZE + '
                      'WRITE_SIZE (profiles/r06_fetch_size_calibration.json: a random gather is one 128-byte request tallied at 64); raw CSVs in profiles/r06_raw/',
-           'kernel': 'perf::hashgrid_fwd_big_kernel<FP16>, L = 20, finest resolution 8192; line_local = 4x4x2-vertex lines in 32x64x256-vertex super-blocks, levels of resolution >= 64',
+           'kernel': 'perf::hashgrid_fwd_big_local_kernel<FP16, 4> + perf::hashgrid_fwd_big_gather_kernel<FP16, 4> (line_local: the 15 line-local levels, then the 5 coarse ones) / '
+                     'perf::hashgrid_fwd_big_gather_kernel<FP16, 1> (tcnn), summed per encode; L = 20, finest resolution 8192; line_local = 4x4x2-vertex lines in '
+                     '32x64x256-vertex super-blocks, levels of resolution >= 64',
            'tables': tables}, open(os.path.join(DST, 'r06_config5_pmc.json'), 'w'), indent=1)
 
 # ---- SQ / TA / TCP / TCC counters of the line-local encode at T = 2^28 ------------------------------------------------------------
@@ -92,17 +112,20 @@ cnt = {'command': 'rocprofv3 --pmc <set> -- python tools/config5.py --pano-log2 
                   'hashgrid_fwd_big_kernel (4,194,304 samples x 20 levels)', 'variants': {}}
 for name, call in (('one lane per sample: four consecutive 16-byte x-run loads (64x64x128 super-blocks)', 'r06f'),
                    ('four lanes per sample: the four x-runs of a sample in one instruction (32x64x256 super-blocks), 4-row strip batches', 'r06j'),
-                   ('four lanes per sample, 128 x 128-pixel tile batches (shipped)', 'r06v')):
+                   ('four lanes per sample, 128 x 128-pixel tile batches', 'r06v'),
+                   ('the same with long-lived waves: four steps of 64 samples per wave, coordinates requested one step ahead (shipped; line-local launch + '
+                    'coarse-level gather launch summed)', 'r06ad')):
     agg = collections.defaultdict(list)
     for d in sorted(glob.glob(os.path.join(G, call, 'pmc_*', ''))):
         fcsv = glob.glob(d + '*counter_collection.csv')
         if not fcsv:
             continue
         keep(fcsv[0], f'config5_counters_{call}_{os.path.basename(os.path.dirname(d))}.csv')
-        for r in csv.DictReader(open(fcsv[0])):
-            if 'hashgrid_fwd_big' in r['Kernel_Name']:
-                agg[r['Counter_Name']].append(float(r['Counter_Value']))
-                agg['launch_ns'].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        names = sorted({r['Counter_Name'] for r in csv.DictReader(open(fcsv[0]))})
+        for g in encodes(fcsv[0], names):
+            for c in names:
+                agg[c].append(g[c])
+                agg['launch_ns'].append(g['ns'])
     m = {k: round(sum(v) / len(v)) for k, v in agg.items()}
     if 'SQ_WAVE_CYCLES' in m:
         m['wave_cycles_waiting_to_issue_frac'] = round(m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES'], 3)
