@@ -225,6 +225,8 @@ __device__ __forceinline__ BigItem big_item(const BigLevels& lv, int bpt) {
     return it;
 }
 
+typedef uint32_t uint2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // (an 8-byte load from a 4-byte aligned address: all gfx950's global loads need)
+
 template <typename T16, int STEPS>
 __global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams gp, BigLevels lv, const float* __restrict__ x01,
                                                                       const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams
     const int l = w.l;
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     const uint32_t* tl = table + gp.offset[l];
+    const bool dense = gp.hashed[l] == 0;
     constexpr int64_t kGroup = 256 * STEPS;
     const int64_t stripe = 8 * (int64_t)bpt * kGroup;            // samples of one turn of all eight XCDs
     for (int64_t Q = w.q0; Q * stripe < n_live; Q += grid_stripes) {
@@ -247,8 +250,22 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams
             if (i - threadIdx.x >= n_live) break;                // (workgroup-uniform)
             const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
             uint32_t v[8];
+            if (dense) {
+                // the two x corners of a dense level are neighbours in the table: ONE 8-byte request per corner pair (the texture addresser
+                // takes a wave's request at four lanes per cycle whatever its width) unless the index wrapped between them
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = tl[c.idx[k]];
+                for (int k = 0; k < 8; k += 2) {
+                    if (c.idx[k + 1] == c.idx[k] + 1u) {
+                        const uint2_a4 p = *reinterpret_cast<const uint2_a4*>(tl + c.idx[k]);
+                        v[k] = p.x; v[k + 1] = p.y;
+                    } else {
+                        v[k] = tl[c.idx[k]]; v[k + 1] = tl[c.idx[k + 1]];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = tl[c.idx[k]];
+            }
             if (it + 1 < STEPS) {                                // the next step's coordinates, behind this step's gathers
                 int64_t i1 = i + 256;
                 if (i1 >= n_live) i1 = n_live - 1;
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams
 
 // line-local levels: lane = (sample s of a group of 16, corner pair r = ky + 2 kz); four groups of a wave in flight.  The four lanes
 // of a quad fetch the coordinates of ONE sample each (group r's) one step ahead and hand them round by quad broadcasts: three
-// registers per lane instead of twelve keep the kernel at eight waves per SIMD.
+// registers per lane instead of twelve (70 in all: seven waves per SIMD).
 template <int K>
 __device__ __forceinline__ float quad_bcast(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));   // quad_perm [K,K,K,K]

@@ -1,24 +1,12 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06ad
+O=$R/gpurun_out/r06ae
 rm -rf $O; mkdir -p $O
 cd $R
-( time timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_config5.py -m gpu -x -q ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-( timeout 900 python -m pytest tests/test_gpu_dist.py -m gpu -x -q -k "config5 or shard" ) > $O/pytest_dist.log 2>&1; tail -2 $O/pytest_dist.log
-for LAY in line_local tcnn; do
-  timeout 600 python tools/config5.py --pano-log2 28 30 --layout $LAY > $O/c5_$LAY.log 2>&1
-  grep -E "seconds_per_panorama|ms_per_launch|\"frac\"|ray_samples_per_s" $O/c5_$LAY.log
-done
+( timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "deep_grid or beyond_32" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 cd /tmp && export TMPDIR=/tmp
-for LAY in tcnn line_local; do
-  for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --pmc $C --output-format csv -d $O/c5_${LAY}_$C -o c -- python $R/tools/config5.py --pano-log2 28 30 --pano-batches 8 --layout $LAY --tile 128 128 > $O/c5_${LAY}_$C.log 2>&1
-  done
-done
-for SET in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum"; do
-  N=$(echo $SET | cut -d' ' -f1)
-  timeout 600 rocprofv3 --pmc $SET --output-format csv -d $O/pmc_$N -o c -- python $R/tools/config5.py --pano-log2 28 --pano-batches 8 --layout line_local --tile 128 128 > $O/pmc_$N.log 2>&1
-done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/tools/config5.py --pano-log2 28 --layout line_local > $O/kt.log 2>&1
+grep -E "big" $O/kt/*kernel_stats.csv | cut -c1-60,200-330
 cd $R
+timeout 600 python tools/config5.py --pano-log2 28 30 --layout line_local > $O/c5_line_local.log 2>&1
+grep -E "seconds_per_panorama|ms_per_launch|\"frac\"|ray_samples_per_s" $O/c5_line_local.log
 find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete
-du -sh $O
