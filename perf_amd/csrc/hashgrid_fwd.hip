@@ -210,7 +210,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // The two kinds of level are two kernels (each keeps its own register budget: 7-8 waves per SIMD), launched one after the other
 // over their own lists of levels.
-struct BigLevels { int32_t count; int32_t level[PERF_MAX_LEVELS]; };
+struct BigLevels { int32_t count; int32_t order; int64_t stripes; int32_t level[PERF_MAX_LEVELS]; };
 
 // work item of workgroup b: XCD x = b % 8, its turn's sub-group, the level and the first stripe
 struct BigItem { int xcd, sub, l; int64_t q0; };
@@ -220,8 +220,13 @@ __device__ __forceinline__ BigItem big_item(const BigLevels& lv, int bpt) {
     const int64_t j = (int64_t)(blockIdx.x >> 3);
     it.sub = (int)(j % bpt);                                     // a turn of an XCD = bpt workgroups = bpt x 256 x STEPS consecutive samples
     const int64_t t = j / bpt;
-    it.l = lv.level[(int)(t % lv.count)];
-    it.q0 = t / lv.count;
+    if (lv.order == 1) {                                         // level-major: every turn of a level, then the next level
+        it.l = lv.level[(int)(t / lv.stripes)];
+        it.q0 = t % lv.stripes;
+    } else {
+        it.l = lv.level[(int)(t % lv.count)];
+        it.q0 = t / lv.count;
+    }
     return it;
 }
 
@@ -389,6 +394,11 @@ static void launch_big(const GridParams& gp, const GridLocal& gl, const float* x
     for (int l = 0; l < gp.n_levels; ++l) {
         if (gl.local[l]) local.level[local.count++] = l; else gather.level[gather.count++] = l;
     }
+    // Order of the work items (measured at T = 2^28, profiles/r06_config5_long_waves.json): beside line-local levels the levels
+    // ALTERNATE from workgroup to workgroup (0.72 ms; a level at a time 0.79: cache-resident and HBM-bound levels share the chip at any
+    // moment); tables beyond the caches in tcnn's layout are served a LEVEL AT A TIME (1.26 ms against 1.47 alternating).
+    gather.order = local.order = local.count ? 0 : 1;
+    gather.stripes = local.stripes = stripes;
     // (line-local levels first: the long launch; the few coarse levels' gathers find the coordinates in the caches)
     if (local.count)
         hipLaunchKernelGGL((hashgrid_fwd_big_local_kernel<T16, kBigSteps>), dim3((unsigned)(stripes * local.count * 8 * kBigTurnGroups)), dim3(256), 0, as_stream(stream),

@@ -759,8 +759,10 @@ def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift, min_res):
 def test_table_beyond_32_bit_offsets(ops, layout, T):
     """5.6e9 entries (21 GiB of 2x16-bit features; T = 30: 1.1e10 entries, 41 GiB -- beyond BASELINE config 5's 31 GiB per encoder):
     level offsets exceed 2^32.  The table is filled on the device with a function of the global entry index; the expected
-    features of 640 points are evaluated on the host from the oracle's corner indices and weights through the same function, so
-    no host copy of the table is needed.  Both table layouts."""
+    features of 65,573 points -- half of them uniform in the cube, half consecutive samples along rays from the centre as a panorama
+    batch holds them (neighbouring lanes share table lines; the deep-grid kernel's waves take several steps and end inside one) --
+    are evaluated on the host from the oracle's corner indices and weights through the same function, so no host copy of the table
+    is needed.  Both table layouts."""
     L, b = 20, 1.5
     cfg = _grid_cfg(n_levels=L, log2_hashmap_size=T, base_resolution=16, per_level_scale=b, layout=layout)
     lv = _lv_of(cfg)
@@ -777,8 +779,13 @@ def test_table_beyond_32_bit_offsets(ops, layout, T):
         f0, f1 = value(idx)
         table[2 * lo: 2 * (lo + idx.numel())] = torch.stack([f0, f1], -1).reshape(-1).half()
         del idx, f0, f1
-    n = 640
-    x = torch.rand(n, 3, generator=torch.Generator().manual_seed(37))
+    g = torch.Generator().manual_seed(37)
+    x_uniform = torch.rand(32768 + 37, 3, generator=g)
+    d = torch.nn.functional.normalize(torch.randn(128, 3, generator=g), dim=-1)
+    t = (torch.arange(256, dtype=torch.float32) + 0.5) * (0.99 / 256)
+    x_rays = (0.5 + 0.5 * d[:, None, :] * t[None, :, None]).reshape(-1, 3).clamp(0.0, 1.0)          # 128 rays x 256 samples, packed by ray
+    x = torch.cat([x_rays, x_uniform])
+    n = x.shape[0]
     feat = ops.hashgrid_fwd(cfg, x.cuda(), table).float().cpu()          # [L, n, 2]
     xn = x.numpy()
     for l in range(L):
