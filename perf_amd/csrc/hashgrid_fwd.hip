@@ -242,6 +242,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     const uint32_t* tl = table + gp.offset[l];
     const bool dense = gp.hashed[l] == 0;
+    const float sc = gp.scale[l];
+    const uint32_t res = gp.res[l], r2 = res * res, size = gp.size[l];
     constexpr int64_t kGroup = 256 * STEPS;
     const int64_t stripe = 8 * (int64_t)bpt * kGroup;            // samples of one turn of all eight XCDs
     for (int64_t Q = w.q0; Q * stripe < n_live; Q += grid_stripes) {
@@ -253,21 +255,29 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams
         for (int it = 0; it < STEPS; ++it) {
             const int64_t i = base + 256 * it;
             if (i - threadIdx.x >= n_live) break;                // (workgroup-uniform)
-            const Corners c = corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
             uint32_t v[8];
+            float f[3];
+            // a dense level whose eight corners of THIS wave need no wrap (every wave but those that touch the table's last cells): the two x
+            // corners are neighbours in the table -- ONE 8-byte request per (y, z) corner pair, no per-corner index arithmetic or bound test
+            // (the launch of the coarse levels is bound by vector issue); same position arithmetic as corners_of
+            bool fast = false;
             if (dense) {
-                // the two x corners of a dense level are neighbours in the table: ONE 8-byte request per corner pair (the texture addresser
-                // takes a wave's request at four lanes per cycle whatever its width) unless the index wrapped between them
-#pragma unroll
-                for (int k = 0; k < 8; k += 2) {
-                    if (c.idx[k + 1] == c.idx[k] + 1u) {
-                        const uint2_a4 p = *reinterpret_cast<const uint2_a4*>(tl + c.idx[k]);
-                        v[k] = p.x; v[k + 1] = p.y;
-                    } else {
-                        v[k] = tl[c.idx[k]]; v[k + 1] = tl[c.idx[k + 1]];
-                    }
+                const float px = grid_pos(x, sc), py = grid_pos(y, sc), pz = grid_pos(z, sc);
+                const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+                const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+                const uint32_t base = gx + gy * res + gz * r2;
+                fast = __all((int)(base + 1u + res + r2 < size)) != 0;      // (wave-uniform)
+                if (fast) {
+                    f[0] = px - flx; f[1] = py - fly; f[2] = pz - flz;
+                    const uint32_t* t0 = tl + base;
+                    const uint2_a4 p0 = *reinterpret_cast<const uint2_a4*>(t0), p1 = *reinterpret_cast<const uint2_a4*>(t0 + res),
+                                   p2 = *reinterpret_cast<const uint2_a4*>(t0 + r2), p3 = *reinterpret_cast<const uint2_a4*>(t0 + res + r2);
+                    v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
                 }
-            } else {
+            }
+            if (!fast) {
+                const Corners c = corners_of(x, y, z, sc, res, size, !dense);
+                f[0] = c.f[0]; f[1] = c.f[1]; f[2] = c.f[2];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = tl[c.idx[k]];
             }
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams
                 x = x01[3 * i1]; y = x01[3 * i1 + 1]; z = x01[3 * i1 + 2];
             }
             float wt[8];
-            corner_weights(c.f, smooth, wt);
+            corner_weights(f, smooth, wt);
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {

@@ -742,9 +742,13 @@ def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift, min_res):
         t16 = table.to(tdt).reshape(-1).cuda()
         part = ops.hashgrid_fwd(cfg, xd, t16, n_dev=torch.tensor([live], dtype=torch.int64, device='cuda'))
         assert torch.equal(part[:, :live], feat[:, :live])
-        # tiny and ragged launches (one sample; less than a 16-sample group; one group short of a wave), an empty live count
-        for m in (1, 15, 70):
+        # tiny and ragged launches (one sample; less than a 16-sample group; one group short of a wave; around the ends of a wave's
+        # step of 64, of its four steps and of a workgroup's 1,024 samples), live counts that end on those boundaries, an empty live count
+        for m in (1, 15, 70, 255, 256, 257, 1023, 1024, 1025):
             assert torch.equal(ops.hashgrid_fwd(cfg, xd[:m].contiguous(), t16), feat[:, :m]), (layout, dt, m)
+        for live2 in (64, 1024, 1088, 2047):
+            part = ops.hashgrid_fwd(cfg, xd, t16, n_dev=torch.tensor([live2], dtype=torch.int64, device='cuda'))
+            assert torch.equal(part[:, :live2], feat[:, :live2]), (layout, dt, live2)
         canary = ops.hashgrid_fwd(cfg, xd[:300].contiguous(), t16, n_dev=torch.tensor([0], dtype=torch.int64, device='cuda'))
         assert canary.shape == (L, 300, 2)
     if layout == 'line_local':
