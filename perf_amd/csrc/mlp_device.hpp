@@ -382,7 +382,11 @@ __device__ __forceinline__ int tr_offset16(int lane) {
 // FAST (chosen by the launcher): every level slot of the first layer is a real level (n_levels == 8 * KS) and the level-major
 // offsets fit 32 bits -- the addressing above, and a FIXED number of loads per request (below).
 template <typename T16, int NH, int KS, bool FAST>
-__global__ __launch_bounds__(256, (KS < 3) ? 2 : 1) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
+// Two workgroups per CU (256 registers per lane) for KS < 3 -- except <NH = 2, KS = 2, plain>, whose general addressing does not fit 256
+// registers (396 B of scratch per lane: 252 us per 1 M samples at L = 12 against 142 us with one workgroup per CU and no scratch).  The
+// NH = 2, KS = 1 variants keep their 88-104 B of scratch: 110 us at two workgroups per CU against 121 us spill-free at one
+// (tools/exp/mlp_bwd_scratch_ab.py; none of these is PeRF's L = 16, whose <2, 2, FAST> carries 16 B).
+__global__ __launch_bounds__(256, (KS < 3 && !(NH == 2 && KS == 2 && !FAST)) ? 2 : 1) void mlp_bwd_kernel(MlpParams mp, const uint16_t* __restrict__ w,
                                                       const uint32_t* __restrict__ feat,
                                                       const int32_t* __restrict__ feat_index, int64_t feat_stride,
                                                       const uint8_t* __restrict__ sel,
