@@ -70,7 +70,9 @@ extern "C" {
  * HBM): a level with local[l] != 0 stores the vertices of a 4 x 4 x 2 block as one 128-byte line (entry x%4 + 4 (y%4) + 16 (z%2)),
  * the blocks of a super-block of 2^sb_shift[0] x 2^sb_shift[1] x 2^sb_shift[2] vertices contiguously (x-major), and addresses the
  * SUPER-BLOCK densely (sx + sy*nsx[l] + sz*nsxy[l], hashed[l] == 0) or by the prime-XOR hash of its coordinates modulo
- * size[l] >> (sb_shift[0] + sb_shift[1] + sb_shift[2]).  Levels with local[l] == 0 keep the TCNN rule. */
+ * size[l] >> (sb_shift[0] + sb_shift[1] + sb_shift[2]).  offset[l] of such a level is a multiple of 32 entries (its blocks ARE cache
+ * lines; perf_amd.grid.GridConfig starts it on a super-block boundary: entries in front of it are padding) and the table pointer is
+ * 128-byte aligned.  Levels with local[l] == 0 keep the TCNN rule. */
 #define PERF_LAYOUT_TCNN 0
 #define PERF_LAYOUT_LINE_LOCAL 1
 

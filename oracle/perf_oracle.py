@@ -134,7 +134,8 @@ def grid_levels(n_levels=16, n_feat=2, log2_hashmap_size=18, base_resolution=16,
     address the super-block either densely (index sx + sy*nx + sz*nx*ny when all n_d = (res + 2^s_d) >> s_d super-blocks per
     dimension fit 2^T entries) or through tcnn's prime-XOR hash OF THE SUPER-BLOCK COORDINATES modulo the number of
     super-blocks in 2^T entries.  A sample's eight corners then lie in (1+1/4)(1+1/4)(1+1/2) = 2.3 lines of ONE page instead
-    of four lines on four pages.  Coarser levels keep tcnn's rule.  Same scale / res / interpolation as tcnn's grid."""
+    of four lines on four pages.  A line-local level starts at a multiple of the super-block size (the entries between the levels
+    are padding).  Coarser levels keep tcnn's rule.  Same scale / res / interpolation as tcnn's grid."""
     assert layout in ('tcnn', 'line_local')
     per_sb = 1 << sum(sb_shift)
     log2_b = F32(np.log2(F32(per_level_scale)))
@@ -157,6 +158,7 @@ def grid_levels(n_levels=16, n_feat=2, log2_hashmap_size=18, base_resolution=16,
             n = min(full, 1 << log2_hashmap_size)
             assert n >= per_sb, 'line_local: 2^log2_hashmap_size must hold at least one super-block'
             local[l], nsx[l], nsxy[l] = True, nd[0], nd[0] * nd[1]
+            total = -(-total // per_sb) * per_sb             # the level starts on a super-block boundary (its 128-byte blocks are cache lines)
         else:
             full = r ** 3
             n = min(full, U32_MASK // 2)

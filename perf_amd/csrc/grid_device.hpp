@@ -44,6 +44,7 @@ static int fill_params(const perf_grid_desc* g, GridParams* p, GridLocal* loc = 
                 if (!g->local[l]) continue;
                 loc->any = 1;
                 PERF_REQUIRE(g->size[l] >= per_sb && g->size[l] % per_sb == 0, "line-local level %d: size %u is not a whole number of super-blocks", l, g->size[l]);
+                PERF_REQUIRE(g->offset[l] % 32u == 0, "line-local level %d starts inside a 128-byte line (offset %llu entries)", l, (unsigned long long)g->offset[l]);
                 if (g->hashed[l]) { const uint32_t ns = g->size[l] / per_sb; PERF_REQUIRE((ns & (ns - 1)) == 0, "line-local hashed level %d: %u super-blocks is not a power of two", l, ns); }
             }
         }

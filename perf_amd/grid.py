@@ -77,6 +77,7 @@ class GridConfig:
                 if n < per_sb:
                     raise ValueError(f'line_local: 2^{self.log2_hashmap_size} entries hold no {self.sb_shift} super-block')
                 self.local[l], self.nsx[l], self.nsxy[l] = 1, nd[0], nd[0] * nd[1]
+                total = -(-total // per_sb) * per_sb         # a line-local level starts on a super-block boundary: its 128-byte blocks are cache lines
             else:
                 cells = r ** 3
                 n = min(cells, 0xFFFFFFFF // 2)

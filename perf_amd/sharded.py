@@ -37,9 +37,15 @@ class GridSlice:
     total: int = field(init=False)
 
     def __post_init__(self):
-        sizes = [int(self.full.size[l]) for l in self.levels]
-        self.offset = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64) if sizes else np.zeros(0, np.uint64)
-        self.total = int(sum(sizes))
+        per_sb = 1 << sum(int(v) for v in self.full.sb_shift)
+        offs, total = [], 0
+        for l in self.levels:
+            if int(self.full.local[l]):
+                total = -(-total // per_sb) * per_sb             # (GridConfig's rule: a line-local level starts on a super-block boundary)
+            offs.append(total)
+            total += int(self.full.size[l])
+        self.offset = np.asarray(offs, np.uint64)
+        self.total = int(total)
 
     @property
     def n_levels(self):
@@ -48,6 +54,15 @@ class GridSlice:
     @property
     def n_params(self):
         return self.total * 2
+
+    def pack(self, level_tables, dtype, device='cpu'):
+        """The slice's table from its levels' tables (flat, 2 features per entry, in slice order): each at its offset, zeros between
+        (the padding in front of a line-local level)."""
+        out = torch.zeros(self.total * 2, dtype=dtype, device=device)
+        for k, t in enumerate(level_tables):
+            lo = 2 * int(self.offset[k])
+            out[lo: lo + t.numel()] = t.to(device=device, dtype=dtype)
+        return out
 
     @property
     def interpolation(self):
@@ -132,7 +147,7 @@ class LevelShardedEncoder:
                 t = (torch.rand(int(grid.size[l]) * 2, generator=g, device='cpu') * 2 - 1) * 1e-4
                 if l in self.local.levels:
                     parts.append(t)
-            table16 = torch.cat(parts).to(self.dtype) if parts else torch.zeros(0, dtype=self.dtype, device='cpu')
+            table16 = self.local.pack(parts, self.dtype)
         self.table16 = table16.to(dev)
 
     # ---- collectives (all-to-all on RCCL; gloo -- tests on one GPU -- has none, so it is composed from all_gather) ------
@@ -229,9 +244,8 @@ class LevelShardedNeRF:
             dist, rank, world = _group()
             levels = assign_levels(grid, world)[rank]
             local = GridSlice(grid, levels)
-            mine = torch.cat([w16[n_net + 2 * int(grid.offset[l]): n_net + 2 * int(grid.offset[l] + grid.size[l])] for l in levels]) \
-                if levels else torch.zeros(0, dtype=w16.dtype, device=w16.device)
-            enc = LevelShardedEncoder(grid, dtype=self.dtype_name, table16=mine.clone())
+            mine = local.pack([w16[n_net + 2 * int(grid.offset[l]): n_net + 2 * int(grid.offset[l] + grid.size[l])] for l in levels], w16.dtype, w16.device)
+            enc = LevelShardedEncoder(grid, dtype=self.dtype_name, table16=mine)
             assert enc.local.levels == local.levels
             self.nets[name] = (enc, mlp, w16[:n_net].clone())
 

@@ -30,7 +30,7 @@ def test_host_level_table_equals_the_oracle(log2_t, sb_shift, min_res):
     for l in range(L):
         assert bool(lv.local[l]) == (int(lv.res[l]) >= min_res)
         if lv.local[l]:
-            assert int(lv.size[l]) % per_sb == 0 and int(lv.offset[l]) % 4 == 0          # whole super-blocks; 16-byte aligned runs
+            assert int(lv.size[l]) % per_sb == 0 and int(lv.offset[l]) % per_sb == 0     # whole super-blocks, starting on a super-block boundary: a block IS a cache line
             if lv.hashed[l]:
                 ns = int(lv.size[l]) // per_sb
                 assert ns & (ns - 1) == 0                                                  # the slot hash is a mask
@@ -39,6 +39,26 @@ def test_host_level_table_equals_the_oracle(log2_t, sb_shift, min_res):
     for l in range(L):
         if not lv.local[l]:
             assert int(lv.size[l]) == int(ref.size[l]) and bool(lv.hashed[l]) == bool(ref.hashed[l])
+
+
+def test_a_level_slice_keeps_the_alignment_rule():
+    """perf_amd.sharded.GridSlice (a rank's levels of a level-sharded table): line-local levels start on super-block boundaries of the
+    slice's own table, and pack() puts each level's entries at its offset."""
+    import torch
+    from perf_amd.sharded import GridSlice
+    cfg, lv = _levels(20, (3, 3, 2), 64)
+    per_sb = 1 << 8
+    first_local = int(np.argmax(lv.local))
+    sl = GridSlice(cfg, [first_local - 1, first_local, first_local + 3])
+    assert int(sl.offset[0]) == 0 and int(sl.offset[1]) % per_sb == 0 and int(sl.offset[2]) % per_sb == 0
+    assert int(sl.offset[1]) >= int(cfg.size[first_local - 1]) and sl.total == int(sl.offset[2]) + int(cfg.size[first_local + 3])
+    parts = [torch.full((2 * int(cfg.size[l]),), float(k + 1)) for k, l in enumerate(sl.levels)]
+    t = sl.pack(parts, torch.float32)
+    assert t.numel() == 2 * sl.total
+    for k, l in enumerate(sl.levels):
+        lo = 2 * int(sl.offset[k])
+        assert bool((t[lo: lo + 2 * int(cfg.size[l])] == k + 1).all())
+    assert float(t.sum()) == sum((k + 1) * 2 * int(cfg.size[l]) for k, l in enumerate(sl.levels))      # zeros between
 
 
 def _vertex_index(lv, l, v):
