@@ -6,7 +6,7 @@
                                    for both table layouts: HBM bytes per launch of hashgrid_fwd_big_kernel (bench.py's config5 block reads it)
   r06_config5_counters.json        SQ / TA / TCP / TCC counters of the line-local encode at T = 2^28, one lane per sample (r06f) and four lanes per
                                    sample (r06j)
-  python tools/exp/r06_fold_config5.py      (reads gpurun_out/r06a, r06f, r06j, r06v, r06ad, r06ai; copies the raw CSVs to profiles/r06_raw/)"""
+  python tools/exp/r06_fold_config5.py      (reads gpurun_out/r06a, r06f, r06j, r06v, r06ai, r06at; copies the raw CSVs to profiles/r06_raw/)"""
 import collections, csv, glob, json, os, shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -83,7 +83,7 @@ def rows(path, counter):
 
 
 tables = {}
-for layout, call in (('tcnn', 'r06ai'), ('line_local', 'r06ad')):
+for layout, call in (('tcnn', 'r06ai'), ('line_local', 'r06at')):
     f = rows(os.path.join(G, call, f'c5_{layout}_FETCH_SIZE', 'c_counter_collection.csv'), 'FETCH_SIZE')
     w = rows(os.path.join(G, call, f'c5_{layout}_WRITE_SIZE', 'c_counter_collection.csv'), 'WRITE_SIZE')
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -114,7 +114,7 @@ for name, call in (('one lane per sample: four consecutive 16-byte x-run loads (
                    ('four lanes per sample: the four x-runs of a sample in one instruction (32x64x256 super-blocks), 4-row strip batches', 'r06j'),
                    ('four lanes per sample, 128 x 128-pixel tile batches', 'r06v'),
                    ('the same with long-lived waves: four steps of 64 samples per wave, coordinates requested one step ahead (shipped; line-local launch + '
-                    'coarse-level gather launch summed)', 'r06ad')):
+                    'coarse-level gather launch summed; levels aligned to super-blocks)', 'r06at')):
     agg = collections.defaultdict(list)
     for d in sorted(glob.glob(os.path.join(G, call, 'pmc_*', ''))):
         fcsv = glob.glob(d + '*counter_collection.csv')
