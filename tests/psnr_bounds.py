@@ -11,8 +11,9 @@ identical batches and draws (tests/golden/psnr_curve*.json).  Per scene family a
     both measured ON THE ORACLE and committed with its curves: `oracle_spread` is the fp32 oracle's own movement under the one-ulp
     perturbation (0.006-0.015 dB room, 0.18 doorway, 0.045 pillars); `oracle_16bit` is the oracle with that storage type emulated
     (parameters and features rounded to it in the forward passes, everything else fp32): what the storage type ALONE does to a
-    trajectory.  For bf16 that is 0.06-0.07 dB rms per seed (room: -0.01 / +0.09 / -0.08 / -0.02 / -0.08 at 150 iterations, -0.07 /
-    +0.07 / +0.02 / -0.10 / -0.02 at 300) -- the same size as the HIP path's bf16 deviations, and for the two seeds where the HIP
+    trajectory.  For bf16 that is 0.06-0.14 dB rms per family and mark (room: -0.01 / +0.09 / -0.08 / -0.02 / -0.08 at 150 iterations,
+    -0.07 / +0.07 / +0.02 / -0.10 / -0.02 at 300; doorway -0.03 / -0.11 / +0.06 and -0.01 / -0.14 / +0.04; pillars +0.04 / -0.11 /
+    +0.11 and +0.05 / -0.17 / +0.16) -- the same size as the HIP path's bf16 deviations, and for the two room seeds where the HIP
     offset is reproducible across its ensemble (0 and 3 at 300 iterations: -0.12) the emulated oracle moves the same way (-0.07,
     -0.10).  Where no emulated curve is committed for a type (fp16: the reference's own storage type) storage_noise is 0: the bound is
     max(0.1 dB, oracle_spread), and every fp16 seed of every family meets it;

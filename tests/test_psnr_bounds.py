@@ -23,10 +23,7 @@ def test_the_fixtures_carry_what_the_bounds_are_made_of(family):
     for k in B.marks_of(g):
         assert 0.0 < sp[k] < 0.25                                                  # the fp32 oracle under a one-ulp change of its initialisation
     emu = g['oracle_16bit']['bf16']['curves']
-    seeds = [str(r['seed']) for r in g['seeds']]
-    assert emu and set(emu) <= set(seeds)                                          # the bf16-storage oracle (a run takes 15-45 min per seed on the CPU)
-    if family == 'room':
-        assert sorted(emu) == sorted(seeds)                                        # ... for every seed of the family the constants were tuned on
+    assert sorted(emu) == sorted(str(r['seed']) for r in g['seeds'])               # the bf16-storage oracle, every seed (15-45 min per seed on the CPU)
     for dtype in ('bf16', 'fp16'):
         for k, b in B.seed_bound(g, dtype).items():
             assert b['base'] == max(0.1, sp[k])
