@@ -98,10 +98,13 @@ __device__ __forceinline__ Corners corners_of(float x, float y, float z, float s
         uint32_t r2 = res * res;
         uint32_t base = gx + gy * res + gz * r2;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uint32_t i = base + (uint32_t)(k & 1) + ((k & 2) ? res : 0u) + ((k & 4) ? r2 : 0u);
-            if (i >= size) i = i % size;
-            c.idx[k] = i;
+        for (int k = 0; k < 8; ++k) c.idx[k] = base + (uint32_t)(k & 1) + ((k & 2) ? res : 0u) + ((k & 4) ? r2 : 0u);
+        // (modulo the level's size: ONE test of the cell's last corner covers the eight -- it only fires at the table's last cells)
+        const uint32_t last = base + 1u + res + r2;
+        if (last >= size || last < base) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c.idx[k] >= size) c.idx[k] = c.idx[k] % size;
         }
     }
     return c;
