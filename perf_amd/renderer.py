@@ -124,14 +124,14 @@ class NeRFOCCRenderer(nn.Module):
 
         weights, trans, opacities, distances, colors = volume_render(sigmas, rgbs, st['t_starts'], st['t_ends'], packed)
 
-        if self.bg_color == 'rand_noise':
-            bg_color = rand['bg'] if 'bg' in rand else torch.rand(n_rays, 3, device=dev)
-        elif self.bg_color == 'white':
-            bg_color = torch.ones(n_rays, 3, device=dev)
-        else:
-            bg_color = torch.zeros(n_rays, 3, device=dev)
-
         if nerf.training:
+            # (the background colour is only read by the training composite: an eval frame does not draw / fill 3 floats per ray for nothing)
+            if self.bg_color == 'rand_noise':
+                bg_color = rand['bg'] if 'bg' in rand else torch.rand(n_rays, 3, device=dev)
+            elif self.bg_color == 'white':
+                bg_color = torch.ones(n_rays, 3, device=dev)
+            else:
+                bg_color = torch.zeros(n_rays, 3, device=dev)
             noise = rand['noise'] if 'noise' in rand else torch.rand_like(distances)
             distances = torch.relu(distances + (noise * 2. - 1.) * (1. - opacities))
             colors = colors + bg_color * (1. - opacities).detach()

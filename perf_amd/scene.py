@@ -544,8 +544,17 @@ class NeRFScene:
         rays_o, rays_d = rays.collapse()
         assert len(rays_o.shape) == 2
         n = len(rays_o)
-        near = 1e-2 * torch.ones([n, 1], device=rays_o.device)       # to_bounded_rays (nerf.py:313-319); unused by occ
-        far = torch.ones([n, 1], device=rays_o.device)
+        # to_bounded_rays (nerf.py:313-319): constants the occupancy renderer never reads -- kept per (n, device) instead of being
+        # filled on every call (three launches of a captured frame otherwise)
+        # (a small dict: every batch size of a frame is met in the eager warm-up pass that precedes a capture, so a captured pass
+        #  never allocates them from a graph's pool)
+        cache = self.__dict__.setdefault('_bounds', {})
+        key = (n, rays_o.device)
+        if key not in cache:
+            if len(cache) >= 8:
+                cache.clear()
+            cache[key] = (1e-2 * torch.ones([n, 1], device=rays_o.device), torch.ones([n, 1], device=rays_o.device))
+        near, far = cache[key]
         res = self.renderer.render(self.nerf, self.estimator, rays_o, rays_d, near, far,
                                    geo_inference=geo_inference, app_inference=app_inference, rand=rand)
         if (res is None) or (not res['is_valid']):
@@ -1317,8 +1326,12 @@ class NeRFScene:
         o_buf = torch.empty(height, width, 3, dtype=torch.float32, device=dev)
         d_buf = torch.empty(height, width, 3, dtype=torch.float32, device=dev)
         width_of = {'rgb': 3, 'distance': 1, 'opacities': 1}
-        outs = {k: torch.empty(n, width_of[k], dtype=torch.float32, device=dev) for k in query_keys}
+        # one batch per frame (config 4): the frame's results ARE the renderer's tensors (owned by the graph's pool: same addresses on
+        # every replay) and the marched count is read where the renderer left it -- no copy nodes; several batches: gathered by copies
+        single = n_batches == 1
+        outs = {} if single else {k: torch.empty(n, width_of[k], dtype=torch.float32, device=dev) for k in query_keys}
         marched = torch.zeros(n_batches, dtype=torch.int64, device=dev)
+        sizes = torch.tensor([min((b + 1) * batch_size, n) - b * batch_size for b in range(n_batches)], dtype=torch.float32, device=dev)
         r = self.renderer
 
         def body():
@@ -1328,6 +1341,11 @@ class NeRFScene:
                 lo, hi = b * batch_size, min((b + 1) * batch_size, n)
                 r.sample_capacity = (hi - lo) * state['per_ray']
                 cur = self.render_once(Rays(fo[lo:hi], fd[lo:hi]), list(query_keys) + ['n_marched_dev'])
+                if single:
+                    for k in query_keys:
+                        outs[k] = cur[k]
+                    state['marched_ref'] = cur['n_marched_dev']
+                    continue
                 for k in query_keys:
                     outs[k][lo:hi].copy_(cur[k])
                 marched[b:b + 1].copy_(cur['n_marched_dev'])
@@ -1354,8 +1372,7 @@ class NeRFScene:
             pose_dev.copy_(torch.as_tensor(pose, dtype=torch.float32, device=pose.device if torch.is_tensor(pose) else 'cpu').reshape(4, 4), non_blocking=True)
             while True:
                 state['graph'].replay()
-                sizes = torch.tensor([min((b + 1) * batch_size, n) - b * batch_size for b in range(n_batches)], device=dev)
-                worst = float((marched.float() / sizes).max().item())
+                worst = float(state['marched_ref'].item()) / n if single else float((marched.float() / sizes).max().item())
                 if worst <= state['per_ray']:
                     break
                 state['per_ray'] = self._eval_spp_cap = int(math.ceil(worst * 1.25))

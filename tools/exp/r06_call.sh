@@ -1,16 +1,14 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06az
+O=$R/gpurun_out/r06ba
 rm -rf $O; mkdir -p $O
 cd $R
-OFF="--no-cpu-baseline --no-psnr --no-reuse-line --sustain-seconds 0 --no-render-block --no-config4 --no-config5 --no-train-app"
-for i in 1 2 3; do
-  timeout 600 python bench.py --steps 30 --warmup 5 $OFF > $O/bench_$i.log 2>&1
-  python - <<PY
+( timeout 1500 python -m pytest tests/test_gpu_config4.py tests/test_gpu_scene.py tests/test_gpu_runner_state.py -m gpu -x -q ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+for i in 1 2; do
+timeout 600 python tools/render_dense.py --poses 300 --batch 524288 > $O/rd_$i.log 2>&1
+python - <<PY
 import json
-t=open('$O/bench_$i.log').read().strip().splitlines()[-1]
-d=json.loads(t)
-k=d['kernels']
-print('run $i', round(d['ms_per_step'],4), {n:k[n]['ms_per_launch'] for n in ('perf_hashgrid_fwd','perf_hashgrid_bwd')})
+t=open('$O/rd_$i.log').read()
+d=json.loads(t[t.rindex('\n{'):] if '\n{' in t else t[t.index('{'):])
+print({k: d[k] for k in d if 'frames_per_s' in k or 'checksum' in k})
 PY
 done
-( timeout 1500 python -m pytest tests/test_gpu_ops.py -m gpu -x -q ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
