@@ -314,10 +314,11 @@ def config5_block(args):
     4096x2048 panorama x 256 samples per ray through both L = 20 fields whose 16-bit tables exceed every cache (T = 2^28: 9.2 GiB
     per encoder; 2^30: 31 GiB, 64-bit entry offsets), NeRFOCCRenderer.render per batch of 4 rows, + compositing.  Per table size:
     ray-samples/s and the encode kernel's algorithmic and MOVED fraction of the HBM peak (the latter from the committed
-    rocprofv3 PMC pass of the same batches, profiles/r06_config5_pmc.json).  Each table size TWICE: with tcnn's table layout
-    (`T<k>`) and with the opt-in line-local layout (`T<k>_line_local`, perf_amd.grid.GridConfig: no reference result exists for
-    these grids, the layout is this build's to choose).  tests/test_gpu_config5.py checks the same workload through
-    size-independent properties."""
+    rocprofv3 PMC pass of the same batches, profiles/r06_config5_pmc.json).  Each table size THREE times: with tcnn's table layout
+    (`T<k>`), with the opt-in line-local layout (`T<k>_line_local`, perf_amd.grid.GridConfig: no reference result exists for
+    these grids, the layout is this build's to choose) and with its overlapping-run variant (`T<k>_line_overlap`: the same 2^T
+    entries per hashed level hold 3/4 as many distinct vertices, a cell's x corner pair is always one request).
+    tests/test_gpu_config5.py checks the same workload through size-independent properties."""
     from perf_amd import panorama as C
     pmc = None
     try:
@@ -326,7 +327,7 @@ def config5_block(args):
         pass
     out = {}
     for log2_t in args.config5_log2:
-        for layout in ('tcnn', 'line_local'):
+        for layout in ('tcnn', 'line_local', 'line_overlap'):
             key = f'T{log2_t}' + ('' if layout == 'tcnn' else '_' + layout)
             torch.cuda.empty_cache()
             free, _total = torch.cuda.mem_get_info()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 10
+#define PERF_ABI_VERSION 11
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -72,9 +72,18 @@ extern "C" {
  * SUPER-BLOCK densely (sx + sy*nsx[l] + sz*nsxy[l], hashed[l] == 0) or by the prime-XOR hash of its coordinates modulo
  * size[l] >> (sb_shift[0] + sb_shift[1] + sb_shift[2]).  offset[l] of such a level is a multiple of 32 entries (its blocks ARE cache
  * lines; perf_amd.grid.GridConfig starts it on a super-block boundary: entries in front of it are padding) and the table pointer is
- * 128-byte aligned.  Levels with local[l] == 0 keep the TCNN rule. */
+ * 128-byte aligned.  Levels with local[l] == 0 keep the TCNN rule.
+ * LINE_OVERLAP (ABI 11): LINE_LOCAL whose 16-byte x runs overlap by one vertex, so that the x corner pair of a cell is ONE request:
+ * the pair of CELL gx lives in run gx / 3 of its row at positions gx % 3 and gx % 3 + 1 -- the LINE_LOCAL rule applied to the storage
+ * coordinate X = gx + gx / 3 (first corner) and X + 1 (second corner).  Position 3 of a run repeats position 0 of the next run of
+ * the same super-block row: the owner of the table keeps the two entries equal (perf_amd.grid.GridConfig.canonicalize_).  The LAST
+ * cell of a super-block row (X % 2^sb_shift[0] == 2^sb_shift[0] - 2) takes its second corner from storage coordinate X + 2 -- the
+ * first vertex of the next super-block -- so no vertex is stored in two super-blocks (hashed super-blocks could not keep such
+ * copies equal).  A super-block row holds 3 * 2^(sb_shift[0] - 2) cells: nsx[l] counts such rows; a hashed level's 2^T entries hold
+ * 3/4 as many distinct vertices.  A cell's eight corners lie in (1 + 1/4)(1 + 1/2) = 1.9 lines instead of 2.3. */
 #define PERF_LAYOUT_TCNN 0
 #define PERF_LAYOUT_LINE_LOCAL 1
+#define PERF_LAYOUT_LINE_OVERLAP 2
 
 /* Geometry of a multiresolution hash grid (tcnn "HashGrid", 3 input dims, 2 features/level).
  * Entry e of level l lives at table[(offset[l] + e) * 2 + f].  Levels with hashed[l]==0 are
@@ -88,8 +97,8 @@ typedef struct perf_grid_desc {
     uint64_t offset[PERF_MAX_LEVELS];   /* 64-bit: tables beyond 2^32 entries (BASELINE config 5) */
     uint32_t hashed[PERF_MAX_LEVELS];
     int32_t layout;                /* PERF_LAYOUT_* */
-    uint32_t sb_shift[3];          /* LINE_LOCAL: log2 vertices of a super-block along x, y (>= 2) and z (>= 1) */
-    uint32_t local[PERF_MAX_LEVELS];    /* LINE_LOCAL: level stored line-local */
+    uint32_t sb_shift[3];          /* LINE_LOCAL / LINE_OVERLAP: log2 vertices (x: storage positions) of a super-block along x, y (>= 2) and z (>= 1) */
+    uint32_t local[PERF_MAX_LEVELS];    /* LINE_LOCAL / LINE_OVERLAP: level stored line-local */
     uint32_t nsx[PERF_MAX_LEVELS];      /* dense line-local levels: super-blocks per row ... */
     uint32_t nsxy[PERF_MAX_LEVELS];     /* ... and per z-slice */
 } perf_grid_desc;

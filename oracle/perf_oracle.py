@@ -108,7 +108,7 @@ class GridLevels:
     offset: np.ndarray     # u32 [L]  first entry of the level
     hashed: np.ndarray     # bool [L]
     total: int             # entries in all levels
-    layout: str = 'tcnn'   # 'tcnn' | 'line_local' (see grid_levels)
+    layout: str = 'tcnn'   # 'tcnn' | 'line_local' | 'line_overlap' (see grid_levels)
     sb_shift: tuple = (5, 6, 8)
     local: np.ndarray = None   # bool [L]  level stored line-local
     nsx: np.ndarray = None     # u32 [L]   dense line-local levels: super-blocks per row
@@ -120,10 +120,11 @@ class GridLevels:
 
 
 LOCAL_MIN_RES = 64          # line_local grids: levels of at least this resolution are stored line-local (default)
+SB_SHIFT = {'tcnn': (5, 6, 8), 'line_local': (5, 6, 8), 'line_overlap': (7, 5, 7)}       # default super-block shapes (perf_amd.grid.SB_SHIFT)
 
 
 def grid_levels(n_levels=16, n_feat=2, log2_hashmap_size=18, base_resolution=16,
-                per_level_scale=1.4472692012786865, layout='tcnn', sb_shift=(5, 6, 8), local_min_res=LOCAL_MIN_RES) -> GridLevels:
+                per_level_scale=1.4472692012786865, layout='tcnn', sb_shift=None, local_min_res=LOCAL_MIN_RES) -> GridLevels:
     """Per-level geometry of a tcnn HashGrid (A.1): scale_l = N_min*b^l - 1 (fp32),
     res_l = ceil(scale_l)+1, size_l = min(align8(res_l^3), 2^T), offsets = prefix sums.
 
@@ -135,8 +136,17 @@ def grid_levels(n_levels=16, n_feat=2, log2_hashmap_size=18, base_resolution=16,
     dimension fit 2^T entries) or through tcnn's prime-XOR hash OF THE SUPER-BLOCK COORDINATES modulo the number of
     super-blocks in 2^T entries.  A sample's eight corners then lie in (1+1/4)(1+1/4)(1+1/2) = 2.3 lines of ONE page instead
     of four lines on four pages.  A line-local level starts at a multiple of the super-block size (the entries between the levels
-    are padding).  Coarser levels keep tcnn's rule.  Same scale / res / interpolation as tcnn's grid."""
-    assert layout in ('tcnn', 'line_local')
+    are padding).  Coarser levels keep tcnn's rule.  Same scale / res / interpolation as tcnn's grid.
+
+    layout='line_overlap': line_local whose 16-byte x runs OVERLAP by one vertex, so that the x corner pair of a cell never straddles
+    two runs: the pair of CELL gx lives in run gx // 3 of its row at positions gx % 3, gx % 3 + 1 -- storage coordinates
+    X = gx + gx // 3 and X + 1 of the line_local rule.  Position 3 of a run repeats position 0 of the next run of the same
+    super-block (whoever writes the table keeps the two equal: canonical_overlap_fill); the last cell of a super-block row takes its
+    second corner from the NEXT super-block's first run (storage X + 2), so no vertex is stored in two super-blocks.  A sample's
+    eight corners lie in (1+1/4)(1+1/2) = 1.9 lines; a super-block row holds 3/4 as many cells (hashed levels: 3/4 as many distinct
+    vertices in the same 2^T entries; dense levels grow by up to 4/3)."""
+    assert layout in ('tcnn', 'line_local', 'line_overlap')
+    sb_shift = tuple(SB_SHIFT[layout] if sb_shift is None else sb_shift)
     per_sb = 1 << sum(sb_shift)
     log2_b = F32(np.log2(F32(per_level_scale)))
     scale = np.zeros(n_levels, F32)
@@ -152,11 +162,13 @@ def grid_levels(n_levels=16, n_feat=2, log2_hashmap_size=18, base_resolution=16,
         e = F32(np.exp2(np.float64(F32(l) * log2_b)))
         s = F32(F32(e * F32(base_resolution)) - F32(1.0))
         r = int(math.ceil(float(s))) + 1
-        if layout == 'line_local' and r >= local_min_res:
+        if layout != 'tcnn' and r >= local_min_res:
             nd = [(r + (1 << sh)) >> sh for sh in sb_shift]          # super-blocks per dimension: vertices 0..res
+            if layout == 'line_overlap':                             # cells 0..res-1 at storage x = gx + gx // 3 (+ 2 for a row's last cell)
+                nd[0] = (((r - 1) + (r - 1) // 3 + 2) >> sb_shift[0]) + 1
             full = nd[0] * nd[1] * nd[2] * per_sb
             n = min(full, 1 << log2_hashmap_size)
-            assert n >= per_sb, 'line_local: 2^log2_hashmap_size must hold at least one super-block'
+            assert n >= per_sb, f'{layout}: 2^log2_hashmap_size must hold at least one super-block'
             local[l], nsx[l], nsxy[l] = True, nd[0], nd[0] * nd[1]
             total = -(-total // per_sb) * per_sb             # the level starts on a super-block boundary (its 128-byte blocks are cache lines)
         else:
@@ -218,6 +230,10 @@ def grid_corner_indices(x: np.ndarray, lv: GridLevels, level: int):
         if lv.local is not None and lv.local[level]:
             shx, shy, shz = lv.sb_shift
             per_sb = 1 << (shx + shy + shz)
+            if lv.layout == 'line_overlap':                          # storage x of the CELL's corner (see grid_levels)
+                x0 = gi[:, 0] + gi[:, 0] // 3
+                m = (1 << shx) - 1
+                cx = (x0 if (c & 1) == 0 else np.where((x0 & m) == m - 1, x0 + 2, x0 + 1)) & U32_MASK
             sx, sy, sz = cx >> shx, cy >> shy, cz >> shz
             if lv.hashed[level]:
                 slot = (sx ^ ((sy * PRIME_Y) & U32_MASK) ^ ((sz * PRIME_Z) & U32_MASK)) % (n // per_sb)
@@ -233,6 +249,23 @@ def grid_corner_indices(x: np.ndarray, lv: GridLevels, level: int):
             h = (cx + cy * r + cz * r * r) & U32_MASK
         idx[:, c] = (h % n).astype(np.uint32)
     return idx, frac
+
+
+def canonical_overlap_fill(table: np.ndarray, lv: GridLevels) -> np.ndarray:
+    """layout='line_overlap': make a table [total, F] a valid one -- position 3 of every 16-byte x run := position 0 of the next run
+    of the same super-block row (the two entries are ONE vertex); the last run of a row keeps its (never read) last entry.
+    Restated by perf_amd.fields.canonical_overlap_fill_ on the device."""
+    assert lv.layout == 'line_overlap'
+    out = np.array(table, copy=True)
+    shx = lv.sb_shift[0]
+    runs = 1 << (shx - 2)                                            # x runs (= blocks along x) of a super-block row
+    for l in range(lv.n_levels):
+        if not lv.local[l]:
+            continue
+        lo, n = int(lv.offset[l]), int(lv.size[l])
+        v = out[lo:lo + n].reshape(n // (32 * runs), runs, 8, 4, -1)  # [row of blocks, block along x, (y, z) of the block, x in run, F]
+        v[:, :-1, :, 3] = v[:, 1:, :, 0]
+    return out
 
 
 def hashgrid_encode(x: torch.Tensor, table: torch.Tensor, lv: GridLevels,

@@ -10,12 +10,12 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libperf_hip.so')
 
-ABI_VERSION = 10         # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
+ABI_VERSION = 11         # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
 MAX_LEVELS = 24
 DTYPE_BF16, DTYPE_FP16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
 INTERP_LINEAR, INTERP_SMOOTHSTEP = 0, 1
-LAYOUT_TCNN, LAYOUT_LINE_LOCAL = 0, 1
+LAYOUT_TCNN, LAYOUT_LINE_LOCAL, LAYOUT_LINE_OVERLAP = 0, 1, 2
 LATTICE = {'single': 0, 'repeated': 1, None: 1}          # PERF_LATTICE_*; None = the default
 DEFAULT_LATTICE = 'repeated'                 # t_{k+1} = fl(t_k + step): how nerfacc's traverse_grids is understood to march (include/perf_hip.h)
 

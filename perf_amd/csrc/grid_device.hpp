@@ -18,6 +18,7 @@ struct GridParams {
 // the line-local part of a descriptor (PERF_LAYOUT_LINE_LOCAL), handed to the kernels that understand it beside GridParams
 struct GridLocal {
     uint32_t any;                       // 1: some level is line-local
+    uint32_t ovl;                       // 1: PERF_LAYOUT_LINE_OVERLAP (the x runs of a line-local level overlap by one vertex)
     uint32_t shx, shy, shz;
     uint32_t local[PERF_MAX_LEVELS];
     uint32_t nsx[PERF_MAX_LEVELS];
@@ -29,13 +30,14 @@ struct GridLocal {
 static int fill_params(const perf_grid_desc* g, GridParams* p, GridLocal* loc = nullptr) {
     PERF_REQUIRE(g != nullptr, "grid desc is NULL");
     PERF_REQUIRE(g->n_levels >= 1 && g->n_levels <= PERF_MAX_LEVELS, "n_levels %d out of range", g->n_levels);
-    PERF_REQUIRE(g->layout == PERF_LAYOUT_TCNN || g->layout == PERF_LAYOUT_LINE_LOCAL, "unknown table layout %d", (int)g->layout);
+    PERF_REQUIRE(g->layout == PERF_LAYOUT_TCNN || g->layout == PERF_LAYOUT_LINE_LOCAL || g->layout == PERF_LAYOUT_LINE_OVERLAP, "unknown table layout %d", (int)g->layout);
     PERF_REQUIRE(g->layout == PERF_LAYOUT_TCNN || loc != nullptr,
-                 "this entry point takes tcnn-layout grids only (PERF_LAYOUT_LINE_LOCAL is inference only: perf_hashgrid_fwd, perf_hashgrid_corners, perf_field_infer)");
+                 "this entry point takes tcnn-layout grids only (PERF_LAYOUT_LINE_LOCAL / _OVERLAP are inference only: perf_hashgrid_fwd, perf_hashgrid_corners, perf_field_infer)");
     if (loc) {
-        loc->any = 0; loc->shx = loc->shy = 2; loc->shz = 1;
+        loc->any = 0; loc->ovl = 0; loc->shx = loc->shy = 2; loc->shz = 1;
         for (int l = 0; l < PERF_MAX_LEVELS; ++l) loc->local[l] = loc->nsx[l] = loc->nsxy[l] = 0;
-        if (g->layout == PERF_LAYOUT_LINE_LOCAL) {
+        if (g->layout != PERF_LAYOUT_TCNN) {
+            loc->ovl = g->layout == PERF_LAYOUT_LINE_OVERLAP ? 1u : 0u;
             loc->shx = g->sb_shift[0]; loc->shy = g->sb_shift[1]; loc->shz = g->sb_shift[2];
             PERF_REQUIRE(loc->shx >= 2 && loc->shy >= 2 && loc->shz >= 1 && loc->shx + loc->shy + loc->shz <= 24, "bad super-block shape");
             const uint32_t per_sb = 1u << (loc->shx + loc->shy + loc->shz);
@@ -56,7 +58,7 @@ static int fill_params(const perf_grid_desc* g, GridParams* p, GridLocal* loc = 
         p->offset[l] = g->offset[l]; p->hashed[l] = g->hashed[l];
         if (l < g->n_levels) {
             PERF_REQUIRE(g->size[l] > 0, "level %d has size 0", l);
-            if (g->hashed[l] && !(g->layout == PERF_LAYOUT_LINE_LOCAL && g->local[l]))
+            if (g->hashed[l] && !(g->layout != PERF_LAYOUT_TCNN && g->local[l]))
                 PERF_REQUIRE((g->size[l] & (g->size[l] - 1)) == 0, "hashed level %d size %u is not a power of two", l, g->size[l]);
         }
     }
@@ -121,6 +123,17 @@ __device__ __forceinline__ uint32_t local_vertex_index(const GridLocal& gl, int 
     return (slot << sh) + (blk << 5) + (vx & 3u) + ((vy & 3u) << 2) + ((vz & 1u) << 4);
 }
 
+// ---- PERF_LAYOUT_LINE_OVERLAP: the 16-byte x runs of a line-local level overlap by one vertex.  The x corner pair of CELL gx lives
+// in ONE run -- run gx / 3 of its row, positions gx % 3 and gx % 3 + 1 -- i.e. at the storage coordinates X = gx + gx / 3 and X + 1 of
+// the line-local rule above; a run's last entry repeats the next run's first (the owner of the table keeps the two equal), except in
+// the last run of a super-block row: its last cell takes its second corner from the next super-block's first run (storage X + 2), so
+// that no vertex is ever stored in two super-blocks (hashed super-blocks could not keep such copies equal).
+__device__ __forceinline__ uint32_t overlap_x(uint32_t gx) { return gx + gx / 3u; }
+__device__ __forceinline__ uint32_t overlap_x1(const GridLocal& gl, uint32_t X0) {
+    const uint32_t m = (1u << gl.shx) - 1u;
+    return (X0 & m) == m - 1u ? X0 + 2u : X0 + 1u;
+}
+
 // corners_of for either layout
 __device__ __forceinline__ Corners corners_of_any(const GridParams& gp, const GridLocal& gl, int l, float x, float y, float z) {
     if (!gl.local[l]) return corners_of(x, y, z, gp.scale[l], gp.res[l], gp.size[l], gp.hashed[l] != 0);
@@ -131,8 +144,9 @@ __device__ __forceinline__ Corners corners_of_any(const GridParams& gp, const Gr
     c.f[0] = px - flx; c.f[1] = py - fly; c.f[2] = pz - flz;
     const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
     c.cell[0] = gx; c.cell[1] = gy; c.cell[2] = gz;
+    const uint32_t X0 = gl.ovl ? overlap_x(gx) : gx, X1 = gl.ovl ? overlap_x1(gl, X0) : gx + 1u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) c.idx[k] = local_vertex_index(gl, l, gp.size[l], gp.hashed[l] != 0, gx + (uint32_t)(k & 1), gy + (uint32_t)((k >> 1) & 1), gz + (uint32_t)(k >> 2));
+    for (int k = 0; k < 8; ++k) c.idx[k] = local_vertex_index(gl, l, gp.size[l], gp.hashed[l] != 0, (k & 1) ? X1 : X0, gy + (uint32_t)((k >> 1) & 1), gz + (uint32_t)(k >> 2));
     return c;
 }
 

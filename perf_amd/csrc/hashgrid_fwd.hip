@@ -311,7 +311,7 @@ template <int K> struct QuadStep {
 };
 template <> struct QuadStep<0> { template <typename F> static __device__ __forceinline__ void run(F&&) {} };
 
-template <typename T16, int STEPS>
+template <typename T16, int STEPS, bool OVL>
 __global__ __launch_bounds__(256) void hashgrid_fwd_big_local_kernel(GridParams gp, GridLocal gl, BigLevels lv, const float* __restrict__ x01,
                                                                      const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
                                                                      int64_t n, const int64_t* __restrict__ n_dev, int64_t grid_stripes, int bpt) {
@@ -327,6 +327,11 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_local_kernel(GridParams 
     const float sc = gp.scale[l];
     const uint32_t size = gp.size[l];
     const bool hashed = gp.hashed[l] != 0;
+    // local_vertex_index() with a lane's (y, z) part formed once per group and ONE pair of 32-bit multiplies whichever way the super-block is
+    // addressed: multipliers, masks and the combining rule are uniform over the level
+    const uint32_t sb_sh = gl.shx + gl.shy + gl.shz;
+    const uint32_t mul_y = hashed ? kPrimeY : gl.nsx[l], mul_z = hashed ? kPrimeZ : gl.nsxy[l], slot_mask = (size >> sb_sh) - 1u;
+    const uint32_t mkx = (1u << (gl.shx - 2)) - 1u, mky = (1u << (gl.shy - 2)) - 1u, mkz = (1u << (gl.shz - 1)) - 1u;
     for (int64_t Q = w.q0; Q * stripe < n_live; Q += grid_stripes) {
         const int64_t base = (((Q << 3) + ((w.xcd - l) & 7)) * bpt + w.sub) * kGroup + (int64_t)wave * (64 * STEPS);
         if (base >= n_live) continue;                                // (wave-uniform)
@@ -344,8 +349,13 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_local_kernel(GridParams 
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
             if (64u * step >= left) break;                            // (wave-uniform)
-            uint4 q[4];
-            uint32_t e[4] = {0u, 0u, 0u, 0u}, lxp = 0u;               // (lxp: the four groups' x positions inside their runs, two bits each)
+            // the requests of the four groups: plain line-local levels, the ALIGNED 16-byte run that holds the pair's first vertex (+ a 4-byte
+            // gather of the second one when the cell starts at the run's last vertex: a quarter of the samples); overlapping runs, exactly
+            // the pair -- 8 bytes, 4-byte aligned, never across a run (+ the gather for the last cell of a super-block row: 1 in 24):
+            // 56 registers instead of 70 (eight waves per SIMD instead of seven), half the bytes returned per request
+            uint4 q[OVL ? 1 : 4];
+            uint2_a4 q2[OVL ? 4 : 1];
+            uint32_t e[4] = {0u, 0u, 0u, 0u}, lxp = 0u;               // (lxp, two bits per group: position of the first vertex in its run; OVL: 1 = second corner in e)
             float w0s[4], w1s[4];
             QuadStep<4>::run([&](auto itc) {
                 constexpr int it = decltype(itc)::value;
@@ -355,11 +365,27 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_local_kernel(GridParams 
                 float fx = px - flx, fy = py - fly, fz = pz - flz;
                 const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
                 const uint32_t vy = gy + (r & 1u), vz = gz + (r >> 1);
-                lxp |= (gx & 3u) << (2 * it);
                 // (a level holds at most 2^30 entries: 32-bit BYTE offsets from the wave-uniform level base, one address register per request)
                 const char* tb = reinterpret_cast<const char*>(tl);
-                q[it] = *reinterpret_cast<const uint4*>(tb + (local_vertex_index(gl, l, size, hashed, gx & ~3u, vy, vz) << 2));   // (16-byte aligned by construction)
-                if ((gx & 3u) == 3u) e[it] = *reinterpret_cast<const uint32_t*>(tb + (local_vertex_index(gl, l, size, hashed, gx + 1u, vy, vz) << 2));
+                const uint32_t ya = (vy >> gl.shy) * mul_y, zb = (vz >> gl.shz) * mul_z;
+                const uint32_t yz_in = (((vy >> 2) & mky) << (gl.shx - 2)) + (((vz >> 1) & mkz) << (gl.shx - 2 + gl.shy - 2));
+                const uint32_t in_blk = ((vy & 3u) << 2) + ((vz & 1u) << 4);
+                auto entry = [&](uint32_t X) {                        // entry of storage vertex (X, vy, vz): local_vertex_index(gl, l, size, hashed, X, vy, vz)
+                    const uint32_t sx = X >> gl.shx;
+                    const uint32_t slot = hashed ? ((sx ^ ya ^ zb) & slot_mask) : (sx + ya + zb);
+                    return (slot << sb_sh) + ((((X >> 2) & mkx) + yz_in) << 5) + (X & 3u) + in_blk;
+                };
+                if constexpr (OVL) {
+                    const uint32_t X = overlap_x(gx), sbm = (1u << gl.shx) - 1u;
+                    const bool edge = (X & sbm) == sbm - 1u;         // the last cell of a super-block row: second corner = the next super-block's first vertex
+                    lxp |= (edge ? 1u : 0u) << (2 * it);
+                    q2[it] = *reinterpret_cast<const uint2_a4*>(tb + (entry(X) << 2));
+                    if (edge) e[it] = *reinterpret_cast<const uint32_t*>(tb + (entry(X + 2u) << 2));
+                } else {
+                    lxp |= (gx & 3u) << (2 * it);
+                    q[it] = *reinterpret_cast<const uint4*>(tb + (entry(gx & ~3u) << 2));   // (16-byte aligned by construction)
+                    if ((gx & 3u) == 3u) e[it] = *reinterpret_cast<const uint32_t*>(tb + (entry(gx + 1u) << 2));
+                }
                 if (smooth) {
                     fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz);
                 }
@@ -375,8 +401,14 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_local_kernel(GridParams 
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const uint32_t lx = (lxp >> (2 * it)) & 3u;
-                const uint32_t a0 = lx == 0u ? q[it].x : (lx == 1u ? q[it].y : (lx == 2u ? q[it].z : q[it].w));
-                const uint32_t a1 = lx == 0u ? q[it].y : (lx == 1u ? q[it].z : (lx == 2u ? q[it].w : e[it]));
+                uint32_t a0, a1;
+                if constexpr (OVL) {
+                    a0 = q2[it].x;
+                    a1 = lx ? e[it] : q2[it].y;
+                } else {
+                    a0 = lx == 0u ? q[it].x : (lx == 1u ? q[it].y : (lx == 2u ? q[it].z : q[it].w));
+                    a1 = lx == 0u ? q[it].y : (lx == 1u ? q[it].z : (lx == 2u ? q[it].w : e[it]));
+                }
                 const float p0 = quad_sum(fmaf(w1s[it], T16::lo(a1), w0s[it] * T16::lo(a0)));     // ... then the sample's four lanes
                 const float p1 = quad_sum(fmaf(w1s[it], T16::hi(a1), w0s[it] * T16::hi(a0)));
                 if ((int)r == it) mine = T16::pack(p0, p1);          // (all four lanes hold the same sums: lane r keeps group r's)
@@ -410,9 +442,15 @@ static void launch_big(const GridParams& gp, const GridLocal& gl, const float* x
     gather.order = local.order = local.count ? 0 : 1;
     gather.stripes = local.stripes = stripes;
     // (line-local levels first: the long launch; the few coarse levels' gathers find the coordinates in the caches)
-    if (local.count)
-        hipLaunchKernelGGL((hashgrid_fwd_big_local_kernel<T16, kBigSteps>), dim3((unsigned)(stripes * local.count * 8 * kBigTurnGroups)), dim3(256), 0, as_stream(stream),
-                           gp, gl, local, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes, kBigTurnGroups);
+    if (local.count) {
+        const dim3 g((unsigned)(stripes * local.count * 8 * kBigTurnGroups));
+        if (gl.ovl)
+            hipLaunchKernelGGL((hashgrid_fwd_big_local_kernel<T16, kBigSteps, true>), g, dim3(256), 0, as_stream(stream),
+                               gp, gl, local, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes, kBigTurnGroups);
+        else
+            hipLaunchKernelGGL((hashgrid_fwd_big_local_kernel<T16, kBigSteps, false>), g, dim3(256), 0, as_stream(stream),
+                               gp, gl, local, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes, kBigTurnGroups);
+    }
     if (!gather.count) return;
     // tables beyond the caches in tcnn's layout (no line-local level) are served best by waves of ONE step -- measured at T = 2^28 with
     // every level in tcnn's layout: 1.50 ms at one step, 1.58 at four, 1.87 at eight -- over the same turns; the coarse, cache-resident

@@ -146,7 +146,7 @@ class InferenceNeRF:
                  table_scale=1e-4, density_bias=0.0, device=None, layout='tcnn', **layout_kw):
         """table_scale / density_bias (tests): tables U(-table_scale, table_scale) and sigma = exp(y + density_bias) instead of the
         fresh initialisation's near-constant sigma = exp(y ~ 0) -- a field with structure, dense enough for rays to terminate.
-        layout: 'tcnn' (default) or the opt-in 'line_local' table layout of perf_amd.grid.GridConfig -- these fields exist for grids
+        layout: 'tcnn' (default) or the opt-in 'line_local' / 'line_overlap' table layouts of perf_amd.grid.GridConfig -- these fields exist for grids
         the reference never defines, no reference result constrains how their tables are laid out."""
         from .grid import GridConfig, MlpConfig
         import math
@@ -173,6 +173,7 @@ class InferenceNeRF:
             for lo in range(n_net, w16.numel(), chunk):
                 hi = min(lo + chunk, w16.numel())
                 w16[lo:hi].copy_((torch.rand(hi - lo, device=dev, generator=gen) * 2 - 1) * table_scale)
+            self.grid.canonicalize_(w16[n_net:])          # (line_overlap: the two copies of a run's shared vertex hold one value)
             self.nets[name] = (mlp, w16)
 
     def eval(self):

@@ -14,6 +14,9 @@ from . import _lib
 
 _F = np.float32
 LOCAL_MIN_RES = 64          # line_local grids: levels of at least this resolution are stored line-local (default)
+# default super-block shapes (log2 vertices along x, y, z; 2 MiB each), by measurement on BASELINE config 5's panorama: z-deep for the rays
+# near the poles; with overlapping runs x-wide as well (the last cell of a super-block row still needs a second request: 1 cell in 96)
+SB_SHIFT = {'tcnn': (5, 6, 8), 'line_local': (5, 6, 8), 'line_overlap': (7, 5, 7)}
 
 
 @dataclass
@@ -28,9 +31,11 @@ class GridConfig:
     # every grid the reference defines.  'line_local' (opt-in, inference only; BASELINE config 5's L = 20 tables sized to HBM, for
     # which no reference result exists): levels with res >= local_min_res store a 4 x 4 x 2 block of vertices as one 128-byte
     # line, the blocks of a 2^sb_shift-vertex super-block (default 32 x 64 x 256 = 2 MiB) contiguously, and hash (or densely
-    # index) the SUPER-BLOCK: a sample's eight corners lie in ~2.3 lines of one page.  include/perf_hip.h PERF_LAYOUT_*.
+    # index) the SUPER-BLOCK: a sample's eight corners lie in ~2.3 lines of one page.  'line_overlap': line_local whose 16-byte x
+    # runs overlap by one vertex (a cell's x corner pair never straddles two runs: ~1.9 lines per sample and level, one request
+    # per (y, z) corner pair; a super-block row holds 3/4 as many cells; see canonicalize_).  include/perf_hip.h PERF_LAYOUT_*.
     layout: str = 'tcnn'
-    sb_shift: tuple = (5, 6, 8)
+    sb_shift: tuple = None              # default: SB_SHIFT[layout]
     local_min_res: int = LOCAL_MIN_RES
     scale: np.ndarray = field(init=False, repr=False)
     res: np.ndarray = field(init=False, repr=False)
@@ -59,9 +64,9 @@ class GridConfig:
         self.local = np.zeros(L, np.uint32)
         self.nsx = np.zeros(L, np.uint32)
         self.nsxy = np.zeros(L, np.uint32)
-        if self.layout not in ('tcnn', 'line_local'):
+        if self.layout not in ('tcnn', 'line_local', 'line_overlap'):
             raise ValueError(f'unsupported table layout {self.layout!r}')
-        self.sb_shift = tuple(int(v) for v in self.sb_shift)
+        self.sb_shift = tuple(int(v) for v in (self.sb_shift if self.sb_shift is not None else SB_SHIFT[self.layout]))
         if len(self.sb_shift) != 3 or self.sb_shift[0] < 2 or self.sb_shift[1] < 2 or self.sb_shift[2] < 1 or sum(self.sb_shift) > 24:
             raise ValueError(f'sb_shift {self.sb_shift}: a super-block holds at least one 4 x 4 x 2 block and at most 2^24 entries')
         per_sb = 1 << sum(self.sb_shift)
@@ -70,12 +75,16 @@ class GridConfig:
             growth = _F(np.exp2(np.float64(_F(l) * log2_b)))
             s = _F(_F(growth * _F(self.base_resolution)) - _F(1.0))
             r = int(math.ceil(float(s))) + 1
-            if self.layout == 'line_local' and r >= self.local_min_res:
+            if self.layout != 'tcnn' and r >= self.local_min_res:
                 nd = [(r + (1 << sh)) >> sh for sh in self.sb_shift]          # super-blocks per dimension (vertices 0..res)
+                if self.layout == 'line_overlap':
+                    # x runs overlap by one vertex: cell gx sits at storage coordinate gx + gx // 3 (a super-block row holds 3/4 as many cells);
+                    # the last cell (res - 1) may take its second corner from storage coordinate + 2
+                    nd[0] = (((r - 1) + (r - 1) // 3 + 2) >> self.sb_shift[0]) + 1
                 cells = nd[0] * nd[1] * nd[2] * per_sb
                 n = min(cells, 1 << self.log2_hashmap_size)
                 if n < per_sb:
-                    raise ValueError(f'line_local: 2^{self.log2_hashmap_size} entries hold no {self.sb_shift} super-block')
+                    raise ValueError(f'{self.layout}: 2^{self.log2_hashmap_size} entries hold no {self.sb_shift} super-block')
                 self.local[l], self.nsx[l], self.nsxy[l] = 1, nd[0], nd[0] * nd[1]
                 total = -(-total // per_sb) * per_sb         # a line-local level starts on a super-block boundary: its 128-byte blocks are cache lines
             else:
@@ -108,6 +117,22 @@ class GridConfig:
     def n_output_dims(self) -> int:
         return self.n_levels * 2
 
+    def canonicalize_(self, table):
+        """layout='line_overlap': make `table` (a tensor of total * 2 features, any dtype / device, modified in place) a VALID table --
+        position 3 of every 16-byte x run := position 0 of the next run of the same super-block row (the two entries hold ONE vertex;
+        oracle/perf_oracle.py:canonical_overlap_fill).  Whoever writes such a table calls this afterwards; other layouts: no-op."""
+        if self.layout != 'line_overlap':
+            return table
+        runs = 1 << (self.sb_shift[0] - 2)
+        flat = table.view(-1)
+        for l in range(self.n_levels):
+            if not self.local[l]:
+                continue
+            lo, n = int(self.offset[l]) * 2, int(self.size[l]) * 2
+            v = flat[lo:lo + n].view(n // (64 * runs), runs, 8, 4, 2)     # [row of blocks, block along x, (y, z) in block, x in run, feature]
+            v[:, :-1, :, 3].copy_(v[:, 1:, :, 0].clone())
+        return table
+
     def desc(self) -> '_lib.GridDesc':
         """The C-ABI descriptor (perf_grid_desc).  Built once per configuration: filling the ctypes arrays costs ~30 us of host
         time, and an eager step passes it to half a dozen entry points (the library only reads it)."""
@@ -122,7 +147,7 @@ class GridConfig:
             d.scale[l] = float(self.scale[l]); d.res[l] = int(self.res[l]); d.size[l] = int(self.size[l])
             d.offset[l] = int(self.offset[l]); d.hashed[l] = int(self.hashed[l])
             d.local[l] = int(self.local[l]); d.nsx[l] = int(self.nsx[l]); d.nsxy[l] = int(self.nsxy[l])
-        d.layout = _lib.LAYOUT_LINE_LOCAL if self.layout == 'line_local' else _lib.LAYOUT_TCNN
+        d.layout = {'tcnn': _lib.LAYOUT_TCNN, 'line_local': _lib.LAYOUT_LINE_LOCAL, 'line_overlap': _lib.LAYOUT_LINE_OVERLAP}[self.layout]
         for k in range(3):
             d.sb_shift[k] = self.sb_shift[k]
         self.__dict__['_desc'] = (key, d)

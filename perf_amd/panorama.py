@@ -161,6 +161,7 @@ def render_panorama_block(log2_t, rows_per_batch=4, spp=SPP5, height=H5, width=W
                                                                                             '(%d x %d-pixel tiles)' % tile) + ', fresh initialisation (nothing pruned), device-side counts',
            'log2_hashmap_size': log2_t, 'table_layout': layout, 'batch_shape': 'strip' if tile is None else list(tile), 'ray_order': ray_order if tile is not None else 'row', 'table_GiB_per_encoder': round(nerf.table_bytes() / 2 ** 30, 2),
            'table_entries': int(nerf.grid.total), 'offsets_exceed_32_bit': bool(nerf.grid.n_params >= 2 ** 32),
+           'distinct_vertices_per_entry_of_hashed_levels': 0.75 if layout == 'line_overlap' else 1.0,      # (overlapping x runs: 24 vertices in 32 entries)
            'build_seconds': round(t_build, 3), 'seconds_per_panorama': round(el, 4), 'rays_per_s': height * width / el,
            'ray_samples_per_s': kept / el, 'marched_samples': marched, 'kept_samples': kept,
            'output_checksum': {k: float(v.double().sum()) for k, v in outs.items()},

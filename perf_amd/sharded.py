@@ -78,7 +78,7 @@ class GridSlice:
             d.scale[k] = float(self.full.scale[l]); d.res[k] = int(self.full.res[l]); d.size[k] = int(self.full.size[l])
             d.offset[k] = int(self.offset[k]); d.hashed[k] = int(self.full.hashed[l])
             d.local[k] = int(self.full.local[l]); d.nsx[k] = int(self.full.nsx[l]); d.nsxy[k] = int(self.full.nsxy[l])
-        d.layout = _lib.LAYOUT_LINE_LOCAL if self.full.layout == 'line_local' else _lib.LAYOUT_TCNN       # (a level keeps its layout on its rank)
+        d.layout = {'tcnn': _lib.LAYOUT_TCNN, 'line_local': _lib.LAYOUT_LINE_LOCAL, 'line_overlap': _lib.LAYOUT_LINE_OVERLAP}[self.full.layout]   # (a level keeps its layout on its rank)
         for k in range(3):
             d.sb_shift[k] = int(self.full.sb_shift[k])
         self._desc = d

@@ -3,7 +3,7 @@
 L = 20 hash grids -- rendered by every rank through the LEVEL-SHARDED fields (tables cut by level over the ranks, positions
 all-gathered, one all-to-all of features per field) and, for comparison, through the unsharded fields on the same rays.
 
-    python -m torch.distributed.run --nproc-per-node 2 ... tests/config5_worker.py <out.pt> <rows_per_rank> <log2_T> [tcnn|line_local]"""
+    python -m torch.distributed.run --nproc-per-node 2 ... tests/config5_worker.py <out.pt> <rows_per_rank> <log2_T> [tcnn|line_local|line_overlap]"""
 import os
 import sys
 

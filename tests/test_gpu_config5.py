@@ -41,7 +41,7 @@ def _check_batch(res, R):
     return n
 
 
-@pytest.mark.parametrize('layout', ['tcnn', 'line_local'])
+@pytest.mark.parametrize('layout', ['tcnn', 'line_local', 'line_overlap'])
 def test_config5_full_panorama_properties(layout):
     """T = 2^28, the whole 4096x2048x256 panorama (2.1e9 marched ray-samples)."""
     from perf_amd import ops
@@ -83,7 +83,7 @@ def test_config5_full_panorama_properties(layout):
         assert torch.equal(again[k], outs[k][r0 * W:(r0 + 16) * W]), k
 
 
-@pytest.mark.parametrize('layout', ['tcnn', 'line_local'])
+@pytest.mark.parametrize('layout', ['tcnn', 'line_local', 'line_overlap'])
 def test_config5_tables_beyond_32_bit_entry_offsets(layout):
     """T = 2^30 (31 GiB per encoder, 8.4e9 entries: 64-bit level offsets in entries, not only in parameters): a band of rows
     around the equator and one at the pole, batch-size independence, bounds."""

@@ -254,7 +254,7 @@ def test_level_sharded_encode_matches_the_unsharded_kernel(tmp_path, n_levels, l
     assert sorted(a[0] + a[1]) == list(range(n_levels)) and abs(len(a[0]) - len(a[1])) <= 1
 
 
-@pytest.mark.parametrize('world,log2_t,rows,layout', [(2, 20, 2, 'tcnn'), (4, 22, 1, 'tcnn'), (2, 21, 2, 'line_local')])
+@pytest.mark.parametrize('world,log2_t,rows,layout', [(2, 20, 2, 'tcnn'), (4, 22, 1, 'tcnn'), (2, 21, 2, 'line_local'), (2, 21, 2, 'line_overlap')])
 def test_config5_row_shard_through_the_level_sharded_path(tmp_path, world, log2_t, rows, layout):
     """BASELINE config 5's inference batch at its stated shape -- rows of a 4096x2048 panorama, 256 samples per ray, L = 20
     hash grids (T = 2^20 / 2^22 here: the box is shared by all ranks AND the unsharded comparison copies) -- rendered by two

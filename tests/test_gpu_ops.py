@@ -697,20 +697,20 @@ def test_deep_grid_forward_20_levels(ops):
     # (the backward of such a field: test_mlp_more_than_16_levels, test_network_with_20_level_grid_forward_and_gradient)
 
 
-@pytest.mark.parametrize('layout', ['tcnn', 'line_local'])
-@pytest.mark.parametrize('log2_t,sb_shift,min_res', [(15, (2, 2, 1), 16), (20, (3, 3, 2), 64), (24, (5, 6, 8), 64)])
+@pytest.mark.parametrize('layout', ['tcnn', 'line_local', 'line_overlap'])
+@pytest.mark.parametrize('log2_t,sb_shift,min_res', [(15, (2, 2, 1), 16), (20, (3, 3, 2), 64), (24, (5, 6, 8), 64), (24, (7, 5, 7), 64)])
 def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift, min_res):
     """The deep-grid forward kernel (one level per workgroup, XCD-stable balanced; 16-byte x-runs on line-local levels) against
     the oracle -- corner indices bit-exact, features within an ulp of the storage type -- for tcnn's layout and for the opt-in
-    line-local one (oracle/perf_oracle.py:grid_levels), at table sizes where the line-local levels are all hashed (2^15, super-blocks
-    of one block), mixed dense / hashed (2^20) and with the shipped 32 x 64 x 256 super-blocks (2^24); ragged n, points on cell and
+    line-local ones (oracle/perf_oracle.py:grid_levels: 'line_local', and 'line_overlap' whose x runs overlap by one vertex), at table sizes where the line-local levels are all hashed (2^15, super-blocks
+    of one block), mixed dense / hashed (2^20) and with the shipped 32 x 64 x 256 / 128 x 32 x 128 super-blocks (2^24); ragged n, points on cell and
     block boundaries, a device-side live count."""
     L, b = 20, 1.3819
     cfg = _grid_cfg(n_levels=L, log2_hashmap_size=log2_t, base_resolution=16, per_level_scale=b, layout=layout, sb_shift=sb_shift,
                     local_min_res=min_res)
     lv = _lv_of(cfg)
     assert cfg.total == lv.total and np.array_equal(cfg.offset, lv.offset) and np.array_equal(cfg.size, lv.size)
-    if layout == 'line_local':
+    if layout != 'tcnn':
         assert int(cfg.local.sum()) == int((cfg.res >= min_res).sum()) > 0
         assert log2_t == 15 or (int(((cfg.local == 1) & (cfg.hashed == 0)).sum()) > 0 and int(((cfg.local == 1) & (cfg.hashed == 1)).sum()) > 0)
     g = torch.Generator().manual_seed(41 + log2_t)
@@ -720,6 +720,10 @@ def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift, min_res):
     for k, l in enumerate((5, 9, 14, 19)):
         v = torch.randint(0, int(cfg.res[l]) - 1, (40, 3), generator=g).float()
         v[:20, 0] = (v[:20, 0] // 4) * 4 + 3                                   # first vertex = last of its block along x
+        cells_per_row = 3 << (sb_shift[0] - 2)                                  # (line_overlap: the last cell of a super-block row and the cell behind it)
+        v[20:30, 0] = (v[20:30, 0] // cells_per_row) * cells_per_row + cells_per_row - 1
+        v[30:40, 0] = (v[30:40, 0] // cells_per_row) * cells_per_row
+        v[:, 0] = v[:, 0].clamp(0, int(cfg.res[l]) - 2)
         x[100 * k: 100 * k + 40] = ((v - 0.5) / float(cfg.scale[l])).clamp(0.0, 0.999999)
     x[-1] = torch.tensor([0.9999999, 0.9999999, 0.9999999])                      # the last cell of every level
     xd = x.cuda()
@@ -751,22 +755,61 @@ def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift, min_res):
             assert torch.equal(part[:, :live2], feat[:, :live2]), (layout, dt, live2)
         canary = ops.hashgrid_fwd(cfg, xd[:300].contiguous(), t16, n_dev=torch.tensor([0], dtype=torch.int64, device='cuda'))
         assert canary.shape == (L, 300, 2)
-    if layout == 'line_local':
+    if layout != 'tcnn':
         # inference only: the gradient entry points refuse the layout instead of scattering into the wrong entries
         from perf_amd._lib import PerfError
         with pytest.raises(PerfError):
             ops.hashgrid_bwd(cfg, xd, torch.zeros(L, n, 2, device='cuda'))
 
 
-@pytest.mark.parametrize('layout', ['tcnn', 'line_local'])
-@pytest.mark.parametrize('T', [29, 30])
+def test_overlapping_runs_hold_one_field(ops):
+    """layout='line_overlap' stores the vertex two neighbouring x runs share TWICE; GridConfig.canonicalize_ (the oracle's
+    canonical_overlap_fill on the device) makes the copies equal.  The table is then ONE continuous field: points a hair to the left and to
+    the right of every cell face along x -- run boundaries, super-block boundaries, dense and hashed levels alike -- encode to the same
+    features up to the step across the face, as with tcnn's layout; the uncanonical random table jumps by O(1) at every third face."""
+    L, b = 12, 1.3819
+    cfg = _grid_cfg(n_levels=L, log2_hashmap_size=20, base_resolution=16, per_level_scale=b, layout='line_overlap', sb_shift=(3, 3, 2))
+    lv = _lv_of(cfg)
+    assert int(((cfg.local == 1) & (cfg.hashed == 0)).sum()) > 0 and int(((cfg.local == 1) & (cfg.hashed == 1)).sum()) > 0
+    g = torch.Generator().manual_seed(7)
+    raw = (torch.rand(cfg.total, 2, generator=g) * 2 - 1)
+    canon = cfg.canonicalize_(raw.clone().cuda())
+    assert np.array_equal(canon.cpu().numpy(), O.canonical_overlap_fill(raw.numpy(), lv))
+    assert torch.equal(cfg.canonicalize_(canon.clone()), canon)
+    for l in range(L):
+        if not cfg.local[l]:
+            continue
+        sc, r = float(cfg.scale[l]), int(cfg.res[l])
+        n = 4000
+        v = torch.stack([torch.randint(1, r - 1, (n,), generator=g), torch.randint(0, r - 1, (n,), generator=g), torch.randint(0, r - 1, (n,), generator=g)], -1).float()
+        yz = torch.rand(n, 2, generator=g) * 0.8 + 0.1
+        eps = 2e-3                                                     # in cells
+        def pts(dx):
+            p = v.clone(); p[:, 0] += dx; p[:, 1:] += yz
+            return ((p - 0.5) / sc).clamp(0.0, 1.0)
+        xl, xr = pts(-eps), pts(+eps)
+        gl_, gr_ = np.floor(O.grid_pos(xl.numpy(), cfg.scale[l]))[:, 0], np.floor(O.grid_pos(xr.numpy(), cfg.scale[l]))[:, 0]
+        ok = torch.from_numpy((gr_ == gl_ + 1) & (gr_ == v[:, 0].numpy()))          # the two points straddle the face at vertex v
+        assert int(ok.sum()) > 0.9 * n
+        for table, one_field in ((canon, True), (raw.cuda(), False)):
+            fl = ops.hashgrid_fwd(cfg, xl.cuda(), table.half().reshape(-1))[l].float().cpu()
+            fr = ops.hashgrid_fwd(cfg, xr.cuda(), table.half().reshape(-1))[l].float().cpu()
+            jump = (fl - fr).abs().max(-1).values[ok]
+            if one_field:
+                assert float(jump.max()) < 2 * eps * 2 * 2 + 2e-3, (l, float(jump.max()))       # |slope| <= 2 per cell and feature, fp16 storage
+            else:
+                third = (v[:, 0][ok] % 3 == 0)
+                assert float(jump[third].mean()) > 0.1 and float(jump[~third].max()) < 2 * eps * 2 * 2 + 2e-3
+
+
+@pytest.mark.parametrize('layout,T', [('tcnn', 29), ('tcnn', 30), ('line_local', 29), ('line_local', 30), ('line_overlap', 29)])
 def test_table_beyond_32_bit_offsets(ops, layout, T):
     """5.6e9 entries (21 GiB of 2x16-bit features; T = 30: 1.1e10 entries, 41 GiB -- beyond BASELINE config 5's 31 GiB per encoder):
     level offsets exceed 2^32.  The table is filled on the device with a function of the global entry index; the expected
     features of 65,573 points -- half of them uniform in the cube, half consecutive samples along rays from the centre as a panorama
     batch holds them (neighbouring lanes share table lines; the deep-grid kernel's waves take several steps and end inside one) --
     are evaluated on the host from the oracle's corner indices and weights through the same function, so no host copy of the table
-    is needed.  Both table layouts."""
+    is needed.  Every table layout."""
     L, b = 20, 1.5
     cfg = _grid_cfg(n_levels=L, log2_hashmap_size=T, base_resolution=16, per_level_scale=b, layout=layout)
     lv = _lv_of(cfg)

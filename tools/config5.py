@@ -30,7 +30,7 @@ def main():
                          'parameter) at these table sizes: encode, 40->64->1 MLP forward/backward, grid backward, fused Adam')
     ap.add_argument('--pano-log2', type=int, nargs='*', default=[],
                     help="bench.py's `config5` block by itself: the whole panorama through NeRFOCCRenderer.render at these table sizes")
-    ap.add_argument('--layout', default='tcnn', choices=['tcnn', 'line_local'], help='table layout of the --pano-log2 fields (perf_amd.grid.GridConfig)')
+    ap.add_argument('--layout', default='tcnn', choices=['tcnn', 'line_local', 'line_overlap'], help='table layout of the --pano-log2 fields (perf_amd.grid.GridConfig)')
     ap.add_argument('--sb-shift', type=int, nargs=3, default=None, help='line_local: log2 vertices of a super-block along x, y, z')
     ap.add_argument('--local-min-res', type=int, default=None, help='line_local: levels of at least this resolution are stored line-local')
     ap.add_argument('--strips', action='store_true', help='--pano-log2: 4-row strips instead of the default 128 x 128-pixel tiles')

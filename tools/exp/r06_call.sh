@@ -1,14 +1,20 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06ba
+O=$R/gpurun_out/r06bi
 rm -rf $O; mkdir -p $O
 cd $R
-( timeout 1500 python -m pytest tests/test_gpu_config4.py tests/test_gpu_scene.py tests/test_gpu_runner_state.py -m gpu -x -q ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-for i in 1 2; do
-timeout 600 python tools/render_dense.py --poses 300 --batch 524288 > $O/rd_$i.log 2>&1
-python - <<PY
-import json
-t=open('$O/rd_$i.log').read()
-d=json.loads(t[t.rindex('\n{'):] if '\n{' in t else t[t.index('{'):])
-print({k: d[k] for k in d if 'frames_per_s' in k or 'checksum' in k})
-PY
+( timeout 1800 python -m pytest tests/test_gpu_ops.py tests/test_gpu_config5.py tests/test_gpu_dist.py -m gpu -x -q -k "deep_grid or overlapping or beyond_32 or config5" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+cd /tmp && export TMPDIR=/tmp
+for LAY in line_overlap; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $C --output-format csv -d $O/c5_${LAY}_$C -o c -- python $R/tools/config5.py --pano-log2 28 30 --pano-batches 8 --layout $LAY --tile 128 128 > $O/c5_${LAY}_$C.log 2>&1
+  done
 done
+for SET in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum"; do
+  N=$(echo $SET | cut -d' ' -f1)
+  timeout 600 rocprofv3 --pmc $SET --output-format csv -d $O/pmc_$N -o c -- python $R/tools/config5.py --pano-log2 28 --pano-batches 8 --layout line_overlap --tile 128 128 > $O/pmc_$N.log 2>&1
+done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/tools/config5.py --pano-log2 28 --layout line_overlap > $O/kt.log 2>&1
+grep big $O/kt/kt_kernel_stats.csv | sed 's/(perf::GridParams.*)",/ /' | cut -c1-160
+cd $R
+find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete
+du -sh $O
