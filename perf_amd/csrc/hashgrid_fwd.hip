@@ -208,8 +208,8 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
-// The two kinds of level are two kernels (each keeps its own register budget: 7-8 waves per SIMD), launched one after the other
-// over their own lists of levels.
+// The two kinds of level are two device functions with their own launches (a grid of one kind only) and one launch that holds both
+// (hashgrid_fwd_big_mixed_kernel: 59-72 registers).
 struct BigLevels { int32_t count; int32_t order; int64_t stripes; int32_t level[PERF_MAX_LEVELS]; };
 
 // work item of workgroup b: XCD x = b % 8, its turn's sub-group, the level and the first stripe
@@ -233,11 +233,9 @@ __device__ __forceinline__ BigItem big_item(const BigLevels& lv, int bpt) {
 typedef uint32_t uint2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // (an 8-byte load from a 4-byte aligned address: all gfx950's global loads need)
 
 template <typename T16, int STEPS>
-__global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams gp, BigLevels lv, const float* __restrict__ x01,
-                                                                      const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
-                                                                      int64_t n, const int64_t* __restrict__ n_dev, int64_t grid_stripes, int bpt) {
-    const int64_t n_live = live_count(n, n_dev);                 // (n stays the level stride)
-    const BigItem w = big_item(lv, bpt);
+__device__ __forceinline__ void big_gather_body(const GridParams& gp, const BigItem& w, const float* __restrict__ x01,
+                                                const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
+                                                int64_t n, int64_t n_live, int64_t grid_stripes, int bpt) {
     const int l = w.l;
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     const uint32_t* tl = table + gp.offset[l];
@@ -299,6 +297,13 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams
     }
 }
 
+template <typename T16, int STEPS>
+__global__ __launch_bounds__(256) void hashgrid_fwd_big_gather_kernel(GridParams gp, BigLevels lv, const float* __restrict__ x01,
+                                                                      const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
+                                                                      int64_t n, const int64_t* __restrict__ n_dev, int64_t grid_stripes, int bpt) {
+    big_gather_body<T16, STEPS>(gp, big_item(lv, bpt), x01, table, feat, n, live_count(n, n_dev), grid_stripes, bpt);       // (n stays the level stride)
+}
+
 // line-local levels: lane = (sample s of a group of 16, corner pair r = ky + 2 kz); four groups of a wave in flight.  The four lanes
 // of a quad fetch the coordinates of ONE sample each (group r's) one step ahead and hand them round by quad broadcasts: three
 // registers per lane instead of twelve (70 in all: seven waves per SIMD).
@@ -312,11 +317,9 @@ template <int K> struct QuadStep {
 template <> struct QuadStep<0> { template <typename F> static __device__ __forceinline__ void run(F&&) {} };
 
 template <typename T16, int STEPS, bool OVL>
-__global__ __launch_bounds__(256) void hashgrid_fwd_big_local_kernel(GridParams gp, GridLocal gl, BigLevels lv, const float* __restrict__ x01,
-                                                                     const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
-                                                                     int64_t n, const int64_t* __restrict__ n_dev, int64_t grid_stripes, int bpt) {
-    const int64_t n_live = live_count(n, n_dev);
-    const BigItem w = big_item(lv, bpt);
+__device__ __forceinline__ void big_local_body(const GridParams& gp, const GridLocal& gl, const BigItem& w, const float* __restrict__ x01,
+                                               const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
+                                               int64_t n, int64_t n_live, int64_t grid_stripes, int bpt) {
     const int l = w.l;
     const bool smooth = gp.interpolation == PERF_INTERP_SMOOTHSTEP;
     const uint32_t* tl = table + gp.offset[l];
@@ -419,6 +422,24 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_local_kernel(GridParams 
     }
 }
 
+template <typename T16, int STEPS, bool OVL>
+__global__ __launch_bounds__(256) void hashgrid_fwd_big_local_kernel(GridParams gp, GridLocal gl, BigLevels lv, const float* __restrict__ x01,
+                                                                     const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
+                                                                     int64_t n, const int64_t* __restrict__ n_dev, int64_t grid_stripes, int bpt) {
+    big_local_body<T16, STEPS, OVL>(gp, gl, big_item(lv, bpt), x01, table, feat, n, live_count(n, n_dev), grid_stripes, bpt);
+}
+
+// both kinds of level in ONE launch (launch_big): a workgroup is one level of either kind
+template <typename T16, int STEPS, bool OVL>
+__global__ __launch_bounds__(256) void hashgrid_fwd_big_mixed_kernel(GridParams gp, GridLocal gl, BigLevels lv, const float* __restrict__ x01,
+                                                                     const uint32_t* __restrict__ table, uint32_t* __restrict__ feat,
+                                                                     int64_t n, const int64_t* __restrict__ n_dev, int64_t grid_stripes, int bpt) {
+    const BigItem w = big_item(lv, bpt);
+    const int64_t n_live = live_count(n, n_dev);
+    if (gl.local[w.l]) big_local_body<T16, STEPS, OVL>(gp, gl, w, x01, table, feat, n, n_live, grid_stripes, bpt);
+    else big_gather_body<T16, STEPS>(gp, w, x01, table, feat, n, n_live, grid_stripes, bpt);
+}
+
 // turns of kBigTurn consecutive samples: 4 steps x 256 samples x 4 workgroups (measured at T = 2^28, line-local: 1 / 2 / 4 / 8
 // workgroups per turn 0.760 / 0.750 / 0.738 / 0.742 ms; 1 / 2 / 4 / 8 steps per wave 0.838 / 0.767 / 0.734 / 0.783 ms)
 constexpr int kBigSteps = 4;
@@ -442,6 +463,22 @@ static void launch_big(const GridParams& gp, const GridLocal& gl, const float* x
     gather.order = local.order = local.count ? 0 : 1;
     gather.stripes = local.stripes = stripes;
     // (line-local levels first: the long launch; the few coarse levels' gathers find the coordinates in the caches)
+    if (local.count && gather.count) {
+        // both kinds of level in ONE launch, the coarse levels behind the line-local ones in the list the workgroups cycle through: the coarse
+        // levels' workgroups are bound by vector arithmetic, the line-local ones by the L1's request rate -- side by side on a CU they hide
+        // a third of the coarse levels' 75 us (two launches one after the other: 0.611 ms per 4.2 M samples at T = 2^28, one: 0.588; the
+        // position of the coarse levels in the list does not matter: first 0.589, last 0.588, spread 0.593)
+        BigLevels all = local;
+        for (int k = 0; k < gather.count; ++k) all.level[all.count++] = gather.level[k];
+        const dim3 g((unsigned)(stripes * all.count * 8 * kBigTurnGroups));
+        if (gl.ovl)
+            hipLaunchKernelGGL((hashgrid_fwd_big_mixed_kernel<T16, kBigSteps, true>), g, dim3(256), 0, as_stream(stream),
+                               gp, gl, all, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes, kBigTurnGroups);
+        else
+            hipLaunchKernelGGL((hashgrid_fwd_big_mixed_kernel<T16, kBigSteps, false>), g, dim3(256), 0, as_stream(stream),
+                               gp, gl, all, x01, (const uint32_t*)table16, (uint32_t*)feat16, n, n_dev, stripes, kBigTurnGroups);
+        return;
+    }
     if (local.count) {
         const dim3 g((unsigned)(stripes * local.count * 8 * kBigTurnGroups));
         if (gl.ovl)
