@@ -199,6 +199,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_v2_kernel(GridParams gp, con
 // fetch with no table line requested: 0.89 ms per 4.2 M samples at T = 2^28 line-local; four steps: 0.74 ms).  Measured and not kept
 // (profiles/r06_config5_long_waves.json): a ring of request slots refilled group by group (3-4 groups in flight at all times, but 95
 // registers = 5 waves per SIMD: 0.90 ms; two slots at 7 waves: 0.80), eight waves forced with 5 spilled registers (0.79).
+// OVERLAPPING RUNS (PERF_LAYOUT_LINE_OVERLAP, grid_device.hpp:overlap_x): the x corner pair of a cell is always inside one run, so a lane
+// requests exactly its pair -- 8 bytes -- and only the last cell of a super-block row needs a second request: 0.705 -> 0.62 ms per 4.2 M
+// samples at T = 2^28 (56 registers: eight waves per SIMD); with the coarse levels in the same launch 0.59-0.60.
 // Placement is a speed assumption only; results do not depend on it.
 constexpr int64_t kBigMaxStripes = 1 << 16;
 
