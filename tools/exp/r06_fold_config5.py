@@ -6,7 +6,7 @@
                                    for both table layouts: HBM bytes per launch of hashgrid_fwd_big_kernel (bench.py's config5 block reads it)
   r06_config5_counters.json        SQ / TA / TCP / TCC counters of the line-local encode at T = 2^28, one lane per sample (r06f) and four lanes per
                                    sample (r06j)
-  python tools/exp/r06_fold_config5.py      (reads gpurun_out/r06a, r06f, r06j, r06v, r06ai, r06at, r06bi; copies the raw CSVs to profiles/r06_raw/)"""
+  python tools/exp/r06_fold_config5.py      (reads gpurun_out/r06a, r06f, r06j, r06v, r06ai, r06at, r06bi, r06bl; copies the raw CSVs to profiles/r06_raw/)"""
 import collections, csv, glob, json, os, shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -83,7 +83,7 @@ def rows(path, counter):
 
 
 tables = {}
-for layout, call in (('tcnn', 'r06ai'), ('line_local', 'r06at'), ('line_overlap', 'r06bi')):
+for layout, call in (('tcnn', 'r06ai'), ('line_local', 'r06bl'), ('line_overlap', 'r06bl')):
     f = rows(os.path.join(G, call, f'c5_{layout}_FETCH_SIZE', 'c_counter_collection.csv'), 'FETCH_SIZE')
     w = rows(os.path.join(G, call, f'c5_{layout}_WRITE_SIZE', 'c_counter_collection.csv'), 'WRITE_SIZE')
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -102,7 +102,7 @@ for layout, call in (('tcnn', 'r06ai'), ('line_local', 'r06at'), ('line_overlap'
 json.dump({'source': 'profiles/r06_config5_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python tools/config5.py --pano-log2 28 30 '
                      '--pano-batches 8 --layout <tcnn|line_local|line_overlap> --tile 128 128` (8 batches of 128 x 128 pixels spread from pole to pole, 2 encodes each); moved = 2 x FETCH_SIZE + '
                      'WRITE_SIZE (profiles/r06_fetch_size_calibration.json: a random gather is one 128-byte request tallied at 64); raw CSVs in profiles/r06_raw/',
-           'kernel': 'perf::hashgrid_fwd_big_local_kernel<FP16, 4> + perf::hashgrid_fwd_big_gather_kernel<FP16, 4> (line_local: the 15 line-local levels, then the 5 coarse ones) / '
+           'kernel': 'perf::hashgrid_fwd_big_mixed_kernel<FP16, 4, OVL> (line_local / line_overlap: the 15 line-local levels and the 5 coarse ones in one launch) / '
                      'perf::hashgrid_fwd_big_gather_kernel<FP16, 1> (tcnn), summed per encode; L = 20, finest resolution 8192; line_local = 4x4x2-vertex lines in '
                      '32x64x256-vertex super-blocks, levels of resolution >= 64; line_overlap = the same lines with x runs that overlap by one vertex (8-byte requests), 128x32x128 super-blocks',
            'tables': tables}, open(os.path.join(DST, 'r06_config5_pmc.json'), 'w'), indent=1)
@@ -115,7 +115,8 @@ for name, call in (('one lane per sample: four consecutive 16-byte x-run loads (
                    ('four lanes per sample, 128 x 128-pixel tile batches', 'r06v'),
                    ('the same with long-lived waves: four steps of 64 samples per wave, coordinates requested one step ahead (shipped; line-local launch + '
                     'coarse-level gather launch summed; levels aligned to super-blocks)', 'r06at'),
-                   ('overlapping x runs (layout line_overlap, 128x32x128 super-blocks): one 8-byte request per (y, z) corner pair, 56 registers', 'r06bi')):
+                   ('overlapping x runs (layout line_overlap, 128x32x128 super-blocks): one 8-byte request per (y, z) corner pair, 56 registers; two launches', 'r06bi'),
+                   ('overlapping x runs, line-local and coarse levels in ONE launch (shipped: hashgrid_fwd_big_mixed_kernel)', 'r06bl')):
     agg = collections.defaultdict(list)
     for d in sorted(glob.glob(os.path.join(G, call, 'pmc_*', ''))):
         fcsv = glob.glob(d + '*counter_collection.csv')
