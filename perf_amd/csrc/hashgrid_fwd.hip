@@ -376,21 +376,22 @@ __device__ __forceinline__ void big_local_body(const GridParams& gp, const GridL
                 const uint32_t ya = (vy >> gl.shy) * mul_y, zb = (vz >> gl.shz) * mul_z;
                 const uint32_t yz_in = (((vy >> 2) & mky) << (gl.shx - 2)) + (((vz >> 1) & mkz) << (gl.shx - 2 + gl.shy - 2));
                 const uint32_t in_blk = ((vy & 3u) << 2) + ((vz & 1u) << 4);
-                auto entry = [&](uint32_t X) {                        // entry of storage vertex (X, vy, vz): local_vertex_index(gl, l, size, hashed, X, vy, vz)
+                auto entry = [&](uint32_t X, uint32_t width) {        // entry of storage vertex (X, vy, vz): local_vertex_index(gl, l, size, hashed, X, vy, vz)
                     const uint32_t sx = X >> gl.shx;
                     const uint32_t slot = hashed ? ((sx ^ ya ^ zb) & slot_mask) : (sx + ya + zb);
-                    return (slot << sb_sh) + ((((X >> 2) & mkx) + yz_in) << 5) + (X & 3u) + in_blk;
+                    const uint32_t i = (slot << sb_sh) + ((((X >> 2) & mkx) + yz_in) << 5) + (X & 3u) + in_blk;
+                    return i < size - width ? i : size - width;       // (a point outside the unit cube must not read outside a densely addressed level; inside, never taken)
                 };
                 if constexpr (OVL) {
                     const uint32_t X = overlap_x(gx), sbm = (1u << gl.shx) - 1u;
                     const bool edge = (X & sbm) == sbm - 1u;         // the last cell of a super-block row: second corner = the next super-block's first vertex
                     lxp |= (edge ? 1u : 0u) << (2 * it);
-                    q2[it] = *reinterpret_cast<const uint2_a4*>(tb + (entry(X) << 2));
-                    if (edge) e[it] = *reinterpret_cast<const uint32_t*>(tb + (entry(X + 2u) << 2));
+                    q2[it] = *reinterpret_cast<const uint2_a4*>(tb + (entry(X, 2u) << 2));
+                    if (edge) e[it] = *reinterpret_cast<const uint32_t*>(tb + (entry(X + 2u, 1u) << 2));
                 } else {
                     lxp |= (gx & 3u) << (2 * it);
-                    q[it] = *reinterpret_cast<const uint4*>(tb + (entry(gx & ~3u) << 2));   // (16-byte aligned by construction)
-                    if ((gx & 3u) == 3u) e[it] = *reinterpret_cast<const uint32_t*>(tb + (entry(gx + 1u) << 2));
+                    q[it] = *reinterpret_cast<const uint4*>(tb + (entry(gx & ~3u, 4u) << 2));   // (16-byte aligned by construction)
+                    if ((gx & 3u) == 3u) e[it] = *reinterpret_cast<const uint32_t*>(tb + (entry(gx + 1u, 1u) << 2));
                 }
                 if (smooth) {
                     fx = fx * fx * (3.0f - 2.0f * fx); fy = fy * fy * (3.0f - 2.0f * fy); fz = fz * fz * (3.0f - 2.0f * fz);
@@ -444,7 +445,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_big_mixed_kernel(GridParams 
 }
 
 // turns of kBigTurn consecutive samples: 4 steps x 256 samples x 4 workgroups (measured at T = 2^28, line-local: 1 / 2 / 4 / 8
-// workgroups per turn 0.760 / 0.750 / 0.738 / 0.742 ms; 1 / 2 / 4 / 8 steps per wave 0.838 / 0.767 / 0.734 / 0.783 ms)
+// workgroups per turn 0.760 / 0.750 / 0.738 / 0.742 ms; 1 / 2 / 4 / 8 steps per wave 0.838 / 0.767 / 0.734 / 0.783 ms; overlapping runs,
+// one launch: (steps, workgroups per turn) (4, 4) 0.597 ms, (4, 8) 0.606, (4, 2) 0.628, (4, 1) 0.675, (2, 4) 0.670, (2, 8) 0.661, (8, 2) 0.658, (8, 4) 0.637)
 constexpr int kBigSteps = 4;
 constexpr int kBigTurnGroups = 4;
 

@@ -755,6 +755,13 @@ def test_deep_grid_forward_both_layouts(ops, layout, log2_t, sb_shift, min_res):
             assert torch.equal(part[:, :live2], feat[:, :live2]), (layout, dt, live2)
         canary = ops.hashgrid_fwd(cfg, xd[:300].contiguous(), t16, n_dev=torch.tensor([0], dtype=torch.int64, device='cuda'))
         assert canary.shape == (L, 300, 2)
+        # points OUTSIDE the unit cube (a caller's positions beyond its box: their selector is 0, their features are never used) read
+        # inside the table -- densely addressed line-local levels clamp the entry -- and leave the other rows alone
+        xo = xd[:512].clone()
+        xo[::7] = torch.tensor([[-0.31, 0.5, 1.7], [5.0, -2.0, 0.2], [1.0001, 1.0001, 1.0001], [-1e-4, 0.3, 0.9]], device='cuda').repeat(19, 1)[:xo[::7].shape[0]]
+        fo = ops.hashgrid_fwd(cfg, xo, t16)
+        keep = torch.ones(512, dtype=torch.bool, device='cuda'); keep[::7] = False
+        assert torch.equal(fo[:, keep], feat[:, :512][:, keep]) and bool(torch.isfinite(fo.float()).all())
     if layout != 'tcnn':
         # inference only: the gradient entry points refuse the layout instead of scattering into the wrong entries
         from perf_amd._lib import PerfError
