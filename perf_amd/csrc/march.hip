@@ -485,13 +485,14 @@ __global__ __launch_bounds__(256) void march_count_kernel(MarchParams mp, const 
 // Needs enough rays to fill the chip with 64-ray waves (the host picks it from kSharedMinRays rays on) and one live word per
 // ray (max_steps <= 4096).
 constexpr int64_t kSharedMinRays = 262144;
+constexpr int kSharedHeadMax = 16;                 // head rows per ray this kernel can hold (the host's STRIDED_HEAD_MAX)
 template <bool HEAD>
 __global__ __launch_bounds__(64) void march_count_shared_kernel(MarchParams mp, const float* __restrict__ ro, const float* __restrict__ rd,
                                                                 int64_t n_rays, const uint32_t* __restrict__ bits,
                                                                 const uint32_t* __restrict__ coarse, uint64_t* __restrict__ masks,
                                                                 int32_t* __restrict__ counts, HeadOut ho, float t0_base,
                                                                 const float* __restrict__ lat_full) {
-    __shared__ int32_t s_head[64];
+    __shared__ int32_t s_head[HEAD ? 64 * kSharedHeadMax : 1];                // [ray of the wave][rank]: lattice index of the ray's first K samples
     const int lane = threadIdx.x;
     const int64_t r_base = (int64_t)blockIdx.x * 64;
     const int res = mp.res;
@@ -562,86 +563,105 @@ __global__ __launch_bounds__(64) void march_count_shared_kernel(MarchParams mp, 
             }
         }
     }
-    // ---- the wave walks its rays
+    // ---- the wave walks its rays.  What a ray leaves behind besides its chunk masks -- the record's first word, its count, its head rows
+    //      -- is kept by the ray's LANE and written after the walk by all lanes at once: one pass of coalesced stores and lane-parallel
+    //      sample_point_store instead of 64 single-lane tails (~55 of the ~310 vector instructions per ray were that tail)
     const uint32_t live_lo32 = (uint32_t)live_mine, live_hi32 = (uint32_t)(live_mine >> 32);
+    char* rec_wave = reinterpret_cast<char*>(masks + r_base * (int64_t)(mp.mask_words + 1));
+    const uint32_t rec_stride = (uint32_t)__builtin_amdgcn_readfirstlane((mp.mask_words + 1) * 8);       // (a scalar: s * rec_stride stays on the scalar unit)
+    int32_t count_mine = 0;
+    uint32_t kept_lo = 0u, kept_hi = 0u;
     for (int s = 0; s < 64; ++s) {
         const int64_t r = r_base + s;
         if (r >= n_rays) break;
         const uint64_t live = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)live_lo32, s) |
                               ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)live_hi32, s) << 32);
+        if (!live) continue;                                         // (count_mine / kept of that lane stay 0)
         const float lo = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lo_mine), s));
         const float hi = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(hi_mine), s));
-        uint64_t* rec = masks + r * (int64_t)(mp.mask_words + 1);
+        // (the record of ray s from the wave's base + a 32-bit offset: formed as r * (mask_words + 1) the compiler multiplied 64-bit
+        //  integers on the vector unit for every ray)
+        char* rec = rec_wave + (uint32_t)s * rec_stride;
         int32_t count = 0;
         uint64_t kept = 0;
-        if (live) {
-            const float o[3] = {ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]};
-            const float d[3] = {rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]};
-            for (uint64_t todo = live; todo;) {
-                int qs[4]; uint32_t cis[4]; bool in_range[4];
+        const float o[3] = {ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]};
+        const float d[3] = {rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]};
+        for (uint64_t todo = live; todo;) {
+            int qs[4]; uint32_t cis[4]; bool in_range[4]; float ta[4];
+            // the lattice points of up to four surviving chunks are requested TOGETHER (as written before -- one load inside each chunk's
+            // branch -- every chunk waited for its own round trip); the table holds 64 points beyond the last chunk: no bound test here
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    qs[u] = -1; cis[u] = 0u; in_range[u] = false;
-                    if (todo) {
-                        qs[u] = __ffsll((unsigned long long)todo) - 1;
-                        todo &= todo - 1;
-                        const int k = qs[u] * 64 + lane;
-                        if (k < mp.max_steps) {
-                            const float ta = lat_full[k];
-                            const float tb = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(ta, mp.step) : lattice_single(t0_base, k + 1, mp.step);
-                            const float mid = mul_rn(add_rn(ta, tb), 0.5f);
-                            if (mid >= lo && mid <= hi) {
-                                int cell[3];
+            for (int u = 0; u < 4; ++u) {
+                qs[u] = -1; ta[u] = 0.f;
+                if (todo) {
+                    qs[u] = __ffsll((unsigned long long)todo) - 1;
+                    todo &= todo - 1;
+                    ta[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lat_full) + (((uint32_t)qs[u] * 64u + (uint32_t)lane) << 2));
+                }
+            }
 #pragma unroll
-                                for (int a = 0; a < 3; ++a) {
-                                    const float p = add_rn(o[a], mul_rn(d[a], mid));
-                                    const float uu = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
-                                    cell[a] = (int)fminf(fmaxf(floorf(uu), 0.0f), rf - 1.0f);
-                                }
-                                cis[u] = (uint32_t)((cell[0] * res + cell[1]) * res + cell[2]);
-                                in_range[u] = true;
-                            }
+            for (int u = 0; u < 4; ++u) {
+                cis[u] = 0u; in_range[u] = false;
+                if (qs[u] < 0) continue;                 // (wave uniform)
+                const int k = qs[u] * 64 + lane;
+                if (k < mp.max_steps) {
+                    const float tb = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(ta[u], mp.step) : lattice_single(t0_base, k + 1, mp.step);
+                    const float mid = mul_rn(add_rn(ta[u], tb), 0.5f);
+                    if (mid >= lo && mid <= hi) {
+                        uint32_t cell[3];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const float p = add_rn(o[a], mul_rn(d[a], mid));
+                            const float uu = mul_rn(mul_rn(sub_rn(p, mp.lo[a]), mp.inv_ext[a]), rf);
+                            cell[a] = (uint32_t)(int)fminf(fmaxf(floorf(uu), 0.0f), rf - 1.0f);
                         }
+                        // (res <= 1024: both products fit 24-bit operands -- two full-rate multiply-adds instead of two 64-bit ones)
+                        cis[u] = (uint32_t)__umul24((uint32_t)__umul24(cell[0], (uint32_t)res) + cell[1], (uint32_t)res) + cell[2];
+                        in_range[u] = true;
                     }
                 }
-                uint32_t words[4];
+            }
+            uint32_t words[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) words[u] = in_range[u] ? bits[cis[u] >> 5] : 0u;
+            for (int u = 0; u < 4; ++u)
+                words[u] = in_range[u] ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(bits) + ((cis[u] >> 5) << 2)) : 0u;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (qs[u] < 0) continue;                 // (wave uniform)
-                    const bool mine = in_range[u] && ((words[u] >> (cis[u] & 31)) & 1u);
-                    const uint64_t m = __ballot(mine);
-                    if (m) {
-                        kept |= 1ull << qs[u];
-                        if (lane == 0) rec[1 + qs[u]] = m;
-                        if (HEAD && count < ho.K && mine) {
-                            const int rank = count + __popcll(m & ((1ull << lane) - 1ull));
-                            if (rank < ho.K) s_head[rank] = qs[u] * 64 + lane;
-                        }
-                        count += __popcll(m);
+            for (int u = 0; u < 4; ++u) {
+                if (qs[u] < 0) continue;                 // (wave uniform)
+                const bool mine = in_range[u] && ((words[u] >> (cis[u] & 31)) & 1u);
+                const uint64_t m = __ballot(mine);
+                if (m) {
+                    kept |= 1ull << qs[u];
+                    if (lane == 0) *reinterpret_cast<uint64_t*>(rec + ((uint32_t)(1 + qs[u]) << 3)) = m;
+                    if (HEAD && count < ho.K && mine) {
+                        const int rank = count + __popcll(m & ((1ull << lane) - 1ull));
+                        if (rank < ho.K) s_head[s * kSharedHeadMax + rank] = qs[u] * 64 + lane;
                     }
+                    count += __popcll(m);
                 }
             }
         }
-        if (lane == 0) { rec[0] = kept; counts[r] = count; }
-        if (HEAD) {
-            const int have = count < ho.K ? count : ho.K;
-            if (lane == 0) { ho.packed[2 * r] = (int32_t)(r * ho.K); ho.packed[2 * r + 1] = have; }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < have) {
-                const int64_t pos = r * ho.K + lane;
-                const int k = s_head[lane];
+        if (lane == s) { count_mine = count; kept_lo = (uint32_t)kept; kept_hi = (uint32_t)(kept >> 32); }
+    }
+    // ---- per lane again: record heads, counts, head rows
+    const int64_t r = r_base + lane;
+    if (r >= n_rays) return;
+    masks[r * (int64_t)(mp.mask_words + 1)] = (uint64_t)kept_lo | ((uint64_t)kept_hi << 32);
+    counts[r] = count_mine;
+    if (HEAD) {
+        const int have = count_mine < ho.K ? count_mine : ho.K;
+        ho.packed[2 * r] = (int32_t)(r * ho.K); ho.packed[2 * r + 1] = have;
+        for (int j = 0; j < ho.K; ++j) {                             // (row j of 64 rays at a time)
+            const int64_t pos = r * ho.K + j;
+            if (j < have) {
+                const int k = s_head[lane * kSharedHeadMax + j];
                 const float a = lat_full[k], b = mp.lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, mp.step) : lattice_single(t0_base, k + 1, mp.step);
                 ho.ts[pos] = a; ho.te[pos] = b; ho.ri[pos] = r;
                 sample_point_store(ro + 3 * r, rd + 3 * r, a, b, ho.bb, ho.x01, ho.sel, pos);
-            }
-            if (lane >= have && lane < ho.K) {               // padding rows: harmless inputs, selector 0
-                const int64_t pos = r * ho.K + lane;
+            } else {                                                 // padding rows: harmless inputs, selector 0
                 ho.ts[pos] = 0.f; ho.te[pos] = 0.f; ho.ri[pos] = r;
                 ho.x01[3 * pos] = 0.5f; ho.x01[3 * pos + 1] = 0.5f; ho.x01[3 * pos + 2] = 0.5f; ho.sel[pos] = 0;
             }
-            __builtin_amdgcn_wave_barrier();                 // (s_head is reused by the next ray)
         }
     }
 }
@@ -926,7 +946,7 @@ static int march_count_launch(const float* rays_o, const float* rays_d, const fl
     sr.n = 0;
     PERF_REQUIRE(!lattice_table || t0 == nullptr || lattice_mode == PERF_LATTICE_REPEATED, "per-ray lattice tables (t0 != NULL) exist for the repeated lattice only");
     if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr && !lattice_table) shared_runs_build(t0_base, step, mp.mask_words * 64 + 64, &sr);
-    if (t0 == nullptr && lattice_table != nullptr && mp.mask_words <= 64 && n_rays >= kSharedMinRays) {      // (see march_count_shared_kernel)
+    if (t0 == nullptr && lattice_table != nullptr && mp.mask_words <= 64 && n_rays >= kSharedMinRays && (!head || head->K <= kSharedHeadMax)) {      // (see march_count_shared_kernel)
         if (head)
             hipLaunchKernelGGL(march_count_shared_kernel<true>, dim3((unsigned)div_up(n_rays, 64)), dim3(64), 0, as_stream(stream), mp, rays_o, rays_d,
                                n_rays, occ_bits, occ_coarse, masks, counts, *head, t0_base, lattice_table);

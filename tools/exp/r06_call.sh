@@ -1,16 +1,29 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06bm
+O=$R/gpurun_out/r06bq
 rm -rf $O; mkdir -p $O
 cd $R
-( timeout 1500 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "deep_grid or overlapping" ) > $O/pytest_ops.log 2>&1; tail -3 $O/pytest_ops.log
-for cfg in "0 0" "2 4" "2 8" "4 2" "4 8" "8 2" "8 4" "4 1" "0 0"; do
-set -- $cfg
-if [ $1 = 0 ]; then unset PERF_EXP_STEPS PERF_EXP_TURN; else export PERF_EXP_STEPS=$1 PERF_EXP_TURN=$2; fi
-timeout 600 python tools/config5.py --pano-log2 28 --layout line_overlap 2>&1 | grep -v amdgpu.ids > $O/c5.log
+( timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_config4.py tests/test_gpu_counts.py -m gpu -x -q -k "march or lattice or config4 or frame or two_phase or head" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+for i in 1 2; do
+timeout 600 python tools/render_dense.py --poses 300 --batch 524288 > $O/rd_$i.log 2>&1
 python - <<PY
-import json,re
-t=open('$O/c5.log').read()
-m=re.findall(r'"(seconds_per_panorama|ms_per_launch|frac)": ([0-9.e+]+)', t)
-print('steps,turn=$cfg', m[:6])
+import json
+t=open('$O/rd_$i.log').read()
+d=json.loads(t[t.rindex('\n{'):] if '\n{' in t else t[t.index('{'):])
+print({k: d[k] for k in d if 'frames_per_s' in k or 'checksum' in k or 'rgb_sum' in k})
 PY
 done
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/tools/render_dense.py --poses 100 --batch 524288 > $O/kt.log 2>&1
+head -4 $O/kt/kt_kernel_stats.csv | sed 's/(perf::MarchParams.*)",/ /' | cut -c1-150
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/pmc -o c -- python $R/tools/render_dense.py --poses 20 --batch 524288 > $O/pmc.log 2>&1
+cd $R
+python - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob('gpurun_out/r06bq/pmc/c_counter_collection.csv')):
+    agg=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if 'march_count_shared' in r['Kernel_Name']:
+            agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    print({k: round(sum(v)/len(v)) for k,v in agg.items()})
+PY
+find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete
