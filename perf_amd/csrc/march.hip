@@ -746,6 +746,58 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
     }
 }
 
+// Large launches on ONE lattice (eval frames, as march_count_shared_kernel): a wave takes 64 rays.  Every ray's LANE reads its count and
+// offset and stores its packed_info pair -- coalesced -- and the wave then walks only the rays that HAVE samples to write, all 64 lanes
+// on the 64 intervals of a chunk.  On an eval frame of a trained scene most rays end inside their head (the two-phase sampler's tail
+// counts are zero): march_write_kernel gave each of them a quarter wave that loaded two words, stored two and retired.  Same rows,
+// same values.
+__global__ __launch_bounds__(256) void march_write_shared_kernel(int64_t n_rays, float step, int32_t mask_words, const uint64_t* __restrict__ masks,
+                                                                 const int32_t* __restrict__ counts, const int32_t* __restrict__ offsets,
+                                                                 int64_t capacity, int64_t* __restrict__ ray_indices, float* __restrict__ ts,
+                                                                 float* __restrict__ te, int32_t* __restrict__ packed,
+                                                                 const float* __restrict__ rays_o, const float* __restrict__ rays_d, Aabb bb,
+                                                                 float* __restrict__ x01, uint8_t* __restrict__ sel, int32_t rank_lo,
+                                                                 float t0_base, int lattice_mode, const float* __restrict__ lat_full) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r_base = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * 64;
+    if (r_base >= n_rays) return;
+    const int64_t rl = r_base + lane;
+    int32_t cnt_mine = 0, off_mine = 0;
+    if (rl < n_rays) {
+        cnt_mine = counts[rl]; off_mine = offsets[rl];
+        if ((int64_t)off_mine + cnt_mine > capacity) cnt_mine = (int32_t)(capacity > off_mine ? capacity - off_mine : 0);   // truncated batch
+        packed[2 * rl] = off_mine; packed[2 * rl + 1] = cnt_mine;
+    }
+    const int nlw = n_live_words(mask_words);
+    for (uint64_t rays = __ballot(cnt_mine > 0); rays; rays &= rays - 1) {
+        const int s = __ffsll((unsigned long long)rays) - 1;
+        const int64_t r = r_base + s;
+        const int32_t cnt = __builtin_amdgcn_readlane(cnt_mine, s), off = __builtin_amdgcn_readlane(off_mine, s);
+        int64_t run = (int64_t)off - rank_lo;            // output position of rank 0 (may lie before `off`)
+        const int64_t end = (int64_t)off + cnt;
+        const uint64_t* rec = masks + r * (int64_t)(mask_words + nlw);
+        for (int g = 0; g < nlw && run < end; ++g) {
+            for (uint64_t todo = rec[g]; todo && run < end; todo &= todo - 1) {
+                const int qq = g * 64 + (__ffsll((unsigned long long)todo) - 1);
+                const uint64_t m = rec[nlw + qq];
+                if ((m >> lane) & 1ull) {
+                    const int64_t pos = run + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos >= off && pos < end) {
+                        const int k = qq * 64 + lane;
+                        const float a = lat_full[k];
+                        const float b = lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, step) : lattice_single(t0_base, k + 1, step);
+                        ts[pos] = a;
+                        te[pos] = b;
+                        ray_indices[pos] = r;
+                        if (x01) sample_point_store(rays_o + 3 * r, rays_d + 3 * r, a, b, bb, x01, sel, pos);
+                    }
+                }
+                run += __popcll(m);
+            }
+        }
+    }
+}
+
 // ---------------- exclusive scan of int32 (counts -> offsets) -----------------------------------
 constexpr int kScanBlock = 1024;   // elements per block (256 threads x 4)
 
@@ -1032,6 +1084,11 @@ extern "C" int perf_occ_march_write(const float* t0, float t0_scale, float t0_ba
     sr.n = 0;
     PERF_REQUIRE(!lattice_table || t0 == nullptr || lattice_mode == PERF_LATTICE_REPEATED, "per-ray lattice tables (t0 != NULL) exist for the repeated lattice only");
     if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr && !lattice_table) shared_runs_build(t0_base, step, chunk_words(max_steps) * 64 + 64, &sr);
+    if (t0 == nullptr && lattice_table != nullptr && n_rays >= kSharedMinRays)        // (see march_write_shared_kernel)
+        hipLaunchKernelGGL(march_write_shared_kernel, dim3((unsigned)div_up(n_rays, 256)), dim3(256), 0, as_stream(stream), n_rays, step,
+                           (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts, t_ends, packed_info,
+                           (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0, t0_base, (int)lattice_mode, lattice_table);
+    else
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
                        t_ends, packed_info, (const float*)nullptr, (const float*)nullptr, Aabb{}, (float*)nullptr, (uint8_t*)nullptr, 0, t0_scale, t0_base, (int)lattice_mode, sr, lattice_table);
@@ -1055,6 +1112,11 @@ extern "C" int perf_occ_march_write_points(const float* t0, float t0_scale, floa
     sr.n = 0;
     PERF_REQUIRE(!lattice_table || t0 == nullptr || lattice_mode == PERF_LATTICE_REPEATED, "per-ray lattice tables (t0 != NULL) exist for the repeated lattice only");
     if (lattice_mode == PERF_LATTICE_REPEATED && t0 == nullptr && !lattice_table) shared_runs_build(t0_base, step, chunk_words(max_steps) * 64 + 64, &sr);
+    if (t0 == nullptr && lattice_table != nullptr && n_rays >= kSharedMinRays)        // (see march_write_shared_kernel)
+        hipLaunchKernelGGL(march_write_shared_kernel, dim3((unsigned)div_up(n_rays, 256)), dim3(256), 0, as_stream(stream), n_rays, step,
+                           (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts, t_ends, packed_info,
+                           rays_o, rays_d, bb, x01, sel, rank_lo, t0_base, (int)lattice_mode, lattice_table);
+    else
     hipLaunchKernelGGL(march_write_kernel, dim3((unsigned)(n_rays / 4 >= 8192 ? div_up(n_rays, 16) : div_up(n_rays, 4))), dim3(256), 0, as_stream(stream), t0, n_rays,
                        step, (int32_t)chunk_words(max_steps), masks, counts, offsets, capacity, ray_indices, t_starts,
                        t_ends, packed_info, rays_o, rays_d, bb, x01, sel, rank_lo, t0_scale, t0_base, (int)lattice_mode, sr, lattice_table);

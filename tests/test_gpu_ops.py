@@ -1263,6 +1263,28 @@ def test_lane_per_ray_marching_of_large_shared_lattice_launches_equals_wave_per_
                 assert torch.equal(ts, ts_a[lo * K:hi * K]) and torch.equal(te, te_a[lo * K:hi * K]) and torch.equal(sel, s_a[lo * K:hi * K])
                 assert torch.equal(x01, x_a[lo * K:hi * K]) and torch.equal(pk[:, 1], pk_a[lo:hi, 1]) and torch.equal(ri + lo, ri_a[lo * K:hi * K])
             assert int(c_all.sum()) > 100000
+            # the WRITE pass of such launches (march_write_shared_kernel: a ray per lane for counts / offsets / packed_info, the wave walks the
+            # rays that have samples) against the halves (march_write_kernel): the plain expansion with positions, the two-phase sampler's
+            # tail form (rank_lo = K, most counts zero) and a truncated capacity
+            if cz is not None:
+                for counts_w, rank_lo, cap_cut in ((c_all, 0, 0), (torch.where((c_all > K) & (torch.arange(R, device='cuda') % 3 == 0), c_all - K, torch.zeros_like(c_all)), K, 0),
+                                                   (c_all, 0, 1000)):
+                    offs, total = ops.exclusive_scan_i32(counts_w)
+                    S = int(total.item()) - cap_cut
+                    ri_a, ts_a, te_a, pk_a, x_a, s_a = ops.occ_march_write(t0, m_all, counts_w, offs, S, step, max_steps, o, d, aabb, rank_lo=rank_lo, lattice=lattice)
+                    for lo, hi in ((0, h), (h, R)):
+                        cw = counts_w[lo:hi].contiguous()
+                        base = int(offs[lo].item())
+                        end = min(int(offs[hi - 1].item()) + int(cw[-1].item()), S)
+                        ow = (offs[lo:hi] - base).contiguous()
+                        mh = m_all.view(R, mw)[lo:hi].contiguous().view(-1)
+                        ri, ts, te, pk, x01, sel = ops.occ_march_write(t0, mh, cw, ow, max(end - base, 0), step, max_steps, o[lo:hi].contiguous(), d[lo:hi].contiguous(),
+                                                                       aabb, rank_lo=rank_lo, lattice=lattice)
+                        n_ = max(end - base, 0)
+                        assert torch.equal(ts[:n_], ts_a[base:end]) and torch.equal(te[:n_], te_a[base:end]) and torch.equal(ri[:n_] + lo, ri_a[base:end]), (lattice, rank_lo, cap_cut)
+                        assert torch.equal(x01[:n_], x_a[base:end]) and torch.equal(sel[:n_], s_a[base:end])
+                        assert torch.equal(pk[:, 1], pk_a[lo:hi, 1]) and torch.equal(pk[:, 0] + base, pk_a[lo:hi, 0])
+                    assert int(pk_a[:, 1].sum()) == S if cap_cut == 0 else int(pk_a[:, 1].sum()) == S
 
 
 @pytest.mark.parametrize('tail_empty,data_parallel', [(False, False), (True, False), (False, True)])

@@ -1,8 +1,8 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06bq
+O=$R/gpurun_out/r06bs
 rm -rf $O; mkdir -p $O
 cd $R
-( timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_config4.py tests/test_gpu_counts.py -m gpu -x -q -k "march or lattice or config4 or frame or two_phase or head" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+( timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_config4.py tests/test_gpu_counts.py tests/test_gpu_scene.py -m gpu -x -q -k "march or lattice or config4 or frame or two_phase or head or render" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 for i in 1 2; do
 timeout 600 python tools/render_dense.py --poses 300 --batch 524288 > $O/rd_$i.log 2>&1
 python - <<PY
@@ -14,16 +14,6 @@ PY
 done
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/tools/render_dense.py --poses 100 --batch 524288 > $O/kt.log 2>&1
-head -4 $O/kt/kt_kernel_stats.csv | sed 's/(perf::MarchParams.*)",/ /' | cut -c1-150
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/pmc -o c -- python $R/tools/render_dense.py --poses 20 --batch 524288 > $O/pmc.log 2>&1
+grep "march_" $O/kt/kt_kernel_stats.csv | sed 's/(.*)",/ /' | cut -c1-150
 cd $R
-python - <<'PY'
-import csv, glob, collections
-for f in sorted(glob.glob('gpurun_out/r06bq/pmc/c_counter_collection.csv')):
-    agg=collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if 'march_count_shared' in r['Kernel_Name']:
-            agg[r['Counter_Name']].append(float(r['Counter_Value']))
-    print({k: round(sum(v)/len(v)) for k,v in agg.items()})
-PY
 find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete
