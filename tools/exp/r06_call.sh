@@ -1,6 +1,11 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06bu
+O=$R/gpurun_out/r06bv
 rm -rf $O; mkdir -p $O
 cd $R
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/exp/gather_probe2.hip -o /tmp/gather_probe2 2>/dev/null
-/tmp/gather_probe2 18 20 22 24 | tee $O/probe2.log
+( time timeout 3000 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+( time timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+( time timeout 900 python bench.py ) > $O/bench.log 2> $O/bench.err; tail -c 300 $O/bench.log; tail -4 $O/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c4 -o kt -- python $R/tools/render_dense.py --poses 300 --batch 524288 > $O/kt_c4.log 2>&1
+cd $R
+find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete
