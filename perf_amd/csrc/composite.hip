@@ -77,7 +77,7 @@ __device__ __forceinline__ unsigned long long team_ballot(bool p) {
     return (b >> (((threadIdx.x & 63) / W) * W)) & ((1ull << W) - 1ull);
 }
 
-// Two launch shapes, told apart by the grid size (team_grid):
+// Three launch shapes, told apart by the grid size (team_grid; the third, packed by sixteen, is described in for_rays_of_wave):
 //  * packed (n_rays / 4 waves; chosen when that still fills the GPU, i.e. eval batches): wave w serves rays 4w..4w+3 --
 //    a quarter wave each when all four hold <= 16 samples, one after the other with all 64 lanes otherwise;
 //  * one wave per ray (small batches: 8,192 training rays of 128 samples must not lose three quarters of their waves): the
@@ -90,6 +90,32 @@ template <typename CountFn, typename Body>
 __device__ __forceinline__ void for_rays_of_wave(int64_t n_rays, CountFn count_of, Body body) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if ((int64_t)gridDim.x * 16 < n_rays) {
+        // packed by sixteen (n_rays / 16 waves: frames of half a million rays): wave w serves rays 16w..16w+15 -- 4-lane teams when all
+        // sixteen hold <= 4 samples (the frames of a trained scene: a sample or two per ray), else its four groups of four one after the
+        // other as below.  (With n_rays / 4 waves three of every four waves loaded sixteen counts and retired.)  Same bits: same teams.
+        const int64_t g16 = w * 16;
+        if (g16 >= n_rays) return;
+        const int64_t r16 = g16 + (lane >> 2);
+        const int c16 = r16 < n_rays ? count_of(r16) : 0;
+        if (__ballot(c16 > 4) == 0ull) {
+            if (r16 < n_rays) body(Team<4>{}, r16, lane & 3);
+            return;
+        }
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int64_t rb = g16 + 4 * g4;
+            if (rb >= n_rays) break;
+            const int64_t rq = rb + (lane >> 4);
+            const int cq = rq < n_rays ? count_of(rq) : 0;
+            if (__ballot(cq > 16) == 0ull) {
+                if (rq < n_rays) body(Team<16>{}, rq, lane & 15);
+            } else {
+                for (int q = 0; q < 4; ++q)
+                    if (rb + q < n_rays) body(Team<64>{}, rb + q, lane);
+            }
+        }
+        return;
+    }
     const bool packed = (int64_t)gridDim.x * 4 < n_rays;
     const int64_t r0 = packed ? w * 4 : (w & ~(int64_t)3);
     if (r0 >= n_rays) return;
@@ -119,6 +145,7 @@ __device__ __forceinline__ void for_rays_of_wave(int64_t n_rays, CountFn count_o
     }
 }
 static inline dim3 team_grid(int64_t n_rays) {
+    if (n_rays / 16 >= 2 * kPackedMinWaves) return dim3((unsigned)div_up(n_rays, 64));       // packed by sixteen: >= 262,144 rays
     return dim3((unsigned)(n_rays / 4 >= kPackedMinWaves ? div_up(n_rays, 16) : div_up(n_rays, 4)));
 }
 

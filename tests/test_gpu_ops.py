@@ -431,6 +431,46 @@ def test_visibility_and_compaction_bit_exact(ops):
     assert np.array_equal(gpacked.cpu().numpy(), O.packed_info_from_ray_indices(ri.numpy()[keep], packed.shape[0]))
 
 
+def test_team_kernels_give_the_same_bits_in_every_launch_shape(ops):
+    """The ray-team kernels (visibility, compaction, compositing) pick their launch shape from the number of rays: one wave per ray,
+    four rays per wave, and -- from 262,144 rays on: an eval frame -- sixteen rays per wave (4-lane teams when all sixteen hold <= 4
+    samples, else their four groups of four one after the other).  A frame-sized launch whose stretches of rays are short (0-4 samples),
+    medium (<= 16), long (up to 150) and mixed gives, in two halves (four rays per wave) and ray by ray in small pieces (one wave per ray),
+    the same bits."""
+    g = torch.Generator().manual_seed(77)
+    R = 270000
+    counts = torch.randint(0, 5, (R,), generator=g)                       # short rays ...
+    seg = torch.arange(R) // 4096
+    counts = torch.where(seg % 5 == 1, torch.randint(0, 17, (R,), generator=g), counts)            # ... stretches of medium ones
+    counts = torch.where(seg % 5 == 2, torch.randint(0, 150, (R,), generator=g), counts)           # ... of long ones
+    lone = torch.randint(0, R, (300,), generator=g)
+    counts[lone] = torch.randint(5, 90, (300,), generator=g)              # ... and single heavier rays among the short ones
+    starts = torch.cumsum(counts, 0) - counts
+    packed = torch.stack([starts, counts], -1).to(torch.int32).cuda()
+    S = int(counts.sum())
+    ts = (torch.rand(S, generator=g) * 1.5).cuda(); te = ts + 5e-3
+    sig = torch.exp(torch.randn(S, generator=g) * 2 + 2).cuda()
+    rgb = torch.rand(S, 3, generator=g).cuda()
+    nc_a, ex_a = ops.visibility_count(sig, ts, te, packed, 1e-4, want_exsum=True)
+    w_a, T_a, al_a, op_a, d_a, col_a = ops.composite_fwd(sig, rgb, ts, te, packed)
+    cp_a = ops.compact_prefix(packed, nc_a, ts, te, sig)
+    assert 0 < int(nc_a.sum()) < S
+    pieces = [(0, R // 2), (R // 2, R)] + [(lo, lo + 3000) for lo in (0, 4096 + 17, 2 * 4096 + 5, 5 * 4096 - 1500, R - 3000)]
+    kept_before = torch.cumsum(nc_a.long(), 0) - nc_a.long()
+    for lo, hi in pieces:
+        s0, s1 = int(starts[lo]), int(starts[hi - 1] + counts[hi - 1])
+        pk = packed[lo:hi].clone(); pk[:, 0] -= s0
+        nc, ex = ops.visibility_count(sig[s0:s1].contiguous(), ts[s0:s1].contiguous(), te[s0:s1].contiguous(), pk, 1e-4, want_exsum=True)
+        assert torch.equal(nc, nc_a[lo:hi]) and torch.equal(ex, ex_a[s0:s1]), (lo, hi)
+        w, T, al, op, dd, col = ops.composite_fwd(sig[s0:s1].contiguous(), rgb[s0:s1].contiguous(), ts[s0:s1].contiguous(), te[s0:s1].contiguous(), pk)
+        for a, b, name in ((w, w_a[s0:s1], 'w'), (T, T_a[s0:s1], 'T'), (al, al_a[s0:s1], 'alpha'), (op, op_a[lo:hi], 'op'), (dd, d_a[lo:hi], 'dist'), (col, col_a[lo:hi], 'col')):
+            assert torch.equal(a, b), (name, lo, hi)
+        cp = ops.compact_prefix(pk, nc, ts[s0:s1].contiguous(), te[s0:s1].contiguous(), sig[s0:s1].contiguous())
+        k0 = int(kept_before[lo]); k1 = k0 + int(nc.sum())
+        assert torch.equal(cp[0] + lo, cp_a[0][k0:k1]) and torch.equal(cp[1], cp_a[1][k0:k1]) and torch.equal(cp[3], cp_a[3][k0:k1])
+        assert torch.equal(cp[4][:, 1], cp_a[4][lo:hi, 1])
+
+
 def test_compaction_hands_out_rows_instead_of_a_feature_copy(ops):
     """perf_compact_prefix(src_index_out) + perf_mlp_bwd(feat_index): the kept samples' features are read where the sampler's
     density pass wrote them.  The rows are the kept positions of the input order; the MLP backward through them is bit-identical
