@@ -923,153 +923,158 @@ __global__ __launch_bounds__(256) void train_head_kernel(const float* __restrict
                                                          float* __restrict__ color, float* __restrict__ terms,
                                                          float* __restrict__ distloss, float* __restrict__ inv_n_out,
                                                          float* __restrict__ d_sig, float* __restrict__ d_rgb) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_rays) return;
-    const int64_t start = packed[2 * r];
-    const int cnt = packed[2 * r + 1];
-    const int n_chunks = (cnt + 63) / 64;
-    // what the loss head reads is requested NOW: the kernel is a chain of dependent round trips (packed_info -> samples ->
-    // loss inputs -> backward) for a few samples per ray, and these do not depend on the forward pass
-    float in_noise = 0.f, in_gt[3] = {0.f, 0.f, 0.f}, in_bg[3] = {0.f, 0.f, 0.f}, in_ratio = 1.0f;
-    int in_tail = 0;              // sample count of ray n_rays - 1 - lane: the first ballot of the search for the last ray with samples
-    if (!APP) {
-        if (hl.noise) in_noise = hl.noise[r];
-        in_gt[0] = hl.gt[r];
-        if (hl.ratio_dev) in_ratio = hl.ratio_dev[0];
-        if (!hl.data_parallel && n_rays - 1 - lane >= 0) in_tail = packed[2 * (n_rays - 1 - lane) + 1];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { in_gt[k] = hl.gt[3 * r + k]; if (hl.bg) in_bg[k] = hl.bg[3 * r + k]; }
-    }
-    // ---- forward
-    float carry = 0.f;
-    float a_op = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
-    float cW = 0.f, cWM = 0.f, a_dl = 0.f;
-    float w_l = 0.f, T_l = 0.f, t0_l = 0.f, t1_l = 0.f, s_l = 0.f;       // the last chunk's sample of this lane
-    for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int i = c0 + lane;
-        const bool valid = i < cnt;
-        float sd = 0.f, t0 = 0.f, t1 = 0.f, s = 0.f;
-        if (valid) { t0 = ts[start + i]; t1 = te[start + i]; s = sig[start + i]; sd = mul_rn(s, sub_rn(t1, t0)); }
-        const float ex = team_chunk_excl<64>(sd, lane, carry);
-        float w_dl = 0.f, T = 0.f;
-        if (valid) {
-            T = expf(-ex);
-            const float al = 1.0f - expf(-sd);
-            const float w = T * al;
-            w_dl = w;
-            weights[start + i] = w;
-            trans[start + i] = T;
-            a_op += w;
-            a_d += w * ((t0 + t1) * 0.5f);
-            if (rgb) {
-                a_r += w * rgb[3 * (start + i)];
-                a_g += w * rgb[3 * (start + i) + 1];
-                a_b += w * rgb[3 * (start + i) + 2];
-            }
+    // The one thing the loss shares between rays besides the batch size -- 1 / (last ray that holds a sample + 1) -- is found by the WAVE,
+    // before its lanes split into ray teams: a ballot over the last 64 rays (it walks further back only over rays without samples).
+    float inv_n = hl.inv_bs;
+    if (!APP && !hl.data_parallel) {
+        const int wl = threadIdx.x & 63;
+        const int in_tail = (n_rays - 1 - wl >= 0) ? packed[2 * (n_rays - 1 - wl) + 1] : 0;
+        float lastf = -1.f;
+        unsigned long long m = __ballot(in_tail > 0);
+        for (int64_t hi = n_rays; ; ) {
+            if (m) { lastf = (float)(hi - 1 - __builtin_ctzll(m)); break; }
+            hi -= 64;
+            if (hi <= 0) break;
+            const int64_t q = hi - 1 - wl;
+            m = __ballot(q >= 0 && packed[2 * q + 1] > 0);
         }
+        inv_n = 1.0f / (lastf + 1.0f > 0.f ? lastf + 1.0f : 1.0f);
+    }
+    // Ray teams as in the compositing kernels (for_rays_of_wave): a training batch late in an episode keeps a sample or two per ray -- a
+    // wavefront per ray then spends its ~80 cross-lane steps (six 64-wide scans and sums each way) on two live lanes; 16- and 4-lane
+    // teams take 4 and 2 steps per scan inside one DPP row.  Same bits: for <= W samples the steps beyond W only ever add exact zeros.
+    for_rays_of_wave(n_rays, [&](int64_t q) { return packed[2 * q + 1]; }, [&](auto team, int64_t r, int l) {
+        constexpr int W = decltype(team)::width;
+        const int64_t start = packed[2 * r];
+        const int cnt = packed[2 * r + 1];
+        const int n_chunks = (cnt + W - 1) / W;
+        // what the loss head reads is requested NOW: the kernel is a chain of dependent round trips (packed_info -> samples ->
+        // loss inputs -> backward) for a few samples per ray, and these do not depend on the forward pass
+        float in_noise = 0.f, in_gt[3] = {0.f, 0.f, 0.f}, in_bg[3] = {0.f, 0.f, 0.f}, in_ratio = 1.0f;
         if (!APP) {
-            const float m = (t0 + t1) * 0.5f, d = t1 - t0;
-            const float Wp = team_chunk_excl<64>(w_dl, lane, cW);
-            const float WMp = team_chunk_excl<64>(w_dl * m, lane, cWM);
-            if (valid) a_dl += d * w_dl * w_dl * (1.0f / 3.0f) + 2.0f * w_dl * (m * Wp - WMp);
+            if (hl.noise) in_noise = hl.noise[r];
+            in_gt[0] = hl.gt[r];
+            if (hl.ratio_dev) in_ratio = hl.ratio_dev[0];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { in_gt[k] = hl.gt[3 * r + k]; if (hl.bg) in_bg[k] = hl.bg[3 * r + k]; }
         }
-        w_l = w_dl; T_l = T; t0_l = t0; t1_l = t1; s_l = s;
-    }
-    if (!APP) a_dl = team_sum<64>(a_dl);
-    a_op = team_sum<64>(a_op); a_d = team_sum<64>(a_d);
-    if (rgb) { a_r = team_sum<64>(a_r); a_g = team_sum<64>(a_g); a_b = team_sum<64>(a_b); }
-    if (lane == 0) {
-        if (!APP) distloss[r] = a_dl;
-        opacity[r] = a_op;
-        distance[r] = a_d;
-        if (rgb && color) { color[3 * r] = a_r; color[3 * r + 1] = a_g; color[3 * r + 2] = a_b; }
-    }
-    // ---- the ray's loss head
-    float gop = 0.f, gd = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, dl_scale = 0.f;
-    if (!APP) {
-        const float op = a_op;
-        const float nz = hl.noise ? (in_noise * 2.0f - 1.0f) : 0.0f;
-        const float pre = a_d + nz * (1.0f - op);
-        const float d = fmaxf(pre, 0.0f);
-        const float diff = d - in_gt[0];
-        gd = (pre > 0.0f) ? sl1_grad(diff, 1e-2f) * hl.inv_bs * hl.w0 * hl.loss_scale : 0.0f;
-        gop = -nz * gd;
-        if (lane == 0) terms[r] = sl1(diff, 1e-2f);
-        float inv_n = hl.inv_bs;
-        if (!hl.data_parallel) {                  // 1 / (last ray that holds a sample + 1)
-            float lastf = -1.f;
-            unsigned long long m = __ballot(in_tail > 0);
-            for (int64_t hi = n_rays; ; ) {
-                if (m) { lastf = (float)(hi - 1 - __builtin_ctzll(m)); break; }
-                hi -= 64;
-                if (hi <= 0) break;
-                const int64_t q = hi - 1 - lane;
-                m = __ballot(q >= 0 && packed[2 * q + 1] > 0);
+        // ---- forward
+        float carry = 0.f;
+        float a_op = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
+        float cW = 0.f, cWM = 0.f, a_dl = 0.f;
+        float w_l = 0.f, T_l = 0.f, t0_l = 0.f, t1_l = 0.f, s_l = 0.f;       // the last chunk's sample of this lane
+        for (int c0 = 0; c0 < cnt; c0 += W) {
+            const int i = c0 + l;
+            const bool valid = i < cnt;
+            float sd = 0.f, t0 = 0.f, t1 = 0.f, s = 0.f;
+            if (valid) { t0 = ts[start + i]; t1 = te[start + i]; s = sig[start + i]; sd = mul_rn(s, sub_rn(t1, t0)); }
+            const float ex = team_chunk_excl<W>(sd, l, carry);
+            float w_dl = 0.f, T = 0.f;
+            if (valid) {
+                T = expf(-ex);
+                const float al = 1.0f - expf(-sd);
+                const float w = T * al;
+                w_dl = w;
+                weights[start + i] = w;
+                trans[start + i] = T;
+                a_op += w;
+                a_d += w * ((t0 + t1) * 0.5f);
+                if (rgb) {
+                    a_r += w * rgb[3 * (start + i)];
+                    a_g += w * rgb[3 * (start + i) + 1];
+                    a_b += w * rgb[3 * (start + i) + 2];
+                }
             }
-            inv_n = 1.0f / (lastf + 1.0f > 0.f ? lastf + 1.0f : 1.0f);
-        }
-        const float ratio = in_ratio;
-        dl_scale = inv_n * hl.dist_w * ratio * hl.loss_scale;
-        if (r == 0 && lane == 0 && inv_n_out) inv_n_out[0] = inv_n;
-    } else {
-        const float om = 1.0f - a_op;
-        const float acc[3] = {a_r, a_g, a_b};
-        float g[3], term = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float c = acc[k] + (hl.bg ? in_bg[k] : 0.0f) * om;
-            const float diff = c - in_gt[k];
-            term += sl1(diff, 5e-2f);
-            g[k] = sl1_grad(diff, 5e-2f) * hl.inv_bs * hl.w0 * hl.loss_scale;
-        }
-        gc0 = g[0]; gc1 = g[1]; gc2 = g[2];
-        if (lane == 0) terms[r] = term;
-    }
-    if (cnt == 0) return;
-    // ---- backward (composite_bwd_kernel; geometry: with the distortion-loss gradient formed here, colour: d rgb only)
-    const float totW = a_op, totWM = a_d;
-    float sufW = 0.f, sufWM = 0.f, bcarry = 0.f;
-    for (int q = n_chunks - 1; q >= 0; --q) {
-        const int i = q * 64 + lane;
-        const bool valid = i < cnt;
-        float w = 0.f, T = 0.f, t0 = 0.f, t1 = 0.f, s = 0.f;
-        if (q == n_chunks - 1) { w = w_l; T = T_l; t0 = t0_l; t1 = t1_l; s = s_l; }
-        else if (valid) { w = weights[start + i]; T = trans[start + i]; t0 = ts[start + i]; t1 = te[start + i]; s = sig[start + i]; }
-        if (APP) {
-            if (valid) { d_rgb[3 * (start + i)] = w * gc0; d_rgb[3 * (start + i) + 1] = w * gc1; d_rgb[3 * (start + i) + 2] = w * gc2; }
-            continue;
-        }
-        float G = 0.f;
-        if (valid) G = gop + gd * ((t0 + t1) * 0.5f);
-        {
-            const float m = (t0 + t1) * 0.5f, wm = w * m;
-            float sw = w, swm = wm;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float y0 = __shfl_down(sw, off), y1 = __shfl_down(swm, off);
-                if (lane + off < 64) { sw += y0; swm += y1; }
+            if (!APP) {
+                const float m = (t0 + t1) * 0.5f, d = t1 - t0;
+                const float Wp = team_chunk_excl<W>(w_dl, l, cW);
+                const float WMp = team_chunk_excl<W>(w_dl * m, l, cWM);
+                if (valid) a_dl += d * w_dl * w_dl * (1.0f / 3.0f) + 2.0f * w_dl * (m * Wp - WMp);
             }
-            const float Wsuf = sufW + (sw - w), WMsuf = sufWM + (swm - wm);
-            const float W = totW - Wsuf - w, WM = totWM - WMsuf - wm;
-            if (valid) G += dl_scale * ((2.0f / 3.0f) * (t1 - t0) * w + 2.0f * (m * (W - Wsuf) - (WM - WMsuf)));
-            sufW += __shfl(sw, 0); sufWM += __shfl(swm, 0);
+            w_l = w_dl; T_l = T; t0_l = t0; t1_l = t1; s_l = s;
         }
-        const float qv = G * w;
-        float suf = qv;
+        if (!APP) a_dl = team_sum<W>(a_dl);
+        a_op = team_sum<W>(a_op); a_d = team_sum<W>(a_d);
+        if (rgb) { a_r = team_sum<W>(a_r); a_g = team_sum<W>(a_g); a_b = team_sum<W>(a_b); }
+        if (l == 0) {
+            if (!APP) distloss[r] = a_dl;
+            opacity[r] = a_op;
+            distance[r] = a_d;
+            if (rgb && color) { color[3 * r] = a_r; color[3 * r + 1] = a_g; color[3 * r + 2] = a_b; }
+        }
+        // ---- the ray's loss head
+        float gop = 0.f, gd = 0.f, gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, dl_scale = 0.f;
+        if (!APP) {
+            const float op = a_op;
+            const float nz = hl.noise ? (in_noise * 2.0f - 1.0f) : 0.0f;
+            const float pre = a_d + nz * (1.0f - op);
+            const float d = fmaxf(pre, 0.0f);
+            const float diff = d - in_gt[0];
+            gd = (pre > 0.0f) ? sl1_grad(diff, 1e-2f) * hl.inv_bs * hl.w0 * hl.loss_scale : 0.0f;
+            gop = -nz * gd;
+            if (l == 0) terms[r] = sl1(diff, 1e-2f);
+            const float ratio = in_ratio;
+            dl_scale = inv_n * hl.dist_w * ratio * hl.loss_scale;
+            if (r == 0 && l == 0 && inv_n_out) inv_n_out[0] = inv_n;
+        } else {
+            const float om = 1.0f - a_op;
+            const float acc[3] = {a_r, a_g, a_b};
+            float g[3], term = 0.f;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float y = __shfl_down(suf, off);
-            if (lane + off < 64) suf += y;
+            for (int k = 0; k < 3; ++k) {
+                const float c = acc[k] + (hl.bg ? in_bg[k] : 0.0f) * om;
+                const float diff = c - in_gt[k];
+                term += sl1(diff, 5e-2f);
+                g[k] = sl1_grad(diff, 5e-2f) * hl.inv_bs * hl.w0 * hl.loss_scale;
+            }
+            gc0 = g[0]; gc1 = g[1]; gc2 = g[2];
+            if (l == 0) terms[r] = term;
         }
-        const float later = bcarry + (suf - qv);
-        if (valid) {
-            const float delta = t1 - t0;
-            d_sig[start + i] = delta * ((G * T) * expf(-s * delta) - later);
+        if (cnt == 0) return;
+        // ---- backward (composite_bwd_kernel; geometry: with the distortion-loss gradient formed here, colour: d rgb only)
+        const float totW = a_op, totWM = a_d;
+        float sufW = 0.f, sufWM = 0.f, bcarry = 0.f;
+        for (int q = n_chunks - 1; q >= 0; --q) {
+            const int i = q * W + l;
+            const bool valid = i < cnt;
+            float w = 0.f, T = 0.f, t0 = 0.f, t1 = 0.f, s = 0.f;
+            if (q == n_chunks - 1) { w = w_l; T = T_l; t0 = t0_l; t1 = t1_l; s = s_l; }
+            else if (valid) { w = weights[start + i]; T = trans[start + i]; t0 = ts[start + i]; t1 = te[start + i]; s = sig[start + i]; }
+            if (APP) {
+                if (valid) { d_rgb[3 * (start + i)] = w * gc0; d_rgb[3 * (start + i) + 1] = w * gc1; d_rgb[3 * (start + i) + 2] = w * gc2; }
+                continue;
+            }
+            float G = 0.f;
+            if (valid) G = gop + gd * ((t0 + t1) * 0.5f);
+            {
+                const float m = (t0 + t1) * 0.5f, wm = w * m;
+                float sw = w, swm = wm;
+#pragma unroll
+                for (int off = 1; off < W; off <<= 1) {
+                    const float y0 = __shfl_down(sw, off, W), y1 = __shfl_down(swm, off, W);
+                    if (l + off < W) { sw += y0; swm += y1; }
+                }
+                const float Wsuf = sufW + (sw - w), WMsuf = sufWM + (swm - wm);
+                const float Wt = totW - Wsuf - w, WM = totWM - WMsuf - wm;
+                if (valid) G += dl_scale * ((2.0f / 3.0f) * (t1 - t0) * w + 2.0f * (m * (Wt - Wsuf) - (WM - WMsuf)));
+                sufW += __shfl(sw, 0, W); sufWM += __shfl(swm, 0, W);
+            }
+            const float qv = G * w;
+            float suf = qv;
+#pragma unroll
+            for (int off = 1; off < W; off <<= 1) {
+                const float y = __shfl_down(suf, off, W);
+                if (l + off < W) suf += y;
+            }
+            const float later = bcarry + (suf - qv);
+            if (valid) {
+                const float delta = t1 - t0;
+                d_sig[start + i] = delta * ((G * T) * expf(-s * delta) - later);
+            }
+            bcarry += __shfl(suf, 0, W);
         }
-        bcarry += __shfl(suf, 0);
-    }
+    });
 }
 
 }  // namespace perf
@@ -1114,7 +1119,7 @@ extern "C" int perf_train_head_geo(const float* sigmas, const float* rgbs, const
     PERF_REQUIRE(!rgbs || color, "perf_train_head_geo: rgbs without a colour output");
     perf::HeadLoss hl{gt_distance, noise, nullptr, ratio_dev, 1.0f / (float)global_batch, depth_weight, distortion_weight, loss_scale,
                       (int)(n_rays != global_batch)};
-    hipLaunchKernelGGL(perf::train_head_kernel<false>, ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
+    hipLaunchKernelGGL(perf::train_head_kernel<false>, perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
                        t_ends, packed_info, n_rays, hl, weights, trans, opacity, distance, color, depth_terms, distloss_per_ray, inv_n_out,
                        d_sigmas, (float*)nullptr);
     PERF_LAUNCH_CHECK("perf_train_head_geo");
@@ -1129,7 +1134,7 @@ extern "C" int perf_train_head_app(const float* sigmas, const float* rgbs, const
     PERF_REQUIRE(sigmas && rgbs && t_starts && t_ends && packed_info && gt_color && weights && trans && opacity && distance && color &&
                  color_terms && d_rgbs, "NULL pointer");
     perf::HeadLoss hl{gt_color, nullptr, bg_color, nullptr, 1.0f / (float)(global_batch * 3), color_weight, 0.0f, loss_scale, 0};
-    hipLaunchKernelGGL(perf::train_head_kernel<true>, ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
+    hipLaunchKernelGGL(perf::train_head_kernel<true>, perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
                        t_ends, packed_info, n_rays, hl, weights, trans, opacity, distance, color, color_terms, (float*)nullptr, (float*)nullptr,
                        (float*)nullptr, d_rgbs);
     PERF_LAUNCH_CHECK("perf_train_head_app");

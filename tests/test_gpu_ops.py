@@ -1327,13 +1327,16 @@ def test_lane_per_ray_marching_of_large_shared_lattice_launches_equals_wave_per_
                     assert int(pk_a[:, 1].sum()) == S if cap_cut == 0 else int(pk_a[:, 1].sum()) == S
 
 
+@pytest.mark.parametrize('maxc', [200, 17, 5])
 @pytest.mark.parametrize('tail_empty,data_parallel', [(False, False), (True, False), (False, True)])
-def test_train_head_in_one_launch_equals_the_three_launch_chains(ops, tail_empty, data_parallel):
-    """perf_train_head_geo / _app (compositing forward -> loss head -> compositing backward, one wavefront per ray, ONE launch)
-    against the chains they replace, on rays of 0 / 1 / 64 / 65 / up to 200 samples: every per-sample and per-ray output and the
-    gradient the field backward starts from bit for bit; the loss values (now summed by the reader from per-ray terms) to
-    summation order.  tail_empty: the last rays hold no sample (flatten_eff_distloss's normaliser is the last ray that does)."""
-    packed, ri, ts, te, sig, rgb = _packed_case(21)
+def test_train_head_in_one_launch_equals_the_three_launch_chains(ops, tail_empty, data_parallel, maxc):
+    """perf_train_head_geo / _app (compositing forward -> loss head -> compositing backward, ONE launch; a wavefront per ray, or -- for the
+    few samples per ray a training batch keeps late in an episode -- 16- and 4-lane ray teams) against the chains they replace, on rays of
+    0 / 1 / 64 / 65 / up to 200 samples (maxc = 200: wavefronts) and on rays of up to 16 / 4 samples around those (quarter waves, 4-lane
+    teams, and the groups that hold a longer ray): every per-sample and per-ray output and the gradient the field backward starts from bit
+    for bit; the loss values (now summed by the reader from per-ray terms) to summation order.  tail_empty: the last rays hold no sample
+    (flatten_eff_distloss's normaliser is the last ray that does)."""
+    packed, ri, ts, te, sig, rgb = _packed_case(21, R=300 if maxc == 200 else 1200, maxc=maxc)
     R = packed.shape[0]
     if tail_empty:          # rays R-70.. lose their samples: the normaliser sits more than one ballot back from the end
         keep = R - 70
