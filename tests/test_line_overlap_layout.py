@@ -128,6 +128,40 @@ def test_a_hashed_level_keeps_super_blocks_together_and_a_cell_in_fewer_lines(lo
     assert inside.sum() > 1000 and (lines[inside] == 1).all()
 
 
+def test_the_oracles_encode_of_a_canonical_table_is_continuous_across_every_cell_face():
+    """oracle/perf_oracle.py:hashgrid_encode over a canonically filled line_overlap table: points a hair left and right of cell faces along
+    x -- run boundaries (every third face), super-block boundaries, dense and hashed levels -- encode to the same features up to the step
+    across the face; the raw random table jumps at the run boundaries.  (The GPU twin: tests/test_gpu_ops.py::test_overlapping_runs_hold_one_field.)"""
+    n_levels = 10
+    cfg, lv = _levels(20, (3, 3, 2), 64, n_levels=n_levels)
+    assert (lv.local & ~lv.hashed).any() and (lv.local & lv.hashed).any()
+    rng = np.random.default_rng(11)
+    raw = (rng.random((lv.total, 2), dtype=np.float32) * 2 - 1)
+    canon = O.canonical_overlap_fill(raw, lv)
+    eps = 2e-3
+    for l in np.flatnonzero(lv.local):
+        sc, r = float(lv.scale[l]), int(lv.res[l])
+        n = 1500
+        v = np.stack([rng.integers(1, r - 1, n), rng.integers(0, r - 1, n), rng.integers(0, r - 1, n)], -1).astype(np.float64)
+        yz = rng.random((n, 2)) * 0.8 + 0.1
+        def pts(dx):
+            p = v.copy(); p[:, 0] += dx; p[:, 1:] += yz
+            return np.clip((p - 0.5) / sc, 0.0, 1.0).astype(np.float32)
+        xl, xr = pts(-eps), pts(+eps)
+        gl, gr = np.floor(O.grid_pos(xl, lv.scale[l]))[:, 0], np.floor(O.grid_pos(xr, lv.scale[l]))[:, 0]
+        ok = (gr == gl + 1) & (gr == v[:, 0])
+        assert ok.sum() > 0.9 * n
+        for table, one_field in ((canon, True), (raw, False)):
+            fl = O.hashgrid_encode(torch.from_numpy(xl), torch.from_numpy(table), lv).numpy()[:, 2 * l:2 * l + 2]
+            fr = O.hashgrid_encode(torch.from_numpy(xr), torch.from_numpy(table), lv).numpy()[:, 2 * l:2 * l + 2]
+            jump = np.abs(fl - fr).max(-1)[ok]
+            if one_field:
+                assert jump.max() < 2 * eps * 2 * 2 + 1e-5, (l, jump.max())
+            else:
+                third = (v[:, 0][ok] % 3 == 0)
+                assert jump[third].mean() > 0.1 and jump[~third].max() < 2 * eps * 2 * 2 + 1e-5
+
+
 def test_the_default_super_block_shape_is_the_layouts_own():
     from perf_amd.grid import SB_SHIFT
     for layout in ('line_local', 'line_overlap'):

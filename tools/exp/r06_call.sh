@@ -1,13 +1,11 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06bz
+O=$R/gpurun_out/r06ca
 rm -rf $O; mkdir -p $O
 cd $R
-for i in 1 2; do
-( timeout 900 python bench.py --no-config5 --no-render-block --no-config4 ) > $O/bench_$i.log 2> $O/bench_$i.err
-python - <<PY
-import json
-t=open('$O/bench_$i.log').read()
-d=json.loads([l for l in t.splitlines() if l.startswith('{')][-1])
-print(d['ms_per_step'], d['faithful'], d['summary'].get('episode_train_seconds'), d['summary'].get('episode_psnr_db'), d['train_app']['ms_per_step'])
-PY
-done
+( time timeout 3000 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+( time timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+( time timeout 900 python bench.py ) > $O/bench.log 2> $O/bench.err; tail -c 300 $O/bench.log; tail -4 $O/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_ep -o kt -- python $R/tools/train_episode.py > $O/kt_ep.log 2>&1
+cd $R
+find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete
