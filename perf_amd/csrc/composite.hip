@@ -91,7 +91,7 @@ __device__ __forceinline__ void for_rays_of_wave(int64_t n_rays, CountFn count_o
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if ((int64_t)gridDim.x * 16 < n_rays) {
-        // packed by sixteen (n_rays / 16 waves: frames of half a million rays): wave w serves rays 16w..16w+15 -- 4-lane teams when all
+        // packed by sixteen (n_rays / 16 waves: frames of half a million rays and more): wave w serves rays 16w..16w+15 -- 4-lane teams when all
         // sixteen hold <= 4 samples (the frames of a trained scene: a sample or two per ray), else its four groups of four one after the
         // other as below.  (With n_rays / 4 waves three of every four waves loaded sixteen counts and retired.)  Same bits: same teams.
         const int64_t g16 = w * 16;
@@ -145,7 +145,10 @@ __device__ __forceinline__ void for_rays_of_wave(int64_t n_rays, CountFn count_o
     }
 }
 static inline dim3 team_grid(int64_t n_rays) {
-    if (n_rays / 16 >= 2 * kPackedMinWaves) return dim3((unsigned)div_up(n_rays, 64));       // packed by sixteen: >= 262,144 rays
+    // packed by sixteen from 524,288 rays on (a 512 x 1024 frame as one batch).  Measured at 262,144 rays (tools/exp/team_shape_ab.py): rays
+    // of two samples gain (visibility 13 -> 9 us, compositing 19 -> 13), rays of 128 samples LOSE (137 -> 159 us, 307 -> 334: sixteen rays
+    // one after the other per wave leave fewer requests in flight) -- the eval render's 262,144-ray batches keep four rays per wave
+    if (n_rays / 16 >= 4 * kPackedMinWaves) return dim3((unsigned)div_up(n_rays, 64));
     return dim3((unsigned)(n_rays / 4 >= kPackedMinWaves ? div_up(n_rays, 16) : div_up(n_rays, 4)));
 }
 

@@ -433,16 +433,16 @@ def test_visibility_and_compaction_bit_exact(ops):
 
 def test_team_kernels_give_the_same_bits_in_every_launch_shape(ops):
     """The ray-team kernels (visibility, compaction, compositing) pick their launch shape from the number of rays: one wave per ray,
-    four rays per wave, and -- from 262,144 rays on: an eval frame -- sixteen rays per wave (4-lane teams when all sixteen hold <= 4
-    samples, else their four groups of four one after the other).  A frame-sized launch whose stretches of rays are short (0-4 samples),
-    medium (<= 16), long (up to 150) and mixed gives, in two halves (four rays per wave) and ray by ray in small pieces (one wave per ray),
-    the same bits."""
+    four rays per wave, and -- from 524,288 rays on: a 512 x 1024 eval frame as one batch -- sixteen rays per wave (4-lane teams when all
+    sixteen hold <= 4 samples, else their four groups of four one after the other).  A frame-sized launch whose stretches of rays are short
+    (0-4 samples), medium (<= 16), long (up to 150) and mixed gives, in two halves (four rays per wave) and ray by ray in small pieces (one
+    wave per ray), the same bits."""
     g = torch.Generator().manual_seed(77)
-    R = 270000
+    R = 530000
     counts = torch.randint(0, 5, (R,), generator=g)                       # short rays ...
     seg = torch.arange(R) // 4096
     counts = torch.where(seg % 5 == 1, torch.randint(0, 17, (R,), generator=g), counts)            # ... stretches of medium ones
-    counts = torch.where(seg % 5 == 2, torch.randint(0, 150, (R,), generator=g), counts)           # ... of long ones
+    counts = torch.where(seg % 10 == 2, torch.randint(0, 150, (R,), generator=g), counts)          # ... of long ones
     lone = torch.randint(0, R, (300,), generator=g)
     counts[lone] = torch.randint(5, 90, (300,), generator=g)              # ... and single heavier rays among the short ones
     starts = torch.cumsum(counts, 0) - counts

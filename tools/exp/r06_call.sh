@@ -1,11 +1,16 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06ca
+O=$R/gpurun_out/r06cc
 rm -rf $O; mkdir -p $O
 cd $R
-( time timeout 3000 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; tail -5 $O/pytest.log
-( time timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) > $O/smoke.log 2>&1; tail -3 $O/smoke.log
-( time timeout 900 python bench.py ) > $O/bench.log 2> $O/bench.err; tail -c 300 $O/bench.log; tail -4 $O/bench.err
-cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_ep -o kt -- python $R/tools/train_episode.py > $O/kt_ep.log 2>&1
-cd $R
-find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete
+( timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_config4.py -m gpu -x -q -k "team or visib or compos or compact or config4 or frame" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+timeout 600 python tools/exp/team_shape_ab.py 2>&1 | grep -v amdgpu.ids > $O/ab.log; python -c "
+import json; d=json.load(open('$O/ab.log')); print({k:(v['perf_visibility_count'],v['perf_composite_fwd']) for k,v in d.items()})"
+for i in 1 2; do
+timeout 600 python tools/render_dense.py --poses 300 --batch 524288 > $O/rd_$i.log 2>&1
+python - <<PY
+import json
+t=open('$O/rd_$i.log').read()
+d=json.loads(t[t.rindex('\n{'):] if '\n{' in t else t[t.index('{'):])
+print({k: d[k] for k in d if 'frames_per_s' in k or 'rgb_sum' in k})
+PY
+done
