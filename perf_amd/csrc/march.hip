@@ -747,8 +747,8 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float* __restric
 }
 
 // Large launches on ONE lattice (eval frames, as march_count_shared_kernel): a wave takes 64 rays.  Every ray's LANE reads its count and
-// offset and stores its packed_info pair -- coalesced -- and the wave then walks only the rays that HAVE samples to write, all 64 lanes
-// on the 64 intervals of a chunk.  On an eval frame of a trained scene most rays end inside their head (the two-phase sampler's tail
+// offset and stores its packed_info pair -- coalesced -- and the wave then walks only the rays that HAVE samples to write, four at a
+// time on quarter waves (or one after the other with all 64 lanes when one of the four writes more than 16 samples).  On an eval frame of a trained scene most rays end inside their head (the two-phase sampler's tail
 // counts are zero): march_write_kernel gave each of them a quarter wave that loaded two words, stored two and retired.  Same rows,
 // same values.
 __global__ __launch_bounds__(256) void march_write_shared_kernel(int64_t n_rays, float step, int32_t mask_words, const uint64_t* __restrict__ masks,
@@ -769,10 +769,9 @@ __global__ __launch_bounds__(256) void march_write_shared_kernel(int64_t n_rays,
         packed[2 * rl] = off_mine; packed[2 * rl + 1] = cnt_mine;
     }
     const int nlw = n_live_words(mask_words);
-    for (uint64_t rays = __ballot(cnt_mine > 0); rays; rays &= rays - 1) {
-        const int s = __ffsll((unsigned long long)rays) - 1;
-        const int64_t r = r_base + s;
-        const int32_t cnt = __builtin_amdgcn_readlane(cnt_mine, s), off = __builtin_amdgcn_readlane(off_mine, s);
+    // one ray's samples, by a team of W lanes that walks the 64 bits of a mask word in 64 / W steps (march_write_kernel's loop)
+    auto walk = [&](auto wc, int64_t r, int32_t cnt, int32_t off, int l) {
+        constexpr int W = decltype(wc)::value;
         int64_t run = (int64_t)off - rank_lo;            // output position of rank 0 (may lie before `off`)
         const int64_t end = (int64_t)off + cnt;
         const uint64_t* rec = masks + r * (int64_t)(mask_words + nlw);
@@ -780,10 +779,12 @@ __global__ __launch_bounds__(256) void march_write_shared_kernel(int64_t n_rays,
             for (uint64_t todo = rec[g]; todo && run < end; todo &= todo - 1) {
                 const int qq = g * 64 + (__ffsll((unsigned long long)todo) - 1);
                 const uint64_t m = rec[nlw + qq];
-                if ((m >> lane) & 1ull) {
-                    const int64_t pos = run + __popcll(m & ((1ull << lane) - 1ull));
+                for (int bit = l; bit < 64; bit += W) {
+                    if (!((m >> bit) & 1ull)) continue;
+                    const uint64_t below = (bit == 0) ? 0ull : (~0ull >> (64 - bit));
+                    const int64_t pos = run + __popcll(m & below);
                     if (pos >= off && pos < end) {
-                        const int k = qq * 64 + lane;
+                        const int k = qq * 64 + bit;
                         const float a = lat_full[k];
                         const float b = lattice_mode == PERF_LATTICE_REPEATED ? add_rn(a, step) : lattice_single(t0_base, k + 1, step);
                         ts[pos] = a;
@@ -794,6 +795,27 @@ __global__ __launch_bounds__(256) void march_write_shared_kernel(int64_t n_rays,
                 }
                 run += __popcll(m);
             }
+        }
+    };
+    // the rays that have samples, four at a time: a quarter wave each while all four write at most 16 samples (the tail of a two-phase
+    // sampler, a thin shell), else one after the other with all 64 lanes
+    for (uint64_t rays = __ballot(cnt_mine > 0); rays;) {
+        int sq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sq[j] = -1;
+            if (rays) { sq[j] = __ffsll((unsigned long long)rays) - 1; rays &= rays - 1; }
+        }
+        const int quarter = lane >> 4;
+        const int s_mine = quarter == 0 ? sq[0] : (quarter == 1 ? sq[1] : (quarter == 2 ? sq[2] : sq[3]));
+        const int32_t cnt_q = __shfl(cnt_mine, s_mine < 0 ? 0 : s_mine), off_q = __shfl(off_mine, s_mine < 0 ? 0 : s_mine);
+        if (__ballot(s_mine >= 0 && cnt_q > 16) == 0ull) {
+            if (s_mine >= 0) walk(std::integral_constant<int, 16>{}, r_base + s_mine, cnt_q, off_q, lane & 15);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sq[j] >= 0)
+                    walk(std::integral_constant<int, 64>{}, r_base + sq[j], __builtin_amdgcn_readlane(cnt_mine, sq[j]), __builtin_amdgcn_readlane(off_mine, sq[j]), lane);
         }
     }
 }
