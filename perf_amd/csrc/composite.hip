@@ -77,7 +77,7 @@ __device__ __forceinline__ unsigned long long team_ballot(bool p) {
     return (b >> (((threadIdx.x & 63) / W) * W)) & ((1ull << W) - 1ull);
 }
 
-// Three launch shapes, told apart by the grid size (team_grid; the third, packed by sixteen, is described in for_rays_of_wave):
+// Two launch shapes, told apart by the grid size (team_grid); a third one -- sixteen rays per wave, BY16 -- has its own instantiations:
 //  * packed (n_rays / 4 waves; chosen when that still fills the GPU, i.e. eval batches): wave w serves rays 4w..4w+3 --
 //    a quarter wave each when all four hold <= 16 samples, one after the other with all 64 lanes otherwise;
 //  * one wave per ray (small batches: 8,192 training rays of 128 samples must not lose three quarters of their waves): the
@@ -86,14 +86,16 @@ __device__ __forceinline__ unsigned long long team_ballot(bool p) {
 // Calls body(Team<4, 16 or 64>, ray, lane-in-team).
 constexpr int64_t kPackedMinWaves = 8192;       // 256 CUs x 32 waves
 
-template <typename CountFn, typename Body>
+// BY16 (its own kernel instantiations, launched with n_rays / 16 waves from 524,288 rays on -- a 512 x 1024 frame as one batch): wave w serves
+// rays 16w..16w+15, with 4-lane teams when all sixteen hold <= 4 samples (with n_rays / 4 waves three of every four waves of such a frame
+// loaded sixteen counts and retired), else its four groups of four one after the other.  NOT a branch of the other shapes' code: with the
+// three bodies instantiated a second time, or with the shapes folded into one loop, the kernels ran 12-40 % slower on rays of 128 samples
+// in EVERY shape (tools/exp/team_shape_ab.py, three library builds: visibility_count 14.0 -> 19.5 us at 32,768 rays).
+template <bool BY16 = false, typename CountFn, typename Body>
 __device__ __forceinline__ void for_rays_of_wave(int64_t n_rays, CountFn count_of, Body body) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if ((int64_t)gridDim.x * 16 < n_rays) {
-        // packed by sixteen (n_rays / 16 waves: frames of half a million rays and more): wave w serves rays 16w..16w+15 -- 4-lane teams when all
-        // sixteen hold <= 4 samples (the frames of a trained scene: a sample or two per ray), else its four groups of four one after the
-        // other as below.  (With n_rays / 4 waves three of every four waves loaded sixteen counts and retired.)  Same bits: same teams.
+    if constexpr (BY16) {
         const int64_t g16 = w * 16;
         if (g16 >= n_rays) return;
         const int64_t r16 = g16 + (lane >> 2);
@@ -145,19 +147,22 @@ __device__ __forceinline__ void for_rays_of_wave(int64_t n_rays, CountFn count_o
     }
 }
 static inline dim3 team_grid(int64_t n_rays) {
-    // packed by sixteen from 524,288 rays on (a 512 x 1024 frame as one batch).  Measured at 262,144 rays (tools/exp/team_shape_ab.py): rays
-    // of two samples gain (visibility 13 -> 9 us, compositing 19 -> 13), rays of 128 samples LOSE (137 -> 159 us, 307 -> 334: sixteen rays
-    // one after the other per wave leave fewer requests in flight) -- the eval render's 262,144-ray batches keep four rays per wave
-    if (n_rays / 16 >= 4 * kPackedMinWaves) return dim3((unsigned)div_up(n_rays, 64));
     return dim3((unsigned)(n_rays / 4 >= kPackedMinWaves ? div_up(n_rays, 16) : div_up(n_rays, 4)));
 }
+// the BY16 instantiations take launches of this many rays and more (measured at 262,144 rays, tools/exp/team_shape_ab.py: rays of two
+// samples gain -- visibility 13 -> 9 us, compositing 19 -> 13 --, rays of 128 samples lose 9-16 %: sixteen rays one after the other per
+// wave leave fewer requests in flight; the eval render's batches stay with four rays per wave)
+constexpr int64_t kBy16MinRays = 16 * 4 * kPackedMinWaves;          // 524,288
+static inline bool team_by16(int64_t n_rays) { return n_rays >= kBy16MinRays; }
+static inline dim3 team_grid16(int64_t n_rays) { return dim3((unsigned)div_up(n_rays, 64)); }
 
+template <bool BY16>
 __global__ __launch_bounds__(256) void visibility_count_kernel(const float* __restrict__ sig, const float* __restrict__ ts,
                                                                const float* __restrict__ te, const int32_t* __restrict__ packed,
                                                                int64_t n_rays, float thr, int32_t* __restrict__ new_counts,
                                                                float* __restrict__ exsum, const int32_t* __restrict__ march_counts,
                                                                int32_t head_k, int32_t* __restrict__ tail_counts) {
-    for_rays_of_wave(n_rays, [&](int64_t r) { return packed[2 * r + 1]; }, [&](auto team, int64_t r, int l) {
+    for_rays_of_wave<BY16>(n_rays, [&](int64_t r) { return packed[2 * r + 1]; }, [&](auto team, int64_t r, int l) {
         constexpr int W = decltype(team)::width;
         const int64_t start = packed[2 * r];
         const int cnt = packed[2 * r + 1];
@@ -225,6 +230,7 @@ __global__ __launch_bounds__(256) void compact_prefix_kernel(const int32_t* __re
         for (int i = lane; i < cnt; i += 64) fc.src_index_out[dst + i] = (int32_t)(src + i);
 }
 
+template <bool BY16>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ sig, const float* __restrict__ rgb,
                                                             const float* __restrict__ ts, const float* __restrict__ te,
                                                             const int32_t* __restrict__ packed, int64_t n_rays,
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
                                                             float* __restrict__ alphas, float* __restrict__ opacity,
                                                             float* __restrict__ distance, float* __restrict__ color,
                                                             float* __restrict__ distloss) {
-    for_rays_of_wave(n_rays, [&](int64_t r) { return packed[2 * r + 1]; }, [&](auto team, int64_t r, int l) {
+    for_rays_of_wave<BY16>(n_rays, [&](int64_t r) { return packed[2 * r + 1]; }, [&](auto team, int64_t r, int l) {
         constexpr int TW = decltype(team)::width;
         const int64_t start = packed[2 * r];
         const int cnt = packed[2 * r + 1];
@@ -450,7 +456,9 @@ extern "C" int perf_visibility_count(const float* sigmas, const float* t_starts,
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && new_counts, "NULL pointer");
     PERF_REQUIRE(!tail_counts || (march_counts && head_samples >= 1), "perf_visibility_count: tail counts need the march counts and the head size");
-    hipLaunchKernelGGL(visibility_count_kernel, team_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
+    if (team_by16(n_rays)) hipLaunchKernelGGL(visibility_count_kernel<true>, team_grid16(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
+                       packed_info, n_rays, thr, new_counts, exsum, march_counts, head_samples, tail_counts);
+    else hipLaunchKernelGGL(visibility_count_kernel<false>, team_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, t_starts, t_ends,
                        packed_info, n_rays, thr, new_counts, exsum, march_counts, head_samples, tail_counts);
     PERF_LAUNCH_CHECK("perf_visibility_count");
     return PERF_OK;
@@ -483,7 +491,9 @@ extern "C" int perf_composite_fwd(const float* sigmas, const float* rgbs, const 
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info, "NULL pointer");
-    hipLaunchKernelGGL(composite_fwd_kernel, team_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
+    if (team_by16(n_rays)) hipLaunchKernelGGL(composite_fwd_kernel<true>, team_grid16(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
+                       t_ends, packed_info, n_rays, weights, trans, alphas, opacity, distance, color, (float*)nullptr);
+    else hipLaunchKernelGGL(composite_fwd_kernel<false>, team_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
                        t_ends, packed_info, n_rays, weights, trans, alphas, opacity, distance, color, (float*)nullptr);
     PERF_LAUNCH_CHECK("perf_composite_fwd");
     return PERF_OK;
@@ -495,7 +505,9 @@ extern "C" int perf_composite_distloss_fwd(const float* sigmas, const float* rgb
     PERF_REQUIRE(n_rays >= 0, "n_rays < 0");
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_info && distloss_per_ray, "NULL pointer");
-    hipLaunchKernelGGL(composite_fwd_kernel, team_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
+    if (team_by16(n_rays)) hipLaunchKernelGGL(composite_fwd_kernel<true>, team_grid16(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
+                       t_ends, packed_info, n_rays, weights, trans, (float*)nullptr, opacity, distance, color, distloss_per_ray);
+    else hipLaunchKernelGGL(composite_fwd_kernel<false>, team_grid(n_rays), dim3(256), 0, as_stream(stream), sigmas, rgbs, t_starts,
                        t_ends, packed_info, n_rays, weights, trans, (float*)nullptr, opacity, distance, color, distloss_per_ray);
     PERF_LAUNCH_CHECK("perf_composite_distloss_fwd");
     return PERF_OK;
@@ -601,8 +613,9 @@ struct TwoSource {
     const float* sig_t; const float* ts_t; const float* te_t; const int32_t* packed_t;
 };
 
+template <bool BY16>
 __global__ __launch_bounds__(256) void visibility_count2_kernel(TwoSource src, int64_t n_rays, float thr, int32_t* __restrict__ new_counts) {
-    for_rays_of_wave(n_rays, [&](int64_t r) { return src.packed_h[2 * r + 1] + src.packed_t[2 * r + 1]; }, [&](auto team, int64_t r, int l) {
+    for_rays_of_wave<BY16>(n_rays, [&](int64_t r) { return src.packed_h[2 * r + 1] + src.packed_t[2 * r + 1]; }, [&](auto team, int64_t r, int l) {
         constexpr int TW = decltype(team)::width;
         const int64_t sh = src.packed_h[2 * r], st = src.packed_t[2 * r];
         const int ch = src.packed_h[2 * r + 1], ct = src.packed_t[2 * r + 1];
@@ -629,6 +642,7 @@ __global__ __launch_bounds__(256) void visibility_count2_kernel(TwoSource src, i
     });
 }
 
+template <bool BY16>
 __global__ __launch_bounds__(256) void compact_prefix2_kernel(TwoSource src, const float* __restrict__ x01_h, const uint8_t* __restrict__ sel_h,
                                                               const float* __restrict__ x01_t, const uint8_t* __restrict__ sel_t,
                                                               const int32_t* __restrict__ new_counts, const int32_t* __restrict__ new_offsets,
@@ -636,7 +650,7 @@ __global__ __launch_bounds__(256) void compact_prefix2_kernel(TwoSource src, con
                                                               float* __restrict__ ts_out, float* __restrict__ te_out, float* __restrict__ sig_out,
                                                               float* __restrict__ x01_out, uint8_t* __restrict__ sel_out,
                                                               int32_t* __restrict__ packed_out, FeatCopy fc) {
-    for_rays_of_wave(n_rays, [&](int64_t r) { return new_counts[r]; }, [&](auto team, int64_t r, int l) {
+    for_rays_of_wave<BY16>(n_rays, [&](int64_t r) { return new_counts[r]; }, [&](auto team, int64_t r, int l) {
         constexpr int TW = decltype(team)::width;
         const int64_t sh = src.packed_h[2 * r], st = src.packed_t[2 * r];
         const int ch = src.packed_h[2 * r + 1];
@@ -684,7 +698,8 @@ extern "C" int perf_visibility_count2(const float* sig_h, const float* ts_h, con
     if (n_rays == 0) return PERF_OK;
     PERF_REQUIRE(packed_h && packed_t && new_counts, "NULL pointer");
     perf::TwoSource src{sig_h, ts_h, te_h, packed_h, sig_t, ts_t, te_t, packed_t};
-    hipLaunchKernelGGL(perf::visibility_count2_kernel, perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, n_rays, thr, new_counts);
+    if (perf::team_by16(n_rays)) hipLaunchKernelGGL(perf::visibility_count2_kernel<true>, perf::team_grid16(n_rays), dim3(256), 0, perf::as_stream(stream), src, n_rays, thr, new_counts);
+    else hipLaunchKernelGGL(perf::visibility_count2_kernel<false>, perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, n_rays, thr, new_counts);
     PERF_LAUNCH_CHECK("perf_visibility_count2");
     return PERF_OK;
 }
@@ -703,7 +718,12 @@ extern "C" int perf_compact_prefix2(const float* sig_h, const float* ts_h, const
     PERF_REQUIRE(packed_h && packed_t && new_counts && new_offsets && packed_out, "NULL pointer");
     PERF_REQUIRE(capacity == 0 || (ray_indices_out && ts_out && te_out), "NULL sample arrays");
     perf::TwoSource src{sig_h, ts_h, te_h, packed_h, sig_t, ts_t, te_t, packed_t};
-    hipLaunchKernelGGL(perf::compact_prefix2_kernel, perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, x01_h, sel_h,
+    if (perf::team_by16(n_rays)) hipLaunchKernelGGL(perf::compact_prefix2_kernel<true>, perf::team_grid16(n_rays), dim3(256), 0, perf::as_stream(stream), src, x01_h, sel_h,
+                       x01_t, sel_t, new_counts, new_offsets, n_rays, capacity, ray_indices_out, ts_out, te_out, sig_out, x01_out,
+                       sel_out, packed_out,
+                       perf::FeatCopy{(const uint32_t*)feat_h, feat_stride_h, (const uint32_t*)feat_t, feat_stride_t, (uint32_t*)feat_out,
+                                      feat_stride_out, n_levels});
+    else hipLaunchKernelGGL(perf::compact_prefix2_kernel<false>, perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), src, x01_h, sel_h,
                        x01_t, sel_t, new_counts, new_offsets, n_rays, capacity, ray_indices_out, ts_out, te_out, sig_out, x01_out,
                        sel_out, packed_out,
                        perf::FeatCopy{(const uint32_t*)feat_h, feat_stride_h, (const uint32_t*)feat_t, feat_stride_t, (uint32_t*)feat_out,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Ray-team kernels on heavy rays (the eval render's batches: 262,144 rays x 128 samples) in the two launch shapes: 262,144 rays take the
-sixteen-rays-per-wave shape, 262,143 the four-rays-per-wave one (composite.hip:team_grid).  ms per launch, HIP events."""
+"""Ray-team kernels (composite.hip:for_rays_of_wave / team_grid) on rays of 128 and of 2 samples at 32,768 rays (the eval render's batches), just
+below / at 262,144 rays and at 524,288 (sixteen rays per wave from there on).  ms per launch, HIP events."""
 import sys, json
 sys.path.insert(0, '.')
 import torch
@@ -19,7 +19,7 @@ def case(R, spp, seed=0):
 
 out = {}
 for spp in (128, 2):
-    for R in (262143, 262144):
+    for R in (32768, 262143, 262144, 524288):
         packed, ts, te, sig, rgb = case(R, spp)
         for _ in range(3):
             nc = ops.visibility_count(sig, ts, te, packed, 1e-4); ops.composite_fwd(sig, rgb, ts, te, packed); ops.compact_prefix(packed, nc, ts, te, sig, capacity=R * spp)
