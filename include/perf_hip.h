@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 11
+#define PERF_ABI_VERSION 12
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -595,14 +595,17 @@ int perf_app_loss(const float* opacity, const float* color, const float* bg_colo
  * depth = sum(depth_terms) / global_batch, distortion = sum(distloss_per_ray) * inv_n_out[0], colour = sum(color_terms) /
  * (3 global_batch) -- left to whoever reads them.  A local batch smaller than global_batch (data parallel) normalises the
  * distortion loss by the global batch like perf_geo_loss.  noise, ratio_dev, bg_color, rgbs (geometry), color (geometry),
- * inv_n_out may be NULL. */
+ * inv_n_out may be NULL.  sample_rows (ABI 12): the rows of the per-sample arrays -- the capacity in sync-free mode, a HINT about the
+ * samples per ray that only selects the launch shape: fewer than 32 rows per ray (or <= 0: unknown) -> rays of <= 16 / <= 4 samples
+ * are served by 16- / 4-lane teams (a training batch late in an episode keeps a sample or two per ray), else a wavefront per ray.
+ * The same bits either way. */
 int perf_train_head_geo(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
-                        const int32_t* packed_info, int64_t n_rays, const float* gt_distance, const float* noise,
+                        const int32_t* packed_info, int64_t n_rays, int64_t sample_rows, const float* gt_distance, const float* noise,
                         int64_t global_batch, float depth_weight, float distortion_weight, const float* ratio_dev,
                         float loss_scale, float* weights, float* trans, float* opacity, float* distance, float* color,
                         float* depth_terms, float* distloss_per_ray, float* inv_n_out, float* d_sigmas, void* stream);
 int perf_train_head_app(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
-                        const int32_t* packed_info, int64_t n_rays, const float* bg_color, const float* gt_color,
+                        const int32_t* packed_info, int64_t n_rays, int64_t sample_rows, const float* bg_color, const float* gt_color,
                         int64_t global_batch, float color_weight, float loss_scale, float* weights, float* trans,
                         float* opacity, float* distance, float* color, float* color_terms, float* d_rgbs, void* stream);
 

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libperf_hip.so')
 
-ABI_VERSION = 11         # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
+ABI_VERSION = 12         # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
 MAX_LEVELS = 24
 DTYPE_BF16, DTYPE_FP16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
@@ -109,8 +109,8 @@ _SIGS = {
     'perf_distloss_bwd': (c_int, [P, P, P, P, c_int64, c_float, P, P, P]),
     'perf_geo_loss': (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_float, c_float, P, c_float, P, P, P, P, P]),
     'perf_app_loss': (c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, P, P, P]),
-    'perf_train_head_geo': (c_int, [P, P, P, P, P, c_int64, P, P, c_int64, c_float, c_float, P, c_float, P, P, P, P, P, P, P, P, P, P]),
-    'perf_train_head_app': (c_int, [P, P, P, P, P, c_int64, P, P, c_int64, c_float, c_float, P, P, P, P, P, P, P, P]),
+    'perf_train_head_geo': (c_int, [P, P, P, P, P, c_int64, c_int64, P, P, c_int64, c_float, c_float, P, c_float, P, P, P, P, P, P, P, P, P, P]),
+    'perf_train_head_app': (c_int, [P, P, P, P, P, c_int64, c_int64, P, P, c_int64, c_float, c_float, P, P, P, P, P, P, P, P]),
     'perf_composite_distloss_fwd': (c_int, [P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     'perf_composite_distloss_bwd': (c_int, [P, P, P, P, c_int64, P, P, P, P, P, P, c_float, P, P, P]),
     'perf_gather_supervision': (c_int, [P, c_int64, P, P, P, P, P, P, P, P, P, P, P]),

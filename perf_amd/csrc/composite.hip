@@ -937,7 +937,10 @@ struct HeadLoss {
     int data_parallel;
 };
 
-template <bool APP>
+// ray teams for batches whose per-sample arrays hold fewer than 32 rows per ray (sample_rows <= 0: unknown -> teams)
+static inline bool head_by_teams(int64_t n_rays, int64_t sample_rows) { return sample_rows <= 0 || sample_rows < 32 * n_rays; }
+
+template <bool APP, bool TEAMS>
 __global__ __launch_bounds__(256) void train_head_kernel(const float* __restrict__ sig, const float* __restrict__ rgb,
                                                          const float* __restrict__ ts, const float* __restrict__ te,
                                                          const int32_t* __restrict__ packed, int64_t n_rays, HeadLoss hl,
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(256) void train_head_kernel(const float* __restrict
     // Ray teams as in the compositing kernels (for_rays_of_wave): a training batch late in an episode keeps a sample or two per ray -- a
     // wavefront per ray then spends its ~80 cross-lane steps (six 64-wide scans and sums each way) on two live lanes; 16- and 4-lane
     // teams take 4 and 2 steps per scan inside one DPP row.  Same bits: for <= W samples the steps beyond W only ever add exact zeros.
-    for_rays_of_wave(n_rays, [&](int64_t q) { return packed[2 * q + 1]; }, [&](auto team, int64_t r, int l) {
+    auto head_of_ray = [&](auto team, int64_t r, int l) {
         constexpr int W = decltype(team)::width;
         const int64_t start = packed[2 * r];
         const int cnt = packed[2 * r + 1];
@@ -1097,7 +1100,16 @@ __global__ __launch_bounds__(256) void train_head_kernel(const float* __restrict
             }
             bcarry += __shfl(suf, 0, W);
         }
-    });
+    };
+    // TEAMS = false (chosen by the host for batches whose sample arrays hold >= 32 rows per ray: the fixed-count benchmark step, the
+    // first steps of an episode): a wavefront per ray and nothing else -- 50 registers and a third of the code; with the team shapes in the
+    // same kernel (77 registers) rays of 128 samples took 7 % (geometry) / 35 % (colour) longer
+    if constexpr (TEAMS) {
+        for_rays_of_wave(n_rays, [&](int64_t q) { return packed[2 * q + 1]; }, head_of_ray);
+    } else {
+        const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (r < n_rays) head_of_ray(Team<64>{}, r, (int)(threadIdx.x & 63));
+    }
 }
 
 }  // namespace perf
@@ -1132,7 +1144,7 @@ extern "C" int perf_app_loss(const float* opacity, const float* color, const flo
 }
 
 extern "C" int perf_train_head_geo(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
-                                   const int32_t* packed_info, int64_t n_rays, const float* gt_distance, const float* noise,
+                                   const int32_t* packed_info, int64_t n_rays, int64_t sample_rows, const float* gt_distance, const float* noise,
                                    int64_t global_batch, float depth_weight, float distortion_weight, const float* ratio_dev,
                                    float loss_scale, float* weights, float* trans, float* opacity, float* distance, float* color,
                                    float* depth_terms, float* distloss_per_ray, float* inv_n_out, float* d_sigmas, void* stream) {
@@ -1142,24 +1154,34 @@ extern "C" int perf_train_head_geo(const float* sigmas, const float* rgbs, const
     PERF_REQUIRE(!rgbs || color, "perf_train_head_geo: rgbs without a colour output");
     perf::HeadLoss hl{gt_distance, noise, nullptr, ratio_dev, 1.0f / (float)global_batch, depth_weight, distortion_weight, loss_scale,
                       (int)(n_rays != global_batch)};
-    hipLaunchKernelGGL(perf::train_head_kernel<false>, perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
-                       t_ends, packed_info, n_rays, hl, weights, trans, opacity, distance, color, depth_terms, distloss_per_ray, inv_n_out,
-                       d_sigmas, (float*)nullptr);
+    if (perf::head_by_teams(n_rays, sample_rows))
+        hipLaunchKernelGGL((perf::train_head_kernel<false, true>), perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
+                           t_ends, packed_info, n_rays, hl, weights, trans, opacity, distance, color, depth_terms, distloss_per_ray, inv_n_out,
+                           d_sigmas, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((perf::train_head_kernel<false, false>), ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
+                           t_ends, packed_info, n_rays, hl, weights, trans, opacity, distance, color, depth_terms, distloss_per_ray, inv_n_out,
+                           d_sigmas, (float*)nullptr);
     PERF_LAUNCH_CHECK("perf_train_head_geo");
     return PERF_OK;
 }
 
 extern "C" int perf_train_head_app(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
-                                   const int32_t* packed_info, int64_t n_rays, const float* bg_color, const float* gt_color,
+                                   const int32_t* packed_info, int64_t n_rays, int64_t sample_rows, const float* bg_color, const float* gt_color,
                                    int64_t global_batch, float color_weight, float loss_scale, float* weights, float* trans,
                                    float* opacity, float* distance, float* color, float* color_terms, float* d_rgbs, void* stream) {
     PERF_REQUIRE(n_rays > 0 && global_batch > 0, "perf_train_head_app: empty batch");
     PERF_REQUIRE(sigmas && rgbs && t_starts && t_ends && packed_info && gt_color && weights && trans && opacity && distance && color &&
                  color_terms && d_rgbs, "NULL pointer");
     perf::HeadLoss hl{gt_color, nullptr, bg_color, nullptr, 1.0f / (float)(global_batch * 3), color_weight, 0.0f, loss_scale, 0};
-    hipLaunchKernelGGL(perf::train_head_kernel<true>, perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
-                       t_ends, packed_info, n_rays, hl, weights, trans, opacity, distance, color, color_terms, (float*)nullptr, (float*)nullptr,
-                       (float*)nullptr, d_rgbs);
+    if (perf::head_by_teams(n_rays, sample_rows))
+        hipLaunchKernelGGL((perf::train_head_kernel<true, true>), perf::team_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
+                           t_ends, packed_info, n_rays, hl, weights, trans, opacity, distance, color, color_terms, (float*)nullptr, (float*)nullptr,
+                           (float*)nullptr, d_rgbs);
+    else
+        hipLaunchKernelGGL((perf::train_head_kernel<true, false>), ray_grid(n_rays), dim3(256), 0, perf::as_stream(stream), sigmas, rgbs, t_starts,
+                           t_ends, packed_info, n_rays, hl, weights, trans, opacity, distance, color, color_terms, (float*)nullptr, (float*)nullptr,
+                           (float*)nullptr, d_rgbs);
     PERF_LAUNCH_CHECK("perf_train_head_app");
     return PERF_OK;
 }

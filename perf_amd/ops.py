@@ -885,7 +885,7 @@ def train_head_geo(sigmas, rgbs, t_starts, t_ends, packed, gt_distance, noise, g
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     o = dict(weights=f(S), trans=f(S), opacity=f(R, 1), distance=f(R, 1), color=f(R, 3) if rgbs is not None else None, depth_terms=f(R),
              distloss_per_ray=f(R), inv_n=f(1), d_sigma=f(S))
-    _call('perf_train_head_geo', _p(_f32(sigmas, 'sigmas')), _p(rgbs), _p(t_starts), _p(t_ends), _p(packed), R,
+    _call('perf_train_head_geo', _p(_f32(sigmas, 'sigmas')), _p(rgbs), _p(t_starts), _p(t_ends), _p(packed), R, S,
           _p(_f32(gt_distance.contiguous(), 'gt')), _p(noise), int(global_batch), float(depth_weight), float(distortion_weight), _p(ratio_dev),
           float(loss_scale), _p(o['weights']), _p(o['trans']), _p(o['opacity']), _p(o['distance']), _p(o['color']), _p(o['depth_terms']),
           _p(o['distloss_per_ray']), _p(o['inv_n']), _p(o['d_sigma']), _stream())
@@ -900,7 +900,7 @@ def train_head_app(sigmas, rgbs, t_starts, t_ends, packed, bg_color, gt_color, g
     dev = sigmas.device
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     o = dict(weights=f(S), trans=f(S), opacity=f(R, 1), distance=f(R, 1), color=f(R, 3), color_terms=f(R), d_rgb=f(S, 3))
-    _call('perf_train_head_app', _p(_f32(sigmas, 'sigmas')), _p(_f32(rgbs, 'rgbs')), _p(t_starts), _p(t_ends), _p(packed), R, _p(bg_color),
+    _call('perf_train_head_app', _p(_f32(sigmas, 'sigmas')), _p(_f32(rgbs, 'rgbs')), _p(t_starts), _p(t_ends), _p(packed), R, S, _p(bg_color),
           _p(_f32(gt_color.contiguous(), 'gt')), int(global_batch), float(color_weight), float(loss_scale), _p(o['weights']), _p(o['trans']),
           _p(o['opacity']), _p(o['distance']), _p(o['color']), _p(o['color_terms']), _p(o['d_rgb']), _stream())
     return o

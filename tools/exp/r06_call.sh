@@ -1,22 +1,15 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06ch
+O=$R/gpurun_out/r06ci
 rm -rf $O; mkdir -p $O
 cd $R
-cp perf_amd/libperf_hip.so /tmp/lib_keep.so
-for v in a d a d; do
-cp tools/exp/_variants/lib_$v.so perf_amd/libperf_hip.so
-timeout 600 python tools/exp/team_shape_ab.py 2>&1 | grep -v amdgpu.ids > $O/ab_$v.log
-python -c "
-import json; d=json.load(open('$O/ab_$v.log')); print('$v', {k.replace(' samples/ray, ','x').replace(' rays',''):(v['perf_visibility_count'],v['perf_composite_fwd']) for k,v in d.items()})"
-done
-cp /tmp/lib_keep.so perf_amd/libperf_hip.so
-( timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_config4.py tests/test_gpu_scene.py -m gpu -x -q -k "team or visib or compos or compact or config4 or frame or head or render" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+( timeout 1800 python -m pytest tests/test_gpu_ops.py tests/test_gpu_scene.py tests/test_gpu_counts.py -m gpu -x -q -k "head or step or scene or train or graph or geo or app" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 for i in 1 2; do
-timeout 600 python tools/render_dense.py --poses 300 --batch 524288 > $O/rd_$i.log 2>&1
+( timeout 900 python bench.py --no-config5 --no-config4 ) > $O/bench_$i.log 2> $O/bench_$i.err
 python - <<PY
 import json
-t=open('$O/rd_$i.log').read()
-d=json.loads(t[t.rindex('\n{'):] if '\n{' in t else t[t.index('{'):])
-print({k: d[k] for k in d if 'frames_per_s' in k or 'rgb_sum' in k})
+t=open('$O/bench_$i.log').read()
+d=json.loads([l for l in t.splitlines() if l.startswith('{')][-1])
+k=d['kernels']
+print(d['ms_per_step'], d['faithful']['geo_ms_per_step'], d['faithful']['app_ms_per_step'], d['summary'].get('episode_psnr_db'), d['train_app']['ms_per_step'], {n:k[n]['ms_per_launch'] for n in ('perf_train_head_geo','perf_visibility_count')}, d['train_app']['kernels'].get('perf_train_head_app',{}).get('ms_per_launch'), d['render']['kernel_ms_per_panorama']['perf_visibility_count'], d['summary']['render_ray_samples_per_s'])
 PY
 done
