@@ -897,6 +897,9 @@ def _line(args, world, head, run, sustained, kern, ev_counts, reuse_block, other
         line[('strong' if head['scaling'] == 'weak' else 'weak')] = other_block
     if notes:
         line['notes'] = notes
+    if summ:
+        # ... and once more as the LAST key: a log that keeps only the final ~2,000 characters of the line still carries every headline scalar
+        line['summary_again'] = {'ms_per_step': line['ms_per_step'], 'roofline_frac': (line.get('roofline') or {}).get('frac'), **summ}
     return line
 
 
