@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PERF_ABI_VERSION 12
+#define PERF_ABI_VERSION 13
 
 #define PERF_OK 0
 #define PERF_E_INVALID (-1)   /* bad argument */
@@ -139,7 +139,10 @@ int perf_adam_step(float* p, float* m, float* v, float* g, void* w16, int64_t n,
  * (modules/scene/nerf.py:204-206,277-279); the caller advances *step_dev accordingly. */
 int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype,
                        const int32_t* step_dev, const float* lr_dev, const int64_t* gate_dev, float beta1, float beta2,
-                       float eps, int zero_grad, void* stream);
+                       float eps, int zero_grad, int32_t* clear_flag, void* stream);
+/* clear_flag (ABI 13, device int32, may be NULL): *clear_flag = 0 is written by this launch whether or not the update is taken --
+ * how the fixed-point overflow flag is consumed when the step's bookkeeping rode in the repair launch (perf_field_bwd_book), whose
+ * workgroups all read the flag and can therefore not clear it themselves. */
 
 /* Device-side bookkeeping of one sync-free training step, one tiny launch, issued between the backward and
  * perf_adam_step_dev.  The step is TAKEN when the batch has samples (*gate_dev > 0 or gate_dev == NULL; the reference skips
@@ -164,6 +167,27 @@ int perf_step_bookkeeping(int32_t* step_dev, const int64_t* gate_dev, int64_t* c
                           int32_t* overflow_flag, const float* remote_flags, int32_t overflow_redone, int64_t* eff_gate_out,
                           const float* schedule, int32_t n_schedule, int32_t* iter_dev, float* lr_out, float* ratio_out,
                           void* stream);
+
+/* The arguments of perf_step_bookkeeping as a POD block (ABI 13), for calls that carry the bookkeeping in one of their own launches
+ * (perf_field_bwd_book).  Same meaning field by field; every pointer device memory, every pointer may be NULL. */
+typedef struct perf_step_book {
+    int32_t* step_dev;
+    const int64_t* gate_dev;
+    int64_t* counters;
+    const int64_t* n_marched_dev;
+    const int64_t* n_kept_dev;
+    int64_t capacity;
+    int32_t* overflow_flag;
+    const float* remote_flags;
+    int64_t* eff_gate_out;
+    const float* schedule;
+    int32_t* iter_dev;
+    float* lr_out;
+    float* ratio_out;
+    int32_t n_schedule;
+    int32_t overflow_redone;
+} perf_step_book;
+int64_t perf_sizeof_step_book(void);
 
 /* ---- sample positions ------------------------------------------------------------------ */
 
@@ -334,6 +358,17 @@ int perf_field_bwd(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const f
                    const void* feat16, const int32_t* feat_index, int64_t feat_stride, const uint8_t* sel, const float* dout,
                    float* grad, int32_t fixed, int32_t redo, int32_t* overflow_flag, int32_t* headroom_state,
                    void* workspace, int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, void* stream);
+
+/* perf_field_bwd of a fixed-point field with its repair launch (fixed != 0, redo != 0 implied) that also does the step's bookkeeping
+ * (ABI 13): ONE thread of the predicated repair launch -- a dispatch that exists in every step and computes nothing in all but a handful
+ * per million -- runs perf_step_bookkeeping's arithmetic on `book` (book->overflow_flag must be this call's overflow_flag), one launch
+ * per training step fewer.  The one difference: *overflow_flag is NOT cleared (every workgroup of the repair launch reads it as its
+ * predicate); pass it to perf_adam_step_dev as clear_flag, or clear it before the next backward.  Everything book names is written
+ * before the call's last launch ends: perf_adam_step_dev reads *eff_gate_out / *step_dev / *lr_out next on the same stream. */
+int perf_field_bwd_book(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const void* w16_net,
+                        const void* feat16, const int32_t* feat_index, int64_t feat_stride, const uint8_t* sel, const float* dout,
+                        float* grad, int32_t* overflow_flag, int32_t* headroom_state, void* workspace, int64_t workspace_bytes,
+                        int64_t n, const int64_t* n_dev, int dtype, const perf_step_book* book, void* stream);
 
 /* Bytes of caller-owned workspace perf_mlp_bwd needs for n samples. */
 int64_t perf_mlp_bwd_workspace_bytes(const perf_mlp_desc* mlp, int64_t n);

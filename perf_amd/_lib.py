@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libperf_hip.so')
 
-ABI_VERSION = 12         # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
+ABI_VERSION = 13         # PERF_ABI_VERSION of include/perf_hip.h this binding was written against
 MAX_LEVELS = 24
 DTYPE_BF16, DTYPE_FP16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_EXP = 0, 1, 2
@@ -33,6 +33,13 @@ class MlpDesc(Structure):
                 ('exp_shift', c_float)]
 
 
+class StepBook(Structure):       # perf_step_book: the arguments of perf_step_bookkeeping as a POD block (perf_field_bwd_book)
+    _fields_ = [('step_dev', c_void_p), ('gate_dev', c_void_p), ('counters', c_void_p), ('n_marched_dev', c_void_p), ('n_kept_dev', c_void_p),
+                ('capacity', c_int64), ('overflow_flag', c_void_p), ('remote_flags', c_void_p), ('eff_gate_out', c_void_p),
+                ('schedule', c_void_p), ('iter_dev', c_void_p), ('lr_out', c_void_p), ('ratio_out', c_void_p), ('n_schedule', c_int32),
+                ('overflow_redone', c_int32)]
+
+
 class PerfError(RuntimeError):
     pass
 
@@ -48,9 +55,10 @@ _SIGS = {
     'perf_last_error': (c_char_p, []),
     'perf_sizeof_grid_desc': (c_int64, []),
     'perf_sizeof_mlp_desc': (c_int64, []),
+    'perf_sizeof_step_book': (c_int64, []),
     'perf_cast_params': (c_int, [P, P, c_int64, c_int, P]),
     'perf_adam_step': (c_int, [P, P, P, P, P, c_int64, c_int, c_int32, c_float, c_float, c_float, c_float, c_int, P]),
-    'perf_adam_step_dev': (c_int, [P, P, P, P, P, c_int64, c_int, P, P, P, c_float, c_float, c_float, c_int, P]),
+    'perf_adam_step_dev': (c_int, [P, P, P, P, P, c_int64, c_int, P, P, P, c_float, c_float, c_float, c_int, P, P]),
     'perf_step_bookkeeping': (c_int, [P, P, P, P, P, c_int64, P, P, c_int32, P, P, c_int32, P, P, P, P]),
     'perf_points_from_rays': (c_int, [P, P, P, P, P, POINTER(c_float), P, P, c_int64, P, P]),
     'perf_points_normalize': (c_int, [P, POINTER(c_float), P, P, c_int64, P]),
@@ -73,6 +81,7 @@ _SIGS = {
     'perf_field_infer': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, P, c_int64, P, P, c_int64, P, c_int, P]),
     'perf_field_bwd_workspace_bytes': (c_int64, [POINTER(GridDesc), POINTER(MlpDesc), c_int64, P, P, P]),
     'perf_field_bwd': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, c_int64, P, P, P, c_int32, c_int32, P, P, P, c_int64, c_int64, P, c_int, P]),
+    'perf_field_bwd_book': (c_int, [POINTER(GridDesc), POINTER(MlpDesc), P, P, P, P, c_int64, P, P, P, P, P, P, c_int64, c_int64, P, c_int, POINTER(StepBook), P]),
     'perf_mlp_bwd_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
     'perf_mlp_bwd': (c_int, [POINTER(MlpDesc), P, P, P, c_int64, P, P, P, P, P, P, c_int64, c_int64, P, c_int, P]),
     'perf_pano_raygen': (c_int, [POINTER(c_float), c_int32, c_int32, c_int32, c_int32, P, P, P]),
@@ -144,7 +153,8 @@ def load():
     if lib.perf_version() != ABI_VERSION:
         raise PerfError(f'{LIB_PATH} has ABI version {lib.perf_version()}, this binding expects {ABI_VERSION}: '
                         'rebuild with `python -m perf_amd.build --force`')
-    if lib.perf_sizeof_grid_desc() != ctypes.sizeof(GridDesc) or lib.perf_sizeof_mlp_desc() != ctypes.sizeof(MlpDesc):
+    if (lib.perf_sizeof_grid_desc() != ctypes.sizeof(GridDesc) or lib.perf_sizeof_mlp_desc() != ctypes.sizeof(MlpDesc)
+            or lib.perf_sizeof_step_book() != ctypes.sizeof(StepBook)):
         raise PerfError('descriptor layout mismatch between perf_amd/_lib.py and include/perf_hip.h')
     _lib = lib
     return lib

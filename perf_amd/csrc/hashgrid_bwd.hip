@@ -5,6 +5,7 @@
 #include "grid_device.hpp"
 #include "grid_fixed_point.hpp"
 #include "mlp_reduce_device.hpp"
+#include "step_book_device.hpp"
 
 namespace perf {
 
@@ -879,9 +880,14 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
                                                                    const uint32_t* __restrict__ bitmaps,
                                                                    const uint32_t* __restrict__ esc_bm, int64_t n,
                                                                    const int64_t* __restrict__ n_dev,
-                                                                   const int32_t* __restrict__ redo_flag) {
+                                                                   const int32_t* __restrict__ redo_flag, perf_step_book book, int has_book) {
     // a predicated REDO launch (perf_hashgrid_bwd, redo_flag): nothing happens unless the fixed-point call before it raised
-    // the flag -- the graph node costs a dispatch, the gradient table is left as that call wrote it
+    // the flag -- the graph node costs a dispatch, the gradient table is left as that call wrote it.  The dispatch exists in every
+    // training step: ONE of its threads does the step's bookkeeping on the way (perf_field_bwd_book) -- everything but clearing the
+    // flag, which every workgroup of this launch reads right here (perf_adam_step_dev's clear_flag consumes it afterwards)
+    if constexpr (!FIXED) {
+        if (redo_flag && has_book && blockIdx.x == 0 && threadIdx.x == 0) step_bookkeeping_thread(book, false);
+    }
     if (redo_flag && redo_flag[0] == 0) return;
     if (redo_flag && hr_state && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&hr_state[2 * PERF_MAX_LEVELS + 1], 1);   // (statistics)
     const int64_t n_live = live_count(n, n_dev);            // samples present; n stays the stride of dfeat / codes
@@ -1211,6 +1217,13 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_reduce_kernel(GridParams gp,
 
 using namespace perf;
 
+namespace perf {
+__global__ void step_book_keep_flag_kernel(perf_step_book b) { step_bookkeeping_thread(b, false); }
+}  // namespace perf
+static void launch_step_book_keep_flag(const perf_step_book& b, void* stream) {
+    hipLaunchKernelGGL(perf::step_book_keep_flag_kernel, dim3(1), dim3(1), 0, as_stream(stream), b);
+}
+
 // levels whose owners can run the coded variant (multi-tile levels); returns their number
 static int plan_codes(const GridParams& gp, int64_t n, TileParams* tp) {
     int slots = 0;
@@ -1272,7 +1285,7 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
                                  int32_t* overflow_flag, int32_t* headroom_state, const int32_t* shifts_dev, int raw_fields,
                                  const int32_t* redo_flag, void* workspace, int64_t workspace_bytes, void* stream) {
     return perf_internal_hashgrid_bwd(grid, x01, dfeat, grad_table, n, n_dev, accumulate, level_absmax, overflow_flag, headroom_state, shifts_dev,
-                                      raw_fields, redo_flag, workspace, workspace_bytes, stream, nullptr);
+                                      raw_fields, redo_flag, workspace, workspace_bytes, stream, nullptr, nullptr);
 }
 
 // job (perf_field_bwd): the deferred second stage of the MLP backward that produced `dfeat` / `level_absmax`; it rides in the
@@ -1280,7 +1293,9 @@ extern "C" int perf_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, c
 int perf_internal_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat,
                                float* grad_table, int64_t n, const int64_t* n_dev, int accumulate, const float* level_absmax,
                                int32_t* overflow_flag, int32_t* headroom_state, const int32_t* shifts_dev, int raw_fields,
-                               const int32_t* redo_flag, void* workspace, int64_t workspace_bytes, void* stream, const MlpReduceJob* job_in) {
+                               const int32_t* redo_flag, void* workspace, int64_t workspace_bytes, void* stream, const MlpReduceJob* job_in,
+                               const perf_step_book* book) {
+    PERF_REQUIRE(!book || redo_flag, "perf_hashgrid_bwd: the bookkeeping rides in a repair launch only");
     MlpReduceJob job{};
     if (job_in) job = *job_in;
     GridParams gp;
@@ -1310,7 +1325,9 @@ int perf_internal_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, con
         if (n > 0)
             hashgrid_bwd_kernel<false><<<dim3(nb), dim3(kBwdThreads), lds_b, as_stream(stream)>>>(
                 gp, rp, x01, (const float2*)dfeat, (float2*)grad_table, nullptr, nullptr, nullptr, headroom_state, nullptr, nullptr,
-                nullptr, nullptr, nullptr, nullptr, n, n_dev, redo_flag);
+                nullptr, nullptr, nullptr, nullptr, n, n_dev, redo_flag, book ? *book : perf_step_book{}, book ? 1 : 0);
+        else if (book)      // (no repair launch to ride in: the bookkeeping's own launch, the flag left for the caller all the same)
+            launch_step_book_keep_flag(*book, stream);
         PERF_LAUNCH_CHECK("perf_hashgrid_bwd(redo)");
         return PERF_OK;
     }
@@ -1405,11 +1422,11 @@ int perf_internal_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, con
     } else if (fixed)
         hashgrid_bwd_kernel<true><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, level_absmax, overflow_flag, headroom_state,
-            shifts_dev, shifts_ws, codes, escape, bitmaps, esc_bm, n, n_dev, nullptr);
+            shifts_dev, shifts_ws, codes, escape, bitmaps, esc_bm, n, n_dev, nullptr, perf_step_book{}, 0);
     else
         hashgrid_bwd_kernel<false><<<dim3(n_blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream)>>>(
             gp, tp, x01, (const float2*)dfeat, (float2*)grad_table, (float2*)workspace, nullptr, nullptr, nullptr, nullptr, nullptr,
-            codes, escape, bitmaps, esc_bm, n, n_dev, nullptr);
+            codes, escape, bitmaps, esc_bm, n, n_dev, nullptr, perf_step_book{}, 0);
     PERF_LAUNCH_CHECK("perf_hashgrid_bwd");
     if (tp.atomic_levels && n > 0) {
         if (!accumulate)

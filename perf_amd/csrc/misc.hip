@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include "common.hpp"
+#include "step_book_device.hpp"
 
 namespace perf {
 
@@ -36,8 +37,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float one_minus_b1, float b2, float one_minus_b2, float step_size,
                                                    float inv_bc2_sqrt, float eps, int zero_grad,
                                                    const int32_t* __restrict__ step_dev, const float* __restrict__ lr_dev,
-                                                   const int64_t* __restrict__ gate_dev) {
+                                                   const int64_t* __restrict__ gate_dev, int32_t* __restrict__ clear_flag) {
     __shared__ float sc[2];
+    if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) clear_flag[0] = 0;      // (taken or not: perf_adam_step_dev)
     if (gate_dev && gate_dev[0] <= 0) return;       // batch without samples: the reference skips the step (nerf.py:204-206)
     if (step_dev) {       // step count and learning rate live on the device (hipGraph replay): derive the scalars here
         if (threadIdx.x == 0) {
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void adam4_kernel(float* __restrict__ p, float
                                                     float one_minus_b1, float b2, float one_minus_b2, float step_size,
                                                     float inv_bc2_sqrt, float eps, int zero_grad,
                                                     const int32_t* __restrict__ step_dev, const float* __restrict__ lr_dev,
-                                                    const int64_t* __restrict__ gate_dev) {
+                                                    const int64_t* __restrict__ gate_dev, int32_t* __restrict__ clear_flag) {
     __shared__ float sc[2];
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     const int cnt = i + 3 < n ? 4 : (i < n ? (int)(n - i) : 0);
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void adam4_kernel(float* __restrict__ p, float
     } else {
         for (int k = 0; k < cnt; ++k) { gi[k] = g[i + k]; mi[k] = m[i + k]; vi[k] = v[i + k]; pi[k] = p[i + k]; }
     }
+    if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) clear_flag[0] = 0;      // (taken or not: perf_adam_step_dev)
     if (gate_dev && gate_dev[0] <= 0) return;       // batch without samples: the reference skips the step (nerf.py:204-206)
     if (step_dev) {
         if (threadIdx.x == 0) {
@@ -251,24 +254,24 @@ extern "C" int perf_cast_params(const float* src, void* dst16, int64_t n, int dt
 
 static int adam_launch(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype, int32_t step,
                        float lr, float beta1, float beta2, float eps, int zero_grad, const int32_t* step_dev,
-                       const float* lr_dev, const int64_t* gate_dev, void* stream);
+                       const float* lr_dev, const int64_t* gate_dev, int32_t* clear_flag, void* stream);
 
 extern "C" int perf_adam_step(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype, int32_t step,
                               float lr, float beta1, float beta2, float eps, int zero_grad, void* stream) {
     PERF_REQUIRE(step >= 1, "perf_adam_step: step < 1");
-    return adam_launch(p, m, v, g, w16, n, dtype, step, lr, beta1, beta2, eps, zero_grad, nullptr, nullptr, nullptr, stream);
+    return adam_launch(p, m, v, g, w16, n, dtype, step, lr, beta1, beta2, eps, zero_grad, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype,
                                   const int32_t* step_dev, const float* lr_dev, const int64_t* gate_dev, float beta1,
-                                  float beta2, float eps, int zero_grad, void* stream) {
+                                  float beta2, float eps, int zero_grad, int32_t* clear_flag, void* stream) {
     PERF_REQUIRE(step_dev && lr_dev, "perf_adam_step_dev: NULL scalar pointers");
-    return adam_launch(p, m, v, g, w16, n, dtype, 1, 0.f, beta1, beta2, eps, zero_grad, step_dev, lr_dev, gate_dev, stream);
+    return adam_launch(p, m, v, g, w16, n, dtype, 1, 0.f, beta1, beta2, eps, zero_grad, step_dev, lr_dev, gate_dev, clear_flag, stream);
 }
 
 static int adam_launch(float* p, float* m, float* v, float* g, void* w16, int64_t n, int dtype, int32_t step,
                        float lr, float beta1, float beta2, float eps, int zero_grad, const int32_t* step_dev,
-                       const float* lr_dev, const int64_t* gate_dev, void* stream) {
+                       const float* lr_dev, const int64_t* gate_dev, int32_t* clear_flag, void* stream) {
     PERF_REQUIRE(n >= 0, "perf_adam_step: n < 0");
     if (n == 0) return PERF_OK;
     PERF_REQUIRE(p && m && v && g, "NULL pointer");
@@ -282,16 +285,16 @@ static int adam_launch(float* p, float* m, float* v, float* g, void* w16, int64_
                             reinterpret_cast<uintptr_t>(g) | (reinterpret_cast<uintptr_t>(w16) << 1);
     if ((align & 15) == 0 && n >= 1024) {       // four elements per thread
         dim3 g4((unsigned)div_up(div_up(n, 4), 256));
-        if (!w16) hipLaunchKernelGGL((adam4_kernel<BF16, false>), g4, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
-        else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam4_kernel<BF16, true>), g4, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
-        else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam4_kernel<FP16, true>), g4, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
+        if (!w16) hipLaunchKernelGGL((adam4_kernel<BF16, false>), g4, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev, clear_flag);
+        else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam4_kernel<BF16, true>), g4, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev, clear_flag);
+        else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam4_kernel<FP16, true>), g4, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev, clear_flag);
         else { set_error("perf_adam_step: bad dtype %d", dtype); return PERF_E_INVALID; }
         PERF_LAUNCH_CHECK("perf_adam_step");
         return PERF_OK;
     }
-    if (!w16) hipLaunchKernelGGL((adam_kernel<BF16, false>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
-    else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam_kernel<BF16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
-    else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam_kernel<FP16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev);
+    if (!w16) hipLaunchKernelGGL((adam_kernel<BF16, false>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)nullptr, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev, clear_flag);
+    else if (dtype == PERF_DTYPE_BF16) hipLaunchKernelGGL((adam_kernel<BF16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev, clear_flag);
+    else if (dtype == PERF_DTYPE_FP16) hipLaunchKernelGGL((adam_kernel<FP16, true>), gr, b, 0, as_stream(stream), p, m, v, g, (uint16_t*)w16, n, omb1, beta2, omb2, step_size, inv_bc2_sqrt, eps, zero_grad, step_dev, lr_dev, gate_dev, clear_flag);
     else { set_error("perf_adam_step: bad dtype %d", dtype); return PERF_E_INVALID; }
     PERF_LAUNCH_CHECK("perf_adam_step");
     return PERF_OK;
@@ -358,68 +361,21 @@ static int raygen_launch(const float* pose, const float* pose_dev, int32_t heigh
     return PERF_OK;
 }
 
-// one thread: the bookkeeping of a sync-free training step (see perf_step_bookkeeping in the header)
+// one thread: the bookkeeping of a sync-free training step (see perf_step_bookkeeping in the header; step_book_device.hpp)
 namespace perf {
-__global__ void step_bookkeeping_kernel(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
-                                        const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
-                                        int32_t* overflow_flag, const float* remote_flags, int overflow_redone, int64_t* eff_gate_out,
-                                        const float* schedule, int32_t n_schedule, int32_t* iter_dev, float* lr_out, float* ratio_out) {
-    // every input is READ before anything is written (the pointers may alias as far as the compiler knows: interleaved, each
-    // load waits for the store before it and the one thread walks a dozen round trips one after the other)
-    const bool sched = schedule && iter_dev && n_schedule > 0;
-    const int it = sched ? iter_dev[0] : 0;
-    const int64_t marched = n_marched_dev ? n_marched_dev[0] : 0;
-    const int64_t gate = gate_dev ? gate_dev[0] : 1;
-    const int32_t own_flag = overflow_flag ? overflow_flag[0] : 0;
-    const float remote_overflow = remote_flags ? remote_flags[0] : 0.f, remote_truncated = remote_flags ? remote_flags[1] : 0.f;
-    const int32_t step_now = step_dev ? step_dev[0] : 0;
-    const int64_t kept = (counters && n_kept_dev) ? n_kept_dev[0] : 0;
-    int64_t cnt[6] = {0, 0, 0, 0, 0, 0};
-    if (counters) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) cnt[k] = counters[k];
-    }
-    // device-side schedule: row i = {learning rate of iteration i, distortion-loss ramp of iteration i}.  This launch sits
-    // between the backward and Adam of iteration `it`: Adam reads lr(it) next, the loss head of iteration it + 1 reads
-    // ratio(it + 1) -- a graph replay then needs no host-side scalar update at all
-    const int cur = it < n_schedule ? it : n_schedule - 1, nxt = it + 1 < n_schedule ? it + 1 : n_schedule - 1;
-    const float lr = sched ? schedule[2 * cur] : 0.f, ratio = sched ? schedule[2 * nxt + 1] : 0.f;
-
-    const bool has_samples = gate > 0;
-    const bool overflow = own_flag != 0 || remote_overflow > 0.f;
-    // remote_flags: {overflow, truncated} summed over the ranks of a data-parallel job (this rank's own included): every rank
-    // takes or skips the step alike
-    const bool truncated = (capacity > 0 && marched > capacity) || remote_truncated > 0.f;
-    // overflow_redone: the caller repaired a flagged gradient in place (perf_hashgrid_bwd's redo launch): the event is counted,
-    // the step is taken
-    const bool take = has_samples && (!overflow || overflow_redone) && !truncated;
-    if (sched) {
-        if (lr_out) lr_out[0] = lr;
-        if (ratio_out) ratio_out[0] = ratio;
-        iter_dev[0] = it + 1;
-    }
-    if (step_dev && take) step_dev[0] = step_now + 1;
-    if (eff_gate_out) eff_gate_out[0] = take ? 1 : 0;
-    if (own_flag != 0) overflow_flag[0] = 0;      // consumed: counted below, the step is skipped
-    if (counters) {
-        counters[0] = cnt[0] + marched;
-        if (n_kept_dev) counters[1] = cnt[1] + kept;
-        counters[2] = cnt[2] + 1;
-        if (marched > cnt[3]) counters[3] = marched;
-        if (has_samples && overflow) counters[4] = cnt[4] + 1;
-        if (has_samples && truncated) counters[5] = cnt[5] + 1;
-    }
-}
+__global__ void step_bookkeeping_kernel(perf_step_book b) { step_bookkeeping_thread(b, true); }
 }  // namespace perf
+
+extern "C" int64_t perf_sizeof_step_book(void) { return (int64_t)sizeof(perf_step_book); }
 
 extern "C" int perf_step_bookkeeping(int32_t* step_dev, const int64_t* gate_dev, int64_t* counters,
                                      const int64_t* n_marched_dev, const int64_t* n_kept_dev, int64_t capacity,
                                      int32_t* overflow_flag, const float* remote_flags, int32_t overflow_redone, int64_t* eff_gate_out,
                                      const float* schedule, int32_t n_schedule, int32_t* iter_dev, float* lr_out, float* ratio_out,
                                      void* stream) {
-    hipLaunchKernelGGL(perf::step_bookkeeping_kernel, dim3(1), dim3(1), 0, as_stream(stream), step_dev, gate_dev, counters,
-                       n_marched_dev, n_kept_dev, capacity, overflow_flag, remote_flags, (int)overflow_redone, eff_gate_out, schedule, n_schedule, iter_dev,
-                       lr_out, ratio_out);
+    perf_step_book b{step_dev, gate_dev, counters, n_marched_dev, n_kept_dev, capacity, overflow_flag, remote_flags, eff_gate_out, schedule, iter_dev,
+                     lr_out, ratio_out, n_schedule, overflow_redone};
+    hipLaunchKernelGGL(perf::step_bookkeeping_kernel, dim3(1), dim3(1), 0, as_stream(stream), b);
     PERF_LAUNCH_CHECK("perf_step_bookkeeping");
     return PERF_OK;
 }

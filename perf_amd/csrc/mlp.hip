@@ -155,10 +155,38 @@ extern "C" int64_t perf_field_bwd_workspace_bytes(const perf_grid_desc* grid, co
     return a16 + b16 + ((c + 15) & ~(int64_t)15) + PERF_MAX_LEVELS * (int64_t)sizeof(float);
 }
 
+static int field_bwd_chain(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const void* w16_net,
+                           const void* feat16, const int32_t* feat_index, int64_t feat_stride, const uint8_t* sel, const float* dout,
+                           float* grad, int32_t fixed, int32_t redo, int32_t* overflow_flag, int32_t* headroom_state,
+                           void* workspace, int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, const perf_step_book* book,
+                           void* stream);
+
 extern "C" int perf_field_bwd(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const void* w16_net,
                               const void* feat16, const int32_t* feat_index, int64_t feat_stride, const uint8_t* sel, const float* dout,
                               float* grad, int32_t fixed, int32_t redo, int32_t* overflow_flag, int32_t* headroom_state,
                               void* workspace, int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, void* stream) {
+    return field_bwd_chain(grid, mlp, x01, w16_net, feat16, feat_index, feat_stride, sel, dout, grad, fixed, redo, overflow_flag, headroom_state,
+                           workspace, workspace_bytes, n, n_dev, dtype, nullptr, stream);
+}
+
+// ... and the step's bookkeeping in one thread of the repair launch (one launch per training step fewer; the flag is left to
+// perf_adam_step_dev's clear_flag)
+extern "C" int perf_field_bwd_book(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const void* w16_net,
+                                   const void* feat16, const int32_t* feat_index, int64_t feat_stride, const uint8_t* sel, const float* dout,
+                                   float* grad, int32_t* overflow_flag, int32_t* headroom_state, void* workspace, int64_t workspace_bytes,
+                                   int64_t n, const int64_t* n_dev, int dtype, const perf_step_book* book, void* stream) {
+    PERF_REQUIRE(book && overflow_flag && headroom_state, "perf_field_bwd_book: NULL pointer");
+    PERF_REQUIRE(book->overflow_flag == overflow_flag, "perf_field_bwd_book: book->overflow_flag must be the call's overflow_flag");
+    PERF_REQUIRE(n > 0, "perf_field_bwd_book: n == 0");
+    return field_bwd_chain(grid, mlp, x01, w16_net, feat16, feat_index, feat_stride, sel, dout, grad, 1, 1, overflow_flag, headroom_state,
+                           workspace, workspace_bytes, n, n_dev, dtype, book, stream);
+}
+
+static int field_bwd_chain(const perf_grid_desc* grid, const perf_mlp_desc* mlp, const float* x01, const void* w16_net,
+                           const void* feat16, const int32_t* feat_index, int64_t feat_stride, const uint8_t* sel, const float* dout,
+                           float* grad, int32_t fixed, int32_t redo, int32_t* overflow_flag, int32_t* headroom_state,
+                           void* workspace, int64_t workspace_bytes, int64_t n, const int64_t* n_dev, int dtype, const perf_step_book* book,
+                           void* stream) {
     PERF_REQUIRE(grid && mlp && grad && workspace, "NULL pointer");
     PERF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "perf_field_bwd: the workspace must be 16-byte aligned");
     int nh, ks;
@@ -182,6 +210,7 @@ extern "C" int perf_field_bwd(const perf_grid_desc* grid, const perf_mlp_desc* m
                                     fixed ? headroom_state : nullptr, nullptr, 0, nullptr, grid_ws, b16, stream, &job);
     if (rc) return rc;
     if (fixed && redo)
-        rc = perf_hashgrid_bwd(grid, x01, dfeat, grad + n_net, n, n_dev, 0, nullptr, nullptr, headroom_state, nullptr, 0, overflow_flag, nullptr, 0, stream);
+        rc = perf_internal_hashgrid_bwd(grid, x01, dfeat, grad + n_net, n, n_dev, 0, nullptr, nullptr, headroom_state, nullptr, 0, overflow_flag, nullptr, 0,
+                                        stream, nullptr, book);
     return rc;
 }

@@ -70,5 +70,6 @@ PERF_INTERNAL int perf_internal_mlp_bwd(const perf_mlp_desc* mlp, const void* w1
 PERF_INTERNAL int perf_internal_hashgrid_bwd(const perf_grid_desc* grid, const float* x01, const float* dfeat, float* grad_table, int64_t n,
                                              const int64_t* n_dev, int accumulate, const float* level_absmax, int32_t* overflow_flag,
                                              int32_t* headroom_state, const int32_t* shifts_dev, int raw_fields, const int32_t* redo_flag,
-                                             void* workspace, int64_t workspace_bytes, void* stream, const perf::MlpReduceJob* job);
+                                             void* workspace, int64_t workspace_bytes, void* stream, const perf::MlpReduceJob* job,
+                                             const perf_step_book* book = nullptr);
 PERF_INTERNAL void perf_internal_launch_mlp_reduce(const perf::MlpReduceJob& job, void* stream);

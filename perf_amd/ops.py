@@ -110,12 +110,39 @@ def adam_step(p, m, v, g, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, w16=None, 
               _stream())
 
 
-def adam_step_dev(p, m, v, g, step_dev, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8, w16=None, zero_grad=False, gate=None):
-    """gate: device int64 [1]; the update is skipped when it holds 0 (a batch without samples)."""
+def adam_step_dev(p, m, v, g, step_dev, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8, w16=None, zero_grad=False, gate=None, clear_flag=None):
+    """gate: device int64 [1]; the update is skipped when it holds 0 (a batch without samples).  clear_flag (device int32 [1]): zeroed by
+    the launch, taken or not -- how the overflow flag is consumed when the bookkeeping rode in the repair launch (field_bwd(book=...))."""
     code = dtype_code(w16.dtype) if w16 is not None else 0
     _call('perf_adam_step_dev', _p(_f32(p, 'p')), _p(_f32(m, 'm')), _p(_f32(v, 'v')), _p(_f32(g, 'g')), _p(w16),
           p.numel(), code, _p(step_dev), _p(lr_dev), _nd(gate), float(beta1), float(beta2), float(eps), int(bool(zero_grad)),
-          _stream())
+          _p(clear_flag), _stream())
+
+
+class StepBook:
+    """The arguments of step_bookkeeping, kept for a call that carries the bookkeeping in one of its own launches (field_bwd(book=...):
+    perf_field_bwd_book).  done: set by the call that did it -- the optimizer then skips its own bookkeeping launch and lets Adam clear the
+    overflow flag."""
+
+    def __init__(self, step_dev=None, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0, overflow=None, remote_flags=None,
+                 eff_gate=None, schedule=None, overflow_redone=False):
+        self.args = dict(step_dev=step_dev, gate=gate, counters=counters, n_marched=n_marched, n_kept=n_kept, capacity=capacity, overflow=overflow,
+                         remote_flags=remote_flags, eff_gate=eff_gate, schedule=schedule, overflow_redone=overflow_redone)
+        self.done = False
+
+    def struct(self):
+        a = self.args
+        table, it, lr_out, ratio_out = a['schedule'] if a['schedule'] is not None else (None, None, None, None)
+        for name in ('gate', 'counters', 'n_marched', 'n_kept', 'eff_gate'):
+            _nd(a[name])                                   # (dtype / device checks of the int64 scalars)
+        q = lambda t: None if t is None else _p(t).value
+        return _lib.StepBook(q(a['step_dev']), q(a['gate']), q(a['counters']), q(a['n_marched']), q(a['n_kept']), int(a['capacity'] or 0),
+                             q(a['overflow']), q(a['remote_flags']), q(a['eff_gate']), q(table), q(it), q(lr_out), q(ratio_out),
+                             int(table.shape[0]) if table is not None else 0, int(bool(a['overflow_redone'])))
+
+    def launch(self):
+        """The stand-alone launch (perf_step_bookkeeping) with the same arguments."""
+        step_bookkeeping(**self.args)
 
 
 def step_bookkeeping(step_dev=None, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0, overflow=None,
@@ -258,7 +285,7 @@ FIELD_BWD_ONE_CALL = True       # False: the three entry points one by one (tool
 
 
 def field_bwd(grid: GridConfig, mlp: MlpConfig, x01, w16_net, feat16, dout, sel=None, fixed=True, redo=True, hr_state=None, n_dev=None,
-              grad=None, extra=0):
+              grad=None, extra=0, book=None):
     """The whole backward of one field in ONE boundary call (perf_field_bwd: MLP backward -> grid backward -> predicated fp32 repair)
     -> flat fp32 gradient [network | grid (+ `extra` trailing slots)].  feat16: [L, n, 2] or an IndexedFeat.  The workspace (MLP
     partials, tile codes, dfeat) is cached per (device, grid, network) and grown on demand: consecutive backwards on one stream reuse
@@ -298,6 +325,16 @@ def field_bwd(grid: GridConfig, mlp: MlpConfig, x01, w16_net, feat16, dout, sel=
             if len(_FIELD_BWD_WS) >= 16 and key not in _FIELD_BWD_WS:
                 _FIELD_BWD_WS.pop(next(iter(_FIELD_BWD_WS)))
             _FIELD_BWD_WS[key] = ws
+    if book is not None and fixed and redo and hr_state is not None and n > 0 and book.args['overflow'] is not None \
+            and book.args['overflow'].data_ptr() == overflow_flag(dev).data_ptr():
+        # book (a StepBook): the step's bookkeeping rides in the repair launch (perf_field_bwd_book) -- one launch per step fewer; the flag
+        # stays for adam_step_dev(clear_flag=...)
+        sb = book.struct()
+        _call('perf_field_bwd_book', ctypes.byref(gd), ctypes.byref(md), _p(_f32(x01, 'x01')), _p(w16_net), _p(feat16), _p(index), stride, _p(sel),
+              _p(_f32(dout, 'dout')), _p(grad), _p(overflow_flag(dev)), _p(hr_state), _p(ws), ws.numel() * 4, n, _nd(n_dev),
+              dtype_code(w16_net.dtype), ctypes.byref(sb), _stream())
+        book.done = True
+        return grad
     _call('perf_field_bwd', ctypes.byref(gd), ctypes.byref(md), _p(_f32(x01, 'x01')), _p(w16_net), _p(feat16), _p(index), stride, _p(sel),
           _p(_f32(dout, 'dout')), _p(grad), int(bool(fixed)), int(bool(fixed and redo)), _p(overflow_flag(dev)) if fixed else None,
           _p(hr_state) if fixed else None, _p(ws), ws.numel() * 4, n, _nd(n_dev), dtype_code(w16_net.dtype), _stream())

@@ -345,7 +345,19 @@ class FusedAdam:
             return None
         return (self.sched_table, self.sched_iter, self.lr_dev, self.sched_ratio_out)
 
-    def step(self, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0, remote_flags=None):
+    def make_book(self, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0):
+        """The bookkeeping step() would launch with these arguments, as an ops.StepBook a backward can carry in its repair launch
+        (ops.field_bwd(book=...): one launch per step fewer); None when this optimizer's step has no repair launch to ride in."""
+        fixed = getattr(self.net, 'grid_grad_accum', 'fp32') == 'fixed'
+        if not (fixed and getattr(self.net, 'redo_supported', False) and self.book_in_repair_launch):
+            return None
+        return ops.StepBook(self.step_dev, gate, counters, n_marched, n_kept if n_kept is not None else gate, capacity=capacity,
+                            overflow=ops.overflow_flag(self.net.params.device), remote_flags=None, eff_gate=self.eff_gate,
+                            schedule=self.schedule_args(), overflow_redone=True)
+
+    book_in_repair_launch = os.environ.get('PERF_BOOK_IN_REPAIR_LAUNCH', '1') != '0'
+
+    def step(self, gate=None, counters=None, n_marched=None, n_kept=None, capacity=0, remote_flags=None, book=None):
         """gate (device int64 [1], optional): the number of samples behind this gradient.  The step is TAKEN unless the gate
         is 0 (the reference skips batches without samples, nerf.py:204-206), the fixed-point grid backward raised its
         overflow flag, or the batch was truncated at `capacity` samples -- decided on the device by perf_step_bookkeeping,
@@ -359,11 +371,13 @@ class FusedAdam:
         flag = ops.overflow_flag(p.device) if fixed else None
         # (a flagged fixed-point gradient was repaired in place by the redo launch behind the backward, NeRFScene._field_grad:
         #  the event is counted, the step is taken)
-        ops.step_bookkeeping(self.step_dev, gate, counters, n_marched, n_kept if n_kept is not None else gate, capacity=capacity,
-                             overflow=flag, remote_flags=remote_flags, eff_gate=self.eff_gate, schedule=self.schedule_args(),
-                             overflow_redone=fixed and getattr(self.net, 'redo_supported', False))
+        rode = book is not None and book.done        # (the backward's repair launch did the bookkeeping: Adam consumes the flag)
+        if not rode:
+            ops.step_bookkeeping(self.step_dev, gate, counters, n_marched, n_kept if n_kept is not None else gate, capacity=capacity,
+                                 overflow=flag, remote_flags=remote_flags, eff_gate=self.eff_gate, schedule=self.schedule_args(),
+                                 overflow_redone=fixed and getattr(self.net, 'redo_supported', False))
         ops.adam_step_dev(p.data, self.exp_avg, self.exp_avg_sq, p.grad[:p.numel()], self.step_dev, self.lr_dev, g['betas'][0],
-                          g['betas'][1], g['eps'], w16=self.w16, zero_grad=False, gate=self.eff_gate)
+                          g['betas'][1], g['eps'], w16=self.w16, zero_grad=False, gate=self.eff_gate, clear_flag=flag if rode else None)
         p.grad = None                              # the next backward installs a fresh gradient (no accumulate pass)
         self.net.set_working_copy(self.w16)        # the kernel wrote the refreshed 16-bit copy
 
@@ -855,7 +869,7 @@ class NeRFScene:
         return torch.rand(n_local * world, cols, device=device)[rank * n_local:(rank + 1) * n_local].contiguous()
 
     # ---- fused steps: explicit kernel chain instead of autograd + ~25 tiny torch ops (same arithmetic) ----------
-    def _field_grad(self, net, x01, w16, feat, sel, dout, n_dev=None, extra=0):
+    def _field_grad(self, net, x01, w16, feat, sel, dout, n_dev=None, extra=0, book=None):
         """Flat gradient [network | grid] (+ `extra` trailing slots: the data-parallel path appends the sample count)."""
         n_net = net.mlp.n_params
         fixed = net.grid_grad_accum == 'fixed'
@@ -864,7 +878,7 @@ class NeRFScene:
             # ONE boundary call (perf_field_bwd): MLP backward -> grid backward -> the predicated fp32 repair launch that keeps a
             # flagged fixed-point step from being dropped (a no-op dispatch otherwise)
             grad = ops.field_bwd(net.grid, net.mlp, x01, w16[:n_net], feat, dout, sel, fixed=fixed, redo=True,
-                                 hr_state=net.headroom_state() if fixed else None, n_dev=n_dev, extra=extra)
+                                 hr_state=net.headroom_state() if fixed else None, n_dev=n_dev, extra=extra, book=book)
             if fixed and not self.fused_adam:
                 # torch.optim.Adam has no perf_step_bookkeeping behind it to consume the flag: left set, every later backward
                 # would run its (slow) fp32 repair as well
@@ -884,9 +898,17 @@ class NeRFScene:
                 ops.overflow_flag(x01.device).zero_()
         return grad
 
+    def _step_book(self, optimizer, dist_info, n_dev, n_marched):
+        """Single process, sync-free mode, fused Adam: the step's bookkeeping as a block the backward's repair launch carries (the
+        arguments _apply_grad hands optimizer.step); None otherwise."""
+        if dist_info[0] is not None or not isinstance(optimizer, FusedAdam) or not torch.is_tensor(n_dev):
+            return None
+        return optimizer.make_book(gate=n_dev, counters=self.sample_counters, n_marched=n_marched, n_kept=n_dev,
+                                   capacity=self.renderer.sample_capacity or 0)
+
     DP_EXTRA = 3           # trailing slots of the data-parallel gradient buffer: [sample count, overflow flag, truncated]
 
-    def _apply_grad(self, net, grad, optimizer, dist_info, overlap, n_kept=None, n_marched=None):
+    def _apply_grad(self, net, grad, optimizer, dist_info, overlap, n_kept=None, n_marched=None, book=None):
         """[one RCCL all-reduce of the flat gradient] -> Adam.  n_kept: number of samples behind `grad` (device int64 [1], or a
         host int in the eager variable-count path).  Under data parallelism three trailing slots of the gradient buffer travel
         with it: the sample count -- the optimizer step is skipped when NO rank had samples (the reference's
@@ -943,7 +965,7 @@ class NeRFScene:
         if isinstance(optimizer, FusedAdam):
             optimizer.step(gate=gate, counters=self.sample_counters, n_marched=n_marched,
                            n_kept=n_kept if torch.is_tensor(n_kept) else None, capacity=self.renderer.sample_capacity or 0,
-                           remote_flags=remote)
+                           remote_flags=remote, book=book)
         else:
             if gate is None or int(gate.item()) > 0:
                 optimizer.step()
@@ -1084,7 +1106,8 @@ class NeRFScene:
                                   late=beside_reduce_scatter if ((defer_color and not exact) or want_prefetch) else None)
             self.global_iter_step_geo += 1
             return
-        grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1), n_dev=n_dev, extra=extra)
+        book = self._step_book(optimizer, dist_info, n_dev, st['n_marched_dev'])
+        grad = self._field_grad(geo, x01, w16, feat, sel, dsig.view(-1, 1), n_dev=n_dev, extra=extra, book=book)
         overlap = None
         if self.overlap_comm and dist_info[0] is not None:
             def overlap():
@@ -1093,7 +1116,7 @@ class NeRFScene:
                 if prefetch_next:
                     prefetch_now()
         self._apply_grad(geo, grad, optimizer, dist_info, overlap, n_kept=n_dev if n_dev is not None else x01.shape[0],
-                         n_marched=st['n_marched_dev'])
+                         n_marched=st['n_marched_dev'], book=book)
         self.global_iter_step_geo += 1
 
     @torch.no_grad()
@@ -1140,9 +1163,10 @@ class NeRFScene:
             self._dp_sharded_step(app, optimizer, dist_info, x01, w16, feat, sel, drgb, n_dev, st['n_marched_dev'])
             self.global_iter_step_app += 1
             return
-        grad = self._field_grad(app, x01, w16, feat, sel, drgb, n_dev=n_dev, extra=extra)
+        book = self._step_book(optimizer, dist_info, n_dev, st['n_marched_dev'])
+        grad = self._field_grad(app, x01, w16, feat, sel, drgb, n_dev=n_dev, extra=extra, book=book)
         self._apply_grad(app, grad, optimizer, dist_info, None, n_kept=n_dev if n_dev is not None else x01.shape[0],
-                         n_marched=st['n_marched_dev'])
+                         n_marched=st['n_marched_dev'], book=book)
         self.global_iter_step_app += 1
 
     def _can_fuse(self):

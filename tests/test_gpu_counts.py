@@ -318,6 +318,69 @@ def test_an_overflowed_fixed_point_gradient_is_repaired_not_dropped(ops):
     assert float((pf - p3).abs().max()) <= 2.1 * lr and float((pf - p3).abs().mean()) <= 2e-3 * lr, (float((pf - p3).abs().max()), float((pf - p3).abs().mean()))
 
 
+def test_bookkeeping_in_the_repair_launch_changes_nothing(ops):
+    """perf_field_bwd_book: the step's bookkeeping done by ONE thread of the predicated repair launch (+ perf_adam_step_dev's
+    clear_flag consuming the overflow flag) against the stand-alone perf_step_bookkeeping launch between backward and Adam: the same
+    parameters bit for bit, the same step count, counters, device-side schedule position and learning rate -- over eager geometry and
+    colour steps and graph replays; then steps whose fixed-point gradient is forced to overflow (repaired in fp32 -- arrival-order
+    atomics, so compared to a tolerance --, taken, counted, the flag consumed); the captured step is one node shorter."""
+    from perf_amd.scene import FusedAdam
+    keep = FusedAdam.book_in_repair_launch
+    out = {}
+    try:
+        for mode in (True, False):
+            FusedAdam.book_in_repair_launch = mode
+            scene, pool, rays, dist, rgb = _room_scene(dtype='bf16', batch=1024, train_steps=0)
+            scene.count_graph_nodes = True
+            geo, app = scene.nerf.geo_mlp, scene.nerf.app_mlp
+            scene.renderer.sample_capacity = 1024 * 128
+            scene.sample_counters.zero_()
+            flag = ops.overflow_flag('cuda'); flag.zero_()
+            torch.manual_seed(5)
+            og, oa = scene.make_optimizer(geo, 1e-3), scene.make_optimizer(app, 1e-3)
+            seen = []
+
+            def pair():
+                scene.update_lr(og, scene.train_conf.geo_optimizer, 0.1)
+                scene.train_one_step_geo(og, pool, progress=0.5)
+                seen.append(int(flag.item()))
+                scene.update_lr(oa, scene.train_conf.app_optimizer, 0.1)
+                scene.train_one_step_app(oa, pool, progress=0.5)
+                seen.append(int(flag.item()))
+
+            pair(); pair()
+            lrs = [1e-3 * 0.99 ** k for k in range(16)]
+            replay = scene.make_graphed_step('geo', og, pool, warmup=0, schedule=(lrs, [min(2 * 0.05 * k, 1.0) for k in range(16)], 0))
+            for k in range(3):
+                replay()
+            torch.cuda.synchronize()
+            exact = dict(geo=geo.params.detach().clone(), app=app.params.detach().clone(), steps=(og.step_count, oa.step_count),
+                         counters=scene.sample_counters.tolist(), it=int(og.sched_iter.item()), lr=float(og.lr_dev.item()),
+                         ratio=float(scene._ratio_dev.item()), hr=geo.headroom_state().clone(), m=og.exp_avg.clone())
+            # ---- flagged steps: one replayed, one eager
+            geo.headroom_state()[:24] = -24
+            replay()
+            seen.append(int(flag.item()))
+            og.clear_schedule()
+            geo.headroom_state()[:24] = -24
+            pair()
+            torch.cuda.synchronize()
+            assert seen == [0] * len(seen), seen                          # consumed by every step, the flagged ones included
+            out[mode] = dict(exact=exact, geo=geo.params.detach().clone(), steps=(og.step_count, oa.step_count),
+                             counters=scene.sample_counters.tolist(), nodes=scene.graph_nodes['geo'],
+                             tol=2.2 * (lrs[3] + scene.lr_at(scene.train_conf.geo_optimizer, 0.1)))
+    finally:
+        FusedAdam.book_in_repair_launch = keep
+    a, b = out[True], out[False]
+    ea, eb = a['exact'], b['exact']
+    assert torch.equal(ea['geo'], eb['geo']) and torch.equal(ea['app'], eb['app']) and torch.equal(ea['m'], eb['m']) and torch.equal(ea['hr'], eb['hr'])
+    assert ea['steps'] == eb['steps'] == (5, 2) and ea['counters'] == eb['counters'] and ea['counters'][4] == 0, (ea['steps'], ea['counters'], eb['counters'])
+    assert ea['it'] == eb['it'] == 3 and ea['lr'] == eb['lr'] == pytest.approx(lrs[2]) and ea['ratio'] == eb['ratio']
+    assert a['steps'] == b['steps'] == (7, 3) and a['counters'][4] == b['counters'][4] == 2 and a['counters'][2] == b['counters'][2], (a['steps'], a['counters'], b['counters'])
+    assert float((a['geo'] - b['geo']).abs().max()) <= a['tol'], (float((a['geo'] - b['geo']).abs().max()), a['tol'])   # (two Adam steps on arrival-order sums)
+    assert a['nodes'] == b['nodes'] - 1, (a['nodes'], b['nodes'])
+
+
 def test_dp_slots_carry_the_statistics_exactly(ops):
     """perf_dp_slot_pack / perf_dp_slot_unpack: integers travel as 16-bit pieces in the fp32 all-reduce buffer and come out
     exactly; the summed slots equal what an all-gather of perf_dp_stats_pack blocks would hold; the job flags add up."""
