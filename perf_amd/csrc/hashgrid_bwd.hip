@@ -24,12 +24,14 @@ constexpr int kBwdThreads = 1024;
 constexpr int kMaxReplicas = 16;
 constexpr int kMaxWork = 512;              // workgroups the XCD-aware placement table can hold
 constexpr int kXcds = 8;
+constexpr int kCus = 248;                  // MI355X has 256 CUs and an owner workgroup (128 KiB of LDS) takes one -- but a launch of 252 did not get
+                                           // one each: 731 us against 361 (call r06cu); 31 per XCD is what is asked for at most
 
 // Load balance: a hashed level has 16 tiles, each receiving 1/16 of the level's 8 corner updates per
 // sample; a coarse dense level has only 1..8 tiles receiving the same total.  Coarse tiles are therefore
 // REPLICATED (R_l copies, each streaming 1/R_l of the samples) so that every workgroup takes about as long as
 // a hashed-tile owner; replicas are summed by a small second kernel.  L16/T18, fixed-point mode:
-// 8 + 8 + 4x3 + 8x2 + 12x16 = 236 workgroups.
+// 8 + 8 + 4x3 + 8x3 + 12x16 = 244 workgroups (round 6: the third replica of level 3 from the CUs left over, see plan_tiles).
 struct TileParams {
     int32_t tiles_of[PERF_MAX_LEVELS];     // tiles per level
     int32_t replicas_of[PERF_MAX_LEVELS];  // replicas per tile
@@ -108,6 +110,25 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
         tp->tiles_of[l] = nt; tp->replicas_of[l] = r;
         if (r > 1) { tp->ws_off[l] = ws; ws += (int64_t)r * gp.size[l]; }
         nb += nt * r;
+    }
+    // ---- CUs left over go to the dense levels of 5..16 tiles (round 6, per-workgroup times of a 1 M-sample call: the 8 tiles x 2
+    // replicas of level 3 of L16 / T18 took 357 us each, every hashed owner 331-350 -- the launch ended with them; 16 of the 20 idle CUs
+    // as two more replicas bring them to ~190).  Only while the launch still fits one workgroup per CU, and only in fixed-point mode
+    // (integer slabs: the sums do not depend on how the samples are split).
+    if (fixed && !no_replicas && !large_grid && tp->bitmap_levels == 0u && tp->atomic_levels == 0u) {
+        for (int want = 4; want >= 3; --want)
+            for (int l = 0; l < gp.n_levels; ++l) {
+                const int nt = tp->tiles_of[l], r = tp->replicas_of[l];
+                if (gp.hashed[l] || nt <= 4 || nt > 16 || r != rs[2] || want <= r) continue;
+                if (nb + nt * (want - r) > kCus) continue;
+                nb += nt * (want - r);
+                tp->replicas_of[l] = want;
+            }
+        ws = 0;                                              // (slab offsets again)
+        for (int l = 0; l < gp.n_levels; ++l) {
+            tp->ws_off[l] = 0;
+            if (tp->replicas_of[l] > 1) { tp->ws_off[l] = ws; ws += (int64_t)tp->replicas_of[l] * gp.size[l]; }
+        }
     }
     *n_blocks = nb; *ws_entries = ws;
     // ---- XCD-aware placement (a speed assumption only: results do not depend on it)
@@ -532,6 +553,18 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     //    (byte 0x7f) -- such a sample is queued by EVERY owner of the level without combinations and applied corner by
     //    corner with bwd_apply's wrapping rule (a few per cent of random points, none of a scene that keeps clear of the
     //    upper faces of its box: no reason to hand the whole level to the generic owners)
+    // Hashed levels: which of a code's four bytes name this tile, as 0x80 in each such byte -- x = code ^ (t in every byte) has a zero byte
+    // there, and ~(((x & 0x7f..) + 0x7f..) | x | 0x7f..) marks zero bytes exactly (no carry leaves a byte).  Five vector instructions per
+    // code (gfx950's three-input bit operation folds the AND and the NOR) where four byte compares, four selects and two ORs took eleven; the
+    // four bits of the queue entry are made from the marks by ONE dot product with (1, 2, 4, 8), and only on the lanes that hit.
+    // (t4: this tile in every byte; a lane without a group of its own in the last iteration compares against 0xff.., which is no tile of
+    //  a hashed level -- at most 255 of them -- so that validity costs one select per iteration instead of one per code)
+    const uint32_t t4 = cx.t * 0x01010101u;
+    auto test_marks = [&](uint32_t code, uint32_t t4) {
+        const uint32_t x = code ^ t4;
+        const uint32_t a = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+        return ~(a | x | 0x7f7f7f7fu);
+    };
     auto test = [&](uint32_t code) {
         uint32_t cm = 0;
         bool wraps = false;
@@ -549,6 +582,14 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
         if (b) {
             const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
             if (cm) queue[pos] = (i << 4) | (cm & 15u);
+            qn += (uint32_t)__popcll(b);
+        }
+    };
+    auto enqueue_marks = [&](uint32_t marks, uint32_t i) {        // (hashed levels: `marks` of test_marks)
+        const unsigned long long b = __ballot(marks != 0u);
+        if (b) {
+            const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (marks) queue[pos] = (i << 4) | __builtin_amdgcn_udot4(marks >> 7, 0x08040201u, 0u, false);
             qn += (uint32_t)__popcll(b);
         }
     };
@@ -611,8 +652,12 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
             grp += kBwdThreads;
             load_codes(grp);
             const uint32_t cs[4] = {c0.x, c0.y, c1.x, c1.y};
+            const uint32_t t4v = valid ? t4 : 0xffffffffu;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
+            for (int s = 0; s < 4; ++s) {
+                if (DENSE) enqueue(valid ? test(cs[s]) : 0u, (uint32_t)(4 * g0 + s));
+                else enqueue_marks(test_marks(cs[s], t4v), (uint32_t)(4 * g0 + s));
+            }
             {
                 PERF_WAIT_BATCH(2);         // all but the 2 code loads
                 apply_batch(bx, byz, bg);
@@ -628,8 +673,9 @@ __device__ __forceinline__ void bwd_stream_codes(const BwdCtx& cx, float* lds_ti
     if (threadIdx.x < 64 && rep == 0) {                 // ragged tail (n % kPer samples)
         const int64_t i = n_full * kPer + lane;
         uint32_t cm = 0u;
-        if (i < n) cm = test(codes_l[i]);
-        enqueue(cm, (uint32_t)i);
+        if (i < n) cm = DENSE ? test(codes_l[i]) : test_marks(codes_l[i], t4);
+        if (DENSE) enqueue(cm, (uint32_t)i);
+        else enqueue_marks(cm, (uint32_t)i);
     }
     for (;;) {
         PERF_WAIT_BATCH(0);

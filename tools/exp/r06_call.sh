@@ -1,13 +1,10 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r06cr
+O=$R/gpurun_out/r06cy
 rm -rf $O; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-OFF="--no-cpu-baseline --no-psnr --no-reuse-line --sustain-seconds 0 --no-render-block --no-config4 --no-config5 --no-train-app"
-cp $R/perf_amd/libperf_hip.so /tmp/keep.so
-for v in good diag_codes diag_noapply; do
-  if [ $v != good ]; then cp $R/tools/exp/_variants/lib_$v.so $R/perf_amd/libperf_hip.so; fi
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$v -o kt -- python $R/bench.py --steps 20 --warmup 5 $OFF > $O/kt_$v.log 2>&1
-  echo $v; grep "hashgrid_bwd_kernel<true>\|tile_codes4" $O/kt_$v/kt_kernel_stats.csv | sed 's/(.*)"//' | cut -c1-120
-  cp /tmp/keep.so $R/perf_amd/libperf_hip.so
+cd $R
+( time timeout 3000 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+for s in room doorway; do
+( timeout 900 python tools/soak_episodes.py --episodes 25 --scene $s --out $O/soak_$s.json ) > $O/soak_$s.log 2>&1
+python -c "
+import json; d=json.load(open('$O/soak_$s.json')); print('$s', d['params_sha256_16'], d['psnr_min_max'], d['seconds_min_max'], d['skipped_for_overflow_total'])"
 done
-find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete
