@@ -266,6 +266,7 @@ extern "C" int perf_adam_step_dev(float* p, float* m, float* v, float* g, void* 
                                   const int32_t* step_dev, const float* lr_dev, const int64_t* gate_dev, float beta1,
                                   float beta2, float eps, int zero_grad, int32_t* clear_flag, void* stream) {
     PERF_REQUIRE(step_dev && lr_dev, "perf_adam_step_dev: NULL scalar pointers");
+    PERF_REQUIRE(!clear_flag || n > 0, "perf_adam_step_dev: clear_flag needs a launch (n > 0)");
     return adam_launch(p, m, v, g, w16, n, dtype, 1, 0.f, beta1, beta2, eps, zero_grad, step_dev, lr_dev, gate_dev, clear_flag, stream);
 }
 
