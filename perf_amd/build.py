@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, 'libperf_hip.so')
 # (the MLP kernels are instantiated in six units of their own: one unit took 65 s, the longest of them now takes ~15 s)
 SOURCES = ['mlp_bwd_bf16_nh2.hip', 'mlp_bwd_fp16_nh2.hip', 'mlp_bwd_bf16_nh1.hip', 'mlp_bwd_fp16_nh1.hip', 'mlp_fwd_bf16.hip', 'mlp_fwd_fp16.hip',
            'hashgrid_bwd.hip', 'hashgrid_fwd.hip', 'hashgrid_aux.hip', 'march.hip', 'misc.hip', 'composite.hip', 'mlp.hip', 'visibility.hip']
-HEADERS = ['common.hpp', 'grid_device.hpp', 'grid_fixed_point.hpp', 'mlp_device.hpp']
+HEADERS = ['common.hpp', 'grid_device.hpp', 'grid_fixed_point.hpp', 'mlp_reduce_device.hpp', 'step_book_device.hpp', 'mlp_device.hpp']
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read per accumulator register before the epilogues)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
          '-mllvm', '-amdgpu-mfma-vgpr-form=1']

@@ -124,6 +124,9 @@ static void plan_tiles(const GridParams& gp, bool fixed, TileParams* tp, int* n_
                 nb += nt * (want - r);
                 tp->replicas_of[l] = want;
             }
+        // (a fourth replica for the 4 tiles of level 2 -- 336 -> 269 us per workgroup, 248 workgroups -- made the launch SLOWER in an A/B on
+        //  one box: 357.0 against 352.5 us, three runs each, call r06dd: the hashed owners end the launch and lose more to four more
+        //  neighbours than level 2 gains)
         ws = 0;                                              // (slab offsets again)
         for (int l = 0; l < gp.n_levels; ++l) {
             tp->ws_off[l] = 0;
@@ -955,6 +958,9 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     const uint32_t n_tiles = (uint32_t)tp.tiles_of[l];
     const uint32_t size = gp.size[l];
     const bool hashed = gp.hashed[l] != 0;
+#ifdef PERF_BWD_BLOCK_TIMES         // tools/exp/bwd_block_times.py: the launch is as long as its SLOWEST workgroup -- which one is it?
+    const long long block_t0 = wall_clock64();
+#endif
     for (int i = threadIdx.x; i < 2 * kTileEntries / 4; i += kBwdThreads)
         reinterpret_cast<float4*>(lds_tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -1011,6 +1017,11 @@ __global__ __launch_bounds__(kBwdThreads) void hashgrid_bwd_kernel(GridParams gp
     const float2* src = reinterpret_cast<const float2*>(lds_tile);
     float2* out = (R > 1) ? ws + tp.ws_off[l] + (int64_t)rep * size : grad + gp.offset[l];
     const bool acc = (R == 1) && tp.accumulate;
+#ifdef PERF_BWD_BLOCK_TIMES         // (two workgroups per level report: a printf from every workgroup stretches the launch it measures)
+    __syncthreads();
+    if (FIXED && threadIdx.x == 0 && (t == 0u || t == n_tiles / 2u))
+        printf("BLOCKT level %d tile %u rep %d of %d ticks %lld\n", l, t, rep, R, wall_clock64() - block_t0);
+#endif
     // fixed point: replica slabs -- and, in raw mode, the table itself -- receive the integer fields, so that replicas
     // (and the ranks of a data-parallel step) are added up exactly, in any order
     const bool int_out = FIXED && (R > 1 || tp.raw_out);
